@@ -1,0 +1,176 @@
+/*
+ * kgdet_hip.h -- C ABI of libkgdet_hip.so, the MI355X (gfx950) implementation of KGDet's hot
+ * operators.  Plain pointers and sizes only; every pointer named "device" is HBM memory on the
+ * current HIP device, `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *
+ * Each entry point replaces one native function that the reference's Python wrappers bind
+ * through pybind11 (R = mmdetection/mmdet/ops in the reference tree); the reference interface
+ * it stands in for is cited next to it.  Conventions kept from the reference: the caller
+ * allocates outputs and gradient buffers, the library writes in place; float32, dense NCHW.
+ * Differences (not observable by callers): kernels run on the given stream instead of the
+ * legacy default stream, scratch comes from a caller-provided workspace instead of per-call
+ * at::zeros, and failures are reported (status code + kgdet_last_error()) instead of printf.
+ *
+ * Return value: 0 on success, non-zero on error (see KGDET_E_*).
+ */
+#ifndef KGDET_HIP_H_
+#define KGDET_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KGDET_OK 0
+#define KGDET_E_SHAPE 1     /* shape/argument check failed (reference: AT_CHECK -> RuntimeError) */
+#define KGDET_E_WORKSPACE 2 /* workspace too small */
+#define KGDET_E_HIP 3       /* HIP runtime error (launch failure etc.) */
+#define KGDET_E_UNSUPPORTED 4
+
+const char *kgdet_last_error(void); /* thread-local message for the last non-zero status */
+int kgdet_version(void);            /* ABI version, currently 1 */
+int kgdet_device_cu_count(void);    /* compute units of the current device (0 if none) */
+
+/* ------------------------------------------------------------------------------------------
+ * Deformable convolution v1 / v2
+ * shape of one call; weight is [O, C/groups, kh, kw], offset [N, dg*2*kh*kw, Ho, Wo] with
+ * (dy,dx) interleaved per tap, taps row-major; mask (v2) [N, dg*kh*kw, Ho, Wo].
+ * ------------------------------------------------------------------------------------------ */
+typedef struct kgdet_dcn_shape {
+  int32_t N, C, H, W;
+  int32_t O, kh, kw;
+  int32_t stride_h, stride_w, pad_h, pad_w, dil_h, dil_w;
+  int32_t groups, deformable_groups;
+} kgdet_dcn_shape;
+
+/* flags for the fused epilogue */
+#define KGDET_DCN_RELU 1u /* out = max(out, 0) */
+
+/* output spatial size, R/dcn/deform_conv.py:96-110; returns KGDET_E_SHAPE if it is < 1 */
+int kgdet_dcn_output_size(const kgdet_dcn_shape *s, int32_t *Ho, int32_t *Wo);
+
+/* bytes of the MFMA-friendly weight image [groups][kh*kw][C/groups (pad 16)][O/groups (pad 256)] */
+size_t kgdet_dcn_packed_weight_bytes(const kgdet_dcn_shape *s);
+/* bytes of scratch (split-K partial tiles) forward / backward need besides the packed weight */
+size_t kgdet_dcn_workspace_bytes(const kgdet_dcn_shape *s);
+
+/* weight [O, C/groups, kh, kw] (device) -> packed (device).  Cache it while the weight is unchanged. */
+int kgdet_dcn_pack_weight(const kgdet_dcn_shape *s, const float *weight, float *packed, void *stream);
+/* packed gradient image -> grad_weight [O, C/groups, kh, kw]; accumulate != 0 adds into grad_weight */
+int kgdet_dcn_unpack_weight_grad(const kgdet_dcn_shape *s, const float *packed, float *grad_weight,
+                                 int accumulate, void *stream);
+
+/*
+ * Forward.  Replaces deform_conv_forward_cuda (R/dcn/src/deform_conv_cuda.cpp:151-156) when
+ * mask == NULL && bias == NULL, and modulated_deform_conv_cuda_forward (:486-492) otherwise.
+ * `packed_weight` comes from kgdet_dcn_pack_weight.  output [N, O, Ho, Wo] is overwritten.
+ * No column matrix is materialised: samples are gathered into LDS and contracted with MFMA.
+ */
+int kgdet_deform_conv_forward(const kgdet_dcn_shape *s, const float *input, const float *offset,
+                              const float *mask /*nullable*/, const float *packed_weight,
+                              const float *bias /*nullable*/, float *output, uint32_t flags,
+                              void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Backward w.r.t. input and offset (and mask for v2).  Replaces
+ * deform_conv_backward_input_cuda (deform_conv_cuda.cpp:260-266) and the input/offset/mask part
+ * of modulated_deform_conv_cuda_backward (:566-573).  grad_input must be zero-filled by the
+ * caller (as R/dcn/deform_conv.py:73 does); it is accumulated with float atomics like the
+ * reference.  grad_offset / grad_mask are overwritten.
+ */
+int kgdet_deform_conv_backward_input(const kgdet_dcn_shape *s, const float *input, const float *offset,
+                                     const float *mask /*nullable*/, const float *packed_weight,
+                                     const float *grad_output, float *grad_input, float *grad_offset,
+                                     float *grad_mask /*nullable*/, void *workspace,
+                                     size_t workspace_bytes, void *stream);
+
+/*
+ * Backward w.r.t. weight (and bias for v2).  Replaces deform_conv_backward_parameters_cuda
+ * (deform_conv_cuda.cpp:373-378, scale = 1) and the weight/bias part of
+ * modulated_deform_conv_cuda_backward.  grad_weight [O, C/groups, kh, kw] is overwritten
+ * (accumulate == 0) or added to (accumulate != 0); grad_bias [O] likewise when not NULL.
+ */
+int kgdet_deform_conv_backward_weight(const kgdet_dcn_shape *s, const float *input, const float *offset,
+                                      const float *mask /*nullable*/, const float *grad_output,
+                                      float *grad_weight, float *grad_bias /*nullable*/, int accumulate,
+                                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Deformable PS-RoI pooling.  Replaces deform_psroi_pooling_cuda_forward / _backward
+ * (R/dcn/src/deform_pool_cuda.cpp:30-34, 54-59).  rois [R,5] = (batch_idx,x1,y1,x2,y2);
+ * trans [R, 2*num_classes, part, part] (NULL when no_trans); out/count [R, out_dim, P, P].
+ * Backward accumulates into zero-filled grad_input / grad_trans (float atomics, as the reference).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct kgdet_psroi_shape {
+  int32_t B, C, H, W;  /* data */
+  int32_t R;           /* number of rois */
+  int32_t out_dim, group_size, pooled_size, part_size, sample_per_part;
+  int32_t no_trans, num_classes; /* num_classes = no_trans ? 1 : trans.size(1)/2 */
+  float spatial_scale, trans_std;
+} kgdet_psroi_shape;
+
+int kgdet_deform_psroi_forward(const kgdet_psroi_shape *s, const float *data, const float *rois,
+                               const float *trans, float *out, float *count, void *stream);
+int kgdet_deform_psroi_backward(const kgdet_psroi_shape *s, const float *grad_out, const float *count,
+                                const float *data, const float *rois, const float *trans,
+                                float *grad_data, float *grad_trans, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sigmoid focal loss.  Replaces sigmoid_focal_loss_cuda.forward / .backward
+ * (R/sigmoid_focal_loss/src/sigmoid_focal_loss.cpp:40-45).  logits [num, C]; targets [num]
+ * int64 (0 = background, 1..C = class); losses / d_logits [num, C].
+ * kgdet_sigmoid_focal_loss_sum additionally fuses the weighted sum the head takes right after
+ * (R/../models/losses/utils.py:39-48): *loss_sum = sum_i w[n_i] * loss_i (weights nullable).
+ * ------------------------------------------------------------------------------------------ */
+int kgdet_sigmoid_focal_loss_forward(const float *logits, const int64_t *targets, int64_t num,
+                                     int32_t num_classes, float gamma, float alpha, float *losses,
+                                     void *stream);
+int kgdet_sigmoid_focal_loss_backward(const float *logits, const int64_t *targets, const float *d_losses,
+                                      int64_t num, int32_t num_classes, float gamma, float alpha,
+                                      float *d_logits, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * NMS.  kgdet_nms replaces nms_cpu.nms / nms_cuda.nms (R/nms/src/nms_cpu.cpp:62-68,
+ * nms_kernel.cu:70-131) with the CPU semantics the project pins: +1 areas, suppress when
+ * IoU >= thr, visiting order = score descending (ties: lower index first), result = kept
+ * indices in ascending index order.  The greedy sweep runs on the device; nothing is copied
+ * to the host.  dets [n,5] float32; keep [n] int64; *num_keep (device int64) receives the count.
+ *
+ * kgdet_nms_batched runs many independent problems (one per (image, class) group) in ONE
+ * launch: segment i covers dets rows [seg_offsets[i], seg_offsets[i+1]); kept indices are
+ * written segment-relative to keep + seg_offsets[i], counts to num_keep[i].
+ * workspace: kgdet_nms_workspace_bytes(total_n, num_segments).
+ *
+ * kgdet_soft_nms replaces soft_nms_cpu (R/nms/src/soft_nms_cpu.pyx:22-127): method 1 linear,
+ * 2 gaussian; out_dets [n,5], out_inds [n] int64, *num_out device int64.
+ * ------------------------------------------------------------------------------------------ */
+size_t kgdet_nms_workspace_bytes(int64_t total_n, int32_t num_segments);
+int kgdet_nms(const float *dets, int64_t n, float iou_thr, int64_t *keep, int64_t *num_keep,
+              void *workspace, size_t workspace_bytes, void *stream);
+int kgdet_nms_batched(const float *dets, const int64_t *seg_offsets, int32_t num_segments,
+                      int64_t total_n, int64_t max_seg_len, float iou_thr, int64_t *keep,
+                      int64_t *num_keep, void *workspace, size_t workspace_bytes, void *stream);
+int kgdet_soft_nms(const float *dets, int64_t n, float iou_thr, int32_t method, float sigma,
+                   float min_score, float *out_dets, int64_t *out_inds, int64_t *num_out,
+                   void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Moment bounding box ("points2bbox", transform_method='moment';
+ * R/../models/anchor_heads/reppoints_head_kp3rep_cas_1_assign_once.py:342-391).
+ * pts [B, 2*n_pts, H, W] with (y,x) interleaved per point; moment_transfer [2] (already
+ * blended with its detached copy by the caller); bbox [B, 4, H, W] = (x1,y1,x2,y2).
+ * Mean and UNBIASED std (n-1) over the points; half extent = std * exp(transfer).
+ * Backward returns grad_pts and grad_transfer[2] (accumulated into a zero-filled buffer).
+ * ------------------------------------------------------------------------------------------ */
+int kgdet_moment_bbox_forward(const float *pts, const float *moment_transfer, int32_t B, int32_t n_pts,
+                              int32_t HW, float *bbox, void *stream);
+int kgdet_moment_bbox_backward(const float *pts, const float *moment_transfer, const float *grad_bbox,
+                               int32_t B, int32_t n_pts, int32_t HW, float *grad_pts,
+                               float *grad_transfer, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KGDET_HIP_H_ */

@@ -1,0 +1,167 @@
+// C-ABI launchers for deformable convolution (see include/kgdet_hip.h for the contract and the
+// reference entry points each one replaces).
+#include "common.h"
+#include "dcn_kernels.h"
+
+namespace kgdet {
+
+namespace {
+
+struct Derived {
+  int Ho, Wo, K, Cg, Og, Cg_pad, Og_pad;
+};
+
+int derive(const kgdet_dcn_shape *s, Derived &d) {
+  // the reference's shape_check (mmdet/ops/dcn/src/deform_conv_cuda.cpp:61-149)
+  KGDET_CHECK_SHAPE(s != nullptr, "null shape");
+  KGDET_CHECK_SHAPE(s->kh > 0 && s->kw > 0, "kernel size should be greater than zero, but got kH: %d kW: %d",
+                    s->kh, s->kw);
+  KGDET_CHECK_SHAPE(s->stride_h > 0 && s->stride_w > 0, "stride should be greater than zero, but got dH: %d dW: %d",
+                    s->stride_h, s->stride_w);
+  KGDET_CHECK_SHAPE(s->dil_h > 0 && s->dil_w > 0,
+                    "dilation should be greater than 0, but got dilationH: %d dilationW: %d", s->dil_h, s->dil_w);
+  KGDET_CHECK_SHAPE(s->N > 0 && s->C > 0 && s->O > 0 && s->H > 0 && s->W > 0, "empty tensor dimension");
+  KGDET_CHECK_SHAPE(s->groups > 0 && s->C % s->groups == 0 && s->O % s->groups == 0,
+                    "channels must divide groups (C=%d O=%d groups=%d)", s->C, s->O, s->groups);
+  KGDET_CHECK_SHAPE(s->deformable_groups > 0 && s->C % s->deformable_groups == 0,
+                    "input channels must divide deformable group size");
+  d.Ho = (s->H + 2 * s->pad_h - (s->dil_h * (s->kh - 1) + 1)) / s->stride_h + 1;
+  d.Wo = (s->W + 2 * s->pad_w - (s->dil_w * (s->kw - 1) + 1)) / s->stride_w + 1;
+  KGDET_CHECK_SHAPE(d.Ho >= 1 && d.Wo >= 1,
+                    "Given input size: (%d x %d x %d). Calculated output size: (%d x %d x %d). Output size is too small",
+                    s->C, s->H, s->W, s->O, d.Ho, d.Wo);
+  d.K = s->kh * s->kw;
+  d.Cg = s->C / s->groups;
+  d.Og = s->O / s->groups;
+  d.Cg_pad = (int)align_up(d.Cg, kChunk);
+  d.Og_pad = (int)align_up(d.Og, kTileM);
+  const long long in_bytes = 4LL * s->N * s->C * s->H * s->W;
+  const long long out_bytes = 4LL * s->N * s->O * d.Ho * d.Wo;
+  const long long off_bytes = 4LL * s->N * s->deformable_groups * 2 * d.K * d.Ho * d.Wo;
+  KGDET_CHECK_SHAPE(in_bytes < (1LL << 31) && out_bytes < (1LL << 31) && off_bytes < (1LL << 31),
+                    "tensor larger than 2 GiB is not supported");
+  return KGDET_OK;
+}
+
+int grid_size() {
+  const int cus = cu_count();
+  return cus > 0 ? cus : 256;
+}
+
+size_t slab_bytes() { return (size_t)grid_size() * 2 * kTileElems * sizeof(float); }
+
+// the MFMA kernels gather 4 consecutive channels per thread with one Tap, so a deformable group
+// boundary must not fall inside such a quad
+bool mfma_ok(const kgdet_dcn_shape *s) { return (s->C / s->deformable_groups) % 4 == 0 || s->deformable_groups == 1; }
+
+void fill_problem(const kgdet_dcn_shape *s, const Derived &d, int group, DcnProblem &p) {
+  p = DcnProblem{};
+  p.N = s->N; p.C_total = s->C; p.c_base = group * d.Cg; p.Cg = d.Cg; p.Cg_pad = d.Cg_pad;
+  p.O_total = s->O; p.o_base = group * d.Og; p.Og = d.Og; p.Og_pad = d.Og_pad;
+  p.H = s->H; p.W = s->W; p.Ho = d.Ho; p.Wo = d.Wo; p.HoWo = d.Ho * d.Wo; p.P = s->N * p.HoWo;
+  p.kh = s->kh; p.kw = s->kw; p.K = d.K;
+  p.sh = s->stride_h; p.sw = s->stride_w; p.ph = s->pad_h; p.pw = s->pad_w; p.dh = s->dil_h; p.dw = s->dil_w;
+  p.DG = s->deformable_groups; p.cpdg = s->C / s->deformable_groups;
+}
+
+}  // namespace
+
+}  // namespace kgdet
+
+using namespace kgdet;
+
+extern "C" {
+
+int kgdet_dcn_output_size(const kgdet_dcn_shape *s, int32_t *Ho, int32_t *Wo) {
+  Derived d;
+  if (int rc = derive(s, d)) return rc;
+  if (Ho) *Ho = d.Ho;
+  if (Wo) *Wo = d.Wo;
+  return KGDET_OK;
+}
+
+size_t kgdet_dcn_packed_weight_bytes(const kgdet_dcn_shape *s) {
+  Derived d;
+  if (derive(s, d)) return 0;
+  return (size_t)s->groups * d.K * d.Cg_pad * d.Og_pad * sizeof(float);
+}
+
+size_t kgdet_dcn_workspace_bytes(const kgdet_dcn_shape *s) {
+  Derived d;
+  if (derive(s, d)) return 0;
+  // slabs for stream-K partial tiles + (backward-weight) a packed gradient image
+  return slab_bytes() + kgdet_dcn_packed_weight_bytes(s);
+}
+
+int kgdet_dcn_pack_weight(const kgdet_dcn_shape *s, const float *weight, float *packed, void *stream) {
+  Derived d;
+  if (int rc = derive(s, d)) return rc;
+  KGDET_CHECK_SHAPE(weight && packed, "null pointer");
+  const size_t lds = (size_t)64 * (d.K + 1) * sizeof(float);
+  KGDET_CHECK_SHAPE(lds <= 64 * 1024, "kernel %dx%d too large to pack", s->kh, s->kw);
+  for (int g = 0; g < s->groups; ++g) {
+    const float *w = weight + (size_t)g * d.Og * d.Cg * d.K;
+    float *dst = packed + (size_t)g * d.K * d.Cg_pad * d.Og_pad;
+    dim3 grid(d.Cg_pad, d.Og_pad / 64);
+    hipLaunchKernelGGL(dcn_pack_weight, grid, dim3(256), lds, (hipStream_t)stream, w, dst, d.Og, d.Cg, d.K,
+                       d.Cg_pad, d.Og_pad);
+  }
+  KGDET_CHECK_LAUNCH("dcn_pack_weight");
+  return KGDET_OK;
+}
+
+int kgdet_dcn_unpack_weight_grad(const kgdet_dcn_shape *s, const float *packed, float *grad_weight,
+                                 int accumulate, void *stream) {
+  Derived d;
+  if (int rc = derive(s, d)) return rc;
+  KGDET_CHECK_SHAPE(grad_weight && packed, "null pointer");
+  const size_t lds = (size_t)64 * (d.K + 1) * sizeof(float);
+  KGDET_CHECK_SHAPE(lds <= 64 * 1024, "kernel %dx%d too large to unpack", s->kh, s->kw);
+  for (int g = 0; g < s->groups; ++g) {
+    float *w = grad_weight + (size_t)g * d.Og * d.Cg * d.K;
+    const float *src = packed + (size_t)g * d.K * d.Cg_pad * d.Og_pad;
+    dim3 grid(d.Cg, d.Og_pad / 64);
+    hipLaunchKernelGGL(dcn_unpack_weight, grid, dim3(256), lds, (hipStream_t)stream, src, w, d.Og, d.Cg, d.K,
+                       d.Cg_pad, d.Og_pad, accumulate);
+  }
+  KGDET_CHECK_LAUNCH("dcn_unpack_weight");
+  return KGDET_OK;
+}
+
+int kgdet_deform_conv_forward(const kgdet_dcn_shape *s, const float *input, const float *offset,
+                              const float *mask, const float *packed_weight, const float *bias,
+                              float *output, uint32_t flags, void *workspace, size_t workspace_bytes,
+                              void *stream) {
+  Derived d;
+  if (int rc = derive(s, d)) return rc;
+  KGDET_CHECK_SHAPE(input && offset && packed_weight && output, "null pointer");
+  if (!mfma_ok(s)) {
+    set_error("deformable_groups=%d with %d channels per group is not supported by the MFMA path",
+              s->deformable_groups, s->C / s->deformable_groups);
+    return KGDET_E_UNSUPPORTED;
+  }
+  if (workspace_bytes < slab_bytes() || workspace == nullptr) {
+    set_error("workspace too small: need %zu bytes, got %zu", slab_bytes(), workspace_bytes);
+    return KGDET_E_WORKSPACE;
+  }
+  const int G = grid_size();
+  for (int g = 0; g < s->groups; ++g) {
+    DcnProblem p;
+    fill_problem(s, d, g, p);
+    p.x = input; p.offset = offset; p.mask = mask; p.bias = bias; p.out = output;
+    p.wpk = packed_weight + (size_t)g * d.K * d.Cg_pad * d.Og_pad;
+    p.flags = flags;
+    p.n_ntiles = ceil_div(p.P, kTileN);
+    p.n_mtiles = d.Og_pad / kTileM;
+    p.chunks_per_tap = d.Cg_pad / kChunk;
+    p.chunks_per_tile = d.K * p.chunks_per_tap;
+    p.total_units = (long long)p.n_ntiles * p.n_mtiles * p.chunks_per_tile;
+    hipLaunchKernelGGL(dcn_fwd_mfma, dim3(G), dim3(kThreads), 0, (hipStream_t)stream, p, (float *)workspace);
+    hipLaunchKernelGGL(dcn_fwd_fixup, dim3(p.n_ntiles * p.n_mtiles), dim3(kThreads), 0, (hipStream_t)stream, p,
+                       (const float *)workspace, G);
+  }
+  KGDET_CHECK_LAUNCH("dcn_fwd_mfma");
+  return KGDET_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,168 @@
+// Deformable convolution on gfx950: shared device-side pieces.
+//
+// The three kernels (forward, backward-input, backward-weight) are all "gather -> LDS -> f32 MFMA"
+// pipelines with the same geometry:
+//   workgroup = 512 threads = 8 waves arranged 4 (M) x 2 (N); each wave owns a 64x64 block of a
+//   256 (M) x 128 (N) tile as 2x2 v_mfma_f32_32x32x2_f32 accumulators (64 VGPRs);
+//   the reduction dimension is consumed in chunks of 16, double-buffered in LDS as
+//   A[k][256] / B[k][128] (k-major), which makes every MFMA operand fetch a conflict-free
+//   ds_read_b32 (lanes 0-31 read 32 consecutive floats of row k, lanes 32-63 of row k+1).
+// f32-input MFMA is bit-exact fp32 (an fma chain), so results track the fp32 reference closely.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kgdet {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTileM = 256;
+constexpr int kTileN = 128;
+constexpr int kChunk = 16;     // reduction elements per LDS stage
+constexpr int kThreads = 512;  // 8 waves
+constexpr int kTileElems = kTileM * kTileN;
+
+// One deformable convolution problem as the kernels see it (one weight group).
+struct DcnProblem {
+  const float *x;       // [N, C_total, H, W]
+  const float *offset;  // [N, DG*2K, Ho, Wo]
+  const float *mask;    // [N, DG*K, Ho, Wo] or nullptr
+  const float *wpk;     // packed weight of this group: [K][Cg_pad][Og_pad]
+  const float *bias;    // [O_total] or nullptr
+  float *out;           // forward: [N, O_total, Ho, Wo]
+  int N, C_total, c_base, Cg, Cg_pad;
+  int O_total, o_base, Og, Og_pad;
+  int H, W, Ho, Wo, HoWo, P;  // P = N*Ho*Wo output pixels
+  int kh, kw, K;
+  int sh, sw, ph, pw, dh, dw;
+  int DG, cpdg;  // deformable groups, channels (of C_total) per deformable group
+  int n_ntiles, n_mtiles, chunks_per_tap, chunks_per_tile;
+  long long total_units;  // n_ntiles * n_mtiles * chunks_per_tile
+  unsigned flags;
+};
+
+// stream-K: workgroup g of G owns units [unit_begin(g), unit_begin(g+1))
+__device__ __forceinline__ long long unit_begin(long long g, long long total, long long G) {
+  return g * total / G;
+}
+
+// Where one tap of one output pixel lands on the input, and how it is interpolated.
+// Corner offsets are clamped into the plane and carry a zero weight when the corner (or the
+// whole tap) is outside, so that gathers never branch: sample = sum_i w[i] * plane[o[i]].
+// Mirrors deformable_im2col_bilinear + the (-1,H)x(-1,W) guard
+// (mmdet/ops/dcn/src/deform_conv_cuda_kernel.cu:84-114, :228).
+struct Tap {
+  int o[4];    // y0x0, y0x1, y1x0, y1x1 (element offsets inside an H*W plane)
+  float w[4];  // bilinear weights (x mask for v2), 0 where invalid
+};
+
+struct TapGeom {  // also what the backward pass needs for d/dy, d/dx
+  float ly, lx;   // fractional parts
+  int in_range;   // tap inside (-1,H)x(-1,W)
+  int va, vb, vc, vd;
+};
+
+__device__ __forceinline__ void make_tap(float y, float x, int H, int W, bool live, float m,
+                                         Tap &t, TapGeom &g) {
+  const bool in = live && (y > -1.0f) && (x > -1.0f) && (y < (float)H) && (x < (float)W);
+  if (!in) { y = 0.0f; x = 0.0f; }
+  const float fy = floorf(y), fx = floorf(x);
+  const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
+  const float ly = y - fy, lx = x - fx, hy = 1.0f - ly, hx = 1.0f - lx;
+  const bool va = in && y0 >= 0 && x0 >= 0;
+  const bool vb = in && y0 >= 0 && x1 <= W - 1;
+  const bool vc = in && y1 <= H - 1 && x0 >= 0;
+  const bool vd = in && y1 <= H - 1 && x1 <= W - 1;
+  const int cy0 = max(y0, 0), cy1 = min(y1, H - 1), cx0 = max(x0, 0), cx1 = min(x1, W - 1);
+  t.o[0] = cy0 * W + cx0;
+  t.o[1] = cy0 * W + cx1;
+  t.o[2] = cy1 * W + cx0;
+  t.o[3] = cy1 * W + cx1;
+  t.w[0] = va ? hy * hx * m : 0.0f;
+  t.w[1] = vb ? hy * lx * m : 0.0f;
+  t.w[2] = vc ? ly * hx * m : 0.0f;
+  t.w[3] = vd ? ly * lx * m : 0.0f;
+  g.ly = ly; g.lx = lx; g.in_range = in;
+  g.va = va; g.vb = vb; g.vc = vc; g.vd = vd;
+}
+
+// sampling position of tap t for output pixel (oy, ox) of image b; deformable group dgi
+__device__ __forceinline__ void tap_position(const DcnProblem &p, int b, int dgi, int t, int hw, int oy,
+                                             int ox, float &y, float &x, float &m) {
+  const long long obase = ((long long)(b * p.DG + dgi) * 2 * p.K + 2 * t) * p.HoWo + hw;
+  const float off_y = p.offset[obase];
+  const float off_x = p.offset[obase + p.HoWo];
+  const int i = t / p.kw, j = t - i * p.kw;
+  y = (float)(oy * p.sh - p.ph + i * p.dh) + off_y;
+  x = (float)(ox * p.sw - p.pw + j * p.dw) + off_x;
+  m = p.mask ? p.mask[((long long)(b * p.DG + dgi) * p.K + t) * p.HoWo + hw] : 1.0f;
+}
+
+// 2x2 MFMA 32x32x2 steps over one 16-deep LDS stage.  A: [16][lda], B: [16][ldb].
+__device__ __forceinline__ void mfma_stage(const float *__restrict__ A, int lda, const float *__restrict__ B,
+                                           int ldb, int a_off, int b_off, int lane, f32x16 (&acc)[2][2]) {
+  const int kk = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int ks = 0; ks < kChunk / 2; ++ks) {
+    const int k = 2 * ks + kk;
+    const float a0 = A[k * lda + a_off + l31];
+    const float a1 = A[k * lda + a_off + 32 + l31];
+    const float b0 = B[k * ldb + b_off + l31];
+    const float b1 = B[k * ldb + b_off + 32 + l31];
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+  }
+}
+
+// row of accumulator register r inside a 32x32 MFMA block (C/D layout, col = lane & 31)
+__device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// raw register image of a tile <-> slab (coalesced 16 B per lane)
+__device__ __forceinline__ void store_slab(float *__restrict__ slab, int tid, const f32x16 (&acc)[2][2]) {
+  f32x4 *s4 = reinterpret_cast<f32x4 *>(slab);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+        s4[((mi * 2 + ni) * 4 + q) * kThreads + tid] = v;
+      }
+}
+
+__device__ __forceinline__ void add_slab(const float *__restrict__ slab, int tid, f32x16 (&acc)[2][2]) {
+  const f32x4 *s4 = reinterpret_cast<const f32x4 *>(slab);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = s4[((mi * 2 + ni) * 4 + q) * kThreads + tid];
+        acc[mi][ni][4 * q] += v[0];
+        acc[mi][ni][4 * q + 1] += v[1];
+        acc[mi][ni][4 * q + 2] += v[2];
+        acc[mi][ni][4 * q + 3] += v[3];
+      }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+}
+
+// Which slab slot does workgroup g use for the segment of its range that starts at `seg_begin`?
+// slot 0 = the segment its range starts with, slot 1 = any later (necessarily final) one.
+__device__ __forceinline__ int slab_slot(long long seg_begin, long long my_begin) {
+  return seg_begin == my_begin ? 0 : 1;
+}
+
+}  // namespace kgdet

@@ -1,0 +1,241 @@
+// Deformable convolution forward for gfx950: bilinear gather -> LDS -> f32 MFMA, no column matrix.
+//
+// Reference path replaced: deformable_im2col (+ modulated) and the addmm_ that follows it
+// (mmdet/ops/dcn/src/deform_conv_cuda_kernel.cu:190-276, 570-632; deform_conv_cuda.cpp:221-245,
+// 534-563).  The reference writes a [C*K, N*Ho*Wo] fp32 column matrix to HBM and reads it back
+// for the GEMM; here a 16-channel x 128-pixel slice of it lives only in LDS.
+//
+// GEMM view:  out[o, p] = sum_{t, c} Wpk[t][c][o] * sample(x[b(p), c], pos(p, t))
+//   M = output channels (tile 256), N = output pixels p = (b, oy, ox) (tile 128),
+//   reduction = (tap t, channel c) in stages of (one tap, 16 channels).
+// Parallelism: M*N has only ~17 tiles at KGDet sizes (256 x 2100), so the reduction is split
+// stream-K style: the n_tiles * stages units are dealt evenly to the G resident workgroups;
+// a workgroup whose range does not cover a whole tile writes its partial tile to a slab and
+// dcn_fwd_fixup sums the slabs in workgroup order (deterministic, no atomics).
+#include "common.h"
+#include "dcn_common.h"
+
+namespace kgdet {
+
+namespace {
+
+constexpr int kLdsA = kChunk * kTileM;  // floats per A stage
+constexpr int kLdsB = kChunk * kTileN;
+
+// A stage = Wpk[t][c0 .. c0+15][m0 .. m0+255]: 16 rows of 1 KiB, copied straight into LDS by the
+// LDS-DMA path (no VGPR round trip).  The LDS image is lane-linear, which is exactly the
+// k-major [16][256] layout mfma_stage reads.
+__device__ __forceinline__ void stage_weights(const DcnProblem &p, int t, int c0, int m0, float *As, int tid) {
+  // the LDS-DMA base must be provably wave-uniform (it goes to M0), or hipcc emits a waterfall loop
+  const int wave_base = __builtin_amdgcn_readfirstlane(tid >> 6) << 6;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int q = tid + kThreads * r;  // float4 index inside the stage
+    const int k = q >> 6, col4 = q & 63;
+    const float *src = p.wpk + ((long long)(t * p.Cg_pad + c0 + k) * p.Og_pad + m0 + col4 * 4);
+    float *dst = As + (wave_base + kThreads * r) * 4;  // wave-uniform base; HW adds lane*16 B
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+  }
+}
+
+// Write one tile (register image) to out[N, O_total, Ho, Wo], with bias / ReLU fused.
+__device__ __forceinline__ void store_output(const DcnProblem &p, int mt, int nt, int tid,
+                                             const f32x16 (&acc)[2][2]) {
+  const int lane = tid & 63, wave = tid >> 6, wm = wave & 3, wn = wave >> 2;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int pix = nt * kTileN + wn * 64 + ni * 32 + (lane & 31);
+    if (pix >= p.P) continue;
+    const int b = pix / p.HoWo, hw = pix - b * p.HoWo;
+    float *obase = p.out + ((long long)b * p.O_total + p.o_base) * p.HoWo + hw;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = mt * kTileM + wm * 64 + mi * 32 + mfma_row(r, lane);
+        if (o >= p.Og) continue;
+        float v = acc[mi][ni][r];
+        if (p.bias) v += p.bias[p.o_base + o];
+        if (p.flags & KGDET_DCN_RELU) v = fmaxf(v, 0.0f);
+        obase[(long long)o * p.HoWo] = v;
+      }
+  }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(kThreads, 2) void dcn_fwd_mfma(const DcnProblem p, float *__restrict__ slabs) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kLdsA + 2 * kLdsB];
+  float *As = lds;
+  float *Bs = lds + 2 * kLdsA;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int n_local = tid & (kTileN - 1);  // pixel column this thread gathers for
+  const int cq = tid >> 7;                 // which 4 of the stage's 16 channels
+  const long long G = gridDim.x, g = blockIdx.x;
+  const long long my_begin = unit_begin(g, p.total_units, G);
+  const long long my_end = unit_begin(g + 1, p.total_units, G);
+  const int HW = p.H * p.W;
+
+  long long cur = my_begin;
+  while (cur < my_end) {
+    const int cpt = p.chunks_per_tile;
+    const int tile = (int)(cur / cpt);
+    const long long tile_begin = (long long)tile * cpt;
+    const int s_begin = (int)(cur - tile_begin);
+    const int s_end = (int)((my_end - tile_begin) < cpt ? (my_end - tile_begin) : cpt);
+    const int mt = tile % p.n_mtiles, nt = tile / p.n_mtiles;
+    const int m0 = mt * kTileM;
+
+    // the output pixel this thread samples for
+    const int pix = nt * kTileN + n_local;
+    const bool live = pix < p.P;
+    const int pb = live ? pix / p.HoWo : 0;
+    const int hw = live ? pix - pb * p.HoWo : 0;
+    const int oy = hw / p.Wo, ox = hw - oy * p.Wo;
+    const float *xb = p.x + ((long long)pb * p.C_total + p.c_base) * HW;
+
+    f32x16 acc[2][2];
+    zero_acc(acc);
+
+    Tap tap;
+    int tap_key = -1;  // (t, deformable group) the cached Tap belongs to
+    float v[4][4];     // gathered corner values of the stage in flight: [channel][corner]
+
+    // issue the gathers of stage s (results land in v)
+    auto gather_issue = [&](int s) {
+      const int t = s / p.chunks_per_tap;
+      const int c0 = (s - t * p.chunks_per_tap) * kChunk + cq * 4;
+      const int dgi = (p.c_base + min(c0, p.Cg - 1)) / p.cpdg;
+      const int key = t * p.DG + dgi;
+      if (key != tap_key) {
+        float y, x, m;
+        TapGeom geo;
+        if (live) tap_position(p, pb, dgi, t, hw, oy, ox, y, x, m); else { y = x = 0.f; m = 0.f; }
+        make_tap(y, x, p.H, p.W, live, m, tap, geo);
+        tap_key = key;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = min(c0 + j, p.Cg - 1);  // padded channels read a valid plane; their weights are 0
+        const float *plane = xb + (long long)c * HW;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[j][q] = plane[tap.o[q]];
+      }
+    };
+    // interpolate and park the stage's samples in LDS: B[k = cq*4 + j][n_local]
+    auto gather_commit = [&](float *Bdst) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float s = tap.w[0] * v[j][0] + tap.w[1] * v[j][1] + tap.w[2] * v[j][2] + tap.w[3] * v[j][3];
+        Bdst[(cq * 4 + j) * kTileN + n_local] = s;
+      }
+    };
+    auto stage_w = [&](int s, float *Adst) {
+      const int t = s / p.chunks_per_tap;
+      const int c0 = (s - t * p.chunks_per_tap) * kChunk;
+      stage_weights(p, t, c0, m0, Adst, tid);
+    };
+
+    // prologue: stage s_begin into buffer 0
+    stage_w(s_begin, As);
+    gather_issue(s_begin);
+    gather_commit(Bs);
+    __syncthreads();
+
+    int buf = 0;
+    for (int s = s_begin; s < s_end; ++s) {
+      const bool more = (s + 1) < s_end;
+      if (more) {
+        stage_w(s + 1, As + (buf ^ 1) * kLdsA);
+        gather_issue(s + 1);
+      }
+      mfma_stage(As + buf * kLdsA, kTileM, Bs + buf * kLdsB, kTileN, wm * 64, wn * 64, lane, acc);
+      if (more) gather_commit(Bs + (buf ^ 1) * kLdsB);
+      __syncthreads();
+      buf ^= 1;
+    }
+
+    if (s_begin == 0 && s_end == cpt) {
+      store_output(p, mt, nt, tid, acc);
+    } else {
+      float *slab = slabs + ((long long)g * 2 + slab_slot(cur, my_begin)) * kTileElems;
+      store_slab(slab, tid, acc);
+    }
+    cur = tile_begin + s_end;
+  }
+}
+
+// One workgroup per tile: if the tile was split across workgroups, add their slabs in order.
+__global__ __launch_bounds__(kThreads) void dcn_fwd_fixup(const DcnProblem p, const float *__restrict__ slabs,
+                                                         int G) {
+  const int tile = blockIdx.x, tid = threadIdx.x;
+  const int cpt = p.chunks_per_tile;
+  const long long tb = (long long)tile * cpt, te = tb + cpt;
+  long long g = tb * G / p.total_units;
+  while (unit_begin(g + 1, p.total_units, G) <= tb) ++g;
+  while (unit_begin(g, p.total_units, G) > tb) --g;
+  // g = first workgroup whose range intersects the tile
+  const long long gb = unit_begin(g, p.total_units, G), ge = unit_begin(g + 1, p.total_units, G);
+  if (gb <= tb && ge >= te) return;  // written directly by workgroup g
+
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  for (; g < G; ++g) {
+    const long long b0 = unit_begin(g, p.total_units, G);
+    if (b0 >= te) break;
+    if (unit_begin(g + 1, p.total_units, G) == b0) continue;  // workgroup with an empty range
+    const long long seg_begin = b0 > tb ? b0 : tb;
+    const float *slab = slabs + ((long long)g * 2 + slab_slot(seg_begin, b0)) * kTileElems;
+    add_slab(slab, tid, acc);
+  }
+  store_output(p, tile % p.n_mtiles, tile / p.n_mtiles, tid, acc);
+}
+
+// ----------------------------------------------------------------------------------------------
+// Weight packing: [O, Cg, K] (one group) -> [K][Cg_pad][Og_pad], zero padded.
+// One workgroup per (c, 64 output channels): reads 64 runs of K contiguous floats, transposes
+// through LDS, writes K runs of 64 contiguous floats.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dcn_pack_weight(const float *__restrict__ w, float *__restrict__ wpk,
+                                                        int Og, int Cg, int K, int Cg_pad, int Og_pad) {
+  extern __shared__ float tile[];  // [64][K+1]
+  const int c = blockIdx.x, o0 = blockIdx.y * 64, tid = threadIdx.x;
+  const int ld = K + 1;
+  for (int e = tid; e < 64 * K; e += 256) {
+    const int oo = e / K, t = e - oo * K;
+    const int o = o0 + oo;
+    tile[oo * ld + t] = (o < Og && c < Cg) ? w[((long long)o * Cg + c) * K + t] : 0.0f;
+  }
+  __syncthreads();
+  for (int e = tid; e < 64 * K; e += 256) {
+    const int t = e >> 6, oo = e & 63;
+    wpk[((long long)t * Cg_pad + c) * Og_pad + o0 + oo] = tile[oo * ld + t];
+  }
+}
+
+// inverse: packed gradient [K][Cg_pad][Og_pad] -> [O, Cg, K]
+__global__ __launch_bounds__(256) void dcn_unpack_weight(const float *__restrict__ wpk, float *__restrict__ w,
+                                                          int Og, int Cg, int K, int Cg_pad, int Og_pad,
+                                                          int accumulate) {
+  extern __shared__ float tile[];
+  const int c = blockIdx.x, o0 = blockIdx.y * 64, tid = threadIdx.x;
+  const int ld = K + 1;
+  for (int e = tid; e < 64 * K; e += 256) {
+    const int t = e >> 6, oo = e & 63;
+    tile[oo * ld + t] = wpk[((long long)t * Cg_pad + c) * Og_pad + o0 + oo];
+  }
+  __syncthreads();
+  for (int e = tid; e < 64 * K; e += 256) {
+    const int oo = e / K, t = e - oo * K;
+    const int o = o0 + oo;
+    if (o < Og) {
+      float *dst = w + ((long long)o * Cg + c) * K + t;
+      *dst = accumulate ? *dst + tile[oo * ld + t] : tile[oo * ld + t];
+    }
+  }
+}
+
+}  // namespace kgdet

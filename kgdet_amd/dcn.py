@@ -1,0 +1,336 @@
+"""Deformable convolution v1 / v2 modules and functions -- host-side mirror of the reference's
+``mmdet/ops/dcn/deform_conv.py`` (same class names, constructor arguments, parameter names and
+error behaviour) on top of the HIP kernels in libkgdet_hip.so.
+
+Reference interface mirrored (R = mmdetection/mmdet/ops/dcn/deform_conv.py):
+  DeformConvFunction :12-110      deform_conv :186           DeformConv :190-236
+  DeformConvPack :239-261         ModulatedDeformConvFunction :113-183
+  ModulatedDeformConv :264-304    ModulatedDeformConvPack :307-337
+
+As in the reference there is no CPU implementation: non-GPU tensors raise NotImplementedError.
+"""
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+from torch.nn.modules.utils import _pair
+
+from . import _lib
+
+_workspaces = {}
+
+
+def _workspace(device, nbytes):
+    """Persistent per-(device, stream) scratch for split-K partial tiles (caller-owned memory in
+    the C ABI; the reference re-allocates its column buffer with at::zeros on every call)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _shape(input, weight, stride, padding, dilation, groups, deformable_groups):
+    s = _lib.DcnShape()
+    s.N, s.C, s.H, s.W = input.shape
+    s.O, _, s.kh, s.kw = weight.shape
+    s.stride_h, s.stride_w = stride
+    s.pad_h, s.pad_w = padding
+    s.dil_h, s.dil_w = dilation
+    s.groups = groups
+    s.deformable_groups = deformable_groups
+    return s
+
+
+def _output_size(input, weight, padding, dilation, stride):
+    """R:96-110"""
+    channels = weight.size(0)
+    output_size = (input.size(0), channels)
+    for d in range(input.dim() - 2):
+        in_size = input.size(d + 2)
+        pad = padding[d]
+        kernel = dilation[d] * (weight.size(d + 2) - 1) + 1
+        stride_ = stride[d]
+        output_size += ((in_size + (2 * pad) - kernel) // stride_ + 1, )
+    if not all(map(lambda s: s > 0, output_size)):
+        raise ValueError('convolution input is too small (output would be {})'.format(
+            'x'.join(map(str, output_size))))
+    return output_size
+
+
+def pack_weight(weight, shape):
+    """weight [O, C/g, kh, kw] -> MFMA-friendly image [g][K][C/g pad16][O/g pad256] (device)."""
+    L = _lib.lib()
+    nbytes = L.kgdet_dcn_packed_weight_bytes(ctypes.byref(shape))
+    packed = torch.empty(nbytes // 4, dtype=torch.float32, device=weight.device)
+    _lib.check(L.kgdet_dcn_pack_weight(ctypes.byref(shape), _lib.ptr(weight), _lib.ptr(packed),
+                                       _lib.current_stream()), 'kgdet_dcn_pack_weight')
+    return packed
+
+
+def _check_offset(offset, shape, out_size, mask=None):
+    """The reference's shape_check messages (R/src/deform_conv_cuda.cpp:128-135) as RuntimeError."""
+    K = shape.kh * shape.kw
+    if offset.size(0) != shape.N:
+        raise RuntimeError('invalid batch size of offset')
+    if offset.size(2) != out_size[2] or offset.size(3) != out_size[3]:
+        raise RuntimeError('invalid spatial size of offset, expected height: {} width: {}, but got '
+                           'height: {} width: {}'.format(out_size[2], out_size[3], offset.size(2),
+                                                         offset.size(3)))
+    if offset.size(1) != shape.deformable_groups * 2 * K:
+        raise RuntimeError('invalid number of channels of offset')
+    if mask is not None and tuple(mask.shape) != (shape.N, shape.deformable_groups * K, out_size[2],
+                                                   out_size[3]):
+        raise RuntimeError('invalid shape of mask')
+
+
+def _forward(input, offset, mask, weight, bias, shape, packed=None, relu=False):
+    L = _lib.lib()
+    input = input.contiguous()
+    offset = offset.contiguous()
+    mask = mask.contiguous() if mask is not None else None
+    if packed is None:
+        packed = pack_weight(weight.contiguous(), shape)
+    out_size = _output_size(input, weight, (shape.pad_h, shape.pad_w), (shape.dil_h, shape.dil_w),
+                            (shape.stride_h, shape.stride_w))
+    _check_offset(offset, shape, out_size, mask)
+    output = input.new_empty(out_size)
+    ws_bytes = L.kgdet_dcn_workspace_bytes(ctypes.byref(shape))
+    ws = _workspace(input.device, ws_bytes)
+    _lib.check(L.kgdet_deform_conv_forward(
+        ctypes.byref(shape), _lib.ptr(input), _lib.ptr(offset), _lib.ptr(mask), _lib.ptr(packed),
+        _lib.ptr(bias), _lib.ptr(output), ctypes.c_uint32(_lib.DCN_RELU if relu else 0),
+        _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.current_stream()), 'kgdet_deform_conv_forward')
+    return output, packed
+
+
+def _backward(input, offset, mask, weight, bias, grad_output, shape, packed, needs):
+    """Returns grad_input, grad_offset, grad_mask, grad_weight, grad_bias (None where not needed)."""
+    L = _lib.lib()
+    grad_output = grad_output.contiguous()
+    ws_bytes = L.kgdet_dcn_workspace_bytes(ctypes.byref(shape))
+    ws = _workspace(input.device, ws_bytes)
+    grad_input = grad_offset = grad_mask = grad_weight = grad_bias = None
+    if needs['input'] or needs['offset'] or needs['mask']:
+        grad_input = torch.zeros_like(input)
+        grad_offset = torch.empty_like(offset)
+        grad_mask = torch.empty_like(mask) if mask is not None else None
+        _lib.check(L.kgdet_deform_conv_backward_input(
+            ctypes.byref(shape), _lib.ptr(input), _lib.ptr(offset), _lib.ptr(mask), _lib.ptr(packed),
+            _lib.ptr(grad_output), _lib.ptr(grad_input), _lib.ptr(grad_offset), _lib.ptr(grad_mask),
+            _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.current_stream()),
+            'kgdet_deform_conv_backward_input')
+    if needs['weight'] or needs['bias']:
+        grad_weight = torch.empty_like(weight, memory_format=torch.contiguous_format)
+        grad_bias = torch.empty_like(bias) if bias is not None else None
+        _lib.check(L.kgdet_deform_conv_backward_weight(
+            ctypes.byref(shape), _lib.ptr(input), _lib.ptr(offset), _lib.ptr(mask),
+            _lib.ptr(grad_output), _lib.ptr(grad_weight), _lib.ptr(grad_bias), 0,
+            _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.current_stream()),
+            'kgdet_deform_conv_backward_weight')
+    return grad_input, grad_offset, grad_mask, grad_weight, grad_bias
+
+
+class DeformConvFunction(Function):
+
+    @staticmethod
+    def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1,
+                deformable_groups=1, im2col_step=64, relu=False):
+        if input is not None and input.dim() != 4:
+            raise ValueError('Expected 4D tensor as input, got {}D tensor instead.'.format(input.dim()))
+        ctx.stride = _pair(stride)
+        ctx.padding = _pair(padding)
+        ctx.dilation = _pair(dilation)
+        ctx.groups = groups
+        ctx.deformable_groups = deformable_groups
+        ctx.im2col_step = im2col_step
+        ctx.relu = relu
+        if not input.is_cuda:
+            raise NotImplementedError
+        # the reference batches images in groups of im2col_step and insists it divides the batch
+        # (R:47-49); the fused kernel needs no such batching but keeps the contract
+        cur_im2col_step = min(ctx.im2col_step, input.shape[0])
+        assert (input.shape[0] % cur_im2col_step) == 0, 'im2col step must divide batchsize'
+        shape = _shape(input, weight, ctx.stride, ctx.padding, ctx.dilation, groups, deformable_groups)
+        output, packed = _forward(input, offset, None, weight, None, shape, relu=relu)
+        ctx.shape = shape
+        ctx.save_for_backward(input, offset, weight, packed, output if relu else None)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        input, offset, weight, packed, output = ctx.saved_tensors
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        if ctx.relu:
+            grad_output = grad_output * (output > 0).to(grad_output.dtype)
+        needs = dict(input=ctx.needs_input_grad[0], offset=ctx.needs_input_grad[1], mask=False,
+                     weight=ctx.needs_input_grad[2], bias=False)
+        gi, go, _, gw, _ = _backward(input.contiguous(), offset.contiguous(), None, weight, None,
+                                     grad_output, ctx.shape, packed, needs)
+        return (gi, go, gw, None, None, None, None, None, None, None)
+
+
+class ModulatedDeformConvFunction(Function):
+
+    @staticmethod
+    def forward(ctx, input, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1,
+                groups=1, deformable_groups=1):
+        ctx.stride = stride
+        ctx.padding = padding
+        ctx.dilation = dilation
+        ctx.groups = groups
+        ctx.deformable_groups = deformable_groups
+        ctx.with_bias = bias is not None
+        if not input.is_cuda:
+            raise NotImplementedError
+        shape = _shape(input, weight, _pair(stride), _pair(padding), _pair(dilation), groups,
+                       deformable_groups)
+        output, packed = _forward(input, offset, mask, weight, bias, shape)
+        ctx.shape = shape
+        ctx.save_for_backward(input, offset, mask, weight, bias, packed)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        input, offset, mask, weight, bias, packed = ctx.saved_tensors
+        needs = dict(input=True, offset=True, mask=True, weight=True, bias=ctx.with_bias)
+        gi, go, gm, gw, gb = _backward(input.contiguous(), offset.contiguous(), mask.contiguous(),
+                                       weight, bias, grad_output, ctx.shape, packed, needs)
+        return (gi, go, gm, gw, gb, None, None, None, None, None)
+
+
+deform_conv = DeformConvFunction.apply
+modulated_deform_conv = ModulatedDeformConvFunction.apply
+
+
+class DeformConv(nn.Module):
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, deformable_groups=1, bias=False):
+        super(DeformConv, self).__init__()
+
+        assert not bias
+        assert in_channels % groups == 0, \
+            'in_channels {} cannot be divisible by groups {}'.format(in_channels, groups)
+        assert out_channels % groups == 0, \
+            'out_channels {} cannot be divisible by groups {}'.format(out_channels, groups)
+
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride = _pair(stride)
+        self.padding = _pair(padding)
+        self.dilation = _pair(dilation)
+        self.groups = groups
+        self.deformable_groups = deformable_groups
+
+        self.weight = nn.Parameter(
+            torch.Tensor(out_channels, in_channels // self.groups, *self.kernel_size))
+
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        n = self.in_channels
+        for k in self.kernel_size:
+            n *= k
+        stdv = 1. / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+
+    def forward(self, x, offset):
+        return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation,
+                           self.groups, self.deformable_groups)
+
+
+class DeformConvPack(DeformConv):
+
+    def __init__(self, *args, **kwargs):
+        super(DeformConvPack, self).__init__(*args, **kwargs)
+
+        self.conv_offset = nn.Conv2d(
+            self.in_channels,
+            self.deformable_groups * 2 * self.kernel_size[0] * self.kernel_size[1],
+            kernel_size=self.kernel_size, stride=_pair(self.stride), padding=_pair(self.padding),
+            bias=True)
+        self.init_offset()
+
+    def init_offset(self):
+        self.conv_offset.weight.data.zero_()
+        self.conv_offset.bias.data.zero_()
+
+    def forward(self, x):
+        offset = self.conv_offset(x)
+        return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation,
+                           self.groups, self.deformable_groups)
+
+
+class ModulatedDeformConv(nn.Module):
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, deformable_groups=1, bias=True):
+        super(ModulatedDeformConv, self).__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride = stride
+        self.padding = padding
+        self.dilation = dilation
+        self.groups = groups
+        self.deformable_groups = deformable_groups
+        self.with_bias = bias
+
+        self.weight = nn.Parameter(
+            torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
+        if bias:
+            self.bias = nn.Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        n = self.in_channels
+        for k in self.kernel_size:
+            n *= k
+        stdv = 1. / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.zero_()
+
+    def forward(self, x, offset, mask):
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride,
+                                     self.padding, self.dilation, self.groups,
+                                     self.deformable_groups)
+
+
+class ModulatedDeformConvPack(ModulatedDeformConv):
+
+    def __init__(self, *args, **kwargs):
+        super(ModulatedDeformConvPack, self).__init__(*args, **kwargs)
+
+        self.conv_offset_mask = nn.Conv2d(
+            self.in_channels,
+            self.deformable_groups * 3 * self.kernel_size[0] * self.kernel_size[1],
+            kernel_size=self.kernel_size, stride=_pair(self.stride), padding=_pair(self.padding),
+            bias=True)
+        self.init_offset()
+
+    def init_offset(self):
+        self.conv_offset_mask.weight.data.zero_()
+        self.conv_offset_mask.bias.data.zero_()
+
+    def forward(self, x):
+        out = self.conv_offset_mask(x)
+        o1, o2, mask = torch.chunk(out, 3, dim=1)
+        offset = torch.cat((o1, o2), dim=1)
+        mask = torch.sigmoid(mask)
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride,
+                                     self.padding, self.dilation, self.groups,
+                                     self.deformable_groups)
