@@ -9,6 +9,9 @@ namespace {
 
 struct Derived {
   int Ho, Wo, K, Cg, Og, Cg_pad, Og_pad;
+  int Og_pad16, Cg_pad256;  // transposed image for backward-input
+  size_t fwd_image_floats() const { return (size_t)K * Cg_pad * Og_pad; }
+  size_t bwd_image_floats() const { return (size_t)K * Og_pad16 * Cg_pad256; }
 };
 
 int derive(const kgdet_dcn_shape *s, Derived &d) {
@@ -35,6 +38,8 @@ int derive(const kgdet_dcn_shape *s, Derived &d) {
   d.Og = s->O / s->groups;
   d.Cg_pad = (int)align_up(d.Cg, kChunk);
   d.Og_pad = (int)align_up(d.Og, kTileM);
+  d.Og_pad16 = (int)align_up(d.Og, kChunk);
+  d.Cg_pad256 = (int)align_up(d.Cg, kTileM);
   const long long in_bytes = 4LL * s->N * s->C * s->H * s->W;
   const long long out_bytes = 4LL * s->N * s->O * d.Ho * d.Wo;
   const long long off_bytes = 4LL * s->N * s->deformable_groups * 2 * d.K * d.Ho * d.Wo;
@@ -53,6 +58,11 @@ size_t slab_bytes() { return (size_t)grid_size() * 2 * kTileElems * sizeof(float
 // the MFMA kernels gather 4 consecutive channels per thread with one Tap, so a deformable group
 // boundary must not fall inside such a quad
 bool mfma_ok(const kgdet_dcn_shape *s) { return (s->C / s->deformable_groups) % 4 == 0 || s->deformable_groups == 1; }
+// backward tiles (256 / 128 channels wide) must lie inside one deformable group
+bool mfma_bwd_ok(const kgdet_dcn_shape *s) {
+  const int cpdg = s->C / s->deformable_groups, Cg = s->C / s->groups;
+  return s->deformable_groups == 1 || cpdg % Cg == 0 || (Cg % cpdg == 0 && cpdg % kTileM == 0);
+}
 
 void fill_problem(const kgdet_dcn_shape *s, const Derived &d, int group, DcnProblem &p) {
   p = DcnProblem{};
@@ -83,14 +93,15 @@ int kgdet_dcn_output_size(const kgdet_dcn_shape *s, int32_t *Ho, int32_t *Wo) {
 size_t kgdet_dcn_packed_weight_bytes(const kgdet_dcn_shape *s) {
   Derived d;
   if (derive(s, d)) return 0;
-  return (size_t)s->groups * d.K * d.Cg_pad * d.Og_pad * sizeof(float);
+  // [forward image per group ...][transposed (backward-input) image per group ...]
+  return (size_t)s->groups * (d.fwd_image_floats() + d.bwd_image_floats()) * sizeof(float);
 }
 
 size_t kgdet_dcn_workspace_bytes(const kgdet_dcn_shape *s) {
   Derived d;
   if (derive(s, d)) return 0;
   // slabs for stream-K partial tiles + (backward-weight) a packed gradient image
-  return slab_bytes() + kgdet_dcn_packed_weight_bytes(s);
+  return slab_bytes() + (size_t)s->groups * d.fwd_image_floats() * sizeof(float);
 }
 
 int kgdet_dcn_pack_weight(const kgdet_dcn_shape *s, const float *weight, float *packed, void *stream) {
@@ -101,10 +112,14 @@ int kgdet_dcn_pack_weight(const kgdet_dcn_shape *s, const float *weight, float *
   KGDET_CHECK_SHAPE(lds <= 64 * 1024, "kernel %dx%d too large to pack", s->kh, s->kw);
   for (int g = 0; g < s->groups; ++g) {
     const float *w = weight + (size_t)g * d.Og * d.Cg * d.K;
-    float *dst = packed + (size_t)g * d.K * d.Cg_pad * d.Og_pad;
+    float *dst = packed + (size_t)g * d.fwd_image_floats();
     dim3 grid(d.Cg_pad, d.Og_pad / 64);
     hipLaunchKernelGGL(dcn_pack_weight, grid, dim3(256), lds, (hipStream_t)stream, w, dst, d.Og, d.Cg, d.K,
                        d.Cg_pad, d.Og_pad);
+    float *dst_t = packed + (size_t)s->groups * d.fwd_image_floats() + (size_t)g * d.bwd_image_floats();
+    dim3 grid_t(d.Og_pad16, d.Cg_pad256 / 64);
+    hipLaunchKernelGGL(dcn_pack_weight_t, grid_t, dim3(256), lds, (hipStream_t)stream, w, dst_t, d.Og, d.Cg, d.K,
+                       d.Og_pad16, d.Cg_pad256);
   }
   KGDET_CHECK_LAUNCH("dcn_pack_weight");
   return KGDET_OK;
@@ -119,7 +134,7 @@ int kgdet_dcn_unpack_weight_grad(const kgdet_dcn_shape *s, const float *packed, 
   KGDET_CHECK_SHAPE(lds <= 64 * 1024, "kernel %dx%d too large to unpack", s->kh, s->kw);
   for (int g = 0; g < s->groups; ++g) {
     float *w = grad_weight + (size_t)g * d.Og * d.Cg * d.K;
-    const float *src = packed + (size_t)g * d.K * d.Cg_pad * d.Og_pad;
+    const float *src = packed + (size_t)g * d.fwd_image_floats();
     dim3 grid(d.Cg, d.Og_pad / 64);
     hipLaunchKernelGGL(dcn_unpack_weight, grid, dim3(256), lds, (hipStream_t)stream, src, w, d.Og, d.Cg, d.K,
                        d.Cg_pad, d.Og_pad, accumulate);
@@ -149,7 +164,7 @@ int kgdet_deform_conv_forward(const kgdet_dcn_shape *s, const float *input, cons
     DcnProblem p;
     fill_problem(s, d, g, p);
     p.x = input; p.offset = offset; p.mask = mask; p.bias = bias; p.out = output;
-    p.wpk = packed_weight + (size_t)g * d.K * d.Cg_pad * d.Og_pad;
+    p.wpk = packed_weight + (size_t)g * d.fwd_image_floats();
     p.flags = flags;
     p.n_ntiles = ceil_div(p.P, kTileN);
     p.n_mtiles = d.Og_pad / kTileM;
@@ -161,6 +176,96 @@ int kgdet_deform_conv_forward(const kgdet_dcn_shape *s, const float *input, cons
                        (const float *)workspace, G);
   }
   KGDET_CHECK_LAUNCH("dcn_fwd_mfma");
+  return KGDET_OK;
+}
+
+int kgdet_deform_conv_backward_input(const kgdet_dcn_shape *s, const float *input, const float *offset,
+                                     const float *mask, const float *packed_weight, const float *grad_output,
+                                     float *grad_input, float *grad_offset, float *grad_mask, void *workspace,
+                                     size_t workspace_bytes, void *stream) {
+  Derived d;
+  if (int rc = derive(s, d)) return rc;
+  KGDET_CHECK_SHAPE(input && offset && packed_weight && grad_output && grad_input && grad_offset, "null pointer");
+  KGDET_CHECK_SHAPE((mask == nullptr) == (grad_mask == nullptr), "mask and grad_mask must come together");
+  if (!mfma_bwd_ok(s)) {
+    set_error("deformable_groups=%d / groups=%d / C=%d: channel tiles straddle deformable groups (unsupported)",
+              s->deformable_groups, s->groups, s->C);
+    return KGDET_E_UNSUPPORTED;
+  }
+  (void)workspace; (void)workspace_bytes;
+  const int G = grid_size();
+  const int cpdg = s->C / s->deformable_groups;
+  // one launch and one channel tile produce a deformable group's whole sum -> plain stores
+  const int direct = (d.Cg == cpdg && d.Cg_pad256 == kTileM) ? 1 : 0;
+  if (!direct) {
+    const size_t off_bytes = sizeof(float) * (size_t)s->N * s->deformable_groups * 2 * d.K * d.Ho * d.Wo;
+    KGDET_HIP_TRY(hipMemsetAsync(grad_offset, 0, off_bytes, (hipStream_t)stream));
+    if (grad_mask) KGDET_HIP_TRY(hipMemsetAsync(grad_mask, 0, off_bytes / 2, (hipStream_t)stream));
+  }
+  for (int g = 0; g < s->groups; ++g) {
+    DcnProblem p;
+    fill_problem(s, d, g, p);
+    p.x = input; p.offset = offset; p.mask = mask;
+    p.wpk = packed_weight + (size_t)s->groups * d.fwd_image_floats() + (size_t)g * d.bwd_image_floats();
+    DcnBwdInputArgs a{};
+    a.grad_out = grad_output; a.grad_input = grad_input; a.grad_offset = grad_offset; a.grad_mask = grad_mask;
+    a.Og_pad16 = d.Og_pad16; a.Cg_pad256 = d.Cg_pad256;
+    a.n_ctiles = d.Cg_pad256 / kTileM;
+    a.n_ntiles = ceil_div(p.P, kTileN);
+    a.n_units = d.K * a.n_ctiles * a.n_ntiles;
+    a.direct = direct;
+    const int grid = a.n_units < G ? a.n_units : G;
+    hipLaunchKernelGGL(dcn_bwd_input_mfma, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, p, a);
+  }
+  KGDET_CHECK_LAUNCH("dcn_bwd_input_mfma");
+  return KGDET_OK;
+}
+
+int kgdet_deform_conv_backward_weight(const kgdet_dcn_shape *s, const float *input, const float *offset,
+                                      const float *mask, const float *grad_output, float *grad_weight,
+                                      float *grad_bias, int accumulate, void *workspace, size_t workspace_bytes,
+                                      void *stream) {
+  Derived d;
+  if (int rc = derive(s, d)) return rc;
+  KGDET_CHECK_SHAPE(input && offset && grad_output && grad_weight, "null pointer");
+  const int cpdg = s->C / s->deformable_groups;
+  if (!(s->deformable_groups == 1 || cpdg % d.Cg == 0 || (d.Cg % cpdg == 0 && cpdg % kTileN == 0))) {
+    set_error("deformable_groups=%d / groups=%d / C=%d: channel tiles straddle deformable groups (unsupported)",
+              s->deformable_groups, s->groups, s->C);
+    return KGDET_E_UNSUPPORTED;
+  }
+  const size_t need = slab_bytes() + (size_t)s->groups * d.fwd_image_floats() * sizeof(float);
+  if (workspace == nullptr || workspace_bytes < need) {
+    set_error("workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    return KGDET_E_WORKSPACE;
+  }
+  float *slabs = (float *)workspace;
+  float *gpk = (float *)((char *)workspace + slab_bytes());  // packed gradient image
+  const int G = grid_size();
+  for (int g = 0; g < s->groups; ++g) {
+    DcnProblem p;
+    fill_problem(s, d, g, p);
+    p.x = input; p.offset = offset; p.mask = mask;
+    p.out = gpk + (size_t)g * d.fwd_image_floats();
+    DcnBwdWeightArgs a{};
+    a.grad_out = grad_output;
+    a.n_ctiles = ceil_div(d.Cg_pad, kTileN);
+    a.n_otiles = d.Og_pad / kTileM;
+    a.stages_per_tile = ceil_div(p.P, kChunk);
+    a.Cg_pad128 = a.n_ctiles * kTileN;
+    const int n_tiles = d.K * a.n_otiles * a.n_ctiles;
+    a.total_units = (long long)n_tiles * a.stages_per_tile;
+    hipLaunchKernelGGL(dcn_bwd_weight_mfma, dim3(G), dim3(kThreads), 0, (hipStream_t)stream, p, a, slabs);
+    hipLaunchKernelGGL(dcn_bwd_weight_fixup, dim3(n_tiles), dim3(kThreads), 0, (hipStream_t)stream, p, a,
+                       (const float *)slabs, G);
+  }
+  KGDET_CHECK_LAUNCH("dcn_bwd_weight_mfma");
+  if (int rc = kgdet_dcn_unpack_weight_grad(s, gpk, grad_weight, accumulate, stream)) return rc;
+  if (grad_bias) {
+    hipLaunchKernelGGL(dcn_bias_grad, dim3(s->O), dim3(256), 0, (hipStream_t)stream, grad_output, grad_bias,
+                       s->N, s->O, d.Ho * d.Wo, accumulate);
+    KGDET_CHECK_LAUNCH("dcn_bias_grad");
+  }
   return KGDET_OK;
 }
 

@@ -216,6 +216,25 @@ __global__ __launch_bounds__(256) void dcn_pack_weight(const float *__restrict__
   }
 }
 
+// Transposed image for backward-input: [O, Cg, K] -> Wt[K][Og_pad16][Cg_pad256], zero padded.
+// One workgroup per (o, 64 channels): reads 64*K contiguous floats, writes K runs of 64 floats.
+__global__ __launch_bounds__(256) void dcn_pack_weight_t(const float *__restrict__ w, float *__restrict__ wpt,
+                                                          int Og, int Cg, int K, int Og_pad16, int Cg_pad256) {
+  extern __shared__ float tile[];  // [64][K+1]
+  const int o = blockIdx.x, c0 = blockIdx.y * 64, tid = threadIdx.x;
+  const int ld = K + 1;
+  for (int e = tid; e < 64 * K; e += 256) {
+    const int cc = e / K, t = e - cc * K;
+    const int c = c0 + cc;
+    tile[cc * ld + t] = (o < Og && c < Cg) ? w[((long long)o * Cg + c) * K + t] : 0.0f;
+  }
+  __syncthreads();
+  for (int e = tid; e < 64 * K; e += 256) {
+    const int t = e >> 6, cc = e & 63;
+    wpt[((long long)t * Og_pad16 + o) * Cg_pad256 + c0 + cc] = tile[cc * ld + t];
+  }
+}
+
 // inverse: packed gradient [K][Cg_pad][Og_pad] -> [O, Cg, K]
 __global__ __launch_bounds__(256) void dcn_unpack_weight(const float *__restrict__ wpk, float *__restrict__ w,
                                                           int Og, int Cg, int K, int Cg_pad, int Og_pad,

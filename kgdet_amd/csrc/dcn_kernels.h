@@ -11,4 +11,27 @@ __global__ void dcn_pack_weight(const float *__restrict__ w, float *__restrict__
 __global__ void dcn_unpack_weight(const float *__restrict__ wpk, float *__restrict__ w, int Og, int Cg, int K,
                                   int Cg_pad, int Og_pad, int accumulate);
 
+__global__ void dcn_pack_weight_t(const float *__restrict__ w, float *__restrict__ wpt, int Og, int Cg, int K,
+                                  int Og_pad16, int Cg_pad256);
+
+struct DcnBwdInputArgs {
+  const float *grad_out;
+  float *grad_input;
+  float *grad_offset;
+  float *grad_mask;
+  int Og_pad16, Cg_pad256, n_ctiles, n_ntiles, n_units;
+  int direct;
+};
+struct DcnBwdWeightArgs {
+  const float *grad_out;
+  int n_ctiles, n_otiles, stages_per_tile, Cg_pad128;
+  long long total_units;
+};
+__global__ void dcn_bwd_input_mfma(const DcnProblem p, const DcnBwdInputArgs a);
+__global__ void dcn_bwd_weight_mfma(const DcnProblem p, const DcnBwdWeightArgs a, float *__restrict__ slabs);
+__global__ void dcn_bwd_weight_fixup(const DcnProblem p, const DcnBwdWeightArgs a, const float *__restrict__ slabs,
+                                     int G);
+__global__ void dcn_bias_grad(const float *__restrict__ grad_out, float *__restrict__ grad_bias, int N, int O,
+                              int HoWo, int accumulate);
+
 }  // namespace kgdet

@@ -107,3 +107,65 @@ def test_errors_match_reference_behaviour():
         dcn.deform_conv(xc, torch.zeros(2, 10, 8, 8).cuda(), torch.zeros(8, 16, 3, 3).cuda(), 1, 1, 1)
     with pytest.raises(ValueError):               # deform_conv.py:26-29
         dcn.deform_conv(xc[0], torch.zeros(2, 18, 8, 8).cuda(), torch.zeros(8, 16, 3, 3).cuda(), 1, 1, 1)
+
+
+BWD_CASES = [
+    (2, 256, 25, 42, 256, 3, 1, 1, 1, 1, 1),
+    (2, 256, 25, 42, 256, 7, 1, 3, 1, 1, 1),
+    (1, 256, 13, 17, 256, 5, 1, 2, 1, 1, 1),
+    (3, 64, 20, 20, 128, 3, 1, 1, 1, 1, 1),
+    (2, 40, 11, 9, 24, 3, 2, 1, 1, 1, 1),
+    (2, 32, 12, 12, 32, 3, 1, 2, 2, 2, 1),
+    (2, 32, 10, 10, 16, 3, 1, 1, 1, 2, 2),      # deformable group == weight group
+    (1, 512, 8, 8, 512, 3, 1, 1, 1, 1, 1),      # two channel tiles -> atomic grad_offset
+]
+
+
+@pytest.mark.parametrize('case', BWD_CASES)
+def test_backward_v1(case):
+    _require_gpu()
+    from kgdet_amd import dcn
+    N, C, H, W, O, k, s, p, d, g, dg = case
+    x, off, w, go, _ = _make(case, seed=5)
+    tx, to, tw = (torch.from_numpy(a).cuda().requires_grad_() for a in (x, off, w))
+    out = dcn.deform_conv(tx, to, tw, s, p, d, g, dg)
+    out.backward(torch.from_numpy(go).cuda())
+    torch.cuda.synchronize()
+    ref = oracle.deform_conv_backward(x.astype(np.float64), off.astype(np.float64), w.astype(np.float64),
+                                      go.astype(np.float64), s, p, d, g, dg)
+    _close(tx.grad.cpu().numpy(), ref['grad_input'], 5e-5)
+    _close(to.grad.cpu().numpy(), ref['grad_offset'], 5e-5)
+    _close(tw.grad.cpu().numpy(), ref['grad_weight'], 5e-5)
+
+
+@pytest.mark.parametrize('case', [BWD_CASES[0], BWD_CASES[4], BWD_CASES[5], BWD_CASES[6]])
+def test_backward_v2(case):
+    _require_gpu()
+    from kgdet_amd import dcn
+    N, C, H, W, O, k, s, p, d, g, dg = case
+    x, off, w, go, mask = _make(case, seed=6, with_mask=True)
+    bias = np.linspace(-1, 1, O).astype(np.float32)
+    tx, to, tm, tw, tb = (torch.from_numpy(a).cuda().requires_grad_() for a in (x, off, mask, w, bias))
+    out = dcn.modulated_deform_conv(tx, to, tm, tw, tb, s, p, d, g, dg)
+    out.backward(torch.from_numpy(go).cuda())
+    ref = oracle.deform_conv_backward(x.astype(np.float64), off.astype(np.float64), w.astype(np.float64),
+                                      go.astype(np.float64), s, p, d, g, dg, mask=mask.astype(np.float64),
+                                      with_bias=True)
+    _close(tx.grad.cpu().numpy(), ref['grad_input'], 5e-5)
+    _close(to.grad.cpu().numpy(), ref['grad_offset'], 5e-5)
+    _close(tm.grad.cpu().numpy(), ref['grad_mask'], 5e-5)
+    _close(tw.grad.cpu().numpy(), ref['grad_weight'], 5e-5)
+    _close(tb.grad.cpu().numpy(), ref['grad_bias'], 5e-5)
+
+
+def test_grad_weight_deterministic():
+    _require_gpu()
+    from kgdet_amd import dcn
+    x, off, w, go, _ = _make(BWD_CASES[1], seed=7)
+    grads = []
+    for _ in range(2):
+        tx, to, tw = (torch.from_numpy(a).cuda().requires_grad_() for a in (x, off, w))
+        dcn.deform_conv(tx, to, tw, 1, 3, 1).backward(torch.from_numpy(go).cuda())
+        grads.append((to.grad.clone(), tw.grad.clone()))
+    assert torch.equal(grads[0][0], grads[1][0])   # grad_offset: no atomics on this shape
+    assert torch.equal(grads[0][1], grads[1][1])   # grad_weight: slab fix-up in fixed order
