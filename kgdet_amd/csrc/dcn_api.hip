@@ -55,6 +55,36 @@ int grid_size() {
 
 size_t slab_bytes() { return (size_t)grid_size() * 2 * kTileElems * sizeof(float); }
 
+constexpr size_t kMaxLds = 160 * 1024;
+
+// LDS-privatised backward-input: one (image, 32-channel slice) plane set must fit in LDS
+struct BwdLdsPlan {
+  bool ok;
+  int n_cslices, S, n_blocks, n_pblocks, n_slices_total;
+  size_t lds_bytes, slab_floats, off_floats, mask_floats;
+};
+
+BwdLdsPlan plan_bwd_lds(const kgdet_dcn_shape *s, const Derived &d) {
+  BwdLdsPlan pl{};
+  pl.lds_bytes = (size_t)32 * s->H * s->W * sizeof(float);
+  const int cpdg = s->C / s->deformable_groups;
+  // a 32-channel slice must not straddle deformable groups
+  const bool dg_ok = s->deformable_groups == 1 || cpdg % d.Cg == 0 || (d.Cg % cpdg == 0 && cpdg % 32 == 0);
+  pl.ok = pl.lds_bytes <= kMaxLds && dg_ok;
+  pl.n_cslices = ceil_div(d.Cg, 32);
+  const int pairs = s->N * pl.n_cslices;
+  pl.S = grid_size() / pairs;
+  if (pl.S < 1) pl.S = 1;
+  if (pl.S > 64) pl.S = 64;
+  pl.n_blocks = pairs * pl.S;
+  pl.n_pblocks = ceil_div(d.Ho * d.Wo, 64);
+  pl.n_slices_total = s->groups * pl.n_cslices;
+  pl.slab_floats = (size_t)pl.n_blocks * 32 * s->H * s->W;
+  pl.off_floats = (size_t)pl.n_slices_total * s->N * 2 * d.K * d.Ho * d.Wo;
+  pl.mask_floats = pl.off_floats / 2;
+  return pl;
+}
+
 // the MFMA kernels gather 4 consecutive channels per thread with one Tap, so a deformable group
 // boundary must not fall inside such a quad
 bool mfma_ok(const kgdet_dcn_shape *s) { return (s->C / s->deformable_groups) % 4 == 0 || s->deformable_groups == 1; }
@@ -101,7 +131,10 @@ size_t kgdet_dcn_workspace_bytes(const kgdet_dcn_shape *s) {
   Derived d;
   if (derive(s, d)) return 0;
   // slabs for stream-K partial tiles + (backward-weight) a packed gradient image
-  return slab_bytes() + (size_t)s->groups * d.fwd_image_floats() * sizeof(float);
+  const size_t fwd_and_wgrad = slab_bytes() + (size_t)s->groups * d.fwd_image_floats() * sizeof(float);
+  const BwdLdsPlan pl = plan_bwd_lds(s, d);
+  const size_t bwd_in = pl.ok ? (pl.slab_floats + pl.off_floats + pl.mask_floats) * sizeof(float) : 0;
+  return fwd_and_wgrad > bwd_in ? fwd_and_wgrad : bwd_in;
 }
 
 int kgdet_dcn_pack_weight(const kgdet_dcn_shape *s, const float *weight, float *packed, void *stream) {
@@ -192,9 +225,48 @@ int kgdet_deform_conv_backward_input(const kgdet_dcn_shape *s, const float *inpu
               s->deformable_groups, s->groups, s->C);
     return KGDET_E_UNSUPPORTED;
   }
-  (void)workspace; (void)workspace_bytes;
   const int G = grid_size();
   const int cpdg = s->C / s->deformable_groups;
+  const BwdLdsPlan pl = plan_bwd_lds(s, d);
+  if (pl.ok) {
+    // LDS-privatised path: no global atomics, outputs need no pre-zeroing
+    const size_t need = (pl.slab_floats + pl.off_floats + pl.mask_floats) * sizeof(float);
+    if (workspace == nullptr || workspace_bytes < need) {
+      set_error("workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+      return KGDET_E_WORKSPACE;
+    }
+    float *slabs = (float *)workspace;
+    float *off_part = slabs + pl.slab_floats;
+    float *mask_part = mask ? off_part + pl.off_floats : nullptr;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+      KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_bwd_input_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)kMaxLds));
+      attr_set = true;
+    }
+    for (int g = 0; g < s->groups; ++g) {
+      DcnProblem p;
+      fill_problem(s, d, g, p);
+      p.x = input; p.offset = offset; p.mask = mask;
+      p.wpk = packed_weight + (size_t)s->groups * d.fwd_image_floats() + (size_t)g * d.bwd_image_floats();
+      DcnBwdInputLdsArgs a{};
+      a.grad_out = grad_output; a.slabs = slabs; a.off_part = off_part; a.mask_part = mask_part;
+      a.Og_pad16 = d.Og_pad16; a.Cg_pad256 = d.Cg_pad256;
+      a.n_cslices = pl.n_cslices; a.S = pl.S; a.n_pblocks = pl.n_pblocks; a.slice_base = g * pl.n_cslices;
+      hipLaunchKernelGGL(dcn_bwd_input_lds, dim3(pl.n_blocks), dim3(kThreads), pl.lds_bytes, (hipStream_t)stream, p, a);
+      hipLaunchKernelGGL(dcn_bwd_input_fixup, dim3(ceil_div(32 * s->H * s->W, 256 * 4), s->N * pl.n_cslices), dim3(256),
+                         0, (hipStream_t)stream, p, a, grad_input);
+    }
+    const long long off_elems = (long long)s->N * s->deformable_groups * 2 * d.K * d.Ho * d.Wo;
+    int fix_grid = (int)((off_elems + 255) / 256);
+    if (fix_grid > 4096) fix_grid = 4096;
+    hipLaunchKernelGGL(dcn_bwd_offset_fixup, dim3(fix_grid), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)off_part, (const float *)mask_part, grad_offset, grad_mask, pl.n_slices_total,
+                       s->N, s->deformable_groups, d.K, d.Ho * d.Wo, pl.n_cslices, d.Cg, cpdg);
+    KGDET_CHECK_LAUNCH("dcn_bwd_input_lds");
+    return KGDET_OK;
+  }
+  // large feature maps: global-atomic path (grad_input must be zero-filled by the caller)
   // one launch and one channel tile produce a deformable group's whole sum -> plain stores
   const int direct = (d.Cg == cpdg && d.Cg_pad256 == kTileM) ? 1 : 0;
   if (!direct) {

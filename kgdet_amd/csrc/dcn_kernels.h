@@ -27,6 +27,18 @@ struct DcnBwdWeightArgs {
   int n_ctiles, n_otiles, stages_per_tile, Cg_pad128;
   long long total_units;
 };
+struct DcnBwdInputLdsArgs {
+  const float *grad_out;
+  float *slabs;      // [N * n_cslices * S][32][H*W] partial grad_input planes
+  float *off_part;   // [n_slices_total][N][2K][HoWo] per-slice partial offset gradients
+  float *mask_part;  // [n_slices_total][N][K][HoWo] or nullptr
+  int Og_pad16, Cg_pad256, n_cslices, S, n_pblocks, slice_base;
+};
+__global__ void dcn_bwd_input_lds(const DcnProblem p, const DcnBwdInputLdsArgs a);
+__global__ void dcn_bwd_input_fixup(const DcnProblem p, const DcnBwdInputLdsArgs a, float *__restrict__ grad_input);
+__global__ void dcn_bwd_offset_fixup(const float *__restrict__ off_part, const float *__restrict__ mask_part,
+                                     float *__restrict__ grad_offset, float *__restrict__ grad_mask, int n_slices,
+                                     int N, int DG, int K, int HoWo, int n_cslices, int Cg, int cpdg);
 __global__ void dcn_bwd_input_mfma(const DcnProblem p, const DcnBwdInputArgs a);
 __global__ void dcn_bwd_weight_mfma(const DcnProblem p, const DcnBwdWeightArgs a, float *__restrict__ slabs);
 __global__ void dcn_bwd_weight_fixup(const DcnProblem p, const DcnBwdWeightArgs a, const float *__restrict__ slabs,

@@ -41,9 +41,33 @@ def main():
         t = e0.elapsed_time(e1) / args.iters * 1e-3
         flops = 2.0 * C * C * K * B * H * W
         byts = 4.0 * (2 * B * C * H * W + 2 * B * K * H * W + C * C * K)
+        # backward
+        go = torch.randn(B, C, H, W, device=dev)
+        needs_i = dict(input=True, offset=True, mask=False, weight=False, bias=False)
+        needs_w = dict(input=False, offset=False, mask=False, weight=True, bias=False)
+        tb = {}
+        for name, needs in (('bwd_in', needs_i), ('bwd_w', needs_w)):
+            for _ in range(2):
+                dcn._backward(x, off, None, w, None, go, shape, packed, needs)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(args.iters):
+                dcn._backward(x, off, None, w, None, go, shape, packed, needs)
+            e1.record()
+            torch.cuda.synchronize()
+            tb[name] = e0.elapsed_time(e1) / args.iters * 1e-3
+        e0.record()
+        for _ in range(args.iters):
+            dcn.pack_weight(w, shape)
+        e1.record()
+        torch.cuda.synchronize()
+        tpack = e0.elapsed_time(e1) / args.iters * 1e-3
         rows.append(dict(B=B, H=H, W=W, k=k, us=round(t * 1e6, 1), tflops=round(flops / t / 1e12, 1),
                          mfma_frac=round(flops / t / FP32_MFMA_PEAK, 3),
-                         hbm_frac=round(byts / t / HBM_PEAK, 4)))
+                         hbm_frac=round(byts / t / HBM_PEAK, 4),
+                         bwd_in_us=round(tb['bwd_in'] * 1e6, 1), bwd_in_frac=round(flops / tb['bwd_in'] / FP32_MFMA_PEAK, 3),
+                         bwd_w_us=round(tb['bwd_w'] * 1e6, 1), bwd_w_frac=round(flops / tb['bwd_w'] / FP32_MFMA_PEAK, 3),
+                         pack_us=round(tpack * 1e6, 1)))
         print(json.dumps(rows[-1]), flush=True)
 
 
