@@ -159,15 +159,15 @@ int kgdet_soft_nms(const float *dets, int64_t n, float iou_thr, int32_t method, 
 /* ------------------------------------------------------------------------------------------
  * Moment bounding box ("points2bbox", transform_method='moment';
  * R/../models/anchor_heads/reppoints_head_kp3rep_cas_1_assign_once.py:342-391).
- * pts [B, 2*n_pts, H, W] with (y,x) interleaved per point; moment_transfer [2] (already
+ * pts [B, 2*n_pts, H, W] with (y,x) interleaved per point (y_first != 0) or (x,y); moment_transfer [2] (already
  * blended with its detached copy by the caller); bbox [B, 4, H, W] = (x1,y1,x2,y2).
  * Mean and UNBIASED std (n-1) over the points; half extent = std * exp(transfer).
  * Backward returns grad_pts and grad_transfer[2] (accumulated into a zero-filled buffer).
  * ------------------------------------------------------------------------------------------ */
 int kgdet_moment_bbox_forward(const float *pts, const float *moment_transfer, int32_t B, int32_t n_pts,
-                              int32_t HW, float *bbox, void *stream);
+                              int32_t HW, int32_t y_first, float *bbox, void *stream);
 int kgdet_moment_bbox_backward(const float *pts, const float *moment_transfer, const float *grad_bbox,
-                               int32_t B, int32_t n_pts, int32_t HW, float *grad_pts,
+                               int32_t B, int32_t n_pts, int32_t HW, int32_t y_first, float *grad_pts,
                                float *grad_transfer, void *stream);
 
 #ifdef __cplusplus

@@ -1,0 +1,408 @@
+// Hard NMS (batched, fully on device) and soft-NMS for gfx950.
+//
+// Reference semantics pinned (bit-exact index selection): mmdet/ops/nms/src/nms_cpu.cpp:5-59
+//   areas (x2-x1+1)*(y2-y1+1); visit in descending score order; a later box is suppressed when
+//   inter / (area_i + area_j - inter) >= thr; the result is the kept indices in ASCENDING index
+//   order.  (The reference's CUDA kernel uses > instead of >= and ships an N x N/64 bit mask to the
+//   host for the greedy sweep, nms_kernel.cu:60,99-123; here the sweep stays on the device.)
+// Soft-NMS: mmdet/ops/nms/src/soft_nms_cpu.pyx:22-127, including its swap-with-last removal order.
+//
+// One workgroup per segment (= one (image, class) problem), everything in LDS:
+//   1. 64-bit keys (descending score, ascending index) -> bitonic sort
+//   2. sorted boxes + areas into LDS
+//   3. greedy suppression in chunks of 64 sorted boxes: wave 0 resolves the chunk internally with
+//      64 readlane steps on 64-bit masks, then all waves apply the chunk's survivors to every
+//      later box in parallel
+//   4. survivors flagged by original index, prefix-scanned, written ascending.
+// The float expressions are written exactly as in the reference and compiled with contraction off,
+// so every >= decision is the same as on the CPU.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace kgdet {
+
+namespace {
+
+constexpr int kNmsThreads = 512;
+constexpr int kNmsMaxLen = 4096;  // boxes per segment that fit the LDS plan below
+
+__device__ __forceinline__ unsigned long long score_key(float s, unsigned idx) {
+  unsigned u = __float_as_uint(s);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending order-preserving map
+  return ((unsigned long long)(~u) << 32) | idx;   // invert: larger score sorts first; ties: lower index
+}
+
+__device__ __forceinline__ bool iou_ge(float ix1, float iy1, float ix2, float iy2, float iarea, float jx1,
+                                       float jy1, float jx2, float jy2, float jarea, float thr) {
+  const float xx1 = fmaxf(ix1, jx1), yy1 = fmaxf(iy1, jy1);
+  const float xx2 = fminf(ix2, jx2), yy2 = fminf(iy2, jy2);
+  const float w = fmaxf(0.0f, xx2 - xx1 + 1), h = fmaxf(0.0f, yy2 - yy1 + 1);
+  const float inter = w * h;
+  const float ovr = inter / (iarea + jarea - inter);
+  return ovr >= thr;
+}
+
+// block-wide exclusive scan of one int per thread (512 threads); returns the prefix, total via out
+__device__ __forceinline__ int block_exclusive_scan(int v, int *lds_wave_sums, int &total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int n = __shfl_up(incl, d);
+    if (lane >= d) incl += n;
+  }
+  if (lane == 63) lds_wave_sums[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kNmsThreads / 64; ++w) {
+    const int s = lds_wave_sums[w];
+    if (w < wave) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  total = tot;
+  return base + incl - v;
+}
+
+}  // namespace
+
+// dynamic LDS layout: keys[NP] u64 | x1,y1,x2,y2,area [n each] | alive[n] u8 (then reused as flags)
+__global__ __launch_bounds__(kNmsThreads) void nms_segments(const float *__restrict__ dets,
+                                                            const long long *__restrict__ seg_offsets,
+                                                            float thr, long long *__restrict__ keep,
+                                                            long long *__restrict__ num_keep, int max_np) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int wave_sums[kNmsThreads / 64];
+  __shared__ unsigned long long chunk_alive;
+
+  const int seg = blockIdx.x, tid = threadIdx.x;
+  const long long seg_begin = seg_offsets[seg];
+  const int n = (int)(seg_offsets[seg + 1] - seg_begin);
+  if (n <= 0) {
+    if (tid == 0) num_keep[seg] = 0;
+    return;
+  }
+  int NP = 64;
+  while (NP < n) NP <<= 1;
+  const float *d = dets + seg_begin * 5;
+
+  unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);
+  float *bx1 = reinterpret_cast<float *>(smem + (size_t)max_np * 8);
+  float *by1 = bx1 + max_np, *bx2 = by1 + max_np, *by2 = bx2 + max_np, *bar = by2 + max_np;
+  unsigned char *alive = reinterpret_cast<unsigned char *>(bar + max_np);
+
+  for (int i = tid; i < NP; i += kNmsThreads)
+    keys[i] = i < n ? score_key(d[5 * i + 4], (unsigned)i) : ~0ull;
+  __syncthreads();
+  // bitonic sort, ascending keys
+  for (int k = 2; k <= NP; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < NP; i += kNmsThreads) {
+        const int l = i ^ j;
+        if (l > i) {
+          const unsigned long long a = keys[i], b = keys[l];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < n; i += kNmsThreads) {
+    const unsigned src = (unsigned)(keys[i] & 0xffffffffu);
+    const float x1 = d[5 * src], y1 = d[5 * src + 1], x2 = d[5 * src + 2], y2 = d[5 * src + 3];
+    bx1[i] = x1; by1[i] = y1; bx2[i] = x2; by2[i] = y2;
+    bar[i] = (x2 - x1 + 1) * (y2 - y1 + 1);
+    alive[i] = 1;
+  }
+  __syncthreads();
+
+  const int lane = tid & 63;
+  for (int c0 = 0; c0 < n; c0 += 64) {
+    if (tid < 64) {  // wave 0: resolve the chunk internally
+      const int i = c0 + lane;
+      const bool have = i < n;
+      const float x1 = have ? bx1[i] : 0.f, y1 = have ? by1[i] : 0.f, x2 = have ? bx2[i] : 0.f,
+                  y2 = have ? by2[i] : 0.f, ar = have ? bar[i] : 0.f;
+      unsigned long long mask = 0;  // bit j: this box suppresses chunk box j (j > lane)
+      for (int j = lane + 1; j < 64 && c0 + j < n; ++j)
+        if (iou_ge(x1, y1, x2, y2, ar, bx1[c0 + j], by1[c0 + j], bx2[c0 + j], by2[c0 + j], bar[c0 + j], thr))
+          mask |= 1ull << j;
+      unsigned long long live = __ballot(have && alive[i]);
+      const unsigned mlo = (unsigned)mask, mhi = (unsigned)(mask >> 32);
+      for (int s = 0; s < 64; ++s) {
+        if ((live >> s) & 1ull) {
+          const unsigned lo = __builtin_amdgcn_readlane(mlo, s), hi = __builtin_amdgcn_readlane(mhi, s);
+          live &= ~(((unsigned long long)hi << 32) | lo);
+        }
+      }
+      if (have) alive[i] = (live >> lane) & 1ull;
+      if (lane == 0) chunk_alive = live;
+    }
+    __syncthreads();
+    const unsigned long long live = chunk_alive;
+    if (live) {
+      for (int j = c0 + 64 + tid; j < n; j += kNmsThreads) {
+        if (!alive[j]) continue;
+        const float x1 = bx1[j], y1 = by1[j], x2 = bx2[j], y2 = by2[j], ar = bar[j];
+        unsigned long long rest = live;
+        bool dead = false;
+        while (rest && !dead) {
+          const int s = __ffsll((long long)rest) - 1;
+          rest &= rest - 1;
+          const int i = c0 + s;
+          dead = iou_ge(bx1[i], by1[i], bx2[i], by2[i], bar[i], x1, y1, x2, y2, ar, thr);
+        }
+        if (dead) alive[j] = 0;
+      }
+    }
+    __syncthreads();
+  }
+
+  // survivors -> flags by original index (reuse the by1 array as int flags), ascending compaction
+  int *flag = reinterpret_cast<int *>(by1);
+  unsigned char keep_sorted_local[kNmsMaxLen / kNmsThreads];
+  for (int i = tid, m = 0; i < n; i += kNmsThreads, ++m) keep_sorted_local[m] = alive[i];
+  __syncthreads();
+  for (int i = tid; i < n; i += kNmsThreads) flag[i] = 0;
+  __syncthreads();
+  for (int i = tid, m = 0; i < n; i += kNmsThreads, ++m)
+    if (keep_sorted_local[m]) flag[(unsigned)(keys[i] & 0xffffffffu)] = 1;
+  __syncthreads();
+  // each thread owns a contiguous run of original indices so the scan preserves ascending order
+  const int per = (n + kNmsThreads - 1) / kNmsThreads;
+  const int lo = tid * per, hi = min(n, lo + per);
+  int cnt = 0;
+  for (int i = lo; i < hi; ++i) cnt += flag[i];
+  int total;
+  int pos = block_exclusive_scan(cnt, wave_sums, total);
+  long long *out = keep + seg_begin;
+  for (int i = lo; i < hi; ++i)
+    if (flag[i]) out[pos++] = i;
+  if (tid == 0) num_keep[seg] = total;
+}
+
+// ----------------------------------------------------------------------------------------------
+// soft-NMS: one workgroup, boxes in LDS, the reference's selection-sort loop with every inner
+// sweep done in parallel.  The reference removes a box whose decayed score drops below min_score
+// by overwriting it with the LAST box and re-examining that slot; the resulting arrangement is
+// reproduced exactly: survivors in front of the new end stay, holes there are filled (left to
+// right) by the surviving boxes behind the new end (taken right to left).
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kNmsThreads) void soft_nms_kernel(const float *__restrict__ dets, int n, float iou_thr,
+                                                               int method, float sigma, float min_score,
+                                                               float *__restrict__ out_dets,
+                                                               long long *__restrict__ out_inds,
+                                                               long long *__restrict__ num_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int wave_sums[kNmsThreads / 64];
+  __shared__ unsigned long long wave_best[kNmsThreads / 64];
+  float *bx1 = reinterpret_cast<float *>(smem);
+  float *by1 = bx1 + n, *bx2 = by1 + n, *by2 = bx2 + n, *bsc = by2 + n;
+  int *bid = reinterpret_cast<int *>(bsc + n);
+  int *hole = bid + n;   // scratch: positions of removed boxes in front of the new end
+  int *mover = hole + n; // scratch: positions of surviving boxes behind the new end
+  int *flag = mover + n; // scratch: survive flags
+  __shared__ int n_front_surv;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < n; i += kNmsThreads) {
+    bx1[i] = dets[5 * i]; by1[i] = dets[5 * i + 1]; bx2[i] = dets[5 * i + 2]; by2[i] = dets[5 * i + 3];
+    bsc[i] = dets[5 * i + 4];
+    bid[i] = i;
+  }
+  __syncthreads();
+
+  int N = n;
+  for (int i = 0; i < N; ++i) {
+    // first maximum of scores in [i, N): key = (score order-preserving bits, inverted position)
+    unsigned long long best = 0;
+    for (int j = i + tid; j < N; j += kNmsThreads) {
+      unsigned u = __float_as_uint(bsc[j]);
+      u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+      const unsigned long long k = ((unsigned long long)u << 32) | (unsigned)(0x7fffffff - j);
+      best = k > best ? k : best;
+    }
+#pragma unroll
+    for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+      const unsigned long long o = __shfl_xor(best, dlt);
+      best = o > best ? o : best;
+    }
+    if (lane == 0) wave_best[wave] = best;
+    __syncthreads();
+    best = wave_best[0];
+#pragma unroll
+    for (int w = 1; w < kNmsThreads / 64; ++w) best = wave_best[w] > best ? wave_best[w] : best;
+    const int maxpos = 0x7fffffff - (int)(best & 0xffffffffu);
+    __syncthreads();
+    if (tid == 0 && maxpos != i) {  // swap rows i and maxpos (pyx:53-67)
+      float t;
+      t = bx1[i]; bx1[i] = bx1[maxpos]; bx1[maxpos] = t;
+      t = by1[i]; by1[i] = by1[maxpos]; by1[maxpos] = t;
+      t = bx2[i]; bx2[i] = bx2[maxpos]; bx2[maxpos] = t;
+      t = by2[i]; by2[i] = by2[maxpos]; by2[maxpos] = t;
+      t = bsc[i]; bsc[i] = bsc[maxpos]; bsc[maxpos] = t;
+      const int ti = bid[i]; bid[i] = bid[maxpos]; bid[maxpos] = ti;
+    }
+    __syncthreads();
+    const float tx1 = bx1[i], ty1 = by1[i], tx2 = bx2[i], ty2 = by2[i];
+
+    // decay every box behind i (pyx:80-112); arithmetic promotions as cython emits them
+    for (int pos = i + 1 + tid; pos < N; pos += kNmsThreads) {
+      const float x1 = bx1[pos], y1 = by1[pos], x2 = bx2[pos], y2 = by2[pos];
+      const float area = (float)(((double)(x2 - x1) + 1.0) * ((double)(y2 - y1) + 1.0));
+      const float iw = (float)((double)(fminf(tx2, x2) - fmaxf(tx1, x1)) + 1.0);
+      if (iw > 0.0f) {
+        const float ih = (float)((double)(fminf(ty2, y2) - fmaxf(ty1, y1)) + 1.0);
+        if (ih > 0.0f) {
+          const float ua = (float)(((((double)(tx2 - tx1) + 1.0) * ((double)(ty2 - ty1) + 1.0)) + (double)area) -
+                                   (double)(iw * ih));
+          const float ov = (iw * ih) / ua;
+          float weight;
+          if (method == 1) weight = ov > iou_thr ? (float)(1.0 - (double)ov) : 1.0f;
+          else if (method == 2) weight = (float)exp((double)((-(ov * ov)) / sigma));
+          else weight = ov > iou_thr ? 0.0f : 1.0f;
+          bsc[pos] = weight * bsc[pos];
+        }
+      }
+    }
+    __syncthreads();
+
+    // removal (pyx:113-123).  A box is tested against min_score only inside the iw>0 && ih>0 branch,
+    // so only "touched" boxes can be dropped in this round.
+    const int M = N - (i + 1);
+    const int per = (M + kNmsThreads - 1) / kNmsThreads;
+    const int lo = min(N, i + 1 + tid * per), hi = min(N, lo + per);
+    int surv = 0;
+    for (int pos = lo; pos < hi; ++pos) {
+      const float x1 = bx1[pos], y1 = by1[pos], x2 = bx2[pos], y2 = by2[pos];
+      const float iw = (float)((double)(fminf(tx2, x2) - fmaxf(tx1, x1)) + 1.0);
+      bool touched = false;
+      if (iw > 0.0f) {
+        const float ih = (float)((double)(fminf(ty2, y2) - fmaxf(ty1, y1)) + 1.0);
+        touched = ih > 0.0f;
+      }
+      const int sv = !(touched && bsc[pos] < min_score);
+      flag[pos] = sv;
+      surv += sv;
+    }
+    int S;
+    const int before = block_exclusive_scan(surv, wave_sums, S);  // survivors in front of this thread's run
+    const int newN = i + 1 + S;
+    if (tid == 0) n_front_surv = S;  // value when newN == N (nothing removed)
+    __syncthreads();
+    {
+      int sb = before;
+      for (int pos = lo; pos < hi; ++pos) {
+        const int sv = flag[pos];
+        if (pos == newN) n_front_surv = sb;                          // survivors inside [i+1, newN)
+        if (!sv && pos < newN) hole[(pos - (i + 1)) - sb] = pos;     // k-th hole, left to right
+        if (sv && pos >= newN) mover[S - sb - 1] = pos;              // k-th surviving box from the right
+        sb += sv;
+      }
+    }
+    __syncthreads();
+    const int H = S - n_front_surv;  // holes in front of the new end == survivors behind it
+    for (int k = tid; k < H; k += kNmsThreads) {
+      const int dst = hole[k], src = mover[k];
+      bx1[dst] = bx1[src]; by1[dst] = by1[src]; bx2[dst] = bx2[src]; by2[dst] = by2[src];
+      bsc[dst] = bsc[src]; bid[dst] = bid[src];
+    }
+    __syncthreads();
+    N = newN;
+  }
+  for (int i = tid; i < N; i += kNmsThreads) {
+    out_dets[5 * i] = bx1[i]; out_dets[5 * i + 1] = by1[i]; out_dets[5 * i + 2] = bx2[i];
+    out_dets[5 * i + 3] = by2[i]; out_dets[5 * i + 4] = bsc[i];
+    out_inds[i] = bid[i];
+  }
+  if (tid == 0) *num_out = N;
+}
+
+}  // namespace kgdet
+
+using namespace kgdet;
+
+extern "C" {
+
+size_t kgdet_nms_workspace_bytes(int64_t total_n, int32_t num_segments) {
+  (void)total_n; (void)num_segments;
+  return 16;  // everything lives in LDS; kept for ABI stability
+}
+
+static int nms_launch(const float *dets, const int64_t *seg_offsets, int32_t num_segments, int64_t max_seg_len,
+                      float iou_thr, int64_t *keep, int64_t *num_keep, void *stream) {
+  KGDET_CHECK_SHAPE(num_segments >= 0 && max_seg_len >= 0, "negative size");
+  if (num_segments == 0) return KGDET_OK;
+  KGDET_CHECK_SHAPE(dets && seg_offsets && keep && num_keep, "null pointer");
+  if (max_seg_len > kNmsMaxLen) {
+    set_error("nms: segment of %lld boxes exceeds the on-chip limit of %d", (long long)max_seg_len, kNmsMaxLen);
+    return KGDET_E_UNSUPPORTED;
+  }
+  int np = 64;
+  while (np < max_seg_len) np <<= 1;
+  const size_t lds = (size_t)np * 8 + (size_t)np * 5 * 4 + (size_t)np;
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)nms_segments, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024 - 256));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)soft_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024 - 256));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(nms_segments, dim3(num_segments), dim3(kNmsThreads), lds, (hipStream_t)stream, dets,
+                     (const long long *)seg_offsets, iou_thr, (long long *)keep, (long long *)num_keep, np);
+  KGDET_CHECK_LAUNCH("nms_segments");
+  return KGDET_OK;
+}
+
+int kgdet_nms_batched(const float *dets, const int64_t *seg_offsets, int32_t num_segments, int64_t total_n,
+                      int64_t max_seg_len, float iou_thr, int64_t *keep, int64_t *num_keep, void *workspace,
+                      size_t workspace_bytes, void *stream) {
+  (void)total_n; (void)workspace; (void)workspace_bytes;
+  return nms_launch(dets, seg_offsets, num_segments, max_seg_len, iou_thr, keep, num_keep, stream);
+}
+
+int kgdet_nms(const float *dets, int64_t n, float iou_thr, int64_t *keep, int64_t *num_keep, void *workspace,
+              size_t workspace_bytes, void *stream) {
+  KGDET_CHECK_SHAPE(n >= 0, "negative size");
+  KGDET_CHECK_SHAPE(workspace && workspace_bytes >= 16, "nms workspace must hold 2 x int64");
+  // segment table {0, n} built on the device side of the stream
+  const int64_t host_offsets[2] = {0, n};
+  KGDET_HIP_TRY(hipMemcpyAsync(workspace, host_offsets, sizeof(host_offsets), hipMemcpyHostToDevice,
+                               (hipStream_t)stream));
+  if (n == 0) {
+    KGDET_HIP_TRY(hipMemsetAsync(num_keep, 0, sizeof(int64_t), (hipStream_t)stream));
+    return KGDET_OK;
+  }
+  return nms_launch(dets, (const int64_t *)workspace, 1, n, iou_thr, keep, num_keep, stream);
+}
+
+int kgdet_soft_nms(const float *dets, int64_t n, float iou_thr, int32_t method, float sigma, float min_score,
+                   float *out_dets, int64_t *out_inds, int64_t *num_out, void *stream) {
+  KGDET_CHECK_SHAPE(n >= 0, "negative size");
+  KGDET_CHECK_SHAPE(num_out, "null pointer");
+  if (n == 0) {
+    KGDET_HIP_TRY(hipMemsetAsync(num_out, 0, sizeof(int64_t), (hipStream_t)stream));
+    return KGDET_OK;
+  }
+  KGDET_CHECK_SHAPE(dets && out_dets && out_inds, "null pointer");
+  const size_t lds = (size_t)n * 9 * 4;
+  if (lds > 160 * 1024 - 256) {
+    set_error("soft_nms: %lld boxes exceed the on-chip limit", (long long)n);
+    return KGDET_E_UNSUPPORTED;
+  }
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)soft_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024 - 256));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(soft_nms_kernel, dim3(1), dim3(kNmsThreads), lds, (hipStream_t)stream, dets, (int)n, iou_thr,
+                     (int)method, sigma, min_score, out_dets, (long long *)out_inds, (long long *)num_out);
+  KGDET_CHECK_LAUNCH("soft_nms_kernel");
+  return KGDET_OK;
+}
+
+}  // extern "C"

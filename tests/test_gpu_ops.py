@@ -1,0 +1,209 @@
+"""GPU parity for the small hot-path ops (through the C ABI) against the CPU oracle and the
+golden vectors produced by the compiled reference.
+
+Bars: NMS / soft-NMS index selection bit-exact (and soft-NMS scores bit-exact); focal loss,
+moment bbox and PS-RoI pooling within 1e-5 of their output scale (different libm / summation).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(actual, desired, tol=1e-5):
+    desired = np.asarray(desired, np.float64)
+    scale = max(float(np.abs(desired).max()), 1e-6)
+    err = float(np.abs(np.asarray(actual, np.float64) - desired).max()) / scale
+    assert err < tol, 'max error %.3e of output scale (tol %.1e)' % (err, tol)
+
+
+@pytest.fixture(scope='module')
+def G(golden_dir):
+    return np.load(os.path.join(golden_dir, 'nms_golden.npz'))
+
+
+def _cases(prefix, G):
+    i = 0
+    while '%s%d_dets' % (prefix, i) in G:
+        yield i
+        i += 1
+
+
+# ---------------------------------------------------------------------------------------------
+def test_nms_reference_golden_bit_exact(G):
+    from kgdet_amd.nms import nms
+    for i in list(_cases('nms', G)) + ['tie']:
+        d = G['nms%s_dets' % i]
+        thr = float(G['nms%s_thr' % i])
+        dets, inds = nms(torch.from_numpy(d).cuda(), thr)
+        np.testing.assert_array_equal(inds.cpu().numpy(), G['nms%s_keep' % i])
+        np.testing.assert_array_equal(dets.cpu().numpy(), d[G['nms%s_keep' % i]])
+
+
+def test_nms_numpy_and_cpu_tensor_inputs_run_on_gpu(G):
+    from kgdet_amd.nms import nms
+    d = G['nms6_dets']
+    dets, inds = nms(d, 0.5)                       # numpy in -> numpy out
+    assert isinstance(inds, np.ndarray) and inds.dtype == np.int64
+    np.testing.assert_array_equal(inds, G['nms6_keep'])
+    dets_t, inds_t = nms(torch.from_numpy(d), 0.5)  # CPU tensor in -> CPU tensor out
+    assert not inds_t.is_cuda
+    np.testing.assert_array_equal(inds_t.numpy(), G['nms6_keep'])
+    e, ei = nms(torch.zeros(0, 5).cuda(), 0.5)
+    assert ei.numel() == 0 and ei.dtype == torch.long
+    with pytest.raises(TypeError):
+        nms([[0, 0, 1, 1, 1]], 0.5)
+
+
+def test_nms_batched_matches_oracle():
+    from kgdet_amd.nms import nms_batched
+    rng = np.random.default_rng(3)
+    segs, offs = [], [0]
+    for n in (0, 1, 37, 300, 64, 1000, 129, 0, 513):
+        x1 = rng.uniform(0, 800, n); y1 = rng.uniform(0, 600, n)
+        d = np.stack([x1, y1, x1 + rng.uniform(1, 300, n), y1 + rng.uniform(1, 300, n),
+                      rng.permutation(n) / max(n, 1) + 0.01], 1).astype(np.float32).reshape(-1, 5)
+        segs.append(d)
+        offs.append(offs[-1] + n)
+    dets = torch.from_numpy(np.concatenate(segs)).cuda()
+    offsets = torch.tensor(offs, dtype=torch.int64).cuda()
+    keep, num = nms_batched(dets, offsets, 0.5)
+    keep, num = keep.cpu().numpy(), num.cpu().numpy()
+    for i, d in enumerate(segs):
+        ref = oracle.nms(d, 0.5)
+        assert num[i] == len(ref)
+        np.testing.assert_array_equal(keep[offs[i]:offs[i] + num[i]], ref)
+
+
+def test_nms_fullsize_properties():
+    """At nms_pre size: idempotence and pairwise-IoU property of the survivors."""
+    from kgdet_amd.nms import nms
+    rng = np.random.default_rng(11)
+    n = 4000
+    x1 = rng.uniform(0, 1300, n); y1 = rng.uniform(0, 780, n)
+    d = np.stack([x1, y1, x1 + rng.uniform(5, 200, n), y1 + rng.uniform(5, 200, n), rng.permutation(n) / n],
+                 1).astype(np.float32)
+    kept, inds = nms(torch.from_numpy(d).cuda(), 0.5)
+    inds = inds.cpu().numpy()
+    assert np.all(np.diff(inds) > 0)                      # ascending index order
+    np.testing.assert_array_equal(inds, oracle.nms(d, 0.5))
+    kept2, inds2 = nms(kept, 0.5)
+    assert inds2.numel() == kept.shape[0]                 # idempotent
+
+
+def test_soft_nms_reference_golden_bit_exact(G):
+    from kgdet_amd.nms import soft_nms
+    names = {1: 'linear', 2: 'gaussian'}
+    for i in _cases('soft', G):
+        thr, method, sigma, min_score = G['soft%d_cfg' % i]
+        d = G['soft%d_dets' % i]
+        nd, ni = soft_nms(torch.from_numpy(d).cuda(), float(thr), names[int(method)], float(sigma),
+                          float(min_score))
+        np.testing.assert_array_equal(ni.cpu().numpy(), G['soft%d_inds' % i])
+        np.testing.assert_array_equal(nd.cpu().numpy(), G['soft%d_new' % i])
+    nd, ni = soft_nms(G['soft4_dets'], 0.5, 'linear', 0.5, 0.05)   # numpy in -> numpy out
+    np.testing.assert_array_equal(ni, G['soft4_inds'])
+    with pytest.raises(ValueError):
+        soft_nms(torch.zeros(1, 5).cuda(), 0.5, method='nope')
+
+
+# ---------------------------------------------------------------------------------------------
+def test_focal_loss_forward_backward():
+    from kgdet_amd.focal_loss import sigmoid_focal_loss, SigmoidFocalLoss
+    rng = np.random.default_rng(0)
+    n, c = 2100, 13
+    logits = (rng.normal(size=(n, c)) * 3).astype(np.float32)
+    logits[0, :3] = [-100, 100, 0]
+    target = rng.integers(0, c + 1, n)
+    target[:200] = 0
+    dl = rng.normal(size=(n, c)).astype(np.float32)
+    x = torch.from_numpy(logits).cuda().requires_grad_()
+    t = torch.from_numpy(target).cuda()
+    loss = sigmoid_focal_loss(x, t, 2.0, 0.25)
+    loss.backward(torch.from_numpy(dl).cuda())
+    _close(loss.detach().cpu().numpy(), oracle.sigmoid_focal_loss_forward(logits, target, 2.0, 0.25))
+    _close(x.grad.cpu().numpy(), oracle.sigmoid_focal_loss_backward(logits, target, dl, 2.0, 0.25))
+    m = SigmoidFocalLoss(2.0, 0.25)
+    assert abs(float(m(x.detach(), t)) - float(loss.sum())) < 1e-2
+    with pytest.raises(NotImplementedError):
+        sigmoid_focal_loss(torch.zeros(2, 3), torch.zeros(2, dtype=torch.long), 2.0, 0.25)
+
+
+def _moment_ref(pts, mt, y_first=True):
+    """autograd restatement of KP3:373-388 in float64"""
+    B, C2, H, W = pts.shape
+    r = pts.view(B, -1, 2, H, W)
+    py = r[:, :, 0] if y_first else r[:, :, 1]
+    px = r[:, :, 1] if y_first else r[:, :, 0]
+    my, mx = py.mean(1, keepdim=True), px.mean(1, keepdim=True)
+    sy, sx = torch.std(py - my, dim=1, keepdim=True), torch.std(px - mx, dim=1, keepdim=True)
+    hw, hh = sx * torch.exp(mt[0]), sy * torch.exp(mt[1])
+    return torch.cat([mx - hw, my - hh, mx + hw, my + hh], 1)
+
+
+@pytest.mark.parametrize('n_pts,y_first', [(83, True), (9, True), (25, False)])
+def test_moment_bbox(n_pts, y_first):
+    from kgdet_amd.moment import moment_bbox
+    torch.manual_seed(0)
+    pts = torch.randn(2, 2 * n_pts, 25, 42, dtype=torch.float64) * 3
+    mt = torch.tensor([0.3, -0.2], dtype=torch.float64)
+    g = torch.randn(2, 4, 25, 42, dtype=torch.float64)
+    p64, m64 = pts.clone().requires_grad_(), mt.clone().requires_grad_()
+    ref = _moment_ref(p64, m64, y_first)
+    ref.backward(g)
+    p = pts.float().cuda().requires_grad_()
+    m = mt.float().cuda().requires_grad_()
+    out = moment_bbox(p, m, y_first)
+    out.backward(g.float().cuda())
+    _close(out.detach().cpu().numpy(), ref.detach().numpy())
+    _close(p.grad.cpu().numpy(), p64.grad.numpy())
+    _close(m.grad.cpu().numpy(), m64.grad.numpy(), 1e-4)
+
+
+def test_moment_bbox_known_answer():
+    """points on a regular grid: mean / unbiased std computable by hand."""
+    from kgdet_amd.moment import moment_bbox
+    ys = torch.tensor([0., 1., 2., 3.])    # mean 1.5, unbiased var = 5/3
+    xs = torch.tensor([10., 10., 14., 14.])  # mean 12, unbiased var = 16/3
+    pts = torch.stack([ys, xs], 1).reshape(1, 8, 1, 1).cuda()
+    out = moment_bbox(pts, torch.zeros(2).cuda(), True).flatten().cpu().numpy()
+    sy, sx = np.sqrt(5 / 3), np.sqrt(16 / 3)
+    np.testing.assert_allclose(out, [12 - sx, 1.5 - sy, 12 + sx, 1.5 + sy], rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('no_trans,group_size,part', [(True, 1, None), (False, 1, None), (False, 7, 7),
+                                                       (False, 1, 4)])
+def test_deform_psroi_pooling(no_trans, group_size, part):
+    from kgdet_amd.deform_pool import deform_roi_pooling
+    rng = np.random.default_rng(1)
+    B, H, W, P, out_c = 2, 24, 30, 7, 8
+    C = out_c * group_size * group_size
+    data = rng.normal(size=(B, C, H, W)).astype(np.float32)
+    R = 12
+    x1 = rng.uniform(-20, 400, R); y1 = rng.uniform(-20, 300, R)
+    rois = np.stack([rng.integers(0, B, R), x1, y1, x1 + rng.uniform(1, 200, R), y1 + rng.uniform(1, 200, R)],
+                    1).astype(np.float32)
+    rois[0, 1:] = [5, 5, 5, 5]           # degenerate roi -> min size 0.1
+    part_size = P if part is None else part
+    ncls = 2
+    offset = (rng.normal(size=(R, 2 * ncls, part_size, part_size)) * 0.5).astype(np.float32)
+    go = rng.normal(size=(R, out_c, P, P)).astype(np.float32)
+    td = torch.from_numpy(data).cuda().requires_grad_()
+    to = torch.from_numpy(offset).cuda().requires_grad_()
+    out = deform_roi_pooling(td, torch.from_numpy(rois).cuda(), to if not no_trans else to.new_empty(0), 1 / 16., P,
+                             out_c, no_trans, group_size, part_size, 4, 0.1)
+    out.backward(torch.from_numpy(go).cuda())
+    ro, rc = oracle.deform_psroi_forward(data, rois, offset, np.float32(1 / 16.), P, out_c, no_trans, group_size,
+                                         part_size, 4, np.float32(0.1))
+    _close(out.detach().cpu().numpy(), ro)
+    gd, gt = oracle.deform_psroi_backward(go, rc, data, rois, offset, np.float32(1 / 16.), P, out_c, no_trans,
+                                          group_size, part_size, 4, np.float32(0.1))
+    _close(td.grad.cpu().numpy(), gd)
+    if not no_trans:
+        _close(to.grad.cpu().numpy(), gt)
