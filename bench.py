@@ -1,0 +1,190 @@
+"""KGDet R50-FPN benchmark on MI355X (contract: see the task statement / DESIGN.md).
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+A step = one data-parallel training iteration of the KGDet detector (configs/kgdet_moment_r50_fpn_1x)
+on a seeded synthetic DeepFashion2-shaped batch of 2 images per GPU at 800x1333 (padded 800x1344):
+forward, the nine losses, backward, gradient all-reduce over RCCL (overlapped with backward),
+grad-clip, Adam step.  Prints ONE JSON line on rank 0.  `value` = images/s over all ranks.
+
+Extra objects on the same line:
+  roofline     -- the dominant hand-written kernel (DeformConv forward, 7x7, B=2: 13.49 GFLOP,
+                  17.97 MB algorithmic) timed live with HIP events on the stream it runs on;
+  cpu_baseline -- the oracle's reference-algorithm deformable conv (materialised im2col + GEMM) on the
+                  host cores, rank 0, N=1 only, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--imgs-per-gpu', type=int, default=2)
+    ap.add_argument('--mode', choices=['train', 'infer'], default='train')
+    ap.add_argument('--dtype', choices=['fp32', 'bf16'], default='fp32',
+                    help='precision of the dense backbone/FPN/tower convolutions (autocast); the deformable '
+                         'path always computes in fp32')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    return ap.parse_args()
+
+
+def dcn_roofline(device, iters=30):
+    """DeformConv forward, k=7, B=2, C=256, 25x42: HIP-event timing on the launch stream."""
+    from kgdet_amd import dcn
+    g = torch.Generator(device='cpu').manual_seed(0)
+    B, C, H, W, k = 2, 256, 25, 42, 7
+    K = k * k
+    x = torch.randn(B, C, H, W, generator=g).to(device)
+    off = (torch.randn(B, 2 * K, H, W, generator=g) * 2).to(device)
+    w = (torch.randn(C, C, k, k, generator=g) * 0.01).to(device)
+    shape = dcn._shape(x, w, (1, 1), (k // 2, k // 2), (1, 1), 1, 1)
+    packed = dcn.pack_weight(w, shape)
+    stream = torch.cuda.current_stream()
+    for _ in range(5):
+        dcn._forward(x, off, None, w, None, shape, packed=packed)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(iters):
+        dcn._forward(x, off, None, w, None, shape, packed=packed)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / iters * 1e-3
+    flops = 2.0 * C * C * K * B * H * W
+    byts = 4.0 * (2 * B * C * H * W + 2 * B * K * H * W + C * C * K)
+    ach = flops / t / 1e12
+    return dict(bound='mfma', kernel='dcn_fwd_mfma+dcn_fwd_fixup (7x7, B=2, 256ch, 25x42)', achieved=round(ach, 2),
+                peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                traffic=None, launch_us=round(t * 1e6, 1),
+                hbm_achieved_GBs=round(byts / t / 1e9, 1), hbm_frac=round(byts / t / 1e9 / HBM_PEAK_GBS, 4))
+
+
+def cpu_baseline():
+    """Reference algorithm (im2col + GEMM) for ONE 7x7 DeformConv forward at B=2 on the host cores."""
+    import numpy as np
+    import oracle
+    rng = np.random.default_rng(0)
+    B, C, H, W, k = 2, 256, 25, 42, 7
+    x = rng.normal(size=(B, C, H, W)).astype(np.float32)
+    off = (rng.normal(size=(B, 2 * k * k, H, W)) * 2).astype(np.float32)
+    w = (rng.normal(size=(C, C, k, k)) * 0.01).astype(np.float32)
+    oracle.deform_conv_forward(x, off, w, 1, 3, 1)
+    n, t0 = 0, time.time()
+    while time.time() - t0 < 12.0 or n < 3:
+        oracle.deform_conv_forward(x, off, w, 1, 3, 1)
+        n += 1
+    t = (time.time() - t0) / n
+    # one training step runs 12 such convs fwd (4 of each size) + backward; express as images/s of the
+    # DeformConv forward work alone: B images per (12-call) head forward, scaled by tap count
+    taps = 4 * (9 + 25 + 49)
+    head_fwd_s = t * taps / 49.0
+    return dict(value=round(B / head_fwd_s, 3), unit='img/s (DeformConv forward of the head only)',
+                cores=os.cpu_count(), kind='port',
+                sample='oracle im2col+GEMM, one 7x7 DeformConv fwd at B=2 timed %d times (%.3f s each), '
+                       'scaled to the 12 DeformConv calls of one head forward' % (n, t))
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU: the HIP path is the product, there is no fallback'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl')
+
+    import kgdet_amd
+    from kgdet_amd import configs, synthetic
+    from kgdet_amd.dist import DistOptimizerHook
+    from kgdet_amd.registry import build_detector
+
+    cfg = configs.kgdet_r50_fpn()
+    torch.manual_seed(0)
+    model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).to(device)
+    if world > 1:  # same initial weights everywhere (the reference broadcasts once at start-up)
+        for p in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(p.data, 0)
+    batch = synthetic.make_batch(args.imgs_per_gpu, device, seed=rank)
+    autocast = torch.autocast('cuda', dtype=torch.bfloat16, enabled=args.dtype == 'bf16')
+
+    if args.mode == 'train':
+        model.train()
+        optimizer = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=cfg.optimizer.lr)
+        hook = DistOptimizerHook(grad_clip=dict(cfg.optimizer_config.grad_clip), overlap=True, bucket_size_mb=32)
+
+        def step():
+            with autocast:
+                losses = model(batch['img'], batch['img_meta'], return_loss=True, gt_bboxes=batch['gt_bboxes'],
+                               gt_labels=batch['gt_labels'], gt_keypoints=batch['gt_keypoints'])
+            loss = sum(v.float() if torch.is_tensor(v) else sum(x.float() for x in v) for k, v in losses.items()
+                       if 'loss' in k)
+            hook.step(model, optimizer, loss)
+            return loss
+    else:
+        model.eval()
+
+        def step():
+            with torch.no_grad(), autocast:
+                return model.simple_test_batch(batch['img'], batch['img_meta'], rescale=True)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        imgs = args.imgs_per_gpu * world * args.steps
+        out = {
+            'metric': 'training images/sec (whole node) KGDet R50-FPN 800x1333' if args.mode == 'train'
+            else 'inference images/sec KGDet R50-FPN 800x1333',
+            'value': round(imgs / dt, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.dtype == 'fp32' else 'bf16(dense convs)+f32(deformable path)',
+            'data': 'synthetic',
+            'config': {'workload': 'KGDet R50-FPN %s step, %d img/GPU at 800x1333 (padded 800x1344), '
+                                   'DeformConv fwd/bwd + focal/moment losses + RCCL grad all-reduce'
+                                   % (args.mode, args.imgs_per_gpu),
+                       'global_batch': args.imgs_per_gpu * world, 'parallelism': 'dp%d' % world},
+        }
+        if not args.no_roofline:
+            out['roofline'] = dcn_roofline(device)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

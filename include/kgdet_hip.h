@@ -43,6 +43,12 @@ typedef struct kgdet_dcn_shape {
   int32_t O, kh, kw;
   int32_t stride_h, stride_w, pad_h, pad_w, dil_h, dil_w;
   int32_t groups, deformable_groups;
+  /* Optional: the output (forward) / grad_output (backward) tensor is channels
+   * [out_channel_offset, out_channel_offset + O) of a wider [N, out_channels_total, Ho, Wo] buffer, so
+   * several convolutions can write straight into one concatenated feature map (KGDet concatenates
+   * the 3x3 / 5x5 / 7x7 branches, R/../anchor_heads/reppoints_head_kp3rep_cas_1_assign_once.py:151-153).
+   * Zero for both means a dense [N, O, Ho, Wo] tensor. */
+  int32_t out_channel_offset, out_channels_total;
 } kgdet_dcn_shape;
 
 /* flags for the fused epilogue */

@@ -23,7 +23,7 @@ DCN_RELU = 1
 class DcnShape(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         'N', 'C', 'H', 'W', 'O', 'kh', 'kw', 'stride_h', 'stride_w', 'pad_h', 'pad_w', 'dil_h',
-        'dil_w', 'groups', 'deformable_groups')]
+        'dil_w', 'groups', 'deformable_groups', 'out_channel_offset', 'out_channels_total')]
 
 
 class PsroiShape(ctypes.Structure):

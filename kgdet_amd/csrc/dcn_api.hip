@@ -28,6 +28,11 @@ int derive(const kgdet_dcn_shape *s, Derived &d) {
                     "channels must divide groups (C=%d O=%d groups=%d)", s->C, s->O, s->groups);
   KGDET_CHECK_SHAPE(s->deformable_groups > 0 && s->C % s->deformable_groups == 0,
                     "input channels must divide deformable group size");
+  KGDET_CHECK_SHAPE(s->out_channel_offset >= 0 &&
+                        (s->out_channels_total == 0 ? s->out_channel_offset == 0
+                                                    : s->out_channel_offset + s->O <= s->out_channels_total),
+                    "output channel window [%d, %d) does not fit %d channels", s->out_channel_offset,
+                    s->out_channel_offset + s->O, s->out_channels_total);
   d.Ho = (s->H + 2 * s->pad_h - (s->dil_h * (s->kh - 1) + 1)) / s->stride_h + 1;
   d.Wo = (s->W + 2 * s->pad_w - (s->dil_w * (s->kw - 1) + 1)) / s->stride_w + 1;
   KGDET_CHECK_SHAPE(d.Ho >= 1 && d.Wo >= 1,
@@ -41,7 +46,7 @@ int derive(const kgdet_dcn_shape *s, Derived &d) {
   d.Og_pad16 = (int)align_up(d.Og, kChunk);
   d.Cg_pad256 = (int)align_up(d.Cg, kTileM);
   const long long in_bytes = 4LL * s->N * s->C * s->H * s->W;
-  const long long out_bytes = 4LL * s->N * s->O * d.Ho * d.Wo;
+  const long long out_bytes = 4LL * s->N * (s->out_channels_total > 0 ? s->out_channels_total : s->O) * d.Ho * d.Wo;
   const long long off_bytes = 4LL * s->N * s->deformable_groups * 2 * d.K * d.Ho * d.Wo;
   KGDET_CHECK_SHAPE(in_bytes < (1LL << 31) && out_bytes < (1LL << 31) && off_bytes < (1LL << 31),
                     "tensor larger than 2 GiB is not supported");
@@ -97,7 +102,9 @@ bool mfma_bwd_ok(const kgdet_dcn_shape *s) {
 void fill_problem(const kgdet_dcn_shape *s, const Derived &d, int group, DcnProblem &p) {
   p = DcnProblem{};
   p.N = s->N; p.C_total = s->C; p.c_base = group * d.Cg; p.Cg = d.Cg; p.Cg_pad = d.Cg_pad;
-  p.O_total = s->O; p.o_base = group * d.Og; p.Og = d.Og; p.Og_pad = d.Og_pad;
+  p.O_total = s->out_channels_total > 0 ? s->out_channels_total : s->O;
+  p.o_base = s->out_channel_offset + group * d.Og; p.Og = d.Og; p.Og_pad = d.Og_pad;
+  p.bias_base = group * d.Og;
   p.H = s->H; p.W = s->W; p.Ho = d.Ho; p.Wo = d.Wo; p.HoWo = d.Ho * d.Wo; p.P = s->N * p.HoWo;
   p.kh = s->kh; p.kw = s->kw; p.K = d.K;
   p.sh = s->stride_h; p.sw = s->stride_w; p.ph = s->pad_h; p.pw = s->pad_w; p.dh = s->dil_h; p.dw = s->dil_w;
@@ -334,8 +341,10 @@ int kgdet_deform_conv_backward_weight(const kgdet_dcn_shape *s, const float *inp
   KGDET_CHECK_LAUNCH("dcn_bwd_weight_mfma");
   if (int rc = kgdet_dcn_unpack_weight_grad(s, gpk, grad_weight, accumulate, stream)) return rc;
   if (grad_bias) {
-    hipLaunchKernelGGL(dcn_bias_grad, dim3(s->O), dim3(256), 0, (hipStream_t)stream, grad_output, grad_bias,
-                       s->N, s->O, d.Ho * d.Wo, accumulate);
+    const int O_total = s->out_channels_total > 0 ? s->out_channels_total : s->O;
+    hipLaunchKernelGGL(dcn_bias_grad, dim3(s->O), dim3(256), 0, (hipStream_t)stream,
+                       grad_output + (size_t)s->out_channel_offset * d.Ho * d.Wo, grad_bias, s->N, O_total,
+                       d.Ho * d.Wo, accumulate);
     KGDET_CHECK_LAUNCH("dcn_bias_grad");
   }
   return KGDET_OK;

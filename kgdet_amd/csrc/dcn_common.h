@@ -32,7 +32,8 @@ struct DcnProblem {
   const float *bias;    // [O_total] or nullptr
   float *out;           // forward: [N, O_total, Ho, Wo]
   int N, C_total, c_base, Cg, Cg_pad;
-  int O_total, o_base, Og, Og_pad;
+  int O_total, o_base, Og, Og_pad;  // o_base: first channel of this group inside the output buffer
+  int bias_base;                    // first channel of this group in the conv's own numbering
   int H, W, Ho, Wo, HoWo, P;  // P = N*Ho*Wo output pixels
   int kh, kw, K;
   int sh, sw, ph, pw, dh, dw;

@@ -56,7 +56,7 @@ __device__ __forceinline__ void store_output(const DcnProblem &p, int mt, int nt
         const int o = mt * kTileM + wm * 64 + mi * 32 + mfma_row(r, lane);
         if (o >= p.Og) continue;
         float v = acc[mi][ni][r];
-        if (p.bias) v += p.bias[p.o_base + o];
+        if (p.bias) v += p.bias[p.bias_base + o];
         if (p.flags & KGDET_DCN_RELU) v = fmaxf(v, 0.0f);
         obase[(long long)o * p.HoWo] = v;
       }

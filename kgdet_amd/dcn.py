@@ -334,3 +334,79 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
         return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride,
                                      self.padding, self.dilation, self.groups,
                                      self.deformable_groups)
+
+
+# ------------------------------------------------------------------------------------------------
+# Fused multi-kernel deformable convolution:  relu(cat([dconv_k(x, offset_k, W_k) for k], dim=1))
+# ------------------------------------------------------------------------------------------------
+class DeformConvCatFunction(Function):
+    """KGDet runs a 3x3, a 5x5 and a 7x7 deformable conv on the same feature map, applies ReLU to
+    each and concatenates them (reppoints_head_kp3rep_cas_1_assign_once.py:145-153).  Here every
+    conv writes its channel window of ONE output buffer with ReLU fused into the kernel epilogue
+    (C ABI fields out_channel_offset / out_channels_total), and backward reads the matching
+    windows of the incoming gradient in place: no cat, no separate ReLU kernels, no slice copies.
+    Stride 1, dilation 1, groups 1 (the head's configuration); args = offset_0, weight_0, pad_0, ...
+    """
+
+    @staticmethod
+    def forward(ctx, x, relu, *args):
+        if not x.is_cuda:
+            raise NotImplementedError
+        assert len(args) % 3 == 0
+        L = _lib.lib()
+        x = x.contiguous()
+        convs = [(args[i].contiguous(), args[i + 1], int(args[i + 2])) for i in range(0, len(args), 3)]
+        O_total = sum(w.shape[0] for _, w, _ in convs)
+        N, C, H, W = x.shape
+        out = x.new_empty(N, O_total, H, W)
+        shapes, packs = [], []
+        o_base = 0
+        for offset, weight, pad in convs:
+            s = _shape(x, weight, (1, 1), (pad, pad), (1, 1), 1, 1)
+            s.out_channel_offset, s.out_channels_total = o_base, O_total
+            _check_offset(offset, s, (N, weight.shape[0], H, W))
+            packed = pack_weight(weight.contiguous(), s)
+            ws = _workspace(x.device, L.kgdet_dcn_workspace_bytes(ctypes.byref(s)))
+            _lib.check(L.kgdet_deform_conv_forward(
+                ctypes.byref(s), _lib.ptr(x), _lib.ptr(offset), None, _lib.ptr(packed), None, _lib.ptr(out),
+                ctypes.c_uint32(_lib.DCN_RELU if relu else 0), _lib.ptr(ws), ctypes.c_size_t(ws.numel()),
+                _lib.current_stream()), 'kgdet_deform_conv_forward')
+            shapes.append(s)
+            packs.append(packed)
+            o_base += weight.shape[0]
+        ctx.shapes = shapes
+        ctx.relu = relu
+        ctx.n = len(convs)
+        ctx.save_for_backward(x, out, *[t for offset, weight, _ in convs for t in (offset, weight)], *packs)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        saved = ctx.saved_tensors
+        x, out = saved[0], saved[1]
+        n = ctx.n
+        ow = saved[2:2 + 2 * n]
+        packs = saved[2 + 2 * n:]
+        if ctx.relu:
+            grad_out = grad_out * (out > 0).to(grad_out.dtype)
+        grad_out = grad_out.contiguous()
+        grads = [None] * (3 * n)
+        grad_x = None
+        for k in range(n):
+            offset, weight = ow[2 * k], ow[2 * k + 1]
+            needs = dict(input=ctx.needs_input_grad[0], offset=ctx.needs_input_grad[2 + 3 * k], mask=False,
+                         weight=ctx.needs_input_grad[3 + 3 * k], bias=False)
+            gi, go, _, gw, _ = _backward(x, offset, None, weight, None, grad_out, ctx.shapes[k], packs[k], needs)
+            if gi is not None and ctx.needs_input_grad[0]:
+                grad_x = gi if grad_x is None else grad_x.add_(gi)
+            grads[3 * k], grads[3 * k + 1] = go, gw
+        return (grad_x, None) + tuple(grads)
+
+
+def deform_conv_cat(x, offsets, weights, paddings, relu=True):
+    """relu(cat([deform_conv(x, o, w, 1, p) for o, w, p in ...], dim=1)) in one buffer."""
+    args = []
+    for o, w, p in zip(offsets, weights, paddings):
+        args += [o, w, p]
+    return DeformConvCatFunction.apply(x, relu, *args)

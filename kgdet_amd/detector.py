@@ -1,0 +1,103 @@
+"""``RepPointsDetectorKp``: backbone -> neck -> keypoint-guided head, result packing.
+
+Mirrors mmdet/models/detectors/reppoints_detector_kp.py:9-148 on top of
+single_stage.py:9-70 and base.py:12-142 (``forward(img, img_meta, return_loss=True, **kw)``
+dispatch, ``forward_train``, ``simple_test``, ``bbox2result_kp``).  The reference asserts one
+image per GPU at test time (base.py:75-76); ``simple_test_batch`` lifts that for the batch-8
+inference configuration, running decode + NMS for the whole batch at once.
+"""
+import numpy as np
+import torch.nn as nn
+
+from .registry import DETECTORS, build_backbone, build_head, build_neck
+
+
+@DETECTORS.register_module
+class RepPointsDetectorKp(nn.Module):
+
+    def __init__(self, backbone, neck, bbox_head, train_cfg=None, test_cfg=None, pretrained=None):
+        super().__init__()
+        self.backbone = build_backbone(backbone)
+        if neck is not None:
+            self.neck = build_neck(neck)
+        self.bbox_head = build_head(bbox_head)
+        self.train_cfg = train_cfg
+        self.test_cfg = test_cfg
+        self.init_weights(pretrained=pretrained)
+
+    @property
+    def with_neck(self):
+        return hasattr(self, 'neck') and self.neck is not None
+
+    @property
+    def with_keypoint(self):
+        return True
+
+    def init_weights(self, pretrained=None):
+        if isinstance(pretrained, str) and pretrained.startswith(('modelzoo://', 'open-mmlab://', 'http')):
+            # there is no network: remote checkpoints cannot be fetched, weights stay randomly initialised
+            pretrained = None
+        self.backbone.init_weights(pretrained=pretrained)
+        if self.with_neck:
+            if isinstance(self.neck, nn.Sequential):
+                for m in self.neck:
+                    m.init_weights()
+            else:
+                self.neck.init_weights()
+        self.bbox_head.init_weights()
+
+    def extract_feat(self, img):
+        x = self.backbone(img)
+        if self.with_neck:
+            x = self.neck(x)
+        return x
+
+    def forward_dummy(self, img):
+        return self.bbox_head(self.extract_feat(img), None)
+
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_keypoints, gt_bboxes_ignore=None):
+        x = self.extract_feat(img)
+        outs = self.bbox_head(x, img_metas)
+        loss_inputs = outs + (gt_bboxes, gt_labels, gt_keypoints, img_metas, self.train_cfg)
+        return self.bbox_head.loss(*loss_inputs, gt_bboxes_ignore=gt_bboxes_ignore)
+
+    def bbox2result_kp(self, bboxes, labels, kpts, num_classes):
+        """per-class numpy lists: (bboxes_in_cls, bbox_scores, kpt_in_cls), or a 1-tuple when empty"""
+        if bboxes.shape[0] == 0:
+            return ([np.zeros((0, 5), dtype=np.float32) for i in range(num_classes - 1)], )
+        bboxes = bboxes.cpu().numpy()
+        labels = labels.cpu().numpy()
+        kpts = kpts.cpu().numpy()
+        return ([bboxes[labels == i, :] for i in range(num_classes - 1)], bboxes[:, 4],
+                [kpts[labels == i, :] for i in range(num_classes - 1)])
+
+    def simple_test_batch(self, img, img_meta, rescale=False):
+        x = self.extract_feat(img)
+        outs = self.bbox_head(x, img_meta)
+        bbox_list = self.bbox_head.get_bboxes(*(outs + (img_meta, self.test_cfg, rescale)))
+        return [self.bbox2result_kp(det_bboxes, det_labels, det_kpts, self.bbox_head.num_classes)
+                for det_bboxes, det_labels, det_kpts in bbox_list]
+
+    def simple_test(self, img, img_meta, rescale=False):
+        return self.simple_test_batch(img, img_meta, rescale)[0]
+
+    def aug_test(self, imgs, img_metas, rescale=False):
+        raise NotImplementedError
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        for var, name in [(imgs, 'imgs'), (img_metas, 'img_metas')]:
+            if not isinstance(var, list):
+                raise TypeError('{} must be a list, but got {}'.format(name, type(var)))
+        num_augs = len(imgs)
+        if num_augs != len(img_metas):
+            raise ValueError('num of augmentations ({}) != num of image meta ({})'.format(len(imgs), len(img_metas)))
+        imgs_per_gpu = imgs[0].size(0)
+        assert imgs_per_gpu == 1
+        if num_augs == 1:
+            return self.simple_test(imgs[0], img_metas[0], **kwargs)
+        return self.aug_test(imgs, img_metas, **kwargs)
+
+    def forward(self, img, img_meta, return_loss=True, **kwargs):
+        if return_loss:
+            return self.forward_train(img, img_meta, **kwargs)
+        return self.forward_test(img, img_meta, **kwargs)

@@ -1,0 +1,149 @@
+"""Plain-PyTorch building blocks around the hot path: conv + norm + activation module, norm
+factory and the weight initialisers the reference takes from mmcv.
+
+Mirrors mmdet/models/utils/conv_module.py:44-164 (``ConvModule``; child names ``conv`` / ``gn`` /
+``bn`` are part of the checkpoint-key contract), mmdet/models/utils/norm.py:3-55 and
+mmdet/models/utils/weight_init.py / mmcv.cnn init helpers.  Dense convolutions stay on
+PyTorch-ROCm (MIOpen); nothing here is hand-written HIP.
+"""
+import warnings
+
+import numpy as np
+import torch.nn as nn
+
+_NORMS = {'BN': ('bn', nn.BatchNorm2d), 'SyncBN': ('bn', nn.SyncBatchNorm), 'GN': ('gn', nn.GroupNorm)}
+_CONVS = {'Conv': nn.Conv2d}
+
+
+def build_norm_layer(cfg, num_features, postfix=''):
+    assert isinstance(cfg, dict) and 'type' in cfg
+    cfg_ = dict(cfg)
+    layer_type = cfg_.pop('type')
+    if layer_type not in _NORMS:
+        raise KeyError('Unrecognized norm type {}'.format(layer_type))
+    abbr, norm_layer = _NORMS[layer_type]
+    assert isinstance(postfix, (int, str))
+    name = abbr + str(postfix)
+    requires_grad = cfg_.pop('requires_grad', True)
+    cfg_.setdefault('eps', 1e-5)
+    if layer_type != 'GN':
+        layer = norm_layer(num_features, **cfg_)
+    else:
+        assert 'num_groups' in cfg_
+        layer = norm_layer(num_channels=num_features, **cfg_)
+    for param in layer.parameters():
+        param.requires_grad = requires_grad
+    return name, layer
+
+
+def build_conv_layer(cfg, *args, **kwargs):
+    if cfg is None:
+        cfg_ = dict(type='Conv')
+    else:
+        assert isinstance(cfg, dict) and 'type' in cfg
+        cfg_ = dict(cfg)
+    layer_type = cfg_.pop('type')
+    if layer_type not in _CONVS:
+        raise KeyError('Unrecognized norm type {}'.format(layer_type))
+    return _CONVS[layer_type](*args, **kwargs, **cfg_)
+
+
+def constant_init(module, val, bias=0):
+    nn.init.constant_(module.weight, val)
+    if hasattr(module, 'bias') and module.bias is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def xavier_init(module, gain=1, bias=0, distribution='normal'):
+    assert distribution in ['uniform', 'normal']
+    if distribution == 'uniform':
+        nn.init.xavier_uniform_(module.weight, gain=gain)
+    else:
+        nn.init.xavier_normal_(module.weight, gain=gain)
+    if hasattr(module, 'bias') and module.bias is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def normal_init(module, mean=0, std=1, bias=0):
+    nn.init.normal_(module.weight, mean, std)
+    if hasattr(module, 'bias') and module.bias is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def kaiming_init(module, mode='fan_out', nonlinearity='relu', bias=0, distribution='normal'):
+    assert distribution in ['uniform', 'normal']
+    if distribution == 'uniform':
+        nn.init.kaiming_uniform_(module.weight, mode=mode, nonlinearity=nonlinearity)
+    else:
+        nn.init.kaiming_normal_(module.weight, mode=mode, nonlinearity=nonlinearity)
+    if hasattr(module, 'bias') and module.bias is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def bias_init_with_prob(prior_prob):
+    """initialise a conv/fc bias so that sigmoid(bias) == prior_prob"""
+    return float(-np.log((1 - prior_prob) / prior_prob))
+
+
+class ConvModule(nn.Module):
+    """conv -> norm -> activation, in configurable order."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 bias='auto', conv_cfg=None, norm_cfg=None, activation='relu', inplace=True,
+                 order=('conv', 'norm', 'act')):
+        super(ConvModule, self).__init__()
+        assert conv_cfg is None or isinstance(conv_cfg, dict)
+        assert norm_cfg is None or isinstance(norm_cfg, dict)
+        self.conv_cfg = conv_cfg
+        self.norm_cfg = norm_cfg
+        self.activation = activation
+        self.inplace = inplace
+        self.order = order
+        assert isinstance(self.order, tuple) and len(self.order) == 3
+        assert set(order) == set(['conv', 'norm', 'act'])
+
+        self.with_norm = norm_cfg is not None
+        self.with_activatation = activation is not None
+        if bias == 'auto':
+            bias = False if self.with_norm else True
+        self.with_bias = bias
+        if self.with_norm and self.with_bias:
+            warnings.warn('ConvModule has norm and bias at the same time')
+
+        self.conv = build_conv_layer(conv_cfg, in_channels, out_channels, kernel_size, stride=stride,
+                                     padding=padding, dilation=dilation, groups=groups, bias=bias)
+        for attr in ('in_channels', 'out_channels', 'kernel_size', 'stride', 'padding', 'dilation',
+                     'transposed', 'output_padding', 'groups'):
+            setattr(self, attr, getattr(self.conv, attr))
+
+        if self.with_norm:
+            norm_channels = out_channels if order.index('norm') > order.index('conv') else in_channels
+            self.norm_name, norm = build_norm_layer(norm_cfg, norm_channels)
+            self.add_module(self.norm_name, norm)
+
+        if self.with_activatation:
+            if self.activation not in ['relu']:
+                raise ValueError('{} is currently not supported.'.format(self.activation))
+            self.activate = nn.ReLU(inplace=inplace)
+
+        self.init_weights()
+
+    @property
+    def norm(self):
+        return getattr(self, self.norm_name)
+
+    def init_weights(self):
+        nonlinearity = 'relu' if self.activation is None else self.activation
+        kaiming_init(self.conv, nonlinearity=nonlinearity)
+        if self.with_norm:
+            constant_init(self.norm, 1, bias=0)
+
+    def forward(self, x, activate=True, norm=True):
+        for layer in self.order:
+            if layer == 'conv':
+                x = self.conv(x)
+            elif layer == 'norm' and norm and self.with_norm:
+                x = self.norm(x)
+            elif layer == 'act' and activate and self.with_activatation:
+                x = self.activate(x)
+        return x

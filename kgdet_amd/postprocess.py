@@ -1,0 +1,106 @@
+"""Per-class NMS of decoded detections, keypoints carried along.
+
+``multiclass_nms_kp`` mirrors mmdet/core/post_processing/bbox_nms_kp.py:6-75 call for call (the NMS
+type is looked up by name exactly as ``getattr(nms_wrapper, nms_type)`` does there).
+``multiclass_nms_kp_batched`` is the MI355X path for hard NMS: every (image, class) group of the
+whole batch goes through ONE launch of the batched HIP NMS, with two small host reads per batch
+instead of one synchronising NMS call per class per image.  Both return, per image,
+(det_bboxes [k,5], det_labels [k], det_kpts [k, ...]) in the reference's order: class-major,
+ascending candidate index inside a class, re-sorted by score only when more than ``max_num`` survive.
+"""
+import torch
+
+from . import nms as nms_wrapper
+
+
+def multiclass_nms_kp(multi_bboxes, multi_scores, multi_kpts, score_thr, nms_cfg, max_num=-1, score_factors=None):
+    num_classes = multi_scores.shape[1]
+    assert multi_kpts.shape[1] % 3 == 0
+    num_kpts = multi_kpts.shape[1] // 3
+    bboxes, labels, kpts = [], [], []
+    nms_cfg_ = dict(nms_cfg)
+    nms_type = nms_cfg_.pop('type', 'nms')
+    nms_op = getattr(nms_wrapper, nms_type)
+    for i in range(1, num_classes):
+        cls_inds = multi_scores[:, i] > score_thr
+        if not cls_inds.any():
+            continue
+        if multi_bboxes.shape[1] == 4:
+            _bboxes = multi_bboxes[cls_inds, :]
+        else:
+            _bboxes = multi_bboxes[cls_inds, i * 4:(i + 1) * 4]
+        _kpts = multi_kpts[cls_inds, :]
+        _scores = multi_scores[cls_inds, i]
+        if score_factors is not None:
+            _scores *= score_factors[cls_inds]
+        cls_dets = torch.cat([_bboxes, _scores[:, None]], dim=1)
+        cls_dets, inds = nms_op(cls_dets, **nms_cfg_)
+        cls_labels = multi_bboxes.new_full((cls_dets.shape[0], ), i - 1, dtype=torch.long)
+        bboxes.append(cls_dets)
+        labels.append(cls_labels)
+        kpts.append(_kpts[inds, :])
+    if bboxes:
+        bboxes = torch.cat(bboxes)
+        labels = torch.cat(labels)
+        kpts = torch.cat(kpts)
+        if bboxes.shape[0] > max_num:
+            _, inds = bboxes[:, -1].sort(descending=True)
+            inds = inds[:max_num]
+            bboxes = bboxes[inds]
+            labels = labels[inds]
+            kpts = kpts[inds]
+    else:
+        bboxes = multi_bboxes.new_zeros((0, 5))
+        labels = multi_bboxes.new_zeros((0, ), dtype=torch.long)
+        kpts = multi_bboxes.new_zeros((0, num_kpts * 3))
+    return bboxes, labels, kpts
+
+
+def multiclass_nms_kp_batched(bboxes, scores, kpts, score_thr, nms_cfg, max_num=-1):
+    """bboxes [B,N,4], scores [B,N,1+C] (column 0 = background), kpts [B,N,...] on the GPU.
+
+    Returns a list of B (det_bboxes, det_labels, det_kpts) tuples identical to calling
+    ``multiclass_nms_kp`` per image with ``type='nms'``.
+    """
+    nms_cfg_ = dict(nms_cfg)
+    nms_type = nms_cfg_.pop('type', 'nms')
+    if nms_type != 'nms':
+        return [multiclass_nms_kp(bboxes[b], scores[b], kpts[b].reshape(kpts.shape[1], -1), score_thr, nms_cfg,
+                                  max_num) for b in range(bboxes.shape[0])]
+    iou_thr = float(nms_cfg_['iou_thr'])
+    B, N = scores.shape[0], scores.shape[1]
+    C = scores.shape[2] - 1
+    cand = (scores[:, :, 1:] > score_thr).permute(0, 2, 1).contiguous()   # [B, C, N] -> row-major = (b, c, n)
+    counts = cand.sum(-1).flatten()                                        # [B*C]
+    offsets = torch.zeros(B * C + 1, dtype=torch.int64, device=scores.device)
+    offsets[1:] = counts.cumsum(0)
+    idx = cand.nonzero()                                                   # [T, 3] sorted by (b, c, n)  (host read #1)
+    T = idx.shape[0]
+    empty = (bboxes.new_zeros((0, 5)), bboxes.new_zeros((0, ), dtype=torch.long),
+             bboxes.new_zeros((0, ) + tuple(kpts.shape[2:])))
+    if T == 0:
+        return [empty for _ in range(B)]
+    b_i, c_i, n_i = idx[:, 0], idx[:, 1], idx[:, 2]
+    dets = torch.cat([bboxes[b_i, n_i], scores[b_i, n_i, c_i + 1].unsqueeze(1)], 1).contiguous()
+    keep, num_keep = nms_wrapper.nms_batched(dets, offsets, iou_thr, max_seg_len=N)
+    # kept entries -> flat positions, still ordered by (b, c, ascending candidate index)
+    seg_of = torch.repeat_interleave(torch.arange(B * C, device=dets.device), counts, output_size=T)
+    pos_in_seg = torch.arange(T, device=dets.device) - offsets[seg_of]
+    is_kept_slot = pos_in_seg < num_keep[seg_of]
+    kept_flat = (offsets[seg_of] + keep)[is_kept_slot]                     # (host read #2: size)
+    kept_img = seg_of[is_kept_slot] // C
+    per_img = torch.bincount(kept_img, minlength=B).tolist()
+    out, start = [], 0
+    for b in range(B):
+        sel = kept_flat[start:start + per_img[b]]
+        start += per_img[b]
+        if sel.numel() == 0:
+            out.append(empty)
+            continue
+        d, lab, kp = dets[sel], c_i[sel], kpts[b_i[sel], n_i[sel]]
+        if d.shape[0] > max_num:
+            _, order = d[:, -1].sort(descending=True, stable=True)
+            order = order[:max_num]
+            d, lab, kp = d[order], lab[order], kp[order]
+        out.append((d, lab, kp))
+    return out

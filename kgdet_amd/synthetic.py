@@ -1,0 +1,48 @@
+"""Seeded synthetic DeepFashion2-shaped batches: there is no network for datasets, so
+the benchmark and the smoke test feed ``N(0,1)`` images with realistic ground truth:
+
+* images ``[B, 3, 800, 1344]`` (800x1333 padded to a multiple of 32, config ``size_divisor=32``),
+* G = 2 boxes per image, width / height U(200, 700) px inside the image, labels 1..13,
+* keypoints ``[G, 294, 3]`` with only the category's slice visible (slices from
+  mmdet/datasets/deepfashion2.py:18-21), coordinates uniform inside the box, v in {1, 2}.
+"""
+import torch
+
+CLASS_KEYPOINT_SLICES = {
+    1: (0, 25), 2: (25, 58), 3: (58, 89), 4: (89, 128), 5: (128, 143), 6: (143, 158), 7: (158, 168),
+    8: (168, 182), 9: (182, 190), 10: (190, 219), 11: (219, 256), 12: (256, 275), 13: (275, 294)}
+
+IMG_SHAPE = (800, 1333, 3)
+PAD_SHAPE = (800, 1344, 3)
+
+
+def make_img_metas(batch, img_shape=IMG_SHAPE, pad_shape=PAD_SHAPE):
+    return [dict(ori_shape=img_shape, img_shape=img_shape, pad_shape=pad_shape, scale_factor=1.0, flip=False,
+                 gt_class_keypoints_dict=CLASS_KEYPOINT_SLICES, flip_indices=list(range(588)))
+            for _ in range(batch)]
+
+
+def make_batch(batch, device, seed=0, num_gt=2, img_shape=IMG_SHAPE, pad_shape=PAD_SHAPE, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    H, W = img_shape[0], img_shape[1]
+    img = torch.randn(batch, 3, pad_shape[0], pad_shape[1], generator=g, dtype=dtype)
+    gt_bboxes, gt_labels, gt_keypoints = [], [], []
+    for _ in range(batch):
+        wh = torch.rand(num_gt, 2, generator=g) * 500 + 200
+        wh[:, 0].clamp_(max=W - 2)
+        wh[:, 1].clamp_(max=H - 2)
+        xy = torch.rand(num_gt, 2, generator=g) * (torch.tensor([W - 1., H - 1.]) - wh)
+        boxes = torch.cat([xy, xy + wh], 1)
+        labels = torch.randint(1, 14, (num_gt, ), generator=g)
+        kps = torch.zeros(num_gt, 294, 3)
+        for i in range(num_gt):
+            lo, hi = CLASS_KEYPOINT_SLICES[int(labels[i])]
+            n = hi - lo
+            kps[i, lo:hi, 0] = boxes[i, 0] + torch.rand(n, generator=g) * wh[i, 0]
+            kps[i, lo:hi, 1] = boxes[i, 1] + torch.rand(n, generator=g) * wh[i, 1]
+            kps[i, lo:hi, 2] = torch.randint(1, 3, (n, ), generator=g).float()
+        gt_bboxes.append(boxes.to(device))
+        gt_labels.append(labels.to(device))
+        gt_keypoints.append(kps.to(device))
+    return dict(img=img.to(device), img_meta=make_img_metas(batch, img_shape, pad_shape), gt_bboxes=gt_bboxes,
+                gt_labels=gt_labels, gt_keypoints=gt_keypoints)
