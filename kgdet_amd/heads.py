@@ -198,7 +198,7 @@ class RepPointsHeadKp3RepCas1AssignOnce(nn.Module):
     # ------------------------------------------------------------------------------------------
     def points2bbox(self, pts, y_first=True):
         """point set [B, 2n, H, W] -> box [B, 4, H, W] (x1, y1, x2, y2), KP3:342-391"""
-        pts_reshape = pts.view(pts.shape[0], -1, 2, *pts.shape[2:])
+        pts_reshape = pts.reshape(pts.shape[0], -1, 2, *pts.shape[2:])
         pts_y = pts_reshape[:, :, 0, ...] if y_first else pts_reshape[:, :, 1, ...]
         pts_x = pts_reshape[:, :, 1, ...] if y_first else pts_reshape[:, :, 0, ...]
         if self.transform_method == 'minmax':
@@ -217,10 +217,10 @@ class RepPointsHeadKp3RepCas1AssignOnce(nn.Module):
 
     def points2kpt(self, pts, y_first=True):
         """(y, x) interleaved -> (x, y) interleaved channel order, KP3:393-410"""
-        pts_reshape = pts.view(pts.shape[0], -1, 2, *pts.shape[2:])
+        pts_reshape = pts.reshape(pts.shape[0], -1, 2, *pts.shape[2:])
         pts_y = pts_reshape[:, :, 0, ...] if y_first else pts_reshape[:, :, 1, ...]
         pts_x = pts_reshape[:, :, 1, ...] if y_first else pts_reshape[:, :, 0, ...]
-        return torch.stack([pts_x, pts_y], dim=2).view(*pts.shape)
+        return torch.stack([pts_x, pts_y], dim=2).reshape(*pts.shape)
 
     def forward_single(self, x):
         cls_feat = x

@@ -1,0 +1,42 @@
+"""CPU stand-ins for the HIP ops, built from the test-side references (tests/torch_ref.py), so that
+the host logic (head wiring, losses, targets) can be exercised without a GPU.  Tests only: the
+product never falls back to these."""
+import contextlib
+
+import torch
+
+from tests import torch_ref
+
+
+def deform_conv_cat(x, offsets, weights, paddings, relu=True):
+    outs = [torch_ref.deform_conv(x, o, w, 1, p, 1) for o, w, p in zip(offsets, weights, paddings)]
+    out = torch.cat(outs, 1)
+    return out.relu() if relu else out
+
+
+def moment_bbox(pts, mt, y_first=True):
+    B, C2, H, W = pts.shape
+    r = pts.view(B, -1, 2, H, W)
+    py = r[:, :, 0] if y_first else r[:, :, 1]
+    px = r[:, :, 1] if y_first else r[:, :, 0]
+    my, mx = py.mean(1, keepdim=True), px.mean(1, keepdim=True)
+    sy, sx = torch.std(py - my, dim=1, keepdim=True), torch.std(px - mx, dim=1, keepdim=True)
+    hw, hh = sx * torch.exp(mt[0]), sy * torch.exp(mt[1])
+    return torch.cat([mx - hw, my - hh, mx + hw, my + hh], 1)
+
+
+def sigmoid_focal_loss(pred, target, gamma=2.0, alpha=0.25):
+    return torch_ref.py_sigmoid_focal_loss(pred, target, gamma, alpha)
+
+
+@contextlib.contextmanager
+def patched():
+    """route the three HIP-only ops of the head to the CPU references for the duration of a test"""
+    from kgdet_amd import dcn, focal_loss, moment
+    saved = (dcn.deform_conv_cat, moment.moment_bbox, focal_loss.sigmoid_focal_loss)
+    dcn.deform_conv_cat, moment.moment_bbox, focal_loss.sigmoid_focal_loss = (deform_conv_cat, moment_bbox,
+                                                                             sigmoid_focal_loss)
+    try:
+        yield
+    finally:
+        dcn.deform_conv_cat, moment.moment_bbox, focal_loss.sigmoid_focal_loss = saved

@@ -1,0 +1,272 @@
+"""CPU tests of the host side: registry/config API, point grid, assigners, targets, losses, FPN2
+pruning, head wiring (with the HIP ops replaced by test-side CPU references), checkpoint keys."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import kgdet_amd
+from kgdet_amd import configs, points, synthetic
+from kgdet_amd.registry import (HEADS, Config, ConfigDict, Registry, build_detector, build_from_cfg, build_head)
+from tests import cpu_ops
+
+REF_CFG = '/root/reference/configs/kgdet_moment_r50_fpn_1x-demo.py'
+
+
+# ---- registry / config --------------------------------------------------------------------------
+def test_registry_contract():
+    R = Registry('thing')
+
+    @R.register_module
+    class A(object):
+        def __init__(self, x, y=2):
+            self.x, self.y = x, y
+
+    assert R.get('A') is A and R.get('B') is None
+    with pytest.raises(KeyError):
+        R.register_module(A)                       # duplicate name
+    with pytest.raises(TypeError):
+        R._register_module(lambda: 0)
+    obj = build_from_cfg(dict(type='A', x=1), R, default_args=dict(y=5, x=9))
+    assert (obj.x, obj.y) == (1, 5)                # default_args only fill missing keys
+    with pytest.raises(KeyError):
+        build_from_cfg(dict(type='Nope'), R)
+    with pytest.raises(AssertionError):
+        build_from_cfg(dict(x=1), R)
+    assert build_from_cfg(dict(type=A, x=3), R).x == 3
+
+
+def test_registered_names_the_configs_need():
+    for name in ('RepPointsHeadKp3RepCas1AssignOnce', 'KGDetHead'):
+        assert HEADS.get(name) is kgdet_amd.heads.RepPointsHeadKp3RepCas1AssignOnce
+    assert kgdet_amd.DETECTORS.get('RepPointsDetectorKp') is not None
+    assert kgdet_amd.BACKBONES.get('ResNet') is not None
+    assert kgdet_amd.NECKS.get('FPN2') is not None and kgdet_amd.NECKS.get('FPN') is not None
+    assert kgdet_amd.LOSSES.get('FocalLoss') is not None and kgdet_amd.LOSSES.get('SmoothL1Loss') is not None
+
+
+def test_config_dict_access(tmp_path):
+    p = tmp_path / 'cfg.py'
+    p.write_text("a = dict(b=dict(c=[1, dict(d=2)]), e=3)\nimport os\nf = 'x'\n")
+    cfg = Config.fromfile(str(p))
+    assert cfg.a.b.c[1].d == 2 and cfg.a['e'] == 3 and cfg.f == 'x'
+    assert cfg.get('zzz', 7) == 7 and 'os' not in cfg
+    assert cfg.a.get('nms_pre', -1) == -1
+    with pytest.raises(FileNotFoundError):
+        Config.fromfile(str(tmp_path / 'missing.py'))
+    with pytest.raises(IOError):
+        (tmp_path / 'c.yaml').write_text('a: 1')
+        Config.fromfile(str(tmp_path / 'c.yaml'))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CFG), reason='reference configs not mounted')
+def test_reference_configs_load_unchanged():
+    cfg = Config.fromfile(REF_CFG)
+    mine = configs.kgdet_r50_fpn()
+    assert cfg.model == mine.model and cfg.train_cfg == mine.train_cfg and cfg.test_cfg == mine.test_cfg
+    model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    n = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    assert n == 59134423
+    full = Config.fromfile(REF_CFG.replace('-demo', '-deepfashion2'))
+    assert full.model == mine.model
+
+
+def test_checkpoint_key_contract():
+    cfg = configs.kgdet_r50_fpn()
+    head = build_head(cfg.model.bbox_head)
+    keys = set(head.state_dict().keys())
+    for k in ('cls_convs.0.conv.weight', 'cls_convs.2.gn.bias', 'reg_convs.1.gn.weight', 'moment_transfer',
+              'kp_rep_block_1.cls_conv.weight', 'kp_rep_block_1.keypts_out.bias',
+              'kp_rep_block_2.cls_dfmconv_3.weight', 'kp_rep_block_3.keypts_dfmconv_7.weight',
+              'kp_rep_block_3.reppts_out.weight', 'kp_rep_block_2.cls_out.bias'):
+        assert k in keys, k
+    assert not any('dcn_base_offset' in k for k in keys)       # plain attributes, not buffers (KP3:47)
+    assert head.num_reppts == 83 and head.cls_out_channels == 13
+    assert tuple(head.kp_rep_block_2.cls_dfmconv_7.weight.shape) == (256, 256, 7, 7)
+    assert tuple(head.kp_rep_block_2.reppts_out.weight.shape) == (166, 588, 1, 1)
+
+
+# ---- point grid / assigners / targets ----------------------------------------------------------
+def test_point_generator():
+    g = points.PointGenerator()
+    p = g.grid_points((2, 3), 32, device='cpu')
+    assert p.tolist() == [[0, 0, 32], [32, 0, 32], [64, 0, 32], [0, 32, 32], [32, 32, 32], [64, 32, 32]]
+    f = g.valid_flags((2, 3), (1, 2), device='cpu')
+    assert f.tolist() == [True, True, False, False, False, False]
+
+
+def _grid(h=25, w=42, stride=32):
+    return points.PointGenerator().grid_points((h, w), stride, device='cpu')
+
+
+def test_point_assigner_single_gt_takes_k_nearest():
+    pts = _grid()
+    gt = torch.tensor([[320., 160., 640., 480.]])              # centre (480, 320) = grid cell (15, 10)
+    res = points.PointAssigner(scale=4, pos_num=9).assign(pts, gt, None, torch.tensor([5]))
+    pos = torch.nonzero(res.gt_inds > 0).flatten().tolist()
+    expect = sorted((10 + dy) * 42 + (15 + dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1))
+    assert pos == expect and set(res.labels[pos].tolist()) == {5}
+    assert int((res.gt_inds == 0).sum()) == 1050 - 9
+    with pytest.raises(ValueError):
+        points.PointAssigner().assign(pts, gt[:0])
+
+
+def test_point_assigner_overlapping_gts_nearest_wins():
+    pts = _grid()
+    gts = torch.tensor([[320., 160., 640., 480.], [352., 160., 672., 480.]])   # centres one cell apart
+    res = points.PointAssigner(scale=4, pos_num=9).assign(pts, gts, None, torch.tensor([1, 2]))
+    inds = res.gt_inds.view(25, 42)
+    assert inds[10, 14] == 1 and inds[10, 17] == 2               # exclusive columns
+    assert inds[10, 15] == 1 and inds[10, 16] == 2               # shared cells go to the nearer centre
+    assert int((res.gt_inds > 0).sum()) == 12
+
+
+def test_point_target_kp_shapes_and_counts():
+    batch = synthetic.make_batch(2, 'cpu', seed=3)
+    gen = points.PointGenerator()
+    centers = [[gen.grid_points((25, 42), 32, device='cpu')] for _ in range(2)]
+    flags = [[gen.valid_flags((25, 42), (25, 42), device='cpu')] for _ in range(2)]
+    cfg = ConfigDict(assigner=dict(type='PointAssigner', scale=4, pos_num=25), allowed_border=-1, pos_weight=-1,
+                     debug=False)
+    out = points.point_target_kp(centers, flags, batch['gt_bboxes'], batch['gt_keypoints'], batch['img_meta'], cfg,
+                                 gt_labels_list=batch['gt_labels'], label_channels=13, sampling=False)
+    labels, lw, bbox_gt, _, bw, kgt, kw, n_pos, n_neg = out
+    assert labels[0].shape == (2, 1050) and kgt[0].shape == (2, 1050, 294, 2)
+    assert n_pos == int((labels[0] > 0).sum()) and 25 <= n_pos <= 100
+    assert torch.all(lw[0] == 1) and torch.all(bw[0][labels[0] > 0] == 1)
+    # keypoint weights mark exactly the visible keypoints of the assigned GT's category slice
+    b, i = torch.nonzero(labels[0] > 0)[0].tolist()
+    lo, hi = synthetic.CLASS_KEYPOINT_SLICES[int(labels[0][b, i])]
+    assert kw[0][b, i, lo:hi].min() == 1 and kw[0][b, i].sum() == 2 * (hi - lo)
+
+
+def test_max_iou_assigner():
+    a = points.MaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0)
+    boxes = torch.tensor([[0., 0., 9., 9.], [0., 0., 9., 4.], [50., 50., 60., 60.], [0., 0., 9., 7.]])
+    res = a.assign(boxes, torch.tensor([[0., 0., 9., 9.]]), None, torch.tensor([3]))
+    assert res.gt_inds.tolist() == [1, 1, 0, 1] and res.labels.tolist() == [3, 3, 0, 3]
+    iou = points.bbox_overlaps(torch.tensor([[0., 0., 9., 9.]]), boxes)
+    np.testing.assert_allclose(iou.numpy(), [[1.0, 0.5, 0.0, 0.8]], rtol=1e-6)
+
+
+# ---- losses ------------------------------------------------------------------------------------
+def test_smooth_l1_and_reduction():
+    from kgdet_amd.losses import SmoothL1Loss, weight_reduce_loss
+    pred = torch.tensor([[0.0, 0.05, 1.0]])
+    tgt = torch.zeros(1, 3)
+    l = SmoothL1Loss(beta=1.0 / 9.0, loss_weight=0.5)(pred, tgt, torch.ones(1, 3), avg_factor=2.0)
+    beta = 1.0 / 9.0
+    expect = 0.5 * (0.5 * 0.05 ** 2 / beta + (1.0 - 0.5 * beta)) / 2.0
+    assert abs(float(l) - expect) < 1e-7
+    with pytest.raises(ValueError):
+        weight_reduce_loss(torch.ones(3), None, 'sum', avg_factor=2)
+
+
+# ---- neck --------------------------------------------------------------------------------------
+def test_fpn2_pruned_forward_equals_full_pyramid():
+    from kgdet_amd.neck import FPN, FPN2
+    torch.manual_seed(0)
+    kw = dict(in_channels=[8, 16, 32, 64], out_channels=32, num_outs=5, start_level=1, add_extra_convs=True,
+              norm_cfg=dict(type='GN', num_groups=8, requires_grad=True))
+    sel = FPN2(select_out=[2], **kw)
+    full = FPN(**kw)
+    full.load_state_dict(sel.state_dict())
+    feats = [torch.randn(2, c, 64 // s, 80 // s) for c, s in zip([8, 16, 32, 64], [1, 2, 4, 8])]
+    out = sel(feats)
+    assert len(out) == 1 and torch.equal(out[0], full(feats)[2])
+    out[0].sum().backward()
+    dead = [n for n, p in sel.named_parameters() if p.grad is None]
+    live = [n for n, p in sel.named_parameters() if p.grad is not None]
+    assert all(n.startswith(('lateral_convs.2', 'fpn_convs.2')) for n in live) and len(dead) > 0
+
+
+# ---- head wiring on CPU (HIP ops replaced by the test references) -------------------------------
+def _small_head():
+    torch.manual_seed(0)
+    cfg = configs.kgdet_r50_fpn().model.bbox_head.copy()
+    cfg.update(in_channels=32, feat_channels=32, point_feat_channels=32, num_keypts=294,
+               norm_cfg=dict(type='GN', num_groups=8, requires_grad=True))
+    head = build_head(cfg)
+    head.init_weights()
+    return head
+
+
+def test_head_forward_loss_and_decode_on_cpu():
+    head = _small_head()
+    x = torch.randn(2, 32, 8, 10)
+    batch = synthetic.make_batch(2, 'cpu', seed=1, img_shape=(256, 320, 3), pad_shape=(256, 320, 3))
+    for k in ('gt_bboxes', 'gt_keypoints'):
+        batch[k] = [t.clamp(max=250) for t in batch[k]]
+    with cpu_ops.patched():
+        outs = head([x], batch['img_meta'])
+        assert len(outs) == 9 and outs[0][0].shape == (2, 13, 8, 10)
+        assert outs[3][0].shape == (2, 588, 8, 10) and outs[6][0].shape == (2, 4, 8, 10)
+        tcfg = configs.kgdet_r50_fpn().train_cfg
+        losses = head.loss(*outs, batch['gt_bboxes'], batch['gt_labels'], batch['gt_keypoints'], batch['img_meta'],
+                           tcfg)
+        assert sorted(losses) == sorted(['loss_%s_%d' % (n, s) for n in ('cls', 'bbox', 'kpt') for s in (1, 2, 3)])
+        total = sum(sum(v) for v in losses.values())
+        assert torch.isfinite(total)
+        total.backward()
+        assert head.kp_rep_block_3.cls_dfmconv_5.weight.grad.abs().sum() > 0
+        assert head.moment_transfer.grad.abs().sum() > 0
+        # stage-1 outputs only reach later stages detached: their reppts conv sees gradient from the
+        # stage-1 bbox loss and (scaled by gradient_mul) from the stage-2 offsets
+        assert head.kp_rep_block_1.reppts_out.weight.grad.abs().sum() > 0
+    # decode path without NMS (pure torch) keeps the reference's shapes and clamping
+    head.eval()
+    with cpu_ops.patched(), torch.no_grad():
+        outs = head([x], batch['img_meta'])
+        tst = configs.kgdet_r50_fpn().test_cfg
+        res = head.get_bboxes(*outs, batch['img_meta'], tst, rescale=True, nms=False)
+    bboxes, scores, kpts = res[0]
+    assert bboxes.shape == (80, 4) and scores.shape == (80, 14) and kpts.shape == (80, 882)
+    assert torch.all(scores[:, 0] == 0) and bboxes.max() <= 320 and bboxes.min() >= 0
+    assert torch.all(kpts.view(80, 294, 3)[:, :, 2] == 1)
+
+
+def test_points2kpt_and_offset_to_pts():
+    head = _small_head()
+    pts = torch.arange(2 * 6 * 2 * 3, dtype=torch.float32).view(2, 6, 2, 3)     # 3 points, (y, x) interleaved
+    k = head.points2kpt(pts)
+    assert torch.equal(k[:, 0::2], pts[:, 1::2]) and torch.equal(k[:, 1::2], pts[:, 0::2])
+    head.point_strides = [32]
+    centers = [[points.PointGenerator().grid_points((2, 3), 32, device='cpu')] for _ in range(2)]
+    out = head.offset_to_pts(centers, [pts])[0]                                 # [B, HW, 2n] as x0,y0,x1,y1..
+    b, hw, i = 1, 4, 2
+    h, w = divmod(hw, 3)
+    assert out[b, hw, 2 * i] == pts[b, 2 * i + 1, h, w] * 32 + centers[0][0][hw, 0]
+    assert out[b, hw, 2 * i + 1] == pts[b, 2 * i, h, w] * 32 + centers[0][0][hw, 1]
+
+
+# ---- C ABI -------------------------------------------------------------------------------------
+def test_shared_library_exports_every_declared_symbol():
+    import ctypes
+    from kgdet_amd import _lib
+    header = open(os.path.join(os.path.dirname(kgdet_amd.__file__), '..', 'include', 'kgdet_hip.h')).read()
+    names = set(re.findall(r'\b(kgdet_[a-z0-9_]+)\s*\(', header))
+    assert len(names) >= 20
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, missing
+    assert L.kgdet_version() == 1
+    s = _lib.DcnShape(2, 256, 25, 42, 256, 7, 7, 1, 1, 3, 3, 1, 1, 1, 1, 0, 0)
+    L.kgdet_dcn_packed_weight_bytes.restype = ctypes.c_size_t
+    assert L.kgdet_dcn_packed_weight_bytes(ctypes.byref(s)) == 2 * 49 * 256 * 256 * 4
+    bad = _lib.DcnShape(2, 256, 2, 2, 256, 7, 7, 1, 1, 0, 0, 1, 1, 1, 1, 0, 0)
+    ho, wo = ctypes.c_int32(), ctypes.c_int32()
+    assert L.kgdet_dcn_output_size(ctypes.byref(bad), ctypes.byref(ho), ctypes.byref(wo)) == _lib.KGDET_E_SHAPE
+    L.kgdet_last_error.restype = ctypes.c_char_p
+    assert b'too small' in L.kgdet_last_error()
+
+
+def test_ops_have_no_cpu_fallback():
+    from kgdet_amd import dcn, focal_loss, moment
+    with pytest.raises(NotImplementedError):
+        dcn.deform_conv(torch.zeros(1, 4, 5, 5), torch.zeros(1, 18, 5, 5), torch.zeros(4, 4, 3, 3), 1, 1, 1)
+    with pytest.raises(NotImplementedError):
+        moment.moment_bbox(torch.zeros(1, 18, 2, 2), torch.zeros(2))
+    with pytest.raises(NotImplementedError):
+        focal_loss.sigmoid_focal_loss(torch.zeros(2, 3), torch.zeros(2, dtype=torch.long), 2.0, 0.25)
