@@ -1,0 +1,100 @@
+"""GPU parity of the KGDet head and detector against the golden fixture produced by the build's CPU
+path (tests/golden/make_head_golden.py) and against the per-class reference post-processing."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from kgdet_amd import configs, synthetic
+from tests.golden.make_head_golden import KPT_STRIDE, make_inputs, small_head
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    b = np.asarray(b, np.float64)
+    return float(np.abs(np.asarray(a, np.float64) - b).max()) / max(float(np.abs(b).max()), 1e-6)
+
+
+@pytest.fixture(scope='module')
+def G(golden_dir):
+    return np.load(os.path.join(golden_dir, 'head_golden.npz'))
+
+
+def test_head_forward_loss_decode_match_cpu_golden(G):
+    assert torch.cuda.is_available()
+    head = small_head().cuda()
+    x, batch = make_inputs()
+    to = lambda l: [t.cuda() for t in l]
+    names = ['cls_1', 'cls_2', 'cls_3', 'kpt_1', 'kpt_2', 'kpt_3', 'bbox_1', 'bbox_2', 'bbox_3']
+    outs = head([x.cuda()], batch['img_meta'])
+    for n, o in zip(names, outs):
+        a = o[0].detach().cpu().numpy()
+        a = a[:, ::KPT_STRIDE] if n.startswith('kpt') else a
+        assert _rel(a, G['out:' + n]) < 2e-4, n
+    cfg = configs.kgdet_r50_fpn()
+    losses = head.loss(*outs, to(batch['gt_bboxes']), to(batch['gt_labels']), to(batch['gt_keypoints']),
+                       batch['img_meta'], cfg.train_cfg)
+    for k, v in losses.items():
+        got = sum(float(t) for t in v)
+        assert abs(got - float(G['loss:' + k])) < 2e-4 * max(1.0, abs(float(G['loss:' + k]))), k
+    sum(sum(v) for v in losses.values()).backward()
+    assert torch.isfinite(head.kp_rep_block_2.keypts_dfmconv_7.weight.grad).all()
+    head.eval()
+    with torch.no_grad():
+        res = head.get_bboxes(*head([x.cuda()], batch['img_meta']), batch['img_meta'], cfg.test_cfg, rescale=True,
+                              nms=False)
+    assert _rel(np.stack([r[0].cpu().numpy() for r in res]), G['dec:bboxes']) < 1e-3
+    assert _rel(np.stack([r[1].cpu().numpy() for r in res]), G['dec:scores']) < 2e-4
+    assert _rel(np.stack([r[2].cpu().numpy() for r in res])[:, :, ::KPT_STRIDE * 3], G['dec:kpts']) < 1e-3
+
+
+def test_batched_postprocess_equals_per_class_reference_path():
+    """multiclass_nms_kp_batched (one launch for all (image, class) groups) == multiclass_nms_kp per image."""
+    from kgdet_amd.postprocess import multiclass_nms_kp, multiclass_nms_kp_batched
+    g = torch.Generator().manual_seed(0)
+    B, N, C = 3, 1000, 13
+    ctr = torch.rand(B, N, 2, generator=g) * torch.tensor([1300., 780.])
+    wh = torch.rand(B, N, 2, generator=g) * 300 + 20
+    boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], -1).clamp(min=0)
+    scores = torch.rand(B, N, C, generator=g) ** 6
+    scores = torch.cat([torch.zeros(B, N, 1), scores], -1)
+    kpts = torch.rand(B, N, 882, generator=g)
+    cfg = configs.kgdet_r50_fpn().test_cfg
+    bat = multiclass_nms_kp_batched(boxes.cuda(), scores.cuda(), kpts.cuda(), cfg.score_thr, cfg.nms, cfg.max_per_img)
+    for b in range(B):
+        ref = multiclass_nms_kp(boxes[b].cuda(), scores[b].cuda(), kpts[b].cuda(), cfg.score_thr, cfg.nms,
+                                cfg.max_per_img)
+        assert bat[b][0].shape[0] == ref[0].shape[0] == 100
+        assert torch.equal(bat[b][0], ref[0]) and torch.equal(bat[b][1], ref[1]) and torch.equal(bat[b][2], ref[2])
+    empty = multiclass_nms_kp_batched(boxes.cuda(), scores.cuda() * 0, kpts.cuda(), 0.05, cfg.nms, 100)
+    assert all(e[0].shape == (0, 5) for e in empty)
+
+
+def test_detector_train_and_batched_inference():
+    cfg = configs.kgdet_r50_fpn()
+    from kgdet_amd.registry import build_detector
+    torch.manual_seed(0)
+    model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda()
+    batch = synthetic.make_batch(2, 'cuda', seed=0, img_shape=(384, 480, 3), pad_shape=(384, 480, 3))
+    for k in ('gt_bboxes', 'gt_keypoints'):
+        batch[k] = [t.clamp(max=370) for t in batch[k]]
+    model.train()
+    losses = model(batch['img'], batch['img_meta'], return_loss=True, gt_bboxes=batch['gt_bboxes'],
+                   gt_labels=batch['gt_labels'], gt_keypoints=batch['gt_keypoints'])
+    total = sum(sum(v) for v in losses.values())
+    total.backward()
+    assert torch.isfinite(total)
+    dead = [n for n, p in model.named_parameters() if p.requires_grad and p.grad is None]
+    assert all(n.startswith('neck.') for n in dead) and len(dead) > 0        # the unused FPN2 branches only
+    live = sum(p.numel() for p in model.parameters() if p.requires_grad and p.grad is not None)
+    assert live == 52250071                                                   # all-reduce payload
+    model.eval()
+    with torch.no_grad():
+        res = model.simple_test_batch(batch['img'], batch['img_meta'], rescale=True)
+        one = model(return_loss=False, img=[batch['img'][:1]], img_meta=[batch['img_meta'][:1]], rescale=True)
+    assert len(res) == 2
+    for a, b in zip(res[0], one):
+        if isinstance(a, list):
+            assert all(np.allclose(x, y, atol=1e-3) for x, y in zip(a, b))
