@@ -212,7 +212,7 @@ int kgdet_deform_conv_forward(const kgdet_dcn_shape *s, const float *input, cons
     p.chunks_per_tile = d.K * p.chunks_per_tap;
     p.total_units = (long long)p.n_ntiles * p.n_mtiles * p.chunks_per_tile;
     hipLaunchKernelGGL(dcn_fwd_mfma, dim3(G), dim3(kThreads), 0, (hipStream_t)stream, p, (float *)workspace);
-    hipLaunchKernelGGL(dcn_fwd_fixup, dim3(p.n_ntiles * p.n_mtiles), dim3(kThreads), 0, (hipStream_t)stream, p,
+    hipLaunchKernelGGL(dcn_fwd_fixup, dim3(p.n_ntiles * p.n_mtiles, 16), dim3(kThreads), 0, (hipStream_t)stream, p,
                        (const float *)workspace, G);
   }
   KGDET_CHECK_LAUNCH("dcn_fwd_mfma");
@@ -335,7 +335,7 @@ int kgdet_deform_conv_backward_weight(const kgdet_dcn_shape *s, const float *inp
     const int n_tiles = d.K * a.n_otiles * a.n_ctiles;
     a.total_units = (long long)n_tiles * a.stages_per_tile;
     hipLaunchKernelGGL(dcn_bwd_weight_mfma, dim3(G), dim3(kThreads), 0, (hipStream_t)stream, p, a, slabs);
-    hipLaunchKernelGGL(dcn_bwd_weight_fixup, dim3(n_tiles), dim3(kThreads), 0, (hipStream_t)stream, p, a,
+    hipLaunchKernelGGL(dcn_bwd_weight_fixup, dim3(n_tiles, 4), dim3(kThreads), 0, (hipStream_t)stream, p, a,
                        (const float *)slabs, G);
   }
   KGDET_CHECK_LAUNCH("dcn_bwd_weight_mfma");

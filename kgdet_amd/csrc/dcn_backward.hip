@@ -326,10 +326,12 @@ __global__ __launch_bounds__(kThreads, 2) void dcn_bwd_weight_mfma(const DcnProb
   }
 }
 
+// grid = (tiles, 4): block (tile, j) owns the 32x32 accumulator block (mi, ni) = (j >> 1, j & 1) of
+// every wave, adds the slabs in workgroup order and stores it transposed (runs along o).
 __global__ __launch_bounds__(kThreads) void dcn_bwd_weight_fixup(const DcnProblem p, const DcnBwdWeightArgs a,
                                                                  const float *__restrict__ slabs, int G) {
   __shared__ float scratch[8 * 32 * 33];
-  const int tile = blockIdx.x, tid = threadIdx.x;
+  const int tile = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
   const int spt = a.stages_per_tile;
   const long long tb = (long long)tile * spt, te = tb + spt;
   long long g = tb * G / a.total_units;
@@ -337,16 +339,37 @@ __global__ __launch_bounds__(kThreads) void dcn_bwd_weight_fixup(const DcnProble
   while (unit_begin(g, a.total_units, G) > tb) --g;
   const long long gb = unit_begin(g, a.total_units, G), ge = unit_begin(g + 1, a.total_units, G);
   if (gb <= tb && ge >= te) return;
-  f32x16 acc[2][2];
-  zero_acc(acc);
+  float acc[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   for (; g < G; ++g) {
     const long long b0 = unit_begin(g, a.total_units, G);
     if (b0 >= te) break;
     if (unit_begin(g + 1, a.total_units, G) == b0) continue;
     const long long seg_begin = b0 > tb ? b0 : tb;
-    add_slab(slabs + ((long long)g * 2 + slab_slot(seg_begin, b0)) * kTileElems, tid, acc);
+    const f32x4 *s4 = reinterpret_cast<const f32x4 *>(slabs + ((long long)g * 2 + slab_slot(seg_begin, b0)) * kTileElems);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = s4[(j * 4 + q) * kThreads + tid];
+      acc[4 * q] += v[0]; acc[4 * q + 1] += v[1]; acc[4 * q + 2] += v[2]; acc[4 * q + 3] += v[3];
+    }
   }
-  store_wgrad(p, a, tile, tid, scratch, acc);
+  const int mi = j >> 1, ni = j & 1;
+  const int lane = tid & 63, wave = tid >> 6, wm = wave & 3, wn = wave >> 2;
+  const int ct = tile % a.n_ctiles;
+  const int ot = (tile / a.n_ctiles) % a.n_otiles;
+  const int t = tile / (a.n_ctiles * a.n_otiles);
+  float *T = scratch + wave * (32 * 33);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) T[(lane & 31) * 33 + mfma_row(r, lane)] = acc[r];
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  const int o = ot * kTileM + wm * 64 + mi * 32 + (lane & 31);
+#pragma unroll
+  for (int cc = 0; cc < 16; ++cc) {
+    const int cl = cc * 2 + (lane >> 5);
+    const int c = ct * kTileN + wn * 64 + ni * 32 + cl;
+    if (c < p.Cg_pad && o < p.Og_pad) p.out[((long long)t * p.Cg_pad + c) * p.Og_pad + o] = T[cl * 33 + (lane & 31)];
+  }
 }
 
 // grad_bias[o] = sum_{b,hw} grad_out[b,o,hw]   (deform_conv_cuda.cpp:659-665)

@@ -168,30 +168,47 @@ __global__ __launch_bounds__(kThreads, 2) void dcn_fwd_mfma(const DcnProblem p, 
   }
 }
 
-// One workgroup per tile: if the tile was split across workgroups, add their slabs in order.
+// Split tiles: add the workgroups' slabs in workgroup order.  grid = (tiles, 16): block (tile, j) owns
+// one float4 column j of the 16-float4 register image, so the additions are spread over 16x more
+// workgroups than tiles (17 tiles alone would leave 93 % of the chip idle).
 __global__ __launch_bounds__(kThreads) void dcn_fwd_fixup(const DcnProblem p, const float *__restrict__ slabs,
                                                          int G) {
-  const int tile = blockIdx.x, tid = threadIdx.x;
+  const int tile = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
   const int cpt = p.chunks_per_tile;
   const long long tb = (long long)tile * cpt, te = tb + cpt;
   long long g = tb * G / p.total_units;
   while (unit_begin(g + 1, p.total_units, G) <= tb) ++g;
   while (unit_begin(g, p.total_units, G) > tb) --g;
-  // g = first workgroup whose range intersects the tile
   const long long gb = unit_begin(g, p.total_units, G), ge = unit_begin(g + 1, p.total_units, G);
   if (gb <= tb && ge >= te) return;  // written directly by workgroup g
 
-  f32x16 acc[2][2];
-  zero_acc(acc);
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
   for (; g < G; ++g) {
     const long long b0 = unit_begin(g, p.total_units, G);
     if (b0 >= te) break;
     if (unit_begin(g + 1, p.total_units, G) == b0) continue;  // workgroup with an empty range
     const long long seg_begin = b0 > tb ? b0 : tb;
-    const float *slab = slabs + ((long long)g * 2 + slab_slot(seg_begin, b0)) * kTileElems;
-    add_slab(slab, tid, acc);
+    const f32x4 *s4 = reinterpret_cast<const f32x4 *>(slabs + ((long long)g * 2 + slab_slot(seg_begin, b0)) * kTileElems);
+    const f32x4 v = s4[j * kThreads + tid];
+    sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
   }
-  store_output(p, tile % p.n_mtiles, tile / p.n_mtiles, tid, acc);
+  // float4 column j = (mi, ni, q): accumulator registers 4q .. 4q+3 of block (mi, ni)
+  const int mi = j >> 3, ni = (j >> 2) & 1, q = j & 3;
+  const int mt = tile % p.n_mtiles, nt = tile / p.n_mtiles;
+  const int lane = tid & 63, wave = tid >> 6, wm = wave & 3, wn = wave >> 2;
+  const int pix = nt * kTileN + wn * 64 + ni * 32 + (lane & 31);
+  if (pix >= p.P) return;
+  const int b = pix / p.HoWo, hw = pix - b * p.HoWo;
+  float *obase = p.out + ((long long)b * p.O_total + p.o_base) * p.HoWo + hw;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int o = mt * kTileM + wm * 64 + mi * 32 + mfma_row(4 * q + e, lane);
+    if (o >= p.Og) continue;
+    float v = sum[e];
+    if (p.bias) v += p.bias[p.bias_base + o];
+    if (p.flags & KGDET_DCN_RELU) v = fmaxf(v, 0.0f);
+    obase[(long long)o * p.HoWo] = v;
+  }
 }
 
 // ----------------------------------------------------------------------------------------------
