@@ -92,7 +92,9 @@ BwdLdsPlan plan_bwd_lds(const kgdet_dcn_shape *s, const Derived &d) {
 
 // the MFMA kernels gather 4 consecutive channels per thread with one Tap, so a deformable group
 // boundary must not fall inside such a quad
-bool mfma_ok(const kgdet_dcn_shape *s) { return (s->C / s->deformable_groups) % 4 == 0 || s->deformable_groups == 1; }
+bool mfma_ok(const kgdet_dcn_shape *s) {
+  return s->W >= 2 && ((s->C / s->deformable_groups) % 4 == 0 || s->deformable_groups == 1);
+}
 // backward tiles (256 / 128 channels wide) must lie inside one deformable group
 bool mfma_bwd_ok(const kgdet_dcn_shape *s) {
   const int cpdg = s->C / s->deformable_groups, Cg = s->C / s->groups;

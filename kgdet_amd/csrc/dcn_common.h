@@ -88,6 +88,37 @@ __device__ __forceinline__ void make_tap(float y, float x, int H, int W, bool li
   g.va = va; g.vb = vb; g.vc = vc; g.vd = vd;
 }
 
+// Forward-only variant: the two corners of a row are adjacent floats, so one (4-byte aligned) 8-byte
+// load fetches both -- half the vector-memory instructions, which matters because the gather path
+// (texture addresser) and not the MFMA pipe is what saturates first (GRBM_TA_BUSY 90 % at 47 % MFMA).
+// The pair always starts inside the row: for x0 == -1 it starts at column 0 and the first element
+// takes the right-corner weight, for x0 == W-1 it starts at W-2 and the second element takes the
+// left-corner weight; dead corners carry weight 0 as before.  Requires W >= 2.
+struct TapPair {
+  int o[2];    // start of the pair in row y0 / row y1 (element offsets inside an H*W plane)
+  float w[4];  // weights of (row0.x, row0.y, row1.x, row1.y)
+};
+
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+
+__device__ __forceinline__ void make_tap_pair(float y, float x, int H, int W, bool live, float m, TapPair &t) {
+  const bool in = live && (y > -1.0f) && (x > -1.0f) && (y < (float)H) && (x < (float)W);
+  if (!in) { y = 0.0f; x = 0.0f; }
+  const float fy = floorf(y), fx = floorf(x);
+  const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1;
+  const float ly = y - fy, lx = x - fx, hy = 1.0f - ly, hx = 1.0f - lx;
+  const float wr0 = (in && y0 >= 0) ? hy * m : 0.0f;       // row y0 valid
+  const float wr1 = (in && y1 <= H - 1) ? ly * m : 0.0f;   // row y1 valid
+  float wx0, wx1;                                           // weights of the pair's two elements
+  if (x0 < 0) { wx0 = lx; wx1 = 0.0f; }                    // only column 0 (the right corner) exists
+  else if (x0 > W - 2) { wx0 = 0.0f; wx1 = hx; }           // only column W-1 (the left corner) exists
+  else { wx0 = hx; wx1 = lx; }
+  const int cx = min(max(x0, 0), W - 2);
+  t.o[0] = max(y0, 0) * W + cx;
+  t.o[1] = min(y1, H - 1) * W + cx;
+  t.w[0] = wr0 * wx0; t.w[1] = wr0 * wx1; t.w[2] = wr1 * wx0; t.w[3] = wr1 * wx1;
+}
+
 // sampling position of tap t for output pixel (oy, ox) of image b; deformable group dgi
 __device__ __forceinline__ void tap_position(const DcnProblem &p, int b, int dgi, int t, int hw, int oy,
                                              int ox, float &y, float &x, float &m) {

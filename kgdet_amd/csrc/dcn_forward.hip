@@ -100,38 +100,41 @@ __global__ __launch_bounds__(kThreads, 2) void dcn_fwd_mfma(const DcnProblem p, 
     f32x16 acc[2][2];
     zero_acc(acc);
 
-    Tap tap;
-    int tap_key = -1;  // (t, deformable group) the cached Tap belongs to
-    float v[4][4];     // gathered corner values of the stage in flight: [channel][corner]
+    // ---- software-pipelined stage loop -------------------------------------------------------------
+    // Iteration s multiplies stage s out of LDS buffer `buf` while it builds stage s+1 in the other
+    // buffer.  The build work is sliced between the eight 4-MFMA k-steps so that every slice issues in
+    // the shadow of the 256 MFMA cycles that precede it: k-steps 0-3 issue the gathers of one channel
+    // each, k-steps 4-7 interpolate one channel each and park it in LDS; operand fragments of the next
+    // k-step are fetched before the current MFMAs; the raw offsets of the next tap are fetched one
+    // stage early, so a tap change costs VALU only.
+    TapPair tap;             // tap of the stage being BUILT
+    f32x2u v[4][2];          // its gathered corner pairs: [channel][row]
+    float raw_y = 0.f, raw_x = 0.f, raw_m = 0.f;  // prefetched position of the following tap
+    int raw_key = -1;
 
-    // issue the gathers of stage s (results land in v)
-    auto gather_issue = [&](int s) {
-      const int t = s / p.chunks_per_tap;
-      const int c0 = (s - t * p.chunks_per_tap) * kChunk + cq * 4;
-      const int dgi = (p.c_base + min(c0, p.Cg - 1)) / p.cpdg;
-      const int key = t * p.DG + dgi;
-      if (key != tap_key) {
-        float y, x, m;
-        TapGeom geo;
-        if (live) tap_position(p, pb, dgi, t, hw, oy, ox, y, x, m); else { y = x = 0.f; m = 0.f; }
-        make_tap(y, x, p.H, p.W, live, m, tap, geo);
-        tap_key = key;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = min(c0 + j, p.Cg - 1);  // padded channels read a valid plane; their weights are 0
-        const float *plane = xb + (long long)c * HW;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[j][q] = plane[tap.o[q]];
-      }
+    auto stage_key = [&](int s, int &t, int &c0, int &dgi) {
+      t = s / p.chunks_per_tap;
+      c0 = (s - t * p.chunks_per_tap) * kChunk + cq * 4;
+      dgi = (p.c_base + min(c0, p.Cg - 1)) / p.cpdg;
+      return t * p.DG + dgi;
     };
-    // interpolate and park the stage's samples in LDS: B[k = cq*4 + j][n_local]
-    auto gather_commit = [&](float *Bdst) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float s = tap.w[0] * v[j][0] + tap.w[1] * v[j][1] + tap.w[2] * v[j][2] + tap.w[3] * v[j][3];
-        Bdst[(cq * 4 + j) * kTileN + n_local] = s;
-      }
+    auto fetch_raw = [&](int s) {  // position + mask of stage s's tap -> raw_*
+      int t, c0, dgi;
+      raw_key = stage_key(s, t, c0, dgi);
+      if (live) tap_position(p, pb, dgi, t, hw, oy, ox, raw_y, raw_x, raw_m);
+      else { raw_y = raw_x = 0.f; raw_m = 0.f; }
+    };
+    auto issue_channel = [&](int s, int j) {
+      int t, c0, dgi;
+      stage_key(s, t, c0, dgi);
+      const int c = min(c0 + j, p.Cg - 1);  // padded channels read a valid plane; their weights are 0
+      const float *plane = xb + (long long)c * HW;
+      v[j][0] = *reinterpret_cast<const f32x2u *>(plane + tap.o[0]);
+      v[j][1] = *reinterpret_cast<const f32x2u *>(plane + tap.o[1]);
+    };
+    auto commit_channel = [&](float *Bdst, int j) {
+      const float sv = tap.w[0] * v[j][0][0] + tap.w[1] * v[j][0][1] + tap.w[2] * v[j][1][0] + tap.w[3] * v[j][1][1];
+      Bdst[(cq * 4 + j) * kTileN + n_local] = sv;
     };
     auto stage_w = [&](int s, float *Adst) {
       const int t = s / p.chunks_per_tap;
@@ -139,21 +142,58 @@ __global__ __launch_bounds__(kThreads, 2) void dcn_fwd_mfma(const DcnProblem p, 
       stage_weights(p, t, c0, m0, Adst, tid);
     };
 
-    // prologue: stage s_begin into buffer 0
-    stage_w(s_begin, As);
-    gather_issue(s_begin);
-    gather_commit(Bs);
+    // prologue: build stage s_begin in buffer 0
+    int tap_key;
+    {
+      fetch_raw(s_begin);
+      make_tap_pair(raw_y, raw_x, p.H, p.W, live, raw_m, tap);
+      tap_key = raw_key;
+      stage_w(s_begin, As);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) issue_channel(s_begin, j);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) commit_channel(Bs, j);
+      if (s_begin + 1 < s_end) fetch_raw(s_begin + 1);
+    }
     __syncthreads();
 
+    const int kk = lane >> 5, l31 = lane & 31;
     int buf = 0;
     for (int s = s_begin; s < s_end; ++s) {
       const bool more = (s + 1) < s_end;
+      const float *A = As + buf * kLdsA + wm * 64 + l31;
+      const float *Bv = Bs + buf * kLdsB + wn * 64 + l31;
+      float *Bnext = Bs + (buf ^ 1) * kLdsB;
       if (more) {
         stage_w(s + 1, As + (buf ^ 1) * kLdsA);
-        gather_issue(s + 1);
+        if (raw_key != tap_key) {  // the stage being built starts a new tap: VALU only, operands prefetched
+          make_tap_pair(raw_y, raw_x, p.H, p.W, live, raw_m, tap);
+          tap_key = raw_key;
+        }
       }
-      mfma_stage(As + buf * kLdsA, kTileM, Bs + buf * kLdsB, kTileN, wm * 64, wn * 64, lane, acc);
-      if (more) gather_commit(Bs + (buf ^ 1) * kLdsB);
+      float a0 = A[kk * kTileM], a1 = A[kk * kTileM + 32], b0 = Bv[kk * kTileN], b1 = Bv[kk * kTileN + 32];
+#pragma unroll
+      for (int ks = 0; ks < kChunk / 2; ++ks) {
+        if (more) {
+          if (ks < 4) issue_channel(s + 1, ks);
+          else commit_channel(Bnext, ks - 4);
+        }
+        float na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+        if (ks + 1 < kChunk / 2) {
+          const int k = 2 * (ks + 1) + kk;
+          na0 = A[k * kTileM]; na1 = A[k * kTileM + 32]; nb0 = Bv[k * kTileN]; nb1 = Bv[k * kTileN + 32];
+        }
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        __builtin_amdgcn_sched_barrier(0);  // keep the slices where they are written
+      }
+      if (more && (s + 2) < s_end) {  // raw position of the tap after next (used only if it differs)
+        int t2, c2, d2;
+        if (stage_key(s + 2, t2, c2, d2) != tap_key) fetch_raw(s + 2);
+      }
       __syncthreads();
       buf ^= 1;
     }
