@@ -65,17 +65,19 @@ constexpr size_t kMaxLds = 160 * 1024;
 // LDS-privatised backward-input: one (image, 32-channel slice) plane set must fit in LDS
 struct BwdLdsPlan {
   bool ok;
-  int n_cslices, S, n_blocks, n_pblocks, n_slices_total;
-  size_t lds_bytes, slab_floats, off_floats, mask_floats;
+  int n_cslices, S, n_blocks, n_pblocks, n_slices_total, HWp;
+  size_t lds_bytes, slab_floats, off_floats, mask_floats, rowptr_ints, entry_pairs, index_lds_bytes;
 };
 
 BwdLdsPlan plan_bwd_lds(const kgdet_dcn_shape *s, const Derived &d) {
   BwdLdsPlan pl{};
-  pl.lds_bytes = (size_t)32 * s->H * s->W * sizeof(float);
+  pl.HWp = (int)align_up((size_t)d.Ho * d.Wo, 64);
+  pl.lds_bytes = (size_t)32 * pl.HWp * sizeof(float) + 8 * 256 * 8;  // colgrad tile [32][HWp] + 8 entry windows
   const int cpdg = s->C / s->deformable_groups;
   // a 32-channel slice must not straddle deformable groups
   const bool dg_ok = s->deformable_groups == 1 || cpdg % d.Cg == 0 || (d.Cg % cpdg == 0 && cpdg % 32 == 0);
-  pl.ok = pl.lds_bytes <= kMaxLds && dg_ok;
+  pl.index_lds_bytes = ((size_t)2 * s->H * s->W + 2) * sizeof(int) + (size_t)4 * d.Ho * d.Wo * 8;
+  pl.ok = pl.lds_bytes <= kMaxLds && pl.index_lds_bytes <= kMaxLds - 64 && s->H * s->W <= 17 * 64 && dg_ok;
   pl.n_cslices = ceil_div(d.Cg, 32);
   const int pairs = s->N * pl.n_cslices;
   pl.S = grid_size() / pairs;
@@ -87,6 +89,8 @@ BwdLdsPlan plan_bwd_lds(const kgdet_dcn_shape *s, const Derived &d) {
   pl.slab_floats = (size_t)pl.n_blocks * 32 * s->H * s->W;
   pl.off_floats = (size_t)pl.n_slices_total * s->N * 2 * d.K * d.Ho * d.Wo;
   pl.mask_floats = pl.off_floats / 2;
+  pl.rowptr_ints = (size_t)s->N * s->deformable_groups * d.K * ((size_t)s->H * s->W + 1);
+  pl.entry_pairs = (size_t)s->N * s->deformable_groups * d.K * 4 * d.Ho * d.Wo;
   return pl;
 }
 
@@ -142,7 +146,9 @@ size_t kgdet_dcn_workspace_bytes(const kgdet_dcn_shape *s) {
   // slabs for stream-K partial tiles + (backward-weight) a packed gradient image
   const size_t fwd_and_wgrad = slab_bytes() + (size_t)s->groups * d.fwd_image_floats() * sizeof(float);
   const BwdLdsPlan pl = plan_bwd_lds(s, d);
-  const size_t bwd_in = pl.ok ? (pl.slab_floats + pl.off_floats + pl.mask_floats) * sizeof(float) : 0;
+  const size_t bwd_in = pl.ok ? (pl.slab_floats + pl.off_floats + pl.mask_floats) * sizeof(float) +
+                                    pl.rowptr_ints * sizeof(int) + pl.entry_pairs * 8 + 64
+                              : 0;
   return fwd_and_wgrad > bwd_in ? fwd_and_wgrad : bwd_in;
 }
 
@@ -238,8 +244,9 @@ int kgdet_deform_conv_backward_input(const kgdet_dcn_shape *s, const float *inpu
   const int cpdg = s->C / s->deformable_groups;
   const BwdLdsPlan pl = plan_bwd_lds(s, d);
   if (pl.ok) {
-    // LDS-privatised path: no global atomics, outputs need no pre-zeroing
-    const size_t need = (pl.slab_floats + pl.off_floats + pl.mask_floats) * sizeof(float);
+    // gather path: no atomics anywhere, outputs need no pre-zeroing
+    const size_t need = (pl.slab_floats + pl.off_floats + pl.mask_floats) * sizeof(float) +
+                        pl.rowptr_ints * sizeof(int) + pl.entry_pairs * 8 + 64;
     if (workspace == nullptr || workspace_bytes < need) {
       set_error("workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
       return KGDET_E_WORKSPACE;
@@ -247,11 +254,22 @@ int kgdet_deform_conv_backward_input(const kgdet_dcn_shape *s, const float *inpu
     float *slabs = (float *)workspace;
     float *off_part = slabs + pl.slab_floats;
     float *mask_part = mask ? off_part + pl.off_floats : nullptr;
+    int2 *entries = (int2 *)align_up((size_t)(off_part + pl.off_floats + pl.mask_floats), 16);
+    int *row_ptr = (int *)(entries + pl.entry_pairs);
     static thread_local bool attr_set = false;
     if (!attr_set) {
-      KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_bwd_input_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
+      KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_bwd_input_gather, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)kMaxLds));
+      KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_bwd_build_index, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)kMaxLds - 64));
       attr_set = true;
+    }
+    {
+      DcnProblem p;
+      fill_problem(s, d, 0, p);
+      p.x = input; p.offset = offset; p.mask = mask;
+      hipLaunchKernelGGL(dcn_bwd_build_index, dim3(s->N * s->deformable_groups * d.K), dim3(256),
+                         pl.index_lds_bytes, (hipStream_t)stream, p, row_ptr, entries);
     }
     for (int g = 0; g < s->groups; ++g) {
       DcnProblem p;
@@ -262,7 +280,9 @@ int kgdet_deform_conv_backward_input(const kgdet_dcn_shape *s, const float *inpu
       a.grad_out = grad_output; a.slabs = slabs; a.off_part = off_part; a.mask_part = mask_part;
       a.Og_pad16 = d.Og_pad16; a.Cg_pad256 = d.Cg_pad256;
       a.n_cslices = pl.n_cslices; a.S = pl.S; a.n_pblocks = pl.n_pblocks; a.slice_base = g * pl.n_cslices;
-      hipLaunchKernelGGL(dcn_bwd_input_lds, dim3(pl.n_blocks), dim3(kThreads), pl.lds_bytes, (hipStream_t)stream, p, a);
+      a.HWp = pl.HWp;
+      hipLaunchKernelGGL(dcn_bwd_input_gather, dim3(pl.n_blocks), dim3(kThreads), pl.lds_bytes, (hipStream_t)stream,
+                         p, a, (const int *)row_ptr, (const int2 *)entries);
       hipLaunchKernelGGL(dcn_bwd_input_fixup, dim3(ceil_div(32 * s->H * s->W, 256 * 4), s->N * pl.n_cslices), dim3(256),
                          0, (hipStream_t)stream, p, a, grad_input);
     }
@@ -272,7 +292,7 @@ int kgdet_deform_conv_backward_input(const kgdet_dcn_shape *s, const float *inpu
     hipLaunchKernelGGL(dcn_bwd_offset_fixup, dim3(fix_grid), dim3(256), 0, (hipStream_t)stream,
                        (const float *)off_part, (const float *)mask_part, grad_offset, grad_mask, pl.n_slices_total,
                        s->N, s->deformable_groups, d.K, d.Ho * d.Wo, pl.n_cslices, d.Cg, cpdg);
-    KGDET_CHECK_LAUNCH("dcn_bwd_input_lds");
+    KGDET_CHECK_LAUNCH("dcn_bwd_input_gather");
     return KGDET_OK;
   }
   // large feature maps: global-atomic path (grad_input must be zero-filled by the caller)

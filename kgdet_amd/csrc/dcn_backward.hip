@@ -76,8 +76,10 @@ __global__ __launch_bounds__(kThreads, 2) void dcn_bwd_input_mfma(const DcnProbl
     auto g_issue = [&](int s) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int o = s * kChunk + kq * 4 + j;
-        gv[j] = (live && o < p.Og) ? gsrc[(long long)o * p.HoWo] : 0.0f;
+        // unconditional load from a clamped row (a select would make hipcc branch + drain vmcnt);
+        // rows >= Og meet zero weights, dead pixels are never stored
+        const int o = min(s * kChunk + kq * 4 + j, p.Og - 1);
+        gv[j] = gsrc[(long long)o * p.HoWo];
       }
     };
     auto g_commit = [&](float *Bdst) {
@@ -271,8 +273,10 @@ __global__ __launch_bounds__(kThreads, 2) void dcn_bwd_weight_mfma(const DcnProb
       const float *gsrc = a.grad_out + ((long long)b * p.O_total + p.o_base) * p.HoWo + hw;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int o = ot * kTileM + sub + 32 * j;
-        gv[j] = (live && o < p.Og) ? gsrc[(long long)o * p.HoWo] : 0.0f;
+        // unconditional load from a clamped row: padded o rows are never unpacked, dead pixels carry
+        // zero samples on the B side
+        const int o = min(ot * kTileM + sub + 32 * j, p.Og - 1);
+        gv[j] = gsrc[(long long)o * p.HoWo];
       }
       // B: samples; all four channels must share a deformable group -> tap per thread and stage
       const int c_first = ct * kTileN + sub;

@@ -95,21 +95,31 @@ __global__ __launch_bounds__(kThreads, 2) void dcn_fwd_mfma(const DcnProblem p, 
     const int pb = live ? pix / p.HoWo : 0;
     const int hw = live ? pix - pb * p.HoWo : 0;
     const int oy = hw / p.Wo, ox = hw - oy * p.Wo;
-    const float *xb = p.x + ((long long)pb * p.C_total + p.c_base) * HW;
+    const unsigned xb_off = ((unsigned)pb * (unsigned)p.C_total + (unsigned)p.c_base) * (unsigned)HW;  // elements
 
     f32x16 acc[2][2];
     zero_acc(acc);
 
     // ---- software-pipelined stage loop -------------------------------------------------------------
-    // Iteration s multiplies stage s out of LDS buffer `buf` while it builds stage s+1 in the other
-    // buffer.  The build work is sliced between the eight 4-MFMA k-steps so that every slice issues in
-    // the shadow of the 256 MFMA cycles that precede it: k-steps 0-3 issue the gathers of one channel
-    // each, k-steps 4-7 interpolate one channel each and park it in LDS; operand fragments of the next
-    // k-step are fetched before the current MFMAs; the raw offsets of the next tap are fetched one
-    // stage early, so a tap change costs VALU only.
-    TapPair tap;             // tap of the stage being BUILT
-    f32x2u v[4][2];          // its gathered corner pairs: [channel][row]
-    float raw_y = 0.f, raw_x = 0.f, raw_m = 0.f;  // prefetched position of the following tap
+    // Two stages deep, entirely with compiler-visible loads (so hipcc's counted s_waitcnt vmcnt(N) stay
+    // exact and nothing ever drains the queue): iteration s multiplies stage s out of LDS buffer s&1,
+    //   - k-steps 0-3: ISSUE the loads of stage s+2 (4 x 2 corner-pair gathers + the 16 KiB weight stage
+    //     as 2 x 16 B per thread) into one register set,
+    //   - k-steps 4-7: COMMIT stage s+1 from the other register set (interpolate -> B, weights -> A of
+    //     LDS buffer (s+1)&1), loaded one iteration earlier,
+    // so every load has ~1.5 stage times (> 3 us) to land, which covers the L2-miss latency of the
+    // weight stream (a one-stage-deep LDS-DMA version measured 1.7 us per stage with nothing else to do).
+    // Every slice issues in the shadow of the MFMAs before it; operand fragments of the next k-step are
+    // fetched before the current MFMAs; raw offsets of an upcoming tap are fetched a stage early.
+    struct StageRegs {
+      f32x2u v[4][2];  // gathered corner pairs [channel][row]
+      f32x4 a[2];      // this thread's 2 x 16 B of the weight stage
+      float w[4];      // bilinear weights the gathers belong to
+    };
+    StageRegs R0, R1;
+    TapPair tap;       // tap used by the loads being ISSUED
+    int tap_key = -1;
+    float raw_y = 0.f, raw_x = 0.f, raw_m = 0.f;  // prefetched position of an upcoming tap
     int raw_key = -1;
 
     auto stage_key = [&](int s, int &t, int &c0, int &dgi) {
@@ -118,65 +128,90 @@ __global__ __launch_bounds__(kThreads, 2) void dcn_fwd_mfma(const DcnProblem p, 
       dgi = (p.c_base + min(c0, p.Cg - 1)) / p.cpdg;
       return t * p.DG + dgi;
     };
-    auto fetch_raw = [&](int s) {  // position + mask of stage s's tap -> raw_*
+    auto fetch_raw = [&](int s) {
       int t, c0, dgi;
       raw_key = stage_key(s, t, c0, dgi);
       if (live) tap_position(p, pb, dgi, t, hw, oy, ox, raw_y, raw_x, raw_m);
       else { raw_y = raw_x = 0.f; raw_m = 0.f; }
     };
-    auto issue_channel = [&](int s, int j) {
+    auto retarget_tap = [&](int s) {  // make `tap` the tap of stage s (VALU only: raw_* already hold it)
+      int t, c0, dgi;
+      const int key = stage_key(s, t, c0, dgi);
+      if (key != tap_key) {
+        if (raw_key != key) fetch_raw(s);  // prologue only
+        make_tap_pair(raw_y, raw_x, p.H, p.W, live, raw_m, tap);
+        tap_key = key;
+      }
+    };
+    auto issue_gather = [&](int s, int j, StageRegs &R) {
       int t, c0, dgi;
       stage_key(s, t, c0, dgi);
       const int c = min(c0 + j, p.Cg - 1);  // padded channels read a valid plane; their weights are 0
-      const float *plane = xb + (long long)c * HW;
-      v[j][0] = *reinterpret_cast<const f32x2u *>(plane + tap.o[0]);
-      v[j][1] = *reinterpret_cast<const f32x2u *>(plane + tap.o[1]);
+      // uniform base + 32-bit byte offset => saddr addressing, one VGPR per address (tensors are < 2 GiB)
+      const unsigned plane_off = xb_off + (unsigned)c * (unsigned)HW;
+      const char *base = reinterpret_cast<const char *>(p.x);
+      R.v[j][0] = *reinterpret_cast<const f32x2u *>(base + (size_t)((plane_off + (unsigned)tap.o[0]) * 4u));
+      R.v[j][1] = *reinterpret_cast<const f32x2u *>(base + (size_t)((plane_off + (unsigned)tap.o[1]) * 4u));
     };
-    auto commit_channel = [&](float *Bdst, int j) {
-      const float sv = tap.w[0] * v[j][0][0] + tap.w[1] * v[j][0][1] + tap.w[2] * v[j][1][0] + tap.w[3] * v[j][1][1];
-      Bdst[(cq * 4 + j) * kTileN + n_local] = sv;
-    };
-    auto stage_w = [&](int s, float *Adst) {
+    auto issue_weights = [&](int s, StageRegs &R) {
       const int t = s / p.chunks_per_tap;
       const int c0 = (s - t * p.chunks_per_tap) * kChunk;
-      stage_weights(p, t, c0, m0, Adst, tid);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int q = tid + kThreads * r;  // float4 index inside the [16][256] stage
+        const int k = q >> 6, col4 = q & 63;
+        const unsigned woff = ((unsigned)(t * p.Cg_pad + c0 + k) * (unsigned)p.Og_pad + (unsigned)(m0 + col4 * 4)) * 4u;
+        R.a[r] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(p.wpk) + (size_t)woff);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) R.w[q] = tap.w[q];
+    };
+    auto commit_gather = [&](float *Bdst, int j, const StageRegs &R) {
+      const float sv = R.w[0] * R.v[j][0][0] + R.w[1] * R.v[j][0][1] + R.w[2] * R.v[j][1][0] + R.w[3] * R.v[j][1][1];
+      Bdst[(cq * 4 + j) * kTileN + n_local] = sv;
+    };
+    auto commit_weights = [&](float *Adst, const StageRegs &R) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) *reinterpret_cast<f32x4 *>(Adst + (tid + kThreads * r) * 4) = R.a[r];
     };
 
-    // prologue: build stage s_begin in buffer 0
-    int tap_key;
-    {
-      fetch_raw(s_begin);
-      make_tap_pair(raw_y, raw_x, p.H, p.W, live, raw_m, tap);
-      tap_key = raw_key;
-      stage_w(s_begin, As);
+    // prologue: stage s_begin straight into buffer 0, loads of stage s_begin+1 in flight in R1
+    retarget_tap(s_begin);
+    issue_weights(s_begin, R0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) issue_channel(s_begin, j);
+    for (int j = 0; j < 4; ++j) issue_gather(s_begin, j, R0);
+    if (s_begin + 1 < s_end) {
+      retarget_tap(s_begin + 1);
+      issue_weights(s_begin + 1, R1);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) commit_channel(Bs, j);
-      if (s_begin + 1 < s_end) fetch_raw(s_begin + 1);
+      for (int j = 0; j < 4; ++j) issue_gather(s_begin + 1, j, R1);
     }
+    commit_weights(As, R0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) commit_gather(Bs, j, R0);
+    if (s_begin + 2 < s_end) fetch_raw(s_begin + 2);
     __syncthreads();
 
     const int kk = lane >> 5, l31 = lane & 31;
-    int buf = 0;
-    for (int s = s_begin; s < s_end; ++s) {
-      const bool more = (s + 1) < s_end;
+    // one stage: MFMAs of stage s from buffer s&1; ISSUE stage s+2 into RI; COMMIT stage s+1 from RC
+    auto run_stage = [&](int s, StageRegs &RI, StageRegs &RC) {
+      const int buf = (s - s_begin) & 1;
+      const bool do_issue = (s + 2) < s_end, do_commit = (s + 1) < s_end;
       const float *A = As + buf * kLdsA + wm * 64 + l31;
       const float *Bv = Bs + buf * kLdsB + wn * 64 + l31;
-      float *Bnext = Bs + (buf ^ 1) * kLdsB;
-      if (more) {
-        stage_w(s + 1, As + (buf ^ 1) * kLdsA);
-        if (raw_key != tap_key) {  // the stage being built starts a new tap: VALU only, operands prefetched
-          make_tap_pair(raw_y, raw_x, p.H, p.W, live, raw_m, tap);
-          tap_key = raw_key;
-        }
-      }
+      float *Anext = As + (buf ^ 1) * kLdsA, *Bnext = Bs + (buf ^ 1) * kLdsB;
+      if (do_issue) retarget_tap(s + 2);
       float a0 = A[kk * kTileM], a1 = A[kk * kTileM + 32], b0 = Bv[kk * kTileN], b1 = Bv[kk * kTileN + 32];
 #pragma unroll
       for (int ks = 0; ks < kChunk / 2; ++ks) {
-        if (more) {
-          if (ks < 4) issue_channel(s + 1, ks);
-          else commit_channel(Bnext, ks - 4);
+        if (ks < 4) {
+          if (do_issue) {
+            if (ks == 0) issue_weights(s + 2, RI);
+            issue_gather(s + 2, ks, RI);
+          }
+        } else if (do_commit) {
+          if (ks == 4) commit_weights(Anext, RC);
+          commit_gather(Bnext, ks - 4, RC);
         }
         float na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
         if (ks + 1 < kChunk / 2) {
@@ -190,12 +225,15 @@ __global__ __launch_bounds__(kThreads, 2) void dcn_fwd_mfma(const DcnProblem p, 
         a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
         __builtin_amdgcn_sched_barrier(0);  // keep the slices where they are written
       }
-      if (more && (s + 2) < s_end) {  // raw position of the tap after next (used only if it differs)
-        int t2, c2, d2;
-        if (stage_key(s + 2, t2, c2, d2) != tap_key) fetch_raw(s + 2);
+      if ((s + 3) < s_end) {  // raw position of the tap three stages ahead, only if it is a new one
+        int t3, c3, d3;
+        if (stage_key(s + 3, t3, c3, d3) != tap_key) fetch_raw(s + 3);
       }
       __syncthreads();
-      buf ^= 1;
+    };
+    for (int s = s_begin; s < s_end; s += 2) {
+      run_stage(s, R0, R1);
+      if (s + 1 < s_end) run_stage(s + 1, R1, R0);
     }
 
     if (s_begin == 0 && s_end == cpt) {

@@ -33,8 +33,11 @@ struct DcnBwdInputLdsArgs {
   float *off_part;   // [n_slices_total][N][2K][HoWo] per-slice partial offset gradients
   float *mask_part;  // [n_slices_total][N][K][HoWo] or nullptr
   int Og_pad16, Cg_pad256, n_cslices, S, n_pblocks, slice_base;
+  int HWp;           // row stride of the LDS colgrad tile (output pixels of one image, padded)
 };
-__global__ void dcn_bwd_input_lds(const DcnProblem p, const DcnBwdInputLdsArgs a);
+__global__ void dcn_bwd_build_index(const DcnProblem p, int *__restrict__ row_ptr, int2 *__restrict__ entries);
+__global__ void dcn_bwd_input_gather(const DcnProblem p, const DcnBwdInputLdsArgs a, const int *__restrict__ row_ptr,
+                                     const int2 *__restrict__ entries);
 __global__ void dcn_bwd_input_fixup(const DcnProblem p, const DcnBwdInputLdsArgs a, float *__restrict__ grad_input);
 __global__ void dcn_bwd_offset_fixup(const float *__restrict__ off_part, const float *__restrict__ mask_part,
                                      float *__restrict__ grad_offset, float *__restrict__ grad_mask, int n_slices,
