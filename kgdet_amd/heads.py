@@ -111,8 +111,92 @@ class Kp3RepBlock(nn.Module):
         return cls_out, keypts_out, reppts_out
 
 
+class PointHeadMixin(object):
+    """point-set helpers shared by the KGDet head and the serial / parallel two-stage heads
+    (identical code in KP3:342-410, 497-579 and reppoints_head_kp_serial.py:187-252, 341-423)"""
+
+    def points2bbox(self, pts, y_first=True):
+        """point set [B, 2n, H, W] -> box [B, 4, H, W] (x1, y1, x2, y2), KP3:342-391"""
+        pts_reshape = pts.reshape(pts.shape[0], -1, 2, *pts.shape[2:])
+        pts_y = pts_reshape[:, :, 0, ...] if y_first else pts_reshape[:, :, 1, ...]
+        pts_x = pts_reshape[:, :, 1, ...] if y_first else pts_reshape[:, :, 0, ...]
+        if self.transform_method == 'minmax':
+            pass
+        elif self.transform_method == 'partial_minmax':
+            pts_y = pts_y[:, :4, ...]
+            pts_x = pts_x[:, :4, ...]
+        elif self.transform_method == 'moment':
+            moment_transfer = (self.moment_transfer * self.moment_mul) + (
+                self.moment_transfer.detach() * (1 - self.moment_mul))
+            if pts.dim() == 2:  # [N, 2n] point sets (serial head loss): one "location" per row
+                return moment.moment_bbox(pts.reshape(pts.shape[0], -1, 1, 1), moment_transfer, y_first).reshape(-1, 4)
+            return moment.moment_bbox(pts, moment_transfer, y_first)
+        else:
+            raise NotImplementedError
+        return torch.cat([pts_x.min(dim=1, keepdim=True)[0], pts_y.min(dim=1, keepdim=True)[0],
+                          pts_x.max(dim=1, keepdim=True)[0], pts_y.max(dim=1, keepdim=True)[0]], dim=1)
+
+    def points2kpt(self, pts, y_first=True):
+        """(y, x) interleaved -> (x, y) interleaved channel order, KP3:393-410"""
+        pts_reshape = pts.reshape(pts.shape[0], -1, 2, *pts.shape[2:])
+        pts_y = pts_reshape[:, :, 0, ...] if y_first else pts_reshape[:, :, 1, ...]
+        pts_x = pts_reshape[:, :, 1, ...] if y_first else pts_reshape[:, :, 0, ...]
+        return torch.stack([pts_x, pts_y], dim=2).reshape(*pts.shape)
+
+    def get_points(self, featmap_sizes, img_metas, device='cuda'):
+        """grid centres and valid flags of every image and level (KP3:497-535)"""
+        num_imgs = len(img_metas)
+        num_levels = len(featmap_sizes)
+        multi_level_points = [
+            self.point_generators[i].grid_points(featmap_sizes[i], self.point_strides[i], device=device)
+            for i in range(num_levels)
+        ]
+        points_list = [[point.clone() for point in multi_level_points] for _ in range(num_imgs)]
+        valid_flag_list = []
+        for img_meta in img_metas:
+            multi_level_flags = []
+            for i in range(num_levels):
+                point_stride = self.point_strides[i]
+                feat_h, feat_w = featmap_sizes[i]
+                h, w, _ = img_meta['pad_shape']
+                valid_feat_h = min(int(np.ceil(h / point_stride)), feat_h)
+                valid_feat_w = min(int(np.ceil(w / point_stride)), feat_w)
+                multi_level_flags.append(self.point_generators[i].valid_flags(
+                    (feat_h, feat_w), (valid_feat_h, valid_feat_w), device=device))
+            valid_flag_list.append(multi_level_flags)
+        return points_list, valid_flag_list
+
+    def centers_to_bboxes(self, point_list):
+        """pseudo boxes of side point_base_scale*stride around the centres (MaxIoUAssigner only)"""
+        bbox_list = []
+        for point in point_list:
+            bbox = []
+            for i_lvl in range(len(self.point_strides)):
+                scale = self.point_base_scale * self.point_strides[i_lvl] * 0.5
+                bbox_shift = torch.Tensor([-scale, -scale, scale, scale]).view(1, 4).type_as(point[0])
+                bbox_center = torch.cat([point[i_lvl][:, :2], point[i_lvl][:, :2]], dim=1)
+                bbox.append(bbox_center + bbox_shift)
+            bbox_list.append(bbox)
+        return bbox_list
+
+    def offset_to_pts(self, center_list, pred_list, y_first=True):
+        """per level [B, H*W, 2n] image coordinates (x, y interleaved) = offset * stride + centre"""
+        num_points = pred_list[0].size(1) // 2
+        pts_list = []
+        for i_lvl in range(len(self.point_strides)):
+            pred = pred_list[i_lvl]                                       # [B, 2n, H, W]
+            B = pred.shape[0]
+            shift = pred.permute(0, 2, 3, 1).reshape(B, -1, num_points, 2)
+            if y_first:
+                shift = shift.flip(-1)                                    # (y, x) -> (x, y)
+            centers = torch.stack([center_list[i_img][i_lvl][:, :2] for i_img in range(B)], 0)
+            pts = shift * self.point_strides[i_lvl] + centers.unsqueeze(2)
+            pts_list.append(pts.reshape(B, -1, 2 * num_points))
+        return pts_list
+
+
 @HEADS.register_module
-class RepPointsHeadKp3RepCas1AssignOnce(nn.Module):
+class RepPointsHeadKp3RepCas1AssignOnce(PointHeadMixin, nn.Module):
     """Three-stage keypoint-guided RepPoints head (stage 1 plain, stages 2-3 deformable), one target
     assignment shared by all stages."""
 
@@ -195,33 +279,6 @@ class RepPointsHeadKp3RepCas1AssignOnce(nn.Module):
         for m in self.reg_convs:
             normal_init(m.conv, std=0.01)
 
-    # ------------------------------------------------------------------------------------------
-    def points2bbox(self, pts, y_first=True):
-        """point set [B, 2n, H, W] -> box [B, 4, H, W] (x1, y1, x2, y2), KP3:342-391"""
-        pts_reshape = pts.reshape(pts.shape[0], -1, 2, *pts.shape[2:])
-        pts_y = pts_reshape[:, :, 0, ...] if y_first else pts_reshape[:, :, 1, ...]
-        pts_x = pts_reshape[:, :, 1, ...] if y_first else pts_reshape[:, :, 0, ...]
-        if self.transform_method == 'minmax':
-            pass
-        elif self.transform_method == 'partial_minmax':
-            pts_y = pts_y[:, :4, ...]
-            pts_x = pts_x[:, :4, ...]
-        elif self.transform_method == 'moment':
-            moment_transfer = (self.moment_transfer * self.moment_mul) + (
-                self.moment_transfer.detach() * (1 - self.moment_mul))
-            return moment.moment_bbox(pts, moment_transfer, y_first)
-        else:
-            raise NotImplementedError
-        return torch.cat([pts_x.min(dim=1, keepdim=True)[0], pts_y.min(dim=1, keepdim=True)[0],
-                          pts_x.max(dim=1, keepdim=True)[0], pts_y.max(dim=1, keepdim=True)[0]], dim=1)
-
-    def points2kpt(self, pts, y_first=True):
-        """(y, x) interleaved -> (x, y) interleaved channel order, KP3:393-410"""
-        pts_reshape = pts.reshape(pts.shape[0], -1, 2, *pts.shape[2:])
-        pts_y = pts_reshape[:, :, 0, ...] if y_first else pts_reshape[:, :, 1, ...]
-        pts_x = pts_reshape[:, :, 1, ...] if y_first else pts_reshape[:, :, 0, ...]
-        return torch.stack([pts_x, pts_y], dim=2).reshape(*pts.shape)
-
     def forward_single(self, x):
         cls_feat = x
         pts_feat = x
@@ -268,58 +325,6 @@ class RepPointsHeadKp3RepCas1AssignOnce(nn.Module):
         if self.flip_forward:
             return multi_apply(self.forward_single_flip, feats, img_metas=img_metas)
         return multi_apply(self.forward_single, feats)
-
-    # ------------------------------------------------------------------------------------------
-    def get_points(self, featmap_sizes, img_metas, device='cuda'):
-        """grid centres and valid flags of every image and level (KP3:497-535)"""
-        num_imgs = len(img_metas)
-        num_levels = len(featmap_sizes)
-        multi_level_points = [
-            self.point_generators[i].grid_points(featmap_sizes[i], self.point_strides[i], device=device)
-            for i in range(num_levels)
-        ]
-        points_list = [[point.clone() for point in multi_level_points] for _ in range(num_imgs)]
-        valid_flag_list = []
-        for img_meta in img_metas:
-            multi_level_flags = []
-            for i in range(num_levels):
-                point_stride = self.point_strides[i]
-                feat_h, feat_w = featmap_sizes[i]
-                h, w, _ = img_meta['pad_shape']
-                valid_feat_h = min(int(np.ceil(h / point_stride)), feat_h)
-                valid_feat_w = min(int(np.ceil(w / point_stride)), feat_w)
-                multi_level_flags.append(self.point_generators[i].valid_flags(
-                    (feat_h, feat_w), (valid_feat_h, valid_feat_w), device=device))
-            valid_flag_list.append(multi_level_flags)
-        return points_list, valid_flag_list
-
-    def centers_to_bboxes(self, point_list):
-        """pseudo boxes of side point_base_scale*stride around the centres (MaxIoUAssigner only)"""
-        bbox_list = []
-        for point in point_list:
-            bbox = []
-            for i_lvl in range(len(self.point_strides)):
-                scale = self.point_base_scale * self.point_strides[i_lvl] * 0.5
-                bbox_shift = torch.Tensor([-scale, -scale, scale, scale]).view(1, 4).type_as(point[0])
-                bbox_center = torch.cat([point[i_lvl][:, :2], point[i_lvl][:, :2]], dim=1)
-                bbox.append(bbox_center + bbox_shift)
-            bbox_list.append(bbox)
-        return bbox_list
-
-    def offset_to_pts(self, center_list, pred_list, y_first=True):
-        """per level [B, H*W, 2n] image coordinates (x, y interleaved) = offset * stride + centre"""
-        num_points = pred_list[0].size(1) // 2
-        pts_list = []
-        for i_lvl in range(len(self.point_strides)):
-            pred = pred_list[i_lvl]                                       # [B, 2n, H, W]
-            B = pred.shape[0]
-            shift = pred.permute(0, 2, 3, 1).reshape(B, -1, num_points, 2)
-            if y_first:
-                shift = shift.flip(-1)                                    # (y, x) -> (x, y)
-            centers = torch.stack([center_list[i_img][i_lvl][:, :2] for i_img in range(B)], 0)
-            pts = shift * self.point_strides[i_lvl] + centers.unsqueeze(2)
-            pts_list.append(pts.reshape(B, -1, 2 * num_points))
-        return pts_list
 
     def loss_single(self, cls_score_1, cls_score_2, cls_score_3, kpt_pred_1, kpt_pred_2, kpt_pred_3, bbox_pred_1,
                     bbox_pred_2, bbox_pred_3, labels, label_weights, bbox_gt, bbox_weights, kpt_gt, kpt_weights,

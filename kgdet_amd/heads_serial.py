@@ -1,0 +1,351 @@
+"""Two-stage (init -> refine) keypoint RepPoints heads over the whole FPN pyramid:
+``RepPointsHeadKpSerial`` and ``RepPointsHeadKpParallel`` (BASELINE config 5).
+
+Host-side mirror of mmdet/models/anchor_heads/reppoints_head_kp_serial.py:16-750 (SER) and
+reppoints_head_kp_parallel.py (identical except that the reppoints get their own conv /
+deformable-conv branch instead of being regressed from the keypoints, :153-168, 314-315, 331-332).
+Same registered names, constructor arguments and parameter names.  Per level one 3x3 deformable
+conv for classification and one for keypoints (plus one for reppoints in the parallel head), all
+through the HIP kernel; the init stage is assigned by ``PointAssigner``, the refine stage by
+``MaxIoUAssigner`` on the boxes of the init reppoints (SER:551-573).
+
+Reference quirks kept so that outputs stay identical: the decode step clamps ``kpts[:, 0::3]`` /
+``kpts[:, 1::3]`` (the keypoint axis, SER:723-724) where the KGDet head clamps the coordinate axis;
+keypoint weights are normalised per row without the x4 of the KGDet head (SER:469-477).
+"""
+from __future__ import division
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import dcn
+from .heads import PointHeadMixin
+from .layers import ConvModule, bias_init_with_prob, normal_init
+from .points import PointGenerator, multi_apply, point_target_kp
+from .postprocess import multiclass_nms_kp
+from .registry import HEADS, build_loss
+
+
+class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
+    parallel_reppts = False  # True: reppoints have their own conv branches (parallel head)
+
+    def __init__(self,
+                 num_classes,
+                 in_channels,
+                 feat_channels=256,
+                 point_feat_channels=256,
+                 stacked_convs=3,
+                 num_reppts=9,
+                 num_keypts=17,
+                 gradient_mul=0.1,
+                 point_strides=[8, 16, 32, 64, 128],
+                 point_base_scale=4,
+                 conv_cfg=None,
+                 norm_cfg=None,
+                 loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+                 loss_bbox_init=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=0.5),
+                 loss_bbox_refine=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0),
+                 loss_kpt_init=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=0.5),
+                 loss_kpt_refine=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0),
+                 use_grid_points=False,
+                 center_init=True,
+                 transform_method='moment',
+                 moment_mul=0.01):
+        super().__init__()
+        self.in_channels = in_channels
+        self.num_classes = num_classes
+        self.feat_channels = feat_channels
+        self.point_feat_channels = point_feat_channels
+        self.stacked_convs = stacked_convs
+        self.num_keypts = num_keypts
+        self.num_reppts = num_reppts
+        self.gradient_mul = gradient_mul
+        self.point_base_scale = point_base_scale
+        self.point_strides = point_strides
+        self.conv_cfg = conv_cfg
+        self.norm_cfg = norm_cfg
+        self.use_sigmoid_cls = loss_cls.get('use_sigmoid', False)
+        self.sampling = loss_cls['type'] not in ['FocalLoss']
+        self.loss_cls = build_loss(loss_cls)
+        self.loss_bbox_init = build_loss(loss_bbox_init)
+        self.loss_bbox_refine = build_loss(loss_bbox_refine)
+        self.loss_kpt_init = build_loss(loss_kpt_init)
+        self.loss_kpt_refine = build_loss(loss_kpt_refine)
+        self.use_grid_points = use_grid_points
+        self.center_init = center_init
+        self.transform_method = transform_method
+        if self.transform_method == 'moment':
+            self.moment_transfer = nn.Parameter(data=torch.zeros(2), requires_grad=True)
+            self.moment_mul = moment_mul
+        self.cls_out_channels = self.num_classes - 1 if self.use_sigmoid_cls else self.num_classes
+        self.point_generators = [PointGenerator() for _ in self.point_strides]
+        # the reppoints are the taps of a sqrt(n) x sqrt(n) deformable conv
+        self.dcn_kernel = int(np.sqrt(num_reppts))
+        self.dcn_pad = int((self.dcn_kernel - 1) / 2)
+        assert self.dcn_kernel * self.dcn_kernel == num_reppts, 'The points number should be a square number.'
+        assert self.dcn_kernel % 2 == 1, 'The points number should be an odd square number.'
+        base = np.arange(-self.dcn_pad, self.dcn_pad + 1).astype(np.float64)
+        yx = np.stack([np.repeat(base, self.dcn_kernel), np.tile(base, self.dcn_kernel)], axis=1).reshape(-1)
+        self.dcn_base_offset = torch.tensor(yx).view(1, -1, 1, 1)
+        self._init_layers()
+
+    def _init_layers(self):
+        self.relu = nn.ReLU(inplace=False)
+        self.cls_convs = nn.ModuleList()
+        self.reg_convs = nn.ModuleList()
+        for i in range(self.stacked_convs):
+            chn = self.in_channels if i == 0 else self.feat_channels
+            self.cls_convs.append(ConvModule(chn, self.feat_channels, 3, stride=1, padding=1,
+                                             conv_cfg=self.conv_cfg, norm_cfg=self.norm_cfg))
+            self.reg_convs.append(ConvModule(chn, self.feat_channels, 3, stride=1, padding=1,
+                                             conv_cfg=self.conv_cfg, norm_cfg=self.norm_cfg))
+        keypts_out_dim = 2 * self.num_keypts
+        reppts_out_dim = 2 * self.num_reppts
+        fc, pc, k, pad = self.feat_channels, self.point_feat_channels, self.dcn_kernel, self.dcn_pad
+        self.cls_refine_dfmconv = dcn.DeformConv(fc, pc, k, 1, pad)
+        self.cls_refine_out = nn.Conv2d(pc, self.cls_out_channels, 1, 1, 0)
+        self.keypts_init_conv = nn.Conv2d(fc, pc, 3, 1, 1)
+        self.keypts_init_out = nn.Conv2d(pc, keypts_out_dim, 1, 1, 0)
+        if self.parallel_reppts:
+            self.reppts_init_conv = nn.Conv2d(fc, pc, 3, 1, 1)
+        self.reppts_init_out = nn.Conv2d(pc if self.parallel_reppts else keypts_out_dim, reppts_out_dim, 1, 1, 0)
+        self.keypts_refine_dfmconv = dcn.DeformConv(fc, pc, k, 1, pad)
+        self.keypts_refine_out = nn.Conv2d(pc, keypts_out_dim, 1, 1, 0)
+        if self.parallel_reppts:
+            self.reppts_refine_dfmconv = dcn.DeformConv(fc, pc, k, 1, pad)
+        self.reppts_refine_out = nn.Conv2d(pc if self.parallel_reppts else keypts_out_dim, reppts_out_dim, 1, 1, 0)
+
+    def init_weights(self):
+        for m in self.cls_convs:
+            normal_init(m.conv, std=0.01)
+        for m in self.reg_convs:
+            normal_init(m.conv, std=0.01)
+        bias_cls = bias_init_with_prob(0.01)
+        normal_init(self.cls_refine_dfmconv, std=0.01)
+        normal_init(self.cls_refine_out, std=0.01, bias=bias_cls)
+        normal_init(self.keypts_init_conv, std=0.01)
+        normal_init(self.keypts_init_out, std=0.01)
+        normal_init(self.reppts_init_out, std=0.01)
+        normal_init(self.keypts_refine_dfmconv, std=0.01)
+        normal_init(self.keypts_refine_out, std=0.01)
+        normal_init(self.reppts_refine_out, std=0.01)
+        if self.parallel_reppts:
+            normal_init(self.reppts_init_conv, std=0.01)
+            normal_init(self.reppts_refine_dfmconv, std=0.01)
+
+    def _dfm(self, conv, feat, offset):
+        """relu(deform_conv) with the ReLU fused into the kernel epilogue"""
+        return dcn.deform_conv_cat(feat, [offset], [conv.weight], [self.dcn_pad])
+
+    def forward_single(self, x):
+        dcn_base_offset = self.dcn_base_offset.type_as(x)
+        if self.use_grid_points or not self.center_init:
+            scale = self.point_base_scale / 2
+            reppts_init = dcn_base_offset / dcn_base_offset.max() * scale
+            keypts_init = 0
+        else:
+            reppts_init = 0
+            keypts_init = 0
+        cls_feat = x
+        pts_feat = x
+        for cls_conv in self.cls_convs:
+            cls_feat = cls_conv(cls_feat)
+        for reg_conv in self.reg_convs:
+            pts_feat = reg_conv(pts_feat)
+        # init stage
+        keypts_out_init = self.keypts_init_out(self.relu(self.keypts_init_conv(pts_feat)))
+        if self.parallel_reppts:
+            reppts_out_init = self.reppts_init_out(self.relu(self.reppts_init_conv(pts_feat)))
+        else:
+            reppts_out_init = self.reppts_init_out(keypts_out_init)
+        reppts_out_init = reppts_out_init + reppts_init
+        keypts_out_init = keypts_out_init + keypts_init
+        # refine stage: taps on the (gradient-scaled) init reppoints
+        grad_mul = self.gradient_mul * reppts_out_init + (1 - self.gradient_mul) * reppts_out_init.detach()
+        dcn_offset = grad_mul - dcn_base_offset
+        cls_out = self.cls_refine_out(self._dfm(self.cls_refine_dfmconv, cls_feat, dcn_offset))
+        keypts_out_refine = self.keypts_refine_out(self._dfm(self.keypts_refine_dfmconv, pts_feat, dcn_offset))
+        if self.parallel_reppts:
+            reppts_out_refine = self.reppts_refine_out(self._dfm(self.reppts_refine_dfmconv, pts_feat, dcn_offset))
+        else:
+            reppts_out_refine = self.reppts_refine_out(keypts_out_refine)
+        keypts_out_refine = keypts_out_refine + keypts_out_init.detach()
+        reppts_out_refine = reppts_out_refine + reppts_out_init.detach()
+        return (cls_out, keypts_out_init, keypts_out_refine, reppts_out_init, reppts_out_refine)
+
+    def forward(self, feats, img_metas):
+        return multi_apply(self.forward_single, feats)
+
+    # ------------------------------------------------------------------------------------------
+    def loss_single(self, cls_score, kpt_pred_init, kpt_pred_refine, rep_pred_init, rep_pred_refine, labels,
+                    label_weights, bbox_gt_init, bbox_weights_init, bbox_gt_refine, bbox_weights_refine, kpt_gt_init,
+                    kpt_weights_init, kpt_gt_refine, kpt_weights_refine, stride, num_total_samples_init,
+                    num_total_samples_refine):
+        labels = labels.reshape(-1)
+        label_weights = label_weights.reshape(-1)
+        cls_score = cls_score.permute(0, 2, 3, 1).reshape(-1, self.cls_out_channels)
+        loss_cls = self.loss_cls(cls_score, labels, label_weights, avg_factor=num_total_samples_refine)
+
+        normalize_term = self.point_base_scale * stride
+        bbox_pred_init = self.points2bbox(rep_pred_init.reshape(-1, 2 * self.num_reppts), y_first=False)
+        bbox_pred_refine = self.points2bbox(rep_pred_refine.reshape(-1, 2 * self.num_reppts), y_first=False)
+        loss_bbox_init = self.loss_bbox_init(bbox_pred_init / normalize_term,
+                                             bbox_gt_init.reshape(-1, 4) / normalize_term,
+                                             bbox_weights_init.reshape(-1, 4), avg_factor=num_total_samples_init)
+        loss_bbox_refine = self.loss_bbox_refine(bbox_pred_refine / normalize_term,
+                                                 bbox_gt_refine.reshape(-1, 4) / normalize_term,
+                                                 bbox_weights_refine.reshape(-1, 4),
+                                                 avg_factor=num_total_samples_refine)
+
+        def kpt_loss(loss_fn, pred, gt, weights, avg):
+            weights = weights.reshape(-1, self.num_keypts * 2)
+            pos_num = weights.sum(1)
+            weights[pos_num > 0] /= pos_num[pos_num > 0].unsqueeze(1)   # in place on the target, as SER:469-477
+            return loss_fn(pred.reshape(-1, self.num_keypts * 2) / normalize_term,
+                           gt.reshape(-1, self.num_keypts * 2) / normalize_term, weights, avg_factor=avg)
+
+        loss_kpt_init = kpt_loss(self.loss_kpt_init, kpt_pred_init, kpt_gt_init, kpt_weights_init,
+                                 num_total_samples_init)
+        loss_kpt_refine = kpt_loss(self.loss_kpt_refine, kpt_pred_refine, kpt_gt_refine, kpt_weights_refine,
+                                   num_total_samples_refine)
+        return loss_cls, loss_bbox_init, loss_bbox_refine, loss_kpt_init, loss_kpt_refine
+
+    def loss(self, cls_scores, keypts_preds_init, keypts_preds_refine, reppts_preds_init, reppts_preds_refine,
+             gt_bboxes, gt_labels, gt_keypoints, img_metas, cfg, gt_bboxes_ignore=None):
+        featmap_sizes = [featmap.size()[-2:] for featmap in cls_scores]
+        assert len(featmap_sizes) == len(self.point_generators)
+        label_channels = self.cls_out_channels if self.use_sigmoid_cls else 1
+        device = cls_scores[0].device
+
+        # init stage targets
+        center_list, valid_flag_list = self.get_points(featmap_sizes, img_metas, device=device)
+        kpt_coord_init = self.offset_to_pts(center_list, keypts_preds_init)
+        rep_coord_init = self.offset_to_pts(center_list, reppts_preds_init)
+        if cfg.init.assigner['type'] == 'PointAssigner':
+            candidate_list = center_list
+        else:
+            candidate_list = self.centers_to_bboxes(center_list)
+        targets_init = point_target_kp(candidate_list, valid_flag_list, gt_bboxes, gt_keypoints, img_metas, cfg.init,
+                                       gt_bboxes_ignore_list=gt_bboxes_ignore, gt_labels_list=gt_labels,
+                                       label_channels=label_channels, sampling=self.sampling)
+        (*_, bbox_gt_list_init, candidate_list_init, bbox_weights_list_init, keypoint_gt_list_init,
+         keypoint_weights_list_init, num_total_pos_init, num_total_neg_init) = targets_init
+        num_total_samples_init = (num_total_pos_init + num_total_neg_init if self.sampling else num_total_pos_init)
+
+        # refine stage targets: boxes of the (detached) init reppoints, MaxIoUAssigner
+        center_list, valid_flag_list = self.get_points(featmap_sizes, img_metas, device=device)
+        kpt_coord_refine = self.offset_to_pts(center_list, keypts_preds_refine)
+        rep_coord_refine = self.offset_to_pts(center_list, reppts_preds_refine)
+        init_boxes = [self.points2bbox(reppts_preds_init[i_lvl].detach()) * self.point_strides[i_lvl]
+                      for i_lvl in range(len(reppts_preds_refine))]
+        bbox_list = []
+        for i_img, center in enumerate(center_list):
+            bbox = []
+            for i_lvl in range(len(reppts_preds_refine)):
+                bbox_center = torch.cat([center[i_lvl][:, :2], center[i_lvl][:, :2]], dim=1)
+                bbox.append(bbox_center + init_boxes[i_lvl][i_img].permute(1, 2, 0).reshape(-1, 4))
+            bbox_list.append(bbox)
+        targets_refine = point_target_kp(bbox_list, valid_flag_list, gt_bboxes, gt_keypoints, img_metas, cfg.refine,
+                                         gt_bboxes_ignore_list=gt_bboxes_ignore, gt_labels_list=gt_labels,
+                                         label_channels=label_channels, sampling=self.sampling)
+        (labels_list, label_weights_list, bbox_gt_list_refine, candidate_list_refine, bbox_weights_list_refine,
+         keypoint_gt_list_refine, keypoint_weights_list_refine, num_total_pos_refine,
+         num_total_neg_refine) = targets_refine
+        num_total_samples_refine = (num_total_pos_refine + num_total_neg_refine
+                                    if self.sampling else num_total_pos_refine)
+
+        per_level = multi_apply(self.loss_single, cls_scores, kpt_coord_init, kpt_coord_refine, rep_coord_init,
+                                rep_coord_refine, labels_list, label_weights_list, bbox_gt_list_init,
+                                bbox_weights_list_init, bbox_gt_list_refine, bbox_weights_list_refine,
+                                keypoint_gt_list_init, keypoint_weights_list_init, keypoint_gt_list_refine,
+                                keypoint_weights_list_refine, self.point_strides,
+                                num_total_samples_init=num_total_samples_init,
+                                num_total_samples_refine=num_total_samples_refine)
+        names = ['loss_cls', 'loss_bbox_init', 'loss_bbox_refine', 'loss_kpt_init', 'loss_kpt_refine']
+        return dict(zip(names, per_level))
+
+    # ------------------------------------------------------------------------------------------
+    def get_bboxes(self, cls_scores, keypts_preds_init, keypts_preds_refine, reppts_preds_init, reppts_preds_refine,
+                   img_metas, cfg, rescale=False, nms=True):
+        assert len(cls_scores) == len(keypts_preds_refine) == len(reppts_preds_refine)
+        bbox_preds_refine = [self.points2bbox(r) for r in reppts_preds_refine]
+        kpt_preds_refine = [self.points2kpt(k) for k in keypts_preds_refine]
+        num_levels = len(cls_scores)
+        device = cls_scores[0].device
+        mlvl_points = [self.point_generators[i].grid_points(cls_scores[i].size()[-2:], self.point_strides[i],
+                                                            device=device) for i in range(num_levels)]
+        result_list = []
+        for img_id in range(len(img_metas)):
+            result_list.append(self.get_bboxes_single(
+                [cls_scores[i][img_id].detach() for i in range(num_levels)],
+                [bbox_preds_refine[i][img_id].detach() for i in range(num_levels)],
+                [kpt_preds_refine[i][img_id].detach() for i in range(num_levels)], mlvl_points,
+                img_metas[img_id]['img_shape'], img_metas[img_id]['scale_factor'], cfg, rescale, nms))
+        return result_list
+
+    def get_bboxes_single(self, cls_scores, bbox_preds, kpt_preds, mlvl_points, img_shape, scale_factor, cfg,
+                          rescale=False, nms=True):
+        assert len(cls_scores) == len(bbox_preds) == len(mlvl_points) == len(kpt_preds)
+        mlvl_bboxes, mlvl_kpts, mlvl_scores = [], [], []
+        num_kpt = self.num_keypts
+        num_kp_channel = kpt_preds[0].size(0) // num_kpt
+        assert num_kp_channel == 2 or num_kp_channel == 3
+        for i_lvl, (cls_score, bbox_pred, kpt_pred, points) in enumerate(zip(cls_scores, bbox_preds, kpt_preds,
+                                                                             mlvl_points)):
+            assert cls_score.size()[-2:] == bbox_pred.size()[-2:] == kpt_pred.size()[-2:]
+            cls_score = cls_score.permute(1, 2, 0).reshape(-1, self.cls_out_channels)
+            scores = cls_score.sigmoid() if self.use_sigmoid_cls else cls_score.softmax(-1)
+            bbox_pred = bbox_pred.permute(1, 2, 0).reshape(-1, 4)
+            if num_kp_channel == 3:
+                kpt_pred = kpt_pred.permute(1, 2, 0).reshape(-1, num_kpt * num_kp_channel)
+            else:
+                kpt_pred = kpt_pred.permute(1, 2, 0).reshape(-1, num_kpt, num_kp_channel)
+                kpt_pred = torch.cat([kpt_pred, kpt_pred.new_full(kpt_pred[:, :, :1].size(), 1)], dim=2)
+                kpt_pred = kpt_pred.reshape(-1, num_kpt * 3)
+            nms_pre = cfg.get('nms_pre', -1)
+            if nms_pre > 0 and scores.shape[0] > nms_pre:
+                max_scores, _ = scores.max(dim=1) if self.use_sigmoid_cls else scores[:, 1:].max(dim=1)
+                _, topk_inds = max_scores.topk(nms_pre)
+                points = points[topk_inds, :]
+                bbox_pred = bbox_pred[topk_inds, :]
+                kpt_pred = kpt_pred[topk_inds, :]
+                scores = scores[topk_inds, :]
+            bbox_pos_center = torch.cat([points[:, :2], points[:, :2]], dim=1)
+            bboxes = bbox_pred * self.point_strides[i_lvl] + bbox_pos_center
+            kpts = kpt_pred.view(-1, num_kpt, 3).clone()
+            kpts[:, :, :2] = kpts[:, :, :2] * self.point_strides[i_lvl] + points[:, :2].unsqueeze(dim=1)
+            bboxes = torch.stack([bboxes[:, 0].clamp(min=0, max=img_shape[1]),
+                                  bboxes[:, 1].clamp(min=0, max=img_shape[0]),
+                                  bboxes[:, 2].clamp(min=0, max=img_shape[1]),
+                                  bboxes[:, 3].clamp(min=0, max=img_shape[0])], dim=-1)
+            # reference quirk (SER:723-724): the slice runs over the keypoint axis, not the coordinate axis
+            kpts[:, 0::3] = kpts[:, 0::3].clamp(min=0, max=img_shape[1])
+            kpts[:, 1::3] = kpts[:, 1::3].clamp(min=0, max=img_shape[0])
+            mlvl_bboxes.append(bboxes)
+            mlvl_scores.append(scores)
+            mlvl_kpts.append(kpts)
+        mlvl_bboxes = torch.cat(mlvl_bboxes)
+        mlvl_kpts = torch.cat(mlvl_kpts)
+        if rescale:
+            mlvl_bboxes /= mlvl_bboxes.new_tensor(scale_factor)
+            mlvl_kpts[:, :, 0:2] = mlvl_kpts[:, :, 0:2] / mlvl_kpts.new_tensor(scale_factor)
+            mlvl_kpts = mlvl_kpts.reshape(-1, num_kpt * 3)
+        mlvl_scores = torch.cat(mlvl_scores)
+        if self.use_sigmoid_cls:
+            mlvl_scores = torch.cat([mlvl_scores.new_zeros(mlvl_scores.shape[0], 1), mlvl_scores], dim=1)
+        if nms:
+            return multiclass_nms_kp(mlvl_bboxes, mlvl_scores, mlvl_kpts, cfg.score_thr, cfg.nms, cfg.max_per_img)
+        return mlvl_bboxes, mlvl_scores, mlvl_kpts
+
+
+@HEADS.register_module
+class RepPointsHeadKpSerial(_RepPointsHeadKpTwoStage):
+    """reppoints regressed from the keypoint maps (1x1 conv on keypts_out)"""
+    parallel_reppts = False
+
+
+@HEADS.register_module
+class RepPointsHeadKpParallel(_RepPointsHeadKpTwoStage):
+    """reppoints predicted by their own conv / deformable-conv branch"""
+    parallel_reppts = True

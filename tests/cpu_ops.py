@@ -15,6 +15,8 @@ def deform_conv_cat(x, offsets, weights, paddings, relu=True):
 
 
 def moment_bbox(pts, mt, y_first=True):
+    if pts.dim() == 2:
+        return moment_bbox(pts.reshape(pts.shape[0], -1, 1, 1), mt, y_first).reshape(-1, 4)
     B, C2, H, W = pts.shape
     r = pts.view(B, -1, 2, H, W)
     py = r[:, :, 0] if y_first else r[:, :, 1]

@@ -98,3 +98,63 @@ def test_detector_train_and_batched_inference():
     for a, b in zip(res[0], one):
         if isinstance(a, list):
             assert all(np.allclose(x, y, atol=1e-3) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize('parallel', [False, True])
+def test_serial_parallel_heads_match_cpu_reference_path(parallel):
+    """config 5 heads: HIP forward / losses vs the same module run through the test-side CPU ops"""
+    from kgdet_amd.registry import build_head
+    from tests import cpu_ops
+    torch.manual_seed(0)
+    cfg = configs.reppoints_kp_r50_fpn(parallel=parallel)
+    hc = cfg.model.bbox_head.copy()
+    hc.update(in_channels=32, feat_channels=32, point_feat_channels=32, point_strides=[8, 16, 32],
+              norm_cfg=dict(type='GN', num_groups=8, requires_grad=True))
+    head = build_head(hc)
+    head.init_weights()
+    g = torch.Generator().manual_seed(3)
+    for m in (head.reppts_init_out, head.keypts_init_out):
+        m.weight.data.normal_(0, 0.2 if m is head.reppts_init_out and not parallel else 0.05, generator=g)
+    feats = [torch.randn(2, 32, 32 // s, 40 // s, generator=g) for s in (1, 2, 4)]
+    batch = synthetic.make_batch(2, 'cpu', seed=4, img_shape=(256, 320, 3), pad_shape=(256, 320, 3))
+    for k in ('gt_bboxes', 'gt_keypoints'):
+        batch[k] = [t.clamp(max=250) for t in batch[k]]
+    with cpu_ops.patched():
+        ref_outs = head(feats, batch['img_meta'])
+        ref_losses = head.loss(*ref_outs, batch['gt_bboxes'], batch['gt_labels'], batch['gt_keypoints'],
+                               batch['img_meta'], cfg.train_cfg)
+        ref_losses = {k: sum(float(t) for t in v) for k, v in ref_losses.items()}
+    head = head.cuda()
+    outs = head([f.cuda() for f in feats], batch['img_meta'])
+    for lvl in range(3):
+        for a, b in zip(outs, ref_outs):
+            assert _rel(a[lvl].detach().cpu().numpy(), b[lvl].detach().numpy()) < 2e-4
+    to = lambda l: [t.cuda() for t in l]
+    losses = head.loss(*outs, to(batch['gt_bboxes']), to(batch['gt_labels']), to(batch['gt_keypoints']),
+                       batch['img_meta'], cfg.train_cfg)
+    for k, v in losses.items():
+        got = sum(float(t) for t in v)
+        assert abs(got - ref_losses[k]) < 5e-4 * max(1.0, abs(ref_losses[k])), (k, got, ref_losses[k])
+    sum(sum(v) for v in losses.values()).backward()
+    assert torch.isfinite(head.keypts_refine_dfmconv.weight.grad).all()
+
+
+def test_config5_detector_with_soft_nms():
+    """serial head on the 5-level pyramid, soft-NMS post-processing (BASELINE config 5), small image"""
+    from kgdet_amd.registry import build_detector
+    cfg = configs.reppoints_kp_r50_fpn(parallel=False, soft_nms=True)
+    torch.manual_seed(0)
+    model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda()
+    batch = synthetic.make_batch(1, 'cuda', seed=1, img_shape=(256, 320, 3), pad_shape=(256, 320, 3))
+    for k in ('gt_bboxes', 'gt_keypoints'):
+        batch[k] = [t.clamp(max=250) for t in batch[k]]
+    model.train()
+    losses = model(batch['img'], batch['img_meta'], return_loss=True, gt_bboxes=batch['gt_bboxes'],
+                   gt_labels=batch['gt_labels'], gt_keypoints=batch['gt_keypoints'])
+    total = sum(sum(v) for v in losses.values())
+    total.backward()
+    assert torch.isfinite(total)
+    model.eval()
+    with torch.no_grad():
+        res = model.simple_test(batch['img'], batch['img_meta'], rescale=True)
+    assert len(res) in (1, 3)

@@ -73,6 +73,50 @@ def test_reference_configs_load_unchanged():
     assert full.model == mine.model
 
 
+@pytest.mark.skipif(not os.path.exists(REF_CFG), reason='reference configs not mounted')
+@pytest.mark.parametrize('name,parallel', [('serial', False), ('parallel', True)])
+def test_reference_serial_parallel_configs_load_unchanged(name, parallel):
+    cfg = Config.fromfile('/root/reference/configs/reppoints_moment_%s_r50_fpn_1x-deepfashion2.py' % name)
+    mine = configs.reppoints_kp_r50_fpn(parallel=parallel)
+    assert cfg.model == mine.model and cfg.train_cfg == mine.train_cfg and cfg.test_cfg == mine.test_cfg
+    head = build_head(cfg.model.bbox_head)
+    keys = set(head.state_dict().keys())
+    assert {'cls_refine_dfmconv.weight', 'keypts_init_conv.weight', 'reppts_init_out.bias',
+            'keypts_refine_dfmconv.weight', 'reppts_refine_out.weight', 'moment_transfer'} <= keys
+    assert ('reppts_refine_dfmconv.weight' in keys) == parallel and ('reppts_init_conv.weight' in keys) == parallel
+    assert tuple(head.reppts_init_out.weight.shape) == ((18, 256, 1, 1) if parallel else (18, 588, 1, 1))
+
+
+@pytest.mark.parametrize('parallel', [False, True])
+def test_serial_parallel_head_forward_loss_decode_on_cpu(parallel):
+    torch.manual_seed(0)
+    cfg = configs.reppoints_kp_r50_fpn(parallel=parallel)
+    hc = cfg.model.bbox_head.copy()
+    hc.update(in_channels=16, feat_channels=16, point_feat_channels=16, point_strides=[8, 16],
+              norm_cfg=dict(type='GN', num_groups=4, requires_grad=True))
+    head = build_head(hc)
+    head.init_weights()
+    feats = [torch.randn(2, 16, 16, 20), torch.randn(2, 16, 8, 10)]
+    batch = synthetic.make_batch(2, 'cpu', seed=2, img_shape=(128, 160, 3), pad_shape=(128, 160, 3))
+    for k in ('gt_bboxes', 'gt_keypoints'):
+        batch[k] = [t.clamp(max=120) for t in batch[k]]
+    with cpu_ops.patched():
+        outs = head(feats, batch['img_meta'])
+        assert len(outs) == 5 and outs[0][0].shape == (2, 13, 16, 20) and outs[3][1].shape == (2, 18, 8, 10)
+        losses = head.loss(*outs, batch['gt_bboxes'], batch['gt_labels'], batch['gt_keypoints'], batch['img_meta'],
+                           cfg.train_cfg)
+        assert sorted(losses) == ['loss_bbox_init', 'loss_bbox_refine', 'loss_cls', 'loss_kpt_init', 'loss_kpt_refine']
+        total = sum(sum(v) for v in losses.values())
+        assert torch.isfinite(total)
+        total.backward()
+        assert head.cls_refine_dfmconv.weight.grad.abs().sum() > 0
+        head.eval()
+        with torch.no_grad():
+            res = head.get_bboxes(*head(feats, batch['img_meta']), batch['img_meta'], cfg.test_cfg, rescale=True,
+                                  nms=False)
+    assert res[0][0].shape == (400, 4) and res[0][1].shape == (400, 14) and res[0][2].shape == (400, 882)
+
+
 def test_checkpoint_key_contract():
     cfg = configs.kgdet_r50_fpn()
     head = build_head(cfg.model.bbox_head)
