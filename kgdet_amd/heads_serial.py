@@ -199,9 +199,12 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
                                                  avg_factor=num_total_samples_refine)
 
         def kpt_loss(loss_fn, pred, gt, weights, avg):
-            weights = weights.reshape(-1, self.num_keypts * 2)
+            # SER:469-477 normalises in place; with one image per GPU the per-level targets are views of one
+            # tensor and the in-place update would invalidate weights autograd saved for another level, so
+            # the normalisation runs on a private copy (same values)
+            weights = weights.reshape(-1, self.num_keypts * 2).clone()
             pos_num = weights.sum(1)
-            weights[pos_num > 0] /= pos_num[pos_num > 0].unsqueeze(1)   # in place on the target, as SER:469-477
+            weights[pos_num > 0] /= pos_num[pos_num > 0].unsqueeze(1)
             return loss_fn(pred.reshape(-1, self.num_keypts * 2) / normalize_term,
                            gt.reshape(-1, self.num_keypts * 2) / normalize_term, weights, avg_factor=avg)
 
