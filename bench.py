@@ -70,7 +70,9 @@ def dcn_roofline(device, iters=30):
     ach = flops / t / 1e12
     return dict(bound='mfma', kernel='dcn_fwd_mfma+dcn_fwd_fixup (7x7, B=2, 256ch, 25x42)', achieved=round(ach, 2),
                 peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                traffic=None, launch_us=round(t * 1e6, 1),
+                # bytes per launch from the committed PMC passes (profiles/r01_dcn_fwd_k7_b2_kernel_stats.md):
+                # (2 x FETCH_SIZE + WRITE_SIZE) KB of dcn_fwd_mfma + dcn_fwd_fixup; cannot be collected live here
+                traffic=3.45e8, algorithmic_bytes=byts, algorithmic_flops=flops, launch_us=round(t * 1e6, 1),
                 hbm_achieved_GBs=round(byts / t / 1e9, 1), hbm_frac=round(byts / t / 1e9 / HBM_PEAK_GBS, 4))
 
 
