@@ -53,6 +53,13 @@ typedef struct kgdet_dcn_shape {
 
 /* flags for the fused epilogue */
 #define KGDET_DCN_RELU 1u /* out = max(out, 0) */
+/* Forward arithmetic.  Default: bf16 MFMA on a hi/lo split of both fp32 operands (3 products, fp32
+ * accumulate; <= 2^-16 relative error per product, i.e. fp32-accurate to ~1e-6 of the output scale).
+ * KGDET_DCN_BF16: operands rounded to bf16 once (autocast inference).  KGDET_DCN_EXACT_FP32: the
+ * v_mfma_f32_32x32x2_f32 kernel, bit-exact fp32 products (also used when a 16-channel slice of one input
+ * image does not fit in LDS: H*W > 1536). */
+#define KGDET_DCN_BF16 2u
+#define KGDET_DCN_EXACT_FP32 4u
 
 /* output spatial size, R/dcn/deform_conv.py:96-110; returns KGDET_E_SHAPE if it is < 1 */
 int kgdet_dcn_output_size(const kgdet_dcn_shape *s, int32_t *Ho, int32_t *Wo);

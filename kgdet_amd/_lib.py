@@ -18,6 +18,8 @@ KGDET_E_HIP = 3
 KGDET_E_UNSUPPORTED = 4
 
 DCN_RELU = 1
+DCN_BF16 = 2         # forward operands rounded to bf16 once (autocast inference)
+DCN_EXACT_FP32 = 4   # forward on the exact-fp32 MFMA kernel instead of the bf16 hi/lo split
 
 
 class DcnShape(ctypes.Structure):

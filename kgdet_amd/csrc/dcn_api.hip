@@ -12,6 +12,8 @@ struct Derived {
   int Og_pad16, Cg_pad256;  // transposed image for backward-input
   size_t fwd_image_floats() const { return (size_t)K * Cg_pad * Og_pad; }
   size_t bwd_image_floats() const { return (size_t)K * Og_pad16 * Cg_pad256; }
+  // bf16 hi/lo image of the plane forward kernel: same element count, 2 x 2 bytes each
+  size_t plane_image_floats() const { return (size_t)K * Cg_pad * Og_pad; }
 };
 
 int derive(const kgdet_dcn_shape *s, Derived &d) {
@@ -99,6 +101,11 @@ BwdLdsPlan plan_bwd_lds(const kgdet_dcn_shape *s, const Derived &d) {
 bool mfma_ok(const kgdet_dcn_shape *s) {
   return s->W >= 2 && ((s->C / s->deformable_groups) % 4 == 0 || s->deformable_groups == 1);
 }
+// plane forward kernel: a 16-channel slice of one input image must fit in LDS next to the operand stages
+constexpr int kPlaneMaxHW = 1536;
+bool plane_ok(const kgdet_dcn_shape *s, const Derived &d) {
+  return mfma_ok(s) && s->H * s->W <= kPlaneMaxHW && (size_t)8 * 33 * (d.K + 1) * sizeof(float) <= kMaxLds - 64;
+}
 // backward tiles (256 / 128 channels wide) must lie inside one deformable group
 bool mfma_bwd_ok(const kgdet_dcn_shape *s) {
   const int cpdg = s->C / s->deformable_groups, Cg = s->C / s->groups;
@@ -137,7 +144,8 @@ size_t kgdet_dcn_packed_weight_bytes(const kgdet_dcn_shape *s) {
   Derived d;
   if (derive(s, d)) return 0;
   // [forward image per group ...][transposed (backward-input) image per group ...]
-  return (size_t)s->groups * (d.fwd_image_floats() + d.bwd_image_floats()) * sizeof(float);
+  // ... [bf16 hi/lo image of the plane forward kernel per group ...]
+  return (size_t)s->groups * (d.fwd_image_floats() + d.bwd_image_floats() + d.plane_image_floats()) * sizeof(float);
 }
 
 size_t kgdet_dcn_workspace_bytes(const kgdet_dcn_shape *s) {
@@ -156,18 +164,37 @@ int kgdet_dcn_pack_weight(const kgdet_dcn_shape *s, const float *weight, float *
   Derived d;
   if (int rc = derive(s, d)) return rc;
   KGDET_CHECK_SHAPE(weight && packed, "null pointer");
+  const size_t lds_all = (size_t)8 * 33 * (d.K + 1) * sizeof(float);
+  const bool fused = lds_all <= kMaxLds - 64;
   const size_t lds = (size_t)64 * (d.K + 1) * sizeof(float);
-  KGDET_CHECK_SHAPE(lds <= 64 * 1024, "kernel %dx%d too large to pack", s->kh, s->kw);
+  KGDET_CHECK_SHAPE(fused || lds <= 64 * 1024, "kernel %dx%d too large to pack", s->kh, s->kw);
+  if (fused) {
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+      KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_pack_weight_all,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds - 64));
+      attr_set = true;
+    }
+  }
   for (int g = 0; g < s->groups; ++g) {
     const float *w = weight + (size_t)g * d.Og * d.Cg * d.K;
     float *dst = packed + (size_t)g * d.fwd_image_floats();
-    dim3 grid(d.Cg_pad, d.Og_pad / 64);
-    hipLaunchKernelGGL(dcn_pack_weight, grid, dim3(256), lds, (hipStream_t)stream, w, dst, d.Og, d.Cg, d.K,
-                       d.Cg_pad, d.Og_pad);
     float *dst_t = packed + (size_t)s->groups * d.fwd_image_floats() + (size_t)g * d.bwd_image_floats();
-    dim3 grid_t(d.Og_pad16, d.Cg_pad256 / 64);
-    hipLaunchKernelGGL(dcn_pack_weight_t, grid_t, dim3(256), lds, (hipStream_t)stream, w, dst_t, d.Og, d.Cg, d.K,
-                       d.Og_pad16, d.Cg_pad256);
+    float *dst_q = packed + (size_t)s->groups * (d.fwd_image_floats() + d.bwd_image_floats()) +
+                   (size_t)g * d.plane_image_floats();
+    if (fused) {
+      dim3 grid(d.Cg_pad256 / 8, d.Og_pad / 32);
+      hipLaunchKernelGGL(dcn_pack_weight_all, grid, dim3(256), lds_all, (hipStream_t)stream, w, dst, dst_t,
+                         plane_ok(s, d) ? (void *)dst_q : nullptr, d.Og, d.Cg, d.K, d.Cg_pad, d.Og_pad,
+                         d.Og_pad16, d.Cg_pad256);
+    } else {
+      dim3 grid(d.Cg_pad, d.Og_pad / 64);
+      hipLaunchKernelGGL(dcn_pack_weight, grid, dim3(256), lds, (hipStream_t)stream, w, dst, d.Og, d.Cg, d.K,
+                         d.Cg_pad, d.Og_pad);
+      dim3 grid_t(d.Og_pad16, d.Cg_pad256 / 64);
+      hipLaunchKernelGGL(dcn_pack_weight_t, grid_t, dim3(256), lds, (hipStream_t)stream, w, dst_t, d.Og, d.Cg, d.K,
+                         d.Og_pad16, d.Cg_pad256);
+    }
   }
   KGDET_CHECK_LAUNCH("dcn_pack_weight");
   return KGDET_OK;
@@ -208,6 +235,17 @@ int kgdet_deform_conv_forward(const kgdet_dcn_shape *s, const float *input, cons
     return KGDET_E_WORKSPACE;
   }
   const int G = grid_size();
+  const bool use_plane = plane_ok(s, d) && !(flags & KGDET_DCN_EXACT_FP32);
+  if (use_plane) {
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+      KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_fwd_plane<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)kMaxLds));
+      KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_fwd_plane<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)kMaxLds));
+      attr_set = true;
+    }
+  }
   for (int g = 0; g < s->groups; ++g) {
     DcnProblem p;
     fill_problem(s, d, g, p);
@@ -218,8 +256,23 @@ int kgdet_deform_conv_forward(const kgdet_dcn_shape *s, const float *input, cons
     p.n_mtiles = d.Og_pad / kTileM;
     p.chunks_per_tap = d.Cg_pad / kChunk;
     p.chunks_per_tile = d.K * p.chunks_per_tap;
+    if (use_plane) {
+      p.wq = packed_weight + (size_t)s->groups * (d.fwd_image_floats() + d.bwd_image_floats()) +
+             (size_t)g * d.plane_image_floats();
+      p.tiles_per_image = ceil_div(p.HoWo, kTileN);
+      p.n_ntiles = p.N * p.tiles_per_image;
+    }
     p.total_units = (long long)p.n_ntiles * p.n_mtiles * p.chunks_per_tile;
-    hipLaunchKernelGGL(dcn_fwd_mfma, dim3(G), dim3(kThreads), 0, (hipStream_t)stream, p, (float *)workspace);
+    if (use_plane) {
+      const int parts = (flags & KGDET_DCN_BF16) ? 1 : 2;
+      const size_t lds = dcn_fwd_plane_lds_bytes(parts, s->H * s->W);
+      if (parts == 1)
+        hipLaunchKernelGGL(dcn_fwd_plane<1>, dim3(G), dim3(kThreads), lds, (hipStream_t)stream, p, (float *)workspace);
+      else
+        hipLaunchKernelGGL(dcn_fwd_plane<2>, dim3(G), dim3(kThreads), lds, (hipStream_t)stream, p, (float *)workspace);
+    } else {
+      hipLaunchKernelGGL(dcn_fwd_mfma, dim3(G), dim3(kThreads), 0, (hipStream_t)stream, p, (float *)workspace);
+    }
     hipLaunchKernelGGL(dcn_fwd_fixup, dim3(p.n_ntiles * p.n_mtiles, 16), dim3(kThreads), 0, (hipStream_t)stream, p,
                        (const float *)workspace, G);
   }

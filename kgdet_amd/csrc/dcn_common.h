@@ -29,6 +29,7 @@ struct DcnProblem {
   const float *offset;  // [N, DG*2K, Ho, Wo]
   const float *mask;    // [N, DG*K, Ho, Wo] or nullptr
   const float *wpk;     // packed weight of this group: [K][Cg_pad][Og_pad]
+  const void *wq;       // bf16 hi/lo image of this group for the plane kernel (dcn_forward_plane.hip)
   const float *bias;    // [O_total] or nullptr
   float *out;           // forward: [N, O_total, Ho, Wo]
   int N, C_total, c_base, Cg, Cg_pad;
@@ -40,8 +41,23 @@ struct DcnProblem {
   int DG, cpdg;  // deformable groups, channels (of C_total) per deformable group
   int n_ntiles, n_mtiles, chunks_per_tap, chunks_per_tile;
   long long total_units;  // n_ntiles * n_mtiles * chunks_per_tile
+  int tiles_per_image;    // > 0: pixel tiles never straddle images (plane kernel); 0: tiles run over N*Ho*Wo
   unsigned flags;
 };
+
+// Output pixel of column `col` of pixel tile `nt`: image b, position hw inside it; false if past the end.
+__device__ __forceinline__ bool tile_pixel(const DcnProblem &p, int nt, int col, int &b, int &hw) {
+  if (p.tiles_per_image > 0) {
+    b = nt / p.tiles_per_image;
+    hw = (nt - b * p.tiles_per_image) * kTileN + col;
+    return hw < p.HoWo;
+  }
+  const int pix = nt * kTileN + col;
+  if (pix >= p.P) { b = 0; hw = 0; return false; }
+  b = pix / p.HoWo;
+  hw = pix - b * p.HoWo;
+  return true;
+}
 
 // stream-K: workgroup g of G owns units [unit_begin(g), unit_begin(g+1))
 __device__ __forceinline__ long long unit_begin(long long g, long long total, long long G) {
@@ -151,6 +167,29 @@ __device__ __forceinline__ void mfma_stage(const float *__restrict__ A, int lda,
 
 // row of accumulator register r inside a 32x32 MFMA block (C/D layout, col = lane & 31)
 __device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// Write one tile (register image) to out[N, O_total, Ho, Wo], with bias / ReLU fused.
+__device__ __forceinline__ void store_output(const DcnProblem &p, int mt, int nt, int tid,
+                                             const f32x16 (&acc)[2][2]) {
+  const int lane = tid & 63, wave = tid >> 6, wm = wave & 3, wn = wave >> 2;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    int b, hw;
+    if (!tile_pixel(p, nt, wn * 64 + ni * 32 + (lane & 31), b, hw)) continue;
+    float *obase = p.out + ((long long)b * p.O_total + p.o_base) * p.HoWo + hw;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = mt * kTileM + wm * 64 + mi * 32 + mfma_row(r, lane);
+        if (o >= p.Og) continue;
+        float v = acc[mi][ni][r];
+        if (p.bias) v += p.bias[p.bias_base + o];
+        if (p.flags & 1u /* KGDET_DCN_RELU */) v = fmaxf(v, 0.0f);
+        obase[(long long)o * p.HoWo] = v;
+      }
+  }
+}
 
 // raw register image of a tile <-> slab (coalesced 16 B per lane)
 __device__ __forceinline__ void store_slab(float *__restrict__ slab, int tid, const f32x16 (&acc)[2][2]) {

@@ -39,30 +39,6 @@ __device__ __forceinline__ void stage_weights(const DcnProblem &p, int t, int c0
   }
 }
 
-// Write one tile (register image) to out[N, O_total, Ho, Wo], with bias / ReLU fused.
-__device__ __forceinline__ void store_output(const DcnProblem &p, int mt, int nt, int tid,
-                                             const f32x16 (&acc)[2][2]) {
-  const int lane = tid & 63, wave = tid >> 6, wm = wave & 3, wn = wave >> 2;
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int pix = nt * kTileN + wn * 64 + ni * 32 + (lane & 31);
-    if (pix >= p.P) continue;
-    const int b = pix / p.HoWo, hw = pix - b * p.HoWo;
-    float *obase = p.out + ((long long)b * p.O_total + p.o_base) * p.HoWo + hw;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = mt * kTileM + wm * 64 + mi * 32 + mfma_row(r, lane);
-        if (o >= p.Og) continue;
-        float v = acc[mi][ni][r];
-        if (p.bias) v += p.bias[p.bias_base + o];
-        if (p.flags & KGDET_DCN_RELU) v = fmaxf(v, 0.0f);
-        obase[(long long)o * p.HoWo] = v;
-      }
-  }
-}
-
 }  // namespace
 
 __global__ __launch_bounds__(kThreads, 2) void dcn_fwd_mfma(const DcnProblem p, float *__restrict__ slabs) {
@@ -274,9 +250,8 @@ __global__ __launch_bounds__(kThreads) void dcn_fwd_fixup(const DcnProblem p, co
   const int mi = j >> 3, ni = (j >> 2) & 1, q = j & 3;
   const int mt = tile % p.n_mtiles, nt = tile / p.n_mtiles;
   const int lane = tid & 63, wave = tid >> 6, wm = wave & 3, wn = wave >> 2;
-  const int pix = nt * kTileN + wn * 64 + ni * 32 + (lane & 31);
-  if (pix >= p.P) return;
-  const int b = pix / p.HoWo, hw = pix - b * p.HoWo;
+  int b, hw;
+  if (!tile_pixel(p, nt, wn * 64 + ni * 32 + (lane & 31), b, hw)) return;
   float *obase = p.out + ((long long)b * p.O_total + p.o_base) * p.HoWo + hw;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {

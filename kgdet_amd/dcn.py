@@ -62,6 +62,40 @@ def _output_size(input, weight, padding, dilation, stride):
     return output_size
 
 
+# Forward arithmetic of the HIP kernels (include/kgdet_hip.h, KGDET_DCN_*):
+#   'split' (default)  bf16 MFMA on a hi/lo split of both fp32 operands: fp32-accurate (~1e-6 of the output scale)
+#   'bf16'             operands rounded to bf16 once, fp32 accumulate -- what autocast(bfloat16) inference asks for
+#   'exact'            v_mfma_f32_32x32x2_f32, bit-exact fp32 products
+_FORWARD_PRECISION = 'split'
+_PRECISION_FLAGS = {'split': 0, 'bf16': _lib.DCN_BF16, 'exact': _lib.DCN_EXACT_FP32}
+
+
+def set_forward_precision(mode):
+    """Select the forward arithmetic ('split' | 'bf16' | 'exact'); returns the previous mode."""
+    global _FORWARD_PRECISION
+    if mode not in _PRECISION_FLAGS:
+        raise ValueError('unknown DeformConv forward precision {!r}'.format(mode))
+    prev, _FORWARD_PRECISION = _FORWARD_PRECISION, mode
+    return prev
+
+
+class forward_precision(object):
+    """Context manager: ``with dcn.forward_precision('bf16'): ...``"""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = set_forward_precision(self.mode)
+
+    def __exit__(self, *exc):
+        set_forward_precision(self.prev)
+
+
+def _fwd_flags(relu):
+    return ctypes.c_uint32((_lib.DCN_RELU if relu else 0) | _PRECISION_FLAGS[_FORWARD_PRECISION])
+
+
 def pack_weight(weight, shape):
     """weight [O, C/g, kh, kw] -> MFMA-friendly image [g][K][C/g pad16][O/g pad256] (device)."""
     L = _lib.lib()
@@ -103,7 +137,7 @@ def _forward(input, offset, mask, weight, bias, shape, packed=None, relu=False):
     ws = _workspace(input.device, ws_bytes)
     _lib.check(L.kgdet_deform_conv_forward(
         ctypes.byref(shape), _lib.ptr(input), _lib.ptr(offset), _lib.ptr(mask), _lib.ptr(packed),
-        _lib.ptr(bias), _lib.ptr(output), ctypes.c_uint32(_lib.DCN_RELU if relu else 0),
+        _lib.ptr(bias), _lib.ptr(output), _fwd_flags(relu),
         _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.current_stream()), 'kgdet_deform_conv_forward')
     return output, packed
 
@@ -369,7 +403,7 @@ class DeformConvCatFunction(Function):
             ws = _workspace(x.device, L.kgdet_dcn_workspace_bytes(ctypes.byref(s)))
             _lib.check(L.kgdet_deform_conv_forward(
                 ctypes.byref(s), _lib.ptr(x), _lib.ptr(offset), None, _lib.ptr(packed), None, _lib.ptr(out),
-                ctypes.c_uint32(_lib.DCN_RELU if relu else 0), _lib.ptr(ws), ctypes.c_size_t(ws.numel()),
+                _fwd_flags(relu), _lib.ptr(ws), ctypes.c_size_t(ws.numel()),
                 _lib.current_stream()), 'kgdet_deform_conv_forward')
             shapes.append(s)
             packs.append(packed)

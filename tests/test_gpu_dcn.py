@@ -50,36 +50,46 @@ def _close(actual, desired, tol=2e-5):
     assert err < tol, 'max error %.3e of output scale (tol %.1e)' % (err, tol)
 
 
+# forward arithmetic modes (include/kgdet_hip.h KGDET_DCN_*) and the error each must stay under, as a
+# fraction of the output scale: the bf16 hi/lo split and the exact-fp32 kernel share the fp32 bound;
+# single-rounded bf16 operands (autocast inference) carry 2^-9 per operand.
+PRECISIONS = [('split', 2e-5), ('exact', 2e-5), ('bf16', 1e-2)]
+
+
+@pytest.mark.parametrize('prec,tol', PRECISIONS)
 @pytest.mark.parametrize('case', CASES)
-def test_forward_v1(case):
+def test_forward_v1(case, prec, tol):
     _require_gpu()
     from kgdet_amd import dcn
     N, C, H, W, O, k, s, p, d, g, dg = case
     x, off, w, _, _ = _make(case)
-    out = dcn.deform_conv(torch.from_numpy(x).cuda(), torch.from_numpy(off).cuda(),
-                          torch.from_numpy(w).cuda(), s, p, d, g, dg)
+    with dcn.forward_precision(prec):
+        out = dcn.deform_conv(torch.from_numpy(x).cuda(), torch.from_numpy(off).cuda(),
+                              torch.from_numpy(w).cuda(), s, p, d, g, dg)
     torch.cuda.synchronize()
     ref64 = oracle.deform_conv_forward(x.astype(np.float64), off.astype(np.float64), w.astype(np.float64),
                                        s, p, d, g, dg)
     assert out.shape == ref64.shape
-    _close(out.cpu().numpy(), ref64)
+    _close(out.cpu().numpy(), ref64, tol)
     ref32 = oracle.deform_conv_forward(x, off, w, s, p, d, g, dg)
-    _close(out.cpu().numpy(), ref32.astype(np.float64))
+    _close(out.cpu().numpy(), ref32.astype(np.float64), tol)
 
 
+@pytest.mark.parametrize('prec,tol', PRECISIONS)
 @pytest.mark.parametrize('case', CASES[:3] + CASES[5:8])
-def test_forward_v2_mask_bias(case):
+def test_forward_v2_mask_bias(case, prec, tol):
     _require_gpu()
     from kgdet_amd import dcn
     N, C, H, W, O, k, s, p, d, g, dg = case
     x, off, w, _, mask = _make(case, seed=1, with_mask=True)
     bias = np.linspace(-1, 1, O).astype(np.float32)
-    out = dcn.modulated_deform_conv(torch.from_numpy(x).cuda(), torch.from_numpy(off).cuda(),
-                                    torch.from_numpy(mask).cuda(), torch.from_numpy(w).cuda(),
-                                    torch.from_numpy(bias).cuda(), s, p, d, g, dg)
+    with dcn.forward_precision(prec):
+        out = dcn.modulated_deform_conv(torch.from_numpy(x).cuda(), torch.from_numpy(off).cuda(),
+                                        torch.from_numpy(mask).cuda(), torch.from_numpy(w).cuda(),
+                                        torch.from_numpy(bias).cuda(), s, p, d, g, dg)
     ref64 = oracle.deform_conv_forward(x.astype(np.float64), off.astype(np.float64), w.astype(np.float64),
                                        s, p, d, g, dg, mask=mask.astype(np.float64), bias=bias.astype(np.float64))
-    _close(out.cpu().numpy(), ref64)
+    _close(out.cpu().numpy(), ref64, tol)
 
 
 def test_forward_deterministic_and_zero_offset_is_conv():

@@ -29,16 +29,20 @@ def main():
         w = torch.randn(C, C, k, k, device=dev) * 0.01
         shape = dcn._shape(x, w, (1, 1), (k // 2, k // 2), (1, 1), 1, 1)
         packed = dcn.pack_weight(w, shape)
-        for _ in range(3):
-            dcn._forward(x, off, None, w, None, shape, packed=packed)
-        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.iters):
-            dcn._forward(x, off, None, w, None, shape, packed=packed)
-        e1.record()
-        torch.cuda.synchronize()
-        t = e0.elapsed_time(e1) / args.iters * 1e-3
+        tf = {}
+        for prec in ('split', 'bf16', 'exact'):
+            with dcn.forward_precision(prec):
+                for _ in range(3):
+                    dcn._forward(x, off, None, w, None, shape, packed=packed)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(args.iters):
+                    dcn._forward(x, off, None, w, None, shape, packed=packed)
+                e1.record()
+                torch.cuda.synchronize()
+            tf[prec] = e0.elapsed_time(e1) / args.iters * 1e-3
+        t = tf['split']
         flops = 2.0 * C * C * K * B * H * W
         byts = 4.0 * (2 * B * C * H * W + 2 * B * K * H * W + C * C * K)
         # backward
@@ -62,7 +66,8 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         tpack = e0.elapsed_time(e1) / args.iters * 1e-3
-        rows.append(dict(B=B, H=H, W=W, k=k, us=round(t * 1e6, 1), tflops=round(flops / t / 1e12, 1),
+        rows.append(dict(B=B, H=H, W=W, k=k, us=round(t * 1e6, 1), bf16_us=round(tf['bf16'] * 1e6, 1),
+                         exact_us=round(tf['exact'] * 1e6, 1), tflops=round(flops / t / 1e12, 1),
                          mfma_frac=round(flops / t / FP32_MFMA_PEAK, 3),
                          hbm_frac=round(byts / t / HBM_PEAK, 4),
                          bwd_in_us=round(tb['bwd_in'] * 1e6, 1), bwd_in_frac=round(flops / tb['bwd_in'] / FP32_MFMA_PEAK, 3),
