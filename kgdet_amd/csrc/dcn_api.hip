@@ -218,25 +218,23 @@ int kgdet_dcn_unpack_weight_grad(const kgdet_dcn_shape *s, const float *packed, 
   return KGDET_OK;
 }
 
-int kgdet_deform_conv_forward(const kgdet_dcn_shape *s, const float *input, const float *offset,
-                              const float *mask, const float *packed_weight, const float *bias,
-                              float *output, uint32_t flags, void *workspace, size_t workspace_bytes,
-                              void *stream) {
-  Derived d;
-  if (int rc = derive(s, d)) return rc;
-  KGDET_CHECK_SHAPE(input && offset && packed_weight && output, "null pointer");
-  if (!mfma_ok(s)) {
-    set_error("deformable_groups=%d with %d channels per group is not supported by the MFMA path",
-              s->deformable_groups, s->C / s->deformable_groups);
-    return KGDET_E_UNSUPPORTED;
-  }
+int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *shapes, const float *const *inputs,
+                                      const float *const *offsets, const float *const *masks,
+                                      const float *const *packed_weights, const float *const *biases,
+                                      float *const *outputs, uint32_t flags, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+  KGDET_CHECK_SHAPE(n >= 1 && shapes && inputs && offsets && packed_weights && outputs, "null pointer / empty group");
   if (workspace_bytes < slab_bytes() || workspace == nullptr) {
     set_error("workspace too small: need %zu bytes, got %zu", slab_bytes(), workspace_bytes);
     return KGDET_E_WORKSPACE;
   }
   const int G = grid_size();
-  const bool use_plane = plane_ok(s, d) && !(flags & KGDET_DCN_EXACT_FP32);
-  if (use_plane) {
+  DcnFwdGroup grp;  // problems collected for one launch of the plane kernel
+  grp.n = 0;
+  size_t lds = 0;
+  const int parts = (flags & KGDET_DCN_BF16) ? 1 : 2;
+  auto flush = [&]() -> int {
+    if (grp.n == 0) return KGDET_OK;
     static thread_local bool attr_set = false;
     if (!attr_set) {
       KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_fwd_plane<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -245,39 +243,79 @@ int kgdet_deform_conv_forward(const kgdet_dcn_shape *s, const float *input, cons
                                         (int)kMaxLds));
       attr_set = true;
     }
-  }
-  for (int g = 0; g < s->groups; ++g) {
-    DcnProblem p;
-    fill_problem(s, d, g, p);
-    p.x = input; p.offset = offset; p.mask = mask; p.bias = bias; p.out = output;
-    p.wpk = packed_weight + (size_t)g * d.fwd_image_floats();
-    p.flags = flags;
-    p.n_ntiles = ceil_div(p.P, kTileN);
-    p.n_mtiles = d.Og_pad / kTileM;
-    p.chunks_per_tap = d.Cg_pad / kChunk;
-    p.chunks_per_tile = d.K * p.chunks_per_tap;
-    if (use_plane) {
-      p.wq = packed_weight + (size_t)s->groups * (d.fwd_image_floats() + d.bwd_image_floats()) +
-             (size_t)g * d.plane_image_floats();
-      p.tiles_per_image = ceil_div(p.HoWo, kTileN);
-      p.n_ntiles = p.N * p.tiles_per_image;
-    }
-    p.total_units = (long long)p.n_ntiles * p.n_mtiles * p.chunks_per_tile;
-    if (use_plane) {
-      const int parts = (flags & KGDET_DCN_BF16) ? 1 : 2;
-      const size_t lds = dcn_fwd_plane_lds_bytes(parts, s->H * s->W);
-      if (parts == 1)
-        hipLaunchKernelGGL(dcn_fwd_plane<1>, dim3(G), dim3(kThreads), lds, (hipStream_t)stream, p, (float *)workspace);
-      else
-        hipLaunchKernelGGL(dcn_fwd_plane<2>, dim3(G), dim3(kThreads), lds, (hipStream_t)stream, p, (float *)workspace);
-    } else {
-      hipLaunchKernelGGL(dcn_fwd_mfma, dim3(G), dim3(kThreads), 0, (hipStream_t)stream, p, (float *)workspace);
-    }
-    hipLaunchKernelGGL(dcn_fwd_fixup, dim3(p.n_ntiles * p.n_mtiles, 16), dim3(kThreads), 0, (hipStream_t)stream, p,
+    if (parts == 1)
+      hipLaunchKernelGGL(dcn_fwd_plane<1>, dim3(G), dim3(kThreads), lds, (hipStream_t)stream, grp, (float *)workspace);
+    else
+      hipLaunchKernelGGL(dcn_fwd_plane<2>, dim3(G), dim3(kThreads), lds, (hipStream_t)stream, grp, (float *)workspace);
+    hipLaunchKernelGGL(dcn_fwd_fixup, dim3(grp.tile_begin[grp.n], 16), dim3(kThreads), 0, (hipStream_t)stream, grp,
                        (const float *)workspace, G);
+    grp.n = 0;
+    lds = 0;
+    return KGDET_OK;
+  };
+  for (int i = 0; i < n; ++i) {
+    const kgdet_dcn_shape *s = shapes[i];
+    Derived d;
+    if (int rc = derive(s, d)) return rc;
+    KGDET_CHECK_SHAPE(inputs[i] && offsets[i] && packed_weights[i] && outputs[i], "null pointer (problem %d)", i);
+    if (!mfma_ok(s)) {
+      set_error("deformable_groups=%d with %d channels per group is not supported by the MFMA path",
+                s->deformable_groups, s->C / s->deformable_groups);
+      return KGDET_E_UNSUPPORTED;
+    }
+    const bool use_plane = plane_ok(s, d) && !(flags & KGDET_DCN_EXACT_FP32);
+    for (int g = 0; g < s->groups; ++g) {
+      DcnProblem p;
+      fill_problem(s, d, g, p);
+      p.x = inputs[i]; p.offset = offsets[i]; p.mask = masks ? masks[i] : nullptr;
+      p.bias = biases ? biases[i] : nullptr; p.out = outputs[i];
+      p.wpk = packed_weights[i] + (size_t)g * d.fwd_image_floats();
+      p.flags = flags;
+      p.n_ntiles = ceil_div(p.P, kTileN);
+      p.n_mtiles = d.Og_pad / kTileM;
+      p.chunks_per_tap = d.Cg_pad / kChunk;
+      p.chunks_per_tile = d.K * p.chunks_per_tap;
+      if (use_plane) {
+        p.wq = packed_weights[i] + (size_t)s->groups * (d.fwd_image_floats() + d.bwd_image_floats()) +
+               (size_t)g * d.plane_image_floats();
+        p.tiles_per_image = ceil_div(p.HoWo, kTileN);
+        p.n_ntiles = p.N * p.tiles_per_image;
+      }
+      p.total_units = (long long)p.n_ntiles * p.n_mtiles * p.chunks_per_tile;
+      if (use_plane) {
+        if (grp.n == 0) { grp.tile_begin[0] = 0; grp.unit_begin[0] = 0; }
+        grp.p[grp.n] = p;
+        grp.tile_begin[grp.n + 1] = grp.tile_begin[grp.n] + p.n_ntiles * p.n_mtiles;
+        grp.unit_begin[grp.n + 1] = grp.unit_begin[grp.n] + p.total_units;
+        ++grp.n;
+        const size_t need = dcn_fwd_plane_lds_bytes(parts, s->H * s->W);
+        lds = need > lds ? need : lds;
+        if (grp.n == kMaxFwdGroup)
+          if (int rc = flush()) return rc;
+      } else {  // exact-fp32 kernel: one launch per problem (slabs are shared, so flush the pending group first)
+        if (int rc = flush()) return rc;
+        DcnFwdGroup one;
+        one.n = 1; one.tile_begin[0] = 0; one.tile_begin[1] = p.n_ntiles * p.n_mtiles;
+        one.unit_begin[0] = 0; one.unit_begin[1] = p.total_units;
+        one.p[0] = p;
+        hipLaunchKernelGGL(dcn_fwd_mfma, dim3(G), dim3(kThreads), 0, (hipStream_t)stream, p, (float *)workspace);
+        hipLaunchKernelGGL(dcn_fwd_fixup, dim3(one.tile_begin[1], 16), dim3(kThreads), 0, (hipStream_t)stream, one,
+                           (const float *)workspace, G);
+      }
+    }
   }
-  KGDET_CHECK_LAUNCH("dcn_fwd_mfma");
+  if (int rc = flush()) return rc;
+  KGDET_CHECK_LAUNCH("dcn_fwd");
   return KGDET_OK;
+}
+
+int kgdet_deform_conv_forward(const kgdet_dcn_shape *s, const float *input, const float *offset,
+                              const float *mask, const float *packed_weight, const float *bias,
+                              float *output, uint32_t flags, void *workspace, size_t workspace_bytes,
+                              void *stream) {
+  KGDET_CHECK_SHAPE(s != nullptr, "null shape");
+  return kgdet_deform_conv_forward_grouped(1, &s, &input, &offset, &mask, &packed_weight, &bias, &output, flags,
+                                           workspace, workspace_bytes, stream);
 }
 
 int kgdet_deform_conv_backward_input(const kgdet_dcn_shape *s, const float *input, const float *offset,

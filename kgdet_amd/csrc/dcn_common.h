@@ -45,6 +45,17 @@ struct DcnProblem {
   unsigned flags;
 };
 
+// Several independent forward problems run as ONE launch (the KGDet head runs a 3x3, a 5x5 and a 7x7
+// deformable conv on each of two feature maps per stage): their (tile, stage) units are concatenated and
+// dealt to the workgroups stream-K style, so slabs, fix-up and launch overhead are paid once per group.
+constexpr int kMaxFwdGroup = 8;
+struct DcnFwdGroup {
+  int n;
+  int tile_begin[kMaxFwdGroup + 1];        // prefix sums of n_ntiles * n_mtiles
+  long long unit_begin[kMaxFwdGroup + 1];  // prefix sums of total_units
+  DcnProblem p[kMaxFwdGroup];
+};
+
 // Output pixel of column `col` of pixel tile `nt`: image b, position hw inside it; false if past the end.
 __device__ __forceinline__ bool tile_pixel(const DcnProblem &p, int nt, int col, int &b, int &hw) {
   if (p.tiles_per_image > 0) {

@@ -225,22 +225,27 @@ __global__ __launch_bounds__(kThreads, 2) void dcn_fwd_mfma(const DcnProblem p, 
 // Split tiles: add the workgroups' slabs in workgroup order.  grid = (tiles, 16): block (tile, j) owns
 // one float4 column j of the 16-float4 register image, so the additions are spread over 16x more
 // workgroups than tiles (17 tiles alone would leave 93 % of the chip idle).
-__global__ __launch_bounds__(kThreads) void dcn_fwd_fixup(const DcnProblem p, const float *__restrict__ slabs,
+__global__ __launch_bounds__(kThreads) void dcn_fwd_fixup(const DcnFwdGroup grp, const float *__restrict__ slabs,
                                                          int G) {
-  const int tile = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
+  const int gtile = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
+  int pi = 0;
+  while (pi + 1 < grp.n && gtile >= grp.tile_begin[pi + 1]) ++pi;
+  const DcnProblem &p = grp.p[pi];
+  const int tile = gtile - grp.tile_begin[pi];
   const int cpt = p.chunks_per_tile;
-  const long long tb = (long long)tile * cpt, te = tb + cpt;
-  long long g = tb * G / p.total_units;
-  while (unit_begin(g + 1, p.total_units, G) <= tb) ++g;
-  while (unit_begin(g, p.total_units, G) > tb) --g;
-  const long long gb = unit_begin(g, p.total_units, G), ge = unit_begin(g + 1, p.total_units, G);
+  const long long total = grp.unit_begin[grp.n];
+  const long long tb = grp.unit_begin[pi] + (long long)tile * cpt, te = tb + cpt;
+  long long g = tb * G / total;
+  while (unit_begin(g + 1, total, G) <= tb) ++g;
+  while (unit_begin(g, total, G) > tb) --g;
+  const long long gb = unit_begin(g, total, G), ge = unit_begin(g + 1, total, G);
   if (gb <= tb && ge >= te) return;  // written directly by workgroup g
 
   f32x4 sum = {0.f, 0.f, 0.f, 0.f};
   for (; g < G; ++g) {
-    const long long b0 = unit_begin(g, p.total_units, G);
+    const long long b0 = unit_begin(g, total, G);
     if (b0 >= te) break;
-    if (unit_begin(g + 1, p.total_units, G) == b0) continue;  // workgroup with an empty range
+    if (unit_begin(g + 1, total, G) == b0) continue;  // workgroup with an empty range
     const long long seg_begin = b0 > tb ? b0 : tb;
     const f32x4 *s4 = reinterpret_cast<const f32x4 *>(slabs + ((long long)g * 2 + slab_slot(seg_begin, b0)) * kTileElems);
     const f32x4 v = s4[j * kThreads + tid];

@@ -47,7 +47,7 @@ struct PlaneStageRegs {
 #define KGDET_ABL 0
 #endif
 template <int PARTS>
-__global__ __launch_bounds__(kThreads, 1) void dcn_fwd_plane(const DcnProblem p, float *__restrict__ slabs) {
+__global__ __launch_bounds__(kThreads, 1) void dcn_fwd_plane(const DcnFwdGroup grp, float *__restrict__ slabs) {
   constexpr int ABL = KGDET_ABL;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *As = smem;                         // [2][PARTS][kAPart]
@@ -59,17 +59,22 @@ __global__ __launch_bounds__(kThreads, 1) void dcn_fwd_plane(const DcnProblem p,
   const int n_local = tid & (kTileN - 1);  // pixel column this thread samples for
   const int cq = tid >> 7;                 // which 4 of the chunk's 16 channels
   const long long G = gridDim.x, g = blockIdx.x;
-  const long long my_begin = unit_begin(g, p.total_units, G);
-  const long long my_end = unit_begin(g + 1, p.total_units, G);
-  const int HW = p.H * p.W;
-  const int K = p.K;
-  const int n_c16 = p.chunks_per_tap;
+  const long long total = grp.unit_begin[grp.n];
+  const long long my_begin = unit_begin(g, total, G);
+  const long long my_end = unit_begin(g + 1, total, G);
 
   long long cur = my_begin;
   while (cur < my_end) {
+    int pi = 0;
+    while (pi + 1 < grp.n && cur >= grp.unit_begin[pi + 1]) ++pi;
+    const DcnProblem &p = grp.p[pi];
+    const long long p_begin = grp.unit_begin[pi];
+    const int HW = p.H * p.W;
+    const int K = p.K;
+    const int n_c16 = p.chunks_per_tap;
     const int cpt = p.chunks_per_tile;
-    const int tile = (int)(cur / cpt);
-    const long long tile_begin = (long long)tile * cpt;
+    const int tile = (int)((cur - p_begin) / cpt);
+    const long long tile_begin = p_begin + (long long)tile * cpt;
     const int s_begin = (int)(cur - tile_begin);
     const int s_end = (int)((my_end - tile_begin) < cpt ? (my_end - tile_begin) : cpt);
     const int mt = tile % p.n_mtiles, nt = tile / p.n_mtiles;
@@ -239,8 +244,8 @@ __global__ __launch_bounds__(kThreads, 1) void dcn_fwd_plane(const DcnProblem p,
   }
 }
 
-template __global__ void dcn_fwd_plane<1>(const DcnProblem p, float *__restrict__ slabs);
-template __global__ void dcn_fwd_plane<2>(const DcnProblem p, float *__restrict__ slabs);
+template __global__ void dcn_fwd_plane<1>(const DcnFwdGroup grp, float *__restrict__ slabs);
+template __global__ void dcn_fwd_plane<2>(const DcnFwdGroup grp, float *__restrict__ slabs);
 
 size_t dcn_fwd_plane_lds_bytes(int parts, int HW) {
   return (size_t)2 * parts * (kAPart + kBPart) + (size_t)kChunk * HW * sizeof(float);

@@ -5,10 +5,10 @@
 namespace kgdet {
 
 __global__ void dcn_fwd_mfma(const DcnProblem p, float *__restrict__ slabs);
-__global__ void dcn_fwd_fixup(const DcnProblem p, const float *__restrict__ slabs, int G);
+__global__ void dcn_fwd_fixup(const DcnFwdGroup grp, const float *__restrict__ slabs, int G);
 // plane variant (dcn_forward_plane.hip): PARTS = 2 hi/lo split (fp32-accurate), 1 = plain bf16 operands
 template <int PARTS>
-__global__ void dcn_fwd_plane(const DcnProblem p, float *__restrict__ slabs);
+__global__ void dcn_fwd_plane(const DcnFwdGroup grp, float *__restrict__ slabs);
 size_t dcn_fwd_plane_lds_bytes(int parts, int HW);
 __global__ void dcn_pack_weight_all(const float *__restrict__ w, float *__restrict__ wpk, float *__restrict__ wpt,
                                     void *__restrict__ wq /*nullable*/, int Og, int Cg, int K, int Cg_pad,

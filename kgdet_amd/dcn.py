@@ -96,6 +96,28 @@ def _fwd_flags(relu):
     return ctypes.c_uint32((_lib.DCN_RELU if relu else 0) | _PRECISION_FLAGS[_FORWARD_PRECISION])
 
 
+def _require_f32(*tensors):
+    """the C ABI is float32 only; never let another dtype be read as float bits"""
+    for t in tensors:
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError('kgdet_amd deformable convolution expects float32 tensors, got {} '
+                            '(under torch.autocast the public functions cast for you)'.format(t.dtype))
+
+
+def _autocast_apply(apply, args):
+    """torch.autocast contract of the deformable ops: like the reference's fp32-only CUDA op they take and
+    return float32 (lower-precision activations are cast up on entry); under bfloat16 autocast the
+    forward products use bf16 operands with fp32 accumulation (KGDET_DCN_BF16) unless a precision was
+    chosen explicitly with set_forward_precision()."""
+    if not torch.is_autocast_enabled('cuda'):
+        return apply(*args)
+    cast = [a.float() if torch.is_tensor(a) and a.is_floating_point() and a.dtype != torch.float32 else a
+            for a in args]
+    bf16 = torch.get_autocast_dtype('cuda') == torch.bfloat16 and _FORWARD_PRECISION == 'split'
+    with torch.autocast('cuda', enabled=False), forward_precision('bf16' if bf16 else _FORWARD_PRECISION):
+        return apply(*cast)
+
+
 def pack_weight(weight, shape):
     """weight [O, C/g, kh, kw] -> MFMA-friendly image [g][K][C/g pad16][O/g pad256] (device)."""
     L = _lib.lib()
@@ -124,6 +146,7 @@ def _check_offset(offset, shape, out_size, mask=None):
 
 def _forward(input, offset, mask, weight, bias, shape, packed=None, relu=False):
     L = _lib.lib()
+    _require_f32(input, offset, mask, weight, bias)
     input = input.contiguous()
     offset = offset.contiguous()
     mask = mask.contiguous() if mask is not None else None
@@ -242,8 +265,16 @@ class ModulatedDeformConvFunction(Function):
         return (gi, go, gm, gw, gb, None, None, None, None, None)
 
 
-deform_conv = DeformConvFunction.apply
-modulated_deform_conv = ModulatedDeformConvFunction.apply
+def deform_conv(*args):
+    """deform_conv(input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
+    im2col_step=64) -- R:186"""
+    return _autocast_apply(DeformConvFunction.apply, args)
+
+
+def modulated_deform_conv(*args):
+    """modulated_deform_conv(input, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,
+    deformable_groups=1) -- R:187"""
+    return _autocast_apply(ModulatedDeformConvFunction.apply, args)
 
 
 class DeformConv(nn.Module):
@@ -374,73 +405,98 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
 # Fused multi-kernel deformable convolution:  relu(cat([dconv_k(x, offset_k, W_k) for k], dim=1))
 # ------------------------------------------------------------------------------------------------
 class DeformConvCatFunction(Function):
-    """KGDet runs a 3x3, a 5x5 and a 7x7 deformable conv on the same feature map, applies ReLU to
-    each and concatenates them (reppoints_head_kp3rep_cas_1_assign_once.py:145-153).  Here every
-    conv writes its channel window of ONE output buffer with ReLU fused into the kernel epilogue
-    (C ABI fields out_channel_offset / out_channels_total), and backward reads the matching
-    windows of the incoming gradient in place: no cat, no separate ReLU kernels, no slice copies.
-    Stride 1, dilation 1, groups 1 (the head's configuration); args = offset_0, weight_0, pad_0, ...
+    """KGDet runs a 3x3, a 5x5 and a 7x7 deformable conv on a feature map, applies ReLU to each and
+    concatenates them -- once on the classification features and once on the keypoint features, with
+    the same offsets (reppoints_head_kp3rep_cas_1_assign_once.py:145-163).  Here
+      * every conv writes its channel window of ONE output buffer per feature map with ReLU fused into
+        the kernel epilogue (C ABI fields out_channel_offset / out_channels_total): no cat, no ReLU
+        kernels, no slice copies, and backward reads the matching gradient windows in place;
+      * all n_x * n_k convs of the call go to the GPU as ONE grouped launch
+        (kgdet_deform_conv_forward_grouped): split-K slabs, fix-up and launch overhead are paid once.
+    Stride 1, dilation 1, groups 1 (the head's configuration).
+    args = x_0 .. x_{n_x-1}, offset_0 .. offset_{n_k-1}, then weights x-major: w[x][k].
     """
 
     @staticmethod
-    def forward(ctx, x, relu, *args):
-        if not x.is_cuda:
+    def forward(ctx, relu, n_x, n_k, pads, *args):
+        xs = [a.contiguous() for a in args[:n_x]]
+        if not xs[0].is_cuda:
             raise NotImplementedError
-        assert len(args) % 3 == 0
+        offsets = [a.contiguous() for a in args[n_x:n_x + n_k]]
+        weights = args[n_x + n_k:]
+        assert len(weights) == n_x * n_k
+        _require_f32(*xs, *offsets, *weights)
         L = _lib.lib()
-        x = x.contiguous()
-        convs = [(args[i].contiguous(), args[i + 1], int(args[i + 2])) for i in range(0, len(args), 3)]
-        O_total = sum(w.shape[0] for _, w, _ in convs)
-        N, C, H, W = x.shape
-        out = x.new_empty(N, O_total, H, W)
-        shapes, packs = [], []
-        o_base = 0
-        for offset, weight, pad in convs:
-            s = _shape(x, weight, (1, 1), (pad, pad), (1, 1), 1, 1)
-            s.out_channel_offset, s.out_channels_total = o_base, O_total
-            _check_offset(offset, s, (N, weight.shape[0], H, W))
-            packed = pack_weight(weight.contiguous(), s)
-            ws = _workspace(x.device, L.kgdet_dcn_workspace_bytes(ctypes.byref(s)))
-            _lib.check(L.kgdet_deform_conv_forward(
-                ctypes.byref(s), _lib.ptr(x), _lib.ptr(offset), None, _lib.ptr(packed), None, _lib.ptr(out),
-                _fwd_flags(relu), _lib.ptr(ws), ctypes.c_size_t(ws.numel()),
-                _lib.current_stream()), 'kgdet_deform_conv_forward')
-            shapes.append(s)
-            packs.append(packed)
-            o_base += weight.shape[0]
-        ctx.shapes = shapes
-        ctx.relu = relu
-        ctx.n = len(convs)
-        ctx.save_for_backward(x, out, *[t for offset, weight, _ in convs for t in (offset, weight)], *packs)
-        return out
+        N, C, H, W = xs[0].shape
+        outs, shapes, packs = [], [], []
+        for i, x in enumerate(xs):
+            ws_i = weights[i * n_k:(i + 1) * n_k]
+            O_total = sum(w.shape[0] for w in ws_i)
+            out = x.new_empty(N, O_total, H, W)
+            o_base = 0
+            for k in range(n_k):
+                s = _shape(x, ws_i[k], (1, 1), (pads[k], pads[k]), (1, 1), 1, 1)
+                s.out_channel_offset, s.out_channels_total = o_base, O_total
+                _check_offset(offsets[k], s, (N, ws_i[k].shape[0], H, W))
+                shapes.append(s)
+                packs.append(pack_weight(ws_i[k].contiguous(), s))
+                o_base += ws_i[k].shape[0]
+            outs.append(out)
+        n = n_x * n_k
+        ws = _workspace(xs[0].device, max(L.kgdet_dcn_workspace_bytes(ctypes.byref(s)) for s in shapes))
+        fptr = ctypes.POINTER(ctypes.c_float)
+        arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        shape_arr = (ctypes.POINTER(_lib.DcnShape) * n)(*[ctypes.pointer(s) for s in shapes])
+        _lib.check(L.kgdet_deform_conv_forward_grouped(
+            ctypes.c_int32(n), shape_arr, arr([xs[j // n_k] for j in range(n)]),
+            arr([offsets[j % n_k] for j in range(n)]), None, arr(packs), None,
+            arr([outs[j // n_k] for j in range(n)]), _fwd_flags(relu), _lib.ptr(ws), ctypes.c_size_t(ws.numel()),
+            _lib.current_stream()), 'kgdet_deform_conv_forward_grouped')
+        ctx.shapes, ctx.relu, ctx.n_x, ctx.n_k = shapes, relu, n_x, n_k
+        ctx.save_for_backward(*xs, *outs, *offsets, *weights, *packs)
+        return tuple(outs)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, grad_out):
+    def backward(ctx, *grad_outs):
+        n_x, n_k = ctx.n_x, ctx.n_k
         saved = ctx.saved_tensors
-        x, out = saved[0], saved[1]
-        n = ctx.n
-        ow = saved[2:2 + 2 * n]
-        packs = saved[2 + 2 * n:]
-        if ctx.relu:
-            grad_out = grad_out * (out > 0).to(grad_out.dtype)
-        grad_out = grad_out.contiguous()
-        grads = [None] * (3 * n)
-        grad_x = None
-        for k in range(n):
-            offset, weight = ow[2 * k], ow[2 * k + 1]
-            needs = dict(input=ctx.needs_input_grad[0], offset=ctx.needs_input_grad[2 + 3 * k], mask=False,
-                         weight=ctx.needs_input_grad[3 + 3 * k], bias=False)
-            gi, go, _, gw, _ = _backward(x, offset, None, weight, None, grad_out, ctx.shapes[k], packs[k], needs)
-            if gi is not None and ctx.needs_input_grad[0]:
-                grad_x = gi if grad_x is None else grad_x.add_(gi)
-            grads[3 * k], grads[3 * k + 1] = go, gw
-        return (grad_x, None) + tuple(grads)
+        xs, outs = saved[:n_x], saved[n_x:2 * n_x]
+        offsets = saved[2 * n_x:2 * n_x + n_k]
+        weights = saved[2 * n_x + n_k:2 * n_x + n_k + n_x * n_k]
+        packs = saved[2 * n_x + n_k + n_x * n_k:]
+        need = ctx.needs_input_grad[4:]
+        grad_xs = [None] * n_x
+        grad_offs = [None] * n_k
+        grad_ws = [None] * (n_x * n_k)
+        for i in range(n_x):
+            grad_out = grad_outs[i]
+            if ctx.relu:
+                grad_out = grad_out * (outs[i] > 0).to(grad_out.dtype)
+            grad_out = grad_out.contiguous()
+            for k in range(n_k):
+                j = i * n_k + k
+                needs = dict(input=need[i], offset=need[n_x + k], mask=False, weight=need[n_x + n_k + j], bias=False)
+                gi, go, _, gw, _ = _backward(xs[i], offsets[k], None, weights[j], None, grad_out, ctx.shapes[j],
+                                             packs[j], needs)
+                if gi is not None and need[i]:
+                    grad_xs[i] = gi if grad_xs[i] is None else grad_xs[i].add_(gi)
+                if go is not None and need[n_x + k]:
+                    grad_offs[k] = go if grad_offs[k] is None else grad_offs[k].add_(go)
+                grad_ws[j] = gw
+        return (None, None, None, None) + tuple(grad_xs) + tuple(grad_offs) + tuple(grad_ws)
+
+
+def deform_conv_cat_multi(xs, offsets, weights, paddings, relu=True):
+    """[relu(cat([deform_conv(x, o_k, w[i][k], 1, p_k) for k], dim=1)) for i, x in enumerate(xs)]
+    as one grouped launch; weights[i][k] belongs to feature map i and kernel size k."""
+    n_x, n_k = len(xs), len(offsets)
+    flat_w = [w for ws in weights for w in ws]
+    outs = _autocast_apply(DeformConvCatFunction.apply,
+                           (relu, n_x, n_k, tuple(int(p) for p in paddings), *xs, *offsets, *flat_w))
+    return list(outs)
 
 
 def deform_conv_cat(x, offsets, weights, paddings, relu=True):
     """relu(cat([deform_conv(x, o, w, 1, p) for o, w, p in ...], dim=1)) in one buffer."""
-    args = []
-    for o, w, p in zip(offsets, weights, paddings):
-        args += [o, w, p]
-    return DeformConvCatFunction.apply(x, relu, *args)
+    return deform_conv_cat_multi([x], offsets, [weights], paddings, relu)[0]

@@ -47,9 +47,9 @@ class DeformRoIPoolingFunction(Function):
         if not data.is_cuda:
             raise NotImplementedError
 
-        data = data.contiguous()
+        data = data.contiguous().float()       # the C ABI is float32 only (autocast activations are cast up)
         rois = rois.contiguous().float()
-        offset = offset.contiguous()
+        offset = offset.contiguous().float()
         n = rois.shape[0]
         output = data.new_empty(n, out_channels, out_size, out_size)
         output_count = data.new_empty(n, out_channels, out_size, out_size)
@@ -69,7 +69,7 @@ class DeformRoIPoolingFunction(Function):
         if not grad_output.is_cuda:
             raise NotImplementedError
         data, rois, offset = ctx.saved_tensors
-        grad_output = grad_output.contiguous()
+        grad_output = grad_output.contiguous().float()
         grad_input = torch.zeros_like(data)
         grad_rois = None
         grad_offset = torch.zeros_like(offset)

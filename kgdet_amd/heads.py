@@ -97,11 +97,11 @@ class Kp3RepBlock(nn.Module):
         if self.deform_conv:
             offsets = self._dcn_offsets(reppts_offset, pts_feat)
             pads = [getattr(self, 'dcn_pad_%d' % k) for k in _KERNELS]
-            cls_dfmconv_feat = dcn.deform_conv_cat(
-                cls_feat, offsets, [getattr(self, 'cls_dfmconv_%d' % k).weight for k in _KERNELS], pads)
+            cls_dfmconv_feat, keypts_dfmconv_feat = dcn.deform_conv_cat_multi(
+                [cls_feat, pts_feat], offsets,
+                [[getattr(self, 'cls_dfmconv_%d' % k).weight for k in _KERNELS],
+                 [getattr(self, 'keypts_dfmconv_%d' % k).weight for k in _KERNELS]], pads)
             cls_out = self.cls_out(cls_dfmconv_feat)
-            keypts_dfmconv_feat = dcn.deform_conv_cat(
-                pts_feat, offsets, [getattr(self, 'keypts_dfmconv_%d' % k).weight for k in _KERNELS], pads)
             keypts_out = self.keypts_out(keypts_dfmconv_feat)
             reppts_out = self.reppts_out(keypts_out)
         else:

@@ -14,6 +14,10 @@ def deform_conv_cat(x, offsets, weights, paddings, relu=True):
     return out.relu() if relu else out
 
 
+def deform_conv_cat_multi(xs, offsets, weights, paddings, relu=True):
+    return [deform_conv_cat(x, offsets, ws, paddings, relu) for x, ws in zip(xs, weights)]
+
+
 def moment_bbox(pts, mt, y_first=True):
     if pts.dim() == 2:
         return moment_bbox(pts.reshape(pts.shape[0], -1, 1, 1), mt, y_first).reshape(-1, 4)
@@ -35,10 +39,11 @@ def sigmoid_focal_loss(pred, target, gamma=2.0, alpha=0.25):
 def patched():
     """route the three HIP-only ops of the head to the CPU references for the duration of a test"""
     from kgdet_amd import dcn, focal_loss, moment
-    saved = (dcn.deform_conv_cat, moment.moment_bbox, focal_loss.sigmoid_focal_loss)
-    dcn.deform_conv_cat, moment.moment_bbox, focal_loss.sigmoid_focal_loss = (deform_conv_cat, moment_bbox,
-                                                                             sigmoid_focal_loss)
+    saved = (dcn.deform_conv_cat, dcn.deform_conv_cat_multi, moment.moment_bbox, focal_loss.sigmoid_focal_loss)
+    (dcn.deform_conv_cat, dcn.deform_conv_cat_multi, moment.moment_bbox,
+     focal_loss.sigmoid_focal_loss) = (deform_conv_cat, deform_conv_cat_multi, moment_bbox, sigmoid_focal_loss)
     try:
         yield
     finally:
-        dcn.deform_conv_cat, moment.moment_bbox, focal_loss.sigmoid_focal_loss = saved
+        (dcn.deform_conv_cat, dcn.deform_conv_cat_multi, moment.moment_bbox,
+         focal_loss.sigmoid_focal_loss) = saved

@@ -179,3 +179,59 @@ def test_grad_weight_deterministic():
         grads.append((to.grad.clone(), tw.grad.clone()))
     assert torch.equal(grads[0][0], grads[1][0])   # grad_offset: no atomics on this shape
     assert torch.equal(grads[0][1], grads[1][1])   # grad_weight: slab fix-up in fixed order
+
+
+def test_grouped_forward_matches_single_calls():
+    """kgdet_deform_conv_forward_grouped == n separate calls, bit for bit (same kernels, same split)... the
+    stream-K partition differs, so fp32 summation order may differ: compare to fp32 round-off of the scale."""
+    _require_gpu()
+    from kgdet_amd import dcn
+    torch.manual_seed(5)
+    B, C, H, W = 2, 256, 25, 42
+    xs = [torch.randn(B, C, H, W, device='cuda') for _ in range(2)]
+    ks = (3, 5, 7)
+    offsets = [torch.randn(B, 2 * k * k, H, W, device='cuda') * 2 for k in ks]
+    weights = [[torch.randn(64, C, k, k, device='cuda') * 0.05 for k in ks] for _ in xs]
+    pads = [k // 2 for k in ks]
+    outs = dcn.deform_conv_cat_multi(xs, offsets, weights, pads, relu=True)
+    again = dcn.deform_conv_cat_multi(xs, offsets, weights, pads, relu=True)
+    for i, x in enumerate(xs):
+        assert torch.equal(outs[i], again[i]), 'grouped launch must be deterministic'
+        ref = torch.cat([dcn.deform_conv(x, offsets[k], weights[i][k], 1, pads[k]) for k in range(3)], 1).relu()
+        _close(outs[i].cpu().numpy(), ref.double().cpu().numpy(), 2e-6)
+    # gradients flow to every input of the grouped function
+    for t in xs + offsets + [w for ws in weights for w in ws]:
+        t.requires_grad_(True)
+    outs = dcn.deform_conv_cat_multi(xs, offsets, weights, pads, relu=True)
+    (outs[0].sum() + 2 * outs[1].sum()).backward()
+    g_off = [o.grad.clone() for o in offsets]
+    for t in xs + offsets + [w for ws in weights for w in ws]:
+        assert t.grad is not None and torch.isfinite(t.grad).all()
+        t.grad = None
+    (dcn.deform_conv_cat(xs[0], offsets, weights[0], pads).sum()
+     + 2 * dcn.deform_conv_cat(xs[1], offsets, weights[1], pads).sum()).backward()
+    for a, o in zip(g_off, offsets):
+        _close(a.cpu().numpy(), o.grad.double().cpu().numpy(), 1e-5)
+
+
+def test_autocast_contract():
+    """under torch.autocast(bfloat16) the ops cast activations up to float32, use bf16 products
+    (KGDET_DCN_BF16) and return float32; a non-float32 tensor outside autocast is rejected, never
+    reinterpreted."""
+    _require_gpu()
+    from kgdet_amd import dcn
+    case = CASES[0]
+    x, off, w, _, _ = _make(case, seed=7)
+    tx, to, tw = (torch.from_numpy(a).cuda() for a in (x, off, w))
+    ref = dcn.deform_conv(tx, to, tw, 1, 1, 1)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        out = dcn.deform_conv(tx.bfloat16(), to, tw, 1, 1, 1)
+        cat = dcn.deform_conv_cat(tx.bfloat16(), [to], [tw], [1], relu=False)
+    assert out.dtype == torch.float32 and cat.dtype == torch.float32
+    ref_b = dcn.deform_conv(tx.bfloat16().float(), to, tw, 1, 1, 1)
+    _close(out.cpu().numpy(), ref_b.double().cpu().numpy(), 1e-2)
+    _close(cat.cpu().numpy(), ref_b.double().cpu().numpy(), 1e-2)
+    assert not torch.equal(out, ref_b), 'bf16 autocast is expected to select the bf16-operand kernel'
+    with pytest.raises(TypeError):
+        dcn.deform_conv(tx.bfloat16(), to, tw, 1, 1, 1)
+    assert torch.equal(ref, dcn.deform_conv(tx, to, tw, 1, 1, 1))
