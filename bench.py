@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0
+PLANE_GROUP_TRAFFIC_BYTES = 1.019e9  # profiles/r01_dcn_fwd_plane_group_b2.md: (2 x FETCH_SIZE + WRITE_SIZE) of the 3 kernels
 
 
 def parse_args():
@@ -44,36 +45,47 @@ def parse_args():
     return ap.parse_args()
 
 
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md); AMD's 5 PF figure includes 2:1 sparsity
+
+
 def dcn_roofline(device, iters=30):
-    """DeformConv forward, k=7, B=2, C=256, 25x42: HIP-event timing on the launch stream."""
+    """DeformConv forward of ONE KGDet head stage at batch 2: the grouped launch of 2 feature maps x
+    (3x3, 5x5, 7x7) on [2, 256, 25, 42] (kgdet_deform_conv_forward_grouped: dcn_build_taps + dcn_fwd_plane +
+    dcn_fwd_fixup), HIP-event timing on the launch stream.  The products are bf16 MFMAs on a hi/lo split of
+    both fp32 operands (3 MFMAs per fp32-accurate multiply), so the MFMA roof is the dense bf16 peak / 3."""
     from kgdet_amd import dcn
     g = torch.Generator(device='cpu').manual_seed(0)
-    B, C, H, W, k = 2, 256, 25, 42, 7
-    K = k * k
-    x = torch.randn(B, C, H, W, generator=g).to(device)
-    off = (torch.randn(B, 2 * K, H, W, generator=g) * 2).to(device)
-    w = (torch.randn(C, C, k, k, generator=g) * 0.01).to(device)
-    shape = dcn._shape(x, w, (1, 1), (k // 2, k // 2), (1, 1), 1, 1)
-    packed = dcn.pack_weight(w, shape)
+    B, C, H, W = 2, 256, 25, 42
+    ks = (3, 5, 7)
+    xs = [torch.randn(B, C, H, W, generator=g).to(device) for _ in range(2)]
+    offs = [(torch.randn(B, 2 * k * k, H, W, generator=g) * 2).to(device) for k in ks]
+    ws = [[(torch.randn(C, C, k, k, generator=g) * 0.01).to(device) for k in ks] for _ in xs]
+    pads = [k // 2 for k in ks]
     stream = torch.cuda.current_stream()
-    for _ in range(5):
-        dcn._forward(x, off, None, w, None, shape, packed=packed)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(iters):
-        dcn._forward(x, off, None, w, None, shape, packed=packed)
-    e1.record(stream)
+    with torch.no_grad():     # weight images are packed once (inference path); training re-packs every step
+        for _ in range(5):
+            dcn.deform_conv_cat_multi(xs, offs, ws, pads)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(iters):
+            dcn.deform_conv_cat_multi(xs, offs, ws, pads)
+        e1.record(stream)
     torch.cuda.synchronize()
     t = e0.elapsed_time(e1) / iters * 1e-3
-    flops = 2.0 * C * C * K * B * H * W
-    byts = 4.0 * (2 * B * C * H * W + 2 * B * K * H * W + C * C * K)
+    flops = sum(2.0 * C * C * k * k * B * H * W for k in ks) * len(xs)
+    byts = sum(4.0 * (2 * B * C * H * W + 2 * B * k * k * H * W + C * C * k * k) for k in ks) * len(xs)
     ach = flops / t / 1e12
-    return dict(bound='mfma', kernel='dcn_fwd_mfma+dcn_fwd_fixup (7x7, B=2, 256ch, 25x42)', achieved=round(ach, 2),
-                peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                # bytes per launch from the committed PMC passes (profiles/r01_dcn_fwd_k7_b2_kernel_stats.md):
-                # (2 x FETCH_SIZE + WRITE_SIZE) KB of dcn_fwd_mfma + dcn_fwd_fixup; cannot be collected live here
-                traffic=3.45e8, algorithmic_bytes=byts, algorithmic_flops=flops, launch_us=round(t * 1e6, 1),
-                hbm_achieved_GBs=round(byts / t / 1e9, 1), hbm_frac=round(byts / t / 1e9 / HBM_PEAK_GBS, 4))
+    peak = BF16_MFMA_PEAK_TFLOPS / 3.0
+    return dict(bound='mfma', kernel='dcn_build_taps+dcn_fwd_plane<2>+dcn_fwd_fixup (one head stage: 2 maps x 3x3/5x5/7x7, '
+                                     'B=2, 256ch, 25x42)',
+                achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4),
+                peak_basis='dense bf16 MFMA 2500 TFLOP/s / 3 products per fp32-accurate multiply (hi/lo split)',
+                frac_of_f32_mfma_peak=round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                # bytes per launch from the committed PMC passes (profiles/): (2 x FETCH_SIZE + WRITE_SIZE) of the
+                # three kernels; cannot be collected live here
+                traffic=PLANE_GROUP_TRAFFIC_BYTES, algorithmic_bytes=byts, algorithmic_flops=flops,
+                launch_us=round(t * 1e6, 1), hbm_achieved_GBs=round(byts / t / 1e9, 1),
+                hbm_frac=round(byts / t / 1e9 / HBM_PEAK_GBS, 4))
 
 
 def cpu_baseline():

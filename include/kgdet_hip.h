@@ -86,11 +86,15 @@ int kgdet_deform_conv_forward(const kgdet_dcn_shape *s, const float *input, cons
                               const float *bias /*nullable*/, float *output, uint32_t flags,
                               void *workspace, size_t workspace_bytes, void *stream);
 
+/* Scratch for kgdet_deform_conv_forward_grouped: split-K slabs plus one table of sampling records per problem
+ * (also >= kgdet_dcn_workspace_bytes of every member, so the same buffer serves their backward calls). */
+size_t kgdet_dcn_group_workspace_bytes(int32_t n, const kgdet_dcn_shape *const *shapes);
+
 /* n independent forward problems in ONE launch: same results as n calls of kgdet_deform_conv_forward
  * with the same flags.  The KGDet head runs a 3x3, a 5x5 and a 7x7 deformable conv on each of two feature
  * maps per stage (reppoints_head_kp3rep_cas_1_assign_once.py:145-163); grouping them shares the split-K
  * partial tiles, the fix-up pass and the launch overhead.  All arrays have n entries; `masks` / `biases`
- * (or single entries) may be NULL.  workspace >= max_i kgdet_dcn_workspace_bytes(shapes[i]). */
+ * (or single entries) may be NULL.  workspace >= kgdet_dcn_group_workspace_bytes(n, shapes). */
 int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *shapes, const float *const *inputs,
                                       const float *const *offsets, const float *const *masks /*nullable*/,
                                       const float *const *packed_weights, const float *const *biases /*nullable*/,

@@ -57,7 +57,7 @@ def lib():
                 'or `make -C kgdet_amd/csrc`. There is no non-HIP fallback.' % LIB_PATH)
         L = ctypes.CDLL(LIB_PATH)
         L.kgdet_last_error.restype = ctypes.c_char_p
-        for name in ('kgdet_dcn_packed_weight_bytes', 'kgdet_dcn_workspace_bytes',
+        for name in ('kgdet_dcn_packed_weight_bytes', 'kgdet_dcn_workspace_bytes', 'kgdet_dcn_group_workspace_bytes',
                      'kgdet_nms_workspace_bytes'):
             if hasattr(L, name):
                 getattr(L, name).restype = ctypes.c_size_t

@@ -60,7 +60,8 @@ int grid_size() {
   return cus > 0 ? cus : 256;
 }
 
-size_t slab_bytes() { return (size_t)grid_size() * 2 * kTileElems * sizeof(float); }
+constexpr int kSlabSlots = 8;  // partial tiles a workgroup may write per launch (plane kernel: one per range it meets)
+size_t slab_bytes() { return (size_t)grid_size() * kSlabSlots * kTileElems * sizeof(float); }
 
 constexpr size_t kMaxLds = 160 * 1024;
 
@@ -104,7 +105,12 @@ bool mfma_ok(const kgdet_dcn_shape *s) {
 // plane forward kernel: a 16-channel slice of one input image must fit in LDS next to the operand stages
 constexpr int kPlaneMaxHW = 1536;
 bool plane_ok(const kgdet_dcn_shape *s, const Derived &d) {
-  return mfma_ok(s) && s->H * s->W <= kPlaneMaxHW && (size_t)8 * 33 * (d.K + 1) * sizeof(float) <= kMaxLds - 64;
+  const int cpdg = s->C / s->deformable_groups;  // a producer thread samples 8 channels with one tap record
+  return mfma_ok(s) && (s->deformable_groups == 1 || cpdg % 8 == 0) && s->H * s->W <= kPlaneMaxHW &&
+         (size_t)8 * 33 * (d.K + 1) * sizeof(float) <= kMaxLds - 64;
+}
+size_t tap_table_bytes(const kgdet_dcn_shape *s, const Derived &d) {
+  return plane_ok(s, d) ? (size_t)s->N * s->deformable_groups * d.K * d.Ho * d.Wo * sizeof(DcnTapRec) : 0;
 }
 // backward tiles (256 / 128 channels wide) must lie inside one deformable group
 bool mfma_bwd_ok(const kgdet_dcn_shape *s) {
@@ -151,13 +157,27 @@ size_t kgdet_dcn_packed_weight_bytes(const kgdet_dcn_shape *s) {
 size_t kgdet_dcn_workspace_bytes(const kgdet_dcn_shape *s) {
   Derived d;
   if (derive(s, d)) return 0;
-  // slabs for stream-K partial tiles + (backward-weight) a packed gradient image
-  const size_t fwd_and_wgrad = slab_bytes() + (size_t)s->groups * d.fwd_image_floats() * sizeof(float);
+  // slabs for stream-K partial tiles + (forward) the tap records / (backward-weight) a packed gradient image
+  const size_t after_slabs = (size_t)s->groups * d.fwd_image_floats() * sizeof(float);
+  const size_t fwd_and_wgrad = slab_bytes() + (after_slabs > tap_table_bytes(s, d) ? after_slabs : tap_table_bytes(s, d));
   const BwdLdsPlan pl = plan_bwd_lds(s, d);
   const size_t bwd_in = pl.ok ? (pl.slab_floats + pl.off_floats + pl.mask_floats) * sizeof(float) +
                                     pl.rowptr_ints * sizeof(int) + pl.entry_pairs * 8 + 64
                               : 0;
   return fwd_and_wgrad > bwd_in ? fwd_and_wgrad : bwd_in;
+}
+
+size_t kgdet_dcn_group_workspace_bytes(int32_t n, const kgdet_dcn_shape *const *shapes) {
+  size_t tables = 0, single = 0;
+  for (int i = 0; i < n; ++i) {
+    Derived d;
+    if (!shapes || derive(shapes[i], d)) return 0;
+    tables += tap_table_bytes(shapes[i], d);
+    const size_t w = kgdet_dcn_workspace_bytes(shapes[i]);
+    single = w > single ? w : single;
+  }
+  const size_t grouped = slab_bytes() + tables;
+  return grouped > single ? grouped : single;
 }
 
 int kgdet_dcn_pack_weight(const kgdet_dcn_shape *s, const float *weight, float *packed, void *stream) {
@@ -231,7 +251,12 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
   const int G = grid_size();
   DcnFwdGroup grp;  // problems collected for one launch of the plane kernel
   grp.n = 0;
+  grp.xcd_slices = 1;
+  grp.slots = kSlabSlots;
   size_t lds = 0;
+  int min_len = 1 << 30;  // shortest range (stages) in the pending group
+  unsigned char *const table_base = (unsigned char *)workspace + slab_bytes();
+  size_t table_used = 0;  // bytes of tap records placed behind the slabs for the pending group
   const int parts = (flags & KGDET_DCN_BF16) ? 1 : 2;
   auto flush = [&]() -> int {
     if (grp.n == 0) return KGDET_OK;
@@ -243,14 +268,18 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
                                         (int)kMaxLds));
       attr_set = true;
     }
+    hipLaunchKernelGGL(dcn_build_taps, dim3(2 * G, grp.n), dim3(256), 0, (hipStream_t)stream, grp);
+    const int threads = dcn_fwd_plane_threads();
     if (parts == 1)
-      hipLaunchKernelGGL(dcn_fwd_plane<1>, dim3(G), dim3(kThreads), lds, (hipStream_t)stream, grp, (float *)workspace);
+      hipLaunchKernelGGL(dcn_fwd_plane<1>, dim3(G), dim3(threads), lds, (hipStream_t)stream, grp, (float *)workspace);
     else
-      hipLaunchKernelGGL(dcn_fwd_plane<2>, dim3(G), dim3(kThreads), lds, (hipStream_t)stream, grp, (float *)workspace);
+      hipLaunchKernelGGL(dcn_fwd_plane<2>, dim3(G), dim3(threads), lds, (hipStream_t)stream, grp, (float *)workspace);
     hipLaunchKernelGGL(dcn_fwd_fixup, dim3(grp.tile_begin[grp.n], 16), dim3(kThreads), 0, (hipStream_t)stream, grp,
                        (const float *)workspace, G);
     grp.n = 0;
     lds = 0;
+    min_len = 1 << 30;
+    table_used = 0;
     return KGDET_OK;
   };
   for (int i = 0; i < n; ++i) {
@@ -282,10 +311,47 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
         p.n_ntiles = p.N * p.tiles_per_image;
       }
       p.total_units = (long long)p.n_ntiles * p.n_mtiles * p.chunks_per_tile;
+      p.kparts = 1;
       if (use_plane) {
-        if (grp.n == 0) { grp.tile_begin[0] = 0; grp.unit_begin[0] = 0; }
+        // cut the reduction so that one part's weights (16 KB per stage with both bf16 parts) fit a per-XCD L2
+        const size_t stage_bytes = (size_t)parts * 8192;
+        // (measured on MI355X: no gain -- the weight stream is not what bounds the kernel, hot weights only
+        //  bought 6 % -- while the extra partial tiles cost 25 %; the partition stays off)
+        while (false && p.kparts < 8 && (size_t)p.chunks_per_tile * stage_bytes / p.kparts > (size_t)1792 * 1024 &&
+               p.chunks_per_tile / (p.kparts * 2) >= 16)
+          p.kparts *= 2;
+        // a workgroup writes one slab per range its slice meets: keep that within kSlabSlots
+        const int len = p.chunks_per_tile / p.kparts;
+        const int new_min = len < min_len ? len : min_len;
+        const long long units_after = (grp.n ? grp.unit_begin[grp.n] : 0) + p.total_units;
+        if (grp.n > 0 && ceil_div((int)ceil_div(units_after, (long long)G), new_min) + 2 > kSlabSlots)
+          if (int rc = flush()) return rc;
+        min_len = len < min_len ? len : min_len;
+        if (grp.n == 0) { grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0; }
+        // tap records: shared with an earlier problem of the group that samples at the same positions
+        p.taps = nullptr;
+        p.build_taps = 0;
+        for (int q = 0; q < grp.n && !p.taps; ++q) {
+          const DcnProblem &o = grp.p[q];
+          if (o.offset == p.offset && o.mask == p.mask && o.N == p.N && o.H == p.H && o.W == p.W && o.kh == p.kh &&
+              o.kw == p.kw && o.sh == p.sh && o.sw == p.sw && o.ph == p.ph && o.pw == p.pw && o.dh == p.dh &&
+              o.dw == p.dw && o.DG == p.DG)
+            p.taps = o.taps;
+        }
+        if (!p.taps) {
+          const size_t tb = tap_table_bytes(s, d);
+          if (slab_bytes() + table_used + tb > workspace_bytes) {
+            set_error("workspace too small for the tap records: need %zu bytes, got %zu (kgdet_dcn_group_workspace_bytes)",
+                      slab_bytes() + table_used + tb, workspace_bytes);
+            return KGDET_E_WORKSPACE;
+          }
+          p.taps = reinterpret_cast<const DcnTapRec *>(table_base + table_used);
+          p.build_taps = 1;
+          table_used += tb;
+        }
         grp.p[grp.n] = p;
         grp.tile_begin[grp.n + 1] = grp.tile_begin[grp.n] + p.n_ntiles * p.n_mtiles;
+        grp.range_begin[grp.n + 1] = grp.range_begin[grp.n] + p.n_ntiles * p.n_mtiles * p.kparts;
         grp.unit_begin[grp.n + 1] = grp.unit_begin[grp.n] + p.total_units;
         ++grp.n;
         const size_t need = dcn_fwd_plane_lds_bytes(parts, s->H * s->W);
@@ -295,7 +361,8 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
       } else {  // exact-fp32 kernel: one launch per problem (slabs are shared, so flush the pending group first)
         if (int rc = flush()) return rc;
         DcnFwdGroup one;
-        one.n = 1; one.tile_begin[0] = 0; one.tile_begin[1] = p.n_ntiles * p.n_mtiles;
+        one.n = 1; one.xcd_slices = 0; one.slots = 2; one.range_begin[0] = 0;
+        one.range_begin[1] = p.n_ntiles * p.n_mtiles; one.tile_begin[0] = 0; one.tile_begin[1] = p.n_ntiles * p.n_mtiles;
         one.unit_begin[0] = 0; one.unit_begin[1] = p.total_units;
         one.p[0] = p;
         hipLaunchKernelGGL(dcn_fwd_mfma, dim3(G), dim3(kThreads), 0, (hipStream_t)stream, p, (float *)workspace);

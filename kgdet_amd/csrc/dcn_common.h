@@ -23,6 +23,16 @@ constexpr int kChunk = 16;     // reduction elements per LDS stage
 constexpr int kThreads = 512;  // 8 waves
 constexpr int kTileElems = kTileM * kTileN;
 
+// One sampling point of the plane forward kernel, precomputed by dcn_build_taps: where the four bilinear
+// corners of (image, tap, output pixel) sit in the LDS feature plane and what they weigh (0 where a corner, or
+// the whole tap, falls outside the image; x the modulation mask for v2).
+struct DcnTapRec {
+  unsigned off[4];  // LDS byte offset of channel quad 0 of the corner pixel; quad c is at off ^ (c << 4)
+  float w[4];
+};
+// byte offset of pixel q's 64-byte row in the [pixel][16 channel] LDS plane
+__device__ __forceinline__ int dcn_plane_offset(int q) { return q * 64; }
+
 // One deformable convolution problem as the kernels see it (one weight group).
 struct DcnProblem {
   const float *x;       // [N, C_total, H, W]
@@ -30,6 +40,8 @@ struct DcnProblem {
   const float *mask;    // [N, DG*K, Ho, Wo] or nullptr
   const float *wpk;     // packed weight of this group: [K][Cg_pad][Og_pad]
   const void *wq;       // bf16 hi/lo image of this group for the plane kernel (dcn_forward_plane.hip)
+  const DcnTapRec *taps;  // [N, DG, K, Ho*Wo] sampling records (plane kernel)
+  int build_taps;         // this problem owns `taps` (others of the group may alias it: same offsets and geometry)
   const float *bias;    // [O_total] or nullptr
   float *out;           // forward: [N, O_total, Ho, Wo]
   int N, C_total, c_base, Cg, Cg_pad;
@@ -42,6 +54,7 @@ struct DcnProblem {
   int n_ntiles, n_mtiles, chunks_per_tap, chunks_per_tile;
   long long total_units;  // n_ntiles * n_mtiles * chunks_per_tile
   int tiles_per_image;    // > 0: pixel tiles never straddle images (plane kernel); 0: tiles run over N*Ho*Wo
+  int kparts;             // plane kernel: the reduction range of every tile is cut into kparts parts (see DcnFwdGroup)
   unsigned flags;
 };
 
@@ -51,10 +64,67 @@ struct DcnProblem {
 constexpr int kMaxFwdGroup = 8;
 struct DcnFwdGroup {
   int n;
+  int xcd_slices;  // 1: workgroup g takes slice sk_slice_of_block(g) and numbers its slabs by range (plane kernel)
+                   // 0: slice g, slab 0 = first partial tile, slab 1 = last partial tile (exact-fp32 kernel)
+  int slots;       // slab slots per workgroup
   int tile_begin[kMaxFwdGroup + 1];        // prefix sums of n_ntiles * n_mtiles
+  int range_begin[kMaxFwdGroup + 1];       // prefix sums of n_ntiles * n_mtiles * kparts
   long long unit_begin[kMaxFwdGroup + 1];  // prefix sums of total_units
   DcnProblem p[kMaxFwdGroup];
 };
+
+// Unit order of the plane kernel.  The weight image of a 7x7 conv is 25 MB (bf16 hi + lo) and every pixel tile
+// streams all of it: with tile-major units the 256 workgroups pull ~0.8 GB per grouped launch through the
+// fabric, which is what bounds the kernel (the per-XCD L2 is 4 MB).  So the reduction range of problem p is cut
+// into p.kparts parts of <= ~1.7 MB of weights and the units are ordered (problem, part, tile, stage): the
+// workgroups of one XCD (consecutive slices, sk_slice_of_block) then walk the tiles of ONE part together and
+// share its weights through their L2.  A RANGE = (problem, part, tile) = a run of consecutive units; a
+// workgroup's slice meets a few ranges, writes one partial tile (slab) per range it meets, in order, and
+// dcn_fwd_fixup adds the slabs of a tile's ranges.
+struct DcnUnitPos {
+  int pi, part, tile;   // problem, reduction part, tile inside the problem
+  int s, s_hi;          // first stage of the unit inside the tile, end of the part's stage range
+  int range;            // global index of the range the unit lies in
+};
+__device__ __forceinline__ int dcn_part_lo(const DcnProblem &p, int part) {
+  return (int)((long long)p.chunks_per_tile * part / p.kparts);
+}
+__device__ __forceinline__ DcnUnitPos dcn_unit_pos(const DcnFwdGroup &grp, long long u) {
+  DcnUnitPos r;
+  r.pi = 0;
+  while (r.pi + 1 < grp.n && u >= grp.unit_begin[r.pi + 1]) ++r.pi;
+  const DcnProblem &p = grp.p[r.pi];
+  const int tiles = p.n_ntiles * p.n_mtiles;
+  const long long v = u - grp.unit_begin[r.pi];
+  r.part = 0;
+  while (r.part + 1 < p.kparts && v >= (long long)tiles * dcn_part_lo(p, r.part + 1)) ++r.part;
+  const int lo = dcn_part_lo(p, r.part);
+  r.s_hi = dcn_part_lo(p, r.part + 1);
+  const int len = r.s_hi - lo;
+  const long long w = v - (long long)tiles * lo;
+  r.tile = (int)(w / len);
+  r.s = lo + (int)(w - (long long)r.tile * len);
+  r.range = grp.range_begin[r.pi] + r.part * tiles + r.tile;
+  return r;
+}
+// first unit of range (pi, part, tile)
+__device__ __forceinline__ long long dcn_range_first_unit(const DcnFwdGroup &grp, int pi, int part, int tile) {
+  const DcnProblem &p = grp.p[pi];
+  const int tiles = p.n_ntiles * p.n_mtiles;
+  const int lo = dcn_part_lo(p, part), len = dcn_part_lo(p, part + 1) - lo;
+  return grp.unit_begin[pi] + (long long)tiles * lo + (long long)tile * len;
+}
+
+// Which slice of the stream-K unit space workgroup g takes.  Blocks are dealt to the 8 XCDs round-robin
+// (block b -> XCD b % 8, each with a private 4 MB L2), so consecutive slices go to the workgroups of ONE
+// XCD: neighbours in the unit space walk the same weight stages a few stages apart and share them through
+// that L2 instead of each pulling them over the fabric.  Locality only; any bijection is correct.
+__device__ __forceinline__ int sk_slice_of_block(int g, int G) {
+  return (G % 8 == 0) ? (g % 8) * (G / 8) + g / 8 : g;
+}
+__device__ __forceinline__ int sk_block_of_slice(int r, int G) {
+  return (G % 8 == 0) ? (r % (G / 8)) * 8 + r / (G / 8) : r;
+}
 
 // Output pixel of column `col` of pixel tile `nt`: image b, position hw inside it; false if past the end.
 __device__ __forceinline__ bool tile_pixel(const DcnProblem &p, int nt, int col, int &b, int &hw) {

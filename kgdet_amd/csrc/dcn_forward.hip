@@ -222,9 +222,9 @@ __global__ __launch_bounds__(kThreads, 2) void dcn_fwd_mfma(const DcnProblem p, 
   }
 }
 
-// Split tiles: add the workgroups' slabs in workgroup order.  grid = (tiles, 16): block (tile, j) owns
-// one float4 column j of the 16-float4 register image, so the additions are spread over 16x more
-// workgroups than tiles (17 tiles alone would leave 93 % of the chip idle).
+// Split tiles: add the workgroups' slabs, ranges in order, workgroups in order (deterministic).
+// grid = (tiles, 16): block (tile, j) owns one float4 column j of the 16-float4 register image, so the
+// additions are spread over 16x more workgroups than tiles (17 tiles alone would leave 93 % of the chip idle).
 __global__ __launch_bounds__(kThreads) void dcn_fwd_fixup(const DcnFwdGroup grp, const float *__restrict__ slabs,
                                                          int G) {
   const int gtile = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
@@ -232,24 +232,30 @@ __global__ __launch_bounds__(kThreads) void dcn_fwd_fixup(const DcnFwdGroup grp,
   while (pi + 1 < grp.n && gtile >= grp.tile_begin[pi + 1]) ++pi;
   const DcnProblem &p = grp.p[pi];
   const int tile = gtile - grp.tile_begin[pi];
-  const int cpt = p.chunks_per_tile;
+  const int tiles = p.n_ntiles * p.n_mtiles;
   const long long total = grp.unit_begin[grp.n];
-  const long long tb = grp.unit_begin[pi] + (long long)tile * cpt, te = tb + cpt;
-  long long g = tb * G / total;
-  while (unit_begin(g + 1, total, G) <= tb) ++g;
-  while (unit_begin(g, total, G) > tb) --g;
-  const long long gb = unit_begin(g, total, G), ge = unit_begin(g + 1, total, G);
-  if (gb <= tb && ge >= te) return;  // written directly by workgroup g
 
   f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-  for (; g < G; ++g) {
-    const long long b0 = unit_begin(g, total, G);
-    if (b0 >= te) break;
-    if (unit_begin(g + 1, total, G) == b0) continue;  // workgroup with an empty range
-    const long long seg_begin = b0 > tb ? b0 : tb;
-    const f32x4 *s4 = reinterpret_cast<const f32x4 *>(slabs + ((long long)g * 2 + slab_slot(seg_begin, b0)) * kTileElems);
-    const f32x4 v = s4[j * kThreads + tid];
-    sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+  for (int part = 0; part < p.kparts; ++part) {
+    const long long tb = dcn_range_first_unit(grp, pi, part, tile);
+    const long long te = tb + (dcn_part_lo(p, part + 1) - dcn_part_lo(p, part));
+    if (te == tb) continue;
+    const int range = grp.range_begin[pi] + part * tiles + tile;
+    long long g = tb * G / total;  // slice that holds unit tb
+    while (unit_begin(g + 1, total, G) <= tb) ++g;
+    while (unit_begin(g, total, G) > tb) --g;
+    if (p.kparts == 1 && unit_begin(g, total, G) <= tb && unit_begin(g + 1, total, G) >= te) return;  // written directly
+    for (; g < G; ++g) {
+      const long long b0 = unit_begin(g, total, G);
+      if (b0 >= te) break;
+      if (unit_begin(g + 1, total, G) == b0) continue;  // slice with an empty range
+      const long long seg_begin = b0 > tb ? b0 : tb;
+      long long slab;
+      if (grp.xcd_slices) slab = (long long)sk_block_of_slice((int)g, G) * grp.slots + (range - dcn_unit_pos(grp, b0).range);
+      else slab = g * 2 + slab_slot(seg_begin, b0);
+      const f32x4 v = reinterpret_cast<const f32x4 *>(slabs + slab * kTileElems)[j * kThreads + tid];
+      sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+    }
   }
   // float4 column j = (mi, ni, q): accumulator registers 4q .. 4q+3 of block (mi, ni)
   const int mi = j >> 3, ni = (j >> 2) & 1, q = j & 3;

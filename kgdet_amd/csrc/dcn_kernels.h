@@ -10,6 +10,8 @@ __global__ void dcn_fwd_fixup(const DcnFwdGroup grp, const float *__restrict__ s
 template <int PARTS>
 __global__ void dcn_fwd_plane(const DcnFwdGroup grp, float *__restrict__ slabs);
 size_t dcn_fwd_plane_lds_bytes(int parts, int HW);
+int dcn_fwd_plane_threads();
+__global__ void dcn_build_taps(const DcnFwdGroup grp);
 __global__ void dcn_pack_weight_all(const float *__restrict__ w, float *__restrict__ wpk, float *__restrict__ wpt,
                                     void *__restrict__ wq /*nullable*/, int Og, int Cg, int K, int Cg_pad,
                                     int Og_pad, int Og_pad16, int Cg_pad256);

@@ -11,6 +11,7 @@ As in the reference there is no CPU implementation: non-GPU tensors raise NotImp
 """
 import ctypes
 import math
+import weakref
 
 import torch
 import torch.nn as nn
@@ -118,13 +119,37 @@ def _autocast_apply(apply, args):
         return apply(*cast)
 
 
+_pack_cache = {}          # id(weight) -> (weakref, key, packed)
+_PACK_CACHE_MAX = 64
+
+
+def clear_pack_cache():
+    """Drop cached weight images (only needed after mutating a weight through ``.data``, which bypasses
+    torch's version counter)."""
+    _pack_cache.clear()
+
+
 def pack_weight(weight, shape):
-    """weight [O, C/g, kh, kw] -> MFMA-friendly image [g][K][C/g pad16][O/g pad256] (device)."""
+    """weight [O, C/g, kh, kw] -> the kernels' weight images (include/kgdet_hip.h, kgdet_dcn_pack_weight).
+    Inference (no autograd on the weight) reuses the images of an unchanged tensor -- same live object,
+    same storage, same ``_version`` (bumped by every in-place update such as a checkpoint load);
+    training packs on every call, its weights change every step anyway."""
+    cacheable = not (torch.is_grad_enabled() and weight.requires_grad)
+    key = (weight.data_ptr(), weight._version, shape.groups, shape.deformable_groups, tuple(weight.shape),
+           shape.H * shape.W <= 1536)
+    if cacheable:
+        hit = _pack_cache.get(id(weight))
+        if hit is not None and hit[0]() is weight and hit[1] == key:
+            return hit[2]
     L = _lib.lib()
     nbytes = L.kgdet_dcn_packed_weight_bytes(ctypes.byref(shape))
     packed = torch.empty(nbytes // 4, dtype=torch.float32, device=weight.device)
     _lib.check(L.kgdet_dcn_pack_weight(ctypes.byref(shape), _lib.ptr(weight), _lib.ptr(packed),
                                        _lib.current_stream()), 'kgdet_dcn_pack_weight')
+    if cacheable:
+        if len(_pack_cache) >= _PACK_CACHE_MAX:
+            _pack_cache.clear()
+        _pack_cache[id(weight)] = (weakref.ref(weight), key, packed)
     return packed
 
 
@@ -443,10 +468,9 @@ class DeformConvCatFunction(Function):
                 o_base += ws_i[k].shape[0]
             outs.append(out)
         n = n_x * n_k
-        ws = _workspace(xs[0].device, max(L.kgdet_dcn_workspace_bytes(ctypes.byref(s)) for s in shapes))
-        fptr = ctypes.POINTER(ctypes.c_float)
         arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
         shape_arr = (ctypes.POINTER(_lib.DcnShape) * n)(*[ctypes.pointer(s) for s in shapes])
+        ws = _workspace(xs[0].device, L.kgdet_dcn_group_workspace_bytes(ctypes.c_int32(n), shape_arr))
         _lib.check(L.kgdet_deform_conv_forward_grouped(
             ctypes.c_int32(n), shape_arr, arr([xs[j // n_k] for j in range(n)]),
             arr([offsets[j % n_k] for j in range(n)]), None, arr(packs), None,

@@ -199,17 +199,18 @@ def test_grouped_forward_matches_single_calls():
         assert torch.equal(outs[i], again[i]), 'grouped launch must be deterministic'
         ref = torch.cat([dcn.deform_conv(x, offsets[k], weights[i][k], 1, pads[k]) for k in range(3)], 1).relu()
         _close(outs[i].cpu().numpy(), ref.double().cpu().numpy(), 2e-6)
-    # gradients flow to every input of the grouped function
+    # gradients flow to every input of the grouped function (no ReLU here: the two paths split the reduction
+    # differently, and an output within round-off of zero may land on either side of the ReLU mask)
     for t in xs + offsets + [w for ws in weights for w in ws]:
         t.requires_grad_(True)
-    outs = dcn.deform_conv_cat_multi(xs, offsets, weights, pads, relu=True)
+    outs = dcn.deform_conv_cat_multi(xs, offsets, weights, pads, relu=False)
     (outs[0].sum() + 2 * outs[1].sum()).backward()
     g_off = [o.grad.clone() for o in offsets]
     for t in xs + offsets + [w for ws in weights for w in ws]:
         assert t.grad is not None and torch.isfinite(t.grad).all()
         t.grad = None
-    (dcn.deform_conv_cat(xs[0], offsets, weights[0], pads).sum()
-     + 2 * dcn.deform_conv_cat(xs[1], offsets, weights[1], pads).sum()).backward()
+    (dcn.deform_conv_cat(xs[0], offsets, weights[0], pads, relu=False).sum()
+     + 2 * dcn.deform_conv_cat(xs[1], offsets, weights[1], pads, relu=False).sum()).backward()
     for a, o in zip(g_off, offsets):
         _close(a.cpu().numpy(), o.grad.double().cpu().numpy(), 1e-5)
 
