@@ -104,9 +104,10 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
 /*
  * Backward w.r.t. input and offset (and mask for v2).  Replaces
  * deform_conv_backward_input_cuda (deform_conv_cuda.cpp:260-266) and the input/offset/mask part
- * of modulated_deform_conv_cuda_backward (:566-573).  grad_input must be zero-filled by the
- * caller (as R/dcn/deform_conv.py:73 does); it is accumulated with float atomics like the
- * reference.  grad_offset / grad_mask are overwritten.
+ * of modulated_deform_conv_cuda_backward (:566-573).  grad_offset / grad_mask are overwritten.
+ * grad_input: pass it zero-filled, as R/dcn/deform_conv.py:73 does.  Maps whose 32-channel plane set
+ * fits LDS (H*W <= 1088) take the atomic-free gather path, which overwrites it deterministically;
+ * larger maps accumulate into it with float atomics like the reference.
  */
 int kgdet_deform_conv_backward_input(const kgdet_dcn_shape *s, const float *input, const float *offset,
                                      const float *mask /*nullable*/, const float *packed_weight,
@@ -149,8 +150,6 @@ int kgdet_deform_psroi_backward(const kgdet_psroi_shape *s, const float *grad_ou
  * Sigmoid focal loss.  Replaces sigmoid_focal_loss_cuda.forward / .backward
  * (R/sigmoid_focal_loss/src/sigmoid_focal_loss.cpp:40-45).  logits [num, C]; targets [num]
  * int64 (0 = background, 1..C = class); losses / d_logits [num, C].
- * kgdet_sigmoid_focal_loss_sum additionally fuses the weighted sum the head takes right after
- * (R/../models/losses/utils.py:39-48): *loss_sum = sum_i w[n_i] * loss_i (weights nullable).
  * ------------------------------------------------------------------------------------------ */
 int kgdet_sigmoid_focal_loss_forward(const float *logits, const int64_t *targets, int64_t num,
                                      int32_t num_classes, float gamma, float alpha, float *losses,
