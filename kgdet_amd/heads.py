@@ -22,7 +22,8 @@ import torch.nn as nn
 
 from . import dcn, moment
 from .layers import ConvModule, bias_init_with_prob, normal_init
-from .points import PointGenerator, multi_apply, point_target_kp
+from .points import (PointGenerator, dense_targets_applicable, multi_apply, point_target_kp,
+                     point_target_kp_dense)
 from .postprocess import multiclass_nms_kp, multiclass_nms_kp_batched
 from .registry import HEADS, build_loss
 
@@ -90,8 +91,18 @@ class Kp3RepBlock(nn.Module):
             part = reppts_offset[:, 2 * start:2 * (start + n), :, :]
             start += n
             part = self.gradient_mul * part + (1 - self.gradient_mul) * part.detach()
-            offsets.append(part - getattr(self, 'dcn_base_offset_%d' % k).type_as(like))
+            offsets.append(part - self._base_offset_on(k, like))
         return offsets
+
+    def _base_offset_on(self, k, like):
+        """the regular-grid tensor on ``like``'s device / dtype.  The reference keeps it as a plain CPU attribute
+        (not a buffer, so not in the state_dict) and uploads it with type_as() on every call -- a blocking
+        host->device copy, six per training step; here the upload happens once per device."""
+        cache = self.__dict__.setdefault('_base_offset_cache', {})
+        key = (k, like.device, like.dtype)
+        if key not in cache:
+            cache[key] = getattr(self, 'dcn_base_offset_%d' % k).to(device=like.device, dtype=like.dtype)
+        return cache[key]
 
     def forward(self, cls_feat, pts_feat, reppts_offset=None):
         if self.deform_conv:
@@ -339,8 +350,9 @@ class RepPointsHeadKp3RepCas1AssignOnce(PointHeadMixin, nn.Module):
         kpt_gt = kpt_gt.reshape(-1, self.num_keypts * 2)
         kpt_weights = kpt_weights.reshape(-1, self.num_keypts * 2)
         kpt_pos_num = kpt_weights.sum(1)
-        kpt_weights[kpt_pos_num > 0] /= kpt_pos_num[kpt_pos_num > 0].unsqueeze(1)
-        kpt_weights *= 4
+        # (rows without a visible keypoint are all zero, so dividing them by 1 instead of skipping them with a
+        #  boolean mask gives the same tensor without a device->host round trip)
+        kpt_weights = kpt_weights / kpt_pos_num.clamp(min=1).unsqueeze(1) * 4
 
         losses = []
         for stage, cls_score in enumerate((cls_score_1, cls_score_2, cls_score_3), 1):
@@ -374,10 +386,20 @@ class RepPointsHeadKp3RepCas1AssignOnce(PointHeadMixin, nn.Module):
             candidate_list = center_list
         else:
             raise NotImplementedError
-        cls_reg_targets = point_target_kp(candidate_list, valid_flag_list, gt_bboxes, gt_keypoints, img_metas,
-                                          cfg.uniform, gt_bboxes_ignore_list=gt_bboxes_ignore,
-                                          gt_labels_list=gt_labels, label_channels=label_channels,
-                                          sampling=self.sampling)
+        # every grid point valid?  (host arithmetic on the image metas, the flags themselves live on the device)
+        all_valid = all(
+            min(int(np.ceil(meta['pad_shape'][0] / s)), fs[0]) == fs[0] and
+            min(int(np.ceil(meta['pad_shape'][1] / s)), fs[1]) == fs[1]
+            for meta in img_metas for s, fs in zip(self.point_strides, featmap_sizes))
+        if not self.sampling and dense_targets_applicable(cfg.uniform, len(self.point_strides), all_valid,
+                                                          gt_bboxes_ignore):
+            cls_reg_targets = point_target_kp_dense(candidate_list, gt_bboxes, gt_keypoints, cfg.uniform,
+                                                    gt_labels_list=gt_labels)   # no host syncs
+        else:
+            cls_reg_targets = point_target_kp(candidate_list, valid_flag_list, gt_bboxes, gt_keypoints, img_metas,
+                                              cfg.uniform, gt_bboxes_ignore_list=gt_bboxes_ignore,
+                                              gt_labels_list=gt_labels, label_channels=label_channels,
+                                              sampling=self.sampling)
         (labels_list, label_weights_list, bbox_gt_list, candidate_list, bbox_weights_list, keypoint_gt_list,
          keypoint_weights_list, num_total_pos, num_total_neg) = cls_reg_targets
         num_total_samples = (num_total_pos + num_total_neg if self.sampling else num_total_pos)

@@ -158,3 +158,54 @@ def test_config5_detector_with_soft_nms():
     with torch.no_grad():
         res = model.simple_test(batch['img'], batch['img_meta'], rescale=True)
     assert len(res) in (1, 3)
+
+
+def test_training_step_has_no_host_syncs_and_dense_targets_match():
+    """The KGDet training step (forward, targets, 9 losses, backward, clip, fused Adam) must not stall the launch
+    queue: torch's sync debug mode raises on any device->host read or blocking host->device copy.  The dense
+    (sync-free) target path must give the same losses as the reference-mirroring path."""
+    from kgdet_amd import points
+    from kgdet_amd.dist import DistOptimizerHook
+    from kgdet_amd.registry import build_detector
+    cfg = configs.kgdet_r50_fpn()
+    torch.manual_seed(0)
+    model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda()
+    batch = synthetic.make_batch(2, 'cuda', seed=0, img_shape=(384, 480, 3), pad_shape=(384, 480, 3))
+    for k in ('gt_bboxes', 'gt_keypoints'):
+        batch[k] = [t.clamp(max=370) for t in batch[k]]
+    model.train()
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-6, fused=True)
+    hook = DistOptimizerHook(grad_clip=dict(cfg.optimizer_config.grad_clip))
+
+    def forward():
+        return model(batch['img'], batch['img_meta'], return_loss=True, gt_bboxes=batch['gt_bboxes'],
+                     gt_labels=batch['gt_labels'], gt_keypoints=batch['gt_keypoints'])
+
+    def step():
+        losses = forward()
+        hook.step(model, opt, sum(sum(v) if isinstance(v, (list, tuple)) else v for v in losses.values()))
+
+    for _ in range(2):      # allocator, workspaces, MIOpen find: warm
+        step()
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        step()
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+    torch.cuda.synchronize()
+
+    with torch.no_grad():
+        dense = forward()
+        saved = points.dense_targets_applicable
+        points.dense_targets_applicable = lambda *a, **k: False
+        import kgdet_amd.heads as heads_mod
+        heads_mod.dense_targets_applicable = points.dense_targets_applicable
+        try:
+            mirrored = forward()
+        finally:
+            points.dense_targets_applicable = saved
+            heads_mod.dense_targets_applicable = saved
+    for k in dense:
+        for a, b in zip(dense[k], mirrored[k]):
+            assert torch.allclose(a, b, rtol=1e-6, atol=0), k

@@ -314,3 +314,42 @@ def test_ops_have_no_cpu_fallback():
         moment.moment_bbox(torch.zeros(1, 18, 2, 2), torch.zeros(2))
     with pytest.raises(NotImplementedError):
         focal_loss.sigmoid_focal_loss(torch.zeros(2, 3), torch.zeros(2, dtype=torch.long), 2.0, 0.25)
+
+
+def test_dense_targets_equal_mirrored_path():
+    """point_target_kp_dense (no host syncs) == the reference-mirroring point_target_kp on a single level:
+    overlapping GTs, a GT with no visible keypoints, ties in the point-to-centre distance."""
+    from kgdet_amd import points as P
+    from kgdet_amd.registry import ConfigDict
+    cfg = ConfigDict(assigner=dict(type='PointAssigner', scale=4, pos_num=25), allowed_border=-1, pos_weight=-1,
+                     debug=False)
+    gen = P.PointGenerator()
+    g = torch.Generator().manual_seed(3)
+    for trial in range(4):
+        pts = gen.grid_points((25, 42), 32, device='cpu')
+        n_gt = 1 + trial
+        xy = torch.rand(n_gt, 2, generator=g) * torch.tensor([900., 500.]) + 100
+        wh = torch.rand(n_gt, 2, generator=g) * 500 + 150
+        if trial == 1:
+            xy[0] = torch.tensor([16 * 32. + 16, 10 * 32. + 16])      # centre equidistant from 4 grid points
+        if trial >= 2:
+            xy[1] = xy[0] + 40                                        # overlapping GTs compete for points
+        gt_b = torch.cat([xy - wh / 2, xy + wh / 2], 1)
+        gt_l = torch.randint(1, 14, (n_gt, ), generator=g)
+        gt_k = torch.rand(n_gt, 294, 3, generator=g) * 800
+        gt_k[:, :, 2] = (torch.rand(n_gt, 294, generator=g) > 0.7).float() * 2
+        if trial == 3:
+            gt_k[0, :, 2] = 0
+        metas = [dict(pad_shape=(800, 1344, 3), img_shape=(800, 1333, 3))] * 2
+        props = [[pts.clone()], [pts.clone()]]
+        valid = [[torch.ones(pts.shape[0], dtype=torch.uint8)], [torch.ones(pts.shape[0], dtype=torch.uint8)]]
+        gtb, gtk, gtl = [gt_b, gt_b.flip(0)], [gt_k, gt_k.flip(0)], [gt_l, gt_l.flip(0)]
+        ref = P.point_target_kp([list(p) for p in props], valid, gtb, gtk, metas, cfg, gt_labels_list=gtl,
+                                label_channels=13, sampling=False)
+        new = P.point_target_kp_dense([list(p) for p in props], gtb, gtk, cfg, gt_labels_list=gtl)
+        assert P.dense_targets_applicable(cfg, 1, True, None)
+        for a, b in zip(ref[:7], new[:7]):
+            assert len(a) == len(b) == 1
+            assert a[0].shape == b[0].shape and a[0].dtype == b[0].dtype
+            assert torch.equal(a[0], b[0])
+        assert int(new[7]) == ref[7] and int(new[8]) == ref[8]
