@@ -457,8 +457,10 @@ class RepPointsHeadKp3RepCas1AssignOnce(PointHeadMixin, nn.Module):
         mlvl_scores = torch.cat([d[1] for d in decoded])
         mlvl_kpts = torch.cat([d[2] for d in decoded])
         if rescale:
-            mlvl_bboxes /= mlvl_bboxes.new_tensor(scale_factor)
-            mlvl_kpts[:, :, 0:2] = mlvl_kpts[:, :, 0:2] / mlvl_kpts.new_tensor(scale_factor)
+            # (a scalar factor divides directly; new_tensor() is a blocking host->device upload per image)
+            sf = scale_factor if isinstance(scale_factor, (int, float)) else mlvl_bboxes.new_tensor(scale_factor)
+            mlvl_bboxes /= sf
+            mlvl_kpts[:, :, 0:2] = mlvl_kpts[:, :, 0:2] / sf
             mlvl_kpts = mlvl_kpts.reshape(-1, self.num_keypts * 3)
         if self.use_sigmoid_cls:
             padding = mlvl_scores.new_zeros(mlvl_scores.shape[0], 1)
