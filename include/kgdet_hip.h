@@ -101,6 +101,14 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
                                       float *const *outputs, uint32_t flags, void *workspace,
                                       size_t workspace_bytes, void *stream);
 
+/* grad_input only, on the plane kernel (transposed sampling; atomic-free, deterministic, overwrites grad_input).
+ * Same quantity as the grad_input of kgdet_deform_conv_backward_input; needs deformable_groups == 1 and
+ * H*W, Ho*Wo <= 1536 (KGDET_E_UNSUPPORTED otherwise).  flags: KGDET_DCN_BF16 or 0 (hi/lo split).
+ * workspace >= kgdet_dcn_workspace_bytes(s). */
+int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, const float *mask /*nullable*/,
+                                 const float *packed_weight, const float *grad_output, float *grad_input,
+                                 uint32_t flags, void *workspace, size_t workspace_bytes, void *stream);
+
 /*
  * Backward w.r.t. input and offset (and mask for v2).  Replaces
  * deform_conv_backward_input_cuda (deform_conv_cuda.cpp:260-266) and the input/offset/mask part

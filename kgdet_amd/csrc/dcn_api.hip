@@ -14,6 +14,8 @@ struct Derived {
   size_t bwd_image_floats() const { return (size_t)K * Og_pad16 * Cg_pad256; }
   // bf16 hi/lo image of the plane forward kernel: same element count, 2 x 2 bytes each
   size_t plane_image_floats() const { return (size_t)K * Cg_pad * Og_pad; }
+  // its transpose (rows = input channels) for the plane grad_input kernel
+  size_t plane_t_image_floats() const { return (size_t)K * Og_pad16 * Cg_pad256; }
 };
 
 int derive(const kgdet_dcn_shape *s, Derived &d) {
@@ -112,6 +114,24 @@ bool plane_ok(const kgdet_dcn_shape *s, const Derived &d) {
 size_t tap_table_bytes(const kgdet_dcn_shape *s, const Derived &d) {
   return plane_ok(s, d) ? (size_t)s->N * s->deformable_groups * d.K * d.Ho * d.Wo * sizeof(DcnTapRec) : 0;
 }
+// grad_input on the plane kernel: a 16-channel slice of one grad_output image in LDS, one deformable group
+bool plane_bwd_input_ok(const kgdet_dcn_shape *s, const Derived &d) {
+  return s->deformable_groups == 1 && d.Ho * d.Wo <= kPlaneMaxHW && s->H * s->W <= kPlaneMaxHW && s->W >= 1 &&
+         (size_t)8 * 33 * (d.K + 1) * sizeof(float) <= kMaxLds - 64 &&
+         dcn_build_inverse_taps_lds_bytes(s->H * s->W, d.Ho * d.Wo) <= kMaxLds - 64;
+}
+struct InvTables {
+  size_t rec_bytes, slot_bytes, spill_bytes;
+  size_t total() const { return rec_bytes + slot_bytes + spill_bytes; }
+};
+InvTables inv_tables(const kgdet_dcn_shape *s, const Derived &d) {
+  InvTables t;
+  const size_t tiles = (size_t)ceil_div(s->H * s->W, kTileN);
+  t.rec_bytes = (size_t)s->N * d.K * s->H * s->W * 64;
+  t.slot_bytes = align_up((size_t)s->N * d.K * tiles * sizeof(DcnInvOvfSlots), 64);
+  t.spill_bytes = (size_t)s->N * d.K * 4 * d.Ho * d.Wo * 8;
+  return t;
+}
 // backward tiles (256 / 128 channels wide) must lie inside one deformable group
 bool mfma_bwd_ok(const kgdet_dcn_shape *s) {
   const int cpdg = s->C / s->deformable_groups, Cg = s->C / s->groups;
@@ -151,7 +171,9 @@ size_t kgdet_dcn_packed_weight_bytes(const kgdet_dcn_shape *s) {
   if (derive(s, d)) return 0;
   // [forward image per group ...][transposed (backward-input) image per group ...]
   // ... [bf16 hi/lo image of the plane forward kernel per group ...]
-  return (size_t)s->groups * (d.fwd_image_floats() + d.bwd_image_floats() + d.plane_image_floats()) * sizeof(float);
+  // ... [its transpose per group ...]
+  return (size_t)s->groups * (d.fwd_image_floats() + d.bwd_image_floats() + d.plane_image_floats() +
+                              d.plane_t_image_floats()) * sizeof(float);
 }
 
 size_t kgdet_dcn_workspace_bytes(const kgdet_dcn_shape *s) {
@@ -164,7 +186,9 @@ size_t kgdet_dcn_workspace_bytes(const kgdet_dcn_shape *s) {
   const size_t bwd_in = pl.ok ? (pl.slab_floats + pl.off_floats + pl.mask_floats) * sizeof(float) +
                                     pl.rowptr_ints * sizeof(int) + pl.entry_pairs * 8 + 64
                               : 0;
-  return fwd_and_wgrad > bwd_in ? fwd_and_wgrad : bwd_in;
+  const size_t bwd_in_plane = plane_bwd_input_ok(s, d) ? slab_bytes() + inv_tables(s, d).total() : 0;
+  size_t need = fwd_and_wgrad > bwd_in ? fwd_and_wgrad : bwd_in;
+  return need > bwd_in_plane ? need : bwd_in_plane;
 }
 
 size_t kgdet_dcn_group_workspace_bytes(int32_t n, const kgdet_dcn_shape *const *shapes) {
@@ -202,11 +226,14 @@ int kgdet_dcn_pack_weight(const kgdet_dcn_shape *s, const float *weight, float *
     float *dst_t = packed + (size_t)s->groups * d.fwd_image_floats() + (size_t)g * d.bwd_image_floats();
     float *dst_q = packed + (size_t)s->groups * (d.fwd_image_floats() + d.bwd_image_floats()) +
                    (size_t)g * d.plane_image_floats();
+    float *dst_qt = packed + (size_t)s->groups * (d.fwd_image_floats() + d.bwd_image_floats() +
+                                                   d.plane_image_floats()) + (size_t)g * d.plane_t_image_floats();
     if (fused) {
       dim3 grid(d.Cg_pad256 / 8, d.Og_pad / 32);
+      const bool plane = plane_ok(s, d);
       hipLaunchKernelGGL(dcn_pack_weight_all, grid, dim3(256), lds_all, (hipStream_t)stream, w, dst, dst_t,
-                         plane_ok(s, d) ? (void *)dst_q : nullptr, d.Og, d.Cg, d.K, d.Cg_pad, d.Og_pad,
-                         d.Og_pad16, d.Cg_pad256);
+                         plane ? (void *)dst_q : nullptr, plane ? (void *)dst_qt : nullptr, d.Og, d.Cg, d.K,
+                         d.Cg_pad, d.Og_pad, d.Og_pad16, d.Cg_pad256);
     } else {
       dim3 grid(d.Cg_pad, d.Og_pad / 64);
       hipLaunchKernelGGL(dcn_pack_weight, grid, dim3(256), lds, (hipStream_t)stream, w, dst, d.Og, d.Cg, d.K,
@@ -383,6 +410,91 @@ int kgdet_deform_conv_forward(const kgdet_dcn_shape *s, const float *input, cons
   KGDET_CHECK_SHAPE(s != nullptr, "null shape");
   return kgdet_deform_conv_forward_grouped(1, &s, &input, &offset, &mask, &packed_weight, &bias, &output, flags,
                                            workspace, workspace_bytes, stream);
+}
+
+int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, const float *mask,
+                                 const float *packed_weight, const float *grad_output, float *grad_input,
+                                 uint32_t flags, void *workspace, size_t workspace_bytes, void *stream) {
+  Derived d;
+  if (int rc = derive(s, d)) return rc;
+  KGDET_CHECK_SHAPE(offset && packed_weight && grad_output && grad_input, "null pointer");
+  if (!plane_bwd_input_ok(s, d)) {
+    set_error("grad_input plane kernel: needs deformable_groups == 1 and maps of at most %d pixels", kPlaneMaxHW);
+    return KGDET_E_UNSUPPORTED;
+  }
+  const InvTables it = inv_tables(s, d);
+  if (workspace == nullptr || workspace_bytes < slab_bytes() + it.total()) {
+    set_error("workspace too small: need %zu bytes, got %zu", slab_bytes() + it.total(), workspace_bytes);
+    return KGDET_E_WORKSPACE;
+  }
+  unsigned char *base = (unsigned char *)workspace + slab_bytes();
+  uint4 *inv = (uint4 *)base;
+  DcnInvOvfSlots *slots = (DcnInvOvfSlots *)(base + it.rec_bytes);
+  uint2 *spill = (uint2 *)(base + it.rec_bytes + it.slot_bytes);
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_build_inverse_taps, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)kMaxLds - 64));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_bwd_input_plane<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)kMaxLds));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_bwd_input_plane<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)kMaxLds));
+    attr_set = true;
+  }
+  {  // inverse sampling records from the forward geometry
+    DcnProblem f;
+    fill_problem(s, d, 0, f);
+    f.offset = offset; f.mask = mask;
+    hipLaunchKernelGGL(dcn_build_inverse_taps, dim3(s->N * d.K), dim3(256),
+                       dcn_build_inverse_taps_lds_bytes(s->H * s->W, d.Ho * d.Wo), (hipStream_t)stream, f, inv, slots,
+                       spill);
+  }
+  const int G = grid_size();
+  const int parts = (flags & KGDET_DCN_BF16) ? 1 : 2;
+  DcnFwdGroup grp;
+  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots;
+  grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
+  const int O_total = s->out_channels_total > 0 ? s->out_channels_total : s->O;
+  for (int g = 0; g < s->groups; ++g) {
+    // the transposed problem: "input" = grad_output window of this group, "output" = grad_input channels of it
+    DcnProblem p{};
+    p.x = grad_output; p.out = grad_input; p.bias = nullptr; p.offset = nullptr; p.mask = nullptr;
+    p.N = s->N;
+    p.C_total = O_total; p.c_base = s->out_channel_offset + g * d.Og; p.Cg = d.Og; p.Cg_pad = d.Og_pad16;
+    p.O_total = s->C; p.o_base = g * d.Cg; p.Og = d.Cg; p.Og_pad = d.Cg_pad256; p.bias_base = 0;
+    p.H = d.Ho; p.W = d.Wo;                       // plane geometry = grad_output
+    p.Ho = s->H; p.Wo = s->W; p.HoWo = s->H * s->W; p.P = s->N * p.HoWo;  // "pixels" = input cells
+    p.kh = s->kh; p.kw = s->kw; p.K = d.K;
+    p.DG = 1; p.cpdg = p.C_total;
+    p.tiles_per_image = ceil_div(p.HoWo, kTileN);
+    p.n_ntiles = p.N * p.tiles_per_image;
+    p.n_mtiles = d.Cg_pad256 / kTileM;
+    p.chunks_per_tap = d.Og_pad16 / kChunk;
+    p.chunks_per_tile = d.K * p.chunks_per_tap;
+    p.total_units = (long long)p.n_ntiles * p.n_mtiles * p.chunks_per_tile;
+    p.kparts = 1;
+    p.flags = 0;
+    p.wq = packed_weight + (size_t)s->groups * (d.fwd_image_floats() + d.bwd_image_floats() + d.plane_image_floats()) +
+           (size_t)g * d.plane_t_image_floats();
+    p.taps = reinterpret_cast<const DcnTapRec *>(inv);
+    p.inv_ovf = slots; p.inv_spill = spill; p.build_taps = 0;
+    if (grp.n == kMaxFwdGroup) { set_error("more than %d weight groups", kMaxFwdGroup); return KGDET_E_UNSUPPORTED; }
+    grp.p[grp.n] = p;
+    grp.tile_begin[grp.n + 1] = grp.tile_begin[grp.n] + p.n_ntiles * p.n_mtiles;
+    grp.range_begin[grp.n + 1] = grp.range_begin[grp.n] + p.n_ntiles * p.n_mtiles;
+    grp.unit_begin[grp.n + 1] = grp.unit_begin[grp.n] + p.total_units;
+    ++grp.n;
+  }
+  const size_t lds = dcn_bwd_input_plane_lds_bytes(parts, d.Ho * d.Wo);
+  const int threads = dcn_fwd_plane_threads();
+  if (parts == 1)
+    hipLaunchKernelGGL(dcn_bwd_input_plane<1>, dim3(G), dim3(threads), lds, (hipStream_t)stream, grp, (float *)workspace);
+  else
+    hipLaunchKernelGGL(dcn_bwd_input_plane<2>, dim3(G), dim3(threads), lds, (hipStream_t)stream, grp, (float *)workspace);
+  hipLaunchKernelGGL(dcn_fwd_fixup, dim3(grp.tile_begin[grp.n], 16), dim3(kThreads), 0, (hipStream_t)stream, grp,
+                     (const float *)workspace, G);
+  KGDET_CHECK_LAUNCH("dcn_bwd_input_plane");
+  return KGDET_OK;
 }
 
 int kgdet_deform_conv_backward_input(const kgdet_dcn_shape *s, const float *input, const float *offset,

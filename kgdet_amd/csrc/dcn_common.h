@@ -30,6 +30,18 @@ struct DcnTapRec {
   unsigned off[4];  // LDS byte offset of channel quad 0 of the corner pixel; quad c is at off ^ (c << 4)
   float w[4];
 };
+// Transposed sampling (grad_input plane kernel): what input cell q collects for tap t.
+//   DcnInvRec      the first 8 (output pixel, weight) contributions, pixels as LDS byte offsets like DcnTapRec
+//                  (zero weight = unused slot); stored as [2 x off[4]][2 x w[4]] = 64 B
+//   DcnInvOvfSlots further contributions of all cells of one (image, tap, 128-cell tile): the first kCap inline
+//                  (staged through LDS by the kernel), all of them also in the spill list from spill_start
+//   entry .x = (LDS byte offset << 7) | cell index inside the tile, .y = weight bits
+struct DcnInvOvfSlots {
+  static constexpr int kCap = 32;
+  int count, spill_start;
+  uint2 e[kCap];
+};
+
 // byte offset of pixel q's 64-byte row in the [pixel][16 channel] LDS plane
 __device__ __forceinline__ int dcn_plane_offset(int q) { return q * 64; }
 
@@ -40,7 +52,9 @@ struct DcnProblem {
   const float *mask;    // [N, DG*K, Ho, Wo] or nullptr
   const float *wpk;     // packed weight of this group: [K][Cg_pad][Og_pad]
   const void *wq;       // bf16 hi/lo image of this group for the plane kernel (dcn_forward_plane.hip)
-  const DcnTapRec *taps;  // [N, DG, K, Ho*Wo] sampling records (plane kernel)
+  const DcnTapRec *taps;  // [N, DG, K, Ho*Wo] sampling records (plane kernel; MODE 1: DcnInvRec, 64 B each)
+  const DcnInvOvfSlots *inv_ovf;  // MODE 1: [N, K, tiles_per_image]
+  const uint2 *inv_spill;         // MODE 1: overflow entries of all (tile, tap)s
   int build_taps;         // this problem owns `taps` (others of the group may alias it: same offsets and geometry)
   const float *bias;    // [O_total] or nullptr
   float *out;           // forward: [N, O_total, Ho, Wo]

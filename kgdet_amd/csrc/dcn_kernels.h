@@ -12,9 +12,16 @@ __global__ void dcn_fwd_plane(const DcnFwdGroup grp, float *__restrict__ slabs);
 size_t dcn_fwd_plane_lds_bytes(int parts, int HW);
 int dcn_fwd_plane_threads();
 __global__ void dcn_build_taps(const DcnFwdGroup grp);
+// grad_input on the plane kernel (dcn_backward_plane.hip)
+template <int PARTS>
+__global__ void dcn_bwd_input_plane(const DcnFwdGroup grp, float *__restrict__ slabs);
+size_t dcn_bwd_input_plane_lds_bytes(int parts, int plane_pixels);
+__global__ void dcn_build_inverse_taps(const DcnProblem p, uint4 *__restrict__ inv, DcnInvOvfSlots *__restrict__ slots,
+                                       uint2 *__restrict__ spill);
+size_t dcn_build_inverse_taps_lds_bytes(int HW, int HoWo);
 __global__ void dcn_pack_weight_all(const float *__restrict__ w, float *__restrict__ wpk, float *__restrict__ wpt,
-                                    void *__restrict__ wq /*nullable*/, int Og, int Cg, int K, int Cg_pad,
-                                    int Og_pad, int Og_pad16, int Cg_pad256);
+                                    void *__restrict__ wq /*nullable*/, void *__restrict__ wqt /*nullable*/, int Og,
+                                    int Cg, int K, int Cg_pad, int Og_pad, int Og_pad16, int Cg_pad256);
 __global__ void dcn_pack_weight(const float *__restrict__ w, float *__restrict__ wpk, int Og, int Cg, int K,
                                 int Cg_pad, int Og_pad);
 __global__ void dcn_unpack_weight(const float *__restrict__ wpk, float *__restrict__ w, int Og, int Cg, int K,

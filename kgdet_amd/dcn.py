@@ -190,6 +190,23 @@ def _forward(input, offset, mask, weight, bias, shape, packed=None, relu=False):
     return output, packed
 
 
+def grad_input_plane(input_size, offset, mask, weight, grad_output, shape, packed=None, bf16=False):
+    """grad_input of a deformable conv on the plane kernel (kgdet_deform_conv_grad_input): transposed sampling,
+    no atomics, deterministic.  ``input_size`` = (N, C, H, W)."""
+    L = _lib.lib()
+    _require_f32(offset, mask, weight, grad_output)
+    if packed is None:
+        packed = pack_weight(weight.contiguous(), shape)
+    grad_output = grad_output.contiguous()
+    grad_input = grad_output.new_empty(tuple(input_size))
+    ws = _workspace(grad_output.device, L.kgdet_dcn_workspace_bytes(ctypes.byref(shape)))
+    _lib.check(L.kgdet_deform_conv_grad_input(
+        ctypes.byref(shape), _lib.ptr(offset.contiguous()), _lib.ptr(mask), _lib.ptr(packed), _lib.ptr(grad_output),
+        _lib.ptr(grad_input), ctypes.c_uint32(_lib.DCN_BF16 if bf16 else 0), _lib.ptr(ws),
+        ctypes.c_size_t(ws.numel()), _lib.current_stream()), 'kgdet_deform_conv_grad_input')
+    return grad_input
+
+
 def _backward(input, offset, mask, weight, bias, grad_output, shape, packed, needs):
     """Returns grad_input, grad_offset, grad_mask, grad_weight, grad_bias (None where not needed)."""
     L = _lib.lib()

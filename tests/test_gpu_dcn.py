@@ -236,3 +236,41 @@ def test_autocast_contract():
     with pytest.raises(TypeError):
         dcn.deform_conv(tx.bfloat16(), to, tw, 1, 1, 1)
     assert torch.equal(ref, dcn.deform_conv(tx, to, tw, 1, 1, 1))
+
+
+@pytest.mark.parametrize('case', [c for c in CASES if c[10] == 1])
+def test_grad_input_plane_kernel(case):
+    """kgdet_deform_conv_grad_input (transposed sampling on the plane kernel) vs the float64 oracle."""
+    _require_gpu()
+    from kgdet_amd import dcn
+    N, C, H, W, O, k, s, p, d, g, dg = case
+    x, off, w, go, _ = _make(case, seed=11)
+    tx, to, tw, tg = (torch.from_numpy(a).cuda() for a in (x, off, w, go))
+    shape = dcn._shape(tx, tw, (s, s), (p, p), (d, d), g, dg)
+    gi = dcn.grad_input_plane(tx.shape, to, None, tw, tg, shape)
+    gi2 = dcn.grad_input_plane(tx.shape, to, None, tw, tg, shape)
+    assert torch.equal(gi, gi2), 'grad_input must be deterministic'
+    ref = oracle.deform_conv_backward(x.astype(np.float64), off.astype(np.float64), w.astype(np.float64),
+                                      go.astype(np.float64), s, p, d, g, dg)['grad_input']
+    _close(gi.cpu().numpy(), ref, 5e-5)
+
+
+def test_grad_input_plane_kernel_long_lists():
+    """all taps of all pixels sample (nearly) the same spot: contribution lists of hundreds of entries exercise the
+    overflow slots and the spill list of the inverse records"""
+    _require_gpu()
+    from kgdet_amd import dcn
+    case = (1, 32, 12, 14, 48, 3, 1, 1, 1, 1, 1)
+    N, C, H, W, O, k, s, p, d, g, dg = case
+    x, off, w, go, _ = _make(case, seed=12)
+    Ho, Wo = oracle.conv_output_size(H, W, k, k, s, p, d)
+    ys, xs = np.meshgrid(np.arange(Ho), np.arange(Wo), indexing='ij')
+    for t in range(k * k):   # cancel the regular grid: every sample lands near (5.3, 6.6)
+        off[:, 2 * t] = 5.3 - (ys - p + t // k) + 0.01 * off[:, 2 * t]
+        off[:, 2 * t + 1] = 6.6 - (xs - p + t % k) + 0.01 * off[:, 2 * t + 1]
+    tx, to, tw, tg = (torch.from_numpy(a).cuda() for a in (x, off, w, go))
+    shape = dcn._shape(tx, tw, (s, s), (p, p), (d, d), g, dg)
+    gi = dcn.grad_input_plane(tx.shape, to, None, tw, tg, shape)
+    ref = oracle.deform_conv_backward(x.astype(np.float64), off.astype(np.float64), w.astype(np.float64),
+                                      go.astype(np.float64), s, p, d, g, dg)['grad_input']
+    _close(gi.cpu().numpy(), ref, 5e-5)

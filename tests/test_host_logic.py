@@ -298,7 +298,7 @@ def test_shared_library_exports_every_declared_symbol():
     assert L.kgdet_version() == 1
     s = _lib.DcnShape(2, 256, 25, 42, 256, 7, 7, 1, 1, 3, 3, 1, 1, 1, 1, 0, 0)
     L.kgdet_dcn_packed_weight_bytes.restype = ctypes.c_size_t
-    assert L.kgdet_dcn_packed_weight_bytes(ctypes.byref(s)) == 3 * 49 * 256 * 256 * 4  # fp32 fwd, fp32 bwd, bf16 hi/lo
+    assert L.kgdet_dcn_packed_weight_bytes(ctypes.byref(s)) == 4 * 49 * 256 * 256 * 4  # fp32 fwd, fp32 bwd, bf16 hi/lo, its transpose
     bad = _lib.DcnShape(2, 256, 2, 2, 256, 7, 7, 1, 1, 0, 0, 1, 1, 1, 1, 0, 0)
     ho, wo = ctypes.c_int32(), ctypes.c_int32()
     assert L.kgdet_dcn_output_size(ctypes.byref(bad), ctypes.byref(ho), ctypes.byref(wo)) == _lib.KGDET_E_SHAPE
