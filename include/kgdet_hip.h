@@ -109,6 +109,14 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
                                  const float *packed_weight, const float *grad_output, float *grad_input,
                                  uint32_t flags, void *workspace, size_t workspace_bytes, void *stream);
 
+/* grad_offset only (v1), with the column gradient W^T grad_out kept in registers and the feature plane in LDS.
+ * Same quantity as the grad_offset of kgdet_deform_conv_backward_input; needs deformable_groups == 1,
+ * groups == 1, O <= 256, H*W <= 1536 (KGDET_E_UNSUPPORTED otherwise).  Overwrites grad_offset.
+ * workspace >= kgdet_dcn_workspace_bytes(s). */
+int kgdet_deform_conv_grad_offset(const kgdet_dcn_shape *s, const float *input, const float *offset,
+                                  const float *packed_weight, const float *grad_output, float *grad_offset,
+                                  uint32_t flags, void *workspace, size_t workspace_bytes, void *stream);
+
 /*
  * Backward w.r.t. input and offset (and mask for v2).  Replaces
  * deform_conv_backward_input_cuda (deform_conv_cuda.cpp:260-266) and the input/offset/mask part

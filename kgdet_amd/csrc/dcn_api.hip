@@ -120,6 +120,13 @@ bool plane_bwd_input_ok(const kgdet_dcn_shape *s, const Derived &d) {
          (size_t)8 * 33 * (d.K + 1) * sizeof(float) <= kMaxLds - 64 &&
          dcn_build_inverse_taps_lds_bytes(s->H * s->W, d.Ho * d.Wo) <= kMaxLds - 64;
 }
+// grad_offset on the plane kernel: v1, one deformable group, <= 256 output channels per group
+bool plane_bwd_offset_ok(const kgdet_dcn_shape *s, const Derived &d) {
+  return s->deformable_groups == 1 && s->groups == 1 && d.Og <= 256 && d.K <= 64 && s->H * s->W <= kPlaneMaxHW &&
+         dcn_bwd_offset_plane_lds_bytes(2, d.K, s->H * s->W) <= kMaxLds &&
+         (size_t)8 * 33 * (d.K + 1) * sizeof(float) <= kMaxLds - 64;
+}
+size_t grad_tap_bytes(const kgdet_dcn_shape *s, const Derived &d) { return (size_t)s->N * d.K * d.Ho * d.Wo * 48; }
 struct InvTables {
   size_t rec_bytes, slot_bytes, spill_bytes;
   size_t total() const { return rec_bytes + slot_bytes + spill_bytes; }
@@ -186,7 +193,9 @@ size_t kgdet_dcn_workspace_bytes(const kgdet_dcn_shape *s) {
   const size_t bwd_in = pl.ok ? (pl.slab_floats + pl.off_floats + pl.mask_floats) * sizeof(float) +
                                     pl.rowptr_ints * sizeof(int) + pl.entry_pairs * 8 + 64
                               : 0;
-  const size_t bwd_in_plane = plane_bwd_input_ok(s, d) ? slab_bytes() + inv_tables(s, d).total() : 0;
+  size_t bwd_in_plane = plane_bwd_input_ok(s, d) ? slab_bytes() + inv_tables(s, d).total() : 0;
+  if (plane_bwd_offset_ok(s, d) && slab_bytes() + grad_tap_bytes(s, d) > bwd_in_plane)
+    bwd_in_plane = slab_bytes() + grad_tap_bytes(s, d);
   size_t need = fwd_and_wgrad > bwd_in ? fwd_and_wgrad : bwd_in;
   return need > bwd_in_plane ? need : bwd_in_plane;
 }
@@ -497,6 +506,74 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
   return KGDET_OK;
 }
 
+int kgdet_deform_conv_grad_offset(const kgdet_dcn_shape *s, const float *input, const float *offset,
+                                  const float *packed_weight, const float *grad_output, float *grad_offset,
+                                  uint32_t flags, void *workspace, size_t workspace_bytes, void *stream) {
+  Derived d;
+  if (int rc = derive(s, d)) return rc;
+  KGDET_CHECK_SHAPE(input && offset && packed_weight && grad_output && grad_offset, "null pointer");
+  if (!plane_bwd_offset_ok(s, d)) {
+    set_error("grad_offset plane kernel: needs deformable_groups == 1, <= 256 output channels per group, H*W <= %d",
+              kPlaneMaxHW);
+    return KGDET_E_UNSUPPORTED;
+  }
+  const size_t need = slab_bytes() + grad_tap_bytes(s, d);
+  if (workspace == nullptr || workspace_bytes < need) {
+    set_error("workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    return KGDET_E_WORKSPACE;
+  }
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_bwd_offset_plane<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)kMaxLds));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_bwd_offset_plane<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)kMaxLds));
+    attr_set = true;
+  }
+  const int G = grid_size();
+  const int parts = (flags & KGDET_DCN_BF16) ? 1 : 2;
+  DcnFwdGroup grp;
+  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots;
+  grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
+  const DcnTapRec *recs = reinterpret_cast<const DcnTapRec *>((unsigned char *)workspace + slab_bytes());
+  for (int g = 0; g < s->groups; ++g) {
+    DcnProblem p;
+    fill_problem(s, d, g, p);
+    p.x = input; p.offset = offset; p.mask = nullptr; p.gout = grad_output; p.goff = grad_offset;
+    p.wq = packed_weight + (size_t)s->groups * (d.fwd_image_floats() + d.bwd_image_floats() + d.plane_image_floats()) +
+           (size_t)g * d.plane_t_image_floats();
+    p.taps = recs; p.build_taps = g == 0;
+    p.tiles_per_image = ceil_div(p.HoWo, kTileN);
+    p.n_ntiles = p.N * p.tiles_per_image;
+    p.n_mtiles = 1;
+    p.chunks_per_tap = d.Cg_pad / kChunk;
+    p.chunks_per_tile = d.K * p.chunks_per_tap;
+    p.total_units = (long long)p.n_ntiles * p.chunks_per_tile;
+    p.kparts = 1;
+    p.flags = flags;
+    if (grp.n == kMaxFwdGroup) { set_error("more than %d weight groups", kMaxFwdGroup); return KGDET_E_UNSUPPORTED; }
+    grp.p[grp.n] = p;
+    grp.tile_begin[grp.n + 1] = grp.tile_begin[grp.n] + p.n_ntiles;
+    grp.range_begin[grp.n + 1] = grp.range_begin[grp.n] + p.n_ntiles;
+    grp.unit_begin[grp.n + 1] = grp.unit_begin[grp.n] + p.total_units;
+    ++grp.n;
+  }
+  KGDET_CHECK_SHAPE(s->groups == 1, "grad_offset plane kernel: weight groups > 1 would need a sum over groups");
+  hipLaunchKernelGGL(dcn_build_grad_taps, dim3(2 * G, grp.n), dim3(256), 0, (hipStream_t)stream, grp);
+  const size_t lds = dcn_bwd_offset_plane_lds_bytes(parts, d.K, s->H * s->W);
+  const int threads = dcn_bwd_offset_plane_threads();
+  if (parts == 1)
+    hipLaunchKernelGGL(dcn_bwd_offset_plane<1>, dim3(G), dim3(threads), lds, (hipStream_t)stream, grp,
+                       (float *)workspace, d.K);
+  else
+    hipLaunchKernelGGL(dcn_bwd_offset_plane<2>, dim3(G), dim3(threads), lds, (hipStream_t)stream, grp,
+                       (float *)workspace, d.K);
+  hipLaunchKernelGGL(dcn_bwd_offset_plane_fixup, dim3(grp.tile_begin[grp.n], 8), dim3(256), 0, (hipStream_t)stream, grp,
+                     (const float *)workspace, G, d.K);
+  KGDET_CHECK_LAUNCH("dcn_bwd_offset_plane");
+  return KGDET_OK;
+}
+
 int kgdet_deform_conv_backward_input(const kgdet_dcn_shape *s, const float *input, const float *offset,
                                      const float *mask, const float *packed_weight, const float *grad_output,
                                      float *grad_input, float *grad_offset, float *grad_mask, void *workspace,
@@ -509,6 +586,17 @@ int kgdet_deform_conv_backward_input(const kgdet_dcn_shape *s, const float *inpu
     set_error("deformable_groups=%d / groups=%d / C=%d: channel tiles straddle deformable groups (unsupported)",
               s->deformable_groups, s->groups, s->C);
     return KGDET_E_UNSUPPORTED;
+  }
+  // v1 on small maps: the two plane kernels (grad_input by transposed sampling, grad_offset with the column
+  // gradient in registers), bf16 hi/lo split MFMA -- 2x faster than the f32 gather kernel below
+  static const bool plane_off = getenv("KGDET_DCN_BWD_GATHER") != nullptr;  // A/B switch for benchmarking
+  if (mask == nullptr && !plane_off && plane_bwd_input_ok(s, d) && plane_bwd_offset_ok(s, d) &&
+      workspace_bytes >= kgdet_dcn_workspace_bytes(s)) {
+    if (int rc = kgdet_deform_conv_grad_input(s, offset, nullptr, packed_weight, grad_output, grad_input, 0, workspace,
+                                              workspace_bytes, stream))
+      return rc;
+    return kgdet_deform_conv_grad_offset(s, input, offset, packed_weight, grad_output, grad_offset, 0, workspace,
+                                         workspace_bytes, stream);
   }
   const int G = grid_size();
   const int cpdg = s->C / s->deformable_groups;

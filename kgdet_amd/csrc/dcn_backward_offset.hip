@@ -1,0 +1,397 @@
+// Deformable convolution backward w.r.t. the offsets on an LDS-resident feature plane (gfx950).
+//
+// Reference path replaced: deformable_col2im_coord (deform_conv_cuda_kernel.cu:337-435, get_coordinate_weight
+// :144-187) applied to columns = W^T grad_out (deform_conv_cuda.cpp:329-332):
+//     grad_offset[b, 2t + dir, p] = sum_c colgrad[c, t, p] * d sample(x[b, c], pos(p, t)) / d dir,
+//     colgrad[c, t, p]            = sum_o W[o, c, t] * grad_out[b, o, p].
+// The reference materialises the [C*K, P] column-gradient matrix in HBM; here it never leaves registers:
+//   * a workgroup owns a tile of 128 output pixels of one image; each of its 8 consumer waves keeps the
+//     grad_out fragment of ITS 16 pixels -- [256 o][16 px], bf16 hi/lo, 64 VGPRs -- for the whole tile;
+//   * a stage = (16-channel chunk, tap): colgrad[16 c][16 px] = W_t^T[16 c x 256 o] . g[256 o x 16 px] as
+//     8 k-steps of v_mfma_f32_16x16x32_bf16 x 3 products (hi/lo split, fp32 accumulate); the W_t^T stage (16 KB)
+//     is staged in LDS by the producer waves straight from the transposed operand image `wqt`;
+//   * the accumulator layout hands every lane 4 consecutive channels of one pixel -- exactly one quad of the
+//     [pixel][16 channel] x plane in LDS, so the four bilinear corners are four ds_read_b128; the lane forms
+//     sum_c colgrad * corner, applies the record's derivative weights, the four quad lanes of a pixel are
+//     reduced with two cross-lane adds and the tap's running sums live in an LDS accumulator [K][128][2];
+//   * the reduction runs chunk-major / tap-minor like the forward kernel (the x plane is copied once per chunk),
+//     stream-K over (tile, stage) units, partial accumulators to slabs, dcn_bwd_offset_plane_fixup adds them.
+// v1 only (no modulation mask), output channels per group <= 256; other shapes stay on the gather kernel.
+#include "dcn_plane.h"
+
+namespace kgdet {
+
+namespace {
+
+constexpr int kOffThreads = kThreads + kProducers;  // 8 consumer + 4 producer waves
+constexpr int kMaxKs = 8;                            // k-steps of 32 output channels: Og <= 256
+
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+
+}  // namespace
+
+// One 48-byte record per (image, tap, output pixel): corner offsets as in DcnTapRec, and the weights that turn
+// the four corner values into d sample / dy and d sample / dx (zero where the corner, or the tap, is outside).
+__global__ __launch_bounds__(256) void dcn_build_grad_taps(const DcnFwdGroup grp) {
+  const DcnProblem &p = grp.p[blockIdx.y];
+  if (!p.build_taps) return;
+  const long long n_rec = (long long)p.N * p.K * p.HoWo;
+  uint4 *out = reinterpret_cast<uint4 *>(const_cast<DcnTapRec *>(p.taps));
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_rec; i += (long long)gridDim.x * 256) {
+    const int hw = (int)(i % p.HoWo);
+    const int t = (int)((i / p.HoWo) % p.K);
+    const int b = (int)(i / ((long long)p.HoWo * p.K));
+    const int oy = hw / p.Wo, ox = hw - oy * p.Wo;
+    const int ti = t / p.kw, tj = t - ti * p.kw;
+    const long long ob = ((long long)b * 2 * p.K + 2 * t) * p.HoWo + hw;
+    const float y = (float)(oy * p.sh - p.ph + ti * p.dh) + p.offset[ob];
+    const float x = (float)(ox * p.sw - p.pw + tj * p.dw) + p.offset[ob + p.HoWo];
+    Tap tap;
+    TapGeom geo;
+    make_tap(y, x, p.H, p.W, true, 1.0f, tap, geo);
+    const float hy = 1.0f - geo.ly, hx = 1.0f - geo.lx;
+    const float ka = geo.va ? 1.f : 0.f, kb = geo.vb ? 1.f : 0.f, kc = geo.vc ? 1.f : 0.f, kd = geo.vd ? 1.f : 0.f;
+    unsigned off[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) off[e] = (unsigned)(dcn_plane_offset(tap.o[e]) + (((tap.o[e] >> 2) & 3) << 4));
+    out[i * 3 + 0] = make_uint4(off[0], off[1], off[2], off[3]);
+    // d/dy = hx (v10 - v00) + lx (v11 - v01),  d/dx = hy (v01 - v00) + ly (v11 - v10)   (:144-187)
+    out[i * 3 + 1] = make_uint4(__float_as_uint(-hx * ka), __float_as_uint(-geo.lx * kb), __float_as_uint(hx * kc),
+                                __float_as_uint(geo.lx * kd));
+    out[i * 3 + 2] = make_uint4(__float_as_uint(-hy * ka), __float_as_uint(hy * kb), __float_as_uint(-geo.ly * kc),
+                                __float_as_uint(geo.ly * kd));
+  }
+}
+
+// LDS: A [2][PARTS][8 KB] | offs_acc [K][128][2] fp32 | x plane [H*W][16 ch] fp32
+size_t dcn_bwd_offset_plane_lds_bytes(int parts, int K, int HW) {
+  return (size_t)2 * parts * kAPart + (size_t)K * kTileN * 2 * sizeof(float) + (size_t)kChunk * HW * sizeof(float);
+}
+int dcn_bwd_offset_plane_threads() { return kOffThreads; }
+
+template <int PARTS, bool PRODUCER>
+__device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__restrict__ slabs, unsigned char *smem,
+                                            int max_K) {
+  unsigned char *As = smem;                                             // [2][PARTS][kAPart]: [o16][khalf][c 16][8 o]
+  float *offs_acc = reinterpret_cast<float *>(smem + 2 * PARTS * kAPart);  // [K][128][2]
+  unsigned char *plane = smem + 2 * PARTS * kAPart + (size_t)max_K * kTileN * 2 * sizeof(float);
+
+  const int wtid = threadIdx.x;
+  const int tid = PRODUCER ? wtid - kThreads : wtid;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int px16 = lane & 15, kg = lane >> 4;       // consumers: pixel inside the wave's 16, channel quad / k group
+  const long long G = gridDim.x, g = blockIdx.x;
+  const long long total = grp.unit_begin[grp.n];
+  const long long slice = sk_slice_of_block((int)g, (int)G);
+  const long long my_begin = unit_begin(slice, total, G);
+  const long long my_end = unit_begin(slice + 1, total, G);
+
+  long long cur = my_begin;
+  int slot = 0;
+  while (cur < my_end) {
+    const DcnUnitPos pos = dcn_unit_pos(grp, cur);
+    const DcnProblem &p = grp.p[pos.pi];
+    const int HW = p.H * p.W;
+    const int K = p.K;
+    const int cpt = p.chunks_per_tile;
+    const int nt = pos.tile;  // one M "tile": the channel chunks are part of the reduction here
+    const int s_begin = pos.s;
+    const int s_end = (int)((my_end - cur) < (long long)(pos.s_hi - pos.s) ? pos.s + (my_end - cur) : pos.s_hi);
+    const int tile_b = nt / p.tiles_per_image;
+    const int tile_px0 = (nt - tile_b * p.tiles_per_image) * kTileN;
+    const int HoWo = p.HoWo;
+    const int n_o16 = (p.Og + kChunk - 1) / kChunk;   // 16-channel chunks of output channels in `wqt`
+    const int n_ks = (n_o16 + 1) / 2;                  // k-steps of 32 output channels
+    // this lane's pixel (columns past the end of the image redo pixel 0: never stored)
+    const int my_px = tile_px0 + wave * 16 + px16;
+    const int my_px_c = my_px < HoWo ? my_px : 0;
+
+    // ---- consumers: grad_out fragment of the wave's 16 pixels, [n_ks][8 o] per lane, bf16 hi / lo ----
+    bf16x8v gh[PRODUCER ? 1 : kMaxKs], gl[PRODUCER ? 1 : kMaxKs];
+    if constexpr (!PRODUCER) {
+      const float *gimg = p.gout + ((long long)tile_b * p.O_total + p.o_base) * HoWo + my_px_c;
+#pragma unroll
+      for (int ks = 0; ks < kMaxKs; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int o = ks * 32 + kg * 8 + j;
+          v[j] = gimg[(long long)min(o, p.Og - 1) * HoWo];  // unconditional, clamped
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int o = ks * 32 + kg * 8 + j;
+          const float f = (o < p.Og && ks < n_ks) ? v[j] : 0.0f;
+          gh[ks][j] = (__bf16)f;
+          gl[ks][j] = (__bf16)(f - (float)gh[ks][j]);
+        }
+      }
+    }
+    // zero the tap accumulators of this range
+    __syncthreads();
+    for (int i = wtid; i < K * kTileN * 2; i += kOffThreads) offs_acc[i] = 0.0f;
+
+    struct Regs {
+      f32x4 a[PARTS][2];     // producers: this thread's 2 x 16 B of each part of the W^T stage
+      uint4 off;             // consumers: the record of (pixel, tap)
+      f32x4 wy, wx;
+    };
+
+    int s = s_begin;
+    int c16 = s / K;
+    int t0 = s - c16 * K;
+    while (s < s_end) {
+      const int n = min(K - t0, s_end - s);
+      const uint4 *rec_base = reinterpret_cast<const uint4 *>(p.taps) + ((size_t)tile_b * K * HoWo + my_px_c) * 3;
+      // W^T stage of (chunk c16, tap t): for every 16-o chunk o16 the rows c16*16 .. +15 of both k-halves:
+      // 256-byte runs inside wqt[ct][o16][t][part][khalf][c 256][8 o]
+      const int ct = (c16 * kChunk) / kTileM, c_in = (c16 * kChunk) % kTileM;
+      const unsigned char *wq_base = reinterpret_cast<const unsigned char *>(p.wq);
+
+      auto issue = [&](int j, Regs &R) {
+        const int t = t0 + min(j, n - 1);
+        if constexpr (PRODUCER) {
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int idx = tid + r * kProducers;          // 16-byte unit of the stage image: [o16 16][khalf 2][c 16]
+            const int c = idx & 15, khalf = (idx >> 4) & 1, o16 = idx >> 5;
+            const int o16c = min(o16, n_o16 - 1);
+#pragma unroll
+            for (int part = 0; part < PARTS; ++part) {
+              const size_t src = (size_t)((ct * n_o16 + o16c) * K + t) * (2 * kAPart) + part * kAPart +
+                                 khalf * (kTileM * 16) + (c_in + c) * 16;
+              R.a[part][r] = *reinterpret_cast<const f32x4 *>(wq_base + src);
+            }
+          }
+        } else {
+          const uint4 *rec = rec_base + (size_t)t * HoWo * 3;
+          R.off = rec[0];
+          R.wy = *reinterpret_cast<const f32x4 *>(rec + 1);
+          R.wx = *reinterpret_cast<const f32x4 *>(rec + 2);
+        }
+      };
+      auto commit_weights = [&](int buf, const Regs &R) {
+        if constexpr (PRODUCER) {
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int idx = tid + r * kProducers;
+            const bool real = (idx >> 5) < n_o16;
+#pragma unroll
+            for (int part = 0; part < PARTS; ++part)
+              *reinterpret_cast<f32x4 *>(As + (buf * PARTS + part) * kAPart + idx * 16) =
+                  real ? R.a[part][r] : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      };
+      auto load_plane = [&]() {  // as in plane_role: x[tile_b, 16 channels of chunk c16] -> LDS [pixel][16 ch], swizzled
+        const int c0 = c16 * kChunk;
+        const float *xb = p.x + ((long long)tile_b * p.C_total + p.c_base) * HW;
+        const int items = 4 * HW;
+        for (int i0 = 0; i0 < items; i0 += kPlaneRounds * kOffThreads) {
+          f32x4 v[kPlaneRounds];
+#pragma unroll
+          for (int r = 0; r < kPlaneRounds; ++r) {
+            const int i = min(i0 + r * kOffThreads + wtid, items - 1);
+            const int q = i % HW, quad = i / HW;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int ch = c0 + quad * 4 + e;
+              // channels past the group's end must read as ZERO here (they would otherwise enter grad_offset
+              // through a non-zero colgrad of padded weight rows... which are zero; keep both sides zero)
+              v[r][e] = ch < p.Cg ? xb[(long long)ch * HW + q] : xb[(long long)(p.Cg - 1) * HW + q] * 0.0f;
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < kPlaneRounds; ++r) {
+            const int i = i0 + r * kOffThreads + wtid;
+            if (i < items) {
+              const int q = i % HW, quad = i / HW;
+              *reinterpret_cast<f32x4 *>(plane + dcn_plane_offset(q) + ((quad ^ ((q >> 2) & 3)) << 4)) = v[r];
+            }
+          }
+        }
+      };
+      // one stage on the consumer side: colgrad block, derivative dot products, tap accumulators
+      auto consume = [&](int j, int buf, const Regs &R) {
+        if constexpr (!PRODUCER) {
+          const unsigned char *A = As + buf * PARTS * kAPart + kg * 256 + px16 * 16;  // lane's row c = px16 (reused name)
+          f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
+#pragma unroll
+          for (int ks = 0; ks < kMaxKs; ++ks) {
+            if (ks < n_ks) {
+              const bf16x8v ah = *reinterpret_cast<const bf16x8v *>(A + ks * 1024);
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, gh[ks], acc0, 0, 0, 0);
+              if constexpr (PARTS == 2) {
+                const bf16x8v al = *reinterpret_cast<const bf16x8v *>(A + kAPart + ks * 1024);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, gh[ks], acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, gl[ks], acc2, 0, 0, 0);
+              }
+            }
+          }
+          f32x4 cg = acc0;
+          if constexpr (PARTS == 2) { cg[0] += acc1[0] + acc2[0]; cg[1] += acc1[1] + acc2[1]; cg[2] += acc1[2] + acc2[2]; cg[3] += acc1[3] + acc2[3]; }
+          // cg[r] = colgrad of channel 4 * kg + r for pixel px16: the x quad kg of the four corners
+          const unsigned o[4] = {R.off.x, R.off.y, R.off.z, R.off.w};
+          float gy = 0.f, gx = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(plane + (o[e] ^ (unsigned)(kg << 4)));
+            const float d = cg[0] * v[0] + cg[1] * v[1] + cg[2] * v[2] + cg[3] * v[3];
+            gy += R.wy[e] * d;
+            gx += R.wx[e] * d;
+          }
+          gy += __shfl_xor(gy, 16);
+          gx += __shfl_xor(gx, 16);
+          gy += __shfl_xor(gy, 32);
+          gx += __shfl_xor(gx, 32);
+          if (kg == 0) {
+            float2 *dst = reinterpret_cast<float2 *>(offs_acc) + (size_t)(t0 + j) * kTileN + wave * 16 + px16;
+            float2 cur2 = *dst;
+            cur2.x += gy;
+            cur2.y += gx;
+            *dst = cur2;
+          }
+        }
+      };
+
+      Regs R0, R1, R2;
+      __syncthreads();  // the previous segment's readers of plane / A are done; offs_acc zeroing is visible
+      issue(0, R0);
+      issue(1, R1);
+      issue(2, R2);
+      load_plane();
+      commit_weights(0, R0);
+      __syncthreads();
+      // stage j: producers move W^T stage j+1 into the other buffer and put stage j+3 in flight; consumers
+      // multiply stage j (their record registers run the same three-deep pipeline)
+      auto body = [&](int j, Regs &RI, Regs &RC, Regs &RN) {
+        const int buf = j & 1;
+        if constexpr (PRODUCER) {
+          if (j + 1 < n) commit_weights(buf ^ 1, RC);
+          issue(j + 3, RI);
+        } else {
+          if (j < n) consume(j, buf, RI);  // RI still holds stage j for the consumers ...
+          issue(j + 3, RI);                // ... until here
+        }
+        (void)RN;
+        __syncthreads();
+      };
+      for (int j = 0; j < n; j += 6) {
+        body(j, R0, R1, R2);
+        body(j + 1, R1, R2, R0);
+        body(j + 2, R2, R0, R1);
+        if (j + 3 < n) {
+          body(j + 3, R0, R1, R2);
+          body(j + 4, R1, R2, R0);
+          body(j + 5, R2, R0, R1);
+        }
+      }
+      s += n;
+      ++c16;
+      t0 = 0;
+    }
+
+    // the range's tap sums: straight to grad_offset if the range is the whole tile, else to a slab
+    __syncthreads();
+    {
+      const bool whole = s_begin == 0 && s_end == cpt;
+      float *slab = slabs + ((long long)g * grp.slots + slot) * (size_t)(max_K * kTileN * 2);
+      for (int i = wtid; i < K * kTileN; i += kOffThreads) {
+        const int t = i / kTileN, col = i - t * kTileN;
+        const float2 v = reinterpret_cast<const float2 *>(offs_acc)[i];
+        if (whole) {
+          const int px = tile_px0 + col;
+          if (px < HoWo) {
+            float *dst = p.goff + ((long long)tile_b * 2 * K + 2 * t) * HoWo + px;
+            dst[0] = v.x;
+            dst[HoWo] = v.y;
+          }
+        } else {
+          reinterpret_cast<float2 *>(slab)[i] = v;
+        }
+      }
+    }
+    ++slot;
+    cur += s_end - s_begin;
+  }
+}
+
+template <int PARTS>
+__global__ __launch_bounds__(kOffThreads, 1) void dcn_bwd_offset_plane(const DcnFwdGroup grp, float *__restrict__ slabs,
+                                                                       int max_K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (threadIdx.x >= kThreads) offset_role<PARTS, true>(grp, slabs, smem, max_K);
+  else offset_role<PARTS, false>(grp, slabs, smem, max_K);
+}
+
+template __global__ void dcn_bwd_offset_plane<1>(const DcnFwdGroup grp, float *__restrict__ slabs, int max_K);
+template __global__ void dcn_bwd_offset_plane<2>(const DcnFwdGroup grp, float *__restrict__ slabs, int max_K);
+
+// Split tiles: add the slabs of a tile's ranges, slices in order.  grid = (tiles, 8): block (tile, y) handles every
+// 8th group of 256 (tap, pixel) elements; the contributing slabs are listed once per block.
+__global__ __launch_bounds__(256) void dcn_bwd_offset_plane_fixup(const DcnFwdGroup grp, const float *__restrict__ slabs,
+                                                                  int G, int max_K) {
+  __shared__ long long contrib[64];
+  __shared__ int n_contrib;
+  __shared__ long long contrib_next;
+  const int gtile = blockIdx.x;
+  int pi = 0;
+  while (pi + 1 < grp.n && gtile >= grp.tile_begin[pi + 1]) ++pi;
+  const DcnProblem &p = grp.p[pi];
+  const int tile = gtile - grp.tile_begin[pi];
+  const long long total = grp.unit_begin[grp.n];
+  const long long tb = dcn_range_first_unit(grp, pi, 0, tile), te = tb + p.chunks_per_tile;
+  long long g0 = tb * G / total;
+  while (unit_begin(g0 + 1, total, G) <= tb) ++g0;
+  while (unit_begin(g0, total, G) > tb) --g0;
+  if (unit_begin(g0, total, G) <= tb && unit_begin(g0 + 1, total, G) >= te) return;  // written directly
+  const size_t slab_floats = (size_t)max_K * kTileN * 2;
+  const int range = grp.range_begin[pi] + tile;
+  const int tile_b = tile / p.tiles_per_image, tile_px0 = (tile - tile_b * p.tiles_per_image) * kTileN;
+  constexpr int kMaxElems = 4;  // (tap, pixel) elements per thread: K * 128 / (256 * gridDim.y), K <= 64
+  float sy[kMaxElems] = {0.f, 0.f, 0.f, 0.f}, sx[kMaxElems] = {0.f, 0.f, 0.f, 0.f};
+  long long g = g0;
+  bool more = true;
+  while (more) {  // contributors in batches of 64, slices in order
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int n = 0;
+      for (; g < G && n < 64; ++g) {
+        const long long b0 = unit_begin(g, total, G);
+        if (b0 >= te) break;
+        if (unit_begin(g + 1, total, G) == b0) continue;
+        contrib[n++] = ((long long)sk_block_of_slice((int)g, G) * grp.slots + (range - dcn_unit_pos(grp, b0).range)) *
+                       (long long)slab_floats;
+      }
+      n_contrib = n;
+      contrib_next = (g < G && unit_begin(g, total, G) < te) ? g : -1;
+    }
+    __syncthreads();
+    const int n = n_contrib;
+    g = contrib_next;
+    more = g >= 0;
+#pragma unroll
+    for (int e = 0; e < kMaxElems; ++e) {
+      const int i = (blockIdx.y + e * gridDim.y) * 256 + threadIdx.x;
+      if (i < p.K * kTileN)
+        for (int q = 0; q < n; ++q) {
+          const float2 v = reinterpret_cast<const float2 *>(slabs + contrib[q])[i];
+          sy[e] += v.x;
+          sx[e] += v.y;
+        }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < kMaxElems; ++e) {
+    const int i = (blockIdx.y + e * gridDim.y) * 256 + threadIdx.x;
+    if (i >= p.K * kTileN) continue;
+    const int t = i / kTileN, px = tile_px0 + (i - t * kTileN);
+    if (px < p.HoWo) {
+      float *dst = p.goff + ((long long)tile_b * 2 * p.K + 2 * t) * p.HoWo + px;
+      dst[0] = sy[e];
+      dst[p.HoWo] = sx[e];
+    }
+  }
+}
+
+}  // namespace kgdet

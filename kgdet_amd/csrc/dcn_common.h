@@ -58,6 +58,8 @@ struct DcnProblem {
   int build_taps;         // this problem owns `taps` (others of the group may alias it: same offsets and geometry)
   const float *bias;    // [O_total] or nullptr
   float *out;           // forward: [N, O_total, Ho, Wo]
+  const float *gout;    // grad_offset kernel: grad_output [N, O_total, Ho, Wo]
+  float *goff;          //                     grad_offset [N, 2K, Ho, Wo]
   int N, C_total, c_base, Cg, Cg_pad;
   int O_total, o_base, Og, Og_pad;  // o_base: first channel of this group inside the output buffer
   int bias_base;                    // first channel of this group in the conv's own numbering

@@ -19,6 +19,13 @@ size_t dcn_bwd_input_plane_lds_bytes(int parts, int plane_pixels);
 __global__ void dcn_build_inverse_taps(const DcnProblem p, uint4 *__restrict__ inv, DcnInvOvfSlots *__restrict__ slots,
                                        uint2 *__restrict__ spill);
 size_t dcn_build_inverse_taps_lds_bytes(int HW, int HoWo);
+// grad_offset on an LDS-resident plane (dcn_backward_offset.hip)
+template <int PARTS>
+__global__ void dcn_bwd_offset_plane(const DcnFwdGroup grp, float *__restrict__ slabs, int max_K);
+__global__ void dcn_bwd_offset_plane_fixup(const DcnFwdGroup grp, const float *__restrict__ slabs, int G, int max_K);
+__global__ void dcn_build_grad_taps(const DcnFwdGroup grp);
+size_t dcn_bwd_offset_plane_lds_bytes(int parts, int K, int HW);
+int dcn_bwd_offset_plane_threads();
 __global__ void dcn_pack_weight_all(const float *__restrict__ w, float *__restrict__ wpk, float *__restrict__ wpt,
                                     void *__restrict__ wq /*nullable*/, void *__restrict__ wqt /*nullable*/, int Og,
                                     int Cg, int K, int Cg_pad, int Og_pad, int Og_pad16, int Cg_pad256);

@@ -207,6 +207,24 @@ def grad_input_plane(input_size, offset, mask, weight, grad_output, shape, packe
     return grad_input
 
 
+def grad_offset_plane(input, offset, weight, grad_output, shape, packed=None, bf16=False):
+    """grad_offset (v1) of a deformable conv with the column gradient kept in registers
+    (kgdet_deform_conv_grad_offset)."""
+    L = _lib.lib()
+    _require_f32(input, offset, weight, grad_output)
+    if packed is None:
+        packed = pack_weight(weight.contiguous(), shape)
+    grad_output = grad_output.contiguous()
+    offset = offset.contiguous()
+    grad_offset = torch.empty_like(offset)
+    ws = _workspace(grad_output.device, L.kgdet_dcn_workspace_bytes(ctypes.byref(shape)))
+    _lib.check(L.kgdet_deform_conv_grad_offset(
+        ctypes.byref(shape), _lib.ptr(input.contiguous()), _lib.ptr(offset), _lib.ptr(packed), _lib.ptr(grad_output),
+        _lib.ptr(grad_offset), ctypes.c_uint32(_lib.DCN_BF16 if bf16 else 0), _lib.ptr(ws),
+        ctypes.c_size_t(ws.numel()), _lib.current_stream()), 'kgdet_deform_conv_grad_offset')
+    return grad_offset
+
+
 def _backward(input, offset, mask, weight, bias, grad_output, shape, packed, needs):
     """Returns grad_input, grad_offset, grad_mask, grad_weight, grad_bias (None where not needed)."""
     L = _lib.lib()

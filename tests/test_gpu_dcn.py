@@ -274,3 +274,20 @@ def test_grad_input_plane_kernel_long_lists():
     ref = oracle.deform_conv_backward(x.astype(np.float64), off.astype(np.float64), w.astype(np.float64),
                                       go.astype(np.float64), s, p, d, g, dg)['grad_input']
     _close(gi.cpu().numpy(), ref, 5e-5)
+
+
+@pytest.mark.parametrize('case', [c for c in CASES if c[10] == 1 and c[9] == 1 and c[4] <= 256])
+def test_grad_offset_plane_kernel(case):
+    """kgdet_deform_conv_grad_offset (column gradient in registers, feature plane in LDS) vs the float64 oracle."""
+    _require_gpu()
+    from kgdet_amd import dcn
+    N, C, H, W, O, k, s, p, d, g, dg = case
+    x, off, w, go, _ = _make(case, seed=13)
+    tx, to, tw, tg = (torch.from_numpy(a).cuda() for a in (x, off, w, go))
+    shape = dcn._shape(tx, tw, (s, s), (p, p), (d, d), g, dg)
+    a = dcn.grad_offset_plane(tx, to, tw, tg, shape)
+    b = dcn.grad_offset_plane(tx, to, tw, tg, shape)
+    assert torch.equal(a, b), 'grad_offset must be deterministic'
+    ref = oracle.deform_conv_backward(x.astype(np.float64), off.astype(np.float64), w.astype(np.float64),
+                                      go.astype(np.float64), s, p, d, g, dg)['grad_offset']
+    _close(a.cpu().numpy(), ref, 5e-5)
