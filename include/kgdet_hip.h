@@ -117,6 +117,16 @@ int kgdet_deform_conv_grad_offset(const kgdet_dcn_shape *s, const float *input, 
                                   const float *packed_weight, const float *grad_output, float *grad_offset,
                                   uint32_t flags, void *workspace, size_t workspace_bytes, void *stream);
 
+/* grad_input and grad_offset of n v1 problems in two grouped launches (one per quantity); same results as
+ * kgdet_deform_conv_grad_input + kgdet_deform_conv_grad_offset per problem.  n <= 8; every problem must be
+ * eligible for both kernels and have groups == 1 (KGDET_E_UNSUPPORTED otherwise -- call the single entry points).
+ * workspace >= kgdet_dcn_group_workspace_bytes(n, shapes). */
+int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *const *shapes, const float *const *inputs,
+                                             const float *const *offsets, const float *const *packed_weights,
+                                             const float *const *grad_outputs, float *const *grad_inputs,
+                                             float *const *grad_offsets, void *workspace, size_t workspace_bytes,
+                                             void *stream);
+
 /*
  * Backward w.r.t. input and offset (and mask for v2).  Replaces
  * deform_conv_backward_input_cuda (deform_conv_cuda.cpp:260-266) and the input/offset/mask part

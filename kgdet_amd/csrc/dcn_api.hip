@@ -201,15 +201,16 @@ size_t kgdet_dcn_workspace_bytes(const kgdet_dcn_shape *s) {
 }
 
 size_t kgdet_dcn_group_workspace_bytes(int32_t n, const kgdet_dcn_shape *const *shapes) {
-  size_t tables = 0, single = 0;
+  size_t tables = 0, bwd_tables = 0, single = 0;
   for (int i = 0; i < n; ++i) {
     Derived d;
     if (!shapes || derive(shapes[i], d)) return 0;
     tables += tap_table_bytes(shapes[i], d);
+    if (plane_bwd_input_ok(shapes[i], d)) bwd_tables += align_up(inv_tables(shapes[i], d).total(), 256);
     const size_t w = kgdet_dcn_workspace_bytes(shapes[i]);
     single = w > single ? w : single;
   }
-  const size_t grouped = slab_bytes() + tables;
+  const size_t grouped = slab_bytes() + (tables > bwd_tables ? tables : bwd_tables);
   return grouped > single ? grouped : single;
 }
 
@@ -571,6 +572,160 @@ int kgdet_deform_conv_grad_offset(const kgdet_dcn_shape *s, const float *input, 
   hipLaunchKernelGGL(dcn_bwd_offset_plane_fixup, dim3(grp.tile_begin[grp.n], 8), dim3(256), 0, (hipStream_t)stream, grp,
                      (const float *)workspace, G, d.K);
   KGDET_CHECK_LAUNCH("dcn_bwd_offset_plane");
+  return KGDET_OK;
+}
+
+// n v1 problems: grad_input of all of them in one dcn_bwd_input_plane launch, grad_offset of all of them in one
+// dcn_bwd_offset_plane launch (inverse / gradient records are built once per distinct offset tensor).
+int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *const *shapes, const float *const *inputs,
+                                             const float *const *offsets, const float *const *packed_weights,
+                                             const float *const *grad_outputs, float *const *grad_inputs,
+                                             float *const *grad_offsets, void *workspace, size_t workspace_bytes,
+                                             void *stream) {
+  KGDET_CHECK_SHAPE(n >= 1 && n <= kMaxFwdGroup && shapes && inputs && offsets && packed_weights && grad_outputs &&
+                        grad_inputs && grad_offsets, "null pointer / group size not in [1, %d]", kMaxFwdGroup);
+  const int G = grid_size();
+  Derived dd[kMaxFwdGroup];
+  int same_as[kMaxFwdGroup];  // earlier problem with the same offsets and geometry (shares its records)
+  size_t inv_off[kMaxFwdGroup], rec_off[kMaxFwdGroup], inv_total = 0, rec_total = 0;
+  int max_K = 0;
+  for (int i = 0; i < n; ++i) {
+    const kgdet_dcn_shape *s = shapes[i];
+    if (int rc = derive(s, dd[i])) return rc;
+    KGDET_CHECK_SHAPE(inputs[i] && offsets[i] && packed_weights[i] && grad_outputs[i] && grad_inputs[i] &&
+                          grad_offsets[i], "null pointer (problem %d)", i);
+    if (s->groups != 1 || !plane_bwd_input_ok(s, dd[i]) || !plane_bwd_offset_ok(s, dd[i])) {
+      set_error("problem %d is not eligible for the plane backward kernels", i);
+      return KGDET_E_UNSUPPORTED;
+    }
+    same_as[i] = -1;
+    for (int q = 0; q < i && same_as[i] < 0; ++q) {
+      const kgdet_dcn_shape *o = shapes[q];
+      if (offsets[q] == offsets[i] && o->N == s->N && o->H == s->H && o->W == s->W && o->kh == s->kh && o->kw == s->kw &&
+          o->stride_h == s->stride_h && o->stride_w == s->stride_w && o->pad_h == s->pad_h && o->pad_w == s->pad_w &&
+          o->dil_h == s->dil_h && o->dil_w == s->dil_w)
+        same_as[i] = same_as[q] >= 0 ? same_as[q] : q;
+    }
+    if (same_as[i] < 0) {
+      inv_off[i] = inv_total; inv_total += align_up(inv_tables(s, dd[i]).total(), 256);
+      rec_off[i] = rec_total; rec_total += align_up(grad_tap_bytes(s, dd[i]), 256);
+    } else {
+      inv_off[i] = inv_off[same_as[i]]; rec_off[i] = rec_off[same_as[i]];
+    }
+    max_K = dd[i].K > max_K ? dd[i].K : max_K;
+  }
+  const size_t tables = inv_total > rec_total ? inv_total : rec_total;  // the two phases run one after the other
+  if (workspace == nullptr || workspace_bytes < slab_bytes() + tables) {
+    set_error("workspace too small: need %zu bytes, got %zu (kgdet_dcn_group_workspace_bytes)", slab_bytes() + tables,
+              workspace_bytes);
+    return KGDET_E_WORKSPACE;
+  }
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_build_inverse_taps, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)kMaxLds - 64));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_bwd_input_plane<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)kMaxLds));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_bwd_offset_plane<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)kMaxLds));
+    attr_set = true;
+  }
+  unsigned char *tab = (unsigned char *)workspace + slab_bytes();
+  auto check_slots = [&](const DcnFwdGroup &grp) -> bool {  // a slice must not meet more ranges than it has slab slots
+    int min_len = 1 << 30;
+    for (int i = 0; i < grp.n; ++i) min_len = grp.p[i].chunks_per_tile < min_len ? grp.p[i].chunks_per_tile : min_len;
+    return ceil_div((int)ceil_div((int)grp.unit_begin[grp.n], G), min_len) + 2 <= kSlabSlots;
+  };
+
+  // ---- phase 1: grad_input (transposed sampling) ----
+  DcnFwdGroup grp;
+  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots;
+  grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
+  size_t lds = 0;
+  for (int i = 0; i < n; ++i) {
+    const kgdet_dcn_shape *s = shapes[i];
+    const Derived &d = dd[i];
+    const InvTables it = inv_tables(s, d);
+    uint4 *inv = (uint4 *)(tab + inv_off[i]);
+    DcnInvOvfSlots *slots = (DcnInvOvfSlots *)(tab + inv_off[i] + it.rec_bytes);
+    uint2 *spill = (uint2 *)(tab + inv_off[i] + it.rec_bytes + it.slot_bytes);
+    if (same_as[i] < 0) {
+      DcnProblem f;
+      fill_problem(s, d, 0, f);
+      f.offset = offsets[i]; f.mask = nullptr;
+      hipLaunchKernelGGL(dcn_build_inverse_taps, dim3(s->N * d.K), dim3(256),
+                         dcn_build_inverse_taps_lds_bytes(s->H * s->W, d.Ho * d.Wo), (hipStream_t)stream, f, inv, slots,
+                         spill);
+    }
+    DcnProblem p{};
+    p.x = grad_outputs[i]; p.out = grad_inputs[i];
+    p.N = s->N;
+    p.C_total = s->out_channels_total > 0 ? s->out_channels_total : s->O;
+    p.c_base = s->out_channel_offset; p.Cg = d.Og; p.Cg_pad = d.Og_pad16;
+    p.O_total = s->C; p.o_base = 0; p.Og = d.Cg; p.Og_pad = d.Cg_pad256;
+    p.H = d.Ho; p.W = d.Wo;
+    p.Ho = s->H; p.Wo = s->W; p.HoWo = s->H * s->W; p.P = s->N * p.HoWo;
+    p.kh = s->kh; p.kw = s->kw; p.K = d.K;
+    p.DG = 1; p.cpdg = p.C_total;
+    p.tiles_per_image = ceil_div(p.HoWo, kTileN);
+    p.n_ntiles = p.N * p.tiles_per_image;
+    p.n_mtiles = d.Cg_pad256 / kTileM;
+    p.chunks_per_tap = d.Og_pad16 / kChunk;
+    p.chunks_per_tile = d.K * p.chunks_per_tap;
+    p.total_units = (long long)p.n_ntiles * p.n_mtiles * p.chunks_per_tile;
+    p.kparts = 1;
+    p.wq = packed_weights[i] + (d.fwd_image_floats() + d.bwd_image_floats() + d.plane_image_floats());
+    p.taps = reinterpret_cast<const DcnTapRec *>(inv);
+    p.inv_ovf = slots; p.inv_spill = spill;
+    grp.p[grp.n] = p;
+    grp.tile_begin[grp.n + 1] = grp.tile_begin[grp.n] + p.n_ntiles * p.n_mtiles;
+    grp.range_begin[grp.n + 1] = grp.range_begin[grp.n] + p.n_ntiles * p.n_mtiles;
+    grp.unit_begin[grp.n + 1] = grp.unit_begin[grp.n] + p.total_units;
+    ++grp.n;
+    const size_t need = dcn_bwd_input_plane_lds_bytes(2, d.Ho * d.Wo);
+    lds = need > lds ? need : lds;
+  }
+  if (!check_slots(grp)) { set_error("group too uneven for the slab slots"); return KGDET_E_UNSUPPORTED; }
+  hipLaunchKernelGGL(dcn_bwd_input_plane<2>, dim3(G), dim3(dcn_fwd_plane_threads()), lds, (hipStream_t)stream, grp,
+                     (float *)workspace);
+  hipLaunchKernelGGL(dcn_fwd_fixup, dim3(grp.tile_begin[grp.n], 16), dim3(kThreads), 0, (hipStream_t)stream, grp,
+                     (const float *)workspace, G);
+
+  // ---- phase 2: grad_offset (column gradient in registers) ----
+  grp.n = 0;
+  lds = 0;
+  for (int i = 0; i < n; ++i) {
+    const kgdet_dcn_shape *s = shapes[i];
+    const Derived &d = dd[i];
+    DcnProblem p;
+    fill_problem(s, d, 0, p);
+    p.x = inputs[i]; p.offset = offsets[i]; p.mask = nullptr; p.gout = grad_outputs[i]; p.goff = grad_offsets[i];
+    p.wq = packed_weights[i] + (d.fwd_image_floats() + d.bwd_image_floats() + d.plane_image_floats());
+    p.taps = reinterpret_cast<const DcnTapRec *>(tab + rec_off[i]);
+    p.build_taps = same_as[i] < 0;
+    p.tiles_per_image = ceil_div(p.HoWo, kTileN);
+    p.n_ntiles = p.N * p.tiles_per_image;
+    p.n_mtiles = 1;
+    p.chunks_per_tap = d.Cg_pad / kChunk;
+    p.chunks_per_tile = d.K * p.chunks_per_tap;
+    p.total_units = (long long)p.n_ntiles * p.chunks_per_tile;
+    p.kparts = 1;
+    p.flags = 0;
+    grp.p[grp.n] = p;
+    grp.tile_begin[grp.n + 1] = grp.tile_begin[grp.n] + p.n_ntiles;
+    grp.range_begin[grp.n + 1] = grp.range_begin[grp.n] + p.n_ntiles;
+    grp.unit_begin[grp.n + 1] = grp.unit_begin[grp.n] + p.total_units;
+    ++grp.n;
+    const size_t need = dcn_bwd_offset_plane_lds_bytes(2, max_K, s->H * s->W);
+    lds = need > lds ? need : lds;
+  }
+  if (lds > kMaxLds || !check_slots(grp)) { set_error("group does not fit the grad_offset kernel"); return KGDET_E_UNSUPPORTED; }
+  hipLaunchKernelGGL(dcn_build_grad_taps, dim3(2 * G, grp.n), dim3(256), 0, (hipStream_t)stream, grp);
+  hipLaunchKernelGGL(dcn_bwd_offset_plane<2>, dim3(G), dim3(dcn_bwd_offset_plane_threads()), lds, (hipStream_t)stream, grp,
+                     (float *)workspace, max_K);
+  hipLaunchKernelGGL(dcn_bwd_offset_plane_fixup, dim3(grp.tile_begin[grp.n], 8), dim3(256), 0, (hipStream_t)stream, grp,
+                     (const float *)workspace, G, max_K);
+  KGDET_CHECK_LAUNCH("dcn_bwd_plane_grouped");
   return KGDET_OK;
 }
 

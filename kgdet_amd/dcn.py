@@ -528,19 +528,47 @@ class DeformConvCatFunction(Function):
         grad_xs = [None] * n_x
         grad_offs = [None] * n_k
         grad_ws = [None] * (n_x * n_k)
+        gouts = []
         for i in range(n_x):
             grad_out = grad_outs[i]
             if ctx.relu:
                 grad_out = grad_out * (outs[i] > 0).to(grad_out.dtype)
-            grad_out = grad_out.contiguous()
+            gouts.append(grad_out.contiguous())
+        need_io = any(need[:n_x + n_k])
+        done_io = False
+        if need_io:
+            # grad_input / grad_offset of all n_x * n_k convs: two grouped launches
+            L = _lib.lib()
+            n = n_x * n_k
+            gis = [torch.empty_like(xs[j // n_k]) for j in range(n)]
+            gos = [torch.empty_like(offsets[j % n_k]) for j in range(n)]
+            arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+            shape_arr = (ctypes.POINTER(_lib.DcnShape) * n)(*[ctypes.pointer(s) for s in ctx.shapes])
+            ws = _workspace(xs[0].device, L.kgdet_dcn_group_workspace_bytes(ctypes.c_int32(n), shape_arr))
+            rc = L.kgdet_deform_conv_backward_input_grouped(
+                ctypes.c_int32(n), shape_arr, arr([xs[j // n_k] for j in range(n)]),
+                arr([offsets[j % n_k] for j in range(n)]), arr(packs), arr([gouts[j // n_k] for j in range(n)]),
+                arr(gis), arr(gos), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.current_stream())
+            if rc == _lib.KGDET_OK:
+                done_io = True
+                for i in range(n_x):
+                    if need[i]:
+                        grad_xs[i] = torch.stack(gis[i * n_k:(i + 1) * n_k]).sum(0) if n_k > 1 else gis[i * n_k]
+                for k in range(n_k):
+                    if need[n_x + k]:
+                        grad_offs[k] = torch.stack(gos[k::n_k]).sum(0) if n_x > 1 else gos[k]
+            elif rc != _lib.KGDET_E_UNSUPPORTED:
+                _lib.check(rc, 'kgdet_deform_conv_backward_input_grouped')
+        for i in range(n_x):
             for k in range(n_k):
                 j = i * n_k + k
-                needs = dict(input=need[i], offset=need[n_x + k], mask=False, weight=need[n_x + n_k + j], bias=False)
-                gi, go, _, gw, _ = _backward(xs[i], offsets[k], None, weights[j], None, grad_out, ctx.shapes[j],
+                needs = dict(input=need[i] and not done_io, offset=need[n_x + k] and not done_io, mask=False,
+                             weight=need[n_x + n_k + j], bias=False)
+                gi, go, _, gw, _ = _backward(xs[i], offsets[k], None, weights[j], None, gouts[i], ctx.shapes[j],
                                              packs[j], needs)
-                if gi is not None and need[i]:
+                if gi is not None and needs['input']:
                     grad_xs[i] = gi if grad_xs[i] is None else grad_xs[i].add_(gi)
-                if go is not None and need[n_x + k]:
+                if go is not None and needs['offset']:
                     grad_offs[k] = go if grad_offs[k] is None else grad_offs[k].add_(go)
                 grad_ws[j] = gw
         return (None, None, None, None) + tuple(grad_xs) + tuple(grad_offs) + tuple(grad_ws)
