@@ -110,6 +110,17 @@ def _autocast_apply(apply, args):
     return float32 (lower-precision activations are cast up on entry); under bfloat16 autocast the
     forward products use bf16 operands with fp32 accumulation (KGDET_DCN_BF16) unless a precision was
     chosen explicitly with set_forward_precision()."""
+    global _inference_depth
+    if not torch.is_grad_enabled():   # seen here, outside the autograd Function (inside it grad mode is always off)
+        _inference_depth += 1
+        try:
+            return _autocast_apply_inner(apply, args)
+        finally:
+            _inference_depth -= 1
+    return _autocast_apply_inner(apply, args)
+
+
+def _autocast_apply_inner(apply, args):
     if not torch.is_autocast_enabled('cuda'):
         return apply(*args)
     cast = [a.float() if torch.is_tensor(a) and a.is_floating_point() and a.dtype != torch.float32 else a
@@ -129,12 +140,16 @@ def clear_pack_cache():
     _pack_cache.clear()
 
 
+_inference_depth = 0   # > 0 while a public op was entered with autograd disabled (torch.no_grad inference)
+
+
 def pack_weight(weight, shape):
     """weight [O, C/g, kh, kw] -> the kernels' weight images (include/kgdet_hip.h, kgdet_dcn_pack_weight).
-    Inference (no autograd on the weight) reuses the images of an unchanged tensor -- same live object,
-    same storage, same ``_version`` (bumped by every in-place update such as a checkpoint load);
-    training packs on every call, its weights change every step anyway."""
-    cacheable = not (torch.is_grad_enabled() and weight.requires_grad)
+    Training packs on every call (its weights change every step, and fused optimizers update them WITHOUT
+    bumping the tensor's ``_version``, so no cheap staleness check exists).  Inference under ``torch.no_grad()``
+    reuses the images of an unchanged tensor -- same live object, storage and ``_version``; the cache is dropped
+    whenever a DeformConv module changes mode (``model.train()`` / ``model.eval()``) and by clear_pack_cache()."""
+    cacheable = _inference_depth > 0
     key = (weight.data_ptr(), weight._version, shape.groups, shape.deformable_groups, tuple(weight.shape),
            shape.H * shape.W <= 1536)
     if cacheable:
@@ -363,6 +378,10 @@ class DeformConv(nn.Module):
 
         self.reset_parameters()
 
+    def train(self, mode=True):
+        clear_pack_cache()   # weights may have been updated without a version bump (fused optimizers)
+        return super().train(mode)
+
     def reset_parameters(self):
         n = self.in_channels
         for k in self.kernel_size:
@@ -419,6 +438,10 @@ class ModulatedDeformConv(nn.Module):
         else:
             self.register_parameter('bias', None)
         self.reset_parameters()
+
+    def train(self, mode=True):
+        clear_pack_cache()   # weights may have been updated without a version bump (fused optimizers)
+        return super().train(mode)
 
     def reset_parameters(self):
         n = self.in_channels

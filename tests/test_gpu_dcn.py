@@ -291,3 +291,34 @@ def test_grad_offset_plane_kernel(case):
     ref = oracle.deform_conv_backward(x.astype(np.float64), off.astype(np.float64), w.astype(np.float64),
                                       go.astype(np.float64), s, p, d, g, dg)['grad_offset']
     _close(a.cpu().numpy(), ref, 5e-5)
+
+
+def test_weight_images_follow_fused_optimizer_updates():
+    """fused optimizers change weights without bumping ``_version``: training must re-pack every call, and the
+    inference cache must not survive a mode switch"""
+    _require_gpu()
+    from kgdet_amd import dcn
+    torch.manual_seed(0)
+    conv = dcn.DeformConv(32, 32, 3, padding=1).cuda()
+    x = torch.randn(1, 32, 12, 12, device='cuda')
+    off = torch.randn(1, 18, 12, 12, device='cuda')
+    opt = torch.optim.Adam(conv.parameters(), lr=0.5, fused=True)
+    y0 = conv(x, off)
+    y0.sum().backward()
+    v0 = conv.weight._version
+    opt.step()
+    assert conv.weight._version == v0, 'this torch build bumps _version in fused Adam: test premise gone'
+    y1 = conv(x, off)
+    assert not torch.allclose(y0, y1), 'forward after the optimizer step still used the old weight images'
+    conv.eval()
+    with torch.no_grad():
+        a = conv(x, off)
+        b = conv(x, off)        # served from the cache
+    assert torch.equal(a, b) and torch.allclose(a, y1.detach())
+    conv.train()
+    conv(x, off).sum().backward()
+    opt.step()
+    conv.eval()
+    with torch.no_grad():
+        c = conv(x, off)
+    assert not torch.allclose(a, c), 'inference after further training used stale weight images'
