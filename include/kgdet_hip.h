@@ -127,6 +127,15 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
                                              float *const *grad_offsets, void *workspace, size_t workspace_bytes,
                                              void *stream);
 
+/* grad_weight of n v1 problems (groups == 1, deformable_groups == 1, H*W <= 1536) in one launch: a GEMM with the
+ * reduction over pixels, sampled B stages from an LDS-resident plane, bf16 hi/lo split MFMA; grad_weights[i]
+ * [O, C, kh, kw] is OVERWRITTEN.  KGDET_E_UNSUPPORTED for other shapes (use kgdet_deform_conv_backward_weight).
+ * workspace >= kgdet_dcn_group_workspace_bytes(n, shapes). */
+int kgdet_deform_conv_grad_weight_grouped(int32_t n, const kgdet_dcn_shape *const *shapes, const float *const *inputs,
+                                          const float *const *offsets, const float *const *grad_outputs,
+                                          float *const *grad_weights, void *workspace, size_t workspace_bytes,
+                                          void *stream);
+
 /*
  * Backward w.r.t. input and offset (and mask for v2).  Replaces
  * deform_conv_backward_input_cuda (deform_conv_cuda.cpp:260-266) and the input/offset/mask part

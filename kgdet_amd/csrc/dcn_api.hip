@@ -201,15 +201,18 @@ size_t kgdet_dcn_workspace_bytes(const kgdet_dcn_shape *s) {
 }
 
 size_t kgdet_dcn_group_workspace_bytes(int32_t n, const kgdet_dcn_shape *const *shapes) {
-  size_t tables = 0, bwd_tables = 0, single = 0;
+  size_t tables = 0, bwd_tables = 0, wgrad_tables = 0, single = 0;
   for (int i = 0; i < n; ++i) {
     Derived d;
     if (!shapes || derive(shapes[i], d)) return 0;
     tables += tap_table_bytes(shapes[i], d);
     if (plane_bwd_input_ok(shapes[i], d)) bwd_tables += align_up(inv_tables(shapes[i], d).total(), 256);
+    wgrad_tables += align_up(tap_table_bytes(shapes[i], d), 256) +
+                    (size_t)(d.Og_pad / kTileM) * shapes[i]->N * ceil_div(d.Ho * d.Wo, kChunk) * 16384;
     const size_t w = kgdet_dcn_workspace_bytes(shapes[i]);
     single = w > single ? w : single;
   }
+  if (wgrad_tables > bwd_tables) bwd_tables = wgrad_tables;
   const size_t grouped = slab_bytes() + (tables > bwd_tables ? tables : bwd_tables);
   return grouped > single ? grouped : single;
 }
@@ -726,6 +729,103 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
   hipLaunchKernelGGL(dcn_bwd_offset_plane_fixup, dim3(grp.tile_begin[grp.n], 8), dim3(256), 0, (hipStream_t)stream, grp,
                      (const float *)workspace, G, max_K);
   KGDET_CHECK_LAUNCH("dcn_bwd_plane_grouped");
+  return KGDET_OK;
+}
+
+// grad_weight of n v1 problems in one launch of the plane kernel (+ record / grad_out image builders, fix-up).
+int kgdet_deform_conv_grad_weight_grouped(int32_t n, const kgdet_dcn_shape *const *shapes, const float *const *inputs,
+                                          const float *const *offsets, const float *const *grad_outputs,
+                                          float *const *grad_weights, void *workspace, size_t workspace_bytes,
+                                          void *stream) {
+  KGDET_CHECK_SHAPE(n >= 1 && n <= kMaxFwdGroup && shapes && inputs && offsets && grad_outputs && grad_weights,
+                    "null pointer / group size not in [1, %d]", kMaxFwdGroup);
+  const int G = grid_size();
+  Derived dd[kMaxFwdGroup];
+  int same_taps[kMaxFwdGroup], same_gq[kMaxFwdGroup];
+  size_t taps_off[kMaxFwdGroup], gq_off[kMaxFwdGroup], total = 0;
+  for (int i = 0; i < n; ++i) {
+    const kgdet_dcn_shape *s = shapes[i];
+    if (int rc = derive(s, dd[i])) return rc;
+    KGDET_CHECK_SHAPE(inputs[i] && offsets[i] && grad_outputs[i] && grad_weights[i], "null pointer (problem %d)", i);
+    if (s->groups != 1 || s->deformable_groups != 1 || !plane_ok(s, dd[i])) {
+      set_error("problem %d is not eligible for the plane grad_weight kernel", i);
+      return KGDET_E_UNSUPPORTED;
+    }
+    same_taps[i] = same_gq[i] = -1;
+    for (int q = 0; q < i; ++q) {
+      const kgdet_dcn_shape *o = shapes[q];
+      const bool geo = o->N == s->N && o->H == s->H && o->W == s->W && o->kh == s->kh && o->kw == s->kw &&
+                       o->stride_h == s->stride_h && o->stride_w == s->stride_w && o->pad_h == s->pad_h &&
+                       o->pad_w == s->pad_w && o->dil_h == s->dil_h && o->dil_w == s->dil_w;
+      if (same_taps[i] < 0 && geo && offsets[q] == offsets[i]) same_taps[i] = same_taps[q] >= 0 ? same_taps[q] : q;
+      if (same_gq[i] < 0 && grad_outputs[q] == grad_outputs[i] && o->N == s->N && o->O == s->O &&
+          o->out_channel_offset == s->out_channel_offset && o->out_channels_total == s->out_channels_total &&
+          dd[q].Ho == dd[i].Ho && dd[q].Wo == dd[i].Wo)
+        same_gq[i] = same_gq[q] >= 0 ? same_gq[q] : q;
+    }
+    if (same_taps[i] < 0) { taps_off[i] = total; total += align_up(tap_table_bytes(s, dd[i]), 256); }
+    else taps_off[i] = taps_off[same_taps[i]];
+    const int n_px16 = ceil_div(dd[i].Ho * dd[i].Wo, kChunk);
+    if (same_gq[i] < 0) { gq_off[i] = total; total += (size_t)(dd[i].Og_pad / kTileM) * s->N * n_px16 * 16384; }
+    else gq_off[i] = gq_off[same_gq[i]];
+  }
+  if (workspace == nullptr || workspace_bytes < slab_bytes() + total) {
+    set_error("workspace too small: need %zu bytes, got %zu (kgdet_dcn_group_workspace_bytes)", slab_bytes() + total,
+              workspace_bytes);
+    return KGDET_E_WORKSPACE;
+  }
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_bwd_weight_plane<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)kMaxLds));
+    attr_set = true;
+  }
+  unsigned char *tab = (unsigned char *)workspace + slab_bytes();
+  DcnFwdGroup grp;
+  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots;
+  grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
+  size_t lds = 0;
+  int min_len = 1 << 30;
+  for (int i = 0; i < n; ++i) {
+    const kgdet_dcn_shape *s = shapes[i];
+    const Derived &d = dd[i];
+    DcnProblem p;
+    fill_problem(s, d, 0, p);
+    const int n_px16 = ceil_div(p.HoWo, kChunk);
+    p.x = inputs[i]; p.offset = offsets[i]; p.mask = nullptr; p.out = grad_weights[i];
+    p.taps = reinterpret_cast<const DcnTapRec *>(tab + taps_off[i]);
+    p.build_taps = same_taps[i] < 0;
+    p.wq = tab + gq_off[i];
+    if (same_gq[i] < 0)
+      hipLaunchKernelGGL(dcn_pack_grad_out, dim3(s->N * n_px16, d.Og_pad / kTileM), dim3(256), 0, (hipStream_t)stream,
+                         grad_outputs[i], (void *)(tab + gq_off[i]), s->N, p.O_total, p.o_base, d.Og, p.HoWo, n_px16, 2);
+    p.n_mtiles = d.Og_pad / kTileM;
+    p.tiles_per_image = ceil_div(d.K, 8);                    // tap groups per channel chunk
+    p.n_ntiles = (d.Cg_pad / kChunk) * p.tiles_per_image;    // (chunk, tap group) column tiles
+    p.chunks_per_tap = n_px16;                               // stages per image
+    p.chunks_per_tile = s->N * n_px16;                       // the reduction runs over the pixels of all images
+    p.total_units = (long long)p.n_ntiles * p.n_mtiles * p.chunks_per_tile;
+    p.kparts = 1;
+    p.flags = 0;
+    grp.p[grp.n] = p;
+    grp.tile_begin[grp.n + 1] = grp.tile_begin[grp.n] + p.n_ntiles * p.n_mtiles;
+    grp.range_begin[grp.n + 1] = grp.range_begin[grp.n] + p.n_ntiles * p.n_mtiles;
+    grp.unit_begin[grp.n + 1] = grp.unit_begin[grp.n] + p.total_units;
+    ++grp.n;
+    min_len = p.chunks_per_tile < min_len ? p.chunks_per_tile : min_len;
+    const size_t need = dcn_bwd_weight_plane_lds_bytes(2, s->H * s->W);
+    lds = need > lds ? need : lds;
+  }
+  if (ceil_div((int)ceil_div((int)grp.unit_begin[grp.n], G), min_len) + 2 > kSlabSlots) {
+    set_error("group too uneven for the slab slots");
+    return KGDET_E_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(dcn_build_taps, dim3(2 * G, grp.n), dim3(256), 0, (hipStream_t)stream, grp);
+  hipLaunchKernelGGL(dcn_bwd_weight_plane<2>, dim3(G), dim3(dcn_fwd_plane_threads()), lds, (hipStream_t)stream, grp,
+                     (float *)workspace);
+  hipLaunchKernelGGL(dcn_bwd_weight_plane_fixup, dim3(grp.tile_begin[grp.n], 16), dim3(kThreads), 0, (hipStream_t)stream,
+                     grp, (const float *)workspace, G);
+  KGDET_CHECK_LAUNCH("dcn_bwd_weight_plane");
   return KGDET_OK;
 }
 

@@ -1,0 +1,329 @@
+// Deformable convolution backward w.r.t. the weight on an LDS-resident feature plane (gfx950).
+//
+// Reference path replaced: deform_conv_backward_parameters_cuda (deform_conv_cuda.cpp:373-484): a second
+// deformable_im2col into a [C*K, P] column matrix in HBM and grad_W += grad_out @ columns^T.
+//
+//     grad_W[o, c, t] = sum_{b, p} grad_out[b, o, p] * sample(x[b, c], pos(p, t))
+// is a GEMM with M = output channels (tile 256), N = (channel, tap) pairs (tile 128 = one 16-channel chunk x 8
+// taps) and the REDUCTION over pixels, in stages of 16 pixels of one image:
+//   * A stage: grad_out[b, o 256, 16 px] -- dcn_pack_grad_out rewrites grad_out once per call into the bf16 hi/lo
+//     fragment image gq[mt][b][px16][part][khalf][o 256][8 px], so a stage is a lane-linear 16 KB copy, exactly
+//     like the weight stage of the forward kernel;
+//   * B stage: samples of the chunk's 16 channels at 8 taps for 16 pixels.  MFMA fragments hold 8 consecutive
+//     reduction indices = 8 consecutive PIXELS per (channel, tap) row, so a producer thread owns (tap, channel
+//     quad, 4 consecutive pixels): 4 forward tap records (dcn_build_taps), 16 ds_read_b128 corner reads from the
+//     [pixel][16 channel] plane, 16 samples, written as four 8-byte row pieces.  Geometry costs nothing here and
+//     the sampling VALU work per sample is a third of the forward kernel's;
+//   * consumers, plane copy, three-deep load pipeline, stream-K over (tile, stage) units, slabs: as dcn_plane.h.
+// The fix-up (or the kernel itself for unsplit tiles) writes grad_W in its natural [O, C, kh, kw] layout: no
+// packed intermediate, no unpack kernel.  v1 only (no mask / bias), deformable groups = 1.
+#include "dcn_plane.h"
+
+namespace kgdet {
+
+namespace {
+constexpr int kTapsPerTile = 8;  // x 16 channels = 128 columns
+}
+
+// grad_out [N, O_total, Ho*Wo] (window o_base .. o_base + Og) -> gq[mt][b][px16][part][khalf][o 256][8 px] bf16
+__global__ __launch_bounds__(256) void dcn_pack_grad_out(const float *__restrict__ gout, void *__restrict__ gq, int N,
+                                                          int O_total, int o_base, int Og, int HoWo, int n_px16,
+                                                          int parts) {
+  const int stage = blockIdx.x;               // (b, px16)
+  const int mt = blockIdx.y;
+  const int b = stage / n_px16, q = stage - b * n_px16;
+  const int o_in = threadIdx.x, o = mt * kTileM + o_in;
+  const float *src = gout + ((long long)b * O_total + o_base + min(o, Og - 1)) * HoWo;
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = src[min(q * 16 + i, HoWo - 1)];
+  unsigned char *dst = reinterpret_cast<unsigned char *>(gq) +
+                       ((size_t)(mt * N + b) * n_px16 + q) * (size_t)(parts * kAPart) + o_in * 16;
+#pragma unroll
+  for (int khalf = 0; khalf < 2; ++khalf) {
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int px = q * 16 + khalf * 8 + j;
+      const float f = (px < HoWo && o < Og) ? v[khalf * 8 + j] : 0.0f;
+      hi[j] = (__bf16)f;
+      lo[j] = (__bf16)(f - (float)hi[j]);
+    }
+    *reinterpret_cast<bf16x8 *>(dst + khalf * (kTileM * 16)) = hi;
+    if (parts == 2) *reinterpret_cast<bf16x8 *>(dst + kAPart + khalf * (kTileM * 16)) = lo;
+  }
+}
+
+size_t dcn_bwd_weight_plane_lds_bytes(int parts, int HW) {
+  return (size_t)2 * parts * (kAPart + kBPart) + (size_t)kChunk * HW * sizeof(float);
+}
+
+// element (row o, column n) of tile (mt, c16, tg) -> grad_weight[o][c][t]
+__device__ __forceinline__ void wgrad_store_elem(const DcnProblem &p, int mt, int c16, int tg, int row, int col, float v) {
+  const int o = mt * kTileM + row;
+  const int c = c16 * kChunk + (col & 15), t = tg * kTapsPerTile + (col >> 4);
+  if (o < p.Og && c < p.Cg && t < p.K) p.out[((long long)o * p.Cg + c) * p.K + t] = v;
+}
+
+template <int PARTS, bool PRODUCER>
+__device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__restrict__ slabs, unsigned char *smem) {
+  unsigned char *As = smem;                                       // [2][PARTS][kAPart]
+  unsigned char *Bs = smem + 2 * PARTS * kAPart;                  // [2][PARTS][kBPart]
+  unsigned char *plane = smem + 2 * PARTS * (kAPart + kBPart);    // [H*W][16 channels] fp32, swizzled
+
+  const int wtid = threadIdx.x;
+  const int tid = PRODUCER ? wtid - kThreads : wtid;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 3, wn = wave >> 2;                        // consumers
+  const bool sampler = tid < 128;                                 // producers: waves 0-1 sample, waves 2-3 copy A
+  const int pq = tid & 3, tl = (tid >> 2) & 7, quad = (tid >> 5) & 3;  // sampler: pixel quad, local tap, channel quad
+  const int ctid = tid & 127;                                     // copier: 16-byte unit index base
+  const long long G = gridDim.x, g = blockIdx.x;
+  const long long total = grp.unit_begin[grp.n];
+  const long long slice = sk_slice_of_block((int)g, (int)G);
+  const long long my_begin = unit_begin(slice, total, G);
+  const long long my_end = unit_begin(slice + 1, total, G);
+
+  long long cur = my_begin;
+  int slot = 0;
+  while (cur < my_end) {
+    const DcnUnitPos pos = dcn_unit_pos(grp, cur);
+    const DcnProblem &p = grp.p[pos.pi];
+    const int HW = p.H * p.W;
+    const int K = p.K, HoWo = p.HoWo;
+    const int cpt = p.chunks_per_tile;        // stages per tile = N * n_px16
+    const int n_px16 = p.chunks_per_tap;      // stages per image
+    const int n_tg = p.tiles_per_image;       // tap groups per channel chunk
+    const int tile = pos.tile;
+    const int s_begin = pos.s;
+    const int s_end = (int)((my_end - cur) < (long long)(pos.s_hi - pos.s) ? pos.s + (my_end - cur) : pos.s_hi);
+    const int mt = tile % p.n_mtiles, nt = tile / p.n_mtiles;
+    const int c16 = nt / n_tg, tg = nt - c16 * n_tg;
+    const int t_mine = tg * kTapsPerTile + tl;
+    const bool tap_live = t_mine < K;
+    const int t_c = tap_live ? t_mine : K - 1;
+
+    f32x16 acc[PRODUCER ? 1 : 2][PRODUCER ? 1 : 2];
+    if constexpr (!PRODUCER) zero_acc(acc);
+
+    struct Regs {
+      uint4 r[8];  // sampler: 4 records (offsets r[2i], weights r[2i+1]); copier: its 8 x 16 B of the grad_out stage
+    };
+
+    int s = s_begin;
+    int b = s / n_px16;
+    int q0 = s - b * n_px16;
+    while (s < s_end) {
+      const int n = min(n_px16 - q0, s_end - s);  // stages of this segment: pixel groups q0 .. q0+n-1 of image b
+      const uint4 *rec_base = reinterpret_cast<const uint4 *>(p.taps) + ((size_t)(b * K + t_c) * HoWo) * 2;
+      const unsigned char *gq_base = reinterpret_cast<const unsigned char *>(p.wq) +
+                                     ((size_t)(mt * p.N + b) * n_px16) * (size_t)(PARTS * kAPart);
+
+      auto issue = [&](int j, Regs &R) {
+        const int q = q0 + min(j, n - 1);
+        if (sampler) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int px = min(q * 16 + pq * 4 + i, HoWo - 1);
+            R.r[2 * i] = rec_base[(size_t)px * 2];
+            R.r[2 * i + 1] = rec_base[(size_t)px * 2 + 1];
+          }
+        } else {
+          const uint4 *src = reinterpret_cast<const uint4 *>(gq_base + (size_t)q * (PARTS * kAPart)) + ctid;
+#pragma unroll
+          for (int u = 0; u < 4 * PARTS; ++u) R.r[u] = src[u * 128];
+        }
+      };
+      auto commit_a = [&](int buf, const Regs &R) {  // copier: grad_out stage -> LDS (lane-linear image)
+        if (!sampler) {
+          uint4 *dst = reinterpret_cast<uint4 *>(As + buf * PARTS * kAPart) + ctid;
+#pragma unroll
+          for (int u = 0; u < 4 * PARTS; ++u) dst[u * 128] = R.r[u];
+        }
+      };
+      auto load_plane = [&]() {  // x[b, chunk c16] -> LDS [pixel][16 ch] fp32, quad slots XOR-swizzled (dcn_plane.h)
+        const int c0 = c16 * kChunk;
+        const float *xb = p.x + ((long long)b * p.C_total + p.c_base) * HW;
+        const int items = 4 * HW;
+        for (int i0 = 0; i0 < items; i0 += kPlaneRounds * kPlaneThreads) {
+          f32x4 v[kPlaneRounds];
+#pragma unroll
+          for (int r = 0; r < kPlaneRounds; ++r) {
+            const int i = min(i0 + r * kPlaneThreads + wtid, items - 1);
+            const int qq = i % HW, qd = i / HW;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[r][e] = xb[(long long)min(c0 + qd * 4 + e, p.Cg - 1) * HW + qq];
+          }
+#pragma unroll
+          for (int r = 0; r < kPlaneRounds; ++r) {
+            const int i = i0 + r * kPlaneThreads + wtid;
+            if (i < items) {
+              const int qq = i % HW, qd = i / HW;
+              *reinterpret_cast<f32x4 *>(plane + dcn_plane_offset(qq) + ((qd ^ ((qq >> 2) & 3)) << 4)) = v[r];
+            }
+          }
+        }
+      };
+      // sampler: 4 pixels x 4 channels at one tap -> four 8-byte pieces of B rows (channel, tap)
+      auto sample = [&](int buf, const Regs &R) {
+        if (!sampler) return;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x4 sv[4];  // [pixel][channel]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const unsigned o[4] = {R.r[2 * i].x, R.r[2 * i].y, R.r[2 * i].z, R.r[2 * i].w};
+          const float w[4] = {__uint_as_float(R.r[2 * i + 1].x), __uint_as_float(R.r[2 * i + 1].y),
+                              __uint_as_float(R.r[2 * i + 1].z), __uint_as_float(R.r[2 * i + 1].w)};
+          f32x2 lo2 = {0.f, 0.f}, hi2 = {0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(plane + (o[e] ^ (unsigned)(quad << 4)));
+            const f32x2 we = {w[e], w[e]};
+            lo2 = __builtin_elementwise_fma(we, f32x2{v[0], v[1]}, lo2);
+            hi2 = __builtin_elementwise_fma(we, f32x2{v[2], v[3]}, hi2);
+          }
+          sv[i] = tap_live ? f32x4{lo2[0], lo2[1], hi2[0], hi2[1]} : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        unsigned char *dst = Bs + buf * PARTS * kBPart + (pq >> 1) * (kTileN * 16) + (tl * 16 + quad * 4) * 16 + (pq & 1) * 8;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+          bf16x4 hi, lo;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            hi[i] = (__bf16)sv[i][ch];
+            lo[i] = (__bf16)(sv[i][ch] - (float)hi[i]);
+          }
+          *reinterpret_cast<bf16x4 *>(dst + ch * 16) = hi;
+          if constexpr (PARTS == 2) *reinterpret_cast<bf16x4 *>(dst + kBPart + ch * 16) = lo;
+        }
+      };
+      auto multiply = [&](int buf) {
+        if constexpr (!PRODUCER) {
+          const unsigned char *A = As + buf * PARTS * kAPart + (lane >> 5) * (kTileM * 16) + (wm * 64 + (lane & 31)) * 16;
+          const unsigned char *B = Bs + buf * PARTS * kBPart + (lane >> 5) * (kTileN * 16) + (wn * 64 + (lane & 31)) * 16;
+          bf16x8 a[PARTS][2], bb[PARTS][2];
+#pragma unroll
+          for (int part = 0; part < PARTS; ++part)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              a[part][i] = *reinterpret_cast<const bf16x8 *>(A + part * kAPart + i * 32 * 16);
+              bb[part][i] = *reinterpret_cast<const bf16x8 *>(B + part * kBPart + i * 32 * 16);
+            }
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            if (tg * kTapsPerTile + wn * 4 + ni * 2 >= K) continue;  // both taps of this 32-column block are padding
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+              if constexpr (PARTS == 2) {
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][mi], bb[0][ni], acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], bb[1][ni], acc[mi][ni], 0, 0, 0);
+              }
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], bb[0][ni], acc[mi][ni], 0, 0, 0);
+            }
+          }
+        }
+      };
+
+      Regs R0, R1, R2;
+      __syncthreads();
+      if constexpr (PRODUCER) {
+        issue(0, R0);
+        issue(1, R1);
+        issue(2, R2);
+      }
+      load_plane();
+      if constexpr (PRODUCER) commit_a(0, R0);
+      __syncthreads();
+      if constexpr (PRODUCER) sample(0, R0);
+      __syncthreads();
+      auto body = [&](int j, Regs &RI, Regs &RC) {
+        const int buf = j & 1;
+        if constexpr (PRODUCER) {
+          issue(j + 3, RI);
+          if (j + 1 < n) {
+            commit_a(buf ^ 1, RC);
+            sample(buf ^ 1, RC);
+          }
+        } else {
+          if (j < n) multiply(buf);
+        }
+        __syncthreads();
+      };
+      for (int j = 0; j < n; j += 6) {
+        body(j, R0, R1);
+        body(j + 1, R1, R2);
+        body(j + 2, R2, R0);
+        if (j + 3 < n) {
+          body(j + 3, R0, R1);
+          body(j + 4, R1, R2);
+          body(j + 5, R2, R0);
+        }
+      }
+      s += n;
+      ++b;
+      q0 = 0;
+    }
+
+    if constexpr (!PRODUCER) {
+      if (s_begin == 0 && s_end == cpt) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              wgrad_store_elem(p, mt, c16, tg, wm * 64 + mi * 32 + mfma_row(r, lane), wn * 64 + ni * 32 + (lane & 31),
+                               acc[mi][ni][r]);
+      } else {
+        store_slab(slabs + ((long long)g * grp.slots + slot) * kTileElems, tid, acc);
+      }
+    }
+    ++slot;
+    cur += s_end - s_begin;
+  }
+}
+
+template <int PARTS>
+__global__ __launch_bounds__(kPlaneThreads, 1) void dcn_bwd_weight_plane(const DcnFwdGroup grp, float *__restrict__ slabs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (threadIdx.x >= kThreads) wgrad_role<PARTS, true>(grp, slabs, smem);
+  else wgrad_role<PARTS, false>(grp, slabs, smem);
+}
+
+template __global__ void dcn_bwd_weight_plane<1>(const DcnFwdGroup grp, float *__restrict__ slabs);
+template __global__ void dcn_bwd_weight_plane<2>(const DcnFwdGroup grp, float *__restrict__ slabs);
+
+// Split tiles: add the slabs, slices in order; grid = (tiles, 16) as dcn_fwd_fixup, output in [O, C, kh, kw].
+__global__ __launch_bounds__(kThreads) void dcn_bwd_weight_plane_fixup(const DcnFwdGroup grp, const float *__restrict__ slabs,
+                                                                       int G) {
+  const int gtile = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
+  int pi = 0;
+  while (pi + 1 < grp.n && gtile >= grp.tile_begin[pi + 1]) ++pi;
+  const DcnProblem &p = grp.p[pi];
+  const int tile = gtile - grp.tile_begin[pi];
+  const long long total = grp.unit_begin[grp.n];
+  const long long tb = dcn_range_first_unit(grp, pi, 0, tile), te = tb + p.chunks_per_tile;
+  long long g = tb * G / total;
+  while (unit_begin(g + 1, total, G) <= tb) ++g;
+  while (unit_begin(g, total, G) > tb) --g;
+  if (unit_begin(g, total, G) <= tb && unit_begin(g + 1, total, G) >= te) return;  // written directly
+  const int range = grp.range_begin[pi] + tile;
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  for (; g < G; ++g) {
+    const long long b0 = unit_begin(g, total, G);
+    if (b0 >= te) break;
+    if (unit_begin(g + 1, total, G) == b0) continue;
+    const long long slab = (long long)sk_block_of_slice((int)g, G) * grp.slots + (range - dcn_unit_pos(grp, b0).range);
+    const f32x4 v = reinterpret_cast<const f32x4 *>(slabs + slab * kTileElems)[j * kThreads + tid];
+    sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+  }
+  const int mi = j >> 3, ni = (j >> 2) & 1, q = j & 3;
+  const int mt = tile % p.n_mtiles, nt = tile / p.n_mtiles;
+  const int c16 = nt / p.tiles_per_image, tg = nt - c16 * p.tiles_per_image;
+  const int lane = tid & 63, wave = tid >> 6, wm = wave & 3, wn = wave >> 2;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    wgrad_store_elem(p, mt, c16, tg, wm * 64 + mi * 32 + mfma_row(4 * q + e, lane), wn * 64 + ni * 32 + (lane & 31), sum[e]);
+}
+
+}  // namespace kgdet

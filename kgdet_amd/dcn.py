@@ -240,6 +240,25 @@ def grad_offset_plane(input, offset, weight, grad_output, shape, packed=None, bf
     return grad_offset
 
 
+def grad_weights_grouped(inputs, offsets, grad_outputs, weights, shapes):
+    """grad_weight of several v1 convs in one launch (kgdet_deform_conv_grad_weight_grouped); problem j uses
+    inputs[j], offsets[j], grad_outputs[j] (the window described by shapes[j]) and returns a tensor like weights[j].
+    Returns None when a problem is not eligible for the plane kernel."""
+    L = _lib.lib()
+    n = len(shapes)
+    gws = [torch.empty_like(w, memory_format=torch.contiguous_format) for w in weights]
+    arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    shape_arr = (ctypes.POINTER(_lib.DcnShape) * n)(*[ctypes.pointer(s) for s in shapes])
+    ws = _workspace(inputs[0].device, L.kgdet_dcn_group_workspace_bytes(ctypes.c_int32(n), shape_arr))
+    rc = L.kgdet_deform_conv_grad_weight_grouped(
+        ctypes.c_int32(n), shape_arr, arr(inputs), arr(offsets), arr(grad_outputs), arr(gws), _lib.ptr(ws),
+        ctypes.c_size_t(ws.numel()), _lib.current_stream())
+    if rc == _lib.KGDET_E_UNSUPPORTED:
+        return None
+    _lib.check(rc, 'kgdet_deform_conv_grad_weight_grouped')
+    return gws
+
+
 def _backward(input, offset, mask, weight, bias, grad_output, shape, packed, needs):
     """Returns grad_input, grad_offset, grad_mask, grad_weight, grad_bias (None where not needed)."""
     L = _lib.lib()
@@ -582,18 +601,28 @@ class DeformConvCatFunction(Function):
                         grad_offs[k] = torch.stack(gos[k::n_k]).sum(0) if n_x > 1 else gos[k]
             elif rc != _lib.KGDET_E_UNSUPPORTED:
                 _lib.check(rc, 'kgdet_deform_conv_backward_input_grouped')
+        done_w = False
+        if all(need[n_x + n_k:]):
+            n = n_x * n_k
+            gws = grad_weights_grouped([xs[j // n_k] for j in range(n)], [offsets[j % n_k] for j in range(n)],
+                                       [gouts[j // n_k] for j in range(n)], weights, ctx.shapes)
+            if gws is not None:
+                grad_ws, done_w = gws, True
         for i in range(n_x):
             for k in range(n_k):
                 j = i * n_k + k
                 needs = dict(input=need[i] and not done_io, offset=need[n_x + k] and not done_io, mask=False,
-                             weight=need[n_x + n_k + j], bias=False)
+                             weight=need[n_x + n_k + j] and not done_w, bias=False)
+                if not any(needs.values()):
+                    continue
                 gi, go, _, gw, _ = _backward(xs[i], offsets[k], None, weights[j], None, gouts[i], ctx.shapes[j],
                                              packs[j], needs)
                 if gi is not None and needs['input']:
                     grad_xs[i] = gi if grad_xs[i] is None else grad_xs[i].add_(gi)
                 if go is not None and needs['offset']:
                     grad_offs[k] = go if grad_offs[k] is None else grad_offs[k].add_(go)
-                grad_ws[j] = gw
+                if needs['weight']:
+                    grad_ws[j] = gw
         return (None, None, None, None) + tuple(grad_xs) + tuple(grad_offs) + tuple(grad_ws)
 
 

@@ -322,3 +322,20 @@ def test_weight_images_follow_fused_optimizer_updates():
     with torch.no_grad():
         c = conv(x, off)
     assert not torch.allclose(a, c), 'inference after further training used stale weight images'
+
+
+@pytest.mark.parametrize('case', [c for c in CASES if c[10] == 1 and c[9] == 1])
+def test_grad_weight_plane_kernel(case):
+    """kgdet_deform_conv_grad_weight_grouped (pixel-reduction GEMM on the plane kernel) vs the float64 oracle."""
+    _require_gpu()
+    from kgdet_amd import dcn
+    N, C, H, W, O, k, s, p, d, g, dg = case
+    x, off, w, go, _ = _make(case, seed=14)
+    tx, to, tw, tg = (torch.from_numpy(a).cuda() for a in (x, off, w, go))
+    shape = dcn._shape(tx, tw, (s, s), (p, p), (d, d), g, dg)
+    a = dcn.grad_weights_grouped([tx], [to], [tg], [tw], [shape])
+    b = dcn.grad_weights_grouped([tx], [to], [tg], [tw], [shape])
+    assert a is not None and torch.equal(a[0], b[0]), 'grad_weight must be deterministic'
+    ref = oracle.deform_conv_backward(x.astype(np.float64), off.astype(np.float64), w.astype(np.float64),
+                                      go.astype(np.float64), s, p, d, g, dg)['grad_weight']
+    _close(a[0].cpu().numpy(), ref, 5e-5)
