@@ -14,15 +14,24 @@
 //     quad, 4 consecutive pixels): 4 forward tap records (dcn_build_taps), 16 ds_read_b128 corner reads from the
 //     [pixel][16 channel] plane, 16 samples, written as four 8-byte row pieces.  Geometry costs nothing here and
 //     the sampling VALU work per sample is a third of the forward kernel's;
-//   * consumers, plane copy, three-deep load pipeline, stream-K over (tile, stage) units, slabs: as dcn_plane.h.
+//   * the tap records of a stage (4 KB) are fetched coalesced by all producer threads and handed to the sampling
+//     threads through LDS; consumers, plane copy, stream-K over (tile, stage) units, slabs: as dcn_plane.h.
 // The fix-up (or the kernel itself for unsplit tiles) writes grad_W in its natural [O, C, kh, kw] layout: no
 // packed intermediate, no unpack kernel.  v1 only (no mask / bias), deformable groups = 1.
+#include <type_traits>
+
 #include "dcn_plane.h"
 
 namespace kgdet {
 
 namespace {
+// plain vector type for register-resident copies: HIP's uint4 is a struct whose assignment lowers to a memcpy
+// between address spaces, which kept the pipeline's register sets in scratch memory
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kTapsPerTile = 8;  // x 16 channels = 128 columns
+#ifndef KGDET_WABL
+#define KGDET_WABL 0
+#endif
 }
 
 // grad_out [N, O_total, Ho*Wo] (window o_base .. o_base + Og) -> gq[mt][b][px16][part][khalf][o 256][8 px] bf16
@@ -55,7 +64,7 @@ __global__ __launch_bounds__(256) void dcn_pack_grad_out(const float *__restrict
 }
 
 size_t dcn_bwd_weight_plane_lds_bytes(int parts, int HW) {
-  return (size_t)2 * parts * (kAPart + kBPart) + (size_t)kChunk * HW * sizeof(float);
+  return (size_t)3 * parts * kAPart + (size_t)2 * parts * kBPart + 2 * 4096 + (size_t)kChunk * HW * sizeof(float);
 }
 
 // element (row o, column n) of tile (mt, c16, tg) -> grad_weight[o][c][t]
@@ -67,17 +76,17 @@ __device__ __forceinline__ void wgrad_store_elem(const DcnProblem &p, int mt, in
 
 template <int PARTS, bool PRODUCER>
 __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__restrict__ slabs, unsigned char *smem) {
-  unsigned char *As = smem;                                       // [2][PARTS][kAPart]
-  unsigned char *Bs = smem + 2 * PARTS * kAPart;                  // [2][PARTS][kBPart]
-  unsigned char *plane = smem + 2 * PARTS * (kAPart + kBPart);    // [H*W][16 channels] fp32, swizzled
+  unsigned char *As = smem;                                       // [3][PARTS][kAPart]  (ring)
+  unsigned char *Bs = smem + 3 * PARTS * kAPart;                  // [2][PARTS][kBPart]
+  u32x4 *Rs = reinterpret_cast<u32x4 *>(smem + 3 * PARTS * kAPart + 2 * PARTS * kBPart);  // [2][256] record pieces
+  unsigned char *plane = smem + 3 * PARTS * kAPart + 2 * PARTS * kBPart + 2 * 4096;  // [H*W][16 channels] fp32, swizzled
 
   const int wtid = threadIdx.x;
   const int tid = PRODUCER ? wtid - kThreads : wtid;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;                        // consumers
-  const bool sampler = tid < 128;                                 // producers: waves 0-1 sample, waves 2-3 copy A
-  const int pq = tid & 3, tl = (tid >> 2) & 7, quad = (tid >> 5) & 3;  // sampler: pixel quad, local tap, channel quad
-  const int ctid = tid & 127;                                     // copier: 16-byte unit index base
+  // producers: every thread samples 2 consecutive pixels x 4 channels at one tap
+  const int pp = tid & 7, tl = (tid >> 3) & 7, quad = (tid >> 6) & 3;  // pixel pair, local tap, channel quad
   const long long G = gridDim.x, g = blockIdx.x;
   const long long total = grp.unit_begin[grp.n];
   const long long slice = sk_slice_of_block((int)g, (int)G);
@@ -99,15 +108,15 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
     const int s_end = (int)((my_end - cur) < (long long)(pos.s_hi - pos.s) ? pos.s + (my_end - cur) : pos.s_hi);
     const int mt = tile % p.n_mtiles, nt = tile / p.n_mtiles;
     const int c16 = nt / n_tg, tg = nt - c16 * n_tg;
-    const int t_mine = tg * kTapsPerTile + tl;
+    const int t_mine = tg * kTapsPerTile + tl;  // the tap this thread samples
     const bool tap_live = t_mine < K;
-    const int t_c = tap_live ? t_mine : K - 1;
 
     f32x16 acc[PRODUCER ? 1 : 2][PRODUCER ? 1 : 2];
     if constexpr (!PRODUCER) zero_acc(acc);
 
     struct Regs {
-      uint4 r[8];  // sampler: 4 records (offsets r[2i], weights r[2i+1]); copier: its 8 x 16 B of the grad_out stage
+      u32x4 rec;            // 16-byte piece tid of the stage's 4 KB of tap records (8 taps x 16 pixels x 32 B)
+      u32x4 a0, a1, a2, a3; // this thread's share of the grad_out stage (a2, a3: the lo part)
     };
 
     int s = s_begin;
@@ -115,33 +124,41 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
     int q0 = s - b * n_px16;
     while (s < s_end) {
       const int n = min(n_px16 - q0, s_end - s);  // stages of this segment: pixel groups q0 .. q0+n-1 of image b
-      const uint4 *rec_base = reinterpret_cast<const uint4 *>(p.taps) + ((size_t)(b * K + t_c) * HoWo) * 2;
       const unsigned char *gq_base = reinterpret_cast<const unsigned char *>(p.wq) +
                                      ((size_t)(mt * p.N + b) * n_px16) * (size_t)(PARTS * kAPart);
 
-      auto issue = [&](int j, Regs &R) {
+      // Every producer thread loads ONE 16-byte piece of the stage's tap records (coalesced: 512 contiguous bytes
+      // per tap) and 2 * PARTS pieces of the grad_out stage; the records go through LDS to the sampling threads.
+      // (Letting each sampling thread fetch its own four records cost 140 us per launch in the texture
+      // addresser -- 32 cache lines per load instruction -- and loads issued under `if (sampler)` another 200 us
+      // of drained-queue latency.)
+      const int r_tl = tid >> 5, r_px = (tid >> 1) & 15, r_h = tid & 1;
+      const int r_t = min(tg * kTapsPerTile + r_tl, K - 1);
+      const u32x4 *rec_src = reinterpret_cast<const u32x4 *>(p.taps) + ((size_t)(b * K + r_t) * HoWo) * 2 + r_h;
+      const int r_slot = ((r_px & 3) * 2 + r_h) * 32 + r_tl * 4 + (r_px >> 2);  // [piece][tap][pixel quad]
+      auto issue = [&](int j, Regs &R) __attribute__((always_inline)) {
         const int q = q0 + min(j, n - 1);
-        if (sampler) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int px = min(q * 16 + pq * 4 + i, HoWo - 1);
-            R.r[2 * i] = rec_base[(size_t)px * 2];
-            R.r[2 * i + 1] = rec_base[(size_t)px * 2 + 1];
-          }
-        } else {
-          const uint4 *src = reinterpret_cast<const uint4 *>(gq_base + (size_t)q * (PARTS * kAPart)) + ctid;
-#pragma unroll
-          for (int u = 0; u < 4 * PARTS; ++u) R.r[u] = src[u * 128];
+        if (KGDET_WABL & 4) { R.rec = u32x4{0, 0, 0, 0}; R.a0 = R.a1 = R.a2 = R.a3 = R.rec; return; }
+        R.rec = rec_src[(size_t)min(q * 16 + r_px, HoWo - 1) * 2];
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(gq_base + (size_t)q * (PARTS * kAPart)) + tid;
+        R.a0 = src[0];
+        R.a1 = src[kProducers];
+        if constexpr (PARTS == 2) {
+          R.a2 = src[2 * kProducers];
+          R.a3 = src[3 * kProducers];
         }
       };
-      auto commit_a = [&](int buf, const Regs &R) {  // copier: grad_out stage -> LDS (lane-linear image)
-        if (!sampler) {
-          uint4 *dst = reinterpret_cast<uint4 *>(As + buf * PARTS * kAPart) + ctid;
-#pragma unroll
-          for (int u = 0; u < 4 * PARTS; ++u) dst[u * 128] = R.r[u];
+      auto commit = [&](int a_slot, int r_slot2, const Regs &R) __attribute__((always_inline)) {  // grad_out stage -> As[a_slot], records -> Rs[r_slot2]
+        u32x4 *dst = reinterpret_cast<u32x4 *>(As + a_slot * PARTS * kAPart) + tid;
+        dst[0] = R.a0;
+        dst[kProducers] = R.a1;
+        if constexpr (PARTS == 2) {
+          dst[2 * kProducers] = R.a2;
+          dst[3 * kProducers] = R.a3;
         }
+        Rs[r_slot2 * 256 + r_slot] = R.rec;
       };
-      auto load_plane = [&]() {  // x[b, chunk c16] -> LDS [pixel][16 ch] fp32, quad slots XOR-swizzled (dcn_plane.h)
+      auto load_plane = [&]() __attribute__((always_inline)) {  // x[b, chunk c16] -> LDS [pixel][16 ch] fp32, quad slots XOR-swizzled (dcn_plane.h)
         const int c0 = c16 * kChunk;
         const float *xb = p.x + ((long long)b * p.C_total + p.c_base) * HW;
         const int items = 4 * HW;
@@ -165,15 +182,17 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
         }
       };
       // sampler: 4 pixels x 4 channels at one tap -> four 8-byte pieces of B rows (channel, tap)
-      auto sample = [&](int buf, const Regs &R) {
-        if (!sampler) return;
+      auto sample = [&](int buf) __attribute__((always_inline)) {  // B stage (slot buf) from the records in Rs[buf] and the plane
+        if (KGDET_WABL & 1) return;
+        // record pieces of pixel px = 2 pp + i sit at [piece ((px & 3) * 2 + h)][tap][px >> 2]
+        const u32x4 *rr = Rs + buf * 256 + ((pp & 1) * 4) * 32 + tl * 4 + (pp >> 1);
         typedef float f32x2 __attribute__((ext_vector_type(2)));
-        f32x4 sv[4];  // [pixel][channel]
+        f32x4 sv[2];  // [pixel][channel]
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const unsigned o[4] = {R.r[2 * i].x, R.r[2 * i].y, R.r[2 * i].z, R.r[2 * i].w};
-          const float w[4] = {__uint_as_float(R.r[2 * i + 1].x), __uint_as_float(R.r[2 * i + 1].y),
-                              __uint_as_float(R.r[2 * i + 1].z), __uint_as_float(R.r[2 * i + 1].w)};
+        for (int i = 0; i < 2; ++i) {
+          const u32x4 ro = rr[(2 * i) * 32], rw = rr[(2 * i + 1) * 32];
+          const unsigned o[4] = {ro[0], ro[1], ro[2], ro[3]};
+          const float w[4] = {__uint_as_float(rw[0]), __uint_as_float(rw[1]), __uint_as_float(rw[2]), __uint_as_float(rw[3])};
           f32x2 lo2 = {0.f, 0.f}, hi2 = {0.f, 0.f};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -184,30 +203,35 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
           }
           sv[i] = tap_live ? f32x4{lo2[0], lo2[1], hi2[0], hi2[1]} : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        unsigned char *dst = Bs + buf * PARTS * kBPart + (pq >> 1) * (kTileN * 16) + (tl * 16 + quad * 4) * 16 + (pq & 1) * 8;
+        // B rows are stored at slot n ^ (n >> 4): the 8 taps of a channel then hit 8 different bank groups
+        // (unswizzled, the lanes of one store differ only in bits that are multiples of 32 dwords)
+        unsigned char *dstb = Bs + buf * PARTS * kBPart + (pp >> 2) * (kTileN * 16) + (pp & 3) * 4;
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
-          bf16x4 hi, lo;
+          unsigned char *dst = dstb + (((tl * 16 + quad * 4 + ch) ^ tl) * 16);
+          bf16x2 hi, lo;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
+          for (int i = 0; i < 2; ++i) {
             hi[i] = (__bf16)sv[i][ch];
             lo[i] = (__bf16)(sv[i][ch] - (float)hi[i]);
           }
-          *reinterpret_cast<bf16x4 *>(dst + ch * 16) = hi;
-          if constexpr (PARTS == 2) *reinterpret_cast<bf16x4 *>(dst + kBPart + ch * 16) = lo;
+          *reinterpret_cast<bf16x2 *>(dst) = hi;
+          if constexpr (PARTS == 2) *reinterpret_cast<bf16x2 *>(dst + kBPart) = lo;
         }
       };
-      auto multiply = [&](int buf) {
-        if constexpr (!PRODUCER) {
-          const unsigned char *A = As + buf * PARTS * kAPart + (lane >> 5) * (kTileM * 16) + (wm * 64 + (lane & 31)) * 16;
-          const unsigned char *B = Bs + buf * PARTS * kBPart + (lane >> 5) * (kTileN * 16) + (wn * 64 + (lane & 31)) * 16;
+      auto multiply = [&](int a_slot, int buf) __attribute__((always_inline)) {
+        if constexpr (!PRODUCER && !(KGDET_WABL & 2)) {
+          const unsigned char *A = As + a_slot * PARTS * kAPart + (lane >> 5) * (kTileM * 16) + (wm * 64 + (lane & 31)) * 16;
+          const unsigned char *B = Bs + buf * PARTS * kBPart + (lane >> 5) * (kTileN * 16);
           bf16x8 a[PARTS][2], bb[PARTS][2];
 #pragma unroll
           for (int part = 0; part < PARTS; ++part)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
+              const int col = wn * 64 + i * 32 + (lane & 31);
               a[part][i] = *reinterpret_cast<const bf16x8 *>(A + part * kAPart + i * 32 * 16);
-              bb[part][i] = *reinterpret_cast<const bf16x8 *>(B + part * kBPart + i * 32 * 16);
+              bb[part][i] = *reinterpret_cast<const bf16x8 *>(B + part * kBPart + (col ^ (col >> 4)) * 16);
             }
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) {
@@ -224,39 +248,46 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
         }
       };
 
-      Regs R0, R1, R2;
+      // Pipeline of stage s: global loads at body s-4, registers -> LDS (A ring slot s % 3, record slot s & 1) at
+      // body s-2, sampled into B[s & 1] at body s-1, multiplied at body s.  Two register sets alternate.
+      Regs RA, RB;
       __syncthreads();
       if constexpr (PRODUCER) {
-        issue(0, R0);
-        issue(1, R1);
-        issue(2, R2);
+        issue(0, RA);
+        issue(1, RB);
       }
       load_plane();
-      if constexpr (PRODUCER) commit_a(0, R0);
+      if constexpr (PRODUCER) {
+        commit(0, 0, RA);
+        commit(1, 1, RB);
+        issue(2, RA);
+        issue(3, RB);
+      }
       __syncthreads();
-      if constexpr (PRODUCER) sample(0, R0);
+      if constexpr (PRODUCER) sample(0);
       __syncthreads();
-      auto body = [&](int j, Regs &RI, Regs &RC) {
-        const int buf = j & 1;
+      // I = body index inside the unrolled group of 6 (compile time: the LDS slots are immediates and the six
+      // bodies stay distinct -- with run-time slot arithmetic hipcc merged them back into a loop and kept the
+      // two register sets in scratch memory, stalling on every freshly issued load to spill it)
+      auto body = [&](auto I, int j, Regs &R) __attribute__((always_inline)) {  // R holds stage j+2
+        constexpr int i = decltype(I)::value;
         if constexpr (PRODUCER) {
-          issue(j + 3, RI);
-          if (j + 1 < n) {
-            commit_a(buf ^ 1, RC);
-            sample(buf ^ 1, RC);
-          }
+          commit((i + 2) % 3, i & 1, R);
+          issue(j + 4, R);
+          if (j + 1 < n) sample((i + 1) & 1);
         } else {
-          if (j < n) multiply(buf);
+          if (j < n) multiply(i % 3, i & 1);
         }
         __syncthreads();
       };
-      for (int j = 0; j < n; j += 6) {
-        body(j, R0, R1);
-        body(j + 1, R1, R2);
-        body(j + 2, R2, R0);
+      for (int j = 0; j < n; j += 6) {  // 6 = lcm(3 A slots, 2 B / record slots, 2 register sets)
+        body(std::integral_constant<int, 0>{}, j, RA);
+        body(std::integral_constant<int, 1>{}, j + 1, RB);
+        body(std::integral_constant<int, 2>{}, j + 2, RA);
         if (j + 3 < n) {
-          body(j + 3, R0, R1);
-          body(j + 4, R1, R2);
-          body(j + 5, R2, R0);
+          body(std::integral_constant<int, 3>{}, j + 3, RB);
+          body(std::integral_constant<int, 4>{}, j + 4, RA);
+          body(std::integral_constant<int, 5>{}, j + 5, RB);
         }
       }
       s += n;
