@@ -353,13 +353,10 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
       p.total_units = (long long)p.n_ntiles * p.n_mtiles * p.chunks_per_tile;
       p.kparts = 1;
       if (use_plane) {
-        // cut the reduction so that one part's weights (16 KB per stage with both bf16 parts) fit a per-XCD L2
-        const size_t stage_bytes = (size_t)parts * 8192;
-        // (measured on MI355X: no gain -- the weight stream is not what bounds the kernel, hot weights only
-        //  bought 6 % -- while the extra partial tiles cost 25 %; the partition stays off)
-        while (false && p.kparts < 8 && (size_t)p.chunks_per_tile * stage_bytes / p.kparts > (size_t)1792 * 1024 &&
-               p.chunks_per_tile / (p.kparts * 2) >= 16)
-          p.kparts *= 2;
+        // kparts > 1 would cut the reduction so that one part's weights fit a per-XCD L2 (units ordered problem, part,
+        // tile, stage -- supported by dcn_unit_pos and the fix-up).  Measured on MI355X: no gain -- the weight stream
+        // is not what bounds the kernel (an always-hot weight stage bought 6 %) -- while the extra partial tiles cost
+        // 25 %; it stays 1.
         // a workgroup writes one slab per range its slice meets: keep that within kSlabSlots
         const int len = p.chunks_per_tile / p.kparts;
         const int new_min = len < min_len ? len : min_len;

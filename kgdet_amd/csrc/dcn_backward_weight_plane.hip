@@ -29,9 +29,6 @@ namespace {
 // between address spaces, which kept the pipeline's register sets in scratch memory
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kTapsPerTile = 8;  // x 16 channels = 128 columns
-#ifndef KGDET_WABL
-#define KGDET_WABL 0
-#endif
 }
 
 // grad_out [N, O_total, Ho*Wo] (window o_base .. o_base + Og) -> gq[mt][b][px16][part][khalf][o 256][8 px] bf16
@@ -138,7 +135,6 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
       const int r_slot = ((r_px & 3) * 2 + r_h) * 32 + r_tl * 4 + (r_px >> 2);  // [piece][tap][pixel quad]
       auto issue = [&](int j, Regs &R) __attribute__((always_inline)) {
         const int q = q0 + min(j, n - 1);
-        if (KGDET_WABL & 4) { R.rec = u32x4{0, 0, 0, 0}; R.a0 = R.a1 = R.a2 = R.a3 = R.rec; return; }
         R.rec = rec_src[(size_t)min(q * 16 + r_px, HoWo - 1) * 2];
         const u32x4 *src = reinterpret_cast<const u32x4 *>(gq_base + (size_t)q * (PARTS * kAPart)) + tid;
         R.a0 = src[0];
@@ -183,7 +179,6 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
       };
       // sampler: 4 pixels x 4 channels at one tap -> four 8-byte pieces of B rows (channel, tap)
       auto sample = [&](int buf) __attribute__((always_inline)) {  // B stage (slot buf) from the records in Rs[buf] and the plane
-        if (KGDET_WABL & 1) return;
         // record pieces of pixel px = 2 pp + i sit at [piece ((px & 3) * 2 + h)][tap][px >> 2]
         const u32x4 *rr = Rs + buf * 256 + ((pp & 1) * 4) * 32 + tl * 4 + (pp >> 1);
         typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -221,7 +216,7 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
         }
       };
       auto multiply = [&](int a_slot, int buf) __attribute__((always_inline)) {
-        if constexpr (!PRODUCER && !(KGDET_WABL & 2)) {
+        if constexpr (!PRODUCER) {
           const unsigned char *A = As + a_slot * PARTS * kAPart + (lane >> 5) * (kTileM * 16) + (wm * 64 + (lane & 31)) * 16;
           const unsigned char *B = Bs + buf * PARTS * kBPart + (lane >> 5) * (kTileN * 16);
           bf16x8 a[PARTS][2], bb[PARTS][2];

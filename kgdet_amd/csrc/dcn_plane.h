@@ -43,9 +43,6 @@ struct PlaneStageRegs {
 
 }  // namespace
 
-#ifndef KGDET_ABL
-#define KGDET_ABL 0
-#endif
 // Loop structure: a workgroup walks its stream-K slice range by range; inside a range the stages that share
 // a feature plane (one channel chunk, consecutive taps) form a SEGMENT.  A segment starts with the plane copy
 // and the priming of the producers' three-deep register pipeline (weight stage + tap record of stages
@@ -57,7 +54,6 @@ struct PlaneStageRegs {
 // accumulators exist only in the consumers' register allocation.
 template <int PARTS, bool PRODUCER, int MODE>
 __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__restrict__ slabs, unsigned char *smem) {
-  constexpr int ABL = KGDET_ABL;
   unsigned char *As = smem;                                                          // [2][PARTS][kAPart]
   unsigned char *Bs = smem + 2 * PARTS * kAPart;                                     // [2][PARTS][kBPart]
   uint2 *ovf_lds = reinterpret_cast<uint2 *>(smem + 2 * PARTS * (kAPart + kBPart));  // [2][kOvfCap + 1] (MODE 1)
@@ -155,7 +151,6 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       // LDS store.  All loads are issued before the first store, unconditionally from clamped addresses
       // (a guarded load makes hipcc branch and drain the queue).
       auto load_plane = [&]() {
-        if (ABL & 16) return;
         const int c0 = c16 * kChunk;
         const float *xb = p.x + ((long long)tile_b * p.C_total + p.c_base) * HW;
         const int items = 4 * HW;  // (pixel, quad) pairs
@@ -185,7 +180,6 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       // Corner offsets in the record are for quad 0; quad c of the same pixel is at offset ^ (c << 4).
       int ovf_tap = 0;  // tap of the stage being sampled (MODE 1 spill path)
       auto sample = [&](int buf, const Regs &R, int ovf_slot) {
-        if (ABL & 8) return;
         // interpolation and hi/lo split on channel PAIRS: v_pk_fma_f32 / v_pk_add_f32 do two lanes' worth per
         // issue slot, and issue slots are what this kernel is short of (VALU and MFMA time add up on a SIMD)
         typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -266,7 +260,6 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       };
       auto multiply = [&](int buf) {
         if constexpr (!PRODUCER) {
-          if (ABL & 2) return;
           const unsigned char *A = As + buf * PARTS * kAPart + (lane >> 5) * (kTileM * 16) + (wm * 64 + (lane & 31)) * 16;
           const unsigned char *B = Bs + buf * PARTS * kBPart + (lane >> 5) * (kTileN * 16) + (wn * 64 + (lane & 31)) * 16;
           bf16x8 a[PARTS][2], b[PARTS][2];
