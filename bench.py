@@ -187,8 +187,10 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.dtype == 'fp32' else 'bf16(dense convs)+f32(deformable path)',
             'data': 'synthetic',
             'config': {'workload': 'KGDet R50-FPN %s step, %d img/GPU at 800x1333 (padded 800x1344), '
-                                   'DeformConv fwd/bwd + focal/moment losses + RCCL grad all-reduce'
-                                   % (args.mode, args.imgs_per_gpu),
+                                   '%s' % (args.mode, args.imgs_per_gpu,
+                                           'DeformConv fwd/bwd + focal/moment losses + RCCL grad all-reduce'
+                                           if args.mode == 'train' else
+                                           'backbone + FPN + DeformConv head forward + keypoint-guided decode + NMS'),
                        'global_batch': args.imgs_per_gpu * world, 'parallelism': 'dp%d' % world},
         }
         if not args.no_roofline:

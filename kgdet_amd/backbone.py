@@ -6,7 +6,12 @@ the optional deformable ``conv2`` + ``conv2_offset`` of the dcn configs, :162-18
 contract (``conv1``, ``bn1``, ``layer{1..4}.{i}.conv{1,2,3}|bn{1,2,3}|downsample.{0,1}``).
 BatchNorm stays in eval mode (``norm_eval``) and ``frozen_stages`` freezes the stem + first stages.
 """
+import ctypes
+import weakref
+
+import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from torch.nn.modules.batchnorm import _BatchNorm
 
 from . import dcn as dcn_ops
@@ -52,6 +57,54 @@ class BasicBlock(nn.Module):
             identity = self.downsample(x)
         out += identity
         return self.relu(out)
+
+
+_fold_cache = {}   # id(conv) -> (weakref to conv, folded weight, folded bias)
+
+
+def clear_fold_cache():
+    _fold_cache.clear()
+
+
+def _epilogue_(y, bias, residual, relu):
+    """y = [relu](y + bias[c] [+ residual]) in place: one HIP pass (csrc/epilogue.hip) on the GPU."""
+    if (y.is_cuda and y.is_contiguous() and y.dtype in (torch.float32, torch.bfloat16)
+            and (residual is None or (residual.dtype == y.dtype and residual.shape == y.shape
+                                      and residual.is_contiguous()))):
+        from . import _lib
+        N, C = y.shape[0], y.shape[1]
+        _lib.check(_lib.lib().kgdet_bias_act(
+            _lib.ptr(y), _lib.ptr(bias), _lib.ptr(residual), ctypes.c_int64(N), ctypes.c_int32(C),
+            ctypes.c_int64(y.numel() // max(N * C, 1)), ctypes.c_int32(0 if y.dtype == torch.float32 else 1),
+            ctypes.c_int32(1 if relu else 0), _lib.current_stream()), 'bias_act')
+        return y
+    if bias is not None:
+        y = y + bias.to(y.dtype).view(1, -1, 1, 1)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y, inplace=True) if relu else y
+
+
+def conv_bn(conv, bn, x, relu=False, residual=None):
+    """``[relu](bn(conv(x)) [+ residual])``.  In inference (autograd off, BatchNorm in eval mode, plain bias-free
+    Conv2d) the frozen statistics are folded into the convolution -- w' = w * gamma / sigma,
+    b' = beta - mu * gamma / sigma -- and bias, residual add and ReLU run as ONE in-place pass over the activation
+    instead of BatchNorm + add + clamp (three).  The folded tensors are cached per conv and dropped whenever the
+    backbone changes mode (``ResNet.train``)."""
+    if (torch.is_grad_enabled() or bn.training or not isinstance(bn, _BatchNorm) or type(conv) is not nn.Conv2d
+            or conv.bias is not None or not bn.track_running_stats):
+        out = bn(conv(x))
+        if residual is not None:
+            out += residual
+        return F.relu(out, inplace=True) if relu else out
+    hit = _fold_cache.get(id(conv))
+    if hit is None or hit[0]() is not conv:
+        scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps) if bn.affine else torch.rsqrt(bn.running_var + bn.eps)
+        shift = (bn.bias if bn.affine else 0) - bn.running_mean * scale
+        hit = (weakref.ref(conv), (conv.weight * scale.view(-1, 1, 1, 1)).detach(), shift.detach().float().contiguous())
+        _fold_cache[id(conv)] = hit
+    out = F.conv2d(x, hit[1], None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    return _epilogue_(out, hit[2], residual, relu)
 
 
 class Bottleneck(nn.Module):
@@ -120,9 +173,12 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         identity = x
-        out = self.relu(self.norm1(self.conv1(x)))
+        out = conv_bn(self.conv1, self.norm1, x, relu=True)
         if not self.with_dcn:
-            out = self.conv2(out)
+            out = conv_bn(self.conv2, self.norm2, out, relu=True)
+            if self.downsample is not None:
+                identity = conv_bn(self.downsample[0], self.downsample[1], x)
+            return conv_bn(self.conv3, self.norm3, out, relu=True, residual=identity)
         elif self.with_modulated_dcn:
             offset_mask = self.conv2_offset(out)
             offset = offset_mask[:, :18, :, :]
@@ -263,7 +319,7 @@ class ResNet(nn.Module):
             raise TypeError('pretrained must be a str or None')
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.norm1(self.conv1(x))))
+        x = self.maxpool(conv_bn(self.conv1, self.norm1, x, relu=True))
         outs = []
         for i, layer_name in enumerate(self.res_layers):
             x = getattr(self, layer_name)(x)
@@ -273,6 +329,7 @@ class ResNet(nn.Module):
 
     def train(self, mode=True):
         super(ResNet, self).train(mode)
+        clear_fold_cache()   # weights may have changed since the last inference pass
         self._freeze_stages()
         if mode and self.norm_eval:
             for m in self.modules():

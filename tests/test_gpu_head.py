@@ -209,3 +209,50 @@ def test_training_step_has_no_host_syncs_and_dense_targets_match():
     for k in dense:
         for a, b in zip(dense[k], mirrored[k]):
             assert torch.allclose(a, b, rtol=1e-6, atol=0), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(2, 5, 7, 9), (3, 64, 16, 24), (1, 3, 1, 1)])
+def test_bias_act_epilogue_matches_torch(dtype, shape):
+    """csrc/epilogue.hip: x = relu(x + b[c] + r) in place, every flag combination, odd and vector-width planes."""
+    from kgdet_amd.backbone import _epilogue_
+    g = torch.Generator(device='cpu').manual_seed(3)
+    x = torch.randn(shape, generator=g).to('cuda', dtype)
+    r = torch.randn(shape, generator=g).to('cuda', dtype)
+    b = torch.randn(shape[1], generator=g).cuda()
+    for use_b in (False, True):
+        for use_r in (False, True):
+            for relu in (False, True):
+                want = x.float()
+                if use_b:
+                    want = want + b.view(1, -1, 1, 1)
+                if use_r:
+                    want = want + r.float()
+                if relu:
+                    want = want.clamp(min=0)
+                got = _epilogue_(x.clone(), b if use_b else None, r if use_r else None, relu)
+                assert got.dtype == dtype
+                # one rounding to the storage type at the end (torch's chain of bf16 ops would round twice)
+                torch.testing.assert_close(got, want.to(dtype), rtol=0, atol=0)
+
+
+@pytest.mark.gpu
+def test_inference_backbone_fold_matches_module_path_on_gpu():
+    """no_grad ResNet-50 forward (folded BN + fused epilogue) == the module-by-module forward under autograd."""
+    from kgdet_amd.backbone import ResNet
+    torch.manual_seed(0)
+    net = ResNet(depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1, style='pytorch').cuda()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+    net.eval()
+    x = torch.randn(2, 3, 96, 128, device='cuda')
+    ref = [o.detach() for o in net(x)]
+    with torch.no_grad():
+        got = net(x)
+    for a, b in zip(got, ref):
+        assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item()

@@ -353,3 +353,29 @@ def test_dense_targets_equal_mirrored_path():
             assert a[0].shape == b[0].shape and a[0].dtype == b[0].dtype
             assert torch.equal(a[0], b[0])
         assert int(new[7]) == ref[7] and int(new[8]) == ref[8]
+
+
+def test_inference_bn_fold_matches_unfolded_backbone():
+    """conv_bn folds frozen BatchNorm statistics into the convolution when autograd is off; same features"""
+    from kgdet_amd.backbone import ResNet
+    torch.manual_seed(0)
+    m = ResNet(depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1, style='pytorch')
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.1)
+            mod.running_var.uniform_(0.5, 1.5)
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0, 0.1)
+    m.eval()
+    x = torch.randn(1, 3, 64, 96)
+    with torch.enable_grad():
+        ref = m(x)            # unfolded: bn(conv(x))
+    with torch.no_grad():
+        out = m(x)            # folded
+        m.layer2[0].conv1.weight.mul_(2.0)
+        m.train()
+        m.eval()              # mode switch drops the folded weights
+        out2 = m(x)
+    for a, b in zip(ref, out):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(a.abs().max()))
+    assert not torch.allclose(out[1], out2[1])
