@@ -27,11 +27,12 @@ extern "C" {
 #define KGDET_E_SHAPE 1     /* shape/argument check failed (reference: AT_CHECK -> RuntimeError) */
 #define KGDET_E_WORKSPACE 2 /* workspace too small */
 #define KGDET_E_HIP 3       /* Inference epilogue of a convolution with folded BatchNorm: x = [relu](x + bias[c] [+ residual]) in place.
- * x, residual: [N, C, HW] contiguous, dtype 0 = float32, 1 = bfloat16; bias [C] float32 (nullable); residual
- * nullable.  No reference counterpart: it fuses the BatchNorm / residual add / ReLU passes of
+ * x, residual: [N, C, HW] contiguous, or [N, HW, C] when channels_last != 0 (then C must be a multiple of 4
+ * (float32) / 8 (bfloat16), else KGDET_E_UNSUPPORTED); dtype 0 = float32, 1 = bfloat16; bias [C] float32
+ * (nullable); residual nullable.  No reference counterpart: it fuses the BatchNorm / residual add / ReLU passes of
  * mmdet/models/backbones/resnet.py:231-262 once the frozen statistics are folded into the weights. */
 int kgdet_bias_act(void *x, const float *bias, const void *residual, int64_t N, int32_t C, int64_t HW, int32_t dtype,
-                   int32_t relu, void *stream);
+                   int32_t relu, int32_t channels_last, void *stream);
 
 /* HIP runtime error (launch failure etc.) */
 #define KGDET_E_UNSUPPORTED 4

@@ -67,17 +67,25 @@ def clear_fold_cache():
 
 
 def _epilogue_(y, bias, residual, relu):
-    """y = [relu](y + bias[c] [+ residual]) in place: one HIP pass (csrc/epilogue.hip) on the GPU."""
-    if (y.is_cuda and y.is_contiguous() and y.dtype in (torch.float32, torch.bfloat16)
-            and (residual is None or (residual.dtype == y.dtype and residual.shape == y.shape
-                                      and residual.is_contiguous()))):
-        from . import _lib
+    """y = [relu](y + bias[c] [+ residual]) in place: one HIP pass (csrc/epilogue.hip) on the GPU, for NCHW and for
+    channels-last storage."""
+    if y.is_cuda and y.dtype in (torch.float32, torch.bfloat16) and y.dim() == 4:
         N, C = y.shape[0], y.shape[1]
-        _lib.check(_lib.lib().kgdet_bias_act(
-            _lib.ptr(y), _lib.ptr(bias), _lib.ptr(residual), ctypes.c_int64(N), ctypes.c_int32(C),
-            ctypes.c_int64(y.numel() // max(N * C, 1)), ctypes.c_int32(0 if y.dtype == torch.float32 else 1),
-            ctypes.c_int32(1 if relu else 0), _lib.current_stream()), 'bias_act')
-        return y
+        if y.is_contiguous():
+            fmt = torch.contiguous_format
+        elif y.is_contiguous(memory_format=torch.channels_last) and C % (4 if y.dtype == torch.float32 else 8) == 0:
+            fmt = torch.channels_last
+        else:
+            fmt = None
+        if fmt is not None and (residual is None or (residual.dtype == y.dtype and residual.shape == y.shape
+                                                     and residual.is_contiguous(memory_format=fmt))):
+            from . import _lib
+            _lib.check(_lib.lib().kgdet_bias_act(
+                _lib.ptr(y), _lib.ptr(bias), _lib.ptr(residual), ctypes.c_int64(N), ctypes.c_int32(C),
+                ctypes.c_int64(y.numel() // max(N * C, 1)), ctypes.c_int32(0 if y.dtype == torch.float32 else 1),
+                ctypes.c_int32(1 if relu else 0), ctypes.c_int32(1 if fmt is torch.channels_last else 0),
+                _lib.current_stream()), 'bias_act')
+            return y
     if bias is not None:
         y = y + bias.to(y.dtype).view(1, -1, 1, 1)
     if residual is not None:
@@ -89,20 +97,29 @@ def conv_bn(conv, bn, x, relu=False, residual=None):
     """``[relu](bn(conv(x)) [+ residual])``.  In inference (autograd off, BatchNorm in eval mode, plain bias-free
     Conv2d) the frozen statistics are folded into the convolution -- w' = w * gamma / sigma,
     b' = beta - mu * gamma / sigma -- and bias, residual add and ReLU run as ONE in-place pass over the activation
-    instead of BatchNorm + add + clamp (three).  The folded tensors are cached per conv and dropped whenever the
-    backbone changes mode (``ResNet.train``)."""
+    instead of BatchNorm + add + clamp (three).  Under bf16 autocast the folded weight is kept in bf16 and
+    channels-last: MIOpen's bf16 kernels on gfx950 are NHWC implicit GEMMs, so NCHW activations cost a transpose
+    in and out of every convolution (6 % of the batch).  The folded tensors are cached per conv and dropped
+    whenever the backbone changes mode (``ResNet.train``)."""
     if (torch.is_grad_enabled() or bn.training or not isinstance(bn, _BatchNorm) or type(conv) is not nn.Conv2d
             or conv.bias is not None or not bn.track_running_stats):
         out = bn(conv(x))
         if residual is not None:
             out += residual
         return F.relu(out, inplace=True) if relu else out
-    hit = _fold_cache.get(id(conv))
+    bf16 = x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled()
+                                                        and torch.get_autocast_dtype('cuda') == torch.bfloat16))
+    hit = _fold_cache.get((id(conv), bf16))
     if hit is None or hit[0]() is not conv:
         scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps) if bn.affine else torch.rsqrt(bn.running_var + bn.eps)
         shift = (bn.bias if bn.affine else 0) - bn.running_mean * scale
-        hit = (weakref.ref(conv), (conv.weight * scale.view(-1, 1, 1, 1)).detach(), shift.detach().float().contiguous())
-        _fold_cache[id(conv)] = hit
+        w = (conv.weight * scale.view(-1, 1, 1, 1)).detach()
+        if bf16:
+            w = w.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        hit = (weakref.ref(conv), w, shift.detach().float().contiguous())
+        _fold_cache[(id(conv), bf16)] = hit
+    if bf16 and not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     out = F.conv2d(x, hit[1], None, conv.stride, conv.padding, conv.dilation, conv.groups)
     return _epilogue_(out, hit[2], residual, relu)
 

@@ -53,18 +53,80 @@ __global__ __launch_bounds__(256) void bias_act_kernel(T *__restrict__ x, const 
   }
 }
 
+// channels-last storage ([N, HW, C], C a multiple of the vector width): a flat pass, bias index = element % C
+template <typename T, bool RES, bool RELU>
+__global__ __launch_bounds__(256) void bias_act_nhwc_kernel(T *__restrict__ x, const float *__restrict__ bias,
+                                                            const T *__restrict__ res, int C, long long nvec) {
+  constexpr int V = Vec16<T>::n;
+  typedef T vec_t __attribute__((ext_vector_type(V)));
+  // the channel of a vector only depends on i mod (C / V): track it incrementally instead of dividing per element
+  const unsigned cv = (unsigned)(C / V);
+  const long long step = gridDim.x * 256LL;
+  const unsigned cstep = (unsigned)(step % cv);
+  long long i = blockIdx.x * 256LL + threadIdx.x;
+  unsigned ci = (unsigned)(i % cv);
+  for (; i < nvec; i += step) {
+    vec_t v = reinterpret_cast<vec_t *>(x)[i];
+    vec_t r;
+    if (RES) r = reinterpret_cast<const vec_t *>(res)[i];
+    float bv[V];
+    if (bias) {
+#pragma unroll
+      for (int k = 0; k < V; k += 4) {
+        const float4 b4 = *reinterpret_cast<const float4 *>(bias + ci * V + k);
+        bv[k] = b4.x; bv[k + 1] = b4.y; bv[k + 2] = b4.z; bv[k + 3] = b4.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < V; ++k) bv[k] = 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      float f = (float)v[k] + bv[k];
+      if (RES) f += (float)r[k];
+      if (RELU) f = fmaxf(f, 0.0f);
+      v[k] = (T)f;
+    }
+    reinterpret_cast<vec_t *>(x)[i] = v;
+    ci += cstep;
+    if (ci >= cv) ci -= cv;
+  }
+}
+
 }  // namespace kgdet
 
 using namespace kgdet;
 
 extern "C" int kgdet_bias_act(void *x, const float *bias, const void *residual, int64_t N, int32_t C, int64_t HW,
-                              int32_t dtype, int32_t relu, void *stream) {
+                              int32_t dtype, int32_t relu, int32_t channels_last, void *stream) {
   KGDET_CHECK_SHAPE(N >= 0 && C > 0 && HW >= 0, "bad sizes");
   KGDET_CHECK_SHAPE(dtype == 0 || dtype == 1, "dtype must be 0 (float32) or 1 (bfloat16)");
   if (N * HW == 0) return KGDET_OK;
   KGDET_CHECK_SHAPE(x != nullptr, "null pointer");
   const long long planes = N * C;
   const int per = dtype == 0 ? 4 : 8;
+  if (channels_last) {
+    if (C % per != 0) {
+      set_error("channels-last epilogue needs C %% %d == 0 (got C=%d)", per, C);
+      return KGDET_E_UNSUPPORTED;
+    }
+    const long long nvec = N * HW * C / per;
+    const long long want = (nvec + 255) / 256;
+    dim3 grid((unsigned)(want > 16384 ? 16384 : want));
+#define LAUNCH_CL(T, RES, RELU)                                                                              \
+  hipLaunchKernelGGL((bias_act_nhwc_kernel<T, RES, RELU>), grid, dim3(256), 0, (hipStream_t)stream, (T *)x, \
+                     bias, (const T *)residual, C, nvec)
+    if (dtype == 0) {
+      if (residual) { if (relu) LAUNCH_CL(float, true, true); else LAUNCH_CL(float, true, false); }
+      else { if (relu) LAUNCH_CL(float, false, true); else LAUNCH_CL(float, false, false); }
+    } else {
+      if (residual) { if (relu) LAUNCH_CL(__bf16, true, true); else LAUNCH_CL(__bf16, true, false); }
+      else { if (relu) LAUNCH_CL(__bf16, false, true); else LAUNCH_CL(__bf16, false, false); }
+    }
+#undef LAUNCH_CL
+    KGDET_CHECK_LAUNCH("bias_act_nhwc");
+    return KGDET_OK;
+  }
   const int gx = (int)((HW / per + 255) / 256) > 0 ? (int)((HW / per + 255) / 256) : 1;
   dim3 grid(gx > 64 ? 64 : gx, planes > 4096 ? 4096 : (int)planes);
 #define LAUNCH(T, RES, RELU)                                                                                      \

@@ -7,6 +7,7 @@ image per GPU at test time (base.py:75-76); ``simple_test_batch`` lifts that for
 inference configuration, running decode + NMS for the whole batch at once.
 """
 import numpy as np
+import torch
 import torch.nn as nn
 
 from .registry import DETECTORS, build_backbone, build_head, build_neck
@@ -50,6 +51,9 @@ class RepPointsDetectorKp(nn.Module):
         x = self.backbone(img)
         if self.with_neck:
             x = self.neck(x)
+        if not torch.is_grad_enabled():
+            # the bf16 inference backbone runs channels-last (backbone.conv_bn); the head's kernels take NCHW
+            x = tuple(o.contiguous() for o in x)
         return x
 
     def forward_dummy(self, img):

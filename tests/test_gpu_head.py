@@ -235,6 +235,12 @@ def test_bias_act_epilogue_matches_torch(dtype, shape):
                 assert got.dtype == dtype
                 # one rounding to the storage type at the end (torch's chain of bf16 ops would round twice)
                 torch.testing.assert_close(got, want.to(dtype), rtol=0, atol=0)
+                if shape[1] % 8 == 0:   # channels-last storage goes through the NHWC kernel
+                    cl = torch.channels_last
+                    got = _epilogue_(x.clone(memory_format=cl), b if use_b else None,
+                                     r.contiguous(memory_format=cl) if use_r else None, relu)
+                    assert got.is_contiguous(memory_format=cl)
+                    torch.testing.assert_close(got, want.to(dtype), rtol=0, atol=0)
 
 
 @pytest.mark.gpu
@@ -256,3 +262,12 @@ def test_inference_backbone_fold_matches_module_path_on_gpu():
         got = net(x)
     for a, b in zip(got, ref):
         assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item()
+    # bf16 autocast: channels-last folded path against the module path under the same autocast
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        ref16 = [o.detach().float() for o in net(x)]
+        with torch.no_grad():
+            got16 = [o.float() for o in net(x)]
+    for a, b, c in zip(got16, ref16, ref):
+        assert a.shape == b.shape
+        # both bf16 paths sit within bf16 noise of the fp32 result; neither is the reference for the other
+        assert (a - c).abs().max().item() <= 2.0 * max((b - c).abs().max().item(), 1e-2 * c.abs().max().item())
