@@ -19,15 +19,8 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-HBM_PEAK_GBS = 8000.0
-PLANE_GROUP_TRAFFIC_BYTES = 1.019e9  # profiles/r01_dcn_fwd_plane_group_b2.md: (2 x FETCH_SIZE + WRITE_SIZE) of the 3 kernels
 
 
 def parse_args():
@@ -38,14 +31,31 @@ def parse_args():
     ap.add_argument('--imgs-per-gpu', type=int, default=2)
     ap.add_argument('--mode', choices=['train', 'infer'], default='train')
     ap.add_argument('--dtype', choices=['fp32', 'bf16'], default='fp32',
-                    help='precision of the dense backbone/FPN/tower convolutions (autocast); the deformable '
-                         'path always computes in fp32')
+                    help='fp32 (the reference precision) or bf16 autocast for the dense convolutions')
+    ap.add_argument('--miopen-find', type=int, choices=[0, 1], default=1,
+                    help='torch.backends.cudnn.benchmark (the reference\'s cfg.cudnn_benchmark, '
+                         'mmdetection/tools/benchmark.py:53-55): MIOpen measures its solvers per convolution shape '
+                         'instead of taking the heuristic pick')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     return ap.parse_args()
 
 
-BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md); AMD's 5 PF figure includes 2:1 sparsity
+ARGS = parse_args() if __name__ == '__main__' else None
+# MIOpen's measured solver picks for this workload's convolution shapes on MI355X (written by MIOpen itself during
+# a first run on the GPU box, see kgdet_amd/miopen_db/README.md): with the records present the find step is a
+# lookup instead of minutes of measuring.  One directory per workload; must be set before MIOpen is initialised.
+if ARGS is not None and ARGS.miopen_find:
+    os.environ.setdefault('MIOPEN_USER_DB_PATH', os.path.join(
+        ROOT, 'kgdet_amd', 'miopen_db', '%s_%s_b%d' % (ARGS.mode, ARGS.dtype, ARGS.imgs_per_gpu)))
+    os.makedirs(os.environ['MIOPEN_USER_DB_PATH'], exist_ok=True)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+PLANE_GROUP_TRAFFIC_BYTES = 1.019e9  # profiles/r01_dcn_fwd_plane_group_b2.md: (2 x FETCH_SIZE + WRITE_SIZE) of the 3 kernels
 
 
 def dcn_roofline(device, iters=30):
@@ -114,7 +124,7 @@ def cpu_baseline():
 
 
 def main():
-    args = parse_args()
+    args = ARGS
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -132,6 +142,7 @@ def main():
 
     cfg = configs.kgdet_r50_fpn()
     torch.manual_seed(0)
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
     model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).to(device)
     if world > 1:  # same initial weights everywhere (the reference broadcasts once at start-up)
         for p in list(model.parameters()) + list(model.buffers()):
