@@ -26,7 +26,25 @@ extern "C" {
 #define KGDET_OK 0
 #define KGDET_E_SHAPE 1     /* shape/argument check failed (reference: AT_CHECK -> RuntimeError) */
 #define KGDET_E_WORKSPACE 2 /* workspace too small */
-#define KGDET_E_HIP 3       /* Inference epilogue of a convolution with folded BatchNorm: x = [relu](x + bias[c] [+ residual]) in place.
+#define KGDET_E_HIP 3       /* Frozen-statistics BatchNorm (+ residual add) (+ ReLU) in one pass -- the norm_eval=True training path of
+ * mmdet/models/backbones/resnet.py:240-262,518-525.  float32, NCHW: x, residual, y [N, C, HW]; gamma, beta (nullable:
+ * 1 / 0), mean, var [C].     y = [relu](x * s + t [+ residual]),  s = gamma / sqrt(var + eps),  t = beta - mean * s.
+ * y may alias x when x is not needed by a later backward. */
+int kgdet_bn_act_forward(const float *x, const float *gamma, const float *beta, const float *mean, const float *var,
+                         float eps, const float *residual, float *y, int64_t N, int32_t C, int64_t HW, int32_t relu,
+                         void *stream);
+/* Backward of the above.  g' = grad_y * [y > 0] (relu) else grad_y;  grad_x = g' * s (grad_x nullable);
+ * grad_residual = g' is WRITTEN only when has_residual && relu (otherwise it equals grad_y and the caller reuses
+ * that tensor); y is read only in that case.  partial: [2][C][P] with P = kgdet_bn_act_partials(N, C, HW):
+ * partial[0][c][:] sums to grad_beta[c], partial[1][c][:] to grad_gamma[c] (per-workgroup partials in a fixed order:
+ * deterministic, no atomics; the caller adds them). */
+int32_t kgdet_bn_act_partials(int64_t N, int32_t C, int64_t HW);
+int kgdet_bn_act_backward(const float *grad_y, const float *x, const float *y, const float *gamma, const float *beta,
+                          const float *mean, const float *var, float eps, int32_t has_residual, int32_t relu,
+                          float *grad_x, float *grad_residual, float *partial, int64_t N, int32_t C, int64_t HW,
+                          void *stream);
+
+/* Inference epilogue of a convolution with folded BatchNorm: x = [relu](x + bias[c] [+ residual]) in place.
  * x, residual: [N, C, HW] contiguous, or [N, HW, C] when channels_last != 0 (then C must be a multiple of 4
  * (float32) / 8 (bfloat16), else KGDET_E_UNSUPPORTED); dtype 0 = float32, 1 = bfloat16; bias [C] float32
  * (nullable); residual nullable.  No reference counterpart: it fuses the BatchNorm / residual add / ReLU passes of

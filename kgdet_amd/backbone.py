@@ -93,6 +93,65 @@ def _epilogue_(y, bias, residual, relu):
     return F.relu(y, inplace=True) if relu else y
 
 
+class _FrozenBNAct(torch.autograd.Function):
+    """``[relu](batch_norm_eval(x) [+ residual])`` as one HIP pass each way (csrc/bn_act.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mean, var, eps, residual, relu):
+        from . import _lib
+        N, C = x.shape[0], x.shape[1]
+        HW = x.numel() // max(N * C, 1)
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().kgdet_bn_act_forward(
+            _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(var), ctypes.c_float(eps),
+            _lib.ptr(residual), _lib.ptr(y), ctypes.c_int64(N), ctypes.c_int32(C), ctypes.c_int64(HW),
+            ctypes.c_int32(1 if relu else 0), _lib.current_stream()), 'bn_act_forward')
+        ctx.eps, ctx.relu, ctx.has_res = eps, relu, residual is not None
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, gamma, beta, mean, var)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import _lib
+        x, y, gamma, beta, mean, var = ctx.saved_tensors
+        gy = gy.contiguous()
+        N, C = x.shape[0], x.shape[1]
+        HW = x.numel() // max(N * C, 1)
+        L = _lib.lib()
+        P = L.kgdet_bn_act_partials(ctypes.c_int64(N), ctypes.c_int32(C), ctypes.c_int64(HW))
+        partial = torch.empty((2, C, max(P, 1)), dtype=torch.float32, device=x.device)
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        masked = ctx.has_res and ctx.relu
+        gres = torch.empty_like(x) if masked else None
+        _lib.check(L.kgdet_bn_act_backward(
+            _lib.ptr(gy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(var),
+            ctypes.c_float(ctx.eps), ctypes.c_int32(1 if ctx.has_res else 0), ctypes.c_int32(1 if ctx.relu else 0),
+            _lib.ptr(gx), _lib.ptr(gres), _lib.ptr(partial), ctypes.c_int64(N), ctypes.c_int32(C), ctypes.c_int64(HW),
+            _lib.current_stream()), 'bn_act_backward')
+        sums = partial.sum(dim=2) if P > 0 else partial.new_zeros((2, C))
+        ggamma = sums[1] if (gamma is not None and ctx.needs_input_grad[1]) else None
+        gbeta = sums[0] if (beta is not None and ctx.needs_input_grad[2]) else None
+        if not ctx.has_res or not ctx.needs_input_grad[6]:
+            gres = None
+        elif not masked:
+            gres = gy
+        return gx, ggamma, gbeta, None, None, None, gres, None
+
+
+def frozen_bn_act(x, bn, residual=None, relu=False):
+    """BatchNorm with frozen statistics (eval mode) + residual add + ReLU.  On the GPU in fp32 this is the fused
+    HIP op; otherwise (CPU tests, autocast dtypes, exotic layouts) the three torch ops of the reference."""
+    if (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and not bn.training
+            and bn.track_running_stats and x.shape[0] * x.shape[1] <= 65535
+            and (residual is None or (residual.dtype == x.dtype and residual.shape == x.shape
+                                      and residual.is_contiguous()))):
+        return _FrozenBNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, residual, relu)
+    out = bn(x)
+    if residual is not None:
+        out = out + residual
+    return F.relu(out, inplace=True) if relu else out
+
+
 def conv_bn(conv, bn, x, relu=False, residual=None):
     """``[relu](bn(conv(x)) [+ residual])``.  In inference (autograd off, BatchNorm in eval mode, plain bias-free
     Conv2d) the frozen statistics are folded into the convolution -- w' = w * gamma / sigma,
@@ -101,12 +160,14 @@ def conv_bn(conv, bn, x, relu=False, residual=None):
     channels-last: MIOpen's bf16 kernels on gfx950 are NHWC implicit GEMMs, so NCHW activations cost a transpose
     in and out of every convolution (6 % of the batch).  The folded tensors are cached per conv and dropped
     whenever the backbone changes mode (``ResNet.train``)."""
-    if (torch.is_grad_enabled() or bn.training or not isinstance(bn, _BatchNorm) or type(conv) is not nn.Conv2d
-            or conv.bias is not None or not bn.track_running_stats):
+    if (bn.training or not isinstance(bn, _BatchNorm) or type(conv) is not nn.Conv2d or conv.bias is not None
+            or not bn.track_running_stats):
         out = bn(conv(x))
         if residual is not None:
             out += residual
         return F.relu(out, inplace=True) if relu else out
+    if torch.is_grad_enabled():
+        return frozen_bn_act(conv(x), bn, residual, relu)
     bf16 = x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled()
                                                         and torch.get_autocast_dtype('cuda') == torch.bfloat16))
     hit = _fold_cache.get((id(conv), bf16))

@@ -1,0 +1,187 @@
+// Frozen-statistics BatchNorm + residual add + ReLU as ONE pass, forward and backward (training, fp32, NCHW).
+//
+// mmdet's ResNet trains with norm_eval=True (mmdet/models/backbones/resnet.py:518-525): BatchNorm uses its running
+// statistics, i.e. it is the per-channel affine map  y = x * s + t,  s = gamma / sqrt(var + eps),  t = beta - mean * s,
+// whose gamma / beta still receive gradients.  A bottleneck (resnet.py:240-262) runs it as BatchNorm, residual add
+// and ReLU -- three passes over the activation forward, threshold + BatchNorm backward (4 reads, 2 writes) backward.
+// Here:   forward   y = [relu](x * s + t [+ r])                                   1-2 reads, 1 write
+//         backward  g' = g * [pre-activation > 0];  grad_x = g' * s;  grad_r = g'  2-3 reads, 1-2 writes
+//                   grad_beta = sum g',  grad_gamma = invstd * sum g' * (x - mean)
+// One workgroup owns a slice of one (image, channel) plane, so the channel constants are scalars; the two channel
+// sums leave as per-workgroup partials [2][C][P] (deterministic; the caller adds the P partials).
+#include "common.h"
+
+namespace kgdet {
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+struct ChannelAffine {
+  float s, t, mean, invstd;
+};
+
+__device__ __forceinline__ ChannelAffine channel_affine(const float *gamma, const float *beta, const float *mean,
+                                                        const float *var, float eps, int c) {
+  ChannelAffine a;
+  a.mean = mean[c];
+  a.invstd = 1.0f / sqrtf(var[c] + eps);
+  a.s = (gamma ? gamma[c] : 1.0f) * a.invstd;
+  a.t = (beta ? beta[c] : 0.0f) - a.mean * a.s;
+  return a;
+}
+
+}  // namespace
+
+// grid (chunks, N*C); a chunk is a contiguous run of `per` elements of the plane (per % 4 == 0)
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta, const float *__restrict__ mean,
+                                                         const float *__restrict__ var, float eps,
+                                                         const float *__restrict__ res, float *__restrict__ y, int C,
+                                                         int HW, int per) {
+  const int plane = blockIdx.y, c = plane % C;
+  const ChannelAffine a = channel_affine(gamma, beta, mean, var, eps, c);
+  const long long base = (long long)plane * HW;
+  const int lo = blockIdx.x * per, hi = min(HW, lo + per);
+  if ((HW & 3) == 0) {
+    for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+      float4 v = *reinterpret_cast<const float4 *>(x + base + i);
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (RES) r = *reinterpret_cast<const float4 *>(res + base + i);
+      v.x = v.x * a.s + a.t + r.x; v.y = v.y * a.s + a.t + r.y;
+      v.z = v.z * a.s + a.t + r.z; v.w = v.w * a.s + a.t + r.w;
+      if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<float4 *>(y + base + i) = v;
+    }
+  } else {
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+      float v = x[base + i] * a.s + a.t;
+      if (RES) v += res[base + i];
+      if (RELU) v = fmaxf(v, 0.f);
+      y[base + i] = v;
+    }
+  }
+}
+
+// y is read only when RES && RELU (the mask cannot be recomputed without the residual input);
+// grad_res is written only when RES && RELU (otherwise the residual gradient IS grad_y)
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float *__restrict__ gy, const float *__restrict__ x,
+                                                         const float *__restrict__ y, const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta, const float *__restrict__ mean,
+                                                         const float *__restrict__ var, float eps,
+                                                         float *__restrict__ gx, float *__restrict__ gres,
+                                                         float *__restrict__ partial, int C, int HW, int per, int P) {
+  __shared__ float red[2][4];
+  const int plane = blockIdx.y, c = plane % C, n = plane / C;
+  const ChannelAffine a = channel_affine(gamma, beta, mean, var, eps, c);
+  const long long base = (long long)plane * HW;
+  const int lo = blockIdx.x * per, hi = min(HW, lo + per);
+  float s1 = 0.f, s2 = 0.f;
+  auto one = [&](float g, float xv, float yv) -> float {
+    if (RELU) {
+      const bool on = RES ? (yv > 0.f) : (xv * a.s + a.t > 0.f);
+      g = on ? g : 0.f;
+    }
+    s1 += g;
+    s2 += g * (xv - a.mean);
+    return g;
+  };
+  if ((HW & 3) == 0) {
+    for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+      float4 g = *reinterpret_cast<const float4 *>(gy + base + i);
+      const float4 xv = *reinterpret_cast<const float4 *>(x + base + i);
+      float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (RES && RELU) yv = *reinterpret_cast<const float4 *>(y + base + i);
+      g.x = one(g.x, xv.x, yv.x); g.y = one(g.y, xv.y, yv.y); g.z = one(g.z, xv.z, yv.z); g.w = one(g.w, xv.w, yv.w);
+      if (RES && RELU) *reinterpret_cast<float4 *>(gres + base + i) = g;
+      if (gx) *reinterpret_cast<float4 *>(gx + base + i) = make_float4(g.x * a.s, g.y * a.s, g.z * a.s, g.w * a.s);
+    }
+  } else {
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+      const float g = one(gy[base + i], x[base + i], (RES && RELU) ? y[base + i] : 0.f);
+      if (RES && RELU) gres[base + i] = g;
+      if (gx) gx[base + i] = g * a.s;
+    }
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][w] = s1; red[1][w] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int slot = n * gridDim.x + blockIdx.x;
+    partial[(long long)c * P + slot] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    partial[(long long)(C + c) * P + slot] = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) * a.invstd;
+  }
+}
+
+namespace {
+
+// chunks per plane: enough workgroups to fill 256 CUs several times over, at least 1024 elements each
+int chunks_for(int64_t planes, int64_t HW) {
+  int64_t want = (4096 + planes - 1) / planes;
+  const int64_t most = (HW + 1023) / 1024;
+  if (want > most) want = most;
+  return want < 1 ? 1 : (int)want;
+}
+
+}  // namespace
+
+}  // namespace kgdet
+
+using namespace kgdet;
+
+extern "C" int32_t kgdet_bn_act_partials(int64_t N, int32_t C, int64_t HW) {
+  if (N <= 0 || C <= 0 || HW <= 0) return 0;
+  return (int32_t)(N * chunks_for(N * C, HW));
+}
+
+extern "C" int kgdet_bn_act_forward(const float *x, const float *gamma, const float *beta, const float *mean,
+                                    const float *var, float eps, const float *residual, float *y, int64_t N, int32_t C,
+                                    int64_t HW, int32_t relu, void *stream) {
+  KGDET_CHECK_SHAPE(N >= 0 && C > 0 && HW >= 0 && HW < (1LL << 31), "bad sizes");
+  if (N * HW == 0) return KGDET_OK;
+  KGDET_CHECK_SHAPE(x && y && mean && var, "null pointer");
+  KGDET_CHECK_SHAPE(N * C <= 65535, "N*C = %lld exceeds the grid limit", (long long)(N * C));
+  const int chunks = chunks_for(N * C, HW);
+  const int per = (int)(((HW + chunks - 1) / chunks + 3) / 4 * 4);
+  dim3 grid(chunks, (unsigned)(N * C));
+#define LAUNCH(RES, RELU)                                                                                      \
+  hipLaunchKernelGGL((bn_act_fwd_kernel<RES, RELU>), grid, dim3(256), 0, (hipStream_t)stream, x, gamma, beta, \
+                     mean, var, eps, residual, y, C, (int)HW, per)
+  if (residual) { if (relu) LAUNCH(true, true); else LAUNCH(true, false); }
+  else { if (relu) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+  KGDET_CHECK_LAUNCH("bn_act_forward");
+  return KGDET_OK;
+}
+
+extern "C" int kgdet_bn_act_backward(const float *grad_y, const float *x, const float *y, const float *gamma,
+                                     const float *beta, const float *mean, const float *var, float eps,
+                                     int32_t has_residual, int32_t relu, float *grad_x, float *grad_residual,
+                                     float *partial, int64_t N, int32_t C, int64_t HW, void *stream) {
+  KGDET_CHECK_SHAPE(N >= 0 && C > 0 && HW >= 0 && HW < (1LL << 31), "bad sizes");
+  if (N * HW == 0) return KGDET_OK;
+  KGDET_CHECK_SHAPE(grad_y && x && mean && var && partial, "null pointer");
+  KGDET_CHECK_SHAPE(!(has_residual && relu) || (y && grad_residual),
+                    "residual + relu needs the forward output and a grad_residual buffer");
+  KGDET_CHECK_SHAPE(N * C <= 65535, "N*C = %lld exceeds the grid limit", (long long)(N * C));
+  const int chunks = chunks_for(N * C, HW);
+  const int per = (int)(((HW + chunks - 1) / chunks + 3) / 4 * 4);
+  const int P = (int)(N * chunks);
+  dim3 grid(chunks, (unsigned)(N * C));
+#define LAUNCH(RES, RELU)                                                                                        \
+  hipLaunchKernelGGL((bn_act_bwd_kernel<RES, RELU>), grid, dim3(256), 0, (hipStream_t)stream, grad_y, x, y, gamma, \
+                     beta, mean, var, eps, grad_x, grad_residual, partial, C, (int)HW, per, P)
+  if (has_residual) { if (relu) LAUNCH(true, true); else LAUNCH(true, false); }
+  else { if (relu) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+  KGDET_CHECK_LAUNCH("bn_act_backward");
+  return KGDET_OK;
+}

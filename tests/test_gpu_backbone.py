@@ -1,0 +1,114 @@
+"""Fused frozen-BatchNorm + residual + ReLU (csrc/bn_act.hip) against the three torch ops it replaces
+(mmdet/models/backbones/resnet.py:240-262 under norm_eval=True)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _bn(C, seed):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    bn = torch.nn.BatchNorm2d(C).cuda()
+    bn.running_mean.copy_(torch.randn(C, generator=g) * 0.3)
+    bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    bn.weight.data.copy_(torch.rand(C, generator=g) + 0.5)
+    bn.bias.data.copy_(torch.randn(C, generator=g) * 0.2)
+    return bn.eval()
+
+
+@pytest.mark.parametrize('shape', [(2, 6, 7, 9), (2, 64, 40, 64), (1, 3, 1, 1), (3, 16, 33, 4), (2, 512, 100, 168)])
+@pytest.mark.parametrize('use_res', [False, True])
+@pytest.mark.parametrize('relu', [False, True])
+def test_frozen_bn_act_matches_torch(shape, use_res, relu):
+    from kgdet_amd.backbone import frozen_bn_act, _FrozenBNAct
+    g = torch.Generator(device='cpu').manual_seed(1)
+    bn = _bn(shape[1], 2)
+    x0 = torch.randn(shape, generator=g).cuda()
+    r0 = torch.randn(shape, generator=g).cuda()
+    gy = torch.randn(shape, generator=g).cuda()
+
+    def run(fused):
+        x = x0.clone().requires_grad_(True)
+        r = r0.clone().requires_grad_(True) if use_res else None
+        bn.zero_grad()
+        if fused:
+            y = frozen_bn_act(x, bn, r, relu)
+            assert isinstance(y.grad_fn, _FrozenBNAct._backward_cls)   # the HIP op ran, not the torch ops
+        else:
+            y = bn(x)
+            if use_res:
+                y = y + r
+            if relu:
+                y = F.relu(y)
+        y.backward(gy)
+        return (y.detach(), x.grad, bn.weight.grad.clone(), bn.bias.grad.clone(), r.grad if use_res else None)
+
+    got, want = run(True), run(False)
+    names = ['y', 'grad_x', 'grad_gamma', 'grad_beta', 'grad_residual']
+    for n, a, b in zip(names, got, want):
+        if b is None:
+            assert a is None
+            continue
+        scale = b.abs().max().item() + 1e-12
+        # elementwise outputs differ by fma contraction only; the channel sums by summation order
+        tol = 2e-6 if n in ('y', 'grad_x', 'grad_residual') else 2e-5
+        # a ReLU mask may flip where the pre-activation is within rounding of zero: allow isolated elements
+        bad = ((a - b).abs() > tol * scale).float().mean().item()
+        assert bad <= (1e-5 if n != 'y' else 0.0) or n in ('grad_gamma', 'grad_beta') and bad == 0, (n, bad)
+
+
+def test_frozen_bn_act_without_input_grad_and_without_affine_grads():
+    from kgdet_amd.backbone import frozen_bn_act
+    bn = _bn(8, 3)
+    for p in bn.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(2, 8, 5, 12, device='cuda')
+    r = torch.randn(2, 8, 5, 12, device='cuda', requires_grad=True)
+    y = frozen_bn_act(x, bn, r, True)
+    y.sum().backward()
+    want = (F.relu(bn(x) + r.detach()) > 0).float()
+    torch.testing.assert_close(r.grad, want)
+    assert bn.weight.grad is None and bn.bias.grad is None
+
+
+def test_training_backbone_uses_fused_op_and_matches_module_path():
+    """ResNet-50 in train() (norm_eval): outputs and every parameter gradient equal the module-by-module path."""
+    from kgdet_amd import backbone as bb
+    torch.manual_seed(0)
+    net = bb.ResNet(depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1, style='pytorch').cuda()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+    net.train()
+    x = torch.randn(2, 3, 96, 128, device='cuda')
+
+    def run():
+        net.zero_grad()
+        outs = net(x)
+        sum(o.square().mean() for o in outs).backward()
+        return [o.detach() for o in outs], {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+
+    outs, grads = run()
+    orig = bb.frozen_bn_act
+
+    def unfused(x, bn, residual=None, relu=False):
+        out = bn(x)
+        if residual is not None:
+            out = out + residual
+        return F.relu(out, inplace=True) if relu else out
+
+    bb.frozen_bn_act = unfused
+    try:
+        outs_ref, grads_ref = run()
+    finally:
+        bb.frozen_bn_act = orig
+    for a, b in zip(outs, outs_ref):
+        assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
+    assert grads.keys() == grads_ref.keys() and len(grads) > 100
+    for n in grads:
+        d = (grads[n] - grads_ref[n]).abs().max().item()
+        assert d <= 2e-4 * (grads_ref[n].abs().max().item() + 1e-12), (n, d)
