@@ -4,6 +4,8 @@ TEST INFRASTRUCTURE ONLY.  Compiles, unmodified,
 
     /root/reference/mmdetection/mmdet/ops/nms/src/nms_cpu.cpp       -> oracle/_ref/ref_nms_cpu*.so
     /root/reference/mmdetection/mmdet/ops/nms/src/soft_nms_cpu.pyx  -> oracle/_ref/soft_nms_cpu*.so
+    /root/reference/deepfashion2_api/PythonAPI/pycocotools/_mask.pyx + common/maskApi.c -> oracle/_ref/_mask*.so
+        (the compiled dependency of the reference's pure-Python COCO / COCOeval, which are then imported in place)
 
 with g++ / cython + gcc directly (not the reference's setup.py).  Nothing is copied into the
 repository: outputs (objects, generated C, .so) go to oracle/_ref/ only, which is git-ignored.
@@ -66,6 +68,52 @@ def build_soft_nms():
     return so
 
 
+REF_API = '/root/reference/deepfashion2_api'
+
+
+def build_mask_api():
+    """pycocotools' only compiled part (_mask.pyx + common/maskApi.c), built where the sources lie."""
+    import numpy as np
+    os.makedirs(OUT, exist_ok=True)
+    ext = sysconfig.get_config_var('EXT_SUFFIX')
+    so = os.path.join(OUT, '_mask' + ext)
+    pyx = os.path.join(REF_API, 'PythonAPI', 'pycocotools', '_mask.pyx')
+    if os.path.exists(so) and os.path.getmtime(so) >= os.path.getmtime(pyx):
+        return so
+    c_file = os.path.join(OUT, '_mask.c')
+    subprocess.check_call([sys.executable, '-m', 'cython', '-3', '-I', os.path.join(REF_API, 'common'), pyx,
+                           '-o', c_file])
+    subprocess.check_call(['gcc', '-O2', '-fPIC', '-shared', '-w', '-std=c99',
+                           '-I' + sysconfig.get_paths()['include'], '-I' + np.get_include(),
+                           '-I' + os.path.join(REF_API, 'common'),
+                           c_file, os.path.join(REF_API, 'common', 'maskApi.c'), '-o', so])
+    return so
+
+
+def load_reference_evaluator():
+    """(COCO, COCOeval) classes of the reference's DeepFashion2 evaluator, imported from where they lie
+    (deepfashion2_api/PythonAPI/pycocotools/{coco,cocoeval}.py are pure Python; their compiled `_mask` dependency
+    comes from oracle/_ref).  None when the reference checkout is absent."""
+    if not os.path.isfile(os.path.join(REF_API, 'PythonAPI', 'pycocotools', 'cocoeval.py')):
+        return None
+    import importlib.util
+    import types
+    import numpy as np
+    if not hasattr(np, 'float'):
+        np.float = float          # cocoeval.py:416 uses the alias numpy 1.24 removed
+    pkg_dir = os.path.join(REF_API, 'PythonAPI', 'pycocotools')
+    pkg = types.ModuleType('pycocotools')
+    pkg.__path__ = [pkg_dir]
+    sys.modules.setdefault('pycocotools', pkg)
+    spec = importlib.util.spec_from_file_location('pycocotools._mask', build_mask_api())
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    sys.modules['pycocotools._mask'] = m
+    from pycocotools.coco import COCO
+    from pycocotools.cocoeval import COCOeval
+    return COCO, COCOeval
+
+
 def load():
     """Returns (nms_cpu_module, soft_nms_cpu_function) built from the reference, or None."""
     ext = sysconfig.get_config_var('EXT_SUFFIX')
@@ -91,3 +139,4 @@ if __name__ == '__main__':
     else:
         print(build_nms_cpu())
         print(build_soft_nms())
+        print(build_mask_api())
