@@ -1,0 +1,189 @@
+"""Training runtime of the KGDet configs without mmcv  (SURVEY 8f row 3).
+
+What the reference gets from ``mmcv==0.2.13``'s ``Runner`` + hooks (third-party, not in the reference tree; pinned by
+``requirements.txt:7``) and ``mmdet/apis/train.py``, restated as one small loop:
+
+* ``parse_losses`` / ``batch_processor`` / ``build_optimizer``  -- ``mmdet/apis/train.py:17-134``.
+* ``LrSchedule`` -- mmcv's ``LrUpdaterHook`` for ``lr_config = dict(policy='step', warmup='linear', warmup_iters=500,
+  warmup_ratio=1/3, step=[8, 11])`` (``configs/kgdet_moment_r50_fpn_1x-demo.py:134-139``): the regular rate is
+  ``base_lr * gamma ** (#steps already passed)`` set at the start of every epoch; during the first ``warmup_iters``
+  iterations it is scaled by ``1 - (1 - it / warmup_iters) * (1 - warmup_ratio)`` ('linear'), ``warmup_ratio``
+  ('constant') or ``warmup_ratio ** (1 - it / warmup_iters)`` ('exp'); at ``it == warmup_iters`` it returns to the
+  regular rate.
+* ``Runner`` -- epoch loop, ``DistOptimizerHook`` (all-reduce + grad-clip 35 + step), checkpoint every ``interval``
+  epochs as ``epoch_{n}.pth`` + ``latest.pth`` with ``meta = {epoch, iter}`` and the optimizer state, ``resume``.
+"""
+import os
+import shutil
+import time
+from collections import OrderedDict
+
+import torch
+
+from .checkpoint import load_checkpoint, save_checkpoint
+from .dist import DistOptimizerHook
+
+
+def parse_losses(losses):
+    log_vars = OrderedDict()
+    for name, value in losses.items():
+        if isinstance(value, torch.Tensor):
+            log_vars[name] = value.mean()
+        elif isinstance(value, list):
+            log_vars[name] = sum(v.mean() for v in value)
+        else:
+            raise TypeError('{} is not a tensor or list of tensors'.format(name))
+    loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+    log_vars['loss'] = loss
+    return loss, log_vars
+
+
+def batch_processor(model, data, train_mode=True):
+    losses = model(**data)
+    loss, log_vars = parse_losses(losses)
+    return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img']))
+
+
+def build_optimizer(model, optimizer_cfg):
+    import re
+    model = model.module if hasattr(model, 'module') else model
+    cfg = dict(optimizer_cfg)
+    paramwise = cfg.pop('paramwise_options', None)
+    cls = getattr(torch.optim, cfg.pop('type'))
+    if paramwise is None:
+        return cls(model.parameters(), **cfg)
+    base_lr, base_wd = cfg['lr'], cfg.get('weight_decay', None)
+    if 'bias_decay_mult' in paramwise or 'norm_decay_mult' in paramwise:
+        assert base_wd is not None
+    groups = []
+    for name, param in model.named_parameters():
+        group = {'params': [param]}
+        if param.requires_grad:
+            if re.search(r'(bn|gn)(\d+)?.(weight|bias)', name):
+                if base_wd is not None:
+                    group['weight_decay'] = base_wd * paramwise.get('norm_decay_mult', 1.)
+            elif name.endswith('.bias'):
+                group['lr'] = base_lr * paramwise.get('bias_lr_mult', 1.)
+                if base_wd is not None:
+                    group['weight_decay'] = base_wd * paramwise.get('bias_decay_mult', 1.)
+        groups.append(group)
+    return cls(groups, **cfg)
+
+
+class LrSchedule(object):
+    def __init__(self, policy='step', step=(), gamma=0.1, by_epoch=True, warmup=None, warmup_iters=0,
+                 warmup_ratio=0.1, **unused):
+        if policy != 'step':
+            raise NotImplementedError('lr policy {!r} (the KGDet configs use "step")'.format(policy))
+        if warmup is not None:
+            if warmup not in ('constant', 'linear', 'exp'):
+                raise ValueError('"{}" is not a supported type for warming up'.format(warmup))
+            assert warmup_iters > 0 and 0 < warmup_ratio <= 1.0
+        self.step = step if isinstance(step, int) else list(step)
+        assert (self.step > 0) if isinstance(self.step, int) else all(s > 0 for s in self.step)
+        self.gamma, self.by_epoch = gamma, by_epoch
+        self.warmup, self.warmup_iters, self.warmup_ratio = warmup, warmup_iters, warmup_ratio
+        self.base_lr, self.regular_lr = [], []
+
+    def before_run(self, optimizer):
+        for g in optimizer.param_groups:
+            g.setdefault('initial_lr', g['lr'])
+        self.base_lr = [g['initial_lr'] for g in optimizer.param_groups]
+
+    def regular(self, progress):
+        if isinstance(self.step, int):
+            return [lr * self.gamma ** (progress // self.step) for lr in self.base_lr]
+        passed = len(self.step)
+        for i, s in enumerate(self.step):
+            if progress < s:
+                passed = i
+                break
+        return [lr * self.gamma ** passed for lr in self.base_lr]
+
+    def warm(self, cur_iter):
+        if self.warmup == 'constant':
+            k = self.warmup_ratio
+        elif self.warmup == 'linear':
+            k = 1 - (1 - cur_iter / self.warmup_iters) * (1 - self.warmup_ratio)
+        else:
+            k = self.warmup_ratio ** (1 - cur_iter / self.warmup_iters)
+        return [lr * k for lr in self.regular_lr]
+
+    @staticmethod
+    def _set(optimizer, lrs):
+        for g, lr in zip(optimizer.param_groups, lrs):
+            g['lr'] = lr
+
+    def before_train_epoch(self, optimizer, epoch):
+        if self.by_epoch:
+            self.regular_lr = self.regular(epoch)
+            self._set(optimizer, self.regular_lr)
+
+    def before_train_iter(self, optimizer, cur_iter):
+        if not self.by_epoch:
+            self.regular_lr = self.regular(cur_iter)
+            if self.warmup is None or cur_iter >= self.warmup_iters:
+                self._set(optimizer, self.regular_lr)
+            else:
+                self._set(optimizer, self.warm(cur_iter))
+        elif self.warmup is not None and cur_iter <= self.warmup_iters:
+            self._set(optimizer, self.regular_lr if cur_iter == self.warmup_iters else self.warm(cur_iter))
+
+
+class Runner(object):
+    def __init__(self, model, optimizer, work_dir=None, lr_config=None, optimizer_config=None, checkpoint_config=None,
+                 log_interval=50, logger=print, batch_processor=batch_processor):
+        self.model, self.optimizer, self.work_dir = model, optimizer, work_dir
+        self.lr = LrSchedule(**(lr_config or dict(policy='step', step=[])))
+        self.opt_hook = DistOptimizerHook(**(optimizer_config or {}))
+        self.ckpt_interval = (checkpoint_config or {}).get('interval', 1)
+        self.log_interval, self.logger, self.batch_processor = log_interval, logger, batch_processor
+        self.epoch, self.iter = 0, 0
+        self.log_history = []
+
+    def current_lr(self):
+        return [g['lr'] for g in self.optimizer.param_groups]
+
+    def save_checkpoint(self, filename_tmpl='epoch_{}.pth', create_latest=True):
+        path = os.path.join(self.work_dir, filename_tmpl.format(self.epoch))
+        save_checkpoint(self.model, path, optimizer=self.optimizer, meta=dict(epoch=self.epoch, iter=self.iter))
+        if create_latest:
+            shutil.copyfile(path, os.path.join(self.work_dir, 'latest.pth'))
+        return path
+
+    def resume(self, checkpoint, resume_optimizer=True, map_location='cpu'):
+        ckpt = load_checkpoint(self.model, checkpoint, map_location=map_location)
+        self.epoch, self.iter = ckpt['meta']['epoch'], ckpt['meta']['iter']
+        if 'optimizer' in ckpt and resume_optimizer:
+            self.optimizer.load_state_dict(ckpt['optimizer'])
+        self.logger('resumed epoch %d, iter %d' % (self.epoch, self.iter))
+        return ckpt
+
+    def train_epoch(self, data_loader, to_device=None):
+        self.model.train()
+        self.lr.before_train_epoch(self.optimizer, self.epoch)
+        t0 = time.time()
+        for i, data in enumerate(data_loader):
+            self.lr.before_train_iter(self.optimizer, self.iter)
+            if to_device is not None:
+                data = to_device(data)
+            out = self.batch_processor(self.model, data, train_mode=True)
+            self.opt_hook.step(self.model, self.optimizer, out['loss'])
+            self.iter += 1
+            if self.log_interval and (i + 1) % self.log_interval == 0:
+                rec = OrderedDict(epoch=self.epoch + 1, iter=i + 1, lr=self.current_lr()[0],
+                                  time=(time.time() - t0) / (i + 1))
+                rec.update((k, float(v.detach()) if isinstance(v, torch.Tensor) else float(v)) for k, v in out['log_vars'].items())     # the only device->host read
+                self.log_history.append(rec)
+                self.logger(', '.join('%s: %.5g' % kv if isinstance(kv[1], float) else '%s: %s' % kv for kv in rec.items()))
+        self.epoch += 1
+
+    def run(self, data_loader, max_epochs, to_device=None, set_epoch=None):
+        self.lr.before_run(self.optimizer)
+        while self.epoch < max_epochs:
+            if set_epoch is not None:
+                set_epoch(self.epoch)
+            self.train_epoch(data_loader, to_device)
+            if self.work_dir is not None and self.ckpt_interval > 0 and self.epoch % self.ckpt_interval == 0:
+                self.save_checkpoint()
+        return self
