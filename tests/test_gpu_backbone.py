@@ -112,3 +112,69 @@ def test_training_backbone_uses_fused_op_and_matches_module_path():
     for n in grads:
         d = (grads[n] - grads_ref[n]).abs().max().item()
         assert d <= 2e-4 * (grads_ref[n].abs().max().item() + 1e-12), (n, d)
+
+
+@pytest.mark.parametrize('modulated', [False, True])
+@pytest.mark.parametrize('stride', [1, 2])
+def test_bottleneck_dcn_option_matches_torch_reference(modulated, stride):
+    """SURVEY 8f row 4 (resnet.py:162-186, 231-238): conv2 replaced by conv2_offset + DeformConv /
+    ModulatedDeformConv.  Forward and all gradients against the grid_sample formulation (tests/torch_ref.py)."""
+    from kgdet_amd import backbone as bb
+    from tests import torch_ref
+    torch.manual_seed(3)
+    down = torch.nn.Sequential(torch.nn.Conv2d(64, 128, 1, stride=stride, bias=False), torch.nn.BatchNorm2d(128))
+    blk = bb.Bottleneck(64, 32, stride=stride, downsample=down,
+                        dcn=dict(modulated=modulated, deformable_groups=1, fallback_on_stride=False)).cuda()
+    assert type(blk.conv2).__name__ == ('ModulatedDeformConv' if modulated else 'DeformConv')
+    assert blk.conv2_offset.out_channels == (27 if modulated else 18)
+    for m in blk.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    blk.eval()            # norm_eval
+    blk.conv2_offset.weight.data.normal_(0, 0.05)
+    x0 = torch.randn(2, 64, 20, 28, device='cuda')
+
+    def reference(x):
+        out = blk.relu(blk.norm1(blk.conv1(x)))
+        om = blk.conv2_offset(out)
+        if modulated:
+            off, mask = om[:, :18], om[:, -9:].sigmoid()
+        else:
+            off, mask = om, None
+        out = torch_ref.deform_conv(out, off, blk.conv2.weight, stride=stride, padding=1, dilation=1, mask=mask)
+        if modulated and blk.conv2.bias is not None:
+            out = out + blk.conv2.bias.view(1, -1, 1, 1)
+        out = blk.relu(blk.norm2(out))
+        out = blk.norm3(blk.conv3(out))
+        return blk.relu(out + blk.downsample(x))
+
+    def run(fn):
+        blk.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        y = fn(x)
+        y.square().mean().backward()
+        return y.detach(), x.grad, {n: p.grad.clone() for n, p in blk.named_parameters() if p.grad is not None}
+
+    y, gx, gp = run(blk)
+    yr, gxr, gpr = run(reference)
+    assert y.shape == (2, 128, 20 // stride, 28 // stride)
+    assert (y - yr).abs().max().item() <= 1e-4 * yr.abs().max().item()
+    assert (gx - gxr).abs().max().item() <= 1e-3 * gxr.abs().max().item()
+    assert gp.keys() == gpr.keys() and 'conv2_offset.weight' in gp
+    for n in gp:
+        assert (gp[n] - gpr[n]).abs().max().item() <= 1e-3 * (gpr[n].abs().max().item() + 1e-12), n
+
+
+def test_resnet_with_dcn_stages_builds_and_steps():
+    from kgdet_amd import backbone as bb
+    torch.manual_seed(0)
+    net = bb.ResNet(depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1, style='pytorch',
+                    dcn=dict(modulated=False, deformable_groups=1, fallback_on_stride=False),
+                    stage_with_dcn=(False, True, True, True)).cuda()
+    net.train()
+    outs = net(torch.randn(1, 3, 128, 160, device='cuda'))
+    assert [o.shape[1] for o in outs] == [256, 512, 1024, 2048]
+    sum(o.mean() for o in outs).backward()
+    assert net.layer3[0].conv2.weight.grad.abs().sum() > 0 and net.layer3[0].conv2_offset.weight.grad is not None
+    assert not hasattr(net.layer1[0], 'conv2_offset')
