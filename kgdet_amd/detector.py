@@ -69,9 +69,9 @@ class RepPointsDetectorKp(nn.Module):
         """per-class numpy lists: (bboxes_in_cls, bbox_scores, kpt_in_cls), or a 1-tuple when empty"""
         if bboxes.shape[0] == 0:
             return ([np.zeros((0, 5), dtype=np.float32) for i in range(num_classes - 1)], )
-        bboxes = bboxes.cpu().numpy()
+        bboxes = bboxes.float().cpu().numpy()
         labels = labels.cpu().numpy()
-        kpts = kpts.cpu().numpy()
+        kpts = kpts.float().cpu().numpy()
         return ([bboxes[labels == i, :] for i in range(num_classes - 1)], bboxes[:, 4],
                 [kpts[labels == i, :] for i in range(num_classes - 1)])
 

@@ -472,7 +472,10 @@ class RepPointsHeadKp3RepCas1AssignOnce(PointHeadMixin, nn.Module):
     def get_bboxes(self, cls_scores_1, cls_scores_2, cls_scores_3, keypts_preds_1, keypts_preds_2, keypts_preds_3,
                    bbox_preds_1, bbox_preds_2, bbox_preds_3, img_metas, cfg, rescale=False, nms=True):
         """detections from the final stage.  With hard NMS the whole batch is suppressed in one launch."""
-        cls_score_final, bbox_preds, keypts_preds_final = cls_scores_3, bbox_preds_3, keypts_preds_3
+        # decode in fp32 whatever the convolutions ran in: bf16 cannot hold a pixel coordinate (8-bit mantissa)
+        cls_score_final = [t.float() for t in cls_scores_3]
+        bbox_preds = [t.float() for t in bbox_preds_3]
+        keypts_preds_final = [t.float() for t in keypts_preds_3]
         assert len(cls_score_final) == len(keypts_preds_final) == len(bbox_preds)
         kpt_preds = [self.points2kpt(keypts_pred) for keypts_pred in keypts_preds_final]
         num_levels = len(cls_score_final)

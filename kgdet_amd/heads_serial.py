@@ -272,8 +272,9 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
     def get_bboxes(self, cls_scores, keypts_preds_init, keypts_preds_refine, reppts_preds_init, reppts_preds_refine,
                    img_metas, cfg, rescale=False, nms=True):
         assert len(cls_scores) == len(keypts_preds_refine) == len(reppts_preds_refine)
-        bbox_preds_refine = [self.points2bbox(r) for r in reppts_preds_refine]
-        kpt_preds_refine = [self.points2kpt(k) for k in keypts_preds_refine]
+        cls_scores = [t.float() for t in cls_scores]             # decode in fp32 under autocast
+        bbox_preds_refine = [self.points2bbox(r.float()) for r in reppts_preds_refine]
+        kpt_preds_refine = [self.points2kpt(k.float()) for k in keypts_preds_refine]
         num_levels = len(cls_scores)
         device = cls_scores[0].device
         mlvl_points = [self.point_generators[i].grid_points(cls_scores[i].size()[-2:], self.point_strides[i],

@@ -271,3 +271,32 @@ def test_inference_backbone_fold_matches_module_path_on_gpu():
         assert a.shape == b.shape
         # both bf16 paths sit within bf16 noise of the fp32 result; neither is the reference for the other
         assert (a - c).abs().max().item() <= 2.0 * max((b - c).abs().max().item(), 1e-2 * c.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_bf16_autocast_inference_with_detections_matches_fp32():
+    """Under bf16 autocast the decode runs in fp32 and the results convert to numpy; detections agree with the fp32
+    run up to what bf16 convolutions do to the scores (same boxes for the confident ones)."""
+    from kgdet_amd import build_detector, configs, synthetic
+    cfg = configs.kgdet_r50_fpn()
+    torch.manual_seed(0)
+    model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().eval()
+    with torch.no_grad():
+        model.bbox_head.kp_rep_block_3.cls_out.bias += 2.2        # lift the 0.01 prior above score_thr for some points
+    batch = synthetic.make_batch(2, torch.device('cuda'), seed=0)
+    with torch.no_grad():
+        ref = model.simple_test_batch(batch['img'], batch['img_meta'], rescale=True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            got = model.simple_test_batch(batch['img'], batch['img_meta'], rescale=True)
+    assert len(ref) == len(got) == 2
+    n_ref = sum(len(d) for d in ref[0][0])
+    assert n_ref > 0 and len(ref[0]) == 3 and len(got[0]) == 3
+    for r, g in zip(ref, got):
+        assert all(d.dtype == np.float32 for d in g[0]) and all(k.dtype == np.float32 for k in g[2])
+        nr, ng = sum(len(d) for d in r[0]), sum(len(d) for d in g[0])
+        assert abs(nr - ng) <= max(3, 0.2 * nr)
+        for c in range(13):                                       # per class: the top detection sits at the same place
+            if len(r[0][c]) and len(g[0][c]):
+                a, b = r[0][c][np.argmax(r[0][c][:, 4])], g[0][c][np.argmax(g[0][c][:, 4])]
+                if a[4] > 0.2 and abs(a[4] - b[4]) < 0.02:
+                    assert np.abs(a[:4] - b[:4]).max() < 0.05 * max(a[2] - a[0], a[3] - a[1]) + 4
