@@ -235,6 +235,18 @@ int kgdet_sigmoid_focal_loss_backward(const float *logits, const int64_t *target
  * 2 gaussian; out_dets [n,5], out_inds [n] int64, *num_out device int64.
  * ------------------------------------------------------------------------------------------ */
 size_t kgdet_nms_workspace_bytes(int64_t total_n, int32_t num_segments);
+/* multiclass_nms_kp for a whole batch (mmdet/core/post_processing/bbox_nms_kp.py:6-75 with type='nms'), two launches,
+ * nothing read by the host: per (image, class) the candidates with score > score_thr are suppressed as kgdet_nms does;
+ * per image the classes' survivors are concatenated (class order, ascending candidate row) and, beyond max_num, the
+ * max_num highest scores are kept (ties: earlier first).  boxes [B, N, 4]; scores [B, N, score_stride] with class c in
+ * column score_col0 + c (C <= 64, N <= 4096, N*C <= 16384); out_det [B, max_num, 5]; out_label (0-based class) and
+ * out_src (candidate row, for gathering the landmarks) [B, max_num] int64; out_count [B] int64; rows past the count
+ * are zero.  workspace: kgdet_multiclass_nms_workspace_bytes(B, N, C). */
+size_t kgdet_multiclass_nms_workspace_bytes(int32_t B, int32_t N, int32_t C);
+int kgdet_multiclass_nms(const float *boxes, const float *scores, int32_t B, int32_t N, int32_t C,
+                         int32_t score_stride, int32_t score_col0, float score_thr, float iou_thr, int32_t max_num,
+                         float *out_det, int64_t *out_label, int64_t *out_src, int64_t *out_count, void *workspace,
+                         size_t workspace_bytes, void *stream);
 int kgdet_nms(const float *dets, int64_t n, float iou_thr, int64_t *keep, int64_t *num_keep,
               void *workspace, size_t workspace_bytes, void *stream);
 int kgdet_nms_batched(const float *dets, const int64_t *seg_offsets, int32_t num_segments,

@@ -69,33 +69,53 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *lds_wave_sums, i
 }  // namespace
 
 // dynamic LDS layout: keys[NP] u64 | x1,y1,x2,y2,area [n each] | alive[n] u8 (then reused as flags)
-__global__ __launch_bounds__(kNmsThreads) void nms_segments(const float *__restrict__ dets,
-                                                            const long long *__restrict__ seg_offsets,
-                                                            float thr, long long *__restrict__ keep,
-                                                            long long *__restrict__ num_keep, int max_np) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ int wave_sums[kNmsThreads / 64];
-  __shared__ unsigned long long chunk_alive;
+// One problem: n boxes at box[i * box_stride + 0..3], scores at score[i * score_stride]; with `filter` only the
+// boxes whose score is > score_thr take part (the per-class candidate filter of multiclass_nms_kp,
+// bbox_nms_kp.py:28-33, done in place instead of by compaction); kept ORIGINAL indices, ascending, go to out[].
+struct NmsProblem {
+  const float *box;
+  int box_stride;
+  const float *score;
+  int score_stride;
+  bool filter;
+  float score_thr;
+  int n;
+  long long *out;
+  long long *num_out;
+};
 
-  const int seg = blockIdx.x, tid = threadIdx.x;
-  const long long seg_begin = seg_offsets[seg];
-  const int n = (int)(seg_offsets[seg + 1] - seg_begin);
-  if (n <= 0) {
-    if (tid == 0) num_keep[seg] = 0;
+__device__ __forceinline__ void nms_block(const NmsProblem pr, float thr, int max_np, unsigned char *smem,
+                                          int *wave_sums, unsigned long long *chunk_alive_p) {
+  const int tid = threadIdx.x;
+  const int n_all = pr.n;
+  if (n_all <= 0) {
+    if (tid == 0) *pr.num_out = 0;
     return;
   }
   int NP = 64;
-  while (NP < n) NP <<= 1;
-  const float *d = dets + seg_begin * 5;
+  while (NP < n_all) NP <<= 1;
+  unsigned long long &chunk_alive = *chunk_alive_p;
 
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);
   float *bx1 = reinterpret_cast<float *>(smem + (size_t)max_np * 8);
   float *by1 = bx1 + max_np, *bx2 = by1 + max_np, *by2 = bx2 + max_np, *bar = by2 + max_np;
   unsigned char *alive = reinterpret_cast<unsigned char *>(bar + max_np);
 
-  for (int i = tid; i < NP; i += kNmsThreads)
-    keys[i] = i < n ? score_key(d[5 * i + 4], (unsigned)i) : ~0ull;
-  __syncthreads();
+  int mine = 0;
+  for (int i = tid; i < NP; i += kNmsThreads) {
+    unsigned long long k = ~0ull;
+    if (i < n_all) {
+      const float s = pr.score[(long long)i * pr.score_stride];
+      if (!pr.filter || s > pr.score_thr) { k = score_key(s, (unsigned)i); ++mine; }
+    }
+    keys[i] = k;
+  }
+  int n;   // boxes taking part = the first n sorted keys
+  block_exclusive_scan(mine, wave_sums, n);
+  if (n == 0) {
+    if (tid == 0) *pr.num_out = 0;
+    return;
+  }
   // bitonic sort, ascending keys
   for (int k = 2; k <= NP; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
@@ -111,7 +131,8 @@ __global__ __launch_bounds__(kNmsThreads) void nms_segments(const float *__restr
     }
   for (int i = tid; i < n; i += kNmsThreads) {
     const unsigned src = (unsigned)(keys[i] & 0xffffffffu);
-    const float x1 = d[5 * src], y1 = d[5 * src + 1], x2 = d[5 * src + 2], y2 = d[5 * src + 3];
+    const float *bp = pr.box + (long long)src * pr.box_stride;
+    const float x1 = bp[0], y1 = bp[1], x2 = bp[2], y2 = bp[3];
     bx1[i] = x1; by1[i] = y1; bx2[i] = x2; by2[i] = y2;
     bar[i] = (x2 - x1 + 1) * (y2 - y1 + 1);
     alive[i] = 1;
@@ -165,23 +186,155 @@ __global__ __launch_bounds__(kNmsThreads) void nms_segments(const float *__restr
   unsigned char keep_sorted_local[kNmsMaxLen / kNmsThreads];
   for (int i = tid, m = 0; i < n; i += kNmsThreads, ++m) keep_sorted_local[m] = alive[i];
   __syncthreads();
-  for (int i = tid; i < n; i += kNmsThreads) flag[i] = 0;
+  for (int i = tid; i < n_all; i += kNmsThreads) flag[i] = 0;
   __syncthreads();
   for (int i = tid, m = 0; i < n; i += kNmsThreads, ++m)
     if (keep_sorted_local[m]) flag[(unsigned)(keys[i] & 0xffffffffu)] = 1;
   __syncthreads();
   // each thread owns a contiguous run of original indices so the scan preserves ascending order
-  const int per = (n + kNmsThreads - 1) / kNmsThreads;
-  const int lo = tid * per, hi = min(n, lo + per);
+  const int per = (n_all + kNmsThreads - 1) / kNmsThreads;
+  const int lo = tid * per, hi = min(n_all, lo + per);
   int cnt = 0;
   for (int i = lo; i < hi; ++i) cnt += flag[i];
   int total;
   int pos = block_exclusive_scan(cnt, wave_sums, total);
-  long long *out = keep + seg_begin;
   for (int i = lo; i < hi; ++i)
-    if (flag[i]) out[pos++] = i;
-  if (tid == 0) num_keep[seg] = total;
+    if (flag[i]) pr.out[pos++] = i;
+  if (tid == 0) *pr.num_out = total;
 }
+
+// dets [T, 5]; segment s = rows [seg_offsets[s], seg_offsets[s + 1])
+__global__ __launch_bounds__(kNmsThreads) void nms_segments(const float *__restrict__ dets,
+                                                            const long long *__restrict__ seg_offsets,
+                                                            float thr, long long *__restrict__ keep,
+                                                            long long *__restrict__ num_keep, int max_np) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int wave_sums[kNmsThreads / 64];
+  __shared__ unsigned long long chunk_alive;
+  const int seg = blockIdx.x;
+  const long long seg_begin = seg_offsets[seg];
+  NmsProblem pr;
+  pr.box = dets + seg_begin * 5;
+  pr.box_stride = 5;
+  pr.score = pr.box + 4;
+  pr.score_stride = 5;
+  pr.filter = false;
+  pr.score_thr = 0.f;
+  pr.n = (int)(seg_offsets[seg + 1] - seg_begin);
+  pr.out = keep + seg_begin;
+  pr.num_out = num_keep + seg;
+  nms_block(pr, thr, max_np, smem, wave_sums, &chunk_alive);
+}
+
+// The per-class loop of multiclass_nms_kp (mmdet/core/post_processing/bbox_nms_kp.py:25-50) for a whole batch in
+// one launch: workgroup (b, c) filters class c's candidates of image b (score > score_thr) and suppresses them.
+// boxes [B, N, 4]; scores [B, N, S] with class c in column col0 + c; keep [B, C, N]; num_keep [B, C].
+__global__ __launch_bounds__(kNmsThreads) void multiclass_nms_segments(const float *__restrict__ boxes,
+                                                                       const float *__restrict__ scores, int N, int C,
+                                                                       int S, int col0, float score_thr, float thr,
+                                                                       long long *__restrict__ keep,
+                                                                       long long *__restrict__ num_keep, int max_np) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int wave_sums[kNmsThreads / 64];
+  __shared__ unsigned long long chunk_alive;
+  const int seg = blockIdx.x, b = seg / C, c = seg - b * C;
+  NmsProblem pr;
+  pr.box = boxes + (long long)b * N * 4;
+  pr.box_stride = 4;
+  pr.score = scores + (long long)b * N * S + col0 + c;
+  pr.score_stride = S;
+  pr.filter = true;
+  pr.score_thr = score_thr;
+  pr.n = N;
+  pr.out = keep + (long long)seg * N;
+  pr.num_out = num_keep + seg;
+  nms_block(pr, thr, max_np, smem, wave_sums, &chunk_alive);
+}
+
+// The tail of multiclass_nms_kp (bbox_nms_kp.py:52-70) per image: concatenate the classes' survivors (class order,
+// ascending candidate index inside a class); more than max_num -> the max_num best by score (ties: earlier in the
+// concatenation first).  One workgroup per image; keys sorted in LDS.
+// out_det [B, max_num, 5]; out_label [B, max_num] (0-based class); out_src [B, max_num] (row n of the image's
+// candidate arrays, for gathering landmarks); out_count [B].  Rows past the count are zero.
+__global__ __launch_bounds__(kNmsThreads) void multiclass_select(const float *__restrict__ boxes,
+                                                                 const float *__restrict__ scores, int N, int C, int S,
+                                                                 int col0, const long long *__restrict__ keep,
+                                                                 const long long *__restrict__ num_keep, int max_num,
+                                                                 float *__restrict__ out_det,
+                                                                 long long *__restrict__ out_label,
+                                                                 long long *__restrict__ out_src,
+                                                                 long long *__restrict__ out_count, int max_np) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int prefix[65];
+  unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) {
+    int run = 0;
+    for (int c = 0; c < C; ++c) {
+      prefix[c] = run;
+      run += (int)num_keep[b * C + c];
+    }
+    prefix[C] = run;
+  }
+  __syncthreads();
+  const int T = prefix[C];
+  const int out_n = min(T, max_num);
+  auto entry = [&](int p, int &c, int &n) {   // position in the concatenation -> (class, candidate row)
+    int lo = 0, hi = C - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (prefix[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    c = lo;
+    n = (int)keep[((long long)b * C + c) * N + (p - prefix[c])];
+  };
+  const float *sc = scores + (long long)b * N * S + col0;
+  if (T > max_num) {
+    int NP = 64;
+    while (NP < T) NP <<= 1;
+    for (int p = tid; p < NP; p += kNmsThreads) {
+      unsigned long long k = ~0ull;
+      if (p < T) {
+        int c, n;
+        entry(p, c, n);
+        k = score_key(sc[(long long)n * S + c], (unsigned)p);
+      }
+      keys[p] = k;
+    }
+    __syncthreads();
+    for (int k = 2; k <= NP; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < NP; i += kNmsThreads) {
+          const int l = i ^ j;
+          if (l > i) {
+            const unsigned long long a = keys[i], bb = keys[l];
+            const bool up = (i & k) == 0;
+            if ((a > bb) == up) { keys[i] = bb; keys[l] = a; }
+          }
+        }
+        __syncthreads();
+      }
+  }
+  for (int r = tid; r < max_num; r += kNmsThreads) {
+    float *od = out_det + ((long long)b * max_num + r) * 5;
+    if (r < out_n) {
+      const int p = T > max_num ? (int)(keys[r] & 0xffffffffu) : r;
+      int c, n;
+      entry(p, c, n);
+      const float *bp = boxes + ((long long)b * N + n) * 4;
+      od[0] = bp[0]; od[1] = bp[1]; od[2] = bp[2]; od[3] = bp[3];
+      od[4] = sc[(long long)n * S + c];
+      out_label[(long long)b * max_num + r] = c;
+      out_src[(long long)b * max_num + r] = n;
+    } else {
+      od[0] = od[1] = od[2] = od[3] = od[4] = 0.f;
+      out_label[(long long)b * max_num + r] = 0;
+      out_src[(long long)b * max_num + r] = 0;
+    }
+  }
+  if (tid == 0) out_count[b] = out_n;
+}
+
 
 // ----------------------------------------------------------------------------------------------
 // soft-NMS: one workgroup, boxes in LDS, the reference's selection-sort loop with every inner
@@ -362,6 +515,56 @@ int kgdet_nms_batched(const float *dets, const int64_t *seg_offsets, int32_t num
                       size_t workspace_bytes, void *stream) {
   (void)total_n; (void)workspace; (void)workspace_bytes;
   return nms_launch(dets, seg_offsets, num_segments, max_seg_len, iou_thr, keep, num_keep, stream);
+}
+
+size_t kgdet_multiclass_nms_workspace_bytes(int32_t B, int32_t N, int32_t C) {
+  return ((size_t)B * C * N + (size_t)B * C) * sizeof(int64_t);
+}
+
+int kgdet_multiclass_nms(const float *boxes, const float *scores, int32_t B, int32_t N, int32_t C,
+                         int32_t score_stride, int32_t score_col0, float score_thr, float iou_thr, int32_t max_num,
+                         float *out_det, int64_t *out_label, int64_t *out_src, int64_t *out_count, void *workspace,
+                         size_t workspace_bytes, void *stream) {
+  KGDET_CHECK_SHAPE(B >= 0 && N >= 0 && C > 0 && C <= 64 && max_num > 0, "bad sizes (1 <= C <= 64)");
+  KGDET_CHECK_SHAPE(score_col0 >= 0 && score_col0 + C <= score_stride, "score columns outside the row");
+  if (B == 0) return KGDET_OK;
+  KGDET_CHECK_SHAPE(out_det && out_label && out_src && out_count, "null pointer");
+  if (N == 0) {
+    KGDET_HIP_TRY(hipMemsetAsync(out_det, 0, (size_t)B * max_num * 5 * 4, (hipStream_t)stream));
+    KGDET_HIP_TRY(hipMemsetAsync(out_label, 0, (size_t)B * max_num * 8, (hipStream_t)stream));
+    KGDET_HIP_TRY(hipMemsetAsync(out_src, 0, (size_t)B * max_num * 8, (hipStream_t)stream));
+    KGDET_HIP_TRY(hipMemsetAsync(out_count, 0, (size_t)B * 8, (hipStream_t)stream));
+    return KGDET_OK;
+  }
+  KGDET_CHECK_SHAPE(boxes && scores, "null pointer");
+  KGDET_CHECK_SHAPE(workspace && workspace_bytes >= kgdet_multiclass_nms_workspace_bytes(B, N, C), "workspace too small");
+  if (N > kNmsMaxLen || (long long)N * C > 16384) {
+    set_error("multiclass_nms: %d candidates x %d classes exceed the on-chip limits (%d per class, 16384 per image)",
+              N, C, kNmsMaxLen);
+    return KGDET_E_UNSUPPORTED;
+  }
+  int64_t *keep = (int64_t *)workspace, *num_keep = keep + (size_t)B * C * N;
+  int np = 64;
+  while (np < N) np <<= 1;
+  int np2 = 64;
+  while (np2 < N * C) np2 <<= 1;
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)multiclass_nms_segments,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)multiclass_select, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      16384 * 8));
+    attr_set = true;
+  }
+  const size_t lds = (size_t)np * 8 + (size_t)np * 5 * 4 + (size_t)np;
+  hipLaunchKernelGGL(multiclass_nms_segments, dim3(B * C), dim3(kNmsThreads), lds, (hipStream_t)stream, boxes, scores,
+                     N, C, score_stride, score_col0, score_thr, iou_thr, (long long *)keep, (long long *)num_keep, np);
+  KGDET_CHECK_LAUNCH("multiclass_nms_segments");
+  hipLaunchKernelGGL(multiclass_select, dim3(B), dim3(kNmsThreads), (size_t)np2 * 8, (hipStream_t)stream, boxes, scores,
+                     N, C, score_stride, score_col0, (const long long *)keep, (const long long *)num_keep, max_num,
+                     out_det, (long long *)out_label, (long long *)out_src, (long long *)out_count, np2);
+  KGDET_CHECK_LAUNCH("multiclass_select");
+  return KGDET_OK;
 }
 
 int kgdet_nms(const float *dets, int64_t n, float iou_thr, int64_t *keep, int64_t *num_keep, void *workspace,

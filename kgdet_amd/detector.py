@@ -69,16 +69,16 @@ class RepPointsDetectorKp(nn.Module):
         """per-class numpy lists: (bboxes_in_cls, bbox_scores, kpt_in_cls), or a 1-tuple when empty"""
         if bboxes.shape[0] == 0:
             return ([np.zeros((0, 5), dtype=np.float32) for i in range(num_classes - 1)], )
-        bboxes = bboxes.float().cpu().numpy()
-        labels = labels.cpu().numpy()
-        kpts = kpts.float().cpu().numpy()
+        if torch.is_tensor(bboxes):
+            bboxes, labels, kpts = bboxes.float().cpu().numpy(), labels.cpu().numpy(), kpts.float().cpu().numpy()
         return ([bboxes[labels == i, :] for i in range(num_classes - 1)], bboxes[:, 4],
                 [kpts[labels == i, :] for i in range(num_classes - 1)])
 
     def simple_test_batch(self, img, img_meta, rescale=False):
         x = self.extract_feat(img)
         outs = self.bbox_head(x, img_meta)
-        bbox_list = self.bbox_head.get_bboxes(*(outs + (img_meta, self.test_cfg, rescale)))
+        get = getattr(self.bbox_head, 'get_bboxes_numpy', self.bbox_head.get_bboxes)   # one D2H copy per batch
+        bbox_list = get(*(outs + (img_meta, self.test_cfg, rescale)))
         return [self.bbox2result_kp(det_bboxes, det_labels, det_kpts, self.bbox_head.num_classes)
                 for det_bboxes, det_labels, det_kpts in bbox_list]
 

@@ -484,6 +484,11 @@ class RepPointsHeadKp3RepCas1AssignOnce(PointHeadMixin, nn.Module):
             self.point_generators[i].grid_points(cls_score_final[i].size()[-2:], self.point_strides[i], device=device)
             for i in range(num_levels)
         ]
+        if nms and self._packed_ok(cls_score_final, img_metas, cfg):
+            det, label, kp, count = self.get_bboxes_packed(cls_score_final, bbox_preds, kpt_preds, mlvl_points,
+                                                           img_metas, cfg, rescale)
+            counts = count.tolist()                      # the only device->host read of the post-processing
+            return [(det[b, :n], label[b, :n], kp[b, :n]) for b, n in enumerate(counts)]
         per_image = []
         for img_id in range(len(img_metas)):
             cls_score_list = [cls_score_final[i][img_id].detach() for i in range(num_levels)]
@@ -505,6 +510,105 @@ class RepPointsHeadKp3RepCas1AssignOnce(PointHeadMixin, nn.Module):
                                          torch.stack([pad(p[1]) for p in per_image]),
                                          torch.stack([pad(p[2]) for p in per_image]), cfg.score_thr, cfg.nms,
                                          cfg.max_per_img)
+
+    def get_bboxes_numpy(self, cls_scores_1, cls_scores_2, cls_scores_3, keypts_preds_1, keypts_preds_2,
+                         keypts_preds_3, bbox_preds_1, bbox_preds_2, bbox_preds_3, img_metas, cfg, rescale=False):
+        """``get_bboxes`` with the results on the host as numpy arrays; on the packed path the whole batch comes
+        back in ONE device->host copy (boxes, labels, count and landmarks side by side)."""
+        cls3, box3 = [t.float() for t in cls_scores_3], [t.float() for t in bbox_preds_3]
+        if not self._packed_ok(cls3, img_metas, cfg):
+            return [(d.float().cpu().numpy(), lab.cpu().numpy(), k.float().cpu().numpy()) for d, lab, k in
+                    self.get_bboxes(cls_scores_1, cls_scores_2, cls_scores_3, keypts_preds_1, keypts_preds_2,
+                                    keypts_preds_3, bbox_preds_1, bbox_preds_2, bbox_preds_3, img_metas, cfg, rescale)]
+        kpt3 = [self.points2kpt(t.float()) for t in keypts_preds_3]
+        points = [self.point_generators[i].grid_points(cls3[i].size()[-2:], self.point_strides[i], device=cls3[i].device)
+                  for i in range(len(cls3))]
+        det, label, kp, count = self.get_bboxes_packed(cls3, box3, kpt3, points, img_metas, cfg, rescale)
+        B, M = label.shape
+        packed = torch.cat([det, label.unsqueeze(-1).float(), count.view(B, 1, 1).expand(B, M, 1).float(), kp],
+                           dim=-1).cpu().numpy()
+        out = []
+        for b in range(B):
+            n = int(packed[b, 0, 6])
+            out.append((packed[b, :n, :5], packed[b, :n, 5].astype(np.int64), packed[b, :n, 7:]))
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    # whole-batch decode + fused NMS: no per-image Python loop, no host read before the results
+    # ------------------------------------------------------------------------------------------
+    def _packed_ok(self, cls_scores, img_metas, cfg):
+        if not (cls_scores[0].is_cuda and cfg.nms.get('type', 'nms') == 'nms' and self.use_sigmoid_cls
+                and cfg.max_per_img > 0):
+            return False
+        if not all(isinstance(m['scale_factor'], (int, float)) for m in img_metas):
+            return False
+        n = sum(min(c.shape[-2] * c.shape[-1], cfg.get('nms_pre', -1)) if cfg.get('nms_pre', -1) > 0
+                else c.shape[-2] * c.shape[-1] for c in cls_scores)
+        return n <= 4096 and n * self.cls_out_channels <= 16384 and self.cls_out_channels <= 64
+
+    @staticmethod
+    def _per_image(values, device):
+        """python numbers, one per image -> a scalar when they agree, else a [B, 1] tensor uploaded without blocking"""
+        if all(v == values[0] for v in values):
+            return values[0]
+        return torch.tensor(values, dtype=torch.float32).pin_memory().to(device, non_blocking=True).unsqueeze(1)
+
+    def _decode_level_batch(self, cls_score, bbox_pred, kpt_pred, points, stride, lim_w, lim_h, cfg):
+        """``_decode_level`` for all images at once: scores [B,n,C], boxes [B,n,4], landmarks [B,n,K,3]"""
+        B, num_kpt = cls_score.shape[0], self.num_keypts
+        ch = kpt_pred.size(1) // num_kpt
+        assert ch == 2 or ch == 3
+        scores = cls_score.permute(0, 2, 3, 1).reshape(B, -1, self.cls_out_channels).sigmoid()
+        bbox_pred = bbox_pred.permute(0, 2, 3, 1).reshape(B, -1, 4)
+        kpt_pred = kpt_pred.permute(0, 2, 3, 1).reshape(B, -1, num_kpt, ch)
+        if ch == 2:
+            kpt_pred = torch.cat([kpt_pred, kpt_pred.new_ones(kpt_pred[..., :1].shape)], dim=-1)
+        ctr = points[:, :2].unsqueeze(0).expand(B, -1, -1)
+        nms_pre = cfg.get('nms_pre', -1)
+        if nms_pre > 0 and scores.shape[1] > nms_pre:
+            _, top = scores.max(dim=2)[0].topk(nms_pre, dim=1)
+            ctr = torch.gather(ctr, 1, top.unsqueeze(-1).expand(B, nms_pre, 2))
+            bbox_pred = torch.gather(bbox_pred, 1, top.unsqueeze(-1).expand(B, nms_pre, 4))
+            kpt_pred = torch.gather(kpt_pred, 1, top.view(B, nms_pre, 1, 1).expand(B, nms_pre, num_kpt, 3))
+            scores = torch.gather(scores, 1, top.unsqueeze(-1).expand(B, nms_pre, scores.shape[2]))
+        bboxes = bbox_pred * stride + torch.cat([ctr, ctr], dim=2)
+        kpts = kpt_pred.clone()
+        kpts[..., :2] = kpts[..., :2] * stride + ctr.unsqueeze(2)
+
+        def clamp(t, lim):      # to [0, img_shape] (not img_shape - 1, KP3:882-888)
+            if isinstance(lim, (int, float)):
+                return t.clamp(min=0, max=lim)
+            return torch.minimum(t.clamp(min=0), lim.view((B, ) + (1, ) * (t.dim() - 1)))
+
+        bboxes = torch.stack([clamp(bboxes[..., 0], lim_w), clamp(bboxes[..., 1], lim_h), clamp(bboxes[..., 2], lim_w),
+                              clamp(bboxes[..., 3], lim_h)], dim=-1)
+        kpts[..., 0] = clamp(kpts[..., 0], lim_w)
+        kpts[..., 1] = clamp(kpts[..., 1], lim_h)
+        return bboxes, scores, kpts
+
+    def get_bboxes_packed(self, cls_scores, bbox_preds, kpt_preds, mlvl_points, img_metas, cfg, rescale=False):
+        """final-stage maps -> fixed-size device tensors (det [B,M,5], labels [B,M], landmarks [B,M,3K], count [B])"""
+        device = cls_scores[0].device
+        lim_w = self._per_image([float(m['img_shape'][1]) for m in img_metas], device)
+        lim_h = self._per_image([float(m['img_shape'][0]) for m in img_metas], device)
+        decoded = [self._decode_level_batch(cls_scores[i].detach().float(), bbox_preds[i].detach().float(),
+                                            kpt_preds[i].detach().float(), mlvl_points[i], self.point_strides[i],
+                                            lim_w, lim_h, cfg) for i in range(len(cls_scores))]
+        bboxes = torch.cat([d[0] for d in decoded], dim=1)
+        scores = torch.cat([d[1] for d in decoded], dim=1)
+        kpts = torch.cat([d[2] for d in decoded], dim=1)
+        if rescale:
+            sf = self._per_image([float(m['scale_factor']) for m in img_metas], device)
+            if isinstance(sf, float):
+                bboxes = bboxes / sf
+                kpts[..., 0:2] = kpts[..., 0:2] / sf
+            else:   # torch divides by a python scalar as x * (1 / s) in fp32: do the same per image
+                inv = torch.reciprocal(sf)
+                bboxes = bboxes * inv.view(-1, 1, 1)
+                kpts[..., 0:2] = kpts[..., 0:2] * inv.view(-1, 1, 1, 1)
+        from .postprocess import multiclass_nms_kp_fused
+        return multiclass_nms_kp_fused(bboxes, scores, kpts.reshape(kpts.shape[0], kpts.shape[1], -1), cfg.score_thr,
+                                       float(cfg.nms['iou_thr']), cfg.max_per_img)
 
 
 HEADS.register_alias('KGDetHead', RepPointsHeadKp3RepCas1AssignOnce)

@@ -104,3 +104,34 @@ def multiclass_nms_kp_batched(bboxes, scores, kpts, score_thr, nms_cfg, max_num=
             d, lab, kp = d[order], lab[order], kp[order]
         out.append((d, lab, kp))
     return out
+
+
+def multiclass_nms_kp_fused(bboxes, scores, kpts, score_thr, iou_thr, max_num):
+    """``multiclass_nms_kp`` (type='nms') for a batch with nothing read by the host: two HIP launches
+    (csrc/nms.hip ``multiclass_nms_segments`` + ``multiclass_select``) and one landmark gather.
+
+    bboxes [B,N,4], scores [B,N,C] (foreground classes only), kpts [B,N,K] float32 on the GPU.
+    Returns fixed-size device tensors (det [B,M,5], labels [B,M] int64 0-based, kpts [B,M,K], count [B] int64),
+    rows past ``count[b]`` zero; ``M = max_num``.  Raises NotImplementedError beyond the on-chip limits
+    (N <= 4096, N*C <= 16384) -- callers fall back to ``multiclass_nms_kp_batched``."""
+    import ctypes
+    from . import _lib
+    B, N, C = scores.shape
+    bboxes, scores = bboxes.contiguous().float(), scores.contiguous().float()
+    L = _lib.lib()
+    L.kgdet_multiclass_nms_workspace_bytes.restype = ctypes.c_size_t
+    ws_bytes = L.kgdet_multiclass_nms_workspace_bytes(ctypes.c_int32(B), ctypes.c_int32(N), ctypes.c_int32(C))
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=bboxes.device)
+    det = torch.empty((B, max_num, 5), dtype=torch.float32, device=bboxes.device)
+    label = torch.empty((B, max_num), dtype=torch.int64, device=bboxes.device)
+    src = torch.empty((B, max_num), dtype=torch.int64, device=bboxes.device)
+    count = torch.empty((B, ), dtype=torch.int64, device=bboxes.device)
+    _lib.check(L.kgdet_multiclass_nms(
+        _lib.ptr(bboxes), _lib.ptr(scores), ctypes.c_int32(B), ctypes.c_int32(N), ctypes.c_int32(C), ctypes.c_int32(C),
+        ctypes.c_int32(0), ctypes.c_float(score_thr), ctypes.c_float(iou_thr), ctypes.c_int32(max_num), _lib.ptr(det),
+        _lib.ptr(label), _lib.ptr(src), _lib.ptr(count), _lib.ptr(ws), ctypes.c_size_t(ws_bytes),
+        _lib.current_stream()), 'kgdet_multiclass_nms')
+    k = kpts.reshape(B, N, -1)
+    out_k = torch.gather(k, 1, src.unsqueeze(-1).expand(B, max_num, k.shape[-1]))
+    out_k = out_k * (torch.arange(max_num, device=count.device).unsqueeze(0) < count.unsqueeze(1)).unsqueeze(-1)
+    return det, label, out_k, count

@@ -300,3 +300,39 @@ def test_bf16_autocast_inference_with_detections_matches_fp32():
                 a, b = r[0][c][np.argmax(r[0][c][:, 4])], g[0][c][np.argmax(g[0][c][:, 4])]
                 if a[4] > 0.2 and abs(a[4] - b[4]) < 0.02:
                     assert np.abs(a[:4] - b[:4]).max() < 0.05 * max(a[2] - a[0], a[3] - a[1]) + 4
+
+
+@pytest.mark.gpu
+def test_packed_batch_postprocess_matches_per_image_path():
+    """get_bboxes through the whole-batch decode + fused NMS == the per-image decode + batched NMS it replaces,
+    with different image shapes and scale factors per image; and simple_test_batch's single-copy numpy path."""
+    from kgdet_amd import build_detector, configs, synthetic
+    cfg = configs.kgdet_r50_fpn()
+    torch.manual_seed(0)
+    model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().eval()
+    batch = synthetic.make_batch(3, torch.device('cuda'), seed=0)
+    synthetic.calibrate_scores(model, batch, cfg.test_cfg.score_thr, 0.03)
+    metas = [dict(m) for m in batch['img_meta']]
+    metas[1].update(img_shape=(700, 1200, 3), scale_factor=1.5)
+    metas[2].update(img_shape=(800, 1000, 3), scale_factor=0.75)
+    head = model.bbox_head
+    with torch.no_grad():
+        outs = head(model.extract_feat(batch['img']), metas)
+        for rescale in (True, False):
+            got = head.get_bboxes(*(outs + (metas, cfg.test_cfg, rescale)))
+            orig = head._packed_ok
+            head._packed_ok = lambda *a, **k: False
+            try:
+                want = head.get_bboxes(*(outs + (metas, cfg.test_cfg, rescale)))
+            finally:
+                head._packed_ok = orig
+            assert len(got) == len(want) == 3 and sum(len(w[0]) for w in want) > 50
+            for (gd, gl, gk), (wd, wl, wk) in zip(got, want):
+                assert torch.equal(gd, wd) and torch.equal(gl, wl) and torch.equal(gk.reshape(wk.shape), wk)
+        res = model.simple_test_batch(batch['img'], metas, rescale=True)
+        want = head.get_bboxes(*(outs + (metas, cfg.test_cfg, True)))
+    for r, (wd, wl, wk) in zip(res, want):
+        assert len(r) == 3 and sum(len(d) for d in r[0]) == len(wd)
+        for c in range(13):
+            sel = (wl == c).cpu().numpy()
+            assert np.array_equal(r[0][c], wd.cpu().numpy()[sel]) and np.array_equal(r[2][c], wk.cpu().numpy()[sel])

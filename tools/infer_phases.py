@@ -11,6 +11,8 @@ torch.manual_seed(0)
 model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).to(dev).eval()
 batch = synthetic.make_batch(B, dev, seed=0)
 ac = torch.autocast('cuda', dtype=torch.bfloat16, enabled=bf16)
+synthetic.calibrate_scores(model, batch, cfg.test_cfg.score_thr, 0.02, ac)
+torch.backends.cudnn.benchmark = True
 def run():
     with torch.no_grad(), ac:
         return model.simple_test_batch(batch['img'], batch['img_meta'], rescale=True)
@@ -27,7 +29,13 @@ with torch.no_grad(), ac:
     t0 = time.time()
     for _ in range(10): outs = model.bbox_head(x, batch['img_meta'])
     torch.cuda.synchronize(); t_h = (time.time() - t0) / 10
-print('backbone+neck %.2f ms, head %.2f ms' % (t_b * 1e3, t_h * 1e3))
+    t0 = time.time()
+    for _ in range(10): dets = model.bbox_head.get_bboxes(*(outs + (batch['img_meta'], model.test_cfg, True)))
+    torch.cuda.synchronize(); t_d = (time.time() - t0) / 10
+    t0 = time.time()
+    for _ in range(10): res = [model.bbox2result_kp(a, b, c, model.bbox_head.num_classes) for a, b, c in dets]
+    torch.cuda.synchronize(); t_r = (time.time() - t0) / 10
+print('backbone+neck %.2f ms, head %.2f ms, decode+nms %.2f ms, to-numpy %.2f ms' % (t_b * 1e3, t_h * 1e3, t_d * 1e3, t_r * 1e3))
 torch.cuda.set_sync_debug_mode('warn')
 with warnings.catch_warnings(record=True) as w:
     warnings.simplefilter('always')
