@@ -82,6 +82,46 @@ class RepPointsDetectorKp(nn.Module):
         return [self.bbox2result_kp(det_bboxes, det_labels, det_kpts, self.bbox_head.num_classes)
                 for det_bboxes, det_labels, det_kpts in bbox_list]
 
+    def graphed_test_batch(self, img, img_meta, rescale=False, autocast_dtype=None, warmup=3):
+        """``simple_test_batch`` for a fixed input shape and fixed image metas as ONE HIP-graph launch.
+
+        A batch is ~360 kernel launches whose CPU-side issue (Python module calls + launch latency) takes about as
+        long as the GPU needs to run them; backbone, neck, head, decode and the fused NMS have no host read, so the
+        whole chain is captured once (``torch.cuda.CUDAGraph`` = hipGraph) and replayed per batch, followed by the
+        single device->host copy of the packed results.  Returns ``run(img) -> results`` (same results as
+        ``simple_test_batch``); raises NotImplementedError when the head's packed post-processing does not apply."""
+        import contextlib
+        assert img.is_cuda and not self.training
+        scope = (lambda: torch.autocast('cuda', dtype=autocast_dtype)) if autocast_dtype is not None \
+            else contextlib.nullcontext
+        static_img = img.clone()
+
+        def chain():
+            outs = self.bbox_head(self.extract_feat(static_img), img_meta)
+            return self.bbox_head.get_bboxes_packed_tensor(*(outs + (img_meta, self.test_cfg, rescale)))
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad(), scope():
+            for _ in range(warmup):          # MIOpen find, lazy module loads, weight caches: all before the capture
+                packed = chain()
+        torch.cuda.current_stream().wait_stream(side)
+        if packed is None:
+            raise NotImplementedError('packed post-processing not applicable to this head / test_cfg / metas')
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), scope(), torch.cuda.graph(graph):
+            static_out = chain()
+        num_classes = self.bbox_head.num_classes
+
+        def run(new_img):
+            static_img.copy_(new_img)
+            graph.replay()
+            dets = self.bbox_head.unpack_results(static_out.cpu().numpy())
+            return [self.bbox2result_kp(d, lab, k, num_classes) for d, lab, k in dets]
+
+        run.graph, run.static_img, run.static_out = graph, static_img, static_out
+        return run
+
     def simple_test(self, img, img_meta, rescale=False):
         return self.simple_test_batch(img, img_meta, rescale)[0]
 

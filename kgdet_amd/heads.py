@@ -511,27 +511,39 @@ class RepPointsHeadKp3RepCas1AssignOnce(PointHeadMixin, nn.Module):
                                          torch.stack([pad(p[2]) for p in per_image]), cfg.score_thr, cfg.nms,
                                          cfg.max_per_img)
 
-    def get_bboxes_numpy(self, cls_scores_1, cls_scores_2, cls_scores_3, keypts_preds_1, keypts_preds_2,
-                         keypts_preds_3, bbox_preds_1, bbox_preds_2, bbox_preds_3, img_metas, cfg, rescale=False):
-        """``get_bboxes`` with the results on the host as numpy arrays; on the packed path the whole batch comes
-        back in ONE device->host copy (boxes, labels, count and landmarks side by side)."""
+    def get_bboxes_packed_tensor(self, cls_scores_1, cls_scores_2, cls_scores_3, keypts_preds_1, keypts_preds_2,
+                                 keypts_preds_3, bbox_preds_1, bbox_preds_2, bbox_preds_3, img_metas, cfg,
+                                 rescale=False):
+        """The batch's detections as ONE device tensor [B, max_per_img, 7 + 3K] -- columns: box (4), score, label,
+        count (repeated), landmarks -- produced without any host read (capturable in a HIP graph); None when the
+        packed path does not apply.  ``unpack_results`` splits its host copy per image."""
         cls3, box3 = [t.float() for t in cls_scores_3], [t.float() for t in bbox_preds_3]
         if not self._packed_ok(cls3, img_metas, cfg):
-            return [(d.float().cpu().numpy(), lab.cpu().numpy(), k.float().cpu().numpy()) for d, lab, k in
-                    self.get_bboxes(cls_scores_1, cls_scores_2, cls_scores_3, keypts_preds_1, keypts_preds_2,
-                                    keypts_preds_3, bbox_preds_1, bbox_preds_2, bbox_preds_3, img_metas, cfg, rescale)]
+            return None
         kpt3 = [self.points2kpt(t.float()) for t in keypts_preds_3]
         points = [self.point_generators[i].grid_points(cls3[i].size()[-2:], self.point_strides[i], device=cls3[i].device)
                   for i in range(len(cls3))]
         det, label, kp, count = self.get_bboxes_packed(cls3, box3, kpt3, points, img_metas, cfg, rescale)
         B, M = label.shape
-        packed = torch.cat([det, label.unsqueeze(-1).float(), count.view(B, 1, 1).expand(B, M, 1).float(), kp],
-                           dim=-1).cpu().numpy()
+        return torch.cat([det, label.unsqueeze(-1).float(), count.view(B, 1, 1).expand(B, M, 1).float(), kp], dim=-1)
+
+    @staticmethod
+    def unpack_results(packed):
+        """host copy of ``get_bboxes_packed_tensor`` -> per image (det [n, 5], labels [n] int64, landmarks [n, 3K])"""
         out = []
-        for b in range(B):
+        for b in range(packed.shape[0]):
             n = int(packed[b, 0, 6])
             out.append((packed[b, :n, :5], packed[b, :n, 5].astype(np.int64), packed[b, :n, 7:]))
         return out
+
+    def get_bboxes_numpy(self, *args, **kwargs):
+        """``get_bboxes`` with the results on the host as numpy arrays; on the packed path the whole batch comes
+        back in ONE device->host copy."""
+        packed = self.get_bboxes_packed_tensor(*args, **kwargs)
+        if packed is None:
+            return [(d.float().cpu().numpy(), lab.cpu().numpy(), k.float().cpu().numpy())
+                    for d, lab, k in self.get_bboxes(*args, **kwargs)]
+        return self.unpack_results(packed.cpu().numpy())
 
     # ------------------------------------------------------------------------------------------
     # whole-batch decode + fused NMS: no per-image Python loop, no host read before the results

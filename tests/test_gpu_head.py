@@ -336,3 +336,36 @@ def test_packed_batch_postprocess_matches_per_image_path():
         for c in range(13):
             sel = (wl == c).cpu().numpy()
             assert np.array_equal(r[0][c], wd.cpu().numpy()[sel]) and np.array_equal(r[2][c], wk.cpu().numpy()[sel])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('bf16', [False, True])
+def test_graphed_test_batch_matches_eager(bf16):
+    """The HIP-graph replay of backbone -> head -> decode -> fused NMS returns what the eager batch returns, also for
+    a new image copied into the captured input buffer."""
+    from kgdet_amd import build_detector, configs, synthetic
+    cfg = configs.kgdet_r50_fpn()
+    torch.manual_seed(0)
+    model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().eval()
+    dtype = torch.bfloat16 if bf16 else None
+    ac = torch.autocast('cuda', dtype=torch.bfloat16, enabled=bf16)
+    a = synthetic.make_batch(2, torch.device('cuda'), seed=0)
+    b = synthetic.make_batch(2, torch.device('cuda'), seed=5)
+    synthetic.calibrate_scores(model, a, cfg.test_cfg.score_thr, 0.03, ac)
+    run = model.graphed_test_batch(a['img'], a['img_meta'], rescale=True, autocast_dtype=dtype)
+    for batch in (a, b, a):
+        got = run(batch['img'])
+        with torch.no_grad(), ac:
+            want = model.simple_test_batch(batch['img'], batch['img_meta'], rescale=True)
+        assert len(got) == len(want) == 2 and sum(len(d) for d in want[0][0]) > 10
+        for g, w in zip(got, want):
+            assert len(g) == len(w) == 3
+            for c in range(13):
+                if not bf16:
+                    assert np.array_equal(g[0][c], w[0][c]) and np.array_equal(g[2][c], w[2][c])
+                elif len(g[0][c]) and len(w[0][c]):
+                    # bf16 convolutions may pick another MIOpen solver inside the capture: the same detections up to
+                    # bf16 convolution noise (which can also flip a borderline candidate)
+                    d = np.abs(g[0][c][:, None, :4] - w[0][c][None, :, :4]).max(-1).min(1)
+                    assert (d < 0.5).mean() >= 0.8
+            assert abs(sum(len(d) for d in g[0]) - sum(len(d) for d in w[0])) <= 2
