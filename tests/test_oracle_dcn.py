@@ -133,3 +133,52 @@ def test_focal_extreme_logits_finite():
     assert np.all(np.isfinite(loss))
     g = oracle.sigmoid_focal_loss_backward(logits, target, np.ones_like(logits))
     assert np.all(np.isfinite(g))
+
+
+@pytest.mark.parametrize('no_trans,group_size,part', [(True, 1, None), (False, 1, None), (False, 3, 3), (False, 1, 2)])
+def test_psroi_oracle_matches_independent_formulation(no_trans, group_size, part):
+    """oracle/psroi_oracle.inc (the restatement of deform_pool_cuda_kernel.cu:53-263, parity unpinned by the
+    reference) against a dense grid_sample formulation; backward against its autograd, in fp64."""
+    import torch
+    from tests import torch_ref
+    rng = np.random.default_rng(4)
+    B, H, W, P, out_c = 2, 11, 13, 3, 4
+    C = out_c * group_size * group_size
+    part_size = P if part is None else part
+    data = rng.normal(size=(B, C, H, W))
+    R = 7
+    x1 = rng.uniform(-20, 150, R); y1 = rng.uniform(-20, 120, R)
+    rois = np.stack([rng.integers(0, B, R), x1, y1, x1 + rng.uniform(1, 120, R), y1 + rng.uniform(1, 120, R)], 1)
+    rois[0, 1:] = [5, 5, 5, 5]            # degenerate RoI -> minimum size 0.1
+    rois[1, 1:] = [300, 300, 400, 400]    # entirely outside -> every sample skipped, count 0
+    rois[2, 1:] = [24, 18, 62, 55]        # well inside the 13 x 11 map (x 8): no sample is clamped
+    rois[3, 1:] = [30, 22, 70, 60]
+    offset = rng.normal(size=(R, 4, part_size, part_size)) * 0.5
+    go = rng.normal(size=(R, out_c, P, P))
+    scale, tstd = 1 / 8., 0.1
+    ro, rc = oracle.deform_psroi_forward(data, rois, offset, scale, P, out_c, no_trans, group_size, part_size, 3, tstd)
+    td = torch.from_numpy(data).requires_grad_()
+    to = torch.from_numpy(offset).requires_grad_()
+    out, cnt = torch_ref.deform_psroi_pool(td, torch.from_numpy(rois), to, scale, P, out_c, no_trans, group_size,
+                                           part_size, 3, tstd)
+    assert np.array_equal(cnt.numpy(), rc) and rc[1].max() == 0 and rc.max() == 9
+    np.testing.assert_allclose(out.detach().numpy(), ro, rtol=0, atol=1e-12)
+    out.backward(torch.from_numpy(go))
+    gd, gt = oracle.deform_psroi_backward(go, rc, data, rois, offset, scale, P, out_c, no_trans, group_size, part_size,
+                                          3, tstd)
+    np.testing.assert_allclose(td.grad.numpy(), gd, rtol=0, atol=1e-12)
+    if not no_trans:
+        # the analytic offset gradient uses floor/ceil corners; autograd of the clamped coordinate has zero slope where
+        # the clamp is active, the kernel does not clamp the derivative: compare where no sample was clamped
+        interior = [r for r in range(R) if _roi_strictly_inside(rois[r], offset[r], scale, tstd, H, W)]
+        assert len(interior) >= 2
+        np.testing.assert_allclose(to.grad.numpy()[interior], gt[interior], rtol=0, atol=1e-10)
+
+
+def _roi_strictly_inside(roi, off, scale, tstd, H, W):
+    """every sample of this RoI lands in [0, W-1] x [0, H-1] whatever its (bounded) offsets: no clamping involved"""
+    rsw, rsh = np.round(roi[1]) * scale - 0.5, np.round(roi[2]) * scale - 0.5
+    rew, reh = (np.round(roi[3]) + 1) * scale - 0.5, (np.round(roi[4]) + 1) * scale - 0.5
+    rw, rh = max(rew - rsw, 0.1), max(reh - rsh, 0.1)
+    m = np.abs(off).max() * tstd
+    return rsw - m * rw > 0 and rew + m * rw < W - 1 and rsh - m * rh > 0 and reh + m * rh < H - 1
