@@ -26,7 +26,24 @@ extern "C" {
 #define KGDET_OK 0
 #define KGDET_E_SHAPE 1     /* shape/argument check failed (reference: AT_CHECK -> RuntimeError) */
 #define KGDET_E_WORKSPACE 2 /* workspace too small */
-#define KGDET_E_HIP 3       /* Frozen-statistics BatchNorm (+ residual add) (+ ReLU) in one pass -- the norm_eval=True training path of
+#define KGDET_E_HIP 3       /* 1x1 convolution, stride 1, float32 NCHW, as bf16 hi/lo-split MFMA GEMMs (fp32-level accuracy) -- the conv1 / conv3 /
+ * stride-1 downsample convolutions of the bottleneck, mmdet/models/backbones/resnet.py:142-186, which the reference
+ * runs through cuDNN / MIOpen.  No reference native entry point.
+ *   kgdet_conv1x1_pack: weight [O, C] -> operand image; transpose = 0 for the forward (y = W x), 1 for grad_input
+ *                       (gx = W^T gy); the reduction length (C resp. O) must be a multiple of 16.
+ *   kgdet_conv1x1_apply: y[b] (M x HW) = A (M x K) . x[b] (K x HW) with A = the packed image; x [B, K, HW], y [B, M, HW].
+ *   kgdet_conv1x1_grad_weight: grad_w [O, C] = sum_b grad_y[b] (O x HW) . x[b]^T (HW x C); HW even; deterministic
+ *                       (per-chunk partial tiles added in fixed order); workspace from the _workspace_bytes query. */
+size_t kgdet_conv1x1_packed_bytes(int32_t M, int32_t K);
+int kgdet_conv1x1_pack(const float *w, int32_t O, int32_t C, int32_t transpose, void *packed, void *stream);
+size_t kgdet_conv1x1_apply_workspace_bytes(int64_t B, int32_t M, int32_t K, int64_t HW); /* 0 for most shapes */
+int kgdet_conv1x1_apply(const void *packed, const float *x, float *y, int64_t B, int32_t M, int32_t K, int64_t HW,
+                        void *workspace, size_t workspace_bytes, void *stream);
+size_t kgdet_conv1x1_grad_weight_workspace_bytes(int64_t B, int32_t O, int32_t C, int64_t HW);
+int kgdet_conv1x1_grad_weight(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O, int32_t C,
+                              int64_t HW, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Frozen-statistics BatchNorm (+ residual add) (+ ReLU) in one pass -- the norm_eval=True training path of
  * mmdet/models/backbones/resnet.py:240-262,518-525.  float32, NCHW: x, residual, y [N, C, HW]; gamma, beta (nullable:
  * 1 / 0), mean, var [C].     y = [relu](x * s + t [+ residual]),  s = gamma / sqrt(var + eps),  t = beta - mean * s.
  * y may alias x when x is not needed by a later backward. */

@@ -14,6 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.modules.batchnorm import _BatchNorm
 
+from . import conv1x1
 from . import dcn as dcn_ops
 from .layers import build_conv_layer, build_norm_layer, constant_init, kaiming_init
 from .registry import BACKBONES
@@ -167,6 +168,8 @@ def conv_bn(conv, bn, x, relu=False, residual=None):
             out += residual
         return F.relu(out, inplace=True) if relu else out
     if torch.is_grad_enabled():
+        if conv1x1.applicable(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups):
+            return frozen_bn_act(conv1x1.conv1x1(x, conv.weight), bn, residual, relu)   # split-bf16 MFMA GEMMs
         return frozen_bn_act(conv(x), bn, residual, relu)
     bf16 = x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled()
                                                         and torch.get_autocast_dtype('cuda') == torch.bfloat16))

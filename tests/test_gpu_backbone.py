@@ -178,3 +178,46 @@ def test_resnet_with_dcn_stages_builds_and_steps():
     sum(o.mean() for o in outs).backward()
     assert net.layer3[0].conv2.weight.grad.abs().sum() > 0 and net.layer3[0].conv2_offset.weight.grad is not None
     assert not hasattr(net.layer1[0], 'conv2_offset')
+
+
+@pytest.mark.parametrize('B,C,O,H,W', [(2, 64, 256, 20, 34), (1, 256, 64, 9, 14), (2, 512, 128, 25, 42), (2, 128, 512, 13, 10),
+                                       (3, 1024, 256, 6, 8), (2, 2048, 512, 25, 42), (2, 16, 48, 5, 6), (2, 32, 16, 129, 2)])
+def test_conv1x1_split_matches_fp64_convolution(B, C, O, H, W):
+    """csrc/conv1x1.hip (bf16 hi/lo-split MFMA GEMMs): forward, grad_input and grad_weight against the fp64
+    convolution, to fp32-level accuracy (1e-5 of the result's scale; MIOpen's fp32 kernels sit at ~1e-6); ragged
+    pixel tiles, M < 128, the K-split and the 8- and 16-byte load variants of grad_weight."""
+    from kgdet_amd import conv1x1 as c1
+    g = torch.Generator(device='cpu').manual_seed(C + O + H)
+    x = torch.randn(B, C, H, W, generator=g).cuda().requires_grad_()
+    w = (torch.randn(O, C, 1, 1, generator=g) * 0.1).cuda().requires_grad_()
+    gy = torch.randn(B, O, H, W, generator=g).cuda()
+    assert c1.applicable(x, w)
+    y = c1.conv1x1(x, w)
+    y.backward(gy)
+    xd, wd = x.detach().double().requires_grad_(), w.detach().double().requires_grad_()
+    yd = F.conv2d(xd, wd)
+    yd.backward(gy.double())
+    for name, a, b in (('y', y, yd), ('grad_x', x.grad, xd.grad), ('grad_w', w.grad, wd.grad)):
+        err = (a.double() - b).abs().max().item() / b.abs().max().item()
+        assert err < 1e-5, (name, err)
+    # deterministic: same bits on a second run
+    x.grad = None; w.grad = None
+    y2 = c1.conv1x1(x, w)
+    y2.backward(gy)
+    assert torch.equal(y, y2)
+    x2g, w2g = x.grad.clone(), w.grad.clone()
+    x.grad = None; w.grad = None
+    c1.conv1x1(x, w).backward(gy)
+    assert torch.equal(x.grad, x2g) and torch.equal(w.grad, w2g)
+
+
+def test_conv1x1_not_applicable_cases_fall_back():
+    from kgdet_amd import conv1x1 as c1
+    x = torch.randn(2, 64, 8, 8, device='cuda')
+    w = torch.randn(32, 64, 1, 1, device='cuda')
+    assert c1.applicable(x, w) and not c1.applicable(x, w, stride=(2, 2)) and not c1.applicable(x.half(), w.half())
+    assert not c1.applicable(x, torch.randn(32, 64, 3, 3, device='cuda'), padding=(1, 1))
+    assert not c1.applicable(torch.randn(2, 40, 8, 8, device='cuda'), torch.randn(32, 40, 1, 1, device='cuda'))
+    assert not c1.applicable(torch.randn(2, 64, 3, 3, device='cuda'), w)          # odd H*W
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        assert not c1.applicable(x, w)
