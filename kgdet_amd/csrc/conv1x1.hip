@@ -161,18 +161,29 @@ __global__ __launch_bounds__(kGemmThreads) void conv1x1_nn(const unsigned char *
     for (int i = 0; i < kPF; ++i) issue(i, R[i]);
     commit(0, R[0]);
     // stage s: set s % kPF was committed one body ago and is free -> loads of stage s + kPF; set (s+1) % kPF is
-    // converted into the other LDS buffer while stage s is multiplied.  kPF bodies per trip: static register names.
-    for (int s0 = 0; s0 < stages; s0 += kPF) {
+    // converted into the other LDS buffer while stage s is multiplied.  The main loop runs whole groups of kPF
+    // bodies with NO condition around the loads (clamped addresses instead): only then does hipcc keep counted
+    // s_waitcnt vmcnt(N) across the back edge -- with guarded bodies it drained the queue (vmcnt(0)) every trip.
+    const int full = stages / kPF * kPF;
+    for (int s0 = 0; s0 < full; s0 += kPF) {
 #pragma unroll
       for (int u = 0; u < kPF; ++u) {
         const int s = s0 + u;
-        if (s < stages) {
-          __syncthreads();
-          issue(s + kPF, R[u]);
-          const unsigned char *As = smem + (s & 1) * 2 * kStage;
-          mma_stage(As, As + kStage, lane, wm, wn, acc);
-          if (s + 1 < stages) commit((s + 1) & 1, R[(u + 1) % kPF]);
-        }
+        __syncthreads();
+        issue(s + kPF, R[u]);
+        const unsigned char *As = smem + (s & 1) * 2 * kStage;
+        mma_stage(As, As + kStage, lane, wm, wn, acc);
+        commit((s + 1) & 1, R[(u + 1) % kPF]);   // past the last stage: a clamped duplicate nobody reads
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kPF - 1; ++u) {   // tail: stages full .. stages-1 are already in R[u]; no loads
+      const int s = full + u;
+      if (s < stages) {
+        __syncthreads();
+        const unsigned char *As = smem + (s & 1) * 2 * kStage;
+        mma_stage(As, As + kStage, lane, wm, wn, acc);
+        if (s + 1 < stages) commit((s + 1) & 1, R[u + 1]);
       }
     }
   }
@@ -282,17 +293,26 @@ __global__ __launch_bounds__(kGemmThreads) void conv1x1_nt(const float *__restri
 #pragma unroll
     for (int i = 0; i < PF; ++i) issue(s_begin + i, R[i]);
     commit(0, R[0]);
-    for (int j0 = 0; j0 < n; j0 += PF) {
+    const int full = n / PF * PF;   // as in conv1x1_nn: unguarded bodies in the main loop, load-free tail
+    for (int j0 = 0; j0 < full; j0 += PF) {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         const int j = j0 + u;
-        if (j < n) {
-          __syncthreads();
-          issue(s_begin + j + PF, R[u]);
-          const unsigned char *As = smem + (j & 1) * 2 * kStage;
-          mma_stage(As, As + kStage, lane, wm, wn, acc);
-          if (j + 1 < n) commit((j + 1) & 1, R[(u + 1) % PF]);
-        }
+        __syncthreads();
+        issue(s_begin + j + PF, R[u]);
+        const unsigned char *As = smem + (j & 1) * 2 * kStage;
+        mma_stage(As, As + kStage, lane, wm, wn, acc);
+        commit((j + 1) & 1, R[(u + 1) % PF]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PF - 1; ++u) {
+      const int j = full + u;
+      if (j < n) {
+        __syncthreads();
+        const unsigned char *As = smem + (j & 1) * 2 * kStage;
+        mma_stage(As, As + kStage, lane, wm, wn, acc);
+        if (j + 1 < n) commit((j + 1) & 1, R[u + 1]);
       }
     }
   }
@@ -312,11 +332,13 @@ __global__ __launch_bounds__(kGemmThreads) void conv1x1_nt(const float *__restri
 
 namespace {
 
+// measured on MI355X (tools/bench_conv1x1_wgrad.py): one workgroup per CU with >= 32 stages each beats finer cuts --
+// every extra split is another [M, N] partial written and re-read
 int nt_splits(int tiles, int total_stages) {
-  int splits = (768 + tiles - 1) / tiles;             // ~3 workgroups per CU
-  const int most = (total_stages + 15) / 16;          // at least 16 stages per workgroup
+  int splits = (256 + tiles - 1) / tiles;
+  const int most = (total_stages + 31) / 32;
   if (splits > most) splits = most;
-  if (splits > 64) splits = 64;
+  if (splits > 128) splits = 128;
   return splits < 1 ? 1 : splits;
 }
 

@@ -208,7 +208,9 @@ def test_conv1x1_split_matches_fp64_convolution(B, C, O, H, W):
     x2g, w2g = x.grad.clone(), w.grad.clone()
     x.grad = None; w.grad = None
     c1.conv1x1(x, w).backward(gy)
-    assert torch.equal(x.grad, x2g) and torch.equal(w.grad, w2g)
+    assert torch.equal(x.grad, x2g)
+    if (H * W) % 4 == 0:     # otherwise grad_weight is MIOpen's (kgdet_amd/conv1x1.py), which makes no such promise
+        assert torch.equal(w.grad, w2g)
 
 
 def test_conv1x1_not_applicable_cases_fall_back():
