@@ -169,7 +169,7 @@ def conv_bn(conv, bn, x, relu=False, residual=None):
         return F.relu(out, inplace=True) if relu else out
     if torch.is_grad_enabled():
         if conv1x1.applicable(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups):
-            return frozen_bn_act(conv1x1.conv1x1(x, conv.weight), bn, residual, relu)   # split-bf16 MFMA GEMMs
+            return frozen_bn_act(conv1x1.conv_split(x, conv.weight), bn, residual, relu)   # split-bf16 MFMA GEMMs
         return frozen_bn_act(conv(x), bn, residual, relu)
     bf16 = x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled()
                                                         and torch.get_autocast_dtype('cuda') == torch.bfloat16))

@@ -8,8 +8,9 @@
 // hi = bf16(v), lo = bf16(v - hi); a product is a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on v_mfma_f32_32x32x16_bf16 with
 // fp32 accumulation -- fp32-level accuracy (~1e-6 of the output scale) at a third of the bf16 rate.
 //
-//   forward      y[b] (Cout x HW) = W (Cout x Cin)     . x[b]  (Cin x HW)    conv1x1_nn, A = packed W
-//   grad_input   gx[b] (Cin x HW) = W^T (Cin x Cout)   . gy[b] (Cout x HW)   conv1x1_nn, A = packed W^T
+//   forward      y[b] (Cout x HW) = W (Cout x Cin)     . x[b]  (Cin x HW)    conv_nn<1>, A = packed W
+//   grad_input   gx[b] (Cin x HW) = W^T (Cin x Cout)   . gy[b] (Cout x HW)   conv_nn<1>, A = packed W^T
+// and the 3x3 (stride 1, padding 1) convolution as the same implicit GEMM over (channel chunk, tap) stages: conv_nn<9>.
 //   grad_weight  gW (Cout x Cin)  = sum_b gy[b] (Cout x HW) . x[b]^T         conv1x1_nt + conv1x1_sum
 //
 // conv1x1_nn: 128 x 128 output tile per workgroup (4 waves x 64 x 64), reduction in stages of 16 channels.
@@ -76,21 +77,28 @@ __device__ __forceinline__ int xcd_tile(int b, int tiles) {
 
 }  // namespace
 
-// image[mt][k16][part][khalf][128][8] of the logical A (M x K): A[m][k] = transpose ? w[k * ld + m] : w[m * ld + k]
-__global__ __launch_bounds__(256) void conv1x1_pack(const float *__restrict__ w, int M, int K, int ld, int transpose,
+// Operand image of a [O, C, T] weight (T = 1 or 9 taps): stages ordered (chunk of 16 reduction channels, tap),
+// image[mt][k16 * T + t][part][khalf][128][8].
+//   transpose = 0 (forward):    rows = O, reduction = C:  A[o][(c, t)] = w[o][c][t]
+//   transpose = 1 (grad_input): rows = C, reduction = O:  A[c][(o, t)] = w[o][c][T - 1 - t]   (taps mirrored)
+__global__ __launch_bounds__(256) void conv1x1_pack(const float *__restrict__ w, int O, int C, int T, int transpose,
                                                     unsigned char *__restrict__ img) {
+  const int M = transpose ? C : O, K = transpose ? O : C;
   const int k16s = K / kTK;
-  const long long total = (long long)((M + kTM - 1) / kTM) * k16s * 2 * kTM;   // (mt, k16, khalf, row)
+  const long long total = (long long)((M + kTM - 1) / kTM) * k16s * T * 2 * kTM;   // (mt, k16, t, khalf, row)
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += gridDim.x * 256LL) {
     const int row = (int)(i % kTM);
     const int khalf = (int)((i / kTM) & 1);
-    const long long st = i / (2 * kTM);
-    const int k16 = (int)(st % k16s), mt = (int)(st / k16s);
+    const long long st = i / (2 * kTM);           // stage index (mt, k16, t)
+    const int t = (int)(st % T);
+    const int k16 = (int)((st / T) % k16s), mt = (int)(st / ((long long)T * k16s));
     const int m = mt * kTM + row, k0 = k16 * kTK + khalf * 8;
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      v[j] = m < M ? (transpose ? w[(long long)(k0 + j) * ld + m] : w[(long long)m * ld + k0 + j]) : 0.0f;
+    for (int j = 0; j < 8; ++j) {
+      const long long o = transpose ? k0 + j : m, ch = transpose ? m : k0 + j;
+      v[j] = m < M ? w[(o * C + ch) * T + (transpose ? T - 1 - t : t)] : 0.0f;
+    }
     bf16x8 hi, lo;
     split8(v, hi, lo);
     unsigned char *dst = img + st * kStage + khalf * (kTM * 16) + row * 16;
@@ -99,63 +107,108 @@ __global__ __launch_bounds__(256) void conv1x1_pack(const float *__restrict__ w,
   }
 }
 
-// y[b][m][n] = sum_k A[m][k] * x[b][k][n];  A as packed image, x [B, K, N], y [B, M, N], N contiguous.
+// y[b][m][p] = sum_{k, t} A[m][(k, t)] * x[b][k][p + shift(t)]  (zero outside the image): a TAPS = 1 (1x1) or 9 (3x3,
+// stride 1, padding 1) convolution as an implicit GEMM.  A as packed image, x [B, K, H*W], y [B, M, H*W].
+// 512 threads: 8 waves as 2 (M) x 4 (N), 64 x 32 outputs each -- two waves per SIMD, so one wave's MFMAs cover the
+// other's loads / conversions even when a problem has only ~1 tile per CU.  B stage: thread (pixel, k quarter) loads
+// 4 channels of its pixel (dword loads, coalesced along pixels; the tap's shift is an address offset, its validity a
+// bit of a per-thread mask computed once), splits, writes 8 bytes per part.  A stage: one 16-byte load per thread.
 // ksplit > 1: workgroup (tile, part) reduces stages [part * per, ...) and writes y-shaped partial `part` of `y`
 // (= a [ksplit][B, M, N] buffer); conv1x1_sum adds the parts.  Used when a problem has too few tiles for 256 CUs.
-constexpr int kPF = 4;   // stages of global loads in flight per thread
+constexpr int kPF = 4;          // stages of global loads in flight per thread
+constexpr int kNNThreads = 512;
 
-__global__ __launch_bounds__(kGemmThreads) void conv1x1_nn(const unsigned char *__restrict__ img,
-                                                           const float *__restrict__ x, float *__restrict__ y, int M,
-                                                           int K, int N, int n_mt, int n_nt, int tiles, int ksplit,
-                                                           long long part_stride) {
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int TAPS>
+__global__ __launch_bounds__(kNNThreads) void conv_nn(const unsigned char *__restrict__ img,
+                                                      const float *__restrict__ x, float *__restrict__ y, int M, int K,
+                                                      int H, int W, int n_mt, int n_nt, int tiles, int ksplit,
+                                                      long long part_stride) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * kStage];   // [buf][A | B][kStage]
   const int unit = xcd_tile(blockIdx.x, tiles * ksplit);
   if (unit >= tiles * ksplit) return;
   // unit order: the K parts and the m tiles of one (image, pixel tile) adjacent -> they share it through one L2
   const int part = unit % ksplit, tile = unit / ksplit;
-  const int mt = tile % n_mt, nt = (tile / n_mt) % n_nt, b = tile / (n_mt * n_nt);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
-  const int n_local = tid & (kTN - 1), khalf = tid >> 7;
+  const int n_local = tid & (kTN - 1), kq = tid >> 7;   // pixel column, quarter of the stage's 16 channels
+  const int N = H * W;
+  const int S = TAPS * (K / kTK), per = (S + ksplit - 1) / ksplit;
+  const int s_begin = part * per, s_end = max(s_begin, min(S, s_begin + per));
+  const int stages = s_end - s_begin;
+  struct Regs {
+    f32x4 a;
+    float v[4];
+    unsigned live;
+  };
+  const int mt = tile % n_mt, nt = (tile / n_mt) % n_nt, b = tile / (n_mt * n_nt);
   const int n0 = nt * kTN;
-  const int n_ld = min(n0 + n_local, N - 1);   // columns past the end re-read the last one: never stored
-  const float *xb = x + (long long)b * K * N + n_ld;
-  const unsigned char *ai = img + (long long)mt * (K / kTK) * kStage + tid * 16;
-  const int all = K / kTK, per = (all + ksplit - 1) / ksplit;
-  const int s_begin = part * per, s_end = min(all, s_begin + per);
-  const int stages = max(s_end - s_begin, 0);
+  const int p = min(n0 + n_local, N - 1);   // columns past the end re-read the last one: never stored
+  unsigned ok = 1u;                          // bit t: tap t of this pixel lies inside the image
+  if (TAPS == 9) {
+    const int h = p / W, w = p - h * W;
+    ok = 0u;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+      ok |= (hh >= 0 && hh < H && ww >= 0 && ww < W) ? (1u << t) : 0u;
+    }
+  }
+  const float *xb = x + (long long)b * K * N + p;
+  const unsigned char *ai = img + (long long)mt * S * kStage + tid * 16;
 
-  f32x16 acc[2][2];
+  f32x16 acc[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-  struct Regs {
-    f32x4 a[2];
-    float v[8];
-  };
   auto issue = [&](int s, Regs &R) {   // clamped: unconditional loads keep hipcc's vmcnt counting exact
-    const int sc = s_begin + min(s, max(stages - 1, 0));
-    const unsigned char *ap = ai + (long long)sc * kStage;
-    R.a[0] = *reinterpret_cast<const f32x4 *>(ap);
-    R.a[1] = *reinterpret_cast<const f32x4 *>(ap + kPart);
-    const float *xp = xb + (long long)(sc * kTK + khalf * 8) * N;
+    const int sc = s_begin + min(s, stages - 1);
+    R.a = *reinterpret_cast<const f32x4 *>(ai + (long long)sc * kStage);
+    const int c16 = sc / TAPS, t = sc - c16 * TAPS;
+    int shift = 0;
+    R.live = 1u;
+    if (TAPS == 9) {
+      R.live = (ok >> t) & 1u;
+      shift = R.live ? (t / 3 - 1) * W + (t % 3 - 1) : 0;
+    }
+    const float *xp = xb + (long long)(c16 * kTK + kq * 4) * N + shift;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) R.v[j] = xp[(long long)j * N];
+    for (int j = 0; j < 4; ++j) R.v[j] = xp[(long long)j * N];
   };
   auto commit = [&](int buf, const Regs &R) {
     unsigned char *As = smem + buf * 2 * kStage, *Bs = As + kStage;
-    *reinterpret_cast<f32x4 *>(As + tid * 16) = R.a[0];
-    *reinterpret_cast<f32x4 *>(As + kPart + tid * 16) = R.a[1];
-    bf16x8 hi, lo;
-    split8(R.v, hi, lo);
-    unsigned char *dst = Bs + khalf * (kTN * 16) + n_local * 16;
-    *reinterpret_cast<bf16x8 *>(dst) = hi;
-    *reinterpret_cast<bf16x8 *>(dst + kPart) = lo;
+    *reinterpret_cast<f32x4 *>(As + tid * 16) = R.a;
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float f = R.live ? R.v[j] : 0.0f;
+      hi[j] = (__bf16)f;
+      lo[j] = (__bf16)(f - (float)hi[j]);
+    }
+    unsigned char *dst = Bs + (kq >> 1) * (kTN * 16) + n_local * 16 + (kq & 1) * 8;
+    *reinterpret_cast<bf16x4 *>(dst) = hi;
+    *reinterpret_cast<bf16x4 *>(dst + kPart) = lo;
   };
-  if (stages > 0) {
+  auto multiply = [&](int buf) {   // wave (wm, wn): rows wm*64 .. +63, columns wn*32 .. +31
+    const unsigned char *A = smem + buf * 2 * kStage + (lane >> 5) * (kTM * 16) + (wm * 64 + (lane & 31)) * 16;
+    const unsigned char *Bp = smem + buf * 2 * kStage + kStage + (lane >> 5) * (kTN * 16) + (wn * 32 + (lane & 31)) * 16;
+    bf16x8 a[2][2], bb[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      a[pt][0] = *reinterpret_cast<const bf16x8 *>(A + pt * kPart);
+      a[pt][1] = *reinterpret_cast<const bf16x8 *>(A + pt * kPart + 32 * 16);
+      bb[pt] = *reinterpret_cast<const bf16x8 *>(Bp + pt * kPart);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {   // small terms first
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][mi], bb[0], acc[mi], 0, 0, 0);
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], bb[1], acc[mi], 0, 0, 0);
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], bb[0], acc[mi], 0, 0, 0);
+    }
+  };
+  {
     Regs R[kPF];
 #pragma unroll
     for (int i = 0; i < kPF; ++i) issue(i, R[i]);
@@ -171,8 +224,7 @@ __global__ __launch_bounds__(kGemmThreads) void conv1x1_nn(const unsigned char *
         const int s = s0 + u;
         __syncthreads();
         issue(s + kPF, R[u]);
-        const unsigned char *As = smem + (s & 1) * 2 * kStage;
-        mma_stage(As, As + kStage, lane, wm, wn, acc);
+        multiply(s & 1);
         commit((s + 1) & 1, R[(u + 1) % kPF]);   // past the last stage: a clamped duplicate nobody reads
       }
     }
@@ -181,8 +233,7 @@ __global__ __launch_bounds__(kGemmThreads) void conv1x1_nn(const unsigned char *
       const int s = full + u;
       if (s < stages) {
         __syncthreads();
-        const unsigned char *As = smem + (s & 1) * 2 * kStage;
-        mma_stage(As, As + kStage, lane, wm, wn, acc);
+        multiply(s & 1);
         if (s + 1 < stages) commit((s + 1) & 1, R[u + 1]);
       }
     }
@@ -190,16 +241,13 @@ __global__ __launch_bounds__(kGemmThreads) void conv1x1_nn(const unsigned char *
 
   // store: lane holds column (lane & 31) of 16 rows per 32 x 32 block -> 128-byte row segments per half wave
   float *yb = y + (long long)part * part_stride + (long long)b * M * N;
+  const int n = n0 + wn * 32 + (lane & 31);
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int n = n0 + wn * 64 + ni * 32 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mt * kTM + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < M && n < N) yb[(long long)m * N + n] = acc[mi][ni][r];
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int m = mt * kTM + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (m < M && n < N) yb[(long long)m * N + n] = acc[mi][r];
     }
 }
 
@@ -358,52 +406,61 @@ int nn_ksplit(long long tiles, int stages) {
 
 using namespace kgdet;
 
-extern "C" size_t kgdet_conv1x1_packed_bytes(int32_t M, int32_t K) {
-  if (M <= 0 || K <= 0 || K % kTK) return 0;
-  return (size_t)((M + kTM - 1) / kTM) * (K / kTK) * kStage;
+extern "C" size_t kgdet_conv_packed_bytes(int32_t M, int32_t K, int32_t taps) {
+  if (M <= 0 || K <= 0 || K % kTK || (taps != 1 && taps != 9)) return 0;
+  return (size_t)((M + kTM - 1) / kTM) * (K / kTK) * taps * kStage;
 }
 
-extern "C" int kgdet_conv1x1_pack(const float *w, int32_t O, int32_t C, int32_t transpose, void *packed,
-                                  void *stream) {
-  // weight [O, C]; transpose = 0: A = W (rows O, reduction C; forward); 1: A = W^T (rows C, reduction O; grad_input)
+extern "C" int kgdet_conv_pack(const float *w, int32_t O, int32_t C, int32_t taps, int32_t transpose, void *packed,
+                               void *stream) {
+  // weight [O, C, taps]; transpose = 0: rows O, reduction C (forward); 1: rows C, reduction O, taps mirrored (grad_input)
   const int M = transpose ? C : O, K = transpose ? O : C;
+  KGDET_CHECK_SHAPE(taps == 1 || taps == 9, "taps must be 1 (1x1) or 9 (3x3)");
   KGDET_CHECK_SHAPE(O > 0 && C > 0 && K % kTK == 0, "reduction length %d is not a multiple of 16", K);
   KGDET_CHECK_SHAPE(w && packed, "null pointer");
-  const long long total = (long long)((M + kTM - 1) / kTM) * (K / kTK) * 2 * kTM;
-  const int blocks = (int)((total + 255) / 256);
-  hipLaunchKernelGGL(conv1x1_pack, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, M, K, C, transpose,
-                     (unsigned char *)packed);
-  KGDET_CHECK_LAUNCH("conv1x1_pack");
+  const long long total = (long long)((M + kTM - 1) / kTM) * (K / kTK) * taps * 2 * kTM;
+  const long long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(conv1x1_pack, dim3((unsigned)(blocks > 65535 ? 65535 : blocks)), dim3(256), 0, (hipStream_t)stream, w,
+                     O, C, taps, transpose, (unsigned char *)packed);
+  KGDET_CHECK_LAUNCH("conv_pack");
   return KGDET_OK;
 }
 
-extern "C" size_t kgdet_conv1x1_apply_workspace_bytes(int64_t B, int32_t M, int32_t K, int64_t HW) {
-  if (B <= 0 || M <= 0 || K <= 0 || HW <= 0 || K % kTK) return 0;
+extern "C" size_t kgdet_conv_apply_workspace_bytes(int64_t B, int32_t M, int32_t K, int32_t H, int32_t W,
+                                                    int32_t taps) {
+  if (B <= 0 || M <= 0 || K <= 0 || H <= 0 || W <= 0 || K % kTK) return 0;
+  const long long HW = (long long)H * W;
   const long long tiles = (long long)((M + kTM - 1) / kTM) * ((HW + kTN - 1) / kTN) * B;
-  const int ks = nn_ksplit(tiles, K / kTK);
+  const int ks = nn_ksplit(tiles, taps * (K / kTK));
   return ks > 1 ? (size_t)ks * B * M * HW * sizeof(float) : 0;
 }
 
-extern "C" int kgdet_conv1x1_apply(const void *packed, const float *x, float *y, int64_t B, int32_t M, int32_t K,
-                                   int64_t HW, void *workspace, size_t workspace_bytes, void *stream) {
-  KGDET_CHECK_SHAPE(B >= 0 && M > 0 && K > 0 && HW >= 0 && HW < (1LL << 30), "bad sizes");
+extern "C" int kgdet_conv_apply(const void *packed, const float *x, float *y, int64_t B, int32_t M, int32_t K, int32_t H,
+                                int32_t W, int32_t taps, void *workspace, size_t workspace_bytes, void *stream) {
+  KGDET_CHECK_SHAPE(B >= 0 && M > 0 && K > 0 && H >= 0 && W >= 0 && (long long)H * W < (1LL << 30), "bad sizes");
+  KGDET_CHECK_SHAPE(taps == 1 || taps == 9, "taps must be 1 (1x1) or 9 (3x3)");
   KGDET_CHECK_SHAPE(K % kTK == 0, "reduction length %d is not a multiple of 16", K);
+  const long long HW = (long long)H * W;
   if (B * HW == 0) return KGDET_OK;
   KGDET_CHECK_SHAPE(packed && x && y, "null pointer");
   const int n_mt = (M + kTM - 1) / kTM, n_nt = (int)((HW + kTN - 1) / kTN);
   const long long tiles = (long long)n_mt * n_nt * B;
-  KGDET_CHECK_SHAPE(tiles < (1LL << 30), "too many tiles");
-  const int ks = nn_ksplit(tiles, K / kTK);
+  KGDET_CHECK_SHAPE(tiles < (1LL << 28), "too many tiles");
+  const int ks = nn_ksplit(tiles, taps * (K / kTK));
   const long long part_stride = B * M * HW;
   if (ks > 1) {
     KGDET_CHECK_SHAPE(workspace && workspace_bytes >= (size_t)ks * part_stride * sizeof(float), "workspace too small");
     KGDET_CHECK_SHAPE(part_stride % 2 == 0, "B*M*H*W must be even");
   }
   const int per = (int)((tiles * ks + 7) / 8);
-  hipLaunchKernelGGL(conv1x1_nn, dim3(per * 8), dim3(kGemmThreads), 0, (hipStream_t)stream,
-                     (const unsigned char *)packed, x, ks > 1 ? (float *)workspace : y, M, K, (int)HW, n_mt, n_nt,
-                     (int)tiles, ks, part_stride);
-  KGDET_CHECK_LAUNCH("conv1x1_nn");
+  float *dst = ks > 1 ? (float *)workspace : y;
+  if (taps == 1)
+    hipLaunchKernelGGL(conv_nn<1>, dim3(per * 8), dim3(kNNThreads), 0, (hipStream_t)stream,
+                       (const unsigned char *)packed, x, dst, M, K, H, W, n_mt, n_nt, (int)tiles, ks, part_stride);
+  else
+    hipLaunchKernelGGL(conv_nn<9>, dim3(per * 8), dim3(kNNThreads), 0, (hipStream_t)stream,
+                       (const unsigned char *)packed, x, dst, M, K, H, W, n_mt, n_nt, (int)tiles, ks, part_stride);
+  KGDET_CHECK_LAUNCH("conv_nn");
   if (ks > 1) {
     const long long blocks = (part_stride / 2 + 255) / 256;
     hipLaunchKernelGGL(conv1x1_sum, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, (hipStream_t)stream,

@@ -180,22 +180,25 @@ def test_resnet_with_dcn_stages_builds_and_steps():
     assert not hasattr(net.layer1[0], 'conv2_offset')
 
 
+@pytest.mark.parametrize('k', [1, 3])
 @pytest.mark.parametrize('B,C,O,H,W', [(2, 64, 256, 20, 34), (1, 256, 64, 9, 14), (2, 512, 128, 25, 42), (2, 128, 512, 13, 10),
                                        (3, 1024, 256, 6, 8), (2, 2048, 512, 25, 42), (2, 16, 48, 5, 6), (2, 32, 16, 129, 2)])
-def test_conv1x1_split_matches_fp64_convolution(B, C, O, H, W):
+def test_conv1x1_split_matches_fp64_convolution(B, C, O, H, W, k):
     """csrc/conv1x1.hip (bf16 hi/lo-split MFMA GEMMs): forward, grad_input and grad_weight against the fp64
     convolution, to fp32-level accuracy (1e-5 of the result's scale; MIOpen's fp32 kernels sit at ~1e-6); ragged
     pixel tiles, M < 128, the K-split and the 8- and 16-byte load variants of grad_weight."""
     from kgdet_amd import conv1x1 as c1
     g = torch.Generator(device='cpu').manual_seed(C + O + H)
     x = torch.randn(B, C, H, W, generator=g).cuda().requires_grad_()
-    w = (torch.randn(O, C, 1, 1, generator=g) * 0.1).cuda().requires_grad_()
+    if k == 3 and C * O > 512 * 512:
+        pytest.skip('3x3 at 2048 x 512 channels: not a backbone shape')
+    w = (torch.randn(O, C, k, k, generator=g) * 0.1).cuda().requires_grad_()
     gy = torch.randn(B, O, H, W, generator=g).cuda()
-    assert c1.applicable(x, w)
+    assert c1.applicable(x, w, padding=(k // 2, k // 2))
     y = c1.conv1x1(x, w)
     y.backward(gy)
     xd, wd = x.detach().double().requires_grad_(), w.detach().double().requires_grad_()
-    yd = F.conv2d(xd, wd)
+    yd = F.conv2d(xd, wd, padding=k // 2)
     yd.backward(gy.double())
     for name, a, b in (('y', y, yd), ('grad_x', x.grad, xd.grad), ('grad_w', w.grad, wd.grad)):
         err = (a.double() - b).abs().max().item() / b.abs().max().item()
@@ -209,7 +212,7 @@ def test_conv1x1_split_matches_fp64_convolution(B, C, O, H, W):
     x.grad = None; w.grad = None
     c1.conv1x1(x, w).backward(gy)
     assert torch.equal(x.grad, x2g)
-    if (H * W) % 4 == 0:     # otherwise grad_weight is MIOpen's (kgdet_amd/conv1x1.py), which makes no such promise
+    if (H * W) % 4 == 0 and k == 1:     # otherwise grad_weight is MIOpen's (kgdet_amd/conv1x1.py), which makes no such promise
         assert torch.equal(w.grad, w2g)
 
 
@@ -218,7 +221,9 @@ def test_conv1x1_not_applicable_cases_fall_back():
     x = torch.randn(2, 64, 8, 8, device='cuda')
     w = torch.randn(32, 64, 1, 1, device='cuda')
     assert c1.applicable(x, w) and not c1.applicable(x, w, stride=(2, 2)) and not c1.applicable(x.half(), w.half())
-    assert not c1.applicable(x, torch.randn(32, 64, 3, 3, device='cuda'), padding=(1, 1))
+    w3 = torch.randn(32, 64, 3, 3, device='cuda')
+    assert c1.applicable(x, w3, padding=(1, 1)) and not c1.applicable(x, w3) and not c1.applicable(x, w3, padding=(1, 1), dilation=(2, 2))
+    assert not c1.applicable(x, w3, stride=(2, 2), padding=(1, 1)) and not c1.applicable(x, torch.randn(32, 64, 5, 5, device='cuda'), padding=(2, 2))
     assert not c1.applicable(torch.randn(2, 40, 8, 8, device='cuda'), torch.randn(32, 40, 1, 1, device='cuda'))
     assert not c1.applicable(torch.randn(2, 64, 3, 3, device='cuda'), w)          # odd H*W
     with torch.autocast('cuda', dtype=torch.bfloat16):
