@@ -269,14 +269,30 @@ __global__ __launch_bounds__(256) void conv1x1_sum(const float *__restrict__ par
   }
 }
 
+// 3x3 grad_weight: out[o][c][t] = sum_s parts[s][o][t * C + c]  (the NT kernel's columns are (tap, channel))
+__global__ __launch_bounds__(256) void conv3x3_wsum(const float *__restrict__ parts, float *__restrict__ out, int O, int C,
+                                                    int count) {
+  const long long n = (long long)O * C * 9;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += gridDim.x * 256LL) {
+    const int o = (int)(i / (9 * C)), rem = (int)(i - (long long)o * 9 * C), t = rem / C, ch = rem - t * C;
+    float s = 0.0f;
+    for (int k = 0; k < count; ++k) s += parts[(long long)k * n + i];
+    out[((long long)o * C + ch) * 9 + t] = s;
+  }
+}
+
 // partial[split][m][n] (natural [M, N] layout) = sum over this split's pixels (and images) of a[b][m][px] * bm[b][n][px]
 // a [B, M, L], bm [B, N, L], L contiguous.  The B * ceil(L / 16) stages are cut into `splits` runs of `per` stages; a
 // stage never straddles two images (the tail of an image is zero-filled).  VEC = floats per load (4 when L % 4 == 0).
-template <int VEC>
-__global__ __launch_bounds__(kGemmThreads) void conv1x1_nt(const float *__restrict__ a, const float *__restrict__ bm,
-                                                           float *__restrict__ partial, int M, int N, int L, int B,
-                                                           int n_mt, int n_nt, int stages_per_image, int per) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * kStage];
+template <int VEC, int TAPS, int DX>
+__device__ __forceinline__ void conv1x1_nt_body(const float *__restrict__ a, const float *__restrict__ bm,
+                                                float *__restrict__ partial, int M, int N, int L, int B, int n_mt,
+                                                int n_nt, int stages_per_image, int per, int H, int W, int Cin,
+                                                unsigned char *smem) {
+  // TAPS == 9 (3x3, stride 1, padding 1): column n = t * Cin + c of the [M, 9 * Cin] result pairs a[.][m][p] with
+  // bm[.][c][p + shift(t)] (zero outside the image); Cin % 128 == 0, so a tile has ONE tap, and W % 4 == 0, so the
+  // row part of the shift keeps 16-byte alignment: a thread's 8 shifted pixels come out of three aligned 4-pixel loads.
+  // DX (the tap's column shift, uniform per tile) is a template parameter so that the selection has static indices.
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
   const int tile = blockIdx.x % (n_mt * n_nt), split = blockIdx.x / (n_mt * n_nt);
   const int mt = tile % n_mt, nt = tile / n_mt;
@@ -284,8 +300,17 @@ __global__ __launch_bounds__(kGemmThreads) void conv1x1_nt(const float *__restri
   const int row = tid >> 1, khalf = tid & 1;
   const int total = B * stages_per_image;
   const int s_begin = split * per, s_end = min(total, s_begin + per);
-  const int am = min(mt * kTM + row, M - 1), bn = min(nt * kTN + row, N - 1);
-  const bool a_real = mt * kTM + row < M, b_real = nt * kTN + row < N;
+  const int am = min(mt * kTM + row, M - 1);
+  const bool a_real = mt * kTM + row < M;
+  const int tap = TAPS == 9 ? (nt * kTN) / Cin : 0;
+  const int dy = TAPS == 9 ? tap / 3 - 1 : 0;
+  constexpr int dx = DX;
+  const int bcols = TAPS == 9 ? Cin : N;                               // rows of bm per image
+  const int bn_raw = TAPS == 9 ? nt * kTN - tap * Cin + row : nt * kTN + row;
+  const int bn = min(bn_raw, bcols - 1);
+  const bool b_real = bn_raw < bcols;
+  constexpr int off = dx < 0 ? -4 : 0, sh = dx - off;                  // element j of the 8 = loaded element j + sh
+  const float inv_w = 1.0f / (float)W;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -296,40 +321,69 @@ __global__ __launch_bounds__(kGemmThreads) void conv1x1_nt(const float *__restri
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   struct Regs {
-    float va[8], vb[8];
+    float va[8], vb[TAPS == 9 ? 12 : 8];
     int valid;   // pixels of this thread's 8 that exist (tail of an image)
+    int p0;
   };
   auto issue = [&](int s, Regs &R) {
     const int sc = min(s, s_end - 1);
     const int img = sc / stages_per_image, st = sc - img * stages_per_image;
     const int p0 = st * kTK + khalf * 8;
     R.valid = min(8, L - p0);
-    const float *ap = a + ((long long)img * M + am) * L, *bp = bm + ((long long)img * N + bn) * L;
+    R.p0 = p0;
+    const float *ap = a + ((long long)img * M + am) * L, *bp = bm + ((long long)img * bcols + bn) * L;
 #pragma unroll
     for (int j = 0; j < 8; j += VEC) {   // L % VEC == 0: the loads stay aligned; clamped at the image's end
       const int p = min(p0 + j, L - VEC);
-      const vec_t u = *reinterpret_cast<const vec_t *>(ap + p), w = *reinterpret_cast<const vec_t *>(bp + p);
+      const vec_t u = *reinterpret_cast<const vec_t *>(ap + p);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        R.va[j + e] = u[e];
-        R.vb[j + e] = w[e];
+      for (int e = 0; e < VEC; ++e) R.va[j + e] = u[e];
+      if (TAPS == 1) {
+        const vec_t w = *reinterpret_cast<const vec_t *>(bp + p);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) R.vb[j + e] = w[e];
+      }
+    }
+    if (TAPS == 9) {
+      const int base = p0 + dy * W + off;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {   // clamped chunks hold wrong pixels only where the tap is outside the image
+        const int q = min(max(base + 4 * k, 0), L - 4);
+        const f32x4 w = *reinterpret_cast<const f32x4 *>(bp + q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) R.vb[4 * k + e] = w[e];
       }
     }
   };
   auto commit = [&](int buf, Regs &R) {
     unsigned char *As = smem + buf * 2 * kStage, *Bs = As + kStage;
+    float vb[8];
+    if (TAPS == 9) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const bool ok = j < R.valid;
-      R.va[j] = (ok && a_real) ? R.va[j] : 0.0f;
-      R.vb[j] = (ok && b_real) ? R.vb[j] : 0.0f;
+      for (int j = 0; j < 8; ++j) vb[j] = R.vb[j + (TAPS == 9 ? sh : 0)];
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {   // a 4-pixel chunk lies in one image row (W % 4 == 0)
+        const int p = R.p0 + 4 * ch;
+        const int h = (int)(((float)p + 0.5f) * inv_w), w = p - h * W;
+        const bool row_ok = p < L && h + dy >= 0 && h + dy < H && b_real;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int col = w + i + dx;
+          vb[4 * ch + i] = (row_ok && col >= 0 && col < W) ? vb[4 * ch + i] : 0.0f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vb[j] = (j < R.valid && b_real) ? R.vb[j] : 0.0f;
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) R.va[j] = (j < R.valid && a_real) ? R.va[j] : 0.0f;
     bf16x8 hi, lo;
     split8(R.va, hi, lo);
     unsigned char *dst = As + khalf * (kTM * 16) + row * 16;
     *reinterpret_cast<bf16x8 *>(dst) = hi;
     *reinterpret_cast<bf16x8 *>(dst + kPart) = lo;
-    split8(R.vb, hi, lo);
+    split8(vb, hi, lo);
     dst = Bs + khalf * (kTN * 16) + row * 16;
     *reinterpret_cast<bf16x8 *>(dst) = hi;
     *reinterpret_cast<bf16x8 *>(dst + kPart) = lo;
@@ -376,6 +430,23 @@ __global__ __launch_bounds__(kGemmThreads) void conv1x1_nt(const float *__restri
         if (m < M && nn < N) out[(long long)m * N + nn] = acc[mi][ni][r];
       }
     }
+}
+
+template <int VEC, int TAPS>
+__global__ __launch_bounds__(kGemmThreads) void conv1x1_nt(const float *__restrict__ a, const float *__restrict__ bm,
+                                                           float *__restrict__ partial, int M, int N, int L, int B,
+                                                           int n_mt, int n_nt, int stages_per_image, int per, int H,
+                                                           int W, int Cin) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * kStage];
+  if (TAPS == 9) {
+    const int tile = blockIdx.x % (n_mt * n_nt), nt = tile / n_mt;
+    const int dx = ((nt * kTN) / Cin) % 3 - 1;   // uniform: one tap per tile
+    if (dx < 0) conv1x1_nt_body<VEC, TAPS, -1>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, smem);
+    else if (dx == 0) conv1x1_nt_body<VEC, TAPS, 0>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, smem);
+    else conv1x1_nt_body<VEC, TAPS, 1>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, smem);
+  } else {
+    conv1x1_nt_body<VEC, TAPS, 0>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, smem);
+  }
 }
 
 namespace {
@@ -490,16 +561,49 @@ extern "C" int kgdet_conv1x1_grad_weight(const float *grad_y, const float *x, fl
   const int per = (total + splits - 1) / splits;
   KGDET_CHECK_SHAPE(((long long)O * C) % 2 == 0, "O*C must be even");
   if (HW % 4 == 0)
-    hipLaunchKernelGGL(conv1x1_nt<4>, dim3(tiles * splits), dim3(kGemmThreads), 0, (hipStream_t)stream, grad_y, x,
-                       (float *)workspace, O, C, (int)HW, (int)B, n_mt, n_nt, spi, per);
+    hipLaunchKernelGGL((conv1x1_nt<4, 1>), dim3(tiles * splits), dim3(kGemmThreads), 0, (hipStream_t)stream, grad_y, x,
+                       (float *)workspace, O, C, (int)HW, (int)B, n_mt, n_nt, spi, per, 0, 0, 0);
   else
-    hipLaunchKernelGGL(conv1x1_nt<2>, dim3(tiles * splits), dim3(kGemmThreads), 0, (hipStream_t)stream, grad_y, x,
-                       (float *)workspace, O, C, (int)HW, (int)B, n_mt, n_nt, spi, per);
+    hipLaunchKernelGGL((conv1x1_nt<2, 1>), dim3(tiles * splits), dim3(kGemmThreads), 0, (hipStream_t)stream, grad_y, x,
+                       (float *)workspace, O, C, (int)HW, (int)B, n_mt, n_nt, spi, per, 0, 0, 0);
   KGDET_CHECK_LAUNCH("conv1x1_nt");
   const long long n = (long long)O * C;
   const long long blocks = (n / 2 + 255) / 256;
   hipLaunchKernelGGL(conv1x1_sum, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, (hipStream_t)stream,
                      (const float *)workspace, grad_w, n, n, splits);
   KGDET_CHECK_LAUNCH("conv1x1_sum");
+  return KGDET_OK;
+}
+
+extern "C" size_t kgdet_conv3x3_grad_weight_workspace_bytes(int64_t B, int32_t O, int32_t C, int32_t H, int32_t W) {
+  if (B <= 0 || O <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+  const int tiles = ((O + kTM - 1) / kTM) * (9 * C / kTN);
+  const int stages = (int)(B * (((long long)H * W + kTK - 1) / kTK));
+  return (size_t)nt_splits(tiles, stages) * O * C * 9 * sizeof(float);
+}
+
+extern "C" int kgdet_conv3x3_grad_weight(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O,
+                                         int32_t C, int32_t H, int32_t W, void *workspace, size_t workspace_bytes,
+                                         void *stream) {
+  KGDET_CHECK_SHAPE(B > 0 && O > 0 && C > 0 && H > 0 && W > 0 && (long long)H * W < (1LL << 23), "bad sizes");
+  if (C % kTN != 0 || W % 4 != 0) {
+    set_error("conv3x3_grad_weight needs C %% 128 == 0 and W %% 4 == 0 (C=%d, W=%d)", C, W);
+    return KGDET_E_UNSUPPORTED;
+  }
+  KGDET_CHECK_SHAPE(grad_y && x && grad_w && workspace, "null pointer");
+  KGDET_CHECK_SHAPE(workspace_bytes >= kgdet_conv3x3_grad_weight_workspace_bytes(B, O, C, H, W), "workspace too small");
+  const int HW = H * W;
+  const int n_mt = (O + kTM - 1) / kTM, n_nt = 9 * C / kTN, tiles = n_mt * n_nt;
+  const int spi = (HW + kTK - 1) / kTK, total = (int)(B * spi);
+  const int splits = nt_splits(tiles, total);
+  const int per = (total + splits - 1) / splits;
+  hipLaunchKernelGGL((conv1x1_nt<4, 9>), dim3(tiles * splits), dim3(kGemmThreads), 0, (hipStream_t)stream, grad_y, x,
+                     (float *)workspace, O, 9 * C, HW, (int)B, n_mt, n_nt, spi, per, H, W, C);
+  KGDET_CHECK_LAUNCH("conv1x1_nt<4, 9>");
+  const long long n = (long long)O * C * 9;
+  const long long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(conv3x3_wsum, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream,
+                     (const float *)workspace, grad_w, O, C, splits);
+  KGDET_CHECK_LAUNCH("conv3x3_wsum");
   return KGDET_OK;
 }

@@ -182,12 +182,14 @@ def test_resnet_with_dcn_stages_builds_and_steps():
 
 @pytest.mark.parametrize('k', [1, 3])
 @pytest.mark.parametrize('B,C,O,H,W', [(2, 64, 256, 20, 34), (1, 256, 64, 9, 14), (2, 512, 128, 25, 42), (2, 128, 512, 13, 10),
-                                       (3, 1024, 256, 6, 8), (2, 2048, 512, 25, 42), (2, 16, 48, 5, 6), (2, 32, 16, 129, 2)])
-def test_conv1x1_split_matches_fp64_convolution(B, C, O, H, W, k):
+                                       (3, 1024, 256, 6, 8), (2, 2048, 512, 25, 42), (2, 16, 48, 5, 6), (2, 32, 16, 129, 2),
+                                       (2, 128, 128, 30, 44), (2, 256, 128, 9, 84), (1, 128, 256, 7, 4)])
+def test_conv1x1_split_matches_fp64_convolution(B, C, O, H, W, k, monkeypatch):
     """csrc/conv1x1.hip (bf16 hi/lo-split MFMA GEMMs): forward, grad_input and grad_weight against the fp64
     convolution, to fp32-level accuracy (1e-5 of the result's scale; MIOpen's fp32 kernels sit at ~1e-6); ragged
     pixel tiles, M < 128, the K-split and the 8- and 16-byte load variants of grad_weight."""
     from kgdet_amd import conv1x1 as c1
+    monkeypatch.setattr(c1, 'SPLIT_GRAD_WEIGHT_3X3', True)     # exercise the 3x3 grad_weight kernel too
     g = torch.Generator(device='cpu').manual_seed(C + O + H)
     x = torch.randn(B, C, H, W, generator=g).cuda().requires_grad_()
     if k == 3 and C * O > 512 * 512:
@@ -212,7 +214,7 @@ def test_conv1x1_split_matches_fp64_convolution(B, C, O, H, W, k):
     x.grad = None; w.grad = None
     c1.conv1x1(x, w).backward(gy)
     assert torch.equal(x.grad, x2g)
-    if (H * W) % 4 == 0 and k == 1:     # otherwise grad_weight is MIOpen's (kgdet_amd/conv1x1.py), which makes no such promise
+    if (H * W) % 4 == 0 and (k == 1 or (C % 128 == 0 and W % 4 == 0)):     # otherwise grad_weight is MIOpen's (kgdet_amd/conv1x1.py), which makes no such promise
         assert torch.equal(w.grad, w2g)
 
 
