@@ -180,11 +180,17 @@ def conv_bn(conv, bn, x, relu=False, residual=None):
         w = (conv.weight * scale.view(-1, 1, 1, 1)).detach()
         if bf16:
             w = w.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        hit = (weakref.ref(conv), w, shift.detach().float().contiguous())
+        packed = None
+        if not bf16 and conv1x1.applicable(x, w, conv.stride, conv.padding, conv.dilation, conv.groups):
+            packed = conv1x1._pack(w.contiguous(), False)     # fp32 inference: split-bf16 MFMA kernels, packed once
+        hit = (weakref.ref(conv), w, shift.detach().float().contiguous(), packed)
         _fold_cache[(id(conv), bf16)] = hit
     if bf16 and not x.is_contiguous(memory_format=torch.channels_last):
         x = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    out = F.conv2d(x, hit[1], None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    if hit[3] is not None and x.dtype == torch.float32 and x.is_contiguous() and x.shape[2] * x.shape[3] % 2 == 0:
+        out = conv1x1._apply(hit[3], x, hit[1].shape[0], hit[1].shape[2] * hit[1].shape[3])
+    else:
+        out = F.conv2d(x, hit[1], None, conv.stride, conv.padding, conv.dilation, conv.groups)
     return _epilogue_(out, hit[2], residual, relu)
 
 
