@@ -14,6 +14,8 @@ from . import _lib
 # The 3x3 grad_weight kernel (conv1x1_nt<4, 9>) is correct but, at 136-145 us for the layer-2 / layer-3 shapes, slower
 # than MIOpen's implicit-GEMM wrw (110 us): off by default, kept for the tests and for the next round's work on it.
 SPLIT_GRAD_WEIGHT_3X3 = False
+import os as _os
+PACK_BOTH = _os.environ.get('KGDET_PACK_BOTH', '1') == '1'
 
 
 def applicable(x, weight, stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1):
@@ -46,6 +48,19 @@ def _pack(weight, transpose):
     return img
 
 
+def _pack_both(weight):
+    """forward and grad_input images of one weight in one launch"""
+    L = _lib_sizes()
+    O, C, taps = weight.shape[0], weight.shape[1], weight.shape[2] * weight.shape[3]
+    n0 = L.kgdet_conv_packed_bytes(ctypes.c_int32(O), ctypes.c_int32(C), ctypes.c_int32(taps))
+    n1 = L.kgdet_conv_packed_bytes(ctypes.c_int32(C), ctypes.c_int32(O), ctypes.c_int32(taps))
+    img = torch.empty(n0, dtype=torch.uint8, device=weight.device)
+    img_t = torch.empty(n1, dtype=torch.uint8, device=weight.device)
+    _lib.check(L.kgdet_conv_pack_both(_lib.ptr(weight), ctypes.c_int32(O), ctypes.c_int32(C), ctypes.c_int32(taps),
+                                      _lib.ptr(img), _lib.ptr(img_t), _lib.current_stream()), 'conv_pack_both')
+    return img, img_t
+
+
 def _apply(img, x, M, taps):
     L = _lib_sizes()
     B, K, H, W = x.shape
@@ -63,8 +78,12 @@ class _ConvSplit(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
         weight = weight.contiguous()
+        if PACK_BOTH and x.requires_grad and weight.shape[0] % 16 == 0:
+            img, ctx.img_t = _pack_both(weight)       # the backward's operand image comes out of the same launch
+        else:
+            img, ctx.img_t = _pack(weight, False), None
         ctx.save_for_backward(x, weight)
-        return _apply(_pack(weight, False), x, weight.shape[0], weight.shape[2] * weight.shape[3])
+        return _apply(img, x, weight.shape[0], weight.shape[2] * weight.shape[3])
 
     @staticmethod
     def backward(ctx, gy):
@@ -73,7 +92,7 @@ class _ConvSplit(torch.autograd.Function):
         O, C, k = weight.shape[0], weight.shape[1], weight.shape[2]
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = _apply(_pack(weight, True), gy, C, k * k)
+            gx = _apply(ctx.img_t if ctx.img_t is not None else _pack(weight, True), gy, C, k * k)
         if ctx.needs_input_grad[1] and k == 3 and SPLIT_GRAD_WEIGHT_3X3 and C % 128 == 0 and x.shape[3] % 4 == 0:
             L = _lib_sizes()
             B, H, W = x.shape[0], x.shape[2], x.shape[3]

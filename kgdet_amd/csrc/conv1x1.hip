@@ -81,8 +81,14 @@ __device__ __forceinline__ int xcd_tile(int b, int tiles) {
 // image[mt][k16 * T + t][part][khalf][128][8].
 //   transpose = 0 (forward):    rows = O, reduction = C:  A[o][(c, t)] = w[o][c][t]
 //   transpose = 1 (grad_input): rows = C, reduction = O:  A[c][(o, t)] = w[o][c][T - 1 - t]   (taps mirrored)
+// gridDim.y == 2: block row 0 writes the forward image to img, row 1 the grad_input image to img_t (one launch per
+// convolution and step instead of two).
 __global__ __launch_bounds__(256) void conv1x1_pack(const float *__restrict__ w, int O, int C, int T, int transpose,
-                                                    unsigned char *__restrict__ img) {
+                                                    unsigned char *__restrict__ img, unsigned char *__restrict__ img_t) {
+  if (gridDim.y == 2) {
+    transpose = blockIdx.y;
+    img = blockIdx.y ? img_t : img;
+  }
   const int M = transpose ? C : O, K = transpose ? O : C;
   const int k16s = K / kTK;
   const long long total = (long long)((M + kTM - 1) / kTM) * k16s * T * 2 * kTM;   // (mt, k16, t, khalf, row)
@@ -492,8 +498,22 @@ extern "C" int kgdet_conv_pack(const float *w, int32_t O, int32_t C, int32_t tap
   const long long total = (long long)((M + kTM - 1) / kTM) * (K / kTK) * taps * 2 * kTM;
   const long long blocks = (total + 255) / 256;
   hipLaunchKernelGGL(conv1x1_pack, dim3((unsigned)(blocks > 65535 ? 65535 : blocks)), dim3(256), 0, (hipStream_t)stream, w,
-                     O, C, taps, transpose, (unsigned char *)packed);
+                     O, C, taps, transpose, (unsigned char *)packed, (unsigned char *)nullptr);
   KGDET_CHECK_LAUNCH("conv_pack");
+  return KGDET_OK;
+}
+
+extern "C" int kgdet_conv_pack_both(const float *w, int32_t O, int32_t C, int32_t taps, void *packed, void *packed_t,
+                                    void *stream) {
+  KGDET_CHECK_SHAPE(taps == 1 || taps == 9, "taps must be 1 (1x1) or 9 (3x3)");
+  KGDET_CHECK_SHAPE(O > 0 && C > 0 && O % kTK == 0 && C % kTK == 0, "O and C must be multiples of 16");
+  KGDET_CHECK_SHAPE(w && packed && packed_t, "null pointer");
+  const long long t0 = (long long)((O + kTM - 1) / kTM) * (C / kTK) * taps * 2 * kTM;
+  const long long t1 = (long long)((C + kTM - 1) / kTM) * (O / kTK) * taps * 2 * kTM;
+  const long long blocks = ((t0 > t1 ? t0 : t1) + 255) / 256;
+  hipLaunchKernelGGL(conv1x1_pack, dim3((unsigned)(blocks > 32768 ? 32768 : blocks), 2), dim3(256), 0,
+                     (hipStream_t)stream, w, O, C, taps, 0, (unsigned char *)packed, (unsigned char *)packed_t);
+  KGDET_CHECK_LAUNCH("conv_pack_both");
   return KGDET_OK;
 }
 
