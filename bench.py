@@ -61,7 +61,7 @@ HBM_PEAK_GBS = 8000.0
 PLANE_GROUP_TRAFFIC_BYTES = 1.019e9  # profiles/r01_dcn_fwd_plane_group_b2.md: (2 x FETCH_SIZE + WRITE_SIZE) of the 3 kernels
 
 
-def dcn_roofline(device, iters=30):
+def dcn_roofline(device, iters=20):
     """DeformConv forward of ONE KGDet head stage at batch 2: the grouped launch of 2 feature maps x
     (3x3, 5x5, 7x7) on [2, 256, 25, 42] (kgdet_deform_conv_forward_grouped: dcn_build_taps + dcn_fwd_plane +
     dcn_fwd_fixup), HIP-event timing on the launch stream.  The products are bf16 MFMAs on a hi/lo split of
@@ -78,13 +78,18 @@ def dcn_roofline(device, iters=30):
     with torch.no_grad():     # weight images are packed once (inference path); training re-packs every step
         for _ in range(5):
             dcn.deform_conv_cat_multi(xs, offs, ws, pads)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(iters):
-            dcn.deform_conv_cat_multi(xs, offs, ws, pads)
-        e1.record(stream)
-    torch.cuda.synchronize()
-    t = e0.elapsed_time(e1) / iters * 1e-3
+        # five event-bracketed runs of `iters` launches, median run: a host hiccup between two launches (the
+        # launch sequence is enqueued from Python) would otherwise be billed to the kernel
+        times = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(iters):
+                dcn.deform_conv_cat_multi(xs, offs, ws, pads)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1) / iters * 1e-3)
+    t = sorted(times)[len(times) // 2]
     flops = sum(2.0 * C * C * k * k * B * H * W for k in ks) * len(xs)
     byts = sum(4.0 * (2 * B * C * H * W + 2 * B * k * k * H * W + C * C * k * k) for k in ks) * len(xs)
     ach = flops / t / 1e12
