@@ -27,12 +27,42 @@ def applicable(x, weight, stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups
             and (x.shape[2] * x.shape[3]) % 2 == 0 and not torch.is_autocast_enabled())
 
 
+_L = None
+_sizes = {}     # (query, args) -> bytes: the workspace / image sizes depend on the shape only
+
+
 def _lib_sizes():
-    L = _lib.lib()
-    for name in ('kgdet_conv_packed_bytes', 'kgdet_conv_apply_workspace_bytes',
-                 'kgdet_conv1x1_grad_weight_workspace_bytes', 'kgdet_conv3x3_grad_weight_workspace_bytes'):
-        getattr(L, name).restype = ctypes.c_size_t
-    return L
+    """the library with argtypes declared once (plain Python ints / pointers marshal ~3x faster than c_int objects)"""
+    global _L
+    if _L is None:
+        L = _lib.lib()
+        vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
+        for name, res, args in (
+                ('kgdet_conv_packed_bytes', sz, [i32, i32, i32]),
+                ('kgdet_conv_apply_workspace_bytes', sz, [i64, i32, i32, i32, i32, i32]),
+                ('kgdet_conv1x1_grad_weight_workspace_bytes', sz, [i64, i32, i32, i64]),
+                ('kgdet_conv3x3_grad_weight_workspace_bytes', sz, [i64, i32, i32, i32, i32]),
+                ('kgdet_conv_pack', ctypes.c_int, [vp, i32, i32, i32, i32, vp, vp]),
+                ('kgdet_conv_pack_both', ctypes.c_int, [vp, i32, i32, i32, vp, vp, vp]),
+                ('kgdet_conv_apply', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i32, i32, i32, vp, sz, vp]),
+                ('kgdet_conv1x1_grad_weight', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i64, vp, sz, vp]),
+                ('kgdet_conv3x3_grad_weight', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i32, i32, vp, sz, vp])):
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _L = L
+    return _L
+
+
+def _size(name, *args):
+    key = (name, args)
+    n = _sizes.get(key)
+    if n is None:
+        n = _sizes[key] = getattr(_lib_sizes(), name)(*args)
+    return n
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
 
 
 def _pack(weight, transpose):
@@ -40,10 +70,8 @@ def _pack(weight, transpose):
     L = _lib_sizes()
     O, C, taps = weight.shape[0], weight.shape[1], weight.shape[2] * weight.shape[3]
     M, K = (C, O) if transpose else (O, C)
-    nbytes = L.kgdet_conv_packed_bytes(ctypes.c_int32(M), ctypes.c_int32(K), ctypes.c_int32(taps))
-    img = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
-    _lib.check(L.kgdet_conv_pack(_lib.ptr(weight), ctypes.c_int32(O), ctypes.c_int32(C), ctypes.c_int32(taps),
-                                 ctypes.c_int32(1 if transpose else 0), _lib.ptr(img), _lib.current_stream()),
+    img = torch.empty(_size('kgdet_conv_packed_bytes', M, K, taps), dtype=torch.uint8, device=weight.device)
+    _lib.check(L.kgdet_conv_pack(weight.data_ptr(), O, C, taps, 1 if transpose else 0, img.data_ptr(), _stream()),
                'conv_pack')
     return img
 
@@ -52,12 +80,10 @@ def _pack_both(weight):
     """forward and grad_input images of one weight in one launch"""
     L = _lib_sizes()
     O, C, taps = weight.shape[0], weight.shape[1], weight.shape[2] * weight.shape[3]
-    n0 = L.kgdet_conv_packed_bytes(ctypes.c_int32(O), ctypes.c_int32(C), ctypes.c_int32(taps))
-    n1 = L.kgdet_conv_packed_bytes(ctypes.c_int32(C), ctypes.c_int32(O), ctypes.c_int32(taps))
-    img = torch.empty(n0, dtype=torch.uint8, device=weight.device)
-    img_t = torch.empty(n1, dtype=torch.uint8, device=weight.device)
-    _lib.check(L.kgdet_conv_pack_both(_lib.ptr(weight), ctypes.c_int32(O), ctypes.c_int32(C), ctypes.c_int32(taps),
-                                      _lib.ptr(img), _lib.ptr(img_t), _lib.current_stream()), 'conv_pack_both')
+    img = torch.empty(_size('kgdet_conv_packed_bytes', O, C, taps), dtype=torch.uint8, device=weight.device)
+    img_t = torch.empty(_size('kgdet_conv_packed_bytes', C, O, taps), dtype=torch.uint8, device=weight.device)
+    _lib.check(L.kgdet_conv_pack_both(weight.data_ptr(), O, C, taps, img.data_ptr(), img_t.data_ptr(), _stream()),
+               'conv_pack_both')
     return img, img_t
 
 
@@ -65,12 +91,10 @@ def _apply(img, x, M, taps):
     L = _lib_sizes()
     B, K, H, W = x.shape
     y = torch.empty((B, M, H, W), dtype=torch.float32, device=x.device)
-    nbytes = L.kgdet_conv_apply_workspace_bytes(ctypes.c_int64(B), ctypes.c_int32(M), ctypes.c_int32(K),
-                                                ctypes.c_int32(H), ctypes.c_int32(W), ctypes.c_int32(taps))
+    nbytes = _size('kgdet_conv_apply_workspace_bytes', B, M, K, H, W, taps)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
-    _lib.check(L.kgdet_conv_apply(_lib.ptr(img), _lib.ptr(x), _lib.ptr(y), ctypes.c_int64(B), ctypes.c_int32(M),
-                                  ctypes.c_int32(K), ctypes.c_int32(H), ctypes.c_int32(W), ctypes.c_int32(taps),
-                                  _lib.ptr(ws), ctypes.c_size_t(nbytes), _lib.current_stream()), 'conv_apply')
+    _lib.check(L.kgdet_conv_apply(img.data_ptr(), x.data_ptr(), y.data_ptr(), B, M, K, H, W, taps,
+                                  ws.data_ptr() if nbytes else None, nbytes, _stream()), 'conv_apply')
     return y
 
 
@@ -96,28 +120,22 @@ class _ConvSplit(torch.autograd.Function):
         if ctx.needs_input_grad[1] and k == 3 and SPLIT_GRAD_WEIGHT_3X3 and C % 128 == 0 and x.shape[3] % 4 == 0:
             L = _lib_sizes()
             B, H, W = x.shape[0], x.shape[2], x.shape[3]
-            nbytes = L.kgdet_conv3x3_grad_weight_workspace_bytes(ctypes.c_int64(B), ctypes.c_int32(O), ctypes.c_int32(C),
-                                                                 ctypes.c_int32(H), ctypes.c_int32(W))
+            nbytes = _size('kgdet_conv3x3_grad_weight_workspace_bytes', B, O, C, H, W)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
             gw = torch.empty_like(weight)
-            _lib.check(L.kgdet_conv3x3_grad_weight(_lib.ptr(gy), _lib.ptr(x), _lib.ptr(gw), ctypes.c_int64(B),
-                                                   ctypes.c_int32(O), ctypes.c_int32(C), ctypes.c_int32(H),
-                                                   ctypes.c_int32(W), _lib.ptr(ws), ctypes.c_size_t(nbytes),
-                                                   _lib.current_stream()), 'conv3x3_grad_weight')
+            _lib.check(L.kgdet_conv3x3_grad_weight(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), B, O, C, H, W,
+                                                   ws.data_ptr(), nbytes, _stream()), 'conv3x3_grad_weight')
         elif ctx.needs_input_grad[1] and (k != 1 or (x.shape[2] * x.shape[3]) % 4 != 0):
             # other 3x3 shapes, and the 8-byte-load variant of the 1x1 kernel (small odd maps, e.g. 25 x 42): MIOpen
             gw = torch.nn.grad.conv2d_weight(x, weight.shape, gy, padding=k // 2)
         elif ctx.needs_input_grad[1]:
             L = _lib_sizes()
             B, HW = x.shape[0], x.shape[2] * x.shape[3]
-            nbytes = L.kgdet_conv1x1_grad_weight_workspace_bytes(ctypes.c_int64(B), ctypes.c_int32(O),
-                                                                 ctypes.c_int32(C), ctypes.c_int64(HW))
+            nbytes = _size('kgdet_conv1x1_grad_weight_workspace_bytes', B, O, C, HW)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
             gw = torch.empty_like(weight)
-            _lib.check(L.kgdet_conv1x1_grad_weight(_lib.ptr(gy), _lib.ptr(x), _lib.ptr(gw), ctypes.c_int64(B),
-                                                   ctypes.c_int32(O), ctypes.c_int32(C), ctypes.c_int64(HW),
-                                                   _lib.ptr(ws), ctypes.c_size_t(nbytes), _lib.current_stream()),
-                       'conv1x1_grad_weight')
+            _lib.check(L.kgdet_conv1x1_grad_weight(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), B, O, C, HW,
+                                                   ws.data_ptr(), nbytes, _stream()), 'conv1x1_grad_weight')
         return gx, gw
 
 

@@ -10,7 +10,7 @@ for B, C, O, H, W in shapes:
     gy = torch.randn(B, O, H, W, device='cuda')
     def run():
         w.grad = None
-        y = c1._Conv1x1.apply(x, w); y.backward(gy)
+        y = c1._ConvSplit.apply(x, w); y.backward(gy)
     for _ in range(3): run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     L = c1._lib_sizes()
