@@ -11,10 +11,11 @@ import torch
 from . import _lib
 
 
-# The 3x3 grad_weight kernel (conv1x1_nt<4, 9>) is correct but, at 136-145 us for the layer-2 / layer-3 shapes, slower
-# than MIOpen's implicit-GEMM wrw (110 us): off by default, kept for the tests and for the next round's work on it.
-SPLIT_GRAD_WEIGHT_3X3 = False
+# The 3x3 grad_weight kernel (conv_nt8<9>): 95-104 us for the layer-2 / layer-3 shapes against MIOpen's implicit-GEMM
+# wrw at 110 us + its layout transposes and output zeroing (~175 us in the step profile).  KGDET_SPLIT_WGRAD3=0 and
+# KGDET_PACK_BOTH=0 switch back for A/B measurements.
 import os as _os
+SPLIT_GRAD_WEIGHT_3X3 = _os.environ.get('KGDET_SPLIT_WGRAD3', '1') == '1'
 PACK_BOTH = _os.environ.get('KGDET_PACK_BOTH', '1') == '1'
 
 

@@ -455,6 +455,157 @@ __global__ __launch_bounds__(kGemmThreads) void conv1x1_nt(const float *__restri
   }
 }
 
+// conv_nt8: grad_weight with 512 threads (8 waves as 2 x 4, 64 x 32 outputs each, two per SIMD) for maps with
+// H*W % 4 == 0.  A thread owns (row, 4-pixel quarter of the stage): one 16-byte load per operand (TAPS == 9 with a
+// column shift: two aligned loads + a static selection), 8-byte LDS writes.  Same partial / sum scheme as conv1x1_nt.
+template <int TAPS, int DX>
+__device__ __forceinline__ void conv_nt8_body(const float *__restrict__ a, const float *__restrict__ bm,
+                                              float *__restrict__ partial, int M, int N, int L, int B, int n_mt, int n_nt,
+                                              int stages_per_image, int per, int H, int W, int Cin, unsigned char *smem) {
+  const int tile = blockIdx.x % (n_mt * n_nt), split = blockIdx.x / (n_mt * n_nt);
+  const int mt = tile % n_mt, nt = tile / n_mt;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
+  const int row = tid >> 2, q = tid & 3;
+  const int total = B * stages_per_image;
+  const int s_begin = split * per, s_end = min(total, s_begin + per);
+  const int am = min(mt * kTM + row, M - 1);
+  const bool a_real = mt * kTM + row < M;
+  const int tap = TAPS == 9 ? (nt * kTN) / Cin : 0;
+  const int dy = TAPS == 9 ? tap / 3 - 1 : 0;
+  constexpr int dx = DX, off = dx < 0 ? -4 : 0, sh = dx - off;
+  constexpr int NB = (TAPS == 9 && dx != 0) ? 8 : 4;                   // floats of bm a thread loads per stage
+  const int bcols = TAPS == 9 ? Cin : N;
+  const int bn_raw = TAPS == 9 ? nt * kTN - tap * Cin + row : nt * kTN + row;
+  const int bn = min(bn_raw, bcols - 1);
+  const bool b_real = bn_raw < bcols;
+  const float inv_w = 1.0f / (float)W;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+  struct Regs {
+    f32x4 va;
+    float vb[NB];
+    int p0;
+  };
+  auto issue = [&](int s, Regs &R) {
+    const int sc = min(s, s_end - 1);
+    const int img = sc / stages_per_image, st = sc - img * stages_per_image;
+    const int p0 = st * kTK + q * 4;
+    R.p0 = p0;
+    const float *ap = a + ((long long)img * M + am) * L, *bp = bm + ((long long)img * bcols + bn) * L;
+    R.va = *reinterpret_cast<const f32x4 *>(ap + min(p0, L - 4));
+    const int base = p0 + dy * W + off;
+#pragma unroll
+    for (int k = 0; k < NB / 4; ++k) {   // clamped chunks hold wrong pixels only where the tap is outside the image
+      const f32x4 w = *reinterpret_cast<const f32x4 *>(bp + min(max(base + 4 * k, 0), L - 4));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) R.vb[4 * k + e] = w[e];
+    }
+  };
+  auto commit = [&](int buf, const Regs &R) {
+    unsigned char *As = smem + buf * 2 * kStage, *Bs = As + kStage;
+    const bool in_img = R.p0 < L;       // L % 4 == 0: a chunk is entirely inside or outside the image
+    bool row_ok = in_img && b_real;
+    int w0 = 0;
+    if (TAPS == 9) {
+      const int h = (int)(((float)R.p0 + 0.5f) * inv_w);
+      w0 = R.p0 - h * W;
+      row_ok = row_ok && h + dy >= 0 && h + dy < H;
+    }
+    bf16x4 ahi, alo, bhi, blo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float fa = (in_img && a_real) ? R.va[i] : 0.0f;
+      ahi[i] = (__bf16)fa;
+      alo[i] = (__bf16)(fa - (float)ahi[i]);
+      const int col = w0 + i + dx;
+      const bool ok = TAPS == 9 ? (row_ok && col >= 0 && col < W) : row_ok;
+      const float fb = ok ? R.vb[i + (TAPS == 9 ? sh : 0)] : 0.0f;
+      bhi[i] = (__bf16)fb;
+      blo[i] = (__bf16)(fb - (float)bhi[i]);
+    }
+    const int o = (q >> 1) * (kTM * 16) + row * 16 + (q & 1) * 8;
+    *reinterpret_cast<bf16x4 *>(As + o) = ahi;
+    *reinterpret_cast<bf16x4 *>(As + kPart + o) = alo;
+    *reinterpret_cast<bf16x4 *>(Bs + o) = bhi;
+    *reinterpret_cast<bf16x4 *>(Bs + kPart + o) = blo;
+  };
+  auto multiply = [&](int buf) {   // wave (wm, wn): rows wm*64 .. +63, columns wn*32 .. +31
+    const unsigned char *A = smem + buf * 2 * kStage + (lane >> 5) * (kTM * 16) + (wm * 64 + (lane & 31)) * 16;
+    const unsigned char *Bp = smem + buf * 2 * kStage + kStage + (lane >> 5) * (kTN * 16) + (wn * 32 + (lane & 31)) * 16;
+    bf16x8 fa[2][2], fb[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      fa[pt][0] = *reinterpret_cast<const bf16x8 *>(A + pt * kPart);
+      fa[pt][1] = *reinterpret_cast<const bf16x8 *>(A + pt * kPart + 32 * 16);
+      fb[pt] = *reinterpret_cast<const bf16x8 *>(Bp + pt * kPart);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][mi], fb[0], acc[mi], 0, 0, 0);
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][mi], fb[1], acc[mi], 0, 0, 0);
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][mi], fb[0], acc[mi], 0, 0, 0);
+    }
+  };
+  constexpr int PF = 4;
+  const int n = s_end - s_begin;
+  if (n > 0) {
+    Regs R[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) issue(s_begin + i, R[i]);
+    commit(0, R[0]);
+    const int full = n / PF * PF;   // unguarded bodies in the main loop, load-free tail (see conv_nn)
+    for (int j0 = 0; j0 < full; j0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int j = j0 + u;
+        __syncthreads();
+        issue(s_begin + j + PF, R[u]);
+        multiply(j & 1);
+        commit((j + 1) & 1, R[(u + 1) % PF]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PF - 1; ++u) {
+      const int j = full + u;
+      if (j < n) {
+        __syncthreads();
+        multiply(j & 1);
+        if (j + 1 < n) commit((j + 1) & 1, R[u + 1]);
+      }
+    }
+  }
+  float *out = partial + (long long)split * M * N;
+  const int nn = nt * kTN + wn * 32 + (lane & 31);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mt * kTM + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (m < M && nn < N) out[(long long)m * N + nn] = acc[mi][r];
+    }
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(kNNThreads) void conv_nt8(const float *__restrict__ a, const float *__restrict__ bm,
+                                                       float *__restrict__ partial, int M, int N, int L, int B, int n_mt,
+                                                       int n_nt, int stages_per_image, int per, int H, int W, int Cin) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * kStage];
+  if (TAPS == 9) {
+    const int tile = blockIdx.x % (n_mt * n_nt), nt = tile / n_mt;
+    const int dx = ((nt * kTN) / Cin) % 3 - 1;   // uniform: one tap per tile
+    if (dx < 0) conv_nt8_body<TAPS, -1>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, smem);
+    else if (dx == 0) conv_nt8_body<TAPS, 0>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, smem);
+    else conv_nt8_body<TAPS, 1>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, smem);
+  } else {
+    conv_nt8_body<TAPS, 0>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, smem);
+  }
+}
+
 namespace {
 
 // measured on MI355X (tools/bench_conv1x1_wgrad.py): one workgroup per CU with >= 32 stages each beats finer cuts --
@@ -581,8 +732,8 @@ extern "C" int kgdet_conv1x1_grad_weight(const float *grad_y, const float *x, fl
   const int per = (total + splits - 1) / splits;
   KGDET_CHECK_SHAPE(((long long)O * C) % 2 == 0, "O*C must be even");
   if (HW % 4 == 0)
-    hipLaunchKernelGGL((conv1x1_nt<4, 1>), dim3(tiles * splits), dim3(kGemmThreads), 0, (hipStream_t)stream, grad_y, x,
-                       (float *)workspace, O, C, (int)HW, (int)B, n_mt, n_nt, spi, per, 0, 0, 0);
+    hipLaunchKernelGGL(conv_nt8<1>, dim3(tiles * splits), dim3(kNNThreads), 0, (hipStream_t)stream, grad_y, x,
+                       (float *)workspace, O, C, (int)HW, (int)B, n_mt, n_nt, spi, per, 1, (int)HW, 0);
   else
     hipLaunchKernelGGL((conv1x1_nt<2, 1>), dim3(tiles * splits), dim3(kGemmThreads), 0, (hipStream_t)stream, grad_y, x,
                        (float *)workspace, O, C, (int)HW, (int)B, n_mt, n_nt, spi, per, 0, 0, 0);
@@ -617,9 +768,9 @@ extern "C" int kgdet_conv3x3_grad_weight(const float *grad_y, const float *x, fl
   const int spi = (HW + kTK - 1) / kTK, total = (int)(B * spi);
   const int splits = nt_splits(tiles, total);
   const int per = (total + splits - 1) / splits;
-  hipLaunchKernelGGL((conv1x1_nt<4, 9>), dim3(tiles * splits), dim3(kGemmThreads), 0, (hipStream_t)stream, grad_y, x,
+  hipLaunchKernelGGL(conv_nt8<9>, dim3(tiles * splits), dim3(kNNThreads), 0, (hipStream_t)stream, grad_y, x,
                      (float *)workspace, O, 9 * C, HW, (int)B, n_mt, n_nt, spi, per, H, W, C);
-  KGDET_CHECK_LAUNCH("conv1x1_nt<4, 9>");
+  KGDET_CHECK_LAUNCH("conv_nt8<9>");
   const long long n = (long long)O * C * 9;
   const long long blocks = (n + 255) / 256;
   hipLaunchKernelGGL(conv3x3_wsum, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream,
