@@ -9,7 +9,10 @@ PyTorch-ROCm (MIOpen); nothing here is hand-written HIP.
 import warnings
 
 import numpy as np
+import torch
 import torch.nn as nn
+
+from . import conv1x1
 
 _NORMS = {'BN': ('bn', nn.BatchNorm2d), 'SyncBN': ('bn', nn.SyncBatchNorm), 'GN': ('gn', nn.GroupNorm)}
 _CONVS = {'Conv': nn.Conv2d}
@@ -141,7 +144,12 @@ class ConvModule(nn.Module):
     def forward(self, x, activate=True, norm=True):
         for layer in self.order:
             if layer == 'conv':
-                x = self.conv(x)
+                conv = self.conv
+                if (type(conv) is nn.Conv2d and conv.bias is None and torch.is_grad_enabled()
+                        and conv1x1.applicable(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)):
+                    x = conv1x1.conv_split(x, conv.weight)     # fp32 training: split-bf16 MFMA kernels (conv1x1.hip)
+                else:
+                    x = conv(x)
             elif layer == 'norm' and norm and self.with_norm:
                 x = self.norm(x)
             elif layer == 'act' and activate and self.with_activatation:
