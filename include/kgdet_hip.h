@@ -32,15 +32,17 @@ extern "C" {
  *   taps = 1: 1x1;  taps = 9: 3x3 with stride 1, padding 1, dilation 1 (conv2 of the bottleneck) as an implicit GEMM.
  *   kgdet_conv_pack: weight [O, C, taps] -> operand image; transpose = 0 for the forward (y = W * x), 1 for
  *                       grad_input (gx = W^T * gy, taps mirrored); the reduction length (C resp. O) a multiple of 16.
- *   kgdet_conv_apply: y[b] (M x HW) = A (M x K*taps) . patches(x[b]) with A = the packed image; x [B, K, H, W],
- *                       y [B, M, H, W]; M = rows of the image.
+ *   kgdet_conv_apply: y[b] (M x HoWo) = A (M x K*taps) . patches(x[b]) with A = the packed image; x [B, K, H, W],
+ *                       y [B, M, ceil(H / stride), ceil(W / stride)]; stride 1 or 2 (forward only: the transposed
+ *                       image gives grad_input for stride 1).
  *   kgdet_conv1x1_grad_weight: grad_w [O, C] = sum_b grad_y[b] (O x HW) . x[b]^T (HW x C); HW even; deterministic
  *                       (per-chunk partial tiles added in fixed order); workspace from the _workspace_bytes query. */
 size_t kgdet_conv_packed_bytes(int32_t M, int32_t K, int32_t taps);
 int kgdet_conv_pack(const float *w, int32_t O, int32_t C, int32_t taps, int32_t transpose, void *packed, void *stream);
-size_t kgdet_conv_apply_workspace_bytes(int64_t B, int32_t M, int32_t K, int32_t H, int32_t W, int32_t taps); /* mostly 0 */
+size_t kgdet_conv_apply_workspace_bytes(int64_t B, int32_t M, int32_t K, int32_t H, int32_t W, int32_t taps,
+                                        int32_t stride); /* mostly 0 */
 int kgdet_conv_apply(const void *packed, const float *x, float *y, int64_t B, int32_t M, int32_t K, int32_t H, int32_t W,
-                     int32_t taps, void *workspace, size_t workspace_bytes, void *stream);
+                     int32_t taps, int32_t stride, void *workspace, size_t workspace_bytes, void *stream);
 size_t kgdet_conv1x1_grad_weight_workspace_bytes(int64_t B, int32_t O, int32_t C, int64_t HW);
 int kgdet_conv1x1_grad_weight(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O, int32_t C,
                               int64_t HW, void *workspace, size_t workspace_bytes, void *stream);

@@ -170,6 +170,8 @@ def conv_bn(conv, bn, x, relu=False, residual=None):
     if torch.is_grad_enabled():
         if conv1x1.applicable(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups):
             return frozen_bn_act(conv1x1.conv_split(x, conv.weight), bn, residual, relu)   # split-bf16 MFMA GEMMs
+        if conv1x1.applicable_stride2(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups):
+            return frozen_bn_act(conv1x1.conv3x3_stride2(x, conv.weight), bn, residual, relu)
         if (conv.kernel_size == (1, 1) and conv.stride == (2, 2) and conv.padding == (0, 0) and x.is_cuda
                 and x.dtype == torch.float32):
             # stride-2 1x1 (the downsample branch): a 1x1 convolution of the subsampled input.  MIOpen's fp32 strided

@@ -40,12 +40,12 @@ def _lib_sizes():
         vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
         for name, res, args in (
                 ('kgdet_conv_packed_bytes', sz, [i32, i32, i32]),
-                ('kgdet_conv_apply_workspace_bytes', sz, [i64, i32, i32, i32, i32, i32]),
+                ('kgdet_conv_apply_workspace_bytes', sz, [i64, i32, i32, i32, i32, i32, i32]),
                 ('kgdet_conv1x1_grad_weight_workspace_bytes', sz, [i64, i32, i32, i64]),
                 ('kgdet_conv3x3_grad_weight_workspace_bytes', sz, [i64, i32, i32, i32, i32]),
                 ('kgdet_conv_pack', ctypes.c_int, [vp, i32, i32, i32, i32, vp, vp]),
                 ('kgdet_conv_pack_both', ctypes.c_int, [vp, i32, i32, i32, vp, vp, vp]),
-                ('kgdet_conv_apply', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i32, i32, i32, vp, sz, vp]),
+                ('kgdet_conv_apply', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
                 ('kgdet_conv1x1_grad_weight', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i64, vp, sz, vp]),
                 ('kgdet_conv3x3_grad_weight', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i32, i32, vp, sz, vp])):
             fn = getattr(L, name)
@@ -88,13 +88,13 @@ def _pack_both(weight):
     return img, img_t
 
 
-def _apply(img, x, M, taps):
+def _apply(img, x, M, taps, stride=1):
     L = _lib_sizes()
     B, K, H, W = x.shape
-    y = torch.empty((B, M, H, W), dtype=torch.float32, device=x.device)
-    nbytes = _size('kgdet_conv_apply_workspace_bytes', B, M, K, H, W, taps)
+    y = torch.empty((B, M, (H + stride - 1) // stride, (W + stride - 1) // stride), dtype=torch.float32, device=x.device)
+    nbytes = _size('kgdet_conv_apply_workspace_bytes', B, M, K, H, W, taps, stride)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
-    _lib.check(L.kgdet_conv_apply(img.data_ptr(), x.data_ptr(), y.data_ptr(), B, M, K, H, W, taps,
+    _lib.check(L.kgdet_conv_apply(img.data_ptr(), x.data_ptr(), y.data_ptr(), B, M, K, H, W, taps, stride,
                                   ws.data_ptr() if nbytes else None, nbytes, _stream()), 'conv_apply')
     return y
 
@@ -145,3 +145,36 @@ def conv_split(x, weight):
 
 
 conv1x1 = conv_split
+
+
+class _ConvSplitStride2(torch.autograd.Function):
+    """3x3 stride-2 padding-1 convolution: forward on conv_nn<9> (MIOpen's fp32 strided kernels run at 15-20 TFLOP/s),
+    backward through MIOpen (a transposed strided convolution does not map onto the kernel's tap loop)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        weight = weight.contiguous()
+        ctx.save_for_backward(x, weight)
+        return _apply(_pack(weight, False), x, weight.shape[0], 9, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gx, gw, _ = torch.ops.aten.convolution_backward(
+            gy.contiguous(), x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
+            [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        return gx, gw
+
+
+STRIDE2 = _os.environ.get('KGDET_CONV_S2', '1') == '1'
+
+
+def applicable_stride2(x, weight, stride, padding, dilation, groups):
+    return (STRIDE2 and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
+            and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (2, 2) and tuple(padding) == (1, 1)
+            and tuple(dilation) == (1, 1) and groups == 1 and x.is_contiguous() and weight.shape[1] % 16 == 0
+            and ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) % 2 == 0 and not torch.is_autocast_enabled())
+
+
+def conv3x3_stride2(x, weight):
+    return _ConvSplitStride2.apply(x, weight)

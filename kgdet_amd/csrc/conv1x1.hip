@@ -130,7 +130,8 @@ template <int TAPS>
 __global__ __launch_bounds__(kNNThreads) void conv_nn(const unsigned char *__restrict__ img,
                                                       const float *__restrict__ x, float *__restrict__ y, int M, int K,
                                                       int H, int W, int n_mt, int n_nt, int tiles, int ksplit,
-                                                      long long part_stride) {
+                                                      long long part_stride, int Hin, int Win, int stride) {
+  // H x W: the OUTPUT map; Hin x Win: the input map; stride 1 (Hin = H, Win = W) or 2 (H = ceil(Hin / 2), ...)
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * kStage];   // [buf][A | B][kStage]
   const int unit = xcd_tile(blockIdx.x, tiles * ksplit);
   if (unit >= tiles * ksplit) return;
@@ -152,15 +153,17 @@ __global__ __launch_bounds__(kNNThreads) void conv_nn(const unsigned char *__res
   const int p = min(n0 + n_local, N - 1);   // columns past the end re-read the last one: never stored
   unsigned ok = 1u;                          // bit t: tap t of this pixel lies inside the image
   if (TAPS == 9) {
-    const int h = p / W, w = p - h * W;
+    const int h = (p / W) * stride, w = (p - (p / W) * W) * stride;
     ok = 0u;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
-      ok |= (hh >= 0 && hh < H && ww >= 0 && ww < W) ? (1u << t) : 0u;
+      ok |= (hh >= 0 && hh < Hin && ww >= 0 && ww < Win) ? (1u << t) : 0u;
     }
   }
-  const float *xb = x + (long long)b * K * N + p;
+  const int Nin = Hin * Win;
+  const int pin = stride == 1 ? p : (p / W) * stride * Win + (p - (p / W) * W) * stride;   // input pixel of tap (0, 0)
+  const float *xb = x + (long long)b * K * Nin + pin;
   const unsigned char *ai = img + (long long)mt * S * kStage + tid * 16;
 
   f32x16 acc[2];
@@ -177,11 +180,11 @@ __global__ __launch_bounds__(kNNThreads) void conv_nn(const unsigned char *__res
     R.live = 1u;
     if (TAPS == 9) {
       R.live = (ok >> t) & 1u;
-      shift = R.live ? (t / 3 - 1) * W + (t % 3 - 1) : 0;
+      shift = R.live ? (t / 3 - 1) * Win + (t % 3 - 1) : 0;
     }
-    const float *xp = xb + (long long)(c16 * kTK + kq * 4) * N + shift;
+    const float *xp = xb + (long long)(c16 * kTK + kq * 4) * Nin + shift;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) R.v[j] = xp[(long long)j * N];
+    for (int j = 0; j < 4; ++j) R.v[j] = xp[(long long)j * Nin];
   };
   auto commit = [&](int buf, const Regs &R) {
     unsigned char *As = smem + buf * 2 * kStage, *Bs = As + kStage;
@@ -668,21 +671,25 @@ extern "C" int kgdet_conv_pack_both(const float *w, int32_t O, int32_t C, int32_
   return KGDET_OK;
 }
 
+// H, W below are the INPUT map; the output map is ceil(H / stride) x ceil(W / stride) (1x1: padding 0, 3x3: padding 1)
 extern "C" size_t kgdet_conv_apply_workspace_bytes(int64_t B, int32_t M, int32_t K, int32_t H, int32_t W,
-                                                    int32_t taps) {
-  if (B <= 0 || M <= 0 || K <= 0 || H <= 0 || W <= 0 || K % kTK) return 0;
-  const long long HW = (long long)H * W;
+                                                    int32_t taps, int32_t stride) {
+  if (B <= 0 || M <= 0 || K <= 0 || H <= 0 || W <= 0 || K % kTK || stride < 1 || stride > 2) return 0;
+  const long long HW = (long long)((H + stride - 1) / stride) * ((W + stride - 1) / stride);
   const long long tiles = (long long)((M + kTM - 1) / kTM) * ((HW + kTN - 1) / kTN) * B;
   const int ks = nn_ksplit(tiles, taps * (K / kTK));
   return ks > 1 ? (size_t)ks * B * M * HW * sizeof(float) : 0;
 }
 
 extern "C" int kgdet_conv_apply(const void *packed, const float *x, float *y, int64_t B, int32_t M, int32_t K, int32_t H,
-                                int32_t W, int32_t taps, void *workspace, size_t workspace_bytes, void *stream) {
+                                int32_t W, int32_t taps, int32_t stride, void *workspace, size_t workspace_bytes,
+                                void *stream) {
   KGDET_CHECK_SHAPE(B >= 0 && M > 0 && K > 0 && H >= 0 && W >= 0 && (long long)H * W < (1LL << 30), "bad sizes");
   KGDET_CHECK_SHAPE(taps == 1 || taps == 9, "taps must be 1 (1x1) or 9 (3x3)");
+  KGDET_CHECK_SHAPE(stride == 1 || stride == 2, "stride must be 1 or 2");
   KGDET_CHECK_SHAPE(K % kTK == 0, "reduction length %d is not a multiple of 16", K);
-  const long long HW = (long long)H * W;
+  const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+  const long long HW = (long long)Ho * Wo;
   if (B * HW == 0) return KGDET_OK;
   KGDET_CHECK_SHAPE(packed && x && y, "null pointer");
   const int n_mt = (M + kTM - 1) / kTM, n_nt = (int)((HW + kTN - 1) / kTN);
@@ -692,16 +699,16 @@ extern "C" int kgdet_conv_apply(const void *packed, const float *x, float *y, in
   const long long part_stride = B * M * HW;
   if (ks > 1) {
     KGDET_CHECK_SHAPE(workspace && workspace_bytes >= (size_t)ks * part_stride * sizeof(float), "workspace too small");
-    KGDET_CHECK_SHAPE(part_stride % 2 == 0, "B*M*H*W must be even");
+    KGDET_CHECK_SHAPE(part_stride % 2 == 0, "B*M*Ho*Wo must be even");
   }
   const int per = (int)((tiles * ks + 7) / 8);
   float *dst = ks > 1 ? (float *)workspace : y;
   if (taps == 1)
-    hipLaunchKernelGGL(conv_nn<1>, dim3(per * 8), dim3(kNNThreads), 0, (hipStream_t)stream,
-                       (const unsigned char *)packed, x, dst, M, K, H, W, n_mt, n_nt, (int)tiles, ks, part_stride);
+    hipLaunchKernelGGL(conv_nn<1>, dim3(per * 8), dim3(kNNThreads), 0, (hipStream_t)stream, (const unsigned char *)packed,
+                       x, dst, M, K, Ho, Wo, n_mt, n_nt, (int)tiles, ks, part_stride, H, W, stride);
   else
-    hipLaunchKernelGGL(conv_nn<9>, dim3(per * 8), dim3(kNNThreads), 0, (hipStream_t)stream,
-                       (const unsigned char *)packed, x, dst, M, K, H, W, n_mt, n_nt, (int)tiles, ks, part_stride);
+    hipLaunchKernelGGL(conv_nn<9>, dim3(per * 8), dim3(kNNThreads), 0, (hipStream_t)stream, (const unsigned char *)packed,
+                       x, dst, M, K, Ho, Wo, n_mt, n_nt, (int)tiles, ks, part_stride, H, W, stride);
   KGDET_CHECK_LAUNCH("conv_nn");
   if (ks > 1) {
     const long long blocks = (part_stride / 2 + 255) / 256;

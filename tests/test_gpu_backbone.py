@@ -231,3 +231,24 @@ def test_conv1x1_not_applicable_cases_fall_back():
     assert not c1.applicable(torch.randn(2, 64, 3, 3, device='cuda'), w)          # odd H*W
     with torch.autocast('cuda', dtype=torch.bfloat16):
         assert not c1.applicable(x, w)
+
+
+@pytest.mark.parametrize('B,C,O,H,W', [(2, 128, 128, 20, 36), (1, 64, 256, 17, 13), (2, 256, 256, 50, 84)])
+def test_conv3x3_stride2_forward_matches_fp64(B, C, O, H, W):
+    """conv_nn<9> with stride 2 (padding 1): forward against the fp64 convolution; backward = MIOpen's, same as F.conv2d"""
+    from kgdet_amd import conv1x1 as c1
+    g = torch.Generator(device='cpu').manual_seed(H * W)
+    x = torch.randn(B, C, H, W, generator=g).cuda().requires_grad_()
+    w = (torch.randn(O, C, 3, 3, generator=g) * 0.1).cuda().requires_grad_()
+    if not c1.applicable_stride2(x, w, (2, 2), (1, 1), (1, 1), 1):
+        pytest.skip('odd number of output pixels')
+    y = c1.conv3x3_stride2(x, w)
+    ref = F.conv2d(x.detach().double(), w.detach().double(), stride=2, padding=1)
+    assert y.shape == ref.shape
+    assert ((y.double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
+    gy = torch.randn(y.shape, generator=g).cuda()
+    y.backward(gy)
+    xr, wr = x.detach().clone().requires_grad_(), w.detach().clone().requires_grad_()
+    F.conv2d(xr, wr, stride=2, padding=1).backward(gy)
+    assert (x.grad - xr.grad).abs().max().item() <= 1e-4 * xr.grad.abs().max().item()
+    assert (w.grad - wr.grad).abs().max().item() <= 1e-4 * wr.grad.abs().max().item()
