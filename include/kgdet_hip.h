@@ -43,6 +43,11 @@ size_t kgdet_conv_apply_workspace_bytes(int64_t B, int32_t M, int32_t K, int32_t
                                         int32_t stride); /* mostly 0 */
 int kgdet_conv_apply(const void *packed, const float *x, float *y, int64_t B, int32_t M, int32_t K, int32_t H, int32_t W,
                      int32_t taps, int32_t stride, void *workspace, size_t workspace_bytes, void *stream);
+/* the same with the inference epilogue fused into the store: y = [relu](conv + bias[m] [+ residual]); bias [M] and
+ * residual [B, M, Ho, Wo] nullable (the folded-BatchNorm bottleneck at inference, kgdet_amd/backbone.py conv_bn). */
+int kgdet_conv_apply_epilogue(const void *packed, const float *x, float *y, const float *bias, const float *residual,
+                              int32_t relu, int64_t B, int32_t M, int32_t K, int32_t H, int32_t W, int32_t taps,
+                              int32_t stride, void *workspace, size_t workspace_bytes, void *stream);
 size_t kgdet_conv1x1_grad_weight_workspace_bytes(int64_t B, int32_t O, int32_t C, int64_t HW);
 int kgdet_conv1x1_grad_weight(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O, int32_t C,
                               int64_t HW, void *workspace, size_t workspace_bytes, void *stream);

@@ -60,6 +60,8 @@ class BasicBlock(nn.Module):
         return self.relu(out)
 
 
+import os as _os
+_FUSE_EPI = _os.environ.get('KGDET_FUSE_EPI', '1') == '1'
 _fold_cache = {}   # id(conv) -> (weakref to conv, folded weight, folded bias)
 
 
@@ -197,6 +199,9 @@ def conv_bn(conv, bn, x, relu=False, residual=None):
     if bf16 and not x.is_contiguous(memory_format=torch.channels_last):
         x = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     if hit[3] is not None and x.dtype == torch.float32 and x.is_contiguous() and x.shape[2] * x.shape[3] % 2 == 0:
+        if _FUSE_EPI and (residual is None or (residual.dtype == torch.float32 and residual.is_contiguous())):
+            # bias, residual and ReLU ride on the convolution's store: no separate epilogue pass
+            return conv1x1._apply(hit[3], x, hit[1].shape[0], hit[1].shape[2] * hit[1].shape[3], 1, hit[2], residual, relu)
         out = conv1x1._apply(hit[3], x, hit[1].shape[0], hit[1].shape[2] * hit[1].shape[3])
     else:
         out = F.conv2d(x, hit[1], None, conv.stride, conv.padding, conv.dilation, conv.groups)

@@ -46,6 +46,8 @@ def _lib_sizes():
                 ('kgdet_conv_pack', ctypes.c_int, [vp, i32, i32, i32, i32, vp, vp]),
                 ('kgdet_conv_pack_both', ctypes.c_int, [vp, i32, i32, i32, vp, vp, vp]),
                 ('kgdet_conv_apply', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+                ('kgdet_conv_apply_epilogue', ctypes.c_int,
+                 [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
                 ('kgdet_conv1x1_grad_weight', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i64, vp, sz, vp]),
                 ('kgdet_conv3x3_grad_weight', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i32, i32, vp, sz, vp])):
             fn = getattr(L, name)
@@ -88,14 +90,17 @@ def _pack_both(weight):
     return img, img_t
 
 
-def _apply(img, x, M, taps, stride=1):
+def _apply(img, x, M, taps, stride=1, bias=None, residual=None, relu=False):
+    """y = conv(x) through the packed image; inference epilogue [relu](y + bias [+ residual]) fused into the store"""
     L = _lib_sizes()
     B, K, H, W = x.shape
     y = torch.empty((B, M, (H + stride - 1) // stride, (W + stride - 1) // stride), dtype=torch.float32, device=x.device)
     nbytes = _size('kgdet_conv_apply_workspace_bytes', B, M, K, H, W, taps, stride)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
-    _lib.check(L.kgdet_conv_apply(img.data_ptr(), x.data_ptr(), y.data_ptr(), B, M, K, H, W, taps, stride,
-                                  ws.data_ptr() if nbytes else None, nbytes, _stream()), 'conv_apply')
+    _lib.check(L.kgdet_conv_apply_epilogue(
+        img.data_ptr(), x.data_ptr(), y.data_ptr(), bias.data_ptr() if bias is not None else None,
+        residual.data_ptr() if residual is not None else None, 1 if relu else 0, B, M, K, H, W, taps, stride,
+        ws.data_ptr() if nbytes else None, nbytes, _stream()), 'conv_apply')
     return y
 
 

@@ -130,7 +130,10 @@ template <int TAPS>
 __global__ __launch_bounds__(kNNThreads) void conv_nn(const unsigned char *__restrict__ img,
                                                       const float *__restrict__ x, float *__restrict__ y, int M, int K,
                                                       int H, int W, int n_mt, int n_nt, int tiles, int ksplit,
-                                                      long long part_stride, int Hin, int Win, int stride) {
+                                                      long long part_stride, int Hin, int Win, int stride,
+                                                      const float *__restrict__ bias,
+                                                      const float *__restrict__ residual, int relu) {
+  // bias [M] / residual [B, M, H, W] / relu: inference epilogue y = [relu](acc + bias[m] [+ residual]) (ksplit == 1)
   // H x W: the OUTPUT map; Hin x Win: the input map; stride 1 (Hin = H, Win = W) or 2 (H = ceil(Hin / 2), ...)
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * kStage];   // [buf][A | B][kStage]
   const int unit = xcd_tile(blockIdx.x, tiles * ksplit);
@@ -251,12 +254,29 @@ __global__ __launch_bounds__(kNNThreads) void conv_nn(const unsigned char *__res
   // store: lane holds column (lane & 31) of 16 rows per 32 x 32 block -> 128-byte row segments per half wave
   float *yb = y + (long long)part * part_stride + (long long)b * M * N;
   const int n = n0 + wn * 32 + (lane & 31);
+  if (bias || residual) {   // epilogue operands first, all loads in flight at once (clamped addresses, no branches)
+    const int nc = min(n, N - 1);
+    float add[2][16];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = min(mt * kTM + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), M - 1);
+        float v = bias ? bias[m] : 0.0f;
+        if (residual) v += residual[((long long)b * M + m) * N + nc];
+        add[mi][r] = v;
+      }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][r] += add[mi][r];
+  }
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = mt * kTM + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (m < M && n < N) yb[(long long)m * N + n] = acc[mi][r];
+      if (m < M && n < N) yb[(long long)m * N + n] = relu ? fmaxf(acc[mi][r], 0.0f) : acc[mi][r];
     }
 }
 
@@ -681,9 +701,13 @@ extern "C" size_t kgdet_conv_apply_workspace_bytes(int64_t B, int32_t M, int32_t
   return ks > 1 ? (size_t)ks * B * M * HW * sizeof(float) : 0;
 }
 
-extern "C" int kgdet_conv_apply(const void *packed, const float *x, float *y, int64_t B, int32_t M, int32_t K, int32_t H,
-                                int32_t W, int32_t taps, int32_t stride, void *workspace, size_t workspace_bytes,
-                                void *stream) {
+extern "C" int kgdet_bias_act(void *x, const float *bias, const void *residual, int64_t N, int32_t C, int64_t HW,
+                              int32_t dtype, int32_t relu, int32_t channels_last, void *stream);
+
+extern "C" int kgdet_conv_apply_epilogue(const void *packed, const float *x, float *y, const float *bias,
+                                         const float *residual, int32_t relu, int64_t B, int32_t M, int32_t K,
+                                         int32_t H, int32_t W, int32_t taps, int32_t stride, void *workspace,
+                                         size_t workspace_bytes, void *stream) {
   KGDET_CHECK_SHAPE(B >= 0 && M > 0 && K > 0 && H >= 0 && W >= 0 && (long long)H * W < (1LL << 30), "bad sizes");
   KGDET_CHECK_SHAPE(taps == 1 || taps == 9, "taps must be 1 (1x1) or 9 (3x3)");
   KGDET_CHECK_SHAPE(stride == 1 || stride == 2, "stride must be 1 or 2");
@@ -705,18 +729,29 @@ extern "C" int kgdet_conv_apply(const void *packed, const float *x, float *y, in
   float *dst = ks > 1 ? (float *)workspace : y;
   if (taps == 1)
     hipLaunchKernelGGL(conv_nn<1>, dim3(per * 8), dim3(kNNThreads), 0, (hipStream_t)stream, (const unsigned char *)packed,
-                       x, dst, M, K, Ho, Wo, n_mt, n_nt, (int)tiles, ks, part_stride, H, W, stride);
+                       x, dst, M, K, Ho, Wo, n_mt, n_nt, (int)tiles, ks, part_stride, H, W, stride,
+                       ks > 1 ? nullptr : bias, ks > 1 ? nullptr : residual, ks > 1 ? 0 : relu);
   else
     hipLaunchKernelGGL(conv_nn<9>, dim3(per * 8), dim3(kNNThreads), 0, (hipStream_t)stream, (const unsigned char *)packed,
-                       x, dst, M, K, Ho, Wo, n_mt, n_nt, (int)tiles, ks, part_stride, H, W, stride);
+                       x, dst, M, K, Ho, Wo, n_mt, n_nt, (int)tiles, ks, part_stride, H, W, stride,
+                       ks > 1 ? nullptr : bias, ks > 1 ? nullptr : residual, ks > 1 ? 0 : relu);
   KGDET_CHECK_LAUNCH("conv_nn");
   if (ks > 1) {
     const long long blocks = (part_stride / 2 + 255) / 256;
     hipLaunchKernelGGL(conv1x1_sum, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, (hipStream_t)stream,
                        (const float *)workspace, y, part_stride, part_stride, ks);
     KGDET_CHECK_LAUNCH("conv1x1_sum");
+    if (bias || residual || relu)   // K-split problems are small: the epilogue as one extra pass
+      return kgdet_bias_act(y, bias, residual, B, M, HW, 0, relu, 0, stream);
   }
   return KGDET_OK;
+}
+
+extern "C" int kgdet_conv_apply(const void *packed, const float *x, float *y, int64_t B, int32_t M, int32_t K, int32_t H,
+                                int32_t W, int32_t taps, int32_t stride, void *workspace, size_t workspace_bytes,
+                                void *stream) {
+  return kgdet_conv_apply_epilogue(packed, x, y, nullptr, nullptr, 0, B, M, K, H, W, taps, stride, workspace,
+                                   workspace_bytes, stream);
 }
 
 extern "C" size_t kgdet_conv1x1_grad_weight_workspace_bytes(int64_t B, int32_t O, int32_t C, int64_t HW) {
