@@ -61,7 +61,7 @@ class BasicBlock(nn.Module):
 
 
 import os as _os
-_FUSE_EPI = _os.environ.get('KGDET_FUSE_EPI', '1') == '1'
+_FUSE_EPI = _os.environ.get('KGDET_FUSE_EPI', '1') == '1'   # fp32 inference: epilogue inside conv_nn's store (0: separate pass, for A/B)
 _fold_cache = {}   # id(conv) -> (weakref to conv, folded weight, folded bias)
 
 
