@@ -1,27 +1,28 @@
-// 1x1 convolution (stride 1, NCHW, fp32 in / fp32 out) as bf16 hi/lo-split MFMA GEMMs for gfx950.
+// 1x1 and 3x3 convolutions (NCHW, fp32 in / fp32 out) as bf16 hi/lo-split MFMA GEMMs for gfx950.
 //
 // The ResNet-50 bottleneck (mmdet/models/backbones/resnet.py:142-186, 231-262) is two 1x1 convolutions around a
-// 3x3; with the reference's fp32 arithmetic MIOpen runs them as fp32 GEMMs at 60-110 TFLOP/s (MI355X fp32 MFMA
-// peak 157).  A 1x1 convolution at these shapes has ~50 flop per byte of fp32 activation traffic, i.e. it sits at
-// ~400 TFLOP/s on the HBM roofline, so the matrix pipe, not memory, is what the fp32 GEMM leaves on the table.
-// Same arithmetic as the deformable kernels (dcn_forward_plane.hip): every fp32 operand v = hi + lo with
-// hi = bf16(v), lo = bf16(v - hi); a product is a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on v_mfma_f32_32x32x16_bf16 with
-// fp32 accumulation -- fp32-level accuracy (~1e-6 of the output scale) at a third of the bf16 rate.
+// 3x3; with the reference's fp32 arithmetic MIOpen runs them at 60-110 TFLOP/s (MI355X fp32 MFMA peak 157; its
+// strided fp32 kernels at 15-20).  A 1x1 convolution at these shapes has ~50 flop per byte of fp32 activation traffic,
+// i.e. it sits at ~400 TFLOP/s on the HBM roofline, and a 3x3 is nine times denser: the matrix pipe, not memory, is
+// what fp32 MFMA leaves on the table.  Same arithmetic as the deformable kernels (dcn_forward_plane.hip): every fp32
+// operand v = hi + lo with hi = bf16(v), lo = bf16(v - hi); a product is a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- ~5e-6 of the output scale (fp32 kernels: ~7e-7) at a third of
+// the bf16 rate.
 //
-//   forward      y[b] (Cout x HW) = W (Cout x Cin)     . x[b]  (Cin x HW)    conv_nn<1>, A = packed W
-//   grad_input   gx[b] (Cin x HW) = W^T (Cin x Cout)   . gy[b] (Cout x HW)   conv_nn<1>, A = packed W^T
-// and the 3x3 (stride 1, padding 1) convolution as the same implicit GEMM over (channel chunk, tap) stages: conv_nn<9>.
-//   grad_weight  gW (Cout x Cin)  = sum_b gy[b] (Cout x HW) . x[b]^T         conv1x1_nt + conv1x1_sum
+//   forward      y[b] (O x HoWo) = W (O x C*taps) . patches(x[b])                conv_nn<1 | 9>, A = packed W
+//   grad_input   gx[b] (C x HW)  = W^T, taps mirrored . patches(gy[b])           conv_nn<1 | 9>, A = packed W^T (stride 1)
+//   grad_weight  gW (O x C*taps) = sum_b gy[b] (O x HW) . patches(x[b])^T        conv_nt8<1 | 9> (+ conv1x1_nt<2,1>)
 //
-// conv1x1_nn: 128 x 128 output tile per workgroup (4 waves x 64 x 64), reduction in stages of 16 channels.
-//   A stage = 8 KB of the pre-split weight image [part][khalf][128 rows][8 bf16] (one 16-byte load per thread and
-//   part); B stage = 16 activation rows of 128 pixels: a thread owns (pixel, khalf), issues 8 dword loads (each a
-//   coalesced 256-byte row segment per wave), splits, writes one 16-byte LDS entry per part.  Loads of stage s+4 are
-//   in flight while stage s+1 is converted and stage s multiplied; one barrier per stage.  Tiles are dealt to the
-//   XCDs in contiguous runs so the M tiles sharing a pixel tile share an L2.
-// conv1x1_nt: both operands are activations with the reduction (pixels) contiguous: a thread loads 8 consecutive
-//   pixels of one row of each operand = one LDS entry each.  The pixel range is cut into `splits` chunks, one
-//   workgroup per (tile, chunk) writes a partial; conv1x1_sum adds them in fixed order (deterministic).
+// conv_nn: 128 x 128 output tile, 512 threads = 8 waves as 2 (M) x 4 (N); reduction in stages of (16 channels, tap).
+//   A stage = 8 KB of the pre-split weight image [part][khalf][128 rows][8 bf16] (one 16-byte load per thread);
+//   B stage = 16 activation rows x 128 pixels: a thread owns (pixel, 4 channels), dword loads coalesced along pixels
+//   (tap shift = address offset, tap validity = bit of a per-thread mask, stride 2 = input index mapping), split on the
+//   fly, 8-byte LDS writes.  Four stages of loads in flight; the main loop has no guarded loads (counted vmcnt); one
+//   barrier per stage; XCD-contiguous tile order; K-split + deterministic sum below 200 tiles; optional inference
+//   epilogue (bias, residual, ReLU) in the store.
+// conv_nt8: both operands are activations with the reduction (pixels) contiguous: a thread loads 4 consecutive pixels
+//   of one row of each operand (3x3 column shift: two aligned loads + static selection).  The pixel range is cut into
+//   chunks, one workgroup per (tile, chunk) writes a partial; conv1x1_sum / conv3x3_wsum add them in fixed order.
 #include "common.h"
 
 namespace kgdet {
