@@ -252,3 +252,29 @@ def test_conv3x3_stride2_forward_matches_fp64(B, C, O, H, W):
     F.conv2d(xr, wr, stride=2, padding=1).backward(gy)
     assert (x.grad - xr.grad).abs().max().item() <= 1e-4 * xr.grad.abs().max().item()
     assert (w.grad - wr.grad).abs().max().item() <= 1e-4 * wr.grad.abs().max().item()
+
+
+@pytest.mark.parametrize('k,stride', [(1, 1), (3, 1), (3, 2), (1, 2)])
+@pytest.mark.parametrize('B,C,O,H,W', [(2, 64, 128, 20, 34), (1, 512, 64, 6, 8), (2, 128, 256, 13, 10)])
+def test_conv_apply_epilogue_flags(B, C, O, H, W, k, stride):
+    """kgdet_conv_apply_epilogue: y = [relu](conv(x) + bias[m] [+ residual]) for every flag combination, on the direct
+    store path and on the K-split path (small maps), 1x1 / 3x3, stride 1 / 2 -- against torch in fp64."""
+    from kgdet_amd import conv1x1 as c1
+    Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+    if (Ho * Wo) % 2:
+        pytest.skip('odd number of output pixels')
+    g = torch.Generator(device='cpu').manual_seed(B * C + H)
+    x = torch.randn(B, C, H, W, generator=g).cuda()
+    w = (torch.randn(O, C, k, k, generator=g) * 0.1).cuda()
+    bias = torch.randn(O, generator=g).cuda()
+    res = torch.randn(B, O, Ho, Wo, generator=g).cuda()
+    img = c1._pack(w, False)
+    ref0 = F.conv2d(x.double(), w.double(), stride=stride, padding=k // 2)
+    for use_b in (False, True):
+        for use_r in (False, True):
+            for relu in (False, True):
+                want = ref0 + (bias.double().view(1, -1, 1, 1) if use_b else 0) + (res.double() if use_r else 0)
+                want = want.clamp(min=0) if relu else want
+                got = c1._apply(img, x, O, k * k, stride, bias if use_b else None, res if use_r else None, relu)
+                assert got.shape == want.shape
+                assert ((got.double() - want).abs().max() / ref0.abs().max()).item() < 1e-5, (use_b, use_r, relu)
