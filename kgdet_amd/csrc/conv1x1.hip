@@ -425,7 +425,7 @@ __device__ __forceinline__ void conv1x1_nt_body(const float *__restrict__ a, con
 #pragma unroll
     for (int i = 0; i < PF; ++i) issue(s_begin + i, R[i]);
     commit(0, R[0]);
-    const int full = n / PF * PF;   // as in conv1x1_nn: unguarded bodies in the main loop, load-free tail
+    const int full = n / PF * PF;   // as in conv_nn: unguarded bodies in the main loop, load-free tail
     for (int j0 = 0; j0 < full; j0 += PF) {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
