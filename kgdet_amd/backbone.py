@@ -96,49 +96,101 @@ def _epilogue_(y, bias, residual, relu):
     return F.relu(y, inplace=True) if relu else y
 
 
+def _bn_act_forward(x, gamma, beta, mean, var, eps, residual, relu):
+    from . import _lib
+    N, C = x.shape[0], x.shape[1]
+    HW = x.numel() // max(N * C, 1)
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().kgdet_bn_act_forward(
+        _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(var), ctypes.c_float(eps),
+        _lib.ptr(residual), _lib.ptr(y), ctypes.c_int64(N), ctypes.c_int32(C), ctypes.c_int64(HW),
+        ctypes.c_int32(1 if relu else 0), _lib.current_stream()), 'bn_act_forward')
+    return y
+
+
+def _bn_act_backward(gy, x, y, gamma, beta, mean, var, eps, has_res, relu, need_gx):
+    """-> (grad_x or None, grad_residual-or-None (None: it IS gy), [grad_beta, grad_gamma] sums [2, C])"""
+    from . import _lib
+    N, C = x.shape[0], x.shape[1]
+    HW = x.numel() // max(N * C, 1)
+    L = _lib.lib()
+    P = L.kgdet_bn_act_partials(ctypes.c_int64(N), ctypes.c_int32(C), ctypes.c_int64(HW))
+    partial = torch.empty((2, C, max(P, 1)), dtype=torch.float32, device=x.device)
+    gx = torch.empty_like(x) if need_gx else None
+    masked = has_res and relu
+    gres = torch.empty_like(x) if masked else None
+    _lib.check(L.kgdet_bn_act_backward(
+        _lib.ptr(gy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(var),
+        ctypes.c_float(eps), ctypes.c_int32(1 if has_res else 0), ctypes.c_int32(1 if relu else 0),
+        _lib.ptr(gx), _lib.ptr(gres), _lib.ptr(partial), ctypes.c_int64(N), ctypes.c_int32(C), ctypes.c_int64(HW),
+        _lib.current_stream()), 'bn_act_backward')
+    sums = partial.sum(dim=2) if P > 0 else partial.new_zeros((2, C))
+    return gx, gres, sums
+
+
 class _FrozenBNAct(torch.autograd.Function):
     """``[relu](batch_norm_eval(x) [+ residual])`` as one HIP pass each way (csrc/bn_act.hip)."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, mean, var, eps, residual, relu):
-        from . import _lib
-        N, C = x.shape[0], x.shape[1]
-        HW = x.numel() // max(N * C, 1)
-        y = torch.empty_like(x)
-        _lib.check(_lib.lib().kgdet_bn_act_forward(
-            _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(var), ctypes.c_float(eps),
-            _lib.ptr(residual), _lib.ptr(y), ctypes.c_int64(N), ctypes.c_int32(C), ctypes.c_int64(HW),
-            ctypes.c_int32(1 if relu else 0), _lib.current_stream()), 'bn_act_forward')
+        y = _bn_act_forward(x, gamma, beta, mean, var, eps, residual, relu)
         ctx.eps, ctx.relu, ctx.has_res = eps, relu, residual is not None
         ctx.save_for_backward(x, y if (relu and residual is not None) else None, gamma, beta, mean, var)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        from . import _lib
         x, y, gamma, beta, mean, var = ctx.saved_tensors
         gy = gy.contiguous()
-        N, C = x.shape[0], x.shape[1]
-        HW = x.numel() // max(N * C, 1)
-        L = _lib.lib()
-        P = L.kgdet_bn_act_partials(ctypes.c_int64(N), ctypes.c_int32(C), ctypes.c_int64(HW))
-        partial = torch.empty((2, C, max(P, 1)), dtype=torch.float32, device=x.device)
-        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        masked = ctx.has_res and ctx.relu
-        gres = torch.empty_like(x) if masked else None
-        _lib.check(L.kgdet_bn_act_backward(
-            _lib.ptr(gy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(var),
-            ctypes.c_float(ctx.eps), ctypes.c_int32(1 if ctx.has_res else 0), ctypes.c_int32(1 if ctx.relu else 0),
-            _lib.ptr(gx), _lib.ptr(gres), _lib.ptr(partial), ctypes.c_int64(N), ctypes.c_int32(C), ctypes.c_int64(HW),
-            _lib.current_stream()), 'bn_act_backward')
-        sums = partial.sum(dim=2) if P > 0 else partial.new_zeros((2, C))
+        gx, gres, sums = _bn_act_backward(gy, x, y, gamma, beta, mean, var, ctx.eps, ctx.has_res, ctx.relu,
+                                          ctx.needs_input_grad[0])
         ggamma = sums[1] if (gamma is not None and ctx.needs_input_grad[1]) else None
         gbeta = sums[0] if (beta is not None and ctx.needs_input_grad[2]) else None
         if not ctx.has_res or not ctx.needs_input_grad[6]:
             gres = None
-        elif not masked:
+        elif gres is None:
             gres = gy
         return gx, ggamma, gbeta, None, None, None, gres, None
+
+
+class _ConvBNAct(torch.autograd.Function):
+    """``[relu](batch_norm_eval(conv(x, w)) [+ residual])`` as ONE autograd node: split-bf16 convolution kernels +
+    the fused BatchNorm pass.  Same kernels as ``conv_split`` followed by ``frozen_bn_act``; merging the two nodes
+    takes ~50 Python autograd-node round trips off the step, whose host side is as long as its GPU side."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, mean, var, eps, residual, relu):
+        weight = weight.contiguous()
+        img, ctx.img_t = conv1x1.forward_images(x, weight)
+        y = conv1x1._apply(img, x, weight.shape[0], weight.shape[2] * weight.shape[3])
+        z = _bn_act_forward(y, gamma, beta, mean, var, eps, residual, relu)
+        ctx.eps, ctx.relu, ctx.has_res = eps, relu, residual is not None
+        ctx.save_for_backward(x, weight, y, z if (relu and residual is not None) else None, gamma, beta, mean, var)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        x, weight, y, z, gamma, beta, mean, var = ctx.saved_tensors
+        gz = gz.contiguous()
+        need_conv = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        gy, gres, sums = _bn_act_backward(gz, y, z, gamma, beta, mean, var, ctx.eps, ctx.has_res, ctx.relu, need_conv)
+        gx = conv1x1.grad_input(weight, ctx.img_t, gy) if ctx.needs_input_grad[0] else None
+        gw = conv1x1.grad_weight(x, weight, gy) if ctx.needs_input_grad[1] else None
+        ggamma = sums[1] if (gamma is not None and ctx.needs_input_grad[2]) else None
+        gbeta = sums[0] if (beta is not None and ctx.needs_input_grad[3]) else None
+        if not ctx.has_res or not ctx.needs_input_grad[7]:
+            gres = None
+        elif gres is None:
+            gres = gz
+        return gx, gw, ggamma, gbeta, None, None, None, gres, None
+
+
+MERGE_CONV_BN = True    # False: two nodes (conv_split, frozen_bn_act) -- the tests compare the two
+
+
+def _fused_bn_ok(x, bn, residual):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not bn.training and bn.track_running_stats
+            and (residual is None or (residual.dtype == x.dtype and residual.is_contiguous())))
 
 
 def frozen_bn_act(x, bn, residual=None, relu=False):
@@ -171,6 +223,10 @@ def conv_bn(conv, bn, x, relu=False, residual=None):
         return F.relu(out, inplace=True) if relu else out
     if torch.is_grad_enabled():
         if conv1x1.applicable(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups):
+            if (MERGE_CONV_BN and _fused_bn_ok(x, bn, residual) and x.shape[0] * conv.weight.shape[0] <= 65535
+                    and (residual is None or residual.shape[1] == conv.weight.shape[0])):
+                return _ConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                                        residual, relu)
             return frozen_bn_act(conv1x1.conv_split(x, conv.weight), bn, residual, relu)   # split-bf16 MFMA GEMMs
         if conv1x1.applicable_stride2(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups):
             return frozen_bn_act(conv1x1.conv3x3_stride2(x, conv.weight), bn, residual, relu)

@@ -104,14 +104,47 @@ def _apply(img, x, M, taps, stride=1, bias=None, residual=None, relu=False):
     return y
 
 
+def forward_images(x, weight):
+    """(forward operand image, grad_input operand image or None) of a contiguous weight"""
+    if PACK_BOTH and x.requires_grad and weight.shape[0] % 16 == 0:
+        return _pack_both(weight)       # the backward's operand image comes out of the same launch
+    return _pack(weight, False), None
+
+
+def grad_weight(x, weight, gy):
+    """grad of ``conv(x, weight)`` (stride 1, padding k // 2) with respect to the weight"""
+    O, C, k = weight.shape[0], weight.shape[1], weight.shape[2]
+    L = _lib_sizes()
+    if k == 3 and SPLIT_GRAD_WEIGHT_3X3 and C % 128 == 0 and x.shape[3] % 4 == 0:
+        B, H, W = x.shape[0], x.shape[2], x.shape[3]
+        nbytes = _size('kgdet_conv3x3_grad_weight_workspace_bytes', B, O, C, H, W)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        gw = torch.empty_like(weight)
+        _lib.check(L.kgdet_conv3x3_grad_weight(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), B, O, C, H, W,
+                                               ws.data_ptr(), nbytes, _stream()), 'conv3x3_grad_weight')
+        return gw
+    if k != 1 or (x.shape[2] * x.shape[3]) % 4 != 0:
+        # other 3x3 shapes, and the 8-byte-load variant of the 1x1 kernel (small odd maps, e.g. 25 x 42): MIOpen
+        return torch.nn.grad.conv2d_weight(x, weight.shape, gy, padding=k // 2)
+    B, HW = x.shape[0], x.shape[2] * x.shape[3]
+    nbytes = _size('kgdet_conv1x1_grad_weight_workspace_bytes', B, O, C, HW)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    gw = torch.empty_like(weight)
+    _lib.check(L.kgdet_conv1x1_grad_weight(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), B, O, C, HW,
+                                           ws.data_ptr(), nbytes, _stream()), 'conv1x1_grad_weight')
+    return gw
+
+
+def grad_input(weight, img_t, gy):
+    C, k = weight.shape[1], weight.shape[2]
+    return _apply(img_t if img_t is not None else _pack(weight, True), gy, C, k * k)
+
+
 class _ConvSplit(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
         weight = weight.contiguous()
-        if PACK_BOTH and x.requires_grad and weight.shape[0] % 16 == 0:
-            img, ctx.img_t = _pack_both(weight)       # the backward's operand image comes out of the same launch
-        else:
-            img, ctx.img_t = _pack(weight, False), None
+        img, ctx.img_t = forward_images(x, weight)
         ctx.save_for_backward(x, weight)
         return _apply(img, x, weight.shape[0], weight.shape[2] * weight.shape[3])
 
@@ -119,29 +152,8 @@ class _ConvSplit(torch.autograd.Function):
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
-        O, C, k = weight.shape[0], weight.shape[1], weight.shape[2]
-        gx = gw = None
-        if ctx.needs_input_grad[0]:
-            gx = _apply(ctx.img_t if ctx.img_t is not None else _pack(weight, True), gy, C, k * k)
-        if ctx.needs_input_grad[1] and k == 3 and SPLIT_GRAD_WEIGHT_3X3 and C % 128 == 0 and x.shape[3] % 4 == 0:
-            L = _lib_sizes()
-            B, H, W = x.shape[0], x.shape[2], x.shape[3]
-            nbytes = _size('kgdet_conv3x3_grad_weight_workspace_bytes', B, O, C, H, W)
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-            gw = torch.empty_like(weight)
-            _lib.check(L.kgdet_conv3x3_grad_weight(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), B, O, C, H, W,
-                                                   ws.data_ptr(), nbytes, _stream()), 'conv3x3_grad_weight')
-        elif ctx.needs_input_grad[1] and (k != 1 or (x.shape[2] * x.shape[3]) % 4 != 0):
-            # other 3x3 shapes, and the 8-byte-load variant of the 1x1 kernel (small odd maps, e.g. 25 x 42): MIOpen
-            gw = torch.nn.grad.conv2d_weight(x, weight.shape, gy, padding=k // 2)
-        elif ctx.needs_input_grad[1]:
-            L = _lib_sizes()
-            B, HW = x.shape[0], x.shape[2] * x.shape[3]
-            nbytes = _size('kgdet_conv1x1_grad_weight_workspace_bytes', B, O, C, HW)
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-            gw = torch.empty_like(weight)
-            _lib.check(L.kgdet_conv1x1_grad_weight(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), B, O, C, HW,
-                                                   ws.data_ptr(), nbytes, _stream()), 'conv1x1_grad_weight')
+        gx = grad_input(weight, ctx.img_t, gy) if ctx.needs_input_grad[0] else None
+        gw = grad_weight(x, weight, gy) if ctx.needs_input_grad[1] else None
         return gx, gw
 
 

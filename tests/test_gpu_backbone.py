@@ -102,10 +102,12 @@ def test_training_backbone_uses_fused_op_and_matches_module_path():
         return F.relu(out, inplace=True) if relu else out
 
     bb.frozen_bn_act = unfused
+    bb.MERGE_CONV_BN = False          # the merged conv + BN node does not go through frozen_bn_act
     try:
         outs_ref, grads_ref = run()
     finally:
         bb.frozen_bn_act = orig
+        bb.MERGE_CONV_BN = True
     for a, b in zip(outs, outs_ref):
         assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
     assert grads.keys() == grads_ref.keys() and len(grads) > 100
