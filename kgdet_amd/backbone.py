@@ -96,15 +96,38 @@ def _epilogue_(y, bias, residual, relu):
     return F.relu(y, inplace=True) if relu else y
 
 
+_BN = None
+_bn_partials = {}
+
+
+def _bn_lib():
+    """bn_act entry points with argtypes declared once (plain ints / pointers marshal faster than c_* objects)"""
+    global _BN
+    if _BN is None:
+        from . import _lib
+        L = _lib.lib()
+        vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+        L.kgdet_bn_act_partials.restype, L.kgdet_bn_act_partials.argtypes = ctypes.c_int32, [i64, i32, i64]
+        L.kgdet_bn_act_forward.restype = ctypes.c_int
+        L.kgdet_bn_act_forward.argtypes = [vp, vp, vp, vp, vp, f32, vp, vp, i64, i32, i64, i32, vp]
+        L.kgdet_bn_act_backward.restype = ctypes.c_int
+        L.kgdet_bn_act_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, f32, i32, i32, vp, vp, vp, i64, i32, i64, vp]
+        _BN = L
+    return _BN
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
 def _bn_act_forward(x, gamma, beta, mean, var, eps, residual, relu):
     from . import _lib
     N, C = x.shape[0], x.shape[1]
     HW = x.numel() // max(N * C, 1)
     y = torch.empty_like(x)
-    _lib.check(_lib.lib().kgdet_bn_act_forward(
-        _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(var), ctypes.c_float(eps),
-        _lib.ptr(residual), _lib.ptr(y), ctypes.c_int64(N), ctypes.c_int32(C), ctypes.c_int64(HW),
-        ctypes.c_int32(1 if relu else 0), _lib.current_stream()), 'bn_act_forward')
+    _lib.check(_bn_lib().kgdet_bn_act_forward(
+        _p(x), _p(gamma), _p(beta), _p(mean), _p(var), eps, _p(residual), _p(y), N, C, HW, 1 if relu else 0,
+        torch.cuda.current_stream().cuda_stream), 'bn_act_forward')
     return y
 
 
@@ -113,17 +136,17 @@ def _bn_act_backward(gy, x, y, gamma, beta, mean, var, eps, has_res, relu, need_
     from . import _lib
     N, C = x.shape[0], x.shape[1]
     HW = x.numel() // max(N * C, 1)
-    L = _lib.lib()
-    P = L.kgdet_bn_act_partials(ctypes.c_int64(N), ctypes.c_int32(C), ctypes.c_int64(HW))
+    L = _bn_lib()
+    P = _bn_partials.get((N, C, HW))
+    if P is None:
+        P = _bn_partials[(N, C, HW)] = L.kgdet_bn_act_partials(N, C, HW)
     partial = torch.empty((2, C, max(P, 1)), dtype=torch.float32, device=x.device)
     gx = torch.empty_like(x) if need_gx else None
     masked = has_res and relu
     gres = torch.empty_like(x) if masked else None
     _lib.check(L.kgdet_bn_act_backward(
-        _lib.ptr(gy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(var),
-        ctypes.c_float(eps), ctypes.c_int32(1 if has_res else 0), ctypes.c_int32(1 if relu else 0),
-        _lib.ptr(gx), _lib.ptr(gres), _lib.ptr(partial), ctypes.c_int64(N), ctypes.c_int32(C), ctypes.c_int64(HW),
-        _lib.current_stream()), 'bn_act_backward')
+        _p(gy), _p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(var), eps, 1 if has_res else 0, 1 if relu else 0,
+        _p(gx), _p(gres), _p(partial), N, C, HW, torch.cuda.current_stream().cuda_stream), 'bn_act_backward')
     sums = partial.sum(dim=2) if P > 0 else partial.new_zeros((2, C))
     return gx, gres, sums
 
