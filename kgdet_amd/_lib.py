@@ -80,6 +80,14 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-def current_stream():
+def raw_stream(device_index=None):
+    """the current HIP stream of the device as an integer handle.  torch.cuda.current_stream() costs ~9 us of Python
+    per call (a training step makes ~400 of them); the raw getter is a single C call."""
     import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(device_index)
+
+
+def current_stream():
+    return ctypes.c_void_p(raw_stream())

@@ -127,7 +127,7 @@ def _bn_act_forward(x, gamma, beta, mean, var, eps, residual, relu):
     y = torch.empty_like(x)
     _lib.check(_bn_lib().kgdet_bn_act_forward(
         _p(x), _p(gamma), _p(beta), _p(mean), _p(var), eps, _p(residual), _p(y), N, C, HW, 1 if relu else 0,
-        torch.cuda.current_stream().cuda_stream), 'bn_act_forward')
+        _lib.raw_stream(x.device.index)), 'bn_act_forward')
     return y
 
 
@@ -146,7 +146,7 @@ def _bn_act_backward(gy, x, y, gamma, beta, mean, var, eps, has_res, relu, need_
     gres = torch.empty_like(x) if masked else None
     _lib.check(L.kgdet_bn_act_backward(
         _p(gy), _p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(var), eps, 1 if has_res else 0, 1 if relu else 0,
-        _p(gx), _p(gres), _p(partial), N, C, HW, torch.cuda.current_stream().cuda_stream), 'bn_act_backward')
+        _p(gx), _p(gres), _p(partial), N, C, HW, _lib.raw_stream(x.device.index)), 'bn_act_backward')
     sums = partial.sum(dim=2) if P > 0 else partial.new_zeros((2, C))
     return gx, gres, sums
 

@@ -65,7 +65,7 @@ def _size(name, *args):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.raw_stream()
 
 
 def _pack(weight, transpose):

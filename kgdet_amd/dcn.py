@@ -27,7 +27,7 @@ _workspaces = {}
 def _workspace(device, nbytes):
     """Persistent per-(device, stream) scratch for split-K partial tiles (caller-owned memory in
     the C ABI; the reference re-allocates its column buffer with at::zeros on every call)."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _lib.raw_stream(device.index))
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
