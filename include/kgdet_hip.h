@@ -67,12 +67,13 @@ int kgdet_bn_act_forward(const float *x, const float *gamma, const float *beta, 
  * grad_residual = g' is WRITTEN only when has_residual && relu (otherwise it equals grad_y and the caller reuses
  * that tensor); y is read only in that case.  partial: [2][C][P] with P = kgdet_bn_act_partials(N, C, HW):
  * partial[0][c][:] sums to grad_beta[c], partial[1][c][:] to grad_gamma[c] (per-workgroup partials in a fixed order:
- * deterministic, no atomics; the caller adds them). */
+ * deterministic, no atomics).  sums (nullable): [2][C] = the partials added in slot order by a second tiny launch --
+ * sums[0] = grad_beta, sums[1] = grad_gamma; NULL: the caller adds them. */
 int32_t kgdet_bn_act_partials(int64_t N, int32_t C, int64_t HW);
 int kgdet_bn_act_backward(const float *grad_y, const float *x, const float *y, const float *gamma, const float *beta,
                           const float *mean, const float *var, float eps, int32_t has_residual, int32_t relu,
-                          float *grad_x, float *grad_residual, float *partial, int64_t N, int32_t C, int64_t HW,
-                          void *stream);
+                          float *grad_x, float *grad_residual, float *partial, float *sums, int64_t N, int32_t C,
+                          int64_t HW, void *stream);
 
 /* Inference epilogue of a convolution with folded BatchNorm: x = [relu](x + bias[c] [+ residual]) in place.
  * x, residual: [N, C, HW] contiguous, or [N, HW, C] when channels_last != 0 (then C must be a multiple of 4

@@ -111,7 +111,7 @@ def _bn_lib():
         L.kgdet_bn_act_forward.restype = ctypes.c_int
         L.kgdet_bn_act_forward.argtypes = [vp, vp, vp, vp, vp, f32, vp, vp, i64, i32, i64, i32, vp]
         L.kgdet_bn_act_backward.restype = ctypes.c_int
-        L.kgdet_bn_act_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, f32, i32, i32, vp, vp, vp, i64, i32, i64, vp]
+        L.kgdet_bn_act_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, f32, i32, i32, vp, vp, vp, vp, i64, i32, i64, vp]
         _BN = L
     return _BN
 
@@ -144,10 +144,10 @@ def _bn_act_backward(gy, x, y, gamma, beta, mean, var, eps, has_res, relu, need_
     gx = torch.empty_like(x) if need_gx else None
     masked = has_res and relu
     gres = torch.empty_like(x) if masked else None
+    sums = torch.empty((2, C), dtype=torch.float32, device=x.device)
     _lib.check(L.kgdet_bn_act_backward(
         _p(gy), _p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(var), eps, 1 if has_res else 0, 1 if relu else 0,
-        _p(gx), _p(gres), _p(partial), N, C, HW, _lib.raw_stream(x.device.index)), 'bn_act_backward')
-    sums = partial.sum(dim=2) if P > 0 else partial.new_zeros((2, C))
+        _p(gx), _p(gres), _p(partial), _p(sums), N, C, HW, _lib.raw_stream(x.device.index)), 'bn_act_backward')
     return gx, gres, sums
 
 

@@ -121,6 +121,17 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float *__restrict
   }
 }
 
+// sums[2][C] = sum over the P partials of every (row, channel), slot order (deterministic): one thread per (row, channel)
+__global__ __launch_bounds__(256) void bn_partial_sum(const float *__restrict__ partial, float *__restrict__ sums, int rows,
+                                                      int P) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows) return;
+  const float *p = partial + (long long)i * P;
+  float s = 0.f;
+  for (int k = 0; k < P; ++k) s += p[k];
+  sums[i] = s;
+}
+
 namespace {
 
 // chunks per plane: enough workgroups to fill 256 CUs several times over, at least 1024 elements each
@@ -165,7 +176,7 @@ extern "C" int kgdet_bn_act_forward(const float *x, const float *gamma, const fl
 extern "C" int kgdet_bn_act_backward(const float *grad_y, const float *x, const float *y, const float *gamma,
                                      const float *beta, const float *mean, const float *var, float eps,
                                      int32_t has_residual, int32_t relu, float *grad_x, float *grad_residual,
-                                     float *partial, int64_t N, int32_t C, int64_t HW, void *stream) {
+                                     float *partial, float *sums, int64_t N, int32_t C, int64_t HW, void *stream) {
   KGDET_CHECK_SHAPE(N >= 0 && C > 0 && HW >= 0 && HW < (1LL << 31), "bad sizes");
   if (N * HW == 0) return KGDET_OK;
   KGDET_CHECK_SHAPE(grad_y && x && mean && var && partial, "null pointer");
@@ -183,5 +194,10 @@ extern "C" int kgdet_bn_act_backward(const float *grad_y, const float *x, const 
   else { if (relu) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
   KGDET_CHECK_LAUNCH("bn_act_backward");
+  if (sums) {   // [2][C]: grad_beta, grad_gamma
+    hipLaunchKernelGGL(bn_partial_sum, dim3((2 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial, sums, 2 * C,
+                       P);
+    KGDET_CHECK_LAUNCH("bn_partial_sum");
+  }
   return KGDET_OK;
 }
