@@ -18,6 +18,13 @@ constexpr int kProducers = 256;                          // 4 producer waves
 constexpr int kPlaneThreads = kThreads + kProducers;     // 8 consumer + 4 producer waves
 constexpr int kPlaneRounds = 3;                          // (pixel, quad) items a thread has in flight while copying a plane
 
+// A (weight) fragments: true = every consumer wave loads its own 64 rows of the stage straight from the weight image
+// (L2) into a two-stage register ring; false = the producers copy the stage into LDS and the consumers read it there.
+#ifndef KGDET_PLANE_A_FROM_L2
+#define KGDET_PLANE_A_FROM_L2 1
+#endif
+constexpr bool kAFromL2 = KGDET_PLANE_A_FROM_L2 != 0;
+
 constexpr int kOvfCap = DcnInvOvfSlots::kCap;   // overflow entries of one (tile, tap) staged through LDS
 
 // MODE of the plane kernels
@@ -122,12 +129,29 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
           R.n_ovf = sl->count;
           R.ovf = sl->e[tid & (kOvfCap - 1)];
         }
+        if constexpr (!kAFromL2) {
+#pragma unroll
+          for (int part = 0; part < PARTS; ++part)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+              R.a[part][r] = *reinterpret_cast<const f32x4 *>(wq_base + (size_t)t * (2 * kAPart) + part * kAPart +
+                                                              r * (kProducers * 16));
+        }
+      };
+      // consumers (kAFromL2): the wave's A fragments of stage j, 16 bytes per lane and fragment, coalesced
+      struct AFrag {
+        bf16x8 a[PARTS][2];
+      };
+      const unsigned char *wq_cons = reinterpret_cast<const unsigned char *>(p.wq) +
+                                     (size_t)((mt * n_c16 + c16) * K) * (2 * kAPart) + (lane >> 5) * (kTileM * 16) +
+                                     (wm * 64 + (lane & 31)) * 16;
+      auto a_issue = [&](int j, AFrag &F) {
+        const unsigned t = (unsigned)(t0 + min(j, n - 1));
+        const unsigned char *b = wq_cons + (size_t)t * (2 * kAPart);
 #pragma unroll
         for (int part = 0; part < PARTS; ++part)
 #pragma unroll
-          for (int r = 0; r < 2; ++r)
-            R.a[part][r] = *reinterpret_cast<const f32x4 *>(wq_base + (size_t)t * (2 * kAPart) + part * kAPart +
-                                                            r * (kProducers * 16));
+          for (int i = 0; i < 2; ++i) F.a[part][i] = *reinterpret_cast<const bf16x8 *>(b + part * kAPart + i * 32 * 16);
       };
       auto commit_ovf = [&](int slot, const Regs &R) {  // MODE 1: the stage's overflow slots -> LDS
         if constexpr (MODE == 1) {
@@ -136,6 +160,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         }
       };
       auto commit_weights = [&](int buf, const Regs &R) {
+        if constexpr (kAFromL2) return;
 #pragma unroll
         for (int part = 0; part < PARTS; ++part)
 #pragma unroll
@@ -258,7 +283,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         *reinterpret_cast<bf16x8 *>(dst) = hi;
         if constexpr (PARTS == 2) *reinterpret_cast<bf16x8 *>(dst + kBPart) = lo;
       };
-      auto multiply = [&](int buf) {
+      auto multiply = [&](int buf, const AFrag &F) {
         if constexpr (!PRODUCER) {
           const unsigned char *A = As + buf * PARTS * kAPart + (lane >> 5) * (kTileM * 16) + (wm * 64 + (lane & 31)) * 16;
           const unsigned char *B = Bs + buf * PARTS * kBPart + (lane >> 5) * (kTileN * 16) + (wn * 64 + (lane & 31)) * 16;
@@ -267,7 +292,8 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
           for (int part = 0; part < PARTS; ++part)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-              a[part][i] = *reinterpret_cast<const bf16x8 *>(A + part * kAPart + i * 32 * 16);
+              if constexpr (kAFromL2) a[part][i] = F.a[part][i];
+              else a[part][i] = *reinterpret_cast<const bf16x8 *>(A + part * kAPart + i * 32 * 16);
               b[part][i] = *reinterpret_cast<const bf16x8 *>(B + part * kBPart + i * 32 * 16);
             }
 #pragma unroll
@@ -285,11 +311,15 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
 
       // prologue: pipeline primed three deep, plane in LDS, stage 0 in buffer 0
       Regs R0, R1, R2;
+      AFrag F0, F1;   // two stages ahead is enough for L2 latency at ~1.4 us per stage; a third set spills
       __syncthreads();  // the previous segment's readers of plane / A / B are done
       if constexpr (PRODUCER) {
         issue(0, R0);
         issue(1, R1);
         issue(2, R2);
+      } else if constexpr (kAFromL2) {
+        a_issue(0, F0);
+        a_issue(1, F1);
       }
       load_plane();
       if constexpr (PRODUCER) {
@@ -305,7 +335,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       __syncthreads();
       // stage j: producers put the loads of stage j+3 in flight (RI, consumed one body ago), move the weight
       // stage j+1 (RC, loaded two bodies ago) into LDS and sample B stage j+1; consumers multiply stage j.
-      auto body = [&](int j, Regs &RI, Regs &RC, Regs &RN) {
+      auto body = [&](int j, Regs &RI, Regs &RC, Regs &RN, AFrag &FI) {   // FI: the fragments of stage j
         const int buf = j & 1;
         if constexpr (PRODUCER) {
           issue(j + 3, RI);
@@ -316,18 +346,19 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
             sample(buf ^ 1, RC, buf ^ 1);
           }
         } else {
-          if (j < n) multiply(buf);
+          if (j < n) multiply(buf, FI);
+          if constexpr (kAFromL2) a_issue(j + 2, FI);   // unconditional, clamped: stage j + 2 into the freed set
         }
         __syncthreads();
       };
       for (int j = 0; j < n; j += 6) {  // 6 = lcm(3 register sets, 2 LDS buffers): static names in the body
-        body(j, R0, R1, R2);
-        body(j + 1, R1, R2, R0);
-        body(j + 2, R2, R0, R1);
+        body(j, R0, R1, R2, F0);
+        body(j + 1, R1, R2, R0, F1);
+        body(j + 2, R2, R0, R1, F0);
         if (j + 3 < n) {
-          body(j + 3, R0, R1, R2);
-          body(j + 4, R1, R2, R0);
-          body(j + 5, R2, R0, R1);
+          body(j + 3, R0, R1, R2, F1);
+          body(j + 4, R1, R2, R0, F0);
+          body(j + 5, R2, R0, R1, F1);
         }
       }
       s += n;
