@@ -18,11 +18,13 @@
 //     loads it.  With the split MFMA the kernel is VALU-issue bound (SQ counters: MFMA pipe 30 % busy,
 //     waves stalled on issue 34 % of the time), so instructions per sample are what matters.
 //   * 12 waves, two roles: waves 0-7 are CONSUMERS (they own the 256 x 128 accumulator tile as 4 x 2 waves
-//     of 64 x 64 and do only operand-fragment reads and MFMAs), waves 8-11 are PRODUCERS (they stream the
-//     weight stages and build the next B stage: one thread samples 8 channels of one pixel).  The SIMD
-//     interleaves the roles' instruction streams; one barrier per stage hands the double-buffered stages over.
+//     of 64 x 64, read the B fragments from LDS, take their A (weight) fragments straight from the weight image in
+//     L2 -- 16 bytes per lane and fragment, two stages ahead in registers; KGDET_PLANE_A_FROM_L2=0 restores the LDS
+//     copy by the producers -- and issue the MFMAs), waves 8-11 are PRODUCERS (they build the next B stage: one
+//     thread samples 8 channels of one pixel).  The SIMD interleaves the roles' instruction streams; one barrier per
+//     stage hands the double-buffered stages over.
 //
-// Operand images (identical in global memory and LDS, so the weight stage is a lane-linear copy):
+// Operand images (the lane-linear fragment order a wave reads with one 16-byte load per lane):
 //   A stage (tap t, channel chunk c16, 256 output channels): [part][khalf][o 256][8 bf16]   8 KB / part
 //   B stage (same reduction slice, 128 pixels):              [part][khalf][px 128][8 bf16]  4 KB / part
 //   lane l of a wave reads row/col (l & 31) of k-half (l >> 5) as one 16-byte ds_read_b128; reduction
