@@ -58,7 +58,7 @@ import torch.distributed as dist  # noqa: E402
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md); AMD's 5 PF figure includes 2:1 sparsity
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0
-PLANE_GROUP_TRAFFIC_BYTES = 1.019e9  # profiles/r01_dcn_fwd_plane_group_b2.md: (2 x FETCH_SIZE + WRITE_SIZE) of the 3 kernels
+PLANE_GROUP_TRAFFIC_BYTES = 0.934e9  # profiles/r01_dcn_fwd_plane_group_b2.md: (2 x FETCH_SIZE + WRITE_SIZE) of the 3 kernels
 
 
 def dcn_roofline(device, iters=20):
