@@ -1,10 +1,10 @@
 #!/bin/bash
-# Kernel-trace stats of the bf16 batch-8 inference bench (run on the GPU box through gpurun).
-R=${1:-r01}
-OUT=$GRAFT_REPO_ROOT/gpurun_out/$R
-mkdir -p $OUT
+# Steady-state kernel table of the bf16 batch-8 inference bench (run on the GPU box through gpurun; keeps no trace).
+# The eager loop is profiled (--graph 0): a graph replay shows up as one opaque launch.
+R=${1:-r01i}
+OUT=/tmp/inferprof
+rm -rf $OUT; mkdir -p $OUT $GRAFT_REPO_ROOT/gpurun_out/$R
 cd /tmp && export TMPDIR=/tmp
-python3 $GRAFT_REPO_ROOT/bench.py --mode infer --dtype bf16 --imgs-per-gpu 8 --steps 3 --warmup 3 --no-cpu-baseline --no-roofline > $OUT/warm_infer.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/infer -o infer -- python3 $GRAFT_REPO_ROOT/bench.py --mode infer --dtype bf16 --imgs-per-gpu 8 --steps 10 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/infer.log 2>&1
-python3 $GRAFT_REPO_ROOT/tools/infer_phases.py 8 bf16 > $OUT/infer_phases.log 2>&1
-ls -R $OUT | head
+rocprofv3 --kernel-trace --output-format csv -d $OUT -o infer -- python3 $GRAFT_REPO_ROOT/bench.py --mode infer --dtype bf16 --imgs-per-gpu 8 --graph 0 --steps 10 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/infer.log 2>&1
+python3 $GRAFT_REPO_ROOT/tools/trace_steady_stats.py $OUT/infer_kernel_trace.csv multiclass_select 1 ${2:-60} > $GRAFT_REPO_ROOT/gpurun_out/$R/infer_steady.md
+head -12 $GRAFT_REPO_ROOT/gpurun_out/$R/infer_steady.md | cut -c1-150
