@@ -136,21 +136,37 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
       auto issue = [&](int j, Regs &R) __attribute__((always_inline)) {
         const int q = q0 + min(j, n - 1);
         R.rec = rec_src[(size_t)min(q * 16 + r_px, HoWo - 1) * 2];
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(gq_base + (size_t)q * (PARTS * kAPart)) + tid;
-        R.a0 = src[0];
-        R.a1 = src[kProducers];
-        if constexpr (PARTS == 2) {
-          R.a2 = src[2 * kProducers];
-          R.a3 = src[3 * kProducers];
+        if constexpr (!kAFromL2) {
+          const u32x4 *src = reinterpret_cast<const u32x4 *>(gq_base + (size_t)q * (PARTS * kAPart)) + tid;
+          R.a0 = src[0];
+          R.a1 = src[kProducers];
+          if constexpr (PARTS == 2) {
+            R.a2 = src[2 * kProducers];
+            R.a3 = src[3 * kProducers];
+          }
         }
       };
+      // consumers (kAFromL2, see dcn_plane.h): the wave's grad_out fragments of stage j straight from the fragment image
+      struct AFrag {
+        bf16x8 a[PARTS][2];
+      };
+      const unsigned char *gq_cons = gq_base + (lane >> 5) * (kTileM * 16) + (wm * 64 + (lane & 31)) * 16;
+      auto a_issue = [&](int j, AFrag &F) __attribute__((always_inline)) {
+        const unsigned char *bsrc = gq_cons + (size_t)(q0 + min(j, n - 1)) * (PARTS * kAPart);
+#pragma unroll
+        for (int part = 0; part < PARTS; ++part)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) F.a[part][i] = *reinterpret_cast<const bf16x8 *>(bsrc + part * kAPart + i * 32 * 16);
+      };
       auto commit = [&](int a_slot, int r_slot2, const Regs &R) __attribute__((always_inline)) {  // grad_out stage -> As[a_slot], records -> Rs[r_slot2]
-        u32x4 *dst = reinterpret_cast<u32x4 *>(As + a_slot * PARTS * kAPart) + tid;
-        dst[0] = R.a0;
-        dst[kProducers] = R.a1;
-        if constexpr (PARTS == 2) {
-          dst[2 * kProducers] = R.a2;
-          dst[3 * kProducers] = R.a3;
+        if constexpr (!kAFromL2) {
+          u32x4 *dst = reinterpret_cast<u32x4 *>(As + a_slot * PARTS * kAPart) + tid;
+          dst[0] = R.a0;
+          dst[kProducers] = R.a1;
+          if constexpr (PARTS == 2) {
+            dst[2 * kProducers] = R.a2;
+            dst[3 * kProducers] = R.a3;
+          }
         }
         Rs[r_slot2 * 256 + r_slot] = R.rec;
       };
@@ -215,7 +231,7 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
           if constexpr (PARTS == 2) *reinterpret_cast<bf16x2 *>(dst + kBPart) = lo;
         }
       };
-      auto multiply = [&](int a_slot, int buf) __attribute__((always_inline)) {
+      auto multiply = [&](int a_slot, int buf, const AFrag &F) __attribute__((always_inline)) {
         if constexpr (!PRODUCER) {
           const unsigned char *A = As + a_slot * PARTS * kAPart + (lane >> 5) * (kTileM * 16) + (wm * 64 + (lane & 31)) * 16;
           const unsigned char *B = Bs + buf * PARTS * kBPart + (lane >> 5) * (kTileN * 16);
@@ -225,7 +241,8 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
               const int col = wn * 64 + i * 32 + (lane & 31);
-              a[part][i] = *reinterpret_cast<const bf16x8 *>(A + part * kAPart + i * 32 * 16);
+              if constexpr (kAFromL2) a[part][i] = F.a[part][i];
+              else a[part][i] = *reinterpret_cast<const bf16x8 *>(A + part * kAPart + i * 32 * 16);
               bb[part][i] = *reinterpret_cast<const bf16x8 *>(B + part * kBPart + (col ^ (col >> 4)) * 16);
             }
 #pragma unroll
@@ -246,10 +263,14 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
       // Pipeline of stage s: global loads at body s-4, registers -> LDS (A ring slot s % 3, record slot s & 1) at
       // body s-2, sampled into B[s & 1] at body s-1, multiplied at body s.  Two register sets alternate.
       Regs RA, RB;
+      AFrag FA, FB;
       __syncthreads();
       if constexpr (PRODUCER) {
         issue(0, RA);
         issue(1, RB);
+      } else if constexpr (kAFromL2) {
+        a_issue(0, FA);
+        a_issue(1, FB);
       }
       load_plane();
       if constexpr (PRODUCER) {
@@ -264,25 +285,26 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
       // I = body index inside the unrolled group of 6 (compile time: the LDS slots are immediates and the six
       // bodies stay distinct -- with run-time slot arithmetic hipcc merged them back into a loop and kept the
       // two register sets in scratch memory, stalling on every freshly issued load to spill it)
-      auto body = [&](auto I, int j, Regs &R) __attribute__((always_inline)) {  // R holds stage j+2
+      auto body = [&](auto I, int j, Regs &R, AFrag &F) __attribute__((always_inline)) {  // R holds stage j+2, F stage j
         constexpr int i = decltype(I)::value;
         if constexpr (PRODUCER) {
           commit((i + 2) % 3, i & 1, R);
           issue(j + 4, R);
           if (j + 1 < n) sample((i + 1) & 1);
         } else {
-          if (j < n) multiply(i % 3, i & 1);
+          if (j < n) multiply(i % 3, i & 1, F);
+          if constexpr (kAFromL2) a_issue(j + 2, F);
         }
         __syncthreads();
       };
       for (int j = 0; j < n; j += 6) {  // 6 = lcm(3 A slots, 2 B / record slots, 2 register sets)
-        body(std::integral_constant<int, 0>{}, j, RA);
-        body(std::integral_constant<int, 1>{}, j + 1, RB);
-        body(std::integral_constant<int, 2>{}, j + 2, RA);
+        body(std::integral_constant<int, 0>{}, j, RA, FA);
+        body(std::integral_constant<int, 1>{}, j + 1, RB, FB);
+        body(std::integral_constant<int, 2>{}, j + 2, RA, FA);
         if (j + 3 < n) {
-          body(std::integral_constant<int, 3>{}, j + 3, RB);
-          body(std::integral_constant<int, 4>{}, j + 4, RA);
-          body(std::integral_constant<int, 5>{}, j + 5, RB);
+          body(std::integral_constant<int, 3>{}, j + 3, RB, FB);
+          body(std::integral_constant<int, 4>{}, j + 4, RA, FA);
+          body(std::integral_constant<int, 5>{}, j + 5, RB, FB);
         }
       }
       s += n;
