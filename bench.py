@@ -43,7 +43,35 @@ def parse_args():
     return ap.parse_args()
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves (the reference's
+    tools/dist_train.sh:8-10 does the same with torch.distributed.launch).  This parent never touches the GPU
+    (`device_count` does not initialise it on this image); the ranks are CHILD processes and the parent exits with
+    the launcher's code -- no exec from a GPU-initialised process."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.exit('bench.py: --gpus %d requested but this node exposes %d GPU(s); refusing to print a %d-GPU line '
+                 'from fewer devices' % (args.gpus, have, args.gpus))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
+               OMP_NUM_THREADS=os.environ.get('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus))))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 ARGS = parse_args() if __name__ == '__main__' else None
+if ARGS is not None:
+    if 'RANK' not in os.environ and ARGS.gpus > 1:
+        launch_ranks(ARGS)
+    if int(os.environ.get('WORLD_SIZE', 1)) != ARGS.gpus:
+        sys.exit('bench.py: --gpus %d but WORLD_SIZE=%s' % (ARGS.gpus, os.environ.get('WORLD_SIZE', '1')))
 # MIOpen's measured solver picks for this workload's convolution shapes on MI355X (written by MIOpen itself during
 # a first run on the GPU box, see kgdet_amd/miopen_db/README.md): with the records present the find step is a
 # lookup instead of minutes of measuring.  One directory per workload; must be set before MIOpen is initialised.
@@ -131,6 +159,28 @@ def cpu_baseline():
                        'scaled to the 12 DeformConv calls of one head forward' % (n, t))
 
 
+def allreduce_busbw(device, world, numel=52250071, iters=10):
+    """Bus bandwidth of the gradient exchange on its own: ONE fp32 buffer of the step's whole payload
+    (52 250 071 gradient values = 209.0 MB), ring convention busbw = 2(N-1)/N * bytes / t."""
+    buf = torch.zeros(numel, dtype=torch.float32, device=device)
+    for _ in range(3):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.time()
+    for _ in range(iters):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    t = torch.tensor([(time.time() - t0) / iters], device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t = float(t.item())
+    byts = numel * 4.0
+    return dict(payload_MB=round(byts / 1e6, 1), ms=round(t * 1e3, 3), algbw_GBs=round(byts / t / 1e9, 1),
+                busbw_GBs=round(2.0 * (world - 1) / world * byts / t / 1e9, 1),
+                note='standalone (not overlapped) all-reduce of the full gradient payload over RCCL/xGMI; in the '
+                     'step it runs in 32 MB buckets on a side stream under backward')
+
+
 def main():
     args = ARGS
     rank = int(os.environ.get('RANK', 0))
@@ -214,6 +264,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    ar = allreduce_busbw(device, world) if (world > 1 and args.mode == 'train') else None
     if rank == 0:
         imgs = args.imgs_per_gpu * world * args.steps
         out = {
@@ -221,7 +272,8 @@ def main():
             else 'inference images/sec KGDet R50-FPN 800x1333',
             'value': round(imgs / dt, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.dtype == 'fp32' else 'bf16(dense convs)+f32(deformable path)',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 (bf16x3 split products, f32 accumulate)' if args.dtype == 'fp32'
+            else 'bf16 (dense convs and deformable operands, f32 accumulate)',
             'data': 'synthetic',
             'config': {'workload': 'KGDet R50-FPN %s step, %d img/GPU at 800x1333 (padded 800x1344), '
                                    '%s' % (args.mode, args.imgs_per_gpu,
@@ -234,6 +286,8 @@ def main():
             out['config']['detections_per_image'] = round(n_det[0] / args.imgs_per_gpu, 1)
         if not args.no_roofline:
             out['roofline'] = dcn_roofline(device)
+        if ar is not None:
+            out['allreduce'] = ar
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

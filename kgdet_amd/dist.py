@@ -8,10 +8,11 @@ world size, copied back, then clipped and applied -- nothing overlaps.
 is the MI355X design: parameters are bucketed in reverse registration order (roughly the order
 autograd finishes them: head first, backbone last); a post-accumulate-grad hook fires a bucket's
 all-reduce on a side HIP stream as soon as its last gradient is ready, so RCCL traffic over the
-xGMI links hides under the backbone's backward.  The division by the world size is folded into the
-bucket copy.  Parameters that never receive a gradient (the unused FPN2 branches) are
+xGMI links hides under the backbone's backward.  Gradients are packed with one multi-tensor copy per
+bucket and never copied back (``p.grad`` becomes a view of the bucket).  Parameters that never receive a gradient (the unused FPN2 branches) are
 found on the first step and excluded, like the reference's ``param.grad is not None`` filter.
 """
+import contextlib
 from collections import OrderedDict
 
 import torch
@@ -52,7 +53,23 @@ def clip_grads(params, max_norm=35, norm_type=2):
 
 
 class OverlappedGradReducer(object):
-    """Bucketed all-reduce launched from gradient hooks, overlapped with the rest of backward."""
+    """Bucketed all-reduce launched from gradient hooks, overlapped with the rest of backward.
+
+    Per bucket and step: ONE multi-tensor copy of the finished gradients into the bucket's flat buffer
+    (``torch._foreach_copy_``), the RCCL all-reduce, ONE division by the world size (all_reduce then ``div_``:
+    the arithmetic of dist_utils.py:17-19), all on a side HIP stream that is ordered after the producing
+    stream by an event.  There is no copy back: after the exchange ``p.grad`` IS the bucket view, so the
+    optimizer and the gradient clip read the averaged values in place.
+
+    Stream contract (the round-1 version got this wrong): ``work.wait()`` is called with the SIDE stream
+    current, so the division is ordered after the collective; the caller's stream waits for the side stream
+    once, at the end of ``finish()``, before any gradient is replaced by its view (which also keeps the
+    caching allocator from handing a packed-from gradient to somebody else before the pack has read it).
+
+    The set of gradient-carrying parameters must be the same on every rank (as for the reference's
+    ``param.grad is not None`` filter).  A bucketed parameter without a gradient in some step contributes
+    zeros; a parameter that starts to receive gradients later makes the buckets rebuild.
+    """
 
     def __init__(self, params, bucket_size_mb=32, process_group=None):
         self.group = process_group
@@ -65,9 +82,13 @@ class OverlappedGradReducer(object):
         self.stream = torch.cuda.Stream() if self.use_cuda else None
         self._hooks = []
         self._pending = []
+        self.launched_from_hooks = 0   # buckets whose exchange started inside backward (diagnostics / tests)
 
     # -- bucket construction ----------------------------------------------------------------------
     def _build(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
         order = list(reversed(self.active))
         self.buckets, cur, cur_bytes = [], [], 0
         for p in order:
@@ -81,81 +102,100 @@ class OverlappedGradReducer(object):
             self.buckets.append(cur)
         self._bucket_of = {}
         self._flat = []
+        self._views = []
         for b, plist in enumerate(self.buckets):
+            flat = torch.empty(sum(p.numel() for p in plist), dtype=plist[0].dtype, device=plist[0].device)
+            views, off = [], 0
             for p in plist:
                 self._bucket_of[p] = b
-            self._flat.append(torch.empty(sum(p.numel() for p in plist), dtype=plist[0].dtype,
-                                          device=plist[0].device))
+                views.append(flat[off:off + p.numel()].view(p.shape))
+                off += p.numel()
+            self._flat.append(flat)
+            self._views.append(views)
+        active = set(self.active)
+        self._inactive = [p for p in self.params if p not in active]
         for p in self.active:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self._reset_counts()
 
     def _reset_counts(self):
         self._remaining = [len(b) for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
         self._pending = []
 
     # -- per-step -------------------------------------------------------------------------------
+    def _side(self):
+        return torch.cuda.stream(self.stream) if self.use_cuda else contextlib.nullcontext()
+
     def _launch(self, b):
-        plist, flat = self.buckets[b], self._flat[b]
+        plist, flat, views = self.buckets[b], self._flat[b], self._views[b]
         if self.use_cuda:
             self.stream.wait_stream(torch.cuda.current_stream())
-            ctx = torch.cuda.stream(self.stream)
-        else:
-            import contextlib
-            ctx = contextlib.nullcontext()
-        with ctx:
-            off = 0
-            for p in plist:  # pack, pre-divided by the world size
-                n = p.numel()
-                torch.mul(p.grad.reshape(-1), 1.0 / self.world_size, out=flat[off:off + n])
-                off += n
+        with self._side():
+            dst = [v for p, v in zip(plist, views) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+            src = [p.grad for p, v in zip(plist, views) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+            if dst:
+                torch._foreach_copy_(dst, src)      # strided sources are fine: copy_ semantics per tensor
+            for p, v in zip(plist, views):
+                if p.grad is None:                  # no gradient this step: contributes zeros
+                    v.zero_()
             work = dist.all_reduce(flat, group=self.group, async_op=True)
+        self._launched[b] = True
         self._pending.append((b, work))
 
     def _on_grad(self, p):
         b = self._bucket_of[p]
         self._remaining[b] -= 1
-        if self._remaining[b] == 0:
+        if self._remaining[b] == 0 and not self._launched[b]:
+            self.launched_from_hooks += 1
             self._launch(b)
 
     def finish(self):
-        """Call after ``loss.backward()``: waits for the buckets and writes averaged grads back."""
+        """Call after ``loss.backward()``: completes the exchange; afterwards every bucketed parameter's
+        ``.grad`` is the averaged gradient (a view of its bucket)."""
+        if self.buckets is not None and any(p.grad is not None for p in self._inactive):
+            # a parameter started to receive gradients: nothing of this step is usable as launched
+            for _, work in self._pending:
+                work.wait()
+            if self.use_cuda:
+                torch.cuda.current_stream().wait_stream(self.stream)
+            for h in self._hooks:
+                h.remove()
+            self._hooks, self.buckets = [], None
         if self.buckets is None:
             # first step: plain (reference-style) all-reduce, and learn which params get gradients
             self.active = [p for p in self.params if p.grad is not None]
             _allreduce_coalesced([p.grad.data for p in self.active], self.world_size, -1)
             self._build()
             return
-        for b, r in enumerate(self._remaining):  # buckets whose hooks did not all fire this step
-            if r > 0:
+        for b in range(len(self.buckets)):   # buckets whose hooks did not all fire this step
+            if not self._launched[b]:
                 self._launch(b)
-        for b, work in self._pending:
-            work.wait()
-            if self.use_cuda:
-                ctx = torch.cuda.stream(self.stream)
-            else:
-                import contextlib
-                ctx = contextlib.nullcontext()
-            with ctx:
-                off = 0
-                for p in self.buckets[b]:
-                    n = p.numel()
-                    if p.grad is not None:
-                        p.grad.copy_(self._flat[b][off:off + n].view_as(p.grad))
-                    off += n
+        with self._side():
+            for b, work in self._pending:
+                work.wait()                  # orders the SIDE stream after the collective
+                self._flat[b].div_(self.world_size)
         if self.use_cuda:
             torch.cuda.current_stream().wait_stream(self.stream)
+        for plist, views in zip(self.buckets, self._views):
+            for p, v in zip(plist, views):
+                p.grad = v
         self._reset_counts()
 
 
 class DistOptimizerHook(object):
-    """zero_grad -> backward -> all-reduce -> clip -> step (dist_utils.py:44-58), callable without mmcv."""
+    """zero_grad -> backward -> all-reduce -> clip -> step (dist_utils.py:44-58), callable without mmcv.
 
-    def __init__(self, grad_clip=None, coalesce=True, bucket_size_mb=-1, overlap=False):
+    ``force_distributed=True`` runs the exchange even in a one-rank group (the reference skips nothing either:
+    it all-reduces whenever it was launched distributed) -- used to exercise the RCCL / side-stream path on a
+    single GPU."""
+
+    def __init__(self, grad_clip=None, coalesce=True, bucket_size_mb=-1, overlap=False, force_distributed=False):
         self.grad_clip = grad_clip
         self.coalesce = coalesce
         self.bucket_size_mb = bucket_size_mb
         self.overlap = overlap
+        self.force_distributed = force_distributed
         self._reducer = None
         self._params = None
 
@@ -164,7 +204,8 @@ class DistOptimizerHook(object):
 
     def step(self, model, optimizer, loss):
         optimizer.zero_grad()
-        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        distributed = dist.is_available() and dist.is_initialized() and \
+            (dist.get_world_size() > 1 or self.force_distributed)
         if distributed and self.overlap and self._reducer is None:
             self._reducer = OverlappedGradReducer(list(model.parameters()),
                                                   self.bucket_size_mb if self.bucket_size_mb > 0 else 32)

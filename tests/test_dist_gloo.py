@@ -53,6 +53,40 @@ def _worker(rank, world, port, q):
         for p, g in zip(model.parameters(), g_ref):
             ok &= bool(torch.allclose(p.grad, g, atol=1e-6))
     ok &= len(red.buckets) > 1
+    ok &= red.launched_from_hooks >= len(red.buckets)      # exchanges started inside backward, not in finish()
+    ok &= all(p.grad.data_ptr() == v.data_ptr() for pl, vl in zip(red.buckets, red._views) for p, v in zip(pl, vl))
+
+    # a bucketed parameter without a gradient in one step contributes zeros (used to raise / hang) ...
+    for p in params:
+        p.grad = None
+    model[0](x).pow(2).sum().backward()            # only the first Linear receives gradients
+    g0 = [p.grad.clone() for p in model[0].parameters()]
+    red.finish()
+    dist.all_gather_object(gathered, [g.numpy() for g in g0])
+    for i, p in enumerate(model[0].parameters()):
+        mean = sum(torch.from_numpy(gathered[r][i]) for r in range(world)) / world
+        ok &= bool(torch.allclose(p.grad, mean, atol=1e-6))
+    ok &= all(float(p.grad.abs().max()) == 0.0 for p in model[2].parameters())
+    # ... and a parameter that starts to receive gradients later is picked up (buckets rebuild)
+    for p in params:
+        p.grad = None
+    (model(x).pow(2).sum() + unused(x[:, :3]).pow(2).sum()).backward()
+    gu = [p.grad.clone() for p in unused.parameters()]
+    red.finish()
+    dist.all_gather_object(gathered, [g.numpy() for g in gu])
+    for i, p in enumerate(unused.parameters()):
+        mean = sum(torch.from_numpy(gathered[r][i]) for r in range(world)) / world
+        ok &= bool(torch.allclose(p.grad, mean, atol=1e-6))
+    ok &= all(p in red._bucket_of for p in unused.parameters())
+    # non-contiguous gradients are packed by value, not by storage order
+    wt = nn.Parameter(torch.randn(4, 6, generator=torch.Generator().manual_seed(7)))
+    red2 = OverlappedGradReducer([wt], bucket_size_mb=1)
+    for step in range(2):
+        wt.grad = (torch.arange(24.).reshape(6, 4) * (rank + 1)).t()     # strided
+        if step:
+            red2._on_grad(wt)
+        red2.finish()
+        ok &= bool(torch.equal(wt.grad, torch.arange(24.).reshape(6, 4).t() * (sum(range(1, world + 1)) / world)))
 
     # the optimizer hook end to end: both ranks stay in sync
     opt = torch.optim.SGD(params, lr=0.1)
