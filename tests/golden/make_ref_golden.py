@@ -1,0 +1,237 @@
+"""Generate the REFERENCE-PINNED fixtures (build container only; needs /root/reference):
+
+    python tests/golden/make_ref_golden.py            -> tests/golden/ref_targets_golden.npz
+                                                          tests/golden/ref_head_golden.npz
+                                                          tests/golden/ref_serial_golden.npz
+
+Everything stored is an OUTPUT OF THE REFERENCE'S OWN PYTHON executed in place by tests/golden/ref_loader.py
+(point_generator.py, point_assigner.py, max_iou_assigner.py, geometry.py, point_target_kp.py, focal_loss.py,
+smooth_l1_loss.py, bbox_nms_kp.py + the compiled nms_cpu.cpp, and the head modules
+reppoints_head_kp3rep_cas_1_assign_once.py / reppoints_head_kp_serial.py) on seeded inputs that the tests
+re-create from the same seeds (tests/golden/ref_cases.py).  Only data travels: no reference text.
+
+The deformable convolution inside the reference heads is the test-side CPU formulation (the reference has it
+only in CUDA) -- see ref_loader.py for exactly what is reference code and what is glue.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from tests.golden import ref_cases, ref_loader  # noqa: E402
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _cfg(d):
+    from kgdet_amd.configs import ConfigDict
+    return ConfigDict(d)
+
+
+# ---------------------------------------------------------------------------------------------------
+def targets(ns, out):
+    for name, case in ref_cases.target_cases().items():
+        gens = [ns.PointGenerator() for _ in case['strides']]
+        pts = [g.grid_points(fs, s, device='cpu') for g, fs, s in zip(gens, case['featmaps'], case['strides'])]
+        for lvl, p in enumerate(pts):
+            out['%s:points%d' % (name, lvl)] = _np(p)
+        B = len(case['gt_bboxes'])
+        flags = []
+        for b in range(B):
+            h, w = case['pad_shapes'][b][:2]
+            fl = []
+            for g, (fh, fw), s in zip(gens, case['featmaps'], case['strides']):
+                vh, vw = min(int(np.ceil(h / s)), fh), min(int(np.ceil(w / s)), fw)
+                fl.append(g.valid_flags((fh, fw), (vh, vw), device='cpu'))
+            flags.append(fl)
+            out['%s:flags%d' % (name, b)] = _np(torch.cat(fl)).astype(np.uint8)
+        metas = [dict(pad_shape=ps) for ps in case['pad_shapes']]
+        cfg = _cfg(case['cfg'])
+        if case.get('boxes_as_proposals'):        # MaxIoUAssigner stage of the serial head: proposals are boxes
+            props = [[ref_cases.pseudo_boxes(p, b, lvl) for lvl, p in enumerate(pts)] for b in range(B)]
+        else:
+            props = [[p.clone() for p in pts] for _ in range(B)]
+        try:
+            res = ns.point_target_kp(props, [[f.clone() for f in fl] for fl in flags],
+                                     [g.clone() for g in case['gt_bboxes']], [k.clone() for k in case['gt_keypoints']],
+                                     metas, cfg, gt_bboxes_ignore_list=None,
+                                     gt_labels_list=[lab.clone() for lab in case['gt_labels']],
+                                     label_channels=13, sampling=False)
+        except Exception as e:                      # the reference's behaviour on this input IS an error
+            out['%s:error' % name] = np.array(type(e).__name__)
+            print(name, '-> reference raises', type(e).__name__, e)
+            continue
+        keys = ['labels', 'label_weights', 'bbox_gt', 'proposals', 'proposal_weights', 'keypoint_gt', 'keypoint_weights']
+        assert B >= 2                  # (images_to_levels squeezes a batch of one: every case has two images)
+        labels_all = _np(torch.cat(res[0], 1))
+        for k, per_level in zip(keys, res[:7]):
+            a = _np(torch.cat(per_level, 1))                          # levels concatenated: [B, P_total, ...]
+            if k in ('keypoint_gt', 'keypoint_weights'):              # [B, P, 294, 2]: zero off the positives
+                assert np.abs(a[labels_all == 0]).max(initial=0) == 0
+                out['%s:%s_pos' % (name, k)] = a[labels_all > 0]
+            else:
+                out['%s:%s' % (name, k)] = a
+        out['%s:num_total_pos' % name] = np.int64(res[7])
+        out['%s:num_total_neg' % name] = np.int64(res[8])
+        print(name, 'pos', int(res[7]), 'neg', int(res[8]))
+
+    # geometry.bbox_overlaps / MaxIoUAssigner.assign / PointAssigner.assign on their own
+    a, b = ref_cases.overlap_boxes()
+    for mode in ('iou', 'iof'):
+        out['overlaps:%s' % mode] = _np(ns.bbox_overlaps(a, b, mode=mode))
+        out['overlaps:%s_aligned' % mode] = _np(ns.bbox_overlaps(a[:b.shape[0]], b, mode=mode, is_aligned=True))
+    for tag, kw in ref_cases.max_iou_cases().items():
+        r = ns.MaxIoUAssigner(**kw).assign(a, b, None, ref_cases.overlap_labels())
+        out['maxiou:%s:gt_inds' % tag] = _np(r.gt_inds)
+        out['maxiou:%s:max_overlaps' % tag] = _np(r.max_overlaps)
+        out['maxiou:%s:labels' % tag] = _np(r.labels)
+    for tag, (pts, gts, labels, kw) in ref_cases.point_assigner_cases().items():
+        try:
+            r = ns.PointAssigner(**kw).assign(pts, gts, None, labels)
+        except Exception as e:
+            out['pointassign:%s:error' % tag] = np.array(type(e).__name__)
+            continue
+        out['pointassign:%s:gt_inds' % tag] = _np(r.gt_inds)
+        if r.labels is not None:
+            out['pointassign:%s:labels' % tag] = _np(r.labels)
+
+    # losses: the reference's own pure-torch focal (focal_loss.py:10-25) and smooth L1
+    pred, target, weight = ref_cases.focal_inputs()
+    onehot = torch.zeros_like(pred)
+    pos = target > 0
+    onehot[pos.nonzero().squeeze(1), target[pos] - 1] = 1
+    for dt, tag in ((torch.float32, 'f32'), (torch.float64, 'f64')):
+        p = pred.detach().clone().to(dt).requires_grad_(True)
+        el = ns.py_sigmoid_focal_loss(p, onehot, None, 2.0, 0.25, 'none')
+        out['focal:%s:elementwise' % tag] = _np(el)
+        total = ns.py_sigmoid_focal_loss(p, onehot, weight.view(-1, 1).to(dt), 2.0, 0.25, 'mean', avg_factor=6.0)
+        total.backward()
+        out['focal:%s:weighted_mean' % tag] = _np(total)
+        out['focal:%s:grad' % tag] = _np(p.grad)
+    sp, st, sw = ref_cases.smooth_l1_inputs()
+    out['smooth_l1:elementwise'] = _np(ns.smooth_l1_loss(sp, st, beta=0.11, reduction='none'))
+    out['smooth_l1:weighted'] = _np(ns.SmoothL1Loss(beta=0.11, loss_weight=0.5)(sp, st, sw, avg_factor=7.0))
+
+
+# ---------------------------------------------------------------------------------------------------
+def _load_into_reference(ref_head, our_head):
+    missing = ref_head.load_state_dict(our_head.state_dict(), strict=True)   # the checkpoint key contract, both ways
+    assert not missing.missing_keys and not missing.unexpected_keys
+
+
+def _loss_total(losses):
+    return sum(sum(v) if isinstance(v, (list, tuple)) else v for v in losses.values())
+
+
+def kgdet_head(ns, out):
+    """The reference's KGDet head (full width: 256 channels, 588 keypoint channels, 83 reppoints) on the
+    training-step shape [2, 256, 25, 42], weights from ref_cases.kgdet_head()."""
+    from kgdet_amd import configs
+    cfg = configs.kgdet_r50_fpn()
+    ours = ref_cases.kgdet_head()
+    hc = dict(cfg.model.bbox_head)
+    hc.pop('type')
+    ref = ns.head_kgdet.RepPointsHeadKp3RepCas1AssignOnce(**hc)
+    _load_into_reference(ref, ours)
+    x, batch = ref_cases.kgdet_inputs()
+    names = ['cls_1', 'cls_2', 'cls_3', 'kpt_1', 'kpt_2', 'kpt_3', 'bbox_1', 'bbox_2', 'bbox_3']
+
+    ref64 = ref.double()
+    x64 = x.double().requires_grad_(True)
+    outs = ref64([x64], batch['img_meta'])
+    for n, o in zip(names, outs):
+        a = _np(o[0])
+        out['out:' + n] = (a[:, ::ref_cases.KPT_STRIDE * 3] if n.startswith('kpt') else a).astype(np.float32)
+    losses = ref64.loss(*outs, batch['gt_bboxes'], batch['gt_labels'], batch['gt_keypoints'], batch['img_meta'],
+                        cfg.train_cfg)
+    for k, v in losses.items():
+        out['loss:' + k] = np.float64(sum(float(t) for t in v))
+    _loss_total(losses).backward()
+    out['grad:x'] = _np(x64.grad)[:, ::8].astype(np.float32)
+    for pname, p in ref64.named_parameters():
+        if p.grad is not None:
+            out['gradnorm:' + pname] = np.float64(p.grad.norm())
+    g = dict(ref64.named_parameters())
+    out['grad:kp_rep_block_3.cls_dfmconv_7.weight'] = _np(g['kp_rep_block_3.cls_dfmconv_7.weight'].grad)[::16, ::16]
+    out['grad:kp_rep_block_2.keypts_dfmconv_3.weight'] = _np(g['kp_rep_block_2.keypts_dfmconv_3.weight'].grad)[::8, ::8]
+    out['grad:moment_transfer'] = _np(g['moment_transfer'].grad)
+    print('kgdet head losses', {k: float(v) for k, v in out.items() if k.startswith('loss:')})
+
+    ref32 = ref.float().eval()
+    with torch.no_grad():
+        outs = ref32([x], batch['img_meta'])
+        res = ref32.get_bboxes(*outs, batch['img_meta'], cfg.test_cfg, rescale=True, nms=False)
+        out['dec:bboxes'] = np.stack([_np(r[0]) for r in res])
+        out['dec:scores'] = np.stack([_np(r[1]) for r in res])
+        out['dec:kpts'] = np.stack([_np(r[2]) for r in res])[:, :, ::ref_cases.KPT_STRIDE * 3]
+        det = ref32.get_bboxes(*ref32([x], batch['img_meta']), batch['img_meta'], cfg.test_cfg, rescale=True, nms=True)
+        for i, (db, dl, dk) in enumerate(det):
+            out['det%d:bboxes' % i], out['det%d:labels' % i] = _np(db), _np(dl)
+            out['det%d:kpts' % i] = _np(dk)[:, ::ref_cases.KPT_STRIDE * 3]
+            print('image', i, 'detections', db.shape[0])
+
+
+def serial_head(ns, out):
+    """The reference's serial (config 5) head: 5 pyramid levels, PointAssigner init stage + MaxIoUAssigner
+    refine stage, weights from ref_cases.serial_head()."""
+    from kgdet_amd import configs
+    cfg = configs.reppoints_kp_r50_fpn()
+    ours = ref_cases.serial_head()
+    hc = dict(cfg.model.bbox_head)
+    hc.pop('type')
+    ref = ns.head_serial.RepPointsHeadKpSerial(**hc)
+    _load_into_reference(ref, ours)
+    xs, batch = ref_cases.serial_inputs()
+    names = ['cls', 'kpt_init', 'kpt_refine', 'rep_init', 'rep_refine']
+    # float32 throughout (the reference's own precision): its refine stage mixes predicted boxes with the GT
+    # tensors, which modern torch refuses across dtypes
+    ref64 = ref
+    x64 = [x.clone().requires_grad_(True) for x in xs]
+    outs = ref64(x64, batch['img_meta'])
+    for n, o in zip(names, outs):
+        for lvl, t in enumerate(o):
+            a = _np(t)
+            out['out:%s:%d' % (n, lvl)] = a[:, ::ref_cases.KPT_STRIDE * 3] if n.startswith('kpt') else a
+    losses = ref64.loss(*outs, batch['gt_bboxes'], batch['gt_labels'], batch['gt_keypoints'], batch['img_meta'],
+                        cfg.train_cfg)
+    for k, v in losses.items():
+        out['loss:' + k] = np.array([float(t) for t in v], np.float64)
+    _loss_total(losses).backward()
+    for lvl, x in enumerate(x64):
+        out['grad:x%d' % lvl] = _np(x.grad)[:, ::8]
+    for pname, p in ref64.named_parameters():
+        if p.grad is not None:
+            out['gradnorm:' + pname] = np.float64(p.grad.norm())
+    print('serial head losses', {k: v.sum() for k, v in out.items() if k.startswith('loss:')})
+    ref32 = ref.float().eval()
+    with torch.no_grad():
+        for tag, test_cfg in (('nms', cfg.test_cfg), ('soft', ref_cases.soft_nms_test_cfg(cfg.test_cfg))):
+            det = ref32.get_bboxes(*ref32(xs, batch['img_meta']), batch['img_meta'], test_cfg, rescale=True, nms=True)
+            for i, (db, dl, dk) in enumerate(det):
+                out['%s:det%d:bboxes' % (tag, i)], out['%s:det%d:labels' % (tag, i)] = _np(db), _np(dl)
+                out['%s:det%d:kpts' % (tag, i)] = _np(dk)[:, ::ref_cases.KPT_STRIDE * 3]
+                print(tag, 'image', i, 'detections', db.shape[0])
+
+
+def main():
+    ns = ref_loader.load()
+    which = sys.argv[1:] or ['targets', 'head', 'serial']
+    for name, fn, fname in (('targets', targets, 'ref_targets_golden.npz'), ('head', kgdet_head, 'ref_head_golden.npz'),
+                            ('serial', serial_head, 'ref_serial_golden.npz')):
+        if name in which:
+            out = {}
+            fn(ns, out)
+            path = os.path.join(HERE, fname)
+            np.savez_compressed(path, **out)
+            print('wrote', path, os.path.getsize(path), 'bytes,', len(out), 'arrays')
+
+
+if __name__ == '__main__':
+    main()

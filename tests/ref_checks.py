@@ -1,0 +1,209 @@
+"""Comparisons of this repo's host logic / head against the REFERENCE-PINNED fixtures
+(tests/golden/ref_*_golden.npz, made by tests/golden/make_ref_golden.py from the reference's own Python).
+Device-agnostic: the CPU suite runs them with the test-side CPU ops, the GPU suite with the HIP ops."""
+import os
+
+import numpy as np
+import torch
+
+from kgdet_amd import configs, points
+from kgdet_amd.registry import ConfigDict
+from tests.golden import ref_cases
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+KEYS = ['labels', 'label_weights', 'bbox_gt', 'proposals', 'proposal_weights', 'keypoint_gt', 'keypoint_weights']
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.abs(a - b).max(initial=0)) / max(float(np.abs(b).max(initial=0)), 1e-6)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def case_inputs(case, device):
+    gens = [points.PointGenerator() for _ in case['strides']]
+    pts = [g.grid_points(fs, s, device=device) for g, fs, s in zip(gens, case['featmaps'], case['strides'])]
+    flags = []
+    for ps in case['pad_shapes']:
+        fl = []
+        for g, (fh, fw), s in zip(gens, case['featmaps'], case['strides']):
+            vh, vw = min(int(np.ceil(ps[0] / s)), fh), min(int(np.ceil(ps[1] / s)), fw)
+            fl.append(g.valid_flags((fh, fw), (vh, vw), device=device))
+        flags.append(fl)
+    return pts, flags
+
+
+def check_points_and_flags(G, name, case, device):
+    pts, flags = case_inputs(case, device)
+    for lvl, p in enumerate(pts):
+        assert np.array_equal(_np(p), G['%s:points%d' % (name, lvl)])
+    for b, fl in enumerate(flags):
+        assert np.array_equal(_np(torch.cat(fl)).astype(np.uint8), G['%s:flags%d' % (name, b)])
+    return pts, flags
+
+
+def run_point_target(case, device, dense):
+    pts, flags = case_inputs(case, device)
+    B = len(case['gt_bboxes'])
+    cfg = ConfigDict(case['cfg'])
+    to = lambda l: [t.to(device) for t in l]
+    if case.get('boxes_as_proposals'):
+        props = [[ref_cases.pseudo_boxes(p.cpu(), b, lvl).to(device) for lvl, p in enumerate(pts)] for b in range(B)]
+    else:
+        props = [[p.clone() for p in pts] for _ in range(B)]
+    if dense:
+        all_valid = all(bool(torch.cat(fl).all()) for fl in flags)
+        assert points.dense_targets_applicable(cfg, len(case['strides']), all_valid)
+        return points.point_target_kp_dense(props, to(case['gt_bboxes']), to(case['gt_keypoints']), cfg,
+                                            gt_labels_list=to(case['gt_labels']))
+    metas = [dict(pad_shape=ps) for ps in case['pad_shapes']]
+    return points.point_target_kp(props, flags, to(case['gt_bboxes']), to(case['gt_keypoints']), metas, cfg,
+                                  gt_bboxes_ignore_list=None, gt_labels_list=to(case['gt_labels']),
+                                  label_channels=13, sampling=False)
+
+
+def check_point_target(G, name, res):
+    """bit-exact: targets are copies of inputs / integer decisions"""
+    labels_all = _np(torch.cat(res[0], 1))
+    for k, per_level in zip(KEYS, res[:7]):
+        a = _np(torch.cat(per_level, 1))
+        if k in ('keypoint_gt', 'keypoint_weights'):
+            assert np.abs(a[labels_all == 0]).max(initial=0) == 0, k
+            assert np.array_equal(a[labels_all > 0], G['%s:%s_pos' % (name, k)]), (name, k)
+        else:
+            assert np.array_equal(a, G['%s:%s' % (name, k)]), (name, k)
+    assert int(res[7]) == int(G['%s:num_total_pos' % name]), name
+    assert int(res[8]) == int(G['%s:num_total_neg' % name]), name
+
+
+# ---------------------------------------------------------------------------------------------------
+def head_outputs_and_losses(head, x_list, batch, train_cfg, device, dtype=torch.float32):
+    to = lambda l: [t.to(device) for t in l]
+    xs = [x.to(device=device, dtype=dtype).requires_grad_(True) for x in x_list]
+    outs = head(xs, batch['img_meta'])
+    losses = head.loss(*outs, to(batch['gt_bboxes']), to(batch['gt_labels']), to(batch['gt_keypoints']),
+                       batch['img_meta'], train_cfg)
+    return xs, outs, losses
+
+
+def check_kgdet_head(head, device, tol_map=2e-4, tol_loss=2e-4, tol_grad=1e-3):
+    """forward maps, the nine losses, gradients, decoded candidates and final detections of the KGDet head at
+    full width against what the REFERENCE head module produced for the same weights and inputs."""
+    G = load('ref_head_golden.npz')
+    cfg = configs.kgdet_r50_fpn()
+    x, batch = ref_cases.kgdet_inputs()
+    names = ['cls_1', 'cls_2', 'cls_3', 'kpt_1', 'kpt_2', 'kpt_3', 'bbox_1', 'bbox_2', 'bbox_3']
+    head.train()
+    xs, outs, losses = head_outputs_and_losses(head, [x], batch, cfg.train_cfg, device)
+    worst = {}
+    for n, o in zip(names, outs):
+        a = _np(o[0])
+        a = a[:, ::ref_cases.KPT_STRIDE * 3] if n.startswith('kpt') else a
+        worst['out:' + n] = rel(a, G['out:' + n])
+        assert worst['out:' + n] < tol_map, (n, worst['out:' + n])
+    for k, v in losses.items():
+        got, want = sum(float(t) for t in v), float(G['loss:' + k])
+        worst['loss:' + k] = abs(got - want) / max(1.0, abs(want))
+        assert worst['loss:' + k] < tol_loss, (k, got, want)
+    sum(sum(v) for v in losses.values()).backward()
+    worst['grad:x'] = rel(_np(xs[0].grad)[:, ::8], G['grad:x'])
+    assert worst['grad:x'] < tol_grad, worst['grad:x']
+    params = dict(head.named_parameters())
+    for key in G.files:
+        if key.startswith('gradnorm:'):
+            got, want = float(params[key[9:]].grad.norm()), float(G[key])
+            assert abs(got - want) <= tol_grad * max(want, 1e-6), (key, got, want)
+    worst['grad:w7'] = rel(_np(params['kp_rep_block_3.cls_dfmconv_7.weight'].grad)[::16, ::16],
+                           G['grad:kp_rep_block_3.cls_dfmconv_7.weight'])
+    worst['grad:w3'] = rel(_np(params['kp_rep_block_2.keypts_dfmconv_3.weight'].grad)[::8, ::8],
+                           G['grad:kp_rep_block_2.keypts_dfmconv_3.weight'])
+    assert worst['grad:w7'] < tol_grad and worst['grad:w3'] < tol_grad, worst
+    assert rel(_np(params['moment_transfer'].grad), G['grad:moment_transfer']) < tol_grad
+
+    head.eval()
+    with torch.no_grad():
+        outs = head([x.to(device)], batch['img_meta'])
+        res = head.get_bboxes(*outs, batch['img_meta'], cfg.test_cfg, rescale=True, nms=False)
+        bb = np.stack([_np(r[0]) for r in res])
+        sc = np.stack([_np(r[1]) for r in res])
+        kp = np.stack([_np(r[2]) for r in res])[:, :, ::ref_cases.KPT_STRIDE * 3]
+        # the top-nms_pre selection is by score: compare as sets keyed by the (unique) decoded box
+        worst['dec'] = _check_candidates(bb, sc, kp, G['dec:bboxes'], G['dec:scores'], G['dec:kpts'])
+        det = head.get_bboxes(*outs, batch['img_meta'], cfg.test_cfg, rescale=True, nms=True)
+        for i, d in enumerate(det):
+            worst['det%d' % i] = _check_detections(_np(d[0]), _np(d[1]), _np(d[2])[:, ::ref_cases.KPT_STRIDE * 3],
+                                                   G['det%d:bboxes' % i], G['det%d:labels' % i], G['det%d:kpts' % i])
+    return worst
+
+
+def _check_candidates(bb, sc, kp, gbb, gsc, gkp, tol=1e-3):
+    assert bb.shape == gbb.shape and sc.shape == gsc.shape and kp.shape == gkp.shape
+    worst = 0.0
+    for b in range(bb.shape[0]):
+        # same candidate ORDER when scores are distinct (topk order); fall back to sorting by the box corner
+        if not np.allclose(bb[b], gbb[b], rtol=tol, atol=tol * 1344):
+            o, go = np.lexsort(bb[b].T.round(1)), np.lexsort(gbb[b].T.round(1))
+        else:
+            o = go = np.arange(bb.shape[1])
+        worst = max(worst, rel(bb[b][o], gbb[b][go]), rel(kp[b][o], gkp[b][go]), rel(sc[b][o], gsc[b][go]))
+    assert worst < tol, worst
+    return worst
+
+
+def _check_detections(db, dl, dk, gdb, gdl, gdk, tol=1e-3):
+    """north star: coordinates within 1e-3 relative, NMS selection identical"""
+    assert db.shape == gdb.shape, (db.shape, gdb.shape)
+    assert np.array_equal(dl, gdl)
+    w = max(rel(db[:, :4], gdb[:, :4]), rel(db[:, 4], gdb[:, 4]), rel(dk, gdk)) if db.shape[0] else 0.0
+    assert w < tol, w
+    return w
+
+
+def check_serial_head(head, device, tol_map=3e-4, tol_loss=5e-4, tol_grad=2e-3):
+    """config 5 (serial) head on a five-level pyramid against the REFERENCE module's float32 run."""
+    G = load('ref_serial_golden.npz')
+    cfg = configs.reppoints_kp_r50_fpn()
+    xs_cpu, batch = ref_cases.serial_inputs()
+    names = ['cls', 'kpt_init', 'kpt_refine', 'rep_init', 'rep_refine']
+    head.train()
+    xs, outs, losses = head_outputs_and_losses(head, xs_cpu, batch, cfg.train_cfg, device)
+    worst = {}
+    for n, o in zip(names, outs):
+        for lvl, t in enumerate(o):
+            a = _np(t)
+            a = a[:, ::ref_cases.KPT_STRIDE * 3] if n.startswith('kpt') else a
+            r = rel(a, G['out:%s:%d' % (n, lvl)])
+            worst['out:' + n] = max(worst.get('out:' + n, 0.0), r)
+            assert r < tol_map, (n, lvl, r)
+    for k, v in losses.items():
+        got, want = np.array([float(t) for t in v]), G['loss:' + k]
+        worst['loss:' + k] = float(np.abs(got - want).max() / max(1.0, np.abs(want).max()))
+        assert worst['loss:' + k] < tol_loss, (k, got, want)
+    sum(sum(v) for v in losses.values()).backward()
+    for lvl, x in enumerate(xs):
+        r = rel(_np(x.grad)[:, ::8], G['grad:x%d' % lvl])
+        worst['grad:x'] = max(worst.get('grad:x', 0.0), r)
+        assert r < tol_grad, (lvl, r)
+    params = dict(head.named_parameters())
+    for key in G.files:
+        if key.startswith('gradnorm:'):
+            got, want = float(params[key[9:]].grad.norm()), float(G[key])
+            assert abs(got - want) <= tol_grad * max(want, 1e-6), (key, got, want)
+    head.eval()
+    with torch.no_grad():
+        for tag, test_cfg in (('nms', cfg.test_cfg), ('soft', ref_cases.soft_nms_test_cfg(cfg.test_cfg))):
+            outs = head([x.to(device) for x in xs_cpu], batch['img_meta'])
+            det = head.get_bboxes(*outs, batch['img_meta'], test_cfg, rescale=True, nms=True)
+            for i, d in enumerate(det):
+                worst['%s:det%d' % (tag, i)] = _check_detections(
+                    _np(d[0]), _np(d[1]), _np(d[2])[:, ::ref_cases.KPT_STRIDE * 3], G['%s:det%d:bboxes' % (tag, i)],
+                    G['%s:det%d:labels' % (tag, i)], G['%s:det%d:kpts' % (tag, i)])
+    return worst
