@@ -72,7 +72,11 @@ def target_cases():
     boxes5 = [[[10., 12., 40., 50.], [60., 30., 200., 180.], [5., 5., 310., 250.], [100., 90., 180., 150.]],
               [[150., 100., 300., 240.], [20., 150., 60., 200.]]]
     add('pyramid_init', strides, fm, [(256, 320, 3)] * 2, boxes5, 15, init)
-    add('pyramid_init_pos3', strides, fm, [(256, 320, 3), (224, 300, 3)], boxes5, 16,
+    # (pos_num > 1 takes the k nearest points: box centres off the grid's symmetry axes, so that no two candidate
+    # points are equidistant -- topk's choice among exact ties is unspecified and differs between CPU and GPU)
+    boxes5b = [[[10.3, 12.9, 41.1, 50.2], [60.7, 30.1, 201.9, 183.3], [5.2, 5.9, 311.3, 251.7], [100.9, 90.3, 183.1, 152.6]],
+               [[150.6, 100.2, 301.3, 243.1], [20.4, 150.9, 63.7, 202.2]]]
+    add('pyramid_init_pos3', strides, fm, [(256, 320, 3), (224, 300, 3)], boxes5b, 16,
         dict(init, assigner=dict(type='PointAssigner', scale=4, pos_num=3)))
     refine = dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0,
                                 ignore_iof_thr=-1), allowed_border=-1, pos_weight=-1, debug=False)

@@ -64,6 +64,13 @@ def _mmcv_glue():
     runner = _bare('mmcv.runner')
     mmcv.is_str = lambda x: isinstance(x, str)
 
+    def dump(obj, file, **kw):                   # mmcv.dump for the '.json' result files of coco_utils.results2json
+        import json
+        assert file.endswith('.json')
+        with open(file, 'w') as f:
+            json.dump(obj, f)
+    mmcv.dump = dump
+
     def constant_init(module, val, bias=0):
         nn.init.constant_(module.weight, val)
         if getattr(module, 'bias', None) is not None:
@@ -215,6 +222,54 @@ def load():
     return ns
 
 
-if __name__ == '__main__':
+def load_detector():
+    """load() + the reference's detector stack, executed in place: models/backbones/resnet.py, models/necks/fpn2.py
+    (+ fpn.py), models/detectors/{base,single_stage,reppoints_detector_kp}.py, core/fp16/decorators.py,
+    core/bbox/transforms.py, core/post_processing/bbox_nms.py, core/evaluation/class_names.py.
+    Extra glue: `mmdet.ops.ContextBlock` / `ModulatedDeformConv` are placeholders that are never instantiated by
+    the KGDet configs; `pycocotools.mask` is the reference's own (oracle/_ref build)."""
     ns = load()
+    if hasattr(ns, 'build_detector'):
+        return ns
+    imp = importlib.import_module
+    from oracle import build_ref
+    build_ref.load_reference_evaluator()                    # registers the reference's pycocotools (+ compiled _mask)
+    if 'terminaltables' not in sys.modules:                 # table printing of recall.py / mean_ap.py: never reached
+        try:
+            import terminaltables  # noqa: F401
+        except ImportError:
+            _bare('terminaltables').AsciiTable = None
+    ops, core = sys.modules['mmdet.ops'], sys.modules['mmdet.core']
+
+    class _NotInKGDet(nn.Module):
+        def __init__(self, *a, **k):
+            raise NotImplementedError('not on the KGDet path')
+    ops.ContextBlock = ops.ModulatedDeformConv = _NotInKGDet
+    for sub in ('core/fp16', 'core/evaluation', 'models/backbones', 'models/necks', 'models/detectors',
+                'models/plugins'):
+        _bare('mmdet.' + sub.replace('/', '.'), os.path.join(REF, sub))
+    dec = imp('mmdet.core.fp16.decorators')
+    core.auto_fp16, core.force_fp32 = dec.auto_fp16, dec.force_fp32
+    transforms = imp('mmdet.core.bbox.transforms')
+    for k in ('bbox2result', 'bbox_mapping_back', 'bbox_mapping', 'bbox2roi', 'bbox_flip'):
+        setattr(core, k, getattr(transforms, k))
+    core.multiclass_nms = imp('mmdet.core.post_processing.bbox_nms').multiclass_nms
+    core.get_classes = imp('mmdet.core.evaluation.class_names').get_classes
+    core.tensor2imgs = sys.modules['mmdet.core.utils.misc'].tensor2imgs
+    ga = imp('mmdet.models.plugins.generalized_attention')
+    sys.modules['mmdet.models.plugins'].GeneralizedAttention = ga.GeneralizedAttention
+    resnet = imp('mmdet.models.backbones.resnet')
+    fpn2 = imp('mmdet.models.necks.fpn2')
+    fpn = imp('mmdet.models.necks.fpn')
+    imp('mmdet.models.detectors.base')
+    imp('mmdet.models.detectors.single_stage')
+    det = imp('mmdet.models.detectors.reppoints_detector_kp')
+    ns.ResNet, ns.FPN2, ns.FPN, ns.RepPointsDetectorKp = resnet.ResNet, fpn2.FPN2, fpn.FPN, det.RepPointsDetectorKp
+    ns.coco_utils = imp('mmdet.core.evaluation.coco_utils')     # results2json / coco_eval of tools/test.py
+    ns.build_detector = sys.modules['mmdet.models.builder'].build_detector
+    return ns
+
+
+if __name__ == '__main__':
+    ns = load_detector()
     print('reference host logic loaded in place:', sorted(k for k in vars(ns)))
