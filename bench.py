@@ -38,6 +38,12 @@ def parse_args():
                          'instead of taking the heuristic pick')
     ap.add_argument('--graph', type=int, choices=[0, 1], default=1,
                     help='inference only: replay the batch as one captured HIP graph (detector.graphed_test_batch)')
+    ap.add_argument('--config', choices=['kgdet', 'serial'], default='kgdet',
+                    help="kgdet: kgdet_moment_r50_fpn_1x (BASELINE configs 2-4); serial: "
+                         "reppoints_moment_serial_r50_fpn_1x-deepfashion2 with soft-NMS (BASELINE config 5)")
+    ap.add_argument('--no-inference-leg', action='store_true',
+                    help='training mode, 1 GPU: skip the bf16 batch-8 inference measurement (a child process) that '
+                         'is reported as the `inference` object of the same JSON line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     return ap.parse_args()
@@ -77,7 +83,8 @@ if ARGS is not None:
 # lookup instead of minutes of measuring.  One directory per workload; must be set before MIOpen is initialised.
 if ARGS is not None and ARGS.miopen_find:
     os.environ.setdefault('MIOPEN_USER_DB_PATH', os.path.join(
-        ROOT, 'kgdet_amd', 'miopen_db', '%s_%s_b%d' % (ARGS.mode, ARGS.dtype, ARGS.imgs_per_gpu)))
+        ROOT, 'kgdet_amd', 'miopen_db', '%s%s_%s_b%d' % ('' if ARGS.config == 'kgdet' else ARGS.config + '_',
+                                                           ARGS.mode, ARGS.dtype, ARGS.imgs_per_gpu)))
     os.makedirs(os.environ['MIOPEN_USER_DB_PATH'], exist_ok=True)
 
 import torch  # noqa: E402
@@ -86,24 +93,39 @@ import torch.distributed as dist  # noqa: E402
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md); AMD's 5 PF figure includes 2:1 sparsity
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0
-PLANE_GROUP_TRAFFIC_BYTES = 0.934e9  # profiles/r01_dcn_fwd_plane_group_b2.md: (2 x FETCH_SIZE + WRITE_SIZE) of the 3 kernels
+ROOFLINE_PROFILE = {2: 'profiles/r02_dcn_fwd_plane_group_b2.md', 8: 'profiles/r02_dcn_fwd_plane_group_b8_bf16.md'}
 
 
-def dcn_roofline(device, iters=20):
-    """DeformConv forward of ONE KGDet head stage at batch 2: the grouped launch of 2 feature maps x
-    (3x3, 5x5, 7x7) on [2, 256, 25, 42] (kgdet_deform_conv_forward_grouped: dcn_build_taps + dcn_fwd_plane +
-    dcn_fwd_fixup), HIP-event timing on the launch stream.  The products are bf16 MFMAs on a hi/lo split of
-    both fp32 operands (3 MFMAs per fp32-accurate multiply), so the MFMA roof is the dense bf16 peak / 3."""
+def profiled_traffic(batch):
+    """HBM/fabric bytes per launch sequence of the roofline kernel, from the PMC passes of the committed rocprofv3
+    profile (line `traffic_bytes_per_launch: N` = 2 x FETCH_SIZE + WRITE_SIZE of the kernels of one grouped launch,
+    corrected as MI355X_MICROARCH.md prescribes).  The counters cannot be collected inside this process; the value is
+    a RECORDED measurement of the profiled build, named here by file, or null when no profile is committed."""
+    path = os.path.join(ROOT, ROOFLINE_PROFILE.get(batch, ''))
+    if not os.path.isfile(path):
+        return None, None
+    for line in open(path):
+        if line.startswith('traffic_bytes_per_launch:'):
+            return float(line.split(':', 1)[1].split()[0]), os.path.relpath(path, ROOT)
+    return None, None
+
+
+def dcn_roofline(device, batch=2, precision='split', iters=20):
+    """DeformConv forward of ONE KGDet head stage: the grouped launch of 2 feature maps x (3x3, 5x5, 7x7) on
+    [batch, 256, 25, 42] (kgdet_deform_conv_forward_grouped: dcn_build_taps + dcn_fwd_plane + dcn_fwd_fixup),
+    HIP-event timing on the launch stream.  'split': the products are bf16 MFMAs on a hi/lo split of both fp32
+    operands (3 MFMAs per fp32-accurate multiply), so the MFMA roof is the dense bf16 peak / 3; 'bf16' (autocast
+    inference): one bf16 MFMA per multiply, roof = the dense bf16 peak."""
     from kgdet_amd import dcn
     g = torch.Generator(device='cpu').manual_seed(0)
-    B, C, H, W = 2, 256, 25, 42
+    B, C, H, W = batch, 256, 25, 42
     ks = (3, 5, 7)
     xs = [torch.randn(B, C, H, W, generator=g).to(device) for _ in range(2)]
     offs = [(torch.randn(B, 2 * k * k, H, W, generator=g) * 2).to(device) for k in ks]
     ws = [[(torch.randn(C, C, k, k, generator=g) * 0.01).to(device) for k in ks] for _ in xs]
     pads = [k // 2 for k in ks]
     stream = torch.cuda.current_stream()
-    with torch.no_grad():     # weight images are packed once (inference path); training re-packs every step
+    with torch.no_grad(), dcn.forward_precision(precision):     # weight images are packed once (inference path)
         for _ in range(5):
             dcn.deform_conv_cat_multi(xs, offs, ws, pads)
         # five event-bracketed runs of `iters` launches, median run: a host hiccup between two launches (the
@@ -121,42 +143,54 @@ def dcn_roofline(device, iters=20):
     flops = sum(2.0 * C * C * k * k * B * H * W for k in ks) * len(xs)
     byts = sum(4.0 * (2 * B * C * H * W + 2 * B * k * k * H * W + C * C * k * k) for k in ks) * len(xs)
     ach = flops / t / 1e12
-    peak = BF16_MFMA_PEAK_TFLOPS / 3.0
-    return dict(bound='mfma', kernel='dcn_build_taps+dcn_fwd_plane<2>+dcn_fwd_fixup (one head stage: 2 maps x 3x3/5x5/7x7, '
-                                     'B=2, 256ch, 25x42)',
+    parts = 3.0 if precision == 'split' else 1.0
+    peak = BF16_MFMA_PEAK_TFLOPS / parts
+    traffic, traffic_src = profiled_traffic(B)
+    return dict(bound='mfma', kernel='dcn_build_taps+dcn_fwd_plane<%d>+dcn_fwd_fixup (one head stage: 2 maps x 3x3/5x5/7x7, '
+                                     'B=%d, 256ch, 25x42)' % (2 if precision == 'split' else 1, B),
                 achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4),
-                peak_basis='dense bf16 MFMA 2500 TFLOP/s / 3 products per fp32-accurate multiply (hi/lo split)',
+                peak_basis='dense bf16 MFMA 2500 TFLOP/s / 3 products per fp32-accurate multiply (hi/lo split)'
+                if precision == 'split' else 'dense bf16 MFMA 2500 TFLOP/s (operands rounded to bf16 once)',
                 frac_of_f32_mfma_peak=round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                # bytes per launch from the committed PMC passes (profiles/): (2 x FETCH_SIZE + WRITE_SIZE) of the
-                # three kernels; cannot be collected live here
-                traffic=PLANE_GROUP_TRAFFIC_BYTES, algorithmic_bytes=byts, algorithmic_flops=flops,
+                traffic=traffic, traffic_source=traffic_src, algorithmic_bytes=byts, algorithmic_flops=flops,
                 launch_us=round(t * 1e6, 1), hbm_achieved_GBs=round(byts / t / 1e9, 1),
                 hbm_frac=round(byts / t / 1e9 / HBM_PEAK_GBS, 4))
 
 
 def cpu_baseline():
-    """Reference algorithm (im2col + GEMM) for ONE 7x7 DeformConv forward at B=2 on the host cores."""
+    """SURVEY 8d protocol: the oracle's reference algorithm (materialised im2col + BLAS GEMM,
+    deform_conv_cuda.cpp:151-258 restated on the CPU) for the three DeformConv shapes of one head stage at B=2, same
+    seeded inputs as the GPU roofline run, 5 warm-up + median of 20 timed calls each; BLAS threads stated."""
     import numpy as np
     import oracle
+    try:
+        from threadpoolctl import threadpool_info
+        blas = [(i.get('internal_api'), i.get('num_threads')) for i in threadpool_info() if i.get('user_api') == 'blas']
+    except Exception:
+        blas = []
+    threads = max([n for _, n in blas], default=os.cpu_count())
     rng = np.random.default_rng(0)
-    B, C, H, W, k = 2, 256, 25, 42, 7
+    B, C, H, W = 2, 256, 25, 42
     x = rng.normal(size=(B, C, H, W)).astype(np.float32)
-    off = (rng.normal(size=(B, 2 * k * k, H, W)) * 2).astype(np.float32)
-    w = (rng.normal(size=(C, C, k, k)) * 0.01).astype(np.float32)
-    oracle.deform_conv_forward(x, off, w, 1, 3, 1)
-    n, t0 = 0, time.time()
-    while time.time() - t0 < 12.0 or n < 3:
-        oracle.deform_conv_forward(x, off, w, 1, 3, 1)
-        n += 1
-    t = (time.time() - t0) / n
-    # one training step runs 12 such convs fwd (4 of each size) + backward; express as images/s of the
-    # DeformConv forward work alone: B images per (12-call) head forward, scaled by tap count
-    taps = 4 * (9 + 25 + 49)
-    head_fwd_s = t * taps / 49.0
+    med = {}
+    for k in (3, 5, 7):
+        off = (rng.normal(size=(B, 2 * k * k, H, W)) * 2).astype(np.float32)
+        w = (rng.normal(size=(C, C, k, k)) * 0.01).astype(np.float32)
+        for _ in range(5):
+            oracle.deform_conv_forward(x, off, w, 1, k // 2, 1)
+        ts = []
+        for _ in range(20):
+            t0 = time.perf_counter()
+            oracle.deform_conv_forward(x, off, w, 1, k // 2, 1)
+            ts.append(time.perf_counter() - t0)
+        med[k] = sorted(ts)[len(ts) // 2]
+    # one training step's head forward = 4 calls of each size (2 branches x 2 deformable stages)
+    head_fwd_s = 4 * sum(med.values())
     return dict(value=round(B / head_fwd_s, 3), unit='img/s (DeformConv forward of the head only)',
-                cores=os.cpu_count(), kind='port',
-                sample='oracle im2col+GEMM, one 7x7 DeformConv fwd at B=2 timed %d times (%.3f s each), '
-                       'scaled to the 12 DeformConv calls of one head forward' % (n, t))
+                cores=threads, host_cpus=os.cpu_count(), kind='port', blas=blas,
+                sample='oracle im2col+GEMM, DeformConv fwd 3x3/5x5/7x7 on [2,256,25,42], 5 warm-up + median of 20 each: '
+                       '%.1f / %.1f / %.1f ms; x4 = the 12 DeformConv calls of one head forward'
+                       % tuple(med[k] * 1e3 for k in (3, 5, 7)))
 
 
 def allreduce_busbw(device, world, numel=52250071, iters=10):
@@ -181,6 +215,23 @@ def allreduce_busbw(device, world, numel=52250071, iters=10):
                      'step it runs in 32 MB buckets on a side stream under backward')
 
 
+def inference_leg():
+    """BASELINE's second metric on the same line: inference img/s, bf16, batch 8 at 800x1333 (config 2), hipGraph
+    replay, decode + NMS at work -- measured by a CHILD process (MIOpen's per-workload find database is chosen by an
+    environment variable that must be set before MIOpen initialises; the child is started, never exec'ed)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--mode', 'infer', '--dtype', 'bf16', '--imgs-per-gpu', '8',
+           '--steps', '30', '--warmup', '5', '--no-cpu-baseline']
+    env = {k: v for k, v in os.environ.items() if k != 'MIOPEN_USER_DB_PATH'}
+    try:
+        res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        line = [l for l in res.stdout.decode().splitlines() if l.startswith('{')][-1]
+        d = json.loads(line)
+    except Exception as e:      # the training number stands on its own; report the failure instead of hiding it
+        return {'error': '%s: %s' % (type(e).__name__, e)}
+    return {k: d[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline') if k in d}
+
+
 def main():
     args = ARGS
     rank = int(os.environ.get('RANK', 0))
@@ -198,7 +249,10 @@ def main():
     from kgdet_amd.dist import DistOptimizerHook
     from kgdet_amd.registry import build_detector
 
-    cfg = configs.kgdet_r50_fpn()
+    cfg = configs.kgdet_r50_fpn() if args.config == 'kgdet' else configs.reppoints_kp_r50_fpn(soft_nms=True)
+    if args.config == 'serial':
+        cfg['optimizer'] = dict(type='SGD', lr=5e-3)      # (the serial config's own optimizer: SGD 5e-3, momentum 0.9, wd 1e-4)
+        cfg['optimizer_config'] = dict(grad_clip=dict(max_norm=35, norm_type=2))
     torch.manual_seed(0)
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).to(device)
@@ -210,8 +264,10 @@ def main():
 
     if args.mode == 'train':
         model.train()
-        optimizer = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=cfg.optimizer.lr,
-                                     fused=True)   # one multi-tensor launch per step instead of ~10 (CPU-bound tail)
+        params = [p for p in model.parameters() if p.requires_grad]
+        # fused: one multi-tensor launch per step instead of ~10 (CPU-bound tail)
+        optimizer = torch.optim.Adam(params, lr=cfg.optimizer.lr, fused=True) if args.config == 'kgdet' else \
+            torch.optim.SGD(params, lr=cfg.optimizer.lr, momentum=0.9, weight_decay=0.0001, fused=True)
         hook = DistOptimizerHook(grad_clip=dict(cfg.optimizer_config.grad_clip), overlap=True, bucket_size_mb=32)
 
         def step():
@@ -224,16 +280,20 @@ def main():
             return loss
     else:
         model.eval()
-        synthetic.calibrate_scores(model, batch, cfg.test_cfg.score_thr, 0.02, autocast)   # so that decode + NMS have work
+        if args.config == 'kgdet':
+            synthetic.calibrate_scores(model, batch, cfg.test_cfg.score_thr, 0.02, autocast)   # so that decode + NMS have work
+        else:
+            synthetic.calibrate_scores_serial(model, batch, cfg.test_cfg.score_thr, 0.002, autocast)
         n_det = [0]
 
-        if args.graph:
+        use_graph = bool(args.graph) and args.config == 'kgdet'   # (soft-NMS post-processing reads back per class)
+        if use_graph:
             # backbone -> head -> decode -> fused NMS as one hipGraph launch + one device->host copy per batch
             run = model.graphed_test_batch(batch['img'], batch['img_meta'], rescale=True,
                                            autocast_dtype=torch.bfloat16 if args.dtype == 'bf16' else None)
 
         def step():
-            if args.graph:
+            if use_graph:
                 res = run(batch['img'])
             else:
                 with torch.no_grad(), autocast:
@@ -275,8 +335,10 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 (bf16x3 split products, f32 accumulate)' if args.dtype == 'fp32'
             else 'bf16 (dense convs and deformable operands, f32 accumulate)',
             'data': 'synthetic',
-            'config': {'workload': 'KGDet R50-FPN %s step, %d img/GPU at 800x1333 (padded 800x1344), '
-                                   '%s' % (args.mode, args.imgs_per_gpu,
+            'config': {'workload': '%s R50-FPN %s step, %d img/GPU at 800x1333 (padded 800x1344), '
+                                   '%s' % ('KGDet' if args.config == 'kgdet' else
+                                           'RepPoints-kp serial head (config 5, 5-level FPN, soft-NMS)',
+                                           args.mode, args.imgs_per_gpu,
                                            'DeformConv fwd/bwd + focal/moment losses + RCCL grad all-reduce'
                                            if args.mode == 'train' else
                                            'backbone + FPN + DeformConv head forward + keypoint-guided decode + NMS'),
@@ -285,7 +347,12 @@ def main():
         if args.mode == 'infer':
             out['config']['detections_per_image'] = round(n_det[0] / args.imgs_per_gpu, 1)
         if not args.no_roofline:
-            out['roofline'] = dcn_roofline(device)
+            if args.mode == 'train':
+                out['roofline'] = dcn_roofline(device, 2, 'split')
+            else:      # the grouped forward the inference batch actually runs
+                out['roofline'] = dcn_roofline(device, args.imgs_per_gpu, 'bf16' if args.dtype == 'bf16' else 'split')
+        if (args.mode == 'train' and world == 1 and args.config == 'kgdet' and not args.no_inference_leg):
+            out['inference'] = inference_leg()
         if ar is not None:
             out['allreduce'] = ar
         if world == 1 and not args.no_cpu_baseline:

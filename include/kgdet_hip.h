@@ -90,6 +90,14 @@ const char *kgdet_last_error(void); /* thread-local message for the last non-zer
 int kgdet_version(void);            /* ABI version, currently 1 */
 int kgdet_device_cu_count(void);    /* compute units of the current device (0 if none) */
 
+/* Process-wide switches (diagnostics / accuracy studies; defaults 0).
+ * KGDET_OPT_EXACT_BACKWARD != 0: kgdet_deform_conv_backward_input takes the exact-fp32 kernels (f32-input MFMA)
+ * instead of the split-bf16 plane kernels it prefers for v1 problems -- the arithmetic of the reference's fp32
+ * col2im path (deform_conv_cuda.cpp:260-371), used to measure what the hi/lo split costs over a training step. */
+#define KGDET_OPT_EXACT_BACKWARD 0
+#define KGDET_OPT_COUNT 1
+int kgdet_set_option(int32_t option, int32_t value);
+
 /* ------------------------------------------------------------------------------------------
  * Deformable convolution v1 / v2
  * shape of one call; weight is [O, C/groups, kh, kw], offset [N, dg*2*kh*kw, Ho, Wo] with

@@ -19,9 +19,12 @@ SPLIT_GRAD_WEIGHT_3X3 = _os.environ.get('KGDET_SPLIT_WGRAD3', '1') == '1'
 PACK_BOTH = _os.environ.get('KGDET_PACK_BOTH', '1') == '1'
 
 
+ENABLED = True      # False: every dense convolution stays on MIOpen's fp32 kernels (dcn.arithmetic('exact'))
+
+
 def applicable(x, weight, stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1):
     k = weight.shape[2]
-    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
+    return (ENABLED and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
             and weight.shape[2] == weight.shape[3] and k in (1, 3) and tuple(stride) == (1, 1)
             and tuple(padding) == (k // 2, k // 2) and tuple(dilation) == (1, 1) and groups == 1
             and x.is_contiguous() and weight.shape[1] % 16 == 0 and weight.shape[0] % 16 == 0
@@ -187,7 +190,7 @@ STRIDE2 = _os.environ.get('KGDET_CONV_S2', '1') == '1'
 
 
 def applicable_stride2(x, weight, stride, padding, dilation, groups):
-    return (STRIDE2 and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
+    return (ENABLED and STRIDE2 and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
             and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (2, 2) and tuple(padding) == (1, 1)
             and tuple(dilation) == (1, 1) and groups == 1 and x.is_contiguous() and weight.shape[1] % 16 == 0
             and ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) % 2 == 0 and not torch.is_autocast_enabled())

@@ -38,6 +38,7 @@ void set_error(const char *fmt, ...);
     }                                                                                  \
   } while (0)
 
+extern int g_options[];  // kgdet_set_option (include/kgdet_hip.h KGDET_OPT_*)
 int cu_count();  // cached multiProcessorCount of the current device
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -841,7 +841,7 @@ int kgdet_deform_conv_backward_input(const kgdet_dcn_shape *s, const float *inpu
   }
   // v1 on small maps: the two plane kernels (grad_input by transposed sampling, grad_offset with the column
   // gradient in registers), bf16 hi/lo split MFMA -- 2x faster than the f32 gather kernel below
-  static const bool plane_off = getenv("KGDET_DCN_BWD_GATHER") != nullptr;  // A/B switch for benchmarking
+  const bool plane_off = g_options[KGDET_OPT_EXACT_BACKWARD] != 0;
   if (mask == nullptr && !plane_off && plane_bwd_input_ok(s, d) && plane_bwd_offset_ok(s, d) &&
       workspace_bytes >= kgdet_dcn_workspace_bytes(s)) {
     if (int rc = kgdet_deform_conv_grad_input(s, offset, nullptr, packed_weight, grad_output, grad_input, 0, workspace,

@@ -93,6 +93,35 @@ class forward_precision(object):
         set_forward_precision(self.prev)
 
 
+_EXACT_BACKWARD = False
+
+
+class arithmetic(object):
+    """``with dcn.arithmetic('exact'):`` -- the whole step in plain fp32 arithmetic: deformable forward on the
+    f32-input MFMA kernel, deformable backward on the exact-fp32 kernels (instead of the split-bf16 plane kernels) and
+    the dense convolutions on MIOpen's fp32 kernels (instead of csrc/conv1x1.hip).  ``'split'`` is the default
+    everywhere.  Used to measure what the hi/lo split costs in accuracy over a whole training step."""
+
+    def __init__(self, mode):
+        assert mode in ('split', 'exact')
+        self.mode = mode
+
+    def __enter__(self):
+        global _EXACT_BACKWARD
+        from . import conv1x1
+        self.prev = (set_forward_precision(self.mode), _EXACT_BACKWARD, conv1x1.ENABLED)
+        _EXACT_BACKWARD = self.mode == 'exact'
+        conv1x1.ENABLED = self.mode != 'exact'
+        _lib.check(_lib.lib().kgdet_set_option(0, int(_EXACT_BACKWARD)), 'kgdet_set_option')
+
+    def __exit__(self, *exc):
+        global _EXACT_BACKWARD
+        from . import conv1x1
+        set_forward_precision(self.prev[0])
+        _EXACT_BACKWARD, conv1x1.ENABLED = self.prev[1], self.prev[2]
+        _lib.check(_lib.lib().kgdet_set_option(0, int(_EXACT_BACKWARD)), 'kgdet_set_option')
+
+
 def _fwd_flags(relu):
     return ctypes.c_uint32((_lib.DCN_RELU if relu else 0) | _PRECISION_FLAGS[_FORWARD_PRECISION])
 
@@ -578,7 +607,7 @@ class DeformConvCatFunction(Function):
             gouts.append(grad_out.contiguous())
         need_io = any(need[:n_x + n_k])
         done_io = False
-        if need_io:
+        if need_io and not _EXACT_BACKWARD:
             # grad_input / grad_offset of all n_x * n_k convs: two grouped launches
             L = _lib.lib()
             n = n_x * n_k
@@ -602,7 +631,7 @@ class DeformConvCatFunction(Function):
             elif rc != _lib.KGDET_E_UNSUPPORTED:
                 _lib.check(rc, 'kgdet_deform_conv_backward_input_grouped')
         done_w = False
-        if all(need[n_x + n_k:]):
+        if all(need[n_x + n_k:]) and not _EXACT_BACKWARD:
             n = n_x * n_k
             gws = grad_weights_grouped([xs[j // n_k] for j in range(n)], [offsets[j % n_k] for j in range(n)],
                                        [gouts[j // n_k] for j in range(n)], weights, ctx.shapes)

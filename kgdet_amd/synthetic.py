@@ -60,3 +60,16 @@ def calibrate_scores(model, batch, score_thr, frac=0.02, autocast=None):
         cut = torch.topk(cls3.flatten(), k).values[-1]
         thr_logit = torch.log(torch.tensor(score_thr / (1 - score_thr), device=cut.device))
         model.bbox_head.kp_rep_block_3.cls_out.bias += (thr_logit - cut)
+
+
+def calibrate_scores_serial(model, batch, score_thr, frac=0.002, autocast=None):
+    """``calibrate_scores`` for the two-stage (serial / parallel) heads: one scalar added to the shared
+    ``cls_refine_out`` bias so that ``frac`` of the (point, class) scores over the five pyramid levels pass."""
+    import contextlib
+    with torch.no_grad(), (autocast or contextlib.nullcontext()):
+        cls = model.bbox_head(model.extract_feat(batch['img']), batch['img_meta'])[0]
+        flat = torch.cat([c.float().flatten() for c in cls])
+        k = max(1, int(frac * flat.numel()))
+        cut = torch.topk(flat, k).values[-1]
+        thr_logit = torch.log(torch.tensor(score_thr / (1 - score_thr), device=cut.device))
+        model.bbox_head.cls_refine_out.bias += (thr_logit - cut)

@@ -28,23 +28,15 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
-def grad_close(a, b, tol):
-    """Gradients that pass through ReLUs.  A pre-activation within rounding distance of zero (a handful of the
-    ~10^6 units of a head) can fall on the other side of the ReLU in a different arithmetic (CPU fp32 / fp64 vs the
-    split-bf16 MFMA kernels: measured 2 of 655 360 decisions at the 32x40 level, tools/exp_serial_dfm.py), which
-    switches that unit's whole gradient patch on or off -- visible when the upstream gradient is a sparse focal-loss
-    gradient.  With the ReLU decisions pinned, every backward kernel agrees with float64 to 5e-6.  So: at least 90 %
-    of the elements within `tol` of the reference (relative to its largest element), none further than 10 %, and the
-    relative L2 distance below 3 %.  Returns the fraction of elements outside `tol`."""
-    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    assert a.shape == b.shape
-    scale = max(float(np.abs(b).max()), 1e-30)
-    err = np.abs(a - b) / scale
-    outside = float((err > tol).mean())
-    assert outside <= 0.10, ('elements outside tolerance', outside)
-    assert float(err.max()) <= 0.10, ('largest deviation', float(err.max()))
-    assert float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)) <= 0.03
-    return outside
+def pyramid_grad_error(grads, refs):
+    """largest deviation over ALL pyramid levels relative to the largest reference element over all levels.
+    Per-level relative errors are not meaningful for the levels that only carry the sparse focal-loss gradient: a
+    pre-activation within rounding distance of zero (measured: 2 of 655 360 ReLU decisions at the 32x40 level,
+    tools/exp_serial_dfm.py) falls on the other side of the ReLU in a different arithmetic and switches that unit's
+    gradient patch on or off -- percents of such a level's tiny gradient, 1e-5 of the pyramid's.  With the ReLU
+    decisions pinned every backward kernel agrees with float64 to 5e-6 (same probe)."""
+    scale = max(max(float(np.abs(r).max()) for r in refs), 1e-30)
+    return max(float(np.abs(np.asarray(g, np.float64) - r).max()) for g, r in zip(grads, refs)) / scale
 
 
 def case_inputs(case, device):
@@ -133,7 +125,8 @@ def check_kgdet_head(head, device, tol_map=2e-4, tol_loss=2e-4, tol_grad=1e-3):
         worst['loss:' + k] = abs(got - want) / max(1.0, abs(want))
         assert worst['loss:' + k] < tol_loss, (k, got, want)
     sum(sum(v) for v in losses.values()).backward()
-    worst['grad:x outside tol'] = grad_close(_np(xs[0].grad)[:, ::8], G['grad:x'], tol_grad)
+    worst['grad:x'] = rel(_np(xs[0].grad)[:, ::8], G['grad:x'])
+    assert worst['grad:x'] < tol_grad, worst['grad:x']
     params = dict(head.named_parameters())
     for key in G.files:
         if key.startswith('gradnorm:'):
@@ -206,9 +199,8 @@ def check_serial_head(head, device, tol_map=3e-4, tol_loss=5e-4, tol_grad=2e-3):
         worst['loss:' + k] = float(np.abs(got - want).max() / max(1.0, np.abs(want).max()))
         assert worst['loss:' + k] < tol_loss, (k, got, want)
     sum(sum(v) for v in losses.values()).backward()
-    for lvl, x in enumerate(xs):
-        r = grad_close(_np(x.grad)[:, ::8], G['grad:x%d' % lvl], tol_grad)
-        worst['grad:x outside tol'] = max(worst.get('grad:x outside tol', 0.0), r)
+    worst['grad:x'] = pyramid_grad_error([_np(x.grad)[:, ::8] for x in xs], [G['grad:x%d' % l] for l in range(len(xs))])
+    assert worst['grad:x'] < tol_grad, worst['grad:x']
     params = dict(head.named_parameters())
     for key in G.files:
         if key.startswith('gradnorm:'):

@@ -369,3 +369,40 @@ def test_graphed_test_batch_matches_eager(bf16):
                     d = np.abs(g[0][c][:, None, :4] - w[0][c][None, :, :4]).max(-1).min(1)
                     assert (d < 0.5).mean() >= 0.8
             assert abs(sum(len(d) for d in g[0]) - sum(len(d) for d in w[0])) <= 2
+
+
+def test_full_size_training_step_split_arithmetic_matches_exact_fp32():
+    """One full-size (2 x 800x1344) training step under the default arithmetic (bf16 hi/lo split products, fp32
+    accumulate, in the deformable kernels AND the backbone's dense convolutions) against the same step in plain
+    fp32 arithmetic (dcn.arithmetic('exact'): f32-input MFMA deformable kernels, MIOpen fp32 convolutions):
+    the nine losses to 1e-4, the gradient norm of every top-level module group to 1e-3."""
+    from kgdet_amd import dcn
+    from kgdet_amd.registry import build_detector
+    cfg = configs.kgdet_r50_fpn()
+
+    def run(mode):
+        torch.manual_seed(0)
+        model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda()
+        model.train()
+        batch = synthetic.make_batch(2, 'cuda', seed=0)
+        with dcn.arithmetic(mode):
+            losses = model(batch['img'], batch['img_meta'], return_loss=True, gt_bboxes=batch['gt_bboxes'],
+                           gt_labels=batch['gt_labels'], gt_keypoints=batch['gt_keypoints'])
+            sum(sum(v) for v in losses.values()).backward()
+        torch.cuda.synchronize()
+        norms = {}
+        for name, p in model.named_parameters():
+            if p.grad is not None:
+                key = '.'.join(name.split('.')[:2])
+                norms[key] = norms.get(key, 0.0) + float(p.grad.double().pow(2).sum())
+        return {k: sum(float(t) for t in v) for k, v in losses.items()}, {k: v ** 0.5 for k, v in norms.items()}
+
+    l_split, g_split = run('split')
+    l_exact, g_exact = run('exact')
+    assert dcn._FORWARD_PRECISION == 'split' and not dcn._EXACT_BACKWARD
+    for k in l_exact:
+        assert abs(l_split[k] - l_exact[k]) <= 1e-4 * max(1.0, abs(l_exact[k])), (k, l_split[k], l_exact[k])
+    assert set(g_split) == set(g_exact) and len(g_exact) > 10
+    worst = max(abs(g_split[k] - g_exact[k]) / max(g_exact[k], 1e-12) for k in g_exact)
+    assert worst <= 1e-3, (worst, {k: (g_split[k], g_exact[k]) for k in g_exact
+                                   if abs(g_split[k] - g_exact[k]) > 1e-3 * g_exact[k]})
