@@ -328,8 +328,9 @@ def main():
     if rank == 0:
         imgs = args.imgs_per_gpu * world * args.steps
         out = {
-            'metric': 'training images/sec (whole node) KGDet R50-FPN 800x1333' if args.mode == 'train'
-            else 'inference images/sec KGDet R50-FPN 800x1333',
+            'metric': ('training images/sec (whole node) %s R50-FPN 800x1333' if args.mode == 'train'
+                       else 'inference images/sec %s R50-FPN 800x1333') % (
+                           'KGDet' if args.config == 'kgdet' else 'RepPoints-kp serial (config 5)'),
             'value': round(imgs / dt, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 (bf16x3 split products, f32 accumulate)' if args.dtype == 'fp32'

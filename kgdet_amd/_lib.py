@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libkgdet_hip.so')
+LIB_PATH = os.environ.get('KGDET_LIB') or os.path.join(_HERE, 'libkgdet_hip.so')   # KGDET_LIB: experiment builds
 CSRC = os.path.join(_HERE, 'csrc')
 
 KGDET_OK = 0

@@ -264,7 +264,10 @@ def conv_bn(conv, bn, x, relu=False, residual=None):
     bf16 = x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled()
                                                         and torch.get_autocast_dtype('cuda') == torch.bfloat16))
     hit = _fold_cache.get((id(conv), bf16))
-    if hit is None or hit[0]() is not conv:
+    # staleness: in-place updates (load_state_dict's copy_, optimizer steps that bump the counter) change _version
+    ver = (conv.weight._version, bn.running_mean._version, bn.running_var._version,
+           bn.weight._version if bn.affine else 0, bn.bias._version if bn.affine else 0)
+    if hit is None or hit[0]() is not conv or hit[4] != ver:
         scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps) if bn.affine else torch.rsqrt(bn.running_var + bn.eps)
         shift = (bn.bias if bn.affine else 0) - bn.running_mean * scale
         w = (conv.weight * scale.view(-1, 1, 1, 1)).detach()
@@ -273,7 +276,7 @@ def conv_bn(conv, bn, x, relu=False, residual=None):
         packed = None
         if not bf16 and conv1x1.applicable(x, w, conv.stride, conv.padding, conv.dilation, conv.groups):
             packed = conv1x1._pack(w.contiguous(), False)     # fp32 inference: split-bf16 MFMA kernels, packed once
-        hit = (weakref.ref(conv), w, shift.detach().float().contiguous(), packed)
+        hit = (weakref.ref(conv), w, shift.detach().float().contiguous(), packed, ver)
         _fold_cache[(id(conv), bf16)] = hit
     if bf16 and not x.is_contiguous(memory_format=torch.channels_last):
         x = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)

@@ -49,6 +49,10 @@ def load_checkpoint(model, filename, map_location=None, strict=False):
     target = model.module if hasattr(model, 'module') else model
     with torch.no_grad():
         load_state_dict(target, _strip_module(state_dict), strict)
+    # derived weight images (folded conv+BN weights, packed deformable-conv operands) belong to the old weights
+    from . import backbone, dcn
+    backbone.clear_fold_cache()
+    dcn.clear_pack_cache()
     return checkpoint
 
 

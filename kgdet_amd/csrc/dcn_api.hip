@@ -65,6 +65,14 @@ int grid_size() {
 constexpr int kSlabSlots = 8;  // partial tiles a workgroup may write per launch (plane kernel: one per range it meets)
 size_t slab_bytes() { return (size_t)grid_size() * kSlabSlots * kTileElems * sizeof(float); }
 
+// A stream-K workgroup writes one slab per range its slice meets.  `tiles` tiles of `cpt` stages each, dealt to the
+// grid alone in a launch: does the slice of one workgroup stay within kSlabSlots ranges?  (Large N / many M tiles /
+// a device with few CUs: beyond the bound the slab index would run into the next workgroup's slabs.)
+bool slab_slots_ok(long long tiles, int cpt) {
+  const long long per_wg = (tiles * cpt + grid_size() - 1) / grid_size();
+  return (per_wg + cpt - 1) / cpt + 2 <= kSlabSlots;
+}
+
 constexpr size_t kMaxLds = 160 * 1024;
 
 // LDS-privatised backward-input: one (image, 32-channel slice) plane set must fit in LDS
@@ -109,7 +117,8 @@ constexpr int kPlaneMaxHW = 1536;
 bool plane_ok(const kgdet_dcn_shape *s, const Derived &d) {
   const int cpdg = s->C / s->deformable_groups;  // a producer thread samples 8 channels with one tap record
   return mfma_ok(s) && (s->deformable_groups == 1 || cpdg % 8 == 0) && s->H * s->W <= kPlaneMaxHW &&
-         (size_t)8 * 33 * (d.K + 1) * sizeof(float) <= kMaxLds - 64;
+         (size_t)8 * 33 * (d.K + 1) * sizeof(float) <= kMaxLds - 64 &&
+         slab_slots_ok((long long)s->N * ceil_div(d.Ho * d.Wo, kTileN) * (d.Og_pad / kTileM), d.K * (d.Cg_pad / kChunk));
 }
 size_t tap_table_bytes(const kgdet_dcn_shape *s, const Derived &d) {
   return plane_ok(s, d) ? (size_t)s->N * s->deformable_groups * d.K * d.Ho * d.Wo * sizeof(DcnTapRec) : 0;
@@ -118,13 +127,16 @@ size_t tap_table_bytes(const kgdet_dcn_shape *s, const Derived &d) {
 bool plane_bwd_input_ok(const kgdet_dcn_shape *s, const Derived &d) {
   return s->deformable_groups == 1 && d.Ho * d.Wo <= kPlaneMaxHW && s->H * s->W <= kPlaneMaxHW && s->W >= 1 &&
          (size_t)8 * 33 * (d.K + 1) * sizeof(float) <= kMaxLds - 64 &&
-         dcn_build_inverse_taps_lds_bytes(s->H * s->W, d.Ho * d.Wo) <= kMaxLds - 64;
+         dcn_build_inverse_taps_lds_bytes(s->H * s->W, d.Ho * d.Wo) <= kMaxLds - 64 &&
+         slab_slots_ok((long long)s->groups * s->N * ceil_div(s->H * s->W, kTileN) * (d.Cg_pad256 / kTileM),
+                       d.K * (d.Og_pad16 / kChunk));
 }
 // grad_offset on the plane kernel: v1, one deformable group, <= 256 output channels per group
 bool plane_bwd_offset_ok(const kgdet_dcn_shape *s, const Derived &d) {
   return s->deformable_groups == 1 && s->groups == 1 && d.Og <= 256 && d.K <= 64 && s->H * s->W <= kPlaneMaxHW &&
          dcn_bwd_offset_plane_lds_bytes(2, d.K, s->H * s->W) <= kMaxLds &&
-         (size_t)8 * 33 * (d.K + 1) * sizeof(float) <= kMaxLds - 64;
+         (size_t)8 * 33 * (d.K + 1) * sizeof(float) <= kMaxLds - 64 &&
+         slab_slots_ok((long long)s->N * ceil_div(d.Ho * d.Wo, kTileN), d.K * (d.Cg_pad / kChunk));
 }
 size_t grad_tap_bytes(const kgdet_dcn_shape *s, const Derived &d) { return (size_t)s->N * d.K * d.Ho * d.Wo * 48; }
 struct InvTables {

@@ -24,6 +24,10 @@ constexpr int kPlaneRounds = 3;                          // (pixel, quad) items 
 #define KGDET_PLANE_A_FROM_L2 1
 #endif
 constexpr bool kAFromL2 = KGDET_PLANE_A_FROM_L2 != 0;
+// Ablation switches for experiment builds (make VARIANT=... EXTRA=-DKGDET_ABL_...; results are WRONG by design):
+//   KGDET_ABL_NOSAMPLE  producers skip the corner reads and the interpolation (B stage = garbage): consumer-bound time
+//   KGDET_ABL_NOMFMA    consumers skip the B-fragment reads and the MFMAs: producer-bound time
+//   KGDET_ABL_NOALOAD   consumers do not load their weight fragments (one load in the prologue): L2 / fabric share
 
 constexpr int kOvfCap = DcnInvOvfSlots::kCap;   // overflow entries of one (tile, tap) staged through LDS
 
@@ -146,6 +150,9 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
                                      (size_t)((mt * n_c16 + c16) * K) * (2 * kAPart) + (lane >> 5) * (kTileM * 16) +
                                      (wm * 64 + (lane & 31)) * 16;
       auto a_issue = [&](int j, AFrag &F) {
+#ifdef KGDET_ABL_NOALOAD
+        if (j > 1) return;
+#endif
         const unsigned t = (unsigned)(t0 + min(j, n - 1));
         const unsigned char *b = wq_cons + (size_t)t * (2 * kAPart);
 #pragma unroll
@@ -205,6 +212,17 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       // Corner offsets in the record are for quad 0; quad c of the same pixel is at offset ^ (c << 4).
       int ovf_tap = 0;  // tap of the stage being sampled (MODE 1 spill path)
       auto sample = [&](int buf, const Regs &R, int ovf_slot) {
+#ifdef KGDET_ABL_NOSAMPLE
+        {
+          bf16x8 z;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) z[q] = (__bf16)R.w[0][q & 3];
+          unsigned char *dst0 = Bs + buf * PARTS * kBPart + half * (kTileN * 16) + n_local * 16;
+          *reinterpret_cast<bf16x8 *>(dst0) = z;
+          if constexpr (PARTS == 2) *reinterpret_cast<bf16x8 *>(dst0 + kBPart) = z;
+          return;
+        }
+#endif
         // interpolation and hi/lo split on channel PAIRS: v_pk_fma_f32 / v_pk_add_f32 do two lanes' worth per
         // issue slot, and issue slots are what this kernel is short of (VALU and MFMA time add up on a SIMD)
         typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -284,6 +302,9 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         if constexpr (PARTS == 2) *reinterpret_cast<bf16x8 *>(dst + kBPart) = lo;
       };
       auto multiply = [&](int buf, const AFrag &F) {
+#ifdef KGDET_ABL_NOMFMA
+        return;
+#endif
         if constexpr (!PRODUCER) {
           const unsigned char *A = As + buf * PARTS * kAPart + (lane >> 5) * (kTileM * 16) + (wm * 64 + (lane & 31)) * 16;
           const unsigned char *B = Bs + buf * PARTS * kBPart + (lane >> 5) * (kTileN * 16) + (wn * 64 + (lane & 31)) * 16;

@@ -120,6 +120,11 @@ class RepPointsDetectorKp(nn.Module):
             return [self.bbox2result_kp(d, lab, k, num_classes) for d, lab, k in dets]
 
         run.graph, run.static_img, run.static_out = graph, static_img, static_out
+        # The captured kernels hold raw pointers into the module-level weight-image caches (packed deformable-conv
+        # operands, folded conv+BN weights).  Those caches are cleared on mode switches / when they fill up, which
+        # would free memory the graph still reads: the graph keeps its own strong references.
+        from . import backbone, dcn
+        run.pinned = ([v[2] for v in dcn._pack_cache.values()], [v[1:4] for v in backbone._fold_cache.values()])
         return run
 
     def simple_test(self, img, img_meta, rescale=False):

@@ -351,3 +351,24 @@ def test_grad_weight_plane_kernel(case):
     ref = oracle.deform_conv_backward(x.astype(np.float64), off.astype(np.float64), w.astype(np.float64),
                                       go.astype(np.float64), s, p, d, g, dg)['grad_weight']
     _close(a[0].cpu().numpy(), ref, 5e-5)
+
+
+def test_more_tiles_than_slab_slots_take_the_safe_path():
+    """a launch whose workgroup slices would meet more tile ranges than a workgroup has slab slots
+    (here 180 images x 9 pixel tiles = 1620 tiles on 256 CUs, > 6 per workgroup) must not run the stream-K plane
+    kernels (their slab index would run into the neighbour's slabs): results stay correct, forward and backward."""
+    _require_gpu()
+    from kgdet_amd import dcn
+    case = (180, 16, 25, 42, 16, 3, 1, 1, 1, 1, 1)
+    N, C, H, W, O, k, s, p, d, g, dg = case
+    x, off, w, go, _ = _make(case, seed=21)
+    tx, to, tw = (torch.from_numpy(a).cuda().requires_grad_() for a in (x, off, w))
+    out = dcn.deform_conv(tx, to, tw, s, p, d, g, dg)
+    out.backward(torch.from_numpy(go).cuda())
+    torch.cuda.synchronize()
+    f64 = lambda a: a.astype(np.float64)
+    _close(out.detach().cpu().numpy(), oracle.deform_conv_forward(f64(x), f64(off), f64(w), s, p, d, g, dg))
+    ref = oracle.deform_conv_backward(f64(x), f64(off), f64(w), f64(go), s, p, d, g, dg)
+    _close(tx.grad.cpu().numpy(), ref['grad_input'], 5e-5)
+    _close(to.grad.cpu().numpy(), ref['grad_offset'], 5e-5)
+    _close(tw.grad.cpu().numpy(), ref['grad_weight'], 5e-5)
