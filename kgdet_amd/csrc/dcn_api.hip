@@ -75,6 +75,16 @@ bool slab_slots_ok(long long tiles, int cpt) {
 
 constexpr size_t kMaxLds = 160 * 1024;
 
+// plane kernels (forward / grad_input): LDS of the launch = the largest need over the group's problems.
+// (A second plane buffer, filled by the producer waves while the current chunk runs, was measured and dropped: the
+// launch got slower, 256 -> 271 us at B=2 and 598 -> 686 us at B=8 -- the producers are the critical path of a stage
+// and the copy adds to exactly their work, while the synchronous copy by all twelve waves is ~6 % of a workgroup.)
+size_t plan_plane_lds(DcnFwdGroup &grp, size_t single, size_t fixed) {
+  grp.plane_bytes = (int)(single - fixed);
+  grp.dbl_plane = 0;
+  return single;
+}
+
 // LDS-privatised backward-input: one (image, 32-channel slice) plane set must fit in LDS
 struct BwdLdsPlan {
   bool ok;
@@ -305,6 +315,8 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
   grp.n = 0;
   grp.xcd_slices = 1;
   grp.slots = kSlabSlots;
+  grp.dbl_plane = 0;
+  grp.plane_bytes = 0;
   size_t lds = 0;
   int min_len = 1 << 30;  // shortest range (stages) in the pending group
   unsigned char *const table_base = (unsigned char *)workspace + slab_bytes();
@@ -312,6 +324,36 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
   const int parts = (flags & KGDET_DCN_BF16) ? 1 : 2;
   auto flush = [&]() -> int {
     if (grp.n == 0) return KGDET_OK;
+    // Static split-K: cut every problem's reduction into parts of about one workgroup's share (whole channel chunks)
+    // so that (problem, part, tile) ranges can be dealt one per workgroup.  With ranges of one (problem, part)
+    // consecutive and consecutive slices on one XCD (sk_slice_of_block), the workgroups of an XCD stream the same
+    // weight stages at the same time: L2 hits instead of one fabric read per pixel tile (measured before: 0.88 GB
+    // of fabric traffic per head-stage launch for 43.5 MB of weights, weight-fragment loads waiting ~2000 cycles).
+    grp.static_ranges = 0;
+    {
+      const long long total = grp.unit_begin[grp.n];
+      const double share = (double)total / G;
+      int ranges = 0;
+      double longest = 0;
+      int kp[kMaxFwdGroup];
+      for (int i = 0; i < grp.n; ++i) {
+        const DcnProblem &q = grp.p[i];
+        int k = (int)((double)q.chunks_per_tile / share + 0.5);
+        k = k < 1 ? 1 : (k > q.chunks_per_tap ? q.chunks_per_tap : k);
+        kp[i] = k;
+        ranges += q.n_ntiles * q.n_mtiles * k;
+        const double len = (double)((q.chunks_per_tap + k - 1) / k) * q.K;
+        longest = len > longest ? len : longest;
+      }
+      static const bool off = getenv("KGDET_DCN_STREAMK") != nullptr;   // A/B switch
+      if (!off && ranges <= G && longest <= 1.25 * share) {
+        grp.static_ranges = 1;
+        for (int i = 0; i < grp.n; ++i) {
+          grp.p[i].kparts = kp[i];
+          grp.range_begin[i + 1] = grp.range_begin[i] + grp.p[i].n_ntiles * grp.p[i].n_mtiles * kp[i];
+        }
+      }
+    }
     static thread_local bool attr_set = false;
     if (!attr_set) {
       KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_fwd_plane<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -322,10 +364,11 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
     }
     hipLaunchKernelGGL(dcn_build_taps, dim3(2 * G, grp.n), dim3(256), 0, (hipStream_t)stream, grp);
     const int threads = dcn_fwd_plane_threads();
+    const size_t lds2 = plan_plane_lds(grp, lds, dcn_fwd_plane_fixed_lds_bytes(parts));
     if (parts == 1)
-      hipLaunchKernelGGL(dcn_fwd_plane<1>, dim3(G), dim3(threads), lds, (hipStream_t)stream, grp, (float *)workspace);
+      hipLaunchKernelGGL(dcn_fwd_plane<1>, dim3(G), dim3(threads), lds2, (hipStream_t)stream, grp, (float *)workspace);
     else
-      hipLaunchKernelGGL(dcn_fwd_plane<2>, dim3(G), dim3(threads), lds, (hipStream_t)stream, grp, (float *)workspace);
+      hipLaunchKernelGGL(dcn_fwd_plane<2>, dim3(G), dim3(threads), lds2, (hipStream_t)stream, grp, (float *)workspace);
     hipLaunchKernelGGL(dcn_fwd_fixup, dim3(grp.tile_begin[grp.n], 16), dim3(kThreads), 0, (hipStream_t)stream, grp,
                        (const float *)workspace, G);
     grp.n = 0;
@@ -410,7 +453,7 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
       } else {  // exact-fp32 kernel: one launch per problem (slabs are shared, so flush the pending group first)
         if (int rc = flush()) return rc;
         DcnFwdGroup one;
-        one.n = 1; one.xcd_slices = 0; one.slots = 2; one.range_begin[0] = 0;
+        one.n = 1; one.xcd_slices = 0; one.slots = 2; one.dbl_plane = 0; one.plane_bytes = 0; one.static_ranges = 0; one.range_begin[0] = 0;
         one.range_begin[1] = p.n_ntiles * p.n_mtiles; one.tile_begin[0] = 0; one.tile_begin[1] = p.n_ntiles * p.n_mtiles;
         one.unit_begin[0] = 0; one.unit_begin[1] = p.total_units;
         one.p[0] = p;
@@ -474,7 +517,7 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
   const int G = grid_size();
   const int parts = (flags & KGDET_DCN_BF16) ? 1 : 2;
   DcnFwdGroup grp;
-  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots;
+  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0;
   grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
   const int O_total = s->out_channels_total > 0 ? s->out_channels_total : s->O;
   for (int g = 0; g < s->groups; ++g) {
@@ -507,7 +550,8 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
     grp.unit_begin[grp.n + 1] = grp.unit_begin[grp.n] + p.total_units;
     ++grp.n;
   }
-  const size_t lds = dcn_bwd_input_plane_lds_bytes(parts, d.Ho * d.Wo);
+  const size_t lds = plan_plane_lds(grp, dcn_bwd_input_plane_lds_bytes(parts, d.Ho * d.Wo),
+                                    dcn_bwd_input_plane_fixed_lds_bytes(parts));
   const int threads = dcn_fwd_plane_threads();
   if (parts == 1)
     hipLaunchKernelGGL(dcn_bwd_input_plane<1>, dim3(G), dim3(threads), lds, (hipStream_t)stream, grp, (float *)workspace);
@@ -546,7 +590,7 @@ int kgdet_deform_conv_grad_offset(const kgdet_dcn_shape *s, const float *input, 
   const int G = grid_size();
   const int parts = (flags & KGDET_DCN_BF16) ? 1 : 2;
   DcnFwdGroup grp;
-  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots;
+  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0;
   grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
   const DcnTapRec *recs = reinterpret_cast<const DcnTapRec *>((unsigned char *)workspace + slab_bytes());
   for (int g = 0; g < s->groups; ++g) {
@@ -651,7 +695,7 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
 
   // ---- phase 1: grad_input (transposed sampling) ----
   DcnFwdGroup grp;
-  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots;
+  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0;
   grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
   size_t lds = 0;
   for (int i = 0; i < n; ++i) {
@@ -698,6 +742,7 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
     lds = need > lds ? need : lds;
   }
   if (!check_slots(grp)) { set_error("group too uneven for the slab slots"); return KGDET_E_UNSUPPORTED; }
+  lds = plan_plane_lds(grp, lds, dcn_bwd_input_plane_fixed_lds_bytes(2));
   hipLaunchKernelGGL(dcn_bwd_input_plane<2>, dim3(G), dim3(dcn_fwd_plane_threads()), lds, (hipStream_t)stream, grp,
                      (float *)workspace);
   hipLaunchKernelGGL(dcn_fwd_fixup, dim3(grp.tile_begin[grp.n], 16), dim3(kThreads), 0, (hipStream_t)stream, grp,
@@ -791,7 +836,7 @@ int kgdet_deform_conv_grad_weight_grouped(int32_t n, const kgdet_dcn_shape *cons
   }
   unsigned char *tab = (unsigned char *)workspace + slab_bytes();
   DcnFwdGroup grp;
-  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots;
+  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0;
   grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
   size_t lds = 0;
   int min_len = 1 << 30;

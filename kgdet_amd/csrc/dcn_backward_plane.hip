@@ -30,8 +30,9 @@ __global__ __launch_bounds__(kPlaneThreads, 1) void dcn_bwd_input_plane(const Dc
 template __global__ void dcn_bwd_input_plane<1>(const DcnFwdGroup grp, float *__restrict__ slabs);
 template __global__ void dcn_bwd_input_plane<2>(const DcnFwdGroup grp, float *__restrict__ slabs);
 
+size_t dcn_bwd_input_plane_fixed_lds_bytes(int parts) { return (size_t)2 * kGroupTaps * parts * kBPart; }
 size_t dcn_bwd_input_plane_lds_bytes(int parts, int plane_pixels) {
-  return (size_t)2 * parts * (kAPart + kBPart) + 2 * (kOvfCap + 1) * 8 + (size_t)kChunk * plane_pixels * sizeof(float);
+  return dcn_bwd_input_plane_fixed_lds_bytes(parts) + (size_t)kChunk * plane_pixels * sizeof(float);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -83,6 +83,11 @@ struct DcnFwdGroup {
   int xcd_slices;  // 1: workgroup g takes slice sk_slice_of_block(g) and numbers its slabs by range (plane kernel)
                    // 0: slice g, slab 0 = first partial tile, slab 1 = last partial tile (exact-fp32 kernel)
   int slots;       // slab slots per workgroup
+  int dbl_plane;   // (unused: second feature-plane buffer, measured and dropped)
+  int plane_bytes; // plane kernels: bytes of the largest feature plane of the group
+  int static_ranges;  // 1: workgroup of slice r computes exactly range r (problem, part, tile), r < range_begin[n];
+                      //    the other workgroups exit.  Ranges of one (problem, part) are consecutive, so the 32
+                      //    workgroups of an XCD walk the SAME weight stages at the same time and share them in L2.
   int tile_begin[kMaxFwdGroup + 1];        // prefix sums of n_ntiles * n_mtiles
   int range_begin[kMaxFwdGroup + 1];       // prefix sums of n_ntiles * n_mtiles * kparts
   long long unit_begin[kMaxFwdGroup + 1];  // prefix sums of total_units
@@ -102,8 +107,10 @@ struct DcnUnitPos {
   int s, s_hi;          // first stage of the unit inside the tile, end of the part's stage range
   int range;            // global index of the range the unit lies in
 };
+// first stage of reduction part `part`: parts are whole channel chunks (a chunk = K consecutive stages sharing a plane)
 __device__ __forceinline__ int dcn_part_lo(const DcnProblem &p, int part) {
-  return (int)((long long)p.chunks_per_tile * part / p.kparts);
+  if (p.kparts == 1) return part ? p.chunks_per_tile : 0;   // (kernels whose stages are not (chunk, tap) pairs never split)
+  return (int)((long long)p.chunks_per_tap * part / p.kparts) * p.K;
 }
 __device__ __forceinline__ DcnUnitPos dcn_unit_pos(const DcnFwdGroup &grp, long long u) {
   DcnUnitPos r;

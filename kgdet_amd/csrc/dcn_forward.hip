@@ -241,6 +241,13 @@ __global__ __launch_bounds__(kThreads) void dcn_fwd_fixup(const DcnFwdGroup grp,
     const long long te = tb + (dcn_part_lo(p, part + 1) - dcn_part_lo(p, part));
     if (te == tb) continue;
     const int range = grp.range_begin[pi] + part * tiles + tile;
+    if (grp.static_ranges) {   // range r was computed whole by the workgroup of slice r (slab slot 0)
+      if (p.kparts == 1) return;  // written directly
+      const long long slab = (long long)sk_block_of_slice(range, G) * grp.slots;
+      const f32x4 v = reinterpret_cast<const f32x4 *>(slabs + slab * kTileElems)[j * kThreads + tid];
+      sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+      continue;
+    }
     long long g = tb * G / total;  // slice that holds unit tb
     while (unit_begin(g + 1, total, G) <= tb) ++g;
     while (unit_begin(g, total, G) > tb) --g;

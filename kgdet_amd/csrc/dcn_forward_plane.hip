@@ -45,6 +45,14 @@ template __global__ void dcn_fwd_plane<2>(const DcnFwdGroup grp, float *__restri
 
 int dcn_fwd_plane_threads() { return kPlaneThreads; }
 
+#ifdef KGDET_PLANE_TRACE
+}  // namespace kgdet
+extern "C" int kgdet_debug_read_plane_trace(unsigned long long *out) {   // the forward kernel's copy
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(kgdet::g_plane_trace), sizeof(unsigned long long) * 256 * 2 * 10);
+}
+namespace kgdet {
+#endif
+
 // Tap records of every problem of a group that owns its table (p.build_taps): one thread per
 // (image, deformable group, tap, output pixel).  grid = (blocks over the largest table, problems).
 // Mirrors deformable_im2col_bilinear + the (-1,H)x(-1,W) guard (deform_conv_cuda_kernel.cu:84-114, :228);
@@ -77,8 +85,10 @@ __global__ __launch_bounds__(256) void dcn_build_taps(const DcnFwdGroup grp) {
   }
 }
 
+// LDS of dcn_fwd_plane: two groups of B stages + the feature plane
+size_t dcn_fwd_plane_fixed_lds_bytes(int parts) { return (size_t)2 * kGroupTaps * parts * kBPart; }
 size_t dcn_fwd_plane_lds_bytes(int parts, int HW) {
-  return (size_t)2 * parts * (kAPart + kBPart) + (size_t)kChunk * HW * sizeof(float);
+  return dcn_fwd_plane_fixed_lds_bytes(parts) + (size_t)kChunk * HW * sizeof(float);
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -10,12 +10,14 @@ __global__ void dcn_fwd_fixup(const DcnFwdGroup grp, const float *__restrict__ s
 template <int PARTS>
 __global__ void dcn_fwd_plane(const DcnFwdGroup grp, float *__restrict__ slabs);
 size_t dcn_fwd_plane_lds_bytes(int parts, int HW);
+size_t dcn_fwd_plane_fixed_lds_bytes(int parts);
 int dcn_fwd_plane_threads();
 __global__ void dcn_build_taps(const DcnFwdGroup grp);
 // grad_input on the plane kernel (dcn_backward_plane.hip)
 template <int PARTS>
 __global__ void dcn_bwd_input_plane(const DcnFwdGroup grp, float *__restrict__ slabs);
 size_t dcn_bwd_input_plane_lds_bytes(int parts, int plane_pixels);
+size_t dcn_bwd_input_plane_fixed_lds_bytes(int parts);
 __global__ void dcn_build_inverse_taps(const DcnProblem p, uint4 *__restrict__ inv, DcnInvOvfSlots *__restrict__ slots,
                                        uint2 *__restrict__ spill);
 size_t dcn_build_inverse_taps_lds_bytes(int HW, int HoWo);

@@ -1,7 +1,9 @@
 // Shared body of the "plane" kernels (dcn_forward_plane.hip, dcn_backward_plane.hip): LDS-resident feature
-// plane, producer / consumer waves, bf16 hi/lo split MFMA, stream-K over (tile, stage) units.
-// See dcn_forward_plane.hip for the design notes.
+// plane, producer / consumer waves, bf16 hi/lo split MFMA, stream-K over (tile, stage) units, one workgroup barrier
+// per GROUP of three stages.  See dcn_forward_plane.hip for the design notes.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 #include "dcn_kernels.h"
 
@@ -10,6 +12,19 @@ namespace kgdet {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+#ifdef KGDET_PLANE_TRACE
+// Experiment build only (make VARIANT=trace EXTRA=-DKGDET_PLANE_TRACE, tools/plane_trace.py): per-workgroup cycle
+// sums by phase, written by lane 0 of the first consumer / producer wave.
+//   [block][role][cat]: 0 prologue barrier wait, 1 prologue loads + plane copy, 2 prologue second barrier wait,
+//   3 prologue sample + third barrier, 4 group work (top of group .. before barrier), 5 group barrier wait,
+//   6 epilogue (slab / output store), 7 whole kernel, 8 stages, 9 segments
+static __device__ unsigned long long g_plane_trace[256 * 2 * 10];   // one copy per translation unit
+#define KGDET_TR_NOW() __builtin_amdgcn_s_memtime()
+#define KGDET_TR_ADD(cat, t_from) do { const unsigned long long n__ = KGDET_TR_NOW(); tr[cat] += n__ - (t_from); (t_from) = n__; } while (0)
+#else
+#define KGDET_TR_ADD(cat, t_from) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int kAPart = 2 * kTileM * 8 * 2;  // bytes of one part of an A stage
@@ -17,19 +32,16 @@ constexpr int kBPart = 2 * kTileN * 8 * 2;
 constexpr int kProducers = 256;                          // 4 producer waves
 constexpr int kPlaneThreads = kThreads + kProducers;     // 8 consumer + 4 producer waves
 constexpr int kPlaneRounds = 3;                          // (pixel, quad) items a thread has in flight while copying a plane
+constexpr int kGroupTaps = 3;                            // stages (taps) between two workgroup barriers
+constexpr bool kAFromL2 = true;   // (grad_weight kernel) consumers take their A fragments from the operand image in L2
 
-// A (weight) fragments: true = every consumer wave loads its own 64 rows of the stage straight from the weight image
-// (L2) into a two-stage register ring; false = the producers copy the stage into LDS and the consumers read it there.
-#ifndef KGDET_PLANE_A_FROM_L2
-#define KGDET_PLANE_A_FROM_L2 1
-#endif
-constexpr bool kAFromL2 = KGDET_PLANE_A_FROM_L2 != 0;
 // Ablation switches for experiment builds (make VARIANT=... EXTRA=-DKGDET_ABL_...; results are WRONG by design):
 //   KGDET_ABL_NOSAMPLE  producers skip the corner reads and the interpolation (B stage = garbage): consumer-bound time
 //   KGDET_ABL_NOMFMA    consumers skip the B-fragment reads and the MFMAs: producer-bound time
 //   KGDET_ABL_NOALOAD   consumers do not load their weight fragments (one load in the prologue): L2 / fabric share
-
-constexpr int kOvfCap = DcnInvOvfSlots::kCap;   // overflow entries of one (tile, tap) staged through LDS
+#ifndef KGDET_PLANE_PRODUCER_PRIO
+#define KGDET_PLANE_PRODUCER_PRIO 2
+#endif
 
 // MODE of the plane kernels
 //   0  forward:     B stage = bilinear samples of x; 4 corners per (pixel, tap) from a DcnTapRec
@@ -42,33 +54,41 @@ struct PlaneModeTraits {
 };
 
 // what a producer thread has in flight for one stage
-template <int PARTS, int MODE>
+template <int MODE>
 struct PlaneStageRegs {
   static constexpr int NG = PlaneModeTraits<MODE>::kGroups;
-  f32x4 a[PARTS][2];  // this thread's 2 x 16 B of each part of the weight stage
   uint4 off[NG];      // LDS byte offsets of the sampled pixels (quad 0)
   f32x4 w[NG];        // and their weights
-  uint2 ovf;          // MODE 1: overflow slot (tid & 31) of the stage's (tile, tap)
-  int n_ovf;          //         and the list's length
+  int2 ovf;           // MODE 1: (length, first entry in the spill list) of the overflow list of the stage's (tile, tap)
 };
 
 }  // namespace
 
 // Loop structure: a workgroup walks its stream-K slice range by range; inside a range the stages that share
 // a feature plane (one channel chunk, consecutive taps) form a SEGMENT.  A segment starts with the plane copy
-// and the priming of the producers' three-deep register pipeline (weight stage + tap record of stages
-// j, j+1, j+2); its steady state is branch-free as far as vector-memory instructions go -- every body issues
-// the loads of stage j+3 unconditionally (clamped to the last stage), so hipcc's counted s_waitcnt vmcnt(N)
-// stay exact and a load has two full stages to land.  Stage coordinates are carried incrementally; there is no
-// integer division in the loop (a runtime s / K costs ~35 dependent SALU ops).
+// and the priming of the register pipelines; its steady state is branch-free as far as vector-memory
+// instructions go -- loads are issued unconditionally from clamped addresses, so hipcc's counted
+// s_waitcnt vmcnt(N) stay exact.
+//
+// Stages are handed from the producers to the consumers in GROUPS of kGroupTaps = 3.  The B buffer in LDS holds two
+// groups: while the consumers multiply the three stages of group g (their weight fragments arrive from L2 two
+// stages ahead, in a two-deep register ring), the producers sample the three stages of group g + 1; the tap records
+// of a group are loaded one whole group before they are used (two sets of three).  ONE workgroup barrier per group.
+// Why (phase trace of the one-barrier-per-stage version, tools/plane_trace.py: cycles per workgroup, 187 stages):
+// both roles did ~1200 cycles of work per stage and each waited ~300 more at the barrier -- for the slowest of the
+// twelve waves, a different one every stage (random-gather bank conflicts, issue arbitration); a group averages
+// that skew over three stages.  Inside a group the producers issue the corner reads of a stage before the
+// arithmetic of the previous one (MODE 0), so the LDS latency of the random gather overlaps VALU work instead of
+// heading a dependent chain, and the consumers' B fragments of the next stage can be fetched under the MFMAs.
+// The producers are the youngest waves of the workgroup, i.e. the losers of every issue arbitration against the
+// two MFMA waves of their SIMD, and their work is latency-bound: they run at a raised static priority.
+// Stage coordinates are carried incrementally; there is no integer division in the loop.
 // The two roles are two instantiations of this function (same loop structure, same barriers), so the
 // accumulators exist only in the consumers' register allocation.
 template <int PARTS, bool PRODUCER, int MODE>
 __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__restrict__ slabs, unsigned char *smem) {
-  unsigned char *As = smem;                                                          // [2][PARTS][kAPart]
-  unsigned char *Bs = smem + 2 * PARTS * kAPart;                                     // [2][PARTS][kBPart]
-  uint2 *ovf_lds = reinterpret_cast<uint2 *>(smem + 2 * PARTS * (kAPart + kBPart));  // [2][kOvfCap + 1] (MODE 1)
-  unsigned char *plane = smem + 2 * PARTS * (kAPart + kBPart) + (MODE == 1 ? 2 * (kOvfCap + 1) * 8 : 0);  // [pixels][16 ch] fp32
+  unsigned char *Bs = smem;                                          // [2 groups][kGroupTaps][PARTS][kBPart]
+  unsigned char *plane = smem + 2 * kGroupTaps * PARTS * kBPart;     // [pixels][16 ch] fp32
 
   const int wtid = threadIdx.x;                               // 0 .. 767 (plane copy)
   const int tid = PRODUCER ? wtid - kThreads : wtid;          // position inside the role
@@ -79,9 +99,26 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
   const long long G = gridDim.x, g = blockIdx.x;
   const long long total = grp.unit_begin[grp.n];
   const long long slice = sk_slice_of_block((int)g, (int)G);
-  const long long my_begin = unit_begin(slice, total, G);
-  const long long my_end = unit_begin(slice + 1, total, G);
+  long long my_begin = unit_begin(slice, total, G);
+  long long my_end = unit_begin(slice + 1, total, G);
+  if (grp.static_ranges) {   // slice r = range r = (problem, part, tile)
+    if (slice >= grp.range_begin[grp.n]) return;
+    int pi = 0;
+    while (pi + 1 < grp.n && slice >= grp.range_begin[pi + 1]) ++pi;
+    const DcnProblem &q = grp.p[pi];
+    const int tiles = q.n_ntiles * q.n_mtiles;
+    const int r = (int)slice - grp.range_begin[pi];
+    const int part = r / tiles;
+    my_begin = dcn_range_first_unit(grp, pi, part, r - part * tiles);
+    my_end = my_begin + (dcn_part_lo(q, part + 1) - dcn_part_lo(q, part));
+  }
 
+  if constexpr (PRODUCER) __builtin_amdgcn_s_setprio(KGDET_PLANE_PRODUCER_PRIO);
+#ifdef KGDET_PLANE_TRACE
+  unsigned long long tr[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tr_t = KGDET_TR_NOW();
+  const unsigned long long tr_start = tr_t;
+#endif
   long long cur = my_begin;
   int slot = 0;  // slabs written so far (one per range met)
   while (cur < my_end) {
@@ -104,7 +141,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
     f32x16 acc[PRODUCER ? 1 : 2][PRODUCER ? 1 : 2];  // consumers only
     if constexpr (!PRODUCER) zero_acc(acc);
 
-    typedef PlaneStageRegs<PARTS, MODE> Regs;
+    typedef PlaneStageRegs<MODE> Regs;
     constexpr int NG = Regs::NG;
 
     int s = s_begin;
@@ -117,10 +154,8 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       const uint4 *rec_base = reinterpret_cast<const uint4 *>(p.taps) +
                               (((size_t)(tile_b * p.DG + dgi) * K) * HoWo + hw_c) * (2 * NG);
       const int tile_in_img = nt - tile_b * p.tiles_per_image;
-      const unsigned char *wq_base = reinterpret_cast<const unsigned char *>(p.wq) +
-                                     (size_t)((mt * n_c16 + c16) * K) * (2 * kAPart) + tid * 16;
 
-      auto issue = [&](int j, Regs &R) {  // loads of stage j (clamped): weight stage + tap record
+      auto issue = [&](int j, Regs &R) {  // loads of stage j (clamped): the tap record
         const unsigned t = (unsigned)(t0 + min(j, n - 1));
         const uint4 *rec = rec_base + (size_t)t * HoWo * (2 * NG);
 #pragma unroll
@@ -130,19 +165,11 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         }
         if constexpr (MODE == 1) {
           const DcnInvOvfSlots *sl = p.inv_ovf + ((size_t)(tile_b * K + t) * p.tiles_per_image + tile_in_img);
-          R.n_ovf = sl->count;
-          R.ovf = sl->e[tid & (kOvfCap - 1)];
-        }
-        if constexpr (!kAFromL2) {
-#pragma unroll
-          for (int part = 0; part < PARTS; ++part)
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-              R.a[part][r] = *reinterpret_cast<const f32x4 *>(wq_base + (size_t)t * (2 * kAPart) + part * kAPart +
-                                                              r * (kProducers * 16));
+          R.ovf = *reinterpret_cast<const int2 *>(sl);   // (count, spill_start)
         }
       };
-      // consumers (kAFromL2): the wave's A fragments of stage j, 16 bytes per lane and fragment, coalesced
+      // consumers: the wave's A (weight) fragments of stage j straight from the weight image (L2), 16 bytes per lane
+      // and fragment, coalesced
       struct AFrag {
         bf16x8 a[PARTS][2];
       };
@@ -159,21 +186,6 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         for (int part = 0; part < PARTS; ++part)
 #pragma unroll
           for (int i = 0; i < 2; ++i) F.a[part][i] = *reinterpret_cast<const bf16x8 *>(b + part * kAPart + i * 32 * 16);
-      };
-      auto commit_ovf = [&](int slot, const Regs &R) {  // MODE 1: the stage's overflow slots -> LDS
-        if constexpr (MODE == 1) {
-          if (tid < kOvfCap) ovf_lds[slot * (kOvfCap + 1) + tid] = R.ovf;
-          if (tid == 0) ovf_lds[slot * (kOvfCap + 1) + kOvfCap] = make_uint2((unsigned)R.n_ovf, 0u);
-        }
-      };
-      auto commit_weights = [&](int buf, const Regs &R) {
-        if constexpr (kAFromL2) return;
-#pragma unroll
-        for (int part = 0; part < PARTS; ++part)
-#pragma unroll
-          for (int r = 0; r < 2; ++r)
-            *reinterpret_cast<f32x4 *>(As + (buf * PARTS + part) * kAPart + tid * 16 + r * (kProducers * 16)) =
-                R.a[part][r];
       };
       // Copy x[tile_b, c_base + 16*c16 .. +15, :, :] into LDS as [pixel][16 channels] (64 B rows).  The four
       // 16-byte channel quads of pixel q sit at slot (quad ^ ((q >> 2) & 3)): with the row start (q & 3) * 16
@@ -208,80 +220,32 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
           }
         }
       };
-      // B stage: sample this thread's 8 channels of its pixel at the record's four corners, split, store.
-      // Corner offsets in the record are for quad 0; quad c of the same pixel is at offset ^ (c << 4).
-      int ovf_tap = 0;  // tap of the stage being sampled (MODE 1 spill path)
-      auto sample = [&](int buf, const Regs &R, int ovf_slot) {
-#ifdef KGDET_ABL_NOSAMPLE
-        {
-          bf16x8 z;
+      // ---- B stage, producers: sample this thread's 8 channels of its pixel, split to bf16 hi / lo, store into slot
+      // `gi` of group buffer `buf`.  Corner offsets in the record are for quad 0; quad c of the same pixel is at
+      // offset ^ (c << 4).  Interpolation and hi/lo split work on channel PAIRS (v_pk_fma_f32 / v_pk_add_f32).
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      typedef f32x4 Corners[2][4];
+      auto corner_reads = [&](const Regs &R, int gq, Corners &v) {
+        const unsigned o[4] = {R.off[gq].x, R.off[gq].y, R.off[gq].z, R.off[gq].w};
 #pragma unroll
-          for (int q = 0; q < 8; ++q) z[q] = (__bf16)R.w[0][q & 3];
-          unsigned char *dst0 = Bs + buf * PARTS * kBPart + half * (kTileN * 16) + n_local * 16;
-          *reinterpret_cast<bf16x8 *>(dst0) = z;
-          if constexpr (PARTS == 2) *reinterpret_cast<bf16x8 *>(dst0 + kBPart) = z;
-          return;
-        }
-#endif
-        // interpolation and hi/lo split on channel PAIRS: v_pk_fma_f32 / v_pk_add_f32 do two lanes' worth per
-        // issue slot, and issue slots are what this kernel is short of (VALU and MFMA time add up on a SIMD)
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        f32x2 sv[2][2] = {{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}};  // [quad][pair]
-#pragma unroll
-        for (int gq = 0; gq < NG; ++gq) {
-          const unsigned o[4] = {R.off[gq].x, R.off[gq].y, R.off[gq].z, R.off[gq].w};
-          f32x4 v[2][4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-              v[c][e] = *reinterpret_cast<const f32x4 *>(plane + (o[e] ^ (unsigned)((half * 2 + c) << 4)));
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int c = 0; c < 2; ++c)
+            v[c][e] = *reinterpret_cast<const f32x4 *>(plane + (o[e] ^ (unsigned)((half * 2 + c) << 4)));
+      };
+      auto corner_fma = [&](const Regs &R, int gq, const Corners &v, f32x2 (&sv)[2][2], bool first) {
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const f32x2 ve = {v[c][e][2 * h2], v[c][e][2 * h2 + 1]};
-                const f32x2 we = {R.w[gq][e], R.w[gq][e]};
-                sv[c][h2] = (gq == 0 && e == 0) ? we * ve : __builtin_elementwise_fma(we, ve, sv[c][h2]);
-              }
-        }
-        if constexpr (MODE == 1) {
-          // contributions beyond the 8 inline ones: the (tile, tap)'s overflow list, staged in LDS one stage ago;
-          // every thread scans it (uniform trip count) and adds the entries of its own cell
-          const uint2 *ov = ovf_lds + ovf_slot * (kOvfCap + 1);
-          const int n_all = (int)ov[kOvfCap].x;
-          const int n_lds = min(n_all, kOvfCap);
-          for (int i = 0; i < n_lds; ++i) {
-            const uint2 e = ov[i];
-            if ((int)(e.x & 127u) == n_local) {
-              const float w = __uint_as_float(e.y);
+          for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-              for (int c = 0; c < 2; ++c) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(plane + ((e.x >> 7) ^ (unsigned)((half * 2 + c) << 4)));
-                sv[c][0] += f32x2{w * v[0], w * v[1]};
-                sv[c][1] += f32x2{w * v[2], w * v[3]};
-              }
+            for (int e = 0; e < 4; ++e) {
+              const f32x2 ve = {v[c][e][2 * h2], v[c][e][2 * h2 + 1]};
+              const f32x2 we = {R.w[gq][e], R.w[gq][e]};
+              sv[c][h2] = (first && e == 0) ? we * ve : __builtin_elementwise_fma(we, ve, sv[c][h2]);
             }
-          }
-          if (n_all > kOvfCap) {  // longer than the staged slots: the rest straight from the spill list (rare)
-            const DcnInvOvfSlots *sl = p.inv_ovf + ((size_t)(tile_b * K + ovf_tap) * p.tiles_per_image + tile_in_img);
-            const uint2 *spill = p.inv_spill + sl->spill_start;
-            for (int i = kOvfCap; i < n_all; ++i) {
-              const uint2 e = spill[i];
-              if ((int)(e.x & 127u) == n_local) {
-                const float w = __uint_as_float(e.y);
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                  const f32x4 v = *reinterpret_cast<const f32x4 *>(plane + ((e.x >> 7) ^ (unsigned)((half * 2 + c) << 4)));
-                  sv[c][0] += f32x2{w * v[0], w * v[1]};
-                  sv[c][1] += f32x2{w * v[2], w * v[3]};
-                }
-              }
-            }
-          }
-        }
+      };
+      auto split_store = [&](int buf, int gi, const f32x2 (&sv)[2][2]) {
         bf16x8 hi, lo;
 #pragma unroll
         for (int c = 0; c < 2; ++c)
@@ -297,90 +261,155 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
               lo[q + 1] = (__bf16)lf[1];
             }
           }
-        unsigned char *dst = Bs + buf * PARTS * kBPart + half * (kTileN * 16) + n_local * 16;
+        unsigned char *dst = Bs + (buf * kGroupTaps + gi) * PARTS * kBPart + half * (kTileN * 16) + n_local * 16;
         *reinterpret_cast<bf16x8 *>(dst) = hi;
         if constexpr (PARTS == 2) *reinterpret_cast<bf16x8 *>(dst + kBPart) = lo;
       };
-      auto multiply = [&](int buf, const AFrag &F) {
+      // MODE 1 (and the unpipelined path): everything of one stage in sequence
+      auto sample = [&](int buf, int gi, const Regs &R) {
+#ifdef KGDET_ABL_NOSAMPLE
+        {
+          f32x2 z[2][2] = {{{R.w[0][0], R.w[0][1]}, {R.w[0][2], R.w[0][3]}}, {{R.w[0][0], R.w[0][1]}, {R.w[0][2], R.w[0][3]}}};
+          split_store(buf, gi, z);
+          return;
+        }
+#endif
+        f32x2 sv[2][2];
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+          Corners v;
+          corner_reads(R, gq, v);
+          corner_fma(R, gq, v, sv, gq == 0);
+        }
+        if constexpr (MODE == 1) {
+          // contributions beyond the 8 inline ones: the (tile, tap)'s overflow list (a cell with more than 8
+          // contributing (pixel, corner) pairs for one tap: rare); every thread scans it (uniform trip count, the
+          // entries come through the scalar / L2 path) and adds the entries of its own cell
+          const uint2 *spill = p.inv_spill + R.ovf.y;
+          for (int i = 0; i < R.ovf.x; ++i) {
+            const uint2 e = spill[i];
+            if ((int)(e.x & 127u) == n_local) {
+              const float w = __uint_as_float(e.y);
+#pragma unroll
+              for (int c = 0; c < 2; ++c) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(plane + ((e.x >> 7) ^ (unsigned)((half * 2 + c) << 4)));
+                sv[c][0] += f32x2{w * v[0], w * v[1]};
+                sv[c][1] += f32x2{w * v[2], w * v[3]};
+              }
+            }
+          }
+        }
+        split_store(buf, gi, sv);
+      };
+      // the three stages jg .. jg+2 of a group from the record set (RA, RB, RC) into group buffer `buf`.  MODE 0: the
+      // corner reads of a stage are issued before the arithmetic of the stage before (two corner register sets).
+      auto sample_group = [&](int jg, int buf, const Regs &RA, const Regs &RB, const Regs &RC) {
+#ifdef KGDET_ABL_NOSAMPLE
+        constexpr bool pipelined = false;
+#else
+        constexpr bool pipelined = MODE == 0;
+#endif
+        if constexpr (pipelined) {
+          Corners V0, V1;
+          f32x2 sv[2][2];
+          corner_reads(RA, 0, V0);
+          corner_reads(RB, 0, V1);     // (clamped records past the end of the segment: harmless reads)
+          corner_fma(RA, 0, V0, sv, true);
+          if (jg < n) split_store(buf, 0, sv);
+          corner_reads(RC, 0, V0);
+          corner_fma(RB, 0, V1, sv, true);
+          if (jg + 1 < n) split_store(buf, 1, sv);
+          corner_fma(RC, 0, V0, sv, true);
+          if (jg + 2 < n) split_store(buf, 2, sv);
+        } else {
+          if (jg < n) sample(buf, 0, RA);
+          if (jg + 1 < n) sample(buf, 1, RB);
+          if (jg + 2 < n) sample(buf, 2, RC);
+        }
+      };
+      // ---- consumers: stage `gi` of group buffer `buf` times the fragment set F
+      auto multiply = [&](int buf, int gi, const AFrag &F) {
 #ifdef KGDET_ABL_NOMFMA
         return;
 #endif
         if constexpr (!PRODUCER) {
-          const unsigned char *A = As + buf * PARTS * kAPart + (lane >> 5) * (kTileM * 16) + (wm * 64 + (lane & 31)) * 16;
-          const unsigned char *B = Bs + buf * PARTS * kBPart + (lane >> 5) * (kTileN * 16) + (wn * 64 + (lane & 31)) * 16;
-          bf16x8 a[PARTS][2], b[PARTS][2];
+          const unsigned char *B = Bs + (buf * kGroupTaps + gi) * PARTS * kBPart + (lane >> 5) * (kTileN * 16) +
+                                   (wn * 64 + (lane & 31)) * 16;
+          bf16x8 b[PARTS][2];
 #pragma unroll
           for (int part = 0; part < PARTS; ++part)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              if constexpr (kAFromL2) a[part][i] = F.a[part][i];
-              else a[part][i] = *reinterpret_cast<const bf16x8 *>(A + part * kAPart + i * 32 * 16);
-              b[part][i] = *reinterpret_cast<const bf16x8 *>(B + part * kBPart + i * 32 * 16);
-            }
+            for (int i = 0; i < 2; ++i) b[part][i] = *reinterpret_cast<const bf16x8 *>(B + part * kBPart + i * 32 * 16);
+          if constexpr (PARTS == 2) {  // small terms first; four independent accumulators per pass
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[1][mi], b[0][ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[0][mi], b[1][ni], acc[mi][ni], 0, 0, 0);
+          }
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-              if constexpr (PARTS == 2) {  // small terms first
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][mi], b[0][ni], acc[mi][ni], 0, 0, 0);
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], b[1][ni], acc[mi][ni], 0, 0, 0);
-              }
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], b[0][ni], acc[mi][ni], 0, 0, 0);
-            }
+            for (int ni = 0; ni < 2; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[0][mi], b[0][ni], acc[mi][ni], 0, 0, 0);
         }
       };
 
-      // prologue: pipeline primed three deep, plane in LDS, stage 0 in buffer 0
-      Regs R0, R1, R2;
-      AFrag F0, F1;   // two stages ahead is enough for L2 latency at ~1.4 us per stage; a third set spills
-      __syncthreads();  // the previous segment's readers of plane / A / B are done
+      // prologue: register pipelines primed, plane in LDS, group 0 (stages 0..2) in group buffer 0
+      Regs RA0, RA1, RA2, RB0, RB1, RB2;   // producers: the records of two groups (set A: even groups, set B: odd groups)
+      AFrag F0, F1;      // consumers: weight fragments two stages ahead (stage t uses F[t & 1]); a third set spills
+#ifdef KGDET_PLANE_TRACE
+      tr_t = KGDET_TR_NOW();
+      tr[9] += 1; tr[8] += n;
+#endif
+      __syncthreads();   // the previous segment's readers of plane / B are done
+      KGDET_TR_ADD(0, tr_t);
       if constexpr (PRODUCER) {
-        issue(0, R0);
-        issue(1, R1);
-        issue(2, R2);
-      } else if constexpr (kAFromL2) {
+        issue(0, RA0); issue(1, RA1); issue(2, RA2);
+        issue(3, RB0); issue(4, RB1); issue(5, RB2);
+      } else {
         a_issue(0, F0);
         a_issue(1, F1);
       }
       load_plane();
+      KGDET_TR_ADD(1, tr_t);
+      __syncthreads();
+      KGDET_TR_ADD(2, tr_t);
       if constexpr (PRODUCER) {
-        commit_weights(0, R0);
-        commit_ovf(0, R0);
-        commit_ovf(1, R1);
+        sample_group(0, 0, RA0, RA1, RA2);
+        issue(6, RA0); issue(7, RA1); issue(8, RA2);
       }
       __syncthreads();
-      if constexpr (PRODUCER) {
-        ovf_tap = t0;
-        sample(0, R0, 0);
-      }
-      __syncthreads();
-      // stage j: producers put the loads of stage j+3 in flight (RI, consumed one body ago), move the weight
-      // stage j+1 (RC, loaded two bodies ago) into LDS and sample B stage j+1; consumers multiply stage j.
-      auto body = [&](int j, Regs &RI, Regs &RC, Regs &RN, AFrag &FI) {   // FI: the fragments of stage j
-        const int buf = j & 1;
+      KGDET_TR_ADD(3, tr_t);
+      // group at stage jg (a multiple of 3) in buffer BUF.  Consumers: multiply stages jg..jg+2 (fragment sets FA, FB,
+      // FA), re-loading each set with the stage two ahead.  Producers: sample stages jg+3..jg+5 from the other
+      // record set into the other buffer, then re-load that record set with the stages of the group after next.
+      auto group = [&](int jg, auto BUF, AFrag &FA, AFrag &FB, Regs &S0, Regs &S1, Regs &S2) {
+        constexpr int buf = decltype(BUF)::value;
         if constexpr (PRODUCER) {
-          issue(j + 3, RI);
-          commit_ovf(buf, RN);  // stage j+2's overflow slots (RN, loaded one body ago): read by sample() next body
-          if (j + 1 < n) {
-            commit_weights(buf ^ 1, RC);
-            ovf_tap = t0 + j + 1;
-            sample(buf ^ 1, RC, buf ^ 1);
-          }
+          sample_group(jg + 3, buf ^ 1, S0, S1, S2);
+          issue(jg + 9, S0); issue(jg + 10, S1); issue(jg + 11, S2);
         } else {
-          if (j < n) multiply(buf, FI);
-          if constexpr (kAFromL2) a_issue(j + 2, FI);   // unconditional, clamped: stage j + 2 into the freed set
+          multiply(buf, 0, FA);
+          a_issue(jg + 2, FA);
+          if (jg + 1 < n) multiply(buf, 1, FB);
+          a_issue(jg + 3, FB);
+          if (jg + 2 < n) multiply(buf, 2, FA);
+          a_issue(jg + 4, FA);
         }
+        KGDET_TR_ADD(4, tr_t);
         __syncthreads();
+        KGDET_TR_ADD(5, tr_t);
       };
-      for (int j = 0; j < n; j += 6) {  // 6 = lcm(3 register sets, 2 LDS buffers): static names in the body
-        body(j, R0, R1, R2, F0);
-        body(j + 1, R1, R2, R0, F1);
-        body(j + 2, R2, R0, R1, F0);
-        if (j + 3 < n) {
-          body(j + 3, R0, R1, R2, F1);
-          body(j + 4, R1, R2, R0, F0);
-          body(j + 5, R2, R0, R1, F1);
-        }
+      for (int jg = 0; jg < n; jg += 2 * kGroupTaps) {
+        // even group in buffer 0: its successor (odd) is sampled from record set B
+        group(jg, std::integral_constant<int, 0>{}, F0, F1, RB0, RB1, RB2);
+        if (jg + kGroupTaps < n) group(jg + kGroupTaps, std::integral_constant<int, 1>{}, F1, F0, RA0, RA1, RA2);
       }
       s += n;
       ++c16;
@@ -395,9 +424,17 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         store_slab(slab, tid, acc);
       }
     }
+    KGDET_TR_ADD(6, tr_t);
     ++slot;
     cur += s_end - s_begin;
   }
+#ifdef KGDET_PLANE_TRACE
+  tr[7] = KGDET_TR_NOW() - tr_start;
+  if ((tid & 63) == 0 && (tid >> 6) == 0) {
+#pragma unroll
+    for (int c = 0; c < 10; ++c) g_plane_trace[((int)blockIdx.x * 2 + (PRODUCER ? 1 : 0)) * 10 + c] = tr[c];
+  }
+#endif
 }
 
 }  // namespace kgdet
