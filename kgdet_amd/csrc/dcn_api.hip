@@ -317,6 +317,7 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
   grp.slots = kSlabSlots;
   grp.dbl_plane = 0;
   grp.plane_bytes = 0;
+  grp.wave_layout = 1;
   size_t lds = 0;
   int min_len = 1 << 30;  // shortest range (stages) in the pending group
   unsigned char *const table_base = (unsigned char *)workspace + slab_bytes();
@@ -453,7 +454,7 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
       } else {  // exact-fp32 kernel: one launch per problem (slabs are shared, so flush the pending group first)
         if (int rc = flush()) return rc;
         DcnFwdGroup one;
-        one.n = 1; one.xcd_slices = 0; one.slots = 2; one.dbl_plane = 0; one.plane_bytes = 0; one.static_ranges = 0; one.range_begin[0] = 0;
+        one.n = 1; one.xcd_slices = 0; one.slots = 2; one.dbl_plane = 0; one.plane_bytes = 0; one.static_ranges = 0; one.wave_layout = 0; one.range_begin[0] = 0;
         one.range_begin[1] = p.n_ntiles * p.n_mtiles; one.tile_begin[0] = 0; one.tile_begin[1] = p.n_ntiles * p.n_mtiles;
         one.unit_begin[0] = 0; one.unit_begin[1] = p.total_units;
         one.p[0] = p;
@@ -517,7 +518,7 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
   const int G = grid_size();
   const int parts = (flags & KGDET_DCN_BF16) ? 1 : 2;
   DcnFwdGroup grp;
-  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0;
+  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.wave_layout = 0;
   grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
   const int O_total = s->out_channels_total > 0 ? s->out_channels_total : s->O;
   for (int g = 0; g < s->groups; ++g) {
@@ -553,6 +554,7 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
   const size_t lds = plan_plane_lds(grp, dcn_bwd_input_plane_lds_bytes(parts, d.Ho * d.Wo),
                                     dcn_bwd_input_plane_fixed_lds_bytes(parts));
   const int threads = dcn_fwd_plane_threads();
+  grp.wave_layout = 1;   // plane_role's accumulator layout (slabs are decoded by dcn_fwd_fixup)
   if (parts == 1)
     hipLaunchKernelGGL(dcn_bwd_input_plane<1>, dim3(G), dim3(threads), lds, (hipStream_t)stream, grp, (float *)workspace);
   else
@@ -590,7 +592,7 @@ int kgdet_deform_conv_grad_offset(const kgdet_dcn_shape *s, const float *input, 
   const int G = grid_size();
   const int parts = (flags & KGDET_DCN_BF16) ? 1 : 2;
   DcnFwdGroup grp;
-  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0;
+  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.wave_layout = 0;
   grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
   const DcnTapRec *recs = reinterpret_cast<const DcnTapRec *>((unsigned char *)workspace + slab_bytes());
   for (int g = 0; g < s->groups; ++g) {
@@ -695,7 +697,7 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
 
   // ---- phase 1: grad_input (transposed sampling) ----
   DcnFwdGroup grp;
-  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0;
+  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.wave_layout = 0;
   grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
   size_t lds = 0;
   for (int i = 0; i < n; ++i) {
@@ -743,6 +745,7 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
   }
   if (!check_slots(grp)) { set_error("group too uneven for the slab slots"); return KGDET_E_UNSUPPORTED; }
   lds = plan_plane_lds(grp, lds, dcn_bwd_input_plane_fixed_lds_bytes(2));
+  grp.wave_layout = 1;   // plane_role's accumulator layout (slabs are decoded by dcn_fwd_fixup)
   hipLaunchKernelGGL(dcn_bwd_input_plane<2>, dim3(G), dim3(dcn_fwd_plane_threads()), lds, (hipStream_t)stream, grp,
                      (float *)workspace);
   hipLaunchKernelGGL(dcn_fwd_fixup, dim3(grp.tile_begin[grp.n], 16), dim3(kThreads), 0, (hipStream_t)stream, grp,
@@ -750,6 +753,7 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
 
   // ---- phase 2: grad_offset (column gradient in registers) ----
   grp.n = 0;
+  grp.wave_layout = 0;
   lds = 0;
   for (int i = 0; i < n; ++i) {
     const kgdet_dcn_shape *s = shapes[i];
@@ -836,7 +840,7 @@ int kgdet_deform_conv_grad_weight_grouped(int32_t n, const kgdet_dcn_shape *cons
   }
   unsigned char *tab = (unsigned char *)workspace + slab_bytes();
   DcnFwdGroup grp;
-  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0;
+  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.wave_layout = 0;
   grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
   size_t lds = 0;
   int min_len = 1 << 30;

@@ -85,6 +85,8 @@ struct DcnFwdGroup {
   int slots;       // slab slots per workgroup
   int dbl_plane;   // (unused: second feature-plane buffer, measured and dropped)
   int plane_bytes; // plane kernels: bytes of the largest feature plane of the group
+  int wave_layout;    // accumulator layout of the slabs: 0 = 4 x 2 waves of 64 x 64 (2 x 2 MFMA blocks each),
+                      // 1 = 8 x 1 waves of 32 x 128 (1 x 4 blocks each; plane kernels: every wave loads DISTINCT weight rows)
   int static_ranges;  // 1: workgroup of slice r computes exactly range r (problem, part, tile), r < range_begin[n];
                       //    the other workgroups exit.  Ranges of one (problem, part) are consecutive, so the 32
                       //    workgroups of an XCD walk the SAME weight stages at the same time and share them in L2.
@@ -332,6 +334,42 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+}
+
+// ---- layout 1: 8 waves x (32 rows x 128 columns), accumulators acc[ni] = MFMA block (rows wave*32.., cols ni*32..)
+__device__ __forceinline__ void store_output_w8(const DcnProblem &p, int mt, int nt, int tid, const f32x16 (&acc)[4]) {
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    int b, hw;
+    if (!tile_pixel(p, nt, ni * 32 + (lane & 31), b, hw)) continue;
+    float *obase = p.out + ((long long)b * p.O_total + p.o_base) * p.HoWo + hw;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = mt * kTileM + wave * 32 + mfma_row(r, lane);
+      if (o >= p.Og) continue;
+      float v = acc[ni][r];
+      if (p.bias) v += p.bias[p.bias_base + o];
+      if (p.flags & 1u /* KGDET_DCN_RELU */) v = fmaxf(v, 0.0f);
+      obase[(long long)o * p.HoWo] = v;
+    }
+  }
+}
+__device__ __forceinline__ void store_slab_w8(float *__restrict__ slab, int tid, const f32x16 (&acc)[4]) {
+  f32x4 *s4 = reinterpret_cast<f32x4 *>(slab);
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = {acc[ni][4 * q], acc[ni][4 * q + 1], acc[ni][4 * q + 2], acc[ni][4 * q + 3]};
+      s4[(ni * 4 + q) * kThreads + tid] = v;     // float4 column j = ni * 4 + q
+    }
+}
+__device__ __forceinline__ void zero_acc_w8(f32x16 (&acc)[4]) {
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ni][r] = 0.0f;
 }
 
 // Which slab slot does workgroup g use for the segment of its range that starts at `seg_begin`?

@@ -264,16 +264,19 @@ __global__ __launch_bounds__(kThreads) void dcn_fwd_fixup(const DcnFwdGroup grp,
       sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
     }
   }
-  // float4 column j = (mi, ni, q): accumulator registers 4q .. 4q+3 of block (mi, ni)
-  const int mi = j >> 3, ni = (j >> 2) & 1, q = j & 3;
+  // layout 0: float4 column j = (mi, ni, q): accumulator registers 4q .. 4q+3 of block (mi, ni) of wave (wm, wn)
+  // layout 1: float4 column j = (ni, q) of wave `wave`: rows wave*32.., columns ni*32..
+  const int q = j & 3;
   const int mt = tile % p.n_mtiles, nt = tile / p.n_mtiles;
-  const int lane = tid & 63, wave = tid >> 6, wm = wave & 3, wn = wave >> 2;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int row0 = grp.wave_layout ? wave * 32 : (wave & 3) * 64 + (j >> 3) * 32;
+  const int col0 = grp.wave_layout ? (j >> 2) * 32 : (wave >> 2) * 64 + ((j >> 2) & 1) * 32;
   int b, hw;
-  if (!tile_pixel(p, nt, wn * 64 + ni * 32 + (lane & 31), b, hw)) return;
+  if (!tile_pixel(p, nt, col0 + (lane & 31), b, hw)) return;
   float *obase = p.out + ((long long)b * p.O_total + p.o_base) * p.HoWo + hw;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const int o = mt * kTileM + wm * 64 + mi * 32 + mfma_row(4 * q + e, lane);
+    const int o = mt * kTileM + row0 + mfma_row(4 * q + e, lane);
     if (o >= p.Og) continue;
     float v = sum[e];
     if (p.bias) v += p.bias[p.bias_base + o];

@@ -93,7 +93,9 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
   const int wtid = threadIdx.x;                               // 0 .. 767 (plane copy)
   const int tid = PRODUCER ? wtid - kThreads : wtid;          // position inside the role
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 3, wn = wave >> 2;                    // consumers: 64 x 64 block of the tile
+  // consumers: wave w owns rows [32 w, 32 w + 32) x all 128 columns of the tile (wave layout 1): every wave loads
+  // DISTINCT weight rows, 16 KB per stage and workgroup instead of 32 KB with 4 x 2 waves of 64 x 64 -- the vector
+  // memory path of a CU takes 64 B per clock, and 32 KB of fragments per stage were 512 of its ~1000 cycles
   const int n_local = tid & (kTileN - 1);                     // producers: pixel column sampled
   const int half = (tid >> 7) & 1;                            //            and which 8 of the chunk's 16 channels
   const long long G = gridDim.x, g = blockIdx.x;
@@ -138,8 +140,8 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
     const int hw_c = hw0 < p.HoWo ? hw0 : 0;
     const int HoWo = p.HoWo;
 
-    f32x16 acc[PRODUCER ? 1 : 2][PRODUCER ? 1 : 2];  // consumers only
-    if constexpr (!PRODUCER) zero_acc(acc);
+    f32x16 acc[PRODUCER ? 1 : 4];  // consumers only
+    if constexpr (!PRODUCER) zero_acc_w8(acc);
 
     typedef PlaneStageRegs<MODE> Regs;
     constexpr int NG = Regs::NG;
@@ -171,11 +173,11 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       // consumers: the wave's A (weight) fragments of stage j straight from the weight image (L2), 16 bytes per lane
       // and fragment, coalesced
       struct AFrag {
-        bf16x8 a[PARTS][2];
+        bf16x8 a[PARTS];
       };
       const unsigned char *wq_cons = reinterpret_cast<const unsigned char *>(p.wq) +
                                      (size_t)((mt * n_c16 + c16) * K) * (2 * kAPart) + (lane >> 5) * (kTileM * 16) +
-                                     (wm * 64 + (lane & 31)) * 16;
+                                     (wave * 32 + (lane & 31)) * 16;
       auto a_issue = [&](int j, AFrag &F) {
 #ifdef KGDET_ABL_NOALOAD
         if (j > 1) return;
@@ -183,9 +185,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         const unsigned t = (unsigned)(t0 + min(j, n - 1));
         const unsigned char *b = wq_cons + (size_t)t * (2 * kAPart);
 #pragma unroll
-        for (int part = 0; part < PARTS; ++part)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) F.a[part][i] = *reinterpret_cast<const bf16x8 *>(b + part * kAPart + i * 32 * 16);
+        for (int part = 0; part < PARTS; ++part) F.a[part] = *reinterpret_cast<const bf16x8 *>(b + part * kAPart);
       };
       // Copy x[tile_b, c_base + 16*c16 .. +15, :, :] into LDS as [pixel][16 channels] (64 B rows).  The four
       // 16-byte channel quads of pixel q sit at slot (quad ^ ((q >> 2) & 3)): with the row start (q & 3) * 16
@@ -334,29 +334,23 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
 #endif
         if constexpr (!PRODUCER) {
           const unsigned char *B = Bs + (buf * kGroupTaps + gi) * PARTS * kBPart + (lane >> 5) * (kTileN * 16) +
-                                   (wn * 64 + (lane & 31)) * 16;
-          bf16x8 b[PARTS][2];
+                                   (lane & 31) * 16;
+          bf16x8 b[PARTS][4];
 #pragma unroll
           for (int part = 0; part < PARTS; ++part)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) b[part][i] = *reinterpret_cast<const bf16x8 *>(B + part * kBPart + i * 32 * 16);
+            for (int ni = 0; ni < 4; ++ni) b[part][ni] = *reinterpret_cast<const bf16x8 *>(B + part * kBPart + ni * 32 * 16);
           if constexpr (PARTS == 2) {  // small terms first; four independent accumulators per pass
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int ni = 0; ni < 4; ++ni)
+              acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[1], b[0][ni], acc[ni], 0, 0, 0);
 #pragma unroll
-              for (int ni = 0; ni < 2; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[1][mi], b[0][ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-              for (int ni = 0; ni < 2; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[0][mi], b[1][ni], acc[mi][ni], 0, 0, 0);
+            for (int ni = 0; ni < 4; ++ni)
+              acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[0], b[1][ni], acc[ni], 0, 0, 0);
           }
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[0][mi], b[0][ni], acc[mi][ni], 0, 0, 0);
+          for (int ni = 0; ni < 4; ++ni)
+            acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[0], b[0][ni], acc[ni], 0, 0, 0);
         }
       };
 
@@ -418,10 +412,10 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
 
     if constexpr (!PRODUCER) {
       if (s_begin == 0 && s_end == cpt) {
-        store_output(p, mt, nt, tid, acc);
+        store_output_w8(p, mt, nt, tid, acc);
       } else {
         float *slab = slabs + ((long long)g * grp.slots + slot) * kTileElems;
-        store_slab(slab, tid, acc);
+        store_slab_w8(slab, tid, acc);
       }
     }
     KGDET_TR_ADD(6, tr_t);

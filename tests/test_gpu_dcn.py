@@ -355,11 +355,11 @@ def test_grad_weight_plane_kernel(case):
 
 def test_more_tiles_than_slab_slots_take_the_safe_path():
     """a launch whose workgroup slices would meet more tile ranges than a workgroup has slab slots
-    (here 180 images x 9 pixel tiles = 1620 tiles on 256 CUs, > 6 per workgroup) must not run the stream-K plane
+    (here 192 images x 9 pixel tiles = 1728 tiles on 256 CUs, > 6 per workgroup) must not run the stream-K plane
     kernels (their slab index would run into the neighbour's slabs): results stay correct, forward and backward."""
     _require_gpu()
     from kgdet_amd import dcn
-    case = (180, 16, 25, 42, 16, 3, 1, 1, 1, 1, 1)
+    case = (192, 16, 25, 42, 16, 3, 1, 1, 1, 1, 1)     # (a multiple of the default im2col_step = 64)
     N, C, H, W, O, k, s, p, d, g, dg = case
     x, off, w, go, _ = _make(case, seed=21)
     tx, to, tw = (torch.from_numpy(a).cuda().requires_grad_() for a in (x, off, w))
