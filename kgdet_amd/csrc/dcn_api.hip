@@ -622,6 +622,7 @@ int kgdet_deform_conv_grad_offset(const kgdet_dcn_shape *s, const float *input, 
     ++grp.n;
   }
   KGDET_CHECK_SHAPE(s->groups == 1, "grad_offset plane kernel: weight groups > 1 would need a sum over groups");
+  plan_static_ranges(grp, G);
   hipLaunchKernelGGL(dcn_build_grad_taps, dim3(2 * G, grp.n), dim3(256), 0, (hipStream_t)stream, grp);
   const size_t lds = dcn_bwd_offset_plane_lds_bytes(parts, d.K, s->H * s->W);
   const int threads = dcn_bwd_offset_plane_threads();
@@ -787,6 +788,7 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
     lds = need > lds ? need : lds;
   }
   if (lds > kMaxLds || !check_slots(grp)) { set_error("group does not fit the grad_offset kernel"); return KGDET_E_UNSUPPORTED; }
+  plan_static_ranges(grp, G);
   hipLaunchKernelGGL(dcn_build_grad_taps, dim3(2 * G, grp.n), dim3(256), 0, (hipStream_t)stream, grp);
   hipLaunchKernelGGL(dcn_bwd_offset_plane<2>, dim3(G), dim3(dcn_bwd_offset_plane_threads()), lds, (hipStream_t)stream, grp,
                      (float *)workspace, max_K);

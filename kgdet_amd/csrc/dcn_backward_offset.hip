@@ -83,8 +83,8 @@ __device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__res
   const long long G = gridDim.x, g = blockIdx.x;
   const long long total = grp.unit_begin[grp.n];
   const long long slice = sk_slice_of_block((int)g, (int)G);
-  const long long my_begin = unit_begin(slice, total, G);
-  const long long my_end = unit_begin(slice + 1, total, G);
+  long long my_begin, my_end;
+  dcn_slice_bounds(grp, slice, G, my_begin, my_end);   // (static ranges: exactly one range, or nothing)
 
   long long cur = my_begin;
   int slot = 0;
@@ -340,6 +340,30 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_plane_fixup(const DcnFwdGr
   const DcnProblem &p = grp.p[pi];
   const int tile = gtile - grp.tile_begin[pi];
   const long long total = grp.unit_begin[grp.n];
+  const size_t slab_floats0 = (size_t)max_K * kTileN * 2;
+  if (grp.static_ranges) {   // one workgroup per (part, tile) range: add the parts' slabs in order
+    if (p.kparts == 1) return;  // written directly
+    const int tiles_ = p.n_ntiles * p.n_mtiles;
+    const int tb_ = tile / p.tiles_per_image, px0_ = (tile - tb_ * p.tiles_per_image) * kTileN;
+    for (int e = 0; e < 4; ++e) {
+      const int i = (blockIdx.y + e * gridDim.y) * 256 + threadIdx.x;
+      if (i >= p.K * kTileN) continue;
+      float sy = 0.f, sx = 0.f;
+      for (int part = 0; part < p.kparts; ++part) {
+        const int range = grp.range_begin[pi] + part * tiles_ + tile;
+        const float2 v = reinterpret_cast<const float2 *>(slabs + (size_t)sk_block_of_slice(range, G) * grp.slots * slab_floats0)[i];
+        sy += v.x;
+        sx += v.y;
+      }
+      const int t = i / kTileN, px = px0_ + (i - t * kTileN);
+      if (px < p.HoWo) {
+        float *dst = p.goff + ((long long)tb_ * 2 * p.K + 2 * t) * p.HoWo + px;
+        dst[0] = sy;
+        dst[p.HoWo] = sx;
+      }
+    }
+    return;
+  }
   const long long tb = dcn_range_first_unit(grp, pi, 0, tile), te = tb + p.chunks_per_tile;
   long long g0 = tb * G / total;
   while (unit_begin(g0 + 1, total, G) <= tb) ++g0;

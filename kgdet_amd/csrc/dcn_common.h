@@ -151,6 +151,27 @@ __device__ __forceinline__ int sk_block_of_slice(int r, int G) {
   return (G % 8 == 0) ? (r % (G / 8)) * 8 + r / (G / 8) : r;
 }
 
+// The unit interval [begin, end) of slice `slice`: stream-K share, or -- static_ranges -- exactly range `slice`
+// (empty beyond the last range).
+__device__ __forceinline__ void dcn_slice_bounds(const DcnFwdGroup &grp, long long slice, long long G, long long &begin,
+                                                 long long &end) {
+  const long long total = grp.unit_begin[grp.n];
+  if (!grp.static_ranges) {
+    begin = slice * total / G;
+    end = (slice + 1) * total / G;
+    return;
+  }
+  if (slice >= grp.range_begin[grp.n]) { begin = end = 0; return; }
+  int pi = 0;
+  while (pi + 1 < grp.n && slice >= grp.range_begin[pi + 1]) ++pi;
+  const DcnProblem &q = grp.p[pi];
+  const int tiles = q.n_ntiles * q.n_mtiles;
+  const int r = (int)slice - grp.range_begin[pi];
+  const int part = r / tiles;
+  begin = dcn_range_first_unit(grp, pi, part, r - part * tiles);
+  end = begin + (dcn_part_lo(q, part + 1) - dcn_part_lo(q, part));
+}
+
 // Output pixel of column `col` of pixel tile `nt`: image b, position hw inside it; false if past the end.
 __device__ __forceinline__ bool tile_pixel(const DcnProblem &p, int nt, int col, int &b, int &hw) {
   if (p.tiles_per_image > 0) {

@@ -99,21 +99,9 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
   const int n_local = tid & (kTileN - 1);                     // producers: pixel column sampled
   const int half = (tid >> 7) & 1;                            //            and which 8 of the chunk's 16 channels
   const long long G = gridDim.x, g = blockIdx.x;
-  const long long total = grp.unit_begin[grp.n];
   const long long slice = sk_slice_of_block((int)g, (int)G);
-  long long my_begin = unit_begin(slice, total, G);
-  long long my_end = unit_begin(slice + 1, total, G);
-  if (grp.static_ranges) {   // slice r = range r = (problem, part, tile)
-    if (slice >= grp.range_begin[grp.n]) return;
-    int pi = 0;
-    while (pi + 1 < grp.n && slice >= grp.range_begin[pi + 1]) ++pi;
-    const DcnProblem &q = grp.p[pi];
-    const int tiles = q.n_ntiles * q.n_mtiles;
-    const int r = (int)slice - grp.range_begin[pi];
-    const int part = r / tiles;
-    my_begin = dcn_range_first_unit(grp, pi, part, r - part * tiles);
-    my_end = my_begin + (dcn_part_lo(q, part + 1) - dcn_part_lo(q, part));
-  }
+  long long my_begin, my_end;
+  dcn_slice_bounds(grp, slice, G, my_begin, my_end);   // (static ranges: exactly one range, or nothing)
 
   if constexpr (PRODUCER) __builtin_amdgcn_s_setprio(KGDET_PLANE_PRODUCER_PRIO);
 #ifdef KGDET_PLANE_TRACE
