@@ -39,6 +39,13 @@ extern "C" {
  *                       (per-chunk partial tiles added in fixed order); workspace from the _workspace_bytes query. */
 size_t kgdet_conv_packed_bytes(int32_t M, int32_t K, int32_t taps);
 int kgdet_conv_pack(const float *w, int32_t O, int32_t C, int32_t taps, int32_t transpose, void *packed, void *stream);
+/* forward and grad_input images of one weight in one launch (O and C multiples of 16) */
+int kgdet_conv_pack_both(const float *w, int32_t O, int32_t C, int32_t taps, void *packed, void *packed_t, void *stream);
+/* Both images of n weights in ONE launch (training re-packs every weight every step).  desc_dev: device table of n x 5
+ * int64 {weight ptr, image ptr, transposed-image ptr, (O << 32) | C, (taps << 32) | first block}, first block = running sum
+ * of kgdet_conv_pack_blocks(O, C, taps) over the preceding entries; total_blocks = the sum over all entries. */
+int64_t kgdet_conv_pack_blocks(int32_t O, int32_t C, int32_t taps);
+int kgdet_conv_pack_multi(const int64_t *desc_dev, int32_t n, int64_t total_blocks, void *stream);
 size_t kgdet_conv_apply_workspace_bytes(int64_t B, int32_t M, int32_t K, int32_t H, int32_t W, int32_t taps,
                                         int32_t stride); /* mostly 0 */
 int kgdet_conv_apply(const void *packed, const float *x, float *y, int64_t B, int32_t M, int32_t K, int32_t H, int32_t W,

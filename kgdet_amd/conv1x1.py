@@ -5,6 +5,7 @@
 to fp32-level accuracy (~5e-6 of the output scale), forward and both gradients; used by the backbone's bottlenecks
 (kgdet_amd/backbone.py), where MIOpen's fp32 kernels run at 60-110 TFLOP/s."""
 import ctypes
+import weakref
 
 import torch
 
@@ -48,6 +49,8 @@ def _lib_sizes():
                 ('kgdet_conv3x3_grad_weight_workspace_bytes', sz, [i64, i32, i32, i32, i32]),
                 ('kgdet_conv_pack', ctypes.c_int, [vp, i32, i32, i32, i32, vp, vp]),
                 ('kgdet_conv_pack_both', ctypes.c_int, [vp, i32, i32, i32, vp, vp, vp]),
+                ('kgdet_conv_pack_blocks', i64, [i32, i32, i32]),
+                ('kgdet_conv_pack_multi', ctypes.c_int, [vp, i32, i64, vp]),
                 ('kgdet_conv_apply', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
                 ('kgdet_conv_apply_epilogue', ctypes.c_int,
                  [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
@@ -107,9 +110,82 @@ def _apply(img, x, M, taps, stride=1, bias=None, residual=None, relu=False):
     return y
 
 
+# ---- one pack launch per training step --------------------------------------------------------------------------------
+# Training re-packs every weight every step (the optimizer changed it): 60 launches of a few microseconds.  Inside a
+# `step_scope()` (the detector's forward_train) the weights seen in earlier steps are packed TOGETHER, into persistent
+# image buffers, by one kgdet_conv_pack_multi launch at scope entry; a weight met for the first time is packed on its own
+# and joins the set.  Outside a scope nothing is cached: every call packs (weights may change between any two calls).
+class _Entry(object):
+    __slots__ = ('ref', 'img', 'img_t', 'token', 'ptr')
+
+
+_entries = {}        # id(weight) -> _Entry
+_token = 0           # current scope generation; 0 = no scope active
+_generation = 0
+_table = None        # (key, device descriptor tensor, total blocks)
+PACK_MULTI = _os.environ.get('KGDET_PACK_MULTI', '1') == '1'
+
+
+def _launch_multi():
+    global _table
+    dead = [k for k, e in _entries.items() if e.ref() is None or e.ref().data_ptr() != e.ptr]
+    for k in dead:
+        del _entries[k]
+    if not _entries:
+        return
+    live = list(_entries.items())
+    key = tuple(k for k, _ in live)
+    L = _lib_sizes()
+    if _table is None or _table[0] != key:
+        rows, first = [], 0
+        for _, e in live:
+            w = e.ref()
+            O, C, taps = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+            rows.append([w.data_ptr(), e.img.data_ptr(), e.img_t.data_ptr(), (O << 32) | C, (taps << 32) | first])
+            first += L.kgdet_conv_pack_blocks(O, C, taps)
+        dev = live[0][1].img.device
+        _table = (key, torch.tensor(rows, dtype=torch.int64).to(dev), first)   # (one upload per change of the set)
+    _lib.check(L.kgdet_conv_pack_multi(_table[1].data_ptr(), len(live), _table[2], _stream()), 'conv_pack_multi')
+    for _, e in live:
+        e.token = _token
+
+
+class step_scope(object):
+    """``with conv1x1.step_scope():`` around ONE training forward (its backward may run after the scope closes: the
+    images live in persistent buffers that are only rewritten by the next scope's pack launch)."""
+
+    def __enter__(self):
+        global _token, _generation
+        self.prev = _token
+        _generation += 1
+        _token = _generation
+        if PACK_MULTI and _entries:
+            _launch_multi()
+
+    def __exit__(self, *exc):
+        global _token
+        _token = self.prev
+
+
 def forward_images(x, weight):
     """(forward operand image, grad_input operand image or None) of a contiguous weight"""
-    if PACK_BOTH and x.requires_grad and weight.shape[0] % 16 == 0:
+    both = PACK_BOTH and x.requires_grad and weight.shape[0] % 16 == 0
+    if both and PACK_MULTI and _token:
+        e = _entries.get(id(weight))
+        if e is not None and e.ref() is weight and e.ptr == weight.data_ptr():
+            if e.token != _token:       # joined the set after this scope's pack launch
+                _lib.check(_lib_sizes().kgdet_conv_pack_both(weight.data_ptr(), weight.shape[0], weight.shape[1],
+                                                             weight.shape[2] * weight.shape[3], e.img.data_ptr(),
+                                                             e.img_t.data_ptr(), _stream()), 'conv_pack_both')
+                e.token = _token
+            return e.img, e.img_t
+        img, img_t = _pack_both(weight)
+        if isinstance(weight, torch.nn.Parameter):     # persistent tensors only
+            e = _Entry()
+            e.ref, e.img, e.img_t, e.token, e.ptr = weakref.ref(weight), img, img_t, _token, weight.data_ptr()
+            _entries[id(weight)] = e
+        return img, img_t
+    if both:
         return _pack_both(weight)       # the backward's operand image comes out of the same launch
     return _pack(weight, False), None
 

@@ -114,6 +114,46 @@ __global__ __launch_bounds__(256) void conv1x1_pack(const float *__restrict__ w,
   }
 }
 
+// Both operand images of MANY weights in one launch (training re-packs every weight every step: 60 launches of a few
+// microseconds each).  desc[i] = {w, img, img_t, (O << 32) | C, (T << 32) | first block}; block b works on descriptor
+// i with first_block[i] <= b < first_block[i + 1], one 256-item slice of each image.
+__global__ __launch_bounds__(256) void conv1x1_pack_multi(const long long *__restrict__ desc, int n) {
+  int lo = 0, hi = n - 1;   // uniform binary search
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)(desc[mid * 5 + 4] & 0xffffffffLL) <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const long long *d = desc + lo * 5;
+  const float *w = reinterpret_cast<const float *>(d[0]);
+  const int O = (int)(d[3] >> 32), C = (int)(d[3] & 0xffffffffLL), T = (int)(d[4] >> 32);
+  const long long i = (long long)((int)blockIdx.x - (int)(d[4] & 0xffffffffLL)) * 256 + threadIdx.x;
+#pragma unroll
+  for (int transpose = 0; transpose < 2; ++transpose) {
+    unsigned char *img = reinterpret_cast<unsigned char *>(d[1 + transpose]);
+    const int M = transpose ? C : O, K = transpose ? O : C;
+    const int k16s = K / kTK;
+    const long long total = (long long)((M + kTM - 1) / kTM) * k16s * T * 2 * kTM;
+    if (i >= total) continue;
+    const int row = (int)(i % kTM);
+    const int khalf = (int)((i / kTM) & 1);
+    const long long st = i / (2 * kTM);
+    const int t = (int)(st % T);
+    const int k16 = (int)((st / T) % k16s), mt = (int)(st / ((long long)T * k16s));
+    const int m = mt * kTM + row, k0 = k16 * kTK + khalf * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long long o = transpose ? k0 + j : m, ch = transpose ? m : k0 + j;
+      v[j] = m < M ? w[(o * C + ch) * T + (transpose ? T - 1 - t : t)] : 0.0f;
+    }
+    bf16x8 hi8, lo8;
+    split8(v, hi8, lo8);
+    unsigned char *dst = img + st * kStage + khalf * (kTM * 16) + row * 16;
+    *reinterpret_cast<bf16x8 *>(dst) = hi8;
+    *reinterpret_cast<bf16x8 *>(dst + kPart) = lo8;
+  }
+}
+
 // y[b][m][p] = sum_{k, t} A[m][(k, t)] * x[b][k][p + shift(t)]  (zero outside the image): a TAPS = 1 (1x1) or 9 (3x3,
 // stride 1, padding 1) convolution as an implicit GEMM.  A as packed image, x [B, K, H*W], y [B, M, H*W].
 // 512 threads: 8 waves as 2 (M) x 4 (N), 64 x 32 outputs each -- two waves per SIMD, so one wave's MFMAs cover the
@@ -689,6 +729,21 @@ extern "C" int kgdet_conv_pack_both(const float *w, int32_t O, int32_t C, int32_
   hipLaunchKernelGGL(conv1x1_pack, dim3((unsigned)(blocks > 32768 ? 32768 : blocks), 2), dim3(256), 0,
                      (hipStream_t)stream, w, O, C, taps, 0, (unsigned char *)packed, (unsigned char *)packed_t);
   KGDET_CHECK_LAUNCH("conv_pack_both");
+  return KGDET_OK;
+}
+
+extern "C" int64_t kgdet_conv_pack_blocks(int32_t O, int32_t C, int32_t taps) {
+  if (O <= 0 || C <= 0 || O % kTK || C % kTK || (taps != 1 && taps != 9)) return 0;
+  const long long t0 = (long long)((O + kTM - 1) / kTM) * (C / kTK) * taps * 2 * kTM;
+  const long long t1 = (long long)((C + kTM - 1) / kTM) * (O / kTK) * taps * 2 * kTM;
+  return ((t0 > t1 ? t0 : t1) + 255) / 256;
+}
+
+extern "C" int kgdet_conv_pack_multi(const int64_t *desc_dev, int32_t n, int64_t total_blocks, void *stream) {
+  KGDET_CHECK_SHAPE(desc_dev && n > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "bad descriptor table");
+  hipLaunchKernelGGL(conv1x1_pack_multi, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const long long *)desc_dev, n);
+  KGDET_CHECK_LAUNCH("conv_pack_multi");
   return KGDET_OK;
 }
 

@@ -60,8 +60,10 @@ class RepPointsDetectorKp(nn.Module):
         return self.bbox_head(self.extract_feat(img), None)
 
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_keypoints, gt_bboxes_ignore=None):
-        x = self.extract_feat(img)
-        outs = self.bbox_head(x, img_metas)
+        from . import conv1x1
+        with conv1x1.step_scope():    # the split-bf16 convolutions' weight images: one pack launch per step
+            x = self.extract_feat(img)
+            outs = self.bbox_head(x, img_metas)
         loss_inputs = outs + (gt_bboxes, gt_labels, gt_keypoints, img_metas, self.train_cfg)
         return self.bbox_head.loss(*loss_inputs, gt_bboxes_ignore=gt_bboxes_ignore)
 

@@ -280,3 +280,45 @@ def test_conv_apply_epilogue_flags(B, C, O, H, W, k, stride):
                 got = c1._apply(img, x, O, k * k, stride, bias if use_b else None, res if use_r else None, relu)
                 assert got.shape == want.shape
                 assert ((got.double() - want).abs().max() / ref0.abs().max()).item() < 1e-5, (use_b, use_r, relu)
+
+
+@pytest.mark.gpu
+def test_step_scope_packs_follow_weight_updates():
+    """conv1x1.step_scope: one multi-weight pack launch per training forward into persistent images.  The images must
+    follow in-place weight updates (fused optimizers do not bump `_version`), a weight met for the first time inside
+    a scope must work, and outside a scope nothing may be served from the persistent images."""
+    import torch.nn.functional as F
+    from kgdet_amd import conv1x1
+    torch.manual_seed(0)
+    ws = [torch.nn.Parameter(torch.randn(64, 32, k, k, device='cuda') * 0.1) for k in (1, 3, 1)]
+    x = torch.randn(2, 32, 12, 16, device='cuda', requires_grad=True)
+    opt = torch.optim.Adam(ws, lr=0.05, fused=True)
+
+    def run(active):
+        outs = []
+        for w in ws[:active]:
+            outs.append(conv1x1.conv_split(x, w))
+        return outs
+
+    for step in range(4):
+        n_active = 2 if step < 2 else 3          # the third weight joins the set at step 2
+        with conv1x1.step_scope():
+            outs = run(n_active)
+        refs = [F.conv2d(x, w, padding=w.shape[2] // 2) for w in ws[:n_active]]
+        for o, r in zip(outs, refs):
+            assert float((o - r).abs().max()) < 2e-5 * float(r.abs().max()), step
+        loss = sum(o.pow(2).sum() for o in outs)
+        gref = torch.autograd.grad(sum(r.pow(2).sum() for r in refs), [x] + ws[:n_active])
+        g = torch.autograd.grad(loss, [x] + ws[:n_active])          # backward AFTER the scope closed
+        for a, b in zip(g, gref):
+            assert float((a - b).abs().max()) < 5e-5 * float(b.abs().max()), step
+        for w, gw in zip(ws[:n_active], g[1:]):
+            w.grad = gw
+        opt.step()
+        opt.zero_grad()
+    assert len(conv1x1._entries) >= 3
+    with torch.no_grad():
+        ws[0].mul_(2.0)
+    out = conv1x1.conv_split(x, ws[0])                                # no scope: must re-pack
+    ref = F.conv2d(x, ws[0])
+    assert float((out - ref).abs().max()) < 2e-5 * float(ref.abs().max())
