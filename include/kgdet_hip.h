@@ -280,6 +280,9 @@ int kgdet_sigmoid_focal_loss_backward(const float *logits, const int64_t *target
  * kgdet_soft_nms replaces soft_nms_cpu (R/nms/src/soft_nms_cpu.pyx:22-127): method 1 linear,
  * 2 gaussian; out_dets [n,5], out_inds [n] int64, *num_out device int64.
  * ------------------------------------------------------------------------------------------ */
+/* Segments of up to 4096 boxes are processed entirely in LDS; longer ones (nms_wrapper.py:8-49 takes any N) run the same
+ * algorithm with their arrays in `workspace` (size from kgdet_nms_workspace_bytes; 16 bytes suffice when no segment
+ * exceeds 4096 boxes).  Kept indices are bit-identical to nms_cpu.cpp either way. */
 size_t kgdet_nms_workspace_bytes(int64_t total_n, int32_t num_segments);
 /* multiclass_nms_kp for a whole batch (mmdet/core/post_processing/bbox_nms_kp.py:6-75 with type='nms'), two launches,
  * nothing read by the host: per (image, class) the candidates with score > score_thr are suppressed as kgdet_nms does;

@@ -84,7 +84,19 @@ struct NmsProblem {
   long long *num_out;
 };
 
-__device__ __forceinline__ void nms_block(const NmsProblem pr, float thr, int max_np, unsigned char *smem,
+// Working arrays of one problem.  On-chip: carved out of dynamic LDS (<= kNmsMaxLen boxes).  Large segments: the same
+// arrays in a global scratch area (one workgroup per segment still, so workgroup barriers order every access) plus a
+// 64-box LDS cache of the chunk being resolved; same decisions, same order, any length.
+struct NmsStore {
+  unsigned long long *keys;   // [NP]
+  float *bx1, *by1, *bx2, *by2, *bar;   // [n] sorted boxes + areas
+  unsigned char *alive;       // [n]
+  int *flag;                  // [n_all] keep flags by original index (on-chip: aliases by1)
+  float *chunk;               // LDS [5][64] cache of the current chunk (large mode), nullptr on-chip
+};
+
+template <bool LARGE>
+__device__ __forceinline__ void nms_block(const NmsProblem pr, float thr, const NmsStore st,
                                           int *wave_sums, unsigned long long *chunk_alive_p) {
   const int tid = threadIdx.x;
   const int n_all = pr.n;
@@ -96,10 +108,9 @@ __device__ __forceinline__ void nms_block(const NmsProblem pr, float thr, int ma
   while (NP < n_all) NP <<= 1;
   unsigned long long &chunk_alive = *chunk_alive_p;
 
-  unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);
-  float *bx1 = reinterpret_cast<float *>(smem + (size_t)max_np * 8);
-  float *by1 = bx1 + max_np, *bx2 = by1 + max_np, *by2 = bx2 + max_np, *bar = by2 + max_np;
-  unsigned char *alive = reinterpret_cast<unsigned char *>(bar + max_np);
+  unsigned long long *keys = st.keys;
+  float *bx1 = st.bx1, *by1 = st.by1, *bx2 = st.bx2, *by2 = st.by2, *bar = st.bar;
+  unsigned char *alive = st.alive;
 
   int mine = 0;
   for (int i = tid; i < NP; i += kNmsThreads) {
@@ -141,14 +152,24 @@ __device__ __forceinline__ void nms_block(const NmsProblem pr, float thr, int ma
 
   const int lane = tid & 63;
   for (int c0 = 0; c0 < n; c0 += 64) {
+    // the chunk's boxes: on-chip they are read in place; large mode caches them in LDS first
+    const float *cx1 = bx1 + c0, *cy1 = by1 + c0, *cx2 = bx2 + c0, *cy2 = by2 + c0, *car = bar + c0;
+    if constexpr (LARGE) {
+      if (tid < 64 && c0 + tid < n) {
+        st.chunk[tid] = bx1[c0 + tid]; st.chunk[64 + tid] = by1[c0 + tid]; st.chunk[128 + tid] = bx2[c0 + tid];
+        st.chunk[192 + tid] = by2[c0 + tid]; st.chunk[256 + tid] = bar[c0 + tid];
+      }
+      __syncthreads();
+      cx1 = st.chunk; cy1 = st.chunk + 64; cx2 = st.chunk + 128; cy2 = st.chunk + 192; car = st.chunk + 256;
+    }
     if (tid < 64) {  // wave 0: resolve the chunk internally
       const int i = c0 + lane;
       const bool have = i < n;
-      const float x1 = have ? bx1[i] : 0.f, y1 = have ? by1[i] : 0.f, x2 = have ? bx2[i] : 0.f,
-                  y2 = have ? by2[i] : 0.f, ar = have ? bar[i] : 0.f;
+      const float x1 = have ? cx1[lane] : 0.f, y1 = have ? cy1[lane] : 0.f, x2 = have ? cx2[lane] : 0.f,
+                  y2 = have ? cy2[lane] : 0.f, ar = have ? car[lane] : 0.f;
       unsigned long long mask = 0;  // bit j: this box suppresses chunk box j (j > lane)
       for (int j = lane + 1; j < 64 && c0 + j < n; ++j)
-        if (iou_ge(x1, y1, x2, y2, ar, bx1[c0 + j], by1[c0 + j], bx2[c0 + j], by2[c0 + j], bar[c0 + j], thr))
+        if (iou_ge(x1, y1, x2, y2, ar, cx1[j], cy1[j], cx2[j], cy2[j], car[j], thr))
           mask |= 1ull << j;
       unsigned long long live = __ballot(have && alive[i]);
       const unsigned mlo = (unsigned)mask, mhi = (unsigned)(mask >> 32);
@@ -172,8 +193,7 @@ __device__ __forceinline__ void nms_block(const NmsProblem pr, float thr, int ma
         while (rest && !dead) {
           const int s = __ffsll((long long)rest) - 1;
           rest &= rest - 1;
-          const int i = c0 + s;
-          dead = iou_ge(bx1[i], by1[i], bx2[i], by2[i], bar[i], x1, y1, x2, y2, ar, thr);
+          dead = iou_ge(cx1[s], cy1[s], cx2[s], cy2[s], car[s], x1, y1, x2, y2, ar, thr);
         }
         if (dead) alive[j] = 0;
       }
@@ -181,15 +201,22 @@ __device__ __forceinline__ void nms_block(const NmsProblem pr, float thr, int ma
     __syncthreads();
   }
 
-  // survivors -> flags by original index (reuse the by1 array as int flags), ascending compaction
-  int *flag = reinterpret_cast<int *>(by1);
-  unsigned char keep_sorted_local[kNmsMaxLen / kNmsThreads];
-  for (int i = tid, m = 0; i < n; i += kNmsThreads, ++m) keep_sorted_local[m] = alive[i];
-  __syncthreads();
-  for (int i = tid; i < n_all; i += kNmsThreads) flag[i] = 0;
-  __syncthreads();
-  for (int i = tid, m = 0; i < n; i += kNmsThreads, ++m)
-    if (keep_sorted_local[m]) flag[(unsigned)(keys[i] & 0xffffffffu)] = 1;
+  // survivors -> flags by original index (on-chip the flags reuse the by1 array), ascending compaction
+  int *flag = st.flag;
+  if constexpr (!LARGE) {
+    unsigned char keep_sorted_local[kNmsMaxLen / kNmsThreads];
+    for (int i = tid, m = 0; i < n; i += kNmsThreads, ++m) keep_sorted_local[m] = alive[i];
+    __syncthreads();
+    for (int i = tid; i < n_all; i += kNmsThreads) flag[i] = 0;
+    __syncthreads();
+    for (int i = tid, m = 0; i < n; i += kNmsThreads, ++m)
+      if (keep_sorted_local[m]) flag[(unsigned)(keys[i] & 0xffffffffu)] = 1;
+  } else {
+    for (int i = tid; i < n_all; i += kNmsThreads) flag[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += kNmsThreads)
+      if (alive[i]) flag[(unsigned)(keys[i] & 0xffffffffu)] = 1;
+  }
   __syncthreads();
   // each thread owns a contiguous run of original indices so the scan preserves ascending order
   const int per = (n_all + kNmsThreads - 1) / kNmsThreads;
@@ -201,6 +228,62 @@ __device__ __forceinline__ void nms_block(const NmsProblem pr, float thr, int ma
   for (int i = lo; i < hi; ++i)
     if (flag[i]) pr.out[pos++] = i;
   if (tid == 0) *pr.num_out = total;
+}
+
+__device__ __forceinline__ NmsStore nms_lds_store(unsigned char *smem, int max_np) {
+  NmsStore st;
+  st.keys = reinterpret_cast<unsigned long long *>(smem);
+  st.bx1 = reinterpret_cast<float *>(smem + (size_t)max_np * 8);
+  st.by1 = st.bx1 + max_np; st.bx2 = st.by1 + max_np; st.by2 = st.bx2 + max_np; st.bar = st.by2 + max_np;
+  st.alive = reinterpret_cast<unsigned char *>(st.bar + max_np);
+  st.flag = reinterpret_cast<int *>(st.by1);
+  st.chunk = nullptr;
+  return st;
+}
+
+// scratch bytes of one large segment of n boxes (NP = n rounded up to a power of two)
+__host__ __device__ inline size_t nms_large_scratch_bytes(long long n) {
+  long long np = 64;
+  while (np < n) np <<= 1;
+  return (size_t)np * 8 + (size_t)n * (5 * 4 + 4) + (((size_t)n + 15) & ~(size_t)15);
+}
+
+// Segments longer than the on-chip limit: same algorithm, arrays in global scratch at scratch + scratch_off[seg].
+__global__ __launch_bounds__(kNmsThreads) void nms_segments_large(const float *__restrict__ dets,
+                                                                  const long long *__restrict__ seg_offsets, float thr,
+                                                                  long long *__restrict__ keep,
+                                                                  long long *__restrict__ num_keep,
+                                                                  unsigned char *__restrict__ scratch) {
+  __shared__ int wave_sums[kNmsThreads / 64];
+  __shared__ unsigned long long chunk_alive;
+  __shared__ float chunk[5 * 64];
+  const int seg = blockIdx.x;
+  const long long seg_begin = seg_offsets[seg];
+  const long long n = seg_offsets[seg + 1] - seg_begin;
+  // this segment's scratch: every segment before it takes nms_large_scratch_bytes(its length), 256-byte aligned
+  size_t off = 0;
+  for (int q = 0; q < seg; ++q) off += (nms_large_scratch_bytes(seg_offsets[q + 1] - seg_offsets[q]) + 255) & ~(size_t)255;
+  long long np = 64;
+  while (np < n) np <<= 1;
+  unsigned char *base = scratch + off;
+  NmsStore st;
+  st.keys = reinterpret_cast<unsigned long long *>(base);
+  st.bx1 = reinterpret_cast<float *>(base + (size_t)np * 8);
+  st.by1 = st.bx1 + n; st.bx2 = st.by1 + n; st.by2 = st.bx2 + n; st.bar = st.by2 + n;
+  st.flag = reinterpret_cast<int *>(st.bar + n);
+  st.alive = reinterpret_cast<unsigned char *>(st.flag + n);
+  st.chunk = chunk;
+  NmsProblem pr;
+  pr.box = dets + seg_begin * 5;
+  pr.box_stride = 5;
+  pr.score = pr.box + 4;
+  pr.score_stride = 5;
+  pr.filter = false;
+  pr.score_thr = 0.f;
+  pr.n = (int)n;
+  pr.out = keep + seg_begin;
+  pr.num_out = num_keep + seg;
+  nms_block<true>(pr, thr, st, wave_sums, &chunk_alive);
 }
 
 // dets [T, 5]; segment s = rows [seg_offsets[s], seg_offsets[s + 1])
@@ -223,7 +306,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_segments(const float *__restr
   pr.n = (int)(seg_offsets[seg + 1] - seg_begin);
   pr.out = keep + seg_begin;
   pr.num_out = num_keep + seg;
-  nms_block(pr, thr, max_np, smem, wave_sums, &chunk_alive);
+  nms_block<false>(pr, thr, nms_lds_store(smem, max_np), wave_sums, &chunk_alive);
 }
 
 // The per-class loop of multiclass_nms_kp (mmdet/core/post_processing/bbox_nms_kp.py:25-50) for a whole batch in
@@ -248,7 +331,7 @@ __global__ __launch_bounds__(kNmsThreads) void multiclass_nms_segments(const flo
   pr.n = N;
   pr.out = keep + (long long)seg * N;
   pr.num_out = num_keep + seg;
-  nms_block(pr, thr, max_np, smem, wave_sums, &chunk_alive);
+  nms_block<false>(pr, thr, nms_lds_store(smem, max_np), wave_sums, &chunk_alive);
 }
 
 // The tail of multiclass_nms_kp (bbox_nms_kp.py:52-70) per image: concatenate the classes' survivors (class order,
@@ -480,18 +563,29 @@ using namespace kgdet;
 extern "C" {
 
 size_t kgdet_nms_workspace_bytes(int64_t total_n, int32_t num_segments) {
-  (void)total_n; (void)num_segments;
-  return 16;  // everything lives in LDS; kept for ABI stability
+  // segments of up to 4096 boxes live entirely in LDS; longer ones keep their arrays here (upper bound for any split
+  // of total_n boxes into num_segments segments)
+  return 16 + 2 * nms_large_scratch_bytes(total_n > 0 ? total_n : 1) + (size_t)(num_segments > 0 ? num_segments : 1) * 256;
 }
 
-static int nms_launch(const float *dets, const int64_t *seg_offsets, int32_t num_segments, int64_t max_seg_len,
-                      float iou_thr, int64_t *keep, int64_t *num_keep, void *stream) {
+static int nms_launch(const float *dets, const int64_t *seg_offsets, int32_t num_segments, int64_t total_n,
+                      int64_t max_seg_len, float iou_thr, int64_t *keep, int64_t *num_keep, void *workspace,
+                      size_t workspace_bytes, void *stream) {
   KGDET_CHECK_SHAPE(num_segments >= 0 && max_seg_len >= 0, "negative size");
   if (num_segments == 0) return KGDET_OK;
   KGDET_CHECK_SHAPE(dets && seg_offsets && keep && num_keep, "null pointer");
-  if (max_seg_len > kNmsMaxLen) {
-    set_error("nms: segment of %lld boxes exceeds the on-chip limit of %d", (long long)max_seg_len, kNmsMaxLen);
-    return KGDET_E_UNSUPPORTED;
+  if (max_seg_len > kNmsMaxLen) {   // no size cliff: the same algorithm on global scratch (nms_wrapper.py:8-49 takes any N)
+    const size_t need = kgdet_nms_workspace_bytes(total_n, num_segments);
+    if (workspace == nullptr || workspace_bytes < need) {
+      set_error("nms: segments beyond %d boxes need %zu bytes of workspace (kgdet_nms_workspace_bytes), got %zu",
+                kNmsMaxLen, need, workspace_bytes);
+      return KGDET_E_WORKSPACE;
+    }
+    hipLaunchKernelGGL(nms_segments_large, dim3(num_segments), dim3(kNmsThreads), 0, (hipStream_t)stream, dets,
+                       (const long long *)seg_offsets, iou_thr, (long long *)keep, (long long *)num_keep,
+                       (unsigned char *)workspace + 16);
+    KGDET_CHECK_LAUNCH("nms_segments_large");
+    return KGDET_OK;
   }
   int np = 64;
   while (np < max_seg_len) np <<= 1;
@@ -513,8 +607,8 @@ static int nms_launch(const float *dets, const int64_t *seg_offsets, int32_t num
 int kgdet_nms_batched(const float *dets, const int64_t *seg_offsets, int32_t num_segments, int64_t total_n,
                       int64_t max_seg_len, float iou_thr, int64_t *keep, int64_t *num_keep, void *workspace,
                       size_t workspace_bytes, void *stream) {
-  (void)total_n; (void)workspace; (void)workspace_bytes;
-  return nms_launch(dets, seg_offsets, num_segments, max_seg_len, iou_thr, keep, num_keep, stream);
+  return nms_launch(dets, seg_offsets, num_segments, total_n, max_seg_len, iou_thr, keep, num_keep, workspace,
+                    workspace_bytes, stream);
 }
 
 size_t kgdet_multiclass_nms_workspace_bytes(int32_t B, int32_t N, int32_t C) {
@@ -579,7 +673,7 @@ int kgdet_nms(const float *dets, int64_t n, float iou_thr, int64_t *keep, int64_
     KGDET_HIP_TRY(hipMemsetAsync(num_keep, 0, sizeof(int64_t), (hipStream_t)stream));
     return KGDET_OK;
   }
-  return nms_launch(dets, (const int64_t *)workspace, 1, n, iou_thr, keep, num_keep, stream);
+  return nms_launch(dets, (const int64_t *)workspace, 1, n, n, iou_thr, keep, num_keep, workspace, workspace_bytes, stream);
 }
 
 int kgdet_soft_nms(const float *dets, int64_t n, float iou_thr, int32_t method, float sigma, float min_score,

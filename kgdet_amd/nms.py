@@ -39,9 +39,13 @@ def nms_batched(dets, seg_offsets, iou_thr, max_seg_len=None):
     if max_seg_len is None:
         max_seg_len = int((seg_offsets[1:] - seg_offsets[:-1]).max().item())
     dets = dets.contiguous().float()
+    ws, ws_bytes = None, 0
+    if max_seg_len > 4096:      # beyond the on-chip limit the kernel keeps its arrays in a scratch buffer
+        ws_bytes = L.kgdet_nms_workspace_bytes(ctypes.c_int64(T), ctypes.c_int32(S))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dets.device)
     _lib.check(L.kgdet_nms_batched(_lib.ptr(dets), _lib.ptr(seg_offsets), ctypes.c_int32(S),
                                    ctypes.c_int64(T), ctypes.c_int64(max_seg_len), ctypes.c_float(iou_thr),
-                                   _lib.ptr(keep), _lib.ptr(num_keep), None, ctypes.c_size_t(0),
+                                   _lib.ptr(keep), _lib.ptr(num_keep), _lib.ptr(ws), ctypes.c_size_t(ws_bytes),
                                    _lib.current_stream()), 'kgdet_nms_batched')
     return keep, num_keep[:S]
 

@@ -102,5 +102,29 @@ def main():
     print('wrote', path, os.path.getsize(path), 'bytes')
 
 
+def large():
+    """tests/golden/nms_large_golden.npz: segments beyond the HIP kernel's on-chip limit of 4096 boxes (own seed, so
+    nms_golden.npz is unaffected).  Only the seeds, thresholds and kept indices are stored: the boxes are re-created
+    by make_boxes from the seed."""
+    import torch
+    ref_nms, _ = build_ref.load()
+    out = {}
+    for i, (n, thr, cluster, quant, seed) in enumerate([(4097, 0.5, True, False, 1), (8000, 0.5, True, False, 2),
+                                                        (8000, 0.3, False, False, 3), (12000, 0.5, True, True, 4)]):
+        d = make_boxes(np.random.default_rng(seed), n, cluster=cluster, quantize=quant)
+        keep = ref_nms.nms(torch.from_numpy(d), float(thr)).numpy().astype(np.int64)
+        out['case%d' % i] = np.array([n, seed, int(cluster), int(quant)], np.int64)
+        out['thr%d' % i] = np.float32(thr)
+        out['keep%d' % i] = keep
+        out['checksum%d' % i] = np.float64(d.astype(np.float64).sum())
+        print('large', i, n, thr, 'kept', len(keep))
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'nms_large_golden.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path), 'bytes')
+
+
 if __name__ == '__main__':
-    main()
+    if 'large' in sys.argv[1:]:
+        large()
+    else:
+        main()

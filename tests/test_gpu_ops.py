@@ -246,3 +246,38 @@ def test_multiclass_nms_fused_matches_per_image_reference_path(N, C, frac, max_n
             dup = (sc.unsqueeze(0) == sc.unsqueeze(1)).sum(1) > 1
             assert bool(same[~dup].all())
         assert float(det[b, n:].abs().sum()) == 0 and float(kp[b, n:].abs().sum()) == 0
+
+
+def test_nms_beyond_the_on_chip_limit_bit_exact(golden_dir):
+    """nms_wrapper.nms accepts any N (nms_wrapper.py:8-49): segments of 4097 / 8000 / 12000 boxes run the same algorithm
+    on a global scratch buffer (csrc/nms.hip nms_segments_large); kept indices bit-exact vs the compiled reference, also
+    as segments of one batched launch mixed with short ones."""
+    import os
+    from kgdet_amd.nms import nms, nms_batched
+    from tests.golden.make_nms_golden import make_boxes
+    L = np.load(os.path.join(golden_dir, 'nms_large_golden.npz'))
+    dets_all, keeps, thr0 = [], [], None
+    i = 0
+    while 'case%d' % i in L:
+        n, seed, cluster, quant = [int(v) for v in L['case%d' % i]]
+        d = make_boxes(np.random.default_rng(seed), n, cluster=bool(cluster), quantize=bool(quant))
+        thr = float(L['thr%d' % i])
+        dets, inds = nms(torch.from_numpy(d).cuda(), thr)
+        np.testing.assert_array_equal(inds.cpu().numpy(), L['keep%d' % i])
+        np.testing.assert_array_equal(dets.cpu().numpy(), d[L['keep%d' % i]])
+        if abs(thr - 0.5) < 1e-9:
+            dets_all.append(d)
+            keeps.append(L['keep%d' % i])
+        i += 1
+    # one batched launch: long, empty, short and long segments together
+    short = make_boxes(np.random.default_rng(9), 300)
+    segs = [dets_all[0], np.zeros((0, 5), np.float32), short, dets_all[1]]
+    offs = np.cumsum([0] + [len(s) for s in segs]).astype(np.int64)
+    keep, num = nms_batched(torch.from_numpy(np.concatenate(segs)).cuda(), torch.from_numpy(offs).cuda(), 0.5)
+    num = num.cpu().numpy()
+    keep = keep.cpu().numpy()
+    import oracle
+    want = [keeps[0], np.zeros(0, np.int64), oracle.nms(short, 0.5), keeps[1]]
+    for s, w in enumerate(want):
+        assert num[s] == len(w)
+        np.testing.assert_array_equal(keep[offs[s]:offs[s] + num[s]], w)

@@ -85,3 +85,19 @@ def test_live_against_compiled_reference():
                 od, oi = oracle.soft_nms(d, thr, name, 0.5, 0.05)
                 np.testing.assert_array_equal(oi, ri)
                 np.testing.assert_array_equal(od, np.asarray(rd, np.float32))
+
+
+def test_nms_large_segments_match_reference_golden(golden_dir):
+    """segments beyond the HIP kernel's on-chip limit (4097 / 8000 / 12000 boxes): the oracle against the compiled
+    reference's kept indices (tests/golden/nms_large_golden.npz, boxes re-created from their seeds)"""
+    import os
+    from tests.golden.make_nms_golden import make_boxes
+    L = np.load(os.path.join(golden_dir, 'nms_large_golden.npz'))
+    i = 0
+    while 'case%d' % i in L:
+        n, seed, cluster, quant = [int(v) for v in L['case%d' % i]]
+        d = make_boxes(np.random.default_rng(seed), n, cluster=bool(cluster), quantize=bool(quant))
+        assert float(d.astype(np.float64).sum()) == float(L['checksum%d' % i])     # the same boxes as the generator's
+        np.testing.assert_array_equal(oracle.nms(d, float(L['thr%d' % i])), L['keep%d' % i])
+        i += 1
+    assert i == 4
