@@ -117,6 +117,16 @@ void plan_static_ranges(DcnFwdGroup &grp, int G) {
   }
 }
 
+// fix-up launch of a plane-kernel group: the static schedule has its own, cheaper kernel
+void launch_plane_fixup(const DcnFwdGroup &grp, const void *workspace, int G, void *stream) {
+  if (grp.static_ranges)
+    hipLaunchKernelGGL(dcn_fwd_fixup_static, dim3(grp.tile_begin[grp.n], 2), dim3(kThreads), 0, (hipStream_t)stream, grp,
+                       (const float *)workspace, G);
+  else
+    hipLaunchKernelGGL(dcn_fwd_fixup, dim3(grp.tile_begin[grp.n], 16), dim3(kThreads), 0, (hipStream_t)stream, grp,
+                       (const float *)workspace, G);
+}
+
 // LDS-privatised backward-input: one (image, 32-channel slice) plane set must fit in LDS
 struct BwdLdsPlan {
   bool ok;
@@ -373,8 +383,7 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
       hipLaunchKernelGGL(dcn_fwd_plane<1>, dim3(G), dim3(threads), lds2, (hipStream_t)stream, grp, (float *)workspace);
     else
       hipLaunchKernelGGL(dcn_fwd_plane<2>, dim3(G), dim3(threads), lds2, (hipStream_t)stream, grp, (float *)workspace);
-    hipLaunchKernelGGL(dcn_fwd_fixup, dim3(grp.tile_begin[grp.n], 16), dim3(kThreads), 0, (hipStream_t)stream, grp,
-                       (const float *)workspace, G);
+    launch_plane_fixup(grp, workspace, G, stream);
     grp.n = 0;
     lds = 0;
     min_len = 1 << 30;
@@ -563,8 +572,7 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
     hipLaunchKernelGGL(dcn_bwd_input_plane<1>, dim3(G), dim3(threads), lds, (hipStream_t)stream, grp, (float *)workspace);
   else
     hipLaunchKernelGGL(dcn_bwd_input_plane<2>, dim3(G), dim3(threads), lds, (hipStream_t)stream, grp, (float *)workspace);
-  hipLaunchKernelGGL(dcn_fwd_fixup, dim3(grp.tile_begin[grp.n], 16), dim3(kThreads), 0, (hipStream_t)stream, grp,
-                     (const float *)workspace, G);
+  launch_plane_fixup(grp, workspace, G, stream);
   KGDET_CHECK_LAUNCH("dcn_bwd_input_plane");
   return KGDET_OK;
 }
@@ -754,8 +762,7 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
   plan_static_ranges(grp, G);
   hipLaunchKernelGGL(dcn_bwd_input_plane<2>, dim3(G), dim3(dcn_fwd_plane_threads()), lds, (hipStream_t)stream, grp,
                      (float *)workspace);
-  hipLaunchKernelGGL(dcn_fwd_fixup, dim3(grp.tile_begin[grp.n], 16), dim3(kThreads), 0, (hipStream_t)stream, grp,
-                     (const float *)workspace, G);
+  launch_plane_fixup(grp, workspace, G, stream);
 
   // ---- phase 2: grad_offset (column gradient in registers) ----
   grp.n = 0;

@@ -285,6 +285,56 @@ __global__ __launch_bounds__(kThreads) void dcn_fwd_fixup(const DcnFwdGroup grp,
   }
 }
 
+// Fix-up of the static one-range-per-workgroup schedule (DcnFwdGroup::static_ranges): tile `gtile` = the sum of its
+// kparts slabs (slot 0 of the workgroup of each (part, tile) range), parts in order.  grid = (tiles, 2): a block
+// sums 8 of the 16 float4 columns of a tile -- per part all eight loads are in flight before the adds.  (The generic
+// fix-up above spends one block per column and walks the stream-K slice arithmetic: 20 us for the head stage against
+// ~8 us here.)
+__global__ __launch_bounds__(kThreads) void dcn_fwd_fixup_static(const DcnFwdGroup grp, const float *__restrict__ slabs,
+                                                                int G) {
+  const int gtile = blockIdx.x, tid = threadIdx.x;
+  int pi = 0;
+  while (pi + 1 < grp.n && gtile >= grp.tile_begin[pi + 1]) ++pi;
+  const DcnProblem &p = grp.p[pi];
+  if (p.kparts == 1) return;  // written directly by the tile's only workgroup
+  const int tile = gtile - grp.tile_begin[pi];
+  const int tiles = p.n_ntiles * p.n_mtiles;
+  constexpr int kCols = 8;
+  const int j0 = blockIdx.y * kCols;
+  f32x4 sum[kCols];
+#pragma unroll
+  for (int c = 0; c < kCols; ++c) sum[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int part = 0; part < p.kparts; ++part) {
+    const int range = grp.range_begin[pi] + part * tiles + tile;
+    const f32x4 *s4 = reinterpret_cast<const f32x4 *>(slabs + (long long)sk_block_of_slice(range, G) * grp.slots * kTileElems);
+    f32x4 v[kCols];
+#pragma unroll
+    for (int c = 0; c < kCols; ++c) v[c] = s4[(j0 + c) * kThreads + tid];
+#pragma unroll
+    for (int c = 0; c < kCols; ++c) sum[c] += v[c];
+  }
+  const int mt = tile % p.n_mtiles, nt = tile / p.n_mtiles;
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int c = 0; c < kCols; ++c) {
+    const int j = j0 + c, q = j & 3;
+    const int row0 = grp.wave_layout ? wave * 32 : (wave & 3) * 64 + (j >> 3) * 32;
+    const int col0 = grp.wave_layout ? (j >> 2) * 32 : (wave >> 2) * 64 + ((j >> 2) & 1) * 32;
+    int b, hw;
+    if (!tile_pixel(p, nt, col0 + (lane & 31), b, hw)) continue;
+    float *obase = p.out + ((long long)b * p.O_total + p.o_base) * p.HoWo + hw;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int o = mt * kTileM + row0 + mfma_row(4 * q + e, lane);
+      if (o >= p.Og) continue;
+      float v = sum[c][e];
+      if (p.bias) v += p.bias[p.bias_base + o];
+      if (p.flags & KGDET_DCN_RELU) v = fmaxf(v, 0.0f);
+      obase[(long long)o * p.HoWo] = v;
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------------------------
 // Weight packing: [O, Cg, K] (one group) -> [K][Cg_pad][Og_pad], zero padded.
 // One workgroup per (c, 64 output channels): reads 64 runs of K contiguous floats, transposes

@@ -6,6 +6,7 @@ namespace kgdet {
 
 __global__ void dcn_fwd_mfma(const DcnProblem p, float *__restrict__ slabs);
 __global__ void dcn_fwd_fixup(const DcnFwdGroup grp, const float *__restrict__ slabs, int G);
+__global__ void dcn_fwd_fixup_static(const DcnFwdGroup grp, const float *__restrict__ slabs, int G);
 // plane variant (dcn_forward_plane.hip): PARTS = 2 hi/lo split (fp32-accurate), 1 = plain bf16 operands
 template <int PARTS>
 __global__ void dcn_fwd_plane(const DcnFwdGroup grp, float *__restrict__ slabs);
