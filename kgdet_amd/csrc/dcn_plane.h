@@ -31,7 +31,7 @@ constexpr int kAPart = 2 * kTileM * 8 * 2;  // bytes of one part of an A stage
 constexpr int kBPart = 2 * kTileN * 8 * 2;
 constexpr int kProducers = 256;                          // 4 producer waves
 constexpr int kPlaneThreads = kThreads + kProducers;     // 8 consumer + 4 producer waves
-constexpr int kPlaneRounds = 3;                          // (pixel, quad) items a thread has in flight while copying a plane
+constexpr int kPlaneRounds = 6;                          // (pixel, quad) items a thread has in flight while copying a plane
 constexpr int kGroupTaps = 3;                            // stages (taps) between two workgroup barriers
 constexpr bool kAFromL2 = true;   // (grad_weight kernel) consumers take their A fragments from the operand image in L2
 
