@@ -261,7 +261,16 @@ size_t kgdet_dcn_workspace_bytes(const kgdet_dcn_shape *s) {
   if (plane_bwd_offset_ok(s, d) && slab_bytes() + grad_tap_bytes(s, d) > bwd_in_plane)
     bwd_in_plane = slab_bytes() + grad_tap_bytes(s, d);
   size_t need = fwd_and_wgrad > bwd_in ? fwd_and_wgrad : bwd_in;
-  return need > bwd_in_plane ? need : bwd_in_plane;
+  need = need > bwd_in_plane ? need : bwd_in_plane;
+  if (!pl.ok && !plane_bwd_input_ok(s, d)) {   // large maps: the materialised column gradient of dcn_backward_large.hip
+    DcnProblem p;
+    fill_problem(s, d, 0, p);
+    if (dcn_bwd_large_ok(p, false, s->groups)) {
+      const size_t big = dcn_bwd_large_workspace_bytes(p);
+      need = need > big ? need : big;
+    }
+  }
+  return need;
 }
 
 size_t kgdet_dcn_group_workspace_bytes(int32_t n, const kgdet_dcn_shape *const *shapes) {
@@ -981,7 +990,16 @@ int kgdet_deform_conv_backward_input(const kgdet_dcn_shape *s, const float *inpu
     KGDET_CHECK_LAUNCH("dcn_bwd_input_gather");
     return KGDET_OK;
   }
-  // large feature maps: global-atomic path (grad_input must be zero-filled by the caller)
+  // large feature maps, v1: materialised transposed column gradient + inverse index, no atomics (dcn_backward_large.hip)
+  if (!plane_off) {
+    DcnProblem p;
+    fill_problem(s, d, 0, p);
+    p.x = input; p.offset = offset; p.mask = nullptr; p.wpk = packed_weight;
+    if (dcn_bwd_large_ok(p, mask != nullptr, s->groups))
+      return dcn_bwd_large(p, grad_output, s->out_channels_total, s->out_channel_offset, grad_input, grad_offset,
+                           workspace, workspace_bytes, stream);
+  }
+  // v2 / groups / deformable groups on large maps: global-atomic path (grad_input must be zero-filled by the caller)
   // one launch and one channel tile produce a deformable group's whole sum -> plain stores
   const int direct = (d.Cg == cpdg && d.Cg_pad256 == kTileM) ? 1 : 0;
   if (!direct) {

@@ -1,0 +1,313 @@
+// Deformable convolution v1 backward (grad_input + grad_offset) for feature maps too large for the LDS-plane kernels
+// (config 5's stride-8 / stride-16 levels: [2, 256, 100, 168], [2, 256, 50, 84]).  No atomics, deterministic.
+//
+// Reference path replaced: deform_conv_backward_input_cuda (deform_conv_cuda.cpp:260-371): columns = W^T grad_out
+// (:329-332), deformable_col2im_coord -> grad_offset (deform_conv_cuda_kernel.cu:337-435), deformable_col2im ->
+// grad_input with one float atomicAdd per (channel, tap, pixel, corner) (:279-334).  Round 1 ran these maps on
+// dcn_bwd_input_mfma, which keeps the atomic scatter; it was 7.9 ms of config 5's 51 ms of kernels per step.
+//
+// Here, with 288 GB of HBM, the column gradient IS materialised once -- transposed, channels innermost:
+//     colT[b][p][t*C + c] = sum_o grad_out[b][o][p] * W[o][c][t]                                  (310 MB at 2x100x168)
+// as ONE split-bf16 MFMA GEMM per image on the backbone's 1x1-convolution kernel (conv_nn<1>, csrc/conv1x1.hip) with
+// the pixels in the role of output channels (A = grad_out^T packed as a weight image, "image" = the permuted weight),
+// and both consumers read it in 1 KB runs:
+//   * grad_offset: one workgroup per output pixel, a thread per channel: colT row x the four corner rows of x^T
+//     (NHWC copy) x the derivative weights, block-reduced per tap;
+//   * grad_input: the scatter turned around with an inverse index.  Every (image, tap, pixel, valid corner) becomes an
+//     entry keyed by its input cell; a STABLE radix sort (hipCUB) groups the entries by cell in enumeration order, so
+//     every cell's sum has a fixed order; one workgroup per 32 cells, a thread per channel, adds w * colT[p][t*C + c].
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+#include "dcn_common.h"
+
+extern "C" int kgdet_conv_pack(const float *w, int32_t O, int32_t C, int32_t taps, int32_t transpose, void *packed,
+                               void *stream);
+extern "C" size_t kgdet_conv_packed_bytes(int32_t M, int32_t K, int32_t taps);
+extern "C" size_t kgdet_conv_apply_workspace_bytes(int64_t B, int32_t M, int32_t K, int32_t H, int32_t W, int32_t taps,
+                                                    int32_t stride);
+extern "C" int kgdet_conv_apply_epilogue(const void *packed, const float *x, float *y, const float *bias,
+                                         const float *residual, int32_t relu, int64_t B, int32_t M, int32_t K,
+                                         int32_t H, int32_t W, int32_t taps, int32_t stride, void *workspace,
+                                         size_t workspace_bytes, void *stream);
+
+namespace kgdet {
+
+namespace {
+
+// src [n][C][P] -> dst [n][P][C]  (32 x 32 tiles through LDS)
+__global__ __launch_bounds__(256) void large_transpose(const float *__restrict__ src, float *__restrict__ dst, int C,
+                                                       long long P, long long src_image_stride) {
+  __shared__ float tile[32][33];
+  const long long p0 = (long long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32, n = blockIdx.z;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float *s = src + n * src_image_stride;
+  float *d = dst + (long long)n * P * C;
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r;
+    const long long p = p0 + tx;
+    tile[r][tx] = (c < C && p < P) ? s[(long long)c * P + p] : 0.0f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const long long p = p0 + r;
+    const int c = c0 + tx;
+    if (p < P && c < C) d[p * C + c] = tile[tx][r];
+  }
+}
+
+// wpk [K][C_pad][O_pad] (the exact-fp32 forward kernel's image, part of the packed weight) -> wp [O][K*C] with
+// wp[o][t*C + c] = W[o][c][t]
+__global__ __launch_bounds__(256) void large_permute_weight(const float *__restrict__ wpk, float *__restrict__ wp, int O,
+                                                            int C, int K, int C_pad, int O_pad) {
+  const long long n = (long long)O * C * K;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int t = (int)((i / C) % K);
+    const int o = (int)(i / ((long long)C * K));
+    wp[i] = wpk[((long long)t * C_pad + c) * O_pad + o];
+  }
+}
+
+// one thread per (image, tap, output pixel): its four corners as (cell key, (tap*P + pixel, weight)) entries
+__global__ __launch_bounds__(256) void large_build_entries(const DcnProblem p, unsigned *__restrict__ keys,
+                                                           unsigned long long *__restrict__ vals) {
+  const long long n = (long long)p.N * p.K * p.HoWo;
+  const int HW = p.H * p.W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int hw = (int)(i % p.HoWo);
+    const int t = (int)((i / p.HoWo) % p.K);
+    const int b = (int)(i / ((long long)p.HoWo * p.K));
+    const int oy = hw / p.Wo, ox = hw - oy * p.Wo;
+    float y, x, m;
+    tap_position(p, b, 0, t, hw, oy, ox, y, x, m);
+    Tap tap;
+    TapGeom geo;
+    make_tap(y, x, p.H, p.W, true, 1.0f, tap, geo);
+    const int valid[4] = {geo.va, geo.vb, geo.vc, geo.vd};
+    const unsigned long long src = (unsigned long long)((unsigned)(t * p.HoWo + hw)) << 32;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      keys[i * 4 + e] = valid[e] ? (unsigned)(b * HW + tap.o[e]) : 0xffffffffu;
+      vals[i * 4 + e] = src | __float_as_uint(tap.w[e]);
+    }
+  }
+}
+
+// row_ptr[cell] = first sorted entry with key >= cell, cells 0 .. n_cells (inclusive)
+__global__ __launch_bounds__(256) void large_row_ptr(const unsigned *__restrict__ keys, long long n_entries, int n_cells,
+                                                     int *__restrict__ row_ptr) {
+  const int cell = blockIdx.x * 256 + threadIdx.x;
+  if (cell > n_cells) return;
+  long long lo = 0, hi = n_entries;
+  while (lo < hi) {
+    const long long mid = (lo + hi) >> 1;
+    if (keys[mid] < (unsigned)cell) lo = mid + 1; else hi = mid;
+  }
+  row_ptr[cell] = (int)lo;
+}
+
+// grad_input[b][c][q] = sum over the entries of cell (b, q), in sorted (= enumeration) order, of w * colT[b][p][t*C + c]
+// grid = (ceil(HW / 32), N, ceil(C / 256)), 256 threads = channels
+__global__ __launch_bounds__(256) void large_gather_input(const float *__restrict__ colT, const int *__restrict__ row_ptr,
+                                                          const unsigned long long *__restrict__ vals,
+                                                          float *__restrict__ grad_input, int C, int K, int HW, int P) {
+  __shared__ float tile[32][257];
+  const int q0 = blockIdx.x * 32, b = blockIdx.y, c = blockIdx.z * 256 + threadIdx.x;
+  const bool live = c < C;
+  const int cc = live ? c : 0;
+  const long long KC = (long long)K * C;
+  const float *base = colT + (long long)b * P * KC + cc;
+  for (int r = 0; r < 32; ++r) {
+    const int q = q0 + r;
+    float acc = 0.0f;
+    if (q < HW) {
+      const int e0 = row_ptr[b * HW + q], e1 = row_ptr[b * HW + q + 1];
+      int e = e0;
+      for (; e + 4 <= e1; e += 4) {   // four independent loads in flight; the adds keep the sorted order
+        float v[4], w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned long long val = vals[e + u];
+          const unsigned tp = (unsigned)(val >> 32);
+          const unsigned t = tp / (unsigned)P, px = tp - t * (unsigned)P;
+          w[u] = __uint_as_float((unsigned)val);
+          v[u] = base[(long long)px * KC + (long long)t * C];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += w[u] * v[u];
+      }
+      for (; e < e1; ++e) {
+        const unsigned long long val = vals[e];
+        const unsigned tp = (unsigned)(val >> 32);
+        const unsigned t = tp / (unsigned)P, px = tp - t * (unsigned)P;
+        acc += __uint_as_float((unsigned)val) * base[(long long)px * KC + (long long)t * C];
+      }
+    }
+    tile[r][threadIdx.x] = acc;
+  }
+  __syncthreads();
+  // [32 cells][256 channels] -> grad_input[b][c][q0 .. q0+31]: 8 lanes share a channel's run
+  const int lane_q = threadIdx.x & 31, ch_sub = threadIdx.x >> 5;  // 32 cells x 8 channels per pass
+  for (int c2 = ch_sub; c2 < 256; c2 += 8) {
+    const int ch = blockIdx.z * 256 + c2, q = q0 + lane_q;
+    if (ch < C && q < HW) grad_input[((long long)b * C + ch) * HW + q] = tile[lane_q][c2];
+  }
+}
+
+// grad_offset[b][2t + dir][p] = sum_c colT[b][p][t*C + c] * (sum_corner dw_dir[corner] * x^T[b][corner][c])
+// (deformable_col2im_coord + get_coordinate_weight, deform_conv_cuda_kernel.cu:144-187, 337-435; out of range -> 0)
+// grid = (P, N), 256 threads = channels (looped for C > 256); kMaxK taps accumulate in registers
+constexpr int kLargeMaxK = 49;
+__global__ __launch_bounds__(256) void large_grad_offset(const DcnProblem p, const float *__restrict__ colT,
+                                                         const float *__restrict__ xT, float *__restrict__ grad_offset) {
+  __shared__ float red[4][2];
+  const int hw = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int oy = hw / p.Wo, ox = hw - oy * p.Wo;
+  const int C = p.C_total, K = p.K, HW = p.H * p.W;
+  const long long KC = (long long)K * C;
+  const float *crow = colT + ((long long)b * p.HoWo + hw) * KC;
+  const float *ximg = xT + (long long)b * HW * C;
+  for (int t = 0; t < K; ++t) {
+    float y, x, m;
+    tap_position(p, b, 0, t, hw, oy, ox, y, x, m);
+    Tap tap;
+    TapGeom geo;
+    make_tap(y, x, p.H, p.W, true, 1.0f, tap, geo);
+    const float hy = 1.0f - geo.ly, hx = 1.0f - geo.lx;
+    const float ka = geo.va ? 1.f : 0.f, kb = geo.vb ? 1.f : 0.f, kc = geo.vc ? 1.f : 0.f, kd = geo.vd ? 1.f : 0.f;
+    const float wy[4] = {-hx * ka, -geo.lx * kb, hx * kc, geo.lx * kd};
+    const float wx[4] = {-hy * ka, hy * kb, -geo.ly * kc, geo.ly * kd};
+    float dy = 0.0f, dx = 0.0f;
+    for (int c = tid; c < C; c += 256) {
+      const float g = crow[(long long)t * C + c];
+      float sy = 0.0f, sx = 0.0f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = ximg[(long long)tap.o[e] * C + c];
+        sy += wy[e] * v;
+        sx += wx[e] * v;
+      }
+      dy += g * sy;
+      dx += g * sx;
+    }
+    // block reduction in a fixed order: lanes by shuffle, then the four waves in order
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      dy += __shfl_down(dy, d);
+      dx += __shfl_down(dx, d);
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { red[tid >> 6][0] = dy; red[tid >> 6][1] = dx; }
+    __syncthreads();
+    if (tid == 0) {
+      const float ty = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+      const float tx = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
+      float *dst = grad_offset + ((long long)b * 2 * K + 2 * t) * p.HoWo + hw;
+      dst[0] = ty;
+      dst[p.HoWo] = tx;
+    }
+  }
+}
+
+struct LargePlan {
+  size_t gT, xT, wp, colT, packed, conv_ws, keys, vals, cub, row_ptr, total;
+  long long n_entries;
+};
+
+LargePlan large_plan(const DcnProblem &p) {
+  LargePlan L;
+  const long long P = p.HoWo, HW = (long long)p.H * p.W, KC = (long long)p.K * p.C_total;
+  L.n_entries = (long long)p.N * p.K * P * 4;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  L.gT = al((size_t)p.N * P * p.Og * 4);
+  L.xT = al((size_t)p.N * HW * p.C_total * 4);
+  L.wp = al((size_t)p.Og * KC * 4);
+  L.colT = al((size_t)p.N * P * KC * 4);
+  L.packed = al(kgdet_conv_packed_bytes((int)P, p.Og, 1));
+  L.conv_ws = al(kgdet_conv_apply_workspace_bytes(1, (int)P, p.Og, 1, (int)KC, 1, 1));
+  L.keys = al((size_t)L.n_entries * 4);
+  L.vals = al((size_t)L.n_entries * 8);
+  size_t temp = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const unsigned *)nullptr, (unsigned *)nullptr,
+                                     (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                     (int)L.n_entries, 0, 32, (hipStream_t)0);
+  L.cub = al(temp);
+  L.row_ptr = al((size_t)(p.N * HW + 1) * 4);
+  L.total = L.gT + L.xT + L.wp + L.colT + L.packed + L.conv_ws + 2 * L.keys + 2 * L.vals + L.cub + L.row_ptr;
+  return L;
+}
+
+}  // namespace
+
+// eligible: v1 (no mask), one weight group, one deformable group, O % 16 == 0, entry count within int range
+bool dcn_bwd_large_ok(const DcnProblem &p, bool has_mask, int groups) {
+  const long long n_entries = (long long)p.N * p.K * p.HoWo * 4;
+  return !has_mask && groups == 1 && p.DG == 1 && p.Og % 16 == 0 && ((long long)p.K * p.C_total) % 2 == 0 &&
+         p.K <= kLargeMaxK && n_entries < (1LL << 31) && (long long)p.N * p.H * p.W < (1LL << 31) - 2 &&
+         (long long)p.K * p.HoWo < (1LL << 32);
+}
+
+size_t dcn_bwd_large_workspace_bytes(const DcnProblem &p) { return large_plan(p).total; }
+
+// p: the FORWARD problem (x, offset, wpk = the [K][Cg_pad][Og_pad] fp32 weight image, geometry; Og = O, C_total = C)
+int dcn_bwd_large(const DcnProblem &p, const float *grad_output, int out_channels_total,
+                  int out_channel_offset, float *grad_input, float *grad_offset, void *workspace, size_t workspace_bytes,
+                  void *stream) {
+  const LargePlan L = large_plan(p);
+  if (workspace == nullptr || workspace_bytes < L.total) {
+    set_error("workspace too small for the large-map backward: need %zu bytes, got %zu", L.total, workspace_bytes);
+    return KGDET_E_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  unsigned char *w8 = (unsigned char *)workspace;
+  float *gT = (float *)w8; w8 += L.gT;
+  float *xT = (float *)w8; w8 += L.xT;
+  float *wp = (float *)w8; w8 += L.wp;
+  float *colT = (float *)w8; w8 += L.colT;
+  void *packed = w8; w8 += L.packed;
+  void *conv_ws = w8; w8 += L.conv_ws;
+  unsigned *keys_a = (unsigned *)w8; w8 += L.keys;
+  unsigned *keys_b = (unsigned *)w8; w8 += L.keys;
+  unsigned long long *vals_a = (unsigned long long *)w8; w8 += L.vals;
+  unsigned long long *vals_b = (unsigned long long *)w8; w8 += L.vals;
+  void *cub_tmp = w8; w8 += L.cub;
+  int *row_ptr = (int *)w8;
+  const int C = p.C_total, O = p.Og, K = p.K;
+  const long long P = p.HoWo, HW = (long long)p.H * p.W, KC = (long long)K * C;
+  const int O_total = out_channels_total > 0 ? out_channels_total : O;
+
+  // grad_out window [N][O][P] (channels out_channel_offset.. of an O_total-wide buffer) -> gT [N][P][O]; x -> xT
+  hipLaunchKernelGGL(large_transpose, dim3((unsigned)((P + 31) / 32), (O + 31) / 32, p.N), dim3(256), 0, st,
+                     grad_output + (long long)out_channel_offset * P, gT, O, P, (long long)O_total * P);
+  hipLaunchKernelGGL(large_transpose, dim3((unsigned)((HW + 31) / 32), (C + 31) / 32, p.N), dim3(256), 0, st, p.x, xT, C,
+                     HW, (long long)C * HW);
+  hipLaunchKernelGGL(large_permute_weight, dim3(1024), dim3(256), 0, st, p.wpk, wp, O, C, K, p.Cg_pad, p.Og_pad);
+  // colT[b] = gT[b] (P x O) * wp (O x KC): the pixels are the "output channels" of a 1x1 convolution over the KC-pixel
+  // "image" wp
+  for (int b = 0; b < p.N; ++b) {
+    if (int rc = kgdet_conv_pack(gT + (long long)b * P * O, (int)P, O, 1, 0, packed, stream)) return rc;
+    if (int rc = kgdet_conv_apply_epilogue(packed, wp, colT + (long long)b * P * KC, nullptr, nullptr, 0, 1, (int)P, O, 1,
+                                           (int)KC, 1, 1, conv_ws, L.conv_ws, stream))
+      return rc;
+  }
+  // inverse index
+  hipLaunchKernelGGL(large_build_entries, dim3(2048), dim3(256), 0, st, p, keys_a, vals_a);
+  size_t temp = L.cub;
+  if (hipcub::DeviceRadixSort::SortPairs(cub_tmp, temp, keys_a, keys_b, vals_a, vals_b, (int)L.n_entries, 0, 32, st) !=
+      hipSuccess) {
+    set_error("hipcub radix sort failed");
+    return KGDET_E_HIP;
+  }
+  const int n_cells = (int)(p.N * HW);
+  hipLaunchKernelGGL(large_row_ptr, dim3((n_cells + 1 + 255) / 256), dim3(256), 0, st, keys_b, L.n_entries, n_cells,
+                     row_ptr);
+  hipLaunchKernelGGL(large_gather_input, dim3((unsigned)((HW + 31) / 32), p.N, (C + 255) / 256), dim3(256), 0, st, colT,
+                     row_ptr, vals_b, grad_input, C, K, (int)HW, (int)P);
+  hipLaunchKernelGGL(large_grad_offset, dim3((unsigned)P, p.N), dim3(256), 0, st, p, colT, xT, grad_offset);
+  KGDET_CHECK_LAUNCH("dcn_bwd_large");
+  return KGDET_OK;
+}
+
+}  // namespace kgdet

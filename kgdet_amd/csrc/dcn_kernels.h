@@ -13,6 +13,11 @@ __global__ void dcn_fwd_plane(const DcnFwdGroup grp, float *__restrict__ slabs);
 size_t dcn_fwd_plane_lds_bytes(int parts, int HW);
 size_t dcn_fwd_plane_fixed_lds_bytes(int parts);
 int dcn_fwd_plane_threads();
+// large-map v1 backward without atomics (dcn_backward_large.hip)
+bool dcn_bwd_large_ok(const DcnProblem &p, bool has_mask, int groups);
+size_t dcn_bwd_large_workspace_bytes(const DcnProblem &p);
+int dcn_bwd_large(const DcnProblem &p, const float *grad_output, int out_channels_total, int out_channel_offset,
+                  float *grad_input, float *grad_offset, void *workspace, size_t workspace_bytes, void *stream);
 __global__ void dcn_build_taps(const DcnFwdGroup grp);
 // grad_input on the plane kernel (dcn_backward_plane.hip)
 template <int PARTS>

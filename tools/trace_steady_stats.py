@@ -15,8 +15,11 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 last_find = max([i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('naive_conv')] or [-1])
 rows = rows[last_find + 1:]
 marks = [i for i, r in enumerate(rows) if marker in r['Kernel_Name']]
+if marker.startswith('~'):      # '~name': ONE dispatch of a kernel whose name contains `name` closes each step
+    marks = [i for i, r in enumerate(rows) if marker[1:] in r['Kernel_Name']]
+    per_step = int(sys.argv[3])
 steps = len(marks) // per_step - 1
-assert steps >= 1, 'not enough steady-state steps in the trace'
+assert steps >= 1, 'not enough steady-state steps in the trace (markers found: %d)' % len(marks)
 lo, hi = marks[len(marks) - 1 - steps * per_step], marks[-1]
 sel = rows[lo + 1:hi + 1]
 span = (int(rows[hi]['End_Timestamp']) - int(rows[lo]['End_Timestamp'])) / steps / 1e6
