@@ -167,8 +167,8 @@ bool mfma_ok(const kgdet_dcn_shape *s) {
 // plane forward kernel: a 16-channel slice of one input image must fit in LDS next to the operand stages
 constexpr int kPlaneMaxHW = 1536;
 bool plane_ok(const kgdet_dcn_shape *s, const Derived &d) {
-  const int cpdg = s->C / s->deformable_groups;  // a producer thread samples 8 channels with one tap record
-  return mfma_ok(s) && (s->deformable_groups == 1 || cpdg % 8 == 0) && s->H * s->W <= kPlaneMaxHW &&
+  const int cpdg = s->C / s->deformable_groups;  // a producer thread samples a 16-channel chunk with one tap record
+  return mfma_ok(s) && (s->deformable_groups == 1 || cpdg % 16 == 0) && s->H * s->W <= kPlaneMaxHW &&
          (size_t)8 * 33 * (d.K + 1) * sizeof(float) <= kMaxLds - 64 &&
          slab_slots_ok((long long)s->N * ceil_div(d.Ho * d.Wo, kTileN) * (d.Og_pad / kTileM), d.K * (d.Cg_pad / kChunk));
 }

@@ -32,7 +32,7 @@ constexpr int kBPart = 2 * kTileN * 8 * 2;
 constexpr int kProducers = 256;                          // 4 producer waves
 constexpr int kPlaneThreads = kThreads + kProducers;     // 8 consumer + 4 producer waves
 constexpr int kPlaneRounds = 6;                          // (pixel, quad) items a thread has in flight while copying a plane
-constexpr int kGroupTaps = 3;                            // stages (taps) between two workgroup barriers
+constexpr int kGroupTaps = 4;                            // stages (taps) between two workgroup barriers
 constexpr bool kAFromL2 = true;   // (grad_weight kernel) consumers take their A fragments from the operand image in L2
 
 // Ablation switches for experiment builds (make VARIANT=... EXTRA=-DKGDET_ABL_...; results are WRONG by design):
@@ -70,10 +70,10 @@ struct PlaneStageRegs {
 // instructions go -- loads are issued unconditionally from clamped addresses, so hipcc's counted
 // s_waitcnt vmcnt(N) stay exact.
 //
-// Stages are handed from the producers to the consumers in GROUPS of kGroupTaps = 3.  The B buffer in LDS holds two
-// groups: while the consumers multiply the three stages of group g (their weight fragments arrive from L2 two
-// stages ahead, in a two-deep register ring), the producers sample the three stages of group g + 1; the tap records
-// of a group are loaded one whole group before they are used (two sets of three).  ONE workgroup barrier per group.
+// Stages are handed from the producers to the consumers in GROUPS of kGroupTaps = 4.  The B buffer in LDS holds two
+// groups: while the consumers multiply the four stages of group g (their weight fragments arrive from L2 two
+// stages ahead, in a two-deep register ring), the producers sample the four stages of group g + 1 (each wave pair two of
+// them); the tap records of a group are loaded one whole group before they are used.  ONE workgroup barrier per group.
 // Why (phase trace of the one-barrier-per-stage version, tools/plane_trace.py: cycles per workgroup, 187 stages):
 // both roles did ~1200 cycles of work per stage and each waited ~300 more at the barrier -- for the slowest of the
 // twelve waves, a different one every stage (random-gather bank conflicts, issue arbitration); a group averages
@@ -97,7 +97,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
   // DISTINCT weight rows, 16 KB per stage and workgroup instead of 32 KB with 4 x 2 waves of 64 x 64 -- the vector
   // memory path of a CU takes 64 B per clock, and 32 KB of fragments per stage were 512 of its ~1000 cycles
   const int n_local = tid & (kTileN - 1);                     // producers: pixel column sampled
-  const int half = (tid >> 7) & 1;                            //            and which 8 of the chunk's 16 channels
+  const int pair = (tid >> 7) & 1;                            //            wave pair: samples stages pair, pair + 2 of a group
   const long long G = gridDim.x, g = blockIdx.x;
   const long long slice = sk_slice_of_block((int)g, (int)G);
   long long my_begin, my_end;
@@ -139,7 +139,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
     int t0 = s - c16 * K;
     while (s < s_end) {
       const int n = min(K - t0, s_end - s);  // stages of this segment: taps t0 .. t0+n-1 of chunk c16
-      const int dgi = p.DG == 1 ? 0 : (p.c_base + min(c16 * kChunk + half * 8, p.Cg - 1)) / p.cpdg;
+      const int dgi = p.DG == 1 ? 0 : (p.c_base + min(c16 * kChunk, p.Cg - 1)) / p.cpdg;   // (cpdg % 16 == 0)
       // records of (image, deformable group): [K][pixels][NG] groups of 32 B
       const uint4 *rec_base = reinterpret_cast<const uint4 *>(p.taps) +
                               (((size_t)(tile_b * p.DG + dgi) * K) * HoWo + hw_c) * (2 * NG);
@@ -208,12 +208,16 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
           }
         }
       };
-      // ---- B stage, producers: sample this thread's 8 channels of its pixel, split to bf16 hi / lo, store into slot
-      // `gi` of group buffer `buf`.  Corner offsets in the record are for quad 0; quad c of the same pixel is at
-      // offset ^ (c << 4).  Interpolation and hi/lo split work on channel PAIRS (v_pk_fma_f32 / v_pk_add_f32).
+      // ---- B stage, producers.  A group has four stages; producer wave pair w (2 waves = 128 pixels) samples stages
+      // w and w + 2 of it -- a thread does ALL 16 channels of its pixel for a stage, as two half-stages of 8 channels
+      // (one ds_read_b128 per corner and channel quad).  So a producer wave has TWO stage times for one stage of work
+      // and four independent half-stages to interleave: it is latency-bound (a lone wave per SIMD running dependent
+      // packed-fp32 chains: ~1100 cycles per stage even with the MFMA pipes idle), and with one stage per stage time it
+      // was the critical path of every stage (phase trace: 233 k of 261 k cycles).
+      // Corner offsets in the record are for quad 0; quad c of the same pixel is at offset ^ (c << 4).
       typedef float f32x2 __attribute__((ext_vector_type(2)));
       typedef f32x4 Corners[2][4];
-      auto corner_reads = [&](const Regs &R, int gq, Corners &v) {
+      auto corner_reads = [&](const Regs &R, int gq, int half, Corners &v) {
         const unsigned o[4] = {R.off[gq].x, R.off[gq].y, R.off[gq].z, R.off[gq].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -233,7 +237,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
               sv[c][h2] = (first && e == 0) ? we * ve : __builtin_elementwise_fma(we, ve, sv[c][h2]);
             }
       };
-      auto split_store = [&](int buf, int gi, const f32x2 (&sv)[2][2]) {
+      auto split_store = [&](int buf, int gi, int half, const f32x2 (&sv)[2][2]) {
         bf16x8 hi, lo;
 #pragma unroll
         for (int c = 0; c < 2; ++c)
@@ -253,12 +257,12 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         *reinterpret_cast<bf16x8 *>(dst) = hi;
         if constexpr (PARTS == 2) *reinterpret_cast<bf16x8 *>(dst + kBPart) = lo;
       };
-      // MODE 1 (and the unpipelined path): everything of one stage in sequence
-      auto sample = [&](int buf, int gi, const Regs &R) {
+      // MODE 1 (and the unpipelined path): one half-stage in sequence
+      auto sample_half = [&](int buf, int gi, int half, const Regs &R) {
 #ifdef KGDET_ABL_NOSAMPLE
         {
           f32x2 z[2][2] = {{{R.w[0][0], R.w[0][1]}, {R.w[0][2], R.w[0][3]}}, {{R.w[0][0], R.w[0][1]}, {R.w[0][2], R.w[0][3]}}};
-          split_store(buf, gi, z);
+          split_store(buf, gi, half, z);
           return;
         }
 #endif
@@ -266,7 +270,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
 #pragma unroll
         for (int gq = 0; gq < NG; ++gq) {
           Corners v;
-          corner_reads(R, gq, v);
+          corner_reads(R, gq, half, v);
           corner_fma(R, gq, v, sv, gq == 0);
         }
         if constexpr (MODE == 1) {
@@ -287,32 +291,36 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
             }
           }
         }
-        split_store(buf, gi, sv);
+        split_store(buf, gi, half, sv);
       };
-      // the three stages jg .. jg+2 of a group from the record set (RA, RB, RC) into group buffer `buf`.  MODE 0: the
-      // corner reads of a stage are issued before the arithmetic of the stage before (two corner register sets).
-      auto sample_group = [&](int jg, int buf, const Regs &RA, const Regs &RB, const Regs &RC) {
+      // this wave pair's two stages of the group that starts at stage jg (stages jg + pair from record RA, jg + pair + 2
+      // from RB) into group buffer `buf`.  MODE 0: four half-stages, the corner reads of one issued before the
+      // arithmetic of the one before (two corner register sets).
+      auto sample_group = [&](int jg, int buf, const Regs &RA, const Regs &RB) {
 #ifdef KGDET_ABL_NOSAMPLE
         constexpr bool pipelined = false;
 #else
         constexpr bool pipelined = MODE == 0;
 #endif
+        const bool a_live = jg + pair < n, b_live = jg + pair + 2 < n;
         if constexpr (pipelined) {
           Corners V0, V1;
           f32x2 sv[2][2];
-          corner_reads(RA, 0, V0);
-          corner_reads(RB, 0, V1);     // (clamped records past the end of the segment: harmless reads)
+          corner_reads(RA, 0, 0, V0);
+          corner_reads(RA, 0, 1, V1);   // (clamped records past the end of the segment: harmless reads)
           corner_fma(RA, 0, V0, sv, true);
-          if (jg < n) split_store(buf, 0, sv);
-          corner_reads(RC, 0, V0);
+          if (a_live) split_store(buf, pair, 0, sv);
+          corner_reads(RB, 0, 0, V0);
+          corner_fma(RA, 0, V1, sv, true);
+          if (a_live) split_store(buf, pair, 1, sv);
+          corner_reads(RB, 0, 1, V1);
+          corner_fma(RB, 0, V0, sv, true);
+          if (b_live) split_store(buf, pair + 2, 0, sv);
           corner_fma(RB, 0, V1, sv, true);
-          if (jg + 1 < n) split_store(buf, 1, sv);
-          corner_fma(RC, 0, V0, sv, true);
-          if (jg + 2 < n) split_store(buf, 2, sv);
+          if (b_live) split_store(buf, pair + 2, 1, sv);
         } else {
-          if (jg < n) sample(buf, 0, RA);
-          if (jg + 1 < n) sample(buf, 1, RB);
-          if (jg + 2 < n) sample(buf, 2, RC);
+          if (a_live) { sample_half(buf, pair, 0, RA); sample_half(buf, pair, 1, RA); }
+          if (b_live) { sample_half(buf, pair + 2, 0, RB); sample_half(buf, pair + 2, 1, RB); }
         }
       };
       // ---- consumers: stage `gi` of group buffer `buf` times the fragment set F
@@ -342,8 +350,9 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         }
       };
 
-      // prologue: register pipelines primed, plane in LDS, group 0 (stages 0..2) in group buffer 0
-      Regs RA0, RA1, RA2, RB0, RB1, RB2;   // producers: the records of two groups (set A: even groups, set B: odd groups)
+      // prologue: register pipelines primed, plane in LDS, group 0 (stages 0..3) in group buffer 0
+      Regs S0, S1, T0, T1;   // producers: this wave pair's two records of the group sampled next (S) and of the one
+                             // after it (T, loaded at the TOP of a group, moved into S at its bottom: a whole group to land)
       AFrag F0, F1;      // consumers: weight fragments two stages ahead (stage t uses F[t & 1]); a third set spills
 #ifdef KGDET_PLANE_TRACE
       tr_t = KGDET_TR_NOW();
@@ -352,8 +361,8 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       __syncthreads();   // the previous segment's readers of plane / B are done
       KGDET_TR_ADD(0, tr_t);
       if constexpr (PRODUCER) {
-        issue(0, RA0); issue(1, RA1); issue(2, RA2);
-        issue(3, RB0); issue(4, RB1); issue(5, RB2);
+        issue(pair, S0); issue(pair + 2, S1);
+        issue(kGroupTaps + pair, T0); issue(kGroupTaps + pair + 2, T1);
       } else {
         a_issue(0, F0);
         a_issue(1, F1);
@@ -363,35 +372,37 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       __syncthreads();
       KGDET_TR_ADD(2, tr_t);
       if constexpr (PRODUCER) {
-        sample_group(0, 0, RA0, RA1, RA2);
-        issue(6, RA0); issue(7, RA1); issue(8, RA2);
+        sample_group(0, 0, S0, S1);
+        S0 = T0; S1 = T1;
       }
       __syncthreads();
       KGDET_TR_ADD(3, tr_t);
-      // group at stage jg (a multiple of 3) in buffer BUF.  Consumers: multiply stages jg..jg+2 (fragment sets FA, FB,
-      // FA), re-loading each set with the stage two ahead.  Producers: sample stages jg+3..jg+5 from the other
-      // record set into the other buffer, then re-load that record set with the stages of the group after next.
-      auto group = [&](int jg, auto BUF, AFrag &FA, AFrag &FB, Regs &S0, Regs &S1, Regs &S2) {
+      // group at stage jg (a multiple of 4) in buffer BUF.  Consumers: multiply stages jg..jg+3 (fragment sets F0, F1,
+      // F0, F1), re-loading each set with the stage two ahead.  Producers: sample their two stages of the NEXT group
+      // from the other record set into the other buffer, then re-load that set for the group after next.
+      auto group = [&](int jg, auto BUF) {
         constexpr int buf = decltype(BUF)::value;
         if constexpr (PRODUCER) {
-          sample_group(jg + 3, buf ^ 1, S0, S1, S2);
-          issue(jg + 9, S0); issue(jg + 10, S1); issue(jg + 11, S2);
+          issue(jg + 2 * kGroupTaps + pair, T0); issue(jg + 2 * kGroupTaps + pair + 2, T1);
+          sample_group(jg + kGroupTaps, buf ^ 1, S0, S1);
+          S0 = T0; S1 = T1;
         } else {
-          multiply(buf, 0, FA);
-          a_issue(jg + 2, FA);
-          if (jg + 1 < n) multiply(buf, 1, FB);
-          a_issue(jg + 3, FB);
-          if (jg + 2 < n) multiply(buf, 2, FA);
-          a_issue(jg + 4, FA);
+          multiply(buf, 0, F0);
+          a_issue(jg + 2, F0);
+          if (jg + 1 < n) multiply(buf, 1, F1);
+          a_issue(jg + 3, F1);
+          if (jg + 2 < n) multiply(buf, 2, F0);
+          a_issue(jg + 4, F0);
+          if (jg + 3 < n) multiply(buf, 3, F1);
+          a_issue(jg + 5, F1);
         }
         KGDET_TR_ADD(4, tr_t);
         __syncthreads();
         KGDET_TR_ADD(5, tr_t);
       };
       for (int jg = 0; jg < n; jg += 2 * kGroupTaps) {
-        // even group in buffer 0: its successor (odd) is sampled from record set B
-        group(jg, std::integral_constant<int, 0>{}, F0, F1, RB0, RB1, RB2);
-        if (jg + kGroupTaps < n) group(jg + kGroupTaps, std::integral_constant<int, 1>{}, F1, F0, RA0, RA1, RA2);
+        group(jg, std::integral_constant<int, 0>{});
+        if (jg + kGroupTaps < n) group(jg + kGroupTaps, std::integral_constant<int, 1>{});
       }
       s += n;
       ++c16;
