@@ -19,7 +19,11 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 //   3 prologue sample + third barrier, 4 group work (top of group .. before barrier), 5 group barrier wait,
 //   6 epilogue (slab / output store), 7 whole kernel, 8 stages, 9 segments
 static __device__ unsigned long long g_plane_trace[256 * 2 * 10];   // one copy per translation unit
+#ifdef KGDET_PLANE_TRACE_REALTIME   // the constant 100 MHz counter instead of the core clock: cycles / ticks = the clock the kernel ran at
+#define KGDET_TR_NOW() __builtin_amdgcn_s_memrealtime()
+#else
 #define KGDET_TR_NOW() __builtin_amdgcn_s_memtime()
+#endif
 #define KGDET_TR_ADD(cat, t_from) do { const unsigned long long n__ = KGDET_TR_NOW(); tr[cat] += n__ - (t_from); (t_from) = n__; } while (0)
 #else
 #define KGDET_TR_ADD(cat, t_from) do { } while (0)
@@ -39,6 +43,8 @@ constexpr bool kAFromL2 = true;   // (grad_weight kernel) consumers take their A
 //   KGDET_ABL_NOSAMPLE  producers skip the corner reads and the interpolation (B stage = garbage): consumer-bound time
 //   KGDET_ABL_NOMFMA    consumers skip the B-fragment reads and the MFMAs: producer-bound time
 //   KGDET_ABL_NOALOAD   consumers do not load their weight fragments (one load in the prologue): L2 / fabric share
+//   KGDET_ABL_NOGATHER  producers interpolate register values instead of LDS corner reads: the gathers' share
+//   KGDET_ABL_NOBSTORE  producers compute the split B stage but do not store it: the LDS stores' share
 #ifndef KGDET_PLANE_PRODUCER_PRIO
 #define KGDET_PLANE_PRODUCER_PRIO 2
 #endif
@@ -223,7 +229,11 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int c = 0; c < 2; ++c)
+#ifdef KGDET_ABL_NOGATHER
+            v[c][e] = f32x4{__uint_as_float(o[e]), R.w[gq][c], R.w[gq][e], (float)half};
+#else
             v[c][e] = *reinterpret_cast<const f32x4 *>(plane + (o[e] ^ (unsigned)((half * 2 + c) << 4)));
+#endif
       };
       auto corner_fma = [&](const Regs &R, int gq, const Corners &v, f32x2 (&sv)[2][2], bool first) {
 #pragma unroll
@@ -254,6 +264,9 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
             }
           }
         unsigned char *dst = Bs + (buf * kGroupTaps + gi) * PARTS * kBPart + half * (kTileN * 16) + n_local * 16;
+#ifdef KGDET_ABL_NOBSTORE
+        if (sv[0][0][0] != 1234.56789f) return;
+#endif
         *reinterpret_cast<bf16x8 *>(dst) = hi;
         if constexpr (PARTS == 2) *reinterpret_cast<bf16x8 *>(dst + kBPart) = lo;
       };

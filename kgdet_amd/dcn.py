@@ -179,14 +179,13 @@ def pack_weight(weight, shape):
     reuses the images of an unchanged tensor -- same live object, storage and ``_version``; the cache is dropped
     whenever a DeformConv module changes mode (``model.train()`` / ``model.eval()``) and by clear_pack_cache()."""
     cacheable = _inference_depth > 0
-    key = (weight.data_ptr(), weight._version, shape.groups, shape.deformable_groups, tuple(weight.shape),
-           shape.H * shape.W <= 1536)
+    L = _lib.lib()
+    nbytes = L.kgdet_dcn_packed_weight_bytes(ctypes.byref(shape))   # (which images exist depends on the map size)
+    key = (weight.data_ptr(), weight._version, shape.groups, shape.deformable_groups, tuple(weight.shape), nbytes)
     if cacheable:
         hit = _pack_cache.get(id(weight))
         if hit is not None and hit[0]() is weight and hit[1] == key:
             return hit[2]
-    L = _lib.lib()
-    nbytes = L.kgdet_dcn_packed_weight_bytes(ctypes.byref(shape))
     packed = torch.empty(nbytes // 4, dtype=torch.float32, device=weight.device)
     _lib.check(L.kgdet_dcn_pack_weight(ctypes.byref(shape), _lib.ptr(weight), _lib.ptr(packed),
                                        _lib.current_stream()), 'kgdet_dcn_pack_weight')

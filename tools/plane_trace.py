@@ -1,4 +1,4 @@
-"""phase breakdown of the plane forward kernel from the trace build (make VARIANT=trace EXTRA='-DKGDET_PLANE_TRACE -fgpu-rdc'):
+"""phase breakdown of the plane forward kernel from the trace build (make VARIANT=trace EXTRA=-DKGDET_PLANE_TRACE):
 KGDET_LIB=kgdet_amd/libkgdet_hip_trace.so python tools/plane_trace.py [B] [prec]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
