@@ -143,27 +143,74 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
     int s = s_begin;
     int c16 = s / K;
     int t0 = s - c16 * K;
+    const int tile_in_img = nt - tile_b * p.tiles_per_image;
+    // records of (image, deformable group) for channel chunk c: [K][pixels][NG] groups of 32 B
+    auto seg_records = [&](int c) {
+      const int dgi = p.DG == 1 ? 0 : (p.c_base + min(c * kChunk, p.Cg - 1)) / p.cpdg;   // (cpdg % 16 == 0)
+      return reinterpret_cast<const uint4 *>(p.taps) + (((size_t)(tile_b * p.DG + dgi) * K) * HoWo + hw_c) * (2 * NG);
+    };
+    // loads of stage min(j, lim) of the segment (first tap tf) whose records start at rb: the tap record
+    auto issue = [&](const uint4 *rb, int tf, int lim, int j, Regs &R) {
+      const unsigned t = (unsigned)(tf + min(j, lim));
+      const uint4 *rec = rb + (size_t)t * HoWo * (2 * NG);
+#pragma unroll
+      for (int gq = 0; gq < NG; ++gq) {
+        R.off[gq] = rec[gq];
+        R.w[gq] = *reinterpret_cast<const f32x4 *>(rec + NG + gq);
+      }
+      if constexpr (MODE == 1) {
+        const DcnInvOvfSlots *sl = p.inv_ovf + ((size_t)(tile_b * K + t) * p.tiles_per_image + tile_in_img);
+        R.ovf = *reinterpret_cast<const int2 *>(sl);   // (count, spill_start)
+      }
+    };
+    // Copy x[tile_b, c_base + 16*c .. +15, :, :] into LDS as [pixel][16 channels] (64 B rows), by NT threads of which
+    // this one is number `me`.  The four 16-byte channel quads of pixel q sit at slot (quad ^ ((q >> 2) & 3)): with the
+    // row start (q & 3) * 16 banks this spreads any 16 consecutive pixels of one quad over all 16 four-bank groups
+    // (ds_read_b128 / ds_write_b128 serve 16 / 8 lanes per LDS cycle) instead of the 4 groups of a plain row-major
+    // image.  A thread moves (pixel, quad) items: 4 coalesced dword loads (one per channel plane) -> one 16-byte
+    // LDS store.  All loads are issued before the first store, unconditionally from clamped addresses
+    // (a guarded load makes hipcc branch and drain the queue).
+    auto load_plane = [&](int c, int me, auto NT_) {
+      constexpr int NT = decltype(NT_)::value;
+      const int c0 = c * kChunk;
+      const float *xb = p.x + ((long long)tile_b * p.C_total + p.c_base) * HW;
+      const int items = 4 * HW;  // (pixel, quad) pairs
+      for (int i0 = 0; i0 < items; i0 += kPlaneRounds * NT) {
+        f32x4 v[kPlaneRounds];
+#pragma unroll
+        for (int r = 0; r < kPlaneRounds; ++r) {
+          const int i = min(i0 + r * NT + me, items - 1);
+          const int q = i % HW, quad = i / HW;  // consecutive threads -> consecutive pixels
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int ch = min(c0 + quad * 4 + e, p.Cg - 1);  // padded channels re-read the last real one
+            v[r][e] = xb[(long long)ch * HW + q];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < kPlaneRounds; ++r) {
+          const int i = i0 + r * NT + me;
+          if (i < items) {
+            const int q = i % HW, quad = i / HW;
+            *reinterpret_cast<f32x4 *>(plane + dcn_plane_offset(q) + ((quad ^ ((q >> 2) & 3)) << 4)) = v[r];
+          }
+        }
+      }
+    };
+    Regs S0, S1, T0, T1;   // producers: this wave pair's two records of the group sampled next (S) and of the one
+                           // after it (T, loaded at the TOP of a group, moved into S at its bottom: a whole group to land)
+    bool primed = false;   // the segment's plane and first records were loaded under the last group of the one before
     while (s < s_end) {
       const int n = min(K - t0, s_end - s);  // stages of this segment: taps t0 .. t0+n-1 of chunk c16
-      const int dgi = p.DG == 1 ? 0 : (p.c_base + min(c16 * kChunk, p.Cg - 1)) / p.cpdg;   // (cpdg % 16 == 0)
-      // records of (image, deformable group): [K][pixels][NG] groups of 32 B
-      const uint4 *rec_base = reinterpret_cast<const uint4 *>(p.taps) +
-                              (((size_t)(tile_b * p.DG + dgi) * K) * HoWo + hw_c) * (2 * NG);
-      const int tile_in_img = nt - tile_b * p.tiles_per_image;
+      // Groups of the segment: a FIRST group of r = 1..4 stages (n - r is a multiple of 4), then full groups.  The
+      // consumers have nothing to multiply while the first group is sampled, so it is the short one (r = 1 for the
+      // 9 / 25 / 49 taps of 3x3 / 5x5 / 7x7), and the LAST group is a full one: the plane is not read any more once its
+      // stages are sampled, and the producers copy the next segment's plane under its four stages of MFMAs.
+      const int r = ((n - 1) & 3) + 1;
+      const int n_groups = 1 + (n - r) / kGroupTaps;
+      const bool has_next = s + n < s_end;
+      const uint4 *rec_base = seg_records(c16);
 
-      auto issue = [&](int j, Regs &R) {  // loads of stage j (clamped): the tap record
-        const unsigned t = (unsigned)(t0 + min(j, n - 1));
-        const uint4 *rec = rec_base + (size_t)t * HoWo * (2 * NG);
-#pragma unroll
-        for (int gq = 0; gq < NG; ++gq) {
-          R.off[gq] = rec[gq];
-          R.w[gq] = *reinterpret_cast<const f32x4 *>(rec + NG + gq);
-        }
-        if constexpr (MODE == 1) {
-          const DcnInvOvfSlots *sl = p.inv_ovf + ((size_t)(tile_b * K + t) * p.tiles_per_image + tile_in_img);
-          R.ovf = *reinterpret_cast<const int2 *>(sl);   // (count, spill_start)
-        }
-      };
       // consumers: the wave's A (weight) fragments of stage j straight from the weight image (L2), 16 bytes per lane
       // and fragment, coalesced
       struct AFrag {
@@ -180,39 +227,6 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         const unsigned char *b = wq_cons + (size_t)t * (2 * kAPart);
 #pragma unroll
         for (int part = 0; part < PARTS; ++part) F.a[part] = *reinterpret_cast<const bf16x8 *>(b + part * kAPart);
-      };
-      // Copy x[tile_b, c_base + 16*c16 .. +15, :, :] into LDS as [pixel][16 channels] (64 B rows).  The four
-      // 16-byte channel quads of pixel q sit at slot (quad ^ ((q >> 2) & 3)): with the row start (q & 3) * 16
-      // banks this spreads any 16 consecutive pixels of one quad over all 16 four-bank groups (ds_read_b128 /
-      // ds_write_b128 serve 16 / 8 lanes per LDS cycle) instead of the 4 groups of a plain row-major image.
-      // A thread moves (pixel, quad) items: 4 coalesced dword loads (one per channel plane) -> one 16-byte
-      // LDS store.  All loads are issued before the first store, unconditionally from clamped addresses
-      // (a guarded load makes hipcc branch and drain the queue).
-      auto load_plane = [&]() {
-        const int c0 = c16 * kChunk;
-        const float *xb = p.x + ((long long)tile_b * p.C_total + p.c_base) * HW;
-        const int items = 4 * HW;  // (pixel, quad) pairs
-        for (int i0 = 0; i0 < items; i0 += kPlaneRounds * kPlaneThreads) {
-          f32x4 v[kPlaneRounds];
-#pragma unroll
-          for (int r = 0; r < kPlaneRounds; ++r) {
-            const int i = min(i0 + r * kPlaneThreads + wtid, items - 1);
-            const int q = i % HW, quad = i / HW;  // consecutive threads -> consecutive pixels
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int ch = min(c0 + quad * 4 + e, p.Cg - 1);  // padded channels re-read the last real one
-              v[r][e] = xb[(long long)ch * HW + q];
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < kPlaneRounds; ++r) {
-            const int i = i0 + r * kPlaneThreads + wtid;
-            if (i < items) {
-              const int q = i % HW, quad = i / HW;
-              *reinterpret_cast<f32x4 *>(plane + dcn_plane_offset(q) + ((quad ^ ((q >> 2) & 3)) << 4)) = v[r];
-            }
-          }
-        }
       };
       // ---- B stage, producers.  A group has four stages; producer wave pair w (2 waves = 128 pixels) samples stages
       // w and w + 2 of it -- a thread does ALL 16 channels of its pixel for a stage, as two half-stages of 8 channels
@@ -306,16 +320,36 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         }
         split_store(buf, gi, half, sv);
       };
-      // this wave pair's two stages of the group that starts at stage jg (stages jg + pair from record RA, jg + pair + 2
-      // from RB) into group buffer `buf`.  MODE 0: four half-stages, the corner reads of one issued before the
+      // this wave pair's two stages of a group (stage pair of the group from record RA, pair + 2 from RB) into group
+      // buffer `buf`.  MODE 0: four half-stages, the corner reads of one issued before the
       // arithmetic of the one before (two corner register sets).
-      auto sample_group = [&](int jg, int buf, const Regs &RA, const Regs &RB) {
+      auto sample_group = [&](int buf, const Regs &RA, const Regs &RB, bool a_live, bool b_live) {
 #ifdef KGDET_ABL_NOSAMPLE
         constexpr bool pipelined = false;
 #else
         constexpr bool pipelined = MODE == 0;
 #endif
-        const bool a_live = jg + pair < n, b_live = jg + pair + 2 < n;
+#ifdef KGDET_PLANE_TRACE_PRODUCER   // unpipelined, timed: slot 0 = issue of 8 corner reads -> data there, slot 6 = the rest
+        if constexpr (pipelined) {
+          auto probe = [&](int gi, int half, const Regs &R, bool live) {
+            Corners V;
+            f32x2 sv[2][2];
+            const unsigned long long ta = KGDET_TR_NOW();
+            corner_reads(R, 0, half, V);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            const unsigned long long tb = KGDET_TR_NOW();
+            corner_fma(R, 0, V, sv, true);
+            if (live) split_store(buf, gi, half, sv);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            const unsigned long long tc = KGDET_TR_NOW();
+            tr[0] += tb - ta;
+            tr[6] += tc - tb;
+          };
+          probe(pair, 0, RA, a_live); probe(pair, 1, RA, a_live);
+          probe(pair + 2, 0, RB, b_live); probe(pair + 2, 1, RB, b_live);
+          return;
+        }
+#endif
         if constexpr (pipelined) {
           Corners V0, V1;
           f32x2 sv[2][2];
@@ -363,60 +397,93 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         }
       };
 
-      // prologue: register pipelines primed, plane in LDS, group 0 (stages 0..3) in group buffer 0
-      Regs S0, S1, T0, T1;   // producers: this wave pair's two records of the group sampled next (S) and of the one
-                             // after it (T, loaded at the TOP of a group, moved into S at its bottom: a whole group to land)
-      AFrag F0, F1;      // consumers: weight fragments two stages ahead (stage t uses F[t & 1]); a third set spills
+      AFrag F0, F1, FX;  // consumers: weight fragments two stages ahead, alternating (a third set in the loop spills);
+                         // FX: stage 0 of an odd first group
 #ifdef KGDET_PLANE_TRACE
       tr_t = KGDET_TR_NOW();
       tr[9] += 1; tr[8] += n;
 #endif
-      __syncthreads();   // the previous segment's readers of plane / B are done
-      KGDET_TR_ADD(0, tr_t);
-      if constexpr (PRODUCER) {
-        issue(pair, S0); issue(pair + 2, S1);
-        issue(kGroupTaps + pair, T0); issue(kGroupTaps + pair + 2, T1);
-      } else {
-        a_issue(0, F0);
-        a_issue(1, F1);
+      // (every group ends with a workgroup barrier: the previous segment's -- or range's -- readers of B and of the plane
+      // are done)
+      if (!primed) {   // first segment of the range: records, then the plane copy by all twelve waves
+        if constexpr (PRODUCER) {
+          issue(rec_base, t0, r - 1, pair, S0); issue(rec_base, t0, r - 1, pair + 2, S1);
+          issue(rec_base, t0, n - 1, r + pair, T0); issue(rec_base, t0, n - 1, r + pair + 2, T1);
+        }
+        load_plane(c16, wtid, std::integral_constant<int, kPlaneThreads>{});
+        KGDET_TR_ADD(1, tr_t);
+        __syncthreads();
+        KGDET_TR_ADD(2, tr_t);
       }
-      load_plane();
-      KGDET_TR_ADD(1, tr_t);
-      __syncthreads();
-      KGDET_TR_ADD(2, tr_t);
+      // first group (buffer 0).  One stage: each wave pair samples one 8-channel half of it (both hold its record)
       if constexpr (PRODUCER) {
-        sample_group(0, 0, S0, S1);
+        if (r == 1) sample_half(0, 0, pair, S0);
+        else sample_group(0, S0, S1, pair < r, pair + 2 < r);
         S0 = T0; S1 = T1;
+      } else {   // full groups find their stages in F0, F1, F0, F1: an odd first group takes its stage 0 from FX
+        if (r & 1) { a_issue(0, FX); a_issue(1, F0); a_issue(2, F1); }
+        else { a_issue(0, F0); a_issue(1, F1); }
       }
       __syncthreads();
       KGDET_TR_ADD(3, tr_t);
-      // group at stage jg (a multiple of 4) in buffer BUF.  Consumers: multiply stages jg..jg+3 (fragment sets F0, F1,
-      // F0, F1), re-loading each set with the stage two ahead.  Producers: sample their two stages of the NEXT group
-      // from the other record set into the other buffer, then re-load that set for the group after next.
-      auto group = [&](int jg, auto BUF) {
+      // producers, while the consumers multiply group gi: sample group gi + 1 into the other buffer from S (and load
+      // the records of group gi + 2 into T); under the last group, the next segment's records and plane instead
+      auto produce = [&](int gi, int buf_next) {
+        if (gi + 1 < n_groups) {
+          const int jn = r + (gi + 1) * kGroupTaps;   // first stage of group gi + 2
+          issue(rec_base, t0, n - 1, jn + pair, T0); issue(rec_base, t0, n - 1, jn + pair + 2, T1);
+          sample_group(buf_next, S0, S1, true, true);
+          S0 = T0; S1 = T1;
+        } else if (has_next) {
+          const int n2 = min(K, s_end - (s + n)), r2 = ((n2 - 1) & 3) + 1;
+          const uint4 *rb2 = seg_records(c16 + 1);
+          issue(rb2, 0, r2 - 1, pair, S0); issue(rb2, 0, r2 - 1, pair + 2, S1);
+          issue(rb2, 0, n2 - 1, r2 + pair, T0); issue(rb2, 0, n2 - 1, r2 + pair + 2, T1);
+          load_plane(c16 + 1, tid, std::integral_constant<int, kProducers>{});
+        }
+      };
+      // group 0
+      if constexpr (PRODUCER) {
+        produce(0, 1);
+      } else {
+        const int o = r & 1;   // (one-sided conditionals only: MFMAs on both sides of a branch make hipcc copy accumulators)
+        if (o) multiply(0, 0, FX);
+        if (r - o >= 2) { multiply(0, o, F0); a_issue(o + 2, F0); multiply(0, o + 1, F1); a_issue(o + 3, F1); }
+        if (r - o >= 4) { multiply(0, o + 2, F0); a_issue(o + 4, F0); multiply(0, o + 3, F1); a_issue(o + 5, F1); }
+      }
+      KGDET_TR_ADD(4, tr_t);
+      __syncthreads();
+      KGDET_TR_ADD(5, tr_t);
+      // full group gi >= 1 (stages jg .. jg + 3) in buffer BUF.  Consumers: fragment sets F0, F1, F0, F1, each re-loaded
+      // with the stage two ahead.
+      auto group = [&](int gi, auto BUF) {
         constexpr int buf = decltype(BUF)::value;
         if constexpr (PRODUCER) {
-          issue(jg + 2 * kGroupTaps + pair, T0); issue(jg + 2 * kGroupTaps + pair + 2, T1);
-          sample_group(jg + kGroupTaps, buf ^ 1, S0, S1);
-          S0 = T0; S1 = T1;
+          produce(gi, buf ^ 1);
         } else {
+          const int jg = r + (gi - 1) * kGroupTaps;
+          // (one scheduling region per stage: across all four, hipcc hoists the B reads of later stages and spills)
           multiply(buf, 0, F0);
           a_issue(jg + 2, F0);
-          if (jg + 1 < n) multiply(buf, 1, F1);
+          __builtin_amdgcn_sched_barrier(0);
+          multiply(buf, 1, F1);
           a_issue(jg + 3, F1);
-          if (jg + 2 < n) multiply(buf, 2, F0);
+          __builtin_amdgcn_sched_barrier(0);
+          multiply(buf, 2, F0);
           a_issue(jg + 4, F0);
-          if (jg + 3 < n) multiply(buf, 3, F1);
+          __builtin_amdgcn_sched_barrier(0);
+          multiply(buf, 3, F1);
           a_issue(jg + 5, F1);
         }
         KGDET_TR_ADD(4, tr_t);
         __syncthreads();
         KGDET_TR_ADD(5, tr_t);
       };
-      for (int jg = 0; jg < n; jg += 2 * kGroupTaps) {
-        group(jg, std::integral_constant<int, 0>{});
-        if (jg + kGroupTaps < n) group(jg + kGroupTaps, std::integral_constant<int, 1>{});
+      for (int gi = 1; gi < n_groups; gi += 2) {
+        group(gi, std::integral_constant<int, 1>{});
+        if (gi + 1 < n_groups) group(gi + 1, std::integral_constant<int, 0>{});
       }
+      primed = has_next;
       s += n;
       ++c16;
       t0 = 0;
