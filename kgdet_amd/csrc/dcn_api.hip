@@ -903,7 +903,7 @@ int kgdet_deform_conv_grad_weight_grouped(int32_t n, const kgdet_dcn_shape *cons
     return KGDET_E_UNSUPPORTED;
   }
   hipLaunchKernelGGL(dcn_build_taps, dim3(2 * G, grp.n), dim3(256), 0, (hipStream_t)stream, grp);
-  hipLaunchKernelGGL(dcn_bwd_weight_plane<2>, dim3(G), dim3(dcn_fwd_plane_threads()), lds, (hipStream_t)stream, grp,
+  hipLaunchKernelGGL(dcn_bwd_weight_plane<2>, dim3(G), dim3(dcn_bwd_weight_plane_threads()), lds, (hipStream_t)stream, grp,
                      (float *)workspace);
   hipLaunchKernelGGL(dcn_bwd_weight_plane_fixup, dim3(grp.tile_begin[grp.n], 16), dim3(kThreads), 0, (hipStream_t)stream,
                      grp, (const float *)workspace, G);

@@ -17,15 +17,25 @@
 // split MFMA, stream-K with the forward's fix-up.  No atomics, deterministic, no pre-zeroing of grad_input.
 // Deformable groups > 1 (different cells lists per channel group inside one M tile) stay on the older kernels.
 #include "dcn_plane.h"
+#ifdef KGDET_PLANE_PHASED   // experiment build: the phased body (dcn_plane_phased.h) instead of producer / consumer waves
+#include "dcn_plane_phased.h"
+#endif
 
 namespace kgdet {
 
 template <int PARTS>
+#ifdef KGDET_PLANE_PHASED
+__global__ __launch_bounds__(kPhThreads, 1) void dcn_bwd_input_plane(const DcnFwdGroup grp, float *__restrict__ slabs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  plane_phased<PARTS, 1>(grp, slabs, smem);
+}
+#else
 __global__ __launch_bounds__(kPlaneThreads, 1) void dcn_bwd_input_plane(const DcnFwdGroup grp, float *__restrict__ slabs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (threadIdx.x >= kThreads) plane_role<PARTS, true, 1>(grp, slabs, smem);
   else plane_role<PARTS, false, 1>(grp, slabs, smem);
 }
+#endif
 
 template __global__ void dcn_bwd_input_plane<1>(const DcnFwdGroup grp, float *__restrict__ slabs);
 template __global__ void dcn_bwd_input_plane<2>(const DcnFwdGroup grp, float *__restrict__ slabs);

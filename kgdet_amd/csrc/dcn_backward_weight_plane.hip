@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void dcn_pack_grad_out(const float *__restrict
   }
 }
 
+int dcn_bwd_weight_plane_threads() { return kPlaneThreads; }
 size_t dcn_bwd_weight_plane_lds_bytes(int parts, int HW) {
   return (size_t)3 * parts * kAPart + (size_t)2 * parts * kBPart + 2 * 4096 + (size_t)kChunk * HW * sizeof(float);
 }

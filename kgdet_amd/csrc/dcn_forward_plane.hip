@@ -30,20 +30,34 @@
 //   lane l of a wave reads row/col (l & 31) of k-half (l >> 5) as one 16-byte ds_read_b128; reduction
 //   element k = khalf*8 + j is channel c16*16 + k for both operands.
 #include "dcn_plane.h"
+#ifdef KGDET_PLANE_PHASED   // experiment build: the phased body (dcn_plane_phased.h) instead of producer / consumer waves
+#include "dcn_plane_phased.h"
+#endif
 
 namespace kgdet {
 
 template <int PARTS>
+#ifdef KGDET_PLANE_PHASED
+__global__ __launch_bounds__(kPhThreads, 1) void dcn_fwd_plane(const DcnFwdGroup grp, float *__restrict__ slabs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  plane_phased<PARTS, 0>(grp, slabs, smem);
+}
+#else
 __global__ __launch_bounds__(kPlaneThreads, 1) void dcn_fwd_plane(const DcnFwdGroup grp, float *__restrict__ slabs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (threadIdx.x >= kThreads) plane_role<PARTS, true, 0>(grp, slabs, smem);
   else plane_role<PARTS, false, 0>(grp, slabs, smem);
 }
+#endif
 
 template __global__ void dcn_fwd_plane<1>(const DcnFwdGroup grp, float *__restrict__ slabs);
 template __global__ void dcn_fwd_plane<2>(const DcnFwdGroup grp, float *__restrict__ slabs);
 
+#ifdef KGDET_PLANE_PHASED
+int dcn_fwd_plane_threads() { return kPhThreads; }
+#else
 int dcn_fwd_plane_threads() { return kPlaneThreads; }
+#endif
 
 #ifdef KGDET_PLANE_TRACE
 }  // namespace kgdet

@@ -41,6 +41,7 @@ __global__ void dcn_bwd_weight_plane_fixup(const DcnFwdGroup grp, const float *_
 __global__ void dcn_pack_grad_out(const float *__restrict__ gout, void *__restrict__ gq, int N, int O_total, int o_base,
                                   int Og, int HoWo, int n_px16, int parts);
 size_t dcn_bwd_weight_plane_lds_bytes(int parts, int HW);
+int dcn_bwd_weight_plane_threads();
 __global__ void dcn_pack_weight_all(const float *__restrict__ w, float *__restrict__ wpk, float *__restrict__ wpt,
                                     void *__restrict__ wq /*nullable*/, void *__restrict__ wqt /*nullable*/, int Og,
                                     int Cg, int K, int Cg_pad, int Og_pad, int Og_pad16, int Cg_pad256);

@@ -170,16 +170,15 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
     // image.  A thread moves (pixel, quad) items: 4 coalesced dword loads (one per channel plane) -> one 16-byte
     // LDS store.  All loads are issued before the first store, unconditionally from clamped addresses
     // (a guarded load makes hipcc branch and drain the queue).
-    auto load_plane = [&](int c, int me, auto NT_) {
+    auto load_plane = [&](int c, int me, auto NT_, int item_lo, int item_hi) {   // items [item_lo, item_hi) of 4 * HW
       constexpr int NT = decltype(NT_)::value;
       const int c0 = c * kChunk;
       const float *xb = p.x + ((long long)tile_b * p.C_total + p.c_base) * HW;
-      const int items = 4 * HW;  // (pixel, quad) pairs
-      for (int i0 = 0; i0 < items; i0 += kPlaneRounds * NT) {
+      for (int i0 = item_lo; i0 < item_hi; i0 += kPlaneRounds * NT) {
         f32x4 v[kPlaneRounds];
 #pragma unroll
         for (int r = 0; r < kPlaneRounds; ++r) {
-          const int i = min(i0 + r * NT + me, items - 1);
+          const int i = min(i0 + r * NT + me, item_hi - 1);
           const int q = i % HW, quad = i / HW;  // consecutive threads -> consecutive pixels
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -190,13 +189,19 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
 #pragma unroll
         for (int r = 0; r < kPlaneRounds; ++r) {
           const int i = i0 + r * NT + me;
-          if (i < items) {
+          if (i < item_hi) {
             const int q = i % HW, quad = i / HW;
             *reinterpret_cast<f32x4 *>(plane + dcn_plane_offset(q) + ((quad ^ ((q >> 2) & 3)) << 4)) = v[r];
           }
         }
       }
     };
+    // The next segment's plane is copied under the LAST group of a segment (the plane is not read any more once that
+    // group's stages are sampled): the producers, who have nothing to sample then, take the first plane_split items,
+    // the consumers the rest after their MFMAs.  Split operands: the consumers are busy for four stages of 12 MFMAs,
+    // the producers take two full batches of loads; bf16: a third each way (equal shares per thread).
+    const int plane_items = 4 * HW;
+    const int plane_split = PARTS == 2 ? min(plane_items, 2 * kPlaneRounds * kProducers) : plane_items / 3;
     Regs S0, S1, T0, T1;   // producers: this wave pair's two records of the group sampled next (S) and of the one
                            // after it (T, loaded at the TOP of a group, moved into S at its bottom: a whole group to land)
     bool primed = false;   // the segment's plane and first records were loaded under the last group of the one before
@@ -351,19 +356,22 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         }
 #endif
         if constexpr (pipelined) {
-          Corners V0, V1;
+          // three corner register sets: the reads of three half-stages are in flight before the first arithmetic (a batch
+          // of 8 random ds_read_b128 comes back after ~840 cycles while the consumers read their B fragments, ~420
+          // alone -- in-kernel probe, tools/micro/lds_gather.hip -- against ~190 cycles of arithmetic per half-stage)
+          Corners V0, V1, V2;
           f32x2 sv[2][2];
           corner_reads(RA, 0, 0, V0);
           corner_reads(RA, 0, 1, V1);   // (clamped records past the end of the segment: harmless reads)
+          corner_reads(RB, 0, 0, V2);
           corner_fma(RA, 0, V0, sv, true);
           if (a_live) split_store(buf, pair, 0, sv);
-          corner_reads(RB, 0, 0, V0);
+          corner_reads(RB, 0, 1, V0);
           corner_fma(RA, 0, V1, sv, true);
           if (a_live) split_store(buf, pair, 1, sv);
-          corner_reads(RB, 0, 1, V1);
-          corner_fma(RB, 0, V0, sv, true);
+          corner_fma(RB, 0, V2, sv, true);
           if (b_live) split_store(buf, pair + 2, 0, sv);
-          corner_fma(RB, 0, V1, sv, true);
+          corner_fma(RB, 0, V0, sv, true);
           if (b_live) split_store(buf, pair + 2, 1, sv);
         } else {
           if (a_live) { sample_half(buf, pair, 0, RA); sample_half(buf, pair, 1, RA); }
@@ -410,7 +418,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
           issue(rec_base, t0, r - 1, pair, S0); issue(rec_base, t0, r - 1, pair + 2, S1);
           issue(rec_base, t0, n - 1, r + pair, T0); issue(rec_base, t0, n - 1, r + pair + 2, T1);
         }
-        load_plane(c16, wtid, std::integral_constant<int, kPlaneThreads>{});
+        load_plane(c16, wtid, std::integral_constant<int, kPlaneThreads>{}, 0, plane_items);
         KGDET_TR_ADD(1, tr_t);
         __syncthreads();
         KGDET_TR_ADD(2, tr_t);
@@ -439,7 +447,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
           const uint4 *rb2 = seg_records(c16 + 1);
           issue(rb2, 0, r2 - 1, pair, S0); issue(rb2, 0, r2 - 1, pair + 2, S1);
           issue(rb2, 0, n2 - 1, r2 + pair, T0); issue(rb2, 0, n2 - 1, r2 + pair + 2, T1);
-          load_plane(c16 + 1, tid, std::integral_constant<int, kProducers>{});
+          load_plane(c16 + 1, tid, std::integral_constant<int, kProducers>{}, 0, plane_split);
         }
       };
       // group 0
@@ -450,6 +458,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         if (o) multiply(0, 0, FX);
         if (r - o >= 2) { multiply(0, o, F0); a_issue(o + 2, F0); multiply(0, o + 1, F1); a_issue(o + 3, F1); }
         if (r - o >= 4) { multiply(0, o + 2, F0); a_issue(o + 4, F0); multiply(0, o + 3, F1); a_issue(o + 5, F1); }
+        if (n_groups == 1 && has_next) load_plane(c16 + 1, tid, std::integral_constant<int, kThreads>{}, plane_split, plane_items);
       }
       KGDET_TR_ADD(4, tr_t);
       __syncthreads();
@@ -474,6 +483,8 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
           __builtin_amdgcn_sched_barrier(0);
           multiply(buf, 3, F1);
           a_issue(jg + 5, F1);
+          if (gi + 1 == n_groups && has_next)
+            load_plane(c16 + 1, tid, std::integral_constant<int, kThreads>{}, plane_split, plane_items);
         }
         KGDET_TR_ADD(4, tr_t);
         __syncthreads();
