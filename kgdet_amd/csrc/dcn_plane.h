@@ -103,7 +103,9 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
   // DISTINCT weight rows, 16 KB per stage and workgroup instead of 32 KB with 4 x 2 waves of 64 x 64 -- the vector
   // memory path of a CU takes 64 B per clock, and 32 KB of fragments per stage were 512 of its ~1000 cycles
   const int n_local = tid & (kTileN - 1);                     // producers: pixel column sampled
-  const int pair = (tid >> 7) & 1;                            //            wave pair: samples stages pair, pair + 2 of a group
+  // (wave-uniform role coordinates in SGPRs: scalar branches and no exec masking -- every VALU instruction of a producer
+  // costs its SIMD's MFMA waves issue slots, tools/micro/mfma_valu.hip)
+  const int pair = __builtin_amdgcn_readfirstlane((tid >> 7) & 1);   // wave pair: samples stages pair, pair + 2 of a group
   const long long G = gridDim.x, g = blockIdx.x;
   const long long slice = sk_slice_of_block((int)g, (int)G);
   long long my_begin, my_end;
@@ -221,9 +223,9 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       struct AFrag {
         bf16x8 a[PARTS];
       };
-      const unsigned char *wq_cons = reinterpret_cast<const unsigned char *>(p.wq) +
-                                     (size_t)((mt * n_c16 + c16) * K) * (2 * kAPart) + (lane >> 5) * (kTileM * 16) +
-                                     (wave * 32 + (lane & 31)) * 16;
+      // (wave-uniform stage base + one 32-bit lane offset: scalar-base loads, no vector address arithmetic between MFMAs)
+      const unsigned char *wq_cons = reinterpret_cast<const unsigned char *>(p.wq) + (size_t)((mt * n_c16 + c16) * K) * (2 * kAPart);
+      const unsigned a_lane = (unsigned)((lane >> 5) * (kTileM * 16) + (wave * 32 + (lane & 31)) * 16);
       auto a_issue = [&](int j, AFrag &F) {
 #ifdef KGDET_ABL_NOALOAD
         if (j > 1) return;
@@ -231,7 +233,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         const unsigned t = (unsigned)(t0 + min(j, n - 1));
         const unsigned char *b = wq_cons + (size_t)t * (2 * kAPart);
 #pragma unroll
-        for (int part = 0; part < PARTS; ++part) F.a[part] = *reinterpret_cast<const bf16x8 *>(b + part * kAPart);
+        for (int part = 0; part < PARTS; ++part) F.a[part] = *reinterpret_cast<const bf16x8 *>(b + part * kAPart + a_lane);
       };
       // ---- B stage, producers.  A group has four stages; producer wave pair w (2 waves = 128 pixels) samples stages
       // w and w + 2 of it -- a thread does ALL 16 channels of its pixel for a stage, as two half-stages of 8 channels
@@ -267,21 +269,26 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
             }
       };
       auto split_store = [&](int buf, int gi, int half, const f32x2 (&sv)[2][2]) {
-        bf16x8 hi, lo;
+        // hi = bf16(v) for a PAIR of values with one v_cvt_pk_bf16_f32; the two hi values back as floats are a shift and
+        // a mask of that dword (20 instructions per 8 values instead of the 28 hipcc emits for scalar conversions)
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 hi_u, lo_u;
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
           for (int h2 = 0; h2 < 2; ++h2) {
-            const int q = c * 4 + h2 * 2;
-            hi[q] = (__bf16)sv[c][h2][0];
-            hi[q + 1] = (__bf16)sv[c][h2][1];
+            const int q = c * 2 + h2;
+            const bf16x2 hp = __builtin_convertvector(sv[c][h2], bf16x2);
+            const unsigned hu = __builtin_bit_cast(unsigned, hp);
+            hi_u[q] = hu;
             if constexpr (PARTS == 2) {
-              const f32x2 hf = {(float)hi[q], (float)hi[q + 1]};
-              const f32x2 lf = sv[c][h2] - hf;
-              lo[q] = (__bf16)lf[0];
-              lo[q + 1] = (__bf16)lf[1];
+              const f32x2 hf = {__uint_as_float(hu << 16), __uint_as_float(hu & 0xffff0000u)};
+              const bf16x2 lp = __builtin_convertvector(sv[c][h2] - hf, bf16x2);
+              lo_u[q] = __builtin_bit_cast(unsigned, lp);
             }
           }
+        const bf16x8 hi = __builtin_bit_cast(bf16x8, hi_u), lo = __builtin_bit_cast(bf16x8, lo_u);
         unsigned char *dst = Bs + (buf * kGroupTaps + gi) * PARTS * kBPart + half * (kTileN * 16) + n_local * 16;
 #ifdef KGDET_ABL_NOBSTORE
         if (sv[0][0][0] != 1234.56789f) return;
