@@ -110,7 +110,7 @@ def profiled_traffic(batch):
     return None, None
 
 
-def dcn_roofline(device, batch=2, precision='split', iters=20):
+def dcn_roofline(device, batch=2, precision='split', iters=100):
     """DeformConv forward of ONE KGDet head stage: the grouped launch of 2 feature maps x (3x3, 5x5, 7x7) on
     [batch, 256, 25, 42] (kgdet_deform_conv_forward_grouped: dcn_build_taps + dcn_fwd_plane + dcn_fwd_fixup),
     HIP-event timing on the launch stream.  'split': the products are bf16 MFMAs on a hi/lo split of both fp32
@@ -126,7 +126,7 @@ def dcn_roofline(device, batch=2, precision='split', iters=20):
     pads = [k // 2 for k in ks]
     stream = torch.cuda.current_stream()
     with torch.no_grad(), dcn.forward_precision(precision):     # weight images are packed once (inference path)
-        for _ in range(5):
+        for _ in range(30):    # weight images packed, clocks up (a cold burst of 20 launches reads ~8 % slower)
             dcn.deform_conv_cat_multi(xs, offs, ws, pads)
         # five event-bracketed runs of `iters` launches, median run: a host hiccup between two launches (the
         # launch sequence is enqueued from Python) would otherwise be billed to the kernel
