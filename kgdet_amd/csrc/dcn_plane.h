@@ -204,8 +204,10 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
     // the producers take two full batches of loads; bf16: a third each way (equal shares per thread).
     const int plane_items = 4 * HW;
     const int plane_split = PARTS == 2 ? min(plane_items, 2 * kPlaneRounds * kProducers) : plane_items / 3;
-    Regs S0, S1, T0, T1;   // producers: this wave pair's two records of the group sampled next (S) and of the one
-                           // after it (T, loaded at the TOP of a group, moved into S at its bottom: a whole group to land)
+    Regs E0, E1, O0, O1;   // producers: this wave pair's two records of the even-numbered (E) and of the odd-numbered (O)
+                           // groups of the segment.  Group g + 2's are loaded at the TOP of iteration g, which samples group
+                           // g + 1 from the other set: a whole group to land, and no register moves (the iterations are
+                           // unrolled by two)
     bool primed = false;   // the segment's plane and first records were loaded under the last group of the one before
     while (s < s_end) {
       const int n = min(K - t0, s_end - s);  // stages of this segment: taps t0 .. t0+n-1 of chunk c16
@@ -422,8 +424,8 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       // are done)
       if (!primed) {   // first segment of the range: records, then the plane copy by all twelve waves
         if constexpr (PRODUCER) {
-          issue(rec_base, t0, r - 1, pair, S0); issue(rec_base, t0, r - 1, pair + 2, S1);
-          issue(rec_base, t0, n - 1, r + pair, T0); issue(rec_base, t0, n - 1, r + pair + 2, T1);
+          issue(rec_base, t0, r - 1, pair, E0); issue(rec_base, t0, r - 1, pair + 2, E1);
+          issue(rec_base, t0, n - 1, r + pair, O0); issue(rec_base, t0, n - 1, r + pair + 2, O1);
         }
         load_plane(c16, wtid, std::integral_constant<int, kPlaneThreads>{}, 0, plane_items);
         KGDET_TR_ADD(1, tr_t);
@@ -432,34 +434,32 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       }
       // first group (buffer 0).  One stage: each wave pair samples one 8-channel half of it (both hold its record)
       if constexpr (PRODUCER) {
-        if (r == 1) sample_half(0, 0, pair, S0);
-        else sample_group(0, S0, S1, pair < r, pair + 2 < r);
-        S0 = T0; S1 = T1;
+        if (r == 1) sample_half(0, 0, pair, E0);
+        else sample_group(0, E0, E1, pair < r, pair + 2 < r);
       } else {   // full groups find their stages in F0, F1, F0, F1: an odd first group takes its stage 0 from FX
         if (r & 1) { a_issue(0, FX); a_issue(1, F0); a_issue(2, F1); }
         else { a_issue(0, F0); a_issue(1, F1); }
       }
       __syncthreads();
       KGDET_TR_ADD(3, tr_t);
-      // producers, while the consumers multiply group gi: sample group gi + 1 into the other buffer from S (and load
-      // the records of group gi + 2 into T); under the last group, the next segment's records and plane instead
-      auto produce = [&](int gi, int buf_next) {
+      // producers, while the consumers multiply group gi: sample group gi + 1 into the other buffer from (Sa, Sb) and
+      // load the records of group gi + 2 into (Ia, Ib); under the last group, the next segment's records and plane instead
+      auto produce = [&](int gi, int buf_next, const Regs &Sa, const Regs &Sb, Regs &Ia, Regs &Ib) {
         if (gi + 1 < n_groups) {
           const int jn = r + (gi + 1) * kGroupTaps;   // first stage of group gi + 2
-          issue(rec_base, t0, n - 1, jn + pair, T0); issue(rec_base, t0, n - 1, jn + pair + 2, T1);
-          sample_group(buf_next, S0, S1, true, true);
-          S0 = T0; S1 = T1;
+          issue(rec_base, t0, n - 1, jn + pair, Ia); issue(rec_base, t0, n - 1, jn + pair + 2, Ib);
+          sample_group(buf_next, Sa, Sb, true, true);
         } else if (has_next) {
           const int n2 = min(K, s_end - (s + n)), r2 = ((n2 - 1) & 3) + 1;
           const uint4 *rb2 = seg_records(c16 + 1);
-          issue(rb2, 0, r2 - 1, pair, S0); issue(rb2, 0, r2 - 1, pair + 2, S1);
-          issue(rb2, 0, n2 - 1, r2 + pair, T0); issue(rb2, 0, n2 - 1, r2 + pair + 2, T1);
+          issue(rb2, 0, r2 - 1, pair, E0); issue(rb2, 0, r2 - 1, pair + 2, E1);
+          issue(rb2, 0, n2 - 1, r2 + pair, O0); issue(rb2, 0, n2 - 1, r2 + pair + 2, O1);
           load_plane(c16 + 1, tid, std::integral_constant<int, kProducers>{}, 0, plane_split);
         }
       };
       // group 0
       if constexpr (PRODUCER) {
-        produce(0, 1);
+        produce(0, 1, O0, O1, E0, E1);
       } else {
         const int o = r & 1;   // (one-sided conditionals only: MFMAs on both sides of a branch make hipcc copy accumulators)
         if (o) multiply(0, 0, FX);
@@ -474,8 +474,9 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       // with the stage two ahead.
       auto group = [&](int gi, auto BUF) {
         constexpr int buf = decltype(BUF)::value;
-        if constexpr (PRODUCER) {
-          produce(gi, buf ^ 1);
+        if constexpr (PRODUCER) {   // (gi odd <=> buf 1: group gi + 1 is even)
+          if constexpr (buf == 1) produce(gi, 0, E0, E1, O0, O1);
+          else produce(gi, 1, O0, O1, E0, E1);
         } else {
           const int jg = r + (gi - 1) * kGroupTaps;
           // (one scheduling region per stage: across all four, hipcc hoists the B reads of later stages and spills)
