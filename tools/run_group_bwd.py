@@ -1,0 +1,24 @@
+"""Forward + backward of one head stage's grouped DeformConv (2 feature maps x 3x3/5x5/7x7 on [B, 256, 25, 42]) a few
+times (profiling target for the three backward plane kernels): python tools/run_group_bwd.py [B] [iters]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from kgdet_amd import dcn
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dev = torch.device('cuda:0')
+torch.manual_seed(0)
+C, H, W = 256, 25, 42
+ks = (3, 5, 7)
+xs = [torch.randn(B, C, H, W, device=dev, requires_grad=True) for _ in range(2)]
+offs = [(torch.randn(B, 2 * k * k, H, W, device=dev) * 2).requires_grad_() for k in ks]
+ws = [[(torch.randn(C, C, k, k, device=dev) * 0.01).requires_grad_() for k in ks] for _ in xs]
+gos = None
+for _ in range(iters):
+    outs = dcn.deform_conv_cat_multi(xs, offs, ws, [k // 2 for k in ks])
+    if gos is None:
+        gos = [torch.randn_like(o) for o in outs]
+    torch.autograd.backward(outs, gos)
+    for t in xs + offs + [w for wl in ws for w in wl]:
+        t.grad = None
+torch.cuda.synchronize()
