@@ -20,6 +20,7 @@ SPLIT_GRAD_WEIGHT_3X3 = _os.environ.get('KGDET_SPLIT_WGRAD3', '1') == '1'
 PACK_BOTH = _os.environ.get('KGDET_PACK_BOTH', '1') == '1'
 
 
+PAD_GRAD_WEIGHT_3X3 = _os.environ.get('KGDET_NO_WPAD') is None   # (A/B switch for the zero-padded odd-width route)
 ENABLED = True      # False: every dense convolution stays on MIOpen's fp32 kernels (dcn.arithmetic('exact'))
 
 
@@ -194,7 +195,15 @@ def grad_weight(x, weight, gy):
     """grad of ``conv(x, weight)`` (stride 1, padding k // 2) with respect to the weight"""
     O, C, k = weight.shape[0], weight.shape[1], weight.shape[2]
     L = _lib_sizes()
-    if k == 3 and SPLIT_GRAD_WEIGHT_3X3 and C % 128 == 0 and x.shape[3] % 4 == 0:
+    if k == 3 and SPLIT_GRAD_WEIGHT_3X3 and C % 128 == 0:
+        if x.shape[3] % 4 and not PAD_GRAD_WEIGHT_3X3:
+            return torch.nn.grad.conv2d_weight(x, weight.shape, gy, padding=1)
+        if x.shape[3] % 4:
+            # the kernel's 16-byte row loads need W % 4 == 0 (25 x 42 head / FPN maps): zero columns on the right of
+            # BOTH operands change nothing -- gy is 0 there, and x's zeros are what the out-of-range taps read anyway --
+            # and two small copies + the split kernel beat MIOpen's fp32 Winograd weight gradient (69 us per call)
+            pad = (0, 4 - x.shape[3] % 4)
+            x, gy = torch.nn.functional.pad(x, pad), torch.nn.functional.pad(gy, pad)
         B, H, W = x.shape[0], x.shape[2], x.shape[3]
         nbytes = _size('kgdet_conv3x3_grad_weight_workspace_bytes', B, O, C, H, W)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
