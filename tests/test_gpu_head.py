@@ -407,3 +407,76 @@ def test_full_size_training_step_split_arithmetic_matches_exact_fp32():
     worst = max(abs(g_split[k] - g_exact[k]) / max(g_exact[k], 1e-12) for k in g_exact)
     assert worst <= 2e-3, (worst, {k: (g_split[k], g_exact[k]) for k in g_exact
                                    if abs(g_split[k] - g_exact[k]) > 1e-3 * g_exact[k]})
+
+
+@pytest.mark.gpu
+def test_inference_batch8_bf16_full_size_is_batch_size_independent():
+    """BASELINE config 2 at its own size: 8 images of 800x1344 under bf16 autocast through backbone -> neck -> head ->
+    whole-batch decode -> fused multiclass NMS, eager and as the HIP-graph replay.  Every image gets its 100
+    detections, and what image i gets does not depend on the batch it travelled in (the same 8 images as two batches
+    of 4), up to bf16 convolution noise (MIOpen may pick another solver for another batch size)."""
+    from kgdet_amd import build_detector, configs, synthetic
+    cfg = configs.kgdet_r50_fpn()
+    torch.manual_seed(0)
+    model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().eval()
+    ac = torch.autocast('cuda', dtype=torch.bfloat16)
+    batch = synthetic.make_batch(8, torch.device('cuda'), seed=0)
+    assert tuple(batch['img'].shape) == (8, 3, 800, 1344)
+    synthetic.calibrate_scores(model, batch, cfg.test_cfg.score_thr, 0.02, ac)
+    with torch.no_grad(), ac:
+        whole = model.simple_test_batch(batch['img'], batch['img_meta'], rescale=True)
+        halves = []
+        for lo in (0, 4):
+            halves += model.simple_test_batch(batch['img'][lo:lo + 4], batch['img_meta'][lo:lo + 4], rescale=True)
+    run = model.graphed_test_batch(batch['img'], batch['img_meta'], rescale=True, autocast_dtype=torch.bfloat16)
+    graphed = run(batch['img'])
+    assert len(whole) == len(halves) == len(graphed) == 8
+    for w, h, g in zip(whole, halves, graphed):
+        assert len(w) == 3 and sum(len(d) for d in w[0]) == cfg.test_cfg.max_per_img == 100
+        for other in (h, g):
+            assert abs(sum(len(d) for d in other[0]) - 100) <= 2
+            close = total = 0
+            for c in range(13):
+                if len(w[0][c]) and len(other[0][c]):
+                    d = np.abs(w[0][c][:, None, :4] - other[0][c][None, :, :4]).max(-1).min(1)
+                    close += int((d < 0.5).sum())
+                total += len(w[0][c])
+            assert close >= 0.8 * total, (close, total)
+
+
+@pytest.mark.gpu
+def test_config5_full_size_training_step_and_soft_nms():
+    """BASELINE config 5 at its own size (serial head, five pyramid levels from 100x168 to 7x11, 2 x 800x1344): one
+    training step under the default arithmetic against the same step in plain fp32 arithmetic (the large stride-8 / 16
+    maps take `dcn_bwd_large` and the exact forward either way; the small ones the plane kernels vs the f32 kernels),
+    then inference with soft-NMS."""
+    from kgdet_amd import dcn
+    from kgdet_amd.registry import build_detector
+    cfg = configs.reppoints_kp_r50_fpn(parallel=False, soft_nms=True)
+
+    def run(mode):
+        torch.manual_seed(0)
+        model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda()
+        model.train()
+        batch = synthetic.make_batch(2, 'cuda', seed=0)
+        with dcn.arithmetic(mode):
+            losses = model(batch['img'], batch['img_meta'], return_loss=True, gt_bboxes=batch['gt_bboxes'],
+                           gt_labels=batch['gt_labels'], gt_keypoints=batch['gt_keypoints'])
+            sum(sum(v) for v in losses.values()).backward()
+        torch.cuda.synchronize()
+        gn = sum(float(p.grad.double().pow(2).sum()) for p in model.parameters() if p.grad is not None) ** 0.5
+        return model, batch, {k: sum(float(t.detach()) for t in v) for k, v in losses.items()}, gn
+
+    model, batch, l_split, g_split = run('split')
+    _, _, l_exact, g_exact = run('exact')
+    assert all(np.isfinite(v) for v in l_split.values()) and len(l_split) >= 3
+    for k in l_exact:
+        assert abs(l_split[k] - l_exact[k]) <= 1e-4 * max(1.0, abs(l_exact[k])), (k, l_split[k], l_exact[k])
+    assert abs(g_split - g_exact) <= 2e-3 * g_exact, (g_split, g_exact)
+    model.eval()
+    synthetic.calibrate_scores_serial(model, batch, cfg.test_cfg.score_thr)
+    with torch.no_grad():
+        res = model.simple_test(batch['img'][:1], batch['img_meta'][:1], rescale=True)
+    dets = res[0] if isinstance(res, (list, tuple)) and len(res) in (1, 3) and not isinstance(res[0], np.ndarray) else res
+    n = sum(len(d) for d in (dets[0] if len(dets) == 3 else dets))
+    assert 0 < n <= cfg.test_cfg.max_per_img
