@@ -92,7 +92,7 @@ size_t plan_plane_lds(DcnFwdGroup &grp, size_t single, size_t fixed) {
 // tile.  Measured on the head-stage forward (6 problems, B=2): fabric reads 883 -> 174 MB per launch, 265 -> 207 us.
 // Falls back to stream-K (static_ranges = 0, kparts = 1) when the ranges outnumber the workgroups or would be too
 // uneven.  Problems must have kparts == 1 on entry.
-void plan_static_ranges(DcnFwdGroup &grp, int G) {
+void plan_static_ranges(DcnFwdGroup &grp, int G, bool force = false) {
   grp.static_ranges = 0;
   const long long total = grp.unit_begin[grp.n];
   const double share = (double)total / G;
@@ -109,7 +109,18 @@ void plan_static_ranges(DcnFwdGroup &grp, int G) {
     longest = len > longest ? len : longest;
   }
   static const bool off = getenv("KGDET_DCN_STREAMK") != nullptr;   // A/B switch
-  if (off || ranges > G || longest > 1.25 * share) return;
+  if (force) {   // a kernel without a stream-K fix-up (v2 grad_offset): fewer, longer parts until the ranges fit
+    while (ranges > G) {
+      int worst = 0;
+      for (int i = 1; i < grp.n; ++i)
+        if (kp[i] > kp[worst]) worst = i;
+      if (kp[worst] == 1) return;   // more tiles than workgroups: no static schedule
+      ranges -= grp.p[worst].n_ntiles * grp.p[worst].n_mtiles * (kp[worst] - (kp[worst] + 1) / 2);
+      kp[worst] = (kp[worst] + 1) / 2;
+    }
+  } else if (off || ranges > G || longest > 1.25 * share) {
+    return;
+  }
   grp.static_ranges = 1;
   for (int i = 0; i < grp.n; ++i) {
     grp.p[i].kparts = kp[i];
@@ -184,13 +195,13 @@ bool plane_bwd_input_ok(const kgdet_dcn_shape *s, const Derived &d) {
                        d.K * (d.Og_pad16 / kChunk));
 }
 // grad_offset on the plane kernel: v1, one deformable group, <= 256 output channels per group
-bool plane_bwd_offset_ok(const kgdet_dcn_shape *s, const Derived &d) {
+bool plane_bwd_offset_ok(const kgdet_dcn_shape *s, const Derived &d, bool masked = false) {
   return s->deformable_groups == 1 && s->groups == 1 && d.Og <= 256 && d.K <= 64 && s->H * s->W <= kPlaneMaxHW &&
-         dcn_bwd_offset_plane_lds_bytes(2, d.K, s->H * s->W) <= kMaxLds &&
+         dcn_bwd_offset_plane_lds_bytes(2, d.K, s->H * s->W, masked) <= kMaxLds &&
          (size_t)8 * 33 * (d.K + 1) * sizeof(float) <= kMaxLds - 64 &&
          slab_slots_ok((long long)s->N * ceil_div(d.Ho * d.Wo, kTileN), d.K * (d.Cg_pad / kChunk));
 }
-size_t grad_tap_bytes(const kgdet_dcn_shape *s, const Derived &d) { return (size_t)s->N * d.K * d.Ho * d.Wo * 48; }
+size_t grad_tap_bytes(const kgdet_dcn_shape *s, const Derived &d) { return (size_t)s->N * d.K * d.Ho * d.Wo * 64; }   // (v2 records: 64 B)
 struct InvTables {
   size_t rec_bytes, slot_bytes, spill_bytes;
   size_t total() const { return rec_bytes + slot_bytes + spill_bytes; }
@@ -262,6 +273,11 @@ size_t kgdet_dcn_workspace_bytes(const kgdet_dcn_shape *s) {
     bwd_in_plane = slab_bytes() + grad_tap_bytes(s, d);
   size_t need = fwd_and_wgrad > bwd_in ? fwd_and_wgrad : bwd_in;
   need = need > bwd_in_plane ? need : bwd_in_plane;
+  if (s->groups == 1 && s->deformable_groups == 1 && plane_ok(s, d)) {   // grad_weight on the plane kernel: records + grad_out image
+    const size_t wplane = slab_bytes() + align_up(tap_table_bytes(s, d), 256) +
+                          (size_t)(d.Og_pad / kTileM) * s->N * ceil_div(d.Ho * d.Wo, kChunk) * 16384;
+    need = need > wplane ? need : wplane;
+  }
   if (!pl.ok && !plane_bwd_input_ok(s, d)) {   // large maps: the materialised column gradient of dcn_backward_large.hip
     DcnProblem p;
     fill_problem(s, d, 0, p);
@@ -316,7 +332,11 @@ int kgdet_dcn_pack_weight(const kgdet_dcn_shape *s, const float *weight, float *
                                                    d.plane_image_floats()) + (size_t)g * d.plane_t_image_floats();
     if (fused) {
       dim3 grid(d.Cg_pad256 / 8, d.Og_pad / 32);
-      const bool plane = plane_ok(s, d);
+      // the bf16 images depend on the WEIGHT alone (never on the map size or batch: a packed weight is reused across
+      // pyramid levels and batch sizes -- kgdet_amd/dcn.py caches it for inference)
+      const int cpdg_ = s->C / s->deformable_groups;
+      const bool plane = ((s->C / s->deformable_groups) % 4 == 0 || s->deformable_groups == 1) &&
+                         (s->deformable_groups == 1 || cpdg_ % 16 == 0);
       hipLaunchKernelGGL(dcn_pack_weight_all, grid, dim3(256), lds_all, (hipStream_t)stream, w, dst, dst_t,
                          plane ? (void *)dst_q : nullptr, plane ? (void *)dst_qt : nullptr, d.Og, d.Cg, d.K,
                          d.Cg_pad, d.Og_pad, d.Og_pad16, d.Cg_pad256);
@@ -586,13 +606,27 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
   return KGDET_OK;
 }
 
+static int grad_offset_plane(const kgdet_dcn_shape *s, const float *input, const float *offset, const float *mask,
+                             const float *packed_weight, const float *grad_output, float *grad_offset, float *grad_mask,
+                             uint32_t flags, void *workspace, size_t workspace_bytes, void *stream);
+
 int kgdet_deform_conv_grad_offset(const kgdet_dcn_shape *s, const float *input, const float *offset,
                                   const float *packed_weight, const float *grad_output, float *grad_offset,
                                   uint32_t flags, void *workspace, size_t workspace_bytes, void *stream) {
+  return grad_offset_plane(s, input, offset, nullptr, packed_weight, grad_output, grad_offset, nullptr, flags, workspace,
+                           workspace_bytes, stream);
+}
+
+// v1 (mask == nullptr) or v2 (mask, grad_mask; split operands and static ranges only: KGDET_E_UNSUPPORTED otherwise, before
+// anything is launched)
+static int grad_offset_plane(const kgdet_dcn_shape *s, const float *input, const float *offset, const float *mask,
+                             const float *packed_weight, const float *grad_output, float *grad_offset, float *grad_mask,
+                             uint32_t flags, void *workspace, size_t workspace_bytes, void *stream) {
   Derived d;
   if (int rc = derive(s, d)) return rc;
   KGDET_CHECK_SHAPE(input && offset && packed_weight && grad_output && grad_offset, "null pointer");
-  if (!plane_bwd_offset_ok(s, d)) {
+  KGDET_CHECK_SHAPE((mask == nullptr) == (grad_mask == nullptr), "mask and grad_mask must come together");
+  if (!plane_bwd_offset_ok(s, d, mask != nullptr) || (mask && (flags & KGDET_DCN_BF16))) {
     set_error("grad_offset plane kernel: needs deformable_groups == 1, <= 256 output channels per group, H*W <= %d",
               kPlaneMaxHW);
     return KGDET_E_UNSUPPORTED;
@@ -608,6 +642,8 @@ int kgdet_deform_conv_grad_offset(const kgdet_dcn_shape *s, const float *input, 
                                       (int)kMaxLds));
     KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_bwd_offset_plane<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)kMaxLds));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_bwd_offset_plane_masked, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)kMaxLds));
     attr_set = true;
   }
   const int G = grid_size();
@@ -619,7 +655,7 @@ int kgdet_deform_conv_grad_offset(const kgdet_dcn_shape *s, const float *input, 
   for (int g = 0; g < s->groups; ++g) {
     DcnProblem p;
     fill_problem(s, d, g, p);
-    p.x = input; p.offset = offset; p.mask = nullptr; p.gout = grad_output; p.goff = grad_offset;
+    p.x = input; p.offset = offset; p.mask = mask; p.gout = grad_output; p.goff = grad_offset; p.gmask = grad_mask;
     p.wq = packed_weight + (size_t)s->groups * (d.fwd_image_floats() + d.bwd_image_floats() + d.plane_image_floats()) +
            (size_t)g * d.plane_t_image_floats();
     p.taps = recs; p.build_taps = g == 0;
@@ -639,10 +675,22 @@ int kgdet_deform_conv_grad_offset(const kgdet_dcn_shape *s, const float *input, 
     ++grp.n;
   }
   KGDET_CHECK_SHAPE(s->groups == 1, "grad_offset plane kernel: weight groups > 1 would need a sum over groups");
-  plan_static_ranges(grp, G);
+  plan_static_ranges(grp, G, mask != nullptr);
+  if (mask && !grp.static_ranges) {
+    set_error("grad_offset plane kernel (v2): more (part, tile) ranges than workgroups");
+    return KGDET_E_UNSUPPORTED;
+  }
   hipLaunchKernelGGL(dcn_build_grad_taps, dim3(2 * G, grp.n), dim3(256), 0, (hipStream_t)stream, grp);
-  const size_t lds = dcn_bwd_offset_plane_lds_bytes(parts, d.K, s->H * s->W);
+  const size_t lds = dcn_bwd_offset_plane_lds_bytes(parts, d.K, s->H * s->W, mask != nullptr);
   const int threads = dcn_bwd_offset_plane_threads();
+  if (mask) {
+    hipLaunchKernelGGL(dcn_bwd_offset_plane_masked, dim3(G), dim3(threads), lds, (hipStream_t)stream, grp, (float *)workspace,
+                       d.K);
+    hipLaunchKernelGGL(dcn_bwd_offset_plane_fixup_masked, dim3(grp.tile_begin[grp.n], 8), dim3(256), 0, (hipStream_t)stream,
+                       grp, (const float *)workspace, G, d.K);
+    KGDET_CHECK_LAUNCH("dcn_bwd_offset_plane_masked");
+    return KGDET_OK;
+  }
   if (parts == 1)
     hipLaunchKernelGGL(dcn_bwd_offset_plane<1>, dim3(G), dim3(threads), lds, (hipStream_t)stream, grp,
                        (float *)workspace, d.K);
@@ -815,10 +863,22 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
 }
 
 // grad_weight of n v1 problems in one launch of the plane kernel (+ record / grad_out image builders, fix-up).
+static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *shapes, const float *const *inputs,
+                                     const float *const *offsets, const float *const *masks, const float *const *grad_outputs,
+                                     float *const *grad_weights, void *workspace, size_t workspace_bytes, void *stream);
+
 int kgdet_deform_conv_grad_weight_grouped(int32_t n, const kgdet_dcn_shape *const *shapes, const float *const *inputs,
                                           const float *const *offsets, const float *const *grad_outputs,
                                           float *const *grad_weights, void *workspace, size_t workspace_bytes,
                                           void *stream) {
+  return grad_weight_plane_grouped(n, shapes, inputs, offsets, nullptr, grad_outputs, grad_weights, workspace, workspace_bytes,
+                                   stream);
+}
+
+// masks: nullptr (v1) or one mask pointer per problem (v2: the tap records carry mask x bilinear weight)
+static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *shapes, const float *const *inputs,
+                                     const float *const *offsets, const float *const *masks, const float *const *grad_outputs,
+                                     float *const *grad_weights, void *workspace, size_t workspace_bytes, void *stream) {
   KGDET_CHECK_SHAPE(n >= 1 && n <= kMaxFwdGroup && shapes && inputs && offsets && grad_outputs && grad_weights,
                     "null pointer / group size not in [1, %d]", kMaxFwdGroup);
   const int G = grid_size();
@@ -839,7 +899,8 @@ int kgdet_deform_conv_grad_weight_grouped(int32_t n, const kgdet_dcn_shape *cons
       const bool geo = o->N == s->N && o->H == s->H && o->W == s->W && o->kh == s->kh && o->kw == s->kw &&
                        o->stride_h == s->stride_h && o->stride_w == s->stride_w && o->pad_h == s->pad_h &&
                        o->pad_w == s->pad_w && o->dil_h == s->dil_h && o->dil_w == s->dil_w;
-      if (same_taps[i] < 0 && geo && offsets[q] == offsets[i]) same_taps[i] = same_taps[q] >= 0 ? same_taps[q] : q;
+      if (same_taps[i] < 0 && geo && offsets[q] == offsets[i] && (!masks || masks[q] == masks[i]))
+        same_taps[i] = same_taps[q] >= 0 ? same_taps[q] : q;
       if (same_gq[i] < 0 && grad_outputs[q] == grad_outputs[i] && o->N == s->N && o->O == s->O &&
           o->out_channel_offset == s->out_channel_offset && o->out_channels_total == s->out_channels_total &&
           dd[q].Ho == dd[i].Ho && dd[q].Wo == dd[i].Wo)
@@ -874,7 +935,7 @@ int kgdet_deform_conv_grad_weight_grouped(int32_t n, const kgdet_dcn_shape *cons
     DcnProblem p;
     fill_problem(s, d, 0, p);
     const int n_px16 = ceil_div(p.HoWo, kChunk);
-    p.x = inputs[i]; p.offset = offsets[i]; p.mask = nullptr; p.out = grad_weights[i];
+    p.x = inputs[i]; p.offset = offsets[i]; p.mask = masks ? masks[i] : nullptr; p.out = grad_weights[i];
     p.taps = reinterpret_cast<const DcnTapRec *>(tab + taps_off[i]);
     p.build_taps = same_taps[i] < 0;
     p.wq = tab + gq_off[i];
@@ -927,13 +988,16 @@ int kgdet_deform_conv_backward_input(const kgdet_dcn_shape *s, const float *inpu
   // v1 on small maps: the two plane kernels (grad_input by transposed sampling, grad_offset with the column
   // gradient in registers), bf16 hi/lo split MFMA -- 2x faster than the f32 gather kernel below
   const bool plane_off = g_options[KGDET_OPT_EXACT_BACKWARD] != 0;
-  if (mask == nullptr && !plane_off && plane_bwd_input_ok(s, d) && plane_bwd_offset_ok(s, d) &&
+  if (!plane_off && plane_bwd_input_ok(s, d) && plane_bwd_offset_ok(s, d, mask != nullptr) &&
       workspace_bytes >= kgdet_dcn_workspace_bytes(s)) {
-    if (int rc = kgdet_deform_conv_grad_input(s, offset, nullptr, packed_weight, grad_output, grad_input, 0, workspace,
-                                              workspace_bytes, stream))
-      return rc;
-    return kgdet_deform_conv_grad_offset(s, input, offset, packed_weight, grad_output, grad_offset, 0, workspace,
-                                         workspace_bytes, stream);
+    // (grad_offset first: the v2 variant declines -- before launching anything -- when its ranges outnumber the
+    // workgroups, and the gather path below then does everything)
+    const int rc = grad_offset_plane(s, input, offset, mask, packed_weight, grad_output, grad_offset, grad_mask, 0, workspace,
+                                     workspace_bytes, stream);
+    if (rc == KGDET_OK)
+      return kgdet_deform_conv_grad_input(s, offset, mask, packed_weight, grad_output, grad_input, 0, workspace,
+                                          workspace_bytes, stream);
+    if (rc != KGDET_E_UNSUPPORTED) return rc;
   }
   const int G = grid_size();
   const int cpdg = s->C / s->deformable_groups;
@@ -1033,6 +1097,23 @@ int kgdet_deform_conv_backward_weight(const kgdet_dcn_shape *s, const float *inp
   Derived d;
   if (int rc = derive(s, d)) return rc;
   KGDET_CHECK_SHAPE(input && offset && grad_output && grad_weight, "null pointer");
+  // one weight group, one deformable group, small map (v1 or v2): the split-operand plane kernel, natural-layout output
+  if (!accumulate && g_options[KGDET_OPT_EXACT_BACKWARD] == 0 && s->groups == 1 && s->deformable_groups == 1 &&
+      plane_ok(s, d)) {
+    const int rc = grad_weight_plane_grouped(1, &s, &input, &offset, mask ? &mask : nullptr, &grad_output, &grad_weight, workspace,
+                                             workspace_bytes, stream);
+    if (rc == KGDET_OK) {
+      if (grad_bias) {
+        const int O_total = s->out_channels_total > 0 ? s->out_channels_total : s->O;
+        hipLaunchKernelGGL(dcn_bias_grad, dim3(s->O), dim3(256), 0, (hipStream_t)stream,
+                           grad_output + (size_t)s->out_channel_offset * d.Ho * d.Wo, grad_bias, s->N, O_total,
+                           d.Ho * d.Wo, accumulate);
+        KGDET_CHECK_LAUNCH("dcn_bias_grad");
+      }
+      return KGDET_OK;
+    }
+    if (rc != KGDET_E_UNSUPPORTED && rc != KGDET_E_WORKSPACE) return rc;   // else: the f32 kernel below
+  }
   const int cpdg = s->C / s->deformable_groups;
   if (!(s->deformable_groups == 1 || cpdg % d.Cg == 0 || (d.Cg % cpdg == 0 && cpdg % kTileN == 0))) {
     set_error("deformable_groups=%d / groups=%d / C=%d: channel tiles straddle deformable groups (unsupported)",

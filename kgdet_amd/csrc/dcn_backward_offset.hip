@@ -32,6 +32,8 @@ typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
 
 // One 48-byte record per (image, tap, output pixel): corner offsets as in DcnTapRec, and the weights that turn
 // the four corner values into d sample / dy and d sample / dx (zero where the corner, or the tap, is outside).
+// Modulated (v2) problems: the derivative weights carry the mask value, and a fourth 16 bytes hold the plain bilinear
+// weights -- d out / d mask is the sampled value itself (deform_conv_cuda_kernel.cu:636-766) -- 64 bytes per record.
 __global__ __launch_bounds__(256) void dcn_build_grad_taps(const DcnFwdGroup grp) {
   const DcnProblem &p = grp.p[blockIdx.y];
   if (!p.build_taps) return;
@@ -50,31 +52,39 @@ __global__ __launch_bounds__(256) void dcn_build_grad_taps(const DcnFwdGroup grp
     TapGeom geo;
     make_tap(y, x, p.H, p.W, true, 1.0f, tap, geo);
     const float hy = 1.0f - geo.ly, hx = 1.0f - geo.lx;
-    const float ka = geo.va ? 1.f : 0.f, kb = geo.vb ? 1.f : 0.f, kc = geo.vc ? 1.f : 0.f, kd = geo.vd ? 1.f : 0.f;
+    const float m = p.mask ? p.mask[((long long)b * p.K + t) * p.HoWo + hw] : 1.0f;
+    const int rs = p.mask ? 4 : 3;   // 16-byte pieces per record
+    const float ka = geo.va ? m : 0.f, kb = geo.vb ? m : 0.f, kc = geo.vc ? m : 0.f, kd = geo.vd ? m : 0.f;
     unsigned off[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) off[e] = (unsigned)(dcn_plane_offset(tap.o[e]) + (((tap.o[e] >> 2) & 3) << 4));
-    out[i * 3 + 0] = make_uint4(off[0], off[1], off[2], off[3]);
+    out[i * rs + 0] = make_uint4(off[0], off[1], off[2], off[3]);
     // d/dy = hx (v10 - v00) + lx (v11 - v01),  d/dx = hy (v01 - v00) + ly (v11 - v10)   (:144-187)
-    out[i * 3 + 1] = make_uint4(__float_as_uint(-hx * ka), __float_as_uint(-geo.lx * kb), __float_as_uint(hx * kc),
+    out[i * rs + 1] = make_uint4(__float_as_uint(-hx * ka), __float_as_uint(-geo.lx * kb), __float_as_uint(hx * kc),
                                 __float_as_uint(geo.lx * kd));
-    out[i * 3 + 2] = make_uint4(__float_as_uint(-hy * ka), __float_as_uint(hy * kb), __float_as_uint(-geo.ly * kc),
+    out[i * rs + 2] = make_uint4(__float_as_uint(-hy * ka), __float_as_uint(hy * kb), __float_as_uint(-geo.ly * kc),
                                 __float_as_uint(geo.ly * kd));
+    if (p.mask)   // (make_tap was called with mask 1: tap.w = the bilinear weights, zero outside)
+      out[i * rs + 3] = make_uint4(__float_as_uint(tap.w[0]), __float_as_uint(tap.w[1]), __float_as_uint(tap.w[2]),
+                                  __float_as_uint(tap.w[3]));
   }
 }
 
-// LDS: A [2][PARTS][8 KB] | offs_acc [K][128][2] fp32 | x plane [H*W][16 ch] fp32
-size_t dcn_bwd_offset_plane_lds_bytes(int parts, int K, int HW) {
-  return (size_t)2 * parts * kAPart + (size_t)K * kTileN * 2 * sizeof(float) + (size_t)kChunk * HW * sizeof(float);
+// LDS: A [2][PARTS][8 KB] | offs_acc [K][128][2 (v2: 4)] fp32 | x plane [H*W][16 ch] fp32
+size_t dcn_bwd_offset_plane_lds_bytes(int parts, int K, int HW, int masked) {
+  return (size_t)2 * parts * kAPart + (size_t)K * kTileN * (masked ? 4 : 2) * sizeof(float) + (size_t)kChunk * HW * sizeof(float);
 }
 int dcn_bwd_offset_plane_threads() { return kOffThreads; }
 
-template <int PARTS, bool PRODUCER>
+// MASK: modulated (v2) problems -- a third sum per (tap, pixel), grad_mask
+template <int PARTS, bool PRODUCER, bool MASK>
 __device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__restrict__ slabs, unsigned char *smem,
                                             int max_K) {
+  constexpr int ACC = MASK ? 4 : 2;   // floats per (tap, pixel) sum: (dy, dx) or (dy, dx, dmask, -)
+  constexpr int RS = MASK ? 4 : 3;    // 16-byte pieces per record
   unsigned char *As = smem;                                             // [2][PARTS][kAPart]: [o16][khalf][c 16][8 o]
-  float *offs_acc = reinterpret_cast<float *>(smem + 2 * PARTS * kAPart);  // [K][128][2]
-  unsigned char *plane = smem + 2 * PARTS * kAPart + (size_t)max_K * kTileN * 2 * sizeof(float);
+  float *offs_acc = reinterpret_cast<float *>(smem + 2 * PARTS * kAPart);  // [K][128][ACC]
+  unsigned char *plane = smem + 2 * PARTS * kAPart + (size_t)max_K * kTileN * ACC * sizeof(float);
 
   const int wtid = threadIdx.x;
   const int tid = PRODUCER ? wtid - kThreads : wtid;
@@ -129,12 +139,12 @@ __device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__res
     }
     // zero the tap accumulators of this range
     __syncthreads();
-    for (int i = wtid; i < K * kTileN * 2; i += kOffThreads) offs_acc[i] = 0.0f;
+    for (int i = wtid; i < K * kTileN * ACC; i += kOffThreads) offs_acc[i] = 0.0f;
 
     struct Regs {
       f32x4 a[PARTS][2];     // producers: this thread's 2 x 16 B of each part of the W^T stage
       uint4 off;             // consumers: the record of (pixel, tap)
-      f32x4 wy, wx;
+      f32x4 wy, wx, wm;
     };
 
     int s = s_begin;
@@ -142,7 +152,7 @@ __device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__res
     int t0 = s - c16 * K;
     while (s < s_end) {
       const int n = min(K - t0, s_end - s);
-      const uint4 *rec_base = reinterpret_cast<const uint4 *>(p.taps) + ((size_t)tile_b * K * HoWo + my_px_c) * 3;
+      const uint4 *rec_base = reinterpret_cast<const uint4 *>(p.taps) + ((size_t)tile_b * K * HoWo + my_px_c) * RS;
       // W^T stage of (chunk c16, tap t): for every 16-o chunk o16 the rows c16*16 .. +15 of both k-halves:
       // 256-byte runs inside wqt[ct][o16][t][part][khalf][c 256][8 o]
       const int ct = (c16 * kChunk) / kTileM, c_in = (c16 * kChunk) % kTileM;
@@ -164,10 +174,11 @@ __device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__res
             }
           }
         } else {
-          const uint4 *rec = rec_base + (size_t)t * HoWo * 3;
+          const uint4 *rec = rec_base + (size_t)t * HoWo * RS;
           R.off = rec[0];
           R.wy = *reinterpret_cast<const f32x4 *>(rec + 1);
           R.wx = *reinterpret_cast<const f32x4 *>(rec + 2);
+          if constexpr (MASK) R.wm = *reinterpret_cast<const f32x4 *>(rec + 3);
         }
       };
       auto commit_weights = [&](int buf, const Regs &R) {
@@ -232,24 +243,38 @@ __device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__res
           if constexpr (PARTS == 2) { cg[0] += acc1[0] + acc2[0]; cg[1] += acc1[1] + acc2[1]; cg[2] += acc1[2] + acc2[2]; cg[3] += acc1[3] + acc2[3]; }
           // cg[r] = colgrad of channel 4 * kg + r for pixel px16: the x quad kg of the four corners
           const unsigned o[4] = {R.off.x, R.off.y, R.off.z, R.off.w};
-          float gy = 0.f, gx = 0.f;
+          float gy = 0.f, gx = 0.f, gm = 0.f;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(plane + (o[e] ^ (unsigned)(kg << 4)));
             const float d = cg[0] * v[0] + cg[1] * v[1] + cg[2] * v[2] + cg[3] * v[3];
             gy += R.wy[e] * d;
             gx += R.wx[e] * d;
+            if constexpr (MASK) gm += R.wm[e] * d;
           }
           gy += __shfl_xor(gy, 16);
           gx += __shfl_xor(gx, 16);
           gy += __shfl_xor(gy, 32);
           gx += __shfl_xor(gx, 32);
+          if constexpr (MASK) {
+            gm += __shfl_xor(gm, 16);
+            gm += __shfl_xor(gm, 32);
+          }
           if (kg == 0) {
-            float2 *dst = reinterpret_cast<float2 *>(offs_acc) + (size_t)(t0 + j) * kTileN + wave * 16 + px16;
-            float2 cur2 = *dst;
-            cur2.x += gy;
-            cur2.y += gx;
-            *dst = cur2;
+            if constexpr (MASK) {
+              f32x4 *dst = reinterpret_cast<f32x4 *>(offs_acc) + (size_t)(t0 + j) * kTileN + wave * 16 + px16;
+              f32x4 cur4 = *dst;
+              cur4[0] += gy;
+              cur4[1] += gx;
+              cur4[2] += gm;
+              *dst = cur4;
+            } else {
+              float2 *dst = reinterpret_cast<float2 *>(offs_acc) + (size_t)(t0 + j) * kTileN + wave * 16 + px16;
+              float2 cur2 = *dst;
+              cur2.x += gy;
+              cur2.y += gx;
+              *dst = cur2;
+            }
           }
         }
       };
@@ -295,19 +320,29 @@ __device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__res
     __syncthreads();
     {
       const bool whole = s_begin == 0 && s_end == cpt;
-      float *slab = slabs + ((long long)g * grp.slots + slot) * (size_t)(max_K * kTileN * 2);
+      float *slab = slabs + ((long long)g * grp.slots + slot) * (size_t)(max_K * kTileN * ACC);
       for (int i = wtid; i < K * kTileN; i += kOffThreads) {
         const int t = i / kTileN, col = i - t * kTileN;
-        const float2 v = reinterpret_cast<const float2 *>(offs_acc)[i];
+        float vy, vx, vm = 0.f;
+        if constexpr (MASK) {
+          const f32x4 v = reinterpret_cast<const f32x4 *>(offs_acc)[i];
+          vy = v[0]; vx = v[1]; vm = v[2];
+        } else {
+          const float2 v = reinterpret_cast<const float2 *>(offs_acc)[i];
+          vy = v.x; vx = v.y;
+        }
         if (whole) {
           const int px = tile_px0 + col;
           if (px < HoWo) {
             float *dst = p.goff + ((long long)tile_b * 2 * K + 2 * t) * HoWo + px;
-            dst[0] = v.x;
-            dst[HoWo] = v.y;
+            dst[0] = vy;
+            dst[HoWo] = vx;
+            if constexpr (MASK) p.gmask[((long long)tile_b * K + t) * HoWo + px] = vm;
           }
+        } else if constexpr (MASK) {
+          reinterpret_cast<f32x4 *>(slab)[i] = f32x4{vy, vx, vm, 0.f};
         } else {
-          reinterpret_cast<float2 *>(slab)[i] = v;
+          reinterpret_cast<float2 *>(slab)[i] = float2{vy, vx};
         }
       }
     }
@@ -320,8 +355,47 @@ template <int PARTS>
 __global__ __launch_bounds__(kOffThreads, 1) void dcn_bwd_offset_plane(const DcnFwdGroup grp, float *__restrict__ slabs,
                                                                        int max_K) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if (threadIdx.x >= kThreads) offset_role<PARTS, true>(grp, slabs, smem, max_K);
-  else offset_role<PARTS, false>(grp, slabs, smem, max_K);
+  if (threadIdx.x >= kThreads) offset_role<PARTS, true, false>(grp, slabs, smem, max_K);
+  else offset_role<PARTS, false, false>(grp, slabs, smem, max_K);
+}
+
+// modulated (v2) problems: grad_offset and grad_mask (static ranges only; split operands only)
+__global__ __launch_bounds__(kOffThreads, 1) void dcn_bwd_offset_plane_masked(const DcnFwdGroup grp, float *__restrict__ slabs,
+                                                                              int max_K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (threadIdx.x >= kThreads) offset_role<2, true, true>(grp, slabs, smem, max_K);
+  else offset_role<2, false, true>(grp, slabs, smem, max_K);
+}
+
+// v2, static ranges: add the parts' slabs (float4 per (tap, pixel)) in order.  grid = (tiles, 8)
+__global__ __launch_bounds__(256) void dcn_bwd_offset_plane_fixup_masked(const DcnFwdGroup grp, const float *__restrict__ slabs,
+                                                                         int G, int max_K) {
+  const int gtile = blockIdx.x;
+  int pi = 0;
+  while (pi + 1 < grp.n && gtile >= grp.tile_begin[pi + 1]) ++pi;
+  const DcnProblem &p = grp.p[pi];
+  if (p.kparts == 1) return;  // written directly
+  const int tile = gtile - grp.tile_begin[pi];
+  const size_t slab_floats = (size_t)max_K * kTileN * 4;
+  const int tiles = p.n_ntiles * p.n_mtiles;
+  const int tb = tile / p.tiles_per_image, px0 = (tile - tb * p.tiles_per_image) * kTileN;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < p.K * kTileN; i += gridDim.y * 256) {
+    float sy = 0.f, sx = 0.f, sm = 0.f;
+    for (int part = 0; part < p.kparts; ++part) {
+      const int range = grp.range_begin[pi] + part * tiles + tile;
+      const f32x4 v = reinterpret_cast<const f32x4 *>(slabs + (size_t)sk_block_of_slice(range, G) * grp.slots * slab_floats)[i];
+      sy += v[0];
+      sx += v[1];
+      sm += v[2];
+    }
+    const int t = i / kTileN, px = px0 + (i - t * kTileN);
+    if (px < p.HoWo) {
+      float *dst = p.goff + ((long long)tb * 2 * p.K + 2 * t) * p.HoWo + px;
+      dst[0] = sy;
+      dst[p.HoWo] = sx;
+      p.gmask[((long long)tb * p.K + t) * p.HoWo + px] = sm;
+    }
+  }
 }
 
 template __global__ void dcn_bwd_offset_plane<1>(const DcnFwdGroup grp, float *__restrict__ slabs, int max_K);

@@ -60,6 +60,7 @@ struct DcnProblem {
   float *out;           // forward: [N, O_total, Ho, Wo]
   const float *gout;    // grad_offset kernel: grad_output [N, O_total, Ho, Wo]
   float *goff;          //                     grad_offset [N, 2K, Ho, Wo]
+  float *gmask;         //                     grad_mask [N, K, Ho, Wo] (v2: `mask` set) or nullptr
   int N, C_total, c_base, Cg, Cg_pad;
   int O_total, o_base, Og, Og_pad;  // o_base: first channel of this group inside the output buffer
   int bias_base;                    // first channel of this group in the conv's own numbering

@@ -32,7 +32,9 @@ template <int PARTS>
 __global__ void dcn_bwd_offset_plane(const DcnFwdGroup grp, float *__restrict__ slabs, int max_K);
 __global__ void dcn_bwd_offset_plane_fixup(const DcnFwdGroup grp, const float *__restrict__ slabs, int G, int max_K);
 __global__ void dcn_build_grad_taps(const DcnFwdGroup grp);
-size_t dcn_bwd_offset_plane_lds_bytes(int parts, int K, int HW);
+size_t dcn_bwd_offset_plane_lds_bytes(int parts, int K, int HW, int masked = 0);
+__global__ void dcn_bwd_offset_plane_masked(const DcnFwdGroup grp, float *__restrict__ slabs, int max_K);
+__global__ void dcn_bwd_offset_plane_fixup_masked(const DcnFwdGroup grp, const float *__restrict__ slabs, int G, int max_K);
 int dcn_bwd_offset_plane_threads();
 // grad_weight on an LDS-resident plane (dcn_backward_weight_plane.hip)
 template <int PARTS>

@@ -180,7 +180,9 @@ def pack_weight(weight, shape):
     whenever a DeformConv module changes mode (``model.train()`` / ``model.eval()``) and by clear_pack_cache()."""
     cacheable = _inference_depth > 0
     L = _lib.lib()
-    nbytes = L.kgdet_dcn_packed_weight_bytes(ctypes.byref(shape))   # (which images exist depends on the map size)
+    nbytes = L.kgdet_dcn_packed_weight_bytes(ctypes.byref(shape))
+    # (the packed images depend on the weight alone, never on the map size or the batch: one pack serves every pyramid
+    # level -- csrc/dcn_api.hip kgdet_dcn_pack_weight)
     key = (weight.data_ptr(), weight._version, shape.groups, shape.deformable_groups, tuple(weight.shape), nbytes)
     if cacheable:
         hit = _pack_cache.get(id(weight))

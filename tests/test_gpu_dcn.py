@@ -378,3 +378,30 @@ def test_more_tiles_than_slab_slots_take_the_safe_path():
     go_ = to.grad.cpu().numpy().astype(np.float64)
     scale = float(np.abs(ref['grad_offset']).max())
     assert float((np.abs(go_ - ref['grad_offset']) > 5e-5 * scale).mean()) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_cached_inference_pack_serves_every_map_size():
+    """Inference caches the packed weight images per weight tensor (kgdet_amd/dcn.py pack_weight); the serial head
+    applies ONE DeformConv weight to five pyramid levels.  A pack made for a map too large for the LDS-plane kernels
+    must still carry the bf16 plane images the small levels read (it once did not: freshly allocated memory reads as
+    zeros, recycled memory as whatever was there -- so the allocator's free blocks are filled with NaN first)."""
+    _require_gpu()
+    from kgdet_amd import dcn
+    torch.manual_seed(3)
+    w = torch.randn(256, 256, 3, 3, device='cuda') * 0.01
+    maps = [(100, 168), (25, 42), (7, 11)]
+    xs = [torch.randn(2, 256, h, ww, device='cuda') for h, ww in maps]
+    offs = [torch.randn(2, 18, h, ww, device='cuda') for h, ww in maps]
+    with torch.no_grad():
+        want = []
+        for x, o in zip(xs, offs):          # one pack per call: the reference
+            dcn.clear_pack_cache()
+            want.append(dcn.deform_conv_cat(x, [o], [w], [1]).clone())
+        dcn.clear_pack_cache()
+        junk = [torch.full((32 * 1024 * 1024,), float('nan'), device='cuda') for _ in range(8)]
+        del junk
+        got = [dcn.deform_conv_cat(x, [o], [w], [1]) for x, o in zip(xs, offs)]     # large map first, pack cached
+    for g, wnt in zip(got, want):
+        assert torch.isfinite(g).all()
+        assert torch.equal(g, wnt)
