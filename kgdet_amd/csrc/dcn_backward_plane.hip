@@ -140,26 +140,9 @@ __global__ __launch_bounds__(256) void dcn_build_inverse_taps(const DcnProblem p
     }
   }
   __syncthreads();
-  // inline records: the first 8 contributions of every cell; pixel -> LDS byte offset of its quad 0
+  // pixel -> LDS byte offset of its quad 0 (< 2^17: the upper 15 bits of a record's last offset are free)
   auto plane_off = [](int px) { return (unsigned)(dcn_plane_offset(px) + (((px >> 2) & 3) << 4)); };
   uint4 *inv_bt = inv + (size_t)(b * p.K + t) * HW * 4;
-  for (int cell = tid; cell < HW; cell += 256) {
-    const int n = cnt[cell], e0 = cursor[cell] - n;
-    unsigned off[8];
-    float w[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int2 e = ent[e0 + min(i, max(n - 1, 0))];
-      off[i] = i < n ? plane_off(e.x) : 0u;
-      w[i] = i < n ? __int_as_float(e.y) : 0.0f;
-    }
-    uint4 *r = inv_bt + (size_t)cell * 4;
-    r[0] = make_uint4(off[0], off[1], off[2], off[3]);
-    r[1] = make_uint4(off[4], off[5], off[6], off[7]);
-    r[2] = make_uint4(__float_as_uint(w[0]), __float_as_uint(w[1]), __float_as_uint(w[2]), __float_as_uint(w[3]));
-    r[3] = make_uint4(__float_as_uint(w[4]), __float_as_uint(w[5]), __float_as_uint(w[6]), __float_as_uint(w[7]));
-  }
-  __syncthreads();
   // overflow: contributions 8.. of every cell, compacted in cell order; `cursor` becomes their start positions
   for (int cell = tid; cell < HW; cell += 256) {
     const int n = cnt[cell];
@@ -173,6 +156,33 @@ __global__ __launch_bounds__(256) void dcn_build_inverse_taps(const DcnProblem p
   for (int cell = tid; cell < HW; cell += 256) extra[cell] = cnt[cell] >> 16;
   __syncthreads();
   scan(extra, epos);
+  // inline records: the first 8 contributions of every cell.  The last offset also carries the cell's overflow range
+  // -- count (5 bits) << 27 | start inside the (tile, tap)'s list (10 bits) << 17 -- so that a producer thread of the
+  // grad_input kernel walks ITS OWN overflow entries instead of scanning the whole list (one dependent scalar load +
+  // a divergent body per entry: 360 us against 210 for a head stage with N(0, 2^2)-pixel offsets).  A tile whose ranges
+  // do not fit the fields gets a negative count: list scan, as before.
+  int *tile_scan = epos + HW;     // [16] tiles whose ranges do not fit the fields (H*W <= 1536: at most 12 tiles)
+  if (tid < 16) tile_scan[tid] = 0;
+  __syncthreads();
+  for (int cell = tid; cell < HW; cell += 256) {
+    const int n = cnt[cell] & 0xffff, ne = cnt[cell] >> 16, e0 = cursor[cell];
+    const int st = epos[cell] - epos[(cell / kTileN) * kTileN];
+    if (ne > 31 || st + ne > 1023) tile_scan[cell / kTileN] = 1;
+    unsigned off[8];
+    float w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int2 e = ent[e0 + min(i, max(n - 1, 0))];
+      off[i] = i < n ? plane_off(e.x) : plane_off(0);   // (weight 0; a plane address all the same: 0 x garbage could be NaN)
+      w[i] = i < n ? __int_as_float(e.y) : 0.0f;
+    }
+    off[7] |= ((unsigned)min(ne, 31) << 27) | ((unsigned)min(st, 1023) << 17);
+    uint4 *r = inv_bt + (size_t)cell * 4;
+    r[0] = make_uint4(off[0], off[1], off[2], off[3]);
+    r[1] = make_uint4(off[4], off[5], off[6], off[7]);
+    r[2] = make_uint4(__float_as_uint(w[0]), __float_as_uint(w[1]), __float_as_uint(w[2]), __float_as_uint(w[3]));
+    r[3] = make_uint4(__float_as_uint(w[4]), __float_as_uint(w[5]), __float_as_uint(w[6]), __float_as_uint(w[7]));
+  }
   uint2 *spill_bt = spill + (size_t)(b * p.K + t) * 4 * p.HoWo;
   DcnInvOvfSlots *slots_bt = slots + (size_t)(b * p.K + t) * n_tiles;
   for (int cell = tid; cell < HW; cell += 256) {
@@ -193,13 +203,13 @@ __global__ __launch_bounds__(256) void dcn_build_inverse_taps(const DcnProblem p
     const int s0 = epos[tile * kTileN];
     const int last = min((tile + 1) * kTileN, HW) - 1;
     const int s1 = epos[last] + extra[last];
-    slots_bt[tile].count = s1 - s0;
+    slots_bt[tile].count = tile_scan[tile] ? -(s1 - s0) : s1 - s0;   // < 0: ranges not in the records, scan the list
     slots_bt[tile].spill_start = (int)((size_t)(b * p.K + t) * 4 * p.HoWo) + s0;
   }
 }
 
 size_t dcn_build_inverse_taps_lds_bytes(int HW, int HoWo) {
-  return ((size_t)2 * HW + 2) * sizeof(int) + (size_t)4 * HoWo * 8 + (size_t)2 * HW * sizeof(int);
+  return ((size_t)2 * HW + 2) * sizeof(int) + (size_t)4 * HoWo * 8 + (size_t)2 * HW * sizeof(int) + 16 * sizeof(int);
 }
 
 }  // namespace kgdet

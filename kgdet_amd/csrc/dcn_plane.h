@@ -247,7 +247,9 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       typedef float f32x2 __attribute__((ext_vector_type(2)));
       typedef f32x4 Corners[2][4];
       auto corner_reads = [&](const Regs &R, int gq, int half, Corners &v) {
-        const unsigned o[4] = {R.off[gq].x, R.off[gq].y, R.off[gq].z, R.off[gq].w};
+        // (MODE 1: the upper bits of a record's last offset hold the cell's overflow range)
+        const unsigned o[4] = {R.off[gq].x, R.off[gq].y, R.off[gq].z,
+                               (MODE == 1 && gq == NG - 1) ? (R.off[gq].w & 0x1ffffu) : R.off[gq].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -315,20 +317,28 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
           corner_fma(R, gq, v, sv, gq == 0);
         }
         if constexpr (MODE == 1) {
-          // contributions beyond the 8 inline ones: the (tile, tap)'s overflow list (a cell with more than 8
-          // contributing (pixel, corner) pairs for one tap: rare); every thread scans it (uniform trip count, the
-          // entries come through the scalar / L2 path) and adds the entries of its own cell
-          const uint2 *spill = p.inv_spill + R.ovf.y;
-          for (int i = 0; i < R.ovf.x; ++i) {
-            const uint2 e = spill[i];
-            if ((int)(e.x & 127u) == n_local) {
-              const float w = __uint_as_float(e.y);
+          // contributions beyond the 8 inline ones (a cell with more than 8 contributing (pixel, corner) pairs for one
+          // tap) sit in the (tile, tap)'s overflow list, in cell order; a cell's range of it is in the record
+          // (dcn_build_inverse_taps), so a thread walks its own entries: a short divergent loop
+          auto add_entry = [&](const uint2 e) {
+            const float w = __uint_as_float(e.y);
 #pragma unroll
-              for (int c = 0; c < 2; ++c) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(plane + ((e.x >> 7) ^ (unsigned)((half * 2 + c) << 4)));
-                sv[c][0] += f32x2{w * v[0], w * v[1]};
-                sv[c][1] += f32x2{w * v[2], w * v[3]};
-              }
+            for (int c = 0; c < 2; ++c) {
+              const f32x4 v = *reinterpret_cast<const f32x4 *>(plane + ((e.x >> 7) ^ (unsigned)((half * 2 + c) << 4)));
+              sv[c][0] += f32x2{w * v[0], w * v[1]};
+              sv[c][1] += f32x2{w * v[2], w * v[3]};
+            }
+          };
+          if (R.ovf.x > 0) {
+            const unsigned pk = R.off[NG - 1].w;
+            const int cnt = (int)(pk >> 27);
+            const uint2 *mine = p.inv_spill + R.ovf.y + ((pk >> 17) & 1023u);
+            for (int i = 0; i < cnt; ++i) add_entry(mine[i]);
+          } else if (R.ovf.x < 0) {   // ranges that do not fit the record's fields: every thread scans the list
+            const uint2 *spill = p.inv_spill + R.ovf.y;
+            for (int i = 0; i < -R.ovf.x; ++i) {
+              const uint2 e = spill[i];
+              if ((int)(e.x & 127u) == n_local) add_entry(e);
             }
           }
         }

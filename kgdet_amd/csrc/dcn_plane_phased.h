@@ -151,7 +151,8 @@ __device__ __forceinline__ void plane_phased(const DcnFwdGroup &grp, float *__re
 
     // ---- sampling: corner offsets in the record are for quad 0; quad c of the same pixel is at offset ^ (c << 4)
     auto corner_reads = [&](const Regs &R, int gq, Corners &v) {
-      const unsigned o[4] = {R.off[gq].x, R.off[gq].y, R.off[gq].z, R.off[gq].w};
+      const unsigned o[4] = {R.off[gq].x, R.off[gq].y, R.off[gq].z,
+                             (MODE == 1 && gq == NG - 1) ? (R.off[gq].w & 0x1ffffu) : R.off[gq].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -203,7 +204,7 @@ __device__ __forceinline__ void plane_phased(const DcnFwdGroup &grp, float *__re
         // contributions beyond the 8 inline ones (a cell with more than 8 contributing (pixel, corner) pairs for one
         // tap: rare); every thread scans the list (uniform trip count) and adds the entries of its own cell
         const uint2 *spill = p.inv_spill + R.ovf.y;
-        for (int i = 0; i < R.ovf.x; ++i) {
+        for (int i = 0; i < (R.ovf.x < 0 ? -R.ovf.x : R.ovf.x); ++i) {   // (|count|: the list scan serves both encodings)
           const uint2 e = spill[i];
           if ((int)(e.x & 127u) == col) {
             const float w = __uint_as_float(e.y);
