@@ -104,7 +104,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
   // memory path of a CU takes 64 B per clock, and 32 KB of fragments per stage were 512 of its ~1000 cycles
   const int n_local = tid & (kTileN - 1);                     // producers: pixel column sampled
   // (wave-uniform role coordinates in SGPRs: scalar branches and no exec masking -- every VALU instruction of a producer
-  // costs its SIMD's MFMA waves issue slots, tools/micro/mfma_valu.hip)
+  // costs its SIMD's MFMA waves issue slots, tools/microbench/mfma_valu.hip)
   const int pair = __builtin_amdgcn_readfirstlane((tid >> 7) & 1);   // wave pair: samples stages pair, pair + 2 of a group
   const long long G = gridDim.x, g = blockIdx.x;
   const long long slice = sk_slice_of_block((int)g, (int)G);
@@ -377,7 +377,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         if constexpr (pipelined) {
           // three corner register sets: the reads of three half-stages are in flight before the first arithmetic (a batch
           // of 8 random ds_read_b128 comes back after ~840 cycles while the consumers read their B fragments, ~420
-          // alone -- in-kernel probe, tools/micro/lds_gather.hip -- against ~190 cycles of arithmetic per half-stage)
+          // alone -- in-kernel probe, tools/microbench/lds_gather.hip -- against ~190 cycles of arithmetic per half-stage)
           Corners V0, V1, V2;
           f32x2 sv[2][2];
           corner_reads(RA, 0, 0, V0);

@@ -4,7 +4,7 @@
 // barrier after each.
 //
 // Why phases and not producer / consumer waves running side by side (dcn_plane.h, the previous design; measured with
-// tools/micro/mfma_valu.hip on gfx950): a SIMD issues MFMAs and ordinary VALU instructions through ONE port.  Beside two
+// tools/microbench/mfma_valu.hip on gfx950): a SIMD issues MFMAs and ordinary VALU instructions through ONE port.  Beside two
 // waves that keep the MFMA pipe full, a third wave gets about one VALU instruction per MFMA slot -- the sampling
 // instruction mix ran 12x slower there (3340 instead of 274 cycles per half-stage, whatever its s_setprio) -- and every
 // instruction it does get costs the MFMA waves ~10 cycles.  In the side-by-side kernel that was ~1500 cycles per stage
