@@ -39,12 +39,29 @@ constexpr int kPart = 2 * kTM * 16;          // bytes of one part of one operand
 constexpr int kStage = 2 * kPart;            // hi + lo
 constexpr int kGemmThreads = 256;
 
+// hi = bf16(v), lo = bf16(v - hi) for a PAIR of values: one v_cvt_pk_bf16_f32 for the two hi parts, their float values
+// back by a shift and a mask of that dword, one packed subtraction, one v_cvt_pk_bf16_f32 for the lo parts -- 5
+// instructions per pair where scalar conversions take 7-8.  These kernels split operands on the fly beside their MFMAs,
+// and a SIMD issues both through one port (tools/microbench/mfma_valu.hip): every VALU instruction costs MFMA time.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair(float v0, float v1, unsigned &hi, unsigned &lo) {
+  const f32x2 v = {v0, v1};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  const f32x2 hf = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, bf16x2));
+}
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8 &hi, bf16x8 &lo) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 h, l;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    hi[i] = (__bf16)v[i];
-    lo[i] = (__bf16)(v[i] - (float)hi[i]);
+  for (int i = 0; i < 4; ++i) {
+    unsigned a, b;
+    split_pair(v[2 * i], v[2 * i + 1], a, b);
+    h[i] = a;
+    l[i] = b;
   }
+  hi = __builtin_bit_cast(bf16x8, h);
+  lo = __builtin_bit_cast(bf16x8, l);
 }
 
 // one stage of MFMAs: wave (wm, wn) multiplies its 64 x 64 block; operands from LDS stage buffers
@@ -233,16 +250,12 @@ __global__ __launch_bounds__(kNNThreads) void conv_nn(const unsigned char *__res
   auto commit = [&](int buf, const Regs &R) {
     unsigned char *As = smem + buf * 2 * kStage, *Bs = As + kStage;
     *reinterpret_cast<f32x4 *>(As + tid * 16) = R.a;
-    bf16x4 hi, lo;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float f = R.live ? R.v[j] : 0.0f;
-      hi[j] = (__bf16)f;
-      lo[j] = (__bf16)(f - (float)hi[j]);
-    }
+    uint2 hi, lo;
+    split_pair(R.live ? R.v[0] : 0.0f, R.live ? R.v[1] : 0.0f, hi.x, lo.x);
+    split_pair(R.live ? R.v[2] : 0.0f, R.live ? R.v[3] : 0.0f, hi.y, lo.y);
     unsigned char *dst = Bs + (kq >> 1) * (kTN * 16) + n_local * 16 + (kq & 1) * 8;
-    *reinterpret_cast<bf16x4 *>(dst) = hi;
-    *reinterpret_cast<bf16x4 *>(dst + kPart) = lo;
+    *reinterpret_cast<uint2 *>(dst) = hi;
+    *reinterpret_cast<uint2 *>(dst + kPart) = lo;
   };
   auto multiply = [&](int buf) {   // wave (wm, wn): rows wm*64 .. +63, columns wn*32 .. +31
     const unsigned char *A = smem + buf * 2 * kStage + (lane >> 5) * (kTM * 16) + (wm * 64 + (lane & 31)) * 16;
@@ -580,23 +593,24 @@ __device__ __forceinline__ void conv_nt8_body(const float *__restrict__ a, const
       w0 = R.p0 - h * W;
       row_ok = row_ok && h + dy >= 0 && h + dy < H;
     }
-    bf16x4 ahi, alo, bhi, blo;
+    float fa[4], fb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float fa = (in_img && a_real) ? R.va[i] : 0.0f;
-      ahi[i] = (__bf16)fa;
-      alo[i] = (__bf16)(fa - (float)ahi[i]);
+      fa[i] = (in_img && a_real) ? R.va[i] : 0.0f;
       const int col = w0 + i + dx;
       const bool ok = TAPS == 9 ? (row_ok && col >= 0 && col < W) : row_ok;
-      const float fb = ok ? R.vb[i + (TAPS == 9 ? sh : 0)] : 0.0f;
-      bhi[i] = (__bf16)fb;
-      blo[i] = (__bf16)(fb - (float)bhi[i]);
+      fb[i] = ok ? R.vb[i + (TAPS == 9 ? sh : 0)] : 0.0f;
     }
+    uint2 ahi, alo, bhi, blo;
+    split_pair(fa[0], fa[1], ahi.x, alo.x);
+    split_pair(fa[2], fa[3], ahi.y, alo.y);
+    split_pair(fb[0], fb[1], bhi.x, blo.x);
+    split_pair(fb[2], fb[3], bhi.y, blo.y);
     const int o = (q >> 1) * (kTM * 16) + row * 16 + (q & 1) * 8;
-    *reinterpret_cast<bf16x4 *>(As + o) = ahi;
-    *reinterpret_cast<bf16x4 *>(As + kPart + o) = alo;
-    *reinterpret_cast<bf16x4 *>(Bs + o) = bhi;
-    *reinterpret_cast<bf16x4 *>(Bs + kPart + o) = blo;
+    *reinterpret_cast<uint2 *>(As + o) = ahi;
+    *reinterpret_cast<uint2 *>(As + kPart + o) = alo;
+    *reinterpret_cast<uint2 *>(Bs + o) = bhi;
+    *reinterpret_cast<uint2 *>(Bs + kPart + o) = blo;
   };
   auto multiply = [&](int buf) {   // wave (wm, wn): rows wm*64 .. +63, columns wn*32 .. +31
     const unsigned char *A = smem + buf * 2 * kStage + (lane >> 5) * (kTM * 16) + (wm * 64 + (lane & 31)) * 16;
