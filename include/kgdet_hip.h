@@ -58,7 +58,8 @@ int kgdet_conv_apply_epilogue(const void *packed, const float *x, float *y, cons
 size_t kgdet_conv1x1_grad_weight_workspace_bytes(int64_t B, int32_t O, int32_t C, int64_t HW);
 int kgdet_conv1x1_grad_weight(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O, int32_t C,
                               int64_t HW, void *workspace, size_t workspace_bytes, void *stream);
-/* 3x3 (stride 1, padding 1): grad_w [O, C, 3, 3]; needs C % 128 == 0 and W % 4 == 0 (else KGDET_E_UNSUPPORTED). */
+/* 3x3 (stride 1, padding 1): grad_w [O, C, 3, 3]; needs C % 128 == 0 (else KGDET_E_UNSUPPORTED).  W % 4 != 0: both operands are
+ * copied into the workspace with zero columns up to a multiple of 4 (one launch) first. */
 size_t kgdet_conv3x3_grad_weight_workspace_bytes(int64_t B, int32_t O, int32_t C, int32_t H, int32_t W);
 int kgdet_conv3x3_grad_weight(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O, int32_t C,
                               int32_t H, int32_t W, void *workspace, size_t workspace_bytes, void *stream);

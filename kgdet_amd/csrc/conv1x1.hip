@@ -858,23 +858,60 @@ extern "C" int kgdet_conv1x1_grad_weight(const float *grad_y, const float *x, fl
   return KGDET_OK;
 }
 
+// rows of W floats -> rows of Wp floats, zero tail, for two tensors in one launch (blockIdx.y: 0 = a, 1 = b)
+__global__ __launch_bounds__(256) void pad_rows2(const float *__restrict__ a, float *__restrict__ ap, long long rows_a,
+                                                 const float *__restrict__ b, float *__restrict__ bp, long long rows_b, int W,
+                                                 int Wp) {
+  const float *src = blockIdx.y ? b : a;
+  float *dst = blockIdx.y ? bp : ap;
+  const long long n = (blockIdx.y ? rows_b : rows_a) * Wp;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long r = i / Wp;
+    const int c = (int)(i - r * Wp);
+    dst[i] = c < W ? src[r * W + c] : 0.0f;
+  }
+}
+
 extern "C" size_t kgdet_conv3x3_grad_weight_workspace_bytes(int64_t B, int32_t O, int32_t C, int32_t H, int32_t W) {
   if (B <= 0 || O <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+  const int Wp = (W + 3) & ~3;
   const int tiles = ((O + kTM - 1) / kTM) * (9 * C / kTN);
-  const int stages = (int)(B * (((long long)H * W + kTK - 1) / kTK));
-  return (size_t)nt_splits(tiles, stages) * O * C * 9 * sizeof(float);
+  const int stages = (int)(B * (((long long)H * Wp + kTK - 1) / kTK));
+  size_t bytes = (size_t)nt_splits(tiles, stages) * O * C * 9 * sizeof(float);
+  if (Wp != W) bytes = ((bytes + 255) & ~(size_t)255) + (size_t)B * (O + C) * H * Wp * sizeof(float);   // padded copies of grad_y and x
+  return bytes;
 }
 
 extern "C" int kgdet_conv3x3_grad_weight(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O,
                                          int32_t C, int32_t H, int32_t W, void *workspace, size_t workspace_bytes,
                                          void *stream) {
-  KGDET_CHECK_SHAPE(B > 0 && O > 0 && C > 0 && H > 0 && W > 0 && (long long)H * W < (1LL << 23), "bad sizes");
-  if (C % kTN != 0 || W % 4 != 0) {
-    set_error("conv3x3_grad_weight needs C %% 128 == 0 and W %% 4 == 0 (C=%d, W=%d)", C, W);
+  KGDET_CHECK_SHAPE(B > 0 && O > 0 && C > 0 && H > 0 && W > 0 && (long long)H * (W + 3) < (1LL << 23), "bad sizes");
+  if (C % kTN != 0) {
+    set_error("conv3x3_grad_weight needs C %% 128 == 0 (C=%d)", C);
     return KGDET_E_UNSUPPORTED;
   }
   KGDET_CHECK_SHAPE(grad_y && x && grad_w && workspace, "null pointer");
   KGDET_CHECK_SHAPE(workspace_bytes >= kgdet_conv3x3_grad_weight_workspace_bytes(B, O, C, H, W), "workspace too small");
+  if (W % 4) {
+    // the kernel's 16-byte row loads need W % 4 == 0 (25 x 42 head / FPN maps): zero columns on the right of BOTH operands
+    // change nothing -- grad_y is 0 there, and x's zeros are what the out-of-range taps read anyway.  One launch pads both
+    // into the tail of the workspace.
+    const int Wp = (W + 3) & ~3;
+    const int tiles_ = ((O + kTM - 1) / kTM) * (9 * C / kTN);
+    const int stages_ = (int)(B * (((long long)H * Wp + kTK - 1) / kTK));
+    const size_t part = ((size_t)nt_splits(tiles_, stages_) * O * C * 9 * sizeof(float) + 255) & ~(size_t)255;
+    float *gyp = reinterpret_cast<float *>(static_cast<unsigned char *>(workspace) + part);
+    float *xp = gyp + (size_t)B * O * H * Wp;
+    const long long rows_a = (long long)B * O * H, rows_b = (long long)B * C * H;
+    const long long most = (rows_a > rows_b ? rows_a : rows_b) * Wp;
+    const long long blocks = (most + 255) / 256;
+    hipLaunchKernelGGL(pad_rows2, dim3((unsigned)(blocks > 4096 ? 4096 : blocks), 2), dim3(256), 0, (hipStream_t)stream,
+                       grad_y, gyp, rows_a, x, xp, rows_b, W, Wp);
+    KGDET_CHECK_LAUNCH("pad_rows2");
+    grad_y = gyp;
+    x = xp;
+    W = Wp;
+  }
   const int HW = H * W;
   const int n_mt = (O + kTM - 1) / kTM, n_nt = 9 * C / kTN, tiles = n_mt * n_nt;
   const int spi = (HW + kTK - 1) / kTK, total = (int)(B * spi);
