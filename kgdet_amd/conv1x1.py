@@ -207,8 +207,8 @@ def grad_weight(x, weight, gy):
         _lib.check(L.kgdet_conv3x3_grad_weight(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), B, O, C, H, W,
                                                ws.data_ptr(), nbytes, _stream()), 'conv3x3_grad_weight')
         return gw
-    if k != 1 or (x.shape[2] * x.shape[3]) % 4 != 0:
-        # other 3x3 shapes, and the 8-byte-load variant of the 1x1 kernel (small odd maps, e.g. 25 x 42): MIOpen
+    if k != 1 or ((x.shape[2] * x.shape[3]) % 4 != 0 and not PAD_GRAD_WEIGHT_3X3):
+        # other 3x3 shapes: MIOpen.  (1x1 on maps with H*W % 4 != 0, e.g. 25 x 42: the library pads both operands)
         return torch.nn.grad.conv2d_weight(x, weight.shape, gy, padding=k // 2)
     B, HW = x.shape[0], x.shape[2] * x.shape[3]
     nbytes = _size('kgdet_conv1x1_grad_weight_workspace_bytes', B, O, C, HW)

@@ -11,7 +11,7 @@
 //
 //   forward      y[b] (O x HoWo) = W (O x C*taps) . patches(x[b])                conv_nn<1 | 9>, A = packed W
 //   grad_input   gx[b] (C x HW)  = W^T, taps mirrored . patches(gy[b])           conv_nn<1 | 9>, A = packed W^T (stride 1)
-//   grad_weight  gW (O x C*taps) = sum_b gy[b] (O x HW) . patches(x[b])^T        conv_nt8<1 | 9> (+ conv1x1_nt<2,1>)
+//   grad_weight  gW (O x C*taps) = sum_b gy[b] (O x HW) . patches(x[b])^T        conv_nt8<1 | 9> (maps with W or H*W % 4 != 0: zero-padded copies)
 //
 // conv_nn: 128 x 128 output tile, 512 threads = 8 waves as 2 (M) x 4 (N); reduction in stages of (16 channels, tap).
 //   A stage = 8 KB of the pre-split weight image [part][khalf][128 rows][8 bf16] (one 16-byte load per thread);
@@ -37,7 +37,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kTM = 128, kTN = 128, kTK = 16;
 constexpr int kPart = 2 * kTM * 16;          // bytes of one part of one operand stage: [khalf][128][8 bf16]
 constexpr int kStage = 2 * kPart;            // hi + lo
-constexpr int kGemmThreads = 256;
 
 // hi = bf16(v), lo = bf16(v - hi) for a PAIR of values: one v_cvt_pk_bf16_f32 for the two hi parts, their float values
 // back by a shift and a mask of that dword, one packed subtraction, one v_cvt_pk_bf16_f32 for the lo parts -- 5
@@ -364,177 +363,13 @@ __global__ __launch_bounds__(256) void conv3x3_wsum(const float *__restrict__ pa
   }
 }
 
-// partial[split][m][n] (natural [M, N] layout) = sum over this split's pixels (and images) of a[b][m][px] * bm[b][n][px]
-// a [B, M, L], bm [B, N, L], L contiguous.  The B * ceil(L / 16) stages are cut into `splits` runs of `per` stages; a
-// stage never straddles two images (the tail of an image is zero-filled).  VEC = floats per load (4 when L % 4 == 0).
-template <int VEC, int TAPS, int DX>
-__device__ __forceinline__ void conv1x1_nt_body(const float *__restrict__ a, const float *__restrict__ bm,
-                                                float *__restrict__ partial, int M, int N, int L, int B, int n_mt,
-                                                int n_nt, int stages_per_image, int per, int H, int W, int Cin,
-                                                unsigned char *smem) {
-  // TAPS == 9 (3x3, stride 1, padding 1): column n = t * Cin + c of the [M, 9 * Cin] result pairs a[.][m][p] with
-  // bm[.][c][p + shift(t)] (zero outside the image); Cin % 128 == 0, so a tile has ONE tap, and W % 4 == 0, so the
-  // row part of the shift keeps 16-byte alignment: a thread's 8 shifted pixels come out of three aligned 4-pixel loads.
-  // DX (the tap's column shift, uniform per tile) is a template parameter so that the selection has static indices.
-  typedef float vec_t __attribute__((ext_vector_type(VEC)));
-  const int tile = blockIdx.x % (n_mt * n_nt), split = blockIdx.x / (n_mt * n_nt);
-  const int mt = tile % n_mt, nt = tile / n_mt;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
-  const int row = tid >> 1, khalf = tid & 1;
-  const int total = B * stages_per_image;
-  const int s_begin = split * per, s_end = min(total, s_begin + per);
-  const int am = min(mt * kTM + row, M - 1);
-  const bool a_real = mt * kTM + row < M;
-  const int tap = TAPS == 9 ? (nt * kTN) / Cin : 0;
-  const int dy = TAPS == 9 ? tap / 3 - 1 : 0;
-  constexpr int dx = DX;
-  const int bcols = TAPS == 9 ? Cin : N;                               // rows of bm per image
-  const int bn_raw = TAPS == 9 ? nt * kTN - tap * Cin + row : nt * kTN + row;
-  const int bn = min(bn_raw, bcols - 1);
-  const bool b_real = bn_raw < bcols;
-  constexpr int off = dx < 0 ? -4 : 0, sh = dx - off;                  // element j of the 8 = loaded element j + sh
-  const float inv_w = 1.0f / (float)W;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  struct Regs {
-    float va[8], vb[TAPS == 9 ? 12 : 8];
-    int valid;   // pixels of this thread's 8 that exist (tail of an image)
-    int p0;
-  };
-  auto issue = [&](int s, Regs &R) {
-    const int sc = min(s, s_end - 1);
-    const int img = sc / stages_per_image, st = sc - img * stages_per_image;
-    const int p0 = st * kTK + khalf * 8;
-    R.valid = min(8, L - p0);
-    R.p0 = p0;
-    const float *ap = a + ((long long)img * M + am) * L, *bp = bm + ((long long)img * bcols + bn) * L;
-#pragma unroll
-    for (int j = 0; j < 8; j += VEC) {   // L % VEC == 0: the loads stay aligned; clamped at the image's end
-      const int p = min(p0 + j, L - VEC);
-      const vec_t u = *reinterpret_cast<const vec_t *>(ap + p);
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) R.va[j + e] = u[e];
-      if (TAPS == 1) {
-        const vec_t w = *reinterpret_cast<const vec_t *>(bp + p);
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) R.vb[j + e] = w[e];
-      }
-    }
-    if (TAPS == 9) {
-      const int base = p0 + dy * W + off;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {   // clamped chunks hold wrong pixels only where the tap is outside the image
-        const int q = min(max(base + 4 * k, 0), L - 4);
-        const f32x4 w = *reinterpret_cast<const f32x4 *>(bp + q);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) R.vb[4 * k + e] = w[e];
-      }
-    }
-  };
-  auto commit = [&](int buf, Regs &R) {
-    unsigned char *As = smem + buf * 2 * kStage, *Bs = As + kStage;
-    float vb[8];
-    if (TAPS == 9) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) vb[j] = R.vb[j + (TAPS == 9 ? sh : 0)];
-#pragma unroll
-      for (int ch = 0; ch < 2; ++ch) {   // a 4-pixel chunk lies in one image row (W % 4 == 0)
-        const int p = R.p0 + 4 * ch;
-        const int h = (int)(((float)p + 0.5f) * inv_w), w = p - h * W;
-        const bool row_ok = p < L && h + dy >= 0 && h + dy < H && b_real;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int col = w + i + dx;
-          vb[4 * ch + i] = (row_ok && col >= 0 && col < W) ? vb[4 * ch + i] : 0.0f;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) vb[j] = (j < R.valid && b_real) ? R.vb[j] : 0.0f;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) R.va[j] = (j < R.valid && a_real) ? R.va[j] : 0.0f;
-    bf16x8 hi, lo;
-    split8(R.va, hi, lo);
-    unsigned char *dst = As + khalf * (kTM * 16) + row * 16;
-    *reinterpret_cast<bf16x8 *>(dst) = hi;
-    *reinterpret_cast<bf16x8 *>(dst + kPart) = lo;
-    split8(vb, hi, lo);
-    dst = Bs + khalf * (kTN * 16) + row * 16;
-    *reinterpret_cast<bf16x8 *>(dst) = hi;
-    *reinterpret_cast<bf16x8 *>(dst + kPart) = lo;
-  };
-  constexpr int PF = 3;
-  const int n = s_end - s_begin;
-  if (n > 0) {
-    Regs R[PF];
-#pragma unroll
-    for (int i = 0; i < PF; ++i) issue(s_begin + i, R[i]);
-    commit(0, R[0]);
-    const int full = n / PF * PF;   // as in conv_nn: unguarded bodies in the main loop, load-free tail
-    for (int j0 = 0; j0 < full; j0 += PF) {
-#pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        const int j = j0 + u;
-        __syncthreads();
-        issue(s_begin + j + PF, R[u]);
-        const unsigned char *As = smem + (j & 1) * 2 * kStage;
-        mma_stage(As, As + kStage, lane, wm, wn, acc);
-        commit((j + 1) & 1, R[(u + 1) % PF]);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < PF - 1; ++u) {
-      const int j = full + u;
-      if (j < n) {
-        __syncthreads();
-        const unsigned char *As = smem + (j & 1) * 2 * kStage;
-        mma_stage(As, As + kStage, lane, wm, wn, acc);
-        if (j + 1 < n) commit((j + 1) & 1, R[u + 1]);
-      }
-    }
-  }
-  float *out = partial + (long long)split * M * N;
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int nn = nt * kTN + wn * 64 + ni * 32 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mt * kTM + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < M && nn < N) out[(long long)m * N + nn] = acc[mi][ni][r];
-      }
-    }
-}
-
-template <int VEC, int TAPS>
-__global__ __launch_bounds__(kGemmThreads) void conv1x1_nt(const float *__restrict__ a, const float *__restrict__ bm,
-                                                           float *__restrict__ partial, int M, int N, int L, int B,
-                                                           int n_mt, int n_nt, int stages_per_image, int per, int H,
-                                                           int W, int Cin) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * kStage];
-  if (TAPS == 9) {
-    const int tile = blockIdx.x % (n_mt * n_nt), nt = tile / n_mt;
-    const int dx = ((nt * kTN) / Cin) % 3 - 1;   // uniform: one tap per tile
-    if (dx < 0) conv1x1_nt_body<VEC, TAPS, -1>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, smem);
-    else if (dx == 0) conv1x1_nt_body<VEC, TAPS, 0>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, smem);
-    else conv1x1_nt_body<VEC, TAPS, 1>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, smem);
-  } else {
-    conv1x1_nt_body<VEC, TAPS, 0>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, smem);
-  }
-}
-
+// grad_weight kernels write partial[split][m][n] (natural [M, N] layout) = sum over the split's pixels (and images) of
+// a[b][m][px] * bm[b][n][px]; a [B, M, L], bm [B, N, L], L contiguous.  The B * ceil(L / 16) stages are cut into `splits`
+// runs of `per` stages; a stage never straddles two images (the tail of an image is zero-filled); conv1x1_sum /
+// conv3x3_wsum add the partials in fixed order.
 // conv_nt8: grad_weight with 512 threads (8 waves as 2 x 4, 64 x 32 outputs each, two per SIMD) for maps with
 // H*W % 4 == 0.  A thread owns (row, 4-pixel quarter of the stage): one 16-byte load per operand (TAPS == 9 with a
-// column shift: two aligned loads + a static selection), 8-byte LDS writes.  Same partial / sum scheme as conv1x1_nt.
+// column shift: two aligned loads + a static selection), 8-byte LDS writes.  
 template <int TAPS, int DX>
 __device__ __forceinline__ void conv_nt8_body(const float *__restrict__ a, const float *__restrict__ bm,
                                               float *__restrict__ partial, int M, int N, int L, int B, int n_mt, int n_nt,
@@ -824,40 +659,6 @@ extern "C" int kgdet_conv_apply(const void *packed, const float *x, float *y, in
                                    workspace_bytes, stream);
 }
 
-extern "C" size_t kgdet_conv1x1_grad_weight_workspace_bytes(int64_t B, int32_t O, int32_t C, int64_t HW) {
-  if (B <= 0 || O <= 0 || C <= 0 || HW <= 0) return 0;
-  const int tiles = ((O + kTM - 1) / kTM) * ((C + kTN - 1) / kTN);
-  const int stages = (int)(B * ((HW + kTK - 1) / kTK));
-  return (size_t)nt_splits(tiles, stages) * O * C * sizeof(float);
-}
-
-extern "C" int kgdet_conv1x1_grad_weight(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O,
-                                         int32_t C, int64_t HW, void *workspace, size_t workspace_bytes,
-                                         void *stream) {
-  KGDET_CHECK_SHAPE(B > 0 && O > 0 && C > 0 && HW > 0 && HW < (1LL << 30), "bad sizes");
-  KGDET_CHECK_SHAPE(HW % 2 == 0, "H*W = %lld must be even (8-byte loads)", (long long)HW);
-  KGDET_CHECK_SHAPE(grad_y && x && grad_w && workspace, "null pointer");
-  KGDET_CHECK_SHAPE(workspace_bytes >= kgdet_conv1x1_grad_weight_workspace_bytes(B, O, C, HW), "workspace too small");
-  const int n_mt = (O + kTM - 1) / kTM, n_nt = (C + kTN - 1) / kTN, tiles = n_mt * n_nt;
-  const int spi = (int)((HW + kTK - 1) / kTK), total = (int)(B * spi);
-  const int splits = nt_splits(tiles, total);
-  const int per = (total + splits - 1) / splits;
-  KGDET_CHECK_SHAPE(((long long)O * C) % 2 == 0, "O*C must be even");
-  if (HW % 4 == 0)
-    hipLaunchKernelGGL(conv_nt8<1>, dim3(tiles * splits), dim3(kNNThreads), 0, (hipStream_t)stream, grad_y, x,
-                       (float *)workspace, O, C, (int)HW, (int)B, n_mt, n_nt, spi, per, 1, (int)HW, 0);
-  else
-    hipLaunchKernelGGL((conv1x1_nt<2, 1>), dim3(tiles * splits), dim3(kGemmThreads), 0, (hipStream_t)stream, grad_y, x,
-                       (float *)workspace, O, C, (int)HW, (int)B, n_mt, n_nt, spi, per, 0, 0, 0);
-  KGDET_CHECK_LAUNCH("conv1x1_nt");
-  const long long n = (long long)O * C;
-  const long long blocks = (n / 2 + 255) / 256;
-  hipLaunchKernelGGL(conv1x1_sum, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, (hipStream_t)stream,
-                     (const float *)workspace, grad_w, n, n, splits);
-  KGDET_CHECK_LAUNCH("conv1x1_sum");
-  return KGDET_OK;
-}
-
 // rows of W floats -> rows of Wp floats, zero tail, for two tensors in one launch (blockIdx.y: 0 = a, 1 = b)
 __global__ __launch_bounds__(256) void pad_rows2(const float *__restrict__ a, float *__restrict__ ap, long long rows_a,
                                                  const float *__restrict__ b, float *__restrict__ bp, long long rows_b, int W,
@@ -870,6 +671,58 @@ __global__ __launch_bounds__(256) void pad_rows2(const float *__restrict__ a, fl
     const int c = (int)(i - r * Wp);
     dst[i] = c < W ? src[r * W + c] : 0.0f;
   }
+}
+
+extern "C" size_t kgdet_conv1x1_grad_weight_workspace_bytes(int64_t B, int32_t O, int32_t C, int64_t HW) {
+  if (B <= 0 || O <= 0 || C <= 0 || HW <= 0) return 0;
+  const long long HWp = (HW + 3) & ~3LL;
+  const int tiles = ((O + kTM - 1) / kTM) * ((C + kTN - 1) / kTN);
+  const int stages = (int)(B * ((HWp + kTK - 1) / kTK));
+  size_t bytes = (size_t)nt_splits(tiles, stages) * O * C * sizeof(float);
+  if (HWp != HW) bytes = ((bytes + 255) & ~(size_t)255) + (size_t)B * (O + C) * HWp * sizeof(float);   // padded copies of grad_y and x
+  return bytes;
+}
+
+extern "C" int kgdet_conv1x1_grad_weight(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O,
+                                         int32_t C, int64_t HW, void *workspace, size_t workspace_bytes,
+                                         void *stream) {
+  KGDET_CHECK_SHAPE(B > 0 && O > 0 && C > 0 && HW > 0 && HW < (1LL << 30), "bad sizes");
+  KGDET_CHECK_SHAPE(grad_y && x && grad_w && workspace, "null pointer");
+  KGDET_CHECK_SHAPE(workspace_bytes >= kgdet_conv1x1_grad_weight_workspace_bytes(B, O, C, HW), "workspace too small");
+  if (HW % 4) {
+    // 16-byte loads need H*W % 4 == 0 (25 x 42 = 1050): both operands go into the workspace with zero pixels up to a
+    // multiple of 4 (one launch; zero grad_y pixels contribute nothing).  The 8-byte-load kernel this replaces lost to
+    // MIOpen's GEMM (50-54 against 41-47 us).
+    const long long HWp = (HW + 3) & ~3LL;
+    const int tiles_ = ((O + kTM - 1) / kTM) * ((C + kTN - 1) / kTN);
+    const int stages_ = (int)(B * ((HWp + kTK - 1) / kTK));
+    const size_t part = ((size_t)nt_splits(tiles_, stages_) * O * C * sizeof(float) + 255) & ~(size_t)255;
+    float *gyp = reinterpret_cast<float *>(static_cast<unsigned char *>(workspace) + part);
+    float *xp = gyp + (size_t)B * O * HWp;
+    const long long rows_a = (long long)B * O, rows_b = (long long)B * C;
+    const long long most = (rows_a > rows_b ? rows_a : rows_b) * HWp;
+    const long long blocks = (most + 255) / 256;
+    hipLaunchKernelGGL(pad_rows2, dim3((unsigned)(blocks > 4096 ? 4096 : blocks), 2), dim3(256), 0, (hipStream_t)stream,
+                       grad_y, gyp, rows_a, x, xp, rows_b, (int)HW, (int)HWp);
+    KGDET_CHECK_LAUNCH("pad_rows2");
+    grad_y = gyp;
+    x = xp;
+    HW = HWp;
+  }
+  const int n_mt = (O + kTM - 1) / kTM, n_nt = (C + kTN - 1) / kTN, tiles = n_mt * n_nt;
+  const int spi = (int)((HW + kTK - 1) / kTK), total = (int)(B * spi);
+  const int splits = nt_splits(tiles, total);
+  const int per = (total + splits - 1) / splits;
+  KGDET_CHECK_SHAPE(((long long)O * C) % 2 == 0, "O*C must be even");
+  hipLaunchKernelGGL(conv_nt8<1>, dim3(tiles * splits), dim3(kNNThreads), 0, (hipStream_t)stream, grad_y, x,
+                     (float *)workspace, O, C, (int)HW, (int)B, n_mt, n_nt, spi, per, 1, (int)HW, 0);
+  KGDET_CHECK_LAUNCH("conv_nt8<1>");
+  const long long n = (long long)O * C;
+  const long long blocks = (n / 2 + 255) / 256;
+  hipLaunchKernelGGL(conv1x1_sum, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, (hipStream_t)stream,
+                     (const float *)workspace, grad_w, n, n, splits);
+  KGDET_CHECK_LAUNCH("conv1x1_sum");
+  return KGDET_OK;
 }
 
 extern "C" size_t kgdet_conv3x3_grad_weight_workspace_bytes(int64_t B, int32_t O, int32_t C, int32_t H, int32_t W) {
