@@ -219,9 +219,10 @@ def grad_weight(x, weight, gy):
     return gw
 
 
-def grad_input(weight, img_t, gy):
+def grad_input(weight, img_t, gy, residual=None):
+    """grad of ``conv(x, weight)`` with respect to x [+ residual: another gradient of x, added in the kernel's store]"""
     C, k = weight.shape[1], weight.shape[2]
-    return _apply(img_t if img_t is not None else _pack(weight, True), gy, C, k * k)
+    return _apply(img_t if img_t is not None else _pack(weight, True), gy, C, k * k, residual=residual)
 
 
 class _ConvSplit(torch.autograd.Function):
