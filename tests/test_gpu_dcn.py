@@ -405,3 +405,45 @@ def test_cached_inference_pack_serves_every_map_size():
     for g, wnt in zip(got, want):
         assert torch.isfinite(g).all()
         assert torch.equal(g, wnt)
+
+
+@pytest.mark.gpu
+def test_random_shapes_split_kernels_agree_with_exact_fp32():
+    """24 random problems (1-8 images, 16-256 channels, 16-512 filters, 1x1 ... 7x7 and non-square kernels, maps up to
+    32 x 40, v1 and v2, offset scales 0.3-3 pixels): forward and every gradient of the split-operand plane kernels against
+    the exact-fp32 kernels (`dcn.arithmetic('exact')`) to 1e-4 of each result's scale (measured: <= 9e-6).  Covers the
+    schedules the fixed cases do not: stream-K slices that start inside a channel chunk, static ranges of uneven parts,
+    first groups of one to four stages, tiles with dead pixel columns."""
+    _require_gpu()
+    from kgdet_amd import dcn
+    rng = np.random.default_rng(1)
+    kernels = [(1, 1), (3, 3), (3, 3), (5, 5), (7, 7), (3, 1), (1, 3)]
+    for case in range(24):
+        N = int(rng.integers(1, 9))
+        C = int(rng.choice([16, 32, 48, 64, 96, 128, 256]))
+        O = int(rng.choice([16, 32, 64, 128, 256, 512]))
+        kh, kw = kernels[int(rng.integers(0, 7))]
+        H, W = int(rng.integers(4, 33)), int(rng.integers(4, 41))
+        v2 = bool(rng.integers(0, 2))
+        sigma = float(rng.choice([0.3, 1.0, 3.0]))
+        g = torch.Generator(device='cpu').manual_seed(case)
+        x = torch.randn(N, C, H, W, generator=g).cuda()
+        off = (torch.randn(N, 2 * kh * kw, H, W, generator=g) * sigma).cuda()
+        w = (torch.randn(O, C, kh, kw, generator=g) * 0.05).cuda()
+        m = torch.rand(N, kh * kw, H, W, generator=g).cuda() if v2 else None
+        go = torch.randn(N, O, H, W, generator=g).cuda()
+        res = {}
+        for mode in ('split', 'exact'):
+            xs, os_, ws = x.clone().requires_grad_(), off.clone().requires_grad_(), w.clone().requires_grad_()
+            ms = m.clone().requires_grad_() if v2 else None
+            with dcn.arithmetic(mode):
+                if v2:
+                    out = dcn.modulated_deform_conv(xs, os_, ms, ws, None, 1, (kh // 2, kw // 2), 1, 1, 1)
+                else:
+                    out = dcn.deform_conv(xs, os_, ws, 1, (kh // 2, kw // 2), 1, 1, 1)
+                out.backward(go)
+            res[mode] = [out.detach(), xs.grad, os_.grad, ws.grad] + ([ms.grad] if v2 else [])
+        for name, a, b in zip(('out', 'grad_input', 'grad_offset', 'grad_weight', 'grad_mask'), res['split'], res['exact']):
+            assert torch.isfinite(a).all(), (case, name)
+            err = float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+            assert err < 1e-4, (case, name, err, (N, C, O, kh, kw, H, W, v2, sigma))
