@@ -15,14 +15,15 @@
 //     ds_read_b128; the reduction runs chunk-major / tap-minor and pixel tiles never straddle images.
 //   * sampling geometry is not recomputed per channel chunk: dcn_build_taps writes one 32-byte record per
 //     (image, tap, output pixel) -- four LDS byte offsets and four bilinear weights -- and the kernel only
-//     loads it.  With the split MFMA the kernel is VALU-issue bound (SQ counters: MFMA pipe 30 % busy,
-//     waves stalled on issue 34 % of the time), so instructions per sample are what matters.
-//   * 12 waves, two roles: waves 0-7 are CONSUMERS (they own the 256 x 128 accumulator tile as 4 x 2 waves
-//     of 64 x 64, read the B fragments from LDS, take their A (weight) fragments straight from the weight image in
-//     L2 -- 16 bytes per lane and fragment, two stages ahead in registers; KGDET_PLANE_A_FROM_L2=0 restores the LDS
-//     copy by the producers -- and issue the MFMAs), waves 8-11 are PRODUCERS (they build the next B stage: one
-//     thread samples 8 channels of one pixel).  The SIMD interleaves the roles' instruction streams; one barrier per
-//     stage hands the double-buffered stages over.
+//     loads it.  With the split MFMA the kernel is bound by the issue port MFMA and VALU instructions share (SQ
+//     counters of the final binary: MFMA pipe 47 % busy, waves waiting to issue 49 % of the time), so instructions per
+//     sample are what matters.
+//   * 12 waves, two roles: waves 0-7 are CONSUMERS (wave w owns rows [32 w, 32 w + 32) x 128 columns of the 256 x 128
+//     accumulator tile, reads the B fragments from LDS, takes its A (weight) fragments straight from the weight image in
+//     L2 -- 16 bytes per lane and fragment, two stages ahead in registers -- and issues the MFMAs), waves 8-11 are
+//     PRODUCERS in two wave pairs (a thread samples all 16 channels of one pixel for two of a group's four stages).  One
+//     barrier per group of four stages hands the double-buffered groups over.  (dcn_plane_phased.h: the measured,
+//     non-adopted alternative with sampling and MFMA phases instead of roles.)
 //
 // Operand images (the lane-linear fragment order a wave reads with one 16-byte load per lane):
 //   A stage (tap t, channel chunk c16, 256 output channels): [part][khalf][o 256][8 bf16]   8 KB / part

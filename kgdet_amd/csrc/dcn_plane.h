@@ -1,6 +1,6 @@
 // Shared body of the "plane" kernels (dcn_forward_plane.hip, dcn_backward_plane.hip): LDS-resident feature
-// plane, producer / consumer waves, bf16 hi/lo split MFMA, stream-K over (tile, stage) units, one workgroup barrier
-// per GROUP of three stages.  See dcn_forward_plane.hip for the design notes.
+// plane, producer / consumer waves, bf16 hi/lo split MFMA, static (problem, part, tile) ranges or stream-K over
+// (tile, stage) units, one workgroup barrier per GROUP of four stages.  See dcn_forward_plane.hip for the design notes.
 #pragma once
 #include <type_traits>
 
@@ -70,11 +70,11 @@ struct PlaneStageRegs {
 
 }  // namespace
 
-// Loop structure: a workgroup walks its stream-K slice range by range; inside a range the stages that share
-// a feature plane (one channel chunk, consecutive taps) form a SEGMENT.  A segment starts with the plane copy
-// and the priming of the register pipelines; its steady state is branch-free as far as vector-memory
-// instructions go -- loads are issued unconditionally from clamped addresses, so hipcc's counted
-// s_waitcnt vmcnt(N) stay exact.
+// Loop structure: a workgroup walks its slice range by range (static schedule: exactly one range); inside a range the
+// stages that share a feature plane (one channel chunk, consecutive taps) form a SEGMENT.  Only the first segment of a
+// range starts with a plane copy by all twelve waves: the next segment's plane and first tap records are loaded under
+// the LAST group of the segment before (see the segment loop).  Loads are issued unconditionally from clamped addresses,
+// so hipcc's counted s_waitcnt vmcnt(N) stay exact.
 //
 // Stages are handed from the producers to the consumers in GROUPS of kGroupTaps = 4.  The B buffer in LDS holds two
 // groups: while the consumers multiply the four stages of group g (their weight fragments arrive from L2 two
@@ -83,11 +83,13 @@ struct PlaneStageRegs {
 // Why (phase trace of the one-barrier-per-stage version, tools/plane_trace.py: cycles per workgroup, 187 stages):
 // both roles did ~1200 cycles of work per stage and each waited ~300 more at the barrier -- for the slowest of the
 // twelve waves, a different one every stage (random-gather bank conflicts, issue arbitration); a group averages
-// that skew over three stages.  Inside a group the producers issue the corner reads of a stage before the
-// arithmetic of the previous one (MODE 0), so the LDS latency of the random gather overlaps VALU work instead of
-// heading a dependent chain, and the consumers' B fragments of the next stage can be fetched under the MFMAs.
-// The producers are the youngest waves of the workgroup, i.e. the losers of every issue arbitration against the
-// two MFMA waves of their SIMD, and their work is latency-bound: they run at a raised static priority.
+// that skew over four stages.  Inside a group the producers keep the corner reads of three half-stages in flight
+// (MODE 0), so the LDS latency of the random gather overlaps VALU work instead of heading a dependent chain.
+// What bounds the kernel is the SIMD's single issue port for MFMA and other VALU instructions
+// (tools/microbench/mfma_valu.hip, profiles/r02_dcn_fwd_plane_group_b2.md): beside the two MFMA waves of its SIMD a
+// producer wave gets about one VALU instruction per MFMA slot whatever its priority (s_setprio 2 is kept: it costs
+// nothing), and each of its instructions costs the MFMA waves ~10 cycles -- hence scalar role ids, scalar-base loads, the
+// packed hi/lo split, record sets that alternate instead of being copied.
 // Stage coordinates are carried incrementally; there is no integer division in the loop.
 // The two roles are two instantiations of this function (same loop structure, same barriers), so the
 // accumulators exist only in the consumers' register allocation.
