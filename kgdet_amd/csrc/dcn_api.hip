@@ -92,10 +92,19 @@ size_t plan_plane_lds(DcnFwdGroup &grp, size_t single, size_t fixed) {
 // tile.  Measured on the head-stage forward (6 problems, B=2): fabric reads 883 -> 174 MB per launch, 265 -> 207 us.
 // Falls back to stream-K (static_ranges = 0, kparts = 1) when the ranges outnumber the workgroups or would be too
 // uneven.  Problems must have kparts == 1 on entry.
-void plan_static_ranges(DcnFwdGroup &grp, int G, bool force = false) {
+// max_rounds > 1 (forward / grad_input plane kernels): when a workgroup's share is long (B = 8 inference: 747 stages) the
+// ranges are cut to ~190 stages all the same and dealt in ROUNDS -- workgroup r computes ranges r, r + G, ... -- instead
+// of falling back to stream-K: every range still starts on a channel chunk, the tiles of one (problem, part) still run
+// together on one XCD, and the fix-up stays the cheap static one.
+void plan_static_ranges(DcnFwdGroup &grp, int G, bool force = false, int max_rounds = 1) {
   grp.static_ranges = 0;
+  grp.rounds = 1;
   const long long total = grp.unit_begin[grp.n];
-  const double share = (double)total / G;
+  static const int env_rounds = getenv("KGDET_DCN_ROUNDS") ? atoi(getenv("KGDET_DCN_ROUNDS")) : 0;   // A/B switch
+  if (env_rounds > 0 && max_rounds > 1) max_rounds = env_rounds;
+  int R = (int)((double)total / G / 220.0 + 0.999);
+  R = R < 1 ? 1 : (R > max_rounds ? max_rounds : R);
+  const double share = (double)total / G / R;   // target length of a range
   int ranges = 0;
   double longest = 0;
   int kp[kMaxFwdGroup];
@@ -110,6 +119,7 @@ void plan_static_ranges(DcnFwdGroup &grp, int G, bool force = false) {
   }
   static const bool off = getenv("KGDET_DCN_STREAMK") != nullptr;   // A/B switch
   if (force) {   // a kernel without a stream-K fix-up (v2 grad_offset): fewer, longer parts until the ranges fit
+    R = 1;
     while (ranges > G) {
       int worst = 0;
       for (int i = 1; i < grp.n; ++i)
@@ -118,10 +128,11 @@ void plan_static_ranges(DcnFwdGroup &grp, int G, bool force = false) {
       ranges -= grp.p[worst].n_ntiles * grp.p[worst].n_mtiles * (kp[worst] - (kp[worst] + 1) / 2);
       kp[worst] = (kp[worst] + 1) / 2;
     }
-  } else if (off || ranges > G || longest > 1.25 * share) {
+  } else if (off || ranges > R * G || longest > 1.25 * share) {
     return;
   }
   grp.static_ranges = 1;
+  grp.rounds = (ranges + G - 1) / G;
   for (int i = 0; i < grp.n; ++i) {
     grp.p[i].kparts = kp[i];
     grp.range_begin[i + 1] = grp.range_begin[i] + grp.p[i].n_ntiles * grp.p[i].n_mtiles * kp[i];
@@ -396,7 +407,7 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
   const int parts = (flags & KGDET_DCN_BF16) ? 1 : 2;
   auto flush = [&]() -> int {
     if (grp.n == 0) return KGDET_OK;
-    plan_static_ranges(grp, G);
+    plan_static_ranges(grp, G, false, kSlabSlots - 2);
     static thread_local bool attr_set = false;
     if (!attr_set) {
       KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_fwd_plane<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -596,7 +607,7 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
                                     dcn_bwd_input_plane_fixed_lds_bytes(parts));
   const int threads = dcn_fwd_plane_threads();
   grp.wave_layout = 1;   // plane_role's accumulator layout (slabs are decoded by dcn_fwd_fixup)
-  plan_static_ranges(grp, G);
+  plan_static_ranges(grp, G, false, kSlabSlots - 2);
   if (parts == 1)
     hipLaunchKernelGGL(dcn_bwd_input_plane<1>, dim3(G), dim3(threads), lds, (hipStream_t)stream, grp, (float *)workspace);
   else
@@ -816,7 +827,7 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
   if (!check_slots(grp)) { set_error("group too uneven for the slab slots"); return KGDET_E_UNSUPPORTED; }
   lds = plan_plane_lds(grp, lds, dcn_bwd_input_plane_fixed_lds_bytes(2));
   grp.wave_layout = 1;   // plane_role's accumulator layout (slabs are decoded by dcn_fwd_fixup)
-  plan_static_ranges(grp, G);
+  plan_static_ranges(grp, G, false, kSlabSlots - 2);
   hipLaunchKernelGGL(dcn_bwd_input_plane<2>, dim3(G), dim3(dcn_fwd_plane_threads()), lds, (hipStream_t)stream, grp,
                      (float *)workspace);
   launch_plane_fixup(grp, workspace, G, stream);

@@ -88,6 +88,7 @@ struct DcnFwdGroup {
   int plane_bytes; // plane kernels: bytes of the largest feature plane of the group
   int wave_layout;    // accumulator layout of the slabs: 0 = 4 x 2 waves of 64 x 64 (2 x 2 MFMA blocks each),
                       // 1 = 8 x 1 waves of 32 x 128 (1 x 4 blocks each; plane kernels: every wave loads DISTINCT weight rows)
+  int rounds;         // static schedule: the workgroup of slice r computes ranges r, r + G, ..., r + (rounds - 1) G
   int static_ranges;  // 1: workgroup of slice r computes exactly range r (problem, part, tile), r < range_begin[n];
                       //    the other workgroups exit.  Ranges of one (problem, part) are consecutive, so the 32
                       //    workgroups of an XCD walk the SAME weight stages at the same time and share them in L2.
@@ -153,15 +154,16 @@ __device__ __forceinline__ int sk_block_of_slice(int r, int G) {
 }
 
 // The unit interval [begin, end) of slice `slice`: stream-K share, or -- static_ranges -- exactly range `slice`
-// (empty beyond the last range).
+// (+ round * G in a multi-round static schedule; empty beyond the last range).
 __device__ __forceinline__ void dcn_slice_bounds(const DcnFwdGroup &grp, long long slice, long long G, long long &begin,
-                                                 long long &end) {
+                                                 long long &end, int round = 0) {
   const long long total = grp.unit_begin[grp.n];
   if (!grp.static_ranges) {
     begin = slice * total / G;
     end = (slice + 1) * total / G;
     return;
   }
+  slice += (long long)round * G;
   if (slice >= grp.range_begin[grp.n]) { begin = end = 0; return; }
   int pi = 0;
   while (pi + 1 < grp.n && slice >= grp.range_begin[pi + 1]) ++pi;

@@ -306,7 +306,8 @@ __global__ __launch_bounds__(kThreads) void dcn_fwd_fixup_static(const DcnFwdGro
   for (int c = 0; c < kCols; ++c) sum[c] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int part = 0; part < p.kparts; ++part) {
     const int range = grp.range_begin[pi] + part * tiles + tile;
-    const f32x4 *s4 = reinterpret_cast<const f32x4 *>(slabs + (long long)sk_block_of_slice(range, G) * grp.slots * kTileElems);
+    // (range r is computed by the workgroup of slice r % G in its round r / G: slab slot r / G)
+    const f32x4 *s4 = reinterpret_cast<const f32x4 *>(slabs + ((long long)sk_block_of_slice(range % G, G) * grp.slots + range / G) * kTileElems);
     f32x4 v[kCols];
 #pragma unroll
     for (int c = 0; c < kCols; ++c) v[c] = s4[(j0 + c) * kThreads + tid];

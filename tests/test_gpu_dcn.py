@@ -193,13 +193,15 @@ def test_grad_weight_deterministic():
     assert torch.equal(grads[0][1], grads[1][1])   # grad_weight: slab fix-up in fixed order
 
 
-def test_grouped_forward_matches_single_calls():
+@pytest.mark.parametrize('B', [2, 8])
+def test_grouped_forward_matches_single_calls(B):
     """kgdet_deform_conv_forward_grouped == n separate calls, bit for bit (same kernels, same split)... the
-    stream-K partition differs, so fp32 summation order may differ: compare to fp32 round-off of the scale."""
+    schedule differs (B = 2: one static range per workgroup; B = 8: a four-round static schedule; the single calls:
+    stream-K or other part counts), so fp32 summation order may differ: compare to fp32 round-off of the scale."""
     _require_gpu()
     from kgdet_amd import dcn
     torch.manual_seed(5)
-    B, C, H, W = 2, 256, 25, 42
+    C, H, W = 256, 25, 42
     xs = [torch.randn(B, C, H, W, device='cuda') for _ in range(2)]
     ks = (3, 5, 7)
     offsets = [torch.randn(B, 2 * k * k, H, W, device='cuda') * 2 for k in ks]
