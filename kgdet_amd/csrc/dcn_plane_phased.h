@@ -59,15 +59,16 @@ __device__ __forceinline__ void plane_phased(const DcnFwdGroup &grp, float *__re
   const long long G = gridDim.x, g = blockIdx.x;
   const long long slice = sk_slice_of_block((int)g, (int)G);
   long long my_begin, my_end;
-  dcn_slice_bounds(grp, slice, G, my_begin, my_end);   // (static ranges: exactly one range, or nothing)
 
 #ifdef KGDET_PLANE_TRACE
   unsigned long long tr[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tr_t = KGDET_TR_NOW();
   const unsigned long long tr_start = tr_t;
 #endif
-  long long cur = my_begin;
   int slot = 0;  // slabs written so far (one per range met)
+  for (int round = 0; round < (grp.static_ranges ? grp.rounds : 1); ++round) {   // (static schedule: one range per round)
+  dcn_slice_bounds(grp, slice, G, my_begin, my_end, round);
+  long long cur = my_begin;
   while (cur < my_end) {
     const DcnUnitPos pos = dcn_unit_pos(grp, cur);
     const DcnProblem &p = grp.p[pos.pi];
@@ -360,6 +361,7 @@ __device__ __forceinline__ void plane_phased(const DcnFwdGroup &grp, float *__re
     KGDET_TR_ADD(6, tr_t);
     ++slot;
     cur += s_end - s_begin;
+  }
   }
 #ifdef KGDET_PLANE_TRACE
   tr[7] = KGDET_TR_NOW() - tr_start;
