@@ -103,7 +103,11 @@ int kgdet_device_cu_count(void);    /* compute units of the current device (0 if
  * instead of the split-bf16 plane kernels it prefers for v1 problems -- the arithmetic of the reference's fp32
  * col2im path (deform_conv_cuda.cpp:260-371), used to measure what the hi/lo split costs over a training step. */
 #define KGDET_OPT_EXACT_BACKWARD 0
-#define KGDET_OPT_COUNT 1
+/* KGDET_OPT_TAP_PAIRS != 0: deformable forwards with >= 7 taps on small maps take the tap-pair kernel (8-channel half-planes
+ * in a ring of three, stages = pairs of taps: csrc/dcn_plane_pairs.h) instead of the default plane kernel.  Same results to
+ * round-off; measured slower on MI355X (192 against 174 us for a KGDet head stage), kept as a working alternative. */
+#define KGDET_OPT_TAP_PAIRS 1
+#define KGDET_OPT_COUNT 2
 int kgdet_set_option(int32_t option, int32_t value);
 
 /* ------------------------------------------------------------------------------------------

@@ -114,7 +114,7 @@ void plan_static_ranges(DcnFwdGroup &grp, int G, bool force = false, int max_rou
     k = k < 1 ? 1 : (k > q.chunks_per_tap ? q.chunks_per_tap : k);
     kp[i] = k;
     ranges += q.n_ntiles * q.n_mtiles * k;
-    const double len = (double)((q.chunks_per_tap + k - 1) / k) * q.K;
+    const double len = (double)((q.chunks_per_tap + k - 1) / k) * q.seg_stages;
     longest = len > longest ? len : longest;
   }
   static const bool off = getenv("KGDET_DCN_STREAMK") != nullptr;   // A/B switch
@@ -238,7 +238,7 @@ void fill_problem(const kgdet_dcn_shape *s, const Derived &d, int group, DcnProb
   p.o_base = s->out_channel_offset + group * d.Og; p.Og = d.Og; p.Og_pad = d.Og_pad;
   p.bias_base = group * d.Og;
   p.H = s->H; p.W = s->W; p.Ho = d.Ho; p.Wo = d.Wo; p.HoWo = d.Ho * d.Wo; p.P = s->N * p.HoWo;
-  p.kh = s->kh; p.kw = s->kw; p.K = d.K;
+  p.kh = s->kh; p.kw = s->kw; p.K = d.K; p.seg_stages = d.K;
   p.sh = s->stride_h; p.sw = s->stride_w; p.ph = s->pad_h; p.pw = s->pad_w; p.dh = s->dil_h; p.dw = s->dil_w;
   p.DG = s->deformable_groups; p.cpdg = s->C / s->deformable_groups;
 }
@@ -399,12 +399,18 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
   grp.slots = kSlabSlots;
   grp.dbl_plane = 0;
   grp.plane_bytes = 0;
+  grp.pair_mode = 0;
+  grp.rounds = 1;
   grp.wave_layout = 1;
   size_t lds = 0;
   int min_len = 1 << 30;  // shortest range (stages) in the pending group
   unsigned char *const table_base = (unsigned char *)workspace + slab_bytes();
   size_t table_used = 0;  // bytes of tap records placed behind the slabs for the pending group
   const int parts = (flags & KGDET_DCN_BF16) ? 1 : 2;
+  bool grp_pair = false;   // the pending group runs the tap-pair kernel (all its problems must agree)
+  int max_hw = 0;
+  static const bool pairs_env = getenv("KGDET_DCN_PAIRS") != nullptr && atoi(getenv("KGDET_DCN_PAIRS")) != 0;   // A/B switch
+  const bool pairs_off = !(pairs_env || g_options[KGDET_OPT_TAP_PAIRS] != 0);   // (off by default: measured slower)
   auto flush = [&]() -> int {
     if (grp.n == 0) return KGDET_OK;
     plan_static_ranges(grp, G, false, kSlabSlots - 2);
@@ -416,16 +422,36 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
                                         (int)kMaxLds));
       attr_set = true;
     }
+    grp.pair_mode = grp_pair ? 1 : 0;
     hipLaunchKernelGGL(dcn_build_taps, dim3(2 * G, grp.n), dim3(256), 0, (hipStream_t)stream, grp);
     const int threads = dcn_fwd_plane_threads();
-    const size_t lds2 = plan_plane_lds(grp, lds, dcn_fwd_plane_fixed_lds_bytes(parts));
-    if (parts == 1)
-      hipLaunchKernelGGL(dcn_fwd_plane<1>, dim3(G), dim3(threads), lds2, (hipStream_t)stream, grp, (float *)workspace);
-    else
-      hipLaunchKernelGGL(dcn_fwd_plane<2>, dim3(G), dim3(threads), lds2, (hipStream_t)stream, grp, (float *)workspace);
+    if (grp_pair) {   // K >= 7 everywhere in the group: half-chunk planes, tap-pair stages (dcn_plane_pairs.h)
+      static thread_local bool pairs_attr_set = false;
+      if (!pairs_attr_set) {
+        KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_fwd_plane_pairs<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)kMaxLds));
+        KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_fwd_plane_pairs<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)kMaxLds));
+        pairs_attr_set = true;
+      }
+      grp.plane_bytes = (int)dcn_fwd_plane_pairs_plane_bytes(max_hw);
+      grp.dbl_plane = 0;
+      const size_t ldsp = dcn_fwd_plane_pairs_lds_bytes(parts, max_hw);
+      if (parts == 1)
+        hipLaunchKernelGGL(dcn_fwd_plane_pairs<1>, dim3(G), dim3(768), ldsp, (hipStream_t)stream, grp, (float *)workspace);
+      else
+        hipLaunchKernelGGL(dcn_fwd_plane_pairs<2>, dim3(G), dim3(768), ldsp, (hipStream_t)stream, grp, (float *)workspace);
+    } else {
+      const size_t lds2 = plan_plane_lds(grp, lds, dcn_fwd_plane_fixed_lds_bytes(parts));
+      if (parts == 1)
+        hipLaunchKernelGGL(dcn_fwd_plane<1>, dim3(G), dim3(threads), lds2, (hipStream_t)stream, grp, (float *)workspace);
+      else
+        hipLaunchKernelGGL(dcn_fwd_plane<2>, dim3(G), dim3(threads), lds2, (hipStream_t)stream, grp, (float *)workspace);
+    }
     launch_plane_fixup(grp, workspace, G, stream);
     grp.n = 0;
     lds = 0;
+    max_hw = 0;
     min_len = 1 << 30;
     table_used = 0;
     return KGDET_OK;
@@ -452,7 +478,18 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
       p.n_mtiles = d.Og_pad / kTileM;
       p.chunks_per_tap = d.Cg_pad / kChunk;
       p.chunks_per_tile = d.K * p.chunks_per_tap;
+      const bool pair = use_plane && !pairs_off && d.K >= 7 &&
+                        dcn_fwd_plane_pairs_lds_bytes(parts, s->H * s->W) <= kMaxLds;
+      if (use_plane && grp.n > 0 && pair != grp_pair)
+        if (int rc = flush()) return rc;
+      if (use_plane && pair) {   // stages = (8-channel half-chunk, tap pair)
+        p.seg_stages = (d.K + 1) / 2;
+        p.chunks_per_tap = 2 * (d.Cg_pad / kChunk);
+        p.chunks_per_tile = p.seg_stages * p.chunks_per_tap;
+      }
       if (use_plane) {
+        grp_pair = pair;
+        max_hw = s->H * s->W > max_hw ? s->H * s->W : max_hw;
         p.wq = packed_weights[i] + (size_t)s->groups * (d.fwd_image_floats() + d.bwd_image_floats()) +
                (size_t)g * d.plane_image_floats();
         p.tiles_per_image = ceil_div(p.HoWo, kTileN);
@@ -506,7 +543,7 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
       } else {  // exact-fp32 kernel: one launch per problem (slabs are shared, so flush the pending group first)
         if (int rc = flush()) return rc;
         DcnFwdGroup one;
-        one.n = 1; one.xcd_slices = 0; one.slots = 2; one.dbl_plane = 0; one.plane_bytes = 0; one.static_ranges = 0; one.wave_layout = 0; one.range_begin[0] = 0;
+        one.n = 1; one.xcd_slices = 0; one.slots = 2; one.dbl_plane = 0; one.plane_bytes = 0; one.static_ranges = 0; one.pair_mode = 0; one.rounds = 1; one.wave_layout = 0; one.range_begin[0] = 0;
         one.range_begin[1] = p.n_ntiles * p.n_mtiles; one.tile_begin[0] = 0; one.tile_begin[1] = p.n_ntiles * p.n_mtiles;
         one.unit_begin[0] = 0; one.unit_begin[1] = p.total_units;
         one.p[0] = p;
@@ -570,7 +607,7 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
   const int G = grid_size();
   const int parts = (flags & KGDET_DCN_BF16) ? 1 : 2;
   DcnFwdGroup grp;
-  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.wave_layout = 0;
+  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.pair_mode = 0; grp.rounds = 1; grp.wave_layout = 0;
   grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
   const int O_total = s->out_channels_total > 0 ? s->out_channels_total : s->O;
   for (int g = 0; g < s->groups; ++g) {
@@ -582,7 +619,7 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
     p.O_total = s->C; p.o_base = g * d.Cg; p.Og = d.Cg; p.Og_pad = d.Cg_pad256; p.bias_base = 0;
     p.H = d.Ho; p.W = d.Wo;                       // plane geometry = grad_output
     p.Ho = s->H; p.Wo = s->W; p.HoWo = s->H * s->W; p.P = s->N * p.HoWo;  // "pixels" = input cells
-    p.kh = s->kh; p.kw = s->kw; p.K = d.K;
+    p.kh = s->kh; p.kw = s->kw; p.K = d.K; p.seg_stages = d.K;
     p.DG = 1; p.cpdg = p.C_total;
     p.tiles_per_image = ceil_div(p.HoWo, kTileN);
     p.n_ntiles = p.N * p.tiles_per_image;
@@ -660,7 +697,7 @@ static int grad_offset_plane(const kgdet_dcn_shape *s, const float *input, const
   const int G = grid_size();
   const int parts = (flags & KGDET_DCN_BF16) ? 1 : 2;
   DcnFwdGroup grp;
-  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.wave_layout = 0;
+  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.pair_mode = 0; grp.rounds = 1; grp.wave_layout = 0;
   grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
   const DcnTapRec *recs = reinterpret_cast<const DcnTapRec *>((unsigned char *)workspace + slab_bytes());
   for (int g = 0; g < s->groups; ++g) {
@@ -778,7 +815,7 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
 
   // ---- phase 1: grad_input (transposed sampling) ----
   DcnFwdGroup grp;
-  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.wave_layout = 0;
+  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.pair_mode = 0; grp.rounds = 1; grp.wave_layout = 0;
   grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
   size_t lds = 0;
   for (int i = 0; i < n; ++i) {
@@ -804,7 +841,7 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
     p.O_total = s->C; p.o_base = 0; p.Og = d.Cg; p.Og_pad = d.Cg_pad256;
     p.H = d.Ho; p.W = d.Wo;
     p.Ho = s->H; p.Wo = s->W; p.HoWo = s->H * s->W; p.P = s->N * p.HoWo;
-    p.kh = s->kh; p.kw = s->kw; p.K = d.K;
+    p.kh = s->kh; p.kw = s->kw; p.K = d.K; p.seg_stages = d.K;
     p.DG = 1; p.cpdg = p.C_total;
     p.tiles_per_image = ceil_div(p.HoWo, kTileN);
     p.n_ntiles = p.N * p.tiles_per_image;
@@ -936,7 +973,7 @@ static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *sh
   }
   unsigned char *tab = (unsigned char *)workspace + slab_bytes();
   DcnFwdGroup grp;
-  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.wave_layout = 0;
+  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.pair_mode = 0; grp.rounds = 1; grp.wave_layout = 0;
   grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
   size_t lds = 0;
   int min_len = 1 << 30;

@@ -72,6 +72,7 @@ struct DcnProblem {
   long long total_units;  // n_ntiles * n_mtiles * chunks_per_tile
   int tiles_per_image;    // > 0: pixel tiles never straddle images (plane kernel); 0: tiles run over N*Ho*Wo
   int kparts;             // plane kernel: the reduction range of every tile is cut into kparts parts (see DcnFwdGroup)
+  int seg_stages;         // stages per chunk of the reduction: K, or ceil(K / 2) with tap-pair stages (dcn_plane_pairs.h)
   unsigned flags;
 };
 
@@ -88,6 +89,7 @@ struct DcnFwdGroup {
   int plane_bytes; // plane kernels: bytes of the largest feature plane of the group
   int wave_layout;    // accumulator layout of the slabs: 0 = 4 x 2 waves of 64 x 64 (2 x 2 MFMA blocks each),
                       // 1 = 8 x 1 waves of 32 x 128 (1 x 4 blocks each; plane kernels: every wave loads DISTINCT weight rows)
+  int pair_mode;      // 1: tap-pair stages on 8-channel half-planes (dcn_plane_pairs.h): tap records address 32-byte rows
   int rounds;         // static schedule: the workgroup of slice r computes ranges r, r + G, ..., r + (rounds - 1) G
   int static_ranges;  // 1: workgroup of slice r computes exactly range r (problem, part, tile), r < range_begin[n];
                       //    the other workgroups exit.  Ranges of one (problem, part) are consecutive, so the 32
@@ -114,7 +116,7 @@ struct DcnUnitPos {
 // first stage of reduction part `part`: parts are whole channel chunks (a chunk = K consecutive stages sharing a plane)
 __device__ __forceinline__ int dcn_part_lo(const DcnProblem &p, int part) {
   if (p.kparts == 1) return part ? p.chunks_per_tile : 0;   // (kernels whose stages are not (chunk, tap) pairs never split)
-  return (int)((long long)p.chunks_per_tap * part / p.kparts) * p.K;
+  return (int)((long long)p.chunks_per_tap * part / p.kparts) * p.seg_stages;
 }
 __device__ __forceinline__ DcnUnitPos dcn_unit_pos(const DcnFwdGroup &grp, long long u) {
   DcnUnitPos r;

@@ -31,6 +31,7 @@
 //   lane l of a wave reads row/col (l & 31) of k-half (l >> 5) as one 16-byte ds_read_b128; reduction
 //   element k = khalf*8 + j is channel c16*16 + k for both operands.
 #include "dcn_plane.h"
+#include "dcn_plane_pairs.h"
 #ifdef KGDET_PLANE_PHASED   // experiment build: the phased body (dcn_plane_phased.h) instead of producer / consumer waves
 #include "dcn_plane_phased.h"
 #endif
@@ -59,6 +60,21 @@ int dcn_fwd_plane_threads() { return kPhThreads; }
 #else
 int dcn_fwd_plane_threads() { return kPlaneThreads; }
 #endif
+
+// K >= 7 taps: half-chunk planes, tap-pair stages (dcn_plane_pairs.h)
+template <int PARTS>
+__global__ __launch_bounds__(kPlaneThreads, 1) void dcn_fwd_plane_pairs(const DcnFwdGroup grp, float *__restrict__ slabs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (threadIdx.x >= kThreads) pair_role<PARTS, true>(grp, slabs, smem);
+  else pair_role<PARTS, false>(grp, slabs, smem);
+}
+template __global__ void dcn_fwd_plane_pairs<1>(const DcnFwdGroup grp, float *__restrict__ slabs);
+template __global__ void dcn_fwd_plane_pairs<2>(const DcnFwdGroup grp, float *__restrict__ slabs);
+size_t dcn_fwd_plane_pairs_fixed_lds_bytes(int parts) { return (size_t)2 * kPairGroup * parts * kBPart; }
+size_t dcn_fwd_plane_pairs_plane_bytes(int HW) { return ((size_t)kPairRow * HW + 255) & ~(size_t)255; }
+size_t dcn_fwd_plane_pairs_lds_bytes(int parts, int HW) {
+  return dcn_fwd_plane_pairs_fixed_lds_bytes(parts) + kPairPlanes * dcn_fwd_plane_pairs_plane_bytes(HW);
+}
 
 #ifdef KGDET_PLANE_TRACE
 }  // namespace kgdet
@@ -93,7 +109,8 @@ __global__ __launch_bounds__(256) void dcn_build_taps(const DcnFwdGroup grp) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int q = tap.o[e];
-      r.off[e] = (unsigned)(dcn_plane_offset(q) + (((q >> 2) & 3) << 4));
+      r.off[e] = grp.pair_mode ? (unsigned)(q * kPairRow + (((q >> 3) & 1) << 4))      // half-plane rows (dcn_plane_pairs.h)
+                               : (unsigned)(dcn_plane_offset(q) + (((q >> 2) & 3) << 4));
       r.w[e] = tap.w[e];
     }
     const_cast<DcnTapRec *>(p.taps)[i] = r;

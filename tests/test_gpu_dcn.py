@@ -449,3 +449,32 @@ def test_random_shapes_split_kernels_agree_with_exact_fp32():
             assert torch.isfinite(a).all(), (case, name)
             err = float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
             assert err < 1e-4, (case, name, err, (N, C, O, kh, kw, H, W, v2, sigma))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B', [2, 5])
+def test_tap_pair_kernel_matches_default_plane_kernel(B):
+    """KGDET_OPT_TAP_PAIRS: the alternative forward kernel for >= 7 taps (8-channel half-planes in a ring of three, stages
+    = pairs of taps, csrc/dcn_plane_pairs.h) on the KGDet head stage -- 3x3 / 5x5 / 7x7, odd tap counts (a missing
+    second tap per half-chunk), static ranges (B = 2) and rounds (B = 5), ReLU + channel-offset epilogue -- against the
+    default plane kernel to fp32 round-off of the output scale."""
+    _require_gpu()
+    from kgdet_amd import dcn, _lib
+    torch.manual_seed(7)
+    C, H, W = 256, 25, 42
+    xs = [torch.randn(B, C, H, W, device='cuda') for _ in range(2)]
+    ks = (3, 5, 7)
+    offsets = [torch.randn(B, 2 * k * k, H, W, device='cuda') * 2 for k in ks]
+    weights = [[torch.randn(64, C, k, k, device='cuda') * 0.05 for k in ks] for _ in xs]
+    pads = [k // 2 for k in ks]
+    with torch.no_grad():
+        want = dcn.deform_conv_cat_multi(xs, offsets, weights, pads, relu=True)
+        _lib.check(_lib.lib().kgdet_set_option(1, 1), 'kgdet_set_option')
+        try:
+            got = dcn.deform_conv_cat_multi(xs, offsets, weights, pads, relu=True)
+            again = dcn.deform_conv_cat_multi(xs, offsets, weights, pads, relu=True)
+        finally:
+            _lib.check(_lib.lib().kgdet_set_option(1, 0), 'kgdet_set_option')
+    for g, a, w in zip(got, again, want):
+        assert torch.equal(g, a), 'deterministic'
+        _close(g.cpu().numpy(), w.double().cpu().numpy(), 5e-6)   # (two split kernels with different summation orders)
