@@ -152,33 +152,37 @@ __device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__res
     int t0 = s - c16 * K;
     while (s < s_end) {
       const int n = min(K - t0, s_end - s);
-      const uint4 *rec_base = reinterpret_cast<const uint4 *>(p.taps) + ((size_t)tile_b * K * HoWo + my_px_c) * RS;
+      // (wave-uniform bases + 32-bit lane offsets: scalar-base loads, no 64-bit vector address arithmetic per stage --
+      // VALU instructions beside the MFMA waves cost MFMA issue slots, tools/microbench/mfma_valu.hip)
+      const unsigned char *rec_seg = reinterpret_cast<const unsigned char *>(p.taps) + (size_t)tile_b * K * HoWo * RS * 16;
+      const unsigned rec_lane = (unsigned)my_px_c * (unsigned)(RS * 16);
       // W^T stage of (chunk c16, tap t): for every 16-o chunk o16 the rows c16*16 .. +15 of both k-halves:
       // 256-byte runs inside wqt[ct][o16][t][part][khalf][c 256][8 o]
       const int ct = (c16 * kChunk) / kTileM, c_in = (c16 * kChunk) % kTileM;
-      const unsigned char *wq_base = reinterpret_cast<const unsigned char *>(p.wq);
+      const unsigned char *wq_base = reinterpret_cast<const unsigned char *>(p.wq) + (size_t)(ct * n_o16) * K * (2 * kAPart);
+      unsigned a_lane[2];   // producers: this thread's two 16-byte units of a stage image, relative to the stage of o16 = 0
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int idx = tid + r * kProducers;          // 16-byte unit of the stage image: [o16 16][khalf 2][c 16]
+        const int c = idx & 15, khalf = (idx >> 4) & 1, o16 = idx >> 5;
+        a_lane[r] = (unsigned)(min(o16, n_o16 - 1) * K) * (unsigned)(2 * kAPart) + khalf * (kTileM * 16) + (c_in + c) * 16;
+      }
 
       auto issue = [&](int j, Regs &R) {
         const int t = t0 + min(j, n - 1);
         if constexpr (PRODUCER) {
 #pragma unroll
           for (int r = 0; r < 2; ++r) {
-            const int idx = tid + r * kProducers;          // 16-byte unit of the stage image: [o16 16][khalf 2][c 16]
-            const int c = idx & 15, khalf = (idx >> 4) & 1, o16 = idx >> 5;
-            const int o16c = min(o16, n_o16 - 1);
 #pragma unroll
-            for (int part = 0; part < PARTS; ++part) {
-              const size_t src = (size_t)((ct * n_o16 + o16c) * K + t) * (2 * kAPart) + part * kAPart +
-                                 khalf * (kTileM * 16) + (c_in + c) * 16;
-              R.a[part][r] = *reinterpret_cast<const f32x4 *>(wq_base + src);
-            }
+            for (int part = 0; part < PARTS; ++part)
+              R.a[part][r] = *reinterpret_cast<const f32x4 *>(wq_base + (size_t)t * (2 * kAPart) + part * kAPart + a_lane[r]);
           }
         } else {
-          const uint4 *rec = rec_base + (size_t)t * HoWo * RS;
-          R.off = rec[0];
-          R.wy = *reinterpret_cast<const f32x4 *>(rec + 1);
-          R.wx = *reinterpret_cast<const f32x4 *>(rec + 2);
-          if constexpr (MASK) R.wm = *reinterpret_cast<const f32x4 *>(rec + 3);
+          const unsigned char *rec = rec_seg + (size_t)t * HoWo * RS * 16;
+          R.off = *reinterpret_cast<const uint4 *>(rec + rec_lane);
+          R.wy = *reinterpret_cast<const f32x4 *>(rec + rec_lane + 16);
+          R.wx = *reinterpret_cast<const f32x4 *>(rec + rec_lane + 32);
+          if constexpr (MASK) R.wm = *reinterpret_cast<const f32x4 *>(rec + rec_lane + 48);
         }
       };
       auto commit_weights = [&](int buf, const Regs &R) {
