@@ -818,6 +818,10 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
   grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.pair_mode = 0; grp.rounds = 1; grp.wave_layout = 0;
   grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
   size_t lds = 0;
+  DcnInvBuildGroup builds;
+  builds.n = 0;
+  int build_blocks = 0;
+  size_t build_lds = 0;
   for (int i = 0; i < n; ++i) {
     const kgdet_dcn_shape *s = shapes[i];
     const Derived &d = dd[i];
@@ -825,13 +829,15 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
     uint4 *inv = (uint4 *)(tab + inv_off[i]);
     DcnInvOvfSlots *slots = (DcnInvOvfSlots *)(tab + inv_off[i] + it.rec_bytes);
     uint2 *spill = (uint2 *)(tab + inv_off[i] + it.rec_bytes + it.slot_bytes);
-    if (same_as[i] < 0) {
-      DcnProblem f;
-      fill_problem(s, d, 0, f);
-      f.offset = offsets[i]; f.mask = nullptr;
-      hipLaunchKernelGGL(dcn_build_inverse_taps, dim3(s->N * d.K), dim3(256),
-                         dcn_build_inverse_taps_lds_bytes(s->H * s->W, d.Ho * d.Wo), (hipStream_t)stream, f, inv, slots,
-                         spill);
+    if (same_as[i] < 0) {   // (all distinct offset tensors of the group: one builder launch below)
+      DcnInvBuild &e = builds.e[builds.n++];
+      fill_problem(s, d, 0, e.p);
+      e.p.offset = offsets[i]; e.p.mask = nullptr;
+      e.inv = inv; e.slots = slots; e.spill = spill;
+      const int blocks = s->N * d.K;
+      build_blocks = blocks > build_blocks ? blocks : build_blocks;
+      const size_t need = dcn_build_inverse_taps_lds_bytes(s->H * s->W, d.Ho * d.Wo);
+      build_lds = need > build_lds ? need : build_lds;
     }
     DcnProblem p{};
     p.x = grad_outputs[i]; p.out = grad_inputs[i];
@@ -862,6 +868,16 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
     lds = need > lds ? need : lds;
   }
   if (!check_slots(grp)) { set_error("group too uneven for the slab slots"); return KGDET_E_UNSUPPORTED; }
+  if (builds.n > 0) {
+    static thread_local bool multi_attr_set = false;
+    if (!multi_attr_set) {
+      KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_build_inverse_taps_multi, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)kMaxLds - 64));
+      multi_attr_set = true;
+    }
+    hipLaunchKernelGGL(dcn_build_inverse_taps_multi, dim3(build_blocks, builds.n), dim3(256), build_lds, (hipStream_t)stream,
+                       builds);
+  }
   lds = plan_plane_lds(grp, lds, dcn_bwd_input_plane_fixed_lds_bytes(2));
   grp.wave_layout = 1;   // plane_role's accumulator layout (slabs are decoded by dcn_fwd_fixup)
   plan_static_ranges(grp, G, false, kSlabSlots - 2);

@@ -53,17 +53,16 @@ size_t dcn_bwd_input_plane_lds_bytes(int parts, int plane_pixels) {
 //   spill [N][K][4 * Ho*Wo] entries  all overflow entries, tile after tile
 // LDS: cnt [HW + 1], cursor [HW], ent [4 * HoWo] (pixel, weight) pairs.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dcn_build_inverse_taps(const DcnProblem p, uint4 *__restrict__ inv,
-                                                              DcnInvOvfSlots *__restrict__ slots,
-                                                              uint2 *__restrict__ spill) {
-  extern __shared__ __attribute__((aligned(16))) int sm[];
+__device__ __forceinline__ void build_inverse_taps_body(const DcnProblem &p, uint4 *__restrict__ inv,
+                                                        DcnInvOvfSlots *__restrict__ slots, uint2 *__restrict__ spill,
+                                                        int block, int *sm) {
   const int HW = p.H * p.W;
   int *cnt = sm;                                          // [HW + 1]
   int *cursor = sm + (HW + 1);                            // [HW]
   int2 *ent = reinterpret_cast<int2 *>(sm + 2 * HW + 2);  // [4 * HoWo]
   __shared__ int wave_tot[4];
 
-  const int t = blockIdx.x % p.K, b = blockIdx.x / p.K;
+  const int t = block % p.K, b = block / p.K;
   const int tid = threadIdx.x;
   const int n_tiles = (HW + kTileN - 1) / kTileN;
 
@@ -206,6 +205,23 @@ __global__ __launch_bounds__(256) void dcn_build_inverse_taps(const DcnProblem p
     slots_bt[tile].count = tile_scan[tile] ? -(s1 - s0) : s1 - s0;   // < 0: ranges not in the records, scan the list
     slots_bt[tile].spill_start = (int)((size_t)(b * p.K + t) * 4 * p.HoWo) + s0;
   }
+}
+
+__global__ __launch_bounds__(256) void dcn_build_inverse_taps(const DcnProblem p, uint4 *__restrict__ inv,
+                                                              DcnInvOvfSlots *__restrict__ slots,
+                                                              uint2 *__restrict__ spill) {
+  extern __shared__ __attribute__((aligned(16))) int sm[];
+  build_inverse_taps_body(p, inv, slots, spill, (int)blockIdx.x, sm);
+}
+
+// the inverse tables of several problems in ONE launch: block (x, y) = (image, tap) x of problem y.  (A problem has N * K
+// blocks -- 18 / 50 / 98 for the three kernel sizes of a KGDet head stage at B = 2: launched one after the other they left
+// most of the chip idle three times over, 3 x 33 us.)
+__global__ __launch_bounds__(256) void dcn_build_inverse_taps_multi(const DcnInvBuildGroup grp) {
+  extern __shared__ __attribute__((aligned(16))) int sm[];
+  const DcnInvBuild &e = grp.e[blockIdx.y];
+  if ((int)blockIdx.x >= e.p.N * e.p.K) return;
+  build_inverse_taps_body(e.p, e.inv, e.slots, e.spill, (int)blockIdx.x, sm);
 }
 
 size_t dcn_build_inverse_taps_lds_bytes(int HW, int HoWo) {

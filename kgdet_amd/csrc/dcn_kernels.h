@@ -32,6 +32,17 @@ size_t dcn_bwd_input_plane_fixed_lds_bytes(int parts);
 __global__ void dcn_build_inverse_taps(const DcnProblem p, uint4 *__restrict__ inv, DcnInvOvfSlots *__restrict__ slots,
                                        uint2 *__restrict__ spill);
 size_t dcn_build_inverse_taps_lds_bytes(int HW, int HoWo);
+struct DcnInvBuild {
+  DcnProblem p;
+  uint4 *inv;
+  DcnInvOvfSlots *slots;
+  uint2 *spill;
+};
+struct DcnInvBuildGroup {
+  int n;
+  DcnInvBuild e[kMaxFwdGroup];
+};
+__global__ void dcn_build_inverse_taps_multi(const DcnInvBuildGroup grp);
 // grad_offset on an LDS-resident plane (dcn_backward_offset.hip)
 template <int PARTS>
 __global__ void dcn_bwd_offset_plane(const DcnFwdGroup grp, float *__restrict__ slabs, int max_K);
