@@ -148,6 +148,10 @@ size_t kgdet_dcn_workspace_bytes(const kgdet_dcn_shape *s);
 
 /* weight [O, C/groups, kh, kw] (device) -> packed (device).  Cache it while the weight is unchanged. */
 int kgdet_dcn_pack_weight(const kgdet_dcn_shape *s, const float *weight, float *packed, void *stream);
+/* n weights at once (training re-packs every DeformConv weight every step: the six of a KGDet head stage in one launch);
+ * same images as n kgdet_dcn_pack_weight calls. */
+int kgdet_dcn_pack_weight_multi(int32_t n, const kgdet_dcn_shape *const *shapes, const float *const *weights,
+                                float *const *packeds, void *stream);
 /* packed gradient image -> grad_weight [O, C/groups, kh, kw]; accumulate != 0 adds into grad_weight */
 int kgdet_dcn_unpack_weight_grad(const kgdet_dcn_shape *s, const float *packed, float *grad_weight,
                                  int accumulate, void *stream);

@@ -364,6 +364,57 @@ int kgdet_dcn_pack_weight(const kgdet_dcn_shape *s, const float *weight, float *
   return KGDET_OK;
 }
 
+// n weights in ONE launch (every weight: one weight group, fused pack kernel); anything else: one call each
+int kgdet_dcn_pack_weight_multi(int32_t n, const kgdet_dcn_shape *const *shapes, const float *const *weights,
+                                float *const *packeds, void *stream) {
+  KGDET_CHECK_SHAPE(n >= 1 && shapes && weights && packeds, "null pointer");
+  int i = 0;
+  while (i < n) {
+    DcnPackGroup grp;
+    int m = 0, gx = 0, gy = 0;
+    size_t lds = 0;
+    for (; i < n && m < kMaxFwdGroup; ++i) {
+      const kgdet_dcn_shape *s = shapes[i];
+      Derived d;
+      if (int rc = derive(s, d)) return rc;
+      KGDET_CHECK_SHAPE(weights[i] && packeds[i], "null pointer (weight %d)", i);
+      const size_t lds_all = (size_t)8 * 33 * (d.K + 1) * sizeof(float);
+      if (s->groups != 1 || lds_all > kMaxLds - 64) {   // not the fused single-group case: on its own
+        if (m > 0) break;
+        if (int rc = kgdet_dcn_pack_weight(s, weights[i], packeds[i], stream)) return rc;
+        continue;
+      }
+      const int cpdg_ = s->C / s->deformable_groups;
+      const bool plane = ((s->C / s->deformable_groups) % 4 == 0 || s->deformable_groups == 1) &&
+                         (s->deformable_groups == 1 || cpdg_ % 16 == 0);
+      DcnPackOne &e = grp.e[m++];
+      float *packed = packeds[i];
+      e.w = weights[i];
+      e.wpk = packed;
+      e.wpt = packed + d.fwd_image_floats();
+      e.wq = plane ? (void *)(packed + d.fwd_image_floats() + d.bwd_image_floats()) : nullptr;
+      e.wqt = plane ? (void *)(packed + d.fwd_image_floats() + d.bwd_image_floats() + d.plane_image_floats()) : nullptr;
+      e.Og = d.Og; e.Cg = d.Cg; e.K = d.K; e.Cg_pad = d.Cg_pad; e.Og_pad = d.Og_pad; e.Og_pad16 = d.Og_pad16;
+      e.Cg_pad256 = d.Cg_pad256;
+      gx = d.Cg_pad256 / 8 > gx ? d.Cg_pad256 / 8 : gx;
+      gy = d.Og_pad / 32 > gy ? d.Og_pad / 32 : gy;
+      lds = lds_all > lds ? lds_all : lds;
+    }
+    if (m > 0) {
+      static thread_local bool attr_set = false;
+      if (!attr_set) {
+        KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_pack_weight_all_multi,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds - 64));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(dcn_pack_weight_all_multi, dim3(gx, gy, m), dim3(256), lds, (hipStream_t)stream, grp);
+      KGDET_CHECK_LAUNCH("dcn_pack_weight_all_multi");
+    }
+  }
+  return KGDET_OK;
+}
+
+
 int kgdet_dcn_unpack_weight_grad(const kgdet_dcn_shape *s, const float *packed, float *grad_weight,
                                  int accumulate, void *stream) {
   Derived d;

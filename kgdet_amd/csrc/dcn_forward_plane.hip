@@ -133,11 +133,10 @@ size_t dcn_fwd_plane_lds_bytes(int parts, int HW) {
 // whole runs of K contiguous floats into an LDS tile [8][33][K+1]; the three images are written from it
 // in runs of 128 B (wpk), 32 B (wpt) and 512 B (wq).
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dcn_pack_weight_all(const float *__restrict__ w, float *__restrict__ wpk,
+__device__ __forceinline__ void pack_weight_all_body(const float *__restrict__ w, float *__restrict__ wpk,
                                                             float *__restrict__ wpt, void *__restrict__ wq,
                                                             void *__restrict__ wqt, int Og, int Cg, int K,
-                                                            int Cg_pad, int Og_pad, int Og_pad16, int Cg_pad256) {
-  extern __shared__ float tile[];  // [(cc * 33 + oo)][K+1]
+                                                            int Cg_pad, int Og_pad, int Og_pad16, int Cg_pad256, float *tile) {
   const int c8 = blockIdx.x, o0 = blockIdx.y * 32, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int ld = K + 1;
@@ -210,6 +209,22 @@ __global__ __launch_bounds__(256) void dcn_pack_weight_all(const float *__restri
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void dcn_pack_weight_all(const float *__restrict__ w, float *__restrict__ wpk,
+                                                            float *__restrict__ wpt, void *__restrict__ wq,
+                                                            void *__restrict__ wqt, int Og, int Cg, int K,
+                                                            int Cg_pad, int Og_pad, int Og_pad16, int Cg_pad256) {
+  extern __shared__ float tile[];  // [(cc * 33 + oo)][K+1]
+  pack_weight_all_body(w, wpk, wpt, wq, wqt, Og, Cg, K, Cg_pad, Og_pad, Og_pad16, Cg_pad256, tile);
+}
+
+// several weights in one launch (the six of a KGDet head stage: training re-packs them every step): blockIdx.z = weight
+__global__ __launch_bounds__(256) void dcn_pack_weight_all_multi(const DcnPackGroup grp) {
+  extern __shared__ float tile[];
+  const DcnPackOne &e = grp.e[blockIdx.z];
+  if ((int)blockIdx.x >= e.Cg_pad256 / 8 || (int)blockIdx.y >= e.Og_pad / 32) return;
+  pack_weight_all_body(e.w, e.wpk, e.wpt, e.wq, e.wqt, e.Og, e.Cg, e.K, e.Cg_pad, e.Og_pad, e.Og_pad16, e.Cg_pad256, tile);
 }
 
 }  // namespace kgdet

@@ -32,6 +32,16 @@ size_t dcn_bwd_input_plane_fixed_lds_bytes(int parts);
 __global__ void dcn_build_inverse_taps(const DcnProblem p, uint4 *__restrict__ inv, DcnInvOvfSlots *__restrict__ slots,
                                        uint2 *__restrict__ spill);
 size_t dcn_build_inverse_taps_lds_bytes(int HW, int HoWo);
+struct DcnPackOne {
+  const float *w;
+  float *wpk, *wpt;
+  void *wq, *wqt;
+  int Og, Cg, K, Cg_pad, Og_pad, Og_pad16, Cg_pad256;
+};
+struct DcnPackGroup {
+  DcnPackOne e[kMaxFwdGroup];
+};
+__global__ void dcn_pack_weight_all_multi(const DcnPackGroup grp);
 struct DcnInvBuild {
   DcnProblem p;
   uint4 *inv;

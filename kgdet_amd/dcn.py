@@ -172,6 +172,37 @@ def clear_pack_cache():
 _inference_depth = 0   # > 0 while a public op was entered with autograd disabled (torch.no_grad inference)
 
 
+def pack_weights(weights, shapes):
+    """pack_weight for several weights: those that need packing (all of them in training) go to the GPU as ONE launch
+    (kgdet_dcn_pack_weight_multi)"""
+    cacheable = _inference_depth > 0
+    L = _lib.lib()
+    out, todo = [None] * len(weights), []
+    for i, (w, s) in enumerate(zip(weights, shapes)):
+        nbytes = L.kgdet_dcn_packed_weight_bytes(ctypes.byref(s))
+        key = (w.data_ptr(), w._version, s.groups, s.deformable_groups, tuple(w.shape), nbytes)
+        if cacheable:
+            hit = _pack_cache.get(id(w))
+            if hit is not None and hit[0]() is w and hit[1] == key:
+                out[i] = hit[2]
+                continue
+        out[i] = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+        todo.append((i, key))
+    if todo:
+        n = len(todo)
+        shape_arr = (ctypes.POINTER(_lib.DcnShape) * n)(*[ctypes.pointer(shapes[i]) for i, _ in todo])
+        w_arr = (ctypes.c_void_p * n)(*[weights[i].data_ptr() for i, _ in todo])
+        p_arr = (ctypes.c_void_p * n)(*[out[i].data_ptr() for i, _ in todo])
+        _lib.check(L.kgdet_dcn_pack_weight_multi(ctypes.c_int32(n), shape_arr, w_arr, p_arr, _lib.current_stream()),
+                   'kgdet_dcn_pack_weight_multi')
+        if cacheable:
+            for i, key in todo:
+                if len(_pack_cache) >= _PACK_CACHE_MAX:
+                    _pack_cache.clear()
+                _pack_cache[id(weights[i])] = (weakref.ref(weights[i]), key, out[i])
+    return out
+
+
 def pack_weight(weight, shape):
     """weight [O, C/g, kh, kw] -> the kernels' weight images (include/kgdet_hip.h, kgdet_dcn_pack_weight).
     Training packs on every call (its weights change every step, and fused optimizers update them WITHOUT
@@ -560,7 +591,7 @@ class DeformConvCatFunction(Function):
         _require_f32(*xs, *offsets, *weights)
         L = _lib.lib()
         N, C, H, W = xs[0].shape
-        outs, shapes, packs = [], [], []
+        outs, shapes, wcs = [], [], []
         for i, x in enumerate(xs):
             ws_i = weights[i * n_k:(i + 1) * n_k]
             O_total = sum(w.shape[0] for w in ws_i)
@@ -571,9 +602,10 @@ class DeformConvCatFunction(Function):
                 s.out_channel_offset, s.out_channels_total = o_base, O_total
                 _check_offset(offsets[k], s, (N, ws_i[k].shape[0], H, W))
                 shapes.append(s)
-                packs.append(pack_weight(ws_i[k].contiguous(), s))
+                wcs.append(ws_i[k].contiguous())
                 o_base += ws_i[k].shape[0]
             outs.append(out)
+        packs = pack_weights(wcs, shapes)      # one launch for all of them
         n = n_x * n_k
         arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
         shape_arr = (ctypes.POINTER(_lib.DcnShape) * n)(*[ctypes.pointer(s) for s in shapes])

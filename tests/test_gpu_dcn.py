@@ -410,6 +410,36 @@ def test_cached_inference_pack_serves_every_map_size():
 
 
 @pytest.mark.gpu
+def test_multi_weight_pack_equals_single_packs():
+    """kgdet_dcn_pack_weight_multi (the six weights of a head stage in one launch) writes the same images as one
+    kgdet_dcn_pack_weight per weight -- mixed kernel sizes, channel counts that need padding, a grouped weight and a
+    7x7 (the two that take the one-call-each route inside the multi call)."""
+    _require_gpu()
+    from kgdet_amd import dcn
+    torch.manual_seed(11)
+    specs = [(256, 256, 3, 1, 1), (64, 256, 1, 1, 1), (40, 24, 3, 1, 1), (256, 256, 5, 1, 1), (32, 64, 3, 2, 1),
+             (16, 32, 7, 1, 1), (256, 64, 3, 1, 4), (100, 36, 1, 1, 1), (256, 256, 3, 1, 1), (8, 8, 3, 1, 1)]
+    ws, shapes = [], []
+    for O, C, k, g, dg in specs:
+        w = torch.randn(O, C // g, k, k, device='cuda')
+        x = torch.empty(1, C, 9, 9, device='cuda')
+        ws.append(w)
+        shapes.append(dcn._shape(x, w, (1, 1), (k // 2, k // 2), (1, 1), g, dg))
+    junk = [torch.full((8 * 1024 * 1024,), float('nan'), device='cuda') for _ in range(4)]
+    del junk
+    single = [dcn.pack_weight(w, s).clone() for w, s in zip(ws, shapes)]
+    junk = [torch.full((8 * 1024 * 1024,), float('nan'), device='cuda') for _ in range(4)]
+    del junk
+    multi = dcn.pack_weights(ws, shapes)
+    for a, b, spec in zip(single, multi, specs):
+        assert a.shape == b.shape
+        # compare the bytes (the images hold bf16 pairs viewed as fp32: NaN patterns are legal payloads); rows the
+        # pack kernels never write are poisoned on both sides, so compare only where the single pack wrote
+        ai, bi = a.view(torch.int32), b.view(torch.int32)
+        assert torch.equal(ai, bi), spec
+
+
+@pytest.mark.gpu
 def test_random_shapes_split_kernels_agree_with_exact_fp32():
     """24 random problems (1-8 images, 16-256 channels, 16-512 filters, 1x1 ... 7x7 and non-square kernels, maps up to
     32 x 40, v1 and v2, offset scales 0.3-3 pixels): forward and every gradient of the split-operand plane kernels against
