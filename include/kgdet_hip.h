@@ -82,6 +82,10 @@ int kgdet_bn_act_backward(const float *grad_y, const float *x, const float *y, c
                           const float *mean, const float *var, float eps, int32_t has_residual, int32_t relu,
                           float *grad_x, float *grad_residual, float *partial, float *sums, int64_t N, int32_t C,
                           int64_t HW, void *stream);
+/* The frozen stem: y = maxpool3x3/s2/p1(relu(batch_norm_eval(x))) in one pass (mmdet/models/backbones/resnet.py:487-491, 528);
+ * x [N, C, H, W] -> y [N, C, (H-1)/2+1, (W-1)/2+1].  Forward only (conv1 / norm1 are frozen: frozen_stages >= 0). */
+int kgdet_bn_relu_maxpool(const float *x, const float *gamma, const float *beta, const float *mean, const float *var,
+                          float eps, float *y, int64_t N, int32_t C, int32_t H, int32_t W, void *stream);
 
 /* Inference epilogue of a convolution with folded BatchNorm: x = [relu](x + bias[c] [+ residual]) in place.
  * x, residual: [N, C, HW] contiguous, or [N, HW, C] when channels_last != 0 (then C must be a multiple of 4

@@ -112,6 +112,8 @@ def _bn_lib():
         L.kgdet_bn_act_forward.argtypes = [vp, vp, vp, vp, vp, f32, vp, vp, i64, i32, i64, i32, vp]
         L.kgdet_bn_act_backward.restype = ctypes.c_int
         L.kgdet_bn_act_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, f32, i32, i32, vp, vp, vp, vp, i64, i32, i64, vp]
+        L.kgdet_bn_relu_maxpool.restype = ctypes.c_int
+        L.kgdet_bn_relu_maxpool.argtypes = [vp, vp, vp, vp, vp, f32, vp, i64, i32, i32, i32, vp]
         _BN = L
     return _BN
 
@@ -215,6 +217,7 @@ class _ConvBNAct(torch.autograd.Function):
         return gx, gw, ggamma, gbeta, None, None, None, gres, None, None
 
 
+FUSE_STEM = True        # False: conv_bn + nn.MaxPool2d (the tests compare the two)
 MERGE_CONV_BN = True    # False: two nodes (conv_split, frozen_bn_act) -- the tests compare the two
 SKIP_ALIAS = _os.environ.get('KGDET_SKIP_ALIAS', '1') == '1'   # identity-branch gradient added inside conv1's grad_input (0: A/B)
 
@@ -525,8 +528,29 @@ class ResNet(nn.Module):
         else:
             raise TypeError('pretrained must be a str or None')
 
+    def _stem(self, x):
+        """maxpool(relu(norm1(conv1(x)))) (resnet.py:528).  A frozen stem in fp32 on the GPU: BatchNorm, ReLU and the
+        pooling are one pass over conv1's output (csrc/bn_act.hip bn_relu_maxpool)"""
+        bn, mp = self.norm1, self.maxpool
+        if (FUSE_STEM and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+                and isinstance(bn, _BatchNorm) and not bn.training and bn.track_running_stats and type(self.conv1) is nn.Conv2d
+                and not (torch.is_grad_enabled() and (x.requires_grad or self.conv1.weight.requires_grad
+                                                      or (bn.affine and (bn.weight.requires_grad or bn.bias.requires_grad))))
+                and (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode) == (3, 2, 1, 1, False)
+                and x.shape[0] * self.conv1.out_channels <= 65535):
+            from . import _lib
+            with torch.no_grad():
+                y = self.conv1(x).contiguous()
+                N, C, H, W = y.shape
+                out = torch.empty((N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=y.dtype, device=y.device)
+                _lib.check(_bn_lib().kgdet_bn_relu_maxpool(
+                    _p(y), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), bn.eps, _p(out), N, C, H, W,
+                    _lib.raw_stream(y.device.index)), 'bn_relu_maxpool')
+            return out
+        return self.maxpool(conv_bn(self.conv1, self.norm1, x, relu=True))
+
     def forward(self, x):
-        x = self.maxpool(conv_bn(self.conv1, self.norm1, x, relu=True))
+        x = self._stem(x)
         outs = []
         for i, layer_name in enumerate(self.res_layers):
             x = getattr(self, layer_name)(x)

@@ -249,6 +249,42 @@ def conv_split(x, weight):
 conv1x1 = conv_split
 
 
+class _ConvBiasAct(torch.autograd.Function):
+    """``[relu](conv(x, weight) + bias)`` with bias and ReLU in the convolution's store (the plain biased 3x3 convolutions of
+    the head's first stage, KP3:69-71: MIOpen's fp32 Winograd takes 62 us for each of their three passes at 25 x 42)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        weight = weight.contiguous()
+        img, ctx.img_t = forward_images(x, weight)
+        y = _apply(img, x, weight.shape[0], weight.shape[2] * weight.shape[3], 1, bias.contiguous(), None, relu)
+        ctx.relu = relu
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        if ctx.relu:
+            gy = torch.ops.aten.threshold_backward(gy, y, 0)
+        gy = gy.contiguous()
+        gx = grad_input(weight, ctx.img_t, gy) if ctx.needs_input_grad[0] else None
+        gw = grad_weight(x, weight, gy) if ctx.needs_input_grad[1] else None
+        gb = gy.sum((0, 2, 3)) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb, None
+
+
+def conv_bias_act(conv, x, relu=False):
+    """``[relu](conv(x))`` of a plain ``nn.Conv2d``: fp32 training on the GPU takes the split-bf16 MFMA kernels, anything else
+    the module itself (+ F.relu)"""
+    if (type(conv) is torch.nn.Conv2d and conv.bias is not None and torch.is_grad_enabled()
+            and conv.bias.dtype == torch.float32
+            and applicable(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)):
+        return _ConvBiasAct.apply(x, conv.weight, conv.bias, relu)
+    y = conv(x)
+    return torch.relu(y) if relu else y
+
+
 class _ConvSplitStride2(torch.autograd.Function):
     """3x3 stride-2 padding-1 convolution: forward on conv_nn<9> (MIOpen's fp32 strided kernels run at 15-20 TFLOP/s),
     backward through MIOpen (a transposed strided convolution does not map onto the kernel's tap loop)."""

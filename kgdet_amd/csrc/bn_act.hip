@@ -148,6 +148,51 @@ int chunks_for(int64_t planes, int64_t HW) {
 
 using namespace kgdet;
 
+// The frozen stem (resnet.py:487-491, 528: maxpool(relu(norm1(conv1(x)))) with conv1 / norm1 never trained): BatchNorm, ReLU
+// and the 3x3 stride-2 padding-1 max pooling in one pass -- the full-resolution normalised map (137 MB at 2 x 64 x 400 x 672)
+// is neither written nor read back.  relu(.) >= 0 and every window holds a valid element, so the padding never wins.
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta,
+                                                              const float *__restrict__ mean,
+                                                              const float *__restrict__ var, float eps,
+                                                              float *__restrict__ y, int C, int H, int W, int Ho, int Wo) {
+  const int plane = blockIdx.y, c = plane % C;
+  const ChannelAffine a = channel_affine(gamma, beta, mean, var, eps, c);
+  const float *xp = x + (long long)plane * H * W;
+  float *yp = y + (long long)plane * Ho * Wo;
+  for (int o = blockIdx.x * 256 + threadIdx.x; o < Ho * Wo; o += gridDim.x * 256) {
+    const int i = o / Wo, j = o - i * Wo;
+    float m = 0.f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int r = 2 * i + dy;
+      if (r < 0 || r >= H) continue;
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int q = 2 * j + dx;
+        if (q < 0 || q >= W) continue;
+        m = fmaxf(m, xp[(long long)r * W + q] * a.s + a.t);
+      }
+    }
+    yp[o] = m;
+  }
+}
+
+extern "C" int kgdet_bn_relu_maxpool(const float *x, const float *gamma, const float *beta, const float *mean,
+                                     const float *var, float eps, float *y, int64_t N, int32_t C, int32_t H, int32_t W,
+                                     void *stream) {
+  KGDET_CHECK_SHAPE(N >= 0 && C > 0 && H > 0 && W > 0, "bad sizes");
+  if (N == 0) return KGDET_OK;
+  KGDET_CHECK_SHAPE(x && y && mean && var, "null pointer");
+  KGDET_CHECK_SHAPE(N * C <= 65535, "N*C = %lld exceeds the grid limit", (long long)(N * C));
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;     // floor((H + 2 - 3) / 2) + 1
+  int chunks = (Ho * Wo + 1023) / 1024;                      // four outputs per thread
+  hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(chunks, (unsigned)(N * C)), dim3(256), 0, (hipStream_t)stream, x, gamma,
+                     beta, mean, var, eps, y, C, H, W, Ho, Wo);
+  KGDET_CHECK_LAUNCH("bn_relu_maxpool");
+  return KGDET_OK;
+}
+
 extern "C" int32_t kgdet_bn_act_partials(int64_t N, int32_t C, int64_t HW) {
   if (N <= 0 || C <= 0 || HW <= 0) return 0;
   return (int32_t)(N * chunks_for(N * C, HW));

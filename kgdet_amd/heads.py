@@ -20,7 +20,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import dcn, moment
+from . import conv1x1, dcn, moment
 from .layers import ConvModule, bias_init_with_prob, normal_init
 from .points import (PointGenerator, dense_targets_applicable, multi_apply, point_target_kp,
                      point_target_kp_dense)
@@ -116,8 +116,8 @@ class Kp3RepBlock(nn.Module):
             keypts_out = self.keypts_out(keypts_dfmconv_feat)
             reppts_out = self.reppts_out(keypts_out)
         else:
-            cls_out = self.cls_out(self.relu(self.cls_conv(cls_feat)))
-            keypts_out = self.keypts_out(self.relu(self.keypts_conv(pts_feat)))
+            cls_out = self.cls_out(conv1x1.conv_bias_act(self.cls_conv, cls_feat, relu=True))
+            keypts_out = self.keypts_out(conv1x1.conv_bias_act(self.keypts_conv, pts_feat, relu=True))
             reppts_out = self.reppts_out(keypts_out)
         return cls_out, keypts_out, reppts_out
 

@@ -103,11 +103,13 @@ def test_training_backbone_uses_fused_op_and_matches_module_path():
 
     bb.frozen_bn_act = unfused
     bb.MERGE_CONV_BN = False          # the merged conv + BN node does not go through frozen_bn_act
+    bb.FUSE_STEM = False
     try:
         outs_ref, grads_ref = run()
     finally:
         bb.frozen_bn_act = orig
         bb.MERGE_CONV_BN = True
+        bb.FUSE_STEM = True
     for a, b in zip(outs, outs_ref):
         assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
     assert grads.keys() == grads_ref.keys() and len(grads) > 100
@@ -115,6 +117,33 @@ def test_training_backbone_uses_fused_op_and_matches_module_path():
         d = (grads[n] - grads_ref[n]).abs().max().item()
         # fp32 summation-order noise through ~50 layers (MIOpen's strided kernels use atomics): a few 1e-4 of the scale
         assert d <= 1e-3 * (grads_ref[n].abs().max().item() + 1e-12), (n, d)
+
+
+@pytest.mark.parametrize('size', [(96, 128), (97, 131), (800, 1344), (30, 33)])
+@pytest.mark.parametrize('grad_mode', [True, False])
+def test_fused_stem_matches_module_path(size, grad_mode):
+    """maxpool(relu(norm1(conv1(x)))) of the frozen stem as conv1 + ONE pass (bn_relu_maxpool) equals the three modules
+    (resnet.py:528), odd sizes included; a stem that trains (frozen_stages = -1) keeps the module path."""
+    from kgdet_amd import backbone as bb
+    torch.manual_seed(1)
+    net = bb.ResNet(depth=50, num_stages=1, strides=(1,), dilations=(1,), out_indices=(0,), frozen_stages=0,
+                    style='pytorch').cuda()
+    net.norm1.running_mean.normal_(0, 0.3)
+    net.norm1.running_var.uniform_(0.5, 1.5)
+    net.norm1.weight.data.normal_(0, 1.0)          # negative scales too
+    net.norm1.bias.data.normal_(0, 0.3)
+    net.train()
+    x = torch.randn(2, 3, *size, device='cuda')
+    with torch.set_grad_enabled(grad_mode):
+        got = net._stem(x)
+        want = F.max_pool2d(F.relu(net.norm1(net.conv1(x))), 3, 2, 1)
+    assert got.shape == want.shape and not got.requires_grad
+    assert (got - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+    net2 = bb.ResNet(depth=50, num_stages=1, strides=(1,), dilations=(1,), out_indices=(0,), frozen_stages=-1,
+                     style='pytorch').cuda()
+    net2.train()
+    y = net2._stem(x)
+    assert y.requires_grad       # a trainable stem stays on autograd-recording modules
 
 
 @pytest.mark.parametrize('modulated', [False, True])
@@ -219,6 +248,37 @@ def test_conv1x1_split_matches_fp64_convolution(B, C, O, H, W, k, monkeypatch):
     assert torch.equal(x.grad, x2g)
     if k == 1 or C % 128 == 0:     # otherwise grad_weight is MIOpen's (kgdet_amd/conv1x1.py), which makes no such promise
         assert torch.equal(w.grad, w2g)
+
+
+@pytest.mark.parametrize('relu', [False, True])
+@pytest.mark.parametrize('B,C,O,H,W,k', [(2, 256, 256, 25, 42, 3), (2, 256, 256, 100, 168, 3), (1, 64, 32, 9, 14, 1)])
+def test_conv_bias_act_matches_fp64(B, C, O, H, W, k, relu):
+    """conv1x1.conv_bias_act: the biased plain convolutions of the head's first stage (KP3:69-71, 119-120) -- bias and ReLU in
+    the store of the split-bf16 kernel; output and the three gradients against the fp64 modules."""
+    from kgdet_amd import conv1x1 as c1
+    torch.manual_seed(C + H)
+    conv = torch.nn.Conv2d(C, O, k, 1, k // 2).cuda()
+    conv.bias.data.normal_(0, 0.5)
+    x = torch.randn(B, C, H, W, device='cuda', requires_grad=True)
+    gy = torch.randn(B, O, H, W, device='cuda')
+    y = c1.conv_bias_act(conv, x, relu=relu)
+    assert type(y.grad_fn).__name__ == '_ConvBiasActBackward'
+    y.backward(gy)
+    conv_d = torch.nn.Conv2d(C, O, k, 1, k // 2).cuda().double()
+    conv_d.load_state_dict({n: v.double() for n, v in conv.state_dict().items()})
+    xd = x.detach().double().requires_grad_()
+    yd = conv_d(xd)
+    # the ReLU mask of the fp32 result (an element within rounding of zero may flip in fp64)
+    yd = yd * (y.detach() > 0) if relu else yd
+    yd.backward(gy.double())
+    for name, a_, b_ in (('y', y, yd), ('grad_x', x.grad, xd.grad), ('grad_w', conv.weight.grad, conv_d.weight.grad),
+                         ('grad_b', conv.bias.grad, conv_d.bias.grad)):
+        err = (a_.double() - b_).abs().max().item() / b_.abs().max().item()
+        assert err < 1e-5, (name, err)
+    # not applicable (CPU / no_grad): the module itself
+    with torch.no_grad():
+        y0 = c1.conv_bias_act(conv, x, relu=relu)
+    assert (y0 - y).abs().max().item() <= 1e-4 * y.abs().max().item()
 
 
 def test_conv1x1_not_applicable_cases_fall_back():
