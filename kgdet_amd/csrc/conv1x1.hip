@@ -250,8 +250,12 @@ __global__ __launch_bounds__(kNNThreads) void conv_nn(const unsigned char *__res
     unsigned char *As = smem + buf * 2 * kStage, *Bs = As + kStage;
     *reinterpret_cast<f32x4 *>(As + tid * 16) = R.a;
     uint2 hi, lo;
+#ifdef KGDET_CONV_ABL_NOSPLIT   // ablation (timing only, wrong results): no conversion VALU
+    hi.x = __float_as_uint(R.v[0]); hi.y = __float_as_uint(R.v[1]); lo.x = __float_as_uint(R.v[2]); lo.y = __float_as_uint(R.v[3]);
+#else
     split_pair(R.live ? R.v[0] : 0.0f, R.live ? R.v[1] : 0.0f, hi.x, lo.x);
     split_pair(R.live ? R.v[2] : 0.0f, R.live ? R.v[3] : 0.0f, hi.y, lo.y);
+#endif
     unsigned char *dst = Bs + (kq >> 1) * (kTN * 16) + n_local * 16 + (kq & 1) * 8;
     *reinterpret_cast<uint2 *>(dst) = hi;
     *reinterpret_cast<uint2 *>(dst + kPart) = lo;
@@ -260,12 +264,28 @@ __global__ __launch_bounds__(kNNThreads) void conv_nn(const unsigned char *__res
     const unsigned char *A = smem + buf * 2 * kStage + (lane >> 5) * (kTM * 16) + (wm * 64 + (lane & 31)) * 16;
     const unsigned char *Bp = smem + buf * 2 * kStage + kStage + (lane >> 5) * (kTN * 16) + (wn * 32 + (lane & 31)) * 16;
     bf16x8 a[2][2], bb[2];
+#ifdef KGDET_CONV_ABL_NOLDSREAD   // ablation: fragments from registers (no LDS reads)
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      a[pt][0] = __builtin_bit_cast(bf16x8, acc[0].lo.lo); a[pt][1] = __builtin_bit_cast(bf16x8, acc[1].lo.lo);
+      bb[pt] = __builtin_bit_cast(bf16x8, acc[1].hi.lo);
+    }
+#else
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
       a[pt][0] = *reinterpret_cast<const bf16x8 *>(A + pt * kPart);
       a[pt][1] = *reinterpret_cast<const bf16x8 *>(A + pt * kPart + 32 * 16);
       bb[pt] = *reinterpret_cast<const bf16x8 *>(Bp + pt * kPart);
     }
+#endif
+#ifdef KGDET_CONV_ABL_NOMFMA
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const f32x4 q = __builtin_bit_cast(f32x4, a[0][mi]) + __builtin_bit_cast(f32x4, a[1][mi]) + __builtin_bit_cast(f32x4, bb[0]) + __builtin_bit_cast(f32x4, bb[1]);
+      acc[mi][0] += q[0]; acc[mi][1] += q[1]; acc[mi][2] += q[2]; acc[mi][3] += q[3];
+    }
+    if (false)
+#endif
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {   // small terms first
       acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][mi], bb[0], acc[mi], 0, 0, 0);
@@ -331,6 +351,380 @@ __global__ __launch_bounds__(kNNThreads) void conv_nn(const unsigned char *__res
       const int m = mt * kTM + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (m < M && n < N) yb[(long long)m * N + n] = relu ? fmaxf(acc[mi][r], 0.0f) : acc[mi][r];
     }
+}
+
+// 3x3, stride 1, padding 1 with the input PATCH of a tile staged once per 16-channel chunk (conv_nn<9> loads, splits and
+// writes the shifted tile once per (chunk, tap): nine times the loads, conversions and address arithmetic -- and with two
+// waves per SIMD the instruction count, not MFMA / LDS / HBM, is what bounds it: ablations of each changed its time by < 5 %).
+// Tile = TY x TX output pixels (TY * TX <= 128, chosen by the host to fit the map: 3 x 42 for the 25 x 42 / 50 x 84 / 100 x 168
+// levels), patch = (TY + 2) x (TX + 2) <= 256 pixels, zero outside the image, split once, stored [part][khalf][256][8 bf16];
+// a tap is an LDS address offset: three row-base registers + immediates.  A stages stream as in conv_nn (one 16-byte load
+// per thread and stage, three register sets, three LDS buffers: static indices in the nine-tap body); one barrier per stage.
+#ifdef KGDET_CONV_TRACE   // experiment build (make VARIANT=ctrace EXTRA=-DKGDET_CONV_TRACE, tools/conv_trace.py): cycle sums per phase
+static __device__ unsigned long long g_conv_trace[1024 * 8];   // [block][cat]: 0 barrier, 1 frag reads, 2 mfma, 3 commit, 4 lds drain, 5 prologue, 6 total, 7 stages
+#define CV_NOW() __builtin_amdgcn_s_memtime()
+#define CV_ADD(cat) do { const unsigned long long n__ = CV_NOW(); tr[cat] += n__ - tr_t; tr_t = n__; } while (0)
+#else
+#define CV_ADD(cat) do { } while (0)
+#endif
+constexpr int kPatchMax = 256;
+constexpr int kPatchPart = 2 * kPatchMax * 16;   // bytes of one part of a B patch: [khalf][256][8 bf16]
+constexpr int kPatchBuf = 2 * kPatchPart;        // hi + lo
+constexpr int kPatchLds = 6 * kStage + 2 * kPatchBuf;
+
+__global__ __launch_bounds__(kNNThreads) void conv3x3_patch(const unsigned char *__restrict__ img,
+                                                            const float *__restrict__ x, float *__restrict__ y, int M,
+                                                            int K, int H, int W, int n_mt, int tiles_x, int n_nt, int tiles,
+                                                            int ksplit, long long part_stride, int TX, int TY,
+                                                            const float *__restrict__ bias,
+                                                            const float *__restrict__ residual, int relu) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // kPatchLds: A x 6 (two sets of three stages) | B x 2
+  const int unit = xcd_tile(blockIdx.x, tiles * ksplit);
+  if (unit >= tiles * ksplit) return;
+  const int part = unit % ksplit, tile = unit / ksplit;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
+  const int N = H * W;
+  const int chunks_all = K / kTK, per = (chunks_all + ksplit - 1) / ksplit;
+  const int c_begin = part * per, c_end = max(c_begin, min(chunks_all, c_begin + per));
+  const int chunks = c_end - c_begin, stages = chunks * 9;
+  const int mt = tile % n_mt, nt = (tile / n_mt) % n_nt, b = tile / (n_mt * n_nt);
+  const int y0 = (nt / tiles_x) * TY, x0 = (nt % tiles_x) * TX;
+  const int PW = TX + 2, PP = PW * (TY + 2);
+
+  // B patch: thread -> (khalf, patch pixel); 8 channels of that pixel per chunk
+  const int khalf_l = tid >> 8, pp = tid & 255;
+  const int ppy = pp / PW, ppx = pp - ppy * PW;
+  const int iy = y0 - 1 + ppy, ix = x0 - 1 + ppx;
+  const bool p_live = pp < PP && iy >= 0 && iy < H && ix >= 0 && ix < W;
+  const float *xb = x + ((long long)b * K + khalf_l * 8) * N + (p_live ? iy * W + ix : 0);
+  unsigned char *b_dst = smem + 6 * kStage + (khalf_l * kPatchMax + pp) * 16;
+
+  // this lane's output pixel and its patch address (tap (-1, -1))
+  const int q = min(wn * 32 + (lane & 31), TX * TY - 1);
+  const int py = q / TX, px = q - py * TX;
+  const unsigned char *b_row0 = smem + 6 * kStage + ((lane >> 5) * kPatchMax + py * PW + px) * 16;
+  const int row_pitch = PW * 16;
+  const unsigned char *a_rd = smem + (lane >> 5) * (kTM * 16) + (wm * 64 + (lane & 31)) * 16;
+  const unsigned char *ai = img + (long long)mt * (chunks_all * 9) * kStage + (long long)min(c_begin, chunks_all - 1) * 9 * kStage + tid * 16;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+  float bv[8];
+  auto issue_b = [&](int ci) {   // chunk ci of this part (clamped: unconditional loads)
+    const float *xp = xb + (long long)min(c_begin + min(ci, chunks - 1), chunks_all - 1) * kTK * N;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = xp[(long long)j * N];
+  };
+  auto commit_b = [&](int buf) {
+    float v[8];
+    // (pure arithmetic floats freely through hipcc's instruction selection: without this anchor the conversion -- and the
+    // wait for the loads it consumes -- lands right behind the loads, at the head of the chunk)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(bv[j]));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = p_live ? bv[j] : 0.0f;
+    bf16x8 hi, lo;
+    split8(v, hi, lo);
+    *reinterpret_cast<bf16x8 *>(b_dst + buf * kPatchBuf) = hi;
+    *reinterpret_cast<bf16x8 *>(b_dst + buf * kPatchBuf + kPatchPart) = lo;
+  };
+  f32x4 R[3];
+#ifdef KGDET_PATCH_ABL_NOAGLOBAL
+  auto issue_a = [&](int s, f32x4 &r) { r[0] = (float)s; };
+#else
+  auto issue_a = [&](int s, f32x4 &r) { r = *reinterpret_cast<const f32x4 *>(ai + (long long)max(min(s, stages - 1), 0) * kStage); };
+#endif
+
+  // One barrier per GROUP of three stages (a tap row).  With a barrier per stage the two waves of a SIMD run in lockstep --
+  // both read fragments, both want the matrix pipe, both commit -- and a stage costs the sum of the phases (trace: 946 ticks
+  // per stage, 244 of them MFMA issue, 319 waiting at the barrier for the wave that got the pipe second); inside a group the
+  // waves drift apart and one multiplies while the other reads and commits.
+  // A: two sets of three stage buffers; group g multiplies set g & 1 while stages of group g + 1 (in registers since group
+  // g - 1) are committed into the other set and the loads of group g + 2 are issued.  Fragments of the next stage of the
+  // group are read while the current one multiplies; a group's first stage reads its own (its data is only visible after
+  // the barrier).
+  struct Frags {
+    bf16x8 a[2][2], b[2];
+  };
+  auto read_frags = [&](Frags &F, const unsigned char *A, const unsigned char *Bp) {
+#ifdef KGDET_PATCH_ABL_NOLDSREAD   // ablations: timing only, wrong results
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      F.a[pt][0] = __builtin_bit_cast(bf16x8, acc[0].lo.lo); F.a[pt][1] = __builtin_bit_cast(bf16x8, acc[1].lo.lo);
+      F.b[pt] = __builtin_bit_cast(bf16x8, acc[1].hi.lo);
+    }
+    return;
+#endif
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      F.a[pt][0] = *reinterpret_cast<const bf16x8 *>(A + pt * kPart);
+      F.a[pt][1] = *reinterpret_cast<const bf16x8 *>(A + pt * kPart + 32 * 16);
+      F.b[pt] = *reinterpret_cast<const bf16x8 *>(Bp + pt * kPatchPart);
+    }
+  };
+  auto mma = [&](const Frags &F) {
+#ifdef KGDET_PATCH_ABL_NOMFMA
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const f32x4 qv = __builtin_bit_cast(f32x4, F.a[0][mi]) + __builtin_bit_cast(f32x4, F.a[1][mi]) + __builtin_bit_cast(f32x4, F.b[0]) + __builtin_bit_cast(f32x4, F.b[1]);
+      acc[mi][0] += qv[0]; acc[mi][1] += qv[1]; acc[mi][2] += qv[2]; acc[mi][3] += qv[3];
+    }
+    return;
+#endif
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {   // small terms first
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[1][mi], F.b[0], acc[mi], 0, 0, 0);
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[0][mi], F.b[1], acc[mi], 0, 0, 0);
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[0][mi], F.b[0], acc[mi], 0, 0, 0);
+    }
+  };
+#ifdef KGDET_CONV_TRACE
+  unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tr_t = CV_NOW();
+  const unsigned long long tr_start = tr_t;
+#endif
+  issue_b(0);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) issue_a(j, R[j]);
+  commit_b(0);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    *reinterpret_cast<f32x4 *>(smem + j * kStage + tid * 16) = R[j];
+    issue_a(3 + j, R[j]);
+  }
+  Frags F[2];
+  CV_ADD(5);
+  for (int ci = 0; ci < chunks; ++ci) {
+    issue_b(ci + 1);
+    const unsigned char *brow = b_row0 + (ci & 1) * kPatchBuf;
+    const int set0 = (ci & 1) * 3 * kStage;            // A set of this chunk's rows 0 and 2; row 1 uses the other
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int g = ci * 3 + r;
+      const int cur = (r & 1) ? 3 * kStage - set0 : set0, nxt = 3 * kStage - cur;
+#ifndef KGDET_PATCH_ABL_NOBARRIER
+      __syncthreads();
+#endif
+      CV_ADD(0);
+      read_frags(F[0], a_rd + cur, brow + r * row_pitch);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        if (j < 2) read_frags(F[(j + 1) & 1], a_rd + cur + (j + 1) * kStage, brow + r * row_pitch + (j + 1) * 16);
+        __builtin_amdgcn_sched_barrier(0);   // (hipcc would sink the prefetch reads to their uses)
+        CV_ADD(1);
+        mma(F[j & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        CV_ADD(2);
+        *reinterpret_cast<f32x4 *>(smem + nxt + j * kStage + tid * 16) = R[j];   // A of stage 3 (g + 1) + j
+        issue_a(3 * (g + 2) + j, R[j]);
+        if (r == 2 && j == 1) commit_b((ci + 1) & 1);   // the next chunk's patch (its last readers finished a chunk ago)
+        __builtin_amdgcn_sched_barrier(0);
+        CV_ADD(3);
+      }
+    }
+  }
+
+#ifdef KGDET_CONV_TRACE
+  tr[6] = CV_NOW() - tr_start;
+  tr[7] = stages;
+  tr[4] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |
+          __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // XCC_ID | HW_ID
+  tr[5] = tr_start;
+  if (tid == 0 && blockIdx.x < 1024)
+    for (int c = 0; c < 8; ++c) g_conv_trace[blockIdx.x * 8 + c] = tr[c];
+#endif
+  // store (as conv_nn): lane holds pixel (lane & 31) of its wave's 32, 16 rows per 32 x 32 block
+  float *yb = y + (long long)part * part_stride + (long long)b * M * N;
+  const int qq = wn * 32 + (lane & 31);
+  const int oy = y0 + py, ox = x0 + px;
+  const bool o_live = qq < TX * TY && oy < H && ox < W;
+  const int n = o_live ? oy * W + ox : 0;
+  if (bias || residual) {
+    float add[2][16];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = min(mt * kTM + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), M - 1);
+        float v = bias ? bias[m] : 0.0f;
+        if (residual) v += residual[((long long)b * M + m) * N + n];
+        add[mi][r] = v;
+      }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][r] += add[mi][r];
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mt * kTM + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (m < M && o_live) yb[(long long)m * N + n] = relu ? fmaxf(acc[mi][r], 0.0f) : acc[mi][r];
+    }
+}
+
+// conv3x3_patch with FOUR waves per workgroup: wave w owns rows 32 w .. 32 w + 31 of the 128-row tile and ALL 128 pixels.
+// Its A fragments (32 rows x 16 channels, hi + lo = 2 KB per stage) come straight from the packed image in L2 into
+// registers -- the image is stored in fragment order -- three stages ahead; only the input patch lives in LDS.  No A
+// staging, no A commit, 8 instead of 6 LDS fragment reads for 12 instead of 6 MFMAs, and ONE barrier per chunk of nine
+// stages (the patch swap).  32 KB of LDS and 4 waves per workgroup: two to three workgroups share a CU, so a launch with
+// slightly more tiles than CUs (272 for [2, 128, 100, 168]) no longer waits for a CU that drew two 8-wave workgroups.
+// WAVES = 4: the whole 128-row tile; WAVES = 2: a 64-row half of it (twice the workgroups, each with its own copy of the
+// patch) -- for launches whose tile count is just above the CU count, where workgroups this small spread evenly.
+// NB = 4 | 5 blocks of 32 pixels per tile: a tile of up to 160 pixels (e.g. 4 x 34) lets [2, *, 100, 168] take 250 tiles --
+// one per CU -- where 128-pixel tiles need 272: a CU finishes a tile in ~28 us whatever shares it, so the 16 CUs that drew
+// two set the time (51 us).
+template <int WAVES, int NB>
+__global__ __launch_bounds__(64 * WAVES) void conv3x3_patch4(const unsigned char *__restrict__ img,
+                                                             const float *__restrict__ x, float *__restrict__ y, int M,
+                                                             int K, int H, int W, int n_mt, int tiles_x, int n_nt,
+                                                             int tiles, int ksplit, long long part_stride, int TX, int TY,
+                                                             const float *__restrict__ bias,
+                                                             const float *__restrict__ residual, int relu) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kPatchBuf];
+  constexpr int HALVES = 4 / WAVES, THREADS = 64 * WAVES, PXT = kPatchMax / THREADS;   // patch pixels per thread
+  const int unit0 = xcd_tile(blockIdx.x, tiles * ksplit * HALVES);
+  if (unit0 >= tiles * ksplit * HALVES) return;
+  const int half = unit0 % HALVES, unit = unit0 / HALVES;
+  const int part = unit % ksplit, tile = unit / ksplit;
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) + half * WAVES;
+  const int N = H * W;
+  const int chunks_all = K / kTK, per = (chunks_all + ksplit - 1) / ksplit;
+  const int c_begin = part * per, c_end = max(c_begin, min(chunks_all, c_begin + per));
+  const int chunks = c_end - c_begin, stages = chunks * 9;
+  const int mt = tile % n_mt, nt = (tile / n_mt) % n_nt, b = tile / (n_mt * n_nt);
+  const int y0 = (nt / tiles_x) * TY, x0 = (nt % tiles_x) * TX;
+  const int PW = TX + 2, PP = PW * (TY + 2);
+
+  if (mt * kTM + half * 64 >= M) return;   // (a 64-row half beyond the last output channel)
+  // B patch: thread -> PXT patch pixels, all 16 channels of the chunk
+  bool p_live[PXT];
+  int p_off[PXT];
+#pragma unroll
+  for (int i = 0; i < PXT; ++i) {
+    const int pp = tid + i * THREADS;
+    const int ppy = pp / PW, ppx = pp - ppy * PW;
+    const int iy = y0 - 1 + ppy, ix = x0 - 1 + ppx;
+    p_live[i] = pp < PP && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    p_off[i] = p_live[i] ? iy * W + ix : 0;
+  }
+  const float *xb = x + (long long)b * K * N;
+  unsigned char *b_dst = smem + tid * 16;
+
+  // this lane's four output pixels (one per 32-pixel block) and their patch addresses (tap (-1, -1))
+  int b_rd[NB], o_n[NB];
+  bool o_live[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int qq = nb * 32 + (lane & 31), q = min(qq, TX * TY - 1);
+    const int py = q / TX, px = q - py * TX;
+    b_rd[nb] = ((lane >> 5) * kPatchMax + py * PW + px) * 16;
+    o_live[nb] = qq < TX * TY && y0 + py < H && x0 + px < W;
+    o_n[nb] = o_live[nb] ? (y0 + py) * W + x0 + px : 0;
+  }
+  const int row_pitch = PW * 16;
+  const unsigned char *ag = img + ((long long)mt * chunks_all + min(c_begin, chunks_all - 1)) * 9 * kStage +
+                            (lane >> 5) * (kTM * 16) + (wave * 32 + (lane & 31)) * 16;
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+  float bv[PXT][16];
+  auto issue_b = [&](int ci) {   // chunk ci of this part (clamped: unconditional loads)
+    const float *xp = xb + (long long)min(c_begin + min(ci, chunks - 1), chunks_all - 1) * kTK * N;
+#pragma unroll
+    for (int i = 0; i < PXT; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) bv[i][j] = xp[(long long)j * N + p_off[i]];
+  };
+  auto commit_b = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PXT; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(bv[i][j]));   // (anchor: see conv3x3_patch)
+#pragma unroll
+    for (int i = 0; i < PXT; ++i)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p_live[i] ? bv[i][kh * 8 + j] : 0.0f;
+        bf16x8 hi, lo;
+        split8(v, hi, lo);
+        unsigned char *d = b_dst + i * THREADS * 16 + buf * kPatchBuf + kh * (kPatchMax * 16);
+        *reinterpret_cast<bf16x8 *>(d) = hi;
+        *reinterpret_cast<bf16x8 *>(d + kPatchPart) = lo;
+      }
+  };
+  bf16x8 AR[3][2];
+  auto issue_a = [&](int s, bf16x8 (&r)[2]) {
+    const unsigned char *p = ag + (long long)max(min(s, stages - 1), 0) * kStage;
+    r[0] = *reinterpret_cast<const bf16x8 *>(p);
+    r[1] = *reinterpret_cast<const bf16x8 *>(p + kPart);
+  };
+
+  issue_b(0);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) issue_a(j, AR[j]);
+  commit_b(0);
+  for (int ci = 0; ci < chunks; ++ci) {
+    issue_b(ci + 1);
+    __syncthreads();   // patch ci is complete; every wave is done with patch ci - 1
+    const unsigned char *bbuf = smem + (ci & 1) * kPatchBuf;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int s = ci * 9 + t;
+      const unsigned char *bt = bbuf + (t / 3) * row_pitch + (t % 3) * 16;
+      bf16x8 bf[NB][2];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        bf[nb][0] = *reinterpret_cast<const bf16x8 *>(bt + b_rd[nb]);
+        bf[nb][1] = *reinterpret_cast<const bf16x8 *>(bt + b_rd[nb] + kPatchPart);
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AR[t % 3][1], bf[nb][0], acc[nb], 0, 0, 0);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AR[t % 3][0], bf[nb][1], acc[nb], 0, 0, 0);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AR[t % 3][0], bf[nb][0], acc[nb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_a(s + 3, AR[t % 3]);
+      if (t == 6) commit_b((ci + 1) & 1);   // the next chunk's patch (the barrier above freed that buffer)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // store: lane holds pixel (lane & 31) of each 32-pixel block, rows 32 w + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  float *yb = y + (long long)part * part_stride + (long long)b * M * N;
+  const int m0 = mt * kTM + wave * 32 + 4 * (lane >> 5);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    if (bias || residual) {
+      float add[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = min(m0 + (r & 3) + 8 * (r >> 2), M - 1);
+        float v = bias ? bias[m] : 0.0f;
+        if (residual) v += residual[((long long)b * M + m) * N + o_n[nb]];
+        add[r] = v;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][r] += add[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + (r & 3) + 8 * (r >> 2);
+      if (m < M && o_live[nb]) yb[(long long)m * N + o_n[nb]] = relu ? fmaxf(acc[nb][r], 0.0f) : acc[nb][r];
+    }
+  }
 }
 
 // out[i] = sum_s parts[s][i], s ascending (deterministic); n a multiple of 2
@@ -541,11 +935,67 @@ int nn_ksplit(long long tiles, int stages) {
   return k < 1 ? 1 : k;
 }
 
+// conv_nn or conv3x3_patch, the pixel tiling and the K split of one convolution (workspace query and launch agree on it)
+struct NNPlan {
+  bool patch;
+  int TX, TY, NB, tiles_x, n_nt, ks;
+  long long tiles;
+};
+int conv_patch_mode() {   // 2: conv3x3_patch4 (default), 1: conv3x3_patch, 0: conv_nn<9>  (A/B)
+  static const int on = [] { const char *e = getenv("KGDET_CONV3X3_PATCH"); return e ? atoi(e) : 2; }();
+  return on;
+}
+bool conv_patch_enabled() { return conv_patch_mode() != 0; }
+NNPlan plan_nn(long long B, int M, int K, int H, int W, int taps, int stride) {
+  NNPlan p;
+  const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+  const int n_mt = (M + kTM - 1) / kTM;
+  p.patch = false;
+  p.TX = p.TY = p.tiles_x = 0;
+  p.NB = 4;
+  p.n_nt = (int)(((long long)Ho * Wo + kTN - 1) / kTN);
+  if (taps == 9 && stride == 1 && conv_patch_enabled()) {
+    // the tile shape with the fewest tiles (ties: the smaller patch); TX >= 8 keeps the stores in >= 32-byte runs
+    long long best = -1;
+    p.NB = 4;
+    for (int cap = 128; cap <= (conv_patch_mode() >= 2 && M > 64 ? 160 : 128); cap += 32)   // (M <= 64: the 64-row variant, 4 blocks)
+      for (int tx = 8; tx <= 126 && tx <= (W + 7) / 8 * 8; ++tx) {
+        const int ty = cap / tx;
+        if (ty < 1 || (tx + 2) * (ty + 2) > kPatchMax) continue;
+        const long long n = (long long)((H + ty - 1) / ty) * ((W + tx - 1) / tx);
+        // time ~ rounds over the 256 CUs x blocks per tile (one CU, one tile at a time: see conv3x3_patch4); below one round
+        // and in the many-round regime the tile count itself decides
+        const long long units = n * n_mt * B;
+        const long long rounds = units <= 256 ? 256 : units <= 512 ? 512 : units;
+        const long long cost = (rounds * (cap / 32)) * 4096 + n * 8 + (cap == 160) * 4 + ((tx + 2) * (ty + 2) > 230);
+        if (best < 0 || cost < best) { best = cost; p.TX = tx; p.TY = ty; p.NB = cap / 32; }
+      }
+    static const int force_tx = [] { const char *e = getenv("KGDET_CONV_TX"); return e ? atoi(e) : 0; }();   // experiments
+    if (force_tx > 0 && (force_tx + 2) * (128 / force_tx + 2) <= kPatchMax) { p.TX = force_tx; p.TY = 128 / force_tx; p.NB = 4; }
+    if (best >= 0) {
+      p.patch = true;
+      p.tiles_x = (W + p.TX - 1) / p.TX;
+      p.n_nt = p.tiles_x * ((H + p.TY - 1) / p.TY);
+    }
+  }
+  p.tiles = (long long)n_mt * p.n_nt * B;
+  p.ks = p.patch ? nn_ksplit(p.tiles, K / kTK * 2) : nn_ksplit(p.tiles, taps * (K / kTK));   // patch: >= 4 chunks per part
+  static const int force_ks = [] { const char *e = getenv("KGDET_CONV_KS"); return e ? atoi(e) : 0; }();   // experiments
+  if (force_ks > 0) p.ks = force_ks;
+  return p;
+}
+
 }  // namespace
 
 }  // namespace kgdet
 
 using namespace kgdet;
+
+#ifdef KGDET_CONV_TRACE
+extern "C" int kgdet_debug_read_conv_trace(unsigned long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(kgdet::g_conv_trace), sizeof(unsigned long long) * 1024 * 8);
+}
+#endif
 
 extern "C" size_t kgdet_conv_packed_bytes(int32_t M, int32_t K, int32_t taps) {
   if (M <= 0 || K <= 0 || K % kTK || (taps != 1 && taps != 9)) return 0;
@@ -601,8 +1051,7 @@ extern "C" size_t kgdet_conv_apply_workspace_bytes(int64_t B, int32_t M, int32_t
                                                     int32_t taps, int32_t stride) {
   if (B <= 0 || M <= 0 || K <= 0 || H <= 0 || W <= 0 || K % kTK || stride < 1 || stride > 2) return 0;
   const long long HW = (long long)((H + stride - 1) / stride) * ((W + stride - 1) / stride);
-  const long long tiles = (long long)((M + kTM - 1) / kTM) * ((HW + kTN - 1) / kTN) * B;
-  const int ks = nn_ksplit(tiles, taps * (K / kTK));
+  const int ks = plan_nn(B, M, K, H, W, taps, stride).ks;
   return ks > 1 ? (size_t)ks * B * M * HW * sizeof(float) : 0;
 }
 
@@ -621,10 +1070,11 @@ extern "C" int kgdet_conv_apply_epilogue(const void *packed, const float *x, flo
   const long long HW = (long long)Ho * Wo;
   if (B * HW == 0) return KGDET_OK;
   KGDET_CHECK_SHAPE(packed && x && y, "null pointer");
-  const int n_mt = (M + kTM - 1) / kTM, n_nt = (int)((HW + kTN - 1) / kTN);
-  const long long tiles = (long long)n_mt * n_nt * B;
+  const NNPlan plan = plan_nn(B, M, K, H, W, taps, stride);
+  const int n_mt = (M + kTM - 1) / kTM, n_nt = plan.n_nt;
+  const long long tiles = plan.tiles;
   KGDET_CHECK_SHAPE(tiles < (1LL << 28), "too many tiles");
-  const int ks = nn_ksplit(tiles, taps * (K / kTK));
+  const int ks = plan.ks;
   const long long part_stride = B * M * HW;
   if (ks > 1) {
     KGDET_CHECK_SHAPE(workspace && workspace_bytes >= (size_t)ks * part_stride * sizeof(float), "workspace too small");
@@ -632,7 +1082,32 @@ extern "C" int kgdet_conv_apply_epilogue(const void *packed, const float *x, flo
   }
   const int per = (int)((tiles * ks + 7) / 8);
   float *dst = ks > 1 ? (float *)workspace : y;
-  if (taps == 1)
+  if (plan.patch && conv_patch_mode() >= 2) {
+    // fewer than ~1.6 whole-tile workgroups per CU: 64-row halves (twice the workgroups) spread evenly over the CUs
+    static const int force_halves = [] { const char *e = getenv("KGDET_CONV_HALVES"); return e ? atoi(e) : -1; }();
+    // ... and M <= 64 (layer 1): the second half has no rows and leaves at once instead of multiplying zeros
+    const bool halves = force_halves >= 0 ? force_halves != 0 : ((ks == 1 && tiles > 256 && tiles < 400) || M <= 64);
+#define KGDET_P4_ARGS (const unsigned char *)packed, x, dst, M, K, H, W, n_mt, plan.tiles_x, n_nt, (int)tiles, ks, part_stride, \
+                      plan.TX, plan.TY, ks > 1 ? nullptr : bias, ks > 1 ? nullptr : residual, ks > 1 ? 0 : relu
+    if (plan.NB == 5)
+      hipLaunchKernelGGL((conv3x3_patch4<4, 5>), dim3(per * 8), dim3(256), 0, (hipStream_t)stream, KGDET_P4_ARGS);
+    else if (halves)
+      hipLaunchKernelGGL((conv3x3_patch4<2, 4>), dim3((int)((tiles * ks * 2 + 7) / 8) * 8), dim3(128), 0, (hipStream_t)stream,
+                         KGDET_P4_ARGS);
+    else
+      hipLaunchKernelGGL((conv3x3_patch4<4, 4>), dim3(per * 8), dim3(256), 0, (hipStream_t)stream, KGDET_P4_ARGS);
+#undef KGDET_P4_ARGS
+  } else if (plan.patch) {
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+      KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_patch, hipFuncAttributeMaxDynamicSharedMemorySize, kPatchLds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3_patch, dim3(per * 8), dim3(kNNThreads), kPatchLds, (hipStream_t)stream,
+                       (const unsigned char *)packed, x, dst, M, K, H, W, n_mt, plan.tiles_x, n_nt, (int)tiles, ks,
+                       part_stride, plan.TX, plan.TY, ks > 1 ? nullptr : bias, ks > 1 ? nullptr : residual,
+                       ks > 1 ? 0 : relu);
+  } else if (taps == 1)
     hipLaunchKernelGGL(conv_nn<1>, dim3(per * 8), dim3(kNNThreads), 0, (hipStream_t)stream, (const unsigned char *)packed,
                        x, dst, M, K, Ho, Wo, n_mt, n_nt, (int)tiles, ks, part_stride, H, W, stride,
                        ks > 1 ? nullptr : bias, ks > 1 ? nullptr : residual, ks > 1 ? 0 : relu);

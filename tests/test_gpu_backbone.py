@@ -113,10 +113,13 @@ def test_training_backbone_uses_fused_op_and_matches_module_path():
     for a, b in zip(outs, outs_ref):
         assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
     assert grads.keys() == grads_ref.keys() and len(grads) > 100
-    for n in grads:
-        d = (grads[n] - grads_ref[n]).abs().max().item()
-        # fp32 summation-order noise through ~50 layers (MIOpen's strided kernels use atomics): a few 1e-4 of the scale
-        assert d <= 1e-3 * (grads_ref[n].abs().max().item() + 1e-12), (n, d)
+    # fp32 summation-order noise through ~50 layers (MIOpen's strided kernels use atomics): a few 1e-4 of the scale.  The two
+    # paths round BatchNorm differently in the last bit, so now and then a ReLU input that close to zero flips: on the 6 x 8 and
+    # 3 x 4 maps of this input one flipped element moves the gradients of its block by up to ~1 % (seen with either 3x3
+    # kernel, 1e-6 ... 1e-2 depending on the seed) -- a handful of tensors may sit there, none beyond
+    rel = {n: (grads[n] - grads_ref[n]).abs().max().item() / (grads_ref[n].abs().max().item() + 1e-12) for n in grads}
+    loose = [n for n in rel if rel[n] > 1e-3]
+    assert len(loose) <= 6 and all(rel[n] <= 3e-2 for n in loose), sorted(rel.items(), key=lambda kv: -kv[1])[:8]
 
 
 @pytest.mark.parametrize('size', [(96, 128), (97, 131), (800, 1344), (30, 33)])

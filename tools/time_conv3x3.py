@@ -1,0 +1,20 @@
+"""Kernel time of the 3x3 (or 1x1) forward convolution alone (packed image ready): HIP events around 200 back-to-back calls.
+python tools/time_conv3x3.py [k1]   (KGDET_LIB=... selects an experiment build)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from kgdet_amd import conv1x1 as c1
+k = 1 if 'k1' in sys.argv else 3
+shapes = [(2, 64, 64, 200, 336), (2, 128, 128, 100, 168), (2, 256, 256, 50, 84), (2, 512, 512, 25, 42), (2, 256, 256, 25, 42), (4, 128, 128, 96, 168)]
+for B, C, O, H, W in shapes:
+    x = torch.randn(B, C, H, W, device='cuda'); w = torch.randn(O, C, k, k, device='cuda') * 0.05
+    img = c1._pack(w, False)
+    for _ in range(10): c1._apply(img, x, O, k * k)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 200
+    e0.record()
+    for _ in range(n): c1._apply(img, x, O, k * k)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / n * 1e3
+    gf = 2 * B * C * O * H * W * k * k / 1e9
+    print('C=%4d O=%4d %3dx%-3d  %6.1f us  %5.1f TF/s (%.2f of 833)' % (C, O, H, W, us, gf / us * 1e3, gf / us * 1e3 / 833))
