@@ -918,8 +918,26 @@ namespace {
 // measured on MI355X (tools/bench_conv1x1_wgrad.py): one workgroup per CU with >= 32 stages each beats finer cuts --
 // every extra split is another [M, N] partial written and re-read
 int nt_splits(int tiles, int total_stages) {
-  int splits = (256 + tiles - 1) / tiles;
+  // Rounds over the 256 CUs decide: a CU works through a tile's stages at a fixed rate whatever shares it (the chip sits at
+  // its 1.4 kW limit in these kernels), so 261 workgroups take two rounds where 252 slightly longer ones take one (3x3,
+  // 128 channels: 107 -> 86 us).  Time ~ ceil(tiles * s / 256) / s; ties go to the finer split.
+  static const int round_up = [] { const char *e = getenv("KGDET_NT_SPLITS_UP"); return e ? atoi(e) : 0; }();   // 1: the old rule (A/B)
   const int most = (total_stages + 31) / 32;
+  int splits = (256 + tiles - 1) / tiles;
+  if (!round_up) {
+    double best = 1e30;
+    const int s_max = 2 * ((256 + tiles - 1) / tiles) < 128 ? 2 * ((256 + tiles - 1) / tiles) : 128;
+    for (int s = 1; s <= s_max; ++s) {
+      const double t = (double)((tiles * s + 255) / 256) / s;
+      if (t < best) best = t;
+    }
+    // among the best: the coarsest split that still fills 7/8 of the CUs (fewer partials to add), else the finest
+    splits = 0;
+    for (int s = 1; s <= s_max && !splits; ++s)
+      if ((double)((tiles * s + 255) / 256) / s <= best * (1.0 + 1e-9) && tiles * s >= 224 && tiles * s <= 256) splits = s;
+    for (int s = s_max; s >= 1 && !splits; --s)
+      if ((double)((tiles * s + 255) / 256) / s <= best * (1.0 + 1e-9)) splits = s;
+  }
   if (splits > most) splits = most;
   if (splits > 128) splits = 128;
   return splits < 1 ? 1 : splits;

@@ -3,7 +3,7 @@ import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from kgdet_amd import conv1x1 as c1, _lib
-for B, C, O, H, W in [(2, 128, 128, 100, 168), (2, 256, 256, 50, 84)]:
+for B, C, O, H, W in [(2, 128, 128, 100, 168), (2, 256, 256, 50, 84), (2, 512, 512, 25, 42), (2, 256, 256, 25, 42)]:
     x = torch.randn(B, C, H, W, device='cuda'); gy = torch.randn(B, O, H, W, device='cuda')
     L = c1._lib_sizes()
     nbytes = L.kgdet_conv3x3_grad_weight_workspace_bytes(ctypes.c_int64(B), ctypes.c_int32(O), ctypes.c_int32(C), ctypes.c_int32(H), ctypes.c_int32(W))

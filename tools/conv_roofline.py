@@ -31,10 +31,11 @@ def resnet50_convs():
 def main():
     times = {}
     for line in open(sys.argv[1]):
-        m = re.match(r"\| `(?:void )?kgdet::(conv_n[nt]8?<\d>)", line)
+        m = re.match(r"\| `(?:void )?kgdet::(conv_n[nt]8?<\d>|conv3x3_patch4?)", line)
         if m:
             cols = [c.strip() for c in line.split('|')]
-            times[m.group(1)] = times.get(m.group(1), 0.0) + float(cols[3])
+            name = 'conv_nn<9>' if m.group(1).startswith('conv3x3_patch') else m.group(1)   # the stride-1 3x3 kernels
+            times[name] = times.get(name, 0.0) + float(cols[-3])
     convs = resnet50_convs()
     # FPN2 lateral 1x1 (2048 -> 256 at 25x42 etc.) and the head towers (6 x 3x3 256 -> 256 at 25x42) are small next to these
     agg = {}
