@@ -183,8 +183,11 @@ constexpr int kNNThreads = 512;
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-template <int TAPS>
-__global__ __launch_bounds__(kNNThreads) void conv_nn(const unsigned char *__restrict__ img,
+// NW = 4 | 5 waves along the pixels: tiles of 128 or 160 pixels (640 threads).  A CU finishes a tile at a fixed rate whatever
+// shares it (see conv3x3_patch4), so what counts is the number of tiles the fullest CU draws: [2, 128, 100 x 168] is 264 tiles of
+// 128 pixels (sixteen CUs draw two) but 210 of 160.
+template <int TAPS, int NW = 4>
+__global__ __launch_bounds__(128 * NW) void conv_nn(const unsigned char *__restrict__ img,
                                                       const float *__restrict__ x, float *__restrict__ y, int M, int K,
                                                       int H, int W, int n_mt, int n_nt, int tiles, int ksplit,
                                                       long long part_stride, int Hin, int Win, int stride,
@@ -192,13 +195,14 @@ __global__ __launch_bounds__(kNNThreads) void conv_nn(const unsigned char *__res
                                                       const float *__restrict__ residual, int relu) {
   // bias [M] / residual [B, M, H, W] / relu: inference epilogue y = [relu](acc + bias[m] [+ residual]) (ksplit == 1)
   // H x W: the OUTPUT map; Hin x Win: the input map; stride 1 (Hin = H, Win = W) or 2 (H = ceil(Hin / 2), ...)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * kStage];   // [buf][A | B][kStage]
+  constexpr int TN = 32 * NW, kPartB = 2 * TN * 16, kBuf = kStage + 2 * kPartB;   // B part: [khalf][TN][8 bf16]
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kBuf];   // [buf][A (kStage) | B (hi, lo)]
   const int unit = xcd_tile(blockIdx.x, tiles * ksplit);
   if (unit >= tiles * ksplit) return;
   // unit order: the K parts and the m tiles of one (image, pixel tile) adjacent -> they share it through one L2
   const int part = unit % ksplit, tile = unit / ksplit;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
-  const int n_local = tid & (kTN - 1), kq = tid >> 7;   // pixel column, quarter of the stage's 16 channels
+  const int n_local = tid % TN, kq = tid / TN;   // pixel column, quarter of the stage's 16 channels
   const int N = H * W;
   const int S = TAPS * (K / kTK), per = (S + ksplit - 1) / ksplit;
   const int s_begin = part * per, s_end = max(s_begin, min(S, s_begin + per));
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(kNNThreads) void conv_nn(const unsigned char *__res
     unsigned live;
   };
   const int mt = tile % n_mt, nt = (tile / n_mt) % n_nt, b = tile / (n_mt * n_nt);
-  const int n0 = nt * kTN;
+  const int n0 = nt * TN;
   const int p = min(n0 + n_local, N - 1);   // columns past the end re-read the last one: never stored
   unsigned ok = 1u;                          // bit t: tap t of this pixel lies inside the image
   if (TAPS == 9) {
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(kNNThreads) void conv_nn(const unsigned char *__res
   const int Nin = Hin * Win;
   const int pin = stride == 1 ? p : (p / W) * stride * Win + (p - (p / W) * W) * stride;   // input pixel of tap (0, 0)
   const float *xb = x + (long long)b * K * Nin + pin;
-  const unsigned char *ai = img + (long long)mt * S * kStage + tid * 16;
+  const unsigned char *ai = img + (long long)mt * S * kStage + (tid & 511) * 16;   // (NW = 5: waves 8, 9 duplicate 0, 1 -- loads stay unconditional)
 
   f32x16 acc[2];
 #pragma unroll
@@ -247,8 +251,8 @@ __global__ __launch_bounds__(kNNThreads) void conv_nn(const unsigned char *__res
     for (int j = 0; j < 4; ++j) R.v[j] = xp[(long long)j * Nin];
   };
   auto commit = [&](int buf, const Regs &R) {
-    unsigned char *As = smem + buf * 2 * kStage, *Bs = As + kStage;
-    *reinterpret_cast<f32x4 *>(As + tid * 16) = R.a;
+    unsigned char *As = smem + buf * kBuf, *Bs = As + kStage;
+    *reinterpret_cast<f32x4 *>(As + (tid & 511) * 16) = R.a;
     uint2 hi, lo;
 #ifdef KGDET_CONV_ABL_NOSPLIT   // ablation (timing only, wrong results): no conversion VALU
     hi.x = __float_as_uint(R.v[0]); hi.y = __float_as_uint(R.v[1]); lo.x = __float_as_uint(R.v[2]); lo.y = __float_as_uint(R.v[3]);
@@ -256,13 +260,13 @@ __global__ __launch_bounds__(kNNThreads) void conv_nn(const unsigned char *__res
     split_pair(R.live ? R.v[0] : 0.0f, R.live ? R.v[1] : 0.0f, hi.x, lo.x);
     split_pair(R.live ? R.v[2] : 0.0f, R.live ? R.v[3] : 0.0f, hi.y, lo.y);
 #endif
-    unsigned char *dst = Bs + (kq >> 1) * (kTN * 16) + n_local * 16 + (kq & 1) * 8;
+    unsigned char *dst = Bs + (kq >> 1) * (TN * 16) + n_local * 16 + (kq & 1) * 8;
     *reinterpret_cast<uint2 *>(dst) = hi;
-    *reinterpret_cast<uint2 *>(dst + kPart) = lo;
+    *reinterpret_cast<uint2 *>(dst + kPartB) = lo;
   };
   auto multiply = [&](int buf) {   // wave (wm, wn): rows wm*64 .. +63, columns wn*32 .. +31
-    const unsigned char *A = smem + buf * 2 * kStage + (lane >> 5) * (kTM * 16) + (wm * 64 + (lane & 31)) * 16;
-    const unsigned char *Bp = smem + buf * 2 * kStage + kStage + (lane >> 5) * (kTN * 16) + (wn * 32 + (lane & 31)) * 16;
+    const unsigned char *A = smem + buf * kBuf + (lane >> 5) * (kTM * 16) + (wm * 64 + (lane & 31)) * 16;
+    const unsigned char *Bp = smem + buf * kBuf + kStage + (lane >> 5) * (TN * 16) + (wn * 32 + (lane & 31)) * 16;
     bf16x8 a[2][2], bb[2];
 #ifdef KGDET_CONV_ABL_NOLDSREAD   // ablation: fragments from registers (no LDS reads)
 #pragma unroll
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(kNNThreads) void conv_nn(const unsigned char *__res
     for (int pt = 0; pt < 2; ++pt) {
       a[pt][0] = *reinterpret_cast<const bf16x8 *>(A + pt * kPart);
       a[pt][1] = *reinterpret_cast<const bf16x8 *>(A + pt * kPart + 32 * 16);
-      bb[pt] = *reinterpret_cast<const bf16x8 *>(Bp + pt * kPart);
+      bb[pt] = *reinterpret_cast<const bf16x8 *>(Bp + pt * kPartB);
     }
 #endif
 #ifdef KGDET_CONV_ABL_NOMFMA
@@ -956,7 +960,7 @@ int nn_ksplit(long long tiles, int stages) {
 // conv_nn or conv3x3_patch, the pixel tiling and the K split of one convolution (workspace query and launch agree on it)
 struct NNPlan {
   bool patch;
-  int TX, TY, NB, tiles_x, n_nt, ks;
+  int TX, TY, NB, NW, tiles_x, n_nt, ks;
   long long tiles;
 };
 int conv_patch_mode() {   // 2: conv3x3_patch4 (default), 1: conv3x3_patch, 0: conv_nn<9>  (A/B)
@@ -970,7 +974,7 @@ NNPlan plan_nn(long long B, int M, int K, int H, int W, int taps, int stride) {
   const int n_mt = (M + kTM - 1) / kTM;
   p.patch = false;
   p.TX = p.TY = p.tiles_x = 0;
-  p.NB = 4;
+  p.NB = p.NW = 4;
   p.n_nt = (int)(((long long)Ho * Wo + kTN - 1) / kTN);
   if (taps == 9 && stride == 1 && conv_patch_enabled()) {
     // the tile shape with the fewest tiles (ties: the smaller patch); TX >= 8 keeps the stores in >= 32-byte runs
@@ -994,6 +998,18 @@ NNPlan plan_nn(long long B, int M, int K, int H, int W, int taps, int stride) {
       p.patch = true;
       p.tiles_x = (W + p.TX - 1) / p.TX;
       p.n_nt = p.tiles_x * ((H + p.TY - 1) / p.TY);
+    }
+  }
+  if (!p.patch) {
+    // conv_nn: 128- or 160-pixel tiles by the number of tiles the fullest of the 256 CUs draws (x the tile's width); only where
+    // no K split is needed anyway, and only for a clear win
+    static const int force_nw = [] { const char *e = getenv("KGDET_CONV_NW"); return e ? atoi(e) : 0; }();   // 4 | 5 (A/B)
+    const long long hw = (long long)Ho * Wo;
+    const long long u4 = (long long)n_mt * ((hw + 127) / 128) * B, u5 = (long long)n_mt * ((hw + 159) / 160) * B;
+    const long long c4 = ((u4 + 255) / 256) * 4, c5 = ((u5 + 255) / 256) * 5;
+    if (force_nw == 5 || (force_nw == 0 && u4 >= 200 && u5 >= 200 && c5 * 10 <= c4 * 9)) {
+      p.NW = 5;
+      p.n_nt = (int)((hw + 159) / 160);
     }
   }
   p.tiles = (long long)n_mt * p.n_nt * B;
@@ -1125,14 +1141,19 @@ extern "C" int kgdet_conv_apply_epilogue(const void *packed, const float *x, flo
                        (const unsigned char *)packed, x, dst, M, K, H, W, n_mt, plan.tiles_x, n_nt, (int)tiles, ks,
                        part_stride, plan.TX, plan.TY, ks > 1 ? nullptr : bias, ks > 1 ? nullptr : residual,
                        ks > 1 ? 0 : relu);
-  } else if (taps == 1)
-    hipLaunchKernelGGL(conv_nn<1>, dim3(per * 8), dim3(kNNThreads), 0, (hipStream_t)stream, (const unsigned char *)packed,
-                       x, dst, M, K, Ho, Wo, n_mt, n_nt, (int)tiles, ks, part_stride, H, W, stride,
-                       ks > 1 ? nullptr : bias, ks > 1 ? nullptr : residual, ks > 1 ? 0 : relu);
-  else
-    hipLaunchKernelGGL(conv_nn<9>, dim3(per * 8), dim3(kNNThreads), 0, (hipStream_t)stream, (const unsigned char *)packed,
-                       x, dst, M, K, Ho, Wo, n_mt, n_nt, (int)tiles, ks, part_stride, H, W, stride,
-                       ks > 1 ? nullptr : bias, ks > 1 ? nullptr : residual, ks > 1 ? 0 : relu);
+  } else {
+#define KGDET_NN_ARGS (const unsigned char *)packed, x, dst, M, K, Ho, Wo, n_mt, n_nt, (int)tiles, ks, part_stride, H, W, stride, \
+                      ks > 1 ? nullptr : bias, ks > 1 ? nullptr : residual, ks > 1 ? 0 : relu
+    if (taps == 1 && plan.NW == 5)
+      hipLaunchKernelGGL((conv_nn<1, 5>), dim3(per * 8), dim3(640), 0, (hipStream_t)stream, KGDET_NN_ARGS);
+    else if (taps == 1)
+      hipLaunchKernelGGL((conv_nn<1, 4>), dim3(per * 8), dim3(512), 0, (hipStream_t)stream, KGDET_NN_ARGS);
+    else if (plan.NW == 5)
+      hipLaunchKernelGGL((conv_nn<9, 5>), dim3(per * 8), dim3(640), 0, (hipStream_t)stream, KGDET_NN_ARGS);
+    else
+      hipLaunchKernelGGL((conv_nn<9, 4>), dim3(per * 8), dim3(512), 0, (hipStream_t)stream, KGDET_NN_ARGS);
+#undef KGDET_NN_ARGS
+  }
   KGDET_CHECK_LAUNCH("conv_nn");
   if (ks > 1) {
     const long long blocks = (part_stride / 2 + 255) / 256;

@@ -218,11 +218,13 @@ def test_resnet_with_dcn_stages_builds_and_steps():
 @pytest.mark.parametrize('k', [1, 3])
 @pytest.mark.parametrize('B,C,O,H,W', [(2, 64, 256, 20, 34), (1, 256, 64, 9, 14), (2, 512, 128, 25, 42), (2, 128, 512, 13, 10),
                                        (3, 1024, 256, 6, 8), (2, 2048, 512, 25, 42), (2, 16, 48, 5, 6), (2, 32, 16, 129, 2),
-                                       (2, 128, 128, 30, 44), (2, 256, 128, 9, 84), (1, 128, 256, 7, 4)])
+                                       (2, 128, 128, 30, 44), (2, 256, 128, 9, 84), (1, 128, 256, 7, 4),
+                                       (2, 512, 128, 100, 168), (2, 64, 2048, 25, 42), (2, 128, 128, 100, 168)])
 def test_conv1x1_split_matches_fp64_convolution(B, C, O, H, W, k, monkeypatch):
     """csrc/conv1x1.hip (bf16 hi/lo-split MFMA GEMMs): forward, grad_input and grad_weight against the fp64
     convolution, to fp32-level accuracy (1e-5 of the result's scale; MIOpen's fp32 kernels sit at ~1e-6); ragged
-    pixel tiles, M < 128, the K-split and the 8- and 16-byte load variants of grad_weight."""
+    pixel tiles, M < 128, the K-split and the 8- and 16-byte load variants of grad_weight; the last three shapes take the
+    160-pixel tiles (264 / 288 tiles of 128 pixels: conv_nn<1, 5>, conv3x3_patch4<4, 5>)."""
     from kgdet_amd import conv1x1 as c1
     monkeypatch.setattr(c1, 'SPLIT_GRAD_WEIGHT_3X3', True)     # exercise the 3x3 grad_weight kernel too
     g = torch.Generator(device='cpu').manual_seed(C + O + H)
