@@ -278,6 +278,20 @@ int kgdet_sigmoid_focal_loss_backward(const float *logits, const int64_t *target
                                       int64_t num, int32_t num_classes, float gamma, float alpha,
                                       float *d_logits, void *stream);
 
+/*
+ * Weighted smooth-L1 sum of the head's box / keypoint losses in one pass each way: what the reference computes as a chain of
+ * element-wise torch ops (mmdet/models/losses/smooth_l1_loss.py:8-45, utils.py:7-52 called from KP3:362-369 with
+ * pred / d and target / d):   sum_out[0] = sum_i weight[i] * l(|pred[i] / d - target[i] / d|),
+ * l(x) = x < beta ? 0.5 x^2 / beta : x - 0.5 beta;   grad_pred[i] = grad_sum[0] * weight[i] * l'(.) / d.
+ * n elements, weight nullable (all ones); partial: kgdet_smooth_l1_partials() floats of scratch; grad_sum: DEVICE scalar (no
+ * host round trip).  The caller applies loss_weight and 1 / avg_factor to the sum.  Deterministic.
+ */
+int32_t kgdet_smooth_l1_partials(void);
+int kgdet_smooth_l1_sum_forward(const float *pred, const float *target, const float *weight, int64_t n, float beta,
+                                float divisor, float *partial, float *sum_out, void *stream);
+int kgdet_smooth_l1_sum_backward(const float *pred, const float *target, const float *weight, const float *grad_sum, int64_t n,
+                                 float beta, float divisor, float *grad_pred, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * NMS.  kgdet_nms replaces nms_cpu.nms / nms_cuda.nms (R/nms/src/nms_cpu.cpp:62-68,
  * nms_kernel.cu:70-131) with the CPU semantics the project pins: +1 areas, suppress when

@@ -122,6 +122,15 @@ class Kp3RepBlock(nn.Module):
         return cls_out, keypts_out, reppts_out
 
 
+def _normalised_loss(loss_module, pred, target, weight, normalize_term, avg_factor):
+    """``loss(pred / normalize_term, target / normalize_term, weight, avg_factor)`` (KP3:362-369); a SmoothL1Loss takes the
+    divisor itself, so that its fused HIP op works on the raw tensors"""
+    from .losses import SmoothL1Loss
+    if type(loss_module) is SmoothL1Loss:
+        return loss_module(pred, target, weight, avg_factor=avg_factor, divisor=normalize_term)
+    return loss_module(pred / normalize_term, target / normalize_term, weight, avg_factor=avg_factor)
+
+
 class PointHeadMixin(object):
     """point-set helpers shared by the KGDet head and the serial / parallel two-stage heads
     (identical code in KP3:342-410, 497-579 and reppoints_head_kp_serial.py:187-252, 341-423)"""
@@ -360,13 +369,11 @@ class RepPointsHeadKp3RepCas1AssignOnce(PointHeadMixin, nn.Module):
             losses.append(getattr(self, 'loss_cls_%d' % stage)(cls_score, labels, label_weights,
                                                                avg_factor=num_total_samples))
         for stage, bbox_pred in enumerate((bbox_pred_1, bbox_pred_2, bbox_pred_3), 1):
-            losses.append(getattr(self, 'loss_bbox_%d' % stage)(
-                bbox_pred.reshape(-1, 4) / normalize_term, bbox_gt / normalize_term, bbox_weights,
-                avg_factor=num_total_samples))
+            losses.append(_normalised_loss(getattr(self, 'loss_bbox_%d' % stage), bbox_pred.reshape(-1, 4), bbox_gt,
+                                           bbox_weights, normalize_term, num_total_samples))
         for stage, kpt_pred in enumerate((kpt_pred_1, kpt_pred_2, kpt_pred_3), 1):
-            losses.append(getattr(self, 'loss_kpt_%d' % stage)(
-                kpt_pred.reshape(-1, self.num_keypts * 2) / normalize_term, kpt_gt / normalize_term, kpt_weights,
-                avg_factor=num_total_samples))
+            losses.append(_normalised_loss(getattr(self, 'loss_kpt_%d' % stage), kpt_pred.reshape(-1, self.num_keypts * 2),
+                                           kpt_gt, kpt_weights, normalize_term, num_total_samples))
         return tuple(losses)
 
     def loss(self, cls_scores_1, cls_scores_2, cls_scores_3, keypts_preds_1, keypts_preds_2, keypts_preds_3,

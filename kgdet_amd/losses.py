@@ -3,7 +3,9 @@
 
 Mirrors mmdet/models/losses/focal_loss.py:28-82, smooth_l1_loss.py:8-45, utils.py:7-52.
 """
+import ctypes
 import functools
+import os as _os
 
 import torch
 import torch.nn as nn
@@ -82,6 +84,47 @@ def smooth_l1_loss(pred, target, beta=1.0):
     return torch.where(diff < beta, 0.5 * diff * diff / beta, diff - 0.5 * beta)
 
 
+FUSED_SMOOTH_L1 = _os.environ.get('KGDET_FUSED_SMOOTH_L1', '1') == '1'    # csrc/smooth_l1.hip (0: the reference's torch chain; A/B)
+
+
+def fused_smooth_l1_applicable(pred, target, weight, reduction, avg_factor):
+    return (FUSED_SMOOTH_L1 and pred.is_cuda and pred.dtype == torch.float32 and target.dtype == torch.float32
+            and pred.shape == target.shape and pred.numel() > 0 and not target.requires_grad
+            and (weight is None or (weight.dtype == torch.float32 and weight.shape == pred.shape and not weight.requires_grad))
+            and reduction == 'mean' and avg_factor is not None and not torch.is_autocast_enabled())
+
+
+class _SmoothL1Sum(torch.autograd.Function):
+    """sum(weight * smooth_l1(pred / d - target / d)) as one HIP pass each way (csrc/smooth_l1.hip); the reference runs it as
+    ~14 element-wise kernels forward and as many backward (smooth_l1_loss.py:8-19, utils.py:7-52)"""
+
+    @staticmethod
+    def forward(ctx, pred, target, weight, beta, divisor):
+        from . import _lib
+        L = _lib.lib()
+        partial = torch.empty(L.kgdet_smooth_l1_partials(), dtype=torch.float32, device=pred.device)
+        out = torch.empty((), dtype=torch.float32, device=pred.device)
+        _lib.check(L.kgdet_smooth_l1_sum_forward(
+            _lib.ptr(pred), _lib.ptr(target), _lib.ptr(weight) if weight is not None else None, ctypes.c_int64(pred.numel()),
+            ctypes.c_float(beta), ctypes.c_float(divisor), _lib.ptr(partial), _lib.ptr(out), _lib.current_stream()),
+            'smooth_l1_sum_forward')
+        ctx.save_for_backward(pred, target, weight)
+        ctx.beta, ctx.divisor = beta, divisor
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        pred, target, weight = ctx.saved_tensors
+        grad = torch.empty_like(pred)
+        g = g.contiguous().float()
+        _lib.check(_lib.lib().kgdet_smooth_l1_sum_backward(
+            _lib.ptr(pred), _lib.ptr(target), _lib.ptr(weight) if weight is not None else None, _lib.ptr(g),
+            ctypes.c_int64(pred.numel()), ctypes.c_float(ctx.beta), ctypes.c_float(ctx.divisor), _lib.ptr(grad),
+            _lib.current_stream()), 'smooth_l1_sum_backward')
+        return grad, None, None, None, None
+
+
 @LOSSES.register_module
 class SmoothL1Loss(nn.Module):
 
@@ -91,8 +134,17 @@ class SmoothL1Loss(nn.Module):
         self.reduction = reduction
         self.loss_weight = loss_weight
 
-    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None, **kwargs):
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None, divisor=None, **kwargs):
+        """``divisor`` (not in the reference signature): the loss of ``pred / divisor`` and ``target / divisor`` -- the head
+        normalises both by ``point_base_scale * stride`` (KP3:362-369); passing the divisor instead lets the fused HIP op
+        take the raw tensors.  Same value either way."""
         assert reduction_override in (None, 'none', 'mean', 'sum')
         reduction = reduction_override if reduction_override else self.reduction
+        if fused_smooth_l1_applicable(pred, target, weight, reduction, avg_factor):
+            s = _SmoothL1Sum.apply(pred.contiguous(), target.contiguous(), None if weight is None else weight.contiguous(),
+                                   float(self.beta), 1.0 if divisor is None else float(divisor))
+            return self.loss_weight * (s / avg_factor)
+        if divisor is not None:
+            pred, target = pred / divisor, target / divisor
         return self.loss_weight * smooth_l1_loss(pred, target, weight, beta=self.beta, reduction=reduction,
                                                  avg_factor=avg_factor, **kwargs)

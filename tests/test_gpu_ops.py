@@ -281,3 +281,36 @@ def test_nms_beyond_the_on_chip_limit_bit_exact(golden_dir):
     for s, w in enumerate(want):
         assert num[s] == len(w)
         np.testing.assert_array_equal(keep[offs[s]:offs[s] + num[s]], w)
+
+
+@pytest.mark.parametrize('shape,beta,divisor,with_weight', [((2100, 588), 1.0 / 9.0, 128.0, True), ((2100, 4), 1.0 / 9.0, 128.0, True),
+                                                            ((37, 5), 1.0, None, False), ((1, 1), 0.5, 3.0, True),
+                                                            ((10500, 588), 1.0 / 9.0, 32.0, True)])
+def test_fused_smooth_l1_matches_reference_chain(shape, beta, divisor, with_weight):
+    """SmoothL1Loss on the HIP op (csrc/smooth_l1.hip: one pass each way) against the reference's chain of torch ops
+    (smooth_l1_loss.py:8-45, utils.py:7-52; KP3:362-369 divides prediction and target by point_base_scale * stride first):
+    the loss to 2e-6 (the only difference is the order of the fp32 sum), the gradient to rounding; a device-tensor
+    avg_factor (the sync-free training path) and a Python one."""
+    from kgdet_amd import losses
+    torch.manual_seed(shape[0])
+    pred = (torch.randn(*shape, device='cuda') * 40 + 300).requires_grad_()
+    target = pred.detach() + torch.randn(*shape, device='cuda') * 20
+    target[::3] = pred.detach()[::3]          # exact zeros of the difference (|x|' = 0 there)
+    weight = (torch.rand(*shape, device='cuda') > 0.7).float() * torch.rand(*shape, device='cuda') if with_weight else None
+    mod = losses.SmoothL1Loss(beta=beta, loss_weight=0.5)
+    for avg in (torch.tensor(17.0, device='cuda'), 17.0):
+        assert losses.fused_smooth_l1_applicable(pred, target, weight, 'mean', avg)
+        got = mod(pred, target, weight, avg_factor=avg, divisor=divisor)
+        assert type(got.grad_fn).__name__ != 'NoneType'
+        got.backward()
+        g_got, pred.grad = pred.grad.clone(), None
+        losses.FUSED_SMOOTH_L1 = False
+        try:
+            want = mod(pred, target, weight, avg_factor=avg, divisor=divisor)
+        finally:
+            losses.FUSED_SMOOTH_L1 = True
+        want.backward()
+        g_want, pred.grad = pred.grad.clone(), None
+        assert abs(float(got) - float(want)) <= 2e-6 * max(abs(float(want)), 1e-6), (float(got), float(want))
+        assert (g_got - g_want).abs().max().item() <= 1e-6 * g_want.abs().max().item() + 1e-12
+        assert ((g_got == 0) == (g_want == 0)).all()
