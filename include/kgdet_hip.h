@@ -94,6 +94,12 @@ int kgdet_bn_relu_maxpool(const float *x, const float *gamma, const float *beta,
  * mmdet/models/backbones/resnet.py:231-262 once the frozen statistics are folded into the weights. */
 int kgdet_bias_act(void *x, const float *bias, const void *residual, int64_t N, int32_t C, int64_t HW, int32_t dtype,
                    int32_t relu, int32_t channels_last, void *stream);
+/* The stem at inference with the frozen BatchNorm folded into conv1: y = maxpool3x3/s2/p1(relu(x + bias[c])) in one pass on
+ * channels-last tensors (mmdet/models/backbones/resnet.py:487-491, 528); x [N, H, W, C] -> y [N, (H-1)/2+1, (W-1)/2+1, C];
+ * dtype 0 = float32 (C % 4 == 0), 1 = bfloat16 (C % 8 == 0), else KGDET_E_UNSUPPORTED; bias [C] float32, nullable.  Same
+ * values as kgdet_bias_act + max pooling (each element is rounded to the storage type before the maximum). */
+int kgdet_bias_relu_maxpool_nhwc(const void *x, const float *bias, void *y, int64_t N, int32_t C, int32_t H, int32_t W,
+                                 int32_t dtype, void *stream);
 
 /* HIP runtime error (launch failure etc.) */
 #define KGDET_E_UNSUPPORTED 4

@@ -217,7 +217,7 @@ class _ConvBNAct(torch.autograd.Function):
         return gx, gw, ggamma, gbeta, None, None, None, gres, None, None
 
 
-FUSE_STEM = True        # False: conv_bn + nn.MaxPool2d (the tests compare the two)
+FUSE_STEM = _os.environ.get('KGDET_FUSE_STEM', '1') == '1'   # 0 / False: conv_bn + nn.MaxPool2d (the tests compare the two)
 MERGE_CONV_BN = True    # False: two nodes (conv_split, frozen_bn_act) -- the tests compare the two
 SKIP_ALIAS = _os.environ.get('KGDET_SKIP_ALIAS', '1') == '1'   # identity-branch gradient added inside conv1's grad_input (0: A/B)
 
@@ -250,7 +250,7 @@ def conv_bn(conv, bn, x, relu=False, residual=None, skip=False):
     return out
 
 
-def _conv_bn(conv, bn, x, relu=False, residual=None, skip=False):
+def _conv_bn(conv, bn, x, relu=False, residual=None, skip=False, raw=False):
     """conv_bn's body (with ``skip`` the training fast path may return the (output, alias) pair itself).  In inference (autograd off, BatchNorm in eval mode, plain bias-free
     Conv2d) the frozen statistics are folded into the convolution -- w' = w * gamma / sigma,
     b' = beta - mu * gamma / sigma -- and bias, residual add and ReLU run as ONE in-place pass over the activation
@@ -311,6 +311,8 @@ def _conv_bn(conv, bn, x, relu=False, residual=None, skip=False):
         out = conv1x1._apply(hit[3], x, hit[1].shape[0], hit[1].shape[2] * hit[1].shape[3])
     else:
         out = F.conv2d(x, hit[1], None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    if raw:     # (the stem: the caller fuses bias + ReLU with the pooling)
+        return out, hit[2]
     return _epilogue_(out, hit[2], residual, relu)
 
 
@@ -547,6 +549,24 @@ class ResNet(nn.Module):
                     _p(y), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), bn.eps, _p(out), N, C, H, W,
                     _lib.raw_stream(y.device.index)), 'bn_relu_maxpool')
             return out
+        if (FUSE_STEM and x.is_cuda and not torch.is_grad_enabled() and isinstance(bn, _BatchNorm) and not bn.training
+                and bn.track_running_stats and type(self.conv1) is nn.Conv2d and self.conv1.bias is None
+                and (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode) == (3, 2, 1, 1, False)):
+            # inference, channels-last (bf16 autocast): BatchNorm is folded into conv1; bias + ReLU + pooling as one pass
+            y, shift = _conv_bn(self.conv1, bn, x, relu=True, raw=True)
+            C = y.shape[1]
+            if (y.dtype in (torch.float32, torch.bfloat16) and y.dim() == 4 and not y.is_contiguous()
+                    and y.is_contiguous(memory_format=torch.channels_last) and C % (4 if y.dtype == torch.float32 else 8) == 0):
+                from . import _lib
+                N, _, H, W = y.shape
+                out = torch.empty((N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=y.dtype, device=y.device,
+                                  memory_format=torch.channels_last)
+                _lib.check(_lib.lib().kgdet_bias_relu_maxpool_nhwc(
+                    _lib.ptr(y), _lib.ptr(shift), _lib.ptr(out), ctypes.c_int64(N), ctypes.c_int32(C), ctypes.c_int32(H),
+                    ctypes.c_int32(W), ctypes.c_int32(0 if y.dtype == torch.float32 else 1), _lib.current_stream()),
+                    'bias_relu_maxpool_nhwc')
+                return out
+            return self.maxpool(_epilogue_(y, shift, None, True))
         return self.maxpool(conv_bn(self.conv1, self.norm1, x, relu=True))
 
     def forward(self, x):

@@ -93,9 +93,79 @@ __global__ __launch_bounds__(256) void bias_act_nhwc_kernel(T *__restrict__ x, c
   }
 }
 
+// The stem at inference (folded BatchNorm): y = maxpool3x3/s2/p1(relu(x + bias[c])) on channels-last tensors in one pass --
+// instead of the in-place epilogue over the full-resolution map and torch's pooling kernel (bf16, batch 8: 275 MB read +
+// written, then read again).  Each element is rounded to T after bias + ReLU, as the two-pass route does, so the results
+// are identical.  x [N, H, W, C] -> y [N, Ho, Wo, C]; a thread owns one output pixel's vector of 16 bytes.
+template <typename T>
+__global__ __launch_bounds__(256) void bias_relu_maxpool_nhwc_kernel(const T *__restrict__ x, const float *__restrict__ bias,
+                                                                     T *__restrict__ y, int C, int H, int W, int Ho, int Wo,
+                                                                     long long nvec) {
+  constexpr int V = Vec16<T>::n;
+  typedef T vec_t __attribute__((ext_vector_type(V)));
+  const int cv = C / V;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < nvec; i += gridDim.x * 256LL) {
+    const int c = (int)(i % cv);
+    long long p = i / cv;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho);
+    const long long n = p / Ho;
+    float bv[V], m[V];
+#pragma unroll
+    for (int k = 0; k < V; k += 4) {
+      const float4 b4 = bias ? *reinterpret_cast<const float4 *>(bias + c * V + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bv[k] = b4.x; bv[k + 1] = b4.y; bv[k + 2] = b4.z; bv[k + 3] = b4.w;
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) m[k] = 0.0f;   // relu(.) >= 0 and every window holds a valid element
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int iy = 2 * oy + dy;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int ix = 2 * ox + dx;
+        if (ix < 0 || ix >= W) continue;
+        const vec_t v = reinterpret_cast<const vec_t *>(x)[((n * H + iy) * W + ix) * cv + c];
+#pragma unroll
+        for (int k = 0; k < V; ++k) m[k] = fmaxf(m[k], (float)(T)fmaxf((float)v[k] + bv[k], 0.0f));
+      }
+    }
+    vec_t o;
+#pragma unroll
+    for (int k = 0; k < V; ++k) o[k] = (T)m[k];
+    reinterpret_cast<vec_t *>(y)[i] = o;
+  }
+}
+
 }  // namespace kgdet
 
 using namespace kgdet;
+
+extern "C" int kgdet_bias_relu_maxpool_nhwc(const void *x, const float *bias, void *y, int64_t N, int32_t C, int32_t H,
+                                            int32_t W, int32_t dtype, void *stream) {
+  KGDET_CHECK_SHAPE(N >= 0 && C > 0 && H > 0 && W > 0 && (dtype == 0 || dtype == 1), "bad arguments");
+  if (N == 0) return KGDET_OK;
+  KGDET_CHECK_SHAPE(x && y, "null pointer");
+  const int V = dtype == 0 ? 4 : 8;
+  if (C % V != 0) {
+    set_error("bias_relu_maxpool_nhwc: C = %d is not a multiple of %d", C, V);
+    return KGDET_E_UNSUPPORTED;
+  }
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long long nvec = (long long)N * Ho * Wo * (C / V);
+  const long long want = (nvec + 255) / 256;
+  dim3 grid((unsigned)(want > 65536 ? 65536 : want));
+  if (dtype == 0)
+    hipLaunchKernelGGL(bias_relu_maxpool_nhwc_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)x, bias,
+                       (float *)y, C, H, W, Ho, Wo, nvec);
+  else
+    hipLaunchKernelGGL(bias_relu_maxpool_nhwc_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16 *)x, bias,
+                       (__bf16 *)y, C, H, W, Ho, Wo, nvec);
+  KGDET_CHECK_LAUNCH("bias_relu_maxpool_nhwc");
+  return KGDET_OK;
+}
 
 extern "C" int kgdet_bias_act(void *x, const float *bias, const void *residual, int64_t N, int32_t C, int64_t HW,
                               int32_t dtype, int32_t relu, int32_t channels_last, void *stream) {

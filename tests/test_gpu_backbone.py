@@ -149,6 +149,32 @@ def test_fused_stem_matches_module_path(size, grad_mode):
     assert y.requires_grad       # a trainable stem stays on autograd-recording modules
 
 
+@pytest.mark.parametrize('size', [(96, 128), (97, 131), (800, 1344)])
+def test_fused_stem_inference_bf16_channels_last(size):
+    """inference under bf16 autocast: conv1 (BatchNorm folded, channels-last) + ONE pass for bias, ReLU and the max pooling
+    (bias_relu_maxpool_nhwc) gives the same tensor, bit for bit, as the in-place epilogue followed by nn.MaxPool2d"""
+    from kgdet_amd import backbone as bb
+    torch.manual_seed(2)
+    net = bb.ResNet(depth=50, num_stages=1, strides=(1,), dilations=(1,), out_indices=(0,), frozen_stages=0,
+                    style='pytorch').cuda()
+    net.norm1.running_mean.normal_(0, 0.3)
+    net.norm1.running_var.uniform_(0.5, 1.5)
+    net.norm1.weight.data.normal_(0, 1.0)
+    net.norm1.bias.data.normal_(0, 0.3)
+    net.eval()
+    x = torch.randn(2, 3, *size, device='cuda')
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+        got = net._stem(x)
+        bb.FUSE_STEM = False
+        try:
+            want = net._stem(x)
+        finally:
+            bb.FUSE_STEM = True
+    assert got.dtype == torch.bfloat16 and got.shape == want.shape
+    assert got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize('modulated', [False, True])
 @pytest.mark.parametrize('stride', [1, 2])
 def test_bottleneck_dcn_option_matches_torch_reference(modulated, stride):
