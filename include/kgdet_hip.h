@@ -286,7 +286,7 @@ int kgdet_sigmoid_focal_loss_backward(const float *logits, const int64_t *target
 
 /*
  * Weighted smooth-L1 sum of the head's box / keypoint losses in one pass each way: what the reference computes as a chain of
- * element-wise torch ops (mmdet/models/losses/smooth_l1_loss.py:8-45, utils.py:7-52 called from KP3:362-369 with
+ * element-wise torch ops (mmdet/models/losses/smooth_l1_loss.py:8-45, utils.py:7-52 called from KP3:621-665 with
  * pred / d and target / d):   sum_out[0] = sum_i weight[i] * l(|pred[i] / d - target[i] / d|),
  * l(x) = x < beta ? 0.5 x^2 / beta : x - 0.5 beta;   grad_pred[i] = grad_sum[0] * weight[i] * l'(.) / d.
  * n elements, weight nullable (all ones); partial: kgdet_smooth_l1_partials() floats of scratch; grad_sum: DEVICE scalar (no

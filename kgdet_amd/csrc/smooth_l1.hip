@@ -1,6 +1,6 @@
 // Weighted smooth-L1 loss of the KGDet head's box / keypoint branches as one pass each way (gfx950).
 //
-// The reference computes  sum(w * smooth_l1(pred / d - target / d)) / avg_factor  (KP3:362-369 with
+// The reference computes  sum(w * smooth_l1(pred / d - target / d)) / avg_factor  (KP3:621-665 with
 // mmdet/models/losses/smooth_l1_loss.py:8-45 and utils.py:7-52) as a chain of element-wise torch kernels -- two divisions,
 // subtract, abs, compare, the two branches, select, weight, sum: fourteen launches forward and about as many backward per
 // loss, six losses per step, on tensors of 2100 x 588 (keypoints) or 2100 x 4 (boxes) elements.  Same expressions, same

@@ -123,7 +123,7 @@ class Kp3RepBlock(nn.Module):
 
 
 def _normalised_loss(loss_module, pred, target, weight, normalize_term, avg_factor):
-    """``loss(pred / normalize_term, target / normalize_term, weight, avg_factor)`` (KP3:362-369); a SmoothL1Loss takes the
+    """``loss(pred / normalize_term, target / normalize_term, weight, avg_factor)`` (KP3:621-665); a SmoothL1Loss takes the
     divisor itself, so that its fused HIP op works on the raw tensors"""
     from .losses import SmoothL1Loss
     if type(loss_module) is SmoothL1Loss:

@@ -136,7 +136,7 @@ class SmoothL1Loss(nn.Module):
 
     def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None, divisor=None, **kwargs):
         """``divisor`` (not in the reference signature): the loss of ``pred / divisor`` and ``target / divisor`` -- the head
-        normalises both by ``point_base_scale * stride`` (KP3:362-369); passing the divisor instead lets the fused HIP op
+        normalises both by ``point_base_scale * stride`` (KP3:621-665); passing the divisor instead lets the fused HIP op
         take the raw tensors.  Same value either way."""
         assert reduction_override in (None, 'none', 'mean', 'sum')
         reduction = reduction_override if reduction_override else self.reduction

@@ -288,7 +288,7 @@ def test_nms_beyond_the_on_chip_limit_bit_exact(golden_dir):
                                                             ((10500, 588), 1.0 / 9.0, 32.0, True)])
 def test_fused_smooth_l1_matches_reference_chain(shape, beta, divisor, with_weight):
     """SmoothL1Loss on the HIP op (csrc/smooth_l1.hip: one pass each way) against the reference's chain of torch ops
-    (smooth_l1_loss.py:8-45, utils.py:7-52; KP3:362-369 divides prediction and target by point_base_scale * stride first):
+    (smooth_l1_loss.py:8-45, utils.py:7-52; KP3:621-665 divides prediction and target by point_base_scale * stride first):
     the loss to 2e-6 (the only difference is the order of the fp32 sum), the gradient to rounding; a device-tensor
     avg_factor (the sync-free training path) and a Python one."""
     from kgdet_amd import losses
