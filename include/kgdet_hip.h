@@ -55,6 +55,11 @@ int kgdet_conv_apply(const void *packed, const float *x, float *y, int64_t B, in
 int kgdet_conv_apply_epilogue(const void *packed, const float *x, float *y, const float *bias, const float *residual,
                               int32_t relu, int64_t B, int32_t M, int32_t K, int32_t H, int32_t W, int32_t taps,
                               int32_t stride, void *workspace, size_t workspace_bytes, void *stream);
+/* grad_x [B, C, Hin, Win] of the 3x3 stride-2 padding-1 convolution (the bottleneck's conv2 at the head of layers 2-4,
+ * mmdet/models/backbones/resnet.py:142-186 with stride 2) from grad_y [B, O, ceil(Hin/2), ceil(Win/2)] and the TRANSPOSED image
+ * of its weight (kgdet_conv_pack(w, O, C, 9, 1, ...)); O % 16 == 0.  Replaces ATen's convolution_backward (MIOpen). */
+int kgdet_conv3x3_s2_grad_input(const void *packed_t, const float *grad_y, float *grad_x, int64_t B, int32_t C, int32_t O,
+                                int32_t Hin, int32_t Win, void *stream);
 size_t kgdet_conv1x1_grad_weight_workspace_bytes(int64_t B, int32_t O, int32_t C, int64_t HW);
 int kgdet_conv1x1_grad_weight(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O, int32_t C,
                               int64_t HW, void *workspace, size_t workspace_bytes, void *stream);

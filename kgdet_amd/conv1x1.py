@@ -55,6 +55,7 @@ def _lib_sizes():
                 ('kgdet_conv_apply', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
                 ('kgdet_conv_apply_epilogue', ctypes.c_int,
                  [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+                ('kgdet_conv3x3_s2_grad_input', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i32, i32, vp]),
                 ('kgdet_conv1x1_grad_weight', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i64, vp, sz, vp]),
                 ('kgdet_conv3x3_grad_weight', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i32, i32, vp, sz, vp])):
             fn = getattr(L, name)
@@ -292,19 +293,34 @@ class _ConvSplitStride2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
         weight = weight.contiguous()
+        img, ctx.img_t = forward_images(x, weight)
         ctx.save_for_backward(x, weight)
-        return _apply(_pack(weight, False), x, weight.shape[0], 9, 2)
+        return _apply(img, x, weight.shape[0], 9, 2)
 
     @staticmethod
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
-        gx, gw, _ = torch.ops.aten.convolution_backward(
-            gy.contiguous(), x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
-            [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        gy = gy.contiguous()
+        gx = None
+        if ctx.needs_input_grad[0] and STRIDE2_GRAD_INPUT and weight.shape[0] % 16 == 0:
+            # the four parity classes of the output pixels on the patch kernel (csrc/conv1x1.hip conv3x3_s2_grad_input)
+            img_t = ctx.img_t if ctx.img_t is not None else _pack(weight, True)
+            gx = torch.empty_like(x)
+            _lib.check(_lib_sizes().kgdet_conv3x3_s2_grad_input(
+                img_t.data_ptr(), gy.data_ptr(), gx.data_ptr(), x.shape[0], x.shape[1], weight.shape[0], x.shape[2], x.shape[3],
+                _stream()), 'conv3x3_s2_grad_input')
+        need_gx = ctx.needs_input_grad[0] and gx is None
+        if need_gx or ctx.needs_input_grad[1]:
+            gx2, gw, _ = torch.ops.aten.convolution_backward(
+                gy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [need_gx, ctx.needs_input_grad[1], False])
+            gx = gx2 if need_gx else gx
+        else:
+            gw = None
         return gx, gw
 
 
 STRIDE2 = _os.environ.get('KGDET_CONV_S2', '1') == '1'
+STRIDE2_GRAD_INPUT = _os.environ.get('KGDET_CONV_S2_GI', '1') == '1'    # 0: MIOpen for the stride-2 grad_input (A/B)
 
 
 def applicable_stride2(x, weight, stride, padding, dilation, groups):

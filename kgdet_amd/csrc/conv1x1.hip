@@ -731,6 +731,142 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_patch4(const unsigned char
   }
 }
 
+// grad_input of the 3x3 STRIDE-2 (padding 1) convolution on the patch machinery.  Output pixel (2i + pa, 2j + qa) receives only the
+// taps with ky = 1 (pa = 0) or ky in {0, 2} (pa = 1) -- likewise in x -- each from gy(i + dy, j + dx), dy, dx in {0, 1}:
+//   gx[c, 2i+pa, 2j+qa] = sum_o sum_(ky, kx of that parity class) w[o, c, ky, kx] * gy[o, i + (pa + 1 - ky) / 2, j + (qa + 1 - kx) / 2]
+// So a tile of gy pixels owns four accumulator sets (the four parity classes of its 2 x 2 output blocks) and the nine taps
+// are the nine stages of a chunk as in conv3x3_patch4, each adding into its class: one patch per chunk serves all classes,
+// the weight fragments come from the ordinary transposed image (block 8 - (3 ky + kx): its taps are mirrored), and a lane
+// stores 2 x 2 adjacent outputs.  64 gy pixels per tile (2 blocks of 32), 4 waves = 128 rows.  (MIOpen's fp32 implicit GEMM
+// for this gradient runs at ~100 TFLOP/s plus two layout transposes.)
+__global__ __launch_bounds__(256) void conv3x3_s2_grad_input(const unsigned char *__restrict__ img_t,
+                                                             const float *__restrict__ gy, float *__restrict__ gx, int M,
+                                                             int K, int H, int W, int Hin, int Win, int n_mt, int tiles_x,
+                                                             int n_nt, int tiles, int TX, int TY) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kPatchBuf];
+  constexpr int NB = 2;
+  const int tile = xcd_tile(blockIdx.x, tiles);
+  if (tile >= tiles) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = H * W;
+  const int chunks = K / kTK, stages = chunks * 9;
+  const int mt = tile % n_mt, nt = (tile / n_mt) % n_nt, b = tile / (n_mt * n_nt);
+  const int y0 = (nt / tiles_x) * TY, x0 = (nt % tiles_x) * TX;
+  const int PW = TX + 2, PP = PW * (TY + 2);
+
+  const int pp = tid;
+  const int ppy = pp / PW, ppx = pp - ppy * PW;
+  const int iy = y0 - 1 + ppy, ix = x0 - 1 + ppx;
+  const bool p_live = pp < PP && iy >= 0 && iy < H && ix >= 0 && ix < W;
+  const float *xb = gy + (long long)b * K * N + (p_live ? iy * W + ix : 0);
+  unsigned char *b_dst = smem + pp * 16;
+
+  int b_rd[NB], o_y[NB], o_x[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int qq = nb * 32 + (lane & 31), q = min(qq, TX * TY - 1);
+    const int py = q / TX, px = q - py * TX;
+    b_rd[nb] = ((lane >> 5) * kPatchMax + py * PW + px) * 16;
+    const bool live = qq < TX * TY && y0 + py < H && x0 + px < W;
+    o_y[nb] = live ? 2 * (y0 + py) : Hin;     // (dead lanes: every output row fails the bound test)
+    o_x[nb] = 2 * (x0 + px);
+  }
+  const int row_pitch = PW * 16;
+  const unsigned char *ag = img_t + (long long)mt * stages * kStage + (lane >> 5) * (kTM * 16) + (wave * 32 + (lane & 31)) * 16;
+
+  f32x16 acc[4][NB];   // [2 pa + qa][pixel block]
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][i][r] = 0.0f;
+
+  float bv[16];
+  auto issue_b = [&](int ci) {
+    const float *xp = xb + (long long)min(ci, chunks - 1) * kTK * N;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bv[j] = xp[(long long)j * N];
+  };
+  auto commit_b = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(bv[j]));
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = p_live ? bv[kh * 8 + j] : 0.0f;
+      bf16x8 hi, lo;
+      split8(v, hi, lo);
+      *reinterpret_cast<bf16x8 *>(b_dst + buf * kPatchBuf + kh * (kPatchMax * 16)) = hi;
+      *reinterpret_cast<bf16x8 *>(b_dst + buf * kPatchBuf + kh * (kPatchMax * 16) + kPatchPart) = lo;
+    }
+  };
+  // stage t of a chunk = tap (ky, kx) = (t / 3, t % 3): image block 8 - t
+  bf16x8 AR[3][2];
+  auto issue_a = [&](int s, bf16x8 (&r)[2]) {
+    const int sc = min(s, stages - 1), ci = sc / 9, t = sc - ci * 9;
+    const unsigned char *p = ag + (long long)(ci * 9 + 8 - t) * kStage;
+    r[0] = *reinterpret_cast<const bf16x8 *>(p);
+    r[1] = *reinterpret_cast<const bf16x8 *>(p + kPart);
+  };
+
+  issue_b(0);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) issue_a(j, AR[j]);
+  commit_b(0);
+  for (int ci = 0; ci < chunks; ++ci) {
+    issue_b(ci + 1);
+    __syncthreads();
+    const unsigned char *bbuf = smem + (ci & 1) * kPatchBuf;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      constexpr int kDummy = 0;
+      const int ky = t / 3, kx = t % 3;
+      const int cls = 2 * (ky != 1) + (kx != 1), dy = ky == 0, dx = kx == 0;
+      const unsigned char *bt = bbuf + (1 + dy) * row_pitch + (1 + dx) * 16;
+      bf16x8 bf[NB][2];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        bf[nb][0] = *reinterpret_cast<const bf16x8 *>(bt + b_rd[nb]);
+        bf[nb][1] = *reinterpret_cast<const bf16x8 *>(bt + b_rd[nb] + kPatchPart);
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[cls][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AR[t % 3][1], bf[nb][0], acc[cls][nb], 0, 0, 0);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[cls][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AR[t % 3][0], bf[nb][1], acc[cls][nb], 0, 0, 0);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[cls][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AR[t % 3][0], bf[nb][0], acc[cls][nb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_a(ci * 9 + t + 3, AR[t % 3]);
+      if (t == 6) commit_b((ci + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      (void)kDummy;
+    }
+  }
+
+  // store: rows 32 w + (r & 3) + 8 (r >> 2) + 4 (lane >> 5); a lane owns the 2 x 2 outputs of its gy pixel
+  const long long Nin = (long long)Hin * Win;
+  float *xo = gx + (long long)b * M * Nin;
+  const int m0 = mt * kTM + wave * 32 + 4 * (lane >> 5);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + (r & 3) + 8 * (r >> 2);
+      if (m >= M) continue;
+      float *row = xo + (long long)m * Nin;
+#pragma unroll
+      for (int pa = 0; pa < 2; ++pa) {
+        const int oy = o_y[nb] + pa;
+        if (oy >= Hin) continue;
+#pragma unroll
+        for (int qa = 0; qa < 2; ++qa)
+          if (o_x[nb] + qa < Win) row[(long long)oy * Win + o_x[nb] + qa] = acc[2 * pa + qa][nb][r];
+      }
+    }
+}
+
 // out[i] = sum_s parts[s][i], s ascending (deterministic); n a multiple of 2
 __global__ __launch_bounds__(256) void conv1x1_sum(const float *__restrict__ parts, float *__restrict__ out,
                                                    long long n, long long stride, int count) {
@@ -1163,6 +1299,32 @@ extern "C" int kgdet_conv_apply_epilogue(const void *packed, const float *x, flo
     if (bias || residual || relu)   // K-split problems are small: the epilogue as one extra pass
       return kgdet_bias_act(y, bias, residual, B, M, HW, 0, relu, 0, stream);
   }
+  return KGDET_OK;
+}
+
+extern "C" int kgdet_conv3x3_s2_grad_input(const void *packed_t, const float *grad_y, float *grad_x, int64_t B, int32_t C,
+                                           int32_t O, int32_t Hin, int32_t Win, void *stream) {
+  // packed_t: kgdet_conv_pack(w, O, C, 9, transpose = 1) of the forward weight [O, C, 3, 3]; grad_y [B, O, ceil(Hin/2), ceil(Win/2)]
+  KGDET_CHECK_SHAPE(B >= 0 && C > 0 && O > 0 && Hin > 0 && Win > 0 && O % kTK == 0, "bad sizes (O must be a multiple of 16)");
+  if (B == 0) return KGDET_OK;
+  KGDET_CHECK_SHAPE(packed_t && grad_y && grad_x, "null pointer");
+  const int H = (Hin + 1) / 2, W = (Win + 1) / 2;
+  // 64-pixel tiles of the grad_y map: the shape with the fewest tiles whose patch fits
+  int TX = 0, TY = 0;
+  long long best = -1;
+  for (int tx = 8; tx <= 64; ++tx) {
+    const int ty = 64 / tx;
+    if (ty < 1 || (tx + 2) * (ty + 2) > kPatchMax) continue;
+    const long long n = (long long)((H + ty - 1) / ty) * ((W + tx - 1) / tx);
+    const long long cost = n * 1024 + (tx + 2) * (ty + 2);
+    if (best < 0 || cost < best) { best = cost; TX = tx; TY = ty; }
+  }
+  const int n_mt = (C + kTM - 1) / kTM, tiles_x = (W + TX - 1) / TX, n_nt = tiles_x * ((H + TY - 1) / TY);
+  const long long tiles = (long long)n_mt * n_nt * B;
+  KGDET_CHECK_SHAPE(tiles < (1LL << 28), "too many tiles");
+  hipLaunchKernelGGL(conv3x3_s2_grad_input, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned char *)packed_t, grad_y, grad_x, C, O, H, W, Hin, Win, n_mt, tiles_x, n_nt, (int)tiles, TX, TY);
+  KGDET_CHECK_LAUNCH("conv3x3_s2_grad_input");
   return KGDET_OK;
 }
 

@@ -326,9 +326,12 @@ def test_conv1x1_not_applicable_cases_fall_back():
         assert not c1.applicable(x, w)
 
 
-@pytest.mark.parametrize('B,C,O,H,W', [(2, 128, 128, 20, 36), (1, 64, 256, 17, 13), (2, 256, 256, 50, 84)])
+@pytest.mark.parametrize('B,C,O,H,W', [(2, 128, 128, 20, 36), (1, 64, 256, 17, 13), (2, 256, 256, 50, 84), (1, 64, 64, 9, 12),
+                                       (2, 128, 128, 200, 336), (2, 512, 512, 50, 84), (3, 32, 48, 7, 20), (1, 160, 16, 33, 11)])
 def test_conv3x3_stride2_forward_matches_fp64(B, C, O, H, W):
-    """conv_nn<9> with stride 2 (padding 1): forward against the fp64 convolution; backward = MIOpen's, same as F.conv2d"""
+    """conv_nn<9> with stride 2 (padding 1): forward against the fp64 convolution; grad_input on conv3x3_s2_grad_input (the four
+    parity classes of the output pixels; odd input sizes, ragged tiles, C not a multiple of 128) against fp64 to 1e-5;
+    grad_weight = MIOpen's, same as F.conv2d"""
     from kgdet_amd import conv1x1 as c1
     g = torch.Generator(device='cpu').manual_seed(H * W)
     x = torch.randn(B, C, H, W, generator=g).cuda().requires_grad_()
@@ -345,6 +348,16 @@ def test_conv3x3_stride2_forward_matches_fp64(B, C, O, H, W):
     F.conv2d(xr, wr, stride=2, padding=1).backward(gy)
     assert (x.grad - xr.grad).abs().max().item() <= 1e-4 * xr.grad.abs().max().item()
     assert (w.grad - wr.grad).abs().max().item() <= 1e-4 * wr.grad.abs().max().item()
+    xd = x.detach().double().requires_grad_()
+    F.conv2d(xd, w.detach().double(), stride=2, padding=1).backward(gy.double())
+    assert ((x.grad.double() - xd.grad).abs().max() / xd.grad.abs().max()).item() < 1e-5
+    assert torch.isfinite(x.grad).all()
+    x.grad = None
+    c1.conv3x3_stride2(x, w).backward(gy)          # deterministic
+    g1 = x.grad.clone()
+    x.grad = None
+    c1.conv3x3_stride2(x, w).backward(gy)
+    assert torch.equal(g1, x.grad)
 
 
 @pytest.mark.parametrize('k,stride', [(1, 1), (3, 1), (3, 2), (1, 2)])
