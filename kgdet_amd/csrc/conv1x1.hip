@@ -1149,7 +1149,21 @@ NNPlan plan_nn(long long B, int M, int K, int H, int W, int taps, int stride) {
     }
   }
   p.tiles = (long long)n_mt * p.n_nt * B;
-  p.ks = p.patch ? nn_ksplit(p.tiles, K / kTK * 2) : nn_ksplit(p.tiles, taps * (K / kTK));   // patch: >= 4 chunks per part
+  p.ks = nn_ksplit(p.tiles, taps * (K / kTK));
+  if (p.patch && p.tiles < 200) {
+    // patch kernels: parts of whole chunks (>= 2 each), chosen by rounds over the CUs x chunks per part (+ the partials to add)
+    static const int old_rule = [] { const char *e = getenv("KGDET_CONV_KS_OLD"); return e ? atoi(e) : 0; }();   // A/B
+    const int chunks = K / kTK;
+    double best = 1e30;
+    p.ks = 1;
+    for (int ks = 1; ks <= 8 && ks * 2 <= chunks; ++ks) {
+      // (a chunk of a tile is ~3.5 us of a CU; a partial is written and read once: ~0.114 chunk times per MB of output)
+      const double out_mb = (double)B * M * Ho * Wo * 4e-6;
+      const double cost = (double)((p.tiles * ks + 255) / 256) * ((chunks + ks - 1) / ks) + 0.114 * out_mb * ks;
+      if (cost < best) { best = cost; p.ks = ks; }
+    }
+    if (old_rule) p.ks = nn_ksplit(p.tiles, chunks * 2);
+  }
   static const int force_ks = [] { const char *e = getenv("KGDET_CONV_KS"); return e ? atoi(e) : 0; }();   // experiments
   if (force_ks > 0) p.ks = force_ks;
   return p;
