@@ -290,6 +290,19 @@ int kgdet_sigmoid_focal_loss_backward(const float *logits, const int64_t *target
                                       float *d_logits, void *stream);
 
 /*
+ * GroupNorm (+ ReLU) of the ConvModules of the head towers and the neck as one pass each way -- ATen runs it as ten kernels
+ * per layer (mmdet/models/utils/conv_module.py:142-165: norm, then activate; mmdet/models/utils/norm.py GN = nn.GroupNorm).
+ * x, y, grad_* [N, C, HW] float32 contiguous; gamma, beta [C] nullable; mean, rstd [N * groups] (saved for the backward);
+ * C / groups <= 64.  Backward: grad_x nullable; dgamma_dbeta [2][N][C] = per-image rows of dgamma, then of dbeta (the caller
+ * adds the N rows); relu != 0 masks grad_y where y <= 0.  Deterministic.
+ */
+int kgdet_gn_act_forward(const float *x, const float *gamma, const float *beta, int32_t groups, float eps, int32_t relu,
+                         float *y, float *mean, float *rstd, int64_t N, int32_t C, int64_t HW, void *stream);
+int kgdet_gn_act_backward(const float *grad_y, const float *x, const float *y, const float *gamma, const float *mean,
+                          const float *rstd, int32_t groups, int32_t relu, float *grad_x, float *dgamma_dbeta, int64_t N,
+                          int32_t C, int64_t HW, void *stream);
+
+/*
  * Weighted smooth-L1 sum of the head's box / keypoint losses in one pass each way: what the reference computes as a chain of
  * element-wise torch ops (mmdet/models/losses/smooth_l1_loss.py:8-45, utils.py:7-52 called from KP3:621-665 with
  * pred / d and target / d):   sum_out[0] = sum_i weight[i] * l(|pred[i] / d - target[i] / d|),

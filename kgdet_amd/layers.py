@@ -6,6 +6,8 @@ Mirrors mmdet/models/utils/conv_module.py:44-164 (``ConvModule``; child names ``
 mmdet/models/utils/weight_init.py / mmcv.cnn init helpers.  Dense convolutions stay on
 PyTorch-ROCm (MIOpen); nothing here is hand-written HIP.
 """
+import ctypes
+import os as _os
 import warnings
 
 import numpy as np
@@ -88,6 +90,60 @@ def bias_init_with_prob(prior_prob):
     return float(-np.log((1 - prior_prob) / prior_prob))
 
 
+FUSED_GN = _os.environ.get('KGDET_FUSED_GN', '1') == '1'     # csrc/group_norm.hip (0: nn.GroupNorm + nn.ReLU; A/B)
+_GN_MAX_GROUP_ELEMS = 65536    # one workgroup owns an (image, group): beyond this ATen's multi-kernel route streams better
+
+
+def gn_act_applicable(x, norm):
+    return (FUSED_GN and type(norm) is nn.GroupNorm and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and x.is_contiguous() and x.numel() > 0 and not torch.is_autocast_enabled()
+            and norm.num_channels // norm.num_groups <= 64
+            and (norm.num_channels // norm.num_groups) * x.shape[2] * x.shape[3] <= _GN_MAX_GROUP_ELEMS)
+
+
+class _GNAct(torch.autograd.Function):
+    """``[relu](group_norm(x))`` (conv_module.py:142-165: norm, then activate) on csrc/group_norm.hip"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, relu):
+        from . import _lib
+        N, C = x.shape[0], x.shape[1]
+        HW = x.shape[2] * x.shape[3]
+        y = torch.empty_like(x)
+        stats = torch.empty((2, N * groups), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().kgdet_gn_act_forward(
+            _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), ctypes.c_int32(groups), ctypes.c_float(eps),
+            ctypes.c_int32(1 if relu else 0), _lib.ptr(y), ctypes.c_void_p(stats[0].data_ptr()),
+            ctypes.c_void_p(stats[1].data_ptr()), ctypes.c_int64(N), ctypes.c_int32(C), ctypes.c_int64(HW),
+            _lib.current_stream()), 'gn_act_forward')
+        ctx.save_for_backward(x, y if relu else None, gamma, stats)
+        ctx.groups, ctx.relu, ctx.has_beta = groups, relu, beta is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import _lib
+        x, y, gamma, stats = ctx.saved_tensors
+        N, C = x.shape[0], x.shape[1]
+        HW = x.shape[2] * x.shape[3]
+        gy = gy.contiguous()
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dgb = torch.empty((2, N, C), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().kgdet_gn_act_backward(
+            _lib.ptr(gy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(gamma), ctypes.c_void_p(stats[0].data_ptr()),
+            ctypes.c_void_p(stats[1].data_ptr()), ctypes.c_int32(ctx.groups), ctypes.c_int32(1 if ctx.relu else 0),
+            _lib.ptr(gx), _lib.ptr(dgb), ctypes.c_int64(N), ctypes.c_int32(C), ctypes.c_int64(HW), _lib.current_stream()),
+            'gn_act_backward')
+        sums = dgb.sum(1) if N > 1 else dgb[:, 0]
+        ggamma = sums[0] if (gamma is not None and ctx.needs_input_grad[1]) else None
+        gbeta = sums[1] if (ctx.has_beta and ctx.needs_input_grad[2]) else None
+        return gx, ggamma, gbeta, None, None, None
+
+
+def gn_act(x, norm, relu):
+    return _GNAct.apply(x, norm.weight, norm.bias, norm.num_groups, norm.eps, relu)
+
+
 class ConvModule(nn.Module):
     """conv -> norm -> activation, in configurable order."""
 
@@ -142,7 +198,8 @@ class ConvModule(nn.Module):
             constant_init(self.norm, 1, bias=0)
 
     def forward(self, x, activate=True, norm=True):
-        for layer in self.order:
+        fused_act = False
+        for li, layer in enumerate(self.order):
             if layer == 'conv':
                 conv = self.conv
                 if (type(conv) is nn.Conv2d and conv.bias is None and torch.is_grad_enabled()
@@ -151,7 +208,14 @@ class ConvModule(nn.Module):
                 else:
                     x = conv(x)
             elif layer == 'norm' and norm and self.with_norm:
-                x = self.norm(x)
+                relu_next = (activate and self.with_activatation and li + 1 < len(self.order)
+                             and self.order[li + 1] == 'act')
+                if gn_act_applicable(x, self.norm):
+                    x = gn_act(x, self.norm, relu_next)     # GroupNorm (+ the ReLU that follows) as one HIP pass each way
+                    fused_act = relu_next
+                else:
+                    x = self.norm(x)
             elif layer == 'act' and activate and self.with_activatation:
-                x = self.activate(x)
+                if not fused_act:
+                    x = self.activate(x)
         return x

@@ -314,3 +314,44 @@ def test_fused_smooth_l1_matches_reference_chain(shape, beta, divisor, with_weig
         assert abs(float(got) - float(want)) <= 2e-6 * max(abs(float(want)), 1e-6), (float(got), float(want))
         assert (g_got - g_want).abs().max().item() <= 1e-6 * g_want.abs().max().item() + 1e-12
         assert ((g_got == 0) == (g_want == 0)).all()
+
+
+@pytest.mark.parametrize('relu', [True, False])
+@pytest.mark.parametrize('N,C,G,H,W', [(2, 256, 32, 25, 42), (2, 256, 32, 13, 21), (1, 64, 32, 7, 5), (3, 96, 4, 16, 20),
+                                       (2, 256, 32, 50, 84)])
+def test_fused_group_norm_relu_matches_torch(N, C, G, H, W, relu):
+    """GroupNorm (+ ReLU) of a ConvModule on csrc/group_norm.hip (one pass each way) against nn.GroupNorm + F.relu in fp64:
+    output, grad_x, grad_gamma, grad_beta to fp32 rounding of their scales"""
+    import torch.nn.functional as F
+    from kgdet_amd import layers
+    torch.manual_seed(C + H)
+    gn = torch.nn.GroupNorm(G, C).cuda()
+    gn.weight.data.normal_(1.0, 0.5)
+    gn.bias.data.normal_(0, 0.5)
+    x = (torch.randn(N, C, H, W, device='cuda') * 3 + 1).requires_grad_()
+    gy = torch.randn(N, C, H, W, device='cuda')
+    assert layers.gn_act_applicable(x, gn)
+    y = layers.gn_act(x, gn, relu)
+    y.backward(gy)
+    gd = torch.nn.GroupNorm(G, C).cuda().double()
+    gd.load_state_dict({k: v.double() for k, v in gn.state_dict().items()})
+    xd = x.detach().double().requires_grad_()
+    yd = gd(xd)
+    if relu:
+        yd = yd * (y.detach() > 0)      # the ReLU mask of the fp32 result (an element within rounding of zero may flip in fp64)
+    yd.backward(gy.double())
+    for name, a_, b_ in (('y', y, yd), ('grad_x', x.grad, xd.grad), ('grad_gamma', gn.weight.grad, gd.weight.grad),
+                         ('grad_beta', gn.bias.grad, gd.bias.grad)):
+        err = (a_.double() - b_).abs().max().item() / b_.abs().max().item()
+        assert err < 2e-6, (name, err)
+    # a ConvModule takes the fused path and gives the same tensor as its modules called one by one
+    m = layers.ConvModule(C, C, 3, padding=1, norm_cfg=dict(type='GN', num_groups=G, requires_grad=True)).cuda()
+    xin = torch.randn(N, C, H, W, device='cuda')
+    with torch.no_grad():
+        got = m(xin)
+        layers.FUSED_GN = False
+        try:
+            want = m(xin)
+        finally:
+            layers.FUSED_GN = True
+    assert (got - want).abs().max().item() <= 1e-5 * want.abs().max().item()
