@@ -99,7 +99,12 @@ def test_dist_optimizer_hook_overlap_equals_flat_allreduce_over_steps(nccl_group
     if spread == 0.0:
         assert diff == 0.0
     else:
-        assert diff <= 4 * spread + 1e-7, (diff, spread)
+        # Adam turns a gradient whose sign is decided by summation-order noise into a step of +-lr, so the LARGEST difference
+        # over 40 M weights is a heavy-tailed statistic (5x between two draws happens); the root-mean-square is not
+        def rms(u, v):
+            return (sum(float((x - y).double().square().sum()) for x, y in zip(u, v)) / sum(x.numel() for x in u)) ** 0.5
+        assert rms(a, b) <= 2 * rms(a, a2) + 1e-12, (rms(a, b), rms(a, a2))
+        assert diff <= 20 * spread + 1e-6, (diff, spread)
 
 
 def test_training_step_with_reducer_has_no_host_syncs(nccl_group):
