@@ -1,5 +1,6 @@
 """Fused frozen-BatchNorm + residual + ReLU (csrc/bn_act.hip) against the three torch ops it replaces
 (mmdet/models/backbones/resnet.py:240-262 under norm_eval=True)."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -310,6 +311,46 @@ def test_conv_bias_act_matches_fp64(B, C, O, H, W, k, relu):
     with torch.no_grad():
         y0 = c1.conv_bias_act(conv, x, relu=relu)
     assert (y0 - y).abs().max().item() <= 1e-4 * y.abs().max().item()
+
+
+def test_dense_conv_kernels_random_shapes_against_fp64():
+    """60 random problems through the dense convolution kernels (1x1, 3x3 stride 1 on the patch kernels, 3x3 stride 2 with its
+    parity-class grad_input): tiny and ragged maps, one-chunk reductions, row counts around the 32 / 64 / 128-row tile edges,
+    K splits with uneven parts -- output, grad_input and grad_weight against the fp64 convolution"""
+    from kgdet_amd import conv1x1 as c1
+    rng = np.random.RandomState(7)
+    done = 0
+    for trial in range(200):
+        if done == 60:
+            break
+        k = int(rng.choice([1, 3, 3]))
+        stride = 2 if (k == 3 and rng.rand() < 0.3) else 1
+        B = int(rng.randint(1, 4))
+        C = 16 * int(rng.randint(1, 18))
+        O = 16 * int(rng.randint(1, 18))
+        H, W = int(rng.randint(1, 41)), int(rng.randint(1, 41))
+        x = torch.randn(B, C, H, W, device='cuda', requires_grad=True)
+        w = (torch.randn(O, C, k, k, device='cuda') * 0.1).requires_grad_()
+        if stride == 1:
+            if not c1.applicable(x, w, padding=(k // 2, k // 2)):
+                continue
+            y = c1.conv_split(x, w)
+        else:
+            if not c1.applicable_stride2(x, w, (2, 2), (1, 1), (1, 1), 1):
+                continue
+            y = c1.conv3x3_stride2(x, w)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        xd, wd = x.detach().double().requires_grad_(), w.detach().double().requires_grad_()
+        yd = F.conv2d(xd, wd, stride=stride, padding=k // 2)
+        yd.backward(gy.double())
+        for name, a_, b_ in (('y', y, yd), ('grad_x', x.grad, xd.grad), ('grad_w', w.grad, wd.grad)):
+            scale = b_.abs().max().item()
+            err = (a_.double() - b_).abs().max().item() / max(scale, 1e-30)
+            tol = 1e-4 if (name == 'grad_w' and stride == 2) else 2e-5     # (stride-2 grad_weight: MIOpen fp32)
+            assert err < tol and torch.isfinite(a_).all(), (name, err, (B, C, O, H, W, k, stride))
+        done += 1
+    assert done == 60
 
 
 def test_conv1x1_not_applicable_cases_fall_back():
