@@ -55,6 +55,11 @@ int kgdet_conv_apply(const void *packed, const float *x, float *y, int64_t B, in
 int kgdet_conv_apply_epilogue(const void *packed, const float *x, float *y, const float *bias, const float *residual,
                               int32_t relu, int64_t B, int32_t M, int32_t K, int32_t H, int32_t W, int32_t taps,
                               int32_t stride, void *workspace, size_t workspace_bytes, void *stream);
+/* The stem convolution conv1 = Conv2d(3, 64, 7, stride 2, padding 3, bias none) (mmdet/models/backbones/resnet.py:487-488):
+ * x [B, 3, H, W] -> y [B, 64, (H-1)/2+1, (W-1)/2+1] with the split-bf16 arithmetic of the other convolutions.  packed: the
+ * image kgdet_conv_pack(w160, 64, 160, 1, 0, ...) of the weight flattened to [64, 147] and zero-padded to [64, 160].
+ * Forward only (the stem is frozen: frozen_stages >= 0). */
+int kgdet_stem_conv7x7_s2(const void *packed, const float *x, float *y, int64_t B, int32_t H, int32_t W, void *stream);
 /* grad_x [B, C, Hin, Win] of the 3x3 stride-2 padding-1 convolution (the bottleneck's conv2 at the head of layers 2-4,
  * mmdet/models/backbones/resnet.py:142-186 with stride 2) from grad_y [B, O, ceil(Hin/2), ceil(Win/2)] and the TRANSPOSED image
  * of its weight (kgdet_conv_pack(w, O, C, 9, 1, ...)); O % 16 == 0.  Replaces ATen's convolution_backward (MIOpen). */

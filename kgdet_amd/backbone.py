@@ -7,6 +7,7 @@ contract (``conv1``, ``bn1``, ``layer{1..4}.{i}.conv{1,2,3}|bn{1,2,3}|downsample
 BatchNorm stays in eval mode (``norm_eval``) and ``frozen_stages`` freezes the stem + first stages.
 """
 import ctypes
+import os as _os
 import weakref
 
 import torch
@@ -18,6 +19,33 @@ from . import conv1x1
 from . import dcn as dcn_ops
 from .layers import build_conv_layer, build_norm_layer, constant_init, kaiming_init
 from .registry import BACKBONES
+
+
+STEM_CONV = _os.environ.get('KGDET_STEM_CONV', '1') == '1'    # csrc/conv1x1.hip stem_conv7x7_s2 (0: MIOpen; A/B)
+_stem_cache = {}
+
+
+def _stem_conv(conv, x):
+    """conv1 of the stem, no autograd (the caller checked that nothing here trains): the 7x7 / stride 2 / 3 -> 64 layer on the
+    split-bf16 MFMA kernel (its packed weight cached per weight version), anything else through the module"""
+    w = conv.weight
+    if (STEM_CONV and x.is_contiguous() and tuple(w.shape) == (64, 3, 7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and w.dtype == torch.float32):
+        key = (w.data_ptr(), w._version)
+        hit = _stem_cache.get(id(conv))
+        if hit is None or hit[0] != key:
+            w160 = torch.zeros((64, 160), dtype=torch.float32, device=w.device)
+            w160[:, :147] = w.detach().reshape(64, 147)
+            hit = (key, conv1x1._pack(w160.view(64, 160, 1, 1), False))
+            _stem_cache[id(conv)] = hit
+        from . import _lib
+        B, _, H, W = x.shape
+        y = torch.empty((B, 64, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().kgdet_stem_conv7x7_s2(
+            _lib.ptr(hit[1]), _lib.ptr(x), _lib.ptr(y), ctypes.c_int64(B), ctypes.c_int32(H), ctypes.c_int32(W),
+            _lib.current_stream()), 'stem_conv7x7_s2')
+        return y
+    return conv(x).contiguous()
 
 
 class BasicBlock(nn.Module):
@@ -60,7 +88,6 @@ class BasicBlock(nn.Module):
         return self.relu(out)
 
 
-import os as _os
 _FUSE_EPI = _os.environ.get('KGDET_FUSE_EPI', '1') == '1'   # fp32 inference: epilogue inside conv_nn's store (0: separate pass, for A/B)
 _fold_cache = {}   # id(conv) -> (weakref to conv, folded weight, folded bias)
 
@@ -542,7 +569,7 @@ class ResNet(nn.Module):
                 and x.shape[0] * self.conv1.out_channels <= 65535):
             from . import _lib
             with torch.no_grad():
-                y = self.conv1(x).contiguous()
+                y = _stem_conv(self.conv1, x)
                 N, C, H, W = y.shape
                 out = torch.empty((N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=y.dtype, device=y.device)
                 _lib.check(_bn_lib().kgdet_bn_relu_maxpool(

@@ -867,6 +867,76 @@ __global__ __launch_bounds__(256) void conv3x3_s2_grad_input(const unsigned char
     }
 }
 
+// The stem: 7x7, stride 2, padding 3, 3 -> 64 channels (mmdet/models/backbones/resnet.py:487-488) as an implicit GEMM with
+// K = 147 (c, ky, kx) padded to 160 = ten stages of 16.  A tile of 8 x 16 output pixels needs a 21 x 37 x 3 input patch
+// (9.3 KB, fp32, in LDS, zero outside the image).  Each lane builds ITS OWN B fragment -- pixel lane & 31, k half lane >> 5 --
+// by gathering 8 patch values through a 160-entry offset table and splitting them, so the activations are never staged as
+// an operand image; A fragments (64 rows: two 32-row blocks) come straight from the packed weight image in L2.  4 waves,
+// wave w = pixels 32 w .. 32 w + 31 of the tile, all 64 rows.  (MIOpen's fp32 Winograd-type kernel for this layer: 220 us.)
+constexpr int kStemTY = 8, kStemTX = 16, kStemPH = 2 * kStemTY + 5, kStemPW = 2 * kStemTX + 5, kStemK = 160;
+
+__global__ __launch_bounds__(256) void stem_conv7x7_s2(const unsigned char *__restrict__ img, const float *__restrict__ x,
+                                                       float *__restrict__ y, int H, int W, int Ho, int Wo, int tiles_x,
+                                                       int tiles_per_image) {
+  __shared__ float patch[3 * kStemPH * kStemPW];
+  __shared__ int koff[kStemK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / tiles_per_image, nt = blockIdx.x - b * tiles_per_image;
+  const int oy0 = (nt / tiles_x) * kStemTY, ox0 = (nt % tiles_x) * kStemTX;
+  const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
+  const float *xb = x + (long long)b * 3 * H * W;
+  for (int i = tid; i < 3 * kStemPH * kStemPW; i += 256) {
+    const int c = i / (kStemPH * kStemPW), r = i - c * (kStemPH * kStemPW), py = r / kStemPW, px = r - py * kStemPW;
+    const int iy = iy0 + py, ix = ix0 + px;
+    patch[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? xb[((long long)c * H + iy) * W + ix] : 0.0f;
+  }
+  if (tid < kStemK) {
+    const int c = tid / 49, r = tid - c * 49, ky = r / 7, kx = r - ky * 7;
+    koff[tid] = tid < 147 ? c * (kStemPH * kStemPW) + ky * kStemPW + kx : 0;   // (k >= 147: zero weights)
+  }
+  __syncthreads();
+  const int q = wave * 32 + (lane & 31), py = q / kStemTX, px = q - py * kStemTX;
+  const float *pbase = patch + (2 * py) * kStemPW + 2 * px;
+  const int kh = (lane >> 5) * 8;
+  const unsigned char *ag = img + (lane >> 5) * (kTM * 16) + (lane & 31) * 16;
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+#pragma unroll
+  for (int s = 0; s < kStemK / kTK; ++s) {
+    bf16x8 a[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      a[0][mi] = *reinterpret_cast<const bf16x8 *>(ag + (long long)s * kStage + mi * 32 * 16);
+      a[1][mi] = *reinterpret_cast<const bf16x8 *>(ag + (long long)s * kStage + kPart + mi * 32 * 16);
+    }
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = pbase[koff[s * kTK + kh + j]];
+    bf16x8 bhi, blo;
+    split8(v, bhi, blo);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {   // small terms first
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][mi], bhi, acc[mi], 0, 0, 0);
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], blo, acc[mi], 0, 0, 0);
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], bhi, acc[mi], 0, 0, 0);
+    }
+  }
+  const int oy = oy0 + py, ox = ox0 + px;
+  if (oy < Ho && ox < Wo) {
+    float *yb = y + (long long)b * 64 * Ho * Wo + (long long)oy * Wo + ox;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        yb[(long long)m * Ho * Wo] = acc[mi][r];
+      }
+  }
+}
+
 // out[i] = sum_s parts[s][i], s ascending (deterministic); n a multiple of 2
 __global__ __launch_bounds__(256) void conv1x1_sum(const float *__restrict__ parts, float *__restrict__ out,
                                                    long long n, long long stride, int count) {
@@ -1339,6 +1409,22 @@ extern "C" int kgdet_conv3x3_s2_grad_input(const void *packed_t, const float *gr
   hipLaunchKernelGGL(conv3x3_s2_grad_input, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream,
                      (const unsigned char *)packed_t, grad_y, grad_x, C, O, H, W, Hin, Win, n_mt, tiles_x, n_nt, (int)tiles, TX, TY);
   KGDET_CHECK_LAUNCH("conv3x3_s2_grad_input");
+  return KGDET_OK;
+}
+
+extern "C" int kgdet_stem_conv7x7_s2(const void *packed, const float *x, float *y, int64_t B, int32_t H, int32_t W,
+                                     void *stream) {
+  // packed: kgdet_conv_pack of the [64, 3, 7, 7] weight flattened to [64, 147] and zero-padded to [64, 160] (taps = 1,
+  // transpose = 0); x [B, 3, H, W] -> y [B, 64, (H - 1) / 2 + 1, (W - 1) / 2 + 1]
+  KGDET_CHECK_SHAPE(B >= 0 && H > 0 && W > 0, "bad sizes");
+  if (B == 0) return KGDET_OK;
+  KGDET_CHECK_SHAPE(packed && x && y, "null pointer");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int tiles_x = (Wo + kStemTX - 1) / kStemTX, tiles_per_image = tiles_x * ((Ho + kStemTY - 1) / kStemTY);
+  KGDET_CHECK_SHAPE((long long)B * tiles_per_image < (1LL << 31), "too many tiles");
+  hipLaunchKernelGGL(stem_conv7x7_s2, dim3((unsigned)(B * tiles_per_image)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned char *)packed, x, y, H, W, Ho, Wo, tiles_x, tiles_per_image);
+  KGDET_CHECK_LAUNCH("stem_conv7x7_s2");
   return KGDET_OK;
 }
 
