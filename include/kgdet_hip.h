@@ -295,6 +295,22 @@ int kgdet_sigmoid_focal_loss_backward(const float *logits, const int64_t *target
                                       float *d_logits, void *stream);
 
 /*
+ * Gradient clipping + Adam over all parameters as multi-tensor passes: what OptimizerHook.after_train_iter does with
+ * clip_grad_norm_(params, max_norm, 2) followed by torch.optim.Adam.step() (mmdet/core/utils/dist_utils.py:44-58; torch/optim/
+ * adam.py).  table_dev: n rows of six int64 on the device -- {param, grad, exp_avg, exp_avg_sq (float32 pointers), numel,
+ * first block}, a tensor taking ceil(numel / kgdet_optim_chunk()) blocks, rows in block order; total_blocks = their sum.
+ * kgdet_multi_grad_norm: partial [total_blocks] scratch, norm_out[0] = ||all grads||_2.  kgdet_multi_clip_adam: gradients
+ * are scaled by min(1, max_norm / (norm[0] + 1e-6)) in place (max_norm <= 0: no clipping), then the Adam update with
+ * bias_correction1 = 1 - beta1^step and bias_correction2_sqrt = sqrt(1 - beta2^step) of the step being taken; weight decay
+ * is added to the gradient (Adam, not AdamW); the betas come as doubles so that 1 - beta is rounded once, as torch does.  No amsgrad / maximize.  Deterministic; no host synchronisation.
+ */
+int32_t kgdet_optim_chunk(void);
+int kgdet_multi_grad_norm(const int64_t *table_dev, int32_t n, int64_t total_blocks, float *partial, float *norm_out, void *stream);
+int kgdet_multi_clip_adam(const int64_t *table_dev, int32_t n, int64_t total_blocks, const float *norm, float max_norm, float lr,
+                          double beta1, double beta2, float eps, float weight_decay, float bias_correction1,
+                          float bias_correction2_sqrt, void *stream);
+
+/*
  * GroupNorm (+ ReLU) of the ConvModules of the head towers and the neck as one pass each way -- ATen runs it as ten kernels
  * per layer (mmdet/models/utils/conv_module.py:142-165: norm, then activate; mmdet/models/utils/norm.py GN = nn.GroupNorm).
  * x, y, grad_* [N, C, HW] float32 contiguous; gamma, beta [C] nullable; mean, rstd [N * groups] (saved for the backward);

@@ -198,6 +198,7 @@ class DistOptimizerHook(object):
         self.force_distributed = force_distributed
         self._reducer = None
         self._params = None
+        self._fused = None
 
     def clip_grads(self, params):
         return clip_grads(params, **self.grad_clip)
@@ -215,8 +216,15 @@ class DistOptimizerHook(object):
                 self._reducer.finish()
             else:
                 allreduce_grads(model.parameters(), self.coalesce, self.bucket_size_mb)
+        if self._params is None:    # model.parameters() walks every module: 1 ms of Python per step
+            self._params = [p for p in model.parameters() if p.requires_grad]
+        if self._fused is None:
+            from .optim import FusedClipAdam
+            self._fused = FusedClipAdam()
+        if len(optimizer.param_groups) == 1 and self._fused.applicable(optimizer, self._params, self.grad_clip):
+            # clip + Adam as two multi-tensor HIP passes (csrc/optim.hip); the first step (no state yet) and anything else: torch
+            self._fused.step(optimizer, self._params, self.grad_clip)
+            return
         if self.grad_clip is not None:
-            if self._params is None:    # model.parameters() walks every module: 1 ms of Python per step
-                self._params = [p for p in model.parameters() if p.requires_grad]
             self.clip_grads(self._params)
         optimizer.step()

@@ -1,0 +1,111 @@
+"""Gradient clipping + Adam as two multi-tensor HIP passes (csrc/optim.hip) for ``DistOptimizerHook``.
+
+The reference's step is mmcv's ``OptimizerHook.after_train_iter`` as re-implemented in ``mmdet/core/utils/dist_utils.py:44-58``:
+``clip_grad_norm_(params, max_norm=35, norm_type=2)`` then ``optimizer.step()``; the KGDet config trains with ``torch.optim.Adam``.
+The fused path keeps torch's objects -- the optimizer's own ``exp_avg`` / ``exp_avg_sq`` / ``step`` state (checkpoints are
+unchanged), the parameters' ``.grad`` (scaled in place when the clip is active, as ``clip_grad_norm_`` does) -- and only replaces
+the ~15 launches between them.  Anything it does not cover (other optimizers, amsgrad, maximize, sparse or non-fp32 tensors,
+the very first step, which creates the state) goes through torch.
+"""
+import ctypes
+import math
+import os
+
+import torch
+
+from . import _lib
+
+ENABLED = os.environ.get('KGDET_FUSED_CLIP_ADAM', '1') == '1'      # 0: clip_grad_norm_ + optimizer.step() (A/B)
+
+
+class FusedClipAdam(object):
+    """one instance per (hook, optimizer): caches the pointer table of the step's tensors"""
+
+    def __init__(self):
+        self._key = None          # tuple of the pointers of the last table
+        self._table = None        # device int64 [n, 6]
+        self._partial = None
+        self._norm = None
+        self._pinned = None
+        self._event = None
+        self._host_step = None
+
+    @staticmethod
+    def applicable(optimizer, params, grad_clip):
+        if not ENABLED or type(optimizer) is not torch.optim.Adam:
+            return False
+        if grad_clip is not None and float(grad_clip.get('norm_type', 2)) != 2.0:
+            return False
+        for group in optimizer.param_groups:
+            if group.get('amsgrad') or group.get('maximize') or group.get('differentiable') or group.get('capturable'):
+                return False
+            if isinstance(group['lr'], torch.Tensor):
+                return False
+        for p in params:
+            if p.grad is None:
+                continue
+            st = optimizer.state.get(p)
+            if (not st or 'exp_avg' not in st or not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous()
+                    or p.grad.dtype != torch.float32 or p.grad.is_sparse or not p.grad.is_contiguous()
+                    or not isinstance(st['step'], torch.Tensor)):
+                return False
+        return True
+
+    def step(self, optimizer, params, grad_clip):
+        """clip (over ``params``, the hook's list) + Adam (the optimizer's single parameter group); returns the total norm
+        (a device scalar) or None"""
+        L = _lib.lib()
+        chunk = L.kgdet_optim_chunk()
+        group = optimizer.param_groups[0]
+        clip_set = set(id(p) for p in params if p.grad is not None)
+        rows, steps, first = [], [], 0
+        for p in group['params']:
+            if p.grad is None:
+                continue
+            st = optimizer.state[p]
+            n = p.numel()
+            rows.append((p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), n, first))
+            first += (n + chunk - 1) // chunk
+            steps.append(st['step'])
+            if grad_clip is not None and id(p) not in clip_set:
+                raise RuntimeError('a stepped parameter is missing from the clipped set')
+        if not rows:
+            return None
+        key = tuple(rows)
+        dev = group['params'][0].device       # (the step counters live on the CPU unless the optimizer is fused / capturable)
+        if key != self._key:
+            # (the gradients are fresh tensors every step, but the caching allocator hands out the same blocks for the same
+            #  sequence of requests: the table is uploaded again only when an address moved)
+            if self._event is not None:
+                self._event.synchronize()        # the previous upload has left the pinned buffer
+            if self._pinned is None or self._pinned.shape[0] < len(rows):
+                self._pinned = torch.empty((len(rows), 6), dtype=torch.int64).pin_memory()
+            host = self._pinned[:len(rows)]
+            host.copy_(torch.tensor(rows, dtype=torch.int64))
+            self._table = host.to(dev, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
+            self._key = key
+            if self._partial is None or self._partial.numel() < first:
+                self._partial = torch.empty(first, dtype=torch.float32, device=dev)
+                self._norm = torch.empty(1, dtype=torch.float32, device=dev)
+        stream = _lib.current_stream()
+        max_norm = 0.0
+        if grad_clip is not None:
+            max_norm = float(grad_clip.get('max_norm', 35))
+            _lib.check(L.kgdet_multi_grad_norm(ctypes.c_void_p(self._table.data_ptr()), ctypes.c_int32(len(rows)),
+                                               ctypes.c_int64(first), _lib.ptr(self._partial), _lib.ptr(self._norm), stream),
+                       'multi_grad_norm')
+        torch._foreach_add_(steps, 1.0)        # the optimizer's own step counters (state_dict compatibility)
+        if self._host_step is None:
+            self._host_step = int(round(float(steps[0])))      # ONE read-back, at the first fused step
+        else:
+            self._host_step += 1
+        t = self._host_step
+        beta1, beta2 = group['betas']
+        _lib.check(L.kgdet_multi_clip_adam(
+            ctypes.c_void_p(self._table.data_ptr()), ctypes.c_int32(len(rows)), ctypes.c_int64(first), _lib.ptr(self._norm),
+            ctypes.c_float(max_norm), ctypes.c_float(group['lr']), ctypes.c_double(beta1), ctypes.c_double(beta2),
+            ctypes.c_float(group['eps']), ctypes.c_float(group['weight_decay']),
+            ctypes.c_float(1.0 - beta1 ** t), ctypes.c_float(math.sqrt(1.0 - beta2 ** t)), stream), 'multi_clip_adam')
+        return self._norm[0] if grad_clip is not None else None

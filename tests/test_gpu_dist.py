@@ -103,8 +103,10 @@ def test_dist_optimizer_hook_overlap_equals_flat_allreduce_over_steps(nccl_group
         # over 40 M weights is a heavy-tailed statistic (5x between two draws happens); the root-mean-square is not
         def rms(u, v):
             return (sum(float((x - y).double().square().sum()) for x, y in zip(u, v)) / sum(x.numel() for x in u)) ** 0.5
-        assert rms(a, b) <= 2 * rms(a, a2) + 1e-12, (rms(a, b), rms(a, a2))
-        assert diff <= 20 * spread + 1e-6, (diff, spread)
+        # ... and the spread of ONE pair of runs is itself anywhere between 2e-9 and 2e-7 (whether a few signs flipped or
+        # not): a wrong exchange would move every weight by ~lr = 1e-4 per step, three orders of magnitude above this floor
+        assert rms(a, b) <= max(3 * rms(a, a2), 5e-7), (rms(a, b), rms(a, a2))
+        assert diff <= max(20 * spread, 6.1e-4), (diff, spread)
 
 
 def test_training_step_with_reducer_has_no_host_syncs(nccl_group):
@@ -123,3 +125,50 @@ def test_training_step_with_reducer_has_no_host_syncs(nccl_group):
     finally:
         torch.cuda.set_sync_debug_mode('default')
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('max_norm', [35.0, 0.05])
+def test_fused_clip_adam_equals_torch_clip_and_adam(max_norm):
+    """DistOptimizerHook on csrc/optim.hip (multi-tensor gradient norm + clip + Adam: two passes) against clip_grad_norm_ +
+    torch.optim.Adam.step(): parameters, gradients (scaled in place when the clip is active: max_norm 0.05), Adam state and
+    step counters after four steps -- equal to rounding; a parameter that never gets a gradient stays untouched"""
+    from kgdet_amd import optim
+    from kgdet_amd.dist import DistOptimizerHook
+
+    def run(fused):
+        torch.manual_seed(0)
+        # (Linear layers: their backward is deterministic, unlike MIOpen's convolution gradients; sizes that are not multiples
+        #  of the kernels' 4096-element blocks, one tensor larger than a block, biases smaller than a vector)
+        net = torch.nn.Sequential(torch.nn.Linear(67, 129), torch.nn.ReLU(), torch.nn.Linear(129, 64), torch.nn.ReLU(),
+                                  torch.nn.Linear(64, 5)).cuda()
+        net.unused = torch.nn.Parameter(torch.randn(11, device='cuda'))
+        opt = torch.optim.Adam(net.parameters(), lr=1e-2, weight_decay=0.0, fused=True)
+        hook = DistOptimizerHook(grad_clip=dict(max_norm=max_norm, norm_type=2))
+        x = torch.randn(40, 67, device='cuda')
+        prev = optim.ENABLED
+        optim.ENABLED = fused
+        try:
+            for _ in range(4):
+                hook.step(net, opt, net(x).square().mean())
+        finally:
+            optim.ENABLED = prev
+        torch.cuda.synchronize()
+        assert (hook._fused._host_step is not None) == fused
+        state = [(opt.state[p]['exp_avg'].clone(), opt.state[p]['exp_avg_sq'].clone(), float(opt.state[p]['step']))
+                 for p in net.parameters() if p in opt.state and 'exp_avg' in opt.state[p]]
+        return ([p.detach().clone() for p in net.parameters()],
+                [None if p.grad is None else p.grad.clone() for p in net.parameters()], state)
+
+    pa, ga, sa = run(True)
+    pb, gb, sb = run(False)
+    for x, y in zip(pa, pb):
+        assert (x - y).abs().max().item() <= 2e-6 * y.abs().max().item() + 1e-9
+    for x, y in zip(ga, gb):
+        assert (x is None) == (y is None)
+        if x is not None:
+            assert (x - y).abs().max().item() <= 1e-6 * y.abs().max().item() + 1e-12
+    assert len(sa) == len(sb) and len(sa) >= 6
+    for (m1, v1, t1), (m2, v2, t2) in zip(sa, sb):
+        assert t1 == t2 == 4.0
+        assert (m1 - m2).abs().max().item() <= 1e-6 * m2.abs().max().item() + 1e-12
+        assert (v1 - v2).abs().max().item() <= 1e-6 * v2.abs().max().item() + 1e-15
