@@ -9,7 +9,7 @@ import csv, collections
 rows = list(csv.DictReader(open('/tmp/convl/t_kernel_trace.csv')))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # last step: after the last-but-one optimizer kernel
-opt = [i for i, r in enumerate(rows) if 'FusedOptimizerTensorListMetadata' in r['Kernel_Name']]
+opt = [i for i, r in enumerate(rows) if 'multi_clip_adam' in r['Kernel_Name'] or 'FusedOptimizerTensorListMetadata' in r['Kernel_Name']]
 starts = [i for j, i in enumerate(opt) if j == 0 or opt[j - 1] != i - 1]
 lo, hi = (starts[-2], starts[-1]) if len(starts) >= 2 else (0, len(rows))
 agg = collections.OrderedDict()
