@@ -4,9 +4,9 @@
 // unbiased std of the n points' x and y at every location, half extents = std * exp(transfer),
 // box = mean -/+ half extent.
 // Only B*H*W = 2100 locations exist, so one thread per location (83 dependent strided loads, three passes)
-// is pure latency: 80-107 us per call.  Here a 256-thread block owns 64 consecutive locations and its four
-// waves split the n points (wave w takes points w, w+4, ...): every load instruction is a coalesced 256-byte
-// row of one channel, a thread has ~21 independent loads in flight per pass, and the three reductions
+// is pure latency: 80-107 us per call.  Here a 1024-thread block owns 64 consecutive locations and its sixteen
+// waves split the n points (wave w takes points w, w+16, ...): every load instruction is a coalesced 256-byte
+// row of one channel, a thread has ~5 independent loads in flight per pass, and the three reductions
 // (sum, residual of the mean, squared deviations) are combined across the waves through LDS.
 #include "common.h"
 
@@ -15,18 +15,21 @@ namespace kgdet {
 namespace {
 
 constexpr int kLoc = 64;    // locations per block
-constexpr int kSplit = 4;   // waves sharing a location's points
+constexpr int kSplit = 16;  // waves sharing a location's points (83 points: ~5 per wave and pass; 4 waves took 24-32 us per call)
 
 struct Moments {
   float mean, stdv;
 };
 
-// sum over the four waves' partials of this location (all 256 threads call it)
+// sum over the waves' partials of this location (all threads call it)
 __device__ __forceinline__ float block_sum(float v, float (*red)[kLoc], int w, int l) {
   __syncthreads();
   red[w][l] = v;
   __syncthreads();
-  return (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < kSplit; ++k) s += red[k][l];
+  return s;
 }
 
 // mean of v_i, then the unbiased std of (v_i - mean) as torch.std(pts - mean) computes it (deviations from the
@@ -55,7 +58,7 @@ __device__ __forceinline__ Moments moments(const float *__restrict__ base, int n
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void moment_bbox_forward(const float *__restrict__ pts,
+__global__ __launch_bounds__(kLoc * kSplit) void moment_bbox_forward(const float *__restrict__ pts,
                                                            const float *__restrict__ transfer, int B, int n, int HW,
                                                            int y_first, float *__restrict__ bbox) {
   __shared__ float red[kSplit][kLoc];
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256) void moment_bbox_forward(const float *__restri
   o[3LL * HW] = my.mean + half_h;
 }
 
-__global__ __launch_bounds__(256) void moment_bbox_backward(const float *__restrict__ pts,
+__global__ __launch_bounds__(kLoc * kSplit) void moment_bbox_backward(const float *__restrict__ pts,
                                                             const float *__restrict__ transfer,
                                                             const float *__restrict__ grad_bbox, int B, int n, int HW,
                                                             int y_first, float *__restrict__ grad_pts,
@@ -138,7 +141,7 @@ int kgdet_moment_bbox_forward(const float *pts, const float *moment_transfer, in
   if ((long long)B * HW == 0) return KGDET_OK;
   KGDET_CHECK_SHAPE(pts && moment_transfer && bbox, "null pointer");
   const int grid = (int)(((long long)B * HW + 63) / 64);
-  hipLaunchKernelGGL(moment_bbox_forward, dim3(grid), dim3(256), 0, (hipStream_t)stream, pts, moment_transfer, B,
+  hipLaunchKernelGGL(moment_bbox_forward, dim3(grid), dim3(kLoc * kSplit), 0, (hipStream_t)stream, pts, moment_transfer, B,
                      n_pts, HW, y_first, bbox);
   KGDET_CHECK_LAUNCH("moment_bbox_forward");
   return KGDET_OK;
@@ -152,7 +155,7 @@ int kgdet_moment_bbox_backward(const float *pts, const float *moment_transfer, c
   if ((long long)B * HW == 0) return KGDET_OK;
   KGDET_CHECK_SHAPE(pts && moment_transfer && grad_bbox && grad_pts && grad_transfer, "null pointer");
   const int grid = (int)(((long long)B * HW + 63) / 64);
-  hipLaunchKernelGGL(moment_bbox_backward, dim3(grid), dim3(256), 0, (hipStream_t)stream, pts, moment_transfer,
+  hipLaunchKernelGGL(moment_bbox_backward, dim3(grid), dim3(kLoc * kSplit), 0, (hipStream_t)stream, pts, moment_transfer,
                      grad_bbox, B, n_pts, HW, y_first, grad_pts, grad_transfer);
   KGDET_CHECK_LAUNCH("moment_bbox_backward");
   return KGDET_OK;
