@@ -149,6 +149,35 @@ __global__ __launch_bounds__(256) void conv1x1_pack_multi(const long long *__res
     const int M = transpose ? C : O, K = transpose ? O : C;
     const int k16s = K / kTK;
     const long long total = (long long)((M + kTM - 1) / kTM) * k16s * T * 2 * kTM;
+    if (!transpose && T == 9) {
+      // forward image of a 3x3 weight: a lane's row is an output channel, whose 8 channels x 9 taps are 72 CONTIGUOUS floats
+      // (16-byte aligned: C % 16 == 0) -- one thread reads them once (18 float4) and writes the nine taps' items, instead of
+      // nine threads each picking 8 floats 36 bytes apart out of the same 288 bytes
+      if (i >= total / 9) continue;
+      const int row = (int)(i % kTM), khalf = (int)((i / kTM) & 1);
+      const long long s2 = i / (2 * kTM);             // (mt, k16)
+      const int k16 = (int)(s2 % k16s), mt = (int)(s2 / k16s);
+      const int m = mt * kTM + row, k0 = k16 * kTK + khalf * 8;
+      float r[72];
+      const f32x4 *src = reinterpret_cast<const f32x4 *>(w + ((long long)min(m, M - 1) * C + k0) * 9);
+#pragma unroll
+      for (int q = 0; q < 18; ++q) {
+        const f32x4 u = src[q];
+        r[4 * q] = u[0]; r[4 * q + 1] = u[1]; r[4 * q + 2] = u[2]; r[4 * q + 3] = u[3];
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = m < M ? r[j * 9 + t] : 0.0f;
+        bf16x8 hi8, lo8;
+        split8(v, hi8, lo8);
+        unsigned char *dst = img + (s2 * 9 + t) * kStage + khalf * (kTM * 16) + row * 16;
+        *reinterpret_cast<bf16x8 *>(dst) = hi8;
+        *reinterpret_cast<bf16x8 *>(dst + kPart) = lo8;
+      }
+      continue;
+    }
     if (i >= total) continue;
     const int row = (int)(i % kTM);
     const int khalf = (int)((i / kTM) & 1);

@@ -448,6 +448,27 @@ def test_conv_apply_epilogue_flags(B, C, O, H, W, k, stride):
 
 
 @pytest.mark.gpu
+def test_multi_pack_images_equal_single_packs_bit_for_bit():
+    """the step's one-launch pack of all weights (conv1x1_pack_multi; 3x3 forward images: one thread per 72 contiguous floats)
+    writes the same operand images, forward and transposed, as kgdet_conv_pack_both per weight -- 1x1 and 3x3, row counts below,
+    at and above one 128-row tile"""
+    from kgdet_amd import conv1x1
+    torch.manual_seed(1)
+    shapes = [(64, 32, 1), (64, 32, 3), (256, 128, 3), (128, 512, 1), (144, 48, 3), (16, 16, 1), (512, 256, 1), (272, 160, 3)]
+    ws = [torch.nn.Parameter(torch.randn(O, C, k, k, device='cuda')) for O, C, k in shapes]
+    x = [torch.randn(1, C, 6, 8, device='cuda', requires_grad=True) for O, C, k in shapes]
+    for _ in range(2):          # first scope: every weight joins the set (packed on its own); second: ONE launch for all
+        with conv1x1.step_scope():
+            for xi, w in zip(x, ws):
+                conv1x1.conv_split(xi, w)
+    for w in ws:
+        e = conv1x1._entries[id(w)]
+        img, img_t = conv1x1._pack_both(w.detach())
+        assert torch.equal(e.img.view(torch.uint8), img.view(torch.uint8)), tuple(w.shape)
+        assert torch.equal(e.img_t.view(torch.uint8), img_t.view(torch.uint8)), tuple(w.shape)
+    conv1x1._entries.clear()
+
+
 def test_step_scope_packs_follow_weight_updates():
     """conv1x1.step_scope: one multi-weight pack launch per training forward into persistent images.  The images must
     follow in-place weight updates (fused optimizers do not bump `_version`), a weight met for the first time inside
