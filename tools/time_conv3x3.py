@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from kgdet_amd import conv1x1 as c1
 k = 1 if 'k1' in sys.argv else 3
-shapes = [(2, 256, 256, 25, 42), (2, 512, 512, 25, 42), (2, 256, 256, 50, 84), (2, 128, 128, 100, 168), (2, 64, 64, 200, 336)]
+shapes = [(2, 128, 128, 100, 168)] if "one" in sys.argv else [(2, 256, 256, 25, 42), (2, 512, 512, 25, 42), (2, 256, 256, 50, 84), (2, 128, 128, 100, 168), (2, 64, 64, 200, 336)]
 if k == 1:   # the bottleneck 1x1 shapes of a [2, 3, 800, 1344] step (+ variants with fewer pixel tiles)
     shapes = [(2, 256, 64, 200, 336), (2, 64, 256, 200, 336), (2, 256, 128, 200, 336), (2, 512, 128, 100, 168), (2, 512, 128, 96, 168),
               (2, 128, 512, 100, 168), (2, 128, 512, 96, 168), (2, 512, 256, 100, 168), (2, 1024, 256, 50, 84), (2, 256, 1024, 50, 84),
