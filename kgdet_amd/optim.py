@@ -29,6 +29,7 @@ class FusedClipAdam(object):
         self._pinned = None
         self._event = None
         self._host_step = None
+        self._step_ref = None
 
     @staticmethod
     def applicable(optimizer, params, grad_clip):
@@ -97,8 +98,11 @@ class FusedClipAdam(object):
                                                ctypes.c_int64(first), _lib.ptr(self._partial), _lib.ptr(self._norm), stream),
                        'multi_grad_norm')
         torch._foreach_add_(steps, 1.0)        # the optimizer's own step counters (state_dict compatibility)
-        if self._host_step is None:
-            self._host_step = int(round(float(steps[0])))      # ONE read-back, at the first fused step
+        if self._host_step is None or steps[0] is not self._step_ref:
+            # ONE read-back, at the first fused step -- and again whenever the optimizer's state was replaced
+            # (load_state_dict on resume creates new step tensors)
+            self._host_step = int(round(float(steps[0])))
+            self._step_ref = steps[0]
         else:
             self._host_step += 1
         t = self._host_step

@@ -172,3 +172,39 @@ def test_fused_clip_adam_equals_torch_clip_and_adam(max_norm):
         assert t1 == t2 == 4.0
         assert (m1 - m2).abs().max().item() <= 1e-6 * m2.abs().max().item() + 1e-12
         assert (v1 - v2).abs().max().item() <= 1e-6 * v2.abs().max().item() + 1e-15
+
+
+def test_fused_clip_adam_follows_a_reloaded_optimizer_state():
+    """resume: optimizer.load_state_dict replaces the state tensors (other step count, other moments); the fused path must pick
+    the new step count up instead of counting on from its own"""
+    from kgdet_amd.dist import DistOptimizerHook
+
+    def make():
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(31, 50), torch.nn.ReLU(), torch.nn.Linear(50, 3)).cuda()
+        return net, torch.optim.Adam(net.parameters(), lr=1e-2, fused=True)
+
+    x = torch.randn(16, 31, device='cuda')
+    net, opt = make()
+    hook = DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2))
+    for _ in range(5):
+        hook.step(net, opt, net(x).square().mean())
+    ckpt_model, ckpt_opt = {k: v.clone() for k, v in net.state_dict().items()}, opt.state_dict()
+    import copy
+    ckpt_opt = copy.deepcopy(ckpt_opt)
+    for _ in range(3):
+        hook.step(net, opt, net(x).square().mean())            # steps 6-8, then "resume" from the step-5 checkpoint
+    want = None
+    for same_hook in (True, False):
+        net.load_state_dict(ckpt_model)
+        opt.load_state_dict(copy.deepcopy(ckpt_opt))
+        h = hook if same_hook else DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2))
+        for _ in range(2):
+            h.step(net, opt, net(x).square().mean())
+        got = [p.detach().clone() for p in net.parameters()]
+        assert float(opt.state[next(iter(net.parameters()))]['step']) == 7.0
+        if want is None:
+            want = got
+        else:
+            for a_, b_ in zip(got, want):
+                assert torch.equal(a_, b_)
