@@ -991,7 +991,15 @@ __global__ __launch_bounds__(256) void conv3x3_wsum(const float *__restrict__ pa
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += gridDim.x * 256LL) {
     const int o = (int)(i / (9 * C)), rem = (int)(i - (long long)o * 9 * C), t = rem / C, ch = rem - t * C;
     float s = 0.0f;
-    for (int k = 0; k < count; ++k) s += parts[(long long)k * n + i];
+    int k = 0;
+    for (; k + 8 <= count; k += 8) {   // eight loads in flight, added in slot order
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = parts[(long long)(k + e) * n + i];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[e];
+    }
+    for (; k < count; ++k) s += parts[(long long)k * n + i];
     out[((long long)o * C + ch) * 9 + t] = s;
   }
 }
