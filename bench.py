@@ -26,8 +26,8 @@ sys.path.insert(0, ROOT)
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--imgs-per-gpu', type=int, default=2)
     ap.add_argument('--mode', choices=['train', 'infer'], default='train')
     ap.add_argument('--dtype', choices=['fp32', 'bf16'], default='fp32',
