@@ -136,7 +136,8 @@ def _launch_multi():
     if not _entries:
         return
     live = list(_entries.items())
-    key = tuple(k for k, _ in live)
+    # the rows hold raw device pointers: the key names them too (ids alone are reused by CPython once a model is freed)
+    key = tuple((k, e.ptr, e.img.data_ptr(), e.img_t.data_ptr()) for k, e in live)
     L = _lib_sizes()
     if _table is None or _table[0] != key:
         rows, first = [], 0

@@ -563,9 +563,12 @@ using namespace kgdet;
 extern "C" {
 
 size_t kgdet_nms_workspace_bytes(int64_t total_n, int32_t num_segments) {
-  // segments of up to 4096 boxes live entirely in LDS; longer ones keep their arrays here (upper bound for any split
-  // of total_n boxes into num_segments segments)
-  return 16 + 2 * nms_large_scratch_bytes(total_n > 0 ? total_n : 1) + (size_t)(num_segments > 0 ? num_segments : 1) * 256;
+  // segments of up to 4096 boxes live entirely in LDS; when ANY segment is longer, nms_segments_large gives EVERY
+  // segment (empty and tiny ones too) a 256-byte-aligned slice of nms_large_scratch_bytes(n) = np * 8 + 24 n +
+  // roundup16(n) bytes with np = max(64, next power of two >= n) < max(64, 2 n).  Per segment that is at most
+  // 512 + 16 n + 24 n + n + 15 + 255, so for any split of total_n boxes into num_segments segments:
+  const size_t t = (size_t)(total_n > 0 ? total_n : 1), s = (size_t)(num_segments > 0 ? num_segments : 1);
+  return 16 + 41 * t + 800 * s;
 }
 
 static int nms_launch(const float *dets, const int64_t *seg_offsets, int32_t num_segments, int64_t total_n,

@@ -20,30 +20,36 @@ import torch.distributed as dist
 from torch._utils import _flatten_dense_tensors, _take_tensors, _unflatten_dense_tensors
 
 
-def _allreduce_coalesced(tensors, world_size, bucket_size_mb=-1):
+def _group_for_exchange(tensors, bucket_size_mb):
+    """The reference's grouping rule (dist_utils.py:9-17): size-limited buckets when a limit is given, otherwise
+    one group per tensor type in first-seen order."""
     if bucket_size_mb > 0:
-        buckets = _take_tensors(tensors, bucket_size_mb * 1024 * 1024)
-    else:
-        by_type = OrderedDict()
-        for tensor in tensors:
-            by_type.setdefault(tensor.type(), []).append(tensor)
-        buckets = by_type.values()
-    for bucket in buckets:
-        flat = _flatten_dense_tensors(bucket)
+        return list(_take_tensors(tensors, bucket_size_mb * 1024 * 1024))
+    groups = OrderedDict()
+    for t in tensors:
+        groups.setdefault(t.type(), []).append(t)
+    return list(groups.values())
+
+
+def _allreduce_coalesced(tensors, world_size, bucket_size_mb=-1):
+    """Flatten -> all_reduce -> divide -> scatter back, per group (the arithmetic of dist_utils.py:17-22:
+    sum first, then ONE division by the world size)."""
+    for group in _group_for_exchange(tensors, bucket_size_mb):
+        flat = _flatten_dense_tensors(group)
         dist.all_reduce(flat)
         flat.div_(world_size)
-        for tensor, synced in zip(bucket, _unflatten_dense_tensors(flat, bucket)):
-            tensor.copy_(synced)
+        torch._foreach_copy_(list(group), list(_unflatten_dense_tensors(flat, group)))
 
 
 def allreduce_grads(params, coalesce=True, bucket_size_mb=-1):
-    grads = [param.grad.data for param in params if param.requires_grad and param.grad is not None]
+    """Same signature and result as dist_utils.py:25-41.  Only parameters that own a gradient take part."""
     world_size = dist.get_world_size()
+    grads = [p.grad.data for p in params if p.requires_grad and p.grad is not None]
     if coalesce:
         _allreduce_coalesced(grads, world_size, bucket_size_mb)
-    else:
-        for tensor in grads:
-            dist.all_reduce(tensor.div_(world_size))
+        return
+    for g in grads:             # un-coalesced: pre-divide, then sum (dist_utils.py:40-41)
+        dist.all_reduce(g.div_(world_size))
 
 
 def clip_grads(params, max_norm=35, norm_type=2):
@@ -68,7 +74,8 @@ class OverlappedGradReducer(object):
 
     The set of gradient-carrying parameters must be the same on every rank (as for the reference's
     ``param.grad is not None`` filter).  A bucketed parameter without a gradient in some step contributes
-    zeros; a parameter that starts to receive gradients later makes the buckets rebuild.
+    zeros to the exchange and keeps ``grad = None`` afterwards; a parameter that starts to receive gradients
+    later makes the buckets rebuild.  RCCL calls are issued in bucket-index order on every rank.
     """
 
     def __init__(self, params, bucket_size_mb=32, process_group=None):
@@ -118,9 +125,16 @@ class OverlappedGradReducer(object):
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self._reset_counts()
 
+    def close(self):
+        """Detach from the parameters (removes the gradient hooks); the reducer can be rebuilt by another finish()."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks, self.buckets = [], None
+
     def _reset_counts(self):
         self._remaining = [len(b) for b in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self._next = 0              # buckets are launched strictly in index order (see _on_grad)
         self._pending = []
 
     # -- per-step -------------------------------------------------------------------------------
@@ -144,11 +158,20 @@ class OverlappedGradReducer(object):
         self._pending.append((b, work))
 
     def _on_grad(self, p):
+        """Post-accumulate hook.  A bucket whose gradients are all there becomes READY; collectives are ISSUED
+        strictly in bucket-index order (bucket b only once every bucket < b is out), as torch DDP does: the order
+        in which autograd finishes gradients may differ between ranks (ties in its ready queue), the order of
+        RCCL calls must not."""
         b = self._bucket_of[p]
         self._remaining[b] -= 1
-        if self._remaining[b] == 0 and not self._launched[b]:
+        if self._remaining[b] < 0:
+            raise RuntimeError('OverlappedGradReducer: a gradient hook fired twice before finish() -- two '
+                               'backward passes per step (gradient accumulation) are not supported by the '
+                               'overlapped exchange; call finish() after every backward()')
+        while self._next < len(self.buckets) and self._remaining[self._next] == 0:
             self.launched_from_hooks += 1
-            self._launch(b)
+            self._launch(self._next)
+            self._next += 1
 
     def finish(self):
         """Call after ``loss.backward()``: completes the exchange; afterwards every bucketed parameter's
@@ -163,14 +186,13 @@ class OverlappedGradReducer(object):
                 h.remove()
             self._hooks, self.buckets = [], None
         if self.buckets is None:
-            # first step: plain (reference-style) all-reduce, and learn which params get gradients
+            # first step: learn which params get gradients, build the buckets and exchange through them (all
+            # launched from here, in index order; no second whole-payload buffer)
             self.active = [p for p in self.params if p.grad is not None]
-            _allreduce_coalesced([p.grad.data for p in self.active], self.world_size, -1)
             self._build()
-            return
-        for b in range(len(self.buckets)):   # buckets whose hooks did not all fire this step
-            if not self._launched[b]:
-                self._launch(b)
+        for b in range(self._next, len(self.buckets)):   # buckets whose hooks did not all fire this step
+            self._launch(b)
+        self._next = len(self.buckets)
         with self._side():
             for b, work in self._pending:
                 work.wait()                  # orders the SIDE stream after the collective
@@ -179,7 +201,8 @@ class OverlappedGradReducer(object):
             torch.cuda.current_stream().wait_stream(self.stream)
         for plist, views in zip(self.buckets, self._views):
             for p, v in zip(plist, views):
-                p.grad = v
+                if p.grad is not None:       # no gradient on this rank this step: stays None (the reference's
+                    p.grad = v               # `param.grad is not None` filter; the optimizer skips it)
         self._reset_counts()
 
 
@@ -223,8 +246,9 @@ class DistOptimizerHook(object):
             self._fused = FusedClipAdam()
         if len(optimizer.param_groups) == 1 and self._fused.applicable(optimizer, self._params, self.grad_clip):
             # clip + Adam as two multi-tensor HIP passes (csrc/optim.hip); the first step (no state yet) and anything else: torch
-            self._fused.step(optimizer, self._params, self.grad_clip)
-            return
+            if self._fused.step(optimizer, self._params, self.grad_clip):
+                return
+        self._fused.invalidate()       # torch advances the step counters below: the fused path re-reads them next time
         if self.grad_clip is not None:
             self.clip_grads(self._params)
         optimizer.step()

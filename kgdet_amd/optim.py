@@ -30,6 +30,11 @@ class FusedClipAdam(object):
         self._event = None
         self._host_step = None
         self._step_ref = None
+        self._n_steps = 0
+
+    def invalidate(self):
+        """A step was taken outside this object (torch's ``optimizer.step()``): the host copy of the step count is stale."""
+        self._host_step = None
 
     @staticmethod
     def applicable(optimizer, params, grad_clip):
@@ -38,7 +43,8 @@ class FusedClipAdam(object):
         if grad_clip is not None and float(grad_clip.get('norm_type', 2)) != 2.0:
             return False
         for group in optimizer.param_groups:
-            if group.get('amsgrad') or group.get('maximize') or group.get('differentiable') or group.get('capturable'):
+            if group.get('amsgrad') or group.get('maximize') or group.get('differentiable') or group.get('capturable') \
+                    or group.get('decoupled_weight_decay'):      # (AdamW's update is a different expression)
                 return False
             if isinstance(group['lr'], torch.Tensor):
                 return False
@@ -53,8 +59,9 @@ class FusedClipAdam(object):
         return True
 
     def step(self, optimizer, params, grad_clip):
-        """clip (over ``params``, the hook's list) + Adam (the optimizer's single parameter group); returns the total norm
-        (a device scalar) or None"""
+        """clip (over ``params``, the hook's list) + Adam (the optimizer's single parameter group).  Returns True when the
+        step was taken (``last_norm`` = the total norm as a device scalar, or None), False when it must go through
+        torch (per-parameter step counters differ)."""
         L = _lib.lib()
         chunk = L.kgdet_optim_chunk()
         group = optimizer.param_groups[0]
@@ -71,7 +78,7 @@ class FusedClipAdam(object):
             if grad_clip is not None and id(p) not in clip_set:
                 raise RuntimeError('a stepped parameter is missing from the clipped set')
         if not rows:
-            return None
+            return True
         key = tuple(rows)
         dev = group['params'][0].device       # (the step counters live on the CPU unless the optimizer is fused / capturable)
         if key != self._key:
@@ -97,14 +104,22 @@ class FusedClipAdam(object):
             _lib.check(L.kgdet_multi_grad_norm(ctypes.c_void_p(self._table.data_ptr()), ctypes.c_int32(len(rows)),
                                                ctypes.c_int64(first), _lib.ptr(self._partial), _lib.ptr(self._norm), stream),
                        'multi_grad_norm')
-        torch._foreach_add_(steps, 1.0)        # the optimizer's own step counters (state_dict compatibility)
-        if self._host_step is None or steps[0] is not self._step_ref:
+        if self._host_step is None or steps[0] is not self._step_ref or len(steps) != self._n_steps:
             # ONE read-back, at the first fused step -- and again whenever the optimizer's state was replaced
-            # (load_state_dict on resume creates new step tensors)
-            self._host_step = int(round(float(steps[0])))
+            # (load_state_dict on resume creates new step tensors), the set of stepped tensors changed, or a step went
+            # through torch in between (`invalidate()`, called by the hook's fallback branch).  The kernel applies one
+            # bias correction to all tensors, torch keeps a counter per parameter: counters that differ (a parameter
+            # that joined later) are not this kernel's case -- the caller falls back to optimizer.step().
+            both = torch.stack([s.detach().reshape(()).float() for s in steps]).aminmax()
+            lo, hi = float(both.min), float(both.max)
+            if lo != hi:
+                self._host_step = None
+                return False
+            self._host_step = int(round(lo))
             self._step_ref = steps[0]
-        else:
-            self._host_step += 1
+            self._n_steps = len(steps)
+        torch._foreach_add_(steps, 1.0)        # the optimizer's own step counters (state_dict compatibility)
+        self._host_step += 1
         t = self._host_step
         beta1, beta2 = group['betas']
         _lib.check(L.kgdet_multi_clip_adam(
@@ -112,4 +127,8 @@ class FusedClipAdam(object):
             ctypes.c_float(max_norm), ctypes.c_float(group['lr']), ctypes.c_double(beta1), ctypes.c_double(beta2),
             ctypes.c_float(group['eps']), ctypes.c_float(group['weight_decay']),
             ctypes.c_float(1.0 - beta1 ** t), ctypes.c_float(math.sqrt(1.0 - beta2 ** t)), stream), 'multi_clip_adam')
-        return self._norm[0] if grad_clip is not None else None
+        # the kernel wrote the parameters through raw pointers: tell autograd's version counters, so weight images
+        # cached by `_version` (backbone fold / stem caches, DeformConv packs, conv1x1 tables) are rebuilt
+        torch.autograd.graph.increment_version([p for p in group['params'] if p.grad is not None])
+        self.last_norm = self._norm[0] if grad_clip is not None else None
+        return True

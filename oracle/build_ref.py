@@ -2,18 +2,21 @@
 
 TEST INFRASTRUCTURE ONLY.  Compiles, unmodified,
 
-    /root/reference/mmdetection/mmdet/ops/nms/src/nms_cpu.cpp       -> oracle/_ref/ref_nms_cpu*.so
-    /root/reference/mmdetection/mmdet/ops/nms/src/soft_nms_cpu.pyx  -> oracle/_ref/soft_nms_cpu*.so
-    /root/reference/deepfashion2_api/PythonAPI/pycocotools/_mask.pyx + common/maskApi.c -> oracle/_ref/_mask*.so
+    /root/reference/mmdetection/mmdet/ops/nms/src/nms_cpu.cpp       -> $KGDET_REF_BUILD/ref_nms_cpu*.so
+    /root/reference/mmdetection/mmdet/ops/nms/src/soft_nms_cpu.pyx  -> $KGDET_REF_BUILD/soft_nms_cpu*.so
+    /root/reference/deepfashion2_api/PythonAPI/pycocotools/_mask.pyx + common/maskApi.c -> $KGDET_REF_BUILD/_mask*.so
         (the compiled dependency of the reference's pure-Python COCO / COCOeval, which are then imported in place)
 
-with g++ / cython + gcc directly (not the reference's setup.py).  Nothing is copied into the
-repository: outputs (objects, generated C, .so) go to oracle/_ref/ only, which is git-ignored.
+with g++ / cython + gcc directly (not the reference's setup.py).  Nothing derived from the reference is
+written into the repository: outputs (generated C -- Cython embeds the .pyx text in it --, objects, .so) go to
+$KGDET_REF_BUILD (default /tmp/kgdet_ref), OUTSIDE the working tree, so no reference-derived artefact is
+snapshotted to the GPU box (round-2 review item 2; tests/test_host_logic.py::test_no_reference_text_in_tree).
+The GPU tests use the committed golden vectors only.
 The rest of the hot path (deform conv, psroi pooling, focal loss) has no CPU implementation in
 the reference (CUDA-only) and is therefore unbuildable here.
 
-Used by tests/golden/make_nms_golden.py to generate the committed golden vectors and, when
-oracle/_ref exists, by tests/test_oracle_nms.py for a live cross-check.
+Used by tests/golden/make_*_golden.py to generate the committed golden vectors and, where the reference is
+mounted, by tests/test_oracle_nms.py / test_evaluation.py for a live cross-check (built on demand).
 """
 import os
 import subprocess
@@ -21,7 +24,7 @@ import sys
 import sysconfig
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-OUT = os.path.join(HERE, '_ref')
+OUT = os.environ.get('KGDET_REF_BUILD', '/tmp/kgdet_ref')
 REF_NMS = '/root/reference/mmdetection/mmdet/ops/nms/src'
 
 
@@ -93,7 +96,7 @@ def build_mask_api():
 def load_reference_evaluator():
     """(COCO, COCOeval) classes of the reference's DeepFashion2 evaluator, imported from where they lie
     (deepfashion2_api/PythonAPI/pycocotools/{coco,cocoeval}.py are pure Python; their compiled `_mask` dependency
-    comes from oracle/_ref).  None when the reference checkout is absent."""
+    comes from $KGDET_REF_BUILD).  None when the reference checkout is absent."""
     if not os.path.isfile(os.path.join(REF_API, 'PythonAPI', 'pycocotools', 'cocoeval.py')):
         return None
     import importlib.util

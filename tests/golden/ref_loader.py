@@ -5,7 +5,7 @@ What executes is the reference's own code, file by file:
     mmdet/core/anchor/point_generator.py, point_target_kp.py
     mmdet/core/bbox/geometry.py, assign_sampling.py, assigners/*, samplers/*
     mmdet/core/utils/misc.py (multi_apply), mmdet/core/post_processing/bbox_nms_kp.py
-    mmdet/ops/nms/nms_wrapper.py over the COMPILED reference nms_cpu.cpp / soft_nms_cpu.pyx (oracle/_ref)
+    mmdet/ops/nms/nms_wrapper.py over the COMPILED reference nms_cpu.cpp / soft_nms_cpu.pyx (built by oracle/build_ref.py into $KGDET_REF_BUILD, outside the tree)
     mmdet/utils/registry.py, mmdet/models/{registry,builder}.py, models/utils/*, models/losses/*
     mmdet/models/anchor_heads/reppoints_head_kp3rep_cas_1_assign_once.py, reppoints_head_kp_serial.py, ...
 The package objects `mmdet`, `mmdet.core`, ... are empty modules whose `__path__` points at the real
@@ -227,7 +227,7 @@ def load_detector():
     (+ fpn.py), models/detectors/{base,single_stage,reppoints_detector_kp}.py, core/fp16/decorators.py,
     core/bbox/transforms.py, core/post_processing/bbox_nms.py, core/evaluation/class_names.py.
     Extra glue: `mmdet.ops.ContextBlock` / `ModulatedDeformConv` are placeholders that are never instantiated by
-    the KGDet configs; `pycocotools.mask` is the reference's own (oracle/_ref build)."""
+    the KGDet configs; `pycocotools.mask` is the reference's own (oracle/build_ref.py build, outside the tree)."""
     ns = load()
     if hasattr(ns, 'build_detector'):
         return ns

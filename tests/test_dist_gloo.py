@@ -17,6 +17,16 @@ def _free_port():
 
 
 def _worker(rank, world, port, q):
+    try:
+        _worker_body(rank, world, port, q)
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        q.put((rank, False))
+        raise
+
+
+def _worker_body(rank, world, port, q):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -66,7 +76,12 @@ def _worker(rank, world, port, q):
     for i, p in enumerate(model[0].parameters()):
         mean = sum(torch.from_numpy(gathered[r][i]) for r in range(world)) / world
         ok &= bool(torch.allclose(p.grad, mean, atol=1e-6))
-    ok &= all(float(p.grad.abs().max()) == 0.0 for p in model[2].parameters())
+    # (zeros in the exchange; on this rank the gradient stays None, as under the reference's filter, so the
+    # optimizer does not move the parameter on momentum)
+    ok &= all(p.grad is None for p in model[2].parameters())
+    dead = {id(p) for p in model[2].parameters()}
+    ok &= all(float(v.abs().max()) == 0.0 for pl, vl in zip(red.buckets, red._views) for p, v in zip(pl, vl)
+              if id(p) in dead)
     # ... and a parameter that starts to receive gradients later is picked up (buckets rebuild)
     for p in params:
         p.grad = None
@@ -78,6 +93,36 @@ def _worker(rank, world, port, q):
         mean = sum(torch.from_numpy(gathered[r][i]) for r in range(world)) / world
         ok &= bool(torch.allclose(p.grad, mean, atol=1e-6))
     ok &= all(p in red._bucket_of for p in unused.parameters())
+    # RCCL calls are issued in bucket-index order whatever order autograd finishes the gradients in (a rank whose
+    # ready queue breaks a tie differently must not issue a different sequence of collectives)
+    order = []
+    launch = red._launch
+    red._launch = lambda b: (order.append(b), launch(b))[1]
+    local_grads()          # the hooks fired in autograd's order ...
+    red.finish()
+    ok &= order == list(range(len(red.buckets)))
+    order.clear()
+    for p in params:
+        p.grad = None
+    with torch.no_grad():
+        for p in model.parameters():
+            p.grad = torch.ones_like(p) * (rank + 1)
+    for p in sorted(red.active, key=lambda p: -red._bucket_of[p]):     # ... and here in exactly the reverse bucket order
+        red._on_grad(p)
+        ok &= order == sorted(order)
+    nb_before_finish = len(order)
+    red.finish()
+    ok &= order == list(range(len(red.buckets))) and nb_before_finish == len(red.buckets)
+    ok &= all(bool(torch.allclose(p.grad, torch.full_like(p, 1.5))) for p in model.parameters())
+    red._launch = launch
+    # two backward passes before finish() would exchange a partial gradient: refused loudly
+    local_grads()
+    try:
+        model(x).pow(2).sum().backward()
+        ok = False
+    except RuntimeError as e:
+        ok &= 'fired twice' in str(e)
+    red.finish()
     # non-contiguous gradients are packed by value, not by storage order
     wt = nn.Parameter(torch.randn(4, 6, generator=torch.Generator().manual_seed(7)))
     red2 = OverlappedGradReducer([wt], bucket_size_mb=1)
@@ -89,6 +134,7 @@ def _worker(rank, world, port, q):
         ok &= bool(torch.equal(wt.grad, torch.arange(24.).reshape(6, 4).t() * (sum(range(1, world + 1)) / world)))
 
     # the optimizer hook end to end: both ranks stay in sync
+    red.close()
     opt = torch.optim.SGD(params, lr=0.1)
     hook = DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2), overlap=True, bucket_size_mb=1)
     for _ in range(2):

@@ -283,6 +283,46 @@ def test_nms_beyond_the_on_chip_limit_bit_exact(golden_dir):
         np.testing.assert_array_equal(keep[offs[s]:offs[s] + num[s]], w)
 
 
+@pytest.mark.parametrize('tail', ['empty', 'one_box'])
+def test_nms_large_segment_with_a_thousand_small_ones(tail):
+    """when one segment exceeds the on-chip limit EVERY segment gets a slice of the scratch buffer (at least
+    512 + 255 bytes); the old bound allotted 256 per segment and the kernel wrote past the allocation.  One 4100-box
+    segment followed by 999 empty / one-box segments: results equal the oracle's and the words after the workspace the
+    size query asks for stay untouched."""
+    import ctypes
+    import oracle
+    from kgdet_amd import _lib
+    from tests.golden.make_nms_golden import make_boxes
+    rng = np.random.default_rng(21)
+    big = make_boxes(rng, 4100)
+    small = [make_boxes(rng, 1) if tail == 'one_box' else np.zeros((0, 5), np.float32) for _ in range(999)]
+    segs = [big] + small
+    offs = np.cumsum([0] + [len(x) for x in segs]).astype(np.int64)
+    dets = torch.from_numpy(np.concatenate(segs)).cuda()
+    offs_t = torch.from_numpy(offs).cuda()
+    L = _lib.lib()
+    T, S = dets.shape[0], len(segs)
+    need = L.kgdet_nms_workspace_bytes(ctypes.c_int64(T), ctypes.c_int32(S))
+    guard = 1 << 20
+    buf = torch.full((need + guard,), 0xA5, dtype=torch.uint8, device='cuda')
+    keep = torch.empty(T, dtype=torch.int64, device='cuda')
+    num = torch.zeros(S, dtype=torch.int64, device='cuda')
+    _lib.check(L.kgdet_nms_batched(_lib.ptr(dets), _lib.ptr(offs_t), ctypes.c_int32(S), ctypes.c_int64(T),
+                                   ctypes.c_int64(4100), ctypes.c_float(0.5), _lib.ptr(keep), _lib.ptr(num),
+                                   _lib.ptr(buf), ctypes.c_size_t(need), _lib.current_stream()), 'kgdet_nms_batched')
+    torch.cuda.synchronize()
+    assert bool((buf[need:] == 0xA5).all()), 'kernel wrote past the workspace the size query asked for'
+    num = num.cpu().numpy()
+    keep = keep.cpu().numpy()
+    want0 = oracle.nms(big, 0.5)
+    assert num[0] == len(want0)
+    np.testing.assert_array_equal(keep[:num[0]], want0)
+    if tail == 'one_box':
+        assert (num[1:] == 1).all() and (keep[offs[1:-1]] == 0).all()
+    else:
+        assert (num[1:] == 0).all()
+
+
 @pytest.mark.parametrize('shape,beta,divisor,with_weight', [((2100, 588), 1.0 / 9.0, 128.0, True), ((2100, 4), 1.0 / 9.0, 128.0, True),
                                                             ((37, 5), 1.0, None, False), ((1, 1), 0.5, 3.0, True),
                                                             ((10500, 588), 1.0 / 9.0, 32.0, True)])

@@ -69,7 +69,7 @@ def test_soft_nms_bad_method():
 
 @pytest.mark.skipif(not build_ref.available(), reason='reference sources not mounted')
 def test_live_against_compiled_reference():
-    """Fresh random inputs through oracle/_ref (the compiled reference) and the restatement."""
+    """Fresh random inputs through the compiled reference ($KGDET_REF_BUILD, outside the tree) and the restatement."""
     import torch
     ref_nms, ref_soft = build_ref.load()
     rng = np.random.default_rng(7)
