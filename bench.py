@@ -7,11 +7,17 @@ on a seeded synthetic DeepFashion2-shaped batch of 2 images per GPU at 800x1333 
 forward, the nine losses, backward, gradient all-reduce over RCCL (overlapped with backward),
 grad-clip, Adam step.  Prints ONE JSON line on rank 0.  `value` = images/s over all ranks.
 
+`value` is the MEDIAN of --windows (5) timed windows of --steps steps each (every window bracketed by barrier +
+synchronize, MAX over ranks); all windows, min and max are on the line.
+
 Extra objects on the same line:
-  roofline     -- the dominant hand-written kernel (DeformConv forward, 7x7, B=2: 13.49 GFLOP,
-                  17.97 MB algorithmic) timed live with HIP events on the stream it runs on;
-  cpu_baseline -- the oracle's reference-algorithm deformable conv (materialised im2col + GEMM) on the
-                  host cores, rank 0, N=1 only, bounded sample.
+  roofline     -- the dominant hand-written launch (DeformConv forward of one head stage: 2 maps x 3x3/5x5/7x7, B=2:
+                  45.69 GFLOP, 72.1 MB algorithmic) timed live with HIP events on the stream it runs on;
+  cpu_baseline -- the oracle's reference-algorithm deformable conv (materialised im2col + GEMM) forward AND backward of
+                  the same head stage plus the reference NMS on 1000 boxes, on the host cores, rank 0, N=1 only,
+                  bounded sample, each leg in the unit of its GPU counterpart (TFLOP/s, Mbox/s);
+  allreduce    -- (N > 1, or --force-dist on one GPU) bus bandwidth of the gradient exchange and `exposed_ms`: what the
+                  overlapped exchange adds to a step.
 """
 import argparse
 import json
@@ -44,6 +50,13 @@ def parse_args():
     ap.add_argument('--no-inference-leg', action='store_true',
                     help='training mode, 1 GPU: skip the bf16 batch-8 inference measurement (a child process) that '
                          'is reported as the `inference` object of the same JSON line')
+    ap.add_argument('--windows', type=int, default=5,
+                    help='timed windows of --steps steps each (every window bracketed by barrier + synchronize); `value` is '
+                         'the MEDIAN window, min / max / all windows are reported beside it')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='run the N-rank code path even with --gpus 1: ranks started through a child torch.distributed.run, '
+                         'init_process_group(nccl), broadcast, overlapped bucketed all-reduce over RCCL, barriers, '
+                         'MAX-reduced time and the `allreduce` object (what a 1-GPU box can prove of the multi-GPU path)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     return ap.parse_args()
@@ -74,7 +87,7 @@ def launch_ranks(args):
 
 ARGS = parse_args() if __name__ == '__main__' else None
 if ARGS is not None:
-    if 'RANK' not in os.environ and ARGS.gpus > 1:
+    if 'RANK' not in os.environ and (ARGS.gpus > 1 or ARGS.force_dist):
         launch_ranks(ARGS)
     if int(os.environ.get('WORLD_SIZE', 1)) != ARGS.gpus:
         sys.exit('bench.py: --gpus %d but WORLD_SIZE=%s' % (ARGS.gpus, os.environ.get('WORLD_SIZE', '1')))
@@ -157,10 +170,69 @@ def dcn_roofline(device, batch=2, precision='split', iters=100):
                 hbm_frac=round(byts / t / 1e9 / HBM_PEAK_GBS, 4))
 
 
-def cpu_baseline():
-    """SURVEY 8d protocol: the oracle's reference algorithm (materialised im2col + BLAS GEMM,
-    deform_conv_cuda.cpp:151-258 restated on the CPU) for the three DeformConv shapes of one head stage at B=2, same
-    seeded inputs as the GPU roofline run, 5 warm-up + median of 20 timed calls each; BLAS threads stated."""
+def dcn_backward_live(device, iters=30):
+    """Backward of the same head stage (grad_input + grad_offset + grad_weight of the six convs: 3 x 45.69 GFLOP), HIP
+    events on the launch stream: (forward + backward) minus forward, median of five runs."""
+    from kgdet_amd import dcn
+    g = torch.Generator(device='cpu').manual_seed(0)
+    B, C, H, W = 2, 256, 25, 42
+    ks = (3, 5, 7)
+    xs = [torch.randn(B, C, H, W, generator=g).to(device).requires_grad_() for _ in range(2)]
+    offs = [(torch.randn(B, 2 * k * k, H, W, generator=g) * 2).to(device).requires_grad_() for k in ks]
+    ws = [[(torch.randn(C, C, k, k, generator=g) * 0.01).to(device).requires_grad_() for k in ks] for _ in xs]
+    pads = [k // 2 for k in ks]
+    leaves = xs + offs + [w for wl in ws for w in wl]
+    stream = torch.cuda.current_stream()
+    gos = None
+
+    def run(backward):
+        nonlocal gos
+        outs = dcn.deform_conv_cat_multi(xs, offs, ws, pads)
+        if gos is None:
+            gos = [torch.randn_like(o) for o in outs]
+        if backward:
+            torch.autograd.backward(outs, gos)
+            for t in leaves:
+                t.grad = None
+
+    med = {}
+    for backward in (False, True):
+        for _ in range(10):
+            run(backward)
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(iters):
+                run(backward)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / iters * 1e-3)
+        med[backward] = sorted(ts)[2]
+    return med[True] - med[False]
+
+
+def nms_live(device, dets, iters=50):
+    from kgdet_amd.nms import nms_batched
+    d = torch.from_numpy(dets).to(device)
+    offs = torch.tensor([0, d.shape[0]], dtype=torch.int64, device=device)
+    for _ in range(5):
+        nms_batched(d, offs, 0.5, max_seg_len=d.shape[0])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        nms_batched(d, offs, 0.5, max_seg_len=d.shape[0])
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def cpu_baseline(device=None, gpu_forward_s=None):
+    """SURVEY 8d protocol, in the roofline row's own unit on both sides: the oracle's reference algorithm (materialised
+    im2col + BLAS GEMM, deform_conv_cuda.cpp:151-484 restated on the CPU) for ONE KGDet head stage at B=2 -- the six
+    DeformConv calls (2 maps x 3x3/5x5/7x7 on [2,256,25,42]) of the roofline launch -- forward (45.69 GFLOP) and backward
+    (grad_input + grad_offset + grad_weight, 3 x 45.69 GFLOP), plus the reference's nms_cpu algorithm on 1000 boxes; same
+    seeded inputs, bounded sample (~20 s), BLAS threads stated.  The GPU's live numbers for the same legs sit beside them."""
     import numpy as np
     import oracle
     try:
@@ -172,25 +244,53 @@ def cpu_baseline():
     rng = np.random.default_rng(0)
     B, C, H, W = 2, 256, 25, 42
     x = rng.normal(size=(B, C, H, W)).astype(np.float32)
-    med = {}
+    go = rng.normal(size=(B, C, H, W)).astype(np.float32)
+
+    def median_time(fn, warm, reps):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2]
+
+    fwd, bwd = {}, {}
     for k in (3, 5, 7):
         off = (rng.normal(size=(B, 2 * k * k, H, W)) * 2).astype(np.float32)
         w = (rng.normal(size=(C, C, k, k)) * 0.01).astype(np.float32)
-        for _ in range(5):
-            oracle.deform_conv_forward(x, off, w, 1, k // 2, 1)
-        ts = []
-        for _ in range(20):
-            t0 = time.perf_counter()
-            oracle.deform_conv_forward(x, off, w, 1, k // 2, 1)
-            ts.append(time.perf_counter() - t0)
-        med[k] = sorted(ts)[len(ts) // 2]
-    # one training step's head forward = 4 calls of each size (2 branches x 2 deformable stages)
-    head_fwd_s = 4 * sum(med.values())
-    return dict(value=round(B / head_fwd_s, 3), unit='img/s (DeformConv forward of the head only)',
-                cores=threads, host_cpus=os.cpu_count(), kind='port', blas=blas,
-                sample='oracle im2col+GEMM, DeformConv fwd 3x3/5x5/7x7 on [2,256,25,42], 5 warm-up + median of 20 each: '
-                       '%.1f / %.1f / %.1f ms; x4 = the 12 DeformConv calls of one head forward'
-                       % tuple(med[k] * 1e3 for k in (3, 5, 7)))
+        fwd[k] = median_time(lambda: oracle.deform_conv_forward(x, off, w, 1, k // 2, 1), 3, 9)
+        bwd[k] = median_time(lambda: oracle.deform_conv_backward(x, off, w, go, 1, k // 2, 1), 1, 5)
+    flops = sum(2.0 * C * C * k * k * B * H * W for k in (3, 5, 7)) * 2          # one head stage
+    stage_fwd_s, stage_bwd_s = 2 * sum(fwd.values()), 2 * sum(bwd.values())
+    brng = np.random.default_rng(5)              # 1000 boxes in 40 clusters: overlapping neighbours, ~150 survivors
+    ctr = brng.uniform(100, 1200, size=(40, 2))[brng.integers(0, 40, size=1000)] + brng.normal(0, 12, size=(1000, 2))
+    wh = brng.uniform(40, 160, size=(1000, 2))
+    boxes = np.concatenate([ctr - wh / 2, ctr + wh / 2, brng.uniform(0.05, 1, size=(1000, 1))], 1).astype(np.float32)
+    nms_s = median_time(lambda: oracle.nms(boxes, 0.5), 3, 50)
+    legs = {
+        'dcn_forward': {'cpu': round(flops / stage_fwd_s / 1e12, 4), 'unit': 'TFLOP/s (one head stage, 45.69 GFLOP)',
+                        'cpu_ms': round(stage_fwd_s * 1e3, 1)},
+        'dcn_backward': {'cpu': round(3 * flops / stage_bwd_s / 1e12, 4),
+                         'unit': 'TFLOP/s (one head stage, grad_input + grad_offset + grad_weight = 137.07 GFLOP)',
+                         'cpu_ms': round(stage_bwd_s * 1e3, 1)},
+        'nms_1000': {'cpu': round(1000 / nms_s / 1e6, 3), 'unit': 'Mbox/s (nms_cpu.cpp algorithm, 1000 boxes, thr 0.5)',
+                     'cpu_ms': round(nms_s * 1e3, 3)},
+    }
+    if device is not None:
+        if gpu_forward_s:
+            legs['dcn_forward'].update(gpu=round(flops / gpu_forward_s / 1e12, 2), gpu_ms=round(gpu_forward_s * 1e3, 4))
+        tb = dcn_backward_live(device)
+        legs['dcn_backward'].update(gpu=round(3 * flops / tb / 1e12, 2), gpu_ms=round(tb * 1e3, 4))
+        tn = nms_live(device, boxes)
+        legs['nms_1000'].update(gpu=round(1000 / tn / 1e6, 3), gpu_ms=round(tn * 1e3, 4))
+    return dict(value=legs['dcn_forward']['cpu'], unit='TFLOP/s (DeformConv forward of one KGDet head stage: the roofline '
+                'row\'s launch and unit)', cores=threads, host_cpus=os.cpu_count(), kind='port', blas=blas, legs=legs,
+                sample='oracle im2col+GEMM on [2,256,25,42]: forward 3x3/5x5/7x7 3 warm-up + median of 9 each '
+                       '(%.1f / %.1f / %.1f ms), backward 1 warm-up + median of 5 each (%.1f / %.1f / %.1f ms), x2 maps = one '
+                       'head stage; oracle nms 1000 boxes median of 50'
+                       % tuple([fwd[k] * 1e3 for k in (3, 5, 7)] + [bwd[k] * 1e3 for k in (3, 5, 7)]))
 
 
 def allreduce_busbw(device, world, numel=52250071, iters=10):
@@ -240,7 +340,8 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs a GPU: the HIP path is the product, there is no fallback'
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist      # the N-rank code path (forced: a one-rank RCCL group)
+    if dist_on:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend='nccl')
 
@@ -256,7 +357,7 @@ def main():
     torch.manual_seed(0)
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).to(device)
-    if world > 1:  # same initial weights everywhere (the reference broadcasts once at start-up)
+    if dist_on:  # same initial weights everywhere (the reference broadcasts once at start-up)
         for p in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(p.data, 0)
     batch = synthetic.make_batch(args.imgs_per_gpu, device, seed=rank)
@@ -268,7 +369,8 @@ def main():
         # fused: one multi-tensor launch per step instead of ~10 (CPU-bound tail)
         optimizer = torch.optim.Adam(params, lr=cfg.optimizer.lr, fused=True) if args.config == 'kgdet' else \
             torch.optim.SGD(params, lr=cfg.optimizer.lr, momentum=0.9, weight_decay=0.0001, fused=True)
-        hook = DistOptimizerHook(grad_clip=dict(cfg.optimizer_config.grad_clip), overlap=True, bucket_size_mb=32)
+        hook = DistOptimizerHook(grad_clip=dict(cfg.optimizer_config.grad_clip), overlap=True, bucket_size_mb=32,
+                                 force_distributed=args.force_dist)
 
         def step():
             with autocast:
@@ -306,25 +408,46 @@ def main():
     import contextlib
     scope = torch.autocast('cuda', dtype=torch.bfloat16, enabled=args.dtype == 'bf16') if args.mode == 'infer' \
         else contextlib.nullcontext()
-    with scope:
-        for _ in range(args.warmup):
-            step()
+    def timed_window():
+        """EXACTLY --steps steps between barrier + synchronize on both sides; MAX over ranks"""
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         t0 = time.time()
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.time() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        if dist_on:
+            dist.barrier()
+        dt = time.time() - t0
+        if dist_on:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
 
-    ar = allreduce_busbw(device, world) if (world > 1 and args.mode == 'train') else None
+    with scope:
+        for _ in range(args.warmup):
+            step()
+        windows = [timed_window() for _ in range(max(1, args.windows))]
+        exposed = None
+        if dist_on and args.mode == 'train':
+            # what the exchange costs the step although it runs under backward: the same window with the exchange
+            # switched off (local gradients only; AFTER the measurement, the weights diverge from here on)
+            hook.set_local_only(True)
+            for _ in range(3):
+                step()
+            local = sorted(timed_window() for _ in range(3))[1]
+            hook.set_local_only(False)
+            exposed = (sorted(windows)[len(windows) // 2] - local) / args.steps
+    dt = sorted(windows)[len(windows) // 2]
+
+    ar = allreduce_busbw(device, world) if (dist_on and args.mode == 'train') else None
+    if ar is not None:
+        ar['exposed_ms'] = round(exposed * 1e3, 3)
+        ar['exposed_note'] = 'median step time with the overlapped exchange minus the same step without it'
+        ar['buckets'] = len(hook._reducer.buckets) if hook._reducer is not None and hook._reducer.buckets else None
+        ar['launched_inside_backward'] = hook._reducer.launched_from_hooks if hook._reducer is not None else None
     if rank == 0:
         imgs = args.imgs_per_gpu * world * args.steps
         out = {
@@ -333,6 +456,9 @@ def main():
                            'KGDet' if args.config == 'kgdet' else 'RepPoints-kp serial (config 5)'),
             'value': round(imgs / dt, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True,
+            'windows': {'n': len(windows), 'steps_each': args.steps, 'statistic': 'median',
+                        'img_s': [round(imgs / w, 1) for w in windows],
+                        'min': round(imgs / max(windows), 1), 'max': round(imgs / min(windows), 1)},
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 (bf16x3 split products, f32 accumulate)' if args.dtype == 'fp32'
             else 'bf16 (dense convs and deformable operands, f32 accumulate)',
             'data': 'synthetic',
@@ -357,9 +483,11 @@ def main():
         if ar is not None:
             out['allreduce'] = ar
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
+            rl = out.get('roofline')
+            out['cpu_baseline'] = cpu_baseline(device, rl['launch_us'] * 1e-6 if rl and rl.get('launch_us') and
+                                               args.mode == 'train' else None)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

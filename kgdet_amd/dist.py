@@ -222,6 +222,15 @@ class DistOptimizerHook(object):
         self._reducer = None
         self._params = None
         self._fused = None
+        self._local_only = False
+
+    def set_local_only(self, flag):
+        """Measurement switch (bench.py `allreduce.exposed_ms`): skip the exchange -- every rank steps on its own
+        gradients -- without touching anything else of the step."""
+        self._local_only = bool(flag)
+        if self._local_only and self._reducer is not None:
+            self._reducer.close()
+            self._reducer = None
 
     def clip_grads(self, params):
         return clip_grads(params, **self.grad_clip)
@@ -229,7 +238,7 @@ class DistOptimizerHook(object):
     def step(self, model, optimizer, loss):
         optimizer.zero_grad()
         distributed = dist.is_available() and dist.is_initialized() and \
-            (dist.get_world_size() > 1 or self.force_distributed)
+            (dist.get_world_size() > 1 or self.force_distributed) and not self._local_only
         if distributed and self.overlap and self._reducer is None:
             self._reducer = OverlappedGradReducer(list(model.parameters()),
                                                   self.bucket_size_mb if self.bucket_size_mb > 0 else 32)

@@ -208,3 +208,72 @@ def test_fused_clip_adam_follows_a_reloaded_optimizer_state():
         else:
             for a_, b_ in zip(got, want):
                 assert torch.equal(a_, b_)
+
+
+def test_fused_clip_adam_after_a_step_through_torch():
+    """a step that falls back to optimizer.step() (here: the fused path switched off for one step) advances
+    torch's step tensors; the fused path must re-read them instead of continuing its own count (bias corrections for
+    t - 1 otherwise)."""
+    from kgdet_amd import optim
+    from kgdet_amd.dist import DistOptimizerHook
+
+    def run(pattern):
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(31, 50), torch.nn.ReLU(), torch.nn.Linear(50, 3)).cuda()
+        opt = torch.optim.Adam(net.parameters(), lr=1e-2, fused=True)
+        hook = DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2))
+        x = torch.randn(16, 31, device='cuda', generator=torch.Generator(device='cuda').manual_seed(1))
+        prev = optim.ENABLED
+        try:
+            for on in pattern:
+                optim.ENABLED = on
+                hook.step(net, opt, net(x).square().mean())
+        finally:
+            optim.ENABLED = prev
+        return [p.detach().clone() for p in net.parameters()], float(opt.state[next(iter(net.parameters()))]['step'])
+
+    pa, ta = run([True, True, True, False, True, True])
+    pb, tb = run([False] * 6)
+    assert ta == tb == 6.0
+    for x, y in zip(pa, pb):
+        assert (x - y).abs().max().item() <= 2e-6 * y.abs().max().item() + 1e-9
+
+
+def test_fused_clip_adam_bumps_parameter_versions():
+    """the kernel writes parameters through raw pointers; caches keyed by `_version` (folded BatchNorm weights,
+    DeformConv packs) must see the update"""
+    from kgdet_amd.dist import DistOptimizerHook
+    torch.manual_seed(0)
+    net = torch.nn.Linear(8, 4).cuda()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2, fused=True)
+    hook = DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2))
+    x = torch.randn(5, 8, device='cuda')
+    for _ in range(2):
+        hook.step(net, opt, net(x).square().mean())
+    assert hook._fused._host_step is not None
+    v0 = net.weight._version
+    hook.step(net, opt, net(x).square().mean())
+    assert net.weight._version > v0
+
+
+def test_bench_force_dist_runs_the_n_rank_path_on_one_gpu():
+    """`python bench.py --gpus 1 --force-dist`: launch_ranks -> child torch.distributed.run -> init_process_group('nccl')
+    -> broadcast -> DistOptimizerHook(overlap, force_distributed) -> barriers -> MAX-reduced windows -> allreduce_busbw;
+    the JSON line carries the `allreduce` object (round-2 review item 1: the world > 1 branch had never executed)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MIOPEN_USER_DB_PATH')}
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--force-dist', '--steps', '4',
+                          '--warmup', '3', '--windows', '2', '--no-cpu-baseline', '--no-roofline', '--no-inference-leg'],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    line = [l for l in res.stdout.decode().splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 1 and d['value'] > 0 and d['scaling'] == 'weak'
+    assert d['windows']['n'] == 2 and len(d['windows']['img_s']) == 2
+    ar = d['allreduce']
+    assert ar['payload_MB'] > 200 and ar['ms'] > 0 and 'exposed_ms' in ar
+    assert ar['buckets'] >= 6 and ar['launched_inside_backward'] >= ar['buckets']
