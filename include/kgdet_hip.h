@@ -264,9 +264,15 @@ int kgdet_deform_conv_backward_weight(const kgdet_dcn_shape *s, const float *inp
 
 /* ------------------------------------------------------------------------------------------
  * Deformable PS-RoI pooling.  Replaces deform_psroi_pooling_cuda_forward / _backward
- * (R/dcn/src/deform_pool_cuda.cpp:30-34, 54-59).  rois [R,5] = (batch_idx,x1,y1,x2,y2);
- * trans [R, 2*num_classes, part, part] (NULL when no_trans); out/count [R, out_dim, P, P].
- * Backward accumulates into zero-filled grad_input / grad_trans (float atomics, as the reference).
+ * (R/dcn/src/deform_pool_cuda.cpp:30-34, 54-59; kernels deform_pool_cuda_kernel.cu:53-140, 143-263).
+ * rois [R,5] = (batch_idx,x1,y1,x2,y2); trans [R, 2*num_classes, part, part] (NULL when no_trans);
+ * out/count [R, out_dim, P, P].
+ * Backward OVERWRITES grad_input [B,C,H,W] and grad_trans (every element written exactly once: no pre-zeroing, no
+ * atomics, bit-repeatable; the reference accumulates with atomicAdd into zero-filled tensors).  It needs
+ * kgdet_deform_psroi_backward_workspace_bytes(s) bytes of caller-owned scratch (per-RoI bounding boxes + the
+ * transposed grad_out / count quotient).
+ * Envelope (LDS record table): pooled_size^2 * sample_per_part^2 <= 2048, pooled_size <= 16, group_size <= 16 --
+ * KGDET_E_SHAPE beyond (the reference's configs use 7 / 4 / 1 or 7).
  * ------------------------------------------------------------------------------------------ */
 typedef struct kgdet_psroi_shape {
   int32_t B, C, H, W;  /* data */
@@ -276,11 +282,15 @@ typedef struct kgdet_psroi_shape {
   float spatial_scale, trans_std;
 } kgdet_psroi_shape;
 
+size_t kgdet_deform_psroi_forward_workspace_bytes(const kgdet_psroi_shape *s);
 int kgdet_deform_psroi_forward(const kgdet_psroi_shape *s, const float *data, const float *rois,
-                               const float *trans, float *out, float *count, void *stream);
+                               const float *trans, float *out, float *count, void *workspace, size_t workspace_bytes,
+                               void *stream);
+size_t kgdet_deform_psroi_backward_workspace_bytes(const kgdet_psroi_shape *s);
 int kgdet_deform_psroi_backward(const kgdet_psroi_shape *s, const float *grad_out, const float *count,
                                 const float *data, const float *rois, const float *trans,
-                                float *grad_data, float *grad_trans, void *stream);
+                                float *grad_data, float *grad_trans, void *workspace, size_t workspace_bytes,
+                                void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sigmoid focal loss.  Replaces sigmoid_focal_loss_cuda.forward / .backward

@@ -1,21 +1,55 @@
-// Deformable position-sensitive RoI pooling forward / backward for gfx950.
-// Replaces DeformablePSROIPoolForwardKernel / BackwardAccKernel
-// (mmdet/ops/dcn/src/deform_pool_cuda_kernel.cu:53-140, 143-263).  One thread per output bin
-// (n, ctop, ph, pw); <= sample_per_part^2 bilinear samples per bin.  Backward accumulates with
-// float atomics exactly where the reference does (feature grad: 4 per sample, trans grad: 2).
-// The mixed float/double arithmetic of the reference (0.5, 0.1, 1. literals) is kept so that
-// bin boundaries round the same way.
+// Deformable position-sensitive RoI pooling for gfx950 -- forward, grad_trans, grad_data.
+// Computes what DeformablePSROIPoolForwardKernel / BackwardAccKernel compute
+// (mmdet/ops/dcn/src/deform_pool_cuda_kernel.cu:53-140, 143-263) with a different decomposition:
+//
+//  * The SAMPLING GEOMETRY of an RoI (P*P bins x S*S samples: two corner columns, two corner rows, two bilinear
+//    fractions) depends on (RoI, offset class) only, not on the channel.  A workgroup evaluates it ONCE, cooperatively,
+//    into 16-byte records in LDS; every channel of the class then reads the records (LDS broadcast, wave-uniform) instead
+//    of redoing ~40 VALU instructions per sample and channel.
+//  * COALESCED GATHERS: the feature map is re-laid-out once per call (psroi_to_cell_major, ~6 us for 8.6 MB) as
+//    dataT[image][group cell][pixel][output channel] -- channels-last for group_size 1 -- so that lanes = 64 consecutive
+//    output channels read ONE contiguous 256-byte piece per bilinear corner.  The reference's mapping (a thread per bin,
+//    NCHW) makes every corner a scattered 4-byte read; measured on [2,256,50,84] x 512 RoIs x 7x7 bins the scattered form
+//    runs at the texture addresser's ~2 lanes per clock and CU (115 us at 2x2, 359 us at 4x4 samples per bin), and
+//    staging per-RoI feature windows in LDS (built and measured: 167 / 364 us) only moves the scattered reads to the
+//    staging loop.
+//  * psroi_gather<0> (forward): workgroup = (RoI, offset class, 64 output channels); its four waves split the bins; results
+//    leave through an LDS staging buffer as one contiguous block.  psroi_gather<1> (grad_trans): workgroup = (RoI, class)
+//    walks all channels of the class, per-lane partial sums, ONE fixed-order wave reduction per bin: no atomics.
+//  * psroi_grad_data: a GATHER by output tile.  One workgroup per (image, 4x6-pixel tile, 256 input channels) keeps the
+//    tile's gradient in LDS, walks the RoIs of its image in index order (culled by a per-RoI bounding box; the sample
+//    records come prepared from psroi_prepare, one visit ahead), and thread = channel adds the in-tile corners of every
+//    sample in the reference's own serial order (RoI, bin row, bin column, sample row, sample column, corner).  Each
+//    (channel, pixel) sum has exactly one writer: NO atomics, bit-repeatable, no pre-zeroed output, and the float result
+//    equals a serial CPU evaluation of the reference loop bit for bit (this file is compiled without fp contraction for
+//    that reason).  psroi_prepare also writes grad_out / count transposed to [RoI][bin][channel] so the per-bin read is
+//    coalesced.
+//
+// The mixed float / double arithmetic of the reference (0.5, 0.1, 1. literals) is kept so that bin boundaries round the
+// same way.  Envelope of the LDS record table: pooled_size^2 * sample_per_part^2 <= 2048 records, group_size <= 16.
 #include "common.h"
+
+#pragma clang fp contract(off)
 
 namespace kgdet {
 
 namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxRecords = 2048;
+constexpr int kMaxGroup = 16;
+constexpr int kTileH = 4, kTileW = 6;  // grad_data tile
+constexpr int kBinBatch = 16;          // bins whose quotients psroi_grad_data fetches together
+constexpr int kListCap = 4096;         // RoIs per overlap-list segment of psroi_grad_data
+constexpr int kTilePix = kTileH * kTileW;
+constexpr int kAccStride = kThreads + 1;
 
 struct Roi {
   int batch;
   float w0, h0, rw, rh, bin_w, bin_h, sub_w, sub_h;
 };
 
+// deform_pool_cuda_kernel.cu:76-97
 __device__ __forceinline__ Roi roi_setup(const float *roi, float scale, int P, int S) {
   Roi r;
   r.batch = (int)roi[0];
@@ -32,106 +66,456 @@ __device__ __forceinline__ Roi roi_setup(const float *roi, float scale, int P, i
   return r;
 }
 
-struct Bin {
-  int n, ctop, ph, pw, part_h, part_w, class_id, c;
-  long long tix, tiy;
-  float wstart, hstart;
-  Roi r;
+// one bilinear sample: corner columns / rows and fractions; xa < 0: outside the map (the reference's `continue`)
+struct __attribute__((aligned(16))) Rec {
+  short xa, xb, ya, yb;
+  float fx, fy;
 };
 
-__device__ __forceinline__ Bin bin_setup(const kgdet_psroi_shape &s, long long idx, const float *rois,
-                                         const float *trans) {
-  Bin b;
-  const int P = s.pooled_size;
-  b.pw = (int)(idx % P);
-  b.ph = (int)((idx / P) % P);
-  b.ctop = (int)((idx / P / P) % s.out_dim);
-  b.n = (int)(idx / P / P / s.out_dim);
-  b.r = roi_setup(rois + 5 * b.n, s.spatial_scale, P, s.sample_per_part);
-  b.part_h = (int)floorf((float)(b.ph) / P * s.part_size);
-  b.part_w = (int)floorf((float)(b.pw) / P * s.part_size);
-  const int ch_each_class = s.no_trans ? s.out_dim : s.out_dim / s.num_classes;
-  b.class_id = b.ctop / ch_each_class;
-  b.tix = (((long long)(b.n * s.num_classes + b.class_id) * 2) * s.part_size + b.part_h) * s.part_size + b.part_w;
-  b.tiy = (((long long)(b.n * s.num_classes + b.class_id) * 2 + 1) * s.part_size + b.part_h) * s.part_size + b.part_w;
-  const float tx = s.no_trans ? 0.0f : trans[b.tix] * s.trans_std;
-  const float ty = s.no_trans ? 0.0f : trans[b.tiy] * s.trans_std;
-  b.wstart = (float)(b.pw) * b.r.bin_w + b.r.w0;
-  b.wstart += tx * b.r.rw;
-  b.hstart = (float)(b.ph) * b.r.bin_h + b.r.h0;
-  b.hstart += ty * b.r.rh;
-  int gw = (int)floorf((float)(b.pw) * s.group_size / P);
-  int gh = (int)floorf((float)(b.ph) * s.group_size / P);
-  gw = min(max(gw, 0), s.group_size - 1);
-  gh = min(max(gh, 0), s.group_size - 1);
-  b.c = (b.ctop * s.group_size + gh) * s.group_size + gw;
-  return b;
+__device__ __forceinline__ int group_cell(int p, int G, int P) {   // :101-106
+  const int g = (int)floorf((float)(p)*G / P);
+  return min(max(g, 0), G - 1);
+}
+
+__device__ __forceinline__ long long trans_index(const kgdet_psroi_shape &s, int n, int cls, int dir, int ph, int pw) {
+  const int part_h = (int)floorf((float)(ph) / s.pooled_size * s.part_size);
+  const int part_w = (int)floorf((float)(pw) / s.pooled_size * s.part_size);
+  return (((long long)(n * s.num_classes + cls) * 2 + dir) * s.part_size + part_h) * s.part_size + part_w;
+}
+
+// sample (ih, iw) of bin (ph, pw) of RoI r under the offsets of class `cls` (:99-134)
+__device__ __forceinline__ Rec make_record(const kgdet_psroi_shape &s, const Roi &r, int n, int cls, int ph, int pw,
+                                           int ih, int iw, const float *__restrict__ trans) {
+  const float tx = s.no_trans ? 0.0f : trans[trans_index(s, n, cls, 0, ph, pw)] * s.trans_std;
+  const float ty = s.no_trans ? 0.0f : trans[trans_index(s, n, cls, 1, ph, pw)] * s.trans_std;
+  float wstart = (float)(pw)*r.bin_w + r.w0;
+  wstart += tx * r.rw;
+  float hstart = (float)(ph)*r.bin_h + r.h0;
+  hstart += ty * r.rh;
+  float w = wstart + iw * r.sub_w;
+  float h = hstart + ih * r.sub_h;
+  Rec q;
+  if (w < -0.5 || w > s.W - 0.5 || h < -0.5 || h > s.H - 0.5) {
+    q.xa = q.xb = q.ya = q.yb = -1;
+    q.fx = q.fy = 0.f;
+    return q;
+  }
+  w = (float)fmin(fmax((double)w, 0.), s.W - 1.);
+  h = (float)fmin(fmax((double)h, 0.), s.H - 1.);
+  const int xa = (int)floorf(w), xb = (int)ceilf(w), ya = (int)floorf(h), yb = (int)ceilf(h);
+  q.xa = (short)xa; q.xb = (short)xb; q.ya = (short)ya; q.yb = (short)yb;
+  q.fx = w - xa;
+  q.fy = h - ya;
+  return q;
+}
+
+__device__ __forceinline__ Rec lds_record(const Rec *recs, int i) {
+  const int4 v = *reinterpret_cast<const int4 *>(recs + i);      // one ds_read_b128
+  Rec q;
+  q.xa = (short)(v.x & 0xffff); q.xb = (short)(v.x >> 16);
+  q.ya = (short)(v.y & 0xffff); q.yb = (short)(v.y >> 16);
+  q.fx = __int_as_float(v.z); q.fy = __int_as_float(v.w);
+  return q;
 }
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void psroi_forward(const kgdet_psroi_shape s, const float *__restrict__ data,
-                                                     const float *__restrict__ rois, const float *__restrict__ trans,
-                                                     float *__restrict__ out, float *__restrict__ count) {
-  const long long total = (long long)s.R * s.out_dim * s.pooled_size * s.pooled_size;
-  for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    const Bin b = bin_setup(s, idx, rois, trans);
-    const float *plane = data + ((long long)b.r.batch * s.C + b.c) * s.H * s.W;
-    float sum = 0.f;
-    int cnt = 0;
-    for (int ih = 0; ih < s.sample_per_part; ++ih)
-      for (int iw = 0; iw < s.sample_per_part; ++iw) {
-        float w = b.wstart + iw * b.r.sub_w;
-        float h = b.hstart + ih * b.r.sub_h;
-        if (w < -0.5 || w > s.W - 0.5 || h < -0.5 || h > s.H - 0.5) continue;
-        w = (float)fmin(fmax((double)w, 0.), s.W - 1.);
-        h = (float)fmin(fmax((double)h, 0.), s.H - 1.);
-        const int xa = (int)floorf(w), xb = (int)ceilf(w), ya = (int)floorf(h), yb = (int)ceilf(h);
-        const float fx = w - xa, fy = h - ya;
-        const float v = (1 - fx) * (1 - fy) * plane[ya * s.W + xa] + (1 - fx) * fy * plane[yb * s.W + xa] +
-                        fx * (1 - fy) * plane[ya * s.W + xb] + fx * fy * plane[yb * s.W + xb];
-        sum += v;
-        cnt++;
-      }
-    out[idx] = cnt == 0 ? 0.0f : sum / cnt;
-    count[idx] = (float)cnt;
+// data [B, C, H, W] -> dataT[b][k][pixel][ctop] with input channel c = ctop * G*G + k (k = group cell): lanes = output
+// channels become contiguous.  Block = (64 pixels, 64 output channels, b * G*G + k); 64 x 65 LDS tile.
+__global__ __launch_bounds__(kThreads) void psroi_to_cell_major(const kgdet_psroi_shape s, const float *__restrict__ data,
+                                                                float *__restrict__ dataT) {
+  __shared__ float tile[64 * 65];
+  const int GG = s.group_size * s.group_size, HW = s.H * s.W;
+  const int b = blockIdx.z / GG, k = blockIdx.z - b * GG;
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tid = threadIdx.x;
+  for (int e = tid; e < 64 * 64; e += kThreads) {
+    const int c = e >> 6, p = e & 63;
+    float v = 0.f;
+    if (c0 + c < s.out_dim && p0 + p < HW) v = data[((long long)b * s.C + (long long)(c0 + c) * GG + k) * HW + p0 + p];
+    tile[c * 65 + p] = v;
+  }
+  __syncthreads();
+  for (int e = tid; e < 64 * 64; e += kThreads) {
+    const int p = e >> 6, c = e & 63;
+    if (c0 + c < s.out_dim && p0 + p < HW)
+      dataT[(((long long)b * GG + k) * HW + p0 + p) * s.out_dim + c0 + c] = tile[c * 65 + p];
   }
 }
 
-__global__ __launch_bounds__(256) void psroi_backward(const kgdet_psroi_shape s, const float *__restrict__ grad_out,
-                                                      const float *__restrict__ count, const float *__restrict__ data,
-                                                      const float *__restrict__ rois, const float *__restrict__ trans,
-                                                      float *__restrict__ grad_data, float *__restrict__ grad_trans) {
-  const long long total = (long long)s.R * s.out_dim * s.pooled_size * s.pooled_size;
-  for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    if (count[idx] <= 0) continue;
-    const Bin b = bin_setup(s, idx, rois, trans);
-    const float diff = grad_out[idx] / count[idx];
-    const float *plane = data + ((long long)b.r.batch * s.C + b.c) * s.H * s.W;
-    float *gplane = grad_data + ((long long)b.r.batch * s.C + b.c) * s.H * s.W;
-    for (int ih = 0; ih < s.sample_per_part; ++ih)
-      for (int iw = 0; iw < s.sample_per_part; ++iw) {
-        float w = b.wstart + iw * b.r.sub_w;
-        float h = b.hstart + ih * b.r.sub_h;
-        if (w < -0.5 || w > s.W - 0.5 || h < -0.5 || h > s.H - 0.5) continue;
-        w = (float)fmin(fmax((double)w, 0.), s.W - 1.);
-        h = (float)fmin(fmax((double)h, 0.), s.H - 1.);
-        const int xa = (int)floorf(w), xb = (int)ceilf(w), ya = (int)floorf(h), yb = (int)ceilf(h);
-        const float fx = w - xa, fy = h - ya;
-        atomicAdd(gplane + ya * s.W + xa, (1 - fx) * (1 - fy) * diff);
-        atomicAdd(gplane + yb * s.W + xa, (1 - fx) * fy * diff);
-        atomicAdd(gplane + ya * s.W + xb, fx * (1 - fy) * diff);
-        atomicAdd(gplane + yb * s.W + xb, fx * fy * diff);
-        if (s.no_trans) continue;
-        const float U00 = plane[ya * s.W + xa], U01 = plane[yb * s.W + xa];
-        const float U10 = plane[ya * s.W + xb], U11 = plane[yb * s.W + xb];
-        float dx = (U11 * fy + U10 * (1 - fy) - U01 * fy - U00 * (1 - fy)) * s.trans_std * diff;
-        dx *= b.r.rw;
-        float dy = (U11 * fx + U01 * (1 - fx) - U10 * fx - U00 * (1 - fx)) * s.trans_std * diff;
-        dy *= b.r.rh;
-        atomicAdd(grad_trans + b.tix, dx);
-        atomicAdd(grad_trans + b.tiy, dy);
+// MODE 0: out / count; block = (RoI, offset class, chunk of 64 output channels).
+// MODE 1: grad_trans; block = (RoI, offset class), all channels of the class, diffT = grad_out / count as [RoI][bin][ctop].
+// Record of the gather kernels: element offsets of the four corners inside one (image, cell) plane of dataT (o00 < 0: the
+// sample lies outside the map) and, MODE 0, the four bilinear weights / MODE 1, the two fractions.  Wave-uniform: read by
+// every lane as an LDS broadcast, moved to SGPRs, so that a corner load is `global_load v, v_lane_offset, s[base + o]`
+// with no vector address arithmetic.
+struct __attribute__((aligned(16))) GRec {
+  int o00, o01, o10, o11;       // (ya, xa), (yb, xa), (ya, xb), (yb, xb)
+  float a, b, c, d;             // MODE 0: w00, w01, w10, w11;  MODE 1: fx, fy, -, -
+};
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void psroi_gather(const kgdet_psroi_shape s, const float *__restrict__ dataT,
+                                                         const float *__restrict__ rois, const float *__restrict__ trans,
+                                                         float *__restrict__ out, float *__restrict__ count,
+                                                         const float *__restrict__ diffT, float *__restrict__ grad_trans,
+                                                         int classes, int ch_per_class, int chunks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int P = s.pooled_size, S = s.sample_per_part, G = s.group_size;
+  const int PP = P * P, SS = S * S, GG = G * G, nrec = PP * SS;
+  GRec *recs = reinterpret_cast<GRec *>(smem);
+  int *bin_cnt = reinterpret_cast<int *>(recs + nrec);
+  float *stage = reinterpret_cast<float *>(bin_cnt + PP);           // MODE 0: [64][PP] results; MODE 1: [2][PP] bin sums
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int blk = blockIdx.x;
+  const int chunk = blk % chunks; blk /= chunks;
+  const int cls = blk % classes;
+  const int n = blk / classes;
+  const Roi r = roi_setup(rois + 5 * n, s.spatial_scale, P, S);
+  const bool roi_ok = r.batch >= 0 && r.batch < s.B;
+  const int HW = s.H * s.W;
+
+  for (int b = tid; b < PP; b += kThreads) bin_cnt[b] = 0;
+  __syncthreads();
+  for (int i = tid; i < nrec; i += kThreads) {
+    const int bin = i / SS, si = i - bin * SS;
+    const int ph = bin / P, pw = bin - ph * P;
+    const int ih = si / S, iw = si - ih * S;
+    const Rec q = make_record(s, r, n, cls, ph, pw, ih, iw, trans);
+    GRec g;
+    if (q.xa < 0 || !roi_ok) {
+      g.o00 = -1; g.o01 = g.o10 = g.o11 = 0;
+      g.a = g.b = g.c = g.d = 0.f;
+    } else {
+      g.o00 = (q.ya * s.W + q.xa) * s.out_dim; g.o01 = (q.yb * s.W + q.xa) * s.out_dim;
+      g.o10 = (q.ya * s.W + q.xb) * s.out_dim; g.o11 = (q.yb * s.W + q.xb) * s.out_dim;
+      if (MODE == 0) {
+        g.a = (1 - q.fx) * (1 - q.fy); g.b = (1 - q.fx) * q.fy; g.c = q.fx * (1 - q.fy); g.d = q.fx * q.fy;
+      } else {
+        g.a = q.fx; g.b = q.fy; g.c = g.d = 0.f;
       }
+      atomicAdd(bin_cnt + bin, 1);
+    }
+    recs[i] = g;
+  }
+  __syncthreads();
+  const float *img = dataT + (long long)(roi_ok ? r.batch : 0) * GG * HW * s.out_dim;
+  auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+  auto unif = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+
+  if (MODE == 0) {
+    const int c0 = cls * ch_per_class + chunk * 64;
+    const int nch = min(64, (cls + 1) * ch_per_class - c0);
+    const int ctop = c0 + min(lane, nch - 1);                 // (idle lanes repeat the last channel: no divergent loads)
+    for (int bin = wave; bin < PP; bin += kThreads / 64) {
+      const int ph = bin / P, pw = bin - ph * P;
+      const int k = group_cell(ph, G, P) * G + group_cell(pw, G, P);
+      const int voff = k * HW * s.out_dim + ctop;             // the lane's part of every corner address of this bin
+      float sum = 0.f;
+      // four samples per round: their sixteen corner loads are issued together (branch-free: a sample outside the map
+      // reads element 0 and is dropped by a select), then summed in sample order
+      for (int si0 = 0; si0 < SS; si0 += 4) {
+        float u00[4], u01[4], u10[4], u11[4], wa[4], wb[4], wc[4], wd[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int4 qo = *reinterpret_cast<const int4 *>(recs + bin * SS + min(si0 + u, SS - 1));
+          const float4 qw = *(reinterpret_cast<const float4 *>(recs + bin * SS + min(si0 + u, SS - 1)) + 1);
+          const int o00 = uni(qo.x);
+          ok[u] = si0 + u < SS && o00 >= 0;
+          u00[u] = (img + max(o00, 0))[voff]; u01[u] = (img + uni(qo.y))[voff];
+          u10[u] = (img + uni(qo.z))[voff];   u11[u] = (img + uni(qo.w))[voff];
+          wa[u] = unif(qw.x); wb[u] = unif(qw.y); wc[u] = unif(qw.z); wd[u] = unif(qw.w);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float v = wa[u] * u00[u] + wb[u] * u01[u] + wc[u] * u10[u] + wd[u] * u11[u];   // :37-49
+          sum = ok[u] ? sum + v : sum;
+        }
+      }
+      const int cnt = bin_cnt[bin];
+      if (lane < nch) stage[lane * PP + bin] = cnt == 0 ? 0.0f : sum / cnt;
+    }
+    __syncthreads();
+    const long long base = ((long long)n * s.out_dim + c0) * PP;
+    for (int e = tid; e < nch * PP; e += kThreads) {
+      out[base + e] = stage[e];
+      count[base + e] = (float)bin_cnt[e % PP];
+    }
+  } else {
+    const int c_begin = cls * ch_per_class;
+    for (int bin = wave; bin < PP; bin += kThreads / 64) {
+      const int ph = bin / P, pw = bin - ph * P;
+      const int k = group_cell(ph, G, P) * G + group_cell(pw, G, P);
+      float dx = 0.f, dy = 0.f;
+      if (bin_cnt[bin] > 0) {
+        for (int cc = 0; cc < ch_per_class; cc += 64) {
+          const bool on = cc + lane < ch_per_class;
+          const int ctop = c_begin + min(cc + lane, ch_per_class - 1);
+          const int voff = k * HW * s.out_dim + ctop;
+          const float diff = on ? diffT[((long long)n * PP + bin) * s.out_dim + ctop] : 0.f;
+          for (int si0 = 0; si0 < SS; si0 += 4) {
+            float u00[4], u01[4], u10[4], u11[4], fxs[4], fys[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int4 qo = *reinterpret_cast<const int4 *>(recs + bin * SS + min(si0 + u, SS - 1));
+              const float4 qw = *(reinterpret_cast<const float4 *>(recs + bin * SS + min(si0 + u, SS - 1)) + 1);
+              const int o00 = uni(qo.x);
+              ok[u] = si0 + u < SS && o00 >= 0;
+              u00[u] = (img + max(o00, 0))[voff]; u01[u] = (img + uni(qo.y))[voff];
+              u10[u] = (img + uni(qo.z))[voff];   u11[u] = (img + uni(qo.w))[voff];
+              fxs[u] = unif(qw.x); fys[u] = unif(qw.y);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const float fx = fxs[u], fy = fys[u];
+              float ddx = (u11[u] * fy + u10[u] * (1 - fy) - u01[u] * fy - u00[u] * (1 - fy)) * s.trans_std * diff;   // :253-258
+              ddx *= r.rw;
+              float ddy = (u11[u] * fx + u01[u] * (1 - fx) - u10[u] * fx - u00[u] * (1 - fx)) * s.trans_std * diff;
+              ddy *= r.rh;
+              dx = ok[u] ? dx + ddx : dx;
+              dy = ok[u] ? dy + ddy : dy;
+            }
+          }
+        }
+      }
+      // fixed-order butterfly over the 64 lanes
+      for (int m = 32; m >= 1; m >>= 1) {
+        dx += __shfl_xor(dx, m);
+        dy += __shfl_xor(dy, m);
+      }
+      if (lane == 0) { stage[bin] = dx; stage[PP + bin] = dy; }
+    }
+    __syncthreads();
+    // bins of one offset cell, row-major, into grad_trans[n, cls, dir, part_h, part_w]: every entry written once
+    const int part = s.part_size;
+    for (int e = tid; e < 2 * part * part; e += kThreads) {
+      const int dir = e / (part * part), cell = e - dir * part * part;
+      const int qh = cell / part, qw = cell - qh * part;
+      float a = 0.f;
+      for (int ph = 0; ph < P; ++ph) {
+        if ((int)floorf((float)(ph) / P * part) != qh) continue;
+        for (int pw = 0; pw < P; ++pw)
+          if ((int)floorf((float)(pw) / P * part) == qw) a += stage[dir * PP + ph * P + pw];
+      }
+      grad_trans[(((long long)(n * s.num_classes + cls) * 2 + dir) * part + qh) * part + qw] = a;
+    }
+  }
+}
+
+// Backward preparation.  Block = RoI: (1) the sample records of every offset class, recs[n][class][bin][sample], and
+// the bounding box of every valid sample corner over all classes (bbox[n] = {xmin, xmax, ymin, ymax}; xmax < 0: the
+// RoI touches nothing), (2) diffT[n][bin][ctop] = grad_out / count (0 where count <= 0), transposed through LDS so that
+// both sides are coalesced.
+__global__ __launch_bounds__(kThreads) void psroi_prepare(const kgdet_psroi_shape s, const float *__restrict__ rois,
+                                                          const float *__restrict__ trans,
+                                                          const float *__restrict__ grad_out,
+                                                          const float *__restrict__ count, int4 *__restrict__ bbox,
+                                                          float *__restrict__ diffT, Rec *__restrict__ recs_out,
+                                                          int classes) {
+  __shared__ int bb[4];
+  __shared__ float tile[64 * 65];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int P = s.pooled_size, S = s.sample_per_part, PP = P * P, SS = S * S;
+  const Roi r = roi_setup(rois + 5 * n, s.spatial_scale, P, S);
+  if (tid == 0) { bb[0] = INT_MAX; bb[1] = -1; bb[2] = INT_MAX; bb[3] = -1; }
+  __syncthreads();
+  if (r.batch >= 0 && r.batch < s.B) {      // (other RoIs are never visited: their records stay unwritten)
+    int xmin = INT_MAX, xmax = -1, ymin = INT_MAX, ymax = -1;
+    for (int i = tid; i < classes * PP * SS; i += kThreads) {
+      const int cls = i / (PP * SS), j = i - cls * PP * SS;
+      const int bin = j / SS, si = j - bin * SS;
+      const int ph = bin / P, pw = bin - ph * P, ih = si / S, iw = si - ih * S;
+      const Rec q = make_record(s, r, n, cls, ph, pw, ih, iw, trans);
+      recs_out[(long long)n * classes * PP * SS + i] = q;
+      if (q.xa < 0) continue;
+      xmin = min(xmin, (int)q.xa); xmax = max(xmax, (int)q.xb);
+      ymin = min(ymin, (int)q.ya); ymax = max(ymax, (int)q.yb);
+    }
+    if (xmax >= 0) {
+      atomicMin(bb + 0, xmin); atomicMax(bb + 1, xmax); atomicMin(bb + 2, ymin); atomicMax(bb + 3, ymax);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) bbox[n] = make_int4(bb[0], bb[1], bb[2], bb[3]);
+  // transpose [out_dim][PP] -> [PP][out_dim] in 64 x 64 tiles
+  const long long base = (long long)n * s.out_dim * PP;
+  for (int c0 = 0; c0 < s.out_dim; c0 += 64)
+    for (int b0 = 0; b0 < PP; b0 += 64) {
+      __syncthreads();
+      for (int e = tid; e < 64 * 64; e += kThreads) {
+        const int c = e >> 6, b = e & 63;
+        float v = 0.f;
+        if (c0 + c < s.out_dim && b0 + b < PP) {
+          const long long idx = base + (long long)(c0 + c) * PP + b0 + b;
+          const float cn = count[idx];
+          v = cn > 0.f ? grad_out[idx] / cn : 0.f;
+        }
+        tile[c * 65 + b] = v;
+      }
+      __syncthreads();
+      for (int e = tid; e < 64 * 64; e += kThreads) {
+        const int b = e >> 6, c = e & 63;
+        if (c0 + c < s.out_dim && b0 + b < PP) diffT[base + (long long)(b0 + b) * s.out_dim + c0 + c] = tile[c * 65 + b];
+      }
+    }
+}
+
+// grad_data as a gather by output tile; block = (tile, 256-channel chunk, image); thread = input channel.
+// Phase 0: the ordered list of the RoIs of this image whose bounding box meets the tile (ballot compaction, ascending).
+// Per visit (RoI of the list x offset class of this channel chunk): the prepared records come from the workspace into
+// registers ONE VISIT AHEAD, are filtered against the tile into LDS, and every thread walks the bins of its group cell
+// that have a sample in the tile -- the bins' grad_out / count quotients are fetched eight bins at a time (coalesced
+// over channels) before they are used.
+__global__ __launch_bounds__(kThreads) void psroi_grad_data(const kgdet_psroi_shape s, const float *__restrict__ rois,
+                                                            const int4 *__restrict__ bbox,
+                                                            const Rec *__restrict__ recs_in,
+                                                            const float *__restrict__ diffT,
+                                                            float *__restrict__ grad_data, int classes,
+                                                            int ch_per_class, int tiles_x, int list_cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int P = s.pooled_size, S = s.sample_per_part, G = s.group_size;
+  const int PP = P * P, SS = S * S, GG = G * G, nrec = PP * SS;
+  Rec *recs = reinterpret_cast<Rec *>(smem);
+  float *acc = reinterpret_cast<float *>(recs + nrec);              // [kTilePix][kAccStride]
+  int *list = reinterpret_cast<int *>(acc + kTilePix * kAccStride); // [list_cap]
+  __shared__ unsigned long long bin_hit[4];                         // PP <= 256 bins
+  __shared__ int wave_cnt[kThreads / 64];
+  __shared__ int list_len;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x, b = blockIdx.z;
+  const int ty0 = (tile / tiles_x) * kTileH, tx0 = (tile % tiles_x) * kTileW;
+  const int ty1 = min(ty0 + kTileH, s.H) - 1, tx1 = min(tx0 + kTileW, s.W) - 1;
+  const int c_first = blockIdx.y * kThreads;
+  const int c = c_first + tid;
+  const bool active = c < s.out_dim * GG && c < s.C;
+  const int ctop = active ? c / GG : 0;
+  const int k = active ? c - ctop * GG : 0;
+  const int gh = k / G, gw = k - gh * G;
+  const int my_cls = ctop / ch_per_class;
+  // this channel's bins: the contiguous row / column ranges that map to its group cell
+  int ph_lo = P, ph_hi = 0, pw_lo = P, pw_hi = 0;
+  for (int p = 0; p < P; ++p) {
+    if (group_cell(p, G, P) == gh) { ph_lo = min(ph_lo, p); ph_hi = max(ph_hi, p + 1); }
+    if (group_cell(p, G, P) == gw) { pw_lo = min(pw_lo, p); pw_hi = max(pw_hi, p + 1); }
+  }
+  const int nw = max(pw_hi - pw_lo, 0), my_bins = active ? max(ph_hi - ph_lo, 0) * nw : 0;
+  const int last_ch = min(min(c_first + kThreads, s.out_dim * GG), s.C) - 1;
+  const int cls_lo = last_ch >= c_first ? (c_first / GG) / ch_per_class : 1;
+  const int cls_hi = last_ch >= c_first ? (last_ch / GG) / ch_per_class : 0;
+  const int ncls = max(cls_hi - cls_lo + 1, 0);
+  constexpr int kRecRegs = kMaxRecords / kThreads;                  // records of one visit held per thread
+
+  for (int e = tid; e < kTilePix * kAccStride; e += kThreads) acc[e] = 0.f;
+  float *col = acc + tid;
+
+  for (int seg = 0; seg < s.R && ncls > 0; seg += list_cap) {
+    // ---- phase 0: RoIs [seg, seg + list_cap) of image b that meet the tile, ascending
+    __syncthreads();
+    if (tid == 0) list_len = 0;
+    for (int base = seg; base < min(seg + list_cap, s.R); base += kThreads) {
+      const int n = base + tid;
+      bool hit = false;
+      if (n < s.R && n < seg + list_cap && (int)rois[5 * n] == b) {
+        const int4 bx = bbox[n];
+        hit = !(bx.y < tx0 || bx.x > tx1 || bx.w < ty0 || bx.z > ty1);
+      }
+      const unsigned long long m = __ballot(hit);
+      if (lane == 0) wave_cnt[wave] = __popcll(m);
+      __syncthreads();
+      int off = list_len;
+      for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+      if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = n;
+      __syncthreads();
+      if (tid == 0) list_len += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    }
+    __syncthreads();
+    const int visits = list_len * ncls;
+
+    int4 pre[kRecRegs];
+    auto fetch = [&](int v) {      // records of visit v -> registers (clamped addresses: always the same number of loads)
+      const int n = list[min(v, visits - 1) / ncls], cls = cls_lo + min(v, visits - 1) % ncls;
+      const int4 *src = reinterpret_cast<const int4 *>(recs_in + ((long long)n * classes + cls) * nrec);
+#pragma unroll
+      for (int j = 0; j < kRecRegs; ++j)
+        if (j * kThreads < nrec) pre[j] = src[min(tid + j * kThreads, nrec - 1)];
+    };
+    if (visits > 0) fetch(0);
+    for (int v = 0; v < visits; ++v) {
+      const int n = list[v / ncls], cls = cls_lo + v % ncls;
+      __syncthreads();                                       // the previous visit's records have been read by everybody
+      if (tid < 4) bin_hit[tid] = 0ull;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < kRecRegs; ++j) {
+        const int i = tid + j * kThreads;
+        if (j * kThreads < nrec && i < nrec) {
+          int4 q = pre[j];
+          const int xa = (short)(q.x & 0xffff), xb = (short)(q.x >> 16), ya = (short)(q.y & 0xffff), yb = (short)(q.y >> 16);
+          const bool in = xa >= 0 && !(xb < tx0 || xa > tx1 || yb < ty0 || ya > ty1);     // a corner in the tile
+          if (!in) q.x = -1;
+          *reinterpret_cast<int4 *>(recs + i) = q;
+          if (in) atomicOr(bin_hit + ((i / SS) >> 6), 1ull << ((i / SS) & 63));
+        }
+      }
+      __syncthreads();
+      fetch(v + 1);                                           // in flight while this visit is accumulated
+      if (my_cls != cls) continue;
+      for (int j0 = 0; j0 < my_bins; j0 += kBinBatch) {
+        // up to kBinBatch bins of this channel's cell per round: first which of them have a sample in the tile, then ALL their
+        // quotients (one coalesced load per bin and wave, all in flight together), then the adds in bin order
+        float dq[kBinBatch];
+        unsigned long long mine = 0ull;
+#pragma unroll
+        for (int u = 0; u < kBinBatch; ++u) {
+          const int j = min(j0 + u, my_bins - 1);
+          const int bin = (ph_lo + j / nw) * P + pw_lo + j % nw;
+          if (j0 + u < my_bins && ((bin_hit[bin >> 6] >> (bin & 63)) & 1ull)) mine |= 1ull << u;
+        }
+        if (mine == 0ull) continue;
+#pragma unroll
+        for (int u = 0; u < kBinBatch; ++u) {
+          const int j = min(j0 + u, my_bins - 1);
+          const int bin = (ph_lo + j / nw) * P + pw_lo + j % nw;
+          dq[u] = 0.f;
+          if ((mine >> u) & 1ull) dq[u] = diffT[((long long)n * PP + bin) * s.out_dim + ctop];
+        }
+#pragma unroll
+        for (int u = 0; u < kBinBatch; ++u) {
+          if (!((mine >> u) & 1ull)) continue;
+          const int j = j0 + u;
+          const int bin = (ph_lo + j / nw) * P + pw_lo + j % nw;
+          const float diff = dq[u];
+          for (int si = 0; si < SS; ++si) {
+            const Rec q = lds_record(recs, bin * SS + si);
+            if (q.xa < 0) continue;
+            const float fx = q.fx, fy = q.fy;
+            const bool xa_in = q.xa >= tx0 && q.xa <= tx1, xb_in = q.xb >= tx0 && q.xb <= tx1;
+            const bool ya_in = q.ya >= ty0 && q.ya <= ty1, yb_in = q.yb >= ty0 && q.yb <= ty1;
+            const int oa = (q.ya - ty0) * kTileW, ob = (q.yb - ty0) * kTileW;
+            const int pa = q.xa - tx0, pb = q.xb - tx0;
+            // the reference's four atomicAdds (:236-245), same order, same expressions
+            // (plain read-add-write: ds_add_f32 was measured 1.7x slower here -- LDS float atomics run at a fraction of the
+            //  read / write rate)
+            if (ya_in && xa_in) col[(oa + pa) * kAccStride] += (1 - fx) * (1 - fy) * diff;
+            if (yb_in && xa_in) col[(ob + pa) * kAccStride] += (1 - fx) * fy * diff;
+            if (ya_in && xb_in) col[(oa + pb) * kAccStride] += fx * (1 - fy) * diff;
+            if (yb_in && xb_in) col[(ob + pb) * kAccStride] += fx * fy * diff;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // write the tile: every element of grad_data[b, c_first .. c_first + 255] inside the tile, used channel or not
+  const int tw = tx1 - tx0 + 1, th = ty1 - ty0 + 1;
+  for (int e = tid; e < kThreads * kTilePix; e += kThreads) {
+    const int ch = e / kTilePix, p = e - ch * kTilePix;
+    const int y = p / kTileW, x = p - y * kTileW;
+    if (c_first + ch >= s.C || y >= th || x >= tw) continue;
+    grad_data[(((long long)b * s.C + c_first + ch) * s.H + ty0 + y) * s.W + tx0 + x] = acc[p * kAccStride + ch];
   }
 }
 
@@ -151,35 +535,133 @@ static int psroi_check(const kgdet_psroi_shape *s) {
   KGDET_CHECK_SHAPE(s->out_dim * s->group_size * s->group_size <= s->C,
                     "input has %d channels, position-sensitive pooling needs %d", s->C,
                     s->out_dim * s->group_size * s->group_size);
+  KGDET_CHECK_SHAPE(s->pooled_size * s->pooled_size * s->sample_per_part * s->sample_per_part <= kMaxRecords &&
+                        s->group_size <= kMaxGroup && s->pooled_size * s->pooled_size <= 256,
+                    "pooled_size^2 * sample_per_part^2 must be <= %d, pooled_size <= 16 and group_size <= %d (LDS record "
+                    "table of the gfx950 kernels)", kMaxRecords, kMaxGroup);
+  KGDET_CHECK_SHAPE(s->H < 32768 && s->W < 32768, "feature map beyond 32767 pixels per side");
+  KGDET_CHECK_SHAPE((long long)s->group_size * s->group_size * s->H * s->W * s->out_dim < (1ll << 30),
+                    "one image of the cell-major map beyond 2^30 elements (32-bit corner offsets)");
   return KGDET_OK;
 }
 
+namespace {
+size_t cell_major_bytes(const kgdet_psroi_shape *s) {
+  return align_up((size_t)s->B * s->group_size * s->group_size * s->H * s->W * s->out_dim * sizeof(float), 256);
+}
+size_t gather_lds(const kgdet_psroi_shape *s, int mode) {
+  const size_t PP = (size_t)s->pooled_size * s->pooled_size, SS = (size_t)s->sample_per_part * s->sample_per_part;
+  return PP * SS * sizeof(GRec) + PP * 4 + (mode == 0 ? 64 : 2) * PP * 4;
+}
+int launch_cell_major(const kgdet_psroi_shape *s, const float *data, float *dataT, hipStream_t stream) {
+  const int GG = s->group_size * s->group_size;
+  KGDET_CHECK_SHAPE((long long)s->B * GG <= 65535, "batch x group cells beyond the launch grid");
+  hipLaunchKernelGGL(psroi_to_cell_major, dim3(ceil_div(s->H * s->W, 64), ceil_div(s->out_dim, 64), s->B * GG),
+                     dim3(kThreads), 0, stream, *s, data, dataT);
+  KGDET_CHECK_LAUNCH("psroi_to_cell_major");
+  return KGDET_OK;
+}
+}  // namespace
+
+size_t kgdet_deform_psroi_forward_workspace_bytes(const kgdet_psroi_shape *s) {
+  return s == nullptr ? 0 : cell_major_bytes(s) + 256;
+}
+
 int kgdet_deform_psroi_forward(const kgdet_psroi_shape *s, const float *data, const float *rois, const float *trans,
-                               float *out, float *count, void *stream) {
+                               float *out, float *count, void *workspace, size_t workspace_bytes, void *stream) {
   if (int rc = psroi_check(s)) return rc;
   const long long total = (long long)s->R * s->out_dim * s->pooled_size * s->pooled_size;
   if (total == 0) return KGDET_OK;
   KGDET_CHECK_SHAPE(data && rois && out && count && (s->no_trans || trans), "null pointer");
-  int grid = (int)((total + 255) / 256);
-  if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(psroi_forward, dim3(grid), dim3(256), 0, (hipStream_t)stream, *s, data, rois, trans, out, count);
-  KGDET_CHECK_LAUNCH("psroi_forward");
+  const size_t need = kgdet_deform_psroi_forward_workspace_bytes(s);
+  if (workspace == nullptr || workspace_bytes < need) {
+    set_error("deform_psroi_forward: needs %zu bytes of workspace (kgdet_deform_psroi_forward_workspace_bytes), got %zu",
+              need, workspace_bytes);
+    return KGDET_E_WORKSPACE;
+  }
+  float *dataT = reinterpret_cast<float *>(workspace);
+  if (int rc = launch_cell_major(s, data, dataT, (hipStream_t)stream)) return rc;
+  const int classes = s->no_trans ? 1 : s->num_classes;
+  const int ch_per_class = s->out_dim / classes, chunks = ceil_div(ch_per_class, 64);
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)psroi_gather<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      150 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(psroi_gather<0>, dim3((unsigned)((long long)s->R * classes * chunks)), dim3(kThreads),
+                     gather_lds(s, 0), (hipStream_t)stream, *s, dataT, rois, trans, out, count, (const float *)nullptr,
+                     (float *)nullptr, classes, ch_per_class, chunks);
+  KGDET_CHECK_LAUNCH("psroi_gather<forward>");
   return KGDET_OK;
+}
+
+size_t kgdet_deform_psroi_backward_workspace_bytes(const kgdet_psroi_shape *s) {
+  if (s == nullptr) return 0;
+  const size_t R = (size_t)(s->R > 0 ? s->R : 0);
+  const size_t total = R * s->out_dim * s->pooled_size * s->pooled_size;
+  const size_t classes = s->no_trans ? 1 : (s->num_classes > 0 ? s->num_classes : 1);
+  const size_t nrec = (size_t)s->pooled_size * s->pooled_size * s->sample_per_part * s->sample_per_part;
+  return align_up(R * sizeof(int4), 256) + align_up(total * sizeof(float), 256) +
+         align_up(R * classes * nrec * sizeof(Rec), 256) + (s->no_trans ? 0 : cell_major_bytes(s)) + 256;
 }
 
 int kgdet_deform_psroi_backward(const kgdet_psroi_shape *s, const float *grad_out, const float *count,
                                 const float *data, const float *rois, const float *trans, float *grad_data,
-                                float *grad_trans, void *stream) {
+                                float *grad_trans, void *workspace, size_t workspace_bytes, void *stream) {
   if (int rc = psroi_check(s)) return rc;
+  KGDET_CHECK_SHAPE(grad_data != nullptr, "null pointer");
   const long long total = (long long)s->R * s->out_dim * s->pooled_size * s->pooled_size;
-  if (total == 0) return KGDET_OK;
-  KGDET_CHECK_SHAPE(grad_out && count && data && rois && grad_data && (s->no_trans || (trans && grad_trans)),
-                    "null pointer");
-  int grid = (int)((total + 255) / 256);
-  if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(psroi_backward, dim3(grid), dim3(256), 0, (hipStream_t)stream, *s, grad_out, count, data, rois,
-                     trans, grad_data, grad_trans);
-  KGDET_CHECK_LAUNCH("psroi_backward");
+  const size_t data_bytes = (size_t)s->B * s->C * s->H * s->W * sizeof(float);
+  if (data_bytes == 0) return KGDET_OK;
+  if (total == 0) {   // no RoI: the gradient is zero (the reference's zero-filled grad_input stays as it is)
+    KGDET_HIP_TRY(hipMemsetAsync(grad_data, 0, data_bytes, (hipStream_t)stream));
+    return KGDET_OK;
+  }
+  KGDET_CHECK_SHAPE(grad_out && count && data && rois && (s->no_trans || (trans && grad_trans)), "null pointer");
+  const size_t need = kgdet_deform_psroi_backward_workspace_bytes(s);
+  if (workspace == nullptr || workspace_bytes < need) {
+    set_error("deform_psroi_backward: needs %zu bytes of workspace (kgdet_deform_psroi_backward_workspace_bytes), got %zu",
+              need, workspace_bytes);
+    return KGDET_E_WORKSPACE;
+  }
+  const int classes = s->no_trans ? 1 : s->num_classes;
+  const int ch_per_class = s->out_dim / classes;
+  const size_t nrec = (size_t)s->pooled_size * s->pooled_size * s->sample_per_part * s->sample_per_part;
+  unsigned char *wsb = reinterpret_cast<unsigned char *>(workspace);
+  int4 *bbox = reinterpret_cast<int4 *>(wsb);
+  wsb += align_up((size_t)s->R * sizeof(int4), 256);
+  float *diffT = reinterpret_cast<float *>(wsb);
+  wsb += align_up((size_t)total * sizeof(float), 256);
+  Rec *recs_ws = reinterpret_cast<Rec *>(wsb);
+  wsb += align_up((size_t)s->R * classes * nrec * sizeof(Rec), 256);
+  float *dataT = reinterpret_cast<float *>(wsb);
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)psroi_gather<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      150 * 1024));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)psroi_grad_data, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      150 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(psroi_prepare, dim3(s->R), dim3(kThreads), 0, (hipStream_t)stream, *s, rois, trans, grad_out, count,
+                     bbox, diffT, recs_ws, classes);
+  KGDET_CHECK_LAUNCH("psroi_prepare");
+  const int tiles_x = ceil_div(s->W, kTileW), tiles_y = ceil_div(s->H, kTileH);
+  const int list_cap = s->R < kListCap ? s->R : kListCap;
+  const size_t lds = nrec * sizeof(Rec) + (size_t)kTilePix * kAccStride * sizeof(float) + (size_t)list_cap * sizeof(int);
+  KGDET_CHECK_SHAPE(s->B <= 65535 && ceil_div(s->C, kThreads) <= 65535, "batch / channel count beyond the launch grid");
+  hipLaunchKernelGGL(psroi_grad_data, dim3(tiles_x * tiles_y, ceil_div(s->C, kThreads), s->B), dim3(kThreads), lds,
+                     (hipStream_t)stream, *s, rois, bbox, recs_ws, diffT, grad_data, classes, ch_per_class, tiles_x,
+                     list_cap);
+  KGDET_CHECK_LAUNCH("psroi_grad_data");
+  if (!s->no_trans) {
+    if (int rc = launch_cell_major(s, data, dataT, (hipStream_t)stream)) return rc;
+    hipLaunchKernelGGL(psroi_gather<1>, dim3((unsigned)((long long)s->R * classes)), dim3(kThreads), gather_lds(s, 1),
+                       (hipStream_t)stream, *s, dataT, rois, trans, (float *)nullptr, (float *)nullptr, diffT, grad_trans,
+                       classes, ch_per_class, 1);
+    KGDET_CHECK_LAUNCH("psroi_gather<grad_trans>");
+  }
   return KGDET_OK;
 }
 

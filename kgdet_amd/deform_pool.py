@@ -1,6 +1,6 @@
 """Deformable PS-RoI pooling -- mirror of ``mmdet/ops/dcn/deform_pool.py``
 (DeformRoIPoolingFunction :9-69, DeformRoIPooling :75-103, DeformRoIPoolingPack :106-164,
-ModulatedDeformRoIPoolingPack :167-245) on the HIP kernels in csrc/psroi.hip.
+ModulatedDeformRoIPoolingPack :167-245) on the HIP kernels in csrc/psroi.hip (LDS-staged RoI windows, deterministic tile-gather backward).
 """
 import ctypes
 
@@ -55,9 +55,13 @@ class DeformRoIPoolingFunction(Function):
         output_count = data.new_empty(n, out_channels, out_size, out_size)
         shape = _shape(data, rois, offset, spatial_scale, out_size, out_channels, no_trans, group_size,
                        ctx.part_size, sample_per_part, trans_std)
-        _lib.check(_lib.lib().kgdet_deform_psroi_forward(
+        L = _lib.lib()
+        ws_bytes = L.kgdet_deform_psroi_forward_workspace_bytes(ctypes.byref(shape))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=data.device)     # the cell-major copy of the map
+        _lib.check(L.kgdet_deform_psroi_forward(
             ctypes.byref(shape), _lib.ptr(data), _lib.ptr(rois), None if no_trans else _lib.ptr(offset),
-            _lib.ptr(output), _lib.ptr(output_count), _lib.current_stream()), 'kgdet_deform_psroi_forward')
+            _lib.ptr(output), _lib.ptr(output_count), _lib.ptr(ws), ctypes.c_size_t(ws_bytes), _lib.current_stream()),
+            'kgdet_deform_psroi_forward')
         ctx.shape = shape
         ctx.save_for_backward(data, rois, offset)
         ctx.output_count = output_count
@@ -70,14 +74,19 @@ class DeformRoIPoolingFunction(Function):
             raise NotImplementedError
         data, rois, offset = ctx.saved_tensors
         grad_output = grad_output.contiguous().float()
-        grad_input = torch.zeros_like(data)
+        # both gradients are written in full by the kernels (a gather per output tile / one workgroup per
+        # (RoI, class): no atomics, so no zero-filled accumulators -- deform_pool.py:57-59 zero-fills for atomicAdd)
+        grad_input = torch.empty_like(data)
         grad_rois = None
-        grad_offset = torch.zeros_like(offset)
-        _lib.check(_lib.lib().kgdet_deform_psroi_backward(
+        grad_offset = torch.empty_like(offset)
+        L = _lib.lib()
+        ws_bytes = L.kgdet_deform_psroi_backward_workspace_bytes(ctypes.byref(ctx.shape))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=data.device)
+        _lib.check(L.kgdet_deform_psroi_backward(
             ctypes.byref(ctx.shape), _lib.ptr(grad_output), _lib.ptr(ctx.output_count), _lib.ptr(data),
             _lib.ptr(rois), None if ctx.no_trans else _lib.ptr(offset), _lib.ptr(grad_input),
-            None if ctx.no_trans else _lib.ptr(grad_offset), _lib.current_stream()),
-            'kgdet_deform_psroi_backward')
+            None if ctx.no_trans else _lib.ptr(grad_offset), _lib.ptr(ws), ctypes.c_size_t(ws_bytes),
+            _lib.current_stream()), 'kgdet_deform_psroi_backward')
         return (grad_input, grad_rois, grad_offset, None, None, None, None, None, None, None, None)
 
 

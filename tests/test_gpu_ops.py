@@ -210,6 +210,67 @@ def test_deform_psroi_pooling(no_trans, group_size, part):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('no_trans,S,group_size,C,out_c', [(False, 2, 1, 256, 256), (True, 4, 1, 256, 256),
+                                                          (False, 4, 7, 392, 8)])
+def test_deform_psroi_pooling_at_size_bit_repeatable(no_trans, S, group_size, C, out_c):
+    """512 RoIs x 256 channels x 7x7 bins on a [2, C, 50, 84] map (DeformRoIPoolingPack's shape; and the
+    position-sensitive 7x7-group variant): forward, grad_data and grad_offset against oracle/psroi_oracle.inc in float32;
+    the backward is BITWISE repeatable (a gather per output tile / one workgroup per (RoI, class): no atomics, round-2
+    review item 7), writes every gradient element (NaN-filled outputs come back finite), and -- because thread = channel
+    adds the samples in the reference loop's own serial order without fp contraction -- grad_data equals the serial
+    float32 oracle bit for bit."""
+    import ctypes
+    from kgdet_amd import _lib
+    from kgdet_amd.deform_pool import deform_roi_pooling
+    rng = np.random.default_rng(7)
+    B, H, W, P, R = 2, 50, 84, 7, 512
+    data = rng.normal(size=(B, C, H, W)).astype(np.float32)
+    x1 = rng.uniform(-30, 1250, R); y1 = rng.uniform(-30, 720, R)
+    rois = np.stack([rng.integers(0, B, R), x1, y1, x1 + rng.uniform(8, 600, R), y1 + rng.uniform(8, 500, R)],
+                    1).astype(np.float32)
+    rois[0, 1:] = [0, 0, 1343, 799]            # the whole image: its window does not fit the LDS budget (direct lane)
+    rois[1, 1:] = [40, 40, 40, 40]             # degenerate
+    rois[2, 1:] = [5000, 5000, 5100, 5100]     # outside the map: count 0 everywhere
+    offset = (rng.normal(size=(R, 2, P, P)) * 0.5).astype(np.float32)
+    go = rng.normal(size=(R, out_c, P, P)).astype(np.float32)
+    td = torch.from_numpy(data).cuda().requires_grad_()
+    to = torch.from_numpy(offset).cuda().requires_grad_()
+    args = (torch.from_numpy(rois).cuda(), to if not no_trans else to.new_empty(0), 1 / 16., P, out_c, no_trans,
+            group_size, P, S, 0.1)
+    out = deform_roi_pooling(td, *args)
+    out.backward(torch.from_numpy(go).cuda())
+    g1 = td.grad.clone()
+    t1 = None if no_trans else to.grad.clone()
+    ro, rc = oracle.deform_psroi_forward(data, rois, offset, np.float32(1 / 16.), P, out_c, no_trans, group_size, P, S,
+                                         np.float32(0.1))
+    _close(out.detach().cpu().numpy(), ro, 2e-6)
+    gd, gt = oracle.deform_psroi_backward(go, rc, data, rois, offset, np.float32(1 / 16.), P, out_c, no_trans,
+                                          group_size, P, S, np.float32(0.1))
+    np.testing.assert_array_equal(g1.cpu().numpy(), gd)          # same summation order, same expressions: bit-exact
+    if not no_trans:
+        _close(t1.cpu().numpy(), gt, 2e-5)
+    # second run into NaN-filled outputs through the C ABI: identical bits, nothing left unwritten
+    L = _lib.lib()
+    from kgdet_amd.deform_pool import _shape
+    shape = _shape(td, args[0], to, 1 / 16., P, out_c, no_trans, group_size, P, S, 0.1)
+    if no_trans:
+        shape.num_classes = 1
+    g2 = torch.full_like(g1, float('nan'))
+    t2 = torch.full_like(to, float('nan'))
+    cnt = torch.from_numpy(rc).cuda()
+    ws_bytes = L.kgdet_deform_psroi_backward_workspace_bytes(ctypes.byref(shape))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device='cuda')
+    _lib.check(L.kgdet_deform_psroi_backward(
+        ctypes.byref(shape), _lib.ptr(torch.from_numpy(go).cuda()), _lib.ptr(cnt), _lib.ptr(td.detach()), _lib.ptr(args[0]),
+        None if no_trans else _lib.ptr(to.detach()), _lib.ptr(g2), None if no_trans else _lib.ptr(t2), _lib.ptr(ws),
+        ctypes.c_size_t(ws_bytes), _lib.current_stream()), 'psroi_backward')
+    torch.cuda.synchronize()
+    assert torch.equal(g1, g2)
+    if not no_trans:
+        assert torch.equal(t1, t2)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('N,C,frac,max_num', [(1000, 13, 0.05, 100), (257, 5, 0.5, 20), (64, 1, 1.0, 100), (1200, 13, 0.2, 100)])
 def test_multiclass_nms_fused_matches_per_image_reference_path(N, C, frac, max_num):
     """csrc/nms.hip multiclass_nms_segments + multiclass_select == bbox_nms_kp.py's per-image, per-class loop
