@@ -304,6 +304,46 @@ int kgdet_sigmoid_focal_loss_backward(const float *logits, const int64_t *target
                                       int64_t num, int32_t num_classes, float gamma, float alpha,
                                       float *d_logits, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Target assignment + the nine losses of the KGDet head (one pyramid level) without materialised targets.
+ * Replaces, for RepPointsHeadKp3RepCas1AssignOnce.loss (reppoints_head_kp3rep_cas_1_assign_once.py:581-665):
+ * PointAssigner.assign (core/bbox/assigners/point_assigner.py:23-121), point_target_kp (core/anchor/
+ * point_target_kp.py:7-169), offset_to_pts (:537-579), FocalLoss / SmoothL1Loss with weight and avg_factor
+ * (models/losses/focal_loss.py:28-82, smooth_l1_loss.py:8-45, utils.py:7-52; sigmoid_focal_loss_cuda.cu:24-97).
+ * Prediction maps are the head's NCHW outputs: cls [B, num_classes, H, W], bbox [B, 4, H, W] (x1, y1, x2, y2
+ * offsets), kpt [B, 2 * num_keypoints, H, W] ((y, x) offset pairs), three stages each.  Points are the level's grid
+ * (x = column * stride, y = row * stride).  losses[9] = cls 1-3, bbox 1-3, kpt 1-3; num_total = sum over images of
+ * max(positives, 1) (a device scalar; nothing is read by the host).  The backward call takes the forward call's
+ * workspace (it holds the per-gt selections) and writes every element of the nine gradient maps.
+ * Limits: B <= 16, 1..64 ground truths per image, H * W <= 4096.
+ * ------------------------------------------------------------------------------------------ */
+#define KGDET_HEAD_MAX_IMAGES 16
+typedef struct kgdet_head_targets {
+  int32_t B, H, W, num_classes, num_keypoints;
+  float stride;
+  int32_t num_gt[KGDET_HEAD_MAX_IMAGES];
+  const float *gt_bboxes[KGDET_HEAD_MAX_IMAGES];     /* [num_gt, 4] */
+  const int64_t *gt_labels[KGDET_HEAD_MAX_IMAGES];   /* [num_gt], NULL: every label 1 */
+  const float *gt_keypoints[KGDET_HEAD_MAX_IMAGES];  /* [num_gt, num_keypoints, 3] (x, y, visibility) */
+} kgdet_head_targets;
+typedef struct kgdet_head_loss_cfg {
+  int32_t pos_num;               /* PointAssigner.pos_num */
+  float pos_weight;              /* label weight of positives (train_cfg.pos_weight <= 0 -> 1) */
+  float normalize_term;          /* point_base_scale * stride */
+  float gamma[3], alpha[3];      /* FocalLoss of stage 1-3 */
+  float beta[6];                 /* SmoothL1Loss: bbox 1-3, kpt 1-3 */
+  float loss_weight[9];          /* cls 1-3, bbox 1-3, kpt 1-3 */
+} kgdet_head_loss_cfg;
+typedef struct kgdet_head_maps {
+  float *cls[3], *bbox[3], *kpt[3];
+} kgdet_head_maps;
+size_t kgdet_head_loss_workspace_bytes(const kgdet_head_targets *t);
+int kgdet_head_loss_forward(const kgdet_head_targets *t, const kgdet_head_loss_cfg *cfg, const kgdet_head_maps *maps,
+                            float *losses, float *num_total, void *workspace, size_t workspace_bytes, void *stream);
+int kgdet_head_loss_backward(const kgdet_head_targets *t, const kgdet_head_loss_cfg *cfg, const kgdet_head_maps *maps,
+                             const float *grad_losses, const float *num_total, const kgdet_head_maps *grads,
+                             const void *workspace, size_t workspace_bytes, void *stream);
+
 /*
  * Gradient clipping + Adam over all parameters as multi-tensor passes: what OptimizerHook.after_train_iter does with
  * clip_grad_norm_(params, max_norm, 2) followed by torch.optim.Adam.step() (mmdet/core/utils/dist_utils.py:44-58; torch/optim/

@@ -384,20 +384,27 @@ class RepPointsHeadKp3RepCas1AssignOnce(PointHeadMixin, nn.Module):
         label_channels = self.cls_out_channels if self.use_sigmoid_cls else 1
         device = cls_scores_3[0].device
 
-        center_list, valid_flag_list = self.get_points(featmap_sizes, img_metas, device=device)
-        kpt_coords = [self.offset_to_pts(center_list, p) for p in (keypts_preds_1, keypts_preds_2, keypts_preds_3)]
-        bbox_coords = [self.offset_to_pts(center_list, p, y_first=False)
-                       for p in (bbox_preds_1, bbox_preds_2, bbox_preds_3)]
-
-        if cfg.uniform.assigner['type'] == 'PointAssigner':
-            candidate_list = center_list
-        else:
+        if cfg.uniform.assigner['type'] != 'PointAssigner':
             raise NotImplementedError
         # every grid point valid?  (host arithmetic on the image metas, the flags themselves live on the device)
         all_valid = all(
             min(int(np.ceil(meta['pad_shape'][0] / s)), fs[0]) == fs[0] and
             min(int(np.ceil(meta['pad_shape'][1] / s)), fs[1]) == fs[1]
             for meta in img_metas for s, fs in zip(self.point_strides, featmap_sizes))
+        from . import head_loss
+        stages = ((cls_scores_1, cls_scores_2, cls_scores_3), (keypts_preds_1, keypts_preds_2, keypts_preds_3),
+                  (bbox_preds_1, bbox_preds_2, bbox_preds_3))
+        if head_loss.applicable(self, cfg.uniform, stages[0], stages[1], stages[2], gt_bboxes, gt_labels, gt_keypoints,
+                                gt_bboxes_ignore, all_valid):
+            # assignment + targets + the nine losses from the raw maps: four HIP launches (csrc/head_loss.hip)
+            return head_loss.head_loss(self, cfg.uniform, stages[0], stages[1], stages[2], gt_bboxes, gt_labels,
+                                       gt_keypoints)
+
+        center_list, valid_flag_list = self.get_points(featmap_sizes, img_metas, device=device)
+        kpt_coords = [self.offset_to_pts(center_list, p) for p in (keypts_preds_1, keypts_preds_2, keypts_preds_3)]
+        bbox_coords = [self.offset_to_pts(center_list, p, y_first=False)
+                       for p in (bbox_preds_1, bbox_preds_2, bbox_preds_3)]
+        candidate_list = center_list
         if not self.sampling and dense_targets_applicable(cfg.uniform, len(self.point_strides), all_valid,
                                                           gt_bboxes_ignore):
             cls_reg_targets = point_target_kp_dense(candidate_list, gt_bboxes, gt_keypoints, cfg.uniform,

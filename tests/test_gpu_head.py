@@ -195,17 +195,29 @@ def test_training_step_has_no_host_syncs_and_dense_targets_match():
         torch.cuda.set_sync_debug_mode('default')
     torch.cuda.synchronize()
 
+    from kgdet_amd import head_loss
     with torch.no_grad():
-        dense = forward()
+        fused = forward()                       # csrc/head_loss.hip: assignment + losses from the raw maps
+        assert head_loss.ENABLED
+        head_loss.ENABLED = False
+        try:
+            dense = forward()                   # the sync-free torch chain
+        finally:
+            head_loss.ENABLED = True
         saved = points.dense_targets_applicable
         points.dense_targets_applicable = lambda *a, **k: False
         import kgdet_amd.heads as heads_mod
         heads_mod.dense_targets_applicable = points.dense_targets_applicable
         try:
-            mirrored = forward()
+            mirrored = forward()                # the reference-mirroring path (host syncs)
         finally:
             points.dense_targets_applicable = saved
             heads_mod.dense_targets_applicable = saved
+    for k in dense:
+        for a, b in zip(dense[k], mirrored[k]):
+            assert torch.allclose(a, b, rtol=1e-6, atol=0), k
+        for a, b in zip(fused[k], mirrored[k]):
+            assert torch.allclose(a, b, rtol=2e-5, atol=0), k      # other summation order
     for k in dense:
         for a, b in zip(dense[k], mirrored[k]):
             assert torch.allclose(a, b, rtol=1e-6, atol=0), k
@@ -480,3 +492,69 @@ def test_config5_full_size_training_step_and_soft_nms():
     dets = res[0] if isinstance(res, (list, tuple)) and len(res) in (1, 3) and not isinstance(res[0], np.ndarray) else res
     n = sum(len(d) for d in (dets[0] if len(dets) == 3 else dets))
     assert 0 < n <= cfg.test_cfg.max_per_img
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['random', 'ties_overlap_invisible', 'one_gt_no_labels'])
+def test_fused_head_loss_equals_the_torch_chain(case):
+    """csrc/head_loss.hip (PointAssigner + point_target_kp + offset_to_pts + 3 x (focal, smooth-L1 boxes, smooth-L1
+    keypoints) with weights and avg_factor, four launches) against the expression-by-expression torch chain of
+    kgdet_amd.heads / points / losses (itself bit-exact to the reference's targets, tests/test_gpu_ref_golden.py) at the
+    KGDet size [2, 13 / 4 / 588, 25, 42]: the nine losses to 2e-6 relative, the nine gradient maps to 2e-6 of their scale,
+    the positive count exactly; ground truths whose centre is equidistant from four grid points, overlapping ground
+    truths, one without a visible keypoint; deterministic."""
+    from kgdet_amd import head_loss
+    from kgdet_amd.registry import build_head
+    cfg = configs.kgdet_r50_fpn()
+    torch.manual_seed(3)
+    head = build_head(cfg.model.bbox_head).cuda()
+    g = torch.Generator().manual_seed({'random': 1, 'ties_overlap_invisible': 2, 'one_gt_no_labels': 3}[case])
+    B, H, W, K = 2, 25, 42, 294
+    n_gt = [3, 5] if case != 'one_gt_no_labels' else [1, 1]
+    gt_b, gt_l, gt_k = [], [], []
+    for b in range(B):
+        xy = torch.rand(n_gt[b], 2, generator=g) * torch.tensor([900., 500.]) + 150
+        wh = torch.rand(n_gt[b], 2, generator=g) * 500 + 120
+        if case == 'ties_overlap_invisible':
+            xy[0] = torch.tensor([16 * 32. + 16, 10 * 32. + 16])      # centre equidistant from 4 grid points
+            wh[0] = torch.tensor([256., 256.])
+            xy[1] = xy[0] + 40                                        # overlapping gts compete for the same points
+        box = torch.cat([xy - wh / 2, xy + wh / 2], 1)
+        kp = torch.cat([torch.rand(n_gt[b], K, 2, generator=g) * 700 + 50,
+                        (torch.rand(n_gt[b], K, 1, generator=g) < 0.15).float() * 2], 2)
+        if case == 'ties_overlap_invisible':
+            kp[-1, :, 2] = 0                                          # a gt without a visible keypoint
+        gt_b.append(box.cuda()); gt_k.append(kp.cuda())
+        gt_l.append(torch.randint(1, 14, (n_gt[b],), generator=g).cuda())
+    labels = None if case == 'one_gt_no_labels' else gt_l
+    img_metas = [dict(pad_shape=(800, 1344, 3), img_shape=(800, 1333, 3), scale_factor=1.0, flip=False)] * B
+
+    def maps():
+        gg = torch.Generator().manual_seed(11)
+        mk = lambda c, s: (torch.randn(B, c, H, W, generator=gg) * s).cuda().requires_grad_()
+        return ([[mk(13, 2.0)] for _ in range(3)], [[mk(2 * K, 4.0)] for _ in range(3)], [[mk(4, 4.0)] for _ in range(3)])
+
+    def run(fused):
+        cls, kpt, bbox = maps()
+        prev = head_loss.ENABLED
+        head_loss.ENABLED = fused
+        try:
+            losses = head.loss(cls[0], cls[1], cls[2], kpt[0], kpt[1], kpt[2], bbox[0], bbox[1], bbox[2], gt_b, labels,
+                               gt_k, img_metas, cfg.train_cfg)
+        finally:
+            head_loss.ENABLED = prev
+        names = sorted(losses)
+        w = torch.linspace(0.5, 1.5, len(names)).tolist()              # distinct upstream gradients per loss
+        sum(wi * sum(losses[n]) for wi, n in zip(w, names)).backward()
+        flat = [m[0] for group in (cls, kpt, bbox) for m in group]
+        return {n: float(sum(losses[n])) for n in names}, [m.grad.clone() for m in flat]
+
+    lf, gf = run(True)
+    lt, gt_ = run(False)
+    for n in lt:
+        assert abs(lf[n] - lt[n]) <= 2e-6 * abs(lt[n]) + 1e-9, (n, lf[n], lt[n])
+    for a, b in zip(gf, gt_):
+        assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item() + 1e-12
+        assert torch.equal(a == 0, b == 0)                             # the same positives, the same visible keypoints
+    lf2, gf2 = run(True)
+    assert lf2 == lf and all(torch.equal(a, b) for a, b in zip(gf, gf2))
