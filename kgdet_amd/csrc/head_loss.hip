@@ -11,7 +11,8 @@
 // the backward of every one of those nodes): 2.5 ms of a 14.6 ms step, all launch latency.  Here:
 //
 //   head_assign_select   block (gt, image): distance of every point to the gt centre (normalised by the gt size), the
-//                        pos_num nearest by RANK (all pairs against an LDS copy of the keys; ties by point index).
+//                        pos_num nearest by RANK among the ~2 pos_num candidates inside a bounding distance (ties by
+//                        point index).
 //   head_loss_forward    block (64-point tile, channel group, image): final assignment of its points (sequential over
 //                        the gts: `min_dist < assigned_dist`, earlier gt wins ties), then the loss ROWS of its group --
 //                        a row = one channel of one prediction map, lanes = points (coalesced NCHW reads): focal
@@ -83,41 +84,56 @@ __device__ __forceinline__ int final_assign(const float *__restrict__ dsel, int 
 }  // namespace
 
 // block (g, b), 256 threads.  dsel[b][g][i] = distance if point i is among the pos_num nearest of gt g, else +inf.
+// "Among the pos_num nearest" = rank < pos_num under the (distance, point index) order.  Ranks are only needed for the
+// points within T = the largest distance inside a ceil(sqrt(pos_num))-sided block of grid points around the centre: that
+// block holds >= pos_num points, so every point beyond T has rank >= pos_num, and every point that precedes a candidate
+// is a candidate itself -- the all-pairs count runs over ~2 pos_num candidates instead of all H * W points.
 __global__ __launch_bounds__(256) void head_assign_select(const kgdet_head_targets t, int pos_num, int gmax,
                                                           float *__restrict__ dsel) {
-  extern __shared__ float dist[];                    // [N]
+  extern __shared__ float dist[];                    // [N] distances, then [N] candidate indices
+  __shared__ int s_tbits, s_count;
   const int g = blockIdx.x, b = blockIdx.y, N = t.H * t.W, tid = threadIdx.x;
   if (g >= t.num_gt[b]) return;
+  int *cand = reinterpret_cast<int *>(dist + N);
   const float *box = t.gt_bboxes[b] + 4 * g;
   // point_assigner.py:69-71: centre and size of the gt; :93-95: ((p - centre) / size).norm(dim=1)
   const float cx = (box[0] + box[2]) / 2, cy = (box[1] + box[3]) / 2;
   const float w = fmaxf(box[2] - box[0], 1e-6f), h = fmaxf(box[3] - box[1], 1e-6f);
+  if (tid == 0) { s_tbits = 0; s_count = 0; }
   for (int i = tid; i < N; i += 256) {
     const float px = (float)(i % t.W) * t.stride, py = (float)(i / t.W) * t.stride;
     const float dx = (px - cx) / w, dy = (py - cy) / h;
     dist[i] = sqrtf(dx * dx + dy * dy);
   }
   __syncthreads();
-  // rank of point i = number of points with a smaller (distance, index) key; all pairs, the j side an LDS broadcast.
-  // Four points per thread and pass.
+  int side = 1;
+  while (side * side < pos_num) ++side;
+  float T = INFINITY;
+  if (side <= t.H && side <= t.W) {
+    const int j0 = min(max((int)floorf(cx / t.stride + 0.5f) - side / 2, 0), t.W - side);
+    const int i0 = min(max((int)floorf(cy / t.stride + 0.5f) - side / 2, 0), t.H - side);
+    for (int e = tid; e < side * side; e += 256)
+      atomicMax(&s_tbits, __float_as_int(dist[(i0 + e / side) * t.W + j0 + e % side]));   // (distances are >= 0)
+    __syncthreads();
+    T = __int_as_float(s_tbits);
+  }
+  for (int i = tid; i < N; i += 256)
+    if (dist[i] <= T) cand[atomicAdd(&s_count, 1)] = i;       // (any order: only counts are taken over the list)
+  __syncthreads();
+  const int M = s_count;
   float *out = dsel + ((long long)b * gmax + g) * N;
-  for (int i0 = tid; i0 < N; i0 += 4 * 256) {
-    float di[4];
-    int idx[4], rank[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      idx[u] = min(i0 + u * 256, N - 1);
-      di[u] = dist[idx[u]];
-      rank[u] = 0;
-    }
-    for (int j = 0; j < N; ++j) {
+  for (int i = tid; i < N; i += 256) out[i] = INFINITY;
+  __syncthreads();
+  for (int c = tid; c < M; c += 256) {
+    const int i = cand[c];
+    const float di = dist[i];
+    int rank = 0;
+    for (int e = 0; e < M; ++e) {
+      const int j = cand[e];
       const float dj = dist[j];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) rank[u] += (dj < di[u] || (dj == di[u] && j < idx[u])) ? 1 : 0;
+      rank += (dj < di || (dj == di && j < i)) ? 1 : 0;
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (i0 + u * 256 < N) out[idx[u]] = rank[u] < pos_num ? di[u] : INFINITY;
+    if (rank < pos_num) out[i] = di;
   }
 }
 
@@ -349,7 +365,7 @@ int kgdet_head_loss_forward(const kgdet_head_targets *t, const kgdet_head_loss_c
   float *dsel = reinterpret_cast<float *>(workspace);
   float *partial = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(workspace) +
                                              align_up((size_t)t->B * kMaxGt * N * sizeof(float), 256));
-  hipLaunchKernelGGL(head_assign_select, dim3(gmax, t->B), dim3(256), (size_t)N * sizeof(float), (hipStream_t)stream, *t,
+  hipLaunchKernelGGL(head_assign_select, dim3(gmax, t->B), dim3(256), (size_t)N * 2 * sizeof(float), (hipStream_t)stream, *t,
                      cfg->pos_num, kMaxGt, dsel);
   KGDET_CHECK_LAUNCH("head_assign_select");
   int groups = 0;
