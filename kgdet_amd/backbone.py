@@ -472,44 +472,29 @@ class ResNet(nn.Module):
         if depth not in self.arch_settings:
             raise KeyError('invalid depth {} for resnet'.format(depth))
         assert gcb is None and gen_attention is None, 'context / attention plugins are outside the KGDet path'
-        self.depth = depth
-        self.num_stages = num_stages
-        assert num_stages >= 1 and num_stages <= 4
-        self.strides = strides
-        self.dilations = dilations
-        assert len(strides) == len(dilations) == num_stages
-        self.out_indices = out_indices
-        assert max(out_indices) < num_stages
-        self.style = style
-        self.frozen_stages = frozen_stages
-        self.conv_cfg = conv_cfg
-        self.norm_cfg = norm_cfg
-        self.with_cp = with_cp
-        self.norm_eval = norm_eval
-        self.dcn = dcn
-        self.stage_with_dcn = stage_with_dcn
-        if dcn is not None:
-            assert len(stage_with_dcn) == num_stages
-        self.zero_init_residual = zero_init_residual
-        self.block, stage_blocks = self.arch_settings[depth]
-        self.stage_blocks = stage_blocks[:num_stages]
+        assert 1 <= num_stages <= 4 and len(strides) == len(dilations) == num_stages and max(out_indices) < num_stages
+        assert dcn is None or len(stage_with_dcn) == num_stages
+        # (the attribute names are the reference's: resnet.py:386-404; configs and checkpoints address them)
+        for key, value in dict(depth=depth, num_stages=num_stages, strides=strides, dilations=dilations,
+                               out_indices=out_indices, style=style, frozen_stages=frozen_stages, conv_cfg=conv_cfg,
+                               norm_cfg=norm_cfg, with_cp=with_cp, norm_eval=norm_eval, dcn=dcn,
+                               stage_with_dcn=stage_with_dcn, zero_init_residual=zero_init_residual).items():
+            setattr(self, key, value)
+        self.block, per_stage = self.arch_settings[depth]
+        self.stage_blocks = per_stage[:num_stages]
         self.inplanes = 64
-
         self._make_stem_layer()
-
         self.res_layers = []
-        for i, num_blocks in enumerate(self.stage_blocks):
-            planes = 64 * 2**i
-            res_layer = make_res_layer(self.block, self.inplanes, planes, num_blocks, stride=strides[i],
-                                       dilation=dilations[i], style=self.style, with_cp=with_cp, conv_cfg=conv_cfg,
-                                       norm_cfg=norm_cfg, dcn=self.dcn if self.stage_with_dcn[i] else None)
+        for stage, num_blocks in enumerate(self.stage_blocks):
+            planes = 64 << stage
+            layer = make_res_layer(self.block, self.inplanes, planes, num_blocks, stride=strides[stage],
+                                   dilation=dilations[stage], style=style, with_cp=with_cp, conv_cfg=conv_cfg,
+                                   norm_cfg=norm_cfg, dcn=dcn if stage_with_dcn[stage] else None)
             self.inplanes = planes * self.block.expansion
-            layer_name = 'layer{}'.format(i + 1)
-            self.add_module(layer_name, res_layer)
-            self.res_layers.append(layer_name)
-
+            self.res_layers.append('layer%d' % (stage + 1))
+            self.add_module(self.res_layers[-1], layer)
         self._freeze_stages()
-        self.feat_dim = self.block.expansion * 64 * 2**(len(self.stage_blocks) - 1)
+        self.feat_dim = self.block.expansion * (64 << (len(self.stage_blocks) - 1))
 
     @property
     def norm1(self):
@@ -523,16 +508,14 @@ class ResNet(nn.Module):
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
 
     def _freeze_stages(self):
-        if self.frozen_stages >= 0:
-            self.norm1.eval()
-            for m in [self.conv1, self.norm1]:
-                for param in m.parameters():
-                    param.requires_grad = False
-        for i in range(1, self.frozen_stages + 1):
-            m = getattr(self, 'layer{}'.format(i))
-            m.eval()
-            for param in m.parameters():
-                param.requires_grad = False
+        """stem (frozen_stages >= 0) and layer1 .. layer<frozen_stages>: eval mode, no gradients (resnet.py:466-478)"""
+        frozen = [self.conv1, self.norm1] if self.frozen_stages >= 0 else []
+        frozen += [getattr(self, 'layer%d' % i) for i in range(1, self.frozen_stages + 1)]
+        for module in frozen:
+            if module is not self.conv1:
+                module.eval()
+            for p in module.parameters():
+                p.requires_grad = False
 
     def init_weights(self, pretrained=None):
         if isinstance(pretrained, str):

@@ -14,46 +14,36 @@ from . import nms as nms_wrapper
 
 
 def multiclass_nms_kp(multi_bboxes, multi_scores, multi_kpts, score_thr, nms_cfg, max_num=-1, score_factors=None):
-    num_classes = multi_scores.shape[1]
+    """One image: per foreground class, candidates with ``score > score_thr`` go through the NMS op named by
+    ``nms_cfg['type']`` (boxes [N, 4] shared by the classes or [N, 4 * classes]); survivors are concatenated class by
+    class, and when more than ``max_num`` remain the top ``max_num`` by score are kept (bbox_nms_kp.py:6-75, including its
+    ``inds[:max_num]`` slice for ``max_num = -1``).  The keypoints of a survivor follow it."""
     assert multi_kpts.shape[1] % 3 == 0
-    num_kpts = multi_kpts.shape[1] // 3
-    bboxes, labels, kpts = [], [], []
-    nms_cfg_ = dict(nms_cfg)
-    nms_type = nms_cfg_.pop('type', 'nms')
-    nms_op = getattr(nms_wrapper, nms_type)
-    for i in range(1, num_classes):
-        cls_inds = multi_scores[:, i] > score_thr
-        if not cls_inds.any():
+    op_args = dict(nms_cfg)
+    op = getattr(nms_wrapper, op_args.pop('type', 'nms'))
+    shared_boxes = multi_bboxes.shape[1] == 4
+    candidate = multi_scores > score_thr                        # column 0 (background) is never looked at
+    dets, labels, rows = [], [], []
+    for cls in range(1, multi_scores.shape[1]):
+        picked = candidate[:, cls]
+        if not bool(picked.any()):
             continue
-        if multi_bboxes.shape[1] == 4:
-            _bboxes = multi_bboxes[cls_inds, :]
-        else:
-            _bboxes = multi_bboxes[cls_inds, i * 4:(i + 1) * 4]
-        _kpts = multi_kpts[cls_inds, :]
-        _scores = multi_scores[cls_inds, i]
+        boxes = multi_bboxes[picked] if shared_boxes else multi_bboxes[picked, 4 * cls:4 * cls + 4]
+        score = multi_scores[picked, cls]
         if score_factors is not None:
-            _scores *= score_factors[cls_inds]
-        cls_dets = torch.cat([_bboxes, _scores[:, None]], dim=1)
-        cls_dets, inds = nms_op(cls_dets, **nms_cfg_)
-        cls_labels = multi_bboxes.new_full((cls_dets.shape[0], ), i - 1, dtype=torch.long)
-        bboxes.append(cls_dets)
-        labels.append(cls_labels)
-        kpts.append(_kpts[inds, :])
-    if bboxes:
-        bboxes = torch.cat(bboxes)
-        labels = torch.cat(labels)
-        kpts = torch.cat(kpts)
-        if bboxes.shape[0] > max_num:
-            _, inds = bboxes[:, -1].sort(descending=True)
-            inds = inds[:max_num]
-            bboxes = bboxes[inds]
-            labels = labels[inds]
-            kpts = kpts[inds]
-    else:
-        bboxes = multi_bboxes.new_zeros((0, 5))
-        labels = multi_bboxes.new_zeros((0, ), dtype=torch.long)
-        kpts = multi_bboxes.new_zeros((0, num_kpts * 3))
-    return bboxes, labels, kpts
+            score = score * score_factors[picked]
+        kept_dets, kept = op(torch.cat([boxes, score.unsqueeze(1)], dim=1), **op_args)
+        dets.append(kept_dets)
+        labels.append(torch.full((kept_dets.shape[0], ), cls - 1, dtype=torch.long, device=multi_bboxes.device))
+        rows.append(picked.nonzero().flatten()[kept])
+    if not dets:
+        return (multi_bboxes.new_zeros((0, 5)), multi_bboxes.new_zeros((0, ), dtype=torch.long),
+                multi_bboxes.new_zeros((0, multi_kpts.shape[1])))
+    dets, labels, kpts = torch.cat(dets), torch.cat(labels), multi_kpts[torch.cat(rows)]
+    if dets.shape[0] > max_num:
+        top = dets[:, 4].sort(descending=True)[1][:max_num]
+        dets, labels, kpts = dets[top], labels[top], kpts[top]
+    return dets, labels, kpts
 
 
 def multiclass_nms_kp_batched(bboxes, scores, kpts, score_thr, nms_cfg, max_num=-1):

@@ -13,35 +13,32 @@ from torch import nn
 
 
 class Registry(object):
+    """name -> class table behind ``@X.register_module`` and ``build_from_cfg`` (the behaviour of
+    mmdet/utils/registry.py:6-46: duplicate names and non-classes are errors, ``get`` returns None for unknown names)."""
 
     def __init__(self, name):
         self._name = name
-        self._module_dict = dict()
+        self._module_dict = {}
+
+    name = property(lambda self: self._name)
+    module_dict = property(lambda self: self._module_dict)
 
     def __repr__(self):
-        return '{}(name={}, items={})'.format(self.__class__.__name__, self._name,
-                                               list(self._module_dict.keys()))
-
-    @property
-    def name(self):
-        return self._name
-
-    @property
-    def module_dict(self):
-        return self._module_dict
+        return '%s(name=%s, items=%s)' % (type(self).__name__, self._name, list(self._module_dict))
 
     def get(self, key):
-        return self._module_dict.get(key, None)
+        return self._module_dict.get(key)
 
     def _register_module(self, module_class, name=None):
         if not inspect.isclass(module_class):
             raise TypeError('module must be a class, but got {}'.format(type(module_class)))
-        module_name = name or module_class.__name__
-        if module_name in self._module_dict:
-            raise KeyError('{} is already registered in {}'.format(module_name, self.name))
-        self._module_dict[module_name] = module_class
+        key = module_class.__name__ if name is None else name
+        if key in self._module_dict:
+            raise KeyError('{} is already registered in {}'.format(key, self._name))
+        self._module_dict[key] = module_class
 
     def register_module(self, cls):
+        """class decorator"""
         self._register_module(cls)
         return cls
 
@@ -51,21 +48,25 @@ class Registry(object):
 
 
 def build_from_cfg(cfg, registry, default_args=None):
-    assert isinstance(cfg, dict) and 'type' in cfg
-    assert isinstance(default_args, dict) or default_args is None
-    args = dict(cfg)
-    obj_type = args.pop('type')
-    if isinstance(obj_type, str):
-        found = registry.get(obj_type)
-        if found is None:
-            raise KeyError('{} is not in the {} registry'.format(obj_type, registry.name))
-        obj_type = found
-    elif not inspect.isclass(obj_type):
-        raise TypeError('type must be a str or valid type, but got {}'.format(type(obj_type)))
-    if default_args is not None:
-        for name, value in default_args.items():
-            args.setdefault(name, value)
-    return obj_type(**args)
+    """Instantiate ``cfg['type']`` (a registered name or a class) with the remaining keys; ``default_args`` fill the
+    keys the config leaves out (registry.py:49-74)."""
+    if not (isinstance(cfg, dict) and 'type' in cfg):
+        raise AssertionError('cfg must be a dict with a "type" key')
+    if not (default_args is None or isinstance(default_args, dict)):
+        raise AssertionError('default_args must be a dict or None')
+    kwargs = {k: v for k, v in cfg.items() if k != 'type'}
+    target = cfg['type']
+    if isinstance(target, str):
+        cls = registry.get(target)
+        if cls is None:
+            raise KeyError('{} is not in the {} registry'.format(target, registry.name))
+    elif inspect.isclass(target):
+        cls = target
+    else:
+        raise TypeError('type must be a str or valid type, but got {}'.format(type(target)))
+    for key, value in (default_args or {}).items():
+        kwargs.setdefault(key, value)
+    return cls(**kwargs)
 
 
 BACKBONES = Registry('backbone')

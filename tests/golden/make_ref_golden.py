@@ -178,17 +178,19 @@ def kgdet_head(ns, out):
             print('image', i, 'detections', db.shape[0])
 
 
-def serial_head(ns, out):
-    """The reference's serial (config 5) head: 5 pyramid levels, PointAssigner init stage + MaxIoUAssigner
-    refine stage, weights from ref_cases.serial_head()."""
+def serial_head(ns, out, parallel=False, size=(256, 320), maps=True):
+    """The reference's serial (config 5) head -- or, ``parallel=True``, its parallel sibling
+    (reppoints_head_kp_parallel.py) --: 5 pyramid levels, PointAssigner init stage + MaxIoUAssigner refine stage,
+    weights from ref_cases.serial_head().  ``size=(384, 512)``: a 3072-pixel stride-8 level (large-map kernels);
+    ``maps=False`` leaves the forward maps out of the fixture (losses, gradients and detections pin them)."""
     from kgdet_amd import configs
-    cfg = configs.reppoints_kp_r50_fpn()
-    ours = ref_cases.serial_head()
+    cfg = configs.reppoints_kp_r50_fpn(parallel=parallel)
+    ours = ref_cases.serial_head(parallel=parallel)
     hc = dict(cfg.model.bbox_head)
     hc.pop('type')
-    ref = ns.head_serial.RepPointsHeadKpSerial(**hc)
+    ref = (ns.head_parallel.RepPointsHeadKpParallel if parallel else ns.head_serial.RepPointsHeadKpSerial)(**hc)
     _load_into_reference(ref, ours)
-    xs, batch = ref_cases.serial_inputs()
+    xs, batch = ref_cases.serial_inputs(size)
     names = ['cls', 'kpt_init', 'kpt_refine', 'rep_init', 'rep_refine']
     # float32 throughout (the reference's own precision): its refine stage mixes predicted boxes with the GT
     # tensors, which modern torch refuses across dtypes
@@ -198,7 +200,8 @@ def serial_head(ns, out):
     for n, o in zip(names, outs):
         for lvl, t in enumerate(o):
             a = _np(t)
-            out['out:%s:%d' % (n, lvl)] = a[:, ::ref_cases.KPT_STRIDE * 3] if n.startswith('kpt') else a
+            if maps:
+                out['out:%s:%d' % (n, lvl)] = a[:, ::ref_cases.KPT_STRIDE * 3] if n.startswith('kpt') else a
     losses = ref64.loss(*outs, batch['gt_bboxes'], batch['gt_labels'], batch['gt_keypoints'], batch['img_meta'],
                         cfg.train_cfg)
     for k, v in losses.items():
@@ -222,9 +225,12 @@ def serial_head(ns, out):
 
 def main():
     ns = ref_loader.load()
-    which = sys.argv[1:] or ['targets', 'head', 'serial']
+    which = sys.argv[1:] or ['targets', 'head', 'serial', 'parallel', 'serial_large']
     for name, fn, fname in (('targets', targets, 'ref_targets_golden.npz'), ('head', kgdet_head, 'ref_head_golden.npz'),
-                            ('serial', serial_head, 'ref_serial_golden.npz')):
+                            ('serial', serial_head, 'ref_serial_golden.npz'),
+                            ('parallel', lambda ns, out: serial_head(ns, out, parallel=True), 'ref_parallel_golden.npz'),
+                            ('serial_large', lambda ns, out: serial_head(ns, out, size=(384, 512), maps=False),
+                             'ref_serial_large_golden.npz')):
         if name in which:
             out = {}
             fn(ns, out)

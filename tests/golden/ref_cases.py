@@ -185,13 +185,16 @@ def serial_head(parallel=False):
     return head
 
 
-def serial_inputs():
-    g = torch.Generator().manual_seed(4)
-    fm = pyramid_featmaps(256, 320, [8, 16, 32, 64, 128])
+def serial_inputs(size=(256, 320)):
+    """five-level pyramid inputs of the serial / parallel heads; ``size=(384, 512)`` puts 48 x 64 = 3072 pixels on the
+    stride-8 level: beyond the 1536-pixel limit of the LDS-plane deformable kernels, i.e. the large-map path"""
+    h_img, w_img = size
+    g = torch.Generator().manual_seed(4 if size == (256, 320) else 14)
+    fm = pyramid_featmaps(h_img, w_img, [8, 16, 32, 64, 128])
     xs = [torch.randn(2, 256, h, w, generator=g) for h, w in fm]
-    batch = synthetic.make_batch(2, 'cpu', seed=6, img_shape=(256, 320, 3), pad_shape=(256, 320, 3))
+    batch = synthetic.make_batch(2, 'cpu', seed=6, img_shape=(h_img, w_img, 3), pad_shape=(h_img, w_img, 3))
     for k in ('gt_bboxes', 'gt_keypoints'):
-        batch[k] = [t.clamp(max=250) for t in batch[k]]
+        batch[k] = [t.clamp(max=h_img - 6) for t in batch[k]]
     return xs, batch
 
 

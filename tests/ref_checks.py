@@ -185,11 +185,12 @@ def _check_detections(db, dl, dk, gdb, gdl, gdk, tol=1e-3):
     return w
 
 
-def check_serial_head(head, device, tol_map=3e-4, tol_loss=5e-4, tol_grad=2e-3):
-    """config 5 (serial) head on a five-level pyramid against the REFERENCE module's float32 run."""
-    G = load('ref_serial_golden.npz')
-    cfg = configs.reppoints_kp_r50_fpn()
-    xs_cpu, batch = ref_cases.serial_inputs()
+def check_serial_head(head, device, tol_map=3e-4, tol_loss=5e-4, tol_grad=2e-3, golden='ref_serial_golden.npz',
+                      parallel=False, size=(256, 320)):
+    """config 5 (serial / parallel) head on a five-level pyramid against the REFERENCE module's float32 run."""
+    G = load(golden)
+    cfg = configs.reppoints_kp_r50_fpn(parallel=parallel)
+    xs_cpu, batch = ref_cases.serial_inputs(size)
     names = ['cls', 'kpt_init', 'kpt_refine', 'rep_init', 'rep_refine']
     head.train()
     xs, outs, losses = head_outputs_and_losses(head, xs_cpu, batch, cfg.train_cfg, device)
@@ -198,6 +199,8 @@ def check_serial_head(head, device, tol_map=3e-4, tol_loss=5e-4, tol_grad=2e-3):
         for lvl, t in enumerate(o):
             a = _np(t)
             a = a[:, ::ref_cases.KPT_STRIDE * 3] if n.startswith('kpt') else a
+            if 'out:%s:%d' % (n, lvl) not in G.files:        # (fixtures made with maps=False)
+                continue
             r = rel(a, G['out:%s:%d' % (n, lvl)])
             worst['out:' + n] = max(worst.get('out:' + n, 0.0), r)
             assert r < tol_map, (n, lvl, r)

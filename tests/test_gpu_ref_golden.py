@@ -73,3 +73,21 @@ def test_hip_serial_head_equals_reference_head():
     head = ref_cases.serial_head().cuda()
     worst = ref_checks.check_serial_head(head, 'cuda')
     print(worst)
+
+
+def test_hip_parallel_head_equals_reference_head():
+    """config 5's sibling: the parallel head (reppoints on their own conv branch, reppoints_head_kp_parallel.py:153-168,
+    314-332) on the HIP ops against the REFERENCE parallel head module (tests/golden/ref_parallel_golden.npz; round-2
+    review: the parallel head had only been compared with itself)"""
+    head = ref_cases.serial_head(parallel=True).cuda()
+    worst = ref_checks.check_serial_head(head, 'cuda', golden='ref_parallel_golden.npz', parallel=True)
+    print(worst)
+
+
+def test_hip_serial_head_large_level_equals_reference_head():
+    """the serial head on a 384 x 512 pyramid: the stride-8 level has 48 x 64 = 3072 pixels, beyond the 1536-pixel limit
+    of the LDS-plane deformable kernels, so the large-map forward / backward kernels are inside a reference-pinned
+    comparison (losses, input gradients over the pyramid, gradient norms, hard- and soft-NMS detections)"""
+    head = ref_cases.serial_head().cuda()
+    worst = ref_checks.check_serial_head(head, 'cuda', golden='ref_serial_large_golden.npz', size=(384, 512))
+    print(worst)

@@ -106,3 +106,11 @@ def test_serial_head_host_logic_equals_reference_head_on_cpu():
     with cpu_ops.patched():
         worst = ref_checks.check_serial_head(head, 'cpu')
     print(worst)
+
+
+def test_parallel_head_host_logic_equals_reference_head_on_cpu():
+    """RepPointsHeadKpParallel (host logic, test-side CPU ops) == the reference's reppoints_head_kp_parallel.py module"""
+    head = ref_cases.serial_head(parallel=True)
+    with cpu_ops.patched():
+        worst = ref_checks.check_serial_head(head, 'cpu', golden='ref_parallel_golden.npz', parallel=True)
+    print(worst)
