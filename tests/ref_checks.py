@@ -128,12 +128,13 @@ def check_kgdet_head(head, device, tol_map=2e-4, tol_loss=2e-4, tol_grad=1e-3):
     # grad:x passes back through the towers' GroupNorm + ReLU stacks: a pre-activation within rounding of zero takes the other
     # side in one of the two implementations and moves the gradient in its 7 x 7 neighbourhood by ~1e-3 of the maximum (which
     # elements do depends on the summation order of the convolution kernel: 388 of 67200 elements beyond 1e-4 with one 3x3
-    # kernel, 1080 with another, in two / three clusters).  So: 99 % of the elements within tol_grad / 10, all within 3 tol_grad.
+    # kernel, 1080 with another, in two / three clusters).  The bound is BASELINE.md's 1e-3 for EVERY element (measured
+    # round 3: 4.1e-4 on the GPU in both arithmetic modes); the share of elements beyond 1e-4 is kept as a second check.
     gx, gx_ref = _np(xs[0].grad)[:, ::8], G['grad:x']
     err = np.abs(gx - gx_ref) / np.abs(gx_ref).max()
     worst['grad:x'] = float(err.max())
     worst['grad:x:frac'] = float((err > tol_grad / 10).mean())
-    assert worst['grad:x'] < 3 * tol_grad and worst['grad:x:frac'] < 0.02, (worst['grad:x'], worst['grad:x:frac'])
+    assert worst['grad:x'] < tol_grad and worst['grad:x:frac'] < 0.02, (worst['grad:x'], worst['grad:x:frac'])
     params = dict(head.named_parameters())
     for key in G.files:
         if key.startswith('gradnorm:'):
@@ -185,7 +186,7 @@ def _check_detections(db, dl, dk, gdb, gdl, gdk, tol=1e-3):
     return w
 
 
-def check_serial_head(head, device, tol_map=3e-4, tol_loss=5e-4, tol_grad=2e-3, golden='ref_serial_golden.npz',
+def check_serial_head(head, device, tol_map=3e-4, tol_loss=5e-4, tol_grad=1e-3, golden='ref_serial_golden.npz',
                       parallel=False, size=(256, 320)):
     """config 5 (serial / parallel) head on a five-level pyramid against the REFERENCE module's float32 run."""
     G = load(golden)

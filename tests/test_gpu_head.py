@@ -417,6 +417,7 @@ def test_full_size_training_step_split_arithmetic_matches_exact_fp32():
         assert abs(l_split[k] - l_exact[k]) <= 1e-4 * max(1.0, abs(l_exact[k])), (k, l_split[k], l_exact[k])
     assert set(g_split) == set(g_exact) and len(g_exact) > 10
     worst = max(abs(g_split[k] - g_exact[k]) / max(g_exact[k], 1e-12) for k in g_exact)
+    print({k: '%.2e' % (abs(g_split[k] - g_exact[k]) / max(g_exact[k], 1e-12)) for k in sorted(g_exact)})
     assert worst <= 2e-3, (worst, {k: (g_split[k], g_exact[k]) for k in g_exact
                                    if abs(g_split[k] - g_exact[k]) > 1e-3 * g_exact[k]})
 
@@ -558,3 +559,47 @@ def test_fused_head_loss_equals_the_torch_chain(case):
         assert torch.equal(a == 0, b == 0)                             # the same positives, the same visible keypoints
     lf2, gf2 = run(True)
     assert lf2 == lf and all(torch.equal(a, b) for a, b in zip(gf, gf2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['split', 'exact'])
+def test_full_size_training_step_matches_float64(mode, golden_dir):
+    """The bench workload's training step (2 x 800 x 1344, seeds 0) on the HIP path against a FLOAT64 evaluation of the
+    same graph (tests/golden/make_step_golden.py: this repo's host graph on the CPU, grid_sample formulation of the
+    deformable ops, everything in double): the nine losses to 1e-5, the gradient norm of every module group to
+    BASELINE.md's 1e-3, sampled gradient slices to 1e-3 of their scale.  A ground truth instead of the comparison of two
+    approximations (round-2 review: the split-vs-'exact' bound had been widened to 2e-3 -- 'exact' runs MIOpen's fp32
+    solvers, which are not more accurate than the split-bf16 kernels: see the per-group numbers printed here)."""
+    from kgdet_amd import dcn
+    from kgdet_amd.registry import build_detector
+    G = np.load(os.path.join(golden_dir, 'step_f64_golden.npz'))
+    cfg = configs.kgdet_r50_fpn()
+    torch.manual_seed(0)
+    model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda()
+    model.train()
+    batch = synthetic.make_batch(2, 'cuda', seed=0)
+    with dcn.arithmetic(mode):
+        losses = model(batch['img'], batch['img_meta'], return_loss=True, gt_bboxes=batch['gt_bboxes'],
+                       gt_labels=batch['gt_labels'], gt_keypoints=batch['gt_keypoints'])
+        sum(sum(v) for v in losses.values()).backward()
+    torch.cuda.synchronize()
+    for k, v in losses.items():
+        got, want = sum(float(t) for t in v), float(G['loss:' + k])
+        assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (k, got, want)
+    groups, params = {}, dict(model.named_parameters())
+    for name, p in params.items():
+        if p.grad is not None:
+            key = '.'.join(name.split('.')[:2])
+            groups[key] = groups.get(key, 0.0) + float(p.grad.double().pow(2).sum())
+    dev = {k: abs(v ** 0.5 - float(G['group:' + k])) / float(G['group:' + k]) for k, v in groups.items()}
+    print(mode, {k: '%.1e' % v for k, v in sorted(dev.items())})
+    assert set('group:' + k for k in groups) == set(k for k in G.files if k.startswith('group:'))
+    assert max(dev.values()) <= 1e-3, dev
+    worst = 0.0
+    for key in G.files:
+        if key.startswith('grad:'):
+            a = params[key[5:]].grad.detach().cpu().numpy()
+            a = a.reshape(a.shape[0], -1)[::max(a.shape[0] // 16, 1), ::7]
+            worst = max(worst, _rel(a, G[key]))
+    print(mode, 'sampled gradient slices: %.1e' % worst)
+    assert worst <= 1e-3
