@@ -344,6 +344,23 @@ int kgdet_head_loss_backward(const kgdet_head_targets *t, const kgdet_head_loss_
                              const float *grad_losses, const float *num_total, const kgdet_head_maps *grads,
                              const void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Element-wise glue of the KGDet step as single passes (no native function in the reference).
+ * kgdet_reppts_offsets_*: the deformable offsets of a Kp3RepBlock from the previous stage's reppoints,
+ *   reppoints_head_kp3rep_cas_1_assign_once.py:131-143: for the 2 k^2-channel slices (k = kernel_sizes[0..2], consecutive)
+ *   of reppts [B, C, HW]: out_k = (gm * part + (1 - gm) * part) - regular_grid_k; backward: grad_reppts = gm * grad_k on the
+ *   slices (NULL grad_k: zeros), 0 on the channels beyond them.
+ * kgdet_subsample2_*: y = x[:, :, ::2, ::2] of [planes, H, W] and grad_x = zero-stuffed grad_y (+ other, nullable) -- the
+ *   stride-2 1x1 downsample branch of resnet.py:180-186 as a 1x1 convolution of the subsampled input; backward needs W % 4 == 0.
+ * ------------------------------------------------------------------------------------------ */
+int kgdet_reppts_offsets_forward(const float *reppts, int32_t B, int32_t C, int32_t HW, const int32_t *kernel_sizes, float gm,
+                                 float *out0, float *out1, float *out2, void *stream);
+int kgdet_reppts_offsets_backward(const float *g0, const float *g1, const float *g2, int32_t B, int32_t C, int32_t HW,
+                                  const int32_t *kernel_sizes, float gm, float *grad_reppts, void *stream);
+int kgdet_subsample2_forward(const float *x, float *y, int64_t planes, int32_t H, int32_t W, void *stream);
+int kgdet_subsample2_backward(const float *grad_y, const float *other /*nullable*/, float *grad_x, int64_t planes, int32_t H,
+                              int32_t W, void *stream);
+
 /*
  * Gradient clipping + Adam over all parameters as multi-tensor passes: what OptimizerHook.after_train_iter does with
  * clip_grad_norm_(params, max_norm, 2) followed by torch.optim.Adam.step() (mmdet/core/utils/dist_utils.py:44-58; torch/optim/

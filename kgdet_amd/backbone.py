@@ -33,10 +33,12 @@ def _stem_conv(conv, x):
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and w.dtype == torch.float32):
         key = (w.data_ptr(), w._version)
         hit = _stem_cache.get(id(conv))
-        if hit is None or hit[0] != key:
+        # (id, address and version can all repeat once a module is freed and another built -- CPython reuses ids, the caching
+        #  allocator addresses: the entry also holds a weak reference to the weight it was packed from)
+        if hit is None or hit[0] != key or hit[2]() is not w:
             w160 = torch.zeros((64, 160), dtype=torch.float32, device=w.device)
             w160[:, :147] = w.detach().reshape(64, 147)
-            hit = (key, conv1x1._pack(w160.view(64, 160, 1, 1), False))
+            hit = (key, conv1x1._pack(w160.view(64, 160, 1, 1), False), weakref.ref(w))
             _stem_cache[id(conv)] = hit
         from . import _lib
         B, _, H, W = x.shape
@@ -268,6 +270,37 @@ def frozen_bn_act(x, bn, residual=None, relu=False):
     return F.relu(out, inplace=True) if relu else out
 
 
+class _Subsample2(torch.autograd.Function):
+    """``x[:, :, ::2, ::2]`` as a contiguous tensor; backward = the zero-stuffed gradient in ONE pass (csrc/glue.hip)
+    instead of slice_backward's zero fill + strided copy"""
+
+    @staticmethod
+    def forward(ctx, x):
+        from . import _lib
+        B, C, H, W = x.shape
+        y = x.new_empty(B, C, (H + 1) // 2, (W + 1) // 2)
+        _lib.check(_lib.lib().kgdet_subsample2_forward(_lib.ptr(x), _lib.ptr(y), ctypes.c_int64(B * C), ctypes.c_int32(H),
+                                                       ctypes.c_int32(W), _lib.current_stream()), 'subsample2_forward')
+        ctx.shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import _lib
+        B, C, H, W = ctx.shape
+        gx = gy.new_empty(B, C, H, W)
+        _lib.check(_lib.lib().kgdet_subsample2_backward(_lib.ptr(gy.contiguous()), None, _lib.ptr(gx), ctypes.c_int64(B * C),
+                                                        ctypes.c_int32(H), ctypes.c_int32(W), _lib.current_stream()),
+                   'subsample2_backward')
+        return gx
+
+
+def _subsample2(x):
+    if x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[3] % 4 == 0 and x.shape[2] % 2 == 0:
+        return _Subsample2.apply(x)
+    return x[:, :, ::2, ::2].contiguous()
+
+
 def conv_bn(conv, bn, x, relu=False, residual=None, skip=False):
     """``[relu](bn(conv(x)) [+ residual])``; ``skip=True``: returns (that, x) where the second is x or an alias of it whose
     gradient is folded into this convolution's grad_input (_ConvBNAct)."""
@@ -308,7 +341,7 @@ def _conv_bn(conv, bn, x, relu=False, residual=None, skip=False, raw=False):
                 and x.dtype == torch.float32):
             # stride-2 1x1 (the downsample branch): a 1x1 convolution of the subsampled input.  MIOpen's fp32 strided
             # kernels run at 13-18 TFLOP/s backward; the quarter-size copy + the split-bf16 GEMMs are ~2x faster
-            xs = x[:, :, ::2, ::2].contiguous()
+            xs = _subsample2(x)
             if conv1x1.applicable(xs, conv.weight):
                 return frozen_bn_act(conv1x1.conv_split(xs, conv.weight), bn, residual, relu)
         return frozen_bn_act(conv(x), bn, residual, relu)

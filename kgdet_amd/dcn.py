@@ -380,7 +380,7 @@ class DeformConvFunction(Function):
         if not grad_output.is_cuda:
             raise NotImplementedError
         if ctx.relu:
-            grad_output = grad_output * (output > 0).to(grad_output.dtype)
+            grad_output = torch.ops.aten.threshold_backward(grad_output, output, 0)     # ReLU backward, one launch
         needs = dict(input=ctx.needs_input_grad[0], offset=ctx.needs_input_grad[1], mask=False,
                      weight=ctx.needs_input_grad[2], bias=False)
         gi, go, _, gw, _ = _backward(input.contiguous(), offset.contiguous(), None, weight, None,
@@ -636,7 +636,7 @@ class DeformConvCatFunction(Function):
         for i in range(n_x):
             grad_out = grad_outs[i]
             if ctx.relu:
-                grad_out = grad_out * (outs[i] > 0).to(grad_out.dtype)
+                grad_out = torch.ops.aten.threshold_backward(grad_out.contiguous(), outs[i], 0)   # ReLU backward, one launch
             gouts.append(grad_out.contiguous())
         need_io = any(need[:n_x + n_k])
         done_io = False

@@ -16,6 +16,9 @@ contract: ``cls_convs.{i}.conv|gn``, ``kp_rep_block_{1,2,3}.{cls,keypts}_dfmconv
 """
 from __future__ import division
 
+import ctypes
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -37,6 +40,40 @@ def _base_offset(k):
     base = np.arange(-pad, pad + 1).astype(np.float64)
     yx = np.stack([np.repeat(base, k), np.tile(base, k)], axis=1).reshape(-1)
     return torch.tensor(yx).view(1, -1, 1, 1)
+
+
+_FUSED_OFFSETS = os.environ.get('KGDET_FUSED_OFFSETS', '1') == '1'     # 0: the torch chain (A/B)
+
+
+class _RepOffsets(torch.autograd.Function):
+    """reppoints [B, >= 166, H, W] -> the three offset tensors of a Kp3RepBlock; the value is the reference's
+    ``gm * part + (1 - gm) * part.detach() - base`` expression, the gradient ``gm * grad`` (csrc/glue.hip)"""
+
+    @staticmethod
+    def forward(ctx, reppts, gm):
+        from . import _lib
+        reppts = reppts.contiguous()
+        B, C, H, W = reppts.shape
+        ks = (ctypes.c_int32 * 3)(*_KERNELS)
+        outs = [reppts.new_empty(B, 2 * k * k, H, W) for k in _KERNELS]
+        _lib.check(_lib.lib().kgdet_reppts_offsets_forward(
+            _lib.ptr(reppts), ctypes.c_int32(B), ctypes.c_int32(C), ctypes.c_int32(H * W), ks, ctypes.c_float(gm),
+            _lib.ptr(outs[0]), _lib.ptr(outs[1]), _lib.ptr(outs[2]), _lib.current_stream()), 'reppts_offsets_forward')
+        ctx.gm, ctx.shape = gm, (B, C, H, W)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        from . import _lib
+        B, C, H, W = ctx.shape
+        gs = [None if g is None else g.contiguous() for g in (g0, g1, g2)]
+        like = next(g for g in gs if g is not None)
+        grad = like.new_empty(B, C, H, W)
+        ks = (ctypes.c_int32 * 3)(*_KERNELS)
+        _lib.check(_lib.lib().kgdet_reppts_offsets_backward(
+            _lib.ptr(gs[0]), _lib.ptr(gs[1]), _lib.ptr(gs[2]), ctypes.c_int32(B), ctypes.c_int32(C), ctypes.c_int32(H * W), ks,
+            ctypes.c_float(ctx.gm), _lib.ptr(grad), _lib.current_stream()), 'reppts_offsets_backward')
+        return grad, None
 
 
 class Kp3RepBlock(nn.Module):
@@ -86,6 +123,9 @@ class Kp3RepBlock(nn.Module):
 
     def _dcn_offsets(self, reppts_offset, like):
         """per kernel size: gradient-scaled reppoints minus the regular grid (KP3:131-143)"""
+        if (_FUSED_OFFSETS and reppts_offset.is_cuda and reppts_offset.dtype == torch.float32
+                and not torch.is_autocast_enabled()):
+            return list(_RepOffsets.apply(reppts_offset, float(self.gradient_mul)))     # one HIP pass each way (csrc/glue.hip)
         offsets, start = [], 0
         for k, n in zip(_KERNELS, _GROUP_POINTS):
             part = reppts_offset[:, 2 * start:2 * (start + n), :, :]

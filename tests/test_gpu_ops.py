@@ -456,3 +456,43 @@ def test_fused_group_norm_relu_matches_torch(N, C, G, H, W, relu):
         finally:
             layers.FUSED_GN = True
     assert (got - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+
+
+def test_glue_kernels_match_the_torch_chain():
+    """csrc/glue.hip: (a) the offsets of a Kp3RepBlock from the previous stage's reppoints -- value bit-identical to the
+    reference expression gm * part + (1 - gm) * part.detach() - base (KP3:131-143), gradient gm * grad -- and (b) the
+    stride-2 subsample + its zero-stuffing backward, against the torch ops they replace."""
+    import kgdet_amd.heads as H
+    from kgdet_amd.backbone import _subsample2
+    from kgdet_amd.registry import build_head
+    g = torch.Generator().manual_seed(0)
+    blk = build_head(configs_kgdet().model.bbox_head).kp_rep_block_2.cuda()
+    for C in (166, 170):
+        x = (torch.randn(2, C, 25, 42, generator=g) * 3).cuda()
+        gos = [torch.randn(2, 2 * k * k, 25, 42, generator=g).cuda() for k in (3, 5, 7)]
+        res = {}
+        for fused in (True, False):
+            H._FUSED_OFFSETS = fused
+            try:
+                xi = x.clone().requires_grad_()
+                offs = blk._dcn_offsets(xi, xi)
+                torch.autograd.backward(offs, gos)
+                res[fused] = ([o.detach() for o in offs], xi.grad.clone())
+            finally:
+                H._FUSED_OFFSETS = True
+        for a, b in zip(res[True][0], res[False][0]):
+            assert a.is_contiguous() and torch.equal(a, b)
+        assert torch.equal(res[True][1], res[False][1])
+    x = torch.randn(2, 8, 50, 84, generator=g).cuda().requires_grad_()
+    y = _subsample2(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xr = x.detach().clone().requires_grad_()
+    yr = xr[:, :, ::2, ::2].contiguous()
+    yr.backward(gy)
+    assert torch.equal(y, yr) and torch.equal(x.grad, xr.grad)
+
+
+def configs_kgdet():
+    from kgdet_amd import configs
+    return configs.kgdet_r50_fpn()

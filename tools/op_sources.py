@@ -20,13 +20,13 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     for _ in range(2): step()
     torch.cuda.synchronize()
-want = ('aten::copy_', 'aten::fill_', 'aten::add', 'aten::add_', 'aten::mul', 'aten::zero_', 'aten::contiguous', 'aten::clone', 'aten::zeros', 'aten::zeros_like')
+want = None
 agg = collections.defaultdict(lambda: [0, 0.0])
 for e in prof.events():
-    if e.name in want and e.device_time_total > 0:
+    if e.name.startswith('aten::') and e.device_time_total > 0 and not e.name.startswith(('aten::conv', 'aten::_conv', 'aten::miopen', 'aten::cudnn')):
         key = (e.name, str([list(s) for s in (e.input_shapes or []) if s][:2]))
         agg[key][0] += 1
         agg[key][1] += e.device_time_total
-rows = sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]
+rows = sorted(agg.items(), key=lambda kv: -kv[1][1])[:70]
 for (name, where), (n, t) in rows:
     print('%7.1f us  %4d x  %-16s %s' % (t / 2, n // 2, name, where))
