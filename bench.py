@@ -440,23 +440,35 @@ def main():
         exposed, reducer_stats = None, None
         if dist_on and args.mode == 'train':
             red = hook._reducer
-            reducer_stats = (len(red.buckets), red.launched_from_hooks) if red is not None and red.buckets else None
-            # what the exchange costs the step although it runs under backward: the same window with the exchange
-            # switched off (local gradients only; AFTER the measurement, the weights diverge from here on)
-            hook.set_local_only(True)
+            if red is not None and red.buckets:
+                before = red.launched_from_hooks
+                for _ in range(2):
+                    step()
+                reducer_stats = (len(red.buckets), (red.launched_from_hooks - before) / 2.0)
+            # what the exchange costs the step although it runs under backward: windows with the exchange switched off
+            # (local gradients only) ALTERNATING with windows with it -- the clock drifts down while the board heats up,
+            # so the two sets must interleave.  AFTER the measurement: the weights diverge between ranks from here on.
+            t_local, t_dist = [], []
             for _ in range(3):
-                step()
-            local = sorted(timed_window() for _ in range(3))[1]
-            hook.set_local_only(False)
-            exposed = (sorted(windows)[len(windows) // 2] - local) / args.steps
+                hook.set_local_only(True)
+                for _ in range(2):
+                    step()
+                t_local.append(timed_window())
+                hook.set_local_only(False)
+                for _ in range(2):
+                    step()
+                t_dist.append(timed_window())
+            exposed = (sorted(t_dist)[1] - sorted(t_local)[1]) / args.steps
     dt = sorted(windows)[len(windows) // 2]
 
     ar = allreduce_busbw(device, world) if (dist_on and args.mode == 'train') else None
     if ar is not None:
         ar['exposed_ms'] = round(exposed * 1e3, 3)
-        ar['exposed_note'] = 'median step time with the overlapped exchange minus the same step without it'
+        ar['exposed_note'] = ('median step time with the overlapped exchange minus the same step without it, three '
+                              'alternating pairs of windows (at one rank the collective is a no-op: this is the cost of '
+                              'the bucket copies and the side stream)')
         ar['buckets'] = reducer_stats[0] if reducer_stats else None
-        ar['launched_inside_backward'] = reducer_stats[1] if reducer_stats else None
+        ar['buckets_issued_inside_backward_per_step'] = reducer_stats[1] if reducer_stats else None
     if rank == 0:
         imgs = args.imgs_per_gpu * world * args.steps
         out = {
@@ -468,7 +480,7 @@ def main():
             'windows': {'n': len(windows), 'steps_each': args.steps, 'statistic': 'median',
                         'img_s': [round(imgs / w, 1) for w in windows],
                         'min': round(imgs / max(windows), 1), 'max': round(imgs / min(windows), 1)},
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 (bf16x3 split products, f32 accumulate)' if args.dtype == 'fp32'
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 (3 MFMA products per multiply on hi/lo-split operands -- fp16 parts forward, bf16 parts for gradients --, f32 accumulate)' if args.dtype == 'fp32'
             else 'bf16 (dense convs and deformable operands, f32 accumulate)',
             'data': 'synthetic',
             'config': {'workload': '%s R50-FPN %s step, %d img/GPU at 800x1333 (padded 800x1344), '

@@ -39,6 +39,21 @@ extern "C" {
  *                       (per-chunk partial tiles added in fixed order); workspace from the _workspace_bytes query. */
 size_t kgdet_conv_packed_bytes(int32_t M, int32_t K, int32_t taps);
 int kgdet_conv_pack(const float *w, int32_t O, int32_t C, int32_t taps, int32_t transpose, void *packed, void *stream);
+/* operand_format of the *_fmt entry points: 0 = two bf16 parts per fp32 value (16 mantissa bits; every gradient operand),
+ * 1 = two fp16 parts (22 bits, fp32-class results at the same MFMA rate) for FORWARD operands -- activations and weights lie
+ * inside fp16's range, values beyond 65504 saturate.  An image packed with format f must be applied with format f; only
+ * forward images (transpose = 0) take format 1.  kgdet_conv_pack_multi: bit 62 of a descriptor's last word selects
+ * format 1 for that row's forward image.  The plain entry points are format 0. */
+int kgdet_conv_pack_fmt(const float *w, int32_t O, int32_t C, int32_t taps, int32_t transpose, void *packed,
+                        int32_t operand_format, void *stream);
+int kgdet_conv_pack_both_fmt(const float *w, int32_t O, int32_t C, int32_t taps, void *packed, void *packed_t,
+                             int32_t forward_format, void *stream);
+int kgdet_conv_apply_epilogue_fmt(const void *packed, const float *x, float *y, const float *bias, const float *residual,
+                                  int32_t relu, int64_t B, int32_t M, int32_t K, int32_t H, int32_t W, int32_t taps,
+                                  int32_t stride, int32_t operand_format, void *workspace, size_t workspace_bytes,
+                                  void *stream);
+int kgdet_stem_conv7x7_s2_fmt(const void *packed, const float *x, float *y, int64_t B, int32_t H, int32_t W,
+                              int32_t operand_format, void *stream);
 /* forward and grad_input images of one weight in one launch (O and C multiples of 16) */
 int kgdet_conv_pack_both(const float *w, int32_t O, int32_t C, int32_t taps, void *packed, void *packed_t, void *stream);
 /* Both images of n weights in ONE launch (training re-packs every weight every step).  desc_dev: device table of n x 5

@@ -43,9 +43,9 @@ def _stem_conv(conv, x):
         from . import _lib
         B, _, H, W = x.shape
         y = torch.empty((B, 64, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
-        _lib.check(_lib.lib().kgdet_stem_conv7x7_s2(
+        _lib.check(_lib.lib().kgdet_stem_conv7x7_s2_fmt(
             _lib.ptr(hit[1]), _lib.ptr(x), _lib.ptr(y), ctypes.c_int64(B), ctypes.c_int32(H), ctypes.c_int32(W),
-            _lib.current_stream()), 'stem_conv7x7_s2')
+            ctypes.c_int32(1 if getattr(hit[1], 'kgdet_f16', False) else 0), _lib.current_stream()), 'stem_conv7x7_s2')
         return y
     return conv(x).contiguous()
 

@@ -48,13 +48,13 @@ def _lib_sizes():
                 ('kgdet_conv_apply_workspace_bytes', sz, [i64, i32, i32, i32, i32, i32, i32]),
                 ('kgdet_conv1x1_grad_weight_workspace_bytes', sz, [i64, i32, i32, i64]),
                 ('kgdet_conv3x3_grad_weight_workspace_bytes', sz, [i64, i32, i32, i32, i32]),
-                ('kgdet_conv_pack', ctypes.c_int, [vp, i32, i32, i32, i32, vp, vp]),
-                ('kgdet_conv_pack_both', ctypes.c_int, [vp, i32, i32, i32, vp, vp, vp]),
+                ('kgdet_conv_pack_fmt', ctypes.c_int, [vp, i32, i32, i32, i32, vp, i32, vp]),
+                ('kgdet_conv_pack_both_fmt', ctypes.c_int, [vp, i32, i32, i32, vp, vp, i32, vp]),
                 ('kgdet_conv_pack_blocks', i64, [i32, i32, i32]),
                 ('kgdet_conv_pack_multi', ctypes.c_int, [vp, i32, i64, vp]),
                 ('kgdet_conv_apply', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
-                ('kgdet_conv_apply_epilogue', ctypes.c_int,
-                 [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+                ('kgdet_conv_apply_epilogue_fmt', ctypes.c_int,
+                 [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
                 ('kgdet_conv3x3_s2_grad_input', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i32, i32, vp]),
                 ('kgdet_conv1x1_grad_weight', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i64, vp, sz, vp]),
                 ('kgdet_conv3x3_grad_weight', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i32, i32, vp, sz, vp])):
@@ -76,15 +76,28 @@ def _stream():
     return _lib.raw_stream()
 
 
+# Operand format of the FORWARD images (activations x weights): two fp16 parts (22 mantissa bits, fp32-class results) instead of
+# two bf16 parts (16 bits) -- csrc/conv1x1.hip split_pair_t.  The packed tensor carries the format as an attribute
+# (`kgdet_f16`), `_apply` reads it; transposed (grad_input) images and the weight-gradient kernels stay bf16: gradients need
+# the exponent range.  KGDET_CONV_FWD_F16=0: bf16 parts everywhere (A/B, and round 2's arithmetic).
+FORWARD_F16 = _os.environ.get('KGDET_CONV_FWD_F16', '1') == '1'
+
+
+def _mark(img, f16):
+    img.kgdet_f16 = bool(f16)
+    return img
+
+
 def _pack(weight, transpose):
     """weight [O, C, k, k] -> operand image (forward: rows O; transpose: rows C with mirrored taps)"""
     L = _lib_sizes()
     O, C, taps = weight.shape[0], weight.shape[1], weight.shape[2] * weight.shape[3]
     M, K = (C, O) if transpose else (O, C)
     img = torch.empty(_size('kgdet_conv_packed_bytes', M, K, taps), dtype=torch.uint8, device=weight.device)
-    _lib.check(L.kgdet_conv_pack(weight.data_ptr(), O, C, taps, 1 if transpose else 0, img.data_ptr(), _stream()),
-               'conv_pack')
-    return img
+    f16 = FORWARD_F16 and not transpose
+    _lib.check(L.kgdet_conv_pack_fmt(weight.data_ptr(), O, C, taps, 1 if transpose else 0, img.data_ptr(), 1 if f16 else 0,
+                                     _stream()), 'conv_pack')
+    return _mark(img, f16)
 
 
 def _pack_both(weight):
@@ -93,9 +106,9 @@ def _pack_both(weight):
     O, C, taps = weight.shape[0], weight.shape[1], weight.shape[2] * weight.shape[3]
     img = torch.empty(_size('kgdet_conv_packed_bytes', O, C, taps), dtype=torch.uint8, device=weight.device)
     img_t = torch.empty(_size('kgdet_conv_packed_bytes', C, O, taps), dtype=torch.uint8, device=weight.device)
-    _lib.check(L.kgdet_conv_pack_both(weight.data_ptr(), O, C, taps, img.data_ptr(), img_t.data_ptr(), _stream()),
-               'conv_pack_both')
-    return img, img_t
+    _lib.check(L.kgdet_conv_pack_both_fmt(weight.data_ptr(), O, C, taps, img.data_ptr(), img_t.data_ptr(),
+                                          1 if FORWARD_F16 else 0, _stream()), 'conv_pack_both')
+    return _mark(img, FORWARD_F16), _mark(img_t, False)
 
 
 def _apply(img, x, M, taps, stride=1, bias=None, residual=None, relu=False):
@@ -105,10 +118,10 @@ def _apply(img, x, M, taps, stride=1, bias=None, residual=None, relu=False):
     y = torch.empty((B, M, (H + stride - 1) // stride, (W + stride - 1) // stride), dtype=torch.float32, device=x.device)
     nbytes = _size('kgdet_conv_apply_workspace_bytes', B, M, K, H, W, taps, stride)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
-    _lib.check(L.kgdet_conv_apply_epilogue(
+    _lib.check(L.kgdet_conv_apply_epilogue_fmt(
         img.data_ptr(), x.data_ptr(), y.data_ptr(), bias.data_ptr() if bias is not None else None,
         residual.data_ptr() if residual is not None else None, 1 if relu else 0, B, M, K, H, W, taps, stride,
-        ws.data_ptr() if nbytes else None, nbytes, _stream()), 'conv_apply')
+        1 if getattr(img, 'kgdet_f16', False) else 0, ws.data_ptr() if nbytes else None, nbytes, _stream()), 'conv_apply')
     return y
 
 
@@ -144,7 +157,9 @@ def _launch_multi():
         for _, e in live:
             w = e.ref()
             O, C, taps = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
-            rows.append([w.data_ptr(), e.img.data_ptr(), e.img_t.data_ptr(), (O << 32) | C, (taps << 32) | first])
+            # (bit 62 of the last word: the forward image in fp16 parts)
+            rows.append([w.data_ptr(), e.img.data_ptr(), e.img_t.data_ptr(), (O << 32) | C,
+                         (taps << 32) | first | ((1 << 62) if getattr(e.img, 'kgdet_f16', False) else 0)])
             first += L.kgdet_conv_pack_blocks(O, C, taps)
         dev = live[0][1].img.device
         _table = (key, torch.tensor(rows, dtype=torch.int64).to(dev), first)   # (one upload per change of the set)
@@ -177,9 +192,10 @@ def forward_images(x, weight):
         e = _entries.get(id(weight))
         if e is not None and e.ref() is weight and e.ptr == weight.data_ptr():
             if e.token != _token:       # joined the set after this scope's pack launch
-                _lib.check(_lib_sizes().kgdet_conv_pack_both(weight.data_ptr(), weight.shape[0], weight.shape[1],
-                                                             weight.shape[2] * weight.shape[3], e.img.data_ptr(),
-                                                             e.img_t.data_ptr(), _stream()), 'conv_pack_both')
+                _lib.check(_lib_sizes().kgdet_conv_pack_both_fmt(weight.data_ptr(), weight.shape[0], weight.shape[1],
+                                                                 weight.shape[2] * weight.shape[3], e.img.data_ptr(),
+                                                                 e.img_t.data_ptr(), 1 if getattr(e.img, 'kgdet_f16', False) else 0,
+                                                                 _stream()), 'conv_pack_both')
                 e.token = _token
             return e.img, e.img_t
         img, img_t = _pack_both(weight)

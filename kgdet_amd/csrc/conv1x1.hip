@@ -63,6 +63,53 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8 &hi, bf16x8 &
   lo = __builtin_bit_cast(bf16x8, l);
 }
 
+// FORWARD operands (activations x weights) can be split into two fp16 parts instead of two bf16 parts: 22 mantissa bits
+// instead of 16 at the same MFMA rate (v_mfma_f32_32x32x16_f16) and the same five conversion instructions per pair
+// (v_cvt_pkrtz_f16_f32: the truncation is exact for the hi part's remainder and leaves <= 2^-21 after the lo part).
+// Round 3 (tests/golden/make_step_golden.py): against a float64 evaluation of the training step the bf16 split left
+// 1.4e-3 on gradient norms and 1.2e-2 on single gradient elements of the classification tower -- all of it from the
+// FORWARD features' 5e-6..9e-6 (tools/step_vs_f64.py KGDET_EXP=fwd_exact: 7e-6 with an fp32 forward and the split backward).
+// Activations and weights sit inside fp16's range; gradients do not (1e-8 and below), so grad_input / grad_weight
+// operands stay bf16 (8 exponent bits).  Values beyond 65504 saturate, below 6e-8 vanish.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16>
+__device__ __forceinline__ void split_pair_t(float v0, float v1, unsigned &hi, unsigned &lo) {
+  if constexpr (!F16) {
+    split_pair(v0, v1, hi, lo);
+  } else {
+    // hi: truncation (v_cvt_pkrtz_f16_f32; the remainder v - hi is exact either way); lo: round to nearest even
+    // (v_cvt_pk_f16_f32 on gfx950) -- truncating both left a bias of -2^-22 per operand that grew to -1.4e-6 of the rms
+    // over the backbone's 50 layers
+    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0, v1));
+    const f32x2 hf = __builtin_convertvector(__builtin_bit_cast(f16x2, hi), f32x2);
+    const f32x2 r = {v0 - hf[0], v1 - hf[1]};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+  }
+}
+template <bool F16>
+__device__ __forceinline__ void split8_t(const float (&v)[8], bf16x8 &hi, bf16x8 &lo) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 h, l;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned a, b;
+    split_pair_t<F16>(v[2 * i], v[2 * i + 1], a, b);
+    h[i] = a;
+    l[i] = b;
+  }
+  hi = __builtin_bit_cast(bf16x8, h);
+  lo = __builtin_bit_cast(bf16x8, l);
+}
+// (bf16x8 is the 16-byte container of either format)
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_t(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 // one stage of MFMAs: wave (wm, wn) multiplies its 64 x 64 block; operands from LDS stage buffers
 __device__ __forceinline__ void mma_stage(const unsigned char *As, const unsigned char *Bs, int lane, int wm, int wn,
                                           f32x16 (&acc)[2][2]) {
@@ -101,11 +148,13 @@ __device__ __forceinline__ int xcd_tile(int b, int tiles) {
 // gridDim.y == 2: block row 0 writes the forward image to img, row 1 the grad_input image to img_t (one launch per
 // convolution and step instead of two).
 __global__ __launch_bounds__(256) void conv1x1_pack(const float *__restrict__ w, int O, int C, int T, int transpose,
-                                                    unsigned char *__restrict__ img, unsigned char *__restrict__ img_t) {
+                                                    unsigned char *__restrict__ img, unsigned char *__restrict__ img_t,
+                                                    int f16_forward) {
   if (gridDim.y == 2) {
     transpose = blockIdx.y;
     img = blockIdx.y ? img_t : img;
   }
+  const bool f16 = f16_forward && !transpose;     // only the forward image (activations x weights) takes fp16 parts
   const int M = transpose ? C : O, K = transpose ? O : C;
   const int k16s = K / kTK;
   const long long total = (long long)((M + kTM - 1) / kTM) * k16s * T * 2 * kTM;   // (mt, k16, t, khalf, row)
@@ -123,7 +172,7 @@ __global__ __launch_bounds__(256) void conv1x1_pack(const float *__restrict__ w,
       v[j] = m < M ? w[(o * C + ch) * T + (transpose ? T - 1 - t : t)] : 0.0f;
     }
     bf16x8 hi, lo;
-    split8(v, hi, lo);
+    if (f16) split8_t<true>(v, hi, lo); else split8(v, hi, lo);
     unsigned char *dst = img + st * kStage + khalf * (kTM * 16) + row * 16;
     *reinterpret_cast<bf16x8 *>(dst) = hi;
     *reinterpret_cast<bf16x8 *>(dst + kPart) = lo;
@@ -141,7 +190,8 @@ __global__ __launch_bounds__(256) void conv1x1_pack_multi(const long long *__res
   }
   const long long *d = desc + lo * 5;
   const float *w = reinterpret_cast<const float *>(d[0]);
-  const int O = (int)(d[3] >> 32), C = (int)(d[3] & 0xffffffffLL), T = (int)(d[4] >> 32);
+  const int O = (int)(d[3] >> 32), C = (int)(d[3] & 0xffffffffLL), T = (int)((d[4] >> 32) & 0xffff);
+  const bool f16_forward = (d[4] >> 62) & 1;     // forward image in fp16 parts
   const long long i = (long long)((int)blockIdx.x - (int)(d[4] & 0xffffffffLL)) * 256 + threadIdx.x;
 #pragma unroll
   for (int transpose = 0; transpose < 2; ++transpose) {
@@ -171,7 +221,7 @@ __global__ __launch_bounds__(256) void conv1x1_pack_multi(const long long *__res
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = m < M ? r[j * 9 + t] : 0.0f;
         bf16x8 hi8, lo8;
-        split8(v, hi8, lo8);
+        if (f16_forward) split8_t<true>(v, hi8, lo8); else split8(v, hi8, lo8);
         unsigned char *dst = img + (s2 * 9 + t) * kStage + khalf * (kTM * 16) + row * 16;
         *reinterpret_cast<bf16x8 *>(dst) = hi8;
         *reinterpret_cast<bf16x8 *>(dst + kPart) = lo8;
@@ -192,7 +242,7 @@ __global__ __launch_bounds__(256) void conv1x1_pack_multi(const long long *__res
       v[j] = m < M ? w[(o * C + ch) * T + (transpose ? T - 1 - t : t)] : 0.0f;
     }
     bf16x8 hi8, lo8;
-    split8(v, hi8, lo8);
+    if (f16_forward && !transpose) split8_t<true>(v, hi8, lo8); else split8(v, hi8, lo8);
     unsigned char *dst = img + st * kStage + khalf * (kTM * 16) + row * 16;
     *reinterpret_cast<bf16x8 *>(dst) = hi8;
     *reinterpret_cast<bf16x8 *>(dst + kPart) = lo8;
@@ -215,7 +265,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // NW = 4 | 5 waves along the pixels: tiles of 128 or 160 pixels (640 threads).  A CU finishes a tile at a fixed rate whatever
 // shares it (see conv3x3_patch4), so what counts is the number of tiles the fullest CU draws: [2, 128, 100 x 168] is 264 tiles of
 // 128 pixels (sixteen CUs draw two) but 210 of 160.
-template <int TAPS, int NW = 4>
+template <int TAPS, int NW = 4, bool F16 = false>
 __global__ __launch_bounds__(128 * NW) void conv_nn(const unsigned char *__restrict__ img,
                                                       const float *__restrict__ x, float *__restrict__ y, int M, int K,
                                                       int H, int W, int n_mt, int n_nt, int tiles, int ksplit,
@@ -286,8 +336,8 @@ __global__ __launch_bounds__(128 * NW) void conv_nn(const unsigned char *__restr
 #ifdef KGDET_CONV_ABL_NOSPLIT   // ablation (timing only, wrong results): no conversion VALU
     hi.x = __float_as_uint(R.v[0]); hi.y = __float_as_uint(R.v[1]); lo.x = __float_as_uint(R.v[2]); lo.y = __float_as_uint(R.v[3]);
 #else
-    split_pair(R.live ? R.v[0] : 0.0f, R.live ? R.v[1] : 0.0f, hi.x, lo.x);
-    split_pair(R.live ? R.v[2] : 0.0f, R.live ? R.v[3] : 0.0f, hi.y, lo.y);
+    split_pair_t<F16>(R.live ? R.v[0] : 0.0f, R.live ? R.v[1] : 0.0f, hi.x, lo.x);
+    split_pair_t<F16>(R.live ? R.v[2] : 0.0f, R.live ? R.v[3] : 0.0f, hi.y, lo.y);
 #endif
     unsigned char *dst = Bs + (kq >> 1) * (TN * 16) + n_local * 16 + (kq & 1) * 8;
     *reinterpret_cast<uint2 *>(dst) = hi;
@@ -321,9 +371,9 @@ __global__ __launch_bounds__(128 * NW) void conv_nn(const unsigned char *__restr
 #endif
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {   // small terms first
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][mi], bb[0], acc[mi], 0, 0, 0);
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], bb[1], acc[mi], 0, 0, 0);
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], bb[0], acc[mi], 0, 0, 0);
+      acc[mi] = mfma_t<F16>(a[1][mi], bb[0], acc[mi]);
+      acc[mi] = mfma_t<F16>(a[0][mi], bb[1], acc[mi]);
+      acc[mi] = mfma_t<F16>(a[0][mi], bb[0], acc[mi]);
     }
   };
   {
@@ -612,7 +662,7 @@ __global__ __launch_bounds__(kNNThreads) void conv3x3_patch(const unsigned char 
 // NB = 4 | 5 blocks of 32 pixels per tile: a tile of up to 160 pixels (e.g. 4 x 34) lets [2, *, 100, 168] take 250 tiles --
 // one per CU -- where 128-pixel tiles need 272: a CU finishes a tile in ~28 us whatever shares it, so the 16 CUs that drew
 // two set the time (51 us).
-template <int WAVES, int NB>
+template <int WAVES, int NB, bool F16 = false>
 __global__ __launch_bounds__(64 * WAVES) void conv3x3_patch4(const unsigned char *__restrict__ img,
                                                              const float *__restrict__ x, float *__restrict__ y, int M,
                                                              int K, int H, int W, int n_mt, int tiles_x, int n_nt,
@@ -691,7 +741,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_patch4(const unsigned char
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = p_live[i] ? bv[i][kh * 8 + j] : 0.0f;
         bf16x8 hi, lo;
-        split8(v, hi, lo);
+        split8_t<F16>(v, hi, lo);
         unsigned char *d = b_dst + i * THREADS * 16 + buf * kPatchBuf + kh * (kPatchMax * 16);
         *reinterpret_cast<bf16x8 *>(d) = hi;
         *reinterpret_cast<bf16x8 *>(d + kPatchPart) = lo;
@@ -723,11 +773,11 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_patch4(const unsigned char
         bf[nb][1] = *reinterpret_cast<const bf16x8 *>(bt + b_rd[nb] + kPatchPart);
       }
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AR[t % 3][1], bf[nb][0], acc[nb], 0, 0, 0);
+      for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_t<F16>(AR[t % 3][1], bf[nb][0], acc[nb]);
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AR[t % 3][0], bf[nb][1], acc[nb], 0, 0, 0);
+      for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_t<F16>(AR[t % 3][0], bf[nb][1], acc[nb]);
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AR[t % 3][0], bf[nb][0], acc[nb], 0, 0, 0);
+      for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_t<F16>(AR[t % 3][0], bf[nb][0], acc[nb]);
       __builtin_amdgcn_sched_barrier(0);
       issue_a(s + 3, AR[t % 3]);
       if (t == 6) commit_b((ci + 1) & 1);   // the next chunk's patch (the barrier above freed that buffer)
@@ -904,6 +954,7 @@ __global__ __launch_bounds__(256) void conv3x3_s2_grad_input(const unsigned char
 // wave w = pixels 32 w .. 32 w + 31 of the tile, all 64 rows.  (MIOpen's fp32 Winograd-type kernel for this layer: 220 us.)
 constexpr int kStemTY = 8, kStemTX = 16, kStemPH = 2 * kStemTY + 5, kStemPW = 2 * kStemTX + 5, kStemK = 160;
 
+template <bool F16>
 __global__ __launch_bounds__(256) void stem_conv7x7_s2(const unsigned char *__restrict__ img, const float *__restrict__ x,
                                                        float *__restrict__ y, int H, int W, int Ho, int Wo, int tiles_x,
                                                        int tiles_per_image) {
@@ -945,12 +996,12 @@ __global__ __launch_bounds__(256) void stem_conv7x7_s2(const unsigned char *__re
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = pbase[koff[s * kTK + kh + j]];
     bf16x8 bhi, blo;
-    split8(v, bhi, blo);
+    split8_t<F16>(v, bhi, blo);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {   // small terms first
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][mi], bhi, acc[mi], 0, 0, 0);
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], blo, acc[mi], 0, 0, 0);
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], bhi, acc[mi], 0, 0, 0);
+      acc[mi] = mfma_t<F16>(a[1][mi], bhi, acc[mi]);
+      acc[mi] = mfma_t<F16>(a[0][mi], blo, acc[mi]);
+      acc[mi] = mfma_t<F16>(a[0][mi], bhi, acc[mi]);
     }
   }
   const int oy = oy0 + py, ox = ox0 + px;
@@ -1293,8 +1344,8 @@ extern "C" size_t kgdet_conv_packed_bytes(int32_t M, int32_t K, int32_t taps) {
   return (size_t)((M + kTM - 1) / kTM) * (K / kTK) * taps * kStage;
 }
 
-extern "C" int kgdet_conv_pack(const float *w, int32_t O, int32_t C, int32_t taps, int32_t transpose, void *packed,
-                               void *stream) {
+extern "C" int kgdet_conv_pack_fmt(const float *w, int32_t O, int32_t C, int32_t taps, int32_t transpose, void *packed,
+                                   int32_t operand_format, void *stream) {
   // weight [O, C, taps]; transpose = 0: rows O, reduction C (forward); 1: rows C, reduction O, taps mirrored (grad_input)
   const int M = transpose ? C : O, K = transpose ? O : C;
   KGDET_CHECK_SHAPE(taps == 1 || taps == 9, "taps must be 1 (1x1) or 9 (3x3)");
@@ -1303,13 +1354,18 @@ extern "C" int kgdet_conv_pack(const float *w, int32_t O, int32_t C, int32_t tap
   const long long total = (long long)((M + kTM - 1) / kTM) * (K / kTK) * taps * 2 * kTM;
   const long long blocks = (total + 255) / 256;
   hipLaunchKernelGGL(conv1x1_pack, dim3((unsigned)(blocks > 65535 ? 65535 : blocks)), dim3(256), 0, (hipStream_t)stream, w,
-                     O, C, taps, transpose, (unsigned char *)packed, (unsigned char *)nullptr);
+                     O, C, taps, transpose, (unsigned char *)packed, (unsigned char *)nullptr, operand_format == 1 ? 1 : 0);
   KGDET_CHECK_LAUNCH("conv_pack");
   return KGDET_OK;
 }
 
-extern "C" int kgdet_conv_pack_both(const float *w, int32_t O, int32_t C, int32_t taps, void *packed, void *packed_t,
-                                    void *stream) {
+extern "C" int kgdet_conv_pack(const float *w, int32_t O, int32_t C, int32_t taps, int32_t transpose, void *packed,
+                               void *stream) {
+  return kgdet_conv_pack_fmt(w, O, C, taps, transpose, packed, 0, stream);
+}
+
+extern "C" int kgdet_conv_pack_both_fmt(const float *w, int32_t O, int32_t C, int32_t taps, void *packed, void *packed_t,
+                                        int32_t forward_format, void *stream) {
   KGDET_CHECK_SHAPE(taps == 1 || taps == 9, "taps must be 1 (1x1) or 9 (3x3)");
   KGDET_CHECK_SHAPE(O > 0 && C > 0 && O % kTK == 0 && C % kTK == 0, "O and C must be multiples of 16");
   KGDET_CHECK_SHAPE(w && packed && packed_t, "null pointer");
@@ -1317,9 +1373,15 @@ extern "C" int kgdet_conv_pack_both(const float *w, int32_t O, int32_t C, int32_
   const long long t1 = (long long)((C + kTM - 1) / kTM) * (O / kTK) * taps * 2 * kTM;
   const long long blocks = ((t0 > t1 ? t0 : t1) + 255) / 256;
   hipLaunchKernelGGL(conv1x1_pack, dim3((unsigned)(blocks > 32768 ? 32768 : blocks), 2), dim3(256), 0,
-                     (hipStream_t)stream, w, O, C, taps, 0, (unsigned char *)packed, (unsigned char *)packed_t);
+                     (hipStream_t)stream, w, O, C, taps, 0, (unsigned char *)packed, (unsigned char *)packed_t,
+                     forward_format == 1 ? 1 : 0);
   KGDET_CHECK_LAUNCH("conv_pack_both");
   return KGDET_OK;
+}
+
+extern "C" int kgdet_conv_pack_both(const float *w, int32_t O, int32_t C, int32_t taps, void *packed, void *packed_t,
+                                    void *stream) {
+  return kgdet_conv_pack_both_fmt(w, O, C, taps, packed, packed_t, 0, stream);
 }
 
 extern "C" int64_t kgdet_conv_pack_blocks(int32_t O, int32_t C, int32_t taps) {
@@ -1349,10 +1411,11 @@ extern "C" size_t kgdet_conv_apply_workspace_bytes(int64_t B, int32_t M, int32_t
 extern "C" int kgdet_bias_act(void *x, const float *bias, const void *residual, int64_t N, int32_t C, int64_t HW,
                               int32_t dtype, int32_t relu, int32_t channels_last, void *stream);
 
-extern "C" int kgdet_conv_apply_epilogue(const void *packed, const float *x, float *y, const float *bias,
-                                         const float *residual, int32_t relu, int64_t B, int32_t M, int32_t K,
-                                         int32_t H, int32_t W, int32_t taps, int32_t stride, void *workspace,
-                                         size_t workspace_bytes, void *stream) {
+extern "C" int kgdet_conv_apply_epilogue_fmt(const void *packed, const float *x, float *y, const float *bias,
+                                             const float *residual, int32_t relu, int64_t B, int32_t M, int32_t K,
+                                             int32_t H, int32_t W, int32_t taps, int32_t stride, int32_t operand_format,
+                                             void *workspace, size_t workspace_bytes, void *stream) {
+  const bool f16 = operand_format == 1;      // the image and the on-the-fly split of x in fp16 parts (forward operands)
   KGDET_CHECK_SHAPE(B >= 0 && M > 0 && K > 0 && H >= 0 && W >= 0 && (long long)H * W < (1LL << 30), "bad sizes");
   KGDET_CHECK_SHAPE(taps == 1 || taps == 9, "taps must be 1 (1x1) or 9 (3x3)");
   KGDET_CHECK_SHAPE(stride == 1 || stride == 2, "stride must be 1 or 2");
@@ -1373,20 +1436,25 @@ extern "C" int kgdet_conv_apply_epilogue(const void *packed, const float *x, flo
   }
   const int per = (int)((tiles * ks + 7) / 8);
   float *dst = ks > 1 ? (float *)workspace : y;
-  if (plan.patch && conv_patch_mode() >= 2) {
+  if (plan.patch && (conv_patch_mode() >= 2 || f16)) {
     // fewer than ~1.6 whole-tile workgroups per CU: 64-row halves (twice the workgroups) spread evenly over the CUs
     static const int force_halves = [] { const char *e = getenv("KGDET_CONV_HALVES"); return e ? atoi(e) : -1; }();
     // ... and M <= 64 (layer 1): the second half has no rows and leaves at once instead of multiplying zeros
     const bool halves = force_halves >= 0 ? force_halves != 0 : ((ks == 1 && tiles > 256 && tiles < 400) || M <= 64);
 #define KGDET_P4_ARGS (const unsigned char *)packed, x, dst, M, K, H, W, n_mt, plan.tiles_x, n_nt, (int)tiles, ks, part_stride, \
                       plan.TX, plan.TY, ks > 1 ? nullptr : bias, ks > 1 ? nullptr : residual, ks > 1 ? 0 : relu
+#define KGDET_P4_LAUNCH(WV, NBK, GRID, THR)                                                                                  \
+    do {                                                                                                                     \
+      if (f16) hipLaunchKernelGGL((conv3x3_patch4<WV, NBK, true>), dim3(GRID), dim3(THR), 0, (hipStream_t)stream, KGDET_P4_ARGS); \
+      else hipLaunchKernelGGL((conv3x3_patch4<WV, NBK, false>), dim3(GRID), dim3(THR), 0, (hipStream_t)stream, KGDET_P4_ARGS);    \
+    } while (0)
     if (plan.NB == 5)
-      hipLaunchKernelGGL((conv3x3_patch4<4, 5>), dim3(per * 8), dim3(256), 0, (hipStream_t)stream, KGDET_P4_ARGS);
+      KGDET_P4_LAUNCH(4, 5, per * 8, 256);
     else if (halves)
-      hipLaunchKernelGGL((conv3x3_patch4<2, 4>), dim3((int)((tiles * ks * 2 + 7) / 8) * 8), dim3(128), 0, (hipStream_t)stream,
-                         KGDET_P4_ARGS);
+      KGDET_P4_LAUNCH(2, 4, (int)((tiles * ks * 2 + 7) / 8) * 8, 128);
     else
-      hipLaunchKernelGGL((conv3x3_patch4<4, 4>), dim3(per * 8), dim3(256), 0, (hipStream_t)stream, KGDET_P4_ARGS);
+      KGDET_P4_LAUNCH(4, 4, per * 8, 256);
+#undef KGDET_P4_LAUNCH
 #undef KGDET_P4_ARGS
   } else if (plan.patch) {
     static thread_local bool attr_set = false;
@@ -1401,14 +1469,20 @@ extern "C" int kgdet_conv_apply_epilogue(const void *packed, const float *x, flo
   } else {
 #define KGDET_NN_ARGS (const unsigned char *)packed, x, dst, M, K, Ho, Wo, n_mt, n_nt, (int)tiles, ks, part_stride, H, W, stride, \
                       ks > 1 ? nullptr : bias, ks > 1 ? nullptr : residual, ks > 1 ? 0 : relu
+#define KGDET_NN_LAUNCH(TP, NWK, THR)                                                                                        \
+    do {                                                                                                                     \
+      if (f16) hipLaunchKernelGGL((conv_nn<TP, NWK, true>), dim3(per * 8), dim3(THR), 0, (hipStream_t)stream, KGDET_NN_ARGS);  \
+      else hipLaunchKernelGGL((conv_nn<TP, NWK, false>), dim3(per * 8), dim3(THR), 0, (hipStream_t)stream, KGDET_NN_ARGS);     \
+    } while (0)
     if (taps == 1 && plan.NW == 5)
-      hipLaunchKernelGGL((conv_nn<1, 5>), dim3(per * 8), dim3(640), 0, (hipStream_t)stream, KGDET_NN_ARGS);
+      KGDET_NN_LAUNCH(1, 5, 640);
     else if (taps == 1)
-      hipLaunchKernelGGL((conv_nn<1, 4>), dim3(per * 8), dim3(512), 0, (hipStream_t)stream, KGDET_NN_ARGS);
+      KGDET_NN_LAUNCH(1, 4, 512);
     else if (plan.NW == 5)
-      hipLaunchKernelGGL((conv_nn<9, 5>), dim3(per * 8), dim3(640), 0, (hipStream_t)stream, KGDET_NN_ARGS);
+      KGDET_NN_LAUNCH(9, 5, 640);
     else
-      hipLaunchKernelGGL((conv_nn<9, 4>), dim3(per * 8), dim3(512), 0, (hipStream_t)stream, KGDET_NN_ARGS);
+      KGDET_NN_LAUNCH(9, 4, 512);
+#undef KGDET_NN_LAUNCH
 #undef KGDET_NN_ARGS
   }
   KGDET_CHECK_LAUNCH("conv_nn");
@@ -1421,6 +1495,14 @@ extern "C" int kgdet_conv_apply_epilogue(const void *packed, const float *x, flo
       return kgdet_bias_act(y, bias, residual, B, M, HW, 0, relu, 0, stream);
   }
   return KGDET_OK;
+}
+
+extern "C" int kgdet_conv_apply_epilogue(const void *packed, const float *x, float *y, const float *bias,
+                                         const float *residual, int32_t relu, int64_t B, int32_t M, int32_t K,
+                                         int32_t H, int32_t W, int32_t taps, int32_t stride, void *workspace,
+                                         size_t workspace_bytes, void *stream) {
+  return kgdet_conv_apply_epilogue_fmt(packed, x, y, bias, residual, relu, B, M, K, H, W, taps, stride, 0, workspace,
+                                       workspace_bytes, stream);
 }
 
 extern "C" int kgdet_conv3x3_s2_grad_input(const void *packed_t, const float *grad_y, float *grad_x, int64_t B, int32_t C,
@@ -1449,8 +1531,8 @@ extern "C" int kgdet_conv3x3_s2_grad_input(const void *packed_t, const float *gr
   return KGDET_OK;
 }
 
-extern "C" int kgdet_stem_conv7x7_s2(const void *packed, const float *x, float *y, int64_t B, int32_t H, int32_t W,
-                                     void *stream) {
+extern "C" int kgdet_stem_conv7x7_s2_fmt(const void *packed, const float *x, float *y, int64_t B, int32_t H, int32_t W,
+                                         int32_t operand_format, void *stream) {
   // packed: kgdet_conv_pack of the [64, 3, 7, 7] weight flattened to [64, 147] and zero-padded to [64, 160] (taps = 1,
   // transpose = 0); x [B, 3, H, W] -> y [B, 64, (H - 1) / 2 + 1, (W - 1) / 2 + 1]
   KGDET_CHECK_SHAPE(B >= 0 && H > 0 && W > 0, "bad sizes");
@@ -1459,10 +1541,19 @@ extern "C" int kgdet_stem_conv7x7_s2(const void *packed, const float *x, float *
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const int tiles_x = (Wo + kStemTX - 1) / kStemTX, tiles_per_image = tiles_x * ((Ho + kStemTY - 1) / kStemTY);
   KGDET_CHECK_SHAPE((long long)B * tiles_per_image < (1LL << 31), "too many tiles");
-  hipLaunchKernelGGL(stem_conv7x7_s2, dim3((unsigned)(B * tiles_per_image)), dim3(256), 0, (hipStream_t)stream,
-                     (const unsigned char *)packed, x, y, H, W, Ho, Wo, tiles_x, tiles_per_image);
+  if (operand_format == 1)
+    hipLaunchKernelGGL(stem_conv7x7_s2<true>, dim3((unsigned)(B * tiles_per_image)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned char *)packed, x, y, H, W, Ho, Wo, tiles_x, tiles_per_image);
+  else
+    hipLaunchKernelGGL(stem_conv7x7_s2<false>, dim3((unsigned)(B * tiles_per_image)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned char *)packed, x, y, H, W, Ho, Wo, tiles_x, tiles_per_image);
   KGDET_CHECK_LAUNCH("stem_conv7x7_s2");
   return KGDET_OK;
+}
+
+extern "C" int kgdet_stem_conv7x7_s2(const void *packed, const float *x, float *y, int64_t B, int32_t H, int32_t W,
+                                     void *stream) {
+  return kgdet_stem_conv7x7_s2_fmt(packed, x, y, B, H, W, 0, stream);
 }
 
 extern "C" int kgdet_conv_apply(const void *packed, const float *x, float *y, int64_t B, int32_t M, int32_t K, int32_t H,

@@ -387,8 +387,9 @@ def test_full_size_training_step_split_arithmetic_matches_exact_fp32():
     """One full-size (2 x 800x1344) training step under the default arithmetic (bf16 hi/lo split products, fp32
     accumulate, in the deformable kernels AND the backbone's dense convolutions) against the same step in plain
     fp32 arithmetic (dcn.arithmetic('exact'): f32-input MFMA deformable kernels, MIOpen fp32 convolutions):
-    the nine losses to 1e-4, the gradient norm of every top-level module group to 2e-3 (measured: every group
-    within 1e-3 except backbone.layer3, the deepest accumulated path, at 1.05e-3)."""
+    the nine losses to 1e-4, the gradient norm of every top-level module group to BASELINE.md's 1e-3 (round 2 needed 2e-3
+    here: 1.05e-3 .. 1.35e-3 on the backbone groups with bf16 parts for the forward operands; with fp16 parts -- see
+    test_full_size_training_step_matches_float64 -- the groups agree to ~1e-4)."""
     from kgdet_amd import dcn
     from kgdet_amd.registry import build_detector
     cfg = configs.kgdet_r50_fpn()
@@ -418,7 +419,7 @@ def test_full_size_training_step_split_arithmetic_matches_exact_fp32():
     assert set(g_split) == set(g_exact) and len(g_exact) > 10
     worst = max(abs(g_split[k] - g_exact[k]) / max(g_exact[k], 1e-12) for k in g_exact)
     print({k: '%.2e' % (abs(g_split[k] - g_exact[k]) / max(g_exact[k], 1e-12)) for k in sorted(g_exact)})
-    assert worst <= 2e-3, (worst, {k: (g_split[k], g_exact[k]) for k in g_exact
+    assert worst <= 1e-3, (worst, {k: (g_split[k], g_exact[k]) for k in g_exact
                                    if abs(g_split[k] - g_exact[k]) > 1e-3 * g_exact[k]})
 
 
@@ -567,19 +568,17 @@ def test_full_size_training_step_matches_float64(mode, golden_dir):
     """The bench workload's training step (2 x 800 x 1344, seeds 0) on the HIP path against a FLOAT64 evaluation of the
     same graph (tests/golden/make_step_golden.py: this repo's host graph on the CPU, grid_sample formulation of the
     deformable ops, everything in double) -- a ground truth instead of the comparison of two approximations.
-    Measured (round 3, tools/step_vs_f64.py, tools/backbone_fwd_dev.py):
-      losses                      1e-6 in both arithmetic modes;
-      forward features            rel. L2 4.7e-6 (layer1) .. 8.9e-6 (layer4) split vs MIOpen fp32, no bias;
-      gradient norm per group     split <= 1.4e-3 (backbone.layer2), 'exact' (MIOpen fp32 + f32 MFMA) <= 2e-5;
-      sampled gradient elements   split 1.2e-2 of the slice maximum on bbox_head.cls_convs.0.conv.weight, 5.7e-3 on
-                                  neck.lateral_convs.2; 'exact' 1.5e-4 / 2.2e-4; deformable weights 7.5e-6 / 1.3e-6.
-    The focal-loss gradient of the classification tower is a small difference of large sums: fp32 arithmetic (1.2e-7 per
-    operation) already shows 1.5e-4 there, and the hi/lo-split products (2^-17.5 per product, 60x coarser) show 60x more.
-    The same tensors set the group norms (bn3.weight of the zero-initialised residual branches are the only backbone
-    weights with a gradient at initialisation).  Switching single pieces to fp32 (KGDET_EXP=... in tools/step_vs_f64.py)
-    shows that the deformable kernels contribute <= 6e-5 and the backbone's FORWARD features -- accurate to 9e-6 -- the
-    rest: conditioning, not a defect, and not ReLU decisions (round 2's explanation).  The bounds below are those
-    measurements with head room; BASELINE.md's 1e-3 holds for the fp32 mode and for every deformable-kernel gradient."""
+    History of this comparison (round 3, tools/step_vs_f64.py, tools/backbone_fwd_dev.py): with bf16 hi/lo parts for EVERY
+    operand (round 2's arithmetic, KGDET_CONV_FWD_F16=0) the step missed BASELINE.md's 1e-3 on gradients: group norms up to
+    1.4e-3 (backbone.layer2), single elements of bbox_head.cls_convs.0.conv.weight 1.2e-2 of the tensor's maximum, against
+    2e-5 / 1.5e-4 for the fp32 mode.  Round 2 had put the split-vs-fp32 gap down to ReLU decisions; switching single pieces
+    to fp32 (KGDET_EXP=...) showed instead that ALL of it came from the forward features of the dense convolutions --
+    accurate to 4.7e-6 .. 8.9e-6, which the focal-loss gradient of the classification tower (a small difference of large
+    sums: amplification ~1000, fp32 itself shows 1.5e-4 there) turns into percents -- and nothing from the split backward or
+    the deformable kernels (<= 6e-5).  The FORWARD operands of the dense convolutions are therefore split into two fp16 parts
+    now (22 mantissa bits, same MFMA rate and instruction count, csrc/conv1x1.hip split_pair_t): forward features 3.4e-7 ..
+    1.2e-6 against MIOpen fp32, gradient norms of every parameter tensor within 3.3e-5 of float64, no measurable cost
+    (141.5 vs 142.5 img/s, same box).  The bounds below are those measurements with head room; BASELINE.md's 1e-3 holds for the fp32 mode and for every deformable-kernel gradient."""
     from kgdet_amd import dcn
     from kgdet_amd.registry import build_detector
     G = np.load(os.path.join(golden_dir, 'step_f64_golden.npz'))
@@ -604,7 +603,7 @@ def test_full_size_training_step_matches_float64(mode, golden_dir):
     dev = {k: abs(v ** 0.5 - float(G['group:' + k])) / float(G['group:' + k]) for k, v in groups.items()}
     print(mode, {k: '%.1e' % v for k, v in sorted(dev.items())})
     assert set('group:' + k for k in groups) == set(k for k in G.files if k.startswith('group:'))
-    bound, slice_bound = {'split': (2e-3, 2e-2), 'exact': (1e-4, 5e-4)}[mode]
+    bound, slice_bound = {'split': (1e-4, 1e-3), 'exact': (1e-4, 5e-4)}[mode]
     assert max(dev.values()) <= bound, dev
     worst = 0.0
     for key in G.files:

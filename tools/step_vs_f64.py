@@ -38,6 +38,30 @@ if exp:
     if 'biasact_exact' in exp:         # only the head's biased stage-1 convolutions
         import kgdet_amd.heads as hh
         hh.conv1x1 = types.SimpleNamespace(conv_bias_act=lambda conv, x, relu=False: torch.relu(conv(x)) if relu else conv(x))
+    if 'fwd_exact' in exp:             # every split dense-convolution FORWARD on fp32 (backward stays split)
+        import torch.nn.functional as F
+        import kgdet_amd.backbone as bb
+        bb.STEM_CONV = False
+        cur = {}
+        orig_fi = conv1x1.forward_images
+
+        orig_ap = conv1x1._apply
+
+        def fi(x, weight):
+            res = orig_fi(x, weight)
+            cur['w'], cur['img'] = weight, res[0]
+            return res
+
+        def ap(img, x, M, taps, stride=1, bias=None, residual=None, relu=False):
+            if img is not cur.get('img'):      # grad_input (the transposed image): stays on the split kernel
+                return orig_ap(img, x, M, taps, stride, bias, residual, relu)
+            w = cur['w']
+            assert w.shape[0] == M and w.shape[2] * w.shape[3] == taps
+            y = F.conv2d(x, w, bias, stride, w.shape[2] // 2)
+            if residual is not None:
+                y = y + residual
+            return torch.relu(y) if relu else y
+        conv1x1.forward_images, conv1x1._apply = fi, ap
     if 'gw_exact' in exp:              # split forward / grad_input, weight gradients through ATen
         def gw(x, weight, gy):
             k = weight.shape[2]
