@@ -22,9 +22,14 @@ import torch.nn as nn
 from . import dcn
 from .heads import PointHeadMixin
 from .layers import ConvModule, bias_init_with_prob, normal_init
-from .points import PointGenerator, multi_apply, point_target_kp
+import os
+
+from .points import (PointGenerator, dense_targets_applicable, multi_apply, point_target_kp,
+                     point_target_kp_dense)
 from .postprocess import multiclass_nms_kp
 from .registry import HEADS, build_loss
+
+DENSE_TARGETS = os.environ.get('KGDET_SERIAL_DENSE_TARGETS', '1') == '1'     # 0: the reference-mirroring (host-syncing) path (A/B)
 
 
 class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
@@ -202,9 +207,10 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
             # SER:469-477 normalises in place; with one image per GPU the per-level targets are views of one
             # tensor and the in-place update would invalidate weights autograd saved for another level, so
             # the normalisation runs on a private copy (same values)
-            weights = weights.reshape(-1, self.num_keypts * 2).clone()
-            pos_num = weights.sum(1)
-            weights[pos_num > 0] /= pos_num[pos_num > 0].unsqueeze(1)
+            # (rows without a visible keypoint are all zero: dividing them by 1 gives the same tensor as the reference's
+            #  boolean-mask update, without its device->host round trip)
+            weights = weights.reshape(-1, self.num_keypts * 2)
+            weights = weights / weights.sum(1).clamp(min=1).unsqueeze(1)
             return loss_fn(pred.reshape(-1, self.num_keypts * 2) / normalize_term,
                            gt.reshape(-1, self.num_keypts * 2) / normalize_term, weights, avg_factor=avg)
 
@@ -229,9 +235,19 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
             candidate_list = center_list
         else:
             candidate_list = self.centers_to_bboxes(center_list)
-        targets_init = point_target_kp(candidate_list, valid_flag_list, gt_bboxes, gt_keypoints, img_metas, cfg.init,
-                                       gt_bboxes_ignore_list=gt_bboxes_ignore, gt_labels_list=gt_labels,
-                                       label_channels=label_channels, sampling=self.sampling)
+        # every grid point valid?  (host arithmetic on the image metas) -> the sync-free dense target path
+        all_valid = all(
+            min(int(np.ceil(meta['pad_shape'][0] / s)), fs[0]) == fs[0] and
+            min(int(np.ceil(meta['pad_shape'][1] / s)), fs[1]) == fs[1]
+            for meta in img_metas for s, fs in zip(self.point_strides, featmap_sizes))
+        dense_ok = lambda c: (not self.sampling and DENSE_TARGETS and
+                              dense_targets_applicable(c, len(self.point_strides), all_valid, gt_bboxes_ignore))
+        if dense_ok(cfg.init):
+            targets_init = point_target_kp_dense(candidate_list, gt_bboxes, gt_keypoints, cfg.init, gt_labels_list=gt_labels)
+        else:
+            targets_init = point_target_kp(candidate_list, valid_flag_list, gt_bboxes, gt_keypoints, img_metas, cfg.init,
+                                           gt_bboxes_ignore_list=gt_bboxes_ignore, gt_labels_list=gt_labels,
+                                           label_channels=label_channels, sampling=self.sampling)
         (*_, bbox_gt_list_init, candidate_list_init, bbox_weights_list_init, keypoint_gt_list_init,
          keypoint_weights_list_init, num_total_pos_init, num_total_neg_init) = targets_init
         num_total_samples_init = (num_total_pos_init + num_total_neg_init if self.sampling else num_total_pos_init)
@@ -249,9 +265,12 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
                 bbox_center = torch.cat([center[i_lvl][:, :2], center[i_lvl][:, :2]], dim=1)
                 bbox.append(bbox_center + init_boxes[i_lvl][i_img].permute(1, 2, 0).reshape(-1, 4))
             bbox_list.append(bbox)
-        targets_refine = point_target_kp(bbox_list, valid_flag_list, gt_bboxes, gt_keypoints, img_metas, cfg.refine,
-                                         gt_bboxes_ignore_list=gt_bboxes_ignore, gt_labels_list=gt_labels,
-                                         label_channels=label_channels, sampling=self.sampling)
+        if dense_ok(cfg.refine):
+            targets_refine = point_target_kp_dense(bbox_list, gt_bboxes, gt_keypoints, cfg.refine, gt_labels_list=gt_labels)
+        else:
+            targets_refine = point_target_kp(bbox_list, valid_flag_list, gt_bboxes, gt_keypoints, img_metas, cfg.refine,
+                                             gt_bboxes_ignore_list=gt_bboxes_ignore, gt_labels_list=gt_labels,
+                                             label_channels=label_channels, sampling=self.sampling)
         (labels_list, label_weights_list, bbox_gt_list_refine, candidate_list_refine, bbox_weights_list_refine,
          keypoint_gt_list_refine, keypoint_weights_list_refine, num_total_pos_refine,
          num_total_neg_refine) = targets_refine

@@ -343,44 +343,74 @@ def point_target_single(flat_proposals, valid_flags, gt_bboxes, gt_keypoints, gt
 # and the positive count stays a device tensor.
 # ------------------------------------------------------------------------------------------------
 def dense_targets_applicable(cfg, num_levels, all_valid, gt_bboxes_ignore_list=None):
+    """any number of pyramid levels; PointAssigner with a fixed pos_num, or MaxIoUAssigner without ignore regions"""
     a = cfg.assigner
-    return (num_levels == 1 and all_valid and a['type'] == 'PointAssigner' and a.get('pos_scale_factor') is None
-            and (gt_bboxes_ignore_list is None or all(g is None for g in gt_bboxes_ignore_list)))
+    if not all_valid or not (gt_bboxes_ignore_list is None or all(g is None for g in gt_bboxes_ignore_list)):
+        return False
+    if a['type'] == 'PointAssigner':
+        return a.get('pos_scale_factor') is None
+    return a['type'] == 'MaxIoUAssigner'
 
 
 def _point_assign_dense(points, gt_bboxes, scale, pos_num):
-    """PointAssigner.assign (point_assigner.py:23-121) for points of one level: every GT is on that level, so
-    the reference's masked subsets are the whole point set and the masked writes become scatters."""
+    """PointAssigner.assign (point_assigner.py:23-121) without masked subsets: the distance of every point to every gt
+    (inf off the gt's pyramid level), the pos_num nearest per gt by ONE batched topk, and the sequential
+    ``min_dist < assigned_dist`` rule (an earlier gt keeps a tie) as ONE first-minimum over the gts."""
     points_xy = points[:, :2]
-    num_points = points.shape[0]
+    points_lvl = torch.log2(points[:, 2]).int()
+    lvl_min, lvl_max = points_lvl.min(), points_lvl.max()
     gt_xy = (gt_bboxes[:, :2] + gt_bboxes[:, 2:]) / 2
     gt_wh = (gt_bboxes[:, 2:] - gt_bboxes[:, :2]).clamp(min=1e-6)
-    assigned_gt_inds = points.new_zeros((num_points, ), dtype=torch.long)
-    assigned_gt_dist = points.new_full((num_points, ), float('inf'))
-    for idx in range(gt_bboxes.shape[0]):
-        # (slices, not the reference's gt_xy[[idx], :]: a list index is uploaded from the host on every use)
-        dist = ((points_xy - gt_xy[idx:idx + 1, :]) / gt_wh[idx:idx + 1, :]).norm(dim=1)
-        min_dist, cand = torch.topk(dist, pos_num, largest=False)
-        closer = min_dist < assigned_gt_dist[cand]
-        assigned_gt_inds.scatter_(0, cand, torch.where(closer, torch.full_like(cand, idx + 1), assigned_gt_inds[cand]))
-        assigned_gt_dist.scatter_(0, cand, torch.where(closer, min_dist, assigned_gt_dist[cand]))
-    return assigned_gt_inds
+    gt_lvl = ((torch.log2(gt_wh[:, 0] / scale) + torch.log2(gt_wh[:, 1] / scale)) / 2).int()
+    gt_lvl = torch.min(torch.max(gt_lvl, lvl_min), lvl_max)
+    dist = ((points_xy[None, :, :] - gt_xy[:, None, :]) / gt_wh[:, None, :]).norm(dim=2)            # [G, N]
+    dist = torch.where(gt_lvl[:, None] == points_lvl[None, :], dist, dist.new_full((), float('inf')))
+    min_dist, cand = torch.topk(dist, pos_num, dim=1, largest=False)
+    picked = torch.full_like(dist, float('inf')).scatter_(1, cand, min_dist)
+    best, gt_of = picked.min(dim=0)                      # ties: the first (earliest) gt
+    return torch.where(best < float('inf'), gt_of + 1, torch.zeros_like(gt_of))
+
+
+def _max_iou_assign_dense(bboxes, gt_bboxes, a):
+    """MaxIoUAssigner.assign_wrt_overlaps (max_iou_assigner.py:93-153) with masks instead of index writes and without the
+    per-gt ``if gt_max_overlaps[i] >= min_pos_iou`` host read: -1 don't care, 0 negative, i > 0 positive for gt i - 1."""
+    overlaps = bbox_overlaps(gt_bboxes, bboxes[:, :4])                                                # [G, N]
+    num_gts = overlaps.shape[0]
+    max_overlaps, argmax_overlaps = overlaps.max(dim=0)
+    gt_max_overlaps, gt_argmax_overlaps = overlaps.max(dim=1)
+    assigned = torch.full_like(argmax_overlaps, -1)
+    neg = a['neg_iou_thr']
+    lo, hi = (0, neg) if isinstance(neg, float) else (neg[0], neg[1])
+    assigned = torch.where((max_overlaps >= lo) & (max_overlaps < hi), torch.zeros_like(assigned), assigned)
+    assigned = torch.where(max_overlaps >= a['pos_iou_thr'], argmax_overlaps + 1, assigned)
+    ok = (gt_max_overlaps >= a.get('min_pos_iou', .0))[:, None]
+    if a.get('gt_max_assign_all', True):
+        hit = (overlaps == gt_max_overlaps[:, None]) & ok
+    else:
+        hit = (torch.arange(overlaps.shape[1], device=overlaps.device)[None, :] == gt_argmax_overlaps[:, None]) & ok
+    # the reference loops over the gts in order: the LAST gt that claims a box wins
+    last = (hit.long() * torch.arange(1, num_gts + 1, device=overlaps.device)[:, None]).max(dim=0)[0]
+    return torch.where(last > 0, last, assigned)
 
 
 def point_target_kp_dense(proposals_list, gt_bboxes_list, gt_kps_list, cfg, gt_labels_list=None):
-    """Same return value as point_target_kp(..., sampling=False) for single-level, all-valid point sets;
+    """Same return value as point_target_kp(..., sampling=False) for all-valid point sets (any number of levels);
     num_total_pos / num_total_neg are 0-dim device tensors."""
     a = cfg.assigner
-    scale, pos_num = a.get('scale', 4), a.get('pos_num', 3)
     pos_weight = 1.0 if cfg.pos_weight <= 0 else cfg.pos_weight
     outs = [[] for _ in range(7)]
     num_total_pos = num_total_neg = None
+    first = proposals_list[0]
+    num_level = [p.shape[0] for p in first] if isinstance(first, (list, tuple)) else [first.shape[0]]
     for i, proposals in enumerate(proposals_list):
         proposals = torch.cat(proposals) if isinstance(proposals, (list, tuple)) else proposals
         gt_bboxes, gt_kps = gt_bboxes_list[i], gt_kps_list[i]
         if proposals.shape[0] == 0 or gt_bboxes.shape[0] == 0:
             raise ValueError('No gt or bboxes')
-        inds = _point_assign_dense(proposals, gt_bboxes, scale, pos_num)
+        if a['type'] == 'PointAssigner':
+            inds = _point_assign_dense(proposals, gt_bboxes, a.get('scale', 4), a.get('pos_num', 3))
+        else:
+            inds = _max_iou_assign_dense(proposals, gt_bboxes, a)
         pos = inds > 0
         gidx = (inds - 1).clamp(min=0)
         pos1, pos2 = pos[:, None], pos[:, None, None]
@@ -388,8 +418,9 @@ def point_target_kp_dense(proposals_list, gt_bboxes_list, gt_kps_list, cfg, gt_l
         labels = (torch.ones_like(inds) if gt_labels_list is None or gt_labels_list[i] is None
                   else gt_labels_list[i][gidx])
         outs[0].append(torch.where(pos, labels, torch.zeros_like(labels)))
-        outs[1].append(torch.where(pos, proposals.new_full((), pos_weight), proposals.new_ones(())).expand(inds.shape[0])
-                       .contiguous())
+        # label weights: positives pos_weight, negatives (assigned == 0) 1, don't-care (-1, MaxIoUAssigner) 0
+        lw = torch.where(pos, proposals.new_full((), pos_weight), (inds == 0).to(proposals.dtype))
+        outs[1].append(lw.contiguous())
         outs[2].append(torch.where(pos1, gt_bboxes[gidx], gt_bboxes.new_zeros(())))
         outs[3].append(torch.where(pos1, proposals, proposals.new_zeros(())))
         outs[4].append(pos1.to(proposals.dtype).expand(-1, 4).contiguous())
@@ -397,10 +428,9 @@ def point_target_kp_dense(proposals_list, gt_bboxes_list, gt_kps_list, cfg, gt_l
         outs[6].append(torch.where(pos2, (kp[:, :, 2:3] != 0).to(proposals.dtype), kp.new_zeros(()))
                        .expand(-1, -1, 2).contiguous())
         n_pos = pos.sum()
-        n_neg = pos.numel() - n_pos
+        n_neg = (inds == 0).sum()
         num_total_pos = n_pos.clamp(min=1) if num_total_pos is None else num_total_pos + n_pos.clamp(min=1)
         num_total_neg = n_neg.clamp(min=1) if num_total_neg is None else num_total_neg + n_neg.clamp(min=1)
-    num_level = [outs[0][0].shape[0]]
     return tuple(images_to_levels(o, num_level) for o in outs) + (num_total_pos, num_total_neg)
 
 

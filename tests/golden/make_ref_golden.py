@@ -145,7 +145,22 @@ def kgdet_head(ns, out):
 
     ref64 = ref.double()
     x64 = x.double().requires_grad_(True)
+    # the ReLU decisions of the float64 forward, per module and call, packed: the gradient comparison pins them
+    # (tests/ref_checks.py pinned_relu) so that a pre-activation within rounding distance of zero cannot put a whole
+    # receptive field of grad:x on the other side
+    calls = {}
+
+    def record(name):
+        def hook(mod, inp, res):
+            i = calls.get(name, 0)
+            calls[name] = i + 1
+            out['relu:%s#%d' % (name, i)] = np.packbits((res.detach() > 0).numpy().reshape(-1))
+        return hook
+    hooks = [m.register_forward_hook(record(n)) for n, m in ref64.named_modules() if isinstance(m, torch.nn.ReLU)]
     outs = ref64([x64], batch['img_meta'])
+    for h in hooks:
+        h.remove()
+    print('recorded ReLU calls', calls)
     for n, o in zip(names, outs):
         a = _np(o[0])
         out['out:' + n] = (a[:, ::ref_cases.KPT_STRIDE * 3] if n.startswith('kpt') else a).astype(np.float32)

@@ -616,3 +616,52 @@ def test_full_size_training_step_matches_float64(mode, golden_dir):
     assert worst <= slice_bound
     assert _rel(params['bbox_head.kp_rep_block_3.cls_dfmconv_7.weight'].grad.detach().cpu().numpy().reshape(256, -1)[::16, ::7],
                 G['grad:bbox_head.kp_rep_block_3.cls_dfmconv_7.weight']) <= 5e-5
+
+
+@pytest.mark.gpu
+def test_config5_training_step_has_no_host_syncs():
+    """config 5 (serial head, five pyramid levels, PointAssigner init stage + MaxIoUAssigner refine stage, SGD): the
+    training step under torch's sync debug mode -- every target of both stages comes from the dense path
+    (points.point_target_kp_dense: batched top-k / first-minimum for the PointAssigner, masks for the MaxIoUAssigner),
+    which is bit-exact against the reference fixtures (tests/test_gpu_ref_golden.py pyramid_init / pyramid_refine); and the
+    dense and the reference-mirroring paths give the same losses."""
+    import kgdet_amd.heads_serial as hs
+    from kgdet_amd.dist import DistOptimizerHook
+    from kgdet_amd.registry import build_detector
+    cfg = configs.reppoints_kp_r50_fpn()
+    torch.manual_seed(0)
+    model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda()
+    batch = synthetic.make_batch(2, 'cuda', seed=0, img_shape=(384, 480, 3), pad_shape=(384, 480, 3))
+    for k in ('gt_bboxes', 'gt_keypoints'):
+        batch[k] = [t.clamp(max=370) for t in batch[k]]
+    model.train()
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-6, momentum=0.9, fused=True)
+    hook = DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2))
+
+    def forward():
+        return model(batch['img'], batch['img_meta'], return_loss=True, gt_bboxes=batch['gt_bboxes'],
+                     gt_labels=batch['gt_labels'], gt_keypoints=batch['gt_keypoints'])
+
+    def step():
+        losses = forward()
+        hook.step(model, opt, sum(sum(v) if isinstance(v, (list, tuple)) else v for v in losses.values()))
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        step()
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        dense = forward()
+        hs.DENSE_TARGETS = False
+        try:
+            mirrored = forward()
+        finally:
+            hs.DENSE_TARGETS = True
+    for k in dense:
+        for a, b in zip(dense[k], mirrored[k]):
+            assert torch.allclose(a, b, rtol=1e-6, atol=0), k

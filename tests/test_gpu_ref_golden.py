@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 CASES = ref_cases.target_cases()
 
 
-@pytest.mark.parametrize('name', ['kgdet_1gt', 'kgdet_overlap', 'kgdet_extremes'])
+@pytest.mark.parametrize('name', ['kgdet_1gt', 'kgdet_overlap', 'kgdet_extremes', 'pyramid_init', 'pyramid_refine'])
 def test_dense_targets_on_gpu_equal_reference(name):
     """points.point_target_kp_dense on the device (what bench.py's training step runs) == point_target_kp.py:98-169"""
     G = ref_checks.load('ref_targets_golden.npz')

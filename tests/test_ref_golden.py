@@ -18,7 +18,7 @@ def G():
 
 CASES = ref_cases.target_cases()
 OK_CASES = [n for n in CASES if n != 'kgdet_empty_gt']
-DENSE_CASES = ['kgdet_1gt', 'kgdet_overlap', 'kgdet_extremes']
+DENSE_CASES = ['kgdet_1gt', 'kgdet_overlap', 'kgdet_extremes', 'pyramid_init', 'pyramid_refine']      # (all points valid)
 
 
 @pytest.mark.parametrize('name', OK_CASES)
