@@ -19,7 +19,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import dcn
+from . import conv1x1, dcn
 from .heads import PointHeadMixin
 from .layers import ConvModule, bias_init_with_prob, normal_init
 import os
@@ -144,7 +144,13 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
         return dcn.deform_conv_cat(feat, [offset], [conv.weight], [self.dcn_pad])
 
     def forward_single(self, x):
-        dcn_base_offset = self.dcn_base_offset.type_as(x)
+        # (the reference keeps the regular grid as a plain CPU attribute and uploads it with type_as() on every call: a
+        #  blocking host->device copy per level and step; uploaded once per device / dtype here)
+        cache = self.__dict__.setdefault('_base_offset_cache', {})
+        key = (x.device, x.dtype)
+        if key not in cache:
+            cache[key] = self.dcn_base_offset.to(device=x.device, dtype=x.dtype)
+        dcn_base_offset = cache[key]
         if self.use_grid_points or not self.center_init:
             scale = self.point_base_scale / 2
             reppts_init = dcn_base_offset / dcn_base_offset.max() * scale
@@ -159,9 +165,10 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
         for reg_conv in self.reg_convs:
             pts_feat = reg_conv(pts_feat)
         # init stage
-        keypts_out_init = self.keypts_init_out(self.relu(self.keypts_init_conv(pts_feat)))
+        # (the biased 3x3 convolutions + ReLU on the split-operand MFMA kernels, as in the KGDet head's first stage)
+        keypts_out_init = self.keypts_init_out(conv1x1.conv_bias_act(self.keypts_init_conv, pts_feat, relu=True))
         if self.parallel_reppts:
-            reppts_out_init = self.reppts_init_out(self.relu(self.reppts_init_conv(pts_feat)))
+            reppts_out_init = self.reppts_init_out(conv1x1.conv_bias_act(self.reppts_init_conv, pts_feat, relu=True))
         else:
             reppts_out_init = self.reppts_init_out(keypts_out_init)
         reppts_out_init = reppts_out_init + reppts_init
