@@ -301,6 +301,61 @@ def _subsample2(x):
     return x[:, :, ::2, ::2].contiguous()
 
 
+GEMM_1X1 = _os.environ.get('KGDET_INFER_GEMM_1X1', '1') == '1'     # 0: every inference convolution through MIOpen (A/B)
+_gemm_choice = {}       # (Cin, Cout, B, H, W, residual?, relu) -> True: hipBLASLt GEMM, False: MIOpen convolution
+
+
+def _conv1x1_as_gemm(conv, hit, x, residual, relu):
+    """bf16 channels-last inference: a 1x1 stride-1 convolution IS the GEMM [B*H*W, Cin] x [Cin, Cout] on the channels-last
+    storage, and hipBLASLt takes the folded-BatchNorm bias (+ ReLU) as its epilogue -- no separate bias / ReLU pass over the
+    activation (csrc/epilogue.hip bias_act_nhwc was the largest kernel of the inference batch).  With a residual the GEMM adds
+    it as its C matrix and only bias + ReLU remain as a pass.  MIOpen's NHWC kernels win on the large early maps, the GEMM on
+    the deep layers (tools/bench_1x1_gemm.py: 1024 -> 256 at 50 x 84: 41 -> 24 us, 64 -> 64 at 200 x 336: 45 -> 86 us), so
+    the choice is MEASURED once per shape during the eager warm-up calls (never while a graph is being captured); returns
+    None when the convolution path should run."""
+    B, cin, H, W = x.shape
+    cout = hit[1].shape[0]
+    key = (cin, cout, B, H, W, residual is not None, bool(relu))
+    choice = _gemm_choice.get(key)
+    if choice is False or (choice is None and torch.cuda.is_current_stream_capturing()):
+        return None
+    w2 = hit[1].view(cout, cin)
+    bias16 = hit[5] if len(hit) > 5 else None
+
+    def gemm():
+        x2 = x.permute(0, 2, 3, 1).reshape(-1, cin)
+        if residual is not None:
+            y2 = torch.addmm(residual.permute(0, 2, 3, 1).reshape(-1, cout), x2, w2.t())
+            y = y2.view(B, H, W, cout).permute(0, 3, 1, 2)
+            return _epilogue_(y, hit[2], None, relu)
+        if relu:
+            y2 = torch._addmm_activation(bias16, x2, w2.t(), use_gelu=False)
+        else:
+            y2 = torch.addmm(bias16, x2, w2.t())
+        return y2.view(B, H, W, cout).permute(0, 3, 1, 2)
+
+    if choice is None:
+        def conv_path():
+            y = F.conv2d(x, hit[1], None, conv.stride, conv.padding, conv.dilation, conv.groups)
+            return _epilogue_(y, hit[2], residual, relu)
+
+        def timed(fn):
+            for _ in range(2):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1)
+        choice = timed(gemm) < 0.95 * timed(conv_path)
+        _gemm_choice[key] = choice
+        if not choice:
+            return None
+    return gemm()
+
+
 def conv_bn(conv, bn, x, relu=False, residual=None, skip=False):
     """``[relu](bn(conv(x)) [+ residual])``; ``skip=True``: returns (that, x) where the second is x or an alias of it whose
     gradient is folded into this convolution's grad_input (_ConvBNAct)."""
@@ -360,10 +415,16 @@ def _conv_bn(conv, bn, x, relu=False, residual=None, skip=False, raw=False):
         packed = None
         if not bf16 and conv1x1.applicable(x, w, conv.stride, conv.padding, conv.dilation, conv.groups):
             packed = conv1x1._pack(w.contiguous(), False)     # fp32 inference: split-bf16 MFMA kernels, packed once
-        hit = (weakref.ref(conv), w, shift.detach().float().contiguous(), packed, ver)
+        hit = (weakref.ref(conv), w, shift.detach().float().contiguous(), packed, ver,
+               shift.detach().to(torch.bfloat16).contiguous() if bf16 else None)
         _fold_cache[(id(conv), bf16)] = hit
     if bf16 and not x.is_contiguous(memory_format=torch.channels_last):
         x = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    if (bf16 and GEMM_1X1 and not raw and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
+            and conv.groups == 1 and x.dtype == torch.bfloat16 and (residual is None or residual.dtype == torch.bfloat16)):
+        out = _conv1x1_as_gemm(conv, hit, x, residual, relu)
+        if out is not None:
+            return out
     if hit[3] is not None and x.dtype == torch.float32 and x.is_contiguous() and x.shape[2] * x.shape[3] % 2 == 0:
         if _FUSE_EPI and (residual is None or (residual.dtype == torch.float32 and residual.is_contiguous())):
             # bias, residual and ReLU ride on the convolution's store: no separate epilogue pass
