@@ -40,8 +40,12 @@ extern "C" {
 size_t kgdet_conv_packed_bytes(int32_t M, int32_t K, int32_t taps);
 int kgdet_conv_pack(const float *w, int32_t O, int32_t C, int32_t taps, int32_t transpose, void *packed, void *stream);
 /* operand_format of the *_fmt entry points: 0 = two bf16 parts per fp32 value (16 mantissa bits; every gradient operand),
- * 1 = two fp16 parts (22 bits, fp32-class results at the same MFMA rate) for FORWARD operands -- activations and weights lie
- * inside fp16's range, values beyond 65504 saturate.  An image packed with format f must be applied with format f; only
+ * 1 = two fp16 parts (22 bits, fp32-class results at the same MFMA rate) for FORWARD operands.  Envelope of format 1: weights up
+ * to 255 in magnitude (the image stores them scaled by 2^8 so that their lo parts stay normal; the kernels scale the
+ * accumulators back), activations of magnitude ~1e-2 .. 6e4 at full accuracy (<= 1e-6 of the output scale); beyond 65504 they
+ * saturate, below ~1e-3 the lo part becomes an fp16 subnormal and the error has an ABSOLUTE floor of ~3e-8 per activation
+ * (1e-4 of the output scale at 1e-3) -- the outputs of BatchNorm / GroupNorm-normalised layers sit inside the envelope;
+ * format 0 has no floor and 16 bits.  An image packed with format f must be applied with format f; only
  * forward images (transpose = 0) take format 1.  kgdet_conv_pack_multi: bit 62 of a descriptor's last word selects
  * format 1 for that row's forward image.  The plain entry points are format 0. */
 int kgdet_conv_pack_fmt(const float *w, int32_t O, int32_t C, int32_t taps, int32_t transpose, void *packed,

@@ -71,6 +71,10 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8 &hi, bf16x8 &
 // FORWARD features' 5e-6..9e-6 (tools/step_vs_f64.py KGDET_EXP=fwd_exact: 7e-6 with an fp32 forward and the split backward).
 // Activations and weights sit inside fp16's range; gradients do not (1e-8 and below), so grad_input / grad_weight
 // operands stay bf16 (8 exponent bits).  Values beyond 65504 saturate, below 6e-8 vanish.
+// fp16's normal range ends at 6.1e-5: the lo part of a weight of 0.03 (7e-6) would be subnormal and keep ~7 of its 11 bits.
+// The pack kernels therefore store fp16-format weights scaled by kF16WeightScale = 2^8 (exact; weights up to 255 in
+// magnitude) and the fp16 kernels multiply their accumulators by 2^-8 before the epilogue (exact as well).
+constexpr float kF16WeightScale = 256.0f;
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <bool F16>
@@ -78,12 +82,13 @@ __device__ __forceinline__ void split_pair_t(float v0, float v1, unsigned &hi, u
   if constexpr (!F16) {
     split_pair(v0, v1, hi, lo);
   } else {
-    // hi: truncation (v_cvt_pkrtz_f16_f32; the remainder v - hi is exact either way); lo: round to nearest even
-    // (v_cvt_pk_f16_f32 on gfx950) -- truncating both left a bias of -2^-22 per operand that grew to -1.4e-6 of the rms
-    // over the backbone's 50 layers
-    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0, v1));
+    // both parts rounded to nearest even (v_cvt_pk_f16_f32 on gfx950); the remainder v - hi is exact in fp32.  Truncated
+    // parts (v_cvt_pkrtz_f16_f32) have the sign of v, so the dropped lo * lo term always had the sign of the product: a
+    // bias of -6e-8 per layer that grew to -1.4e-6 (both truncated) / -3e-7 (hi truncated) of the rms over the backbone
+    const f32x2 v = {v0, v1};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
     const f32x2 hf = __builtin_convertvector(__builtin_bit_cast(f16x2, hi), f32x2);
-    const f32x2 r = {v0 - hf[0], v1 - hf[1]};
+    const f32x2 r = v - hf;
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
   }
 }
@@ -172,7 +177,13 @@ __global__ __launch_bounds__(256) void conv1x1_pack(const float *__restrict__ w,
       v[j] = m < M ? w[(o * C + ch) * T + (transpose ? T - 1 - t : t)] : 0.0f;
     }
     bf16x8 hi, lo;
-    if (f16) split8_t<true>(v, hi, lo); else split8(v, hi, lo);
+    if (f16) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= kF16WeightScale;
+      split8_t<true>(v, hi, lo);
+    } else {
+      split8(v, hi, lo);
+    }
     unsigned char *dst = img + st * kStage + khalf * (kTM * 16) + row * 16;
     *reinterpret_cast<bf16x8 *>(dst) = hi;
     *reinterpret_cast<bf16x8 *>(dst + kPart) = lo;
@@ -221,7 +232,13 @@ __global__ __launch_bounds__(256) void conv1x1_pack_multi(const long long *__res
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = m < M ? r[j * 9 + t] : 0.0f;
         bf16x8 hi8, lo8;
-        if (f16_forward) split8_t<true>(v, hi8, lo8); else split8(v, hi8, lo8);
+        if (f16_forward) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] *= kF16WeightScale;
+          split8_t<true>(v, hi8, lo8);
+        } else {
+          split8(v, hi8, lo8);
+        }
         unsigned char *dst = img + (s2 * 9 + t) * kStage + khalf * (kTM * 16) + row * 16;
         *reinterpret_cast<bf16x8 *>(dst) = hi8;
         *reinterpret_cast<bf16x8 *>(dst + kPart) = lo8;
@@ -242,7 +259,13 @@ __global__ __launch_bounds__(256) void conv1x1_pack_multi(const long long *__res
       v[j] = m < M ? w[(o * C + ch) * T + (transpose ? T - 1 - t : t)] : 0.0f;
     }
     bf16x8 hi8, lo8;
-    if (f16_forward && !transpose) split8_t<true>(v, hi8, lo8); else split8(v, hi8, lo8);
+    if (f16_forward && !transpose) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= kF16WeightScale;
+      split8_t<true>(v, hi8, lo8);
+    } else {
+      split8(v, hi8, lo8);
+    }
     unsigned char *dst = img + st * kStage + khalf * (kTM * 16) + row * 16;
     *reinterpret_cast<bf16x8 *>(dst) = hi8;
     *reinterpret_cast<bf16x8 *>(dst + kPart) = lo8;
@@ -410,6 +433,12 @@ __global__ __launch_bounds__(128 * NW) void conv_nn(const unsigned char *__restr
   // store: lane holds column (lane & 31) of 16 rows per 32 x 32 block -> 128-byte row segments per half wave
   float *yb = y + (long long)part * part_stride + (long long)b * M * N;
   const int n = n0 + wn * 32 + (lane & 31);
+  if constexpr (F16) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][r] *= 1.0f / kF16WeightScale;
+  }
   if (bias || residual) {   // epilogue operands first, all loads in flight at once (clamped addresses, no branches)
     const int nc = min(n, N - 1);
     float add[2][16];
@@ -790,6 +819,10 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_patch4(const unsigned char
   const int m0 = mt * kTM + wave * 32 + 4 * (lane >> 5);
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
+    if constexpr (F16) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][r] *= 1.0f / kF16WeightScale;
+    }
     if (bias || residual) {
       float add[16];
 #pragma unroll
@@ -1012,7 +1045,7 @@ __global__ __launch_bounds__(256) void stem_conv7x7_s2(const unsigned char *__re
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        yb[(long long)m * Ho * Wo] = acc[mi][r];
+        yb[(long long)m * Ho * Wo] = F16 ? acc[mi][r] * (1.0f / kF16WeightScale) : acc[mi][r];
       }
   }
 }

@@ -508,3 +508,26 @@ def test_step_scope_packs_follow_weight_updates():
     out = conv1x1.conv_split(x, ws[0])                                # no scope: must re-pack
     ref = F.conv2d(x, ws[0])
     assert float((out - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('xs,ws,tol', [(1.0, 0.03, 1e-6), (100.0, 0.03, 1e-6), (1.0, 1.0, 1e-6), (1e-3, 0.03, 1e-4), (1e-5, 0.03, 1e-2)])
+def test_fp16_forward_parts_envelope(xs, ws, tol):
+    """The forward operands of the dense convolutions are split into two fp16 parts (csrc/conv1x1.hip split_pair_t, weights
+    pre-scaled by 2^8): fp32-class results (<= 1e-6 of the output scale against float64; the bf16 parts gave 5e-6) for
+    activations of magnitude ~1e-2 .. 6e4 and weights up to 255 -- what BatchNorm / GroupNorm-normalised networks produce.
+    Below that the lo part of an activation becomes an fp16 subnormal and the error floor is an ABSOLUTE ~3e-8 per activation:
+    1e-4 of the output scale at |x| ~ 1e-3, 1e-2 at 1e-5 (documented in include/kgdet_hip.h; KGDET_CONV_FWD_F16=0 selects
+    bf16 parts, which have no such floor and 16 instead of 22 bits).  The same holds for 3x3 and 1x1 kernels."""
+    from kgdet_amd import conv1x1 as c1
+    assert c1.FORWARD_F16
+    g = torch.Generator().manual_seed(0)
+    for k in (1, 3):
+        x = (torch.randn(2, 64, 40, 44, generator=g) * xs).cuda()
+        w = (torch.randn(128, 64, k, k, generator=g) * ws).cuda()
+        img = c1._pack(w, False)
+        assert img.kgdet_f16
+        y = c1._apply(img, x, 128, k * k)
+        ref = F.conv2d(x.double(), w.double(), padding=k // 2)
+        err = float((y.double() - ref).abs().max() / ref.abs().max())
+        assert err < tol, (k, err)
