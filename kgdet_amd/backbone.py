@@ -285,6 +285,7 @@ class _Subsample2(torch.autograd.Function):
         return y
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, gy):
         from . import _lib
         B, C, H, W = ctx.shape

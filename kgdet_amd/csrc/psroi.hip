@@ -16,7 +16,7 @@
 //  * psroi_gather<0> (forward): workgroup = (RoI, offset class, 64 output channels); its four waves split the bins; results
 //    leave through an LDS staging buffer as one contiguous block.  psroi_gather<1> (grad_trans): workgroup = (RoI, class)
 //    walks all channels of the class, per-lane partial sums, ONE fixed-order wave reduction per bin: no atomics.
-//  * psroi_grad_data: a GATHER by output tile.  One workgroup per (image, 4x6-pixel tile, 256 input channels) keeps the
+//  * psroi_grad_data: a GATHER by output tile.  One single-wave workgroup per (image, 4x6-pixel tile, 64 input channels) keeps the
 //    tile's gradient in LDS, walks the RoIs of its image in index order (culled by a per-RoI bounding box; the sample
 //    records come prepared from psroi_prepare, one visit ahead), and thread = channel adds the in-tile corners of every
 //    sample in the reference's own serial order (RoI, bin row, bin column, sample row, sample column, corner).  Each
@@ -42,7 +42,8 @@ constexpr int kTileH = 4, kTileW = 6;  // grad_data tile
 constexpr int kBinBatch = 16;          // bins whose quotients psroi_grad_data fetches together
 constexpr int kListCap = 4096;         // RoIs per overlap-list segment of psroi_grad_data
 constexpr int kTilePix = kTileH * kTileW;
-constexpr int kAccStride = kThreads + 1;
+constexpr int kGdThreads = 64;         // psroi_grad_data: one wave per workgroup
+constexpr int kGdStride = kGdThreads + 1;
 
 struct Roi {
   int batch;
@@ -362,13 +363,17 @@ __global__ __launch_bounds__(kThreads) void psroi_prepare(const kgdet_psroi_shap
     }
 }
 
-// grad_data as a gather by output tile; block = (tile, 256-channel chunk, image); thread = input channel.
+// grad_data as a gather by output tile; block = ONE WAVE = (tile, 64-channel chunk, image); thread = input channel.
+// (A workgroup of four waves = 256 channels met at two barriers per visit; one-wave workgroups need none -- a wave's LDS
+// operations complete in order -- and take the same time, 625 against 616 us: what bounds the kernel is each wave's chain of
+// dependent LDS read-add-write operations, ~1500 waves resident either way.)
 // Phase 0: the ordered list of the RoIs of this image whose bounding box meets the tile (ballot compaction, ascending).
 // Per visit (RoI of the list x offset class of this channel chunk): the prepared records come from the workspace into
 // registers ONE VISIT AHEAD, are filtered against the tile into LDS, and every thread walks the bins of its group cell
 // that have a sample in the tile -- the bins' grad_out / count quotients are fetched eight bins at a time (coalesced
 // over channels) before they are used.
-__global__ __launch_bounds__(kThreads) void psroi_grad_data(const kgdet_psroi_shape s, const float *__restrict__ rois,
+template <int kRecRegs>      // records of one visit held per thread (kRecRegs * 64 >= P*P*S*S): 4, 13 or 32 registers of 16 bytes
+__global__ __launch_bounds__(kGdThreads) void psroi_grad_data(const kgdet_psroi_shape s, const float *__restrict__ rois,
                                                             const int4 *__restrict__ bbox,
                                                             const Rec *__restrict__ recs_in,
                                                             const float *__restrict__ diffT,
@@ -378,17 +383,14 @@ __global__ __launch_bounds__(kThreads) void psroi_grad_data(const kgdet_psroi_sh
   const int P = s.pooled_size, S = s.sample_per_part, G = s.group_size;
   const int PP = P * P, SS = S * S, GG = G * G, nrec = PP * SS;
   Rec *recs = reinterpret_cast<Rec *>(smem);
-  float *acc = reinterpret_cast<float *>(recs + nrec);              // [kTilePix][kAccStride]
-  int *list = reinterpret_cast<int *>(acc + kTilePix * kAccStride); // [list_cap]
-  __shared__ unsigned long long bin_hit[4];                         // PP <= 256 bins
-  __shared__ int wave_cnt[kThreads / 64];
-  __shared__ int list_len;
+  float *acc = reinterpret_cast<float *>(recs + nrec);              // [kTilePix][kGdStride]
+  int *list = reinterpret_cast<int *>(acc + kTilePix * kGdStride);  // [list_cap]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid;
   const int tile = blockIdx.x, b = blockIdx.z;
   const int ty0 = (tile / tiles_x) * kTileH, tx0 = (tile % tiles_x) * kTileW;
   const int ty1 = min(ty0 + kTileH, s.H) - 1, tx1 = min(tx0 + kTileW, s.W) - 1;
-  const int c_first = blockIdx.y * kThreads;
+  const int c_first = blockIdx.y * kGdThreads;
   const int c = c_first + tid;
   const bool active = c < s.out_dim * GG && c < s.C;
   const int ctop = active ? c / GG : 0;
@@ -402,20 +404,18 @@ __global__ __launch_bounds__(kThreads) void psroi_grad_data(const kgdet_psroi_sh
     if (group_cell(p, G, P) == gw) { pw_lo = min(pw_lo, p); pw_hi = max(pw_hi, p + 1); }
   }
   const int nw = max(pw_hi - pw_lo, 0), my_bins = active ? max(ph_hi - ph_lo, 0) * nw : 0;
-  const int last_ch = min(min(c_first + kThreads, s.out_dim * GG), s.C) - 1;
+  const int last_ch = min(min(c_first + kGdThreads, s.out_dim * GG), s.C) - 1;
   const int cls_lo = last_ch >= c_first ? (c_first / GG) / ch_per_class : 1;
   const int cls_hi = last_ch >= c_first ? (last_ch / GG) / ch_per_class : 0;
   const int ncls = max(cls_hi - cls_lo + 1, 0);
-  constexpr int kRecRegs = kMaxRecords / kThreads;                  // records of one visit held per thread
 
-  for (int e = tid; e < kTilePix * kAccStride; e += kThreads) acc[e] = 0.f;
+  for (int e = tid; e < kTilePix * kGdStride; e += kGdThreads) acc[e] = 0.f;
   float *col = acc + tid;
 
   for (int seg = 0; seg < s.R && ncls > 0; seg += list_cap) {
     // ---- phase 0: RoIs [seg, seg + list_cap) of image b that meet the tile, ascending
-    __syncthreads();
-    if (tid == 0) list_len = 0;
-    for (int base = seg; base < min(seg + list_cap, s.R); base += kThreads) {
+    int len = 0;      // (wave-uniform)
+    for (int base = seg; base < min(seg + list_cap, s.R); base += kGdThreads) {
       const int n = base + tid;
       bool hit = false;
       if (n < s.R && n < seg + list_cap && (int)rois[5 * n] == b) {
@@ -423,15 +423,12 @@ __global__ __launch_bounds__(kThreads) void psroi_grad_data(const kgdet_psroi_sh
         hit = !(bx.y < tx0 || bx.x > tx1 || bx.w < ty0 || bx.z > ty1);
       }
       const unsigned long long m = __ballot(hit);
-      if (lane == 0) wave_cnt[wave] = __popcll(m);
-      __syncthreads();
-      int off = list_len;
-      for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-      if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = n;
-      __syncthreads();
-      if (tid == 0) list_len += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+      if (hit) list[len + __popcll(m & ((1ull << lane) - 1ull))] = n;
+      len += __popcll(m);
     }
-    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const int list_len = len;
     const int visits = list_len * ncls;
 
     int4 pre[kRecRegs];
@@ -440,27 +437,40 @@ __global__ __launch_bounds__(kThreads) void psroi_grad_data(const kgdet_psroi_sh
       const int4 *src = reinterpret_cast<const int4 *>(recs_in + ((long long)n * classes + cls) * nrec);
 #pragma unroll
       for (int j = 0; j < kRecRegs; ++j)
-        if (j * kThreads < nrec) pre[j] = src[min(tid + j * kThreads, nrec - 1)];
+        if (j * kGdThreads < nrec) pre[j] = src[min(tid + j * kGdThreads, nrec - 1)];
     };
     if (visits > 0) fetch(0);
     for (int v = 0; v < visits; ++v) {
       const int n = list[v / ncls], cls = cls_lo + v % ncls;
-      __syncthreads();                                       // the previous visit's records have been read by everybody
-      if (tid < 4) bin_hit[tid] = 0ull;
-      __syncthreads();
+      // (one wave: LDS operations complete in order, a wave barrier keeps the compiler from reordering across the phases)
+      __builtin_amdgcn_wave_barrier();
+      unsigned long long hit_bits[4] = {0ull, 0ull, 0ull, 0ull};
 #pragma unroll
       for (int j = 0; j < kRecRegs; ++j) {
-        const int i = tid + j * kThreads;
-        if (j * kThreads < nrec && i < nrec) {
+        const int i = tid + j * kGdThreads;
+        if (j * kGdThreads < nrec) {
           int4 q = pre[j];
           const int xa = (short)(q.x & 0xffff), xb = (short)(q.x >> 16), ya = (short)(q.y & 0xffff), yb = (short)(q.y >> 16);
-          const bool in = xa >= 0 && !(xb < tx0 || xa > tx1 || yb < ty0 || ya > ty1);     // a corner in the tile
+          const bool in = i < nrec && xa >= 0 && !(xb < tx0 || xa > tx1 || yb < ty0 || ya > ty1);     // a corner in the tile
           if (!in) q.x = -1;
-          *reinterpret_cast<int4 *>(recs + i) = q;
-          if (in) atomicOr(bin_hit + ((i / SS) >> 6), 1ull << ((i / SS) & 63));
+          if (i < nrec) *reinterpret_cast<int4 *>(recs + i) = q;
+          // bins of this lane's record with a sample in the tile -> OR over the wave (uniform 256-bit set)
+          const int bin = min(i, nrec - 1) / SS;
+          if (in) hit_bits[bin >> 6] |= 1ull << (bin & 63);
         }
       }
-      __syncthreads();
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        unsigned long long x = hit_bits[w];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+          const unsigned lo = __shfl_xor((unsigned)x, d), hi = __shfl_xor((unsigned)(x >> 32), d);
+          x |= ((unsigned long long)hi << 32) | lo;
+        }
+        hit_bits[w] = x;
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the records are in LDS
+      __builtin_amdgcn_wave_barrier();
       fetch(v + 1);                                           // in flight while this visit is accumulated
       if (my_cls != cls) continue;
       for (int j0 = 0; j0 < my_bins; j0 += kBinBatch) {
@@ -472,7 +482,7 @@ __global__ __launch_bounds__(kThreads) void psroi_grad_data(const kgdet_psroi_sh
         for (int u = 0; u < kBinBatch; ++u) {
           const int j = min(j0 + u, my_bins - 1);
           const int bin = (ph_lo + j / nw) * P + pw_lo + j % nw;
-          if (j0 + u < my_bins && ((bin_hit[bin >> 6] >> (bin & 63)) & 1ull)) mine |= 1ull << u;
+          if (j0 + u < my_bins && ((hit_bits[bin >> 6] >> (bin & 63)) & 1ull)) mine |= 1ull << u;
         }
         if (mine == 0ull) continue;
 #pragma unroll
@@ -499,23 +509,24 @@ __global__ __launch_bounds__(kThreads) void psroi_grad_data(const kgdet_psroi_sh
             // the reference's four atomicAdds (:236-245), same order, same expressions
             // (plain read-add-write: ds_add_f32 was measured 1.7x slower here -- LDS float atomics run at a fraction of the
             //  read / write rate)
-            if (ya_in && xa_in) col[(oa + pa) * kAccStride] += (1 - fx) * (1 - fy) * diff;
-            if (yb_in && xa_in) col[(ob + pa) * kAccStride] += (1 - fx) * fy * diff;
-            if (ya_in && xb_in) col[(oa + pb) * kAccStride] += fx * (1 - fy) * diff;
-            if (yb_in && xb_in) col[(ob + pb) * kAccStride] += fx * fy * diff;
+            if (ya_in && xa_in) col[(oa + pa) * kGdStride] += (1 - fx) * (1 - fy) * diff;
+            if (yb_in && xa_in) col[(ob + pa) * kGdStride] += (1 - fx) * fy * diff;
+            if (ya_in && xb_in) col[(oa + pb) * kGdStride] += fx * (1 - fy) * diff;
+            if (yb_in && xb_in) col[(ob + pb) * kGdStride] += fx * fy * diff;
           }
         }
       }
     }
   }
-  __syncthreads();
-  // write the tile: every element of grad_data[b, c_first .. c_first + 255] inside the tile, used channel or not
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  // write the tile: every element of grad_data[b, c_first .. c_first + 63] inside the tile, used channel or not
   const int tw = tx1 - tx0 + 1, th = ty1 - ty0 + 1;
-  for (int e = tid; e < kThreads * kTilePix; e += kThreads) {
+  for (int e = tid; e < kGdThreads * kTilePix; e += kGdThreads) {
     const int ch = e / kTilePix, p = e - ch * kTilePix;
     const int y = p / kTileW, x = p - y * kTileW;
     if (c_first + ch >= s.C || y >= th || x >= tw) continue;
-    grad_data[(((long long)b * s.C + c_first + ch) * s.H + ty0 + y) * s.W + tx0 + x] = acc[p * kAccStride + ch];
+    grad_data[(((long long)b * s.C + c_first + ch) * s.H + ty0 + y) * s.W + tx0 + x] = acc[p * kGdStride + ch];
   }
 }
 
@@ -640,8 +651,9 @@ int kgdet_deform_psroi_backward(const kgdet_psroi_shape *s, const float *grad_ou
   if (!attr_set) {
     KGDET_HIP_TRY(hipFuncSetAttribute((const void *)psroi_gather<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       150 * 1024));
-    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)psroi_grad_data, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      150 * 1024));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)psroi_grad_data<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)psroi_grad_data<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)psroi_grad_data<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_set = true;
   }
   hipLaunchKernelGGL(psroi_prepare, dim3(s->R), dim3(kThreads), 0, (hipStream_t)stream, *s, rois, trans, grad_out, count,
@@ -649,11 +661,14 @@ int kgdet_deform_psroi_backward(const kgdet_psroi_shape *s, const float *grad_ou
   KGDET_CHECK_LAUNCH("psroi_prepare");
   const int tiles_x = ceil_div(s->W, kTileW), tiles_y = ceil_div(s->H, kTileH);
   const int list_cap = s->R < kListCap ? s->R : kListCap;
-  const size_t lds = nrec * sizeof(Rec) + (size_t)kTilePix * kAccStride * sizeof(float) + (size_t)list_cap * sizeof(int);
-  KGDET_CHECK_SHAPE(s->B <= 65535 && ceil_div(s->C, kThreads) <= 65535, "batch / channel count beyond the launch grid");
-  hipLaunchKernelGGL(psroi_grad_data, dim3(tiles_x * tiles_y, ceil_div(s->C, kThreads), s->B), dim3(kThreads), lds,
-                     (hipStream_t)stream, *s, rois, bbox, recs_ws, diffT, grad_data, classes, ch_per_class, tiles_x,
-                     list_cap);
+  const size_t lds = nrec * sizeof(Rec) + (size_t)kTilePix * kGdStride * sizeof(float) + (size_t)list_cap * sizeof(int);
+  KGDET_CHECK_SHAPE(s->B <= 65535 && ceil_div(s->C, kGdThreads) <= 65535, "batch / channel count beyond the launch grid");
+  const dim3 gd_grid(tiles_x * tiles_y, ceil_div(s->C, kGdThreads), s->B);
+#define KGDET_GD_ARGS (hipStream_t)stream, *s, rois, bbox, recs_ws, diffT, grad_data, classes, ch_per_class, tiles_x, list_cap
+  if (nrec <= 4 * kGdThreads) hipLaunchKernelGGL(psroi_grad_data<4>, gd_grid, dim3(kGdThreads), lds, KGDET_GD_ARGS);
+  else if (nrec <= 13 * kGdThreads) hipLaunchKernelGGL(psroi_grad_data<13>, gd_grid, dim3(kGdThreads), lds, KGDET_GD_ARGS);
+  else hipLaunchKernelGGL(psroi_grad_data<32>, gd_grid, dim3(kGdThreads), lds, KGDET_GD_ARGS);
+#undef KGDET_GD_ARGS
   KGDET_CHECK_LAUNCH("psroi_grad_data");
   if (!s->no_trans) {
     if (int rc = launch_cell_major(s, data, dataT, (hipStream_t)stream)) return rc;

@@ -99,6 +99,7 @@ class _HeadLoss(torch.autograd.Function):
         return tuple(out[k] for k in range(9))
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, *grad_losses):
         maps = ctx.saved_tensors
         dev = maps[0].device

@@ -63,6 +63,7 @@ class _RepOffsets(torch.autograd.Function):
         return tuple(outs)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, g0, g1, g2):
         from . import _lib
         B, C, H, W = ctx.shape

@@ -5,6 +5,6 @@ R=${1:-r01i}
 OUT=/tmp/inferprof
 rm -rf $OUT; mkdir -p $OUT $GRAFT_REPO_ROOT/gpurun_out/$R
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT -o infer -- python3 $GRAFT_REPO_ROOT/bench.py --mode infer --dtype bf16 --imgs-per-gpu 8 --graph 0 --steps 10 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/infer.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT -o infer -- python3 $GRAFT_REPO_ROOT/bench.py --mode infer --dtype bf16 --imgs-per-gpu 8 --graph 0 --steps 10 --warmup 2 --windows 1 --no-cpu-baseline --no-roofline > $OUT/infer.log 2>&1
 python3 $GRAFT_REPO_ROOT/tools/trace_steady_stats.py $OUT/infer_kernel_trace.csv multiclass_select 1 ${2:-60} > $GRAFT_REPO_ROOT/gpurun_out/$R/infer_steady.md
 head -12 $GRAFT_REPO_ROOT/gpurun_out/$R/infer_steady.md | cut -c1-150
