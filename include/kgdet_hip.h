@@ -473,9 +473,12 @@ int kgdet_soft_nms(const float *dets, int64_t n, float iou_thr, int32_t method, 
  * ------------------------------------------------------------------------------------------ */
 int kgdet_moment_bbox_forward(const float *pts, const float *moment_transfer, int32_t B, int32_t n_pts,
                               int32_t HW, int32_t y_first, float *bbox, void *stream);
+/* backward: grad_pts and grad_transfer [2] are OVERWRITTEN; the two transfer sums leave the blocks as partials in the
+ * caller's workspace and are added in block order (no float atomics: bit-repeatable). */
+size_t kgdet_moment_bbox_backward_workspace_bytes(int32_t B, int32_t HW);
 int kgdet_moment_bbox_backward(const float *pts, const float *moment_transfer, const float *grad_bbox,
                                int32_t B, int32_t n_pts, int32_t HW, int32_t y_first, float *grad_pts,
-                               float *grad_transfer, void *stream);
+                               float *grad_transfer, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

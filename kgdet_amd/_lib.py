@@ -59,7 +59,8 @@ def lib():
         L.kgdet_last_error.restype = ctypes.c_char_p
         for name in ('kgdet_dcn_packed_weight_bytes', 'kgdet_dcn_workspace_bytes', 'kgdet_dcn_group_workspace_bytes',
                      'kgdet_nms_workspace_bytes', 'kgdet_deform_psroi_backward_workspace_bytes',
-                     'kgdet_deform_psroi_forward_workspace_bytes', 'kgdet_head_loss_workspace_bytes'):
+                     'kgdet_deform_psroi_forward_workspace_bytes', 'kgdet_head_loss_workspace_bytes',
+                     'kgdet_moment_bbox_backward_workspace_bytes'):
             if hasattr(L, name):
                 getattr(L, name).restype = ctypes.c_size_t
         _lib = L

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kLoc * kSplit) void moment_bbox_backward(const floa
                                                             const float *__restrict__ transfer,
                                                             const float *__restrict__ grad_bbox, int B, int n, int HW,
                                                             int y_first, float *__restrict__ grad_pts,
-                                                            float *__restrict__ grad_transfer) {
+                                                            float *__restrict__ partial /*[gridDim.x][2]*/) {
   __shared__ float red[kSplit][kLoc];
   const int l = threadIdx.x & (kLoc - 1), w = threadIdx.x >> 6;
   const long long idx = blockIdx.x * (long long)kLoc + l;
@@ -121,11 +121,21 @@ __global__ __launch_bounds__(kLoc * kSplit) void moment_bbox_backward(const floa
       gt0 += __shfl_xor(gt0, d);
       gt1 += __shfl_xor(gt1, d);
     }
-    if (l == 0) {
-      atomicAdd(grad_transfer, gt0);
-      atomicAdd(grad_transfer + 1, gt1);
+    if (l == 0) {      // per-block partials, added in block order by moment_transfer_finish: no float atomics, bit-repeatable
+      partial[2 * blockIdx.x] = gt0;
+      partial[2 * blockIdx.x + 1] = gt1;
     }
   }
+}
+
+__global__ __launch_bounds__(64) void moment_transfer_finish(const float *__restrict__ partial, int blocks,
+                                                             float *__restrict__ grad_transfer) {
+  const int l = threadIdx.x;
+  float a = 0.f, b = 0.f;
+  for (int i = l; i < blocks; i += 64) { a += partial[2 * i]; b += partial[2 * i + 1]; }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
+  if (l == 0) { grad_transfer[0] = a; grad_transfer[1] = b; }
 }
 
 }  // namespace kgdet
@@ -147,16 +157,24 @@ int kgdet_moment_bbox_forward(const float *pts, const float *moment_transfer, in
   return KGDET_OK;
 }
 
+size_t kgdet_moment_bbox_backward_workspace_bytes(int32_t B, int32_t HW) {
+  return (size_t)(((long long)(B > 0 ? B : 0) * (HW > 0 ? HW : 0) + 63) / 64) * 2 * sizeof(float) + 16;
+}
+
 int kgdet_moment_bbox_backward(const float *pts, const float *moment_transfer, const float *grad_bbox, int32_t B,
                                int32_t n_pts, int32_t HW, int32_t y_first, float *grad_pts, float *grad_transfer,
-                               void *stream) {
+                               void *workspace, size_t workspace_bytes, void *stream) {
   KGDET_CHECK_SHAPE(B >= 0 && HW >= 0, "bad sizes");
   KGDET_CHECK_SHAPE(n_pts >= 2, "moment bbox needs at least 2 points (unbiased std)");
   if ((long long)B * HW == 0) return KGDET_OK;
   KGDET_CHECK_SHAPE(pts && moment_transfer && grad_bbox && grad_pts && grad_transfer, "null pointer");
+  KGDET_CHECK_SHAPE(workspace && workspace_bytes >= kgdet_moment_bbox_backward_workspace_bytes(B, HW),
+                    "workspace too small (kgdet_moment_bbox_backward_workspace_bytes)");
   const int grid = (int)(((long long)B * HW + 63) / 64);
   hipLaunchKernelGGL(moment_bbox_backward, dim3(grid), dim3(kLoc * kSplit), 0, (hipStream_t)stream, pts, moment_transfer,
-                     grad_bbox, B, n_pts, HW, y_first, grad_pts, grad_transfer);
+                     grad_bbox, B, n_pts, HW, y_first, grad_pts, (float *)workspace);
+  hipLaunchKernelGGL(moment_transfer_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float *)workspace, grid,
+                     grad_transfer);
   KGDET_CHECK_LAUNCH("moment_bbox_backward");
   return KGDET_OK;
 }

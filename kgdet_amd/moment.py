@@ -40,11 +40,14 @@ class MomentBBoxFunction(Function):
         B, C2, H, W = pts.shape
         grad_bbox = grad_bbox.contiguous().float()
         grad_pts = torch.empty_like(pts)
-        grad_mt = torch.zeros_like(mt)
-        _lib.check(_lib.lib().kgdet_moment_bbox_backward(
+        grad_mt = torch.empty_like(mt)        # (written by the kernel: per-block partials added in block order, no atomics)
+        L = _lib.lib()
+        ws_bytes = L.kgdet_moment_bbox_backward_workspace_bytes(ctypes.c_int32(B), ctypes.c_int32(H * W))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pts.device)
+        _lib.check(L.kgdet_moment_bbox_backward(
             _lib.ptr(pts), _lib.ptr(mt), _lib.ptr(grad_bbox), ctypes.c_int32(B), ctypes.c_int32(C2 // 2),
             ctypes.c_int32(H * W), ctypes.c_int32(1 if ctx.y_first else 0), _lib.ptr(grad_pts),
-            _lib.ptr(grad_mt), _lib.current_stream()), 'kgdet_moment_bbox_backward')
+            _lib.ptr(grad_mt), _lib.ptr(ws), ctypes.c_size_t(ws_bytes), _lib.current_stream()), 'kgdet_moment_bbox_backward')
         return grad_pts, grad_mt, None
 
 

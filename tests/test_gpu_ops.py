@@ -496,3 +496,22 @@ def test_glue_kernels_match_the_torch_chain():
 def configs_kgdet():
     from kgdet_amd import configs
     return configs.kgdet_r50_fpn()
+
+
+def test_moment_bbox_backward_is_bit_repeatable():
+    """the transfer gradient is summed from per-block partials in block order (round 3; it used float atomics): same bits every run"""
+    from kgdet_amd.moment import moment_bbox
+    g = torch.Generator().manual_seed(0)
+    pts = torch.randn(2, 166, 50, 84, generator=g).cuda().requires_grad_()
+    mt = torch.tensor([0.2, -0.1]).cuda().requires_grad_()
+    go = torch.randn(2, 4, 50, 84, generator=g).cuda()
+    res = []
+    for _ in range(3):
+        pts.grad = mt.grad = None
+        moment_bbox(pts, mt, True).backward(go)
+        res.append((pts.grad.clone(), mt.grad.clone()))
+    assert all(torch.equal(res[0][0], r[0]) and torch.equal(res[0][1], r[1]) for r in res[1:])
+    ref_mt = mt.detach().double().requires_grad_()
+    p64 = pts.detach().double().requires_grad_()
+    _moment_ref(p64, ref_mt, True).backward(go.double())
+    assert (res[0][1].double() - ref_mt.grad).abs().max() <= 1e-5 * ref_mt.grad.abs().max()
