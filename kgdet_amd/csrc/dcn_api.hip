@@ -187,7 +187,6 @@ bool mfma_ok(const kgdet_dcn_shape *s) {
   return s->W >= 2 && ((s->C / s->deformable_groups) % 4 == 0 || s->deformable_groups == 1);
 }
 // plane forward kernel: a 16-channel slice of one input image must fit in LDS next to the operand stages
-constexpr int kPlaneMaxHW = 1536;
 bool plane_ok(const kgdet_dcn_shape *s, const Derived &d) {
   const int cpdg = s->C / s->deformable_groups;  // a producer thread samples a 16-channel chunk with one tap record
   return mfma_ok(s) && (s->deformable_groups == 1 || cpdg % 16 == 0) && s->H * s->W <= kPlaneMaxHW &&

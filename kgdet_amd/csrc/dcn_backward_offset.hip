@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void dcn_build_grad_taps(const DcnFwdGroup grp
     const float ka = geo.va ? m : 0.f, kb = geo.vb ? m : 0.f, kc = geo.vc ? m : 0.f, kd = geo.vd ? m : 0.f;
     unsigned off[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) off[e] = (unsigned)(dcn_plane_offset(tap.o[e]) + (((tap.o[e] >> 2) & 3) << 4));
+    for (int e = 0; e < 4; ++e) off[e] = (unsigned)dcn_plane_offset(tap.o[e]);
     out[i * rs + 0] = make_uint4(off[0], off[1], off[2], off[3]);
     // d/dy = hx (v10 - v00) + lx (v11 - v01),  d/dx = hy (v01 - v00) + ly (v11 - v10)   (:144-187)
     out[i * rs + 1] = make_uint4(__float_as_uint(-hx * ka), __float_as_uint(-geo.lx * kb), __float_as_uint(hx * kc),
@@ -70,9 +70,11 @@ __global__ __launch_bounds__(256) void dcn_build_grad_taps(const DcnFwdGroup grp
   }
 }
 
-// LDS: A [2][PARTS][8 KB] | offs_acc [K][128][2 (v2: 4)] fp32 | x plane [H*W][16 ch] fp32
+// LDS: A [2][PARTS][8 KB] | offs_acc [K][128][2 (v2: 4)] fp32 | x plane [4 quads][H*W padded to 64][4 ch] fp32
+// (the quad planes of dcn_common.h at a run-time stride: what is left for the plane depends on K)
 size_t dcn_bwd_offset_plane_lds_bytes(int parts, int K, int HW, int masked) {
-  return (size_t)2 * parts * kAPart + (size_t)K * kTileN * (masked ? 4 : 2) * sizeof(float) + (size_t)kChunk * HW * sizeof(float);
+  return (size_t)2 * parts * kAPart + (size_t)K * kTileN * (masked ? 4 : 2) * sizeof(float) +
+         (size_t)kChunk * dcn_plane_padded_pixels(HW) * sizeof(float);
 }
 int dcn_bwd_offset_plane_threads() { return kOffThreads; }
 
@@ -102,6 +104,8 @@ __device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__res
     const DcnUnitPos pos = dcn_unit_pos(grp, cur);
     const DcnProblem &p = grp.p[pos.pi];
     const int HW = p.H * p.W;
+    const unsigned qstride = (unsigned)dcn_plane_padded_pixels(HW) * 16u;   // bytes between the plane's channel quads
+    const unsigned char *plane_kg = plane + kg * qstride;                     // consumers: this lane's quad plane
     const int K = p.K;
     const int cpt = p.chunks_per_tile;
     const int nt = pos.tile;  // one M "tile": the channel chunks are part of the reduction here
@@ -198,33 +202,13 @@ __device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__res
           }
         }
       };
-      auto load_plane = [&]() {  // as in plane_role: x[tile_b, 16 channels of chunk c16] -> LDS [pixel][16 ch], swizzled
-        const int c0 = c16 * kChunk;
+      auto load_plane = [&]() {  // as in plane_role: x[tile_b, 16 channels of chunk c16] -> the LDS quad planes
+        // (channels past the group's end must read as ZERO here: they would otherwise enter grad_offset through a
+        // non-zero colgrad of padded weight rows... which are zero; keep both sides zero)
         const float *xb = p.x + ((long long)tile_b * p.C_total + p.c_base) * HW;
-        const int items = 4 * HW;
-        for (int i0 = 0; i0 < items; i0 += kPlaneRounds * kOffThreads) {
-          f32x4 v[kPlaneRounds];
-#pragma unroll
-          for (int r = 0; r < kPlaneRounds; ++r) {
-            const int i = min(i0 + r * kOffThreads + wtid, items - 1);
-            const int q = i % HW, quad = i / HW;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int ch = c0 + quad * 4 + e;
-              // channels past the group's end must read as ZERO here (they would otherwise enter grad_offset
-              // through a non-zero colgrad of padded weight rows... which are zero; keep both sides zero)
-              v[r][e] = ch < p.Cg ? xb[(long long)ch * HW + q] : xb[(long long)(p.Cg - 1) * HW + q] * 0.0f;
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < kPlaneRounds; ++r) {
-            const int i = i0 + r * kOffThreads + wtid;
-            if (i < items) {
-              const int q = i % HW, quad = i / HW;
-              *reinterpret_cast<f32x4 *>(plane + dcn_plane_offset(q) + ((quad ^ ((q >> 2) & 3)) << 4)) = v[r];
-            }
-          }
-        }
+        dcn_plane_copy<kPlaneRounds, true>(xb, HW, p.Cg, c16 * kChunk, plane, qstride,
+                                           __builtin_amdgcn_readfirstlane(wtid >> 6), kOffThreads / 64, dcn_plane_units(HW),
+                                           wtid & 63);
       };
       // one stage on the consumer side: colgrad block, derivative dot products, tap accumulators
       auto consume = [&](int j, int buf, const Regs &R) {
@@ -250,7 +234,7 @@ __device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__res
           float gy = 0.f, gx = 0.f, gm = 0.f;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(plane + (o[e] ^ (unsigned)(kg << 4)));
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(plane_kg + o[e]);
             const float d = cg[0] * v[0] + cg[1] * v[1] + cg[2] * v[2] + cg[3] * v[3];
             gy += R.wy[e] * d;
             gx += R.wx[e] * d;

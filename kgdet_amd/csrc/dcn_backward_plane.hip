@@ -17,32 +17,22 @@
 // split MFMA, stream-K with the forward's fix-up.  No atomics, deterministic, no pre-zeroing of grad_input.
 // Deformable groups > 1 (different cells lists per channel group inside one M tile) stay on the older kernels.
 #include "dcn_plane.h"
-#ifdef KGDET_PLANE_PHASED   // experiment build: the phased body (dcn_plane_phased.h) instead of producer / consumer waves
-#include "dcn_plane_phased.h"
-#endif
 
 namespace kgdet {
 
 template <int PARTS>
-#ifdef KGDET_PLANE_PHASED
-__global__ __launch_bounds__(kPhThreads, 1) void dcn_bwd_input_plane(const DcnFwdGroup grp, float *__restrict__ slabs) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  plane_phased<PARTS, 1>(grp, slabs, smem);
-}
-#else
 __global__ __launch_bounds__(kPlaneThreads, 1) void dcn_bwd_input_plane(const DcnFwdGroup grp, float *__restrict__ slabs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (threadIdx.x >= kThreads) plane_role<PARTS, true, 1>(grp, slabs, smem);
   else plane_role<PARTS, false, 1>(grp, slabs, smem);
 }
-#endif
 
 template __global__ void dcn_bwd_input_plane<1>(const DcnFwdGroup grp, float *__restrict__ slabs);
 template __global__ void dcn_bwd_input_plane<2>(const DcnFwdGroup grp, float *__restrict__ slabs);
 
 size_t dcn_bwd_input_plane_fixed_lds_bytes(int parts) { return (size_t)2 * kGroupTaps * parts * kBPart; }
 size_t dcn_bwd_input_plane_lds_bytes(int parts, int plane_pixels) {
-  return dcn_bwd_input_plane_fixed_lds_bytes(parts) + (size_t)kChunk * plane_pixels * sizeof(float);
+  return plane_pixels <= kPlaneMaxHW ? dcn_bwd_input_plane_fixed_lds_bytes(parts) + (size_t)4 * kPlaneQuadStride : (size_t)1 << 30;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -140,7 +130,7 @@ __device__ __forceinline__ void build_inverse_taps_body(const DcnProblem &p, uin
   }
   __syncthreads();
   // pixel -> LDS byte offset of its quad 0 (< 2^17: the upper 15 bits of a record's last offset are free)
-  auto plane_off = [](int px) { return (unsigned)(dcn_plane_offset(px) + (((px >> 2) & 3) << 4)); };
+  auto plane_off = [](int px) { return (unsigned)dcn_plane_offset(px); };
   uint4 *inv_bt = inv + (size_t)(b * p.K + t) * HW * 4;
   // overflow: contributions 8.. of every cell, compacted in cell order; `cursor` becomes their start positions
   for (int cell = tid; cell < HW; cell += 256) {

@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void dcn_pack_grad_out(const float *__restrict
 
 int dcn_bwd_weight_plane_threads() { return kPlaneThreads; }
 size_t dcn_bwd_weight_plane_lds_bytes(int parts, int HW) {
-  return (size_t)3 * parts * kAPart + (size_t)2 * parts * kBPart + 2 * 4096 + (size_t)kChunk * HW * sizeof(float);
+  return (size_t)3 * parts * kAPart + (size_t)2 * parts * kBPart + 2 * 4096 +
+         (size_t)kChunk * dcn_plane_padded_pixels(HW) * sizeof(float);
 }
 
 // element (row o, column n) of tile (mt, c16, tg) -> grad_weight[o][c][t]
@@ -77,7 +78,7 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
   unsigned char *As = smem;                                       // [3][PARTS][kAPart]  (ring)
   unsigned char *Bs = smem + 3 * PARTS * kAPart;                  // [2][PARTS][kBPart]
   u32x4 *Rs = reinterpret_cast<u32x4 *>(smem + 3 * PARTS * kAPart + 2 * PARTS * kBPart);  // [2][256] record pieces
-  unsigned char *plane = smem + 3 * PARTS * kAPart + 2 * PARTS * kBPart + 2 * 4096;  // [H*W][16 channels] fp32, swizzled
+  unsigned char *plane = smem + 3 * PARTS * kAPart + 2 * PARTS * kBPart + 2 * 4096;  // [4 quads][H*W padded][4 channels] fp32
 
   const int wtid = threadIdx.x;
   const int tid = PRODUCER ? wtid - kThreads : wtid;
@@ -97,6 +98,8 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
     const DcnUnitPos pos = dcn_unit_pos(grp, cur);
     const DcnProblem &p = grp.p[pos.pi];
     const int HW = p.H * p.W;
+    const unsigned qstride = (unsigned)dcn_plane_padded_pixels(HW) * 16u;   // bytes between the plane's channel quads
+    const unsigned char *plane_q = plane + quad * qstride;                    // producers: this thread's quad plane
     const int K = p.K, HoWo = p.HoWo;
     const int cpt = p.chunks_per_tile;        // stages per tile = N * n_px16
     const int n_px16 = p.chunks_per_tap;      // stages per image
@@ -171,28 +174,10 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
         }
         Rs[r_slot2 * 256 + r_slot] = R.rec;
       };
-      auto load_plane = [&]() __attribute__((always_inline)) {  // x[b, chunk c16] -> LDS [pixel][16 ch] fp32, quad slots XOR-swizzled (dcn_plane.h)
-        const int c0 = c16 * kChunk;
+      auto load_plane = [&]() __attribute__((always_inline)) {  // x[b, chunk c16] -> the LDS quad planes (dcn_common.h)
         const float *xb = p.x + ((long long)b * p.C_total + p.c_base) * HW;
-        const int items = 4 * HW;
-        for (int i0 = 0; i0 < items; i0 += kPlaneRounds * kPlaneThreads) {
-          f32x4 v[kPlaneRounds];
-#pragma unroll
-          for (int r = 0; r < kPlaneRounds; ++r) {
-            const int i = min(i0 + r * kPlaneThreads + wtid, items - 1);
-            const int qq = i % HW, qd = i / HW;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[r][e] = xb[(long long)min(c0 + qd * 4 + e, p.Cg - 1) * HW + qq];
-          }
-#pragma unroll
-          for (int r = 0; r < kPlaneRounds; ++r) {
-            const int i = i0 + r * kPlaneThreads + wtid;
-            if (i < items) {
-              const int qq = i % HW, qd = i / HW;
-              *reinterpret_cast<f32x4 *>(plane + dcn_plane_offset(qq) + ((qd ^ ((qq >> 2) & 3)) << 4)) = v[r];
-            }
-          }
-        }
+        dcn_plane_copy<kPlaneRounds>(xb, HW, p.Cg, c16 * kChunk, plane, qstride, __builtin_amdgcn_readfirstlane(wtid >> 6),
+                                     kPlaneThreads / 64, dcn_plane_units(HW), wtid & 63);
       };
       // sampler: 4 pixels x 4 channels at one tap -> four 8-byte pieces of B rows (channel, tap)
       auto sample = [&](int buf) __attribute__((always_inline)) {  // B stage (slot buf) from the records in Rs[buf] and the plane
@@ -208,7 +193,7 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
           f32x2 lo2 = {0.f, 0.f}, hi2 = {0.f, 0.f};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(plane + (o[e] ^ (unsigned)(quad << 4)));
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(plane_q + o[e]);
             const f32x2 we = {w[e], w[e]};
             lo2 = __builtin_elementwise_fma(we, f32x2{v[0], v[1]}, lo2);
             hi2 = __builtin_elementwise_fma(we, f32x2{v[2], v[3]}, hi2);

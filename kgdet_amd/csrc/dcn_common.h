@@ -27,7 +27,7 @@ constexpr int kTileElems = kTileM * kTileN;
 // corners of (image, tap, output pixel) sit in the LDS feature plane and what they weigh (0 where a corner, or
 // the whole tap, falls outside the image; x the modulation mask for v2).
 struct DcnTapRec {
-  unsigned off[4];  // LDS byte offset of channel quad 0 of the corner pixel; quad c is at off ^ (c << 4)
+  unsigned off[4];  // LDS byte offset of channel quad 0 of the corner pixel (pixel * 16); quad c is one quad stride further
   float w[4];
 };
 // Transposed sampling (grad_input plane kernel): what input cell q collects for tap t.
@@ -42,8 +42,81 @@ struct DcnInvOvfSlots {
   uint2 e[kCap];
 };
 
-// byte offset of pixel q's 64-byte row in the [pixel][16 channel] LDS plane
-__device__ __forceinline__ int dcn_plane_offset(int q) { return q * 64; }
+// The LDS feature plane of the plane kernels: a 16-channel slice of one image as FOUR quad planes
+// [quad][pixel][4 channels] fp32 -- pixel q's channel quad c at c * stride + q * 16.  A bilinear corner of 4 channels is
+// one ds_read_b128, and the quad is an IMMEDIATE offset of that instruction where the stride is a compile-time constant
+// (kPlaneQuadStride: plane_role, the forward / grad_input kernels, whose plane starts at LDS address 0), so a tap
+// record's four offsets are used as they are (the [pixel][16 channel] rows of rounds 1-2 needed an XOR swizzle per read
+// to spread the quads over the banks: 12 VALU instructions per stage and SIMD beside the MFMA waves).  16 consecutive
+// pixels of a quad cover all 64 banks.  grad_offset / grad_weight kernels use the same records with a run-time stride
+// of pixels_padded * 16 (their LDS budgets depend on K).
+constexpr int kPlaneMaxHW = 1344;                       // 3 * stride must fit the 16-bit offset field of ds_read
+constexpr int kPlaneQuadStride = kPlaneMaxHW * 16;      // 21504 B
+__device__ __host__ __forceinline__ int dcn_plane_offset(int q) { return q * 16; }
+__device__ __host__ __forceinline__ int dcn_plane_padded_pixels(int HW) { return (HW + 63) & ~63; }
+
+// Copy x[image, c0 .. c0 + 15, :, :] (xb = the image's first channel of the group, Cg channels, HW pixels each) into the
+// quad planes.  The work is cut into UNITS = (quad, block of 64 pixels), one wave per unit: quad and block are wave-uniform,
+// so the four loads of an item are buffer loads with ONE shared 32-bit lane offset and the 16-byte LDS store needs
+// one address add -- 4 vector instructions per unit and lane (the item-per-thread copy of rounds 1-2 spent ~39 on the
+// divisions by HW and 64-bit addresses, a third of all VALU instructions of the forward kernel).  Lanes past the end
+// of the image re-read its last pixel and store into the padding of their quad plane (stride >= padded pixels * 16).
+// This wave takes units u_first, u_first + u_step, ... < u_hi, ROUNDS of them in flight (all loads before the first
+// store, unconditional from clamped addresses, so the counted s_waitcnt stay exact).  u_first, u_step, u_hi must be
+// wave-uniform (readfirstlane).  ZERO_PAD: channels past Cg read as zero instead of repeating the last one.
+// Buffer resource over a wave-uniform base pointer (pinned to SGPRs with readfirstlane): loads through it take the form
+// buffer_load v, v_offset, s[rsrc], s_offset -- a 32-bit lane offset, a scalar offset computed on the scalar unit and an
+// immediate -- so a load costs NO vector instruction beside the MFMA waves.  (Plain pointers read out of a dynamically
+// indexed DcnProblem lose their address space: hipcc emits flat_load with a 64-bit vector add per load, and flat loads
+// also count on lgkmcnt, the counter the LDS reads wait on.)  Offsets are bytes, < 4 GB from the base; no range check.
+typedef __amdgpu_buffer_rsrc_t dcn_rsrc_t;
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dcn_rsrc_t dcn_make_rsrc(const void *ptr) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ float dcn_buf_f32(dcn_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ u32x4_t dcn_buf_b128(dcn_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+}
+template <int ROUNDS, bool ZERO_PAD = false>
+__device__ __forceinline__ void dcn_plane_copy(const float *__restrict__ xb, int HW, int Cg, int c0, unsigned char *plane,
+                                               unsigned stride, int u_first, int u_step, int u_hi, int lane) {
+  const int nblk = (HW + 63) >> 6;
+  // (u >= k * nblk) as 1 + ((u - k * nblk) >> 31): sums of compare results make hipcc leave the scalar unit
+  auto quad_of = [&](int u) { return 3 + ((u - nblk) >> 31) + ((u - 2 * nblk) >> 31) + ((u - 3 * nblk) >> 31); };
+  const dcn_rsrc_t xrs = dcn_make_rsrc(xb);
+  for (int u0 = u_first; u0 < u_hi; u0 += ROUNDS * u_step) {
+    f32x4 v[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int u = min(u0 + r * u_step, u_hi - 1);
+      const int quad = quad_of(u);
+      const int blk = u - quad * nblk;
+      const unsigned voff = (unsigned)min(blk * 64 + lane, HW - 1) * 4u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ch = c0 + quad * 4 + e;
+        const unsigned soff = (unsigned)(min(ch, Cg - 1) * HW) * 4u;   // (a channel group of one image: < 4 GB)
+        const float f = dcn_buf_f32(xrs, voff, soff);
+        v[r][e] = (ZERO_PAD && ch >= Cg) ? f * 0.0f : f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int u = u0 + r * u_step;
+      if (u < u_hi) {
+        const int quad = quad_of(u);
+        const int blk = u - quad * nblk;
+        *reinterpret_cast<f32x4 *>(plane + quad * stride + (unsigned)(blk * 64 + lane) * 16u) = v[r];
+      }
+    }
+  }
+}
+__device__ __forceinline__ int dcn_plane_units(int HW) { return 4 * ((HW + 63) >> 6); }
 
 // One deformable convolution problem as the kernels see it (one weight group).
 struct DcnProblem {

@@ -10,9 +10,10 @@
 //     a_lo*b_lo term and the representation residuals are <= 2^-16 relative per product (against the f64
 //     oracle: ~1e-6 of the output scale, tests/test_gpu_dcn.py).  PARTS = 1 keeps only the hi parts:
 //     plain bf16 operands for autocast inference.
-//   * gathers: a 16-channel slice of ONE image is copied into LDS as [pixel][16 channels] (67 KB at 25x42)
-//     and reused by all K taps of that channel chunk, so a bilinear corner of 4 channels is one
-//     ds_read_b128; the reduction runs chunk-major / tap-minor and pixel tiles never straddle images.
+//   * gathers: a 16-channel slice of ONE image is copied into LDS as four quad planes [quad][pixel][4 channels]
+//     (dcn_common.h; 67 KB at 25x42) and reused by all K taps of that channel chunk, so a bilinear corner of 4
+//     channels is one ds_read_b128 whose address is the record's offset + an immediate; the reduction runs
+//     chunk-major / tap-minor and pixel tiles never straddle images.
 //   * sampling geometry is not recomputed per channel chunk: dcn_build_taps writes one 32-byte record per
 //     (image, tap, output pixel) -- four LDS byte offsets and four bilinear weights -- and the kernel only
 //     loads it.  With the split MFMA the kernel is bound by the issue port MFMA and VALU instructions share (SQ
@@ -32,34 +33,20 @@
 //   element k = khalf*8 + j is channel c16*16 + k for both operands.
 #include "dcn_plane.h"
 #include "dcn_plane_pairs.h"
-#ifdef KGDET_PLANE_PHASED   // experiment build: the phased body (dcn_plane_phased.h) instead of producer / consumer waves
-#include "dcn_plane_phased.h"
-#endif
 
 namespace kgdet {
 
 template <int PARTS>
-#ifdef KGDET_PLANE_PHASED
-__global__ __launch_bounds__(kPhThreads, 1) void dcn_fwd_plane(const DcnFwdGroup grp, float *__restrict__ slabs) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  plane_phased<PARTS, 0>(grp, slabs, smem);
-}
-#else
 __global__ __launch_bounds__(kPlaneThreads, 1) void dcn_fwd_plane(const DcnFwdGroup grp, float *__restrict__ slabs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (threadIdx.x >= kThreads) plane_role<PARTS, true, 0>(grp, slabs, smem);
   else plane_role<PARTS, false, 0>(grp, slabs, smem);
 }
-#endif
 
 template __global__ void dcn_fwd_plane<1>(const DcnFwdGroup grp, float *__restrict__ slabs);
 template __global__ void dcn_fwd_plane<2>(const DcnFwdGroup grp, float *__restrict__ slabs);
 
-#ifdef KGDET_PLANE_PHASED
-int dcn_fwd_plane_threads() { return kPhThreads; }
-#else
 int dcn_fwd_plane_threads() { return kPlaneThreads; }
-#endif
 
 // K >= 7 taps: half-chunk planes, tap-pair stages (dcn_plane_pairs.h)
 template <int PARTS>
@@ -110,17 +97,18 @@ __global__ __launch_bounds__(256) void dcn_build_taps(const DcnFwdGroup grp) {
     for (int e = 0; e < 4; ++e) {
       const int q = tap.o[e];
       r.off[e] = grp.pair_mode ? (unsigned)(q * kPairRow + (((q >> 3) & 1) << 4))      // half-plane rows (dcn_plane_pairs.h)
-                               : (unsigned)(dcn_plane_offset(q) + (((q >> 2) & 3) << 4));
+                               : (unsigned)dcn_plane_offset(q);
       r.w[e] = tap.w[e];
     }
     const_cast<DcnTapRec *>(p.taps)[i] = r;
   }
 }
 
-// LDS of dcn_fwd_plane: two groups of B stages + the feature plane
+// LDS of dcn_fwd_plane: the four quad planes at their fixed stride (whatever the image size: the quad is an immediate
+// offset of the corner reads) + two groups of B stages
 size_t dcn_fwd_plane_fixed_lds_bytes(int parts) { return (size_t)2 * kGroupTaps * parts * kBPart; }
 size_t dcn_fwd_plane_lds_bytes(int parts, int HW) {
-  return dcn_fwd_plane_fixed_lds_bytes(parts) + (size_t)kChunk * HW * sizeof(float);
+  return HW <= kPlaneMaxHW ? dcn_fwd_plane_fixed_lds_bytes(parts) + (size_t)4 * kPlaneQuadStride : (size_t)1 << 30;
 }
 
 // ----------------------------------------------------------------------------------------------

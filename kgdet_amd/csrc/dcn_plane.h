@@ -95,12 +95,19 @@ struct PlaneStageRegs {
 // accumulators exist only in the consumers' register allocation.
 template <int PARTS, bool PRODUCER, int MODE>
 __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__restrict__ slabs, unsigned char *smem) {
-  unsigned char *Bs = smem;                                          // [2 groups][kGroupTaps][PARTS][kBPart]
-  unsigned char *plane = smem + 2 * kGroupTaps * PARTS * kBPart;     // [pixels][16 ch] fp32
+  unsigned char *plane = smem;                                       // [4 quads][kPlaneMaxHW pixels][4 ch] fp32, LDS address 0:
+                                                                     // tap-record offsets + an immediate address a corner read
+  unsigned char *Bs = smem + 4 * kPlaneQuadStride;                   // [2 groups][kGroupTaps][PARTS][kBPart]
+  // a corner read: the record's offset IS the LDS address (through `plane + offset` hipcc adds the symbol's 0 per read)
+  typedef const f32x4 __attribute__((address_space(3))) *LdsQuadPtr;
+  auto lds_quad = [](unsigned addr) { return *(LdsQuadPtr)(addr); };
+  if ((unsigned)(unsigned long long)(const unsigned char __attribute__((address_space(3))) *)smem != 0u) __builtin_trap();   // (no static LDS in these kernels)
 
   const int wtid = threadIdx.x;                               // 0 .. 767 (plane copy)
   const int tid = PRODUCER ? wtid - kThreads : wtid;          // position inside the role
   const int lane = tid & 63, wave = tid >> 6;
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave inside the role / among all twelve, in SGPRs
+  const int wave_all = __builtin_amdgcn_readfirstlane(wtid >> 6);  // (plane copy: wave-uniform units)
   // consumers: wave w owns rows [32 w, 32 w + 32) x all 128 columns of the tile (wave layout 1): every wave loads
   // DISTINCT weight rows, 16 KB per stage and workgroup instead of 32 KB with 4 x 2 waves of 64 x 64 -- the vector
   // memory path of a CU takes 64 B per clock, and 32 KB of fragments per stage were 512 of its ~1000 cycles
@@ -150,64 +157,47 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
     int c16 = s / K;
     int t0 = s - c16 * K;
     const int tile_in_img = nt - tile_b * p.tiles_per_image;
-    // records of (image, deformable group) for channel chunk c: [K][pixels][NG] groups of 32 B
+    // records of (image, deformable group) for channel chunk c: [K][pixels][NG] groups of 32 B; seg_records = byte offset
+    // of the chunk's first tap (scalar), rec_lane = this thread's pixel (the one vector offset of every record load)
+    const dcn_rsrc_t rec_rs = dcn_make_rsrc(p.taps);
+    const unsigned rec_lane = (unsigned)hw_c * (unsigned)(32 * NG);
     auto seg_records = [&](int c) {
       const int dgi = p.DG == 1 ? 0 : (p.c_base + min(c * kChunk, p.Cg - 1)) / p.cpdg;   // (cpdg % 16 == 0)
-      return reinterpret_cast<const uint4 *>(p.taps) + (((size_t)(tile_b * p.DG + dgi) * K) * HoWo + hw_c) * (2 * NG);
+      return (unsigned)((tile_b * p.DG + dgi) * K) * (unsigned)(HoWo * 32 * NG);
     };
     // loads of stage min(j, lim) of the segment (first tap tf) whose records start at rb: the tap record
-    auto issue = [&](const uint4 *rb, int tf, int lim, int j, Regs &R) {
+    auto issue = [&](unsigned rb, int tf, int lim, int j, Regs &R) {
       const unsigned t = (unsigned)(tf + min(j, lim));
-      const uint4 *rec = rb + (size_t)t * HoWo * (2 * NG);
+      const unsigned so = rb + t * (unsigned)(HoWo * 32 * NG);
 #pragma unroll
       for (int gq = 0; gq < NG; ++gq) {
-        R.off[gq] = rec[gq];
-        R.w[gq] = *reinterpret_cast<const f32x4 *>(rec + NG + gq);
+        R.off[gq] = __builtin_bit_cast(uint4, dcn_buf_b128(rec_rs, rec_lane + 16 * gq, so));
+        R.w[gq] = __builtin_bit_cast(f32x4, dcn_buf_b128(rec_rs, rec_lane + 16 * (NG + gq), so));
       }
       if constexpr (MODE == 1) {
         const DcnInvOvfSlots *sl = p.inv_ovf + ((size_t)(tile_b * K + t) * p.tiles_per_image + tile_in_img);
         R.ovf = *reinterpret_cast<const int2 *>(sl);   // (count, spill_start)
       }
     };
-    // Copy x[tile_b, c_base + 16*c .. +15, :, :] into LDS as [pixel][16 channels] (64 B rows), by NT threads of which
-    // this one is number `me`.  The four 16-byte channel quads of pixel q sit at slot (quad ^ ((q >> 2) & 3)): with the
-    // row start (q & 3) * 16 banks this spreads any 16 consecutive pixels of one quad over all 16 four-bank groups
-    // (ds_read_b128 / ds_write_b128 serve 16 / 8 lanes per LDS cycle) instead of the 4 groups of a plain row-major
-    // image.  A thread moves (pixel, quad) items: 4 coalesced dword loads (one per channel plane) -> one 16-byte
-    // LDS store.  All loads are issued before the first store, unconditionally from clamped addresses
-    // (a guarded load makes hipcc branch and drain the queue).
-    auto load_plane = [&](int c, int me, auto NT_, int item_lo, int item_hi) {   // items [item_lo, item_hi) of 4 * HW
-      constexpr int NT = decltype(NT_)::value;
-      const int c0 = c * kChunk;
-      const float *xb = p.x + ((long long)tile_b * p.C_total + p.c_base) * HW;
-      for (int i0 = item_lo; i0 < item_hi; i0 += kPlaneRounds * NT) {
-        f32x4 v[kPlaneRounds];
-#pragma unroll
-        for (int r = 0; r < kPlaneRounds; ++r) {
-          const int i = min(i0 + r * NT + me, item_hi - 1);
-          const int q = i % HW, quad = i / HW;  // consecutive threads -> consecutive pixels
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int ch = min(c0 + quad * 4 + e, p.Cg - 1);  // padded channels re-read the last real one
-            v[r][e] = xb[(long long)ch * HW + q];
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < kPlaneRounds; ++r) {
-          const int i = i0 + r * NT + me;
-          if (i < item_hi) {
-            const int q = i % HW, quad = i / HW;
-            *reinterpret_cast<f32x4 *>(plane + dcn_plane_offset(q) + ((quad ^ ((q >> 2) & 3)) << 4)) = v[r];
-          }
-        }
-      }
+    // Copy x[tile_b, c_base + 16*c .. +15, :, :] into the LDS quad planes (dcn_plane_copy, dcn_common.h): units
+    // [unit_lo, unit_hi) of the plane, this wave being number `w` of `NW_` waves that share them.
+    const float *xb_img = p.x + ((long long)tile_b * p.C_total + p.c_base) * HW;
+    auto load_plane = [&](int c, int w, auto NW_, auto ROUNDS_, int unit_lo, int unit_hi) {
+      constexpr int NW = decltype(NW_)::value;
+      constexpr int ROUNDS = decltype(ROUNDS_)::value;
+      dcn_plane_copy<ROUNDS>(xb_img, HW, p.Cg, c * kChunk, plane, (unsigned)kPlaneQuadStride, unit_lo + w, NW, unit_hi, lane);
     };
     // The next segment's plane is copied under the LAST group of a segment (the plane is not read any more once that
-    // group's stages are sampled): the producers, who have nothing to sample then, take the first plane_split items,
+    // group's stages are sampled): the producers, who have nothing to sample then, take the first plane_split units,
     // the consumers the rest after their MFMAs.  Split operands: the consumers are busy for four stages of 12 MFMAs,
-    // the producers take two full batches of loads; bf16: a third each way (equal shares per thread).
-    const int plane_items = 4 * HW;
-    const int plane_split = PARTS == 2 ? min(plane_items, 2 * kPlaneRounds * kProducers) : plane_items / 3;
+    // the producers take two full batches of loads; bf16: a third each way (equal shares per wave).
+    const int plane_items = dcn_plane_units(HW);
+    const int plane_split = PARTS == 2 ? min(plane_items, 2 * kPlaneRounds * (kProducers / 64)) : plane_items / 3;
+    typedef std::integral_constant<int, kPlaneThreads / 64> AllWaves;
+    typedef std::integral_constant<int, kProducers / 64> ProducerWaves;
+    typedef std::integral_constant<int, kThreads / 64> ConsumerWaves;
+    typedef std::integral_constant<int, kPlaneRounds> FullRounds;
+    typedef std::integral_constant<int, kPlaneRounds / 2> HalfRounds;   // the consumers' share is the small one
     Regs E0, E1, O0, O1;   // producers: this wave pair's two records of the even-numbered (E) and of the odd-numbered (O)
                            // groups of the segment.  Group g + 2's are loaded at the TOP of iteration g, which samples group
                            // g + 1 from the other set: a whole group to land, and no register moves (the iterations are
@@ -222,24 +212,25 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       const int r = ((n - 1) & 3) + 1;
       const int n_groups = 1 + (n - r) / kGroupTaps;
       const bool has_next = s + n < s_end;
-      const uint4 *rec_base = seg_records(c16);
+      const unsigned rec_base = seg_records(c16);
 
       // consumers: the wave's A (weight) fragments of stage j straight from the weight image (L2), 16 bytes per lane
       // and fragment, coalesced
       struct AFrag {
         bf16x8 a[PARTS];
       };
-      // (wave-uniform stage base + one 32-bit lane offset: scalar-base loads, no vector address arithmetic between MFMAs)
-      const unsigned char *wq_cons = reinterpret_cast<const unsigned char *>(p.wq) + (size_t)((mt * n_c16 + c16) * K) * (2 * kAPart);
+      // (buffer loads: wave-uniform stage offset + one 32-bit lane offset, no vector address arithmetic between MFMAs)
+      const dcn_rsrc_t wq_rs = dcn_make_rsrc(p.wq);
+      const unsigned wq_seg = (unsigned)((mt * n_c16 + c16) * K) * (unsigned)(2 * kAPart);
       const unsigned a_lane = (unsigned)((lane >> 5) * (kTileM * 16) + (wave * 32 + (lane & 31)) * 16);
       auto a_issue = [&](int j, AFrag &F) {
 #ifdef KGDET_ABL_NOALOAD
         if (j > 1) return;
 #endif
         const unsigned t = (unsigned)(t0 + min(j, n - 1));
-        const unsigned char *b = wq_cons + (size_t)t * (2 * kAPart);
 #pragma unroll
-        for (int part = 0; part < PARTS; ++part) F.a[part] = *reinterpret_cast<const bf16x8 *>(b + part * kAPart + a_lane);
+        for (int part = 0; part < PARTS; ++part)
+          F.a[part] = __builtin_bit_cast(bf16x8, dcn_buf_b128(wq_rs, a_lane, wq_seg + t * (2 * kAPart) + part * kAPart));
       };
       // ---- B stage, producers.  A group has four stages; producer wave pair w (2 waves = 128 pixels) samples stages
       // w and w + 2 of it -- a thread does ALL 16 channels of its pixel for a stage, as two half-stages of 8 channels
@@ -247,7 +238,8 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       // and four independent half-stages to interleave: it is latency-bound (a lone wave per SIMD running dependent
       // packed-fp32 chains: ~1100 cycles per stage even with the MFMA pipes idle), and with one stage per stage time it
       // was the critical path of every stage (phase trace: 233 k of 261 k cycles).
-      // Corner offsets in the record are for quad 0; quad c of the same pixel is at offset ^ (c << 4).
+      // Corner offsets in the record are for quad 0; quad c of the same pixel is kPlaneQuadStride * c further: an
+      // immediate offset of the ds_read_b128.
       typedef float f32x2 __attribute__((ext_vector_type(2)));
       typedef f32x4 Corners[2][4];
       auto corner_reads = [&](const Regs &R, int gq, int half, Corners &v) {
@@ -261,7 +253,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
 #ifdef KGDET_ABL_NOGATHER
             v[c][e] = f32x4{__uint_as_float(o[e]), R.w[gq][c], R.w[gq][e], (float)half};
 #else
-            v[c][e] = *reinterpret_cast<const f32x4 *>(plane + (o[e] ^ (unsigned)((half * 2 + c) << 4)));
+            v[c][e] = lds_quad(o[e] + (unsigned)((half * 2 + c) * kPlaneQuadStride));
 #endif
       };
       auto corner_fma = [&](const Regs &R, int gq, const Corners &v, f32x2 (&sv)[2][2], bool first) {
@@ -328,7 +320,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
             const float w = __uint_as_float(e.y);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-              const f32x4 v = *reinterpret_cast<const f32x4 *>(plane + ((e.x >> 7) ^ (unsigned)((half * 2 + c) << 4)));
+              const f32x4 v = lds_quad((e.x >> 7) + (unsigned)((half * 2 + c) * kPlaneQuadStride));
               sv[c][0] += f32x2{w * v[0], w * v[1]};
               sv[c][1] += f32x2{w * v[2], w * v[3]};
             }
@@ -441,7 +433,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
           issue(rec_base, t0, r - 1, pair, E0); issue(rec_base, t0, r - 1, pair + 2, E1);
           issue(rec_base, t0, n - 1, r + pair, O0); issue(rec_base, t0, n - 1, r + pair + 2, O1);
         }
-        load_plane(c16, wtid, std::integral_constant<int, kPlaneThreads>{}, 0, plane_items);
+        load_plane(c16, wave_all, AllWaves{}, FullRounds{}, 0, plane_items);
         KGDET_TR_ADD(1, tr_t);
         __syncthreads();
         KGDET_TR_ADD(2, tr_t);
@@ -465,10 +457,10 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
           sample_group(buf_next, Sa, Sb, true, true);
         } else if (has_next) {
           const int n2 = min(K, s_end - (s + n)), r2 = ((n2 - 1) & 3) + 1;
-          const uint4 *rb2 = seg_records(c16 + 1);
+          const unsigned rb2 = seg_records(c16 + 1);
           issue(rb2, 0, r2 - 1, pair, E0); issue(rb2, 0, r2 - 1, pair + 2, E1);
           issue(rb2, 0, n2 - 1, r2 + pair, O0); issue(rb2, 0, n2 - 1, r2 + pair + 2, O1);
-          load_plane(c16 + 1, tid, std::integral_constant<int, kProducers>{}, 0, plane_split);
+          load_plane(c16 + 1, wave_s, ProducerWaves{}, FullRounds{}, 0, plane_split);
         }
       };
       // group 0
@@ -479,7 +471,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         if (o) multiply(0, 0, FX);
         if (r - o >= 2) { multiply(0, o, F0); a_issue(o + 2, F0); multiply(0, o + 1, F1); a_issue(o + 3, F1); }
         if (r - o >= 4) { multiply(0, o + 2, F0); a_issue(o + 4, F0); multiply(0, o + 3, F1); a_issue(o + 5, F1); }
-        if (n_groups == 1 && has_next) load_plane(c16 + 1, tid, std::integral_constant<int, kThreads>{}, plane_split, plane_items);
+        if (n_groups == 1 && has_next) load_plane(c16 + 1, wave_s, ConsumerWaves{}, HalfRounds{}, plane_split, plane_items);
       }
       KGDET_TR_ADD(4, tr_t);
       __syncthreads();
@@ -506,7 +498,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
           multiply(buf, 3, F1);
           a_issue(jg + 5, F1);
           if (gi + 1 == n_groups && has_next)
-            load_plane(c16 + 1, tid, std::integral_constant<int, kThreads>{}, plane_split, plane_items);
+            load_plane(c16 + 1, wave_s, ConsumerWaves{}, HalfRounds{}, plane_split, plane_items);
         }
         KGDET_TR_ADD(4, tr_t);
         __syncthreads();
