@@ -45,6 +45,22 @@ constexpr bool kAFromL2 = true;   // (grad_weight kernel) consumers take their A
 //   KGDET_ABL_NOALOAD   consumers do not load their weight fragments (one load in the prologue): L2 / fabric share
 //   KGDET_ABL_NOGATHER  producers interpolate register values instead of LDS corner reads: the gathers' share
 //   KGDET_ABL_NOBSTORE  producers compute the split B stage but do not store it: the LDS stores' share
+// Pacing of the consumers' MFMAs (tools/microbench/mfma_valu.hip): a wave whose next MFMA queues behind the busy matrix
+// pipe keeps the SIMD's vector issue port, and the producer wave of that SIMD gets ~one instruction per MFMA; an s_nop
+// after each MFMA leaves the port to the producer.
+#ifndef KGDET_PLANE_PACE
+#define KGDET_PLANE_PACE 0
+#endif
+#if KGDET_PLANE_PACE == 0
+#define KGDET_MFMA_PACE() do { } while (0)
+#elif KGDET_PLANE_PACE == 100
+#define KGDET_MFMA_PACE() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_sleep(1); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define KGDET_MFMA_PACE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop %0" ::"n"(KGDET_PLANE_PACE)); __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
+#ifndef KGDET_PLANE_SCALAR_FMA
+#define KGDET_PLANE_SCALAR_FMA 1
+#endif
 #ifndef KGDET_PLANE_PRODUCER_PRIO
 #define KGDET_PLANE_PRODUCER_PRIO 2
 #endif
@@ -263,9 +279,18 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
           for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+#if KGDET_PLANE_SCALAR_FMA
+              // two v_fma_f32 instead of one v_pk_fma_f32: beside MFMA waves a packed fp32 instruction costs ~20 cycles
+              // more than the pair of scalar ones (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
+              const float w1 = R.w[gq][e];
+              const float a0 = v[c][e][2 * h2], a1 = v[c][e][2 * h2 + 1];
+              if (first && e == 0) { sv[c][h2][0] = w1 * a0; sv[c][h2][1] = w1 * a1; }
+              else { sv[c][h2][0] = __builtin_fmaf(w1, a0, sv[c][h2][0]); sv[c][h2][1] = __builtin_fmaf(w1, a1, sv[c][h2][1]); }
+#else
               const f32x2 ve = {v[c][e][2 * h2], v[c][e][2 * h2 + 1]};
               const f32x2 we = {R.w[gq][e], R.w[gq][e]};
               sv[c][h2] = (first && e == 0) ? we * ve : __builtin_elementwise_fma(we, ve, sv[c][h2]);
+#endif
             }
       };
       auto split_store = [&](int buf, int gi, int half, const f32x2 (&sv)[2][2]) {
@@ -284,7 +309,12 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
             hi_u[q] = hu;
             if constexpr (PARTS == 2) {
               const f32x2 hf = {__uint_as_float(hu << 16), __uint_as_float(hu & 0xffff0000u)};
+#if KGDET_PLANE_SCALAR_FMA
+              const f32x2 df = {sv[c][h2][0] - hf[0], sv[c][h2][1] - hf[1]};
+              const bf16x2 lp = __builtin_convertvector(df, bf16x2);
+#else
               const bf16x2 lp = __builtin_convertvector(sv[c][h2] - hf, bf16x2);
+#endif
               lo_u[q] = __builtin_bit_cast(unsigned, lp);
             }
           }
@@ -408,15 +438,21 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
             for (int ni = 0; ni < 4; ++ni) b[part][ni] = *reinterpret_cast<const bf16x8 *>(B + part * kBPart + ni * 32 * 16);
           if constexpr (PARTS == 2) {  // small terms first; four independent accumulators per pass
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < 4; ++ni) {
               acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[1], b[0][ni], acc[ni], 0, 0, 0);
+              KGDET_MFMA_PACE();
+            }
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < 4; ++ni) {
               acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[0], b[1][ni], acc[ni], 0, 0, 0);
+              KGDET_MFMA_PACE();
+            }
           }
 #pragma unroll
-          for (int ni = 0; ni < 4; ++ni)
+          for (int ni = 0; ni < 4; ++ni) {
             acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[0], b[0][ni], acc[ni], 0, 0, 0);
+            KGDET_MFMA_PACE();
+          }
         }
       };
 

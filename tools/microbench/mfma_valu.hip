@@ -14,7 +14,7 @@ __device__ unsigned g_simd[12];
 // PLACE 0: waves 0-7 MFMA, 8-11 VALU (one VALU wave beside two MFMA waves on every SIMD)
 //       1: waves with (w & 3) == 3 VALU (3 waves, all on one SIMD if waves are dealt to SIMDs cyclically), w = 10 idle,
 //          the other 8 MFMA (3 + 3 + 2 per SIMD)
-template <int MFMA_ON, int AGPR, int GATHER, int PLACE>
+template <int MFMA_ON, int AGPR, int GATHER, int PLACE, int PACE = 0>
 __global__ __launch_bounds__(768, 1) void mix(int iters, float *sink, float seed) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   for (int i = threadIdx.x; i < 16384; i += 768) reinterpret_cast<float *>(lds)[i] = i * 0.25f;
@@ -37,6 +37,15 @@ __global__ __launch_bounds__(768, 1) void mix(int iters, float *sink, float seed
         for (int k = 0; k < 4; ++k) {
           if (AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[k]) : "v"(a), "v"(b));
           else acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[k], 0, 0, 0);
+          // PACE: the MFMA wave idles between its MFMAs (s_nop does not hold the vector issue port) instead of queueing the
+          // next MFMA behind the busy pipe
+          if (PACE == 1) asm volatile("s_nop 7");
+          if (PACE == 2) asm volatile("s_nop 15");
+          if (PACE == 3) asm volatile("s_nop 15\n s_nop 7");
+          if (PACE == 4) asm volatile("s_nop 15\n s_nop 15");
+          if (PACE == 5) asm volatile("s_nop 15\n s_nop 15\n s_nop 7");
+          if (PACE == 6) asm volatile("s_nop 15\n s_nop 15\n s_nop 15");
+          if (PACE == 7) asm volatile("s_sleep 1");
         }
     }
     float s = 0.f;
@@ -93,14 +102,14 @@ __global__ __launch_bounds__(768, 1) void mix(int iters, float *sink, float seed
   if (keep == 1.2345f) sink[1] = keep;
 }
 
-template <int MFMA_ON, int AGPR, int GATHER, int PLACE>
+template <int MFMA_ON, int AGPR, int GATHER, int PLACE, int PACE = 0>
 void run(float *sink) {
   const int iters = 3000;
-  hipFuncSetAttribute(reinterpret_cast<const void *>(mix<MFMA_ON, AGPR, GATHER, PLACE>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(mix<MFMA_ON, AGPR, GATHER, PLACE, PACE>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  mix<MFMA_ON, AGPR, GATHER, PLACE><<<256, 768, 100 * 1024>>>(iters, sink, 1.5f);
+  mix<MFMA_ON, AGPR, GATHER, PLACE, PACE><<<256, 768, 100 * 1024>>>(iters, sink, 1.5f);
   hipEventRecord(e0);
-  mix<MFMA_ON, AGPR, GATHER, PLACE><<<256, 768, 100 * 1024>>>(iters, sink, 1.5f);
+  mix<MFMA_ON, AGPR, GATHER, PLACE, PACE><<<256, 768, 100 * 1024>>>(iters, sink, 1.5f);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -108,7 +117,7 @@ void run(float *sink) {
   hipMemcpyFromSymbol(out, HIP_SYMBOL(g_out), sizeof(out));
   unsigned simd[12];
   hipMemcpyFromSymbol(simd, HIP_SYMBOL(g_simd), sizeof(simd));
-  printf("place %d mfma %s acc in %s  gathers %s : VALU wave %.0f cycles per half-stage;  kernel %.3f ms   SIMD of waves 0..11:", PLACE, MFMA_ON ? "ON " : "off",
+  printf("pace %d place %d mfma %s acc in %s  gathers %s : VALU wave %.0f cycles per half-stage;  kernel %.3f ms   SIMD of waves 0..11:", PACE, PLACE, MFMA_ON ? "ON " : "off",
          AGPR ? "AGPR" : "VGPR", GATHER ? "yes" : "no ", (double)out[0] / iters, ms);
   for (int w = 0; w < 12; ++w) printf(" %u", (simd[w] >> 4) & 3);
   printf("\n");
@@ -211,6 +220,8 @@ int main() {
   run<0, 0, 0, 0>(sink); run<1, 0, 0, 0>(sink); run<1, 1, 0, 0>(sink);
   run<0, 0, 1, 0>(sink); run<1, 0, 1, 0>(sink);
   run<0, 0, 1, 1>(sink); run<1, 0, 1, 1>(sink); run<1, 0, 0, 1>(sink);
+  run<1, 0, 1, 0, 1>(sink); run<1, 0, 1, 0, 2>(sink); run<1, 0, 1, 0, 3>(sink); run<1, 0, 1, 0, 4>(sink); run<1, 0, 1, 0, 5>(sink);
+  run<1, 0, 1, 0, 6>(sink); run<1, 0, 1, 0, 7>(sink);
   run_phased<1, 2>(sink); run_phased<2, 4>(sink); run_phased<3, 6>(sink); run_phased<4, 8>(sink);
   return 0;
 }
