@@ -21,7 +21,7 @@
 namespace kgdet {
 
 template <int PARTS>
-__global__ __launch_bounds__(kPlaneThreads, 1) void dcn_bwd_input_plane(const DcnFwdGroup grp, float *__restrict__ slabs) {
+__global__ __launch_bounds__(kRoleThreads, 1) void dcn_bwd_input_plane(const DcnFwdGroup grp, float *__restrict__ slabs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (threadIdx.x >= kThreads) plane_role<PARTS, true, 1>(grp, slabs, smem);
   else plane_role<PARTS, false, 1>(grp, slabs, smem);

@@ -37,7 +37,7 @@
 namespace kgdet {
 
 template <int PARTS>
-__global__ __launch_bounds__(kPlaneThreads, 1) void dcn_fwd_plane(const DcnFwdGroup grp, float *__restrict__ slabs) {
+__global__ __launch_bounds__(kRoleThreads, 1) void dcn_fwd_plane(const DcnFwdGroup grp, float *__restrict__ slabs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (threadIdx.x >= kThreads) plane_role<PARTS, true, 0>(grp, slabs, smem);
   else plane_role<PARTS, false, 0>(grp, slabs, smem);
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(kPlaneThreads, 1) void dcn_fwd_plane(const DcnFwdGr
 template __global__ void dcn_fwd_plane<1>(const DcnFwdGroup grp, float *__restrict__ slabs);
 template __global__ void dcn_fwd_plane<2>(const DcnFwdGroup grp, float *__restrict__ slabs);
 
-int dcn_fwd_plane_threads() { return kPlaneThreads; }
+int dcn_fwd_plane_threads() { return kRoleThreads; }
 
 // K >= 7 taps: half-chunk planes, tap-pair stages (dcn_plane_pairs.h)
 template <int PARTS>

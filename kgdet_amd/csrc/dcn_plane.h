@@ -34,7 +34,16 @@ namespace {
 constexpr int kAPart = 2 * kTileM * 8 * 2;  // bytes of one part of an A stage
 constexpr int kBPart = 2 * kTileN * 8 * 2;
 constexpr int kProducers = 256;                          // 4 producer waves
-constexpr int kPlaneThreads = kThreads + kProducers;     // 8 consumer + 4 producer waves
+constexpr int kPlaneThreads = kThreads + kProducers;     // 8 consumer + 4 producer waves (grad_weight kernel, tap-pair kernel)
+// plane_role (forward / grad_input): kRolePairs producer wave pairs; a pair (128 threads = the tile's 128 pixels) samples
+// kGroupTaps / kRolePairs stages of every group
+#ifndef KGDET_PLANE_PAIRS
+#define KGDET_PLANE_PAIRS 4
+#endif
+constexpr int kRolePairs = KGDET_PLANE_PAIRS;
+constexpr int kRoleProducers = kRolePairs * 128;
+constexpr int kRoleThreads = kThreads + kRoleProducers;
+static_assert(kRolePairs == 2 || kRolePairs == 4, "two or four producer wave pairs");
 constexpr int kPlaneRounds = 6;                          // (pixel, quad) items a thread has in flight while copying a plane
 constexpr int kGroupTaps = 4;                            // stages (taps) between two workgroup barriers
 constexpr bool kAFromL2 = true;   // (grad_weight kernel) consumers take their A fragments from the operand image in L2
@@ -62,7 +71,7 @@ constexpr bool kAFromL2 = true;   // (grad_weight kernel) consumers take their A
 #define KGDET_PLANE_SCALAR_FMA 1
 #endif
 #ifndef KGDET_PLANE_PRODUCER_PRIO
-#define KGDET_PLANE_PRODUCER_PRIO 2
+#define KGDET_PLANE_PRODUCER_PRIO 0   // (with eight producer waves they have slack: prio 2 costs the consumers 5 %)
 #endif
 
 // MODE of the plane kernels
@@ -130,12 +139,15 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
   const int n_local = tid & (kTileN - 1);                     // producers: pixel column sampled
   // (wave-uniform role coordinates in SGPRs: scalar branches and no exec masking -- every VALU instruction of a producer
   // costs its SIMD's MFMA waves issue slots, tools/microbench/mfma_valu.hip)
-  const int pair = __builtin_amdgcn_readfirstlane((tid >> 7) & 1);   // wave pair: samples stages pair, pair + 2 of a group
+  const int pair = __builtin_amdgcn_readfirstlane((tid >> 7) & (kRolePairs - 1));   // wave pair: samples stage pair (and, with two pairs, pair + 2) of a group
   const long long G = gridDim.x, g = blockIdx.x;
   const long long slice = sk_slice_of_block((int)g, (int)G);
   long long my_begin, my_end;
 
   if constexpr (PRODUCER) __builtin_amdgcn_s_setprio(KGDET_PLANE_PRODUCER_PRIO);
+#ifdef KGDET_PLANE_CONSUMER_PRIO
+  else __builtin_amdgcn_s_setprio(KGDET_PLANE_CONSUMER_PRIO);
+#endif
 #ifdef KGDET_PLANE_TRACE
   unsigned long long tr[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tr_t = KGDET_TR_NOW();
@@ -208,9 +220,9 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
     // the consumers the rest after their MFMAs.  Split operands: the consumers are busy for four stages of 12 MFMAs,
     // the producers take two full batches of loads; bf16: a third each way (equal shares per wave).
     const int plane_items = dcn_plane_units(HW);
-    const int plane_split = PARTS == 2 ? min(plane_items, 2 * kPlaneRounds * (kProducers / 64)) : plane_items / 3;
-    typedef std::integral_constant<int, kPlaneThreads / 64> AllWaves;
-    typedef std::integral_constant<int, kProducers / 64> ProducerWaves;
+    const int plane_split = PARTS == 2 ? min(plane_items, 8 * kPlaneRounds) : plane_items * (kRoleProducers / 64) / (kRoleThreads / 64);
+    typedef std::integral_constant<int, kRoleThreads / 64> AllWaves;
+    typedef std::integral_constant<int, kRoleProducers / 64> ProducerWaves;
     typedef std::integral_constant<int, kThreads / 64> ConsumerWaves;
     typedef std::integral_constant<int, kPlaneRounds> FullRounds;
     typedef std::integral_constant<int, kPlaneRounds / 2> HalfRounds;   // the consumers' share is the small one
@@ -396,11 +408,24 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
             tr[6] += tc - tb;
           };
           probe(pair, 0, RA, a_live); probe(pair, 1, RA, a_live);
-          probe(pair + 2, 0, RB, b_live); probe(pair + 2, 1, RB, b_live);
+          if constexpr (kRolePairs == 2) { probe(pair + 2, 0, RB, b_live); probe(pair + 2, 1, RB, b_live); }
           return;
         }
 #endif
-        if constexpr (pipelined) {
+        if constexpr (kRolePairs == 4) {   // one stage per pair: both half-stages' corner reads in flight
+          if constexpr (pipelined) {
+            Corners V0, V1;
+            f32x2 sv[2][2];
+            corner_reads(RA, 0, 0, V0);
+            corner_reads(RA, 0, 1, V1);
+            corner_fma(RA, 0, V0, sv, true);
+            if (a_live) split_store(buf, pair, 0, sv);
+            corner_fma(RA, 0, V1, sv, true);
+            if (a_live) split_store(buf, pair, 1, sv);
+          } else {
+            if (a_live) { sample_half(buf, pair, 0, RA); sample_half(buf, pair, 1, RA); }
+          }
+        } else if constexpr (pipelined) {
           // three corner register sets: the reads of three half-stages are in flight before the first arithmetic (a batch
           // of 8 random ds_read_b128 comes back after ~840 cycles while the consumers read their B fragments, ~420
           // alone -- in-kernel probe, tools/microbench/lds_gather.hip -- against ~190 cycles of arithmetic per half-stage)
@@ -466,8 +491,9 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       // are done)
       if (!primed) {   // first segment of the range: records, then the plane copy by all twelve waves
         if constexpr (PRODUCER) {
-          issue(rec_base, t0, r - 1, pair, E0); issue(rec_base, t0, r - 1, pair + 2, E1);
-          issue(rec_base, t0, n - 1, r + pair, O0); issue(rec_base, t0, n - 1, r + pair + 2, O1);
+          issue(rec_base, t0, r - 1, pair, E0);
+          issue(rec_base, t0, n - 1, r + pair, O0);
+          if constexpr (kRolePairs == 2) { issue(rec_base, t0, r - 1, pair + 2, E1); issue(rec_base, t0, n - 1, r + pair + 2, O1); }
         }
         load_plane(c16, wave_all, AllWaves{}, FullRounds{}, 0, plane_items);
         KGDET_TR_ADD(1, tr_t);
@@ -476,7 +502,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       }
       // first group (buffer 0).  One stage: each wave pair samples one 8-channel half of it (both hold its record)
       if constexpr (PRODUCER) {
-        if (r == 1) sample_half(0, 0, pair, E0);
+        if (r == 1) { if (pair < 2) sample_half(0, 0, pair, E0); }
         else sample_group(0, E0, E1, pair < r, pair + 2 < r);
       } else {   // full groups find their stages in F0, F1, F0, F1: an odd first group takes its stage 0 from FX
         if (r & 1) { a_issue(0, FX); a_issue(1, F0); a_issue(2, F1); }
@@ -489,13 +515,15 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       auto produce = [&](int gi, int buf_next, const Regs &Sa, const Regs &Sb, Regs &Ia, Regs &Ib) {
         if (gi + 1 < n_groups) {
           const int jn = r + (gi + 1) * kGroupTaps;   // first stage of group gi + 2
-          issue(rec_base, t0, n - 1, jn + pair, Ia); issue(rec_base, t0, n - 1, jn + pair + 2, Ib);
+          issue(rec_base, t0, n - 1, jn + pair, Ia);
+          if constexpr (kRolePairs == 2) issue(rec_base, t0, n - 1, jn + pair + 2, Ib);
           sample_group(buf_next, Sa, Sb, true, true);
         } else if (has_next) {
           const int n2 = min(K, s_end - (s + n)), r2 = ((n2 - 1) & 3) + 1;
           const unsigned rb2 = seg_records(c16 + 1);
-          issue(rb2, 0, r2 - 1, pair, E0); issue(rb2, 0, r2 - 1, pair + 2, E1);
-          issue(rb2, 0, n2 - 1, r2 + pair, O0); issue(rb2, 0, n2 - 1, r2 + pair + 2, O1);
+          issue(rb2, 0, r2 - 1, pair, E0);
+          issue(rb2, 0, n2 - 1, r2 + pair, O0);
+          if constexpr (kRolePairs == 2) { issue(rb2, 0, r2 - 1, pair + 2, E1); issue(rb2, 0, n2 - 1, r2 + pair + 2, O1); }
           load_plane(c16 + 1, wave_s, ProducerWaves{}, FullRounds{}, 0, plane_split);
         }
       };
