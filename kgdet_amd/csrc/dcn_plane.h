@@ -481,8 +481,8 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         }
       };
 
-      AFrag F0, F1, FX;  // consumers: weight fragments two stages ahead, alternating (a third set in the loop spills);
-                         // FX: stage 0 of an odd first group
+      AFrag F0, F1;      // consumers: weight fragments two stages ahead, alternating (a third set in the loop spills): stage
+                         // j of a segment sits in F0 when j - r is even, so that full groups find F0, F1, F0, F1
 #ifdef KGDET_PLANE_TRACE
       tr_t = KGDET_TR_NOW();
       tr[9] += 1; tr[8] += n;
@@ -504,8 +504,8 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       if constexpr (PRODUCER) {
         if (r == 1) { if (pair < 2) sample_half(0, 0, pair, E0); }
         else sample_group(0, E0, E1, pair < r, pair + 2 < r);
-      } else {   // full groups find their stages in F0, F1, F0, F1: an odd first group takes its stage 0 from FX
-        if (r & 1) { a_issue(0, FX); a_issue(1, F0); a_issue(2, F1); }
+      } else {   // full groups find their stages in F0, F1, F0, F1: an odd first group starts with F1
+        if (r & 1) { a_issue(0, F1); a_issue(1, F0); }
         else { a_issue(0, F0); a_issue(1, F1); }
       }
       __syncthreads();
@@ -532,7 +532,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         produce(0, 1, O0, O1, E0, E1);
       } else {
         const int o = r & 1;   // (one-sided conditionals only: MFMAs on both sides of a branch make hipcc copy accumulators)
-        if (o) multiply(0, 0, FX);
+        if (o) { multiply(0, 0, F1); a_issue(2, F1); }
         if (r - o >= 2) { multiply(0, o, F0); a_issue(o + 2, F0); multiply(0, o + 1, F1); a_issue(o + 3, F1); }
         if (r - o >= 4) { multiply(0, o + 2, F0); a_issue(o + 4, F0); multiply(0, o + 3, F1); a_issue(o + 5, F1); }
         if (n_groups == 1 && has_next) load_plane(c16 + 1, wave_s, ConsumerWaves{}, HalfRounds{}, plane_split, plane_items);
@@ -579,11 +579,15 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
     }
 
     if constexpr (!PRODUCER) {
+      // (the thread index rebuilt from the lane counter and the wave's SGPR, behind an opaque barrier: hipcc otherwise hoists
+      // the stores' lane-dependent addresses to the top of the range and, at 128 registers, spills them)
+      int tid_e = wave_s * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      asm volatile("" : "+v"(tid_e));
       if (s_begin == 0 && s_end == cpt) {
-        store_output_w8(p, mt, nt, tid, acc);
+        store_output_w8(p, mt, nt, tid_e, acc);
       } else {
         float *slab = slabs + ((long long)g * grp.slots + slot) * kTileElems;
-        store_slab_w8(slab, tid, acc);
+        store_slab_w8(slab, tid_e, acc);
       }
     }
     KGDET_TR_ADD(6, tr_t);
