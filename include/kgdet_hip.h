@@ -173,7 +173,7 @@ typedef struct kgdet_dcn_shape {
  * accumulate; <= 2^-16 relative error per product, i.e. fp32-accurate to ~1e-6 of the output scale).
  * KGDET_DCN_BF16: operands rounded to bf16 once (autocast inference).  KGDET_DCN_EXACT_FP32: the
  * v_mfma_f32_32x32x2_f32 kernel, bit-exact fp32 products (also used when a 16-channel slice of one input
- * image does not fit in LDS: H*W > 1536). */
+ * image does not fit in LDS: H*W > 1344). */
 #define KGDET_DCN_BF16 2u
 #define KGDET_DCN_EXACT_FP32 4u
 
@@ -222,16 +222,19 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
                                       size_t workspace_bytes, void *stream);
 
 /* grad_input only, on the plane kernel (transposed sampling; atomic-free, deterministic, overwrites grad_input).
- * Same quantity as the grad_input of kgdet_deform_conv_backward_input; needs deformable_groups == 1 and
- * H*W, Ho*Wo <= 1536 (KGDET_E_UNSUPPORTED otherwise).  flags: KGDET_DCN_BF16 or 0 (hi/lo split).
+ * Same quantity as the grad_input of kgdet_deform_conv_backward_input; weight groups and deformable groups run as
+ * channel runs (channels that share both; at most 8 runs, each starting on a 256-channel boundary of its weight group or
+ * ending before the next one); needs H*W, Ho*Wo <= 1344 (KGDET_E_UNSUPPORTED otherwise).  flags: KGDET_DCN_BF16 or 0
+ * (hi/lo split).
  * workspace >= kgdet_dcn_workspace_bytes(s). */
 int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, const float *mask /*nullable*/,
                                  const float *packed_weight, const float *grad_output, float *grad_input,
                                  uint32_t flags, void *workspace, size_t workspace_bytes, void *stream);
 
 /* grad_offset only (v1), with the column gradient W^T grad_out kept in registers and the feature plane in LDS.
- * Same quantity as the grad_offset of kgdet_deform_conv_backward_input; needs deformable_groups == 1,
- * groups == 1, O <= 256, H*W <= 1536 (KGDET_E_UNSUPPORTED otherwise).  Overwrites grad_offset.
+ * Same quantity as the grad_offset of kgdet_deform_conv_backward_input; needs every deformable group inside ONE weight
+ * group (groups == 1 with any number of deformable groups of whole 16-channel chunks, or deformable groups that subdivide
+ * the weight groups), O / groups <= 256, H*W <= 1344 (KGDET_E_UNSUPPORTED otherwise).  Overwrites grad_offset.
  * workspace >= kgdet_dcn_workspace_bytes(s). */
 int kgdet_deform_conv_grad_offset(const kgdet_dcn_shape *s, const float *input, const float *offset,
                                   const float *packed_weight, const float *grad_output, float *grad_offset,
@@ -239,7 +242,8 @@ int kgdet_deform_conv_grad_offset(const kgdet_dcn_shape *s, const float *input, 
 
 /* grad_input and grad_offset of n v1 problems in two grouped launches (one per quantity); same results as
  * kgdet_deform_conv_grad_input + kgdet_deform_conv_grad_offset per problem.  n <= 8; every problem must be
- * eligible for both kernels and have groups == 1 (KGDET_E_UNSUPPORTED otherwise -- call the single entry points).
+ * eligible for both kernels and have groups == 1, deformable_groups == 1 (KGDET_E_UNSUPPORTED otherwise -- call the
+ * single entry points).
  * workspace >= kgdet_dcn_group_workspace_bytes(n, shapes). */
 int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *const *shapes, const float *const *inputs,
                                              const float *const *offsets, const float *const *packed_weights,
@@ -247,7 +251,8 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
                                              float *const *grad_offsets, void *workspace, size_t workspace_bytes,
                                              void *stream);
 
-/* grad_weight of n v1 problems (groups == 1, deformable_groups == 1, H*W <= 1536) in one launch: a GEMM with the
+/* grad_weight of n v1 problems (H*W <= 1344; weight groups and deformable groups as channel runs, at most 8 runs over
+ * all problems) in one launch: a GEMM with the
  * reduction over pixels, sampled B stages from an LDS-resident plane, bf16 hi/lo split MFMA; grad_weights[i]
  * [O, C, kh, kw] is OVERWRITTEN.  KGDET_E_UNSUPPORTED for other shapes (use kgdet_deform_conv_backward_weight).
  * workspace >= kgdet_dcn_group_workspace_bytes(n, shapes). */

@@ -1,6 +1,8 @@
 // C-ABI launchers for deformable convolution (see include/kgdet_hip.h for the contract and the
 // reference entry points each one replaces).
 #include "common.h"
+#include <algorithm>
+
 #include "dcn_kernels.h"
 
 namespace kgdet {
@@ -196,27 +198,55 @@ bool plane_ok(const kgdet_dcn_shape *s, const Derived &d) {
 size_t tap_table_bytes(const kgdet_dcn_shape *s, const Derived &d) {
   return plane_ok(s, d) ? (size_t)s->N * s->deformable_groups * d.K * d.Ho * d.Wo * sizeof(DcnTapRec) : 0;
 }
-// grad_input on the plane kernel: a 16-channel slice of one grad_output image in LDS, one deformable group
+// Channel runs of the backward plane kernels: maximal runs of input channels inside one weight group AND one deformable
+// group (one run = one sub-problem: its own tap / inverse records, its weight group's operand image and grad_out window).
+struct ChannelRun { int c0, c1, g, dgi; };
+int channel_runs(const kgdet_dcn_shape *s, const Derived &d, ChannelRun *runs, int cap) {
+  const int cpdg = s->C / s->deformable_groups;
+  int n = 0;
+  for (int c0 = 0; c0 < s->C;) {
+    const int g = c0 / d.Cg, dgi = c0 / cpdg;
+    const int c1 = std::min((g + 1) * d.Cg, (dgi + 1) * cpdg);
+    if (n < cap) runs[n] = ChannelRun{c0, c1, g, dgi};
+    ++n;
+    c0 = c1;
+  }
+  return n;
+}
+// grad_input on the plane kernel: a 16-channel slice of one grad_output image in LDS; a channel run must start on a
+// 256-row tile of the transposed weight image or end inside the tile it starts in
 bool plane_bwd_input_ok(const kgdet_dcn_shape *s, const Derived &d) {
-  return s->deformable_groups == 1 && d.Ho * d.Wo <= kPlaneMaxHW && s->H * s->W <= kPlaneMaxHW && s->W >= 1 &&
+  ChannelRun runs[kMaxFwdGroup];
+  const int n_runs = channel_runs(s, d, runs, kMaxFwdGroup);
+  if (n_runs > kMaxFwdGroup) return false;
+  for (int i = 0; i < n_runs; ++i) {
+    const int row0 = (runs[i].c0 - runs[i].g * d.Cg) % kTileM;
+    if (row0 != 0 && row0 + (runs[i].c1 - runs[i].c0) > kTileM) return false;
+  }
+  return d.Ho * d.Wo <= kPlaneMaxHW && s->H * s->W <= kPlaneMaxHW && s->W >= 1 &&
          (size_t)8 * 33 * (d.K + 1) * sizeof(float) <= kMaxLds - 64 &&
          dcn_build_inverse_taps_lds_bytes(s->H * s->W, d.Ho * d.Wo) <= kMaxLds - 64 &&
-         slab_slots_ok((long long)s->groups * s->N * ceil_div(s->H * s->W, kTileN) * (d.Cg_pad256 / kTileM),
+         slab_slots_ok((long long)n_runs * s->N * ceil_div(s->H * s->W, kTileN) * (d.Cg_pad256 / kTileM),
                        d.K * (d.Og_pad16 / kChunk));
 }
-// grad_offset on the plane kernel: v1, one deformable group, <= 256 output channels per group
+// grad_offset on the plane kernel: <= 256 output channels per group; every deformable group inside ONE weight group (its
+// sum then comes from one sub-problem; a deformable group spread over several weight groups would need a sum over them),
+// in whole 16-channel chunks
 bool plane_bwd_offset_ok(const kgdet_dcn_shape *s, const Derived &d, bool masked = false) {
-  return s->deformable_groups == 1 && s->groups == 1 && d.Og <= 256 && d.K <= 64 && s->H * s->W <= kPlaneMaxHW &&
+  const int cpdg = s->C / s->deformable_groups;
+  const bool runs_ok = (s->groups == 1 && s->deformable_groups == 1) ||
+                       (d.Cg % cpdg == 0 && cpdg % kChunk == 0 && s->deformable_groups <= kMaxFwdGroup);
+  return runs_ok && d.Og <= 256 && d.K <= 64 && s->H * s->W <= kPlaneMaxHW &&
          dcn_bwd_offset_plane_lds_bytes(2, d.K, s->H * s->W, masked) <= kMaxLds &&
          (size_t)8 * 33 * (d.K + 1) * sizeof(float) <= kMaxLds - 64 &&
-         slab_slots_ok((long long)s->N * ceil_div(d.Ho * d.Wo, kTileN), d.K * (d.Cg_pad / kChunk));
+         slab_slots_ok((long long)s->N * ceil_div(d.Ho * d.Wo, kTileN), d.K * (ceil_div(cpdg, kChunk)));
 }
-size_t grad_tap_bytes(const kgdet_dcn_shape *s, const Derived &d) { return (size_t)s->N * d.K * d.Ho * d.Wo * 64; }   // (v2 records: 64 B)
+size_t grad_tap_bytes(const kgdet_dcn_shape *s, const Derived &d) { return (size_t)s->N * s->deformable_groups * d.K * d.Ho * d.Wo * 64; }   // (v2 records: 64 B; one table per deformable group)
 struct InvTables {
   size_t rec_bytes, slot_bytes, spill_bytes;
   size_t total() const { return rec_bytes + slot_bytes + spill_bytes; }
 };
-InvTables inv_tables(const kgdet_dcn_shape *s, const Derived &d) {
+InvTables inv_tables(const kgdet_dcn_shape *s, const Derived &d) {   // of ONE deformable group
   InvTables t;
   const size_t tiles = (size_t)ceil_div(s->H * s->W, kTileN);
   t.rec_bytes = (size_t)s->N * d.K * s->H * s->W * 64;
@@ -224,6 +254,7 @@ InvTables inv_tables(const kgdet_dcn_shape *s, const Derived &d) {
   t.spill_bytes = (size_t)s->N * d.K * 4 * d.Ho * d.Wo * 8;
   return t;
 }
+size_t inv_tables_all(const kgdet_dcn_shape *s, const Derived &d) { return s->deformable_groups * align_up(inv_tables(s, d).total(), 256); }
 // backward tiles (256 / 128 channels wide) must lie inside one deformable group
 bool mfma_bwd_ok(const kgdet_dcn_shape *s) {
   const int cpdg = s->C / s->deformable_groups, Cg = s->C / s->groups;
@@ -278,14 +309,14 @@ size_t kgdet_dcn_workspace_bytes(const kgdet_dcn_shape *s) {
   const size_t bwd_in = pl.ok ? (pl.slab_floats + pl.off_floats + pl.mask_floats) * sizeof(float) +
                                     pl.rowptr_ints * sizeof(int) + pl.entry_pairs * 8 + 64
                               : 0;
-  size_t bwd_in_plane = plane_bwd_input_ok(s, d) ? slab_bytes() + inv_tables(s, d).total() : 0;
+  size_t bwd_in_plane = plane_bwd_input_ok(s, d) ? slab_bytes() + inv_tables_all(s, d) : 0;
   if (plane_bwd_offset_ok(s, d) && slab_bytes() + grad_tap_bytes(s, d) > bwd_in_plane)
     bwd_in_plane = slab_bytes() + grad_tap_bytes(s, d);
   size_t need = fwd_and_wgrad > bwd_in ? fwd_and_wgrad : bwd_in;
   need = need > bwd_in_plane ? need : bwd_in_plane;
-  if (s->groups == 1 && s->deformable_groups == 1 && plane_ok(s, d)) {   // grad_weight on the plane kernel: records + grad_out image
+  if (plane_ok(s, d)) {   // grad_weight on the plane kernel: records + one grad_out image per weight group
     const size_t wplane = slab_bytes() + align_up(tap_table_bytes(s, d), 256) +
-                          (size_t)(d.Og_pad / kTileM) * s->N * ceil_div(d.Ho * d.Wo, kChunk) * 16384;
+                          (size_t)s->groups * (d.Og_pad / kTileM) * s->N * ceil_div(d.Ho * d.Wo, kChunk) * 16384;
     need = need > wplane ? need : wplane;
   }
   if (!pl.ok && !plane_bwd_input_ok(s, d)) {   // large maps: the materialised column gradient of dcn_backward_large.hip
@@ -305,9 +336,9 @@ size_t kgdet_dcn_group_workspace_bytes(int32_t n, const kgdet_dcn_shape *const *
     Derived d;
     if (!shapes || derive(shapes[i], d)) return 0;
     tables += tap_table_bytes(shapes[i], d);
-    if (plane_bwd_input_ok(shapes[i], d)) bwd_tables += align_up(inv_tables(shapes[i], d).total(), 256);
+    if (plane_bwd_input_ok(shapes[i], d)) bwd_tables += inv_tables_all(shapes[i], d);
     wgrad_tables += align_up(tap_table_bytes(shapes[i], d), 256) +
-                    (size_t)(d.Og_pad / kTileM) * shapes[i]->N * ceil_div(d.Ho * d.Wo, kChunk) * 16384;
+                    (size_t)shapes[i]->groups * (d.Og_pad / kTileM) * shapes[i]->N * ceil_div(d.Ho * d.Wo, kChunk) * 16384;
     const size_t w = kgdet_dcn_workspace_bytes(shapes[i]);
     single = w > single ? w : single;
   }
@@ -624,18 +655,17 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
   if (int rc = derive(s, d)) return rc;
   KGDET_CHECK_SHAPE(offset && packed_weight && grad_output && grad_input, "null pointer");
   if (!plane_bwd_input_ok(s, d)) {
-    set_error("grad_input plane kernel: needs deformable_groups == 1 and maps of at most %d pixels", kPlaneMaxHW);
+    set_error("grad_input plane kernel: maps of at most %d pixels, at most %d (weight group, deformable group) channel runs, "
+              "each starting on a 256-channel tile or ending inside one", kPlaneMaxHW, kMaxFwdGroup);
     return KGDET_E_UNSUPPORTED;
   }
   const InvTables it = inv_tables(s, d);
-  if (workspace == nullptr || workspace_bytes < slab_bytes() + it.total()) {
-    set_error("workspace too small: need %zu bytes, got %zu", slab_bytes() + it.total(), workspace_bytes);
+  const size_t it_stride = align_up(it.total(), 256);
+  if (workspace == nullptr || workspace_bytes < slab_bytes() + inv_tables_all(s, d)) {
+    set_error("workspace too small: need %zu bytes, got %zu", slab_bytes() + inv_tables_all(s, d), workspace_bytes);
     return KGDET_E_WORKSPACE;
   }
   unsigned char *base = (unsigned char *)workspace + slab_bytes();
-  uint4 *inv = (uint4 *)base;
-  DcnInvOvfSlots *slots = (DcnInvOvfSlots *)(base + it.rec_bytes);
-  uint2 *spill = (uint2 *)(base + it.rec_bytes + it.slot_bytes);
   static thread_local bool attr_set = false;
   if (!attr_set) {
     KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_build_inverse_taps, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -646,13 +676,14 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
                                       (int)kMaxLds));
     attr_set = true;
   }
-  {  // inverse sampling records from the forward geometry
+  for (int dgi = 0; dgi < s->deformable_groups; ++dgi) {  // inverse sampling records from the forward geometry, per deformable group
     DcnProblem f;
     fill_problem(s, d, 0, f);
-    f.offset = offset; f.mask = mask;
+    f.offset = offset; f.mask = mask; f.dgi = dgi;
+    unsigned char *tb = base + (size_t)dgi * it_stride;
     hipLaunchKernelGGL(dcn_build_inverse_taps, dim3(s->N * d.K), dim3(256),
-                       dcn_build_inverse_taps_lds_bytes(s->H * s->W, d.Ho * d.Wo), (hipStream_t)stream, f, inv, slots,
-                       spill);
+                       dcn_build_inverse_taps_lds_bytes(s->H * s->W, d.Ho * d.Wo), (hipStream_t)stream, f, (uint4 *)tb,
+                       (DcnInvOvfSlots *)(tb + it.rec_bytes), (uint2 *)(tb + it.rec_bytes + it.slot_bytes));
   }
   const int G = grid_size();
   const int parts = (flags & KGDET_DCN_BF16) ? 1 : 2;
@@ -660,20 +691,24 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
   grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.pair_mode = 0; grp.rounds = 1; grp.wave_layout = 0;
   grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
   const int O_total = s->out_channels_total > 0 ? s->out_channels_total : s->O;
-  for (int g = 0; g < s->groups; ++g) {
-    // the transposed problem: "input" = grad_output window of this group, "output" = grad_input channels of it
+  ChannelRun runs[kMaxFwdGroup];
+  const int n_runs = channel_runs(s, d, runs, kMaxFwdGroup);
+  for (int r = 0; r < n_runs; ++r) {
+    const int g = runs[r].g, len = runs[r].c1 - runs[r].c0, row = runs[r].c0 - g * d.Cg;
+    // the transposed problem: "input" = grad_output window of the run's weight group, "output" = the run's grad_input channels
     DcnProblem p{};
     p.x = grad_output; p.out = grad_input; p.bias = nullptr; p.offset = nullptr; p.mask = nullptr;
     p.N = s->N;
     p.C_total = O_total; p.c_base = s->out_channel_offset + g * d.Og; p.Cg = d.Og; p.Cg_pad = d.Og_pad16;
-    p.O_total = s->C; p.o_base = g * d.Cg; p.Og = d.Cg; p.Og_pad = d.Cg_pad256; p.bias_base = 0;
+    p.O_total = s->C; p.o_base = runs[r].c0; p.Og = len; p.Og_pad = ceil_div(len, kTileM) * kTileM; p.bias_base = 0;
+    p.mt_base = row / kTileM; p.row0 = row % kTileM;
     p.H = d.Ho; p.W = d.Wo;                       // plane geometry = grad_output
     p.Ho = s->H; p.Wo = s->W; p.HoWo = s->H * s->W; p.P = s->N * p.HoWo;  // "pixels" = input cells
     p.kh = s->kh; p.kw = s->kw; p.K = d.K; p.seg_stages = d.K;
     p.DG = 1; p.cpdg = p.C_total;
     p.tiles_per_image = ceil_div(p.HoWo, kTileN);
     p.n_ntiles = p.N * p.tiles_per_image;
-    p.n_mtiles = d.Cg_pad256 / kTileM;
+    p.n_mtiles = p.Og_pad / kTileM;
     p.chunks_per_tap = d.Og_pad16 / kChunk;
     p.chunks_per_tile = d.K * p.chunks_per_tap;
     p.total_units = (long long)p.n_ntiles * p.n_mtiles * p.chunks_per_tile;
@@ -681,9 +716,10 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
     p.flags = 0;
     p.wq = packed_weight + (size_t)s->groups * (d.fwd_image_floats() + d.bwd_image_floats() + d.plane_image_floats()) +
            (size_t)g * d.plane_t_image_floats();
-    p.taps = reinterpret_cast<const DcnTapRec *>(inv);
-    p.inv_ovf = slots; p.inv_spill = spill; p.build_taps = 0;
-    if (grp.n == kMaxFwdGroup) { set_error("more than %d weight groups", kMaxFwdGroup); return KGDET_E_UNSUPPORTED; }
+    unsigned char *tb = base + (size_t)runs[r].dgi * it_stride;
+    p.taps = reinterpret_cast<const DcnTapRec *>(tb);
+    p.inv_ovf = (const DcnInvOvfSlots *)(tb + it.rec_bytes); p.inv_spill = (const uint2 *)(tb + it.rec_bytes + it.slot_bytes);
+    p.build_taps = 0;
     grp.p[grp.n] = p;
     grp.tile_begin[grp.n + 1] = grp.tile_begin[grp.n] + p.n_ntiles * p.n_mtiles;
     grp.range_begin[grp.n + 1] = grp.range_begin[grp.n] + p.n_ntiles * p.n_mtiles;
@@ -725,8 +761,8 @@ static int grad_offset_plane(const kgdet_dcn_shape *s, const float *input, const
   KGDET_CHECK_SHAPE(input && offset && packed_weight && grad_output && grad_offset, "null pointer");
   KGDET_CHECK_SHAPE((mask == nullptr) == (grad_mask == nullptr), "mask and grad_mask must come together");
   if (!plane_bwd_offset_ok(s, d, mask != nullptr) || (mask && (flags & KGDET_DCN_BF16))) {
-    set_error("grad_offset plane kernel: needs deformable_groups == 1, <= 256 output channels per group, H*W <= %d",
-              kPlaneMaxHW);
+    set_error("grad_offset plane kernel: needs every deformable group inside one weight group (whole 16-channel chunks), "
+              "<= 256 output channels per group, H*W <= %d", kPlaneMaxHW);
     return KGDET_E_UNSUPPORTED;
   }
   const size_t need = slab_bytes() + grad_tap_bytes(s, d);
@@ -749,30 +785,35 @@ static int grad_offset_plane(const kgdet_dcn_shape *s, const float *input, const
   DcnFwdGroup grp;
   grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.pair_mode = 0; grp.rounds = 1; grp.wave_layout = 0;
   grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
-  const DcnTapRec *recs = reinterpret_cast<const DcnTapRec *>((unsigned char *)workspace + slab_bytes());
-  for (int g = 0; g < s->groups; ++g) {
+  // one sub-problem per deformable group (= channel run: plane_bwd_offset_ok), each with its own record table
+  const unsigned char *recs = (const unsigned char *)workspace + slab_bytes();
+  const size_t rec_stride = (size_t)s->N * d.K * d.Ho * d.Wo * 64;
+  ChannelRun runs[kMaxFwdGroup];
+  const int n_runs = channel_runs(s, d, runs, kMaxFwdGroup);
+  for (int r = 0; r < n_runs; ++r) {
+    const int g = runs[r].g;
     DcnProblem p;
     fill_problem(s, d, g, p);
     p.x = input; p.offset = offset; p.mask = mask; p.gout = grad_output; p.goff = grad_offset; p.gmask = grad_mask;
+    p.c_base = runs[r].c0; p.Cg = runs[r].c1 - runs[r].c0; p.Cg_pad = ceil_div(p.Cg, kChunk) * kChunk;
+    p.dgi = runs[r].dgi; p.c16_base = (runs[r].c0 - g * d.Cg) / kChunk;
     p.wq = packed_weight + (size_t)s->groups * (d.fwd_image_floats() + d.bwd_image_floats() + d.plane_image_floats()) +
            (size_t)g * d.plane_t_image_floats();
-    p.taps = recs; p.build_taps = g == 0;
+    p.taps = reinterpret_cast<const DcnTapRec *>(recs + (size_t)runs[r].dgi * rec_stride); p.build_taps = 1;
     p.tiles_per_image = ceil_div(p.HoWo, kTileN);
     p.n_ntiles = p.N * p.tiles_per_image;
     p.n_mtiles = 1;
-    p.chunks_per_tap = d.Cg_pad / kChunk;
+    p.chunks_per_tap = p.Cg_pad / kChunk;
     p.chunks_per_tile = d.K * p.chunks_per_tap;
     p.total_units = (long long)p.n_ntiles * p.chunks_per_tile;
     p.kparts = 1;
     p.flags = flags;
-    if (grp.n == kMaxFwdGroup) { set_error("more than %d weight groups", kMaxFwdGroup); return KGDET_E_UNSUPPORTED; }
     grp.p[grp.n] = p;
     grp.tile_begin[grp.n + 1] = grp.tile_begin[grp.n] + p.n_ntiles;
     grp.range_begin[grp.n + 1] = grp.range_begin[grp.n] + p.n_ntiles;
     grp.unit_begin[grp.n + 1] = grp.unit_begin[grp.n] + p.total_units;
     ++grp.n;
   }
-  KGDET_CHECK_SHAPE(s->groups == 1, "grad_offset plane kernel: weight groups > 1 would need a sum over groups");
   plan_static_ranges(grp, G, mask != nullptr);
   if (mask && !grp.static_ranges) {
     set_error("grad_offset plane kernel (v2): more (part, tile) ranges than workgroups");
@@ -820,7 +861,7 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
     if (int rc = derive(s, dd[i])) return rc;
     KGDET_CHECK_SHAPE(inputs[i] && offsets[i] && packed_weights[i] && grad_outputs[i] && grad_inputs[i] &&
                           grad_offsets[i], "null pointer (problem %d)", i);
-    if (s->groups != 1 || !plane_bwd_input_ok(s, dd[i]) || !plane_bwd_offset_ok(s, dd[i])) {
+    if (s->groups != 1 || s->deformable_groups != 1 || !plane_bwd_input_ok(s, dd[i]) || !plane_bwd_offset_ok(s, dd[i])) {
       set_error("problem %d is not eligible for the plane backward kernels", i);
       return KGDET_E_UNSUPPORTED;
     }
@@ -990,6 +1031,9 @@ int kgdet_deform_conv_grad_weight_grouped(int32_t n, const kgdet_dcn_shape *cons
 }
 
 // masks: nullptr (v1) or one mask pointer per problem (v2: the tap records carry mask x bilinear weight)
+// Weight groups and deformable groups: a problem is cut into runs of input channels that share both (sub-problems: the
+// input window, the weight group's grad_out image and output rows, the deformable group's tap records); at most
+// kMaxFwdGroup sub-problems per launch.
 static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *shapes, const float *const *inputs,
                                      const float *const *offsets, const float *const *masks, const float *const *grad_outputs,
                                      float *const *grad_weights, void *workspace, size_t workspace_bytes, void *stream) {
@@ -999,23 +1043,31 @@ static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *sh
   Derived dd[kMaxFwdGroup];
   int same_taps[kMaxFwdGroup], same_gq[kMaxFwdGroup];
   size_t taps_off[kMaxFwdGroup], gq_off[kMaxFwdGroup], total = 0;
+  int n_sub = 0;
   for (int i = 0; i < n; ++i) {
     const kgdet_dcn_shape *s = shapes[i];
     if (int rc = derive(s, dd[i])) return rc;
     KGDET_CHECK_SHAPE(inputs[i] && offsets[i] && grad_outputs[i] && grad_weights[i], "null pointer (problem %d)", i);
-    if (s->groups != 1 || s->deformable_groups != 1 || !plane_ok(s, dd[i])) {
+    if (!plane_ok(s, dd[i])) {
       set_error("problem %d is not eligible for the plane grad_weight kernel", i);
       return KGDET_E_UNSUPPORTED;
+    }
+    const int cpdg = s->C / s->deformable_groups;
+    for (int c0 = 0; c0 < s->C;) {   // runs of channels inside one weight group and one deformable group
+      const int c1 = std::min((c0 / dd[i].Cg + 1) * dd[i].Cg, (c0 / cpdg + 1) * cpdg);
+      ++n_sub;
+      c0 = c1;
     }
     same_taps[i] = same_gq[i] = -1;
     for (int q = 0; q < i; ++q) {
       const kgdet_dcn_shape *o = shapes[q];
       const bool geo = o->N == s->N && o->H == s->H && o->W == s->W && o->kh == s->kh && o->kw == s->kw &&
                        o->stride_h == s->stride_h && o->stride_w == s->stride_w && o->pad_h == s->pad_h &&
-                       o->pad_w == s->pad_w && o->dil_h == s->dil_h && o->dil_w == s->dil_w;
+                       o->pad_w == s->pad_w && o->dil_h == s->dil_h && o->dil_w == s->dil_w &&
+                       o->deformable_groups == s->deformable_groups;
       if (same_taps[i] < 0 && geo && offsets[q] == offsets[i] && (!masks || masks[q] == masks[i]))
         same_taps[i] = same_taps[q] >= 0 ? same_taps[q] : q;
-      if (same_gq[i] < 0 && grad_outputs[q] == grad_outputs[i] && o->N == s->N && o->O == s->O &&
+      if (same_gq[i] < 0 && grad_outputs[q] == grad_outputs[i] && o->N == s->N && o->O == s->O && o->groups == s->groups &&
           o->out_channel_offset == s->out_channel_offset && o->out_channels_total == s->out_channels_total &&
           dd[q].Ho == dd[i].Ho && dd[q].Wo == dd[i].Wo)
         same_gq[i] = same_gq[q] >= 0 ? same_gq[q] : q;
@@ -1023,8 +1075,12 @@ static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *sh
     if (same_taps[i] < 0) { taps_off[i] = total; total += align_up(tap_table_bytes(s, dd[i]), 256); }
     else taps_off[i] = taps_off[same_taps[i]];
     const int n_px16 = ceil_div(dd[i].Ho * dd[i].Wo, kChunk);
-    if (same_gq[i] < 0) { gq_off[i] = total; total += (size_t)(dd[i].Og_pad / kTileM) * s->N * n_px16 * 16384; }
+    if (same_gq[i] < 0) { gq_off[i] = total; total += (size_t)s->groups * (dd[i].Og_pad / kTileM) * s->N * n_px16 * 16384; }
     else gq_off[i] = gq_off[same_gq[i]];
+  }
+  if (n_sub > kMaxFwdGroup) {
+    set_error("more than %d (weight group, deformable group) channel runs in one launch", kMaxFwdGroup);
+    return KGDET_E_UNSUPPORTED;
   }
   if (workspace == nullptr || workspace_bytes < slab_bytes() + total) {
     set_error("workspace too small: need %zu bytes, got %zu (kgdet_dcn_group_workspace_bytes)", slab_bytes() + total,
@@ -1046,30 +1102,47 @@ static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *sh
   for (int i = 0; i < n; ++i) {
     const kgdet_dcn_shape *s = shapes[i];
     const Derived &d = dd[i];
-    DcnProblem p;
-    fill_problem(s, d, 0, p);
-    const int n_px16 = ceil_div(p.HoWo, kChunk);
-    p.x = inputs[i]; p.offset = offsets[i]; p.mask = masks ? masks[i] : nullptr; p.out = grad_weights[i];
-    p.taps = reinterpret_cast<const DcnTapRec *>(tab + taps_off[i]);
-    p.build_taps = same_taps[i] < 0;
-    p.wq = tab + gq_off[i];
-    if (same_gq[i] < 0)
-      hipLaunchKernelGGL(dcn_pack_grad_out, dim3(s->N * n_px16, d.Og_pad / kTileM), dim3(256), 0, (hipStream_t)stream,
-                         grad_outputs[i], (void *)(tab + gq_off[i]), s->N, p.O_total, p.o_base, d.Og, p.HoWo, n_px16, 2);
-    p.n_mtiles = d.Og_pad / kTileM;
-    p.tiles_per_image = ceil_div(d.K, 8);                    // tap groups per channel chunk
-    p.n_ntiles = (d.Cg_pad / kChunk) * p.tiles_per_image;    // (chunk, tap group) column tiles
-    p.chunks_per_tap = n_px16;                               // stages per image
-    p.chunks_per_tile = s->N * n_px16;                       // the reduction runs over the pixels of all images
-    p.total_units = (long long)p.n_ntiles * p.n_mtiles * p.chunks_per_tile;
-    p.kparts = 1;
-    p.flags = 0;
-    grp.p[grp.n] = p;
-    grp.tile_begin[grp.n + 1] = grp.tile_begin[grp.n] + p.n_ntiles * p.n_mtiles;
-    grp.range_begin[grp.n + 1] = grp.range_begin[grp.n] + p.n_ntiles * p.n_mtiles;
-    grp.unit_begin[grp.n + 1] = grp.unit_begin[grp.n] + p.total_units;
-    ++grp.n;
-    min_len = p.chunks_per_tile < min_len ? p.chunks_per_tile : min_len;
+    const int cpdg = s->C / s->deformable_groups;
+    const int n_px16 = ceil_div(d.Ho * d.Wo, kChunk);
+    const size_t gq_group_bytes = (size_t)(d.Og_pad / kTileM) * s->N * n_px16 * 16384;
+    int packed_group = -1;   // grad_out images of the weight groups are packed as their first channel run is met
+    bool first_sub = true;
+    for (int c0 = 0; c0 < s->C;) {
+      const int g = c0 / d.Cg, dgi = c0 / cpdg;
+      const int c1 = std::min((g + 1) * d.Cg, (dgi + 1) * cpdg);
+      DcnProblem p;
+      fill_problem(s, d, g, p);
+      p.x = inputs[i]; p.offset = offsets[i]; p.mask = masks ? masks[i] : nullptr;
+      p.c_base = c0; p.Cg = c1 - c0; p.Cg_pad = ceil_div(p.Cg, kChunk) * kChunk;
+      p.dgi = dgi;
+      p.w_ld = d.Cg;                                                      // a weight row holds the whole group's channels
+      p.out = grad_weights[i] + ((size_t)g * d.Og * d.Cg + (size_t)(c0 - g * d.Cg)) * d.K;
+      p.taps = reinterpret_cast<const DcnTapRec *>(tab + taps_off[i]);
+      p.build_taps = same_taps[i] < 0 && first_sub;
+      p.wq = tab + gq_off[i] + (size_t)g * gq_group_bytes;
+      if (same_gq[i] < 0 && packed_group < g) {
+        hipLaunchKernelGGL(dcn_pack_grad_out, dim3(s->N * n_px16, d.Og_pad / kTileM), dim3(256), 0, (hipStream_t)stream,
+                           grad_outputs[i], (void *)(tab + gq_off[i] + (size_t)g * gq_group_bytes), s->N, p.O_total, p.o_base,
+                           d.Og, p.HoWo, n_px16, 2);
+        packed_group = g;
+      }
+      p.n_mtiles = d.Og_pad / kTileM;
+      p.tiles_per_image = ceil_div(d.K, 8);                    // tap groups per channel chunk
+      p.n_ntiles = (p.Cg_pad / kChunk) * p.tiles_per_image;    // (chunk, tap group) column tiles
+      p.chunks_per_tap = n_px16;                               // stages per image
+      p.chunks_per_tile = s->N * n_px16;                       // the reduction runs over the pixels of all images
+      p.total_units = (long long)p.n_ntiles * p.n_mtiles * p.chunks_per_tile;
+      p.kparts = 1;
+      p.flags = 0;
+      grp.p[grp.n] = p;
+      grp.tile_begin[grp.n + 1] = grp.tile_begin[grp.n] + p.n_ntiles * p.n_mtiles;
+      grp.range_begin[grp.n + 1] = grp.range_begin[grp.n] + p.n_ntiles * p.n_mtiles;
+      grp.unit_begin[grp.n + 1] = grp.unit_begin[grp.n] + p.total_units;
+      ++grp.n;
+      min_len = p.chunks_per_tile < min_len ? p.chunks_per_tile : min_len;
+      first_sub = false;
+      c0 = c1;
+    }
     const size_t need = dcn_bwd_weight_plane_lds_bytes(2, s->H * s->W);
     lds = need > lds ? need : lds;
   }
@@ -1094,11 +1167,6 @@ int kgdet_deform_conv_backward_input(const kgdet_dcn_shape *s, const float *inpu
   if (int rc = derive(s, d)) return rc;
   KGDET_CHECK_SHAPE(input && offset && packed_weight && grad_output && grad_input && grad_offset, "null pointer");
   KGDET_CHECK_SHAPE((mask == nullptr) == (grad_mask == nullptr), "mask and grad_mask must come together");
-  if (!mfma_bwd_ok(s)) {
-    set_error("deformable_groups=%d / groups=%d / C=%d: channel tiles straddle deformable groups (unsupported)",
-              s->deformable_groups, s->groups, s->C);
-    return KGDET_E_UNSUPPORTED;
-  }
   // v1 on small maps: the two plane kernels (grad_input by transposed sampling, grad_offset with the column
   // gradient in registers), bf16 hi/lo split MFMA -- 2x faster than the f32 gather kernel below
   const bool plane_off = g_options[KGDET_OPT_EXACT_BACKWARD] != 0;
@@ -1112,6 +1180,11 @@ int kgdet_deform_conv_backward_input(const kgdet_dcn_shape *s, const float *inpu
       return kgdet_deform_conv_grad_input(s, offset, mask, packed_weight, grad_output, grad_input, 0, workspace,
                                           workspace_bytes, stream);
     if (rc != KGDET_E_UNSUPPORTED) return rc;
+  }
+  if (!mfma_bwd_ok(s)) {
+    set_error("deformable_groups=%d / groups=%d / C=%d: channel tiles straddle deformable groups (unsupported)",
+              s->deformable_groups, s->groups, s->C);
+    return KGDET_E_UNSUPPORTED;
   }
   const int G = grid_size();
   const int cpdg = s->C / s->deformable_groups;
@@ -1211,9 +1284,8 @@ int kgdet_deform_conv_backward_weight(const kgdet_dcn_shape *s, const float *inp
   Derived d;
   if (int rc = derive(s, d)) return rc;
   KGDET_CHECK_SHAPE(input && offset && grad_output && grad_weight, "null pointer");
-  // one weight group, one deformable group, small map (v1 or v2): the split-operand plane kernel, natural-layout output
-  if (!accumulate && g_options[KGDET_OPT_EXACT_BACKWARD] == 0 && s->groups == 1 && s->deformable_groups == 1 &&
-      plane_ok(s, d)) {
+  // small map (v1 or v2, any weight / deformable groups): the split-operand plane kernel, natural-layout output
+  if (!accumulate && g_options[KGDET_OPT_EXACT_BACKWARD] == 0 && plane_ok(s, d)) {
     const int rc = grad_weight_plane_grouped(1, &s, &input, &offset, mask ? &mask : nullptr, &grad_output, &grad_weight, workspace,
                                              workspace_bytes, stream);
     if (rc == KGDET_OK) {

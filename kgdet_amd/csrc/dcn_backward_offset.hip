@@ -45,14 +45,14 @@ __global__ __launch_bounds__(256) void dcn_build_grad_taps(const DcnFwdGroup grp
     const int b = (int)(i / ((long long)p.HoWo * p.K));
     const int oy = hw / p.Wo, ox = hw - oy * p.Wo;
     const int ti = t / p.kw, tj = t - ti * p.kw;
-    const long long ob = ((long long)b * 2 * p.K + 2 * t) * p.HoWo + hw;
+    const long long ob = ((long long)(b * p.DG + p.dgi) * 2 * p.K + 2 * t) * p.HoWo + hw;   // (this run's deformable group)
     const float y = (float)(oy * p.sh - p.ph + ti * p.dh) + p.offset[ob];
     const float x = (float)(ox * p.sw - p.pw + tj * p.dw) + p.offset[ob + p.HoWo];
     Tap tap;
     TapGeom geo;
     make_tap(y, x, p.H, p.W, true, 1.0f, tap, geo);
     const float hy = 1.0f - geo.ly, hx = 1.0f - geo.lx;
-    const float m = p.mask ? p.mask[((long long)b * p.K + t) * p.HoWo + hw] : 1.0f;
+    const float m = p.mask ? p.mask[((long long)(b * p.DG + p.dgi) * p.K + t) * p.HoWo + hw] : 1.0f;
     const int rs = p.mask ? 4 : 3;   // 16-byte pieces per record
     const float ka = geo.va ? m : 0.f, kb = geo.vb ? m : 0.f, kc = geo.vc ? m : 0.f, kd = geo.vd ? m : 0.f;
     unsigned off[4];
@@ -162,7 +162,7 @@ __device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__res
       const unsigned rec_lane = (unsigned)my_px_c * (unsigned)(RS * 16);
       // W^T stage of (chunk c16, tap t): for every 16-o chunk o16 the rows c16*16 .. +15 of both k-halves:
       // 256-byte runs inside wqt[ct][o16][t][part][khalf][c 256][8 o]
-      const int ct = (c16 * kChunk) / kTileM, c_in = (c16 * kChunk) % kTileM;
+      const int ct = ((c16 + p.c16_base) * kChunk) / kTileM, c_in = ((c16 + p.c16_base) * kChunk) % kTileM;
       const unsigned char *wq_base = reinterpret_cast<const unsigned char *>(p.wq) + (size_t)(ct * n_o16) * K * (2 * kAPart);
       unsigned a_lane[2];   // producers: this thread's two 16-byte units of a stage image, relative to the stage of o16 = 0
 #pragma unroll
@@ -322,10 +322,10 @@ __device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__res
         if (whole) {
           const int px = tile_px0 + col;
           if (px < HoWo) {
-            float *dst = p.goff + ((long long)tile_b * 2 * K + 2 * t) * HoWo + px;
+            float *dst = p.goff + ((long long)(tile_b * p.DG + p.dgi) * 2 * K + 2 * t) * HoWo + px;
             dst[0] = vy;
             dst[HoWo] = vx;
-            if constexpr (MASK) p.gmask[((long long)tile_b * K + t) * HoWo + px] = vm;
+            if constexpr (MASK) p.gmask[((long long)(tile_b * p.DG + p.dgi) * K + t) * HoWo + px] = vm;
           }
         } else if constexpr (MASK) {
           reinterpret_cast<f32x4 *>(slab)[i] = f32x4{vy, vx, vm, 0.f};
@@ -378,10 +378,10 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_plane_fixup_masked(const D
     }
     const int t = i / kTileN, px = px0 + (i - t * kTileN);
     if (px < p.HoWo) {
-      float *dst = p.goff + ((long long)tb * 2 * p.K + 2 * t) * p.HoWo + px;
+      float *dst = p.goff + ((long long)(tb * p.DG + p.dgi) * 2 * p.K + 2 * t) * p.HoWo + px;
       dst[0] = sy;
       dst[p.HoWo] = sx;
-      p.gmask[((long long)tb * p.K + t) * p.HoWo + px] = sm;
+      p.gmask[((long long)(tb * p.DG + p.dgi) * p.K + t) * p.HoWo + px] = sm;
     }
   }
 }
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_plane_fixup(const DcnFwdGr
       }
       const int t = i / kTileN, px = px0_ + (i - t * kTileN);
       if (px < p.HoWo) {
-        float *dst = p.goff + ((long long)tb_ * 2 * p.K + 2 * t) * p.HoWo + px;
+        float *dst = p.goff + ((long long)(tb_ * p.DG + p.dgi) * 2 * p.K + 2 * t) * p.HoWo + px;
         dst[0] = sy;
         dst[p.HoWo] = sx;
       }
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_plane_fixup(const DcnFwdGr
     if (i >= p.K * kTileN) continue;
     const int t = i / kTileN, px = tile_px0 + (i - t * kTileN);
     if (px < p.HoWo) {
-      float *dst = p.goff + ((long long)tile_b * 2 * p.K + 2 * t) * p.HoWo + px;
+      float *dst = p.goff + ((long long)(tile_b * p.DG + p.dgi) * 2 * p.K + 2 * t) * p.HoWo + px;
       dst[0] = sy[e];
       dst[p.HoWo] = sx[e];
     }

@@ -37,7 +37,7 @@ size_t dcn_bwd_input_plane_lds_bytes(int parts, int plane_pixels) {
 
 // ------------------------------------------------------------------------------------------------
 // Inverse sampling records.  One workgroup per (image, tap); p describes the FORWARD problem
-// (x [N, C, H, W], offsets over Ho x Wo); deformable groups = 1.
+// (x [N, C, H, W], offsets over Ho x Wo) and names the deformable group (p.dgi) whose offsets are read.
 //   inv   [N][K][H*W] DcnInvRec     first 8 contributions of every input cell
 //   slots [N][K][tiles] DcnInvOvfSlots  (tiles = ceil(H*W / 128))
 //   spill [N][K][4 * Ho*Wo] entries  all overflow entries, tile after tile
@@ -62,7 +62,7 @@ __device__ __forceinline__ void build_inverse_taps_body(const DcnProblem &p, uin
   for (int px = tid; px < p.HoWo; px += 256) {
     const int oy = px / p.Wo, ox = px - oy * p.Wo;
     float y, x, m;
-    tap_position(p, b, 0, t, px, oy, ox, y, x, m);
+    tap_position(p, b, p.dgi, t, px, oy, ox, y, x, m);
     Tap tap;
     TapGeom geo;
     make_tap(y, x, p.H, p.W, true, m, tap, geo);
@@ -104,7 +104,7 @@ __device__ __forceinline__ void build_inverse_taps_body(const DcnProblem &p, uin
   for (int px = tid; px < p.HoWo; px += 256) {
     const int oy = px / p.Wo, ox = px - oy * p.Wo;
     float y, x, m;
-    tap_position(p, b, 0, t, px, oy, ox, y, x, m);
+    tap_position(p, b, p.dgi, t, px, oy, ox, y, x, m);
     Tap tap;
     TapGeom geo;
     make_tap(y, x, p.H, p.W, true, m, tap, geo);

@@ -70,7 +70,7 @@ size_t dcn_bwd_weight_plane_lds_bytes(int parts, int HW) {
 __device__ __forceinline__ void wgrad_store_elem(const DcnProblem &p, int mt, int c16, int tg, int row, int col, float v) {
   const int o = mt * kTileM + row;
   const int c = c16 * kChunk + (col & 15), t = tg * kTapsPerTile + (col >> 4);
-  if (o < p.Og && c < p.Cg && t < p.K) p.out[((long long)o * p.Cg + c) * p.K + t] = v;
+  if (o < p.Og && c < p.Cg && t < p.K) p.out[((long long)o * p.w_ld + c) * p.K + t] = v;
 }
 
 template <int PARTS, bool PRODUCER>
@@ -135,7 +135,7 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
       // of drained-queue latency.)
       const int r_tl = tid >> 5, r_px = (tid >> 1) & 15, r_h = tid & 1;
       const int r_t = min(tg * kTapsPerTile + r_tl, K - 1);
-      const u32x4 *rec_src = reinterpret_cast<const u32x4 *>(p.taps) + ((size_t)(b * K + r_t) * HoWo) * 2 + r_h;
+      const u32x4 *rec_src = reinterpret_cast<const u32x4 *>(p.taps) + ((size_t)((b * p.DG + p.dgi) * K + r_t) * HoWo) * 2 + r_h;
       const int r_slot = ((r_px & 3) * 2 + r_h) * 32 + r_tl * 4 + (r_px >> 2);  // [piece][tap][pixel quad]
       auto issue = [&](int j, Regs &R) __attribute__((always_inline)) {
         const int q = q0 + min(j, n - 1);

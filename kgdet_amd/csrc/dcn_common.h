@@ -141,6 +141,10 @@ struct DcnProblem {
   int kh, kw, K;
   int sh, sw, ph, pw, dh, dw;
   int DG, cpdg;  // deformable groups, channels (of C_total) per deformable group
+  int dgi;       // backward plane kernels: the ONE deformable group this (sub-)problem's channels belong to
+  int w_ld;      // grad_weight plane kernel: channels per row of the weight the tile is stored into (>= Cg: channel runs)
+  int c16_base;  // grad_offset plane kernel: first 16-channel chunk of this channel run inside its weight group (rows of wqt)
+  int mt_base, row0;  // grad_input plane kernel: first 256-row tile of wqt and first row inside it of this channel run
   int n_ntiles, n_mtiles, chunks_per_tap, chunks_per_tile;
   long long total_units;  // n_ntiles * n_mtiles * chunks_per_tile
   int tiles_per_image;    // > 0: pixel tiles never straddle images (plane kernel); 0: tiles run over N*Ho*Wo

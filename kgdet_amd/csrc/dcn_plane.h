@@ -249,8 +249,10 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       };
       // (buffer loads: wave-uniform stage offset + one 32-bit lane offset, no vector address arithmetic between MFMAs)
       const dcn_rsrc_t wq_rs = dcn_make_rsrc(p.wq);
-      const unsigned wq_seg = (unsigned)((mt * n_c16 + c16) * K) * (unsigned)(2 * kAPart);
-      const unsigned a_lane = (unsigned)((lane >> 5) * (kTileM * 16) + (wave * 32 + (lane & 31)) * 16);
+      // (grad_input of a channel run that starts inside a 256-row tile of wqt: rows row0 .., clamped -- rows past the run
+      // are computed from another run's weights and never stored)
+      const unsigned wq_seg = (unsigned)(((mt + p.mt_base) * n_c16 + c16) * K) * (unsigned)(2 * kAPart);
+      const unsigned a_lane = (unsigned)((lane >> 5) * (kTileM * 16) + min(p.row0 + wave * 32 + (lane & 31), kTileM - 1) * 16);
       auto a_issue = [&](int j, AFrag &F) {
 #ifdef KGDET_ABL_NOALOAD
         if (j > 1) return;

@@ -35,10 +35,24 @@ CASES = [
 ]
 
 
+# weight groups x deformable groups on the backward plane kernels (the calls below return "unsupported" instead of falling
+# back, so a pass means the plane kernel computed the result)
+GROUP_CASES = [
+    (2, 32, 12, 12, 32, 3, 1, 2, 2, 2, 1),      # two weight groups
+    (2, 32, 10, 10, 16, 3, 1, 1, 1, 2, 2),      # deformable group == weight group
+    (2, 64, 10, 10, 32, 3, 1, 1, 1, 1, 4),      # deformable groups of 16 channels
+    (2, 64, 12, 12, 64, 3, 1, 1, 1, 2, 4),      # two weight groups x four deformable groups
+    (1, 96, 9, 11, 48, 5, 1, 2, 1, 3, 1),       # three weight groups
+    (2, 256, 16, 20, 256, 3, 1, 1, 1, 1, 4),    # 64-channel runs: start inside a 256-row tile of the transposed weights
+    (1, 512, 8, 8, 512, 3, 1, 1, 1, 1, 2),      # 256-channel runs: one weight tile each
+    (1, 512, 8, 8, 256, 3, 1, 1, 1, 2, 2),      # two weight groups, each one deformable group of 256 channels
+]
+
+
 def _plane_map(case):
     """maps the LDS-plane kernels take directly (csrc/dcn_api.hip kPlaneMaxHW); larger maps go through the autograd
     entry points, which route them themselves"""
-    return case[2] * case[3] <= 1536
+    return case[2] * case[3] <= 1344
 
 
 def _make(case, seed=0, with_mask=False):
@@ -136,6 +150,9 @@ BWD_CASES = [
     (2, 40, 11, 9, 24, 3, 2, 1, 1, 1, 1),
     (2, 32, 12, 12, 32, 3, 1, 2, 2, 2, 1),
     (2, 32, 10, 10, 16, 3, 1, 1, 1, 2, 2),      # deformable group == weight group
+    (2, 64, 10, 10, 32, 3, 1, 1, 1, 1, 4),      # deformable groups of 16 channels (plane kernels: one channel run each)
+    (2, 64, 12, 12, 64, 3, 1, 1, 1, 2, 4),      # two weight groups x four deformable groups
+    (1, 96, 9, 11, 48, 5, 1, 2, 1, 3, 1),       # three weight groups
     (1, 512, 8, 8, 512, 3, 1, 1, 1, 1, 1),      # two channel tiles -> atomic grad_offset
     (2, 256, 32, 40, 256, 3, 1, 1, 1, 1, 1),
     (2, 256, 50, 84, 256, 3, 1, 1, 1, 1, 1),    # config 5 large maps (reppoints_head_kp_serial.py:143-161)
@@ -160,7 +177,7 @@ def test_backward_v1(case):
     _close(tw.grad.cpu().numpy(), ref['grad_weight'], 5e-5)
 
 
-@pytest.mark.parametrize('case', [BWD_CASES[0], BWD_CASES[4], BWD_CASES[5], BWD_CASES[6]])
+@pytest.mark.parametrize('case', [BWD_CASES[0], BWD_CASES[4], BWD_CASES[5], BWD_CASES[6], BWD_CASES[7], BWD_CASES[8]])
 def test_backward_v2(case):
     _require_gpu()
     from kgdet_amd import dcn
@@ -252,7 +269,7 @@ def test_autocast_contract():
     assert torch.equal(ref, dcn.deform_conv(tx, to, tw, 1, 1, 1))
 
 
-@pytest.mark.parametrize('case', [c for c in CASES if c[10] == 1 and _plane_map(c)])
+@pytest.mark.parametrize('case', [c for c in CASES if c[10] == 1 and _plane_map(c)] + GROUP_CASES)
 def test_grad_input_plane_kernel(case):
     """kgdet_deform_conv_grad_input (transposed sampling on the plane kernel) vs the float64 oracle."""
     _require_gpu()
@@ -290,7 +307,8 @@ def test_grad_input_plane_kernel_long_lists():
     _close(gi.cpu().numpy(), ref, 5e-5)
 
 
-@pytest.mark.parametrize('case', [c for c in CASES if c[10] == 1 and c[9] == 1 and c[4] <= 256 and _plane_map(c)])
+@pytest.mark.parametrize('case', [c for c in CASES if c[10] == 1 and c[9] == 1 and c[4] <= 256 and _plane_map(c)] +
+                         [c for c in GROUP_CASES if (c[1] // c[9]) % (c[1] // c[10]) == 0 and c[4] // c[9] <= 256])   # a deformable group inside ONE weight group
 def test_grad_offset_plane_kernel(case):
     """kgdet_deform_conv_grad_offset (column gradient in registers, feature plane in LDS) vs the float64 oracle."""
     _require_gpu()
@@ -338,7 +356,7 @@ def test_weight_images_follow_fused_optimizer_updates():
     assert not torch.allclose(a, c), 'inference after further training used stale weight images'
 
 
-@pytest.mark.parametrize('case', [c for c in CASES if c[10] == 1 and c[9] == 1 and _plane_map(c)])
+@pytest.mark.parametrize('case', [c for c in CASES if c[10] == 1 and c[9] == 1 and _plane_map(c)] + GROUP_CASES)
 def test_grad_weight_plane_kernel(case):
     """kgdet_deform_conv_grad_weight_grouped (pixel-reduction GEMM on the plane kernel) vs the float64 oracle."""
     _require_gpu()

@@ -85,7 +85,7 @@ def test_hip_parallel_head_equals_reference_head():
 
 
 def test_hip_serial_head_large_level_equals_reference_head():
-    """the serial head on a 384 x 512 pyramid: the stride-8 level has 48 x 64 = 3072 pixels, beyond the 1536-pixel limit
+    """the serial head on a 384 x 512 pyramid: the stride-8 level has 48 x 64 = 3072 pixels, beyond the 1344-pixel limit
     of the LDS-plane deformable kernels, so the large-map forward / backward kernels are inside a reference-pinned
     comparison (losses, input gradients over the pyramid, gradient norms, hard- and soft-NMS detections)"""
     head = ref_cases.serial_head().cuda()
