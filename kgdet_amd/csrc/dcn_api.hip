@@ -517,6 +517,7 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
       }
       grp.plane_bytes = (int)dcn_fwd_plane_pairs_plane_bytes(max_hw);
       grp.dbl_plane = 0;
+      grp.wave_layout = 1;
       const size_t ldsp = dcn_fwd_plane_pairs_lds_bytes(parts, max_hw);
       if (parts == 1)
         hipLaunchKernelGGL(dcn_fwd_plane_pairs<1>, dim3(G), dim3(768), ldsp, (hipStream_t)stream, grp, (float *)workspace);
@@ -524,6 +525,7 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
         hipLaunchKernelGGL(dcn_fwd_plane_pairs<2>, dim3(G), dim3(768), ldsp, (hipStream_t)stream, grp, (float *)workspace);
     } else {
       const size_t lds2 = plan_plane_lds(grp, lds, dcn_fwd_plane_fixed_lds_bytes(parts));
+      grp.wave_layout = dcn_plane_wave_layout();
       if (parts == 1)
         hipLaunchKernelGGL(dcn_fwd_plane<1>, dim3(G), dim3(threads), lds2, (hipStream_t)stream, grp, (float *)workspace);
       else
@@ -729,7 +731,7 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
   const size_t lds = plan_plane_lds(grp, dcn_bwd_input_plane_lds_bytes(parts, d.Ho * d.Wo),
                                     dcn_bwd_input_plane_fixed_lds_bytes(parts));
   const int threads = dcn_fwd_plane_threads();
-  grp.wave_layout = 1;   // plane_role's accumulator layout (slabs are decoded by dcn_fwd_fixup)
+  grp.wave_layout = dcn_plane_wave_layout();   // plane_role's accumulator layout (slabs are decoded by dcn_fwd_fixup)
   plan_static_ranges(grp, G, false, kSlabSlots - 2);
   if (parts == 1)
     hipLaunchKernelGGL(dcn_bwd_input_plane<1>, dim3(G), dim3(threads), lds, (hipStream_t)stream, grp, (float *)workspace);
@@ -970,7 +972,7 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
                        builds);
   }
   lds = plan_plane_lds(grp, lds, dcn_bwd_input_plane_fixed_lds_bytes(2));
-  grp.wave_layout = 1;   // plane_role's accumulator layout (slabs are decoded by dcn_fwd_fixup)
+  grp.wave_layout = dcn_plane_wave_layout();   // plane_role's accumulator layout (slabs are decoded by dcn_fwd_fixup)
   plan_static_ranges(grp, G, false, kSlabSlots - 2);
   hipLaunchKernelGGL(dcn_bwd_input_plane<2>, dim3(G), dim3(dcn_fwd_plane_threads()), lds, (hipStream_t)stream, grp,
                      (float *)workspace);

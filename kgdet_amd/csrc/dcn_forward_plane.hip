@@ -47,6 +47,7 @@ template __global__ void dcn_fwd_plane<1>(const DcnFwdGroup grp, float *__restri
 template __global__ void dcn_fwd_plane<2>(const DcnFwdGroup grp, float *__restrict__ slabs);
 
 int dcn_fwd_plane_threads() { return kRoleThreads; }
+int dcn_plane_wave_layout() { return KGDET_PLANE_WAVES42 ? 0 : 1; }   // DcnFwdGroup::wave_layout of plane_role's slabs
 
 // K >= 7 taps: half-chunk planes, tap-pair stages (dcn_plane_pairs.h)
 template <int PARTS>

@@ -11,6 +11,7 @@ __global__ void dcn_fwd_fixup_static(const DcnFwdGroup grp, const float *__restr
 template <int PARTS>
 __global__ void dcn_fwd_plane(const DcnFwdGroup grp, float *__restrict__ slabs);
 size_t dcn_fwd_plane_lds_bytes(int parts, int HW);
+int dcn_plane_wave_layout();
 size_t dcn_fwd_plane_fixed_lds_bytes(int parts);
 int dcn_fwd_plane_threads();
 template <int PARTS>

@@ -67,6 +67,11 @@ constexpr bool kAFromL2 = true;   // (grad_weight kernel) consumers take their A
 #else
 #define KGDET_MFMA_PACE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop %0" ::"n"(KGDET_PLANE_PACE)); __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
+// consumer wave layout: 0 = 8 x 1 waves of 32 x 128 (every wave reads the whole B stage, distinct weight rows),
+// 1 = 4 x 2 waves of 64 x 64 (half the B reads per wave, every weight fragment fetched by two waves)
+#ifndef KGDET_PLANE_WAVES42
+#define KGDET_PLANE_WAVES42 0
+#endif
 #ifndef KGDET_PLANE_SCALAR_FMA
 #define KGDET_PLANE_SCALAR_FMA 1
 #endif
@@ -175,8 +180,14 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
     const int hw_c = hw0 < p.HoWo ? hw0 : 0;
     const int HoWo = p.HoWo;
 
-    f32x16 acc[PRODUCER ? 1 : 4];  // consumers only
-    if constexpr (!PRODUCER) zero_acc_w8(acc);
+    constexpr bool k42 = (KGDET_PLANE_WAVES42 != 0) && (PARTS > 0);   // (value-dependent: the other layout's calls are discarded, not checked)
+    typedef std::conditional_t<k42, f32x16[2][2], f32x16[4]> Acc;
+    Acc acc;  // consumers only (dead in the producers' instantiation)
+    if constexpr (!PRODUCER) {
+      if constexpr (k42) zero_acc(acc);
+      else zero_acc_w8(acc);
+    }
+    const int wm = wave_s & 3, wn = wave_s >> 2;   // (4 x 2 layout)
 
     typedef PlaneStageRegs<MODE> Regs;
     constexpr int NG = Regs::NG;
@@ -245,14 +256,19 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       // consumers: the wave's A (weight) fragments of stage j straight from the weight image (L2), 16 bytes per lane
       // and fragment, coalesced
       struct AFrag {
-        bf16x8 a[PARTS];
+        bf16x8 a[PARTS][k42 ? 2 : 1];
       };
       // (buffer loads: wave-uniform stage offset + one 32-bit lane offset, no vector address arithmetic between MFMAs)
-      const dcn_rsrc_t wq_rs = dcn_make_rsrc(p.wq);
       // (grad_input of a channel run that starts inside a 256-row tile of wqt: rows row0 .., clamped -- rows past the run
       // are computed from another run's weights and never stored)
+      const dcn_rsrc_t wq_rs = dcn_make_rsrc(p.wq);
       const unsigned wq_seg = (unsigned)(((mt + p.mt_base) * n_c16 + c16) * K) * (unsigned)(2 * kAPart);
-      const unsigned a_lane = (unsigned)((lane >> 5) * (kTileM * 16) + min(p.row0 + wave * 32 + (lane & 31), kTileM - 1) * 16);
+      unsigned a_lane[k42 ? 2 : 1];
+#pragma unroll
+      for (int mi = 0; mi < (k42 ? 2 : 1); ++mi) {
+        const int row = k42 ? wm * 64 + mi * 32 + (lane & 31) : wave * 32 + (lane & 31);
+        a_lane[mi] = (unsigned)((lane >> 5) * (kTileM * 16) + min(p.row0 + row, kTileM - 1) * 16);
+      }
       auto a_issue = [&](int j, AFrag &F) {
 #ifdef KGDET_ABL_NOALOAD
         if (j > 1) return;
@@ -260,7 +276,9 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         const unsigned t = (unsigned)(t0 + min(j, n - 1));
 #pragma unroll
         for (int part = 0; part < PARTS; ++part)
-          F.a[part] = __builtin_bit_cast(bf16x8, dcn_buf_b128(wq_rs, a_lane, wq_seg + t * (2 * kAPart) + part * kAPart));
+#pragma unroll
+          for (int mi = 0; mi < (k42 ? 2 : 1); ++mi)
+            F.a[part][mi] = __builtin_bit_cast(bf16x8, dcn_buf_b128(wq_rs, a_lane[mi], wq_seg + t * (2 * kAPart) + part * kAPart));
       };
       // ---- B stage, producers.  A group has four stages; producer wave pair w (2 waves = 128 pixels) samples stages
       // w and w + 2 of it -- a thread does ALL 16 channels of its pixel for a stage, as two half-stages of 8 channels
@@ -458,27 +476,53 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         if constexpr (!PRODUCER) {
           const unsigned char *B = Bs + (buf * kGroupTaps + gi) * PARTS * kBPart + (lane >> 5) * (kTileN * 16) +
                                    (lane & 31) * 16;
-          bf16x8 b[PARTS][4];
+          if constexpr (k42) {
+            bf16x8 b[PARTS][2];
 #pragma unroll
-          for (int part = 0; part < PARTS; ++part)
+            for (int part = 0; part < PARTS; ++part)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) b[part][ni] = *reinterpret_cast<const bf16x8 *>(B + part * kBPart + ni * 32 * 16);
-          if constexpr (PARTS == 2) {  // small terms first; four independent accumulators per pass
+              for (int ni = 0; ni < 2; ++ni)
+                b[part][ni] = *reinterpret_cast<const bf16x8 *>(B + part * kBPart + (wn * 2 + ni) * 32 * 16);
+            if constexpr (PARTS == 2) {  // small terms first; four independent accumulators per pass
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-              acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[1], b[0][ni], acc[ni], 0, 0, 0);
-              KGDET_MFMA_PACE();
+              for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[1][mi], b[0][ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+              for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[0][mi], b[1][ni], acc[mi][ni], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[0][mi], b[0][ni], acc[mi][ni], 0, 0, 0);
+          } else {
+            bf16x8 b[PARTS][4];
+#pragma unroll
+            for (int part = 0; part < PARTS; ++part)
+#pragma unroll
+              for (int ni = 0; ni < 4; ++ni) b[part][ni] = *reinterpret_cast<const bf16x8 *>(B + part * kBPart + ni * 32 * 16);
+            if constexpr (PARTS == 2) {  // small terms first; four independent accumulators per pass
+#pragma unroll
+              for (int ni = 0; ni < 4; ++ni) {
+                acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[1][0], b[0][ni], acc[ni], 0, 0, 0);
+                KGDET_MFMA_PACE();
+              }
+#pragma unroll
+              for (int ni = 0; ni < 4; ++ni) {
+                acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[0][0], b[1][ni], acc[ni], 0, 0, 0);
+                KGDET_MFMA_PACE();
+              }
             }
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-              acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[0], b[1][ni], acc[ni], 0, 0, 0);
+              acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[0][0], b[0][ni], acc[ni], 0, 0, 0);
               KGDET_MFMA_PACE();
             }
-          }
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) {
-            acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[0], b[0][ni], acc[ni], 0, 0, 0);
-            KGDET_MFMA_PACE();
           }
         }
       };
@@ -586,10 +630,12 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       int tid_e = wave_s * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
       asm volatile("" : "+v"(tid_e));
       if (s_begin == 0 && s_end == cpt) {
-        store_output_w8(p, mt, nt, tid_e, acc);
+        if constexpr (k42) store_output(p, mt, nt, tid_e, acc);
+        else store_output_w8(p, mt, nt, tid_e, acc);
       } else {
         float *slab = slabs + ((long long)g * grp.slots + slot) * kTileElems;
-        store_slab_w8(slab, tid_e, acc);
+        if constexpr (k42) store_slab(slab, tid_e, acc);
+        else store_slab_w8(slab, tid_e, acc);
       }
     }
     KGDET_TR_ADD(6, tr_t);
