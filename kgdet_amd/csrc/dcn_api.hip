@@ -1243,16 +1243,16 @@ int kgdet_deform_conv_backward_input(const kgdet_dcn_shape *s, const float *inpu
     KGDET_CHECK_LAUNCH("dcn_bwd_input_gather");
     return KGDET_OK;
   }
-  // large feature maps, v1: materialised transposed column gradient + inverse index, no atomics (dcn_backward_large.hip)
+  // large feature maps, v1 and v2: materialised transposed column gradient + inverse index, no atomics (dcn_backward_large.hip)
   if (!plane_off) {
     DcnProblem p;
     fill_problem(s, d, 0, p);
-    p.x = input; p.offset = offset; p.mask = nullptr; p.wpk = packed_weight;
+    p.x = input; p.offset = offset; p.mask = mask; p.wpk = packed_weight;
     if (dcn_bwd_large_ok(p, mask != nullptr, s->groups))
-      return dcn_bwd_large(p, grad_output, s->out_channels_total, s->out_channel_offset, grad_input, grad_offset,
+      return dcn_bwd_large(p, grad_output, s->out_channels_total, s->out_channel_offset, grad_input, grad_offset, grad_mask,
                            workspace, workspace_bytes, stream);
   }
-  // v2 / groups / deformable groups on large maps: global-atomic path (grad_input must be zero-filled by the caller)
+  // weight groups / deformable groups on large maps: global-atomic path (grad_input must be zero-filled by the caller)
   // one launch and one channel tile produce a deformable group's whole sum -> plain stores
   const int direct = (d.Cg == cpdg && d.Cg_pad256 == kTileM) ? 1 : 0;
   if (!direct) {

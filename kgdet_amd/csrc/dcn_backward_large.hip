@@ -1,4 +1,4 @@
-// Deformable convolution v1 backward (grad_input + grad_offset) for feature maps too large for the LDS-plane kernels
+// Deformable convolution v1 / v2 backward (grad_input + grad_offset [+ grad_mask]) for feature maps too large for the LDS-plane kernels
 // (config 5's stride-8 / stride-16 levels: [2, 256, 100, 168], [2, 256, 50, 84]).  No atomics, deterministic.
 //
 // Reference path replaced: deform_conv_backward_input_cuda (deform_conv_cuda.cpp:260-371): columns = W^T grad_out
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void large_build_entries(const DcnProblem p, u
     tap_position(p, b, 0, t, hw, oy, ox, y, x, m);
     Tap tap;
     TapGeom geo;
-    make_tap(y, x, p.H, p.W, true, 1.0f, tap, geo);
+    make_tap(y, x, p.H, p.W, true, m, tap, geo);   // (v2: the modulation mask rides on the corner weights; m = 1 for v1)
     const int valid[4] = {geo.va, geo.vb, geo.vc, geo.vd};
     const unsigned long long src = (unsigned long long)((unsigned)(t * p.HoWo + hw)) << 32;
 #pragma unroll
@@ -161,8 +161,9 @@ __global__ __launch_bounds__(256) void large_gather_input(const float *__restric
 // grid = (P, N), 256 threads = channels (looped for C > 256); kMaxK taps accumulate in registers
 constexpr int kLargeMaxK = 49;
 __global__ __launch_bounds__(256) void large_grad_offset(const DcnProblem p, const float *__restrict__ colT,
-                                                         const float *__restrict__ xT, float *__restrict__ grad_offset) {
-  __shared__ float red[4][2];
+                                                         const float *__restrict__ xT, float *__restrict__ grad_offset,
+                                                         float *__restrict__ grad_mask) {
+  __shared__ float red[4][3];
   const int hw = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int oy = hw / p.Wo, ox = hw - oy * p.Wo;
   const int C = p.C_total, K = p.K, HW = p.H * p.W;
@@ -174,32 +175,36 @@ __global__ __launch_bounds__(256) void large_grad_offset(const DcnProblem p, con
     tap_position(p, b, 0, t, hw, oy, ox, y, x, m);
     Tap tap;
     TapGeom geo;
-    make_tap(y, x, p.H, p.W, true, 1.0f, tap, geo);
+    make_tap(y, x, p.H, p.W, true, 1.0f, tap, geo);   // tap.w: the plain bilinear weights (d out / d mask = the sample)
     const float hy = 1.0f - geo.ly, hx = 1.0f - geo.lx;
-    const float ka = geo.va ? 1.f : 0.f, kb = geo.vb ? 1.f : 0.f, kc = geo.vc ? 1.f : 0.f, kd = geo.vd ? 1.f : 0.f;
+    // v2: the offset derivatives carry the mask value (deform_conv_cuda_kernel.cu:636-766)
+    const float ka = geo.va ? m : 0.f, kb = geo.vb ? m : 0.f, kc = geo.vc ? m : 0.f, kd = geo.vd ? m : 0.f;
     const float wy[4] = {-hx * ka, -geo.lx * kb, hx * kc, geo.lx * kd};
     const float wx[4] = {-hy * ka, hy * kb, -geo.ly * kc, geo.ly * kd};
-    float dy = 0.0f, dx = 0.0f;
+    float dy = 0.0f, dx = 0.0f, dm = 0.0f;
     for (int c = tid; c < C; c += 256) {
       const float g = crow[(long long)t * C + c];
-      float sy = 0.0f, sx = 0.0f;
+      float sy = 0.0f, sx = 0.0f, sm = 0.0f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float v = ximg[(long long)tap.o[e] * C + c];
         sy += wy[e] * v;
         sx += wx[e] * v;
+        sm += tap.w[e] * v;
       }
       dy += g * sy;
       dx += g * sx;
+      dm += g * sm;
     }
     // block reduction in a fixed order: lanes by shuffle, then the four waves in order
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
       dy += __shfl_down(dy, d);
       dx += __shfl_down(dx, d);
+      dm += __shfl_down(dm, d);
     }
     __syncthreads();
-    if ((tid & 63) == 0) { red[tid >> 6][0] = dy; red[tid >> 6][1] = dx; }
+    if ((tid & 63) == 0) { red[tid >> 6][0] = dy; red[tid >> 6][1] = dx; red[tid >> 6][2] = dm; }
     __syncthreads();
     if (tid == 0) {
       const float ty = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
@@ -207,6 +212,7 @@ __global__ __launch_bounds__(256) void large_grad_offset(const DcnProblem p, con
       float *dst = grad_offset + ((long long)b * 2 * K + 2 * t) * p.HoWo + hw;
       dst[0] = ty;
       dst[p.HoWo] = tx;
+      if (grad_mask) grad_mask[((long long)b * K + t) * p.HoWo + hw] = ((red[0][2] + red[1][2]) + red[2][2]) + red[3][2];
     }
   }
 }
@@ -241,10 +247,11 @@ LargePlan large_plan(const DcnProblem &p) {
 
 }  // namespace
 
-// eligible: v1 (no mask), one weight group, one deformable group, O % 16 == 0, entry count within int range
+// eligible: v1 or v2 (mask), one weight group, one deformable group, O % 16 == 0, entry count within int range
 bool dcn_bwd_large_ok(const DcnProblem &p, bool has_mask, int groups) {
   const long long n_entries = (long long)p.N * p.K * p.HoWo * 4;
-  return !has_mask && groups == 1 && p.DG == 1 && p.Og % 16 == 0 && ((long long)p.K * p.C_total) % 2 == 0 &&
+  (void)has_mask;
+  return groups == 1 && p.DG == 1 && p.Og % 16 == 0 && ((long long)p.K * p.C_total) % 2 == 0 &&
          p.K <= kLargeMaxK && n_entries < (1LL << 31) && (long long)p.N * p.H * p.W < (1LL << 31) - 2 &&
          (long long)p.K * p.HoWo < (1LL << 32);
 }
@@ -253,8 +260,8 @@ size_t dcn_bwd_large_workspace_bytes(const DcnProblem &p) { return large_plan(p)
 
 // p: the FORWARD problem (x, offset, wpk = the [K][Cg_pad][Og_pad] fp32 weight image, geometry; Og = O, C_total = C)
 int dcn_bwd_large(const DcnProblem &p, const float *grad_output, int out_channels_total,
-                  int out_channel_offset, float *grad_input, float *grad_offset, void *workspace, size_t workspace_bytes,
-                  void *stream) {
+                  int out_channel_offset, float *grad_input, float *grad_offset, float *grad_mask, void *workspace,
+                  size_t workspace_bytes, void *stream) {
   const LargePlan L = large_plan(p);
   if (workspace == nullptr || workspace_bytes < L.total) {
     set_error("workspace too small for the large-map backward: need %zu bytes, got %zu", L.total, workspace_bytes);
@@ -305,7 +312,8 @@ int dcn_bwd_large(const DcnProblem &p, const float *grad_output, int out_channel
                      row_ptr);
   hipLaunchKernelGGL(large_gather_input, dim3((unsigned)((HW + 31) / 32), p.N, (C + 255) / 256), dim3(256), 0, st, colT,
                      row_ptr, vals_b, grad_input, C, K, (int)HW, (int)P);
-  hipLaunchKernelGGL(large_grad_offset, dim3((unsigned)P, p.N), dim3(256), 0, st, p, colT, xT, grad_offset);
+  hipLaunchKernelGGL(large_grad_offset, dim3((unsigned)P, p.N), dim3(256), 0, st, p, colT, xT, grad_offset,
+                     p.mask ? grad_mask : nullptr);
   KGDET_CHECK_LAUNCH("dcn_bwd_large");
   return KGDET_OK;
 }

@@ -93,7 +93,6 @@ __device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__res
   const int lane = tid & 63, wave = tid >> 6;
   const int px16 = lane & 15, kg = lane >> 4;       // consumers: pixel inside the wave's 16, channel quad / k group
   const long long G = gridDim.x, g = blockIdx.x;
-  const long long total = grp.unit_begin[grp.n];
   const long long slice = sk_slice_of_block((int)g, (int)G);
   long long my_begin, my_end;
   dcn_slice_bounds(grp, slice, G, my_begin, my_end);   // (static ranges: exactly one range, or nothing)

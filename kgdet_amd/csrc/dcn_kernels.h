@@ -23,7 +23,7 @@ size_t dcn_fwd_plane_pairs_lds_bytes(int parts, int HW);
 bool dcn_bwd_large_ok(const DcnProblem &p, bool has_mask, int groups);
 size_t dcn_bwd_large_workspace_bytes(const DcnProblem &p);
 int dcn_bwd_large(const DcnProblem &p, const float *grad_output, int out_channels_total, int out_channel_offset,
-                  float *grad_input, float *grad_offset, void *workspace, size_t workspace_bytes, void *stream);
+                  float *grad_input, float *grad_offset, float *grad_mask, void *workspace, size_t workspace_bytes, void *stream);
 __global__ void dcn_build_taps(const DcnFwdGroup grp);
 // grad_input on the plane kernel (dcn_backward_plane.hip)
 template <int PARTS>

@@ -177,7 +177,10 @@ def test_backward_v1(case):
     _close(tw.grad.cpu().numpy(), ref['grad_weight'], 5e-5)
 
 
-@pytest.mark.parametrize('case', [BWD_CASES[0], BWD_CASES[4], BWD_CASES[5], BWD_CASES[6], BWD_CASES[7], BWD_CASES[8]])
+LARGE_V2_CASE = (2, 64, 40, 48, 64, 3, 1, 1, 1, 1, 1)   # 1920 pixels: beyond the LDS-plane kernels, modulated (backbone DCNv2 maps)
+
+
+@pytest.mark.parametrize('case', [BWD_CASES[0], BWD_CASES[4], BWD_CASES[5], BWD_CASES[6], BWD_CASES[7], BWD_CASES[8], LARGE_V2_CASE])
 def test_backward_v2(case):
     _require_gpu()
     from kgdet_amd import dcn
@@ -195,6 +198,21 @@ def test_backward_v2(case):
     _close(tm.grad.cpu().numpy(), ref['grad_mask'], 5e-5)
     _close(tw.grad.cpu().numpy(), ref['grad_weight'], 5e-5)
     _close(tb.grad.cpu().numpy(), ref['grad_bias'], 5e-5)
+
+
+def test_large_map_v2_backward_is_repeatable():
+    """modulated DCN on a map beyond the LDS-plane kernels: the column-gradient path (no float atomics) serves v2 too"""
+    _require_gpu()
+    from kgdet_amd import dcn
+    N, C, H, W, O, k, s, p, d, g, dg = LARGE_V2_CASE
+    x, off, w, go, mask = _make(LARGE_V2_CASE, seed=8, with_mask=True)
+    grads = []
+    for _ in range(2):
+        tx, to, tm, tw = (torch.from_numpy(a).cuda().requires_grad_() for a in (x, off, mask, w))
+        dcn.modulated_deform_conv(tx, to, tm, tw, None, s, p, d, g, dg).backward(torch.from_numpy(go).cuda())
+        grads.append((tx.grad.clone(), to.grad.clone(), tm.grad.clone()))
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
 
 
 def test_grad_weight_deterministic():

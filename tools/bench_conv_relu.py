@@ -6,7 +6,7 @@ import torch
 import torch.nn.functional as F
 from kgdet_amd import backbone
 dev = torch.device('cuda:0')
-torch.backends.cudnn.benchmark = True
+torch.backends.cudnn.benchmark = os.environ.get("BENCHMARK", "1") == "1"
 shapes = [(8, 64, 200, 336, 1), (8, 128, 200, 336, 2), (8, 128, 100, 168, 1), (8, 256, 100, 168, 2), (8, 256, 50, 84, 1),
           (8, 512, 50, 84, 2), (8, 512, 25, 42, 1)]
 
