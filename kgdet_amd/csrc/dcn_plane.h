@@ -129,8 +129,8 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
                                                                      // tap-record offsets + an immediate address a corner read
   unsigned char *Bs = smem + 4 * kPlaneQuadStride;                   // [2 groups][kGroupTaps][PARTS][kBPart]
   // a corner read: the record's offset IS the LDS address (through `plane + offset` hipcc adds the symbol's 0 per read)
-  typedef const f32x4 __attribute__((address_space(3))) *LdsQuadPtr;
 #if defined(__HIP_DEVICE_COMPILE__)
+  typedef const f32x4 __attribute__((address_space(3))) *LdsQuadPtr;
   auto lds_quad = [](unsigned addr) { return *(LdsQuadPtr)(addr); };
 #else
   auto lds_quad = [](unsigned) { return f32x4{0.f, 0.f, 0.f, 0.f}; };   // (host pass: pointers are 64-bit there)
