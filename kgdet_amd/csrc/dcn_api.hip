@@ -1050,7 +1050,7 @@ static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *sh
     const kgdet_dcn_shape *s = shapes[i];
     if (int rc = derive(s, dd[i])) return rc;
     KGDET_CHECK_SHAPE(inputs[i] && offsets[i] && grad_outputs[i] && grad_weights[i], "null pointer (problem %d)", i);
-    if (!plane_ok(s, dd[i])) {
+    if (!plane_ok(s, dd[i]) || dd[i].K > 128) {   // (the fix-up: at most 16 tap groups per channel chunk)
       set_error("problem %d is not eligible for the plane grad_weight kernel", i);
       return KGDET_E_UNSUPPORTED;
     }
@@ -1148,15 +1148,39 @@ static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *sh
     const size_t need = dcn_bwd_weight_plane_lds_bytes(2, s->H * s->W);
     lds = need > lds ? need : lds;
   }
-  if (ceil_div((int)ceil_div((int)grp.unit_begin[grp.n], G), min_len) + 2 > kSlabSlots) {
+  // The fix-up lists at most 32 slabs per tile: small problems run on fewer workgroups, so that a workgroup's share of the
+  // units is at least 1/30 of the longest tile.
+  int Gw = G;
+  {
+    int max_len = 0;
+    for (int i = 0; i < grp.n; ++i) max_len = grp.p[i].chunks_per_tile > max_len ? grp.p[i].chunks_per_tile : max_len;
+    const long long need = ceil_div(max_len, 30);
+    const long long fit = grp.unit_begin[grp.n] / need;
+    if (fit < Gw) Gw = (int)std::max<long long>(1, fit);
+  }
+  if (ceil_div((int)ceil_div((int)grp.unit_begin[grp.n], Gw), min_len) + 2 > kSlabSlots) {
     set_error("group too uneven for the slab slots");
     return KGDET_E_UNSUPPORTED;
   }
   hipLaunchKernelGGL(dcn_build_taps, dim3(2 * G, grp.n), dim3(256), 0, (hipStream_t)stream, grp);
-  hipLaunchKernelGGL(dcn_bwd_weight_plane<2>, dim3(G), dim3(dcn_bwd_weight_plane_threads()), lds, (hipStream_t)stream, grp,
+  hipLaunchKernelGGL(dcn_bwd_weight_plane<2>, dim3(Gw), dim3(dcn_bwd_weight_plane_threads()), lds, (hipStream_t)stream, grp,
                      (float *)workspace);
-  hipLaunchKernelGGL(dcn_bwd_weight_plane_fixup, dim3(grp.tile_begin[grp.n], 16), dim3(kThreads), 0, (hipStream_t)stream,
-                     grp, (const float *)workspace, G);
+  {
+    int fix_blocks = 0, max_K = 0;
+    for (int i = 0; i < grp.n; ++i) {
+      fix_blocks += (grp.p[i].n_ntiles / grp.p[i].tiles_per_image) * grp.p[i].n_mtiles * 32;
+      max_K = grp.p[i].K > max_K ? grp.p[i].K : max_K;
+    }
+    const size_t fix_lds = (size_t)8 * 16 * max_K * sizeof(float);
+    static thread_local bool fix_attr_set = false;
+    if (!fix_attr_set) {
+      KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_bwd_weight_plane_fixup, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        80 * 1024));   // (beside its static slab lists)
+      fix_attr_set = true;
+    }
+    hipLaunchKernelGGL(dcn_bwd_weight_plane_fixup, dim3(fix_blocks), dim3(256), fix_lds, (hipStream_t)stream, grp,
+                       (const float *)workspace, Gw);
+  }
   KGDET_CHECK_LAUNCH("dcn_bwd_weight_plane");
   return KGDET_OK;
 }

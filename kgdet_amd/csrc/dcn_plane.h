@@ -235,7 +235,10 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
     // the consumers the rest after their MFMAs.  Split operands: the consumers are busy for four stages of 12 MFMAs,
     // the producers take two full batches of loads; bf16: a third each way (equal shares per wave).
     const int plane_items = dcn_plane_units(HW);
-    const int plane_split = PARTS == 2 ? min(plane_items, 8 * kPlaneRounds) : plane_items * (kRoleProducers / 64) / (kRoleThreads / 64);
+#ifndef KGDET_PLANE_SPLIT_UNITS
+#define KGDET_PLANE_SPLIT_UNITS (8 * kPlaneRounds)
+#endif
+    const int plane_split = PARTS == 2 ? min(plane_items, KGDET_PLANE_SPLIT_UNITS) : plane_items * (kRoleProducers / 64) / (kRoleThreads / 64);
     typedef std::integral_constant<int, kRoleThreads / 64> AllWaves;
     typedef std::integral_constant<int, kRoleProducers / 64> ProducerWaves;
     typedef std::integral_constant<int, kThreads / 64> ConsumerWaves;
