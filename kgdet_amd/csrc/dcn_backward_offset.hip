@@ -155,14 +155,16 @@ __device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__res
     int t0 = s - c16 * K;
     while (s < s_end) {
       const int n = min(K - t0, s_end - s);
-      // (wave-uniform bases + 32-bit lane offsets: scalar-base loads, no 64-bit vector address arithmetic per stage --
+      // (buffer loads -- SGPR resource, 32-bit lane offset, scalar stage offset: no vector address arithmetic per stage;
       // VALU instructions beside the MFMA waves cost MFMA issue slots, tools/microbench/mfma_valu.hip)
-      const unsigned char *rec_seg = reinterpret_cast<const unsigned char *>(p.taps) + (size_t)tile_b * K * HoWo * RS * 16;
+      const dcn_rsrc_t rec_rs = dcn_make_rsrc(p.taps);
+      const unsigned rec_seg = (unsigned)(tile_b * K) * (unsigned)(HoWo * RS * 16);
       const unsigned rec_lane = (unsigned)my_px_c * (unsigned)(RS * 16);
       // W^T stage of (chunk c16, tap t): for every 16-o chunk o16 the rows c16*16 .. +15 of both k-halves:
       // 256-byte runs inside wqt[ct][o16][t][part][khalf][c 256][8 o]
       const int ct = ((c16 + p.c16_base) * kChunk) / kTileM, c_in = ((c16 + p.c16_base) * kChunk) % kTileM;
-      const unsigned char *wq_base = reinterpret_cast<const unsigned char *>(p.wq) + (size_t)(ct * n_o16) * K * (2 * kAPart);
+      const dcn_rsrc_t wq_rs = dcn_make_rsrc(p.wq);
+      const unsigned wq_base = (unsigned)(ct * n_o16 * K) * (unsigned)(2 * kAPart);
       unsigned a_lane[2];   // producers: this thread's two 16-byte units of a stage image, relative to the stage of o16 = 0
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
@@ -172,20 +174,20 @@ __device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__res
       }
 
       auto issue = [&](int j, Regs &R) {
-        const int t = t0 + min(j, n - 1);
+        const unsigned t = (unsigned)(t0 + min(j, n - 1));
         if constexpr (PRODUCER) {
 #pragma unroll
           for (int r = 0; r < 2; ++r) {
 #pragma unroll
             for (int part = 0; part < PARTS; ++part)
-              R.a[part][r] = *reinterpret_cast<const f32x4 *>(wq_base + (size_t)t * (2 * kAPart) + part * kAPart + a_lane[r]);
+              R.a[part][r] = __builtin_bit_cast(f32x4, dcn_buf_b128(wq_rs, a_lane[r], wq_base + t * (2 * kAPart) + part * kAPart));
           }
         } else {
-          const unsigned char *rec = rec_seg + (size_t)t * HoWo * RS * 16;
-          R.off = *reinterpret_cast<const uint4 *>(rec + rec_lane);
-          R.wy = *reinterpret_cast<const f32x4 *>(rec + rec_lane + 16);
-          R.wx = *reinterpret_cast<const f32x4 *>(rec + rec_lane + 32);
-          if constexpr (MASK) R.wm = *reinterpret_cast<const f32x4 *>(rec + rec_lane + 48);
+          const unsigned so = rec_seg + t * (unsigned)(HoWo * RS * 16);
+          R.off = __builtin_bit_cast(uint4, dcn_buf_b128(rec_rs, rec_lane, so));
+          R.wy = __builtin_bit_cast(f32x4, dcn_buf_b128(rec_rs, rec_lane + 16, so));
+          R.wx = __builtin_bit_cast(f32x4, dcn_buf_b128(rec_rs, rec_lane + 32, so));
+          if constexpr (MASK) R.wm = __builtin_bit_cast(f32x4, dcn_buf_b128(rec_rs, rec_lane + 48, so));
         }
       };
       auto commit_weights = [&](int buf, const Regs &R) {
