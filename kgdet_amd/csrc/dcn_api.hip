@@ -195,6 +195,19 @@ bool plane_ok(const kgdet_dcn_shape *s, const Derived &d) {
          (size_t)8 * 33 * (d.K + 1) * sizeof(float) <= kMaxLds - 64 &&
          slab_slots_ok((long long)s->N * ceil_div(d.Ho * d.Wo, kTileN) * (d.Og_pad / kTileM), d.K * (d.Cg_pad / kChunk));
 }
+// forward on maps beyond the LDS plane: producers gather from a pixel-major copy of x (plane_role MODE 2); offsets into
+// that copy and into the weight image must stay below 4 GB
+bool gather_ok(const kgdet_dcn_shape *s, const Derived &d) {
+  const int cpdg = s->C / s->deformable_groups;
+  return mfma_ok(s) && (s->deformable_groups == 1 || cpdg % 16 == 0) && !plane_ok(s, d) &&
+         (size_t)s->N * s->H * s->W * s->C * 4 < ((size_t)1 << 32) - 4096 &&
+         (size_t)s->N * s->deformable_groups * d.K * d.Ho * d.Wo * sizeof(DcnTapRec) < ((size_t)1 << 32) &&
+         (size_t)8 * 33 * (d.K + 1) * sizeof(float) <= kMaxLds - 64;
+}
+size_t gather_table_bytes(const kgdet_dcn_shape *s, const Derived &d) {
+  return align_up((size_t)s->N * s->deformable_groups * d.K * d.Ho * d.Wo * sizeof(DcnTapRec), 256);
+}
+size_t gather_image_bytes(const kgdet_dcn_shape *s) { return align_up((size_t)s->N * s->H * s->W * s->C * 4 + 256, 256); }
 size_t tap_table_bytes(const kgdet_dcn_shape *s, const Derived &d) {
   return plane_ok(s, d) ? (size_t)s->N * s->deformable_groups * d.K * d.Ho * d.Wo * sizeof(DcnTapRec) : 0;
 }
@@ -318,6 +331,10 @@ size_t kgdet_dcn_workspace_bytes(const kgdet_dcn_shape *s) {
     const size_t wplane = slab_bytes() + align_up(tap_table_bytes(s, d), 256) +
                           (size_t)s->groups * (d.Og_pad / kTileM) * s->N * ceil_div(d.Ho * d.Wo, kChunk) * 16384;
     need = need > wplane ? need : wplane;
+  }
+  if (gather_ok(s, d)) {   // forward on large maps: records + the pixel-major copy of x behind the slabs
+    const size_t gw = slab_bytes() + gather_table_bytes(s, d) + gather_image_bytes(s);
+    need = need > gw ? need : gw;
   }
   if (!pl.ok && !plane_bwd_input_ok(s, d)) {   // large maps: the materialised column gradient of dcn_backward_large.hip
     DcnProblem p;
@@ -480,7 +497,7 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
   grp.slots = kSlabSlots;
   grp.dbl_plane = 0;
   grp.plane_bytes = 0;
-  grp.pair_mode = 0;
+  grp.pair_mode = 0; grp.gather_mode = 0;
   grp.rounds = 1;
   grp.wave_layout = 1;
   size_t lds = 0;
@@ -623,10 +640,62 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
         lds = need > lds ? need : lds;
         if (grp.n == kMaxFwdGroup)
           if (int rc = flush()) return rc;
+      } else if (!(flags & KGDET_DCN_EXACT_FP32) && gather_ok(s, d)) {
+        // map beyond the LDS plane: split operands, producers gather from a pixel-major copy of x (one launch per problem)
+        if (int rc = flush()) return rc;
+        const size_t tb = gather_table_bytes(s, d), ib = gather_image_bytes(s);
+        if (slab_bytes() + tb + ib > workspace_bytes) {
+          set_error("workspace too small for the large-map forward: need %zu bytes, got %zu (kgdet_dcn_workspace_bytes)",
+                    slab_bytes() + tb + ib, workspace_bytes);
+          return KGDET_E_WORKSPACE;
+        }
+        float *xT = reinterpret_cast<float *>(table_base + tb);
+        const long long HW = (long long)s->H * s->W;
+        if (g == 0)
+          hipLaunchKernelGGL(dcn_to_pixel_major, dim3((unsigned)((HW + 31) / 32), (s->C + 31) / 32, s->N), dim3(256), 0,
+                             (hipStream_t)stream, inputs[i], xT, s->C, HW, (long long)s->C * HW);
+        p.x = xT;
+        p.wq = packed_weights[i] + (size_t)s->groups * (d.fwd_image_floats() + d.bwd_image_floats()) +
+               (size_t)g * d.plane_image_floats();
+        p.tiles_per_image = ceil_div(p.HoWo, kTileN);
+        p.n_ntiles = p.N * p.tiles_per_image;
+        p.total_units = (long long)p.n_ntiles * p.n_mtiles * p.chunks_per_tile;
+        p.taps = reinterpret_cast<const DcnTapRec *>(table_base);
+        p.build_taps = g == 0;
+        DcnFwdGroup gg;
+        gg.n = 1; gg.xcd_slices = 1; gg.slots = kSlabSlots; gg.dbl_plane = 0; gg.plane_bytes = 0; gg.static_ranges = 0;
+        gg.pair_mode = 0; gg.gather_mode = 1; gg.rounds = 1; gg.wave_layout = dcn_plane_wave_layout();
+        gg.tile_begin[0] = 0; gg.range_begin[0] = 0; gg.unit_begin[0] = 0;
+        gg.p[0] = p;
+        gg.tile_begin[1] = p.n_ntiles * p.n_mtiles;
+        gg.range_begin[1] = p.n_ntiles * p.n_mtiles;
+        gg.unit_begin[1] = p.total_units;
+        if (ceil_div((int)ceil_div(p.total_units, (long long)G), p.chunks_per_tile) + 2 > kSlabSlots) {
+          set_error("large-map forward: more tiles per workgroup than slab slots");
+          return KGDET_E_UNSUPPORTED;
+        }
+        plan_static_ranges(gg, G, false, kSlabSlots - 2);
+        static thread_local bool gattr_set = false;
+        if (!gattr_set) {
+          KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_fwd_gather<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)kMaxLds));
+          KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_fwd_gather<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)kMaxLds));
+          gattr_set = true;
+        }
+        if (p.build_taps) hipLaunchKernelGGL(dcn_build_taps, dim3(2 * G, 1), dim3(256), 0, (hipStream_t)stream, gg);
+        const size_t glds = dcn_fwd_plane_fixed_lds_bytes(parts);
+        if (parts == 1)
+          hipLaunchKernelGGL(dcn_fwd_gather<1>, dim3(G), dim3(dcn_fwd_plane_threads()), glds, (hipStream_t)stream, gg,
+                             (float *)workspace);
+        else
+          hipLaunchKernelGGL(dcn_fwd_gather<2>, dim3(G), dim3(dcn_fwd_plane_threads()), glds, (hipStream_t)stream, gg,
+                             (float *)workspace);
+        launch_plane_fixup(gg, workspace, G, stream);
       } else {  // exact-fp32 kernel: one launch per problem (slabs are shared, so flush the pending group first)
         if (int rc = flush()) return rc;
         DcnFwdGroup one;
-        one.n = 1; one.xcd_slices = 0; one.slots = 2; one.dbl_plane = 0; one.plane_bytes = 0; one.static_ranges = 0; one.pair_mode = 0; one.rounds = 1; one.wave_layout = 0; one.range_begin[0] = 0;
+        one.n = 1; one.xcd_slices = 0; one.slots = 2; one.dbl_plane = 0; one.plane_bytes = 0; one.static_ranges = 0; one.pair_mode = 0; one.gather_mode = 0; one.rounds = 1; one.wave_layout = 0; one.range_begin[0] = 0;
         one.range_begin[1] = p.n_ntiles * p.n_mtiles; one.tile_begin[0] = 0; one.tile_begin[1] = p.n_ntiles * p.n_mtiles;
         one.unit_begin[0] = 0; one.unit_begin[1] = p.total_units;
         one.p[0] = p;
@@ -690,7 +759,7 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
   const int G = grid_size();
   const int parts = (flags & KGDET_DCN_BF16) ? 1 : 2;
   DcnFwdGroup grp;
-  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.pair_mode = 0; grp.rounds = 1; grp.wave_layout = 0;
+  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.pair_mode = 0; grp.gather_mode = 0; grp.rounds = 1; grp.wave_layout = 0;
   grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
   const int O_total = s->out_channels_total > 0 ? s->out_channels_total : s->O;
   ChannelRun runs[kMaxFwdGroup];
@@ -785,7 +854,7 @@ static int grad_offset_plane(const kgdet_dcn_shape *s, const float *input, const
   const int G = grid_size();
   const int parts = (flags & KGDET_DCN_BF16) ? 1 : 2;
   DcnFwdGroup grp;
-  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.pair_mode = 0; grp.rounds = 1; grp.wave_layout = 0;
+  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.pair_mode = 0; grp.gather_mode = 0; grp.rounds = 1; grp.wave_layout = 0;
   grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
   // one sub-problem per deformable group (= channel run: plane_bwd_offset_ok), each with its own record table
   const unsigned char *recs = (const unsigned char *)workspace + slab_bytes();
@@ -908,7 +977,7 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
 
   // ---- phase 1: grad_input (transposed sampling) ----
   DcnFwdGroup grp;
-  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.pair_mode = 0; grp.rounds = 1; grp.wave_layout = 0;
+  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.pair_mode = 0; grp.gather_mode = 0; grp.rounds = 1; grp.wave_layout = 0;
   grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
   size_t lds = 0;
   DcnInvBuildGroup builds;
@@ -1097,7 +1166,7 @@ static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *sh
   }
   unsigned char *tab = (unsigned char *)workspace + slab_bytes();
   DcnFwdGroup grp;
-  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.pair_mode = 0; grp.rounds = 1; grp.wave_layout = 0;
+  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.pair_mode = 0; grp.gather_mode = 0; grp.rounds = 1; grp.wave_layout = 0;
   grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
   size_t lds = 0;
   int min_len = 1 << 30;

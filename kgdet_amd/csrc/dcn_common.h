@@ -167,6 +167,8 @@ struct DcnFwdGroup {
   int wave_layout;    // accumulator layout of the slabs: 0 = 4 x 2 waves of 64 x 64 (2 x 2 MFMA blocks each),
                       // 1 = 8 x 1 waves of 32 x 128 (1 x 4 blocks each; plane kernels: every wave loads DISTINCT weight rows)
   int pair_mode;      // 1: tap-pair stages on 8-channel half-planes (dcn_plane_pairs.h): tap records address 32-byte rows
+  int gather_mode;    // 1: no LDS plane (maps beyond kPlaneMaxHW): x is a pixel-major copy [N][H*W][C] and the tap records hold
+                      //    byte offsets of its rows -- the producers gather 16-byte channel quads with buffer loads (plane_role MODE 2)
   int rounds;         // static schedule: the workgroup of slice r computes ranges r, r + G, ..., r + (rounds - 1) G
   int static_ranges;  // 1: workgroup of slice r computes exactly range r (problem, part, tile), r < range_begin[n];
                       //    the other workgroups exit.  Ranges of one (problem, part) are consecutive, so the 32

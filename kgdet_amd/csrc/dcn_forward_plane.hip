@@ -46,6 +46,40 @@ __global__ __launch_bounds__(kRoleThreads, 1) void dcn_fwd_plane(const DcnFwdGro
 template __global__ void dcn_fwd_plane<1>(const DcnFwdGroup grp, float *__restrict__ slabs);
 template __global__ void dcn_fwd_plane<2>(const DcnFwdGroup grp, float *__restrict__ slabs);
 
+
+// Maps beyond the LDS plane (config 5's stride-8 / stride-16 levels): the same roles, the producers' corner reads are
+// buffer loads from a pixel-major copy of x (plane_role MODE 2, dcn_plane.h).  LDS = the B stages only.
+template <int PARTS>
+__global__ __launch_bounds__(kRoleThreads, 1) void dcn_fwd_gather(const DcnFwdGroup grp, float *__restrict__ slabs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (threadIdx.x >= kThreads) plane_role<PARTS, true, 2>(grp, slabs, smem);
+  else plane_role<PARTS, false, 2>(grp, slabs, smem);
+}
+template __global__ void dcn_fwd_gather<1>(const DcnFwdGroup grp, float *__restrict__ slabs);
+template __global__ void dcn_fwd_gather<2>(const DcnFwdGroup grp, float *__restrict__ slabs);
+
+// x [n][C][P] (image stride src_image_stride floats) -> [n][P][C]: 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void dcn_to_pixel_major(const float *__restrict__ src, float *__restrict__ dst, int C,
+                                                          long long P, long long src_image_stride) {
+  __shared__ float tile[32][33];
+  const long long p0 = (long long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32, n = blockIdx.z;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float *s = src + n * src_image_stride;
+  float *d = dst + (long long)n * P * C;
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r;
+    const long long px = p0 + tx;
+    tile[r][tx] = (c < C && px < P) ? s[(long long)c * P + px] : 0.0f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const long long px = p0 + r;
+    const int c = c0 + tx;
+    if (px < P && c < C) d[px * C + c] = tile[tx][r];
+  }
+}
+
 int dcn_fwd_plane_threads() { return kRoleThreads; }
 int dcn_plane_wave_layout() { return KGDET_PLANE_WAVES42 ? 0 : 1; }   // DcnFwdGroup::wave_layout of plane_role's slabs
 
@@ -98,7 +132,8 @@ __global__ __launch_bounds__(256) void dcn_build_taps(const DcnFwdGroup grp) {
     for (int e = 0; e < 4; ++e) {
       const int q = tap.o[e];
       r.off[e] = grp.pair_mode ? (unsigned)(q * kPairRow + (((q >> 3) & 1) << 4))      // half-plane rows (dcn_plane_pairs.h)
-                               : (unsigned)dcn_plane_offset(q);
+                 : grp.gather_mode ? (unsigned)q * (unsigned)(p.C_total * 4)           // rows of the pixel-major image
+                                   : (unsigned)dcn_plane_offset(q);
       r.w[e] = tap.w[e];
     }
     const_cast<DcnTapRec *>(p.taps)[i] = r;

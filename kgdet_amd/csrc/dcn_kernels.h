@@ -12,6 +12,10 @@ template <int PARTS>
 __global__ void dcn_fwd_plane(const DcnFwdGroup grp, float *__restrict__ slabs);
 size_t dcn_fwd_plane_lds_bytes(int parts, int HW);
 int dcn_plane_wave_layout();
+template <int PARTS>
+__global__ void dcn_fwd_gather(const DcnFwdGroup grp, float *__restrict__ slabs);
+__global__ void dcn_to_pixel_major(const float *__restrict__ src, float *__restrict__ dst, int C, long long P,
+                                   long long src_image_stride);
 size_t dcn_fwd_plane_fixed_lds_bytes(int parts);
 int dcn_fwd_plane_threads();
 template <int PARTS>

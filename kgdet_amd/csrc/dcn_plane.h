@@ -84,6 +84,9 @@ constexpr bool kAFromL2 = true;   // (grad_weight kernel) consumers take their A
 //   1  grad_input:  B stage = transposed sampling of grad_output: input cell q collects, for tap t, every
 //                   (output pixel, weight) pair whose corner is q -- the first 8 from a DcnInvRec, the rest from
 //                   the (tile, tap)'s overflow list
+//   2  forward on a map beyond the LDS plane's capacity: like MODE 0, but the corners are 16-byte buffer loads from a
+//                   pixel-major copy of x ([N][H*W][C]: a pixel's 16 channels of a chunk are 64 contiguous bytes), the
+//                   tap records hold the rows' byte offsets; no plane, no plane copy, any map size
 template <int MODE>
 struct PlaneModeTraits {
   static constexpr int kGroups = MODE == 1 ? 2 : 1;  // groups of 4 (pixel, weight) entries in the record
@@ -127,7 +130,7 @@ template <int PARTS, bool PRODUCER, int MODE>
 __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__restrict__ slabs, unsigned char *smem) {
   unsigned char *plane = smem;                                       // [4 quads][kPlaneMaxHW pixels][4 ch] fp32, LDS address 0:
                                                                      // tap-record offsets + an immediate address a corner read
-  unsigned char *Bs = smem + 4 * kPlaneQuadStride;                   // [2 groups][kGroupTaps][PARTS][kBPart]
+  unsigned char *Bs = smem + (MODE == 2 ? 0 : 4 * kPlaneQuadStride);   // [2 groups][kGroupTaps][PARTS][kBPart]
   // a corner read: the record's offset IS the LDS address (through `plane + offset` hipcc adds the symbol's 0 per read)
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef const f32x4 __attribute__((address_space(3))) *LdsQuadPtr;
@@ -225,6 +228,9 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
     // Copy x[tile_b, c_base + 16*c .. +15, :, :] into the LDS quad planes (dcn_plane_copy, dcn_common.h): units
     // [unit_lo, unit_hi) of the plane, this wave being number `w` of `NW_` waves that share them.
     const float *xb_img = p.x + ((long long)tile_b * p.C_total + p.c_base) * HW;
+    // MODE 2: the pixel-major image; byte offset of this tile's image and channel window (the chunk is added per segment)
+    const dcn_rsrc_t xg_rs = dcn_make_rsrc(p.x);
+    const unsigned xg_img = (unsigned)(((long long)tile_b * HW * p.C_total + p.c_base) * 4);
     auto load_plane = [&](int c, int w, auto NW_, auto ROUNDS_, int unit_lo, int unit_hi) {
       constexpr int NW = decltype(NW_)::value;
       constexpr int ROUNDS = decltype(ROUNDS_)::value;
@@ -259,6 +265,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       const int n_groups = 1 + (n - r) / kGroupTaps;
       const bool has_next = s + n < s_end;
       const unsigned rec_base = seg_records(c16);
+      const unsigned xg_seg = xg_img + (unsigned)(c16 * kChunk * 4);   // (MODE 2) this segment's channel chunk
 
       // consumers: the wave's A (weight) fragments of stage j straight from the weight image (L2), 16 bytes per lane
       // and fragment, coalesced
@@ -308,7 +315,10 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
 #ifdef KGDET_ABL_NOGATHER
             v[c][e] = f32x4{__uint_as_float(o[e]), R.w[gq][c], R.w[gq][e], (float)half};
 #else
-            v[c][e] = lds_quad(o[e] + (unsigned)((half * 2 + c) * kPlaneQuadStride));
+            if constexpr (MODE == 2)
+              v[c][e] = __builtin_bit_cast(f32x4, dcn_buf_b128(xg_rs, o[e], xg_seg + (unsigned)((half * 2 + c) * 16)));
+            else
+              v[c][e] = lds_quad(o[e] + (unsigned)((half * 2 + c) * kPlaneQuadStride));
 #endif
       };
       auto corner_fma = [&](const Regs &R, int gq, const Corners &v, f32x2 (&sv)[2][2], bool first) {
@@ -416,7 +426,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
 #ifdef KGDET_ABL_NOSAMPLE
         constexpr bool pipelined = false;
 #else
-        constexpr bool pipelined = MODE == 0;
+        constexpr bool pipelined = MODE == 0 || MODE == 2;
 #endif
 #ifdef KGDET_PLANE_TRACE_PRODUCER   // unpipelined, timed: slot 0 = issue of 8 corner reads -> data there, slot 6 = the rest
         if constexpr (pipelined) {
@@ -548,7 +558,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
           issue(rec_base, t0, n - 1, r + pair, O0);
           if constexpr (kRolePairs == 2) { issue(rec_base, t0, r - 1, pair + 2, E1); issue(rec_base, t0, n - 1, r + pair + 2, O1); }
         }
-        load_plane(c16, wave_all, AllWaves{}, FullRounds{}, 0, plane_items);
+        if constexpr (MODE != 2) load_plane(c16, wave_all, AllWaves{}, FullRounds{}, 0, plane_items);
         KGDET_TR_ADD(1, tr_t);
         __syncthreads();
         KGDET_TR_ADD(2, tr_t);
@@ -577,7 +587,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
           issue(rb2, 0, r2 - 1, pair, E0);
           issue(rb2, 0, n2 - 1, r2 + pair, O0);
           if constexpr (kRolePairs == 2) { issue(rb2, 0, r2 - 1, pair + 2, E1); issue(rb2, 0, n2 - 1, r2 + pair + 2, O1); }
-          load_plane(c16 + 1, wave_s, ProducerWaves{}, FullRounds{}, 0, plane_split);
+          if constexpr (MODE != 2) load_plane(c16 + 1, wave_s, ProducerWaves{}, FullRounds{}, 0, plane_split);
         }
       };
       // group 0
@@ -588,7 +598,8 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         if (o) { multiply(0, 0, F1); a_issue(2, F1); }
         if (r - o >= 2) { multiply(0, o, F0); a_issue(o + 2, F0); multiply(0, o + 1, F1); a_issue(o + 3, F1); }
         if (r - o >= 4) { multiply(0, o + 2, F0); a_issue(o + 4, F0); multiply(0, o + 3, F1); a_issue(o + 5, F1); }
-        if (n_groups == 1 && has_next) load_plane(c16 + 1, wave_s, ConsumerWaves{}, HalfRounds{}, plane_split, plane_items);
+        if constexpr (MODE != 2)
+          if (n_groups == 1 && has_next) load_plane(c16 + 1, wave_s, ConsumerWaves{}, HalfRounds{}, plane_split, plane_items);
       }
       KGDET_TR_ADD(4, tr_t);
       __syncthreads();
@@ -614,8 +625,9 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
           __builtin_amdgcn_sched_barrier(0);
           multiply(buf, 3, F1);
           a_issue(jg + 5, F1);
-          if (gi + 1 == n_groups && has_next)
-            load_plane(c16 + 1, wave_s, ConsumerWaves{}, HalfRounds{}, plane_split, plane_items);
+          if constexpr (MODE != 2)
+            if (gi + 1 == n_groups && has_next)
+              load_plane(c16 + 1, wave_s, ConsumerWaves{}, HalfRounds{}, plane_split, plane_items);
         }
         KGDET_TR_ADD(4, tr_t);
         __syncthreads();
