@@ -422,7 +422,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       // this wave pair's two stages of a group (stage pair of the group from record RA, pair + 2 from RB) into group
       // buffer `buf`.  MODE 0: four half-stages, the corner reads of one issued before the
       // arithmetic of the one before (two corner register sets).
-      auto sample_group = [&](int buf, const Regs &RA, const Regs &RB, bool a_live, bool b_live) {
+      auto sample_group = [&](int buf, const Regs &RA, const Regs &RB, bool a_live, bool b_live, auto after_reads) {
 #ifdef KGDET_ABL_NOSAMPLE
         constexpr bool pipelined = false;
 #else
@@ -455,6 +455,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
             f32x2 sv[2][2];
             corner_reads(RA, 0, 0, V0);
             corner_reads(RA, 0, 1, V1);
+            after_reads();   // (MODE 2: the next records' loads go out BEHIND the corner loads -- vmcnt retires in order)
             corner_fma(RA, 0, V0, sv, true);
             if (a_live) split_store(buf, pair, 0, sv);
             corner_fma(RA, 0, V1, sv, true);
@@ -566,7 +567,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       // first group (buffer 0).  One stage: each wave pair samples one 8-channel half of it (both hold its record)
       if constexpr (PRODUCER) {
         if (r == 1) { if (pair < 2) sample_half(0, 0, pair, E0); }
-        else sample_group(0, E0, E1, pair < r, pair + 2 < r);
+        else sample_group(0, E0, E1, pair < r, pair + 2 < r, [] {});
       } else {   // full groups find their stages in F0, F1, F0, F1: an odd first group starts with F1
         if (r & 1) { a_issue(0, F1); a_issue(1, F0); }
         else { a_issue(0, F0); a_issue(1, F1); }
@@ -578,9 +579,13 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       auto produce = [&](int gi, int buf_next, const Regs &Sa, const Regs &Sb, Regs &Ia, Regs &Ib) {
         if (gi + 1 < n_groups) {
           const int jn = r + (gi + 1) * kGroupTaps;   // first stage of group gi + 2
-          issue(rec_base, t0, n - 1, jn + pair, Ia);
-          if constexpr (kRolePairs == 2) issue(rec_base, t0, n - 1, jn + pair + 2, Ib);
-          sample_group(buf_next, Sa, Sb, true, true);
+          if constexpr (MODE == 2 && kRolePairs == 4) {
+            sample_group(buf_next, Sa, Sb, true, true, [&] { issue(rec_base, t0, n - 1, jn + pair, Ia); });
+          } else {
+            issue(rec_base, t0, n - 1, jn + pair, Ia);
+            if constexpr (kRolePairs == 2) issue(rec_base, t0, n - 1, jn + pair + 2, Ib);
+            sample_group(buf_next, Sa, Sb, true, true, [] {});
+          }
         } else if (has_next) {
           const int n2 = min(K, s_end - (s + n)), r2 = ((n2 - 1) & 3) + 1;
           const unsigned rb2 = seg_records(c16 + 1);
