@@ -115,6 +115,33 @@ def test_forward_v2_mask_bias(case, prec, tol):
     _close(out.cpu().numpy(), ref64, tol)
 
 
+def test_large_map_forward_runs_on_split_operands():
+    """maps beyond the LDS plane (config 5's stride-8 / stride-16 levels): the default arithmetic takes the split-operand
+    kernel with gathered corners (plane_role MODE 2), not the exact-fp32 kernel -- close to it, not bit-equal, repeatable"""
+    _require_gpu()
+    from kgdet_amd import dcn
+    case = (2, 64, 40, 48, 64, 3, 1, 1, 1, 1, 1)
+    N, C, H, W, O, k, s, p, d, g, dg = case
+    x, off, w, _, _ = _make(case, seed=21)
+    tx, to, tw = (torch.from_numpy(a).cuda() for a in (x, off, w))
+    with torch.no_grad():
+        with dcn.forward_precision('split'):
+            a = dcn.deform_conv(tx, to, tw, s, p, d, g, dg)
+            a2 = dcn.deform_conv(tx, to, tw, s, p, d, g, dg)
+        with dcn.forward_precision('exact'):
+            b = dcn.deform_conv(tx, to, tw, s, p, d, g, dg)
+    assert torch.equal(a, a2)
+    assert not torch.equal(a, b), 'the split-operand path was expected for the default arithmetic'
+    _close(a.cpu().numpy(), b.double().cpu().numpy(), 2e-5)
+    # two weight groups and a modulation mask on the same path
+    case2 = (1, 64, 40, 48, 32, 3, 1, 1, 1, 2, 1)
+    x, off, w, _, mask = _make(case2, seed=22, with_mask=True)
+    out = dcn.modulated_deform_conv(*(torch.from_numpy(t).cuda() for t in (x, off, mask, w)), None, 1, 1, 1, 2, 1)
+    ref = oracle.deform_conv_forward(x.astype(np.float64), off.astype(np.float64), w.astype(np.float64), 1, 1, 1, 2, 1,
+                                     mask=mask.astype(np.float64))
+    _close(out.detach().cpu().numpy(), ref, 2e-5)
+
+
 def test_forward_deterministic_and_zero_offset_is_conv():
     _require_gpu()
     from kgdet_amd import dcn
