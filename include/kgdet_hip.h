@@ -60,9 +60,10 @@ int kgdet_stem_conv7x7_s2_fmt(const void *packed, const float *x, float *y, int6
                               int32_t operand_format, void *stream);
 /* forward and grad_input images of one weight in one launch (O and C multiples of 16) */
 int kgdet_conv_pack_both(const float *w, int32_t O, int32_t C, int32_t taps, void *packed, void *packed_t, void *stream);
-/* Both images of n weights in ONE launch (training re-packs every weight every step).  desc_dev: device table of n x 5
- * int64 {weight ptr, image ptr, transposed-image ptr, (O << 32) | C, (taps << 32) | first block}, first block = running sum
- * of kgdet_conv_pack_blocks(O, C, taps) over the preceding entries; total_blocks = the sum over all entries. */
+/* Both images of n weights in ONE launch (training re-packs every weight every step).  desc_dev: device table of n x 6
+ * int64 {weight ptr, image ptr, transposed-image ptr, (O << 32) | C, (taps << 32) | first block, scale ptr or 0}, first
+ * block = running sum of kgdet_conv_pack_blocks(O, C, taps) over the preceding entries; total_blocks = the sum over all
+ * entries.  scale: float [O]; the images are those of w[o] * scale[o] (a frozen-statistics BatchNorm folded into the weight). */
 int64_t kgdet_conv_pack_blocks(int32_t O, int32_t C, int32_t taps);
 int kgdet_conv_pack_multi(const int64_t *desc_dev, int32_t n, int64_t total_blocks, void *stream);
 size_t kgdet_conv_apply_workspace_bytes(int64_t B, int32_t M, int32_t K, int32_t H, int32_t W, int32_t taps,
@@ -111,6 +112,17 @@ int kgdet_bn_act_backward(const float *grad_y, const float *x, const float *y, c
                           const float *mean, const float *var, float eps, int32_t has_residual, int32_t relu,
                           float *grad_x, float *grad_residual, float *partial, float *sums, int64_t N, int32_t C,
                           int64_t HW, void *stream);
+/* Frozen-statistics BatchNorm folded into the convolution in front of it (mmdet resnet.py:518-525 norm_eval; replaces the
+ * separate BatchNorm pass of resnet.py:240-262): the forward is kgdet_conv_apply_epilogue* with the image of w * s and bias t.
+ * Backward: g = grad_z * [z > 0] (relu; without relu only the channel sums are formed and g is not written) + per-workgroup
+ * partial channel sums [C][P], P = kgdet_bn_act_partials(N, C, HW); then per convolution kgdet_bn_fold_finish:
+ * grad_beta = sum of partials, grad_gamma = (<w[o], G[o]> - mean * grad_beta) / sqrt(var + eps) with G the weight gradient
+ * of conv(x, .) against g, and G scaled by s in place (= grad_w).  Deterministic. */
+int kgdet_bn_fold_backward(const float *grad_z, const float *z, int32_t relu, float *g, float *partial, int64_t N, int32_t C,
+                           int64_t HW, void *stream);
+int kgdet_bn_fold_finish(const float *partial, int32_t P, const float *w, float *G /*nullable*/, const float *s,
+                         const float *mean, const float *var, float eps, float *grad_beta /*nullable*/,
+                         float *grad_gamma /*nullable*/, int32_t O, int32_t CK, void *stream);
 /* The frozen stem: y = maxpool3x3/s2/p1(relu(batch_norm_eval(x))) in one pass (mmdet/models/backbones/resnet.py:487-491, 528);
  * x [N, C, H, W] -> y [N, C, (H-1)/2+1, (W-1)/2+1].  Forward only (conv1 / norm1 are frozen: frozen_stages >= 0). */
 int kgdet_bn_relu_maxpool(const float *x, const float *gamma, const float *beta, const float *mean, const float *var,

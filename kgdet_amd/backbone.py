@@ -246,6 +246,67 @@ class _ConvBNAct(torch.autograd.Function):
         return gx, gw, ggamma, gbeta, None, None, None, gres, None, None
 
 
+def _bn_fold_lib():
+    L = _bn_lib()
+    if not hasattr(L, '_kgdet_fold_ready'):
+        vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+        L.kgdet_bn_fold_backward.restype = ctypes.c_int
+        L.kgdet_bn_fold_backward.argtypes = [vp, vp, i32, vp, vp, i64, i32, i64, vp]
+        L.kgdet_bn_fold_finish.restype = ctypes.c_int
+        L.kgdet_bn_fold_finish.argtypes = [vp, i32, vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, vp]
+        L._kgdet_fold_ready = True
+    return L
+
+
+class _ConvBNActFold(torch.autograd.Function):
+    """``[relu](batch_norm_eval(conv(x, w)) [+ residual])`` with the BatchNorm FOLDED into the convolution: the step scope's
+    pack launch wrote the operand images of ``w * s`` (s = gamma / sqrt(var + eps)), so the forward is ONE kernel --
+    ``z = [relu](conv(x, w s) + t [+ r])`` in the convolution's store, t = beta - mean s -- and y = conv(x, w) is neither
+    written nor kept for the backward.  Backward: ``g = gz [z > 0]`` (one pass, which also IS the residual branch's gradient),
+    grad_x = conv_grad_input(g, w s), G = conv_grad_weight(x, g), grad_w = s G, grad_beta = sum g and
+    grad_gamma = invstd (<w[o], G[o]> - mean sum g): sum_p g[o, p] y[o, p] = <w[o], G[o]> exactly, so neither y nor a
+    non-zero gamma is needed (mmdet zero-initialises the last BatchNorm of every bottleneck).  Replaces _ConvBNAct from a
+    pair's second step on (conv1x1.fold_images); same arguments and results."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, mean, var, eps, residual, relu, skip, fold):
+        img, ctx.img_t, s, t = fold
+        z = conv1x1._apply(img, x, weight.shape[0], weight.shape[2] * weight.shape[3], 1, t, residual, relu)
+        ctx.eps, ctx.relu, ctx.has_res = eps, relu, residual is not None
+        ctx.save_for_backward(x, weight, z if relu else None, s, mean, var)
+        return (z, x) if skip else z
+
+    @staticmethod
+    def backward(ctx, gz, gskip=None):
+        from . import _lib
+        x, weight, z, s, mean, var = ctx.saved_tensors
+        gz = gz.contiguous()
+        L = _bn_fold_lib()
+        N, O = gz.shape[0], gz.shape[1]
+        HW = gz.numel() // max(N * O, 1)
+        P = _bn_partials.get((N, O, HW))
+        if P is None:
+            P = _bn_partials[(N, O, HW)] = L.kgdet_bn_act_partials(N, O, HW)
+        partial = torch.empty((O, max(P, 1)), dtype=torch.float32, device=gz.device)
+        g = torch.empty_like(gz) if ctx.relu else gz
+        st = _lib.raw_stream(gz.device.index)
+        _lib.check(L.kgdet_bn_fold_backward(_p(gz), _p(z), 1 if ctx.relu else 0, _p(g) if ctx.relu else None, _p(partial), N, O,
+                                            HW, st), 'bn_fold_backward')
+        if gskip is not None and (gskip.dtype != torch.float32 or not gskip.is_contiguous()):
+            gskip = gskip.float().contiguous()
+        gx = conv1x1.grad_input(weight, ctx.img_t, g, residual=gskip) if ctx.needs_input_grad[0] else None
+        need_w, need_g, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        gw = conv1x1.grad_weight(x, weight, g) if (need_w or need_g) else None
+        sums = torch.empty((2, O), dtype=torch.float32, device=gz.device) if (need_g or need_b or need_w) else None
+        if sums is not None:
+            _lib.check(L.kgdet_bn_fold_finish(_p(partial), max(P, 1), _p(weight), _p(gw), _p(s), _p(mean), _p(var), ctx.eps,
+                                              _p(sums[0]), _p(sums[1]) if gw is not None else None, O,
+                                              weight.numel() // O, st), 'bn_fold_finish')
+        gres = g if (ctx.has_res and ctx.needs_input_grad[7]) else None
+        return (gx, gw if need_w else None, sums[1] if need_g else None, sums[0] if need_b else None, None, None, None, gres,
+                None, None, None)
+
+
 FUSE_STEM = _os.environ.get('KGDET_FUSE_STEM', '1') == '1'   # 0 / False: conv_bn + nn.MaxPool2d (the tests compare the two)
 MERGE_CONV_BN = True    # False: two nodes (conv_split, frozen_bn_act) -- the tests compare the two
 SKIP_ALIAS = _os.environ.get('KGDET_SKIP_ALIAS', '1') == '1'   # identity-branch gradient added inside conv1's grad_input (0: A/B)
@@ -384,6 +445,14 @@ def _conv_bn(conv, bn, x, relu=False, residual=None, skip=False, raw=False):
         if conv1x1.applicable(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups):
             if (MERGE_CONV_BN and _fused_bn_ok(x, bn, residual) and x.shape[0] * conv.weight.shape[0] <= 65535
                     and (residual is None or residual.shape[1] == conv.weight.shape[0])):
+                fold = conv1x1.fold_images(conv.weight, bn) if bn.affine else None
+                if fold is not None:     # from the pair's second step on: BatchNorm folded into the convolution
+                    if skip and SKIP_ALIAS and x.requires_grad:
+                        return _ConvBNActFold.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                                    bn.eps, residual, relu, True, fold)
+                    out = _ConvBNActFold.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                                               residual, relu, False, fold)
+                    return (out, x) if skip else out
                 if skip and SKIP_ALIAS and x.requires_grad:
                     return _ConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
                                             residual, relu, True)

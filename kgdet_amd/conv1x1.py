@@ -141,31 +141,106 @@ _table = None        # (key, device descriptor tensor, total blocks)
 PACK_MULTI = _os.environ.get('KGDET_PACK_MULTI', '1') == '1'
 
 
+# ---- frozen-statistics BatchNorm folded into the convolution in front of it (kgdet_amd/backbone.py _ConvBNActFold) ------
+# A (weight, BatchNorm) pair seen inside a step scope joins `_fold_entries`; from the next scope on the scope's pack launch
+# writes the images of w * s, s = gamma / sqrt(var + eps), and the pair's s and t = beta - mean * s are refreshed before it by a
+# handful of multi-tensor torch ops over flat buffers (the parameters change every step).
+FOLD_BN = _os.environ.get('KGDET_FOLD_BN', '1') == '1'
+
+
+class _FoldEntry(object):
+    __slots__ = ('ref', 'bn', 'img', 'img_t', 's', 't', 'token', 'ptr')
+
+
+_fold_entries = {}   # id(weight) -> _FoldEntry
+_fold_flat = None    # (key, S, T, TMP, EPS, s views, t views, tmp views, gammas, betas, means, vars)
+
+
+def _fold_refresh(live):
+    """s and t of every folded pair, into flat buffers whose slices the entries hold"""
+    global _fold_flat
+    key = tuple((k, e.ptr, id(e.bn())) for k, e in live)
+    if _fold_flat is None or _fold_flat[0] != key:
+        dev = live[0][1].img.device
+        sizes = [e.ref().shape[0] for _, e in live]
+        total = sum(sizes)
+        S, T, TMP = (torch.empty(total, dtype=torch.float32, device=dev) for _ in range(3))
+        EPS = torch.cat([torch.full((n,), float(e.bn().eps), dtype=torch.float32) for n, (_, e) in zip(sizes, live)]).to(dev)
+        sv, tv, mv, off = [], [], [], 0
+        for n, (_, e) in zip(sizes, live):
+            sv.append(S[off:off + n]); tv.append(T[off:off + n]); mv.append(TMP[off:off + n])
+            e.s, e.t = sv[-1], tv[-1]
+            off += n
+        bns = [e.bn() for _, e in live]
+        _fold_flat = (key, S, T, TMP, EPS, sv, tv, mv, [b.weight for b in bns], [b.bias for b in bns],
+                      [b.running_mean for b in bns], [b.running_var for b in bns])
+    _, S, T, TMP, EPS, sv, tv, mv, gammas, betas, means, vars_ = _fold_flat
+    with torch.no_grad():
+        torch._foreach_copy_(mv, vars_)
+        TMP.add_(EPS).rsqrt_()                        # 1 / sqrt(var + eps)
+        torch._foreach_copy_(sv, gammas)
+        S.mul_(TMP)                                   # s = gamma * invstd
+        torch._foreach_copy_(tv, means)
+        T.mul_(S).neg_()
+        torch._foreach_add_(tv, betas)                # t = beta - mean * s
+
+
 def _launch_multi():
     global _table
     dead = [k for k, e in _entries.items() if e.ref() is None or e.ref().data_ptr() != e.ptr]
     for k in dead:
         del _entries[k]
-    if not _entries:
+    dead = [k for k, e in _fold_entries.items() if e.ref() is None or e.bn() is None or e.ref().data_ptr() != e.ptr]
+    for k in dead:
+        del _fold_entries[k]
+    for k in _fold_entries:            # a folded pair's plain images (its first step ran unfolded) are not needed any more
+        _entries.pop(k, None)
+    if not _entries and not _fold_entries:
         return
     live = list(_entries.items())
+    folded = list(_fold_entries.items())
+    if folded:
+        _fold_refresh(folded)
     # the rows hold raw device pointers: the key names them too (ids alone are reused by CPython once a model is freed)
-    key = tuple((k, e.ptr, e.img.data_ptr(), e.img_t.data_ptr()) for k, e in live)
+    key = (tuple((k, e.ptr, e.img.data_ptr(), e.img_t.data_ptr()) for k, e in live),
+           tuple((k, e.ptr, e.img.data_ptr(), e.img_t.data_ptr(), e.s.data_ptr()) for k, e in folded))
     L = _lib_sizes()
     if _table is None or _table[0] != key:
         rows, first = [], 0
-        for _, e in live:
+        for _, e in live + folded:
             w = e.ref()
             O, C, taps = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
-            # (bit 62 of the last word: the forward image in fp16 parts)
+            # (bit 62 of the fifth word: the forward image in fp16 parts; sixth word: per-output-channel scale or 0)
             rows.append([w.data_ptr(), e.img.data_ptr(), e.img_t.data_ptr(), (O << 32) | C,
-                         (taps << 32) | first | ((1 << 62) if getattr(e.img, 'kgdet_f16', False) else 0)])
+                         (taps << 32) | first | ((1 << 62) if getattr(e.img, 'kgdet_f16', False) else 0),
+                         e.s.data_ptr() if isinstance(e, _FoldEntry) else 0])
             first += L.kgdet_conv_pack_blocks(O, C, taps)
-        dev = live[0][1].img.device
+        dev = (live + folded)[0][1].img.device
         _table = (key, torch.tensor(rows, dtype=torch.int64).to(dev), first)   # (one upload per change of the set)
-    _lib.check(L.kgdet_conv_pack_multi(_table[1].data_ptr(), len(live), _table[2], _stream()), 'conv_pack_multi')
-    for _, e in live:
+    _lib.check(L.kgdet_conv_pack_multi(_table[1].data_ptr(), len(live) + len(folded), _table[2], _stream()), 'conv_pack_multi')
+    for _, e in live + folded:
         e.token = _token
+
+
+def fold_images(weight, bn):
+    """(forward image, grad_input image, s, t) of conv(., weight) followed by the frozen-statistics BatchNorm ``bn``, packed by
+    the current step scope's launch -- or None: outside a scope, or the pair is new (it joins the set for the next scope)"""
+    if not (FOLD_BN and PACK_MULTI and _token):
+        return None
+    e = _fold_entries.get(id(weight))
+    if e is not None and e.ref() is weight and e.ptr == weight.data_ptr() and e.bn() is bn:
+        return (e.img, e.img_t, e.s, e.t) if e.token == _token else None
+    O, C, taps = weight.shape[0], weight.shape[1], weight.shape[2] * weight.shape[3]
+    if (isinstance(weight, torch.nn.Parameter) and weight.is_contiguous() and O % 16 == 0 and C % 16 == 0 and bn.affine
+            and taps in (1, 9)):
+        e = _FoldEntry()
+        e.ref, e.bn, e.ptr, e.token = weakref.ref(weight), weakref.ref(bn), weight.data_ptr(), 0
+        e.img = _mark(torch.empty(_size('kgdet_conv_packed_bytes', O, C, taps), dtype=torch.uint8, device=weight.device),
+                      FORWARD_F16)
+        e.img_t = _mark(torch.empty(_size('kgdet_conv_packed_bytes', C, O, taps), dtype=torch.uint8, device=weight.device), False)
+        e.s = e.t = None
+        _fold_entries[id(weight)] = e
+    return None
 
 
 class step_scope(object):
@@ -177,7 +252,7 @@ class step_scope(object):
         self.prev = _token
         _generation += 1
         _token = _generation
-        if PACK_MULTI and _entries:
+        if PACK_MULTI and (_entries or _fold_entries):
             _launch_multi()
 
     def __exit__(self, *exc):

@@ -132,6 +132,79 @@ __global__ __launch_bounds__(256) void bn_partial_sum(const float *__restrict__ 
   sums[i] = s;
 }
 
+// ---- BatchNorm folded into the convolution (kgdet_amd/backbone.py _ConvBNActFold) ---------------------------------------
+// forward:  z = [relu](conv(x, w * s) + t [+ r])  in the convolution's store (csrc/conv1x1.hip), y = conv(x, w) is never formed.
+// backward: g' = g * [z > 0]  (this kernel; it also IS the residual branch's gradient), grad_x = conv_grad_input(g', w * s),
+//           G = conv_grad_weight(x, g'), grad_w = s (.) G, grad_beta = sum g',
+//           grad_gamma = invstd * (sum g' * y - mean * sum g')  with  sum_p g'[o, p] * y[o, p] = <w[o], G[o]>  (bn_fold_finish) --
+//           the identity needs neither y nor gamma != 0.
+template <bool RELU>
+__global__ __launch_bounds__(256) void relu_sum_bwd_kernel(const float *__restrict__ gz, const float *__restrict__ z,
+                                                           float *__restrict__ g, float *__restrict__ partial, int C, int HW,
+                                                           int per, int P) {
+  __shared__ float red[4];
+  const int plane = blockIdx.y, c = plane % C, n = plane / C;
+  const long long base = (long long)plane * HW;
+  const int lo = blockIdx.x * per, hi = min(HW, lo + per);
+  float s1 = 0.f;
+  if ((HW & 3) == 0) {
+    for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+      float4 v = *reinterpret_cast<const float4 *>(gz + base + i);
+      if (RELU) {
+        const float4 zv = *reinterpret_cast<const float4 *>(z + base + i);
+        v.x = zv.x > 0.f ? v.x : 0.f; v.y = zv.y > 0.f ? v.y : 0.f; v.z = zv.z > 0.f ? v.z : 0.f; v.w = zv.w > 0.f ? v.w : 0.f;
+        *reinterpret_cast<float4 *>(g + base + i) = v;
+      }
+      s1 += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+      float v = gz[base + i];
+      if (RELU) { v = z[base + i] > 0.f ? v : 0.f; g[base + i] = v; }
+      s1 += v;
+    }
+  }
+  s1 = wave_sum(s1);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s1;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(long long)c * P + n * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// one workgroup per output channel o: grad_beta[o] = sum of the P partials (slot order), dot = <w[o], G[o]> over the CK
+// elements of the row (fixed order: lane-strided partial sums, wave butterflies, the four waves in order),
+// grad_gamma[o] = invstd[o] * (dot - mean[o] * grad_beta[o]), and the row of G is scaled by s[o] in place (= grad_w).
+__global__ __launch_bounds__(256) void bn_fold_finish_kernel(const float *__restrict__ partial, int P,
+                                                             const float *__restrict__ w, float *__restrict__ G,
+                                                             const float *__restrict__ s, const float *__restrict__ mean,
+                                                             const float *__restrict__ var, float eps,
+                                                             float *__restrict__ gbeta, float *__restrict__ ggamma, int CK) {
+  __shared__ float red[2][4];
+  const int o = blockIdx.x;
+  float sb = 0.f;
+  for (int k = threadIdx.x; k < P; k += 256) sb += partial[(long long)o * P + k];
+  float dot = 0.f;
+  const float so = s[o];
+  const float *wr = w + (long long)o * CK;
+  float *gr = G ? G + (long long)o * CK : nullptr;
+  if (gr) {
+    for (int k = threadIdx.x; k < CK; k += 256) {
+      const float gv = gr[k];
+      dot += wr[k] * gv;
+      gr[k] = gv * so;
+    }
+  }
+  sb = wave_sum(sb);
+  dot = wave_sum(dot);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sb; red[1][threadIdx.x >> 6] = dot; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float b = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const float d = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    if (gbeta) gbeta[o] = b;
+    if (ggamma) ggamma[o] = (d - mean[o] * b) / sqrtf(var[o] + eps);
+  }
+}
+
 namespace {
 
 // chunks per plane: enough workgroups to fill 256 CUs several times over, at least 1024 elements each
@@ -244,5 +317,37 @@ extern "C" int kgdet_bn_act_backward(const float *grad_y, const float *x, const 
                        P);
     KGDET_CHECK_LAUNCH("bn_partial_sum");
   }
+  return KGDET_OK;
+}
+
+extern "C" int kgdet_bn_fold_backward(const float *grad_z, const float *z, int32_t relu, float *g, float *partial, int64_t N,
+                                      int32_t C, int64_t HW, void *stream) {
+  KGDET_CHECK_SHAPE(N >= 0 && C > 0 && HW >= 0 && HW < (1LL << 31), "bad sizes");
+  if (N * HW == 0) return KGDET_OK;
+  KGDET_CHECK_SHAPE(grad_z && partial && (!relu || (z && g)), "null pointer");
+  KGDET_CHECK_SHAPE(N * C <= 65535, "N*C = %lld exceeds the grid limit", (long long)(N * C));
+  const int chunks = chunks_for(N * C, HW);
+  const int per = (int)(((HW + chunks - 1) / chunks + 3) / 4 * 4);
+  const int P = (int)(N * chunks);
+  dim3 grid(chunks, (unsigned)(N * C));
+  if (relu)
+    hipLaunchKernelGGL(relu_sum_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, grad_z, z, g, partial, C, (int)HW,
+                       per, P);
+  else
+    hipLaunchKernelGGL(relu_sum_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, grad_z, z, g, partial, C,
+                       (int)HW, per, P);
+  KGDET_CHECK_LAUNCH("bn_fold_backward");
+  return KGDET_OK;
+}
+
+extern "C" int kgdet_bn_fold_finish(const float *partial, int32_t P, const float *w, float *G, const float *s,
+                                    const float *mean, const float *var, float eps, float *grad_beta, float *grad_gamma,
+                                    int32_t O, int32_t CK, void *stream) {
+  KGDET_CHECK_SHAPE(O > 0 && CK > 0 && P > 0, "bad sizes");
+  KGDET_CHECK_SHAPE(partial && w && s && mean && var, "null pointer");
+  KGDET_CHECK_SHAPE(G || !grad_gamma, "grad_gamma needs the raw weight gradient");
+  hipLaunchKernelGGL(bn_fold_finish_kernel, dim3(O), dim3(256), 0, (hipStream_t)stream, partial, P, w, G, s, mean, var, eps,
+                     grad_beta, grad_gamma, CK);
+  KGDET_CHECK_LAUNCH("bn_fold_finish");
   return KGDET_OK;
 }

@@ -191,16 +191,20 @@ __global__ __launch_bounds__(256) void conv1x1_pack(const float *__restrict__ w,
 }
 
 // Both operand images of MANY weights in one launch (training re-packs every weight every step: 60 launches of a few
-// microseconds each).  desc[i] = {w, img, img_t, (O << 32) | C, (T << 32) | first block}; block b works on descriptor
-// i with first_block[i] <= b < first_block[i + 1], one 256-item slice of each image.
+// microseconds each).  desc[i] = {w, img, img_t, (O << 32) | C, (T << 32) | first block, scale}; block b works on descriptor
+// i with first_block[i] <= b < first_block[i + 1], one 256-item slice of each image.  scale (or 0): float [O], the images
+// are those of w[o] * scale[o] -- a frozen-statistics BatchNorm behind the convolution folded into its weight
+// (kgdet_amd/backbone.py _ConvBNActFold).
+constexpr int kPackDescWords = 6;
 __global__ __launch_bounds__(256) void conv1x1_pack_multi(const long long *__restrict__ desc, int n) {
   int lo = 0, hi = n - 1;   // uniform binary search
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if ((int)(desc[mid * 5 + 4] & 0xffffffffLL) <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    if ((int)(desc[mid * kPackDescWords + 4] & 0xffffffffLL) <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
-  const long long *d = desc + lo * 5;
+  const long long *d = desc + lo * kPackDescWords;
   const float *w = reinterpret_cast<const float *>(d[0]);
+  const float *scale = reinterpret_cast<const float *>(d[5]);
   const int O = (int)(d[3] >> 32), C = (int)(d[3] & 0xffffffffLL), T = (int)((d[4] >> 32) & 0xffff);
   const bool f16_forward = (d[4] >> 62) & 1;     // forward image in fp16 parts
   const long long i = (long long)((int)blockIdx.x - (int)(d[4] & 0xffffffffLL)) * 256 + threadIdx.x;
@@ -226,11 +230,12 @@ __global__ __launch_bounds__(256) void conv1x1_pack_multi(const long long *__res
         const f32x4 u = src[q];
         r[4 * q] = u[0]; r[4 * q + 1] = u[1]; r[4 * q + 2] = u[2]; r[4 * q + 3] = u[3];
       }
+      const float sc9 = (scale && m < M) ? scale[m] : 1.0f;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = m < M ? r[j * 9 + t] : 0.0f;
+        for (int j = 0; j < 8; ++j) v[j] = m < M ? r[j * 9 + t] * sc9 : 0.0f;
         bf16x8 hi8, lo8;
         if (f16_forward) {
 #pragma unroll
@@ -257,6 +262,7 @@ __global__ __launch_bounds__(256) void conv1x1_pack_multi(const long long *__res
     for (int j = 0; j < 8; ++j) {
       const long long o = transpose ? k0 + j : m, ch = transpose ? m : k0 + j;
       v[j] = m < M ? w[(o * C + ch) * T + (transpose ? T - 1 - t : t)] : 0.0f;
+      if (scale && m < M) v[j] *= scale[o];
     }
     bf16x8 hi8, lo8;
     if (f16_forward && !transpose) {

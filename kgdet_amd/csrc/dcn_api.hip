@@ -640,7 +640,8 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
         lds = need > lds ? need : lds;
         if (grp.n == kMaxFwdGroup)
           if (int rc = flush()) return rc;
-      } else if (!(flags & KGDET_DCN_EXACT_FP32) && gather_ok(s, d)) {
+      } else if (!(flags & KGDET_DCN_EXACT_FP32) && gather_ok(s, d) &&
+                 slab_slots_ok((long long)s->N * ceil_div(d.Ho * d.Wo, kTileN) * (d.Og_pad / kTileM), d.K * (d.Cg_pad / kChunk))) {
         // map beyond the LDS plane: split operands, producers gather from a pixel-major copy of x (one launch per problem)
         if (int rc = flush()) return rc;
         const size_t tb = gather_table_bytes(s, d), ib = gather_image_bytes(s);

@@ -123,6 +123,58 @@ def test_training_backbone_uses_fused_op_and_matches_module_path():
     assert len(loose) <= 6 and all(rel[n] <= 3e-2 for n in loose), sorted(rel.items(), key=lambda kv: -kv[1])[:8]
 
 
+def test_folded_batchnorm_step_equals_the_unfolded_step():
+    """From a (convolution, BatchNorm) pair's second step inside conv1x1.step_scope on, the frozen-statistics BatchNorm is
+    folded into the convolution (backbone._ConvBNActFold: images of w * s, bias t, no BatchNorm pass, grad_gamma from
+    <w, grad_w_raw>).  Outputs and every parameter gradient of that step equal the unfolded path's -- with the last
+    BatchNorm of every bottleneck zero-initialised as mmdet does (gamma = 0: nothing may divide by it)."""
+    from kgdet_amd import backbone as bb, conv1x1
+    x = torch.randn(2, 3, 128, 160, device='cuda', generator=torch.Generator('cuda').manual_seed(3))
+
+    def run(fold):
+        conv1x1._entries.clear(); conv1x1._fold_entries.clear()
+        torch.manual_seed(0)
+        net = bb.ResNet(depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1, style='pytorch').cuda()
+        for n, m in net.named_modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.data.uniform_(0.5, 1.5)
+                m.bias.data.normal_(0, 0.1)
+                if n.endswith('bn3') and 'layer3' in n:
+                    m.weight.data.zero_()          # zero_init_residual
+        net.train()
+        opt = torch.optim.SGD(net.parameters(), lr=1e-3)
+        conv1x1.FOLD_BN = fold
+        try:
+            for step in range(3):
+                opt.zero_grad()
+                with conv1x1.step_scope():
+                    outs = net(x)
+                sum(o.square().mean() for o in outs).backward()
+                if step == 2:
+                    return ([o.detach().clone() for o in outs],
+                            {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None},
+                            len(conv1x1._fold_entries))
+                opt.step()
+        finally:
+            conv1x1.FOLD_BN = True
+            conv1x1._entries.clear(); conv1x1._fold_entries.clear()
+
+    outs, grads, n_folded = run(True)
+    outs_ref, grads_ref, n_ref = run(False)
+    assert n_folded >= 30 and n_ref == 0, (n_folded, n_ref)
+    for a, b in zip(outs, outs_ref):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+    assert grads.keys() == grads_ref.keys() and len(grads) > 100
+    rel = {n: (grads[n] - grads_ref[n]).abs().max().item() / (grads_ref[n].abs().max().item() + 1e-12) for n in grads}
+    # (a ReLU input within rounding of zero may flip between the two roundings of BatchNorm: see the test above)
+    loose = [n for n in rel if rel[n] > 1e-3]
+    assert len(loose) <= 6 and all(rel[n] <= 3e-2 for n in loose), sorted(rel.items(), key=lambda kv: -kv[1])[:8]
+    zero_gamma = [n for n in grads if n.endswith('bn3.weight') and 'layer3' in n]
+    assert zero_gamma and all(rel[n] <= 1e-3 and grads_ref[n].abs().max().item() > 0 for n in zero_gamma)
+
+
 @pytest.mark.parametrize('size', [(96, 128), (97, 131), (800, 1344), (30, 33)])
 @pytest.mark.parametrize('grad_mode', [True, False])
 def test_fused_stem_matches_module_path(size, grad_mode):

@@ -587,11 +587,18 @@ def test_full_size_training_step_matches_float64(mode, golden_dir):
     model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda()
     model.train()
     batch = synthetic.make_batch(2, 'cuda', seed=0)
+    from kgdet_amd import conv1x1
+    conv1x1._entries.clear(); conv1x1._fold_entries.clear()
     with dcn.arithmetic(mode):
-        losses = model(batch['img'], batch['img_meta'], return_loss=True, gt_bboxes=batch['gt_bboxes'],
-                       gt_labels=batch['gt_labels'], gt_keypoints=batch['gt_keypoints'])
-        sum(sum(v) for v in losses.values()).backward()
+        # twice, same parameters: from a (convolution, BatchNorm) pair's second step on the BatchNorm is folded into the
+        # convolution (backbone._ConvBNActFold) -- the second pass is the one compared
+        for rep in range(2):
+            model.zero_grad()
+            losses = model(batch['img'], batch['img_meta'], return_loss=True, gt_bboxes=batch['gt_bboxes'],
+                           gt_labels=batch['gt_labels'], gt_keypoints=batch['gt_keypoints'])
+            sum(sum(v) for v in losses.values()).backward()
     torch.cuda.synchronize()
+    assert (len(conv1x1._fold_entries) >= 30) == (mode == 'split'), len(conv1x1._fold_entries)
     for k, v in losses.items():
         got, want = sum(float(t) for t in v), float(G['loss:' + k])
         assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (k, got, want)
