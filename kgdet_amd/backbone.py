@@ -468,6 +468,12 @@ def _conv_bn(conv, bn, x, relu=False, residual=None, skip=False, raw=False):
             # kernels run at 13-18 TFLOP/s backward; the quarter-size copy + the split-bf16 GEMMs are ~2x faster
             xs = _subsample2(x)
             if conv1x1.applicable(xs, conv.weight):
+                fold = (conv1x1.fold_images(conv.weight, bn)
+                        if (MERGE_CONV_BN and bn.affine and _fused_bn_ok(xs, bn, residual)
+                            and xs.shape[0] * conv.weight.shape[0] <= 65535) else None)
+                if fold is not None:
+                    return _ConvBNActFold.apply(xs, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                                                residual, relu, False, fold)
                 return frozen_bn_act(conv1x1.conv_split(xs, conv.weight), bn, residual, relu)
         return frozen_bn_act(conv(x), bn, residual, relu)
     bf16 = x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled()
