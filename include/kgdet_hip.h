@@ -118,6 +118,11 @@ int kgdet_bn_act_backward(const float *grad_y, const float *x, const float *y, c
  * partial channel sums [C][P], P = kgdet_bn_act_partials(N, C, HW); then per convolution kgdet_bn_fold_finish:
  * grad_beta = sum of partials, grad_gamma = (<w[o], G[o]> - mean * grad_beta) / sqrt(var + eps) with G the weight gradient
  * of conv(x, .) against g, and G scaled by s in place (= grad_w).  Deterministic. */
+/* Inference, bf16 channels-last: conv3 + folded bn3 + identity add + ReLU of a bottleneck (mmdet/models/backbones/resnet.py:
+ * 240-262) as ONE kernel: out[m][n] = [relu](bf16(sum_k x[m][k] weight[n][k]) + bias[n] + residual[m][n]); x [M, K], weight
+ * [N, K], residual / out [M, N] bf16 (M = B*H*W), bias fp32 [N]; K % 16 == 0, K <= 384, N % 128 == 0. */
+int kgdet_conv1x1_nhwc_residual(const void *x, const void *weight, const float *bias, const void *residual, void *out,
+                                int64_t M, int32_t K, int32_t N, int32_t relu, void *stream);
 int kgdet_bn_fold_backward(const float *grad_z, const float *z, int32_t relu, float *g, float *partial, int64_t N, int32_t C,
                            int64_t HW, void *stream);
 int kgdet_bn_fold_finish(const float *partial, int32_t P, const float *w, float *G /*nullable*/, const float *s,

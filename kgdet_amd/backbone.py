@@ -363,6 +363,7 @@ def _subsample2(x):
     return x[:, :, ::2, ::2].contiguous()
 
 
+FUSED_RESIDUAL_1X1 = _os.environ.get('KGDET_INFER_FUSED_RES', '1') == '1'   # conv3 + bn3 + add + ReLU as one kernel where measured faster (0: A/B)
 GEMM_1X1 = _os.environ.get('KGDET_INFER_GEMM_1X1', '1') == '1'     # 0: every inference convolution through MIOpen (A/B)
 _gemm_choice = {}       # (Cin, Cout, B, H, W, residual?, relu) -> True: hipBLASLt GEMM, False: MIOpen convolution
 
@@ -396,6 +397,21 @@ def _conv1x1_as_gemm(conv, hit, x, residual, relu):
             y2 = torch.addmm(bias16, x2, w2.t())
         return y2.view(B, H, W, cout).permute(0, 3, 1, 2)
 
+    def fused():
+        # conv3 + bn3 + identity + ReLU as ONE kernel (csrc/conv_nhwc.hip): x, the residual and the output cross the fabric once
+        from . import _lib
+        y = torch.empty_like(residual)
+        _lib.check(_lib.lib().kgdet_conv1x1_nhwc_residual(
+            _lib.ptr(x), _lib.ptr(hit[1]), _lib.ptr(hit[2]), _lib.ptr(residual), _lib.ptr(y), ctypes.c_int64(B * H * W),
+            ctypes.c_int32(cin), ctypes.c_int32(cout), ctypes.c_int32(1 if relu else 0), _lib.current_stream()),
+            'conv1x1_nhwc_residual')
+        return y
+
+    fused_ok = (residual is not None and cin % 16 == 0 and cin <= 384 and cout % 128 == 0
+                and x.is_contiguous(memory_format=torch.channels_last) and residual.is_contiguous(memory_format=torch.channels_last)
+                and residual.shape == (B, cout, H, W) and hit[1].is_contiguous(memory_format=torch.channels_last))
+    if choice == 'fused':
+        return fused()
     if choice is None:
         def conv_path():
             y = F.conv2d(x, hit[1], None, conv.stride, conv.padding, conv.dilation, conv.groups)
@@ -411,8 +427,15 @@ def _conv1x1_as_gemm(conv, hit, x, residual, relu):
             e1.record()
             e1.synchronize()
             return e0.elapsed_time(e1)
-        choice = timed(gemm) < 0.95 * timed(conv_path)
+        t_conv, t_gemm = timed(conv_path), timed(gemm)
+        t_fused = timed(fused) if (fused_ok and FUSED_RESIDUAL_1X1) else float('inf')
+        if t_fused < 0.95 * min(t_conv, t_gemm):
+            choice = 'fused'
+        else:
+            choice = t_gemm < 0.95 * t_conv
         _gemm_choice[key] = choice
+        if choice == 'fused':
+            return fused()
         if not choice:
             return None
     return gemm()
