@@ -25,43 +25,46 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 }  // namespace
 
-// LDS: [W tile: K / 8 x 128 n x 8 k bf16][per wave: staging of a 32-pixel x 128-channel bf16 tile, rows padded to 272 bytes]
-constexpr int kStageRow = 272;                    // 256 bytes of channels + 16: 8-byte column accesses of 32 rows spread over the banks
-constexpr int kStageBytes = 32 * kStageRow;       // 8704 per wave
+// LDS: [W tile: K / 8 x 128 n x 8 k bf16][per wave: staging of a 32-pixel x 64-channel bf16 half tile, rows padded to 144 bytes]
+// [128 bias values]
+constexpr int kStageRow = 144;                    // 128 bytes of channels + 16: 8-byte column accesses of 32 rows spread over the banks
+constexpr int kStageBytes = 32 * kStageRow;       // 4608 per wave
 
-template <bool RELU>
-__global__ __launch_bounds__(256, 3) void conv1x1_nhwc_res(const __bf16 *__restrict__ A, const __bf16 *__restrict__ Wt,
-                                                           const float *__restrict__ bias, const __bf16 *__restrict__ R,
-                                                           __bf16 *__restrict__ D, long long M, int K, int N, int n_ctiles,
-                                                           long long n_rtiles) {
+template <bool RELU, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 2) void conv1x1_nhwc_res(
+    const __bf16 *__restrict__ A, const __bf16 *__restrict__ Wt, const float *__restrict__ bias, const __bf16 *__restrict__ R,
+    __bf16 *__restrict__ D, long long M, int K, int N, int n_ctiles, long long n_rtiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int THREADS = 64 * WAVES, ROWS = 32 * WAVES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ct = blockIdx.x % n_ctiles;                   // column tiles of one pixel tile sit in neighbouring workgroups
   const long long first = blockIdx.x / n_ctiles, step = gridDim.x / n_ctiles;
   const int n0 = ct * 128;
   const int k8s = K >> 3;
-  for (int i = tid; i < k8s * 128; i += 256) {            // weight tile -> LDS, 16-byte pieces
+  for (int i = tid; i < k8s * 128; i += THREADS) {        // weight tile -> LDS, 16-byte pieces
     const int n = i & 127, k8 = i >> 7;
     *reinterpret_cast<bf16x8 *>(smem + (size_t)i * 16) = *reinterpret_cast<const bf16x8 *>(Wt + (long long)(n0 + n) * K + k8 * 8);
   }
-  float *lbias = reinterpret_cast<float *>(smem + (size_t)K * 128 * 2 + 4 * kStageBytes);   // the tile's 128 bias values
+  float *lbias = reinterpret_cast<float *>(smem + (size_t)K * 128 * 2 + WAVES * kStageBytes);   // the tile's 128 bias values
   if (tid < 128) lbias[tid] = bias[n0 + tid];
   __syncthreads();
   unsigned char *stage = smem + (size_t)K * 128 * 2 + wave * kStageBytes;
   const int px = lane & 31, kh = lane >> 5;
   const int ksteps = K >> 4;
-  // row-major view of the wave's tile for the global side: instruction j moves rows 4 j + (lane >> 4), 16 bytes at column
-  // piece (lane & 15): four whole 256-byte row segments per instruction
-  const int rrow = lane >> 4, rcol = (lane & 15) * 16;
+  // row-major view of a half tile (32 pixels x 64 channels) for the global side: instruction j moves rows 8 j + (lane >> 3),
+  // 16 bytes at column piece (lane & 7): eight whole 128-byte row segments per instruction
+  const int rrow = lane >> 3, rcol = (lane & 7) * 16;
   for (long long rt = first; rt < n_rtiles; rt += step) {
-    const long long m0 = rt * 128 + wave * 32;
-    // residual tile -> registers (coalesced: whole row segments), issued ahead of the products
-    bf16x8 rv[8];
+    const long long m0 = rt * ROWS + wave * 32;
+    // residual tile -> registers (coalesced), issued ahead of the products
+    bf16x8 rv[2][4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const long long m = m0 + 4 * j + rrow;
-      rv[j] = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const unsigned char *>(R + (m < M ? m : M - 1) * N + n0) + rcol);
-    }
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const long long m = m0 + 8 * j + rrow;
+        rv[h][j] = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const unsigned char *>(R + (m < M ? m : M - 1) * N + n0 + h * 64) + rcol);
+      }
     f32x16 acc[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
@@ -69,43 +72,54 @@ __global__ __launch_bounds__(256, 3) void conv1x1_nhwc_res(const __bf16 *__restr
       for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
     const long long mp = m0 + px < M ? m0 + px : M - 1;
     const __bf16 *arow = A + mp * K + kh * 8;
-    for (int ks = 0; ks < ksteps; ++ks) {
-      const bf16x8 b = *reinterpret_cast<const bf16x8 *>(arow + ks * 16);
+    auto kstep = [&](int ks, const bf16x8 b) {
       const unsigned char *wl = smem + ((size_t)(ks * 2 + kh) * 128 + px) * 16;
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) {
         const bf16x8 a = *reinterpret_cast<const bf16x8 *>(wl + nb * 32 * 16);
         acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nb], 0, 0, 0);
       }
+    };
+    int ks = 0;
+    for (; ks + 4 <= ksteps; ks += 4) {          // four activation fragments in flight
+      bf16x8 b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) b[u] = *reinterpret_cast<const bf16x8 *>(arow + (ks + u) * 16);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) kstep(ks + u, b[u]);
     }
-    // residual through the staging tile into the accumulator layout (a lane: ONE pixel, runs of four channels)
+    for (; ks < ksteps; ++ks) kstep(ks, *reinterpret_cast<const bf16x8 *>(arow + ks * 16));
 #pragma unroll
-    for (int j = 0; j < 8; ++j) *reinterpret_cast<bf16x8 *>(stage + (4 * j + rrow) * kStageRow + rcol) = rv[j];
-    // (a wave's LDS accesses are ordered: no barrier inside the wave-private tile)
+    for (int h = 0; h < 2; ++h) {
+      // residual half through the staging tile into the accumulator layout (a lane: ONE pixel, runs of four channels)
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<bf16x8 *>(stage + (8 * j + rrow) * kStageRow + rcol) = rv[h][j];
+      // (a wave's LDS accesses are ordered: no barrier inside the wave-private tile)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int c = nb * 32 + 8 * g + 4 * kh;
-        unsigned char *cell = stage + px * kStageRow + c * 2;
-        const bf16x4 res = *reinterpret_cast<const bf16x4 *>(cell);
-        const f32x4 bv = *reinterpret_cast<const f32x4 *>(lbias + c);   // (from LDS: global loads of all 16 pieces get hoisted and spill)
-        bf16x4 o;
+      for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          // (the convolution's result rounded to bf16 first, as the two-kernel route stores it)
-          float f = (float)(__bf16)acc[nb][4 * g + e] + bv[e] + (float)res[e];
-          if (RELU) f = fmaxf(f, 0.0f);
-          o[e] = (__bf16)f;
+        for (int g = 0; g < 4; ++g) {
+          const int c = nh * 32 + 8 * g + 4 * kh;           // channel inside the half
+          unsigned char *cell = stage + px * kStageRow + c * 2;
+          const bf16x4 res = *reinterpret_cast<const bf16x4 *>(cell);
+          const f32x4 bv = *reinterpret_cast<const f32x4 *>(lbias + h * 64 + c);   // (from LDS: global loads of all pieces get hoisted and spill)
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // (the convolution's result rounded to bf16 first, as the two-kernel route stores it)
+            float f = (float)(__bf16)acc[2 * h + nh][4 * g + e] + bv[e] + (float)res[e];
+            if (RELU) f = fmaxf(f, 0.0f);
+            o[e] = (__bf16)f;
+          }
+          *reinterpret_cast<bf16x4 *>(cell) = o;
         }
-        *reinterpret_cast<bf16x4 *>(cell) = o;
-      }
-    // results back out, row-major, coalesced
+      // results back out, row-major, coalesced
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const long long m = m0 + 4 * j + rrow;
-      const bf16x8 v = *reinterpret_cast<const bf16x8 *>(stage + (4 * j + rrow) * kStageRow + rcol);
-      if (m < M) *reinterpret_cast<bf16x8 *>(reinterpret_cast<unsigned char *>(D + m * N + n0) + rcol) = v;
+      for (int j = 0; j < 4; ++j) {
+        const long long m = m0 + 8 * j + rrow;
+        const bf16x8 v = *reinterpret_cast<const bf16x8 *>(stage + (8 * j + rrow) * kStageRow + rcol);
+        if (m < M) *reinterpret_cast<bf16x8 *>(reinterpret_cast<unsigned char *>(D + m * N + n0 + h * 64) + rcol) = v;
+      }
     }
   }
 }
@@ -116,28 +130,30 @@ using namespace kgdet;
 
 extern "C" int kgdet_conv1x1_nhwc_residual(const void *x, const void *weight, const float *bias, const void *residual,
                                            void *out, int64_t M, int32_t K, int32_t N, int32_t relu, void *stream) {
-  KGDET_CHECK_SHAPE(M >= 0 && K > 0 && N > 0 && K % 16 == 0 && N % 128 == 0 && K <= 384, "bad sizes (K %% 16, N %% 128, K <= 384)");
+  KGDET_CHECK_SHAPE(M >= 0 && K > 0 && N > 0 && K % 16 == 0 && N % 128 == 0 && K <= 448, "bad sizes (K %% 16, N %% 128, K <= 448)");
   if (M == 0) return KGDET_OK;
   KGDET_CHECK_SHAPE(x && weight && bias && residual && out, "null pointer");
   const int n_ctiles = N / 128;
-  const long long n_rtiles = (M + 127) / 128;
-  const size_t lds = (size_t)K * 128 * 2 + 4 * kStageBytes + 512;
+  const int waves = K >= 256 ? 8 : 4;                       // a 64 KB+ weight tile is shared by eight waves
+  const long long n_rtiles = (M + 32 * waves - 1) / (32 * waves);
+  const size_t lds = (size_t)K * 128 * 2 + (size_t)waves * kStageBytes + 512;
   long long groups = n_rtiles < 768 ? n_rtiles : 768;      // persistent: a few workgroups per CU
   static thread_local bool attr_set = false;
   if (!attr_set) {
-    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv1x1_nhwc_res<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv1x1_nhwc_res<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv1x1_nhwc_res<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv1x1_nhwc_res<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv1x1_nhwc_res<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv1x1_nhwc_res<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   const dim3 grid((unsigned)(groups * n_ctiles));
-  if (relu)
-    hipLaunchKernelGGL(conv1x1_nhwc_res<true>, grid, dim3(256), lds, (hipStream_t)stream, (const __bf16 *)x,
-                       (const __bf16 *)weight, bias, (const __bf16 *)residual, (__bf16 *)out, (long long)M, K, N, n_ctiles,
-                       n_rtiles);
-  else
-    hipLaunchKernelGGL(conv1x1_nhwc_res<false>, grid, dim3(256), lds, (hipStream_t)stream, (const __bf16 *)x,
-                       (const __bf16 *)weight, bias, (const __bf16 *)residual, (__bf16 *)out, (long long)M, K, N, n_ctiles,
-                       n_rtiles);
+#define KGDET_NHWC_LAUNCH(RELU_, W_)                                                                                        \
+  hipLaunchKernelGGL((conv1x1_nhwc_res<RELU_, W_>), grid, dim3(64 * W_), lds, (hipStream_t)stream, (const __bf16 *)x,        \
+                     (const __bf16 *)weight, bias, (const __bf16 *)residual, (__bf16 *)out, (long long)M, K, N, n_ctiles,    \
+                     n_rtiles)
+  if (waves == 8) { if (relu) KGDET_NHWC_LAUNCH(true, 8); else KGDET_NHWC_LAUNCH(false, 8); }
+  else { if (relu) KGDET_NHWC_LAUNCH(true, 4); else KGDET_NHWC_LAUNCH(false, 4); }
+#undef KGDET_NHWC_LAUNCH
   KGDET_CHECK_LAUNCH("conv1x1_nhwc_residual");
   return KGDET_OK;
 }

@@ -123,6 +123,31 @@ def test_training_backbone_uses_fused_op_and_matches_module_path():
     assert len(loose) <= 6 and all(rel[n] <= 3e-2 for n in loose), sorted(rel.items(), key=lambda kv: -kv[1])[:8]
 
 
+@pytest.mark.parametrize('B,K,H,W,relu', [(2, 64, 50, 84, True), (1, 128, 25, 42, True), (3, 256, 13, 21, False), (1, 48, 7, 9, True)])
+def test_fused_residual_conv_nhwc_matches_conv_plus_epilogue(B, K, H, W, relu):
+    """csrc/conv_nhwc.hip: conv3 + folded bn3 + identity add + ReLU of a bottleneck (resnet.py:240-262) in one bf16
+    channels-last kernel, against F.conv2d + the separate epilogue pass it replaces (same rounding sequence: the product is
+    rounded to bf16 before bias and residual are added) -- ragged pixel counts, 4- and 8-wave variants, K not a multiple of 64"""
+    import ctypes
+    from kgdet_amd import backbone, _lib
+    N = 4 * K if K % 32 == 0 else 128
+    g = torch.Generator('cuda').manual_seed(B * 1000 + K)
+    x = torch.randn(B, K, H, W, device='cuda', generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    r = torch.randn(B, N, H, W, device='cuda', generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(N, K, 1, 1, device='cuda', generator=g) * 0.1).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(N, device='cuda', generator=g)
+    out = torch.full_like(r, float('nan'))
+    _lib.check(_lib.lib().kgdet_conv1x1_nhwc_residual(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(r), _lib.ptr(out),
+                                                      ctypes.c_int64(B * H * W), ctypes.c_int32(K), ctypes.c_int32(N),
+                                                      ctypes.c_int32(1 if relu else 0), _lib.current_stream()), 'nhwc')
+    ref = torch.nn.functional.conv2d(x.float(), w.float()).to(torch.bfloat16).float() + b.view(1, -1, 1, 1) + r.float()
+    ref = (torch.relu(ref) if relu else ref).to(torch.bfloat16)
+    assert out.is_contiguous(memory_format=torch.channels_last) and not torch.isnan(out.float()).any()
+    # one bf16 ulp where the fp32 sums of the two routes round differently
+    assert float((out.float() - ref.float()).abs().max()) <= 2 ** -7 * float(ref.float().abs().max())
+    assert float((out.float() - ref.float()).abs().mean()) <= 1e-3 * float(ref.float().abs().mean())
+
+
 def test_folded_batchnorm_step_equals_the_unfolded_step():
     """From a (convolution, BatchNorm) pair's second step inside conv1x1.step_scope on, the frozen-statistics BatchNorm is
     folded into the convolution (backbone._ConvBNActFold: images of w * s, bias t, no BatchNorm pass, grad_gamma from
