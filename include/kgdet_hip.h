@@ -128,6 +128,16 @@ int kgdet_bn_fold_backward(const float *grad_z, const float *z, int32_t relu, fl
 int kgdet_bn_fold_finish(const float *partial, int32_t P, const float *w, float *G /*nullable*/, const float *s,
                          const float *mean, const float *var, float eps, float *grad_beta /*nullable*/,
                          float *grad_gamma /*nullable*/, int32_t O, int32_t CK, void *stream);
+/* kgdet_conv1x1_grad_weight / kgdet_conv3x3_grad_weight with kgdet_bn_fold_finish as the epilogue of their split sum (one
+ * launch less per convolution): grad_w = s * G, grad_beta, grad_gamma as above; bn_partial / P from kgdet_bn_fold_backward. */
+int kgdet_conv1x1_grad_weight_fold(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O, int32_t C,
+                                   int64_t HW, void *workspace, size_t workspace_bytes, const float *w, const float *s,
+                                   const float *mean, const float *var, float eps, const float *bn_partial, int32_t P,
+                                   float *grad_beta /*nullable*/, float *grad_gamma /*nullable*/, void *stream);
+int kgdet_conv3x3_grad_weight_fold(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O, int32_t C,
+                                   int32_t H, int32_t W, void *workspace, size_t workspace_bytes, const float *w,
+                                   const float *s, const float *mean, const float *var, float eps, const float *bn_partial,
+                                   int32_t P, float *grad_beta /*nullable*/, float *grad_gamma /*nullable*/, void *stream);
 /* The frozen stem: y = maxpool3x3/s2/p1(relu(batch_norm_eval(x))) in one pass (mmdet/models/backbones/resnet.py:487-491, 528);
  * x [N, C, H, W] -> y [N, C, (H-1)/2+1, (W-1)/2+1].  Forward only (conv1 / norm1 are frozen: frozen_stages >= 0). */
 int kgdet_bn_relu_maxpool(const float *x, const float *gamma, const float *beta, const float *mean, const float *var,

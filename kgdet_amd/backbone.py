@@ -296,9 +296,15 @@ class _ConvBNActFold(torch.autograd.Function):
             gskip = gskip.float().contiguous()
         gx = conv1x1.grad_input(weight, ctx.img_t, g, residual=gskip) if ctx.needs_input_grad[0] else None
         need_w, need_g, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
-        gw = conv1x1.grad_weight(x, weight, g) if (need_w or need_g) else None
-        sums = torch.empty((2, O), dtype=torch.float32, device=gz.device) if (need_g or need_b or need_w) else None
-        if sums is not None:
+        gw = sums = None
+        if need_w or need_g:      # the split sum of the weight gradient, grad_w = s G and the BatchNorm sums in one launch
+            both = conv1x1.grad_weight_fold(x, weight, g, s, mean, var, ctx.eps, partial, max(P, 1))
+            if both is not None:
+                gw, sums = both
+            else:
+                gw = conv1x1.grad_weight(x, weight, g)
+        if sums is None and (need_g or need_b or need_w):
+            sums = torch.empty((2, O), dtype=torch.float32, device=gz.device)
             _lib.check(L.kgdet_bn_fold_finish(_p(partial), max(P, 1), _p(weight), _p(gw), _p(s), _p(mean), _p(var), ctx.eps,
                                               _p(sums[0]), _p(sums[1]) if gw is not None else None, O,
                                               weight.numel() // O, st), 'bn_fold_finish')

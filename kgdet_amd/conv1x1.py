@@ -57,6 +57,10 @@ def _lib_sizes():
                  [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
                 ('kgdet_conv3x3_s2_grad_input', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i32, i32, vp]),
                 ('kgdet_conv1x1_grad_weight', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i64, vp, sz, vp]),
+                ('kgdet_conv1x1_grad_weight_fold', ctypes.c_int,
+                 [vp, vp, vp, i64, i32, i32, i64, vp, sz, vp, vp, vp, vp, ctypes.c_float, vp, i32, vp, vp, vp]),
+                ('kgdet_conv3x3_grad_weight_fold', ctypes.c_int,
+                 [vp, vp, vp, i64, i32, i32, i32, i32, vp, sz, vp, vp, vp, vp, ctypes.c_float, vp, i32, vp, vp, vp]),
                 ('kgdet_conv3x3_grad_weight', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i32, i32, vp, sz, vp])):
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
@@ -310,6 +314,36 @@ def grad_weight(x, weight, gy):
     _lib.check(L.kgdet_conv1x1_grad_weight(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), B, O, C, HW,
                                            ws.data_ptr(), nbytes, _stream()), 'conv1x1_grad_weight')
     return gw
+
+
+def grad_weight_fold(x, weight, gy, s, mean, var, eps, bn_partial, P, want_gamma=True):
+    """grad_weight of a convolution with a folded BatchNorm (backbone._ConvBNActFold): (s * G, sums [2, O] = grad_beta,
+    grad_gamma) from ONE launch behind the split kernel -- or None where grad_weight would take another route"""
+    O, C, k = weight.shape[0], weight.shape[1], weight.shape[2]
+    L = _lib_sizes()
+    if k == 3 and SPLIT_GRAD_WEIGHT_3X3 and C % 128 == 0 and (x.shape[3] % 4 == 0 or PAD_GRAD_WEIGHT_3X3):
+        B, H, W = x.shape[0], x.shape[2], x.shape[3]
+        nbytes = _size('kgdet_conv3x3_grad_weight_workspace_bytes', B, O, C, H, W)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        gw = torch.empty_like(weight)
+        sums = torch.empty((2, O), dtype=torch.float32, device=x.device)
+        _lib.check(L.kgdet_conv3x3_grad_weight_fold(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), B, O, C, H, W, ws.data_ptr(), nbytes,
+                                                    weight.data_ptr(), s.data_ptr(), mean.data_ptr(), var.data_ptr(), eps,
+                                                    bn_partial.data_ptr(), P, sums[0].data_ptr(),
+                                                    sums[1].data_ptr() if want_gamma else None, _stream()), 'conv3x3_grad_weight_fold')
+        return gw, sums
+    if k == 1 and ((x.shape[2] * x.shape[3]) % 4 == 0 or PAD_GRAD_WEIGHT_3X3):
+        B, HW = x.shape[0], x.shape[2] * x.shape[3]
+        nbytes = _size('kgdet_conv1x1_grad_weight_workspace_bytes', B, O, C, HW)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        gw = torch.empty_like(weight)
+        sums = torch.empty((2, O), dtype=torch.float32, device=x.device)
+        _lib.check(L.kgdet_conv1x1_grad_weight_fold(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), B, O, C, HW, ws.data_ptr(), nbytes,
+                                                    weight.data_ptr(), s.data_ptr(), mean.data_ptr(), var.data_ptr(), eps,
+                                                    bn_partial.data_ptr(), P, sums[0].data_ptr(),
+                                                    sums[1].data_ptr() if want_gamma else None, _stream()), 'conv1x1_grad_weight_fold')
+        return gw, sums
+    return None
 
 
 def grad_input(weight, img_t, gy, residual=None):

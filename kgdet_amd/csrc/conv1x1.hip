@@ -1074,6 +1074,66 @@ __global__ __launch_bounds__(256) void conv1x1_sum(const float *__restrict__ par
   }
 }
 
+// the same sum with the convolution's epilogue in its store: out = [relu](sum + bias[channel] [+ residual]), channel =
+// (i / HW) % M (a K-split problem is small; the separate epilogue pass it used to take cost a launch, ~5 us of a step each)
+__global__ __launch_bounds__(256) void conv1x1_sum_epilogue(const float *__restrict__ parts, float *__restrict__ out,
+                                                            long long n, long long stride, int count,
+                                                            const float *__restrict__ bias, const float *__restrict__ residual,
+                                                            int relu, int M, long long HW) {
+  for (long long i = (blockIdx.x * 256LL + threadIdx.x) * 2; i < n; i += gridDim.x * 512LL) {   // (HW is even: both in one plane)
+    f32x2 s = {0.0f, 0.0f};
+    for (int k = 0; k < count; ++k) s += *reinterpret_cast<const f32x2 *>(parts + (long long)k * stride + i);
+    if (bias) {
+      const float b = bias[(i / HW) % M];
+      s[0] += b; s[1] += b;
+    }
+    if (residual) s += *reinterpret_cast<const f32x2 *>(residual + i);
+    if (relu) { s[0] = fmaxf(s[0], 0.0f); s[1] = fmaxf(s[1], 0.0f); }
+    *reinterpret_cast<f32x2 *>(out + i) = s;
+  }
+}
+
+// Weight gradient of a convolution whose BatchNorm is folded into it (kgdet_amd/backbone.py _ConvBNActFold), the split sum and
+// the BatchNorm parameter gradients in ONE pass: workgroup o adds the row's partials G[o][.] (slot order), forms
+// dot = <w[o], G[o]>, stores grad_w[o] = s[o] * G[o], and adds the row's BatchNorm partials: grad_beta[o] = sum g,
+// grad_gamma[o] = (dot - mean[o] * grad_beta[o]) / sqrt(var[o] + eps)   (csrc/bn_act.hip bn_fold_finish_kernel as the sum's
+// epilogue: a launch less per convolution and step).  T9: the partials' columns are (tap, channel), grad_w's (channel, tap).
+struct ConvFoldArgs {
+  const float *w, *s, *mean, *var, *bn_partial;
+  float *grad_beta, *grad_gamma;
+  float eps;
+  int P;
+};
+template <bool T9>
+__global__ __launch_bounds__(256) void conv_wsum_fold(const float *__restrict__ parts, float *__restrict__ out, int C,
+                                                      long long stride, int count, const ConvFoldArgs f) {
+  __shared__ float red[2][4];
+  const int o = blockIdx.x, CK = T9 ? 9 * C : C;
+  const float so = f.s[o];
+  const float *wr = f.w + (long long)o * CK;
+  const float *pr = parts + (long long)o * CK;
+  float *gr = out + (long long)o * CK;
+  float dot = 0.0f, sb = 0.0f;
+  for (int j = threadIdx.x; j < CK; j += 256) {
+    const int src = T9 ? (j % 9) * C + j / 9 : j;     // out column j = (channel, tap); partial column = (tap, channel)
+    float g = 0.0f;
+    for (int k = 0; k < count; ++k) g += pr[(long long)k * stride + src];
+    dot += wr[j] * g;
+    gr[j] = g * so;
+  }
+  for (int k = threadIdx.x; k < f.P; k += 256) sb += f.bn_partial[(long long)o * f.P + k];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { dot += __shfl_xor(dot, d); sb += __shfl_xor(sb, d); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sb; red[1][threadIdx.x >> 6] = dot; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float b = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const float d = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    if (f.grad_beta) f.grad_beta[o] = b;
+    if (f.grad_gamma) f.grad_gamma[o] = (d - f.mean[o] * b) / sqrtf(f.var[o] + f.eps);
+  }
+}
+
 // 3x3 grad_weight: out[o][c][t] = sum_s parts[s][o][t * C + c]  (the NT kernel's columns are (tap, channel))
 __global__ __launch_bounds__(256) void conv3x3_wsum(const float *__restrict__ parts, float *__restrict__ out, int O, int C,
                                                     int count) {
@@ -1527,11 +1587,15 @@ extern "C" int kgdet_conv_apply_epilogue_fmt(const void *packed, const float *x,
   KGDET_CHECK_LAUNCH("conv_nn");
   if (ks > 1) {
     const long long blocks = (part_stride / 2 + 255) / 256;
-    hipLaunchKernelGGL(conv1x1_sum, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, (hipStream_t)stream,
-                       (const float *)workspace, y, part_stride, part_stride, ks);
+    if ((bias || residual || relu) && HW % 2 == 0)   // the epilogue in the sum's store
+      hipLaunchKernelGGL(conv1x1_sum_epilogue, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0,
+                         (hipStream_t)stream, (const float *)workspace, y, part_stride, part_stride, ks, bias, residual, relu,
+                         M, (long long)HW);
+    else
+      hipLaunchKernelGGL(conv1x1_sum, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, (hipStream_t)stream,
+                         (const float *)workspace, y, part_stride, part_stride, ks);
     KGDET_CHECK_LAUNCH("conv1x1_sum");
-    if (bias || residual || relu)   // K-split problems are small: the epilogue as one extra pass
-      return kgdet_bias_act(y, bias, residual, B, M, HW, 0, relu, 0, stream);
+    if ((bias || residual || relu) && HW % 2 != 0) return kgdet_bias_act(y, bias, residual, B, M, HW, 0, relu, 0, stream);
   }
   return KGDET_OK;
 }
@@ -1626,9 +1690,9 @@ extern "C" size_t kgdet_conv1x1_grad_weight_workspace_bytes(int64_t B, int32_t O
   return bytes;
 }
 
-extern "C" int kgdet_conv1x1_grad_weight(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O,
-                                         int32_t C, int64_t HW, void *workspace, size_t workspace_bytes,
-                                         void *stream) {
+static int conv1x1_grad_weight_impl(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O, int32_t C,
+                                    int64_t HW, void *workspace, size_t workspace_bytes, void *stream,
+                                    const ConvFoldArgs *fold) {
   KGDET_CHECK_SHAPE(B > 0 && O > 0 && C > 0 && HW > 0 && HW < (1LL << 30), "bad sizes");
   KGDET_CHECK_SHAPE(grad_y && x && grad_w && workspace, "null pointer");
   KGDET_CHECK_SHAPE(workspace_bytes >= kgdet_conv1x1_grad_weight_workspace_bytes(B, O, C, HW), "workspace too small");
@@ -1661,11 +1725,41 @@ extern "C" int kgdet_conv1x1_grad_weight(const float *grad_y, const float *x, fl
                      (float *)workspace, O, C, (int)HW, (int)B, n_mt, n_nt, spi, per, 1, (int)HW, 0);
   KGDET_CHECK_LAUNCH("conv_nt8<1>");
   const long long n = (long long)O * C;
+  if (fold) {
+    hipLaunchKernelGGL(conv_wsum_fold<false>, dim3(O), dim3(256), 0, (hipStream_t)stream, (const float *)workspace, grad_w, C,
+                       n, splits, *fold);
+    KGDET_CHECK_LAUNCH("conv_wsum_fold");
+    return KGDET_OK;
+  }
   const long long blocks = (n / 2 + 255) / 256;
   hipLaunchKernelGGL(conv1x1_sum, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, (hipStream_t)stream,
                      (const float *)workspace, grad_w, n, n, splits);
   KGDET_CHECK_LAUNCH("conv1x1_sum");
   return KGDET_OK;
+}
+
+extern "C" int kgdet_conv1x1_grad_weight(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O,
+                                         int32_t C, int64_t HW, void *workspace, size_t workspace_bytes,
+                                         void *stream) {
+  return conv1x1_grad_weight_impl(grad_y, x, grad_w, B, O, C, HW, workspace, workspace_bytes, stream, nullptr);
+}
+
+static int fold_args(ConvFoldArgs &f, const float *w, const float *s, const float *mean, const float *var, float eps,
+                     const float *bn_partial, int32_t P, float *grad_beta, float *grad_gamma) {
+  KGDET_CHECK_SHAPE(w && s && mean && var && bn_partial && P > 0, "null pointer (folded BatchNorm arguments)");
+  f.w = w; f.s = s; f.mean = mean; f.var = var; f.bn_partial = bn_partial; f.grad_beta = grad_beta; f.grad_gamma = grad_gamma;
+  f.eps = eps; f.P = P;
+  return KGDET_OK;
+}
+
+extern "C" int kgdet_conv1x1_grad_weight_fold(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O,
+                                              int32_t C, int64_t HW, void *workspace, size_t workspace_bytes, const float *w,
+                                              const float *s, const float *mean, const float *var, float eps,
+                                              const float *bn_partial, int32_t P, float *grad_beta, float *grad_gamma,
+                                              void *stream) {
+  ConvFoldArgs f;
+  if (int rc = fold_args(f, w, s, mean, var, eps, bn_partial, P, grad_beta, grad_gamma)) return rc;
+  return conv1x1_grad_weight_impl(grad_y, x, grad_w, B, O, C, HW, workspace, workspace_bytes, stream, &f);
 }
 
 extern "C" size_t kgdet_conv3x3_grad_weight_workspace_bytes(int64_t B, int32_t O, int32_t C, int32_t H, int32_t W) {
@@ -1678,9 +1772,9 @@ extern "C" size_t kgdet_conv3x3_grad_weight_workspace_bytes(int64_t B, int32_t O
   return bytes;
 }
 
-extern "C" int kgdet_conv3x3_grad_weight(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O,
-                                         int32_t C, int32_t H, int32_t W, void *workspace, size_t workspace_bytes,
-                                         void *stream) {
+static int conv3x3_grad_weight_impl(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O, int32_t C,
+                                    int32_t H, int32_t W, void *workspace, size_t workspace_bytes, void *stream,
+                                    const ConvFoldArgs *fold) {
   KGDET_CHECK_SHAPE(B > 0 && O > 0 && C > 0 && H > 0 && W > 0 && (long long)H * (W + 3) < (1LL << 23), "bad sizes");
   if (C % kTN != 0) {
     set_error("conv3x3_grad_weight needs C %% 128 == 0 (C=%d)", C);
@@ -1717,9 +1811,31 @@ extern "C" int kgdet_conv3x3_grad_weight(const float *grad_y, const float *x, fl
                      (float *)workspace, O, 9 * C, HW, (int)B, n_mt, n_nt, spi, per, H, W, C);
   KGDET_CHECK_LAUNCH("conv_nt8<9>");
   const long long n = (long long)O * C * 9;
+  if (fold) {
+    hipLaunchKernelGGL(conv_wsum_fold<true>, dim3(O), dim3(256), 0, (hipStream_t)stream, (const float *)workspace, grad_w, C, n,
+                       splits, *fold);
+    KGDET_CHECK_LAUNCH("conv_wsum_fold");
+    return KGDET_OK;
+  }
   const long long blocks = (n + 255) / 256;
   hipLaunchKernelGGL(conv3x3_wsum, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream,
                      (const float *)workspace, grad_w, O, C, splits);
   KGDET_CHECK_LAUNCH("conv3x3_wsum");
   return KGDET_OK;
+}
+
+extern "C" int kgdet_conv3x3_grad_weight(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O,
+                                         int32_t C, int32_t H, int32_t W, void *workspace, size_t workspace_bytes,
+                                         void *stream) {
+  return conv3x3_grad_weight_impl(grad_y, x, grad_w, B, O, C, H, W, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int kgdet_conv3x3_grad_weight_fold(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O,
+                                              int32_t C, int32_t H, int32_t W, void *workspace, size_t workspace_bytes,
+                                              const float *w, const float *s, const float *mean, const float *var, float eps,
+                                              const float *bn_partial, int32_t P, float *grad_beta, float *grad_gamma,
+                                              void *stream) {
+  ConvFoldArgs f;
+  if (int rc = fold_args(f, w, s, mean, var, eps, bn_partial, P, grad_beta, grad_gamma)) return rc;
+  return conv3x3_grad_weight_impl(grad_y, x, grad_w, B, O, C, H, W, workspace, workspace_bytes, stream, &f);
 }
