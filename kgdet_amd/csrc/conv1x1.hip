@@ -1114,10 +1114,16 @@ __global__ __launch_bounds__(256) void conv_wsum_fold(const float *__restrict__ 
   const float *pr = parts + (long long)o * CK;
   float *gr = out + (long long)o * CK;
   float dot = 0.0f, sb = 0.0f;
-  for (int j = threadIdx.x; j < CK; j += 256) {
-    const int src = T9 ? (j % 9) * C + j / 9 : j;     // out column j = (channel, tap); partial column = (tap, channel)
+  for (int q = threadIdx.x; q < CK; q += 256) {          // q: the partials' column (coalesced reads)
+    const int j = T9 ? (q % C) * 9 + q / C : q;          // partial column (tap, channel) -> grad_w column (channel, tap)
     float g = 0.0f;
-    for (int k = 0; k < count; ++k) g += pr[(long long)k * stride + src];
+    int k = 0;
+    for (; k + 4 <= count; k += 4) {                     // four loads in flight, added in slot order
+      const float v0 = pr[(long long)k * stride + q], v1 = pr[(long long)(k + 1) * stride + q];
+      const float v2 = pr[(long long)(k + 2) * stride + q], v3 = pr[(long long)(k + 3) * stride + q];
+      g = (((g + v0) + v1) + v2) + v3;
+    }
+    for (; k < count; ++k) g += pr[(long long)k * stride + q];
     dot += wr[j] * g;
     gr[j] = g * so;
   }
