@@ -133,12 +133,59 @@ def _worker_body(rank, world, port, q):
         red2.finish()
         ok &= bool(torch.equal(wt.grad, torch.arange(24.).reshape(6, 4).t() * (sum(range(1, world + 1)) / world)))
 
-    # the optimizer hook end to end: both ranks stay in sync
+    # sentinel mode: with begin_step() after the gradients were set to None, ONE hook per bucket is left after a full-hook
+    # step; results stay the averaged gradients, launches stay in bucket order and inside backward; a step whose
+    # gradients are not None at begin_step, or without begin_step, launches nothing early; a missing gradient delays to finish()
     red.close()
+    red3 = OverlappedGradReducer(params, bucket_size_mb=0.0005)
+    for step in range(5):
+        for p in params:
+            p.grad = None
+        red3.begin_step()
+        model(x).pow(2).sum().backward()
+        red3.finish()
+        for p, g in zip(model.parameters(), g_ref):
+            ok &= bool(torch.allclose(p.grad, g, atol=1e-6))
+    ok &= red3._sentinel and len(red3._hooks) == len(red3.buckets)
+    order3 = []
+    launch3 = red3._launch
+    red3._launch = lambda b: (order3.append(b), launch3(b))[1]
+    for p in params:
+        p.grad = None
+    red3.begin_step()
+    model(x).pow(2).sum().backward()
+    ok &= order3 == list(range(len(red3.buckets)))          # all out before finish(), in index order
+    red3.finish()
+    for p, g in zip(model.parameters(), g_ref):
+        ok &= bool(torch.allclose(p.grad, g, atol=1e-6))
+    order3.clear()
+    for p in params:                                         # no begin_step: nothing may leave from the hooks
+        p.grad = None
+    model(x).pow(2).sum().backward()
+    ok &= order3 == []
+    red3.finish()
+    ok &= order3 == list(range(len(red3.buckets)))
+    for p, g in zip(model.parameters(), g_ref):
+        ok &= bool(torch.allclose(p.grad, g, atol=1e-6))
+    order3.clear()
+    red3.begin_step()                                        # gradients still set: begin_step must refuse to vouch
+    ok &= not red3._began
+    for p in params:
+        p.grad = None
+    red3.begin_step()
+    model[0](x).pow(2).sum().backward()                      # later layers get no gradient: their buckets wait for finish()
+    n_early = len(order3)
+    red3.finish()
+    ok &= order3 == list(range(len(red3.buckets))) and n_early < len(red3.buckets)
+    red3._launch = launch3
+    red3.close()
+
+    # the optimizer hook end to end: both ranks stay in sync
     opt = torch.optim.SGD(params, lr=0.1)
     hook = DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2), overlap=True, bucket_size_mb=1)
-    for _ in range(2):
+    for _ in range(4):
         hook.step(model, opt, model(x).pow(2).sum())
+    ok &= hook._reducer._sentinel
     w = [p.detach().clone() for p in model.parameters()]
     dist.all_gather_object(gathered, [t.numpy() for t in w])
     for i in range(len(w)):
