@@ -118,6 +118,46 @@ __device__ __forceinline__ void dcn_plane_copy(const float *__restrict__ xb, int
 }
 __device__ __forceinline__ int dcn_plane_units(int HW) { return 4 * ((HW + 63) >> 6); }
 
+// The bf16 plane of the one-product (KGDET_DCN_BF16) forward kernel: two planes [oct][pixel][8 channels bf16] at the same
+// stride -- a corner of EIGHT channels is one ds_read_b128, half the gathers and half the LDS bytes of the fp32 planes (the
+// bf16 kernel's producers are what bounds it: one MFMA per product).  x is rounded to bf16 before the interpolation instead
+// of after it; same error class.  Units = (oct, block of 64 pixels): eight buffer loads, four v_cvt_pk, one 16-byte store.
+typedef __bf16 dcn_bf16x8 __attribute__((ext_vector_type(8)));
+template <int ROUNDS>
+__device__ __forceinline__ void dcn_plane_copy_bf16(const float *__restrict__ xb, int HW, int Cg, int c0, unsigned char *plane,
+                                                    unsigned stride, int u_first, int u_step, int u_hi, int lane) {
+  const int nblk = (HW + 63) >> 6;
+  const dcn_rsrc_t xrs = dcn_make_rsrc(xb);
+  for (int u0 = u_first; u0 < u_hi; u0 += ROUNDS * u_step) {
+    float v[ROUNDS][8];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int u = min(u0 + r * u_step, u_hi - 1);
+      const int oct = 1 + ((u - nblk) >> 31);            // (u >= nblk)
+      const int blk = u - oct * nblk;
+      const unsigned voff = (unsigned)min(blk * 64 + lane, HW - 1) * 4u;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ch = c0 + oct * 8 + e;
+        v[r][e] = dcn_buf_f32(xrs, voff, (unsigned)(min(ch, Cg - 1) * HW) * 4u);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int u = u0 + r * u_step;
+      if (u < u_hi) {
+        const int oct = 1 + ((u - nblk) >> 31);
+        const int blk = u - oct * nblk;
+        dcn_bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[r][e];
+        *reinterpret_cast<dcn_bf16x8 *>(plane + oct * stride + (unsigned)(blk * 64 + lane) * 16u) = o;
+      }
+    }
+  }
+}
+__device__ __forceinline__ int dcn_plane_units_bf16(int HW) { return 2 * ((HW + 63) >> 6); }
+
 // One deformable convolution problem as the kernels see it (one weight group).
 struct DcnProblem {
   const float *x;       // [N, C_total, H, W]

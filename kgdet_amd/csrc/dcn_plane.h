@@ -231,16 +231,21 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
     // MODE 2: the pixel-major image; byte offset of this tile's image and channel window (the chunk is added per segment)
     const dcn_rsrc_t xg_rs = dcn_make_rsrc(p.x);
     const unsigned xg_img = (unsigned)(((long long)tile_b * HW * p.C_total + p.c_base) * 4);
+    constexpr bool kBf16Plane = PARTS == 1 && MODE == 0;   // one-product forward: the plane holds bf16 (dcn_common.h)
     auto load_plane = [&](int c, int w, auto NW_, auto ROUNDS_, int unit_lo, int unit_hi) {
       constexpr int NW = decltype(NW_)::value;
       constexpr int ROUNDS = decltype(ROUNDS_)::value;
-      dcn_plane_copy<ROUNDS>(xb_img, HW, p.Cg, c * kChunk, plane, (unsigned)kPlaneQuadStride, unit_lo + w, NW, unit_hi, lane);
+      if constexpr (kBf16Plane)
+        dcn_plane_copy_bf16<(ROUNDS + 1) / 2>(xb_img, HW, p.Cg, c * kChunk, plane, (unsigned)kPlaneQuadStride, unit_lo + w, NW,
+                                              unit_hi, lane);
+      else
+        dcn_plane_copy<ROUNDS>(xb_img, HW, p.Cg, c * kChunk, plane, (unsigned)kPlaneQuadStride, unit_lo + w, NW, unit_hi, lane);
     };
     // The next segment's plane is copied under the LAST group of a segment (the plane is not read any more once that
     // group's stages are sampled): the producers, who have nothing to sample then, take the first plane_split units,
     // the consumers the rest after their MFMAs.  Split operands: the consumers are busy for four stages of 12 MFMAs,
     // the producers take two full batches of loads; bf16: a third each way (equal shares per wave).
-    const int plane_items = dcn_plane_units(HW);
+    const int plane_items = kBf16Plane ? dcn_plane_units_bf16(HW) : dcn_plane_units(HW);
 #ifndef KGDET_PLANE_SPLIT_UNITS
 #define KGDET_PLANE_SPLIT_UNITS (8 * kPlaneRounds)
 #endif
@@ -308,6 +313,17 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         // (MODE 1: the upper bits of a record's last offset hold the cell's overflow range)
         const unsigned o[4] = {R.off[gq].x, R.off[gq].y, R.off[gq].z,
                                (MODE == 1 && gq == NG - 1) ? (R.off[gq].w & 0x1ffffu) : R.off[gq].w};
+        if constexpr (kBf16Plane) {   // eight channels of a corner in ONE read; bf16 -> fp32 is a shift / a mask per value
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const u32x4_t raw = __builtin_bit_cast(u32x4_t, lds_quad(o[e] + (unsigned)(half * kPlaneQuadStride)));
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+              v[c][e] = f32x4{__uint_as_float(raw[2 * c] << 16), __uint_as_float(raw[2 * c] & 0xffff0000u),
+                              __uint_as_float(raw[2 * c + 1] << 16), __uint_as_float(raw[2 * c + 1] & 0xffff0000u)};
+          }
+          return;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
