@@ -123,6 +123,11 @@ int kgdet_bn_act_backward(const float *grad_y, const float *x, const float *y, c
  * [N, K], residual / out [M, N] bf16 (M = B*H*W), bias fp32 [N]; K % 16 == 0, K <= 384, N % 128 == 0. */
 int kgdet_conv1x1_nhwc_residual(const void *x, const void *weight, const float *bias, const void *residual, void *out,
                                 int64_t M, int32_t K, int32_t N, int32_t relu, void *stream);
+/* the same with x = the RAW output of the convolution in front (conv2 without its epilogue): relu(x + in_bias[k]) (rounded to
+ * bf16, as the separate pass stores it) is applied to the activations as they are loaded; in_bias fp32 [K] */
+int kgdet_conv1x1_nhwc_residual_in(const void *x, const float *in_bias, const void *weight, const float *bias,
+                                   const void *residual, void *out, int64_t M, int32_t K, int32_t N, int32_t relu,
+                                   void *stream);
 int kgdet_bn_fold_backward(const float *grad_z, const float *z, int32_t relu, float *g, float *partial, int64_t N, int32_t C,
                            int64_t HW, void *stream);
 int kgdet_bn_fold_finish(const float *partial, int32_t P, const float *w, float *G /*nullable*/, const float *s,

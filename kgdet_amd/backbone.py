@@ -374,7 +374,14 @@ GEMM_1X1 = _os.environ.get('KGDET_INFER_GEMM_1X1', '1') == '1'     # 0: every in
 _gemm_choice = {}       # (Cin, Cout, B, H, W, residual?, relu) -> True: hipBLASLt GEMM, False: MIOpen convolution
 
 
-def _conv1x1_as_gemm(conv, hit, x, residual, relu):
+def fused_residual_ready(conv3, B, H, W):
+    """True when conv3 + bn3 + add + ReLU of this shape runs on the fused kernel (measured choice): the caller may then hand it
+    conv2's RAW output and bias (`_conv_bn(..., in_bias=...)`) instead of running conv2's epilogue pass"""
+    return (FUSED_RESIDUAL_1X1 and GEMM_1X1 and
+            _gemm_choice.get((conv3.in_channels, conv3.out_channels, B, H, W, True, True)) == 'fused')
+
+
+def _conv1x1_as_gemm(conv, hit, x, residual, relu, in_bias=None):
     """bf16 channels-last inference: a 1x1 stride-1 convolution IS the GEMM [B*H*W, Cin] x [Cin, Cout] on the channels-last
     storage, and hipBLASLt takes the folded-BatchNorm bias (+ ReLU) as its epilogue -- no separate bias / ReLU pass over the
     activation (csrc/epilogue.hip bias_act_nhwc was the largest kernel of the inference batch).  With a residual the GEMM adds
@@ -404,13 +411,14 @@ def _conv1x1_as_gemm(conv, hit, x, residual, relu):
         return y2.view(B, H, W, cout).permute(0, 3, 1, 2)
 
     def fused():
-        # conv3 + bn3 + identity + ReLU as ONE kernel (csrc/conv_nhwc.hip): x, the residual and the output cross the fabric once
+        # conv3 + bn3 + identity + ReLU as ONE kernel (csrc/conv_nhwc.hip): x, the residual and the output cross the fabric once;
+        # with in_bias, x is conv2's RAW output and its bias + ReLU happen as the activations are loaded
         from . import _lib
         y = torch.empty_like(residual)
-        _lib.check(_lib.lib().kgdet_conv1x1_nhwc_residual(
-            _lib.ptr(x), _lib.ptr(hit[1]), _lib.ptr(hit[2]), _lib.ptr(residual), _lib.ptr(y), ctypes.c_int64(B * H * W),
-            ctypes.c_int32(cin), ctypes.c_int32(cout), ctypes.c_int32(1 if relu else 0), _lib.current_stream()),
-            'conv1x1_nhwc_residual')
+        _lib.check(_lib.lib().kgdet_conv1x1_nhwc_residual_in(
+            _lib.ptr(x), _lib.ptr(in_bias), _lib.ptr(hit[1]), _lib.ptr(hit[2]), _lib.ptr(residual), _lib.ptr(y),
+            ctypes.c_int64(B * H * W), ctypes.c_int32(cin), ctypes.c_int32(cout), ctypes.c_int32(1 if relu else 0),
+            _lib.current_stream()), 'conv1x1_nhwc_residual')
         return y
 
     fused_ok = (residual is not None and cin % 16 == 0 and cin <= 384 and cout % 128 == 0
@@ -418,6 +426,8 @@ def _conv1x1_as_gemm(conv, hit, x, residual, relu):
                 and residual.shape == (B, cout, H, W) and hit[1].is_contiguous(memory_format=torch.channels_last))
     if choice == 'fused':
         return fused()
+    if in_bias is not None:          # (only passed once the choice is 'fused', fused_residual_ready: the caller's problem)
+        return None
     if choice is None:
         def conv_path():
             y = F.conv2d(x, hit[1], None, conv.stride, conv.padding, conv.dilation, conv.groups)
@@ -456,7 +466,7 @@ def conv_bn(conv, bn, x, relu=False, residual=None, skip=False):
     return out
 
 
-def _conv_bn(conv, bn, x, relu=False, residual=None, skip=False, raw=False):
+def _conv_bn(conv, bn, x, relu=False, residual=None, skip=False, raw=False, in_bias=None):
     """conv_bn's body (with ``skip`` the training fast path may return the (output, alias) pair itself).  In inference (autograd off, BatchNorm in eval mode, plain bias-free
     Conv2d) the frozen statistics are folded into the convolution -- w' = w * gamma / sigma,
     b' = beta - mu * gamma / sigma -- and bias, residual add and ReLU run as ONE in-place pass over the activation
@@ -527,9 +537,11 @@ def _conv_bn(conv, bn, x, relu=False, residual=None, skip=False, raw=False):
         x = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     if (bf16 and GEMM_1X1 and not raw and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
             and conv.groups == 1 and x.dtype == torch.bfloat16 and (residual is None or residual.dtype == torch.bfloat16)):
-        out = _conv1x1_as_gemm(conv, hit, x, residual, relu)
+        out = _conv1x1_as_gemm(conv, hit, x, residual, relu, in_bias)
         if out is not None:
             return out
+    if in_bias is not None:      # the convolution route after all: conv2's epilogue as its own pass
+        x = _epilogue_(x, in_bias, None, True)
     if hit[3] is not None and x.dtype == torch.float32 and x.is_contiguous() and x.shape[2] * x.shape[3] % 2 == 0:
         if _FUSE_EPI and (residual is None or (residual.dtype == torch.float32 and residual.is_contiguous())):
             # bias, residual and ReLU ride on the convolution's store: no separate epilogue pass
@@ -613,6 +625,13 @@ class Bottleneck(nn.Module):
         else:
             out = conv_bn(self.conv1, self.norm1, x, relu=True)
         if not self.with_dcn:
+            if (not torch.is_grad_enabled() and out.dtype == torch.bfloat16 and self.conv2.stride == (1, 1)
+                    and fused_residual_ready(self.conv3, out.shape[0], out.shape[2], out.shape[3])):
+                # bf16 inference: conv2's bias + ReLU ride on the activation loads of the fused conv3 kernel
+                out, shift2 = _conv_bn(self.conv2, self.norm2, out, relu=True, raw=True)
+                if self.downsample is not None:
+                    identity = conv_bn(self.downsample[0], self.downsample[1], x)
+                return _conv_bn(self.conv3, self.norm3, out, relu=True, residual=identity, in_bias=shift2)
             out = conv_bn(self.conv2, self.norm2, out, relu=True)
             if self.downsample is not None:
                 identity = conv_bn(self.downsample[0], self.downsample[1], x)

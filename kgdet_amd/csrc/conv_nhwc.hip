@@ -30,10 +30,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kStageRow = 144;                    // 128 bytes of channels + 16: 8-byte column accesses of 32 rows spread over the banks
 constexpr int kStageBytes = 32 * kStageRow;       // 4608 per wave
 
-template <bool RELU, int WAVES>
+// IN_EPI: x is the RAW output of the convolution in front (conv2 without its epilogue): relu(x + in_bias[k]) is applied to
+// the activation fragments as they are loaded -- the pass over conv2's output that did it is gone.
+template <bool RELU, int WAVES, bool IN_EPI>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 2) void conv1x1_nhwc_res(
     const __bf16 *__restrict__ A, const __bf16 *__restrict__ Wt, const float *__restrict__ bias, const __bf16 *__restrict__ R,
-    __bf16 *__restrict__ D, long long M, int K, int N, int n_ctiles, long long n_rtiles) {
+    __bf16 *__restrict__ D, long long M, int K, int N, int n_ctiles, long long n_rtiles, const float *__restrict__ in_bias) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int THREADS = 64 * WAVES, ROWS = 32 * WAVES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -47,6 +49,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 2) void conv1x1_nhwc_r
   }
   float *lbias = reinterpret_cast<float *>(smem + (size_t)K * 128 * 2 + WAVES * kStageBytes);   // the tile's 128 bias values
   if (tid < 128) lbias[tid] = bias[n0 + tid];
+  float *libias = lbias + 128;                                                                   // IN_EPI: the K input biases
+  if constexpr (IN_EPI)
+    for (int i = tid; i < K; i += THREADS) libias[i] = in_bias[i];
   __syncthreads();
   unsigned char *stage = smem + (size_t)K * 128 * 2 + wave * kStageBytes;
   const int px = lane & 31, kh = lane >> 5;
@@ -72,7 +77,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 2) void conv1x1_nhwc_r
       for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
     const long long mp = m0 + px < M ? m0 + px : M - 1;
     const __bf16 *arow = A + mp * K + kh * 8;
-    auto kstep = [&](int ks, const bf16x8 b) {
+    auto kstep = [&](int ks, bf16x8 b) {
+      if constexpr (IN_EPI) {
+        const f32x4 i0 = *reinterpret_cast<const f32x4 *>(libias + ks * 16 + kh * 8);
+        const f32x4 i1 = *reinterpret_cast<const f32x4 *>(libias + ks * 16 + kh * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = (__bf16)fmaxf((float)b[j] + (j < 4 ? i0[j & 3] : i1[j & 3]), 0.0f);
+      }
       const unsigned char *wl = smem + ((size_t)(ks * 2 + kh) * 128 + px) * 16;
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) {
@@ -128,32 +139,40 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 2) void conv1x1_nhwc_r
 
 using namespace kgdet;
 
-extern "C" int kgdet_conv1x1_nhwc_residual(const void *x, const void *weight, const float *bias, const void *residual,
-                                           void *out, int64_t M, int32_t K, int32_t N, int32_t relu, void *stream) {
+extern "C" int kgdet_conv1x1_nhwc_residual_in(const void *x, const float *in_bias, const void *weight, const float *bias,
+                                              const void *residual, void *out, int64_t M, int32_t K, int32_t N, int32_t relu,
+                                              void *stream) {
   KGDET_CHECK_SHAPE(M >= 0 && K > 0 && N > 0 && K % 16 == 0 && N % 128 == 0 && K <= 448, "bad sizes (K %% 16, N %% 128, K <= 448)");
   if (M == 0) return KGDET_OK;
   KGDET_CHECK_SHAPE(x && weight && bias && residual && out, "null pointer");
   const int n_ctiles = N / 128;
   const int waves = K >= 256 ? 8 : 4;                       // a 64 KB+ weight tile is shared by eight waves
   const long long n_rtiles = (M + 32 * waves - 1) / (32 * waves);
-  const size_t lds = (size_t)K * 128 * 2 + (size_t)waves * kStageBytes + 512;
+  const size_t lds = (size_t)K * 128 * 2 + (size_t)waves * kStageBytes + 512 + (size_t)K * 4;
   long long groups = n_rtiles < 768 ? n_rtiles : 768;      // persistent: a few workgroups per CU
-  static thread_local bool attr_set = false;
-  if (!attr_set) {
-    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv1x1_nhwc_res<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv1x1_nhwc_res<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv1x1_nhwc_res<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv1x1_nhwc_res<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
   const dim3 grid((unsigned)(groups * n_ctiles));
-#define KGDET_NHWC_LAUNCH(RELU_, W_)                                                                                        \
-  hipLaunchKernelGGL((conv1x1_nhwc_res<RELU_, W_>), grid, dim3(64 * W_), lds, (hipStream_t)stream, (const __bf16 *)x,        \
-                     (const __bf16 *)weight, bias, (const __bf16 *)residual, (__bf16 *)out, (long long)M, K, N, n_ctiles,    \
-                     n_rtiles)
-  if (waves == 8) { if (relu) KGDET_NHWC_LAUNCH(true, 8); else KGDET_NHWC_LAUNCH(false, 8); }
-  else { if (relu) KGDET_NHWC_LAUNCH(true, 4); else KGDET_NHWC_LAUNCH(false, 4); }
+#define KGDET_NHWC_LAUNCH(RELU_, W_, IN_)                                                                                   \
+  do {                                                                                                                      \
+    static thread_local bool attr_set = false;                                                                              \
+    if (!attr_set) {                                                                                                        \
+      KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv1x1_nhwc_res<RELU_, W_, IN_>,                                      \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                           \
+      attr_set = true;                                                                                                      \
+    }                                                                                                                       \
+    hipLaunchKernelGGL((conv1x1_nhwc_res<RELU_, W_, IN_>), grid, dim3(64 * W_), lds, (hipStream_t)stream,                    \
+                       (const __bf16 *)x, (const __bf16 *)weight, bias, (const __bf16 *)residual, (__bf16 *)out,            \
+                       (long long)M, K, N, n_ctiles, n_rtiles, in_bias);                                                    \
+  } while (0)
+#define KGDET_NHWC_PICK(RELU_, W_) do { if (in_bias) KGDET_NHWC_LAUNCH(RELU_, W_, true); else KGDET_NHWC_LAUNCH(RELU_, W_, false); } while (0)
+  if (waves == 8) { if (relu) KGDET_NHWC_PICK(true, 8); else KGDET_NHWC_PICK(false, 8); }
+  else { if (relu) KGDET_NHWC_PICK(true, 4); else KGDET_NHWC_PICK(false, 4); }
+#undef KGDET_NHWC_PICK
 #undef KGDET_NHWC_LAUNCH
   KGDET_CHECK_LAUNCH("conv1x1_nhwc_residual");
   return KGDET_OK;
+}
+
+extern "C" int kgdet_conv1x1_nhwc_residual(const void *x, const void *weight, const float *bias, const void *residual,
+                                           void *out, int64_t M, int32_t K, int32_t N, int32_t relu, void *stream) {
+  return kgdet_conv1x1_nhwc_residual_in(x, nullptr, weight, bias, residual, out, M, K, N, relu, stream);
 }

@@ -146,6 +146,17 @@ def test_fused_residual_conv_nhwc_matches_conv_plus_epilogue(B, K, H, W, relu):
     # one bf16 ulp where the fp32 sums of the two routes round differently
     assert float((out.float() - ref.float()).abs().max()) <= 2 ** -7 * float(ref.float().abs().max())
     assert float((out.float() - ref.float()).abs().mean()) <= 1e-3 * float(ref.float().abs().mean())
+    # the same with conv2's epilogue deferred into the activation loads: x raw, relu(x + in_bias) applied on the fly
+    ib = torch.randn(K, device='cuda', generator=g)
+    out2 = torch.full_like(r, float('nan'))
+    _lib.check(_lib.lib().kgdet_conv1x1_nhwc_residual_in(_lib.ptr(x), _lib.ptr(ib), _lib.ptr(w), _lib.ptr(b), _lib.ptr(r),
+                                                         _lib.ptr(out2), ctypes.c_int64(B * H * W), ctypes.c_int32(K),
+                                                         ctypes.c_int32(N), ctypes.c_int32(1 if relu else 0),
+                                                         _lib.current_stream()), 'nhwc_in')
+    x2 = torch.relu(x.float() + ib.view(1, -1, 1, 1)).to(torch.bfloat16)
+    ref2 = torch.nn.functional.conv2d(x2.float(), w.float()).to(torch.bfloat16).float() + b.view(1, -1, 1, 1) + r.float()
+    ref2 = (torch.relu(ref2) if relu else ref2).to(torch.bfloat16)
+    assert float((out2.float() - ref2.float()).abs().max()) <= 2 ** -7 * float(ref2.float().abs().max())
 
 
 def test_folded_batchnorm_step_equals_the_unfolded_step():
