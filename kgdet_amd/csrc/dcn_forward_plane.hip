@@ -16,15 +16,17 @@
 //     chunk-major / tap-minor and pixel tiles never straddle images.
 //   * sampling geometry is not recomputed per channel chunk: dcn_build_taps writes one 32-byte record per
 //     (image, tap, output pixel) -- four LDS byte offsets and four bilinear weights -- and the kernel only
-//     loads it.  With the split MFMA the kernel is bound by the issue port MFMA and VALU instructions share (SQ
-//     counters of the final binary: MFMA pipe 47 % busy, waves waiting to issue 49 % of the time), so instructions per
-//     sample are what matters.
-//   * 12 waves, two roles: waves 0-7 are CONSUMERS (wave w owns rows [32 w, 32 w + 32) x 128 columns of the 256 x 128
-//     accumulator tile, reads the B fragments from LDS, takes its A (weight) fragments straight from the weight image in
-//     L2 -- 16 bytes per lane and fragment, two stages ahead in registers -- and issues the MFMAs), waves 8-11 are
-//     PRODUCERS in two wave pairs (a thread samples all 16 channels of one pixel for two of a group's four stages).  One
-//     barrier per group of four stages hands the double-buffered groups over.  (dcn_plane_phased.h: the measured,
-//     non-adopted alternative with sampling and MFMA phases instead of roles.)
+//     loads it (buffer loads: SGPR resource + one 32-bit lane offset + a scalar offset).  Beside MFMA waves every vector
+//     instruction of a producer is expensive (one issue port per SIMD), so instructions per sample are what matters.
+//   * 16 waves of 128 registers, two roles: waves 0-7 are CONSUMERS (wave w owns rows [32 w, 32 w + 32) x 128 columns of
+//     the 256 x 128 accumulator tile, reads the B fragments from LDS, takes its A (weight) fragments straight from the weight
+//     image in L2 -- 16 bytes per lane and fragment, two stages ahead in registers -- and issues the MFMAs), waves 8-15 are
+//     PRODUCERS in four wave pairs at s_setprio 0 (a thread samples all 16 channels of one pixel for ONE of a group's four
+//     stages; round 2 had two pairs doing two stages each at priority 2: the producers were the critical path, LDS gather
+//     latency).  One barrier per group of four stages hands the double-buffered groups over.
+//   * KGDET_DCN_BF16 (PARTS = 1): the LDS plane holds bf16, eight channels of a corner per ds_read_b128.
+//   * dcn_fwd_gather (plane_role MODE 2): maps beyond the LDS plane -- no plane, the corners are buffer loads from a
+//     pixel-major copy of x.
 //
 // Operand images (the lane-linear fragment order a wave reads with one 16-byte load per lane):
 //   A stage (tap t, channel chunk c16, 256 output channels): [part][khalf][o 256][8 bf16]   8 KB / part

@@ -105,24 +105,25 @@ struct PlaneStageRegs {
 
 // Loop structure: a workgroup walks its slice range by range (static schedule: exactly one range); inside a range the
 // stages that share a feature plane (one channel chunk, consecutive taps) form a SEGMENT.  Only the first segment of a
-// range starts with a plane copy by all twelve waves: the next segment's plane and first tap records are loaded under
+// range starts with a plane copy by all sixteen waves: the next segment's plane and first tap records are loaded under
 // the LAST group of the segment before (see the segment loop).  Loads are issued unconditionally from clamped addresses,
 // so hipcc's counted s_waitcnt vmcnt(N) stay exact.
 //
 // Stages are handed from the producers to the consumers in GROUPS of kGroupTaps = 4.  The B buffer in LDS holds two
 // groups: while the consumers multiply the four stages of group g (their weight fragments arrive from L2 two
-// stages ahead, in a two-deep register ring), the producers sample the four stages of group g + 1 (each wave pair two of
-// them); the tap records of a group are loaded one whole group before they are used.  ONE workgroup barrier per group.
+// stages ahead, in a two-deep register ring), the producers sample the four stages of group g + 1 (each of the four wave
+// pairs one of them); the tap records of a group are loaded one whole group before they are used.  ONE workgroup barrier
+// per group.
 // Why (phase trace of the one-barrier-per-stage version, tools/plane_trace.py: cycles per workgroup, 187 stages):
 // both roles did ~1200 cycles of work per stage and each waited ~300 more at the barrier -- for the slowest of the
-// twelve waves, a different one every stage (random-gather bank conflicts, issue arbitration); a group averages
-// that skew over four stages.  Inside a group the producers keep the corner reads of three half-stages in flight
-// (MODE 0), so the LDS latency of the random gather overlaps VALU work instead of heading a dependent chain.
-// What bounds the kernel is the SIMD's single issue port for MFMA and other VALU instructions
-// (tools/microbench/mfma_valu.hip, profiles/r02_dcn_fwd_plane_group_b2.md): beside the two MFMA waves of its SIMD a
-// producer wave gets about one VALU instruction per MFMA slot whatever its priority (s_setprio 2 is kept: it costs
-// nothing), and each of its instructions costs the MFMA waves ~10 cycles -- hence scalar role ids, scalar-base loads, the
-// packed hi/lo split, record sets that alternate instead of being copied.
+// waves, a different one every stage (random-gather bank conflicts, issue arbitration); a group averages
+// that skew over four stages.  Inside a group a producer keeps the corner reads of both half-stages of its stage in flight
+// (MODE 0 / 2), so the gather latency overlaps VALU work instead of heading a dependent chain.
+// The SIMD has a single issue port for MFMA and other VALU instructions (tools/microbench/mfma_valu.hip,
+// profiles/r02_dcn_fwd_plane_group_b2.md): beside the two MFMA waves of its SIMD a producer wave gets few slots and each of its
+// instructions costs the MFMA waves cycles -- hence scalar role ids, buffer loads with scalar offsets, record sets that
+// alternate instead of being copied, scalar (not packed) fp32 FMAs.  With eight producer waves at priority 0 the producers
+// have slack and the consumers are the critical path (profiles/r03_dcn_fwd_plane_group_b2.md).
 // Stage coordinates are carried incrementally; there is no integer division in the loop.
 // The two roles are two instantiations of this function (same loop structure, same barriers), so the
 // accumulators exist only in the consumers' register allocation.
