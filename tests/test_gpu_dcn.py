@@ -140,6 +140,12 @@ def test_large_map_forward_runs_on_split_operands():
     ref = oracle.deform_conv_forward(x.astype(np.float64), off.astype(np.float64), w.astype(np.float64), 1, 1, 1, 2, 1,
                                      mask=mask.astype(np.float64))
     _close(out.detach().cpu().numpy(), ref, 2e-5)
+    # four deformable groups of 16 channels
+    case3 = (1, 64, 40, 48, 32, 3, 1, 1, 1, 1, 4)
+    x, off, w, _, _ = _make(case3, seed=23)
+    out = dcn.deform_conv(*(torch.from_numpy(t).cuda() for t in (x, off, w)), 1, 1, 1, 1, 4)
+    ref = oracle.deform_conv_forward(x.astype(np.float64), off.astype(np.float64), w.astype(np.float64), 1, 1, 1, 1, 4)
+    _close(out.detach().cpu().numpy(), ref, 2e-5)
 
 
 def test_forward_deterministic_and_zero_offset_is_conv():
