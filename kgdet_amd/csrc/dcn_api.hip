@@ -332,8 +332,9 @@ size_t kgdet_dcn_workspace_bytes(const kgdet_dcn_shape *s) {
                           (size_t)s->groups * (d.Og_pad / kTileM) * s->N * ceil_div(d.Ho * d.Wo, kChunk) * 16384;
     need = need > wplane ? need : wplane;
   }
-  if (gather_ok(s, d)) {   // forward on large maps: records + the pixel-major copy of x behind the slabs
-    const size_t gw = slab_bytes() + gather_table_bytes(s, d) + gather_image_bytes(s);
+  if (gather_ok(s, d)) {   // forward / grad_weight on large maps: records (+ grad_out images) + the pixel-major copy of x
+    const size_t gw = slab_bytes() + gather_table_bytes(s, d) + gather_image_bytes(s) +
+                      (size_t)s->groups * (d.Og_pad / kTileM) * s->N * ceil_div(d.Ho * d.Wo, kChunk) * 16384;
     need = need > gw ? need : gw;
   }
   if (!pl.ok && !plane_bwd_input_ok(s, d)) {   // large maps: the materialised column gradient of dcn_backward_large.hip
@@ -1092,7 +1093,8 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
 // grad_weight of n v1 problems in one launch of the plane kernel (+ record / grad_out image builders, fix-up).
 static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *shapes, const float *const *inputs,
                                      const float *const *offsets, const float *const *masks, const float *const *grad_outputs,
-                                     float *const *grad_weights, void *workspace, size_t workspace_bytes, void *stream);
+                                     float *const *grad_weights, void *workspace, size_t workspace_bytes, void *stream,
+                                     bool gather = false);
 
 int kgdet_deform_conv_grad_weight_grouped(int32_t n, const kgdet_dcn_shape *const *shapes, const float *const *inputs,
                                           const float *const *offsets, const float *const *grad_outputs,
@@ -1106,11 +1108,14 @@ int kgdet_deform_conv_grad_weight_grouped(int32_t n, const kgdet_dcn_shape *cons
 // Weight groups and deformable groups: a problem is cut into runs of input channels that share both (sub-problems: the
 // input window, the weight group's grad_out image and output rows, the deformable group's tap records); at most
 // kMaxFwdGroup sub-problems per launch.
+// gather: one problem on a map beyond the LDS plane -- pixel-major copy of x behind the tables, dcn_bwd_weight_gather.
 static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *shapes, const float *const *inputs,
                                      const float *const *offsets, const float *const *masks, const float *const *grad_outputs,
-                                     float *const *grad_weights, void *workspace, size_t workspace_bytes, void *stream) {
+                                     float *const *grad_weights, void *workspace, size_t workspace_bytes, void *stream,
+                                     bool gather) {
   KGDET_CHECK_SHAPE(n >= 1 && n <= kMaxFwdGroup && shapes && inputs && offsets && grad_outputs && grad_weights,
                     "null pointer / group size not in [1, %d]", kMaxFwdGroup);
+  KGDET_CHECK_SHAPE(!gather || n == 1, "the large-map grad_weight kernel takes one problem per launch");
   const int G = grid_size();
   Derived dd[kMaxFwdGroup];
   int same_taps[kMaxFwdGroup], same_gq[kMaxFwdGroup];
@@ -1120,7 +1125,7 @@ static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *sh
     const kgdet_dcn_shape *s = shapes[i];
     if (int rc = derive(s, dd[i])) return rc;
     KGDET_CHECK_SHAPE(inputs[i] && offsets[i] && grad_outputs[i] && grad_weights[i], "null pointer (problem %d)", i);
-    if (!plane_ok(s, dd[i]) || dd[i].K > 128) {   // (the fix-up: at most 16 tap groups per channel chunk)
+    if (!(gather ? gather_ok(s, dd[i]) : plane_ok(s, dd[i])) || dd[i].K > 128) {   // (the fix-up: at most 16 tap groups per channel chunk)
       set_error("problem %d is not eligible for the plane grad_weight kernel", i);
       return KGDET_E_UNSUPPORTED;
     }
@@ -1144,7 +1149,7 @@ static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *sh
           dd[q].Ho == dd[i].Ho && dd[q].Wo == dd[i].Wo)
         same_gq[i] = same_gq[q] >= 0 ? same_gq[q] : q;
     }
-    if (same_taps[i] < 0) { taps_off[i] = total; total += align_up(tap_table_bytes(s, dd[i]), 256); }
+    if (same_taps[i] < 0) { taps_off[i] = total; total += gather ? gather_table_bytes(s, dd[i]) : align_up(tap_table_bytes(s, dd[i]), 256); }
     else taps_off[i] = taps_off[same_taps[i]];
     const int n_px16 = ceil_div(dd[i].Ho * dd[i].Wo, kChunk);
     if (same_gq[i] < 0) { gq_off[i] = total; total += (size_t)s->groups * (dd[i].Og_pad / kTileM) * s->N * n_px16 * 16384; }
@@ -1154,6 +1159,8 @@ static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *sh
     set_error("more than %d (weight group, deformable group) channel runs in one launch", kMaxFwdGroup);
     return KGDET_E_UNSUPPORTED;
   }
+  const size_t image_off = total;   // (gather) the pixel-major copy of x
+  if (gather) total += gather_image_bytes(shapes[0]);
   if (workspace == nullptr || workspace_bytes < slab_bytes() + total) {
     set_error("workspace too small: need %zu bytes, got %zu (kgdet_dcn_group_workspace_bytes)", slab_bytes() + total,
               workspace_bytes);
@@ -1163,11 +1170,19 @@ static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *sh
   if (!attr_set) {
     KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_bwd_weight_plane<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)kMaxLds));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_bwd_weight_gather<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)kMaxLds));
     attr_set = true;
   }
   unsigned char *tab = (unsigned char *)workspace + slab_bytes();
+  if (gather) {
+    const kgdet_dcn_shape *s = shapes[0];
+    const long long HW = (long long)s->H * s->W;
+    hipLaunchKernelGGL(dcn_to_pixel_major, dim3((unsigned)((HW + 31) / 32), (s->C + 31) / 32, s->N), dim3(256), 0,
+                       (hipStream_t)stream, inputs[0], reinterpret_cast<float *>(tab + image_off), s->C, HW, (long long)s->C * HW);
+  }
   DcnFwdGroup grp;
-  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.pair_mode = 0; grp.gather_mode = 0; grp.rounds = 1; grp.wave_layout = 0;
+  grp.n = 0; grp.xcd_slices = 1; grp.slots = kSlabSlots; grp.dbl_plane = 0; grp.plane_bytes = 0; grp.static_ranges = 0; grp.pair_mode = 0; grp.gather_mode = gather ? 1 : 0; grp.rounds = 1; grp.wave_layout = 0;
   grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
   size_t lds = 0;
   int min_len = 1 << 30;
@@ -1184,7 +1199,8 @@ static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *sh
       const int c1 = std::min((g + 1) * d.Cg, (dgi + 1) * cpdg);
       DcnProblem p;
       fill_problem(s, d, g, p);
-      p.x = inputs[i]; p.offset = offsets[i]; p.mask = masks ? masks[i] : nullptr;
+      p.x = gather ? reinterpret_cast<const float *>(tab + image_off) : inputs[i];
+      p.offset = offsets[i]; p.mask = masks ? masks[i] : nullptr;
       p.c_base = c0; p.Cg = c1 - c0; p.Cg_pad = ceil_div(p.Cg, kChunk) * kChunk;
       p.dgi = dgi;
       p.w_ld = d.Cg;                                                      // a weight row holds the whole group's channels
@@ -1215,7 +1231,7 @@ static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *sh
       first_sub = false;
       c0 = c1;
     }
-    const size_t need = dcn_bwd_weight_plane_lds_bytes(2, s->H * s->W);
+    const size_t need = gather ? dcn_bwd_weight_gather_lds_bytes(2) : dcn_bwd_weight_plane_lds_bytes(2, s->H * s->W);
     lds = need > lds ? need : lds;
   }
   // The fix-up lists at most 32 slabs per tile: small problems run on fewer workgroups, so that a workgroup's share of the
@@ -1233,8 +1249,12 @@ static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *sh
     return KGDET_E_UNSUPPORTED;
   }
   hipLaunchKernelGGL(dcn_build_taps, dim3(2 * G, grp.n), dim3(256), 0, (hipStream_t)stream, grp);
-  hipLaunchKernelGGL(dcn_bwd_weight_plane<2>, dim3(Gw), dim3(dcn_bwd_weight_plane_threads()), lds, (hipStream_t)stream, grp,
-                     (float *)workspace);
+  if (gather)
+    hipLaunchKernelGGL(dcn_bwd_weight_gather<2>, dim3(Gw), dim3(dcn_bwd_weight_plane_threads()), lds, (hipStream_t)stream, grp,
+                       (float *)workspace);
+  else
+    hipLaunchKernelGGL(dcn_bwd_weight_plane<2>, dim3(Gw), dim3(dcn_bwd_weight_plane_threads()), lds, (hipStream_t)stream, grp,
+                       (float *)workspace);
   {
     int fix_blocks = 0, max_K = 0;
     for (int i = 0; i < grp.n; ++i) {
@@ -1380,10 +1400,11 @@ int kgdet_deform_conv_backward_weight(const kgdet_dcn_shape *s, const float *inp
   Derived d;
   if (int rc = derive(s, d)) return rc;
   KGDET_CHECK_SHAPE(input && offset && grad_output && grad_weight, "null pointer");
-  // small map (v1 or v2, any weight / deformable groups): the split-operand plane kernel, natural-layout output
-  if (!accumulate && g_options[KGDET_OPT_EXACT_BACKWARD] == 0 && plane_ok(s, d)) {
+  // v1 or v2, any weight / deformable groups: the split-operand kernel with natural-layout output -- small maps on the
+  // LDS plane, larger ones gathering from a pixel-major copy of x
+  if (!accumulate && g_options[KGDET_OPT_EXACT_BACKWARD] == 0 && (plane_ok(s, d) || gather_ok(s, d))) {
     const int rc = grad_weight_plane_grouped(1, &s, &input, &offset, mask ? &mask : nullptr, &grad_output, &grad_weight, workspace,
-                                             workspace_bytes, stream);
+                                             workspace_bytes, stream, !plane_ok(s, d));
     if (rc == KGDET_OK) {
       if (grad_bias) {
         const int O_total = s->out_channels_total > 0 ? s->out_channels_total : s->O;

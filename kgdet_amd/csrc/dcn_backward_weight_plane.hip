@@ -17,7 +17,11 @@
 //   * the tap records of a stage (4 KB) are fetched coalesced by all producer threads and handed to the sampling
 //     threads through LDS; consumers, plane copy, stream-K over (tile, stage) units, slabs: as dcn_plane.h.
 // The fix-up (or the kernel itself for unsplit tiles) writes grad_W in its natural [O, C, kh, kw] layout: no
-// packed intermediate, no unpack kernel.  v1 only (no mask / bias), deformable groups = 1.
+// packed intermediate, no unpack kernel.  v1 and v2 (the records carry mask x bilinear weight); weight groups and
+// deformable groups run as channel-run sub-problems (dcn_api.hip).
+// Maps beyond the LDS plane (GATHER): no plane -- the corner reads are 16-byte buffer loads from a pixel-major copy of x
+// (dcn_to_pixel_major; the records hold row offsets of that copy), issued one stage ahead of the arithmetic that uses
+// them; the record ring is one slot deeper for that.
 #include <type_traits>
 
 #include "dcn_plane.h"
@@ -65,6 +69,7 @@ size_t dcn_bwd_weight_plane_lds_bytes(int parts, int HW) {
   return (size_t)3 * parts * kAPart + (size_t)2 * parts * kBPart + 2 * 4096 +
          (size_t)kChunk * dcn_plane_padded_pixels(HW) * sizeof(float);
 }
+size_t dcn_bwd_weight_gather_lds_bytes(int parts) { return (size_t)3 * parts * kAPart + (size_t)2 * parts * kBPart + 3 * 4096; }
 
 // element (row o, column n) of tile (mt, c16, tg) -> grad_weight[o][c][t]
 __device__ __forceinline__ void wgrad_store_elem(const DcnProblem &p, int mt, int c16, int tg, int row, int col, float v) {
@@ -73,12 +78,13 @@ __device__ __forceinline__ void wgrad_store_elem(const DcnProblem &p, int mt, in
   if (o < p.Og && c < p.Cg && t < p.K) p.out[((long long)o * p.w_ld + c) * p.K + t] = v;
 }
 
-template <int PARTS, bool PRODUCER>
+template <int PARTS, bool PRODUCER, bool GATHER>
 __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__restrict__ slabs, unsigned char *smem) {
+  static_assert(kAFromL2 || !GATHER, "the gather pipeline has no slot timeline for grad_out stages in LDS");
   unsigned char *As = smem;                                       // [3][PARTS][kAPart]  (ring)
   unsigned char *Bs = smem + 3 * PARTS * kAPart;                  // [2][PARTS][kBPart]
-  u32x4 *Rs = reinterpret_cast<u32x4 *>(smem + 3 * PARTS * kAPart + 2 * PARTS * kBPart);  // [2][256] record pieces
-  unsigned char *plane = smem + 3 * PARTS * kAPart + 2 * PARTS * kBPart + 2 * 4096;  // [4 quads][H*W padded][4 channels] fp32
+  u32x4 *Rs = reinterpret_cast<u32x4 *>(smem + 3 * PARTS * kAPart + 2 * PARTS * kBPart);  // [2 | GATHER: 3][256] record pieces
+  unsigned char *plane = smem + 3 * PARTS * kAPart + 2 * PARTS * kBPart + 2 * 4096;  // [4 quads][H*W padded][4 channels] fp32 (not GATHER)
 
   const int wtid = threadIdx.x;
   const int tid = PRODUCER ? wtid - kThreads : wtid;
@@ -100,6 +106,7 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
     const int HW = p.H * p.W;
     const unsigned qstride = (unsigned)dcn_plane_padded_pixels(HW) * 16u;   // bytes between the plane's channel quads
     const unsigned char *plane_q = plane + quad * qstride;                    // producers: this thread's quad plane
+    const dcn_rsrc_t x_rs = dcn_make_rsrc(p.x);                               // (GATHER) the pixel-major copy of x
     const int K = p.K, HoWo = p.HoWo;
     const int n_px16 = p.chunks_per_tap;      // stages per image
     const int n_tg = p.tiles_per_image;       // tap groups per channel chunk
@@ -124,6 +131,9 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
     int q0 = s - b * n_px16;
     while (s < s_end) {
       const int n = min(n_px16 - q0, s_end - s);  // stages of this segment: pixel groups q0 .. q0+n-1 of image b
+      // (GATHER) image b, this wave's four channels of chunk c16: scalar part of the corner addresses
+      const unsigned x_soff = __builtin_amdgcn_readfirstlane(
+          (unsigned)(((size_t)b * HW * p.C_total + p.c_base + c16 * kChunk + quad * 4) * sizeof(float)));
       const unsigned char *gq_base = reinterpret_cast<const unsigned char *>(p.wq) +
                                      ((size_t)(mt * p.N + b) * n_px16) * (size_t)(PARTS * kAPart);
 
@@ -179,20 +189,37 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
                                      kPlaneThreads / 64, dcn_plane_units(HW), wtid & 63);
       };
       // sampler: 4 pixels x 4 channels at one tap -> four 8-byte pieces of B rows (channel, tap)
-      auto sample = [&](int buf) __attribute__((always_inline)) {  // B stage (slot buf) from the records in Rs[buf] and the plane
+      // (GATHER) the corner values of a stage, fetched one body ahead of the arithmetic: [pixel][corner]
+      struct Corners {
+        f32x4 v[2][4];
+      };
+      auto gather_issue = [&](int rslot, Corners &V) __attribute__((always_inline)) {
+        const u32x4 *rr = Rs + rslot * 256 + ((pp & 1) * 4) * 32 + tl * 4 + (pp >> 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const u32x4 ro = rr[(2 * i) * 32];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) V.v[i][e] = __builtin_bit_cast(f32x4, dcn_buf_b128(x_rs, ro[e], x_soff));
+        }
+      };
+      auto sample = [&](int rslot, int buf, const Corners &V) __attribute__((always_inline)) {  // B stage (slot buf) from the records in Rs[rslot] and the plane / V
         // record pieces of pixel px = 2 pp + i sit at [piece ((px & 3) * 2 + h)][tap][px >> 2]
-        const u32x4 *rr = Rs + buf * 256 + ((pp & 1) * 4) * 32 + tl * 4 + (pp >> 1);
+        const u32x4 *rr = Rs + rslot * 256 + ((pp & 1) * 4) * 32 + tl * 4 + (pp >> 1);
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         f32x4 sv[2];  // [pixel][channel]
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const u32x4 ro = rr[(2 * i) * 32], rw = rr[(2 * i + 1) * 32];
+          u32x4 ro = {0u, 0u, 0u, 0u};
+          if constexpr (!GATHER) ro = rr[(2 * i) * 32];
+          const u32x4 rw = rr[(2 * i + 1) * 32];
           const unsigned o[4] = {ro[0], ro[1], ro[2], ro[3]};
           const float w[4] = {__uint_as_float(rw[0]), __uint_as_float(rw[1]), __uint_as_float(rw[2]), __uint_as_float(rw[3])};
           f32x2 lo2 = {0.f, 0.f}, hi2 = {0.f, 0.f};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(plane_q + o[e]);
+            f32x4 v;
+            if constexpr (GATHER) v = V.v[i][e];
+            else v = *reinterpret_cast<const f32x4 *>(plane_q + o[e]);
             const f32x2 we = {w[e], w[e]};
             lo2 = __builtin_elementwise_fma(we, f32x2{v[0], v[1]}, lo2);
             hi2 = __builtin_elementwise_fma(we, f32x2{v[2], v[3]}, hi2);
@@ -247,8 +274,11 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
 
       // Pipeline of stage s: global loads at body s-4, registers -> LDS (A ring slot s % 3, record slot s & 1) at
       // body s-2, sampled into B[s & 1] at body s-1, multiplied at body s.  Two register sets alternate.
+      // GATHER: record loads at body s-5, -> record slot s % 3 at body s-3, corner loads issued at body s-2, samples
+      // into B[s & 1] at body s-1.
       Regs RA, RB;
       AFrag FA, FB;
+      Corners V;
       __syncthreads();
       if constexpr (PRODUCER) {
         issue(0, RA);
@@ -257,7 +287,7 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
         a_issue(0, FA);
         a_issue(1, FB);
       }
-      load_plane();
+      if constexpr (!GATHER) load_plane();
       if constexpr (PRODUCER) {
         commit(0, 0, RA);
         commit(1, 1, RB);
@@ -265,31 +295,49 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
         issue(3, RB);
       }
       __syncthreads();
-      if constexpr (PRODUCER) sample(0);
+      if constexpr (PRODUCER) {
+        if constexpr (GATHER) {
+          gather_issue(0, V);
+          commit(2, 2, RA);
+          issue(4, RA);
+          sample(0, 0, V);
+          gather_issue(1, V);
+        } else {
+          sample(0, 0, V);
+        }
+      }
       __syncthreads();
       // I = body index inside the unrolled group of 6 (compile time: the LDS slots are immediates and the six
       // bodies stay distinct -- with run-time slot arithmetic hipcc merged them back into a loop and kept the
       // two register sets in scratch memory, stalling on every freshly issued load to spill it)
-      auto body = [&](auto I, int j, Regs &R, AFrag &F) __attribute__((always_inline)) {  // R holds stage j+2, F stage j
+      auto body = [&](auto I, int j, Regs &R, AFrag &F) __attribute__((always_inline)) {  // R holds stage j+2 (GATHER: j+3), F stage j
         constexpr int i = decltype(I)::value;
         if constexpr (PRODUCER) {
-          commit((i + 2) % 3, i & 1, R);
-          issue(j + 4, R);
-          if (j + 1 < n) sample((i + 1) & 1);
+          if constexpr (GATHER) {
+            if (j + 1 < n) sample((i + 1) % 3, (i + 1) & 1, V);   // V: the corners of stage j+1
+            gather_issue((i + 2) % 3, V);
+            commit(i % 3, i % 3, R);                              // stage j+3 -> the slot stage j left
+            issue(j + 5, R);
+          } else {
+            commit((i + 2) % 3, i & 1, R);
+            issue(j + 4, R);
+            if (j + 1 < n) sample((i + 1) & 1, (i + 1) & 1, V);
+          }
         } else {
           if (j < n) multiply(i % 3, i & 1, F);
           if constexpr (kAFromL2) a_issue(j + 2, F);
         }
         __syncthreads();
       };
+      // (GATHER: stage s lives in the register set of its parity, so body j takes the set of parity j+3)
       for (int j = 0; j < n; j += 6) {  // 6 = lcm(3 A slots, 2 B / record slots, 2 register sets)
-        body(std::integral_constant<int, 0>{}, j, RA, FA);
-        body(std::integral_constant<int, 1>{}, j + 1, RB, FB);
-        body(std::integral_constant<int, 2>{}, j + 2, RA, FA);
+        body(std::integral_constant<int, 0>{}, j, GATHER ? RB : RA, FA);
+        body(std::integral_constant<int, 1>{}, j + 1, GATHER ? RA : RB, FB);
+        body(std::integral_constant<int, 2>{}, j + 2, GATHER ? RB : RA, FA);
         if (j + 3 < n) {
-          body(std::integral_constant<int, 3>{}, j + 3, RB, FB);
-          body(std::integral_constant<int, 4>{}, j + 4, RA, FA);
-          body(std::integral_constant<int, 5>{}, j + 5, RB, FB);
+          body(std::integral_constant<int, 3>{}, j + 3, GATHER ? RA : RB, FB);
+          body(std::integral_constant<int, 4>{}, j + 4, GATHER ? RB : RA, FA);
+          body(std::integral_constant<int, 5>{}, j + 5, GATHER ? RA : RB, FB);
         }
       }
       s += n;
@@ -309,12 +357,22 @@ __device__ __forceinline__ void wgrad_role(const DcnFwdGroup &grp, float *__rest
 template <int PARTS>
 __global__ __launch_bounds__(kPlaneThreads, 1) void dcn_bwd_weight_plane(const DcnFwdGroup grp, float *__restrict__ slabs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if (threadIdx.x >= kThreads) wgrad_role<PARTS, true>(grp, slabs, smem);
-  else wgrad_role<PARTS, false>(grp, slabs, smem);
+  if (threadIdx.x >= kThreads) wgrad_role<PARTS, true, false>(grp, slabs, smem);
+  else wgrad_role<PARTS, false, false>(grp, slabs, smem);
 }
 
 template __global__ void dcn_bwd_weight_plane<1>(const DcnFwdGroup grp, float *__restrict__ slabs);
 template __global__ void dcn_bwd_weight_plane<2>(const DcnFwdGroup grp, float *__restrict__ slabs);
+
+// maps beyond the LDS plane: grp.gather_mode records, p.x = the pixel-major copy of x
+template <int PARTS>
+__global__ __launch_bounds__(kPlaneThreads, 1) void dcn_bwd_weight_gather(const DcnFwdGroup grp, float *__restrict__ slabs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (threadIdx.x >= kThreads) wgrad_role<PARTS, true, true>(grp, slabs, smem);
+  else wgrad_role<PARTS, false, true>(grp, slabs, smem);
+}
+
+template __global__ void dcn_bwd_weight_gather<2>(const DcnFwdGroup grp, float *__restrict__ slabs);
 
 // Fix-up: one workgroup per (problem, channel chunk c16, M tile, block of 8 output channels).  For every tap group tg of
 // the chunk it adds the slabs of tile (c16, tg) -- the workgroups' partial tiles in slice order, a fixed order -- and drops the

@@ -70,10 +70,13 @@ int dcn_bwd_offset_plane_threads();
 // grad_weight on an LDS-resident plane (dcn_backward_weight_plane.hip)
 template <int PARTS>
 __global__ void dcn_bwd_weight_plane(const DcnFwdGroup grp, float *__restrict__ slabs);
+template <int PARTS>
+__global__ void dcn_bwd_weight_gather(const DcnFwdGroup grp, float *__restrict__ slabs);
 __global__ void dcn_bwd_weight_plane_fixup(const DcnFwdGroup grp, const float *__restrict__ slabs, int G);
 __global__ void dcn_pack_grad_out(const float *__restrict__ gout, void *__restrict__ gq, int N, int O_total, int o_base,
                                   int Og, int HoWo, int n_px16, int parts);
 size_t dcn_bwd_weight_plane_lds_bytes(int parts, int HW);
+size_t dcn_bwd_weight_gather_lds_bytes(int parts);
 int dcn_bwd_weight_plane_threads();
 __global__ void dcn_pack_weight_all(const float *__restrict__ w, float *__restrict__ wpk, float *__restrict__ wpt,
                                     void *__restrict__ wq /*nullable*/, void *__restrict__ wqt /*nullable*/, int Og,

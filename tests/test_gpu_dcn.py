@@ -248,6 +248,46 @@ def test_large_map_v2_backward_is_repeatable():
         assert torch.equal(a, b)
 
 
+LARGE_WGRAD_CASES = [
+    (2, 64, 40, 48, 64, 3, 1, 1, 1, 1, 1),      # one channel run
+    (1, 64, 40, 48, 32, 3, 1, 1, 1, 2, 4),      # two weight groups x four deformable groups of 16 channels
+    (1, 48, 38, 37, 40, 5, 1, 2, 1, 1, 1),      # 5x5 (four tap groups, the last one padded), ragged last pixel stage
+    (1, 32, 80, 40, 24, 3, 2, 1, 1, 1, 1),      # stride 2: a large input map, a small output map
+]
+
+
+@pytest.mark.parametrize('with_mask', [False, True])
+@pytest.mark.parametrize('case', LARGE_WGRAD_CASES)
+def test_large_map_grad_weight_gathers_from_pixel_major_copy(case, with_mask):
+    """maps beyond the LDS plane: grad_weight on split operands, corners gathered from the pixel-major copy of x
+    (csrc/dcn_backward_weight_plane.hip dcn_bwd_weight_gather) -- against the f64 oracle, the fp32 kernel and itself"""
+    _require_gpu()
+    from kgdet_amd import dcn, _lib
+    N, C, H, W, O, k, s, p, d, g, dg = case
+    assert H * W > 1344
+    x, off, w, go, mask = _make(case, seed=9, with_mask=with_mask)
+    tx, to, tw, tg = (torch.from_numpy(a).cuda() for a in (x, off, w, go))
+    tm = torch.from_numpy(mask).cuda() if with_mask else None
+    shape = dcn._shape(tx, tw, (s, s), (p, p), (d, d), g, dg)
+    needs = dict(input=False, offset=False, mask=False, weight=True, bias=False)
+    got = [dcn._backward(tx, to, tm, tw, None, tg, shape, None, needs)[3] for _ in range(2)]
+    assert torch.equal(got[0], got[1])            # slabs added in a fixed order
+    try:
+        _lib.check(_lib.lib().kgdet_set_option(0, 1), 'kgdet_set_option')
+        exact = dcn._backward(tx, to, tm, tw, None, tg, shape, None, needs)[3]
+    except NotImplementedError:     # the fp32 kernel's channel tiles cannot straddle deformable groups (case 1)
+        assert g > 1 and dg > 1
+        exact = None
+    finally:
+        _lib.check(_lib.lib().kgdet_set_option(0, 0), 'kgdet_set_option')
+    ref = oracle.deform_conv_backward(x.astype(np.float64), off.astype(np.float64), w.astype(np.float64),
+                                      go.astype(np.float64), s, p, d, g, dg,
+                                      mask=mask.astype(np.float64) if with_mask else None)['grad_weight']
+    _close(got[0].cpu().numpy(), ref, 2e-5)
+    if exact is not None:
+        _close(exact.cpu().numpy(), ref, 2e-5)
+
+
 def test_grad_weight_deterministic():
     _require_gpu()
     from kgdet_amd import dcn
