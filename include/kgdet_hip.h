@@ -312,6 +312,9 @@ int kgdet_deform_conv_backward_input(const kgdet_dcn_shape *s, const float *inpu
  * (deform_conv_cuda.cpp:373-378, scale = 1) and the weight/bias part of
  * modulated_deform_conv_cuda_backward.  grad_weight [O, C/groups, kh, kw] is overwritten
  * (accumulate == 0) or added to (accumulate != 0); grad_bias [O] likewise when not NULL.
+ * accumulate == 0: bf16 hi/lo split MFMA kernels with natural-layout output -- an LDS-resident plane for maps up to 1344
+ * pixels, corners gathered from a pixel-major copy of the input (in the workspace) beyond; any weight groups /
+ * deformable groups of 16-channel multiples.  accumulate != 0 or KGDET_OPT_EXACT_BACKWARD: the fp32 MFMA kernel.
  */
 int kgdet_deform_conv_backward_weight(const kgdet_dcn_shape *s, const float *input, const float *offset,
                                       const float *mask /*nullable*/, const float *grad_output,
