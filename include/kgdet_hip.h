@@ -448,6 +448,21 @@ int kgdet_gn_act_forward(const float *x, const float *gamma, const float *beta, 
 int kgdet_gn_act_backward(const float *grad_y, const float *x, const float *y, const float *gamma, const float *mean,
                           const float *rstd, int32_t groups, int32_t relu, float *grad_x, float *dgamma_dbeta, int64_t N,
                           int32_t C, int64_t HW, void *stream);
+/*
+ * The same for groups of any size: beyond 65536 elements per (image, group) -- the 100 x 168 level of the five-level heads:
+ * 8 channels x 16800 pixels, 64 (image, group) pairs -- the pixels of a group are cut into kgdet_gn_act_slices(...) slices with
+ * a workgroup each (slice moments combined with the parallel-variance formula; per-channel gradient sums added in slice
+ * order: deterministic), through `scratch` of kgdet_gn_act_scratch_floats(...) floats (NULL when that is 0; the forward's and the
+ * backward's scratch need not be the same buffer).  Small groups run the kernels above.
+ */
+int32_t kgdet_gn_act_slices(int64_t N, int32_t C, int32_t groups, int64_t HW);
+size_t kgdet_gn_act_scratch_floats(int64_t N, int32_t C, int32_t groups, int64_t HW);
+int kgdet_gn_act_forward_split(const float *x, const float *gamma, const float *beta, int32_t groups, float eps, int32_t relu,
+                               float *y, float *mean, float *rstd, float *scratch, int64_t N, int32_t C, int64_t HW,
+                               void *stream);
+int kgdet_gn_act_backward_split(const float *grad_y, const float *x, const float *y, const float *gamma, const float *mean,
+                                const float *rstd, int32_t groups, int32_t relu, float *grad_x, float *dgamma_dbeta,
+                                float *scratch, int64_t N, int32_t C, int64_t HW, void *stream);
 
 /*
  * Weighted smooth-L1 sum of the head's box / keypoint losses in one pass each way: what the reference computes as a chain of

@@ -122,9 +122,240 @@ __global__ __launch_bounds__(kGnThreads) void gn_act_backward(const float *__res
   }
 }
 
+// ---- large groups (config 5's 100 x 168 level: 8 channels x 16800 pixels per group, 64 (image, group) pairs): the pixels of
+// an (image, group) are cut into S slices, one workgroup each.  Forward: slice moments (mean, centred squares; two passes over
+// the slice, the second one from L2) combined with the parallel-variance formula by every workgroup of the normalising pass.
+// Backward: per-channel (ds, db) of every slice, added in slice order by every workgroup of the pass that writes grad_x.
+// grid = (N * G, S).
+__device__ __forceinline__ void gn_slice(int HW, int S, int s, int &p0, int &p1) {
+  const int per = (HW + S - 1) / S;
+  p0 = min(HW, s * per);
+  p1 = min(HW, p0 + per);
+}
+
+__global__ __launch_bounds__(kGnThreads) void gn_split_moments(const float *__restrict__ x, float *__restrict__ parts, int C,
+                                                               int G, int HW, int S) {
+  __shared__ float red[16];
+  const int n = blockIdx.x / G, g = blockIdx.x % G, D = C / G;
+  const long long base = ((long long)n * C + (long long)g * D) * HW;
+  int p0, p1;
+  gn_slice(HW, S, blockIdx.y, p0, p1);
+  const float cnt = (float)D * (float)(p1 - p0);
+  float sum = 0.f;
+  for (int d = 0; d < D; ++d)
+    for (int p = p0 + threadIdx.x; p < p1; p += kGnThreads) sum += x[base + (long long)d * HW + p];
+  const float mean = cnt > 0.f ? gn_block_sum(sum, red) / cnt : 0.f;
+  float q = 0.f;
+  for (int d = 0; d < D; ++d)
+    for (int p = p0 + threadIdx.x; p < p1; p += kGnThreads) {
+      const float v = x[base + (long long)d * HW + p] - mean;
+      q += v * v;
+    }
+  q = gn_block_sum(q, red);
+  if (threadIdx.x == 0) {
+    float *dst = parts + ((long long)blockIdx.x * S + blockIdx.y) * 2;
+    dst[0] = mean;
+    dst[1] = q;
+  }
+}
+
+__global__ __launch_bounds__(kGnThreads) void gn_split_forward(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                               const float *__restrict__ beta, float eps, int relu,
+                                                               float *__restrict__ y, float *__restrict__ mean_out,
+                                                               float *__restrict__ rstd_out, const float *__restrict__ parts,
+                                                               int C, int G, int HW, int S) {
+  const int n = blockIdx.x / G, g = blockIdx.x % G, D = C / G;
+  const long long base = ((long long)n * C + (long long)g * D) * HW;
+  const float *pp = parts + (long long)blockIdx.x * S * 2;
+  const float total = (float)D * (float)HW;
+  float mean = 0.f;
+  for (int s = 0; s < S; ++s) {
+    int a, b;
+    gn_slice(HW, S, s, a, b);
+    mean += pp[2 * s] * ((float)D * (float)(b - a));
+  }
+  mean /= total;
+  float m2 = 0.f;
+  for (int s = 0; s < S; ++s) {
+    int a, b;
+    gn_slice(HW, S, s, a, b);
+    const float dm = pp[2 * s] - mean;
+    m2 += pp[2 * s + 1] + (float)D * (float)(b - a) * dm * dm;
+  }
+  const float rstd = 1.0f / sqrtf(m2 / total + eps);
+  if (threadIdx.x == 0 && blockIdx.y == 0) {
+    mean_out[blockIdx.x] = mean;
+    rstd_out[blockIdx.x] = rstd;
+  }
+  int p0, p1;
+  gn_slice(HW, S, blockIdx.y, p0, p1);
+  for (int d = 0; d < D; ++d) {
+    const int c = g * D + d;
+    const float sc = rstd * (gamma ? gamma[c] : 1.0f), sh = (beta ? beta[c] : 0.0f) - mean * sc;
+    const long long cb = base + (long long)d * HW;
+    for (int p = p0 + threadIdx.x; p < p1; p += kGnThreads) {
+      float v = x[cb + p] * sc + sh;
+      if (relu) v = fmaxf(v, 0.0f);
+      y[cb + p] = v;
+    }
+  }
+}
+
+// parts: [N * G][S][2][D]  (ds, then db, of the slice)
+__global__ __launch_bounds__(kGnThreads) void gn_split_bwd_sums(const float *__restrict__ gy, const float *__restrict__ x,
+                                                                const float *__restrict__ y, int relu,
+                                                                float *__restrict__ parts, int C, int G, int HW, int S) {
+  __shared__ float part_ds[64][16], part_db[64][16];   // [channel][wave slice]
+  const int n = blockIdx.x / G, g = blockIdx.x % G, D = C / G;
+  const long long base = ((long long)n * C + (long long)g * D) * HW;
+  int p0, p1;
+  gn_slice(HW, S, blockIdx.y, p0, p1);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wpc = D <= 16 ? 16 / D : 1;
+  for (int d0 = 0; d0 < D; d0 += 16 / wpc) {
+    const int d = d0 + wave / wpc, sub = wave % wpc;
+    if (d < D && wave < (16 / wpc) * wpc) {
+      const long long cb = base + (long long)d * HW;
+      float ds = 0.f, db = 0.f;
+      for (int i = p0 + sub * 64 + lane; i < p1; i += wpc * 64) {
+        float gv = gy[cb + i];
+        if (relu && !(y[cb + i] > 0.0f)) gv = 0.0f;
+        ds += gv * x[cb + i];
+        db += gv;
+      }
+#pragma unroll
+      for (int s = 32; s > 0; s >>= 1) { ds += __shfl_xor(ds, s); db += __shfl_xor(db, s); }
+      if (lane == 0) { part_ds[d][sub] = ds; part_db[d][sub] = db; }
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < D) {
+    float ds = 0.f, db = 0.f;
+    for (int s = 0; s < wpc; ++s) { ds += part_ds[threadIdx.x][s]; db += part_db[threadIdx.x][s]; }
+    float *dst = parts + ((long long)blockIdx.x * S + blockIdx.y) * 2 * D;
+    dst[threadIdx.x] = ds;
+    dst[D + threadIdx.x] = db;
+  }
+}
+
+__global__ __launch_bounds__(kGnThreads) void gn_split_backward(const float *__restrict__ gy, const float *__restrict__ x,
+                                                                const float *__restrict__ y, const float *__restrict__ gamma,
+                                                                const float *__restrict__ mean_in,
+                                                                const float *__restrict__ rstd_in, int relu,
+                                                                float *__restrict__ gx, float *__restrict__ dgb,
+                                                                const float *__restrict__ parts, int N, int C, int G, int HW,
+                                                                int S) {
+  __shared__ float ch_ds[64], ch_db[64];
+  const int n = blockIdx.x / G, g = blockIdx.x % G, D = C / G;
+  const long long base = ((long long)n * C + (long long)g * D) * HW;
+  const float mean = mean_in[blockIdx.x], rstd = rstd_in[blockIdx.x];
+  if ((int)threadIdx.x < D) {
+    const float *pp = parts + (long long)blockIdx.x * S * 2 * D;
+    float ds = 0.f, db = 0.f;
+    for (int s = 0; s < S; ++s) { ds += pp[s * 2 * D + threadIdx.x]; db += pp[s * 2 * D + D + threadIdx.x]; }
+    ch_ds[threadIdx.x] = ds;
+    ch_db[threadIdx.x] = db;
+    if (blockIdx.y == 0) {
+      const int c = g * D + threadIdx.x;
+      dgb[(long long)n * C + c] = (ds - mean * db) * rstd;
+      dgb[((long long)N + n) * C + c] = db;
+    }
+  }
+  __syncthreads();
+  if (!gx) return;
+  float S1 = 0.f, S2 = 0.f;
+  for (int d = 0; d < D; ++d) {
+    const float gm = gamma ? gamma[g * D + d] : 1.0f;
+    S1 += gm * ch_db[d];
+    S2 += gm * ch_ds[d];
+  }
+  const float inv = 1.0f / ((float)D * (float)HW);
+  const float c2 = (S1 * mean - S2) * rstd * rstd * rstd * inv;
+  const float c3 = -c2 * mean - S1 * rstd * inv;
+  int p0, p1;
+  gn_slice(HW, S, blockIdx.y, p0, p1);
+  for (int d = 0; d < D; ++d) {
+    const float gr = (gamma ? gamma[g * D + d] : 1.0f) * rstd;
+    const long long cb = base + (long long)d * HW;
+    for (int p = p0 + threadIdx.x; p < p1; p += kGnThreads) {
+      float gv = gy[cb + p];
+      if (relu && !(y[cb + p] > 0.0f)) gv = 0.0f;
+      gx[cb + p] = gv * gr + c2 * x[cb + p] + c3;
+    }
+  }
+}
+
 }  // namespace kgdet
 
 using namespace kgdet;
+
+// slices per (image, group) of the split kernels (1: the one-workgroup kernels); scratch floats they need
+namespace {
+constexpr long long kGnSplitElems = 65536;   // beyond: one workgroup per (image, group) leaves most of the chip idle
+constexpr int kGnMaxSlices = 16;
+int gn_slices(int64_t N, int32_t C, int32_t groups, int64_t HW) {
+  const long long elems = (long long)(C / groups) * HW;
+  if (elems <= kGnSplitElems) return 1;
+  long long S = (elems + 16383) / 16384;
+  while (S > 1 && N * groups * S > 1024) --S;          // (enough workgroups to fill the chip twice is plenty)
+  return (int)(S > kGnMaxSlices ? kGnMaxSlices : S);
+}
+}  // namespace
+
+extern "C" int32_t kgdet_gn_act_slices(int64_t N, int32_t C, int32_t groups, int64_t HW) {
+  if (C <= 0 || groups <= 0 || C % groups) return 1;
+  return gn_slices(N, C, groups, HW);
+}
+extern "C" size_t kgdet_gn_act_scratch_floats(int64_t N, int32_t C, int32_t groups, int64_t HW) {
+  if (C <= 0 || groups <= 0 || C % groups) return 0;
+  const int S = gn_slices(N, C, groups, HW);
+  return S > 1 ? (size_t)N * groups * S * 2 * (size_t)(C / groups) : 0;
+}
+
+extern "C" int kgdet_gn_act_forward_split(const float *x, const float *gamma, const float *beta, int32_t groups, float eps,
+                                          int32_t relu, float *y, float *mean, float *rstd, float *scratch, int64_t N,
+                                          int32_t C, int64_t HW, void *stream) {
+  KGDET_CHECK_SHAPE(N >= 0 && C > 0 && groups > 0 && C % groups == 0 && HW >= 0 && HW < (1LL << 31) &&
+                    (long long)(C / groups) * HW < (1LL << 31), "bad sizes");
+  KGDET_CHECK_SHAPE(C / groups <= 64 && N * groups < (1LL << 31), "at most 64 channels per group");
+  if (N * HW == 0) return KGDET_OK;
+  const int S = gn_slices(N, C, groups, HW);
+  KGDET_CHECK_SHAPE(x && y && mean && rstd && (S == 1 || scratch), "null pointer");
+  if (S == 1) {
+    hipLaunchKernelGGL(gn_act_forward, dim3((unsigned)(N * groups)), dim3(kGnThreads), 0, (hipStream_t)stream, x, gamma, beta,
+                       eps, relu, y, mean, rstd, C, groups, (int)HW);
+  } else {
+    hipLaunchKernelGGL(gn_split_moments, dim3((unsigned)(N * groups), S), dim3(kGnThreads), 0, (hipStream_t)stream, x, scratch,
+                       C, groups, (int)HW, S);
+    hipLaunchKernelGGL(gn_split_forward, dim3((unsigned)(N * groups), S), dim3(kGnThreads), 0, (hipStream_t)stream, x, gamma,
+                       beta, eps, relu, y, mean, rstd, (const float *)scratch, C, groups, (int)HW, S);
+  }
+  KGDET_CHECK_LAUNCH("gn_act_forward_split");
+  return KGDET_OK;
+}
+
+extern "C" int kgdet_gn_act_backward_split(const float *grad_y, const float *x, const float *y, const float *gamma,
+                                           const float *mean, const float *rstd, int32_t groups, int32_t relu, float *grad_x,
+                                           float *dgamma_dbeta, float *scratch, int64_t N, int32_t C, int64_t HW,
+                                           void *stream) {
+  KGDET_CHECK_SHAPE(N >= 0 && C > 0 && groups > 0 && C % groups == 0 && HW >= 0 && HW < (1LL << 31) &&
+                    (long long)(C / groups) * HW < (1LL << 31), "bad sizes");
+  KGDET_CHECK_SHAPE(C / groups <= 64 && N * groups < (1LL << 31), "at most 64 channels per group");
+  if (N * HW == 0) return KGDET_OK;
+  const int S = gn_slices(N, C, groups, HW);
+  KGDET_CHECK_SHAPE(grad_y && x && mean && rstd && dgamma_dbeta && (!relu || y) && (S == 1 || scratch), "null pointer");
+  if (S == 1) {
+    hipLaunchKernelGGL(gn_act_backward, dim3((unsigned)(N * groups)), dim3(kGnThreads), 0, (hipStream_t)stream, grad_y, x, y,
+                       gamma, mean, rstd, relu, grad_x, dgamma_dbeta, (int)N, C, groups, (int)HW);
+  } else {
+    hipLaunchKernelGGL(gn_split_bwd_sums, dim3((unsigned)(N * groups), S), dim3(kGnThreads), 0, (hipStream_t)stream, grad_y, x,
+                       y, relu, scratch, C, groups, (int)HW, S);
+    hipLaunchKernelGGL(gn_split_backward, dim3((unsigned)(N * groups), S), dim3(kGnThreads), 0, (hipStream_t)stream, grad_y, x,
+                       y, gamma, mean, rstd, relu, grad_x, dgamma_dbeta, (const float *)scratch, (int)N, C, groups, (int)HW, S);
+  }
+  KGDET_CHECK_LAUNCH("gn_act_backward_split");
+  return KGDET_OK;
+}
 
 extern "C" int kgdet_gn_act_forward(const float *x, const float *gamma, const float *beta, int32_t groups, float eps,
                                     int32_t relu, float *y, float *mean, float *rstd, int64_t N, int32_t C, int64_t HW,

@@ -91,14 +91,22 @@ def bias_init_with_prob(prior_prob):
 
 
 FUSED_GN = _os.environ.get('KGDET_FUSED_GN', '1') == '1'     # csrc/group_norm.hip (0: nn.GroupNorm + nn.ReLU; A/B)
-_GN_MAX_GROUP_ELEMS = 65536    # one workgroup owns an (image, group): beyond this ATen's multi-kernel route streams better
+GN_SPLIT = _os.environ.get('KGDET_GN_SPLIT', '1') == '1'     # groups beyond 65536 elements on the sliced kernels (0: ATen; A/B)
 
 
 def gn_act_applicable(x, norm):
     return (FUSED_GN and type(norm) is nn.GroupNorm and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
             and x.is_contiguous() and x.numel() > 0 and not torch.is_autocast_enabled()
             and norm.num_channels // norm.num_groups <= 64
-            and (norm.num_channels // norm.num_groups) * x.shape[2] * x.shape[3] <= _GN_MAX_GROUP_ELEMS)
+            and (norm.num_channels // norm.num_groups) * x.shape[2] * x.shape[3] < (2 ** 31 if GN_SPLIT else 65537))
+
+
+def _gn_scratch(x, N, C, groups, HW):
+    from . import _lib
+    L = _lib.lib()
+    L.kgdet_gn_act_scratch_floats.restype = ctypes.c_size_t
+    n = L.kgdet_gn_act_scratch_floats(ctypes.c_int64(N), ctypes.c_int32(C), ctypes.c_int32(groups), ctypes.c_int64(HW))
+    return torch.empty(n, dtype=torch.float32, device=x.device) if n else None
 
 
 class _GNAct(torch.autograd.Function):
@@ -111,10 +119,11 @@ class _GNAct(torch.autograd.Function):
         HW = x.shape[2] * x.shape[3]
         y = torch.empty_like(x)
         stats = torch.empty((2, N * groups), dtype=torch.float32, device=x.device)
-        _lib.check(_lib.lib().kgdet_gn_act_forward(
+        scratch = _gn_scratch(x, N, C, groups, HW)     # (large groups: slice moments, csrc/group_norm.hip)
+        _lib.check(_lib.lib().kgdet_gn_act_forward_split(
             _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), ctypes.c_int32(groups), ctypes.c_float(eps),
             ctypes.c_int32(1 if relu else 0), _lib.ptr(y), ctypes.c_void_p(stats[0].data_ptr()),
-            ctypes.c_void_p(stats[1].data_ptr()), ctypes.c_int64(N), ctypes.c_int32(C), ctypes.c_int64(HW),
+            ctypes.c_void_p(stats[1].data_ptr()), _lib.ptr(scratch), ctypes.c_int64(N), ctypes.c_int32(C), ctypes.c_int64(HW),
             _lib.current_stream()), 'gn_act_forward')
         ctx.save_for_backward(x, y if relu else None, gamma, stats)
         ctx.groups, ctx.relu, ctx.has_beta = groups, relu, beta is not None
@@ -129,11 +138,12 @@ class _GNAct(torch.autograd.Function):
         gy = gy.contiguous()
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dgb = torch.empty((2, N, C), dtype=torch.float32, device=x.device)
-        _lib.check(_lib.lib().kgdet_gn_act_backward(
+        scratch = _gn_scratch(x, N, C, ctx.groups, HW)
+        _lib.check(_lib.lib().kgdet_gn_act_backward_split(
             _lib.ptr(gy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(gamma), ctypes.c_void_p(stats[0].data_ptr()),
             ctypes.c_void_p(stats[1].data_ptr()), ctypes.c_int32(ctx.groups), ctypes.c_int32(1 if ctx.relu else 0),
-            _lib.ptr(gx), _lib.ptr(dgb), ctypes.c_int64(N), ctypes.c_int32(C), ctypes.c_int64(HW), _lib.current_stream()),
-            'gn_act_backward')
+            _lib.ptr(gx), _lib.ptr(dgb), _lib.ptr(scratch), ctypes.c_int64(N), ctypes.c_int32(C), ctypes.c_int64(HW),
+            _lib.current_stream()), 'gn_act_backward')
         sums = dgb.sum(1) if N > 1 else dgb[:, 0]
         ggamma = sums[0] if (gamma is not None and ctx.needs_input_grad[1]) else None
         gbeta = sums[1] if (ctx.has_beta and ctx.needs_input_grad[2]) else None

@@ -419,7 +419,10 @@ def test_fused_smooth_l1_matches_reference_chain(shape, beta, divisor, with_weig
 
 @pytest.mark.parametrize('relu', [True, False])
 @pytest.mark.parametrize('N,C,G,H,W', [(2, 256, 32, 25, 42), (2, 256, 32, 13, 21), (1, 64, 32, 7, 5), (3, 96, 4, 16, 20),
-                                       (2, 256, 32, 50, 84)])
+                                       (2, 256, 32, 50, 84),
+                                       (2, 256, 32, 100, 168),      # 134400 elements per group: 9 pixel slices (config 5, stride 8)
+                                       (1, 64, 2, 75, 61),          # 32 channels per group, ragged slices
+                                       (1, 48, 1, 40, 40)])         # 48 channels per group: one wave per channel, 5 slices
 def test_fused_group_norm_relu_matches_torch(N, C, G, H, W, relu):
     """GroupNorm (+ ReLU) of a ConvModule on csrc/group_norm.hip (one pass each way) against nn.GroupNorm + F.relu in fp64:
     output, grad_x, grad_gamma, grad_beta to fp32 rounding of their scales"""
