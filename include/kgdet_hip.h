@@ -411,6 +411,10 @@ int kgdet_head_loss_backward(const kgdet_head_targets *t, const kgdet_head_loss_
  *   slices (NULL grad_k: zeros), 0 on the channels beyond them.
  * kgdet_subsample2_*: y = x[:, :, ::2, ::2] of [planes, H, W] and grad_x = zero-stuffed grad_y (+ other, nullable) -- the
  *   stride-2 1x1 downsample branch of resnet.py:180-186 as a 1x1 convolution of the subsampled input; backward needs W % 4 == 0.
+ * kgdet_pts_from_offsets_*: a level's predicted offsets pred [B, C = 2n, HW] as image coordinates pts [B, HW, 2n] =
+ *   offset * stride + centre with (x, y) interleaved -- offset_to_pts of reppoints_head_kp_serial.py:400-421 (permute, flip when
+ *   the channels are (y, x) pairs: y_first, multiply, add) in one pass; centres [B, HW, 2] = (x, y).  Values equal the torch
+ *   chain's bit for bit (separate multiply and add).  Backward: grad_pred = transposed (pair-swapped) grad_pts * stride.
  * ------------------------------------------------------------------------------------------ */
 int kgdet_reppts_offsets_forward(const float *reppts, int32_t B, int32_t C, int32_t HW, const int32_t *kernel_sizes, float gm,
                                  float *out0, float *out1, float *out2, void *stream);
@@ -419,6 +423,10 @@ int kgdet_reppts_offsets_backward(const float *g0, const float *g1, const float 
 int kgdet_subsample2_forward(const float *x, float *y, int64_t planes, int32_t H, int32_t W, void *stream);
 int kgdet_subsample2_backward(const float *grad_y, const float *other /*nullable*/, float *grad_x, int64_t planes, int32_t H,
                               int32_t W, void *stream);
+int kgdet_pts_from_offsets_forward(const float *pred, const float *centres, float *pts, int64_t B, int32_t C, int64_t HW,
+                                   float stride, int32_t y_first, void *stream);
+int kgdet_pts_from_offsets_backward(const float *grad_pts, float *grad_pred, int64_t B, int32_t C, int64_t HW, float stride,
+                                    int32_t y_first, void *stream);
 
 /*
  * Gradient clipping + Adam over all parameters as multi-tensor passes: what OptimizerHook.after_train_iter does with

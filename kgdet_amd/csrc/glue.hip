@@ -9,6 +9,10 @@
 //    resnet.py:180-186 runs as a 1x1 convolution of the subsampled input) and its backward
 //    grad_x = zero-stuffed grad_xs [+ other] in ONE pass: `other` is the gradient the trunk already holds for x, so the
 //    zero fill, the strided scatter and the accumulation of the torch chain are one write of grad_x.
+//  pts_from_offsets_forward / _backward: a level's predicted offsets [B, 2n, H, W] (channel = (point, y | x)) as image
+//    coordinates [B, H*W, 2n] (x, y interleaved) = offset * stride + centre (reppoints_head_kp_serial.py offset_to_pts:
+//    permute + reshape copy, flip, multiply, add -- four passes over a [2, 588, 100, 168] tensor, and their four backward
+//    passes): a 32-pixel x 64-channel transpose through LDS, the pair swap in the channel index.
 #include "common.h"
 
 // (the offsets must equal torch's separate multiply / multiply / add / subtract bit for bit)
@@ -88,6 +92,47 @@ __global__ __launch_bounds__(256) void subsample2_backward(const float *__restri
   }
 }
 
+// pred [B][C][HW] -> out [B][HW][C]: out[b][p][c ^ swap] = pred[b][c][p] * stride + centres[b][p][(c ^ swap) & 1]
+// BACKWARD == true: the other way round, grad_pred[b][c][p] = g[b][p][c ^ swap] * stride.
+// grid = (ceil(HW / 32), ceil(C / 64), B), 256 threads.
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void pts_from_offsets(const float *__restrict__ src, const float *__restrict__ centres,
+                                                        float *__restrict__ dst, int C, int HW, float stride, int swap) {
+  __shared__ float tile[64][33];
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 64, b = blockIdx.z;
+  const float *pred = (BACKWARD ? dst : src) + (long long)b * C * HW;       // channel-major side
+  const float *pts = (BACKWARD ? src : dst) + (long long)b * HW * C;        // pixel-major side
+  const int tid = threadIdx.x;
+  if constexpr (!BACKWARD) {
+    const int px = tid & 31;
+    for (int r = tid >> 5; r < 64; r += 8) {
+      const int c = c0 + r, p = p0 + px;
+      tile[r][px] = (c < C && p < HW) ? pred[(long long)c * HW + p] : 0.0f;
+    }
+    __syncthreads();
+    const int cc = tid & 63;
+    for (int r = tid >> 6; r < 32; r += 4) {
+      const int p = p0 + r, co = c0 + cc;            // output channel; its source channel is co ^ swap (same 64-block)
+      if (p < HW && co < C) {
+        const float v = tile[cc ^ swap][r] * stride;
+        const_cast<float *>(pts)[(long long)p * C + co] = v + centres[((long long)b * HW + p) * 2 + (co & 1)];
+      }
+    }
+  } else {
+    const int cc = tid & 63;
+    for (int r = tid >> 6; r < 32; r += 4) {
+      const int p = p0 + r, co = c0 + cc;
+      tile[cc][r] = (p < HW && co < C) ? pts[(long long)p * C + co] : 0.0f;
+    }
+    __syncthreads();
+    const int px = tid & 31;
+    for (int r = tid >> 5; r < 64; r += 8) {
+      const int c = c0 + r, p = p0 + px;
+      if (c < C && p < HW) const_cast<float *>(pred)[(long long)c * HW + p] = tile[r ^ swap][px] * stride;
+    }
+  }
+}
+
 }  // namespace kgdet
 
 using namespace kgdet;
@@ -148,6 +193,26 @@ int kgdet_subsample2_backward(const float *grad_y, const float *other, float *gr
   hipLaunchKernelGGL(subsample2_backward, dim3((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, grad_y, other, grad_x, (long long)planes, H, W, Ho, Wo);
   KGDET_CHECK_LAUNCH("subsample2_backward");
+  return KGDET_OK;
+}
+
+int kgdet_pts_from_offsets_forward(const float *pred, const float *centres, float *pts, int64_t B, int32_t C, int64_t HW,
+                                   float stride, int32_t y_first, void *stream) {
+  KGDET_CHECK_SHAPE(pred && centres && pts && B > 0 && C > 0 && C % 2 == 0 && HW > 0 && HW < (1LL << 31) && B < 65536,
+                    "bad arguments");
+  hipLaunchKernelGGL(pts_from_offsets<false>, dim3((unsigned)((HW + 31) / 32), (unsigned)((C + 63) / 64), (unsigned)B), dim3(256), 0,
+                     (hipStream_t)stream, pred, centres, pts, C, (int)HW, stride, y_first ? 1 : 0);
+  KGDET_CHECK_LAUNCH("pts_from_offsets_forward");
+  return KGDET_OK;
+}
+
+int kgdet_pts_from_offsets_backward(const float *grad_pts, float *grad_pred, int64_t B, int32_t C, int64_t HW, float stride,
+                                    int32_t y_first, void *stream) {
+  KGDET_CHECK_SHAPE(grad_pts && grad_pred && B > 0 && C > 0 && C % 2 == 0 && HW > 0 && HW < (1LL << 31) && B < 65536,
+                    "bad arguments");
+  hipLaunchKernelGGL(pts_from_offsets<true>, dim3((unsigned)((HW + 31) / 32), (unsigned)((C + 63) / 64), (unsigned)B), dim3(256), 0,
+                     (hipStream_t)stream, grad_pts, (const float *)nullptr, grad_pred, C, (int)HW, stride, y_first ? 1 : 0);
+  KGDET_CHECK_LAUNCH("pts_from_offsets_backward");
   return KGDET_OK;
 }
 

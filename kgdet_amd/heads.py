@@ -45,6 +45,37 @@ def _base_offset(k):
 _FUSED_OFFSETS = os.environ.get('KGDET_FUSED_OFFSETS', '1') == '1'     # 0: the torch chain (A/B)
 
 
+class _PtsFromOffsets(torch.autograd.Function):
+    """offsets [B, 2n, H, W] -> image coordinates [B, H*W, 2n] = offset * stride + centre, (x, y) interleaved: the permute /
+    flip / multiply / add chain of offset_to_pts (SER:400-421) as one pass each way (csrc/glue.hip); same values bit for bit"""
+
+    @staticmethod
+    def forward(ctx, pred, centres, stride, y_first):
+        from . import _lib
+        pred = pred.contiguous()
+        B, C, H, W = pred.shape
+        pts = pred.new_empty(B, H * W, C)
+        _lib.check(_lib.lib().kgdet_pts_from_offsets_forward(
+            _lib.ptr(pred), _lib.ptr(centres.contiguous()), _lib.ptr(pts), ctypes.c_int64(B), ctypes.c_int32(C),
+            ctypes.c_int64(H * W), ctypes.c_float(stride), ctypes.c_int32(1 if y_first else 0), _lib.current_stream()),
+            'pts_from_offsets_forward')
+        ctx.shape, ctx.stride, ctx.y_first = (B, C, H, W), stride, y_first
+        return pts
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from . import _lib
+        B, C, H, W = ctx.shape
+        g = g.contiguous()
+        grad = g.new_empty(B, C, H, W)
+        _lib.check(_lib.lib().kgdet_pts_from_offsets_backward(
+            _lib.ptr(g), _lib.ptr(grad), ctypes.c_int64(B), ctypes.c_int32(C), ctypes.c_int64(H * W),
+            ctypes.c_float(ctx.stride), ctypes.c_int32(1 if ctx.y_first else 0), _lib.current_stream()),
+            'pts_from_offsets_backward')
+        return grad, None, None, None
+
+
 class _RepOffsets(torch.autograd.Function):
     """reppoints [B, >= 166, H, W] -> the three offset tensors of a Kp3RepBlock; the value is the reference's
     ``gm * part + (1 - gm) * part.detach() - base`` expression, the gradient ``gm * grad`` (csrc/glue.hip)"""
@@ -247,6 +278,11 @@ class PointHeadMixin(object):
         for i_lvl in range(len(self.point_strides)):
             pred = pred_list[i_lvl]                                       # [B, 2n, H, W]
             B = pred.shape[0]
+            if (_FUSED_OFFSETS and pred.is_cuda and pred.dtype == torch.float32 and not torch.is_autocast_enabled()
+                    and pred.numel() > 0):
+                centers = torch.stack([center_list[i_img][i_lvl][:, :2] for i_img in range(B)], 0)
+                pts_list.append(_PtsFromOffsets.apply(pred, centers, float(self.point_strides[i_lvl]), bool(y_first)))
+                continue
             shift = pred.permute(0, 2, 3, 1).reshape(B, -1, num_points, 2)
             if y_first:
                 shift = shift.flip(-1)                                    # (y, x) -> (x, y)

@@ -171,8 +171,11 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
             reppts_out_init = self.reppts_init_out(conv1x1.conv_bias_act(self.reppts_init_conv, pts_feat, relu=True))
         else:
             reppts_out_init = self.reppts_init_out(keypts_out_init)
-        reppts_out_init = reppts_out_init + reppts_init
-        keypts_out_init = keypts_out_init + keypts_init
+        # (adding the integer 0 of the centre-init case would be a pass over a [B, 588, H, W] tensor for nothing)
+        if not (isinstance(reppts_init, int) and reppts_init == 0):
+            reppts_out_init = reppts_out_init + reppts_init
+        if not (isinstance(keypts_init, int) and keypts_init == 0):
+            keypts_out_init = keypts_out_init + keypts_init
         # refine stage: taps on the (gradient-scaled) init reppoints
         grad_mul = self.gradient_mul * reppts_out_init + (1 - self.gradient_mul) * reppts_out_init.detach()
         dcn_offset = grad_mul - dcn_base_offset

@@ -518,3 +518,35 @@ def test_moment_bbox_backward_is_bit_repeatable():
     p64 = pts.detach().double().requires_grad_()
     _moment_ref(p64, ref_mt, True).backward(go.double())
     assert (res[0][1].double() - ref_mt.grad).abs().max() <= 1e-5 * ref_mt.grad.abs().max()
+
+
+@pytest.mark.parametrize('y_first', [True, False])
+@pytest.mark.parametrize('B,C,H,W,stride', [(2, 588, 25, 42, 32), (2, 18, 13, 21, 64), (1, 34, 7, 11, 128), (3, 130, 5, 9, 8)])
+def test_fused_offset_to_pts_equals_the_torch_chain(B, C, H, W, stride, y_first):
+    """offset_to_pts (reppoints_head_kp_serial.py:400-421) as one HIP pass each way (csrc/glue.hip): values and gradients
+    bit-identical to the permute / flip / multiply / add chain"""
+    from kgdet_amd import heads
+    torch.manual_seed(C)
+    pred = torch.randn(B, C, H, W, device='cuda', requires_grad=True)
+    pts = torch.stack(torch.meshgrid(torch.arange(W, device='cuda') * float(stride), torch.arange(H, device='cuda') * float(stride),
+                                     indexing='xy'), -1).reshape(-1, 2)
+    centre = torch.cat([pts, torch.full((H * W, 1), float(stride), device='cuda')], 1)
+
+    class _Head(heads.PointHeadMixin):
+        point_strides = [stride]
+
+    center_list = [[centre.clone()] for _ in range(B)]
+    g = torch.randn(B, H * W, C, device='cuda')
+    outs = []
+    for fused in (True, False):
+        heads._FUSED_OFFSETS = fused
+        try:
+            p = pred.detach().clone().requires_grad_()
+            out = _Head().offset_to_pts(center_list, [p], y_first=y_first)[0]
+            out.backward(g)
+            outs.append((out.detach(), p.grad))
+        finally:
+            heads._FUSED_OFFSETS = True
+    assert outs[0][0].shape == (B, H * W, C)
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
