@@ -22,6 +22,7 @@ import torch.nn as nn
 from . import conv1x1, dcn
 from .heads import PointHeadMixin
 from .layers import ConvModule, bias_init_with_prob, normal_init
+from .losses import SmoothL1Loss
 import os
 
 from .points import (PointGenerator, dense_targets_applicable, multi_apply, point_target_kp,
@@ -205,13 +206,17 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
         normalize_term = self.point_base_scale * stride
         bbox_pred_init = self.points2bbox(rep_pred_init.reshape(-1, 2 * self.num_reppts), y_first=False)
         bbox_pred_refine = self.points2bbox(rep_pred_refine.reshape(-1, 2 * self.num_reppts), y_first=False)
-        loss_bbox_init = self.loss_bbox_init(bbox_pred_init / normalize_term,
-                                             bbox_gt_init.reshape(-1, 4) / normalize_term,
-                                             bbox_weights_init.reshape(-1, 4), avg_factor=num_total_samples_init)
-        loss_bbox_refine = self.loss_bbox_refine(bbox_pred_refine / normalize_term,
-                                                 bbox_gt_refine.reshape(-1, 4) / normalize_term,
-                                                 bbox_weights_refine.reshape(-1, 4),
-                                                 avg_factor=num_total_samples_refine)
+        # (SmoothL1Loss takes the normalisation as `divisor`: the fused op reads the raw tensors -- no pred / d, target / d
+        #  passes over [points, 588] tensors; same values)
+        def normalised(loss_fn, pred, gt, weights, avg):
+            if isinstance(loss_fn, SmoothL1Loss):
+                return loss_fn(pred, gt, weights, avg_factor=avg, divisor=normalize_term)
+            return loss_fn(pred / normalize_term, gt / normalize_term, weights, avg_factor=avg)
+
+        loss_bbox_init = normalised(self.loss_bbox_init, bbox_pred_init, bbox_gt_init.reshape(-1, 4),
+                                    bbox_weights_init.reshape(-1, 4), num_total_samples_init)
+        loss_bbox_refine = normalised(self.loss_bbox_refine, bbox_pred_refine, bbox_gt_refine.reshape(-1, 4),
+                                      bbox_weights_refine.reshape(-1, 4), num_total_samples_refine)
 
         def kpt_loss(loss_fn, pred, gt, weights, avg):
             # SER:469-477 normalises in place; with one image per GPU the per-level targets are views of one
@@ -221,8 +226,7 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
             #  boolean-mask update, without its device->host round trip)
             weights = weights.reshape(-1, self.num_keypts * 2)
             weights = weights / weights.sum(1).clamp(min=1).unsqueeze(1)
-            return loss_fn(pred.reshape(-1, self.num_keypts * 2) / normalize_term,
-                           gt.reshape(-1, self.num_keypts * 2) / normalize_term, weights, avg_factor=avg)
+            return normalised(loss_fn, pred.reshape(-1, self.num_keypts * 2), gt.reshape(-1, self.num_keypts * 2), weights, avg)
 
         loss_kpt_init = kpt_loss(self.loss_kpt_init, kpt_pred_init, kpt_gt_init, kpt_weights_init,
                                  num_total_samples_init)
