@@ -29,32 +29,42 @@ __device__ __forceinline__ float gn_block_sum(float v, float *red) {   // all th
 }
 }  // namespace
 
-__global__ __launch_bounds__(kGnThreads) void gn_act_forward(const float *__restrict__ x, const float *__restrict__ gamma,
+// T = float, or __bf16 (autocast inference: torch runs group_norm in fp32 between a bf16 -> fp32 cast of the convolution's output
+// and the fp32 -> bf16 cast in front of the next convolution; here the bf16 tensor is read and written directly, fp32 arithmetic,
+// one rounding at the same place)
+// NHWC: x is channels-last ([N][HW][C], the layout the inference backbone / neck hand over); y is always [N][C][HW].
+template <typename T, bool NHWC = false>
+__global__ __launch_bounds__(kGnThreads) void gn_act_forward(const T *__restrict__ x, const float *__restrict__ gamma,
                                                              const float *__restrict__ beta, float eps, int relu,
-                                                             float *__restrict__ y, float *__restrict__ mean_out,
+                                                             T *__restrict__ y, float *__restrict__ mean_out,
                                                              float *__restrict__ rstd_out, int C, int G, int HW) {
   __shared__ float red[16];
   const int n = blockIdx.x / G, g = blockIdx.x % G, D = C / G;
-  const long long base = ((long long)n * C + (long long)g * D) * HW;
+  const long long base = ((long long)n * C + (long long)g * D) * HW;      // of the group in [N][C][HW]
+  const long long xbase = NHWC ? (long long)n * HW * C + (long long)g * D : base;
   const int total = D * HW;
+  // element i of the group: NHWC walks the D channels of a pixel first (contiguous in x)
+  auto x_at = [&](int i) { return NHWC ? xbase + (long long)(i / D) * C + (i % D) : xbase + i; };
   float s = 0.f;
-  for (int i = threadIdx.x; i < total; i += kGnThreads) s += x[base + i];
+  for (int i = threadIdx.x; i < total; i += kGnThreads) s += (float)x[x_at(i)];
   const float mean = gn_block_sum(s, red) / (float)total;
   float q = 0.f;
   for (int i = threadIdx.x; i < total; i += kGnThreads) {
-    const float d = x[base + i] - mean;
+    const float d = (float)x[x_at(i)] - mean;
     q += d * d;
   }
   const float rstd = 1.0f / sqrtf(gn_block_sum(q, red) / (float)total + eps);
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && mean_out) {
     mean_out[blockIdx.x] = mean;
     rstd_out[blockIdx.x] = rstd;
   }
-  for (int i = threadIdx.x; i < total; i += kGnThreads) {
-    const int c = g * D + i / HW;
-    float v = (x[base + i] - mean) * rstd * (gamma ? gamma[c] : 1.0f) + (beta ? beta[c] : 0.0f);
+  for (int i = threadIdx.x; i < total; i += kGnThreads) {   // (in y's order)
+    const int d = i / HW, p = i - d * HW;
+    const int c = g * D + d;
+    const float xv = (float)x[NHWC ? xbase + (long long)p * C + d : xbase + i];
+    float v = (xv - mean) * rstd * (gamma ? gamma[c] : 1.0f) + (beta ? beta[c] : 0.0f);
     if (relu) v = fmaxf(v, 0.0f);
-    y[base + i] = v;
+    y[base + i] = (T)v;
   }
 }
 
@@ -322,7 +332,7 @@ extern "C" int kgdet_gn_act_forward_split(const float *x, const float *gamma, co
   const int S = gn_slices(N, C, groups, HW);
   KGDET_CHECK_SHAPE(x && y && mean && rstd && (S == 1 || scratch), "null pointer");
   if (S == 1) {
-    hipLaunchKernelGGL(gn_act_forward, dim3((unsigned)(N * groups)), dim3(kGnThreads), 0, (hipStream_t)stream, x, gamma, beta,
+    hipLaunchKernelGGL(gn_act_forward<float>, dim3((unsigned)(N * groups)), dim3(kGnThreads), 0, (hipStream_t)stream, x, gamma, beta,
                        eps, relu, y, mean, rstd, C, groups, (int)HW);
   } else {
     hipLaunchKernelGGL(gn_split_moments, dim3((unsigned)(N * groups), S), dim3(kGnThreads), 0, (hipStream_t)stream, x, scratch,
@@ -357,6 +367,25 @@ extern "C" int kgdet_gn_act_backward_split(const float *grad_y, const float *x, 
   return KGDET_OK;
 }
 
+// bf16 in, bf16 out, fp32 arithmetic (inference under autocast); groups of at most 65536 elements
+extern "C" int kgdet_gn_act_forward_bf16(const void *x, int32_t x_channels_last, const float *gamma, const float *beta,
+                                         int32_t groups, float eps, int32_t relu, void *y, int64_t N, int32_t C, int64_t HW,
+                                         void *stream) {
+  KGDET_CHECK_SHAPE(N >= 0 && C > 0 && groups > 0 && C % groups == 0 && HW >= 0 && (long long)(C / groups) * HW <= kGnSplitElems,
+                    "bad sizes (at most %lld elements per group)", kGnSplitElems);
+  KGDET_CHECK_SHAPE(C / groups <= 64 && N * groups < (1LL << 31), "at most 64 channels per group");
+  if (N * HW == 0) return KGDET_OK;
+  KGDET_CHECK_SHAPE(x && y, "null pointer");
+  if (x_channels_last)
+    hipLaunchKernelGGL((gn_act_forward<__bf16, true>), dim3((unsigned)(N * groups)), dim3(kGnThreads), 0, (hipStream_t)stream,
+                       (const __bf16 *)x, gamma, beta, eps, relu, (__bf16 *)y, (float *)nullptr, (float *)nullptr, C, groups, (int)HW);
+  else
+    hipLaunchKernelGGL((gn_act_forward<__bf16, false>), dim3((unsigned)(N * groups)), dim3(kGnThreads), 0, (hipStream_t)stream,
+                       (const __bf16 *)x, gamma, beta, eps, relu, (__bf16 *)y, (float *)nullptr, (float *)nullptr, C, groups, (int)HW);
+  KGDET_CHECK_LAUNCH("gn_act_forward_bf16");
+  return KGDET_OK;
+}
+
 extern "C" int kgdet_gn_act_forward(const float *x, const float *gamma, const float *beta, int32_t groups, float eps,
                                     int32_t relu, float *y, float *mean, float *rstd, int64_t N, int32_t C, int64_t HW,
                                     void *stream) {
@@ -365,7 +394,7 @@ extern "C" int kgdet_gn_act_forward(const float *x, const float *gamma, const fl
   KGDET_CHECK_SHAPE(C / groups <= 64 && N * groups < (1LL << 31), "at most 64 channels per group");
   if (N * HW == 0) return KGDET_OK;
   KGDET_CHECK_SHAPE(x && y && mean && rstd, "null pointer");
-  hipLaunchKernelGGL(gn_act_forward, dim3((unsigned)(N * groups)), dim3(kGnThreads), 0, (hipStream_t)stream, x, gamma, beta, eps,
+  hipLaunchKernelGGL(gn_act_forward<float>, dim3((unsigned)(N * groups)), dim3(kGnThreads), 0, (hipStream_t)stream, x, gamma, beta, eps,
                      relu, y, mean, rstd, C, groups, (int)HW);
   KGDET_CHECK_LAUNCH("gn_act_forward");
   return KGDET_OK;

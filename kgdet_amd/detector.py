@@ -13,6 +13,9 @@ import torch.nn as nn
 from .registry import DETECTORS, build_backbone, build_head, build_neck
 
 
+_PINNED_RESULTS = __import__('os').environ.get('KGDET_PINNED_RESULTS', '1') == '1'    # 0: `.cpu()` into pageable memory (A/B)
+
+
 @DETECTORS.register_module
 class RepPointsDetectorKp(nn.Module):
 
@@ -91,7 +94,8 @@ class RepPointsDetectorKp(nn.Module):
         long as the GPU needs to run them; backbone, neck, head, decode and the fused NMS have no host read, so the
         whole chain is captured once (``torch.cuda.CUDAGraph`` = hipGraph) and replayed per batch, followed by the
         single device->host copy of the packed results.  Returns ``run(img) -> results`` (same results as
-        ``simple_test_batch``); raises NotImplementedError when the head's packed post-processing does not apply."""
+        ``simple_test_batch``); ``run.static_img`` is the graph's input buffer -- ``run(run.static_img)`` after writing the
+        batch into it (e.g. as the destination of the loader's host->device copy) skips the 103 MB device copy; raises NotImplementedError when the head's packed post-processing does not apply."""
         import contextlib
         assert img.is_cuda and not self.training
         scope = (lambda: torch.autocast('cuda', dtype=autocast_dtype)) if autocast_dtype is not None \
@@ -115,11 +119,22 @@ class RepPointsDetectorKp(nn.Module):
             static_out = chain()
         num_classes = self.bbox_head.num_classes
 
+        # the results land in a page-locked buffer (a `.cpu()` into pageable memory is staged by the driver: 232 us for the
+        # 2.8 MB of a batch of 8 against ~60); bbox2result_kp copies the valid rows out of it, so it is reused per batch
+        host_out = torch.empty(static_out.shape, dtype=static_out.dtype, pin_memory=True)
+
         def run(new_img):
-            static_img.copy_(new_img)
+            if new_img is not static_img:       # (run.static_img IS the input buffer: a loader that writes into it saves the copy)
+                static_img.copy_(new_img)
             graph.replay()
-            dets = self.bbox_head.unpack_results(static_out.cpu().numpy())
-            return [self.bbox2result_kp(d, lab, k, num_classes) for d, lab, k in dets]
+            if _PINNED_RESULTS:
+                host_out.copy_(static_out, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                dets = self.bbox_head.unpack_results(host_out.numpy())
+            else:
+                dets = self.bbox_head.unpack_results(static_out.cpu().numpy())
+            # (d.copy(): the score column of the result is a view of d; labels and the per-class rows are copies already)
+            return [self.bbox2result_kp(d.copy(), lab, k, num_classes) for d, lab, k in dets]
 
         run.graph, run.static_img, run.static_out = graph, static_img, static_out
         # The captured kernels hold raw pointers into the module-level weight-image caches (packed deformable-conv

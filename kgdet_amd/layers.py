@@ -109,6 +109,27 @@ def _gn_scratch(x, N, C, groups, HW):
     return torch.empty(n, dtype=torch.float32, device=x.device) if n else None
 
 
+def gn_act_bf16_applicable(x, norm):
+    """inference under autocast: the convolution in front hands over bf16; torch would cast to fp32, normalise in three
+    launches, apply the ReLU and cast back in front of the next convolution"""
+    return (FUSED_GN and type(norm) is nn.GroupNorm and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4
+            and (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last))
+            and x.numel() > 0 and not torch.is_grad_enabled()
+            and norm.num_channels // norm.num_groups <= 64
+            and (norm.num_channels // norm.num_groups) * x.shape[2] * x.shape[3] <= 65536)
+
+
+def gn_act_bf16(x, norm, relu):
+    from . import _lib
+    N, C = x.shape[0], x.shape[1]
+    y = torch.empty(x.shape, dtype=x.dtype, device=x.device)      # (contiguous, whatever x's layout)
+    _lib.check(_lib.lib().kgdet_gn_act_forward_bf16(
+        _lib.ptr(x), ctypes.c_int32(0 if x.is_contiguous() else 1), _lib.ptr(norm.weight), _lib.ptr(norm.bias), ctypes.c_int32(norm.num_groups), ctypes.c_float(norm.eps),
+        ctypes.c_int32(1 if relu else 0), _lib.ptr(y), ctypes.c_int64(N), ctypes.c_int32(C),
+        ctypes.c_int64(x.shape[2] * x.shape[3]), _lib.current_stream()), 'gn_act_forward_bf16')
+    return y
+
+
 class _GNAct(torch.autograd.Function):
     """``[relu](group_norm(x))`` (conv_module.py:142-165: norm, then activate) on csrc/group_norm.hip"""
 
@@ -224,6 +245,9 @@ class ConvModule(nn.Module):
                              and self.order[li + 1] == 'act')
                 if gn_act_applicable(x, self.norm):
                     x = gn_act(x, self.norm, relu_next)     # GroupNorm (+ the ReLU that follows) as one HIP pass each way
+                    fused_act = relu_next
+                elif gn_act_bf16_applicable(x, self.norm):
+                    x = gn_act_bf16(x, self.norm, relu_next)
                     fused_act = relu_next
                 else:
                     x = self.norm(x)

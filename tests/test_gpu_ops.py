@@ -550,3 +550,32 @@ def test_fused_offset_to_pts_equals_the_torch_chain(B, C, H, W, stride, y_first)
     assert outs[0][0].shape == (B, H * W, C)
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize('channels_last', [False, True])
+@pytest.mark.parametrize('relu', [True, False])
+def test_bf16_group_norm_relu_equals_autocast_chain(relu, channels_last):
+    """inference under autocast: GroupNorm (+ ReLU) reading and writing bf16 (csrc/group_norm.hip gn_act_forward<bf16>) against
+    torch's chain -- bf16 -> fp32 cast, fp32 group_norm, ReLU, fp32 -> bf16 cast: the same tensor up to one bf16 ulp where the fp32
+    results differ in rounding"""
+    import torch.nn.functional as F
+    from kgdet_amd import layers
+    torch.manual_seed(3)
+    gn = torch.nn.GroupNorm(32, 256).cuda()
+    gn.weight.data.normal_(1.0, 0.5)
+    gn.bias.data.normal_(0, 0.5)
+    x = (torch.randn(8, 256, 25, 42, device='cuda') * 3 + 1).bfloat16()
+    if channels_last:
+        x = x.contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        assert layers.gn_act_bf16_applicable(x, gn)
+        got = layers.gn_act_bf16(x, gn, relu)
+        want = F.group_norm(x.float(), 32, gn.weight, gn.bias, gn.eps)
+        if relu:
+            want = want.relu()
+        want_b = want.bfloat16()
+    assert got.dtype == torch.bfloat16 and got.shape == x.shape and got.is_contiguous()
+    diff = (got.float() - want_b.float()).abs()
+    ulp = want.abs().clamp(min=2.0 ** -10) * 2.0 ** -7     # one bf16 step at the value's magnitude
+    assert (diff <= ulp).all()
+    assert (diff > 0).float().mean().item() < 0.01         # and almost everywhere the very same bf16 value
