@@ -200,6 +200,7 @@ bool plane_ok(const kgdet_dcn_shape *s, const Derived &d) {
 bool gather_ok(const kgdet_dcn_shape *s, const Derived &d) {
   const int cpdg = s->C / s->deformable_groups;
   return mfma_ok(s) && (s->deformable_groups == 1 || cpdg % 16 == 0) && !plane_ok(s, d) &&
+         s->C % 4 == 0 &&                                     // (a pixel's channel quads are 16-byte loads)
          (size_t)s->N * s->H * s->W * s->C * 4 < ((size_t)1 << 32) - 4096 &&
          (size_t)s->N * s->deformable_groups * d.K * d.Ho * d.Wo * sizeof(DcnTapRec) < ((size_t)1 << 32) &&
          (size_t)8 * 33 * (d.K + 1) * sizeof(float) <= kMaxLds - 64;
