@@ -401,6 +401,25 @@ class _ConvBiasAct(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+CACHE_INFER_CASTS = _os.environ.get('KGDET_CACHE_INFER_CASTS', '1') == '1'     # 0: autocast casts weights and biases per batch (A/B)
+
+
+def conv_infer(conv, x):
+    """``conv(x)``; inference under autocast keeps the reduced-precision copies of weight and bias across batches (autocast's own
+    cache ends with its context: a batch re-cast the head's nine 3x3 weights, the 1x1 output weights and every bias -- ~30 launches,
+    ~120 us of a 7 ms batch).  The copies follow the parameters' version counters."""
+    if (CACHE_INFER_CASTS and type(conv) is torch.nn.Conv2d and not torch.is_grad_enabled() and x.is_cuda
+            and torch.is_autocast_enabled() and conv.weight.dtype == torch.float32 and conv.padding_mode == 'zeros'):
+        dt = torch.get_autocast_gpu_dtype()
+        key = (conv.weight._version, conv.weight.data_ptr(), None if conv.bias is None else conv.bias._version, dt)
+        c = conv.__dict__.get('_kgdet_cast_cache')
+        if c is None or c[0] != key:
+            c = (key, conv.weight.detach().to(dt), None if conv.bias is None else conv.bias.detach().to(dt))
+            conv.__dict__['_kgdet_cast_cache'] = c
+        return torch.nn.functional.conv2d(x, c[1], c[2], conv.stride, conv.padding, conv.dilation, conv.groups)
+    return conv(x)
+
+
 def conv_bias_act(conv, x, relu=False):
     """``[relu](conv(x))`` of a plain ``nn.Conv2d``: fp32 training on the GPU takes the split-bf16 MFMA kernels, anything else
     the module itself (+ F.relu)"""
@@ -408,7 +427,7 @@ def conv_bias_act(conv, x, relu=False):
             and conv.bias.dtype == torch.float32
             and applicable(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)):
         return _ConvBiasAct.apply(x, conv.weight, conv.bias, relu)
-    y = conv(x)
+    y = conv_infer(conv, x)
     return torch.relu(y) if relu else y
 
 

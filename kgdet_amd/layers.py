@@ -239,7 +239,7 @@ class ConvModule(nn.Module):
                 elif type(conv) is nn.Conv2d and conv.bias is not None and torch.is_grad_enabled():
                     x = conv1x1.conv_bias_act(conv, x, relu=False)   # (config 5's FPN: biased convolutions without a norm)
                 else:
-                    x = conv(x)
+                    x = conv1x1.conv_infer(conv, x)
             elif layer == 'norm' and norm and self.with_norm:
                 relu_next = (activate and self.with_activatation and li + 1 < len(self.order)
                              and self.order[li + 1] == 'act')
