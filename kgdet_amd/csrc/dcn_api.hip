@@ -151,6 +151,18 @@ void launch_plane_fixup(const DcnFwdGroup &grp, const void *workspace, int G, vo
                        (const float *)workspace, G);
 }
 
+// Grid of a plane-kernel launch: small groups run on fewer workgroups, so that a workgroup's share is at least ~16 stages.
+// (With all 256 workgroups on the 7 x 11 level of a five-level head -- 2 tiles x 144 stages -- every workgroup computed one stage
+// and wrote a 128 KB slab; the fix-up then added 128 slabs per tile with two workgroups: 128 us per launch, four launches per step.)
+int small_launch_grid(const DcnFwdGroup &grp, int G) {
+  static const bool off = getenv("KGDET_DCN_FULL_GRID") != nullptr;   // A/B switch
+  int min_len = 1 << 30;                                 // (a slice must not meet more ranges than it has slab slots)
+  for (int i = 0; i < grp.n; ++i) min_len = std::min(min_len, grp.p[i].chunks_per_tile);
+  const long long per = std::max<long long>(1, std::min<long long>(16, (long long)(kSlabSlots - 2) * min_len));
+  const long long g = grp.unit_begin[grp.n] / per;
+  return off ? G : (int)std::max<long long>(1, std::min<long long>(G, g));
+}
+
 // LDS-privatised backward-input: one (image, 32-channel slice) plane set must fit in LDS
 struct BwdLdsPlan {
   bool ok;
@@ -513,6 +525,8 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
   const bool pairs_off = !(pairs_env || g_options[KGDET_OPT_TAP_PAIRS] != 0);   // (off by default: measured slower)
   auto flush = [&]() -> int {
     if (grp.n == 0) return KGDET_OK;
+    const int Gf = G;                                  // (the full grid: record builders)
+    const int G = small_launch_grid(grp, Gf);
     plan_static_ranges(grp, G, false, kSlabSlots - 2);
     static thread_local bool attr_set = false;
     if (!attr_set) {
@@ -523,7 +537,7 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
       attr_set = true;
     }
     grp.pair_mode = grp_pair ? 1 : 0;
-    hipLaunchKernelGGL(dcn_build_taps, dim3(2 * G, grp.n), dim3(256), 0, (hipStream_t)stream, grp);
+    hipLaunchKernelGGL(dcn_build_taps, dim3(2 * Gf, grp.n), dim3(256), 0, (hipStream_t)stream, grp);
     const int threads = dcn_fwd_plane_threads();
     if (grp_pair) {   // K >= 7 everywhere in the group: half-chunk planes, tap-pair stages (dcn_plane_pairs.h)
       static thread_local bool pairs_attr_set = false;
@@ -804,12 +818,13 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
                                     dcn_bwd_input_plane_fixed_lds_bytes(parts));
   const int threads = dcn_fwd_plane_threads();
   grp.wave_layout = dcn_plane_wave_layout();   // plane_role's accumulator layout (slabs are decoded by dcn_fwd_fixup)
-  plan_static_ranges(grp, G, false, kSlabSlots - 2);
+  const int Gs = small_launch_grid(grp, G);
+  plan_static_ranges(grp, Gs, false, kSlabSlots - 2);
   if (parts == 1)
-    hipLaunchKernelGGL(dcn_bwd_input_plane<1>, dim3(G), dim3(threads), lds, (hipStream_t)stream, grp, (float *)workspace);
+    hipLaunchKernelGGL(dcn_bwd_input_plane<1>, dim3(Gs), dim3(threads), lds, (hipStream_t)stream, grp, (float *)workspace);
   else
-    hipLaunchKernelGGL(dcn_bwd_input_plane<2>, dim3(G), dim3(threads), lds, (hipStream_t)stream, grp, (float *)workspace);
-  launch_plane_fixup(grp, workspace, G, stream);
+    hipLaunchKernelGGL(dcn_bwd_input_plane<2>, dim3(Gs), dim3(threads), lds, (hipStream_t)stream, grp, (float *)workspace);
+  launch_plane_fixup(grp, workspace, Gs, stream);
   KGDET_CHECK_LAUNCH("dcn_bwd_input_plane");
   return KGDET_OK;
 }
@@ -888,7 +903,8 @@ static int grad_offset_plane(const kgdet_dcn_shape *s, const float *input, const
     grp.unit_begin[grp.n + 1] = grp.unit_begin[grp.n] + p.total_units;
     ++grp.n;
   }
-  plan_static_ranges(grp, G, mask != nullptr);
+  const int Gs = mask ? G : small_launch_grid(grp, G);      // (v2 needs one workgroup per range: the full grid)
+  plan_static_ranges(grp, Gs, mask != nullptr);
   if (mask && !grp.static_ranges) {
     set_error("grad_offset plane kernel (v2): more (part, tile) ranges than workgroups");
     return KGDET_E_UNSUPPORTED;
@@ -905,13 +921,13 @@ static int grad_offset_plane(const kgdet_dcn_shape *s, const float *input, const
     return KGDET_OK;
   }
   if (parts == 1)
-    hipLaunchKernelGGL(dcn_bwd_offset_plane<1>, dim3(G), dim3(threads), lds, (hipStream_t)stream, grp,
+    hipLaunchKernelGGL(dcn_bwd_offset_plane<1>, dim3(Gs), dim3(threads), lds, (hipStream_t)stream, grp,
                        (float *)workspace, d.K);
   else
-    hipLaunchKernelGGL(dcn_bwd_offset_plane<2>, dim3(G), dim3(threads), lds, (hipStream_t)stream, grp,
+    hipLaunchKernelGGL(dcn_bwd_offset_plane<2>, dim3(Gs), dim3(threads), lds, (hipStream_t)stream, grp,
                        (float *)workspace, d.K);
   hipLaunchKernelGGL(dcn_bwd_offset_plane_fixup, dim3(grp.tile_begin[grp.n], 8), dim3(256), 0, (hipStream_t)stream, grp,
-                     (const float *)workspace, G, d.K);
+                     (const float *)workspace, Gs, d.K);
   KGDET_CHECK_LAUNCH("dcn_bwd_offset_plane");
   return KGDET_OK;
 }
@@ -1045,10 +1061,11 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
   }
   lds = plan_plane_lds(grp, lds, dcn_bwd_input_plane_fixed_lds_bytes(2));
   grp.wave_layout = dcn_plane_wave_layout();   // plane_role's accumulator layout (slabs are decoded by dcn_fwd_fixup)
-  plan_static_ranges(grp, G, false, kSlabSlots - 2);
-  hipLaunchKernelGGL(dcn_bwd_input_plane<2>, dim3(G), dim3(dcn_fwd_plane_threads()), lds, (hipStream_t)stream, grp,
+  const int Gs = small_launch_grid(grp, G);
+  plan_static_ranges(grp, Gs, false, kSlabSlots - 2);
+  hipLaunchKernelGGL(dcn_bwd_input_plane<2>, dim3(Gs), dim3(dcn_fwd_plane_threads()), lds, (hipStream_t)stream, grp,
                      (float *)workspace);
-  launch_plane_fixup(grp, workspace, G, stream);
+  launch_plane_fixup(grp, workspace, Gs, stream);
 
   // ---- phase 2: grad_offset (column gradient in registers) ----
   grp.n = 0;
@@ -1081,12 +1098,13 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
     lds = need > lds ? need : lds;
   }
   if (lds > kMaxLds || !check_slots(grp)) { set_error("group does not fit the grad_offset kernel"); return KGDET_E_UNSUPPORTED; }
-  plan_static_ranges(grp, G);
+  const int Go = small_launch_grid(grp, G);
+  plan_static_ranges(grp, Go);
   hipLaunchKernelGGL(dcn_build_grad_taps, dim3(2 * G, grp.n), dim3(256), 0, (hipStream_t)stream, grp);
-  hipLaunchKernelGGL(dcn_bwd_offset_plane<2>, dim3(G), dim3(dcn_bwd_offset_plane_threads()), lds, (hipStream_t)stream, grp,
+  hipLaunchKernelGGL(dcn_bwd_offset_plane<2>, dim3(Go), dim3(dcn_bwd_offset_plane_threads()), lds, (hipStream_t)stream, grp,
                      (float *)workspace, max_K);
   hipLaunchKernelGGL(dcn_bwd_offset_plane_fixup, dim3(grp.tile_begin[grp.n], 8), dim3(256), 0, (hipStream_t)stream, grp,
-                     (const float *)workspace, G, max_K);
+                     (const float *)workspace, Go, max_K);
   KGDET_CHECK_LAUNCH("dcn_bwd_plane_grouped");
   return KGDET_OK;
 }
