@@ -22,6 +22,8 @@ import torch.nn as nn
 from . import conv1x1, dcn
 from .heads import PointHeadMixin
 from .layers import ConvModule, bias_init_with_prob, normal_init
+
+GROUPED_REFINE = __import__('os').environ.get('KGDET_SERIAL_GROUPED_DCN', '1') == '1'   # 0: one call per deformable convolution (A/B)
 from .losses import SmoothL1Loss
 import os
 
@@ -180,8 +182,17 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
         # refine stage: taps on the (gradient-scaled) init reppoints
         grad_mul = self.gradient_mul * reppts_out_init + (1 - self.gradient_mul) * reppts_out_init.detach()
         dcn_offset = grad_mul - dcn_base_offset
-        cls_out = self.cls_refine_out(self._dfm(self.cls_refine_dfmconv, cls_feat, dcn_offset))
-        keypts_out_refine = self.keypts_refine_out(self._dfm(self.keypts_refine_dfmconv, pts_feat, dcn_offset))
+        # the refine stage's deformable convolutions share their offsets: ONE grouped call (one set of tap / inverse records,
+        # grouped launches forward and backward, ReLU in the epilogue) instead of two or three
+        if GROUPED_REFINE and cls_feat.is_cuda and not self.parallel_reppts:
+            cls_dfm, kpt_dfm = dcn.deform_conv_cat_multi(
+                [cls_feat, pts_feat], [dcn_offset],
+                [[self.cls_refine_dfmconv.weight], [self.keypts_refine_dfmconv.weight]], [self.dcn_pad])
+        else:
+            cls_dfm = self._dfm(self.cls_refine_dfmconv, cls_feat, dcn_offset)
+            kpt_dfm = self._dfm(self.keypts_refine_dfmconv, pts_feat, dcn_offset)
+        cls_out = self.cls_refine_out(cls_dfm)
+        keypts_out_refine = self.keypts_refine_out(kpt_dfm)
         if self.parallel_reppts:
             reppts_out_refine = self.reppts_refine_out(self._dfm(self.reppts_refine_dfmconv, pts_feat, dcn_offset))
         else:
