@@ -17,6 +17,7 @@
 //     entry keyed by its input cell; a STABLE radix sort (hipCUB) groups the entries by cell in enumeration order, so
 //     every cell's sum has a fixed order; one workgroup per 32 cells, a thread per channel, adds w * colT[p][t*C + c].
 #include <hipcub/hipcub.hpp>
+#include <type_traits>
 
 #include "common.h"
 #include "dcn_common.h"
@@ -109,48 +110,50 @@ __global__ __launch_bounds__(256) void large_row_ptr(const unsigned *__restrict_
 }
 
 // grad_input[b][c][q] = sum over the entries of cell (b, q), in sorted (= enumeration) order, of w * colT[b][p][t*C + c]
-// grid = (ceil(HW / 32), N, ceil(C / 256)), 256 threads = channels
+// grid = (ceil(HW / kGatherCells), N, ceil(C / 256)), 256 threads = channels.
+// The kernel is latency-bound (a cell's ~36 rows are 36 dependent-free but sequentially issued 1 KB reads per wave): 16 cells
+// per workgroup keep the LDS tile at 16 KB, so eight workgroups share a CU (32 cells: four), and eight loads are in flight
+// per thread -- 319 -> ~190 us on [2, 256, 100, 168] 3x3.  The adds keep the sorted order whatever the batch size.
+constexpr int kGatherCells = 16;
 __global__ __launch_bounds__(256) void large_gather_input(const float *__restrict__ colT, const int *__restrict__ row_ptr,
                                                           const unsigned long long *__restrict__ vals,
                                                           float *__restrict__ grad_input, int C, int K, int HW, int P) {
-  __shared__ float tile[32][257];
-  const int q0 = blockIdx.x * 32, b = blockIdx.y, c = blockIdx.z * 256 + threadIdx.x;
+  __shared__ float tile[kGatherCells][257];
+  const int q0 = blockIdx.x * kGatherCells, b = blockIdx.y, c = blockIdx.z * 256 + threadIdx.x;
   const bool live = c < C;
   const int cc = live ? c : 0;
   const long long KC = (long long)K * C;
   const float *base = colT + (long long)b * P * KC + cc;
-  for (int r = 0; r < 32; ++r) {
+  auto batch = [&](int e, auto N_, float &acc) __attribute__((always_inline)) {
+    constexpr int N = decltype(N_)::value;
+    float v[N], w[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      const unsigned long long val = vals[e + u];
+      const unsigned tp = (unsigned)(val >> 32);
+      const unsigned t = tp / (unsigned)P, px = tp - t * (unsigned)P;
+      w[u] = __uint_as_float((unsigned)val);
+      v[u] = base[(long long)px * KC + (long long)t * C];
+    }
+#pragma unroll
+    for (int u = 0; u < N; ++u) acc += w[u] * v[u];
+  };
+  for (int r = 0; r < kGatherCells; ++r) {
     const int q = q0 + r;
     float acc = 0.0f;
     if (q < HW) {
       const int e0 = row_ptr[b * HW + q], e1 = row_ptr[b * HW + q + 1];
       int e = e0;
-      for (; e + 4 <= e1; e += 4) {   // four independent loads in flight; the adds keep the sorted order
-        float v[4], w[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const unsigned long long val = vals[e + u];
-          const unsigned tp = (unsigned)(val >> 32);
-          const unsigned t = tp / (unsigned)P, px = tp - t * (unsigned)P;
-          w[u] = __uint_as_float((unsigned)val);
-          v[u] = base[(long long)px * KC + (long long)t * C];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc += w[u] * v[u];
-      }
-      for (; e < e1; ++e) {
-        const unsigned long long val = vals[e];
-        const unsigned tp = (unsigned)(val >> 32);
-        const unsigned t = tp / (unsigned)P, px = tp - t * (unsigned)P;
-        acc += __uint_as_float((unsigned)val) * base[(long long)px * KC + (long long)t * C];
-      }
+      for (; e + 8 <= e1; e += 8) batch(e, std::integral_constant<int, 8>{}, acc);
+      if (e + 4 <= e1) { batch(e, std::integral_constant<int, 4>{}, acc); e += 4; }
+      for (; e < e1; ++e) batch(e, std::integral_constant<int, 1>{}, acc);
     }
     tile[r][threadIdx.x] = acc;
   }
   __syncthreads();
-  // [32 cells][256 channels] -> grad_input[b][c][q0 .. q0+31]: 8 lanes share a channel's run
-  const int lane_q = threadIdx.x & 31, ch_sub = threadIdx.x >> 5;  // 32 cells x 8 channels per pass
-  for (int c2 = ch_sub; c2 < 256; c2 += 8) {
+  // [cells][256 channels] -> grad_input[b][c][q0 .. q0 + kGatherCells - 1]: 16 lanes share a channel's run
+  const int lane_q = threadIdx.x & (kGatherCells - 1), ch_sub = threadIdx.x / kGatherCells;
+  for (int c2 = ch_sub; c2 < 256; c2 += 256 / kGatherCells) {
     const int ch = blockIdx.z * 256 + c2, q = q0 + lane_q;
     if (ch < C && q < HW) grad_input[((long long)b * C + ch) * HW + q] = tile[lane_q][c2];
   }
@@ -310,7 +313,7 @@ int dcn_bwd_large(const DcnProblem &p, const float *grad_output, int out_channel
   const int n_cells = (int)(p.N * HW);
   hipLaunchKernelGGL(large_row_ptr, dim3((n_cells + 1 + 255) / 256), dim3(256), 0, st, keys_b, L.n_entries, n_cells,
                      row_ptr);
-  hipLaunchKernelGGL(large_gather_input, dim3((unsigned)((HW + 31) / 32), p.N, (C + 255) / 256), dim3(256), 0, st, colT,
+  hipLaunchKernelGGL(large_gather_input, dim3((unsigned)((HW + kGatherCells - 1) / kGatherCells), p.N, (C + 255) / 256), dim3(256), 0, st, colT,
                      row_ptr, vals_b, grad_input, C, K, (int)HW, (int)P);
   hipLaunchKernelGGL(large_grad_offset, dim3((unsigned)P, p.N), dim3(256), 0, st, p, colT, xT, grad_offset,
                      p.mask ? grad_mask : nullptr);
