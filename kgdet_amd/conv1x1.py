@@ -373,6 +373,41 @@ def conv_split(x, weight):
     return _ConvSplit.apply(x, weight)
 
 
+PAD_ODD_MAPS = _os.environ.get('KGDET_PAD_ODD_MAPS', '1') == '1'     # 0: maps with an odd pixel count stay on MIOpen (A/B)
+
+
+def odd_map_applicable(x, weight, stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1):
+    """a map with an odd number of pixels (13 x 21, 7 x 11: the two coarsest levels of a five-level head) that the split kernels
+    take once ONE zero column is appended: for a 1x1 / 3x3 stride-1 convolution with its own zero padding the appended column
+    reads as that padding, so the first W output columns are the convolution of the unpadded map.  (MIOpen's fp32 Winograd
+    kernel costs ~47 us per pass whatever the map size: 47 launches, 1.8 ms of a config-5 step.)"""
+    return (PAD_ODD_MAPS and x.dim() == 4 and (x.shape[2] * x.shape[3]) % 2 == 1 and x.shape[2] % 2 == 1 and x.is_cuda
+            and x.dtype == torch.float32 and x.is_contiguous()
+            and applicable(_PadProbe(x), weight, stride, padding, dilation, groups))
+
+
+class _PadProbe(object):
+    """what `applicable` asks of a tensor, for x with one more column (no allocation)"""
+
+    def __init__(self, x):
+        self.is_cuda, self.dtype = x.is_cuda, x.dtype
+        self.shape = (x.shape[0], x.shape[1], x.shape[2], x.shape[3] + 1)
+
+    def dim(self):
+        return 4
+
+    def is_contiguous(self):
+        return True
+
+
+def pad_odd(x):
+    return torch.nn.functional.pad(x, (0, 1))
+
+
+def unpad_odd(y, width):
+    return y[..., :width].contiguous()
+
+
 conv1x1 = conv_split
 
 
@@ -427,6 +462,9 @@ def conv_bias_act(conv, x, relu=False):
             and conv.bias.dtype == torch.float32
             and applicable(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)):
         return _ConvBiasAct.apply(x, conv.weight, conv.bias, relu)
+    if (type(conv) is torch.nn.Conv2d and conv.bias is not None and torch.is_grad_enabled() and conv.bias.dtype == torch.float32
+            and odd_map_applicable(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)):
+        return unpad_odd(_ConvBiasAct.apply(pad_odd(x), conv.weight, conv.bias, relu), x.shape[3])
     y = conv_infer(conv, x)
     return torch.relu(y) if relu else y
 

@@ -236,6 +236,9 @@ class ConvModule(nn.Module):
                 if (type(conv) is nn.Conv2d and conv.bias is None and torch.is_grad_enabled()
                         and conv1x1.applicable(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)):
                     x = conv1x1.conv_split(x, conv.weight)     # fp32 training: split-operand MFMA kernels (conv1x1.hip)
+                elif (type(conv) is nn.Conv2d and conv.bias is None and torch.is_grad_enabled()
+                        and conv1x1.odd_map_applicable(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)):
+                    x = conv1x1.unpad_odd(conv1x1.conv_split(conv1x1.pad_odd(x), conv.weight), x.shape[3])
                 elif type(conv) is nn.Conv2d and conv.bias is not None and torch.is_grad_enabled():
                     x = conv1x1.conv_bias_act(conv, x, relu=False)   # (config 5's FPN: biased convolutions without a norm)
                 else:
