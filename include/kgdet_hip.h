@@ -472,7 +472,7 @@ int kgdet_gn_act_backward_split(const float *grad_y, const float *x, const float
                                 const float *rstd, int32_t groups, int32_t relu, float *grad_x, float *dgamma_dbeta,
                                 float *scratch, int64_t N, int32_t C, int64_t HW, void *stream);
 /* Inference under autocast: x, y bfloat16, fp32 arithmetic, no saved statistics; at most 65536 elements per group.
- * x [N, C, HW], or channels-last [N, HW, C] when x_channels_last != 0; y always [N, C, HW]. */
+ * x and y [N, C, HW], or both channels-last [N, HW, C] when x_channels_last != 0. */
 int kgdet_gn_act_forward_bf16(const void *x, int32_t x_channels_last, const float *gamma, const float *beta, int32_t groups,
                               float eps, int32_t relu, void *y, int64_t N, int32_t C, int64_t HW, void *stream);
 

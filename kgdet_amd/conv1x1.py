@@ -439,6 +439,9 @@ class _ConvBiasAct(torch.autograd.Function):
 CACHE_INFER_CASTS = _os.environ.get('KGDET_CACHE_INFER_CASTS', '1') == '1'     # 0: autocast casts weights and biases per batch (A/B)
 
 
+GEMM_1X1_NCHW = _os.environ.get('KGDET_INFER_GEMM_1X1_NCHW', '1') == '1'     # 0: MIOpen for the head's 1x1 output convolutions (A/B)
+
+
 def conv_infer(conv, x):
     """``conv(x)``; inference under autocast keeps the reduced-precision copies of weight and bias across batches (autocast's own
     cache ends with its context: a batch re-cast the head's nine 3x3 weights, the 1x1 output weights and every bias -- ~30 launches,
@@ -446,11 +449,26 @@ def conv_infer(conv, x):
     if (CACHE_INFER_CASTS and type(conv) is torch.nn.Conv2d and not torch.is_grad_enabled() and x.is_cuda
             and torch.is_autocast_enabled() and conv.weight.dtype == torch.float32 and conv.padding_mode == 'zeros'):
         dt = torch.get_autocast_gpu_dtype()
-        key = (conv.weight._version, conv.weight.data_ptr(), None if conv.bias is None else conv.bias._version, dt)
+        # channels-last activations meet a channels-last weight: MIOpen then runs its NHWC kernel as it is, without the
+        # layout-conversion launches it wraps around an NCHW call (36 per batch of the KGDet head)
+        cl = x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+        key = (conv.weight._version, conv.weight.data_ptr(), None if conv.bias is None else conv.bias._version, dt, cl)
         c = conv.__dict__.get('_kgdet_cast_cache')
         if c is None or c[0] != key:
-            c = (key, conv.weight.detach().to(dt), None if conv.bias is None else conv.bias.detach().to(dt))
+            w = conv.weight.detach().to(dt)
+            if cl:
+                w = w.contiguous(memory_format=torch.channels_last)
+            c = (key, w, None if conv.bias is None else conv.bias.detach().to(dt))
             conv.__dict__['_kgdet_cast_cache'] = c
+        if (GEMM_1X1_NCHW and not cl and x.dim() == 4 and x.is_contiguous() and x.dtype == dt and conv.kernel_size == (1, 1)
+                and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1):
+            # a 1x1 convolution of an NCHW tensor (the deformable stages' outputs) IS W [Cout, Cin] @ x[b] [Cin, H*W]: one
+            # batched GEMM in place, where MIOpen converts the activation to NHWC, convolves and converts back (+ a bias pass)
+            B, _, H, W = x.shape
+            y = torch.matmul(c[1].view(c[1].shape[0], -1), x.view(B, x.shape[1], H * W))
+            if c[2] is not None:
+                y += c[2].view(1, -1, 1)
+            return y.view(B, -1, H, W)
         return torch.nn.functional.conv2d(x, c[1], c[2], conv.stride, conv.padding, conv.dilation, conv.groups)
     return conv(x)
 

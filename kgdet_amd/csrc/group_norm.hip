@@ -32,7 +32,8 @@ __device__ __forceinline__ float gn_block_sum(float v, float *red) {   // all th
 // T = float, or __bf16 (autocast inference: torch runs group_norm in fp32 between a bf16 -> fp32 cast of the convolution's output
 // and the fp32 -> bf16 cast in front of the next convolution; here the bf16 tensor is read and written directly, fp32 arithmetic,
 // one rounding at the same place)
-// NHWC: x is channels-last ([N][HW][C], the layout the inference backbone / neck hand over); y is always [N][C][HW].
+// NHWC: x and y are channels-last ([N][HW][C], the layout the inference backbone / neck hand over and MIOpen's bf16 kernels
+// work in: a tower that stays channels-last needs none of MIOpen's layout-conversion launches around its convolutions).
 template <typename T, bool NHWC = false>
 __global__ __launch_bounds__(kGnThreads) void gn_act_forward(const T *__restrict__ x, const float *__restrict__ gamma,
                                                              const float *__restrict__ beta, float eps, int relu,
@@ -58,13 +59,12 @@ __global__ __launch_bounds__(kGnThreads) void gn_act_forward(const T *__restrict
     mean_out[blockIdx.x] = mean;
     rstd_out[blockIdx.x] = rstd;
   }
-  for (int i = threadIdx.x; i < total; i += kGnThreads) {   // (in y's order)
-    const int d = i / HW, p = i - d * HW;
-    const int c = g * D + d;
-    const float xv = (float)x[NHWC ? xbase + (long long)p * C + d : xbase + i];
-    float v = (xv - mean) * rstd * (gamma ? gamma[c] : 1.0f) + (beta ? beta[c] : 0.0f);
+  for (int i = threadIdx.x; i < total; i += kGnThreads) {
+    const int c = g * D + (NHWC ? i % D : i / HW);
+    const long long at = x_at(i);
+    float v = ((float)x[at] - mean) * rstd * (gamma ? gamma[c] : 1.0f) + (beta ? beta[c] : 0.0f);
     if (relu) v = fmaxf(v, 0.0f);
-    y[base + i] = (T)v;
+    y[at] = (T)v;
   }
 }
 

@@ -122,7 +122,7 @@ def gn_act_bf16_applicable(x, norm):
 def gn_act_bf16(x, norm, relu):
     from . import _lib
     N, C = x.shape[0], x.shape[1]
-    y = torch.empty(x.shape, dtype=x.dtype, device=x.device)      # (contiguous, whatever x's layout)
+    y = torch.empty_like(x)      # (x's layout: a channels-last tower stays channels-last)
     _lib.check(_lib.lib().kgdet_gn_act_forward_bf16(
         _lib.ptr(x), ctypes.c_int32(0 if x.is_contiguous() else 1), _lib.ptr(norm.weight), _lib.ptr(norm.bias), ctypes.c_int32(norm.num_groups), ctypes.c_float(norm.eps),
         ctypes.c_int32(1 if relu else 0), _lib.ptr(y), ctypes.c_int64(N), ctypes.c_int32(C),
