@@ -1205,6 +1205,8 @@ static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *sh
   grp.tile_begin[0] = 0; grp.range_begin[0] = 0; grp.unit_begin[0] = 0;
   size_t lds = 0;
   int min_len = 1 << 30;
+  DcnPackGradOut pack;          // the grad_out images of the call: one launch (at most one per channel run: <= kMaxFwdGroup)
+  int n_pack = 0, pack_x = 0, pack_y = 0;
   for (int i = 0; i < n; ++i) {
     const kgdet_dcn_shape *s = shapes[i];
     const Derived &d = dd[i];
@@ -1228,9 +1230,12 @@ static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *sh
       p.build_taps = same_taps[i] < 0 && first_sub;
       p.wq = tab + gq_off[i] + (size_t)g * gq_group_bytes;
       if (same_gq[i] < 0 && packed_group < g) {
-        hipLaunchKernelGGL(dcn_pack_grad_out, dim3(s->N * n_px16, d.Og_pad / kTileM), dim3(256), 0, (hipStream_t)stream,
-                           grad_outputs[i], (void *)(tab + gq_off[i] + (size_t)g * gq_group_bytes), s->N, p.O_total, p.o_base,
-                           d.Og, p.HoWo, n_px16, 2);
+        DcnPackGradOutItem &it = pack.item[n_pack++];
+        it.gout = grad_outputs[i]; it.gq = (void *)(tab + gq_off[i] + (size_t)g * gq_group_bytes);
+        it.N = s->N; it.O_total = p.O_total; it.o_base = p.o_base; it.Og = d.Og; it.HoWo = p.HoWo; it.n_px16 = n_px16;
+        it.n_mtiles = d.Og_pad / kTileM;
+        pack_x = std::max(pack_x, s->N * n_px16);
+        pack_y = std::max(pack_y, d.Og_pad / kTileM);
         packed_group = g;
       }
       p.n_mtiles = d.Og_pad / kTileM;
@@ -1267,6 +1272,8 @@ static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *sh
     set_error("group too uneven for the slab slots");
     return KGDET_E_UNSUPPORTED;
   }
+  if (n_pack > 0)
+    hipLaunchKernelGGL(dcn_pack_grad_out, dim3(pack_x, pack_y, n_pack), dim3(256), 0, (hipStream_t)stream, pack, 2);
   hipLaunchKernelGGL(dcn_build_taps, dim3(2 * G, grp.n), dim3(256), 0, (hipStream_t)stream, grp);
   if (gather)
     hipLaunchKernelGGL(dcn_bwd_weight_gather<2>, dim3(Gw), dim3(dcn_bwd_weight_plane_threads()), lds, (hipStream_t)stream, grp,

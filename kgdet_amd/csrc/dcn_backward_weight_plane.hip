@@ -36,18 +36,22 @@ constexpr int kTapsPerTile = 8;  // x 16 channels = 128 columns
 }
 
 // grad_out [N, O_total, Ho*Wo] (window o_base .. o_base + Og) -> gq[mt][b][px16][part][khalf][o 256][8 px] bf16
-__global__ __launch_bounds__(256) void dcn_pack_grad_out(const float *__restrict__ gout, void *__restrict__ gq, int N,
-                                                          int O_total, int o_base, int Og, int HoWo, int n_px16,
-                                                          int parts) {
+// All grad_out images of a grouped call in ONE launch: blockIdx.z = image (a head stage packs six: one launch instead of six).
+// grid = (max over images of N * n_px16, max of M tiles, images), 256 threads.
+__global__ __launch_bounds__(256) void dcn_pack_grad_out(const DcnPackGradOut g, int parts) {
+  const DcnPackGradOutItem &it = g.item[blockIdx.z];
   const int stage = blockIdx.x;               // (b, px16)
   const int mt = blockIdx.y;
+  if (stage >= it.N * it.n_px16 || mt >= it.n_mtiles) return;
+  const int N = it.N, O_total = it.O_total, o_base = it.o_base, Og = it.Og, HoWo = it.HoWo, n_px16 = it.n_px16;
+  const float *__restrict__ gout = it.gout;
   const int b = stage / n_px16, q = stage - b * n_px16;
   const int o_in = threadIdx.x, o = mt * kTileM + o_in;
   const float *src = gout + ((long long)b * O_total + o_base + min(o, Og - 1)) * HoWo;
   float v[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) v[i] = src[min(q * 16 + i, HoWo - 1)];
-  unsigned char *dst = reinterpret_cast<unsigned char *>(gq) +
+  unsigned char *dst = reinterpret_cast<unsigned char *>(it.gq) +
                        ((size_t)(mt * N + b) * n_px16 + q) * (size_t)(parts * kAPart) + o_in * 16;
 #pragma unroll
   for (int khalf = 0; khalf < 2; ++khalf) {

@@ -73,8 +73,15 @@ __global__ void dcn_bwd_weight_plane(const DcnFwdGroup grp, float *__restrict__ 
 template <int PARTS>
 __global__ void dcn_bwd_weight_gather(const DcnFwdGroup grp, float *__restrict__ slabs);
 __global__ void dcn_bwd_weight_plane_fixup(const DcnFwdGroup grp, const float *__restrict__ slabs, int G);
-__global__ void dcn_pack_grad_out(const float *__restrict__ gout, void *__restrict__ gq, int N, int O_total, int o_base,
-                                  int Og, int HoWo, int n_px16, int parts);
+struct DcnPackGradOutItem {
+  const float *gout;
+  void *gq;
+  int N, O_total, o_base, Og, HoWo, n_px16, n_mtiles;
+};
+struct DcnPackGradOut {
+  DcnPackGradOutItem item[kMaxFwdGroup];
+};
+__global__ void dcn_pack_grad_out(const DcnPackGradOut g, int parts);
 size_t dcn_bwd_weight_plane_lds_bytes(int parts, int HW);
 size_t dcn_bwd_weight_gather_lds_bytes(int parts);
 int dcn_bwd_weight_plane_threads();
