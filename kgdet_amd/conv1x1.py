@@ -448,7 +448,7 @@ def conv_infer(conv, x):
     ~120 us of a 7 ms batch).  The copies follow the parameters' version counters."""
     if (CACHE_INFER_CASTS and type(conv) is torch.nn.Conv2d and not torch.is_grad_enabled() and x.is_cuda
             and torch.is_autocast_enabled() and conv.weight.dtype == torch.float32 and conv.padding_mode == 'zeros'):
-        dt = torch.get_autocast_gpu_dtype()
+        dt = torch.get_autocast_dtype('cuda')
         # channels-last activations meet a channels-last weight: MIOpen then runs its NHWC kernel as it is, without the
         # layout-conversion launches it wraps around an NCHW call (36 per batch of the KGDet head)
         cl = x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)

@@ -579,3 +579,59 @@ def test_bf16_group_norm_relu_equals_autocast_chain(relu, channels_last):
     ulp = want.abs().clamp(min=2.0 ** -10) * 2.0 ** -7     # one bf16 step at the value's magnitude
     assert (diff <= ulp).all()
     assert (diff > 0).float().mean().item() < 0.01         # and almost everywhere the very same bf16 value
+
+
+def test_conv_infer_keeps_cast_copies_and_follows_weight_updates():
+    """inference under autocast: conv1x1.conv_infer == the module under autocast (NCHW 3x3 / channels-last 3x3 / 1x1 as a batched GEMM),
+    the reduced-precision copies are kept across calls and rebuilt when a parameter changes"""
+    from kgdet_amd import conv1x1
+    torch.manual_seed(0)
+    for k, cl in ((3, False), (3, True), (1, False)):
+        conv = torch.nn.Conv2d(64, 48, k, 1, k // 2).cuda()
+        x = torch.randn(2, 64, 13, 21, device='cuda').bfloat16()
+        if cl:
+            x = x.contiguous(memory_format=torch.channels_last)
+        with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+            want = conv(x)
+            got = conv1x1.conv_infer(conv, x)
+            cache = conv.__dict__['_kgdet_cast_cache']
+            assert conv1x1.conv_infer(conv, x) is not None and conv.__dict__['_kgdet_cast_cache'] is cache      # kept
+            assert got.dtype == torch.bfloat16 and got.shape == want.shape
+            assert (got.float() - want.float()).abs().max().item() <= 2.0 ** -7 * want.float().abs().max().item()
+            conv.weight.mul_(2.0)                                                                                # version bump
+            conv.bias.add_(1.0)
+        with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):     # (a fresh context: autocast's own cast cache is not
+            got2, want2 = conv1x1.conv_infer(conv, x), conv(x)                  #  invalidated by in-place updates inside one)
+            assert conv.__dict__['_kgdet_cast_cache'] is not cache
+            assert (got2.float() - want2.float()).abs().max().item() <= 2.0 ** -7 * want2.float().abs().max().item()
+        # with gradients enabled (training) the module itself runs
+        y = conv1x1.conv_infer(conv, x.float().contiguous())
+        assert y.requires_grad
+
+
+def test_odd_pixel_count_maps_take_the_split_kernels_behind_a_zero_column():
+    """13 x 21 / 7 x 11 levels of a five-level head: ConvModule and conv_bias_act append one zero column, run the split-operand
+    kernels and cut the column off again -- same values and gradients as the fp32 convolution to split-arithmetic rounding"""
+    import torch.nn.functional as F
+    from kgdet_amd import conv1x1, layers
+    torch.manual_seed(1)
+    for H, W in ((13, 21), (7, 11)):
+        x = torch.randn(2, 64, H, W, device='cuda', requires_grad=True)
+        m = layers.ConvModule(64, 32, 3, padding=1, norm_cfg=dict(type='GN', num_groups=4, requires_grad=True)).cuda()
+        assert conv1x1.odd_map_applicable(x, m.conv.weight, (1, 1), (1, 1), (1, 1), 1)
+        conv = torch.nn.Conv2d(64, 32, 3, 1, 1).cuda()
+        gy = torch.randn(2, 32, H, W, device='cuda')
+        outs = []
+        for flag in (True, False):
+            conv1x1.PAD_ODD_MAPS = flag
+            try:
+                xa = x.detach().clone().requires_grad_()
+                ya = m(xa) + conv1x1.conv_bias_act(conv, xa, relu=True)
+                ya.backward(gy)
+                outs.append((ya.detach(), xa.grad, m.conv.weight.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()))
+                m.zero_grad(); conv.zero_grad()
+            finally:
+                conv1x1.PAD_ODD_MAPS = True
+        for a, b in zip(*outs):
+            assert a.shape == b.shape and a.is_contiguous()
+            assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-7
