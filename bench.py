@@ -104,11 +104,23 @@ if ARGS is not None:
 # MIOpen's measured solver picks for this workload's convolution shapes on MI355X (written by MIOpen itself during
 # a first run on the GPU box, see kgdet_amd/miopen_db/README.md): with the records present the find step is a
 # lookup instead of minutes of measuring.  One directory per workload; must be set before MIOpen is initialised.
-if ARGS is not None and ARGS.miopen_find:
-    os.environ.setdefault('MIOPEN_USER_DB_PATH', os.path.join(
-        ROOT, 'kgdet_amd', 'miopen_db', '%s%s_%s_b%d' % ('' if ARGS.config == 'kgdet' else ARGS.config + '_',
-                                                           ARGS.mode, ARGS.dtype, ARGS.imgs_per_gpu)))
-    os.makedirs(os.environ['MIOPEN_USER_DB_PATH'], exist_ok=True)
+if ARGS is not None and ARGS.miopen_find and 'MIOPEN_USER_DB_PATH' not in os.environ:
+    _db = os.path.join(ROOT, 'kgdet_amd', 'miopen_db', '%s%s_%s_b%d' % (
+        '' if ARGS.config == 'kgdet' else ARGS.config + '_', ARGS.mode, ARGS.dtype, ARGS.imgs_per_gpu))
+    if 'RANK' in os.environ:
+        # N ranks must not open ONE user find-db for writing (round-3 review): every rank works on a private copy of the
+        # committed records in its own temporary directory (removed at exit); a one-process run keeps the in-tree
+        # directory, which is how the records get there in the first place.
+        import atexit
+        import shutil
+        import tempfile
+        _priv = tempfile.mkdtemp(prefix='kgdet_miopen_r%s_' % os.environ['RANK'])
+        if os.path.isdir(_db):
+            shutil.copytree(_db, _priv, dirs_exist_ok=True)
+        atexit.register(shutil.rmtree, _priv, True)
+        _db = _priv
+    os.makedirs(_db, exist_ok=True)
+    os.environ['MIOPEN_USER_DB_PATH'] = _db
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -96,6 +96,7 @@ _fold_cache = {}   # id(conv) -> (weakref to conv, folded weight, folded bias)
 
 def clear_fold_cache():
     _fold_cache.clear()
+    _stem_cache.clear()
 
 
 def _epilogue_(y, bias, residual, relu):
@@ -424,10 +425,12 @@ def _conv1x1_as_gemm(conv, hit, x, residual, relu, in_bias=None):
     fused_ok = (residual is not None and cin % 16 == 0 and cin <= 384 and cout % 128 == 0
                 and x.is_contiguous(memory_format=torch.channels_last) and residual.is_contiguous(memory_format=torch.channels_last)
                 and residual.shape == (B, cout, H, W) and hit[1].is_contiguous(memory_format=torch.channels_last))
-    if choice == 'fused':
+    if choice == 'fused' and fused_ok:   # the choice is keyed by shape; layout / contiguity are properties of THIS call
         return fused()
     if in_bias is not None:          # (only passed once the choice is 'fused', fused_residual_ready: the caller's problem)
         return None
+    if choice == 'fused':            # same shape, other layout: the GEMM path below handles any strides
+        return gemm()
     if choice is None:
         def conv_path():
             y = F.conv2d(x, hit[1], None, conv.stride, conv.padding, conv.dilation, conv.groups)

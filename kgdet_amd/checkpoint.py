@@ -50,9 +50,8 @@ def load_checkpoint(model, filename, map_location=None, strict=False):
     with torch.no_grad():
         load_state_dict(target, _strip_module(state_dict), strict)
     # derived weight images (folded conv+BN weights, packed deformable-conv operands) belong to the old weights
-    from . import backbone, dcn
-    backbone.clear_fold_cache()
-    dcn.clear_pack_cache()
+    from . import conv1x1
+    conv1x1.invalidate_inference_caches()
     return checkpoint
 
 

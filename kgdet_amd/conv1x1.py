@@ -163,7 +163,10 @@ _fold_flat = None    # (key, S, T, TMP, EPS, s views, t views, tmp views, gammas
 def _fold_refresh(live):
     """s and t of every folded pair, into flat buffers whose slices the entries hold"""
     global _fold_flat
-    key = tuple((k, e.ptr, id(e.bn())) for k, e in live)
+    # (the BatchNorm's parameter / buffer OBJECTS are part of the key: replacing bn.weight by a new Parameter, or a buffer by
+    #  load_state_dict(assign=True), must not leave the old tensors' values in the folded images)
+    key = tuple((k, e.ptr, id(e.bn()), id(e.bn().weight), id(e.bn().bias), id(e.bn().running_mean), id(e.bn().running_var),
+                 e.bn().weight.data_ptr(), e.bn().running_var.data_ptr()) for k, e in live)
     if _fold_flat is None or _fold_flat[0] != key:
         dev = live[0][1].img.device
         sizes = [e.ref().shape[0] for _, e in live]
@@ -442,6 +445,25 @@ CACHE_INFER_CASTS = _os.environ.get('KGDET_CACHE_INFER_CASTS', '1') == '1'     #
 GEMM_1X1_NCHW = _os.environ.get('KGDET_INFER_GEMM_1X1_NCHW', '1') == '1'     # 0: MIOpen for the head's 1x1 output convolutions (A/B)
 
 
+# module -> (key, reduced-precision weight, bias).  Weak keys, module-level: the copies are neither deep-copied nor pickled with
+# the module (they used to sit in conv.__dict__).
+_cast_cache = weakref.WeakKeyDictionary()
+
+
+def invalidate_inference_caches():
+    """Drop every derived inference-time copy of the weights: the autocast cast cache here, the folded conv + BatchNorm weights
+    (backbone._fold_cache, the stem pack) and the packed deformable operands (dcn._pack_cache).  The caches follow the
+    parameters' version counters, data pointers and object identities; a write THROUGH ``.data`` (``p.data.copy_``, EMA /
+    weight-averaging utilities, some checkpoint loaders) changes none of the three -- callers that do that must call this.
+    ``checkpoint.load_checkpoint`` and ``ResNet.train()`` do."""
+    global _fold_flat
+    _cast_cache.clear()
+    _fold_flat = None
+    from . import backbone, dcn
+    backbone.clear_fold_cache()
+    dcn.clear_pack_cache()
+
+
 def conv_infer(conv, x):
     """``conv(x)``; inference under autocast keeps the reduced-precision copies of weight and bias across batches (autocast's own
     cache ends with its context: a batch re-cast the head's nine 3x3 weights, the 1x1 output weights and every bias -- ~30 launches,
@@ -452,14 +474,15 @@ def conv_infer(conv, x):
         # channels-last activations meet a channels-last weight: MIOpen then runs its NHWC kernel as it is, without the
         # layout-conversion launches it wraps around an NCHW call (36 per batch of the KGDet head)
         cl = x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
-        key = (conv.weight._version, conv.weight.data_ptr(), None if conv.bias is None else conv.bias._version, dt, cl)
-        c = conv.__dict__.get('_kgdet_cast_cache')
+        key = (conv.weight._version, conv.weight.data_ptr(), id(conv.weight),
+               None if conv.bias is None else (conv.bias._version, conv.bias.data_ptr(), id(conv.bias)), dt, cl)
+        c = _cast_cache.get(conv)
         if c is None or c[0] != key:
             w = conv.weight.detach().to(dt)
             if cl:
                 w = w.contiguous(memory_format=torch.channels_last)
             c = (key, w, None if conv.bias is None else conv.bias.detach().to(dt))
-            conv.__dict__['_kgdet_cast_cache'] = c
+            _cast_cache[conv] = c
         if (GEMM_1X1_NCHW and not cl and x.dim() == 4 and x.is_contiguous() and x.dtype == dt and conv.kernel_size == (1, 1)
                 and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1):
             # a 1x1 convolution of an NCHW tensor (the deformable stages' outputs) IS W [Cout, Cin] @ x[b] [Cin, H*W]: one

@@ -75,6 +75,15 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8 &hi, bf16x8 &
 // The pack kernels therefore store fp16-format weights scaled by kF16WeightScale = 2^8 (exact; weights up to 255 in
 // magnitude) and the fp16 kernels multiply their accumulators by 2^-8 before the epilogue (exact as well).
 constexpr float kF16WeightScale = 256.0f;
+// "Values beyond 65504 saturate" is made true by the MODE register's FP16_OVFL bit (bit 23: an overflowed FP16 VALU result
+// is clamped to +/-MAX_FP16, true infinities stay): set once at the top of every kernel that produces fp16 parts, no
+// instruction per element.  Without it v_cvt_pk_f16_f32 rounds |v| > 65504 to inf, hi = inf, lo = v - inf = -inf, and the
+// MFMA sum inf + (-inf) is NaN for the whole output channel (round-3 ADVICE; a folded BatchNorm scale gamma / sqrt(var + eps)
+// of a channel with a tiny running variance reaches that through w * s * 2^8).  With it: hi = 65504, lo = f16(v - 65504),
+// exact up to 131008 and clamped beyond -- finite, and the envelope test pins it.
+__device__ __forceinline__ void f16_saturate_on() {
+  __builtin_amdgcn_s_setreg(1 /*HW_REG_MODE*/ | (23 << 6) /*offset*/ | (0 << 11) /*size - 1*/, 1u);
+}
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <bool F16>
@@ -160,6 +169,7 @@ __global__ __launch_bounds__(256) void conv1x1_pack(const float *__restrict__ w,
     img = blockIdx.y ? img_t : img;
   }
   const bool f16 = f16_forward && !transpose;     // only the forward image (activations x weights) takes fp16 parts
+  f16_saturate_on();
   const int M = transpose ? C : O, K = transpose ? O : C;
   const int k16s = K / kTK;
   const long long total = (long long)((M + kTM - 1) / kTM) * k16s * T * 2 * kTM;   // (mt, k16, t, khalf, row)
@@ -207,6 +217,7 @@ __global__ __launch_bounds__(256) void conv1x1_pack_multi(const long long *__res
   const float *scale = reinterpret_cast<const float *>(d[5]);
   const int O = (int)(d[3] >> 32), C = (int)(d[3] & 0xffffffffLL), T = (int)((d[4] >> 32) & 0xffff);
   const bool f16_forward = (d[4] >> 62) & 1;     // forward image in fp16 parts
+  f16_saturate_on();
   const long long i = (long long)((int)blockIdx.x - (int)(d[4] & 0xffffffffLL)) * 256 + threadIdx.x;
 #pragma unroll
   for (int transpose = 0; transpose < 2; ++transpose) {
@@ -305,6 +316,7 @@ __global__ __launch_bounds__(128 * NW) void conv_nn(const unsigned char *__restr
   // H x W: the OUTPUT map; Hin x Win: the input map; stride 1 (Hin = H, Win = W) or 2 (H = ceil(Hin / 2), ...)
   constexpr int TN = 32 * NW, kPartB = 2 * TN * 16, kBuf = kStage + 2 * kPartB;   // B part: [khalf][TN][8 bf16]
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kBuf];   // [buf][A (kStage) | B (hi, lo)]
+  if constexpr (F16) f16_saturate_on();
   const int unit = xcd_tile(blockIdx.x, tiles * ksplit);
   if (unit >= tiles * ksplit) return;
   // unit order: the K parts and the m tiles of one (image, pixel tile) adjacent -> they share it through one L2
@@ -705,6 +717,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_patch4(const unsigned char
                                                              const float *__restrict__ bias,
                                                              const float *__restrict__ residual, int relu) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kPatchBuf];
+  if constexpr (F16) f16_saturate_on();
   constexpr int HALVES = 4 / WAVES, THREADS = 64 * WAVES, PXT = kPatchMax / THREADS;   // patch pixels per thread
   const int unit0 = xcd_tile(blockIdx.x, tiles * ksplit * HALVES);
   if (unit0 >= tiles * ksplit * HALVES) return;
@@ -999,6 +1012,7 @@ __global__ __launch_bounds__(256) void stem_conv7x7_s2(const unsigned char *__re
                                                        int tiles_per_image) {
   __shared__ float patch[3 * kStemPH * kStemPW];
   __shared__ int koff[kStemK];
+  if constexpr (F16) f16_saturate_on();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / tiles_per_image, nt = blockIdx.x - b * tiles_per_image;
   const int oy0 = (nt / tiles_x) * kStemTY, ox0 = (nt % tiles_x) * kStemTX;

@@ -73,9 +73,17 @@ class OverlappedGradReducer(object):
     caching allocator from handing a packed-from gradient to somebody else before the pack has read it).
 
     The set of gradient-carrying parameters must be the same on every rank (as for the reference's
-    ``param.grad is not None`` filter).  A bucketed parameter without a gradient in some step contributes
-    zeros to the exchange and keeps ``grad = None`` afterwards; a parameter that starts to receive gradients
-    later makes the buckets rebuild.  RCCL calls are issued in bucket-index order on every rank.
+    ``param.grad is not None`` filter, where a mismatch fails on the flat buffer's size).  A bucketed parameter
+    without a gradient in some step contributes zeros to the exchange and keeps ``grad = None`` afterwards; a
+    parameter that starts to receive gradients later makes the buckets rebuild.  RCCL calls are issued in
+    bucket-index order on every rank.
+
+    Both preconditions are ENFORCED (round 4): (a) when the buckets are built every rank hashes its bucket layout
+    (parameter count, sizes and dtypes in bucket order) and one tiny all-gather compares the hashes -- a mismatch
+    raises on every rank instead of hanging in the first differently-sized collective; (b) every flat buffer carries
+    one has-gradient flag per parameter behind the payload, summed by the same all-reduce; the sums are copied to
+    page-locked host memory without a synchronisation and inspected at the NEXT step's ``finish()``: a parameter
+    with a gradient on some ranks only (0 < count < world size) raises there -- one step late, never silently.
     """
 
     def __init__(self, params, bucket_size_mb=32, process_group=None):
@@ -118,8 +126,10 @@ class OverlappedGradReducer(object):
         self._bucket_of = {}
         self._flat = []
         self._views = []
+        self._flags, self._ones, self._flag_host, self._flag_event = [], [], [], []
         for b, plist in enumerate(self.buckets):
-            flat = torch.empty(sum(p.numel() for p in plist), dtype=plist[0].dtype, device=plist[0].device)
+            n = sum(p.numel() for p in plist)
+            flat = torch.empty(n + len(plist), dtype=plist[0].dtype, device=plist[0].device)   # payload | has-grad flags
             views, off = [], 0
             for p in plist:
                 self._bucket_of[p] = b
@@ -127,6 +137,12 @@ class OverlappedGradReducer(object):
                 off += p.numel()
             self._flat.append(flat)
             self._views.append(views)
+            self._flags.append(flat[n:])
+            self._ones.append(torch.ones(len(plist), dtype=flat.dtype, device=flat.device))
+            host = torch.empty(len(plist), dtype=flat.dtype)
+            self._flag_host.append(host.pin_memory() if self.use_cuda else host)
+            self._flag_event.append(None)
+        self._check_layout()
         active = set(self.active)
         self._inactive = [p for p in self.params if p not in active]
         for p in self.active:
@@ -134,6 +150,42 @@ class OverlappedGradReducer(object):
         self._sentinel = False
         self._arrival = [None] * len(self.buckets)     # last parameter to arrive, per bucket
         self._reset_counts()
+
+    def _check_layout(self):
+        """Every rank must have cut the same buckets: same count, same sizes, same dtypes, same order.  One all-gather of
+        a 4-word digest per rank at build time (not per step); a mismatch raises everywhere instead of deadlocking in
+        the first collective whose sizes differ."""
+        import hashlib
+        desc = ';'.join(','.join('%d:%s' % (p.numel(), str(p.dtype)) for p in plist) for plist in self.buckets)
+        h = hashlib.sha256(desc.encode()).digest()
+        dev = self._flat[0].device if self._flat else torch.device('cpu')
+        mine = torch.tensor([len(self.buckets), sum(len(b) for b in self.buckets),
+                             int.from_bytes(h[:7], 'little'), int.from_bytes(h[7:14], 'little')],
+                            dtype=torch.int64, device=dev)
+        self.layout_digest = mine.tolist()
+        if self.world_size == 1:
+            return
+        every = [torch.empty_like(mine) for _ in range(self.world_size)]
+        dist.all_gather(every, mine, group=self.group)
+        rows = [t.tolist() for t in every]
+        if any(r != rows[0] for r in rows):
+            raise RuntimeError('OverlappedGradReducer: ranks disagree on the gradient buckets (buckets, parameters, digest '
+                               'per rank: %s) -- the set of gradient-carrying parameters differs between ranks' % rows)
+
+    def _check_flags(self, b):
+        """The has-gradient counts of bucket b from the PREVIOUS exchange (copied to page-locked memory behind it)."""
+        ev = self._flag_event[b]
+        if ev is None:
+            return
+        if self.use_cuda:
+            ev.synchronize()            # recorded a whole step ago: already complete, no stall
+        self._flag_event[b] = None
+        cnt = self._flag_host[b]
+        bad = ((cnt > 0.5) & (cnt < self.world_size - 0.5)).nonzero().flatten().tolist()
+        if bad:
+            raise RuntimeError('OverlappedGradReducer: %d parameter(s) of bucket %d received a gradient on some ranks only in '
+                               'the previous step (counts %s of %d ranks): the replicas have diverged'
+                               % (len(bad), b, [float(cnt[i]) for i in bad[:8]], self.world_size))
 
     def begin_step(self):
         """Optional, right after ``zero_grad(set_to_none=True)``: tells the reducer that every gradient starts this backward as
@@ -187,16 +239,18 @@ class OverlappedGradReducer(object):
         # (the pack runs on the SIDE stream: on the producing stream -- a copy that cannot disturb the convolutions' whole
         #  rounds over the CUs -- it was measured slower: exposed 1.0-1.1 against 0.67-0.72 ms per step at one rank)
         with self._side():
-            dst, src = [], []
-            for p, v in zip(plist, views):          # ONE pass over the bucket's parameters (this runs inside backward)
+            dst, src, missing = [self._flags[b]], [self._ones[b]], []
+            for i, (p, v) in enumerate(zip(plist, views)):   # ONE pass over the bucket's parameters (this runs inside backward)
                 g = p.grad
                 if g is None:
                     v.zero_()                       # no gradient this step: contributes zeros
+                    missing.append(i)
                 elif g.data_ptr() != v.data_ptr():
                     dst.append(v)
                     src.append(g)
-            if dst:
-                torch._foreach_copy_(dst, src)      # strided sources are fine: copy_ semantics per tensor
+            torch._foreach_copy_(dst, src)          # strided sources are fine: copy_ semantics per tensor; flags ride along
+            for i in missing:                       # (rare path: one more tiny launch each, no host->device copy)
+                self._flags[b][i].zero_()
             work = dist.all_reduce(flat, group=self.group, async_op=True)
         self._launched[b] = True
         self._pending.append((b, work))
@@ -242,8 +296,15 @@ class OverlappedGradReducer(object):
         with self._side():
             for b, work in self._pending:
                 work.wait()                  # orders the SIDE stream after the collective
+                self._check_flags(b)         # last step's counts (host copy long complete); raises on a partial gradient
+                self._flag_host[b].copy_(self._flags[b], non_blocking=True)    # this step's counts, inspected next step
+                if self.use_cuda:
+                    self._flag_event[b] = torch.cuda.Event()
+                    self._flag_event[b].record(self.stream)
+                else:
+                    self._flag_event[b] = True
                 if self.world_size > 1:      # (sum, then ONE division: dist_utils.py:17-19; x / 1 is x)
-                    self._flat[b].div_(self.world_size)
+                    self._flat[b][:self._flat[b].numel() - len(self.buckets[b])].div_(self.world_size)
         if self.use_cuda:
             torch.cuda.current_stream().wait_stream(self.stream)
         for plist, views in zip(self.buckets, self._views):

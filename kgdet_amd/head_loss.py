@@ -74,7 +74,12 @@ def applicable(head, cfg, cls_scores, kpt_preds, bbox_preds, gt_bboxes, gt_label
         if g < 1 or g > MAX_GT or gt_bboxes[b].dtype != torch.float32 or gt_keypoints[b].dtype != torch.float32 or \
                 gt_keypoints[b].shape[1:] != (head.num_keypts, 3):
             return False
-        if gt_labels is not None and gt_labels[b] is not None and gt_labels[b].dtype != torch.int64:
+        # the kernels dereference the raw ground-truth pointers: they must live on the maps' device (CPU-resident or
+        # other-GPU ground truth takes the torch chain, which raises torch's own device-mismatch error or works)
+        if gt_bboxes[b].device != t0.device or gt_keypoints[b].device != t0.device:
+            return False
+        if gt_labels is not None and gt_labels[b] is not None and (gt_labels[b].dtype != torch.int64 or
+                                                                   gt_labels[b].device != t0.device):
             return False
     return True
 

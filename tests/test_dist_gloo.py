@@ -205,3 +205,86 @@ def test_two_rank_gradient_allreduce():
     for p in procs:
         p.join(timeout=60)
     assert res == {0: True, 1: True}
+
+
+def _worker_enforce(rank, world, port, q):
+    """Round-4 hardening (ADVICE r3 dist.py:251): the preconditions of the overlapped exchange are
+    enforced instead of documented."""
+    ok = True
+    try:
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        from kgdet_amd.dist import OverlappedGradReducer
+        torch.manual_seed(0)
+        model = nn.Sequential(nn.Linear(8, 16), nn.ReLU(), nn.Linear(16, 4))
+        extra = nn.Linear(8, 2)
+        params = list(model.parameters()) + list(extra.parameters())
+        x = torch.randn(5, 8, generator=torch.Generator().manual_seed(100 + rank))
+
+        # (a) ranks that would cut different buckets (rank 1 also trains `extra`) fail loudly at build time, on BOTH ranks,
+        #     instead of hanging in the first collective whose sizes differ
+        loss = model(x).pow(2).sum() + (extra(x).pow(2).sum() if rank == 1 else 0.0)
+        loss.backward()
+        red = OverlappedGradReducer(params, bucket_size_mb=0.0005)
+        try:
+            red.finish()
+            ok = False
+        except RuntimeError as e:
+            ok &= 'disagree on the gradient buckets' in str(e)
+        red.close()
+
+        # (b) same buckets everywhere; then one rank misses one parameter's gradient in a step: the exchange itself goes
+        #     through (zeros), the NEXT finish() raises on every rank
+        for p in params:
+            p.grad = None
+        red = OverlappedGradReducer(list(model.parameters()), bucket_size_mb=0.0005)
+        for _ in range(2):
+            for p in model.parameters():
+                p.grad = None
+            model(x).pow(2).sum().backward()
+            red.finish()
+        ok &= red.layout_digest[0] == len(red.buckets)
+        for p in model.parameters():
+            p.grad = None
+
+        def without_bias():                          # the last layer's bias takes no part: its gradient stays None
+            return torch.nn.functional.linear(torch.relu(model[0](x)), model[2].weight).pow(2).sum()
+        (without_bias() if rank == 1 else model(x).pow(2).sum()).backward()     # lost on rank 1 only
+        red.finish()                                 # completes: zeros from rank 1
+        for p in model.parameters():
+            p.grad = None
+        model(x).pow(2).sum().backward()
+        try:
+            red.finish()
+            ok = False
+        except RuntimeError as e:
+            ok &= 'some ranks only' in str(e)
+        # a parameter without a gradient on EVERY rank is legal (count 0): no error
+        red.close()
+        red = OverlappedGradReducer(list(model.parameters()), bucket_size_mb=0.0005)
+        for step in range(4):
+            for p in model.parameters():
+                p.grad = None
+            (without_bias() if step == 2 else model(x).pow(2).sum()).backward()
+            red.finish()
+        q.put((rank, bool(ok)))
+        dist.destroy_process_group()
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        q.put((rank, False))
+        raise
+
+
+def test_two_rank_preconditions_are_enforced():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_enforce, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == {0: True, 1: True}

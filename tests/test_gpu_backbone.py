@@ -619,3 +619,42 @@ def test_fp16_forward_parts_envelope(xs, ws, tol):
         ref = F.conv2d(x.double(), w.double(), padding=k // 2)
         err = float((y.double() - ref).abs().max() / ref.abs().max())
         assert err < tol, (k, err)
+
+
+@pytest.mark.gpu
+def test_fp16_forward_parts_saturate_instead_of_nan():
+    """Round-3 ADVICE (medium): an operand beyond fp16's range used to become hi = inf, lo = v - inf = -inf and the MFMA sum
+    inf + (-inf) = NaN poisoned the whole output channel.  The fp16-part kernels now run with the MODE register's FP16_OVFL
+    bit set (csrc/conv1x1.hip f16_saturate_on): a part beyond +/-65504 is clamped, so (a) activations up to 131008 = 2 x
+    65504 are still represented by hi + lo and the result keeps fp32-class accuracy, (b) a folded BatchNorm channel with a
+    tiny running variance (var = 1e-12, gamma = 1: w * s ~ 3e3 beyond the 255 the 2^8-scaled image holds) gives a FINITE,
+    clamped channel and leaves every other channel exact."""
+    from kgdet_amd import conv1x1 as c1
+    assert c1.FORWARD_F16
+    g = torch.Generator().manual_seed(1)
+    for k in (1, 3):
+        x = torch.randn(2, 64, 40, 44, generator=g)
+        x[:, 3] *= 1e5                                  # |x| up to ~4e5 in one input channel: beyond fp16, partly beyond 2 x max
+        x[:, 5] = x[:, 5].sign() * 1.2e5                # inside 2 x 65504: exactly representable by the two parts
+        x = x.cuda()
+        w = (torch.randn(128, 64, k, k, generator=g) * 0.05).cuda()
+        img = c1._pack(w, False)
+        assert img.kgdet_f16
+        y = c1._apply(img, x, 128, k * k)
+        assert torch.isfinite(y).all(), 'an out-of-range activation produced inf / NaN'
+        xc = x.clone()
+        xc[:, 3] = xc[:, 3].clamp(-131008.0, 131008.0)  # what hi + lo hold after saturation
+        ref = F.conv2d(xc.double(), w.double(), padding=k // 2)
+        err = float((y.double() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-6, (k, err)
+        # a weight row beyond the image's range (a folded BatchNorm scale of 1 / sqrt(1e-12 + 1e-5) ~ 316 on |w| ~ 10)
+        w2 = w.clone()
+        w2[7] *= 4e4
+        img2 = c1._pack(w2, False)
+        x2 = torch.randn(2, 64, 40, 44, generator=g).cuda()
+        y2 = c1._apply(img2, x2, 128, k * k)
+        assert torch.isfinite(y2).all(), 'an out-of-range weight row produced inf / NaN'
+        ref2 = F.conv2d(x2.double(), w.double(), padding=k // 2)
+        keep = [o for o in range(128) if o != 7]
+        err2 = float((y2[:, keep].double() - ref2[:, keep]).abs().max() / ref2[:, keep].abs().max())
+        assert err2 < 2e-6, (k, err2)

@@ -443,3 +443,33 @@ def test_nms_workspace_bound_covers_every_split():
         need = layout(lengths)
         got = L.kgdet_nms_workspace_bytes(ctypes.c_int64(sum(lengths)), ctypes.c_int32(len(lengths)))
         assert got >= need, (lengths[:5], len(lengths), got, need)
+
+
+def _run_bench(argv, env_extra):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        if k not in env_extra:
+            env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + argv, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=300)
+
+
+def test_bench_refuses_an_n_gpu_line_from_fewer_devices():
+    """`bench.py --gpus N` (reference: tools/dist_train.sh:8-10 starts the ranks) checks the device count BEFORE anything
+    touches a GPU and exits non-zero with a message instead of printing an N-GPU line from fewer devices."""
+    import torch
+    n = torch.cuda.device_count() + 2
+    r = _run_bench(['--gpus', str(n), '--steps', '1', '--warmup', '0'], {})
+    assert r.returncode != 0
+    assert b'refusing to print' in r.stderr and not any(l.startswith(b'{') for l in r.stdout.splitlines())
+
+
+def test_bench_world_size_mismatch_exits_nonzero():
+    """Launched by a torch.distributed.run whose --nproc-per-node differs from --gpus: exit, do not measure."""
+    r = _run_bench(['--gpus', '4', '--steps', '1', '--warmup', '0'],
+                   {'RANK': '0', 'LOCAL_RANK': '0', 'WORLD_SIZE': '2', 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '29999'})
+    assert r.returncode != 0
+    assert b'WORLD_SIZE=2' in r.stderr and not any(l.startswith(b'{') for l in r.stdout.splitlines())
