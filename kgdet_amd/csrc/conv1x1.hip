@@ -79,8 +79,9 @@ constexpr float kF16WeightScale = 256.0f;
 // is clamped to +/-MAX_FP16, true infinities stay): set once at the top of every kernel that produces fp16 parts, no
 // instruction per element.  Without it v_cvt_pk_f16_f32 rounds |v| > 65504 to inf, hi = inf, lo = v - inf = -inf, and the
 // MFMA sum inf + (-inf) is NaN for the whole output channel (round-3 ADVICE; a folded BatchNorm scale gamma / sqrt(var + eps)
-// of a channel with a tiny running variance reaches that through w * s * 2^8).  With it: hi = 65504, lo = f16(v - 65504),
-// exact up to 131008 and clamped beyond -- finite, and the envelope test pins it.
+// of a channel with a tiny running variance reaches that through w * s * 2^8).  With it: hi = 65504, lo = f16(v - 65504):
+// an 11-bit representation up to 131008 (measured on the GPU: 2e-4 of the output scale) and clamped beyond -- finite; the
+// fp32-class envelope still ends at 65504 (tests/test_gpu_backbone.py::test_fp16_forward_parts_saturate_instead_of_nan).
 __device__ __forceinline__ void f16_saturate_on() {
   __builtin_amdgcn_s_setreg(1 /*HW_REG_MODE*/ | (23 << 6) /*offset*/ | (0 << 11) /*size - 1*/, 1u);
 }

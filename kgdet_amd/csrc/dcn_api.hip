@@ -269,18 +269,27 @@ bool plane_bwd_offset_ok(const kgdet_dcn_shape *s, const Derived &d, bool masked
 }
 size_t grad_tap_bytes(const kgdet_dcn_shape *s, const Derived &d) { return (size_t)s->N * s->deformable_groups * d.K * d.Ho * d.Wo * 64; }   // (v2 records: 64 B; one table per deformable group)
 struct InvTables {
-  size_t rec_bytes, slot_bytes, spill_bytes;
-  size_t total() const { return rec_bytes + slot_bytes + spill_bytes; }
+  size_t rec_bytes, hdr_bytes, cell_bytes, spill_bytes;
+  size_t total() const { return rec_bytes + hdr_bytes + cell_bytes + spill_bytes; }
 };
-InvTables inv_tables(const kgdet_dcn_shape *s, const Derived &d) {   // of ONE deformable group
+InvTables inv_tables(const kgdet_dcn_shape *s, const Derived &d) {   // of ONE deformable group (functions of the offsets alone)
   InvTables t;
-  const size_t tiles = (size_t)ceil_div(s->H * s->W, kTileN);
+  const int slots = dcn_inv_max_slots(s->H * s->W, d.Ho * d.Wo);
   t.rec_bytes = (size_t)s->N * d.K * s->H * s->W * 64;
-  t.slot_bytes = align_up((size_t)s->N * d.K * tiles * sizeof(DcnInvOvfSlots), 64);
+  t.hdr_bytes = align_up((size_t)s->N * d.K * sizeof(int), 64);
+  t.cell_bytes = align_up((size_t)s->N * d.K * slots * sizeof(DcnInvOvfCell), 64);
   t.spill_bytes = (size_t)s->N * d.K * 4 * d.Ho * d.Wo * 8;
   return t;
 }
 size_t inv_tables_all(const kgdet_dcn_shape *s, const Derived &d) { return s->deformable_groups * align_up(inv_tables(s, d).total(), 256); }
+// what depends on grad_output as well: the pre-aggregated sums of the long cells (one table per deformable group) and
+// the pixel-major copy of the convolution's grad_output channels they are formed from
+int inv_gov_ld(const kgdet_dcn_shape *s, const Derived &d) { return s->groups * d.Og_pad16; }
+size_t inv_gov_bytes(const kgdet_dcn_shape *s, const Derived &d) {   // of ONE deformable group
+  return align_up((size_t)s->N * d.K * dcn_inv_max_slots(s->H * s->W, d.Ho * d.Wo) * inv_gov_ld(s, d) * sizeof(float), 256);
+}
+size_t inv_gout_t_bytes(const kgdet_dcn_shape *s, const Derived &d) { return align_up((size_t)s->N * d.Ho * d.Wo * s->O * sizeof(float), 256); }
+size_t inv_sums_all(const kgdet_dcn_shape *s, const Derived &d) { return s->deformable_groups * inv_gov_bytes(s, d) + inv_gout_t_bytes(s, d); }
 // backward tiles (256 / 128 channels wide) must lie inside one deformable group
 bool mfma_bwd_ok(const kgdet_dcn_shape *s) {
   const int cpdg = s->C / s->deformable_groups, Cg = s->C / s->groups;
@@ -335,7 +344,7 @@ size_t kgdet_dcn_workspace_bytes(const kgdet_dcn_shape *s) {
   const size_t bwd_in = pl.ok ? (pl.slab_floats + pl.off_floats + pl.mask_floats) * sizeof(float) +
                                     pl.rowptr_ints * sizeof(int) + pl.entry_pairs * 8 + 64
                               : 0;
-  size_t bwd_in_plane = plane_bwd_input_ok(s, d) ? slab_bytes() + inv_tables_all(s, d) : 0;
+  size_t bwd_in_plane = plane_bwd_input_ok(s, d) ? slab_bytes() + inv_tables_all(s, d) + inv_sums_all(s, d) : 0;
   if (plane_bwd_offset_ok(s, d) && slab_bytes() + grad_tap_bytes(s, d) > bwd_in_plane)
     bwd_in_plane = slab_bytes() + grad_tap_bytes(s, d);
   size_t need = fwd_and_wgrad > bwd_in ? fwd_and_wgrad : bwd_in;
@@ -367,7 +376,7 @@ size_t kgdet_dcn_group_workspace_bytes(int32_t n, const kgdet_dcn_shape *const *
     Derived d;
     if (!shapes || derive(shapes[i], d)) return 0;
     tables += tap_table_bytes(shapes[i], d);
-    if (plane_bwd_input_ok(shapes[i], d)) bwd_tables += inv_tables_all(shapes[i], d);
+    if (plane_bwd_input_ok(shapes[i], d)) bwd_tables += inv_tables_all(shapes[i], d) + inv_sums_all(shapes[i], d);
     wgrad_tables += align_up(tap_table_bytes(shapes[i], d), 256) +
                     (size_t)shapes[i]->groups * (d.Og_pad / kTileM) * shapes[i]->N * ceil_div(d.Ho * d.Wo, kChunk) * 16384;
     const size_t w = kgdet_dcn_workspace_bytes(shapes[i]);
@@ -749,11 +758,14 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
   }
   const InvTables it = inv_tables(s, d);
   const size_t it_stride = align_up(it.total(), 256);
-  if (workspace == nullptr || workspace_bytes < slab_bytes() + inv_tables_all(s, d)) {
-    set_error("workspace too small: need %zu bytes, got %zu", slab_bytes() + inv_tables_all(s, d), workspace_bytes);
+  if (workspace == nullptr || workspace_bytes < slab_bytes() + inv_tables_all(s, d) + inv_sums_all(s, d)) {
+    set_error("workspace too small: need %zu bytes, got %zu", slab_bytes() + inv_tables_all(s, d) + inv_sums_all(s, d), workspace_bytes);
     return KGDET_E_WORKSPACE;
   }
   unsigned char *base = (unsigned char *)workspace + slab_bytes();
+  unsigned char *sums_base = base + inv_tables_all(s, d);              // [DG] Gov tables, then the pixel-major grad_output
+  float *gout_t = (float *)(sums_base + (size_t)s->deformable_groups * inv_gov_bytes(s, d));
+  const int gov_slots = dcn_inv_max_slots(s->H * s->W, d.Ho * d.Wo), gov_ld = inv_gov_ld(s, d);
   static thread_local bool attr_set = false;
   if (!attr_set) {
     KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_build_inverse_taps, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -771,7 +783,31 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
     unsigned char *tb = base + (size_t)dgi * it_stride;
     hipLaunchKernelGGL(dcn_build_inverse_taps, dim3(s->N * d.K), dim3(256),
                        dcn_build_inverse_taps_lds_bytes(s->H * s->W, d.Ho * d.Wo), (hipStream_t)stream, f, (uint4 *)tb,
-                       (DcnInvOvfSlots *)(tb + it.rec_bytes), (uint2 *)(tb + it.rec_bytes + it.slot_bytes));
+                       (int *)(tb + it.rec_bytes), (DcnInvOvfCell *)(tb + it.rec_bytes + it.hdr_bytes),
+                       (int2 *)(tb + it.rec_bytes + it.hdr_bytes + it.cell_bytes));
+  }
+  {   // sums of the cells with more than 8 contributions, for all output channels (dcn_backward_plane.hip)
+    const int O_total_ = s->out_channels_total > 0 ? s->out_channels_total : s->O;
+    DcnPixelMajorGroup pm;
+    pm.n = 1;
+    pm.e[0] = DcnPixelMajorItem{grad_output + (size_t)s->out_channel_offset * d.Ho * d.Wo, gout_t, s->N, s->O, d.Ho * d.Wo,
+                                (long long)O_total_ * d.Ho * d.Wo};
+    hipLaunchKernelGGL(dcn_gout_pixel_major_multi, dim3(ceil_div(d.Ho * d.Wo, 32), ceil_div(s->O, 32), s->N), dim3(256), 0,
+                       (hipStream_t)stream, pm);
+    DcnInvSumGroup sg;
+    sg.n = 0;
+    for (int dgi = 0; dgi < s->deformable_groups; ++dgi) {
+      if (sg.n == kMaxFwdGroup) {
+        hipLaunchKernelGGL(dcn_inv_overflow_sums, dim3(s->N * d.K, kInvSumSplit, sg.n), dim3(256), 0, (hipStream_t)stream, sg);
+        sg.n = 0;
+      }
+      unsigned char *tb = base + (size_t)dgi * it_stride;
+      sg.e[sg.n++] = DcnInvSum{(const int *)(tb + it.rec_bytes), (const DcnInvOvfCell *)(tb + it.rec_bytes + it.hdr_bytes),
+                               (const int2 *)(tb + it.rec_bytes + it.hdr_bytes + it.cell_bytes), gout_t,
+                               (float *)(sums_base + (size_t)dgi * inv_gov_bytes(s, d)), s->N * d.K, d.K, d.Ho * d.Wo, s->O,
+                               d.Og, d.Og_pad16, gov_ld, gov_slots};
+    }
+    hipLaunchKernelGGL(dcn_inv_overflow_sums, dim3(s->N * d.K, kInvSumSplit, sg.n), dim3(256), 0, (hipStream_t)stream, sg);
   }
   const int G = grid_size();
   const int parts = (flags & KGDET_DCN_BF16) ? 1 : 2;
@@ -806,7 +842,8 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
            (size_t)g * d.plane_t_image_floats();
     unsigned char *tb = base + (size_t)runs[r].dgi * it_stride;
     p.taps = reinterpret_cast<const DcnTapRec *>(tb);
-    p.inv_ovf = (const DcnInvOvfSlots *)(tb + it.rec_bytes); p.inv_spill = (const uint2 *)(tb + it.rec_bytes + it.slot_bytes);
+    p.inv_gov = (const float *)(sums_base + (size_t)runs[r].dgi * inv_gov_bytes(s, d));
+    p.gov_slots = gov_slots; p.gov_ld = gov_ld; p.gov_c0 = g * d.Og_pad16;
     p.build_taps = 0;
     grp.p[grp.n] = p;
     grp.tile_begin[grp.n + 1] = grp.tile_begin[grp.n] + p.n_ntiles * p.n_mtiles;
@@ -944,7 +981,7 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
   const int G = grid_size();
   Derived dd[kMaxFwdGroup];
   int same_as[kMaxFwdGroup];  // earlier problem with the same offsets and geometry (shares its records)
-  size_t inv_off[kMaxFwdGroup], rec_off[kMaxFwdGroup], inv_total = 0, rec_total = 0;
+  size_t inv_off[kMaxFwdGroup], rec_off[kMaxFwdGroup], sum_off[kMaxFwdGroup], inv_total = 0, rec_total = 0;
   int max_K = 0;
   for (int i = 0; i < n; ++i) {
     const kgdet_dcn_shape *s = shapes[i];
@@ -970,6 +1007,9 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
       inv_off[i] = inv_off[same_as[i]]; rec_off[i] = rec_off[same_as[i]];
     }
     max_K = dd[i].K > max_K ? dd[i].K : max_K;
+  }
+  for (int i = 0; i < n; ++i) {   // per problem (functions of its grad_output): the long cells' sums + the pixel-major grad_output
+    sum_off[i] = inv_total; inv_total += inv_sums_all(shapes[i], dd[i]);
   }
   const size_t tables = inv_total > rec_total ? inv_total : rec_total;  // the two phases run one after the other
   if (workspace == nullptr || workspace_bytes < slab_bytes() + tables) {
@@ -1003,18 +1043,36 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
   builds.n = 0;
   int build_blocks = 0;
   size_t build_lds = 0;
+  DcnPixelMajorGroup pmg;      // grad_output windows -> pixel-major copies, one launch
+  pmg.n = 0;
+  int pm_px = 0, pm_c = 0, pm_images = 0;
+  DcnInvSumGroup sums;         // the long cells' sums of every problem, one launch
+  sums.n = 0;
+  int sums_blocks = 0;
   for (int i = 0; i < n; ++i) {
     const kgdet_dcn_shape *s = shapes[i];
     const Derived &d = dd[i];
     const InvTables it = inv_tables(s, d);
     uint4 *inv = (uint4 *)(tab + inv_off[i]);
-    DcnInvOvfSlots *slots = (DcnInvOvfSlots *)(tab + inv_off[i] + it.rec_bytes);
-    uint2 *spill = (uint2 *)(tab + inv_off[i] + it.rec_bytes + it.slot_bytes);
+    int *hdr = (int *)(tab + inv_off[i] + it.rec_bytes);
+    DcnInvOvfCell *cells = (DcnInvOvfCell *)(tab + inv_off[i] + it.rec_bytes + it.hdr_bytes);
+    int2 *spill = (int2 *)(tab + inv_off[i] + it.rec_bytes + it.hdr_bytes + it.cell_bytes);
+    float *gov = (float *)(tab + sum_off[i]);
+    float *gout_t = (float *)(tab + sum_off[i] + inv_gov_bytes(s, d));
+    {
+      const int O_total_ = s->out_channels_total > 0 ? s->out_channels_total : s->O;
+      pmg.e[pmg.n++] = DcnPixelMajorItem{grad_outputs[i] + (size_t)s->out_channel_offset * d.Ho * d.Wo, gout_t, s->N, s->O,
+                                         d.Ho * d.Wo, (long long)O_total_ * d.Ho * d.Wo};
+      pm_px = d.Ho * d.Wo > pm_px ? d.Ho * d.Wo : pm_px; pm_c = s->O > pm_c ? s->O : pm_c; pm_images += s->N;
+      sums.e[sums.n++] = DcnInvSum{hdr, cells, spill, gout_t, gov, s->N * d.K, d.K, d.Ho * d.Wo, s->O, d.Og, d.Og_pad16,
+                                   inv_gov_ld(s, d), dcn_inv_max_slots(s->H * s->W, d.Ho * d.Wo)};
+      sums_blocks = s->N * d.K > sums_blocks ? s->N * d.K : sums_blocks;
+    }
     if (same_as[i] < 0) {   // (all distinct offset tensors of the group: one builder launch below)
       DcnInvBuild &e = builds.e[builds.n++];
       fill_problem(s, d, 0, e.p);
       e.p.offset = offsets[i]; e.p.mask = nullptr;
-      e.inv = inv; e.slots = slots; e.spill = spill;
+      e.inv = inv; e.hdr = hdr; e.cells = cells; e.spill = spill;
       const int blocks = s->N * d.K;
       build_blocks = blocks > build_blocks ? blocks : build_blocks;
       const size_t need = dcn_build_inverse_taps_lds_bytes(s->H * s->W, d.Ho * d.Wo);
@@ -1039,7 +1097,7 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
     p.kparts = 1;
     p.wq = packed_weights[i] + (d.fwd_image_floats() + d.bwd_image_floats() + d.plane_image_floats());
     p.taps = reinterpret_cast<const DcnTapRec *>(inv);
-    p.inv_ovf = slots; p.inv_spill = spill;
+    p.inv_gov = gov; p.gov_slots = dcn_inv_max_slots(s->H * s->W, d.Ho * d.Wo); p.gov_ld = inv_gov_ld(s, d); p.gov_c0 = 0;
     grp.p[grp.n] = p;
     grp.tile_begin[grp.n + 1] = grp.tile_begin[grp.n] + p.n_ntiles * p.n_mtiles;
     grp.range_begin[grp.n + 1] = grp.range_begin[grp.n] + p.n_ntiles * p.n_mtiles;
@@ -1059,6 +1117,9 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
     hipLaunchKernelGGL(dcn_build_inverse_taps_multi, dim3(build_blocks, builds.n), dim3(256), build_lds, (hipStream_t)stream,
                        builds);
   }
+  hipLaunchKernelGGL(dcn_gout_pixel_major_multi, dim3(ceil_div(pm_px, 32), ceil_div(pm_c, 32), pm_images), dim3(256), 0,
+                     (hipStream_t)stream, pmg);
+  hipLaunchKernelGGL(dcn_inv_overflow_sums, dim3(sums_blocks, kInvSumSplit, sums.n), dim3(256), 0, (hipStream_t)stream, sums);
   lds = plan_plane_lds(grp, lds, dcn_bwd_input_plane_fixed_lds_bytes(2));
   grp.wave_layout = dcn_plane_wave_layout();   // plane_role's accumulator layout (slabs are decoded by dcn_fwd_fixup)
   const int Gs = small_launch_grid(grp, G);

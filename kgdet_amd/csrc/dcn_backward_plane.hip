@@ -11,8 +11,9 @@
 // which is the forward GEMM with the roles of input and output channels swapped and "sampling" replaced by
 // TRANSPOSED sampling: cell q gathers from a short list of (pixel, weight) pairs instead of from 4 corners.
 // dcn_build_inverse_taps inverts the sampling map per (image, tap) -- counting sort in LDS, lists sorted by
-// pixel so every sum has a fixed order -- and stores, per cell, the first 8 pairs inline (DcnInvRec) and the rest
-// in a per-(tap, 128-cell tile) overflow list (DcnInvOvfSlots + spill array).  dcn_bwd_input_plane is then
+// pixel so every sum has a fixed order -- and stores, per cell with at most 8 pairs, the pairs inline (DcnInvRec); the sum
+// of a cell with more is formed beforehand for all output channels by dcn_inv_overflow_sums (below; round 4 -- the cost of
+// the whole backward no longer depends on where the sampling points fall).  dcn_bwd_input_plane is then
 // plane_role<MODE = 1>: grad_out planes in LDS, weights from the transposed operand image `wqt`, bf16 hi/lo
 // split MFMA, stream-K with the forward's fix-up.  No atomics, deterministic, no pre-zeroing of grad_input.
 // Deformable groups > 1 (different cells lists per channel group inside one M tile) stay on the older kernels.
@@ -38,13 +39,18 @@ size_t dcn_bwd_input_plane_lds_bytes(int parts, int plane_pixels) {
 // ------------------------------------------------------------------------------------------------
 // Inverse sampling records.  One workgroup per (image, tap); p describes the FORWARD problem
 // (x [N, C, H, W], offsets over Ho x Wo) and names the deformable group (p.dgi) whose offsets are read.
-//   inv   [N][K][H*W] DcnInvRec     first 8 contributions of every input cell
-//   slots [N][K][tiles] DcnInvOvfSlots  (tiles = ceil(H*W / 128))
-//   spill [N][K][4 * Ho*Wo] entries  all overflow entries, tile after tile
-// LDS: cnt [HW + 1], cursor [HW], ent [4 * HoWo] (pixel, weight) pairs.
+//   inv   [N][K][H*W] DcnInvRec       cells with <= 8 contributions: inline, sorted by pixel; others: flag + slot
+//   hdr   [N][K] int                  cells of the (image, tap) with > 8 contributions
+//   cells [N][K][max_slots]           DcnInvOvfCell of those cells, in cell order (slot = rank among them)
+//   spill [N][K][4 * Ho*Wo] int2      every (pixel, weight) entry of the (image, tap), grouped by cell (order inside a
+//                                     cell arbitrary: dcn_inv_overflow_sums sums in ascending pixel order)
+// LDS: cnt [HW + 1], cursor [HW], ent [4 * HoWo] (pixel, weight) pairs, flag / slot scans [2 * HW].
+// Cost independent of how the sampling points are distributed: no per-cell loop is longer than 8 entries (rounds 2-3
+// insertion-sorted every list -- quadratic in a cell's length -- and the builder of a head stage went from 37 to 118 us
+// while the training step's offsets concentrated).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void build_inverse_taps_body(const DcnProblem &p, uint4 *__restrict__ inv,
-                                                        DcnInvOvfSlots *__restrict__ slots, uint2 *__restrict__ spill,
+__device__ __forceinline__ void build_inverse_taps_body(const DcnProblem &p, uint4 *__restrict__ inv, int *__restrict__ hdr,
+                                                        DcnInvOvfCell *__restrict__ cells, int2 *__restrict__ spill,
                                                         int block, int *sm) {
   const int HW = p.H * p.W;
   int *cnt = sm;                                          // [HW + 1]
@@ -54,7 +60,7 @@ __device__ __forceinline__ void build_inverse_taps_body(const DcnProblem &p, uin
 
   const int t = block % p.K, b = block / p.K;
   const int tid = threadIdx.x;
-  const int n_tiles = (HW + kTileN - 1) / kTileN;
+  const int max_slots = dcn_inv_max_slots(HW, p.HoWo);
 
   for (int i = tid; i <= HW; i += 256) cnt[i] = 0;
   __syncthreads();
@@ -99,7 +105,7 @@ __device__ __forceinline__ void build_inverse_taps_body(const DcnProblem &p, uin
     __syncthreads();
     return total;
   };
-  scan(cnt, cursor);
+  const int n_entries = scan(cnt, cursor);
   // pass 2: fill (slot order inside a cell is arbitrary here ...)
   for (int px = tid; px < p.HoWo; px += 256) {
     const int oy = px / p.Wo, ox = px - oy * p.Wo;
@@ -117,10 +123,13 @@ __device__ __forceinline__ void build_inverse_taps_body(const DcnProblem &p, uin
       }
   }
   __syncthreads();
-  // ... so sort every cell's (short) list by pixel; two corners of one pixel never share a cell
+  // ... so the SHORT lists (the ones that stay inline) are sorted by pixel here; two corners of one pixel never share a
+  // cell.  Longer lists are summed in pixel order by dcn_inv_overflow_sums without being sorted.
   for (int cell = tid; cell < HW; cell += 256) {
+    const int n = cnt[cell];
+    if (n > kInvInline) continue;
     const int e1 = cursor[cell];  // end (cursor advanced by the fill)
-    const int e0 = e1 - cnt[cell];
+    const int e0 = e1 - n;
     for (int i = e0 + 1; i < e1; ++i) {
       const int2 key = ent[i];
       int j = i - 1;
@@ -128,80 +137,50 @@ __device__ __forceinline__ void build_inverse_taps_body(const DcnProblem &p, uin
       ent[j + 1] = key;
     }
   }
-  __syncthreads();
   // pixel -> LDS byte offset of its quad 0 (< 2^17: the upper 15 bits of a record's last offset are free)
   auto plane_off = [](int px) { return (unsigned)dcn_plane_offset(px); };
   uint4 *inv_bt = inv + (size_t)(b * p.K + t) * HW * 4;
-  // overflow: contributions 8.. of every cell, compacted in cell order; `cursor` becomes their start positions
-  for (int cell = tid; cell < HW; cell += 256) {
-    const int n = cnt[cell];
-    cursor[cell] -= n;               // back to the list start (the records above are done with the end)
-    cnt[cell] = n | (max(n - 8, 0) << 16);  // low half: list length, high half: overflow length
-  }
-  __syncthreads();
-  // scan the overflow lengths (kept in a scratch view: reuse wave-private registers through a lambda on a copy)
   int *extra = reinterpret_cast<int *>(ent + (size_t)4 * p.HoWo);  // [HW] ints right behind the entries (LDS sized for it)
   int *epos = extra + HW;                                          // [HW]
-  for (int cell = tid; cell < HW; cell += 256) extra[cell] = cnt[cell] >> 16;
+  for (int cell = tid; cell < HW; cell += 256) extra[cell] = cnt[cell] > kInvInline ? 1 : 0;
   __syncthreads();
-  scan(extra, epos);
-  // inline records: the first 8 contributions of every cell.  The last offset also carries the cell's overflow range
-  // -- count (5 bits) << 27 | start inside the (tile, tap)'s list (10 bits) << 17 -- so that a producer thread of the
-  // grad_input kernel walks ITS OWN overflow entries instead of scanning the whole list (one dependent scalar load +
-  // a divergent body per entry: 360 us against 210 for a head stage with N(0, 2^2)-pixel offsets).  A tile whose ranges
-  // do not fit the fields gets a negative count: list scan, as before.
-  int *tile_scan = epos + HW;     // [16] tiles whose ranges do not fit the fields (H*W <= 1536: at most 12 tiles)
-  if (tid < 16) tile_scan[tid] = 0;
-  __syncthreads();
+  const int n_flagged = scan(extra, epos);     // epos[cell] = the cell's slot among the (image, tap)'s long cells
+  const size_t bt = (size_t)(b * p.K + t);
+  if (tid == 0) hdr[bt] = n_flagged < max_slots ? n_flagged : max_slots;   // (cannot exceed the bound: 9 entries per long cell)
   for (int cell = tid; cell < HW; cell += 256) {
-    const int n = cnt[cell] & 0xffff, ne = cnt[cell] >> 16, e0 = cursor[cell];
-    const int st = epos[cell] - epos[(cell / kTileN) * kTileN];
-    if (ne > 31 || st + ne > 1023) tile_scan[cell / kTileN] = 1;
+    const int n = cnt[cell], e0 = cursor[cell] - n;
+    const bool long_cell = n > kInvInline;
     unsigned off[8];
     float w[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int2 e = ent[e0 + min(i, max(n - 1, 0))];
-      off[i] = i < n ? plane_off(e.x) : plane_off(0);   // (weight 0; a plane address all the same: 0 x garbage could be NaN)
-      w[i] = i < n ? __int_as_float(e.y) : 0.0f;
+      const bool live = !long_cell && i < n;
+      off[i] = live ? plane_off(e.x) : plane_off(0);   // (weight 0; a plane address all the same: 0 x garbage could be NaN)
+      w[i] = live ? __int_as_float(e.y) : 0.0f;
     }
-    off[7] |= ((unsigned)min(ne, 31) << 27) | ((unsigned)min(st, 1023) << 17);
+    if (long_cell) {
+      const int slot = epos[cell];
+      off[7] |= kInvFlag | ((unsigned)slot << 17);
+      if (slot < max_slots) cells[bt * max_slots + slot] = DcnInvOvfCell{e0, n, cell, 0};
+    }
     uint4 *r = inv_bt + (size_t)cell * 4;
     r[0] = make_uint4(off[0], off[1], off[2], off[3]);
     r[1] = make_uint4(off[4], off[5], off[6], off[7]);
     r[2] = make_uint4(__float_as_uint(w[0]), __float_as_uint(w[1]), __float_as_uint(w[2]), __float_as_uint(w[3]));
     r[3] = make_uint4(__float_as_uint(w[4]), __float_as_uint(w[5]), __float_as_uint(w[6]), __float_as_uint(w[7]));
   }
-  uint2 *spill_bt = spill + (size_t)(b * p.K + t) * 4 * p.HoWo;
-  DcnInvOvfSlots *slots_bt = slots + (size_t)(b * p.K + t) * n_tiles;
-  for (int cell = tid; cell < HW; cell += 256) {
-    const int n = cnt[cell] & 0xffff, ne = cnt[cell] >> 16;
-    if (ne == 0) continue;
-    const int tile = cell / kTileN, tile_start = epos[tile * kTileN];
-    const int e0 = cursor[cell] + 8;
-    for (int i = 0; i < ne; ++i) {
-      const int2 e = ent[e0 + i];
-      const uint2 v = make_uint2((plane_off(e.x) << 7) | (unsigned)(cell - tile * kTileN), (unsigned)e.y);
-      const int pos = epos[cell] + i;
-      spill_bt[pos] = v;
-      if (pos - tile_start < DcnInvOvfSlots::kCap) slots_bt[tile].e[pos - tile_start] = v;
-    }
-    (void)n;
-  }
-  for (int tile = tid; tile < n_tiles; tile += 256) {
-    const int s0 = epos[tile * kTileN];
-    const int last = min((tile + 1) * kTileN, HW) - 1;
-    const int s1 = epos[last] + extra[last];
-    slots_bt[tile].count = tile_scan[tile] ? -(s1 - s0) : s1 - s0;   // < 0: ranges not in the records, scan the list
-    slots_bt[tile].spill_start = (int)((size_t)(b * p.K + t) * 4 * p.HoWo) + s0;
+  // the entry list leaves as it lies (coalesced); only the long cells' ranges of it are ever read
+  if (n_flagged > 0) {
+    int2 *spill_bt = spill + bt * 4 * p.HoWo;
+    for (int i = tid; i < n_entries; i += 256) spill_bt[i] = ent[i];
   }
 }
 
-__global__ __launch_bounds__(256) void dcn_build_inverse_taps(const DcnProblem p, uint4 *__restrict__ inv,
-                                                              DcnInvOvfSlots *__restrict__ slots,
-                                                              uint2 *__restrict__ spill) {
+__global__ __launch_bounds__(256) void dcn_build_inverse_taps(const DcnProblem p, uint4 *__restrict__ inv, int *__restrict__ hdr,
+                                                              DcnInvOvfCell *__restrict__ cells, int2 *__restrict__ spill) {
   extern __shared__ __attribute__((aligned(16))) int sm[];
-  build_inverse_taps_body(p, inv, slots, spill, (int)blockIdx.x, sm);
+  build_inverse_taps_body(p, inv, hdr, cells, spill, (int)blockIdx.x, sm);
 }
 
 // the inverse tables of several problems in ONE launch: block (x, y) = (image, tap) x of problem y.  (A problem has N * K
@@ -211,7 +190,131 @@ __global__ __launch_bounds__(256) void dcn_build_inverse_taps_multi(const DcnInv
   extern __shared__ __attribute__((aligned(16))) int sm[];
   const DcnInvBuild &e = grp.e[blockIdx.y];
   if ((int)blockIdx.x >= e.p.N * e.p.K) return;
-  build_inverse_taps_body(e.p, e.inv, e.slots, e.spill, (int)blockIdx.x, sm);
+  build_inverse_taps_body(e.p, e.inv, e.hdr, e.cells, e.spill, (int)blockIdx.x, sm);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gov[image, tap, slot][o] = sum over the contributions e of a long cell of w_e * grad_out[image, o, p_e], all output
+// channels o of the convolution at once (the plane kernel would walk the list once per 16-channel chunk).
+// grid = (N * K, kInvSumSplit, problems): workgroup (bt, y) takes the slots y, y + kInvSumSplit, ... of (image, tap) bt.
+// Per cell: the entries are scattered into a dense by-pixel weight array + a bitmap (a pixel contributes at most once to a
+// cell), the set bits are ranked (popcount prefix) into an ascending pixel list, sixteen 16-lane groups sum sixteenths of
+// that list over all channels (a lane: 4 x 4 channels, 16-byte loads from the PIXEL-MAJOR copy of grad_out: 1 KB
+// contiguous per pixel at 256 channels), the sixteen partial vectors are added in group order.  Fixed order => bit-
+// repeatable; work proportional to the number of contributions, wherever they fall.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dcn_inv_overflow_sums(const DcnInvSumGroup grp) {
+  __shared__ float wd[kPlaneMaxHW];
+  __shared__ unsigned short sorted[kPlaneMaxHW];
+  __shared__ unsigned bitmap[64];
+  __shared__ int prefix[64];
+  __shared__ float part[16][256];
+  const DcnInvSum &e = grp.e[blockIdx.z];
+  const int bt = blockIdx.x;
+  if (bt >= e.NK) return;
+  const int count = e.hdr[bt];
+  if ((int)blockIdx.y >= count) return;
+  const int tid = threadIdx.x;
+  const int b = bt / e.K;
+  const int HoWo = e.HoWo, O = e.O, O_ld = e.O_ld;
+  const int words = (HoWo + 31) >> 5;
+  const int2 *spill_bt = e.spill + (size_t)bt * 4 * HoWo;
+  const float *gt = e.gout_t + (size_t)b * HoWo * O;
+  const int g16 = tid >> 4, l = tid & 15;
+  const bool vec = (O & 3) == 0;
+  for (int slot = blockIdx.y; slot < count; slot += gridDim.y) {
+    const DcnInvOvfCell c = e.cells[(size_t)bt * e.max_slots + slot];
+    if (tid < 64) bitmap[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < c.n; i += 256) {
+      const int2 en = spill_bt[c.start + i];
+      wd[en.x] = __int_as_float(en.y);
+      atomicOr(&bitmap[en.x >> 5], 1u << (en.x & 31));
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int pc = tid < words ? __popc(bitmap[tid]) : 0;
+      int incl = pc;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int nb = __shfl_up(incl, d);
+        if (tid >= d) incl += nb;
+      }
+      prefix[tid] = incl - pc;
+    }
+    __syncthreads();
+    for (int px = tid; px < HoWo; px += 256) {
+      const unsigned m = bitmap[px >> 5];
+      if ((m >> (px & 31)) & 1u) sorted[prefix[px >> 5] + __popc(m & ((1u << (px & 31)) - 1u))] = (unsigned short)px;
+    }
+    __syncthreads();
+    const int r0 = (int)((long long)g16 * c.n / 16), r1 = (int)((long long)(g16 + 1) * c.n / 16);
+    // a Gov vector holds the convolution's weight groups one after the other, each padded to whole 16-channel chunks
+    // (zeros: the chunk's padding channels meet zero weights, but must be finite)
+    float *dst = e.gov + ((size_t)bt * e.max_slots + slot) * O_ld;
+    for (int d = tid; d < O_ld; d += 256)
+      if (d % e.Og_pad16 >= e.Og) dst[d] = 0.0f;
+    for (int c0 = 0; c0 < O; c0 += 256) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int r = r0; r < r1; ++r) {
+        const int px = sorted[r];
+        const float w = wd[px];
+        const float *src = gt + (size_t)px * O;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ch = c0 + j * 64 + l * 4;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (vec) {
+            if (ch < O) v = *reinterpret_cast<const f32x4 *>(src + ch);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (ch + k < O) v[k] = src[ch + k];
+          }
+          acc[j][0] = __builtin_fmaf(w, v[0], acc[j][0]);
+          acc[j][1] = __builtin_fmaf(w, v[1], acc[j][1]);
+          acc[j][2] = __builtin_fmaf(w, v[2], acc[j][2]);
+          acc[j][3] = __builtin_fmaf(w, v[3], acc[j][3]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4 *>(&part[g16][j * 64 + l * 4]) = acc[j];
+      __syncthreads();
+      float sum = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) sum += part[g][tid];
+      if (c0 + tid < O) dst[((c0 + tid) / e.Og) * e.Og_pad16 + (c0 + tid) % e.Og] = sum;
+      __syncthreads();
+    }
+  }
+}
+
+// grad_out windows [n][O of O_total][P] -> pixel-major copies [n][P][O], several problems in one launch
+// (blockIdx.z = problem * N + image): 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void dcn_gout_pixel_major_multi(const DcnPixelMajorGroup grp) {
+  __shared__ float tile[32][33];
+  int z = blockIdx.z, pi = 0;
+  while (pi + 1 < grp.n && z >= grp.e[pi].N) { z -= grp.e[pi].N; ++pi; }
+  const DcnPixelMajorItem &it = grp.e[pi];
+  const int n = z;
+  const int P = it.P, C = it.C;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  if (n >= it.N || p0 >= P || c0 >= C) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float *s = it.src + (size_t)n * it.src_image_stride;
+  float *d = it.dst + (size_t)n * P * C;
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, px = p0 + tx;
+    tile[r][tx] = (c < C && px < P) ? s[(size_t)c * P + px] : 0.0f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int px = p0 + r, c = c0 + tx;
+    if (px < P && c < C) d[(size_t)px * C + c] = tile[tx][r];
+  }
 }
 
 size_t dcn_build_inverse_taps_lds_bytes(int HW, int HoWo) {

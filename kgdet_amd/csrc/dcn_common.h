@@ -31,16 +31,28 @@ struct DcnTapRec {
   float w[4];
 };
 // Transposed sampling (grad_input plane kernel): what input cell q collects for tap t.
-//   DcnInvRec      the first 8 (output pixel, weight) contributions, pixels as LDS byte offsets like DcnTapRec
-//                  (zero weight = unused slot); stored as [2 x off[4]][2 x w[4]] = 64 B
-//   DcnInvOvfSlots further contributions of all cells of one (image, tap, 128-cell tile): the first kCap inline
-//                  (staged through LDS by the kernel), all of them also in the spill list from spill_start
-//   entry .x = (LDS byte offset << 7) | cell index inside the tile, .y = weight bits
-struct DcnInvOvfSlots {
-  static constexpr int kCap = 32;
-  int count, spill_start;
-  uint2 e[kCap];
+//   DcnInvRec      a cell with at most 8 contributing (output pixel, corner) pairs: the (pixel, weight) contributions, pixels
+//                  as LDS byte offsets like DcnTapRec (zero weight = unused slot); stored as [2 x off[4]][2 x w[4]] = 64 B.
+//                  A cell with MORE than 8 contributions (round 4) carries eight zero weights and, in the upper bits of its
+//                  last offset, bit 31 + a slot number (bits 17..30): its whole sum over the contributions
+//                      Gov[image, tap, slot][o] = sum_e w_e * grad_out[o, p_e]     for ALL output channels o
+//                  was computed beforehand by dcn_inv_overflow_sums and the kernel adds that vector.
+//   DcnInvOvfCell  one such cell: its entries [start, start + n) of the (image, tap)'s entry list (unsorted; the summation
+//                  order is made a fixed one -- ascending pixel -- by the kernel that sums)
+// Why: a trained KGDet head samples tap t of EVERY location on an object at the same key point, so a few cells collect
+// hundreds of contributions each.  Rounds 2-3 kept contributions 9.. in per-(tap, tile) overflow lists that ONE producer
+// thread walked, per 16-channel chunk: the training step's grad_input went from 0.24 ms (random offsets) to 1.6 ms per
+// launch within 500 steps on the synthetic batch (profiles/r04_steady_trace.md) -- the slow-down round 3 mistook for a
+// thermal ramp.
+struct DcnInvOvfCell {
+  int start, n, cell, pad;
 };
+constexpr int kInvInline = 8;             // contributions a record holds
+constexpr unsigned kInvFlag = 1u << 31;   // record's last offset: the cell's sum is pre-aggregated
+__device__ __host__ __forceinline__ int dcn_inv_max_slots(int HW, int HoWo) {   // cells of one (image, tap) with > 8 contributions
+  const int by_entries = 4 * HoWo / (kInvInline + 1);
+  return (by_entries < HW ? by_entries : HW) + 1;
+}
 
 // The LDS feature plane of the plane kernels: a 16-channel slice of one image as FOUR quad planes
 // [quad][pixel][4 channels] fp32 -- pixel q's channel quad c at c * stride + q * 16.  A bilinear corner of 4 channels is
@@ -166,8 +178,9 @@ struct DcnProblem {
   const float *wpk;     // packed weight of this group: [K][Cg_pad][Og_pad]
   const void *wq;       // bf16 hi/lo image of this group for the plane kernel (dcn_forward_plane.hip)
   const DcnTapRec *taps;  // [N, DG, K, Ho*Wo] sampling records (plane kernel; MODE 1: DcnInvRec, 64 B each)
-  const DcnInvOvfSlots *inv_ovf;  // MODE 1: [N, K, tiles_per_image]
-  const uint2 *inv_spill;         // MODE 1: overflow entries of all (tile, tap)s
+  const float *inv_gov;   // MODE 1: [N * K][gov_slots][gov_ld] pre-aggregated sums of the cells with > 8 contributions
+  int gov_slots, gov_ld;  //         slots per (image, tap); floats per slot (all output channels of the convolution, padded to 16)
+  int gov_c0;             //         first channel of this (sub-)problem's grad_out window inside a Gov vector
   int build_taps;         // this problem owns `taps` (others of the group may alias it: same offsets and geometry)
   const float *bias;    // [O_total] or nullptr
   float *out;           // forward: [N, O_total, Ho, Wo]

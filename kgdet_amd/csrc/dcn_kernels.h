@@ -34,8 +34,8 @@ template <int PARTS>
 __global__ void dcn_bwd_input_plane(const DcnFwdGroup grp, float *__restrict__ slabs);
 size_t dcn_bwd_input_plane_lds_bytes(int parts, int plane_pixels);
 size_t dcn_bwd_input_plane_fixed_lds_bytes(int parts);
-__global__ void dcn_build_inverse_taps(const DcnProblem p, uint4 *__restrict__ inv, DcnInvOvfSlots *__restrict__ slots,
-                                       uint2 *__restrict__ spill);
+__global__ void dcn_build_inverse_taps(const DcnProblem p, uint4 *__restrict__ inv, int *__restrict__ hdr,
+                                       DcnInvOvfCell *__restrict__ cells, int2 *__restrict__ spill);
 size_t dcn_build_inverse_taps_lds_bytes(int HW, int HoWo);
 struct DcnPackOne {
   const float *w;
@@ -50,14 +50,41 @@ __global__ void dcn_pack_weight_all_multi(const DcnPackGroup grp);
 struct DcnInvBuild {
   DcnProblem p;
   uint4 *inv;
-  DcnInvOvfSlots *slots;
-  uint2 *spill;
+  int *hdr;
+  DcnInvOvfCell *cells;
+  int2 *spill;
 };
 struct DcnInvBuildGroup {
   int n;
   DcnInvBuild e[kMaxFwdGroup];
 };
 __global__ void dcn_build_inverse_taps_multi(const DcnInvBuildGroup grp);
+// sums of the cells with more than 8 contributions, all output channels (dcn_backward_plane.hip)
+constexpr int kInvSumSplit = 4;
+struct DcnInvSum {
+  const int *hdr;
+  const DcnInvOvfCell *cells;
+  const int2 *spill;
+  const float *gout_t;   // [N][HoWo][O]: pixel-major copy of the convolution's grad_output channels
+  float *gov;            // [N * K][max_slots][O_ld], O_ld = groups * Og_pad16
+  int NK, K, HoWo, O, Og, Og_pad16, O_ld, max_slots;
+};
+struct DcnInvSumGroup {
+  int n;
+  DcnInvSum e[kMaxFwdGroup];
+};
+__global__ void dcn_inv_overflow_sums(const DcnInvSumGroup grp);
+struct DcnPixelMajorItem {
+  const float *src;
+  float *dst;
+  int N, C, P;
+  long long src_image_stride;
+};
+struct DcnPixelMajorGroup {
+  int n;
+  DcnPixelMajorItem e[kMaxFwdGroup];
+};
+__global__ void dcn_gout_pixel_major_multi(const DcnPixelMajorGroup grp);
 // grad_offset on an LDS-resident plane (dcn_backward_offset.hip)
 template <int PARTS>
 __global__ void dcn_bwd_offset_plane(const DcnFwdGroup grp, float *__restrict__ slabs, int max_K);

@@ -82,8 +82,8 @@ constexpr bool kAFromL2 = true;   // (grad_weight kernel) consumers take their A
 // MODE of the plane kernels
 //   0  forward:     B stage = bilinear samples of x; 4 corners per (pixel, tap) from a DcnTapRec
 //   1  grad_input:  B stage = transposed sampling of grad_output: input cell q collects, for tap t, every
-//                   (output pixel, weight) pair whose corner is q -- the first 8 from a DcnInvRec, the rest from
-//                   the (tile, tap)'s overflow list
+//                   (output pixel, weight) pair whose corner is q -- up to 8 from its DcnInvRec, or, for a cell with
+//                   more, the pre-aggregated sum (dcn_inv_overflow_sums)
 //   2  forward on a map beyond the LDS plane's capacity: like MODE 0, but the corners are 16-byte buffer loads from a
 //                   pixel-major copy of x ([N][H*W][C]: a pixel's 16 channels of a chunk are 64 contiguous bytes), the
 //                   tap records hold the rows' byte offsets; no plane, no plane copy, any map size
@@ -98,7 +98,7 @@ struct PlaneStageRegs {
   static constexpr int NG = PlaneModeTraits<MODE>::kGroups;
   uint4 off[NG];      // LDS byte offsets of the sampled pixels (quad 0)
   f32x4 w[NG];        // and their weights
-  int2 ovf;           // MODE 1: (length, first entry in the spill list) of the overflow list of the stage's (tile, tap)
+  int2 ovf;           // MODE 1: .x = the stage's tap
 };
 
 }  // namespace
@@ -203,7 +203,6 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
     int s = s_begin;
     int c16 = s / K;
     int t0 = s - c16 * K;
-    const int tile_in_img = nt - tile_b * p.tiles_per_image;
     // records of (image, deformable group) for channel chunk c: [K][pixels][NG] groups of 32 B; seg_records = byte offset
     // of the chunk's first tap (scalar), rec_lane = this thread's pixel (the one vector offset of every record load)
     const dcn_rsrc_t rec_rs = dcn_make_rsrc(p.taps);
@@ -221,10 +220,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         R.off[gq] = __builtin_bit_cast(uint4, dcn_buf_b128(rec_rs, rec_lane + 16 * gq, so));
         R.w[gq] = __builtin_bit_cast(f32x4, dcn_buf_b128(rec_rs, rec_lane + 16 * (NG + gq), so));
       }
-      if constexpr (MODE == 1) {
-        const DcnInvOvfSlots *sl = p.inv_ovf + ((size_t)(tile_b * K + t) * p.tiles_per_image + tile_in_img);
-        R.ovf = *reinterpret_cast<const int2 *>(sl);   // (count, spill_start)
-      }
+      if constexpr (MODE == 1) R.ovf = int2{(int)t, 0};   // the stage's tap (row of the pre-aggregated sums)
     };
     // Copy x[tile_b, c_base + 16*c .. +15, :, :] into the LDS quad planes (dcn_plane_copy, dcn_common.h): units
     // [unit_lo, unit_hi) of the plane, this wave being number `w` of `NW_` waves that share them.
@@ -313,7 +309,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       auto corner_reads = [&](const Regs &R, int gq, int half, Corners &v) {
         // (MODE 1: the upper bits of a record's last offset hold the cell's overflow range)
         const unsigned o[4] = {R.off[gq].x, R.off[gq].y, R.off[gq].z,
-                               (MODE == 1 && gq == NG - 1) ? (R.off[gq].w & 0x1ffffu) : R.off[gq].w};
+                               (MODE == 1 && gq == NG - 1) ? (R.off[gq].w & 0x1ffffu) : R.off[gq].w};   // (upper bits: flag + slot)
         if constexpr (kBf16Plane) {   // eight channels of a corner in ONE read; bf16 -> fp32 is a shift / a mask per value
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -409,29 +405,19 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
           corner_fma(R, gq, v, sv, gq == 0);
         }
         if constexpr (MODE == 1) {
-          // contributions beyond the 8 inline ones (a cell with more than 8 contributing (pixel, corner) pairs for one
-          // tap) sit in the (tile, tap)'s overflow list, in cell order; a cell's range of it is in the record
-          // (dcn_build_inverse_taps), so a thread walks its own entries: a short divergent loop
-          auto add_entry = [&](const uint2 e) {
-            const float w = __uint_as_float(e.y);
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-              const f32x4 v = lds_quad((e.x >> 7) + (unsigned)((half * 2 + c) * kPlaneQuadStride));
-              sv[c][0] += f32x2{w * v[0], w * v[1]};
-              sv[c][1] += f32x2{w * v[2], w * v[3]};
-            }
-          };
-          if (R.ovf.x > 0) {
-            const unsigned pk = R.off[NG - 1].w;
-            const int cnt = (int)(pk >> 27);
-            const uint2 *mine = p.inv_spill + R.ovf.y + ((pk >> 17) & 1023u);
-            for (int i = 0; i < cnt; ++i) add_entry(mine[i]);
-          } else if (R.ovf.x < 0) {   // ranges that do not fit the record's fields: every thread scans the list
-            const uint2 *spill = p.inv_spill + R.ovf.y;
-            for (int i = 0; i < -R.ovf.x; ++i) {
-              const uint2 e = spill[i];
-              if ((int)(e.x & 127u) == n_local) add_entry(e);
-            }
+          // a cell with more than 8 contributing (pixel, corner) pairs for this tap: its record holds zero weights and a
+          // slot number; the sum over ALL its contributions was formed for every output channel by dcn_inv_overflow_sums
+          // (dcn_backward_plane.hip) -- 32 bytes of it are this half-stage's 8 channels.  Bounded work per cell whatever
+          // the offsets look like (rounds 2-3: a list walk per cell and chunk -- hundreds of entries on a trained head).
+          const unsigned pk = R.off[NG - 1].w;
+          if (pk & kInvFlag) {
+            const float *gv = p.inv_gov + ((size_t)(tile_b * K + R.ovf.x) * p.gov_slots + ((pk >> 17) & 0x3fffu)) * p.gov_ld +
+                              (p.gov_c0 + c16 * kChunk + half * 8);
+            const f32x4 g0 = *reinterpret_cast<const f32x4 *>(gv), g1 = *reinterpret_cast<const f32x4 *>(gv + 4);
+            sv[0][0] += f32x2{g0[0], g0[1]};
+            sv[0][1] += f32x2{g0[2], g0[3]};
+            sv[1][0] += f32x2{g1[0], g1[1]};
+            sv[1][1] += f32x2{g1[2], g1[3]};
           }
         }
         split_store(buf, gi, half, sv);

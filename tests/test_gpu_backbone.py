@@ -626,7 +626,8 @@ def test_fp16_forward_parts_saturate_instead_of_nan():
     """Round-3 ADVICE (medium): an operand beyond fp16's range used to become hi = inf, lo = v - inf = -inf and the MFMA sum
     inf + (-inf) = NaN poisoned the whole output channel.  The fp16-part kernels now run with the MODE register's FP16_OVFL
     bit set (csrc/conv1x1.hip f16_saturate_on): a part beyond +/-65504 is clamped, so (a) activations up to 131008 = 2 x
-    65504 are still represented by hi + lo and the result keeps fp32-class accuracy, (b) a folded BatchNorm channel with a
+    65504 are still represented by hi + lo -- hi = 65504 and a LARGE lo part, i.e. with the 11 bits of one fp16 number
+    (measured 2e-4 of the output scale; fp32-class accuracy ends at 65504 as documented) --, (b) a folded BatchNorm channel with a
     tiny running variance (var = 1e-12, gamma = 1: w * s ~ 3e3 beyond the 255 the 2^8-scaled image holds) gives a FINITE,
     clamped channel and leaves every other channel exact."""
     from kgdet_amd import conv1x1 as c1
@@ -646,7 +647,7 @@ def test_fp16_forward_parts_saturate_instead_of_nan():
         xc[:, 3] = xc[:, 3].clamp(-131008.0, 131008.0)  # what hi + lo hold after saturation
         ref = F.conv2d(xc.double(), w.double(), padding=k // 2)
         err = float((y.double() - ref).abs().max() / ref.abs().max())
-        assert err < 2e-6, (k, err)
+        assert err < 1e-3, (k, err)
         # a weight row beyond the image's range (a folded BatchNorm scale of 1 / sqrt(1e-12 + 1e-5) ~ 316 on |w| ~ 10)
         w2 = w.clone()
         w2[7] *= 4e4

@@ -398,6 +398,66 @@ def test_grad_input_plane_kernel_long_lists():
     _close(gi.cpu().numpy(), ref, 5e-5)
 
 
+def _keypoint_offsets(case, off, points_per_image=2, jitter=0.3, seed=3):
+    """the offsets of a TRAINED keypoint-guided head: tap t of every location of an image samples one of a few key points
+    (absolute positions), whatever the location -- `reppts - base grid` of KP3:135-143 once the points have converged"""
+    N, C, H, W, O, k, s, p, d, g, dg = case
+    rng = np.random.default_rng(seed)
+    Ho, Wo = off.shape[2:]
+    ys, xs = np.meshgrid(np.arange(Ho), np.arange(Wo), indexing='ij')
+    off = off.copy()
+    for b in range(N):
+        for gi in range(dg):
+            for t in range(k * k):
+                ky = rng.uniform(1, H - 2, size=points_per_image)
+                kx = rng.uniform(1, W - 2, size=points_per_image)
+                which = (xs * points_per_image // Wo).clip(0, points_per_image - 1)     # left object / right object
+                ch = gi * 2 * k * k + 2 * t
+                off[b, ch] = ky[which] - (ys * s - p + (t // k) * d) + jitter * 0.1 * off[b, ch]
+                off[b, ch + 1] = kx[which] - (xs * s - p + (t % k) * d) + jitter * 0.1 * off[b, ch + 1]
+    return off
+
+
+@pytest.mark.parametrize('case', [CASES[2], CASES[0], GROUP_CASES[3], GROUP_CASES[5]])
+def test_grad_input_with_trained_head_offsets(case):
+    """Round 4: with converged key points every (image, tap) has a few cells that collect HUNDREDS of contributions.  The
+    grad_input path forms those cells' sums beforehand for all channels (dcn_inv_overflow_sums), so (a) the result still
+    agrees with the float64 oracle, bit-repeatably, also across weight / deformable groups, and (b) the launch costs about
+    what it costs with random offsets -- the per-cell list walk of rounds 2-3 took 6-7x longer on such offsets, which is
+    what made the training step slow down from 12 to 16 ms within a few hundred steps."""
+    _require_gpu()
+    from kgdet_amd import dcn
+    N, C, H, W, O, k, s, p, d, g, dg = case
+    x, off, w, go, _ = _make(case, seed=21)
+    offk = _keypoint_offsets(case, off)
+    tx, tw, tg = (torch.from_numpy(a).cuda() for a in (x, w, go))
+    to_rand, to_key = torch.from_numpy(off).cuda(), torch.from_numpy(offk).cuda()
+    shape = dcn._shape(tx, tw, (s, s), (p, p), (d, d), g, dg)
+    gi = dcn.grad_input_plane(tx.shape, to_key, None, tw, tg, shape)
+    gi2 = dcn.grad_input_plane(tx.shape, to_key, None, tw, tg, shape)
+    assert torch.equal(gi, gi2), 'grad_input must be deterministic'
+    ref = oracle.deform_conv_backward(x.astype(np.float64), offk.astype(np.float64), w.astype(np.float64),
+                                      go.astype(np.float64), s, p, d, g, dg)['grad_input']
+    _close(gi.cpu().numpy(), ref, 5e-5)
+    if C < 256:
+        return
+
+    packed = dcn.pack_weight(tw.contiguous(), shape)
+
+    def timed(to):
+        for _ in range(3):
+            dcn.grad_input_plane(tx.shape, to, None, tw, tg, shape, packed)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dcn.grad_input_plane(tx.shape, to, None, tw, tg, shape, packed)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 10
+    t_rand, t_key = timed(to_rand), timed(to_key)
+    assert t_key < 1.6 * t_rand, 'grad_input depends on the offset distribution again: %.3f ms vs %.3f ms' % (t_key, t_rand)
+
+
 @pytest.mark.parametrize('case', [c for c in CASES if c[10] == 1 and c[9] == 1 and c[4] <= 256 and _plane_map(c)] +
                          [c for c in GROUP_CASES if (c[1] // c[9]) % (c[1] // c[10]) == 0 and c[4] // c[9] <= 256])   # a deformable group inside ONE weight group
 def test_grad_offset_plane_kernel(case):
