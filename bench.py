@@ -334,10 +334,21 @@ class BoardSampler:
         self._stop = None
         self._thread = None
         self.source = None
-        cards = sorted(glob.glob('/sys/class/drm/card[0-9]*/device/hwmon/hwmon*'))
-        # cards with an amdgpu hwmon, in card order; local rank i = the i-th of them
-        hw = [h for h in cards if any(os.path.exists(os.path.join(h, f)) for f in ('power1_average', 'power1_input'))]
-        self.hwmon = hw[index] if index < len(hw) else None
+        # the hwmon of THIS process's device, found through its PCI address (the host's sysfs lists every board of the node,
+        # the container sees one of them); fall back to the i-th amdgpu hwmon in card order
+        self.hwmon = None
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            bdf = '%04x:%02x:%02x.0' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            hit = sorted(glob.glob('/sys/bus/pci/devices/%s/hwmon/hwmon*' % bdf))
+            if hit:
+                self.hwmon = hit[0]
+        except Exception:
+            pass
+        if self.hwmon is None:
+            cards = sorted(glob.glob('/sys/class/drm/card[0-9]*/device/hwmon/hwmon*'))
+            hw = [h for h in cards if any(os.path.exists(os.path.join(h, f)) for f in ('power1_average', 'power1_input'))]
+            self.hwmon = hw[index] if index < len(hw) else None
         if self.hwmon:
             self.source = 'sysfs:' + self.hwmon
         else:
