@@ -261,18 +261,25 @@ def cpu_baseline(device=None, gpu_forward_s=None):
     seeded inputs, bounded sample (~20 s), BLAS threads stated.  The GPU's live numbers for the same legs sit beside them."""
     import numpy as np
     import oracle
+    # BLAS threads PINNED (round-3 review: 64 OpenBLAS threads roaming over 256 shared host CPUs gave 5x5 = 0.95 x 7x7): at
+    # most 16 threads for the whole baseline, stated on the line; every leg reports its MINIMUM beside the median
+    pin = max(1, min(16, os.cpu_count() or 1))
+    limiter = None
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
+        limiter = threadpool_limits(limits=pin)
         blas = [(i.get('internal_api'), i.get('num_threads')) for i in threadpool_info() if i.get('user_api') == 'blas']
     except Exception:
         blas = []
-    threads = max([n for _, n in blas], default=os.cpu_count())
+    threads = max([n for _, n in blas], default=pin)
     rng = np.random.default_rng(0)
     B, C, H, W = 2, 256, 25, 42
     x = rng.normal(size=(B, C, H, W)).astype(np.float32)
     go = rng.normal(size=(B, C, H, W)).astype(np.float32)
 
-    def median_time(fn, warm, reps):
+    mins = {}
+
+    def median_time(fn, warm, reps, tag=None):
         for _ in range(warm):
             fn()
         ts = []
@@ -280,14 +287,16 @@ def cpu_baseline(device=None, gpu_forward_s=None):
             t0 = time.perf_counter()
             fn()
             ts.append(time.perf_counter() - t0)
+        if tag is not None:
+            mins[tag] = min(ts)
         return sorted(ts)[len(ts) // 2]
 
     fwd, bwd = {}, {}
     for k in (3, 5, 7):
         off = (rng.normal(size=(B, 2 * k * k, H, W)) * 2).astype(np.float32)
         w = (rng.normal(size=(C, C, k, k)) * 0.01).astype(np.float32)
-        fwd[k] = median_time(lambda: oracle.deform_conv_forward(x, off, w, 1, k // 2, 1), 3, 9)
-        bwd[k] = median_time(lambda: oracle.deform_conv_backward(x, off, w, go, 1, k // 2, 1), 1, 5)
+        fwd[k] = median_time(lambda: oracle.deform_conv_forward(x, off, w, 1, k // 2, 1), 3, 9, 'fwd%d' % k)
+        bwd[k] = median_time(lambda: oracle.deform_conv_backward(x, off, w, go, 1, k // 2, 1), 1, 5, 'bwd%d' % k)
     flops = sum(2.0 * C * C * k * k * B * H * W for k in (3, 5, 7)) * 2          # one head stage
     stage_fwd_s, stage_bwd_s = 2 * sum(fwd.values()), 2 * sum(bwd.values())
     brng = np.random.default_rng(5)              # 1000 boxes in 40 clusters: overlapping neighbours, ~150 survivors
@@ -307,6 +316,10 @@ def cpu_baseline(device=None, gpu_forward_s=None):
                              'as one batched launch)',
                      'cpu_ms': round(nms_s * 1e3, 3), 'cpu_ms_104_segments': round(104 * nms_s * 1e3, 2)},
     }
+    legs['dcn_forward']['cpu_ms_min'] = round(2 * sum(mins['fwd%d' % k] for k in (3, 5, 7)) * 1e3, 1)
+    legs['dcn_backward']['cpu_ms_min'] = round(2 * sum(mins['bwd%d' % k] for k in (3, 5, 7)) * 1e3, 1)
+    if limiter is not None:
+        limiter.restore_original_limits()
     if device is not None:
         if gpu_forward_s:
             legs['dcn_forward'].update(gpu=round(flops / gpu_forward_s / 1e12, 2), gpu_ms=round(gpu_forward_s * 1e3, 4))

@@ -2,6 +2,7 @@
 
     python tests/golden/make_ref_golden.py            -> tests/golden/ref_targets_golden.npz
                                                           tests/golden/ref_head_golden.npz
+                                                          tests/golden/ref_head_flip_golden.npz
                                                           tests/golden/ref_serial_golden.npz
 
 Everything stored is an OUTPUT OF THE REFERENCE'S OWN PYTHON executed in place by tests/golden/ref_loader.py
@@ -193,6 +194,40 @@ def kgdet_head(ns, out):
             print('image', i, 'detections', db.shape[0])
 
 
+def kgdet_head_flip(ns, out):
+    """The reference's KGDet head with ``flip_forward=True`` (KP3:448-488: test-time horizontal-flip fusion of all nine
+    maps), eval mode, float32 -- the configs ship it switched off, so no other fixture runs it.  The keypoint channels
+    are permuted by the DATASET's ``flip_indices`` (left / right landmark swaps of the 13 categories, deepfashion2.py),
+    not by the identity of the synthetic batch."""
+    from kgdet_amd import configs
+    cfg = configs.kgdet_r50_fpn()
+    ours = ref_cases.kgdet_head()
+    hc = dict(cfg.model.bbox_head)
+    hc.pop('type')
+    hc['flip_forward'] = True
+    ref = ns.head_kgdet.RepPointsHeadKp3RepCas1AssignOnce(**hc)
+    _load_into_reference(ref, ours)
+    x, batch = ref_cases.kgdet_inputs()
+    metas = ref_cases.flip_metas(batch['img_meta'])
+    names = ['cls_1', 'cls_2', 'cls_3', 'kpt_1', 'kpt_2', 'kpt_3', 'bbox_1', 'bbox_2', 'bbox_3']
+    ref32 = ref.float().eval()
+    with torch.no_grad():
+        outs = ref32([x], metas)
+        for n, o in zip(names, outs):
+            a = _np(o[0])
+            out['out:' + n] = a[:, ::ref_cases.KPT_STRIDE] if n.startswith('kpt') else a
+        plain = ns.head_kgdet.RepPointsHeadKp3RepCas1AssignOnce(**dict(hc, flip_forward=False))
+        _load_into_reference(plain, ours)
+        plain_cls = _np(plain.float().eval()([x], metas)[2][0])
+        out['plain:cls_3'] = plain_cls                                        # (the fusion must CHANGE the maps: a guard)
+        det = ref32.get_bboxes(*outs, metas, cfg.test_cfg, rescale=True, nms=True)
+        for i, (db, dl, dk) in enumerate(det):
+            out['det%d:bboxes' % i], out['det%d:labels' % i] = _np(db), _np(dl)
+            out['det%d:kpts' % i] = _np(dk)[:, ::ref_cases.KPT_STRIDE * 3]
+            print('flip image', i, 'detections', db.shape[0])
+    print('flip fusion moved cls_3 by', float(np.abs(out['out:cls_3'] - plain_cls).max()))
+
+
 def serial_head(ns, out, parallel=False, size=(256, 320), maps=True):
     """The reference's serial (config 5) head -- or, ``parallel=True``, its parallel sibling
     (reppoints_head_kp_parallel.py) --: 5 pyramid levels, PointAssigner init stage + MaxIoUAssigner refine stage,
@@ -240,8 +275,9 @@ def serial_head(ns, out, parallel=False, size=(256, 320), maps=True):
 
 def main():
     ns = ref_loader.load()
-    which = sys.argv[1:] or ['targets', 'head', 'serial', 'parallel', 'serial_large']
+    which = sys.argv[1:] or ['targets', 'head', 'head_flip', 'serial', 'parallel', 'serial_large']
     for name, fn, fname in (('targets', targets, 'ref_targets_golden.npz'), ('head', kgdet_head, 'ref_head_golden.npz'),
+                            ('head_flip', kgdet_head_flip, 'ref_head_flip_golden.npz'),
                             ('serial', serial_head, 'ref_serial_golden.npz'),
                             ('parallel', lambda ns, out: serial_head(ns, out, parallel=True), 'ref_parallel_golden.npz'),
                             ('serial_large', lambda ns, out: serial_head(ns, out, size=(384, 512), maps=False),

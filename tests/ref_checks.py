@@ -240,6 +240,34 @@ def check_kgdet_head(head, device, tol_map=2e-4, tol_loss=2e-4, tol_grad=1e-3):
     return worst
 
 
+def check_kgdet_head_flip(head, device, tol_map=2e-4):
+    """``flip_forward=True`` (KP3:448-488) against the reference head run the same way: the nine fused maps and the final
+    detections.  `head` is this repo's head built with flip_forward=True and ref_cases.kgdet_head()'s weights."""
+    from kgdet_amd import configs
+    G = load('ref_head_flip_golden.npz')
+    cfg = configs.kgdet_r50_fpn()
+    x, batch = ref_cases.kgdet_inputs()
+    metas = ref_cases.flip_metas(batch['img_meta'])
+    names = ['cls_1', 'cls_2', 'cls_3', 'kpt_1', 'kpt_2', 'kpt_3', 'bbox_1', 'bbox_2', 'bbox_3']
+    worst = {}
+    assert head.flip_forward
+    head.eval()
+    with torch.no_grad():
+        outs = head([x.to(device)], metas)
+        for n, o in zip(names, outs):
+            a = _np(o[0])
+            a = a[:, ::ref_cases.KPT_STRIDE] if n.startswith('kpt') else a
+            worst['out:' + n] = rel(a, G['out:' + n])
+            assert worst['out:' + n] < tol_map, (n, worst)
+        # the fixture is not the unfused head's output in disguise
+        assert float(np.abs(G['out:cls_3'] - G['plain:cls_3']).max()) > 1e-3
+        det = head.get_bboxes(*outs, metas, cfg.test_cfg, rescale=True, nms=True)
+        for i, d in enumerate(det):
+            worst['det%d' % i] = _check_detections(_np(d[0]), _np(d[1]), _np(d[2])[:, ::ref_cases.KPT_STRIDE * 3],
+                                                   G['det%d:bboxes' % i], G['det%d:labels' % i], G['det%d:kpts' % i])
+    return worst
+
+
 def _check_candidates(bb, sc, kp, gbb, gsc, gkp, tol=1e-3):
     assert bb.shape == gbb.shape and sc.shape == gsc.shape and kp.shape == gkp.shape
     worst = 0.0

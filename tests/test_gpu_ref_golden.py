@@ -67,6 +67,15 @@ def test_hip_kgdet_head_equals_reference_head(precision):
     print(precision, worst)
 
 
+def test_hip_kgdet_head_flip_forward_equals_reference_head():
+    """the HIP-backed head with flip_forward=True against the reference head's flip-fused maps (2e-4) and detections (1e-3,
+    NMS selection identical)"""
+    head = ref_cases.kgdet_head().cuda()
+    head.flip_forward = True
+    worst = ref_checks.check_kgdet_head_flip(head, 'cuda')
+    print(worst)
+
+
 def test_hip_serial_head_equals_reference_head():
     """config 5: HIP-backed serial head, five pyramid levels, PointAssigner + MaxIoUAssigner targets, hard and soft
     NMS, against the REFERENCE serial head module"""

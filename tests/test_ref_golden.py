@@ -101,6 +101,16 @@ def test_kgdet_head_host_logic_equals_reference_head_on_cpu():
     print(worst)
 
 
+def test_kgdet_head_flip_forward_equals_reference_head_on_cpu():
+    """flip_forward=True (KP3:448-488, off in every shipped config): the nine flip-fused maps and the detections of this repo's
+    head == the reference head's, with the dataset's real left / right keypoint permutation"""
+    head = ref_cases.kgdet_head()
+    head.flip_forward = True
+    with cpu_ops.patched():
+        worst = ref_checks.check_kgdet_head_flip(head, 'cpu')
+    print(worst)
+
+
 def test_serial_head_host_logic_equals_reference_head_on_cpu():
     head = ref_cases.serial_head()
     with cpu_ops.patched():
