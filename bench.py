@@ -519,7 +519,7 @@ def main():
             synthetic.calibrate_scores_serial(model, batch, cfg.test_cfg.score_thr, 0.002, autocast)
         n_det = [0]
 
-        use_graph = bool(args.graph) and args.config == 'kgdet'   # (soft-NMS post-processing reads back per class)
+        use_graph = bool(args.graph)   # (config 5 too since round 4: the batched device soft-NMS reads nothing back)
         if use_graph:
             # backbone -> head -> decode -> fused NMS as one hipGraph launch + one device->host copy per batch
             run = model.graphed_test_batch(batch['img'], batch['img_meta'], rescale=True,

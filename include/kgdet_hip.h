@@ -521,6 +521,21 @@ int kgdet_multiclass_nms(const float *boxes, const float *scores, int32_t B, int
                          int32_t score_stride, int32_t score_col0, float score_thr, float iou_thr, int32_t max_num,
                          float *out_det, int64_t *out_label, int64_t *out_src, int64_t *out_count, void *workspace,
                          size_t workspace_bytes, void *stream);
+/* multiclass_nms_kp with test_cfg.nms.type = 'soft_nms' for a whole batch (bbox_nms_kp.py:25-50 ->
+ * R/nms/nms_wrapper.py:52-78 -> R/nms/src/soft_nms_cpu.pyx:22-127), two launches, nothing read by the host (round 4: the
+ * per-class host loop over kgdet_soft_nms kept config-5 inference eager): per (image, class) the candidates with
+ * score > score_thr go through the reference's selection-sort loop in LDS, in ascending candidate row order as
+ * `multi_bboxes[cls_inds]` hands them over (method 0 hard / 1 linear / 2 gaussian, `sigma`, `min_score` as soft_nms_cpu);
+ * per image the survivors are concatenated class by class in the loop's own order and, beyond max_num, the max_num
+ * highest DECAYED scores are kept (ties: earlier first).  Same array shapes as kgdet_multiclass_nms; out_det's fifth
+ * column is the decayed score.  Limits: N * 36 bytes of LDS (N <= 4544), C <= 64, C * max_num <= 16384.
+ * workspace: kgdet_multiclass_soft_nms_workspace_bytes(B, N, C). */
+size_t kgdet_multiclass_soft_nms_workspace_bytes(int32_t B, int32_t N, int32_t C);
+int kgdet_multiclass_soft_nms(const float *boxes, const float *scores, int32_t B, int32_t N, int32_t C,
+                              int32_t score_stride, int32_t score_col0, float score_thr, float iou_thr,
+                              int32_t method, float sigma, float min_score, int32_t max_num, float *out_det,
+                              int64_t *out_label, int64_t *out_src, int64_t *out_count, void *workspace,
+                              size_t workspace_bytes, void *stream);
 int kgdet_nms(const float *dets, int64_t n, float iou_thr, int64_t *keep, int64_t *num_keep,
               void *workspace, size_t workspace_bytes, void *stream);
 int kgdet_nms_batched(const float *dets, const int64_t *seg_offsets, int32_t num_segments,

@@ -426,30 +426,31 @@ __global__ __launch_bounds__(kNmsThreads) void multiclass_select(const float *__
 // reproduced exactly: survivors in front of the new end stay, holes there are filled (left to
 // right) by the surviving boxes behind the new end (taken right to left).
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kNmsThreads) void soft_nms_kernel(const float *__restrict__ dets, int n, float iou_thr,
-                                                               int method, float sigma, float min_score,
-                                                               float *__restrict__ out_dets,
-                                                               long long *__restrict__ out_inds,
-                                                               long long *__restrict__ num_out) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ int wave_sums[kNmsThreads / 64];
-  __shared__ unsigned long long wave_best[kNmsThreads / 64];
-  float *bx1 = reinterpret_cast<float *>(smem);
-  float *by1 = bx1 + n, *bx2 = by1 + n, *by2 = bx2 + n, *bsc = by2 + n;
-  int *bid = reinterpret_cast<int *>(bsc + n);
-  int *hole = bid + n;   // scratch: positions of removed boxes in front of the new end
-  int *mover = hole + n; // scratch: positions of surviving boxes behind the new end
-  int *flag = mover + n; // scratch: survive flags
-  __shared__ int n_front_surv;
+// the LDS arrays of one soft-NMS problem of capacity `cap` boxes (9 words per box)
+struct SoftNmsStore {
+  float *bx1, *by1, *bx2, *by2, *bsc;
+  int *bid, *hole, *mover, *flag;
+};
+__device__ __forceinline__ SoftNmsStore soft_nms_store(unsigned char *smem, int cap) {
+  SoftNmsStore st;
+  st.bx1 = reinterpret_cast<float *>(smem);
+  st.by1 = st.bx1 + cap; st.bx2 = st.by1 + cap; st.by2 = st.bx2 + cap; st.bsc = st.by2 + cap;
+  st.bid = reinterpret_cast<int *>(st.bsc + cap);
+  st.hole = st.bid + cap;    // scratch: positions of removed boxes in front of the new end
+  st.mover = st.hole + cap;  // scratch: positions of surviving boxes behind the new end
+  st.flag = st.mover + cap;  // scratch: survive flags
+  return st;
+}
 
+// the reference's loop (soft_nms_cpu.pyx:44-125) over the n boxes already in `st` (bid = their original rows); returns
+// the number of boxes left, arranged as the reference leaves them.  All threads of the workgroup call it.
+__device__ __forceinline__ int soft_nms_block(const SoftNmsStore &st, int n, float iou_thr, int method, float sigma,
+                                              float min_score, int *wave_sums, unsigned long long *wave_best,
+                                              int *n_front_surv_p) {
+  float *bx1 = st.bx1, *by1 = st.by1, *bx2 = st.bx2, *by2 = st.by2, *bsc = st.bsc;
+  int *bid = st.bid, *hole = st.hole, *mover = st.mover, *flag = st.flag;
+  int &n_front_surv = *n_front_surv_p;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < n; i += kNmsThreads) {
-    bx1[i] = dets[5 * i]; by1[i] = dets[5 * i + 1]; bx2[i] = dets[5 * i + 2]; by2[i] = dets[5 * i + 3];
-    bsc[i] = dets[5 * i + 4];
-    bid[i] = i;
-  }
-  __syncthreads();
-
   int N = n;
   for (int i = 0; i < N; ++i) {
     // first maximum of scores in [i, N): key = (score order-preserving bits, inverted position)
@@ -548,12 +549,158 @@ __global__ __launch_bounds__(kNmsThreads) void soft_nms_kernel(const float *__re
     __syncthreads();
     N = newN;
   }
+  return N;
+}
+
+__global__ __launch_bounds__(kNmsThreads) void soft_nms_kernel(const float *__restrict__ dets, int n, float iou_thr,
+                                                               int method, float sigma, float min_score,
+                                                               float *__restrict__ out_dets,
+                                                               long long *__restrict__ out_inds,
+                                                               long long *__restrict__ num_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int wave_sums[kNmsThreads / 64];
+  __shared__ unsigned long long wave_best[kNmsThreads / 64];
+  __shared__ int n_front_surv;
+  const SoftNmsStore st = soft_nms_store(smem, n);
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n; i += kNmsThreads) {
+    st.bx1[i] = dets[5 * i]; st.by1[i] = dets[5 * i + 1]; st.bx2[i] = dets[5 * i + 2]; st.by2[i] = dets[5 * i + 3];
+    st.bsc[i] = dets[5 * i + 4];
+    st.bid[i] = i;
+  }
+  __syncthreads();
+  const int N = soft_nms_block(st, n, iou_thr, method, sigma, min_score, wave_sums, wave_best, &n_front_surv);
   for (int i = tid; i < N; i += kNmsThreads) {
-    out_dets[5 * i] = bx1[i]; out_dets[5 * i + 1] = by1[i]; out_dets[5 * i + 2] = bx2[i];
-    out_dets[5 * i + 3] = by2[i]; out_dets[5 * i + 4] = bsc[i];
-    out_inds[i] = bid[i];
+    out_dets[5 * i] = st.bx1[i]; out_dets[5 * i + 1] = st.by1[i]; out_dets[5 * i + 2] = st.bx2[i];
+    out_dets[5 * i + 3] = st.by2[i]; out_dets[5 * i + 4] = st.bsc[i];
+    out_inds[i] = st.bid[i];
   }
   if (tid == 0) *num_out = N;
+}
+
+// multiclass_nms_kp with nms type 'soft_nms' (bbox_nms_kp.py:25-50 -> nms_wrapper.soft_nms -> soft_nms_cpu.pyx) for a whole
+// batch in one launch: workgroup (b, c) collects class c's candidates of image b (score > score_thr, ascending candidate
+// row: what `multi_bboxes[cls_inds]` hands the op) and runs the reference's loop on them in LDS.
+// boxes [B, N, 4]; scores [B, N, S], class c in column col0 + c.
+// seg_dets [B, C, N, 5] (box + decayed score), seg_src [B, C, N] (candidate row), seg_count [B, C].
+__global__ __launch_bounds__(kNmsThreads) void multiclass_soft_nms_segments(
+    const float *__restrict__ boxes, const float *__restrict__ scores, int N, int C, int S, int col0, float score_thr,
+    float iou_thr, int method, float sigma, float min_score, float *__restrict__ seg_dets, int *__restrict__ seg_src,
+    int *__restrict__ seg_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int wave_sums[kNmsThreads / 64];
+  __shared__ unsigned long long wave_best[kNmsThreads / 64];
+  __shared__ int n_front_surv;
+  const SoftNmsStore st = soft_nms_store(smem, N);
+  const int seg = blockIdx.x, b = seg / C, c = seg - b * C, tid = threadIdx.x;
+  const float *bp = boxes + (long long)b * N * 4;
+  const float *sp = scores + (long long)b * N * S + col0 + c;
+  // candidates in ascending row order: each thread owns a contiguous run of rows
+  const int per = (N + kNmsThreads - 1) / kNmsThreads;
+  const int lo = min(N, tid * per), hi = min(N, lo + per);
+  int cnt = 0;
+  for (int i = lo; i < hi; ++i) cnt += sp[(long long)i * S] > score_thr ? 1 : 0;
+  int n;
+  int pos = block_exclusive_scan(cnt, wave_sums, n);
+  for (int i = lo; i < hi; ++i) {
+    const float sc = sp[(long long)i * S];
+    if (sc > score_thr) {
+      st.bx1[pos] = bp[4 * i]; st.by1[pos] = bp[4 * i + 1]; st.bx2[pos] = bp[4 * i + 2]; st.by2[pos] = bp[4 * i + 3];
+      st.bsc[pos] = sc;
+      st.bid[pos] = i;
+      ++pos;
+    }
+  }
+  __syncthreads();
+  const int M = n > 0 ? soft_nms_block(st, n, iou_thr, method, sigma, min_score, wave_sums, wave_best, &n_front_surv) : 0;
+  float *od = seg_dets + (long long)seg * N * 5;
+  int *os = seg_src + (long long)seg * N;
+  for (int i = tid; i < M; i += kNmsThreads) {
+    od[5 * i] = st.bx1[i]; od[5 * i + 1] = st.by1[i]; od[5 * i + 2] = st.bx2[i]; od[5 * i + 3] = st.by2[i];
+    od[5 * i + 4] = st.bsc[i];
+    os[i] = st.bid[i];
+  }
+  if (tid == 0) seg_count[seg] = M;
+}
+
+// The tail of multiclass_nms_kp (bbox_nms_kp.py:52-70) behind the soft-NMS segments: concatenation in class order; more
+// than max_num -> the max_num best by (decayed) score, ties: earlier in the concatenation first.  A class's survivors
+// leave soft-NMS in non-increasing score order (a box's score is final when it is selected as the maximum of what is left,
+// and what is left only decays), so a class contributes at most its FIRST max_num entries to the top max_num: at most
+// C * max_num keys are sorted, whatever N is.  One workgroup per image.
+__global__ __launch_bounds__(kNmsThreads) void multiclass_soft_select(const float *__restrict__ seg_dets,
+                                                                      const int *__restrict__ seg_src,
+                                                                      const int *__restrict__ seg_count, int N, int C,
+                                                                      int max_num, float *__restrict__ out_det,
+                                                                      long long *__restrict__ out_label,
+                                                                      long long *__restrict__ out_src,
+                                                                      long long *__restrict__ out_count, int max_np) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int prefix[65], tprefix[65];   // full concatenation / truncated (first max_num per class)
+  unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) {
+    int run = 0, trun = 0;
+    for (int c = 0; c < C; ++c) {
+      prefix[c] = run; tprefix[c] = trun;
+      const int k = seg_count[b * C + c];
+      run += k; trun += min(k, max_num);
+    }
+    prefix[C] = run; tprefix[C] = trun;
+  }
+  __syncthreads();
+  const int T = prefix[C], TT = tprefix[C];
+  const int out_n = min(T, max_num);
+  auto find = [&](const int *pf, int p) {
+    int lo = 0, hi = C - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (pf[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+  };
+  if (T > max_num) {
+    int NP = 64;
+    while (NP < TT) NP <<= 1;
+    for (int q = tid; q < NP; q += kNmsThreads) {
+      unsigned long long k = ~0ull;
+      if (q < TT) {
+        const int c = find(tprefix, q), i = q - tprefix[c];
+        k = score_key(seg_dets[(((long long)b * C + c) * N + i) * 5 + 4], (unsigned)(prefix[c] + i));
+      }
+      keys[q] = k;
+    }
+    __syncthreads();
+    for (int k = 2; k <= NP; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < NP; i += kNmsThreads) {
+          const int l = i ^ j;
+          if (l > i) {
+            const unsigned long long a = keys[i], bb = keys[l];
+            const bool up = (i & k) == 0;
+            if ((a > bb) == up) { keys[i] = bb; keys[l] = a; }
+          }
+        }
+        __syncthreads();
+      }
+  }
+  (void)max_np;
+  for (int r = tid; r < max_num; r += kNmsThreads) {
+    float *od = out_det + ((long long)b * max_num + r) * 5;
+    if (r < out_n) {
+      const int p = T > max_num ? (int)(keys[r] & 0xffffffffu) : r;
+      const int c = find(prefix, p), i = p - prefix[c];
+      const float *sd = seg_dets + (((long long)b * C + c) * N + i) * 5;
+      od[0] = sd[0]; od[1] = sd[1]; od[2] = sd[2]; od[3] = sd[3]; od[4] = sd[4];
+      out_label[(long long)b * max_num + r] = c;
+      out_src[(long long)b * max_num + r] = seg_src[((long long)b * C + c) * N + i];
+    } else {
+      od[0] = od[1] = od[2] = od[3] = od[4] = 0.f;
+      out_label[(long long)b * max_num + r] = 0;
+      out_src[(long long)b * max_num + r] = 0;
+    }
+  }
+  if (tid == 0) out_count[b] = out_n;
 }
 
 }  // namespace kgdet
@@ -661,6 +808,58 @@ int kgdet_multiclass_nms(const float *boxes, const float *scores, int32_t B, int
                      N, C, score_stride, score_col0, (const long long *)keep, (const long long *)num_keep, max_num,
                      out_det, (long long *)out_label, (long long *)out_src, (long long *)out_count, np2);
   KGDET_CHECK_LAUNCH("multiclass_select");
+  return KGDET_OK;
+}
+
+size_t kgdet_multiclass_soft_nms_workspace_bytes(int32_t B, int32_t N, int32_t C) {
+  return (size_t)B * C * N * (5 * sizeof(float) + sizeof(int)) + (size_t)B * C * sizeof(int) + 64;
+}
+
+int kgdet_multiclass_soft_nms(const float *boxes, const float *scores, int32_t B, int32_t N, int32_t C,
+                              int32_t score_stride, int32_t score_col0, float score_thr, float iou_thr, int32_t method,
+                              float sigma, float min_score, int32_t max_num, float *out_det, int64_t *out_label,
+                              int64_t *out_src, int64_t *out_count, void *workspace, size_t workspace_bytes, void *stream) {
+  KGDET_CHECK_SHAPE(B >= 0 && N >= 0 && C > 0 && C <= 64 && max_num > 0, "bad sizes (1 <= C <= 64)");
+  KGDET_CHECK_SHAPE(score_col0 >= 0 && score_col0 + C <= score_stride, "score columns outside the row");
+  KGDET_CHECK_SHAPE(method >= 0 && method <= 2, "method: 0 hard, 1 linear, 2 gaussian");
+  if (B == 0) return KGDET_OK;
+  KGDET_CHECK_SHAPE(out_det && out_label && out_src && out_count, "null pointer");
+  if (N == 0) {
+    KGDET_HIP_TRY(hipMemsetAsync(out_det, 0, (size_t)B * max_num * 5 * 4, (hipStream_t)stream));
+    KGDET_HIP_TRY(hipMemsetAsync(out_label, 0, (size_t)B * max_num * 8, (hipStream_t)stream));
+    KGDET_HIP_TRY(hipMemsetAsync(out_src, 0, (size_t)B * max_num * 8, (hipStream_t)stream));
+    KGDET_HIP_TRY(hipMemsetAsync(out_count, 0, (size_t)B * 8, (hipStream_t)stream));
+    return KGDET_OK;
+  }
+  KGDET_CHECK_SHAPE(boxes && scores, "null pointer");
+  KGDET_CHECK_SHAPE(workspace && workspace_bytes >= kgdet_multiclass_soft_nms_workspace_bytes(B, N, C), "workspace too small");
+  const size_t lds = (size_t)N * 9 * 4;
+  int np2 = 64;
+  while (np2 < C * max_num) np2 <<= 1;
+  if (lds > 160 * 1024 - 256 || np2 > 16384) {
+    set_error("multiclass_soft_nms: %d candidates (limit %d) / %d classes x %d detections (limit 16384 keys) exceed the "
+              "on-chip limits", N, (160 * 1024 - 256) / 36, C, max_num);
+    return KGDET_E_UNSUPPORTED;
+  }
+  float *seg_dets = (float *)workspace;
+  int *seg_src = (int *)(seg_dets + (size_t)B * C * N * 5);
+  int *seg_count = seg_src + (size_t)B * C * N;
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)multiclass_soft_nms_segments,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)multiclass_soft_select, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      16384 * 8));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(multiclass_soft_nms_segments, dim3(B * C), dim3(kNmsThreads), lds, (hipStream_t)stream, boxes, scores,
+                     N, C, score_stride, score_col0, score_thr, iou_thr, (int)method, sigma, min_score, seg_dets, seg_src,
+                     seg_count);
+  KGDET_CHECK_LAUNCH("multiclass_soft_nms_segments");
+  hipLaunchKernelGGL(multiclass_soft_select, dim3(B), dim3(kNmsThreads), (size_t)np2 * 8, (hipStream_t)stream,
+                     (const float *)seg_dets, (const int *)seg_src, (const int *)seg_count, N, C, max_num, out_det,
+                     (long long *)out_label, (long long *)out_src, (long long *)out_count, np2);
+  KGDET_CHECK_LAUNCH("multiclass_soft_select");
   return KGDET_OK;
 }
 

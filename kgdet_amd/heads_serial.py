@@ -387,6 +387,119 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
         return mlvl_bboxes, mlvl_scores, mlvl_kpts
 
 
+    # ------------------------------------------------------------------------------------------
+    # whole-batch decode + fused (soft-)NMS: no per-image / per-class Python loop, no host read before the
+    # results -- capturable as one HIP graph (detector.graphed_test_batch).  Same values as get_bboxes_single.
+    # ------------------------------------------------------------------------------------------
+    def _packed_ok(self, cls_scores, img_metas, cfg, rescale):
+        kind = cfg.nms.get('type', 'nms')
+        if not (cls_scores[0].is_cuda and kind in ('nms', 'soft_nms') and self.use_sigmoid_cls and cfg.max_per_img > 0
+                and rescale):      # (rescale=False leaves the landmarks [n, K, 3]: SER:730-734 reshapes only when rescaling)
+            return False
+        if not all(isinstance(m['scale_factor'], (int, float)) for m in img_metas):
+            return False
+        pre = cfg.get('nms_pre', -1)
+        n = sum(min(c.shape[-2] * c.shape[-1], pre) if pre > 0 else c.shape[-2] * c.shape[-1] for c in cls_scores)
+        C = self.cls_out_channels
+        if kind == 'nms':
+            return n <= 4096 and n * C <= 16384 and C <= 64
+        if cfg.nms.get('method', 'linear') not in ('linear', 'gaussian'):
+            return False
+        return n * 36 <= 160 * 1024 - 256 and C <= 64 and C * cfg.max_per_img <= 16384
+
+    def _decode_level_batch(self, cls_score, bbox_pred, kpt_pred, points, stride, lim_w, lim_h, cfg):
+        """one level of get_bboxes_single for all images at once: boxes [B,n,4], scores [B,n,C], landmarks [B,n,K,3]"""
+        B, num_kpt = cls_score.shape[0], self.num_keypts
+        ch = kpt_pred.size(1) // num_kpt
+        assert ch == 2 or ch == 3
+        scores = cls_score.permute(0, 2, 3, 1).reshape(B, -1, self.cls_out_channels).sigmoid()
+        bbox_pred = bbox_pred.permute(0, 2, 3, 1).reshape(B, -1, 4)
+        kpt_pred = kpt_pred.permute(0, 2, 3, 1).reshape(B, -1, num_kpt, ch)
+        if ch == 2:
+            kpt_pred = torch.cat([kpt_pred, kpt_pred.new_ones(kpt_pred[..., :1].shape)], dim=-1)
+        ctr = points[:, :2].unsqueeze(0).expand(B, -1, -1)
+        nms_pre = cfg.get('nms_pre', -1)
+        if nms_pre > 0 and scores.shape[1] > nms_pre:
+            _, top = scores.max(dim=2)[0].topk(nms_pre, dim=1)
+            ctr = torch.gather(ctr, 1, top.unsqueeze(-1).expand(B, nms_pre, 2))
+            bbox_pred = torch.gather(bbox_pred, 1, top.unsqueeze(-1).expand(B, nms_pre, 4))
+            kpt_pred = torch.gather(kpt_pred, 1, top.view(B, nms_pre, 1, 1).expand(B, nms_pre, num_kpt, 3))
+            scores = torch.gather(scores, 1, top.unsqueeze(-1).expand(B, nms_pre, scores.shape[2]))
+        bboxes = bbox_pred * stride + torch.cat([ctr, ctr], dim=2)
+        kpts = kpt_pred.clone()
+        kpts[..., :2] = kpts[..., :2] * stride + ctr.unsqueeze(2)
+
+        def clamp(t, lim):
+            if isinstance(lim, (int, float)):
+                return t.clamp(min=0, max=lim)
+            return torch.minimum(t.clamp(min=0), lim.view((B, ) + (1, ) * (t.dim() - 1)))
+
+        bboxes = torch.stack([clamp(bboxes[..., 0], lim_w), clamp(bboxes[..., 1], lim_h), clamp(bboxes[..., 2], lim_w),
+                              clamp(bboxes[..., 3], lim_h)], dim=-1)
+        # reference quirk kept (SER:723-724): the slices run over the KEYPOINT axis -- every third landmark's (x, y, v)
+        kpts[:, :, 0::3] = clamp(kpts[:, :, 0::3], lim_w)
+        kpts[:, :, 1::3] = clamp(kpts[:, :, 1::3], lim_h)
+        return bboxes, scores, kpts
+
+    def get_bboxes_packed(self, cls_scores, bbox_preds, kpt_preds, mlvl_points, img_metas, cfg, rescale=True):
+        """refine-stage maps -> fixed-size device tensors (det [B,M,5], labels [B,M], landmarks [B,M,3K], count [B])"""
+        from .heads import RepPointsHeadKp3RepCas1AssignOnce as _K
+        from .postprocess import multiclass_nms_kp_fused, multiclass_soft_nms_kp_fused
+        device = cls_scores[0].device
+        lim_w = _K._per_image([float(m['img_shape'][1]) for m in img_metas], device)
+        lim_h = _K._per_image([float(m['img_shape'][0]) for m in img_metas], device)
+        decoded = [self._decode_level_batch(cls_scores[i].detach().float(), bbox_preds[i].detach().float(),
+                                            kpt_preds[i].detach().float(), mlvl_points[i], self.point_strides[i],
+                                            lim_w, lim_h, cfg) for i in range(len(cls_scores))]
+        bboxes = torch.cat([d[0] for d in decoded], dim=1)
+        scores = torch.cat([d[1] for d in decoded], dim=1)
+        kpts = torch.cat([d[2] for d in decoded], dim=1)
+        # get_bboxes_single divides by `new_tensor(scale_factor)`: a TRUE division (by a python scalar torch multiplies with
+        # the reciprocal -- one ulp off for factors like 1.5), so the divisor is a tensor here as well; a fill kernel when the
+        # images agree (capturable in a graph), one non-blocking upload otherwise
+        sf = _K._per_image([float(m['scale_factor']) for m in img_metas], device)
+        if isinstance(sf, float):
+            sf = torch.full((bboxes.shape[0], 1), sf, dtype=torch.float32, device=device)
+        bboxes = bboxes / sf.view(-1, 1, 1)
+        kpts[..., 0:2] = kpts[..., 0:2] / sf.view(-1, 1, 1, 1)
+        kpts = kpts.reshape(kpts.shape[0], kpts.shape[1], -1)
+        if cfg.nms.get('type', 'nms') == 'soft_nms':
+            return multiclass_soft_nms_kp_fused(bboxes, scores, kpts, cfg.score_thr, cfg.nms, cfg.max_per_img)
+        return multiclass_nms_kp_fused(bboxes, scores, kpts, cfg.score_thr, float(cfg.nms['iou_thr']), cfg.max_per_img)
+
+    def get_bboxes_packed_tensor(self, cls_scores, keypts_preds_init, keypts_preds_refine, reppts_preds_init,
+                                 reppts_preds_refine, img_metas, cfg, rescale=False):
+        """The batch's detections as ONE device tensor [B, max_per_img, 7 + 3K] -- box (4), score, label, count (repeated),
+        landmarks -- produced without any host read; None when the packed path does not apply."""
+        cls = [t.float() for t in cls_scores]
+        if not self._packed_ok(cls, img_metas, cfg, rescale):
+            return None
+        box = [self.points2bbox(r.float()) for r in reppts_preds_refine]
+        kpt = [self.points2kpt(k.float()) for k in keypts_preds_refine]
+        points = [self.point_generators[i].grid_points(cls[i].size()[-2:], self.point_strides[i], device=cls[i].device)
+                  for i in range(len(cls))]
+        det, label, kp, count = self.get_bboxes_packed(cls, box, kpt, points, img_metas, cfg, rescale)
+        B, M = label.shape
+        return torch.cat([det, label.unsqueeze(-1).float(), count.view(B, 1, 1).expand(B, M, 1).float(), kp], dim=-1)
+
+    @staticmethod
+    def unpack_results(packed):
+        """host copy of ``get_bboxes_packed_tensor`` -> per image (det [n, 5], labels [n] int64, landmarks [n, 3K])"""
+        out = []
+        for b in range(packed.shape[0]):
+            n = int(packed[b, 0, 6])
+            out.append((packed[b, :n, :5], packed[b, :n, 5].astype(np.int64), packed[b, :n, 7:]))
+        return out
+
+    def get_bboxes_numpy(self, *args, **kwargs):
+        """``get_bboxes`` with the results on the host as numpy arrays; on the packed path ONE device->host copy per batch"""
+        packed = self.get_bboxes_packed_tensor(*args, **kwargs)
+        if packed is None:
+            return [(d.float().cpu().numpy(), lab.cpu().numpy(), k.float().cpu().numpy().reshape(k.shape[0], -1))
+                    for d, lab, k in self.get_bboxes(*args, **kwargs)]
+        return self.unpack_results(packed.cpu().numpy())
+
+
 @HEADS.register_module
 class RepPointsHeadKpSerial(_RepPointsHeadKpTwoStage):
     """reppoints regressed from the keypoint maps (1x1 conv on keypts_out)"""

@@ -125,3 +125,44 @@ def multiclass_nms_kp_fused(bboxes, scores, kpts, score_thr, iou_thr, max_num):
     out_k = torch.gather(k, 1, src.unsqueeze(-1).expand(B, max_num, k.shape[-1]))
     out_k = out_k * (torch.arange(max_num, device=count.device).unsqueeze(0) < count.unsqueeze(1)).unsqueeze(-1)
     return det, label, out_k, count
+
+
+_SOFT_METHODS = {'linear': 1, 'gaussian': 2}      # (nms_wrapper.py:66-68; anything else is the reference's ValueError)
+
+
+def multiclass_soft_nms_kp_fused(bboxes, scores, kpts, score_thr, nms_cfg, max_num):
+    """``multiclass_nms_kp`` with ``nms_cfg['type'] == 'soft_nms'`` for a batch with nothing read by the host: two HIP launches
+    (csrc/nms.hip ``multiclass_soft_nms_segments`` + ``multiclass_soft_select``) and one landmark gather -- what lets the
+    config-5 (serial head, soft-NMS) inference batch be captured as one HIP graph.  Same arguments and returns as
+    ``multiclass_nms_kp_fused``; the fifth detection column is the DECAYED score, as ``soft_nms`` returns it.  Raises
+    NotImplementedError beyond the on-chip limits (N * 36 bytes of LDS, classes * max_num <= 16384)."""
+    import ctypes
+    from . import _lib
+    cfg = dict(nms_cfg)
+    assert cfg.pop('type') == 'soft_nms'
+    method = cfg.get('method', 'linear')
+    if method not in _SOFT_METHODS:
+        raise ValueError('Invalid method for SoftNMS: {}'.format(method))
+    iou_thr, sigma, min_score = float(cfg['iou_thr']), float(cfg.get('sigma', 0.5)), float(cfg.get('min_score', 1e-3))
+    B, N, C = scores.shape
+    if N * 36 > 160 * 1024 - 256 or C > 64 or C * max_num > 16384:
+        raise NotImplementedError('beyond the fused soft-NMS limits')
+    bboxes, scores = bboxes.contiguous().float(), scores.contiguous().float()
+    L = _lib.lib()
+    L.kgdet_multiclass_soft_nms_workspace_bytes.restype = ctypes.c_size_t
+    ws_bytes = L.kgdet_multiclass_soft_nms_workspace_bytes(ctypes.c_int32(B), ctypes.c_int32(N), ctypes.c_int32(C))
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=bboxes.device)
+    det = torch.empty((B, max_num, 5), dtype=torch.float32, device=bboxes.device)
+    label = torch.empty((B, max_num), dtype=torch.int64, device=bboxes.device)
+    src = torch.empty((B, max_num), dtype=torch.int64, device=bboxes.device)
+    count = torch.empty((B, ), dtype=torch.int64, device=bboxes.device)
+    _lib.check(L.kgdet_multiclass_soft_nms(
+        _lib.ptr(bboxes), _lib.ptr(scores), ctypes.c_int32(B), ctypes.c_int32(N), ctypes.c_int32(C), ctypes.c_int32(C),
+        ctypes.c_int32(0), ctypes.c_float(score_thr), ctypes.c_float(iou_thr), ctypes.c_int32(_SOFT_METHODS[method]),
+        ctypes.c_float(sigma), ctypes.c_float(min_score), ctypes.c_int32(max_num), _lib.ptr(det), _lib.ptr(label),
+        _lib.ptr(src), _lib.ptr(count), _lib.ptr(ws), ctypes.c_size_t(ws_bytes), _lib.current_stream()),
+        'kgdet_multiclass_soft_nms')
+    k = kpts.reshape(B, N, -1)
+    out_k = torch.gather(k, 1, src.unsqueeze(-1).expand(B, max_num, k.shape[-1]))
+    out_k = out_k * (torch.arange(max_num, device=count.device).unsqueeze(0) < count.unsqueeze(1)).unsqueeze(-1)
+    return det, label, out_k, count

@@ -383,6 +383,53 @@ def test_graphed_test_batch_matches_eager(bf16):
             assert abs(sum(len(d) for d in g[0]) - sum(len(d) for d in w[0])) <= 2
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('soft', [True, False])
+def test_serial_head_packed_postprocess_and_graph_match_the_per_image_path(soft):
+    """config 5 (serial head, five levels, <= 3350 candidates per image): the whole-batch decode + fused (soft-)NMS ==
+    get_bboxes' per-image, per-class path, also with different image shapes / scale factors per image; and the batch as ONE
+    HIP graph (detector.graphed_test_batch -- eager until round 4 because of soft-NMS's per-class host loop) returns what the
+    eager batch returns, also for a new image copied into the captured input buffer."""
+    from kgdet_amd import build_detector, configs, synthetic
+    cfg = configs.reppoints_kp_r50_fpn(soft_nms=soft)
+    torch.manual_seed(0)
+    model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().eval()
+    a = synthetic.make_batch(2, torch.device('cuda'), seed=0, img_shape=(384, 500, 3), pad_shape=(384, 512, 3))
+    b = synthetic.make_batch(2, torch.device('cuda'), seed=5, img_shape=(384, 500, 3), pad_shape=(384, 512, 3))
+    synthetic.calibrate_scores_serial(model, a, cfg.test_cfg.score_thr, 0.004)
+    metas = [dict(m) for m in a['img_meta']]
+    metas[1].update(img_shape=(300, 480, 3), scale_factor=1.5)
+    head = model.bbox_head
+    with torch.no_grad():
+        outs = head(model.extract_feat(a['img']), metas)
+        want = head.get_bboxes(*(outs + (metas, cfg.test_cfg, True)))
+        if soft:
+            got = head.get_bboxes_numpy(*(outs + (metas, cfg.test_cfg, True)))
+            assert head.get_bboxes_packed_tensor(*(outs + (metas, cfg.test_cfg, True))) is not None
+            assert sum(len(w[0]) for w in want) > 30
+            for (gd, gl, gk), (wd, wl, wk) in zip(got, want):
+                assert np.array_equal(gd, wd.cpu().numpy()) and np.array_equal(gl, wl.cpu().numpy())
+                assert np.array_equal(gk, wk.reshape(wk.shape[0], -1).cpu().numpy())
+        else:       # hard NMS with 13 classes x thousands of candidates is beyond the fused kernel's key budget: falls back
+            assert head.get_bboxes_packed_tensor(*(outs + (metas, cfg.test_cfg, True))) is None
+            return
+    run = model.graphed_test_batch(a['img'], a['img_meta'], rescale=True)
+    for batch in (a, b, a):
+        got = run(batch['img'])
+        with torch.no_grad():
+            want = model.simple_test_batch(batch['img'], batch['img_meta'], rescale=True)
+        assert len(got) == len(want) == 2
+        for g, w in zip(got, want):
+            assert len(g) == len(w)
+            if len(w) == 3:
+                for c in range(13):
+                    # (same selection; coordinates to 1e-6: on the five-level pyramid one of MIOpen's fp32 solvers sums with
+                    #  atomics -- two EAGER runs of the same batch already differ by one ulp in single detections,
+                    #  tools/dbg_serial_graph.py)
+                    assert g[0][c].shape == w[0][c].shape and g[2][c].shape == w[2][c].shape
+                    assert np.allclose(g[0][c], w[0][c], rtol=1e-6, atol=1e-4) and np.allclose(g[2][c], w[2][c], rtol=1e-6, atol=1e-4)
+
+
 def test_full_size_training_step_split_arithmetic_matches_exact_fp32():
     """One full-size (2 x 800x1344) training step under the default arithmetic (bf16 hi/lo split products, fp32
     accumulate, in the deformable kernels AND the backbone's dense convolutions) against the same step in plain

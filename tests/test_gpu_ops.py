@@ -96,6 +96,66 @@ def test_nms_fullsize_properties():
     assert inds2.numel() == kept.shape[0]                 # idempotent
 
 
+def test_fused_multiclass_soft_nms_reproduces_the_reference_goldens(G):
+    """kgdet_multiclass_soft_nms (round 4: the whole batch's per-class soft-NMS in two launches, nothing read by the host): every
+    golden case of the COMPILED reference soft_nms_cpu.pyx, fed as one class of one image with all boxes above the score
+    threshold, leaves the kernel with the reference's survivors, order and decayed scores, bit for bit (3350-box case
+    included); a second class and a second image around it must not disturb it."""
+    from kgdet_amd.postprocess import multiclass_soft_nms_kp_fused
+    names = {1: 'linear', 2: 'gaussian'}
+    for i in _cases('soft', G):
+        thr, method, sigma, min_score = G['soft%d_cfg' % i]
+        d = G['soft%d_dets' % i]
+        n = d.shape[0]
+        if n == 0 or n > 4500:
+            continue
+        boxes = torch.zeros(2, n, 4)
+        boxes[1] = torch.from_numpy(d[:, :4])
+        floor = float(d[:, 4].min()) - 1.0                      # every golden box is a candidate ...
+        scores = torch.full((2, n, 3), floor - 1.0)             # ... and nothing else, except a few rows of
+        scores[1, :, 1] = torch.from_numpy(d[:, 4])
+        scores[0, :min(n, 5), 0] = 0.9                          # another image / other classes: their own problems
+        scores[1, :min(n, 5), 2] = 0.5
+        kp = torch.arange(n, dtype=torch.float32).view(1, n, 1).expand(2, n, 3).contiguous()
+        cfg = dict(type='soft_nms', iou_thr=float(thr), method=names[int(method)], sigma=float(sigma), min_score=float(min_score))
+        M = n + 16
+        det, label, k, count = multiclass_soft_nms_kp_fused(boxes.cuda(), scores.cuda(), kp.cuda(), floor, cfg, M)
+        cnt = int(count[1])
+        lab = label[1, :cnt].cpu().numpy()
+        sel = lab == 1
+        np.testing.assert_array_equal(det[1, :cnt][torch.from_numpy(sel).cuda()].cpu().numpy(), G['soft%d_new' % i])
+        np.testing.assert_array_equal(k[1, :cnt, 0].cpu().numpy()[sel].astype(np.int64), G['soft%d_inds' % i])
+        assert np.all(np.diff(lab) >= 0)                        # class-major concatenation
+
+
+@pytest.mark.parametrize('method', ['linear', 'gaussian'])
+def test_fused_multiclass_soft_nms_equals_the_per_class_path(method):
+    """the fused batch path == multiclass_nms_kp (the per-image, per-class loop over the bit-exact soft_nms op) -- candidate
+    filter, per-class order, landmark rows, and the top-max_num cut by decayed score -- on clustered boxes: 3 images x 5
+    classes x 700 candidates, with max_num below AND above the number of survivors"""
+    from kgdet_amd.postprocess import multiclass_nms_kp, multiclass_soft_nms_kp_fused
+    rng = np.random.default_rng(3)
+    B, N, C = 3, 700, 5
+    ctr = rng.uniform(100, 1200, size=(B, 30, 2))[np.arange(B)[:, None], rng.integers(0, 30, size=(B, N))]
+    ctr = ctr + rng.normal(0, 15, size=(B, N, 2))
+    wh = rng.uniform(40, 160, size=(B, N, 2))
+    boxes = torch.from_numpy(np.concatenate([ctr - wh / 2, ctr + wh / 2], -1).astype(np.float32)).cuda()
+    scores = torch.from_numpy((rng.uniform(0, 1, size=(B, N, C)) ** 3).astype(np.float32)).cuda()
+    kpts = torch.from_numpy(rng.normal(size=(B, N, 9)).astype(np.float32)).cuda()
+    cfg = dict(type='soft_nms', iou_thr=0.5, method=method, sigma=0.5, min_score=0.05)
+    for max_num in (100, 4000):
+        det, label, k, count = multiclass_soft_nms_kp_fused(boxes, scores, kpts, 0.05, cfg, max_num)
+        for b in range(B):
+            ms = torch.cat([scores.new_zeros(N, 1), scores[b]], 1)
+            wd, wl, wk = multiclass_nms_kp(boxes[b], ms, kpts[b], 0.05, cfg, max_num)
+            n = int(count[b])
+            assert n == wd.shape[0] and n > 50
+            if n == max_num:        # the cut is by decayed score; equal scores could come in either order from torch's sort
+                assert len(np.unique(wd[:, 4].cpu().numpy())) == n
+            assert torch.equal(det[b, :n], wd) and torch.equal(label[b, :n], wl) and torch.equal(k[b, :n], wk)
+            assert float(det[b, n:].abs().sum()) == 0.0
+
+
 def test_soft_nms_reference_golden_bit_exact(G):
     from kgdet_amd.nms import soft_nms
     names = {1: 'linear', 2: 'gaussian'}
