@@ -178,7 +178,12 @@ int kgdet_device_cu_count(void);    /* compute units of the current device (0 if
  * in a ring of three, stages = pairs of taps: csrc/dcn_plane_pairs.h) instead of the default plane kernel.  Same results to
  * round-off; measured slower on MI355X (192 against 174 us for a KGDet head stage), kept as a working alternative. */
 #define KGDET_OPT_TAP_PAIRS 1
-#define KGDET_OPT_COUNT 2
+/* KGDET_OPT_WGRAD_STREAMK != 0: kgdet_deform_conv_grad_weight_grouped keeps rounds 1-3's schedule -- 256 x 128 tiles, (tile,
+ * stage) units dealt stream-K, partial tiles + fix-up -- where it would otherwise run the output-stationary kernel (round 4:
+ * one 256 x 208 tile per workgroup for the whole reduction, csrc/dcn_backward_weight_os.hip).  Same results to round-off
+ * (another summation order); for A/B measurements and so that both kernels stay under test. */
+#define KGDET_OPT_WGRAD_STREAMK 2
+#define KGDET_OPT_COUNT 3
 int kgdet_set_option(int32_t option, int32_t value);
 
 /* ------------------------------------------------------------------------------------------

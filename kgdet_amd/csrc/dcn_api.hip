@@ -1241,6 +1241,24 @@ static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *sh
   }
   const size_t image_off = total;   // (gather) the pixel-major copy of x
   if (gather) total += gather_image_bytes(shapes[0]);
+  // Output-stationary kernel (dcn_backward_weight_os.hip, round 4): a workgroup owns a 256 x (16 channels x 13 taps) tile for
+  // the whole reduction over pixels -- no partial tiles, no fix-up -- when all tiles of the call fit ONE round over the CUs
+  // (a KGDet head stage: 224).  Otherwise (and KGDET_DCN_WGRAD_OS=0, A/B) the stream-K kernel + fix-up below.
+  bool use_os = false;
+  if (!gather) {
+    static const int os_on = [] { const char *e = getenv("KGDET_DCN_WGRAD_OS"); return e ? atoi(e) : 1; }();
+    long long os_tiles = 0;
+    for (int i = 0; i < n; ++i) {
+      const kgdet_dcn_shape *s = shapes[i];
+      const int cpdg = s->C / s->deformable_groups;
+      for (int c0 = 0; c0 < s->C;) {
+        const int c1 = std::min((c0 / dd[i].Cg + 1) * dd[i].Cg, (c0 / cpdg + 1) * cpdg);
+        os_tiles += (long long)(dd[i].Og_pad / kTileM) * ceil_div(c1 - c0, kChunk) * ceil_div(dd[i].K, dcn_bwd_weight_os_taps());
+        c0 = c1;
+      }
+    }
+    use_os = os_on && g_options[KGDET_OPT_WGRAD_STREAMK] == 0 && os_tiles <= G;
+  }
   if (workspace == nullptr || workspace_bytes < slab_bytes() + total) {
     set_error("workspace too small: need %zu bytes, got %zu (kgdet_dcn_group_workspace_bytes)", slab_bytes() + total,
               workspace_bytes);
@@ -1300,7 +1318,7 @@ static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *sh
         packed_group = g;
       }
       p.n_mtiles = d.Og_pad / kTileM;
-      p.tiles_per_image = ceil_div(d.K, 8);                    // tap groups per channel chunk
+      p.tiles_per_image = ceil_div(d.K, use_os ? dcn_bwd_weight_os_taps() : 8);   // tap groups per channel chunk
       p.n_ntiles = (p.Cg_pad / kChunk) * p.tiles_per_image;    // (chunk, tap group) column tiles
       p.chunks_per_tap = n_px16;                               // stages per image
       p.chunks_per_tile = s->N * n_px16;                       // the reduction runs over the pixels of all images
@@ -1316,8 +1334,24 @@ static int grad_weight_plane_grouped(int32_t n, const kgdet_dcn_shape *const *sh
       first_sub = false;
       c0 = c1;
     }
-    const size_t need = gather ? dcn_bwd_weight_gather_lds_bytes(2) : dcn_bwd_weight_plane_lds_bytes(2, s->H * s->W);
+    const size_t need = gather ? dcn_bwd_weight_gather_lds_bytes(2)
+                               : use_os ? dcn_bwd_weight_os_lds_bytes(2, s->H * s->W) : dcn_bwd_weight_plane_lds_bytes(2, s->H * s->W);
     lds = need > lds ? need : lds;
+  }
+  if (use_os) {
+    static thread_local bool os_attr_set = false;
+    if (!os_attr_set) {
+      KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_bwd_weight_os<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)kMaxLds));
+      os_attr_set = true;
+    }
+    if (n_pack > 0)
+      hipLaunchKernelGGL(dcn_pack_grad_out, dim3(pack_x, pack_y, n_pack), dim3(256), 0, (hipStream_t)stream, pack, 2);
+    hipLaunchKernelGGL(dcn_build_taps, dim3(2 * G, grp.n), dim3(256), 0, (hipStream_t)stream, grp);
+    const int Gos = ceil_div(grp.tile_begin[grp.n], 8) * 8;      // (a multiple of 8: the XCD-contiguous tile order is a bijection)
+    hipLaunchKernelGGL(dcn_bwd_weight_os<2>, dim3(Gos), dim3(dcn_bwd_weight_os_threads()), lds, (hipStream_t)stream, grp);
+    KGDET_CHECK_LAUNCH("dcn_bwd_weight_os");
+    return KGDET_OK;
   }
   // The fix-up lists at most 32 slabs per tile: small problems run on fewer workgroups, so that a workgroup's share of the
   // units is at least 1/30 of the longest tile.

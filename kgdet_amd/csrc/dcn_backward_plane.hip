@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void dcn_inv_overflow_sums(const DcnInvSumGrou
       f32x4 acc[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+#pragma unroll 8
       for (int r = r0; r < r1; ++r) {
         const int px = sorted[r];
         const float w = wd[px];

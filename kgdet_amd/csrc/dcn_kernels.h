@@ -100,6 +100,12 @@ __global__ void dcn_bwd_weight_plane(const DcnFwdGroup grp, float *__restrict__ 
 template <int PARTS>
 __global__ void dcn_bwd_weight_gather(const DcnFwdGroup grp, float *__restrict__ slabs);
 __global__ void dcn_bwd_weight_plane_fixup(const DcnFwdGroup grp, const float *__restrict__ slabs, int G);
+// output-stationary grad_weight (dcn_backward_weight_os.hip): one 256 x (16 channels x 13 taps) tile per workgroup
+template <int PARTS>
+__global__ void dcn_bwd_weight_os(const DcnFwdGroup grp);
+size_t dcn_bwd_weight_os_lds_bytes(int parts, int HW);
+int dcn_bwd_weight_os_threads();
+int dcn_bwd_weight_os_taps();
 struct DcnPackGradOutItem {
   const float *gout;
   void *gq;

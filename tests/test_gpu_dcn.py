@@ -455,7 +455,8 @@ def test_grad_input_with_trained_head_offsets(case):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / 10
     t_rand, t_key = timed(to_rand), timed(to_key)
-    assert t_key < 1.6 * t_rand, 'grad_input depends on the offset distribution again: %.3f ms vs %.3f ms' % (t_key, t_rand)
+    # (measured 1.3-1.6x: the pre-aggregation reads every contribution's 1 KB row of grad_out once; rounds 2-3: 6-7x)
+    assert t_key < 2.0 * t_rand, 'grad_input depends on the offset distribution again: %.3f ms vs %.3f ms' % (t_key, t_rand)
 
 
 @pytest.mark.parametrize('case', [c for c in CASES if c[10] == 1 and c[9] == 1 and c[4] <= 256 and _plane_map(c)] +
@@ -522,6 +523,31 @@ def test_grad_weight_plane_kernel(case):
     ref = oracle.deform_conv_backward(x.astype(np.float64), off.astype(np.float64), w.astype(np.float64),
                                       go.astype(np.float64), s, p, d, g, dg)['grad_weight']
     _close(a[0].cpu().numpy(), ref, 5e-5)
+
+
+@pytest.mark.parametrize('case', [CASES[0], CASES[2], CASES[5], GROUP_CASES[3]])
+def test_grad_weight_stream_k_schedule_stays_correct(case):
+    """KGDET_OPT_WGRAD_STREAMK: rounds 1-3's schedule (256 x 128 tiles dealt stream-K, partial tiles + fix-up) stays a working
+    alternative to the output-stationary kernel the calls above run (round 4): both against the float64 oracle, and against
+    each other to round-off"""
+    _require_gpu()
+    from kgdet_amd import _lib, dcn
+    N, C, H, W, O, k, s, p, d, g, dg = case
+    x, off, w, go, _ = _make(case, seed=15)
+    tx, to, tw, tg = (torch.from_numpy(a).cuda() for a in (x, off, w, go))
+    shape = dcn._shape(tx, tw, (s, s), (p, p), (d, d), g, dg)
+    a = dcn.grad_weights_grouped([tx], [to], [tg], [tw], [shape])
+    _lib.check(_lib.lib().kgdet_set_option(2, 1), 'kgdet_set_option')
+    try:
+        b = dcn.grad_weights_grouped([tx], [to], [tg], [tw], [shape])
+    finally:
+        _lib.check(_lib.lib().kgdet_set_option(2, 0), 'kgdet_set_option')
+    ref = oracle.deform_conv_backward(x.astype(np.float64), off.astype(np.float64), w.astype(np.float64),
+                                      go.astype(np.float64), s, p, d, g, dg)['grad_weight']
+    _close(a[0].cpu().numpy(), ref, 5e-5)
+    _close(b[0].cpu().numpy(), ref, 5e-5)
+    _close(a[0].cpu().numpy(), b[0].double().cpu().numpy(), 2e-5)
+    assert not torch.equal(a[0], b[0]) or a[0].numel() < 64, 'the option is expected to select the other schedule'
 
 
 def test_more_tiles_than_slab_slots_take_the_safe_path():
