@@ -13,7 +13,7 @@
 // Here a tile is 256 x (16 channels x 13 taps = 208 columns, 7 MFMA blocks of 32) and a workgroup owns ONE tile for the
 // WHOLE reduction: 16 chunks x ceil(K / 13) tap groups = 64 / 32 / 16 tiles for a 7x7 / 5x5 / 3x3 weight, 224 for the
 // six problems of a KGDet head stage -- one round over the 256 CUs.  No split over pixels, no partial tiles, no fix-up:
-// the accumulators are written straight to grad_weight [O, C, kh, kw] (13-float runs).
+// the accumulators are written straight to grad_weight [O, C, kh, kw] (13-float runs; tile columns ordered (channel, tap)).
 //   * consumers: 8 waves, wave w = rows [32 w, 32 w + 32) x all 7 column blocks (112 accumulator registers); its two
 //     grad_out fragments per stage come straight from the bf16 hi/lo fragment image dcn_pack_grad_out writes
 //     (gq[mt][b][px16][part][khalf][o 256][8 px]: 16 bytes per lane and part, two stages ahead);
@@ -89,8 +89,12 @@ __device__ __forceinline__ void wgrad_os_role(const DcnFwdGroup &grp, unsigned c
   // columns of taps that do not exist (and the 16 padding columns of block 6) stay zero for the whole kernel
   for (int i = wtid; i < 2 * PARTS * kOsBPart / 16; i += kPlaneThreads) reinterpret_cast<u32x4 *>(Bs)[i] = u32x4{0u, 0u, 0u, 0u};
 
-  // producer thread -> (pixel quad pq: pixels 4 pq .. 4 pq + 3 of the stage, channel quad, local tap tl)
-  const int pq = tid & 3, quad = (tid >> 2) & 3, tl = tid >> 4;
+  // producer thread -> (local tap tl = lane & 15, pixel quad pq: pixels 4 pq .. 4 pq + 3 of the stage, channel quad = the wave).
+  // Columns of the tile are ordered (channel, tap): column = channel_in_chunk * taps_here + tl, so the 16 lanes of a store
+  // group (one pixel quad, taps 0 .. 15) write 16 consecutive 16-byte rows -- conflict-free (with (tap, channel) columns and
+  // taps across the waves the lanes of a store differed in multiples of 256 bytes only: 8-way bank conflicts on every B
+  // store, ~1000 LDS cycles per stage).
+  const int tl = tid & 15, pq = (tid >> 4) & 3, quad = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned char *plane_q = plane + quad * qstride;
   // record pieces this thread loads: j = tid and j = tid + 256 -> (tap r_tl, pixel r_px, half r_h)
   const int r_px = (tid >> 1) & 15, r_h = tid & 1;
@@ -136,7 +140,7 @@ __device__ __forceinline__ void wgrad_os_role(const DcnFwdGroup &grp, unsigned c
     };
     // this thread's 4 pixels x 4 channels at its tap -> four 8-byte pieces of B rows (tap, channel), hi and lo
     auto sample = [&](int slot, int buf) __attribute__((always_inline)) {
-      if (tl >= kOsTaps) return;      // (lanes 16 .. 63 of the fourth producer wave)
+      if (tl >= taps_here) return;    // (taps 13 .. 15 of every pixel quad, and the taps a short last group lacks)
 #ifdef KGDET_OS_ABL_NOSAMPLE
       return;
 #endif
@@ -153,7 +157,6 @@ __device__ __forceinline__ void wgrad_os_role(const DcnFwdGroup &grp, unsigned c
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[i][e] = *reinterpret_cast<const f32x4 *>(plane_q + ro[i][e]);
-      const bool live = tl < taps_here;
       float sv[4][4];   // [pixel][channel]
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -162,9 +165,9 @@ __device__ __forceinline__ void wgrad_os_role(const DcnFwdGroup &grp, unsigned c
           float a = __uint_as_float(rw[i][0]) * v[i][0][ch];
 #pragma unroll
           for (int e = 1; e < 4; ++e) a = __builtin_fmaf(__uint_as_float(rw[i][e]), v[i][e][ch], a);
-          sv[i][ch] = live ? a : 0.0f;
+          sv[i][ch] = a;
         }
-      unsigned char *dstb = Bs + buf * PARTS * kOsBPart + (pq >> 1) * (kOsCols * 16) + (tl * 16 + quad * 4) * 16 + (pq & 1) * 8;
+      unsigned char *dstb = Bs + buf * PARTS * kOsBPart + (pq >> 1) * (kOsCols * 16) + (quad * 4 * taps_here + tl) * 16 + (pq & 1) * 8;
       typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
       typedef float f32x2 __attribute__((ext_vector_type(2)));
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -179,8 +182,8 @@ __device__ __forceinline__ void wgrad_os_role(const DcnFwdGroup &grp, unsigned c
           const f32x2 d = {x2[0] - __uint_as_float(hu << 16), x2[1] - __uint_as_float(hu & 0xffff0000u)};
           lo[h] = __builtin_bit_cast(unsigned, __builtin_convertvector(d, bf16x2));
         }
-        *reinterpret_cast<u32x2 *>(dstb + ch * 16) = hi;
-        if constexpr (PARTS == 2) *reinterpret_cast<u32x2 *>(dstb + ch * 16 + kOsBPart) = lo;
+        *reinterpret_cast<u32x2 *>(dstb + ch * taps_here * 16) = hi;
+        if constexpr (PARTS == 2) *reinterpret_cast<u32x2 *>(dstb + ch * taps_here * 16 + kOsBPart) = lo;
       }
     };
     auto multiply = [&](int buf, const AFrag &F) __attribute__((always_inline)) {
@@ -189,24 +192,32 @@ __device__ __forceinline__ void wgrad_os_role(const DcnFwdGroup &grp, unsigned c
 #endif
       if constexpr (!PRODUCER) {
         const unsigned char *B = Bs + buf * PARTS * kOsBPart + (lane >> 5) * (kOsCols * 16) + (lane & 31) * 16;
-#pragma unroll
-        for (int ni = 0; ni < kOsBlocks; ++ni) {
-          if (ni >= nb_live) continue;      // (workgroup-uniform)
-          bf16x8 bb[PARTS];
+        // B fragments ONE block ahead of the MFMAs that use them (two alternating sets; read-wait-multiply per block left the
+        // LDS latency exposed seven times per stage -- the consumers alone ran at 46 % of the MFMA rate; two blocks ahead
+        // spills at the 168-register budget)
+        bf16x8 bb[2][PARTS];
+        auto fetch = [&](int ni, bf16x8 (&dst)[PARTS]) __attribute__((always_inline)) {
 #pragma unroll
           for (int part = 0; part < PARTS; ++part)
-            bb[part] = *reinterpret_cast<const bf16x8 *>(B + part * kOsBPart + ni * 32 * 16);
+            dst[part] = *reinterpret_cast<const bf16x8 *>(B + part * kOsBPart + ni * 32 * 16);
+        };
+        // (all seven blocks, also of a short tap group whose last blocks are zero columns: straight-line code -- with a
+        //  uniform branch per block hipcc kept one accumulator in scratch memory; the full tiles set the time anyway)
+        fetch(0, bb[0]);
+#pragma unroll
+        for (int ni = 0; ni < kOsBlocks; ++ni) {
+          if (ni + 1 < kOsBlocks) fetch(ni + 1, bb[(ni + 1) & 1]);
           if constexpr (PARTS == 2) {       // small terms first
-            acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[1], bb[0], acc[ni], 0, 0, 0);
-            acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[0], bb[1], acc[ni], 0, 0, 0);
+            acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[1], bb[ni & 1][0], acc[ni], 0, 0, 0);
+            acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[0], bb[ni & 1][1], acc[ni], 0, 0, 0);
           }
-          acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[0], bb[0], acc[ni], 0, 0, 0);
+          acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[0], bb[ni & 1][0], acc[ni], 0, 0, 0);
         }
       }
     };
 
     // Pipeline of stage s: record loads at body s-4, registers -> LDS record slot s & 1 at body s-2, sampled into
-    // B[s & 1] at body s-1, multiplied at body s (grad_out fragments requested at body s-2).  Two register sets alternate.
+    // B[s & 1] at body s-1, multiplied at body s (grad_out fragments requested at the top of body s-1).  Two register sets alternate.
     Regs RA, RB;
     AFrag FA, FB;
     __syncthreads();     // the image before: its last B stage is multiplied, its plane no longer read
@@ -215,7 +226,6 @@ __device__ __forceinline__ void wgrad_os_role(const DcnFwdGroup &grp, unsigned c
       issue(1, RB);
     } else {
       a_issue(0, FA);
-      a_issue(1, FB);
     }
     load_plane();
     if constexpr (PRODUCER) {
@@ -227,21 +237,24 @@ __device__ __forceinline__ void wgrad_os_role(const DcnFwdGroup &grp, unsigned c
     __syncthreads();
     if constexpr (PRODUCER) sample(0, 0);
     __syncthreads();
-    auto body = [&](auto I, int j, Regs &R, AFrag &F) __attribute__((always_inline)) {   // R holds stage j + 2, F stage j
+    auto body = [&](auto I, int j, Regs &R, AFrag &F, AFrag &G) __attribute__((always_inline)) {   // R holds stage j + 2, F stage j, G takes stage j + 1
       constexpr int i = decltype(I)::value;
       if constexpr (PRODUCER) {
         commit(i, R);
         issue(j + 4, R);
         if (j + 1 < n) sample(i ^ 1, i ^ 1);
       } else {
+        // the NEXT stage's grad_out fragments are requested at the top of the body, into the set the stage before released:
+        // a whole stage time to arrive.  (Requested two stages ahead at the END of the body, the wait at the next body's
+        // top -- vmcnt counts in order -- also waited for the loads just issued: an L2 round trip per stage.)
+        a_issue(j + 1, G);
         if (j < n) multiply(i, F);
-        a_issue(j + 2, F);
       }
       __syncthreads();
     };
     for (int j = 0; j < n; j += 2) {
-      body(std::integral_constant<int, 0>{}, j, RA, FA);
-      body(std::integral_constant<int, 1>{}, j + 1, RB, FB);
+      body(std::integral_constant<int, 0>{}, j, RA, FA, FB);
+      body(std::integral_constant<int, 1>{}, j + 1, RB, FB, FA);
     }
   }
 
@@ -251,8 +264,9 @@ __device__ __forceinline__ void wgrad_os_role(const DcnFwdGroup &grp, unsigned c
     for (int ni = 0; ni < kOsBlocks; ++ni) {
       if (ni >= nb_live) continue;
       const int col = ni * 32 + (lane & 31);
-      const int tl = col >> 4, c = c16 * kChunk + (col & 15), t = t0 + tl;
-      if (tl >= taps_here || c >= p.Cg) continue;
+      const int cc = col / taps_here, tlc = col - cc * taps_here;      // column = channel_in_chunk * taps_here + tap
+      const int c = c16 * kChunk + cc, t = t0 + tlc;
+      if (cc >= kChunk || c >= p.Cg) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = mt * kTileM + wave * 32 + mfma_row(r, lane);
