@@ -216,6 +216,9 @@ __device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__res
         if constexpr (!PRODUCER) {
           const unsigned char *A = As + buf * PARTS * kAPart + kg * 256 + px16 * 16;  // lane's row c = px16 (reused name)
           f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
+#ifdef KGDET_OFF_ABL_NOMFMA
+          acc0 = f32x4{R.wy[0], R.wy[1], R.wx[0], R.wx[1]};
+#else
 #pragma unroll
           for (int ks = 0; ks < kMaxKs; ++ks) {
             if (ks < n_ks) {
@@ -228,9 +231,15 @@ __device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__res
               }
             }
           }
+#endif
           f32x4 cg = acc0;
           if constexpr (PARTS == 2) { cg[0] += acc1[0] + acc2[0]; cg[1] += acc1[1] + acc2[1]; cg[2] += acc1[2] + acc2[2]; cg[3] += acc1[3] + acc2[3]; }
           // cg[r] = colgrad of channel 4 * kg + r for pixel px16: the x quad kg of the four corners
+#ifdef KGDET_OFF_ABL_NOTAIL
+          if (cg[0] != 1234.5f) return;
+#endif
+          // (requesting the corner quads before the MFMAs -- they do not depend on the column gradient -- spills at the
+          //  168-register budget: 64 registers of grad_out fragments, three record sets)
           const unsigned o[4] = {R.off.x, R.off.y, R.off.z, R.off.w};
           float gy = 0.f, gx = 0.f, gm = 0.f;
 #pragma unroll
@@ -241,14 +250,21 @@ __device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__res
             gx += R.wx[e] * d;
             if constexpr (MASK) gm += R.wm[e] * d;
           }
-          gy += __shfl_xor(gy, 16);
-          gx += __shfl_xor(gx, 16);
-          gy += __shfl_xor(gy, 32);
-          gx += __shfl_xor(gx, 32);
-          if constexpr (MASK) {
-            gm += __shfl_xor(gm, 16);
-            gm += __shfl_xor(gm, 32);
-          }
+          // sum over the four quad lanes of a pixel (lanes px16 + 16 kg): x + x[lane ^ 16], then + [lane ^ 32], as ONE vector
+          // instruction each -- gfx950's v_permlane16_swap / v_permlane32_swap on two copies of the value (every lane ends up
+          // with the sum of its row pair / its halves; a + b is commutative, so the bits equal the ds_bpermute shuffles' that
+          // rounds 1-3 used -- four LDS-crossbar round trips per stage at the end of a dependent chain)
+          auto quad_sum = [](float x) __attribute__((always_inline)) {
+            const unsigned u = __float_as_uint(x);
+            const auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+            const float s16 = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+            const unsigned w = __float_as_uint(s16);
+            const auto r32 = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+            return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+          };
+          gy = quad_sum(gy);
+          gx = quad_sum(gx);
+          if constexpr (MASK) gm = quad_sum(gm);
           if (kg == 0) {
             if constexpr (MASK) {
               f32x4 *dst = reinterpret_cast<f32x4 *>(offs_acc) + (size_t)(t0 + j) * kTileN + wave * 16 + px16;
