@@ -38,7 +38,14 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kMaxRecords = 2048;
 constexpr int kMaxGroup = 16;
-constexpr int kTileH = 4, kTileW = 6;  // grad_data tile
+// grad_data tile (round 4, same shape as profiles/r03_psroi.md, S = 2): 2 x 6 570 us, 4 x 3 580, 4 x 6 616 (rounds 2-3), 8 x 4 711,
+// 2 x 3 725 -- the kernel's time is nearly independent of the tile (total visits x per-visit work ~ constant), i.e. it is
+// not occupancy-bound as round 3 assumed
+#ifndef KGDET_PSROI_TILE_H
+#define KGDET_PSROI_TILE_H 2
+#define KGDET_PSROI_TILE_W 6
+#endif
+constexpr int kTileH = KGDET_PSROI_TILE_H, kTileW = KGDET_PSROI_TILE_W;
 constexpr int kBinBatch = 16;          // bins whose quotients psroi_grad_data fetches together
 constexpr int kListCap = 4096;         // RoIs per overlap-list segment of psroi_grad_data
 constexpr int kTilePix = kTileH * kTileW;
