@@ -805,7 +805,7 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
       sg.e[sg.n++] = DcnInvSum{(const int *)(tb + it.rec_bytes), (const DcnInvOvfCell *)(tb + it.rec_bytes + it.hdr_bytes),
                                (const int2 *)(tb + it.rec_bytes + it.hdr_bytes + it.cell_bytes), gout_t,
                                (float *)(sums_base + (size_t)dgi * inv_gov_bytes(s, d)), s->N * d.K, d.K, d.Ho * d.Wo, s->O,
-                               d.Og, d.Og_pad16, gov_ld, gov_slots};
+                               d.Og, d.Og_pad16, gov_ld, gov_slots, s->W};
     }
     hipLaunchKernelGGL(dcn_inv_overflow_sums, dim3(s->N * d.K, kInvSumSplit, sg.n), dim3(256), 0, (hipStream_t)stream, sg);
   }
@@ -1065,7 +1065,7 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
                                          d.Ho * d.Wo, (long long)O_total_ * d.Ho * d.Wo};
       pm_px = d.Ho * d.Wo > pm_px ? d.Ho * d.Wo : pm_px; pm_c = s->O > pm_c ? s->O : pm_c; pm_images += s->N;
       sums.e[sums.n++] = DcnInvSum{hdr, cells, spill, gout_t, gov, s->N * d.K, d.K, d.Ho * d.Wo, s->O, d.Og, d.Og_pad16,
-                                   inv_gov_ld(s, d), dcn_inv_max_slots(s->H * s->W, d.Ho * d.Wo)};
+                                   inv_gov_ld(s, d), dcn_inv_max_slots(s->H * s->W, d.Ho * d.Wo), s->W};
       sums_blocks = s->N * d.K > sums_blocks ? s->N * d.K : sums_blocks;
     }
     if (same_as[i] < 0) {   // (all distinct offset tensors of the group: one builder launch below)

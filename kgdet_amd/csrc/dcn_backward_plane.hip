@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void dcn_build_inverse_taps_multi(const DcnInv
 // repeatable; work proportional to the number of contributions, wherever they fall.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dcn_inv_overflow_sums(const DcnInvSumGroup grp) {
-  __shared__ float wd[kPlaneMaxHW];
+  __shared__ float wd[4 * kPlaneMaxHW];
   __shared__ unsigned short sorted[kPlaneMaxHW];
   __shared__ unsigned bitmap[64];
   __shared__ int prefix[64];
@@ -222,14 +222,116 @@ __global__ __launch_bounds__(256) void dcn_inv_overflow_sums(const DcnInvSumGrou
   const float *gt = e.gout_t + (size_t)b * HoWo * O;
   const int g16 = tid >> 4, l = tid & 15;
   const bool vec = (O & 3) == 0;
-  for (int slot = blockIdx.y; slot < count; slot += gridDim.y) {
-    const DcnInvOvfCell c = e.cells[(size_t)bt * e.max_slots + slot];
-    if (tid < 64) bitmap[tid] = 0;
+  // ---- cells with at most 64 contributions: ONE WAVE per cell, no workgroup barrier (the four waves work on four cells at
+  // once).  Lane i holds entry i; its rank = the number of entries with a smaller pixel (pixels of a cell are distinct); the
+  // entries go to the wave's LDS slots in rank order and the wave walks them in that order, lanes = 64 channel quads (one
+  // 16-byte load per entry and lane).  On converged key-point offsets an (image, tap) has dozens of such medium cells (the
+  // cells within the key point's jitter) beside the few hot ones: through the seven-barrier workgroup path below they were
+  // most of the kernel's time.
+  {
+    __shared__ unsigned short w_px[4][64];
+    __shared__ float w_w[4][64];
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    int small_idx = 0;
+    for (int slot = blockIdx.y; slot < count; slot += gridDim.y) {
+      const DcnInvOvfCell c = e.cells[(size_t)bt * e.max_slots + slot];
+      if (c.n > 64) continue;
+      if ((small_idx++ & 3) != wave) continue;
+      int2 en = make_int2(0x7fffffff, 0);
+      if (lane < c.n) en = spill_bt[c.start + lane];
+      int rank = 0;
+      for (int j = 0; j < c.n; ++j) rank += __builtin_amdgcn_readlane(en.x, j) < en.x ? 1 : 0;
+      __builtin_amdgcn_wave_barrier();                 // (the previous cell's reads of the slots are done: same wave, in order)
+      if (lane < c.n) {
+        w_px[wave][rank] = (unsigned short)en.x;
+        w_w[wave][rank] = __int_as_float(en.y);
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0)
+      __builtin_amdgcn_wave_barrier();
+      float *dst = e.gov + ((size_t)bt * e.max_slots + slot) * O_ld;
+      for (int d = lane; d < O_ld; d += 64)
+        if (d % e.Og_pad16 >= e.Og) dst[d] = 0.0f;
+      for (int c0 = 0; c0 < O; c0 += 256) {
+        const int ch = c0 + lane * 4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int r = 0; r < c.n; ++r) {
+          const int px = w_px[wave][r];
+          const float w = w_w[wave][r];
+          const float *src = gt + (size_t)px * O;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (vec) {
+            if (ch < O) v = *reinterpret_cast<const f32x4 *>(src + ch);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (ch + k < O) v[k] = src[ch + k];
+          }
+          acc[0] = __builtin_fmaf(w, v[0], acc[0]);
+          acc[1] = __builtin_fmaf(w, v[1], acc[1]);
+          acc[2] = __builtin_fmaf(w, v[2], acc[2]);
+          acc[3] = __builtin_fmaf(w, v[3], acc[3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (ch + k < O) dst[((ch + k) / e.Og) * e.Og_pad16 + (ch + k) % e.Og] = acc[k];
+      }
+    }
+  }
+  // ---- longer lists: the whole workgroup per CLUSTER of up to four such cells (q, q + 1, q + W, q + W + 1: the four bilinear
+  // corners of a sample).  With converged key points those four cells list (nearly) the same pixels, each with its own corner
+  // weight: the cluster is summed in ONE pass over the union of the pixels -- a pixel's 1 KB row of grad_out is loaded once and
+  // multiplied into up to four accumulator sets (cell by cell the hot cells read 1.4 GB of rows per head stage: this kernel's
+  // time is those reads).  Clusters are formed greedily in cell order by one thread, identically in every workgroup of the
+  // (image, tap); at most 4 * HoWo / 65 < 96 cells can have more than 64 contributions.
+  __shared__ short big[96];
+  __shared__ short members[96][4];
+  __shared__ int n_clusters_s;
+  if (tid == 0) {
+    int nb = 0;
+    for (int sl = 0; sl < count && nb < 96; ++sl)
+      if (e.cells[(size_t)bt * e.max_slots + sl].n > 64) big[nb++] = (short)sl;
+    unsigned long long taken0 = 0ull, taken1 = 0ull;
+    auto is_taken = [&](int i) { return i < 64 ? (taken0 >> i) & 1ull : (taken1 >> (i - 64)) & 1ull; };
+    auto take = [&](int i) { if (i < 64) taken0 |= 1ull << i; else taken1 |= 1ull << (i - 64); };
+    int nc = 0;
+    for (int i = 0; i < nb; ++i) {
+      if (is_taken(i)) continue;
+      take(i);
+      const int q = e.cells[(size_t)bt * e.max_slots + big[i]].cell, x = q % e.W;
+      short m[4] = {big[i], -1, -1, -1};
+      int k = 1;
+      const int want[3] = {x + 1 < e.W ? q + 1 : -1, q + e.W, x + 1 < e.W ? q + e.W + 1 : -1};
+      for (int j = i + 1; j < nb && k < 4; ++j) {
+        if (is_taken(j)) continue;
+        const int cj = e.cells[(size_t)bt * e.max_slots + big[j]].cell;
+        if (cj > q + e.W + 1) break;
+        if (cj == want[0] || cj == want[1] || cj == want[2]) { m[k++] = big[j]; take(j); }
+      }
+      members[nc][0] = m[0]; members[nc][1] = m[1]; members[nc][2] = m[2]; members[nc][3] = m[3];
+      ++nc;
+    }
+    n_clusters_s = nc;
+  }
+  __syncthreads();
+  const int n_clusters = n_clusters_s;
+  float *wd4 = wd;                  // [4][HoWo]: by-pixel weights of the members
+  for (int cl = blockIdx.y; cl < n_clusters; cl += gridDim.y) {
+    int slot[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) slot[k] = members[cl][k];
+    const int nm = 1 + (slot[1] >= 0) + (slot[2] >= 0) + (slot[3] >= 0);    // (members are packed to the front)
     __syncthreads();
-    for (int i = tid; i < c.n; i += 256) {
-      const int2 en = spill_bt[c.start + i];
-      wd[en.x] = __int_as_float(en.y);
-      atomicOr(&bitmap[en.x >> 5], 1u << (en.x & 31));
+    if (tid < 64) bitmap[tid] = 0;
+    for (int i = tid; i < nm * HoWo; i += 256) wd4[i] = 0.0f;
+    __syncthreads();
+    for (int k = 0; k < nm; ++k) {
+      const DcnInvOvfCell c = e.cells[(size_t)bt * e.max_slots + slot[k]];
+      for (int i = tid; i < c.n; i += 256) {
+        const int2 en = spill_bt[c.start + i];
+        wd4[k * HoWo + en.x] = __int_as_float(en.y);
+        atomicOr(&bitmap[en.x >> 5], 1u << (en.x & 31));
+      }
     }
     __syncthreads();
     if (tid < 64) {
@@ -243,51 +345,70 @@ __global__ __launch_bounds__(256) void dcn_inv_overflow_sums(const DcnInvSumGrou
       prefix[tid] = incl - pc;
     }
     __syncthreads();
+    const int n_px = prefix[words - 1] + __popc(bitmap[words - 1]);
     for (int px = tid; px < HoWo; px += 256) {
       const unsigned m = bitmap[px >> 5];
       if ((m >> (px & 31)) & 1u) sorted[prefix[px >> 5] + __popc(m & ((1u << (px & 31)) - 1u))] = (unsigned short)px;
     }
     __syncthreads();
-    const int r0 = (int)((long long)g16 * c.n / 16), r1 = (int)((long long)(g16 + 1) * c.n / 16);
-    // a Gov vector holds the convolution's weight groups one after the other, each padded to whole 16-channel chunks
-    // (zeros: the chunk's padding channels meet zero weights, but must be finite)
-    float *dst = e.gov + ((size_t)bt * e.max_slots + slot) * O_ld;
-    for (int d = tid; d < O_ld; d += 256)
-      if (d % e.Og_pad16 >= e.Og) dst[d] = 0.0f;
+    const int r0 = (int)((long long)g16 * n_px / 16), r1 = (int)((long long)(g16 + 1) * n_px / 16);
     for (int c0 = 0; c0 < O; c0 += 256) {
-      f32x4 acc[4];
+      f32x4 acc[4][4];   // [member][channel block j]
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[k][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
       for (int r = r0; r < r1; ++r) {
         const int px = sorted[r];
-        const float w = wd[px];
         const float *src = gt + (size_t)px * O;
+        f32x4 v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int ch = c0 + j * 64 + l * 4;
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
           if (vec) {
-            if (ch < O) v = *reinterpret_cast<const f32x4 *>(src + ch);
+            if (ch < O) v[j] = *reinterpret_cast<const f32x4 *>(src + ch);
           } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-              if (ch + k < O) v[k] = src[ch + k];
+            for (int i = 0; i < 4; ++i)
+              if (ch + i < O) v[j][i] = src[ch + i];
           }
-          acc[j][0] = __builtin_fmaf(w, v[0], acc[j][0]);
-          acc[j][1] = __builtin_fmaf(w, v[1], acc[j][1]);
-          acc[j][2] = __builtin_fmaf(w, v[2], acc[j][2]);
-          acc[j][3] = __builtin_fmaf(w, v[3], acc[j][3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (k >= nm) continue;
+          const float w = wd4[k * HoWo + px];
+          if (w == 0.0f) continue;          // (the pixel does not feed this member)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc[k][j][0] = __builtin_fmaf(w, v[j][0], acc[k][j][0]);
+            acc[k][j][1] = __builtin_fmaf(w, v[j][1], acc[k][j][1]);
+            acc[k][j][2] = __builtin_fmaf(w, v[j][2], acc[k][j][2]);
+            acc[k][j][3] = __builtin_fmaf(w, v[j][3], acc[k][j][3]);
+          }
         }
       }
+      for (int k = 0; k < nm; ++k) {      // the members' sixteen partial vectors, one member at a time through `part`
 #pragma unroll
-      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4 *>(&part[g16][j * 64 + l * 4]) = acc[j];
-      __syncthreads();
-      float sum = 0.f;
+        for (int kk = 0; kk < 4; ++kk)
+          if (kk == k) {
 #pragma unroll
-      for (int g = 0; g < 16; ++g) sum += part[g][tid];
-      if (c0 + tid < O) dst[((c0 + tid) / e.Og) * e.Og_pad16 + (c0 + tid) % e.Og] = sum;
-      __syncthreads();
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4 *>(&part[g16][j * 64 + l * 4]) = acc[kk][j];
+          }
+        __syncthreads();
+        // a Gov vector holds the convolution's weight groups one after the other, each padded to whole 16-channel chunks
+        // (zeros: the chunk's padding channels meet zero weights, but must be finite)
+        float *dst = e.gov + ((size_t)bt * e.max_slots + slot[k]) * O_ld;
+        if (c0 == 0)
+          for (int d = tid; d < O_ld; d += 256)
+            if (d % e.Og_pad16 >= e.Og) dst[d] = 0.0f;
+        float sum = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) sum += part[g][tid];
+        if (c0 + tid < O) dst[((c0 + tid) / e.Og) * e.Og_pad16 + (c0 + tid) % e.Og] = sum;
+        __syncthreads();
+      }
     }
   }
 }

@@ -68,6 +68,7 @@ struct DcnInvSum {
   const float *gout_t;   // [N][HoWo][O]: pixel-major copy of the convolution's grad_output channels
   float *gov;            // [N * K][max_slots][O_ld], O_ld = groups * Og_pad16
   int NK, K, HoWo, O, Og, Og_pad16, O_ld, max_slots;
+  int W;                 // width of the INPUT map (cells q = y * W + x): neighbours of a cell for the cluster rule
 };
 struct DcnInvSumGroup {
   int n;
