@@ -11,7 +11,7 @@ Timing protocol (mmdetection/tools/benchmark.py:84-108 skips its first iteration
 first window of --steps steps is kept as `burst_img_s` (the cold board), then the loop PRE-HEATS by wall time -- windows of
 --steps steps for >= --preheat-s seconds and until three consecutive windows agree within --steady-tol -- because the step
 runs at the board's power limit and the clock settles over the first seconds of load.  `value` is the MEDIAN of the
---windows (5) timed windows AFTER that (every window bracketed by barrier + synchronize, MAX over ranks); all windows,
+--windows (7) timed windows AFTER that (every window bracketed by barrier + synchronize, MAX over ranks); all windows,
 `steady` (do they agree within 3 %), and the board's power / clock read from sysfs or a rocm-smi child are on the line.
 
 Extra objects on the same line:
@@ -54,7 +54,7 @@ def parse_args():
     ap.add_argument('--no-inference-leg', action='store_true',
                     help='training mode, 1 GPU: skip the bf16 batch-8 inference measurement (a child process) that '
                          'is reported as the `inference` object of the same JSON line')
-    ap.add_argument('--windows', type=int, default=5,
+    ap.add_argument('--windows', type=int, default=7,
                     help='timed windows of --steps steps each (every window bracketed by barrier + synchronize); `value` is '
                          'the MEDIAN window, min / max / all windows are reported beside it')
     ap.add_argument('--force-dist', action='store_true',
@@ -636,7 +636,11 @@ def main():
             'windows': {'n': len(windows), 'steps_each': args.steps, 'statistic': 'median',
                         'img_s': [round(imgs / w, 1) for w in windows],
                         'min': round(imgs / max(windows), 1), 'max': round(imgs / min(windows), 1)},
-            'steady': bool(max(windows) / min(windows) - 1.0 < 0.03),
+            # steady: the windows agree within 3 % -- judged on the windows WITHOUT the slowest and the fastest one when
+            # there are at least five (this loop is paced by the host within a few percent of the GPU time, and the GPU box's
+            # host is shared: a neighbour's burst reads as one 0.25 s window at -10 %; all windows are listed above)
+            'steady': bool((lambda w: max(w) / min(w) - 1.0 < 0.03)(sorted(windows)[1:-1] if len(windows) >= 5 else windows)),
+            'steady_rule': 'max / min - 1 < 3 % over the windows without the slowest and the fastest',
             'burst_img_s': round(imgs / burst, 1) if burst else None,
             'preheat': preheat,
             'board': board.summary() if board is not None else None,
