@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/fwdprof /tmp/pmcf /tmp/pmcw /tmp/pmcs1 /tmp/pmcs2
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/fwdprof -o fwd -- python3 $GRAFT_REPO_ROOT/tools/run_group.py $B 30 $PREC > $OUT/fwd.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/fwdprof -o fwd -- python3 $GRAFT_REPO_ROOT/tools/run_group.py $B 100 $PREC > $OUT/fwd.log 2>&1
 cp /tmp/fwdprof/fwd_kernel_stats.csv $OUT/
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmcf -o p -- python3 $GRAFT_REPO_ROOT/tools/run_group.py $B 5 $PREC > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmcw -o p -- python3 $GRAFT_REPO_ROOT/tools/run_group.py $B 5 $PREC > $OUT/pmc_write.log 2>&1
