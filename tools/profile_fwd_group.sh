@@ -16,7 +16,7 @@ for d in pmcf pmcw pmcs1 pmcs2; do cp /tmp/$d/p_counter_collection.csv $OUT/$d.c
 python3 - $OUT <<'PY'
 import csv, collections, sys
 out = sys.argv[1]
-print('## kernel stats (30 launches)')
+print('## kernel stats')
 for r in csv.DictReader(open(out + '/fwd_kernel_stats.csv')):
     if 'dcn_' in r['Name']:
         print('| `%s` | %s | %.1f | %.1f | %.1f |' % (r['Name'][:70], r['Calls'], float(r['AverageNs']) / 1e3, float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3))
