@@ -27,6 +27,10 @@
 //
 // The mixed float / double arithmetic of the reference (0.5, 0.1, 1. literals) is kept so that bin boundaries round the
 // same way.  Envelope of the LDS record table: pooled_size^2 * sample_per_part^2 <= 2048 records, group_size <= 16.
+#include <limits.h>
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 
 #pragma clang fp contract(off)
@@ -124,6 +128,13 @@ __device__ __forceinline__ Rec lds_record(const Rec *recs, int i) {
   q.ya = (short)(v.y & 0xffff); q.yb = (short)(v.y >> 16);
   q.fx = __int_as_float(v.z); q.fy = __int_as_float(v.w);
   return q;
+}
+
+// first list of (image, offset class, group cell of bin (ph, pw)); lists are indexed [image][class][cell][pixel]
+__device__ __forceinline__ long long list_base(const kgdet_psroi_shape &s, int batch, int classes, int cls, int ph, int pw) {
+  const int G = s.group_size;
+  const int k = group_cell(ph, G, s.pooled_size) * G + group_cell(pw, G, s.pooled_size);
+  return (((long long)batch * classes + cls) * G * G + k) * s.H * s.W;
 }
 
 }  // namespace
@@ -321,7 +332,7 @@ __global__ __launch_bounds__(kThreads) void psroi_prepare(const kgdet_psroi_shap
                                                           const float *__restrict__ grad_out,
                                                           const float *__restrict__ count, int4 *__restrict__ bbox,
                                                           float *__restrict__ diffT, Rec *__restrict__ recs_out,
-                                                          int classes) {
+                                                          int classes, int *__restrict__ list_cnt /*nullable*/) {
   __shared__ int bb[4];
   __shared__ float tile[64 * 65];
   const int n = blockIdx.x, tid = threadIdx.x;
@@ -338,6 +349,11 @@ __global__ __launch_bounds__(kThreads) void psroi_prepare(const kgdet_psroi_shap
       const Rec q = make_record(s, r, n, cls, ph, pw, ih, iw, trans);
       recs_out[(long long)n * classes * PP * SS + i] = q;
       if (q.xa < 0) continue;
+      if (list_cnt) {     // entries of the per-pixel contribution lists (psroi_list_*): one per corner
+        int *lc = list_cnt + list_base(s, r.batch, classes, cls, ph, pw);
+        atomicAdd(lc + q.ya * s.W + q.xa, 1); atomicAdd(lc + q.yb * s.W + q.xa, 1);
+        atomicAdd(lc + q.ya * s.W + q.xb, 1); atomicAdd(lc + q.yb * s.W + q.xb, 1);
+      }
       xmin = min(xmin, (int)q.xa); xmax = max(xmax, (int)q.xb);
       ymin = min(ymin, (int)q.ya); ymax = max(ymax, (int)q.yb);
     }
@@ -537,6 +553,187 @@ __global__ __launch_bounds__(kGdThreads) void psroi_grad_data(const kgdet_psroi_
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// grad_data from per-pixel contribution lists (round 4; the tile gather above stays as the fallback / A-B path).
+// What the tile gather pays per (tile, 64 channels, overlapping RoI) -- fetch and filter all P*P*S*S records to find the
+// few with a corner in the tile -- does not depend on the channel, and grows with the number of tiles an RoI covers.
+// Here the channel-independent part is done ONCE per call:
+//   list L = (image, offset class, group cell, pixel) holds every (RoI, bin, sample, corner) that lands on the pixel as
+//   (row of diffT, bilinear weight), in the reference loop's serial order (RoI, bin row, bin column, sample row, sample
+//   column, corner);
+//   psroi_prepare counts, psroi_list_alloc hands out storage (a bump allocation: where a list lies is arbitrary, what it
+//   holds is not), psroi_list_fill drops the entries in (slot order arbitrary), psroi_list_sort ranks every list by the
+//   entries' sequence numbers (unique keys: rank = number of smaller keys) and writes it out in order;
+// and the channel-wide part is a pure stream: one wave per (list, run of channels) walks its list -- entries through scalar
+// loads, eight diffT rows in flight, lanes = 4 consecutive output channels (one 1 KB row piece per load and wave) -- and
+// adds w * diff in list order.  Exactly one writer per element: no atomics on floats, bit-repeatable, and the same bits as
+// the serial float32 evaluation (same products, same order).
+constexpr int kSortChunk = 1024;       // keys of a list a wave holds in LDS at a time
+
+// storage for every list (wave-aggregated bump allocation), counters reset to serve as fill cursors
+__global__ __launch_bounds__(kThreads) void psroi_list_alloc(int *__restrict__ cnt, int *__restrict__ start,
+                                                             int *__restrict__ total, long long NL) {
+  const long long L = (long long)blockIdx.x * kThreads + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = L < NL ? cnt[L] : 0;
+  int incl = c;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  const int wave_sum = __shfl(incl, 63);
+  int base = 0;
+  if (lane == 63 && wave_sum > 0) base = atomicAdd(total, wave_sum);
+  base = __shfl(base, 63);
+  if (L < NL) {
+    start[L] = base + incl - c;
+    cnt[L] = 0;
+  }
+}
+
+// thread = record: its four corner entries (sequence number, weight) into their lists
+__global__ __launch_bounds__(kThreads) void psroi_list_fill(const kgdet_psroi_shape s, const float *__restrict__ rois,
+                                                            const Rec *__restrict__ recs, const int *__restrict__ start,
+                                                            int *__restrict__ cursor, int2 *__restrict__ ent, int classes) {
+  const int P = s.pooled_size, SS = s.sample_per_part * s.sample_per_part, nrec = P * P * SS;
+  const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= (long long)s.R * classes * nrec) return;
+  const int nc = (int)(i / nrec), rec = (int)(i - (long long)nc * nrec);
+  const int n = nc / classes, cls = nc - n * classes;
+  const int batch = (int)rois[5 * n];
+  if (batch < 0 || batch >= s.B) return;
+  const int4 v = reinterpret_cast<const int4 *>(recs)[i];
+  const int xa = (short)(v.x & 0xffff), xb = (short)(v.x >> 16), ya = (short)(v.y & 0xffff), yb = (short)(v.y >> 16);
+  if (xa < 0) return;
+  const float fx = __int_as_float(v.z), fy = __int_as_float(v.w);
+  const int bin = rec / SS, ph = bin / P, pw = bin - ph * P;
+  const long long lb = list_base(s, batch, classes, cls, ph, pw);
+  const int seq = (int)i * 4;
+  // the reference's four atomicAdds (:236-245), their order and their weight expressions
+  const long long L0 = lb + ya * s.W + xa, L1 = lb + yb * s.W + xa, L2 = lb + ya * s.W + xb, L3 = lb + yb * s.W + xb;
+  const float w0 = (1 - fx) * (1 - fy), w1 = (1 - fx) * fy, w2 = fx * (1 - fy), w3 = fx * fy;
+  ent[start[L0] + atomicAdd(cursor + L0, 1)] = make_int2(seq, __float_as_int(w0));
+  ent[start[L1] + atomicAdd(cursor + L1, 1)] = make_int2(seq + 1, __float_as_int(w1));
+  ent[start[L2] + atomicAdd(cursor + L2, 1)] = make_int2(seq + 2, __float_as_int(w2));
+  ent[start[L3] + atomicAdd(cursor + L3, 1)] = make_int2(seq + 3, __float_as_int(w3));
+}
+
+// wave = list: entries (sequence number, weight) in slot order -> (diffT row, weight) in sequence order.  Rank sort: the keys
+// are unique, an entry's place is the number of smaller keys; up to 64 entries by lane reads, beyond through an LDS copy of the
+// keys read as broadcasts (four keys per ds_read_b128 against four entries per lane).
+__global__ __launch_bounds__(kThreads) void psroi_list_sort(const int *__restrict__ start, const int *__restrict__ len,
+                                                            const int2 *__restrict__ ent_in, int2 *__restrict__ ent_out,
+                                                            long long NL, int nrec, int classes, int SS, int PP) {
+  __shared__ __attribute__((aligned(16))) int keys[kThreads / 64][kSortChunk];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const long long L = (long long)blockIdx.x * (kThreads / 64) + wave;
+  if (L >= NL) return;
+  const int n = __builtin_amdgcn_readfirstlane(len[L]);
+  if (n == 0) return;
+  const int base = __builtin_amdgcn_readfirstlane(start[L]);
+  int *kw = keys[wave];
+  auto emit = [&](int2 e, int rank) {
+    const int q = e.x >> 2, nc = q / nrec, rec = q - nc * nrec;
+    ent_out[base + rank] = make_int2((nc / classes) * PP + rec / SS, e.y);
+  };
+  if (n <= 64) {
+    const int2 e = lane < n ? ent_in[base + lane] : make_int2(INT_MAX, 0);
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += __shfl(e.x, j) < e.x ? 1 : 0;
+    if (lane < n) emit(e, rank);
+    return;
+  }
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    int2 e[4];
+    int rank[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = i0 + u * 64 + lane;
+      e[u] = idx < n ? ent_in[base + idx] : make_int2(INT_MAX, 0);
+    }
+    for (int c0 = 0; c0 < n; c0 += kSortChunk) {
+      if (n > kSortChunk || i0 == 0) {
+        __builtin_amdgcn_wave_barrier();
+        for (int j = lane; j < kSortChunk; j += 64) kw[j] = c0 + j < n ? ent_in[base + c0 + j].x : INT_MAX;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+      }
+      const int m4 = (min(kSortChunk, n - c0) + 3) & ~3;
+      for (int j = 0; j < m4; j += 4) {
+        const int4 k4 = *reinterpret_cast<const int4 *>(kw + j);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          rank[u] += (k4.x < e[u].x ? 1 : 0) + (k4.y < e[u].x ? 1 : 0) + (k4.z < e[u].x ? 1 : 0) + (k4.w < e[u].x ? 1 : 0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u * 64 + lane < n) emit(e[u], rank[u]);
+  }
+}
+
+// wave = (list, run of 64 * VEC output channels of the list's offset class); lane = VEC consecutive output channels.
+// Workgroups are renumbered so that one XCD (workgroup id mod 8) walks a contiguous range of lists = neighbouring pixels,
+// whose entries share diffT rows: the rows stay in that XCD's L2.
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void psroi_grad_data_lists(const kgdet_psroi_shape s, const int *__restrict__ start,
+                                                                  const int *__restrict__ len,
+                                                                  const int2 *__restrict__ ent,
+                                                                  const float *__restrict__ diffT,
+                                                                  float *__restrict__ grad_data, int classes,
+                                                                  int ch_per_class, int chunks, long long items) {
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  const int per_xcd = gridDim.x >> 3;
+  const long long blk = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const long long item = blk * (kThreads / 64) + wave;
+  if (item >= items) return;
+  const int GG = s.group_size * s.group_size, HW = s.H * s.W;
+  const long long L = item / chunks;
+  const int chunk = (int)(item - L * chunks);
+  long long t = L / HW;
+  const int pix = (int)(L - t * HW);
+  const int k = (int)(t % GG);
+  t /= GG;
+  const int cls = (int)(t % classes), b = (int)(t / classes);
+  const int n = __builtin_amdgcn_readfirstlane(len[L]);
+  const int2 *ep = ent + __builtin_amdgcn_readfirstlane(start[L]);
+  const int ct = chunk * 64 * VEC + lane * VEC;                 // first channel of this lane inside the class
+  const bool live = ct < ch_per_class;                          // (VEC = 4: ch_per_class % 4 == 0, all four or none)
+  const float *dcol = diffT + cls * ch_per_class + (live ? ct : 0);
+  const long long od = s.out_dim;
+  vec_t acc = 0.f;
+  int e = 0;
+  for (; e + 8 <= n; e += 8) {
+    int2 q[8];
+    vec_t d[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) q[u] = ep[e + u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) d[u] = *reinterpret_cast<const vec_t *>(dcol + q[u].x * od);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = acc + __int_as_float(q[u].y) * d[u];
+  }
+  for (; e < n; ++e) {
+    const int2 q = ep[e];
+    acc = acc + __int_as_float(q.y) * *reinterpret_cast<const vec_t *>(dcol + q.x * od);
+  }
+  if (!live) return;
+  float *g = grad_data + (((long long)b * s.C + (long long)(cls * ch_per_class + ct) * GG + k) * HW + pix);
+#pragma unroll
+  for (int v = 0; v < VEC; ++v)
+    if (VEC == 1) g[0] = acc[0]; else g[(long long)v * GG * HW] = acc[v];
+}
+
+// channels beyond out_dim * group_size^2 take no part in the pooling: their gradient is zero
+__global__ __launch_bounds__(kThreads) void psroi_zero_tail(float *__restrict__ grad_data, long long image_stride,
+                                                            long long first, long long count) {
+  float *g = grad_data + blockIdx.y * image_stride + first;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < count; i += (long long)gridDim.x * kThreads) g[i] = 0.f;
+}
+
 }  // namespace kgdet
 
 using namespace kgdet;
@@ -614,6 +811,29 @@ int kgdet_deform_psroi_forward(const kgdet_psroi_shape *s, const float *data, co
   return KGDET_OK;
 }
 
+namespace {
+inline long long ceil_div(long long a, long long b) { return (a + b - 1) / b; }
+// per-pixel contribution lists of grad_data: counters / cursors [NL] + the allocation counter, starts [NL], two entry arrays
+long long lists_count(const kgdet_psroi_shape *s) {
+  const long long classes = s->no_trans ? 1 : (s->num_classes > 0 ? s->num_classes : 1);
+  return (long long)(s->B > 0 ? s->B : 0) * classes * s->group_size * s->group_size * s->H * s->W;
+}
+long long lists_entries(const kgdet_psroi_shape *s) {
+  const long long classes = s->no_trans ? 1 : (s->num_classes > 0 ? s->num_classes : 1);
+  return (long long)(s->R > 0 ? s->R : 0) * classes * s->pooled_size * s->pooled_size * s->sample_per_part *
+         s->sample_per_part * 4;
+}
+bool lists_ok(const kgdet_psroi_shape *s) {
+  static const bool off = [] { const char *e = getenv("KGDET_PSROI_GRAD_DATA"); return e && strcmp(e, "tiles") == 0; }();   // A/B switch
+  return !off && lists_count(s) <= (1ll << 26) && lists_entries(s) < (1ll << 31) - 4;
+}
+size_t lists_bytes(const kgdet_psroi_shape *s) {
+  if (!lists_ok(s)) return 0;
+  const size_t NL = (size_t)lists_count(s), T = (size_t)lists_entries(s);
+  return align_up((NL + 64) * sizeof(int), 256) + align_up(NL * sizeof(int), 256) + 2 * align_up(T * sizeof(int2), 256);
+}
+}  // namespace
+
 size_t kgdet_deform_psroi_backward_workspace_bytes(const kgdet_psroi_shape *s) {
   if (s == nullptr) return 0;
   const size_t R = (size_t)(s->R > 0 ? s->R : 0);
@@ -621,7 +841,7 @@ size_t kgdet_deform_psroi_backward_workspace_bytes(const kgdet_psroi_shape *s) {
   const size_t classes = s->no_trans ? 1 : (s->num_classes > 0 ? s->num_classes : 1);
   const size_t nrec = (size_t)s->pooled_size * s->pooled_size * s->sample_per_part * s->sample_per_part;
   return align_up(R * sizeof(int4), 256) + align_up(total * sizeof(float), 256) +
-         align_up(R * classes * nrec * sizeof(Rec), 256) + (s->no_trans ? 0 : cell_major_bytes(s)) + 256;
+         align_up(R * classes * nrec * sizeof(Rec), 256) + (s->no_trans ? 0 : cell_major_bytes(s)) + lists_bytes(s) + 256;
 }
 
 int kgdet_deform_psroi_backward(const kgdet_psroi_shape *s, const float *grad_out, const float *count,
@@ -654,6 +874,17 @@ int kgdet_deform_psroi_backward(const kgdet_psroi_shape *s, const float *grad_ou
   Rec *recs_ws = reinterpret_cast<Rec *>(wsb);
   wsb += align_up((size_t)s->R * classes * nrec * sizeof(Rec), 256);
   float *dataT = reinterpret_cast<float *>(wsb);
+  wsb += s->no_trans ? 0 : cell_major_bytes(s);
+  const bool use_lists = lists_ok(s);
+  const long long NL = lists_count(s), T = lists_entries(s);
+  int *list_cnt = reinterpret_cast<int *>(wsb);
+  int *list_total = list_cnt + NL;
+  wsb += align_up((size_t)(NL + 64) * sizeof(int), 256);
+  int *list_start = reinterpret_cast<int *>(wsb);
+  wsb += align_up((size_t)NL * sizeof(int), 256);
+  int2 *ent_slot = reinterpret_cast<int2 *>(wsb);
+  wsb += align_up((size_t)T * sizeof(int2), 256);
+  int2 *ent_sorted = reinterpret_cast<int2 *>(wsb);
   static thread_local bool attr_set = false;
   if (!attr_set) {
     KGDET_HIP_TRY(hipFuncSetAttribute((const void *)psroi_gather<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -663,20 +894,55 @@ int kgdet_deform_psroi_backward(const kgdet_psroi_shape *s, const float *grad_ou
     KGDET_HIP_TRY(hipFuncSetAttribute((const void *)psroi_grad_data<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_set = true;
   }
+  if (use_lists) KGDET_HIP_TRY(hipMemsetAsync(list_cnt, 0, (size_t)(NL + 64) * sizeof(int), (hipStream_t)stream));
   hipLaunchKernelGGL(psroi_prepare, dim3(s->R), dim3(kThreads), 0, (hipStream_t)stream, *s, rois, trans, grad_out, count,
-                     bbox, diffT, recs_ws, classes);
+                     bbox, diffT, recs_ws, classes, use_lists ? list_cnt : (int *)nullptr);
   KGDET_CHECK_LAUNCH("psroi_prepare");
-  const int tiles_x = ceil_div(s->W, kTileW), tiles_y = ceil_div(s->H, kTileH);
-  const int list_cap = s->R < kListCap ? s->R : kListCap;
-  const size_t lds = nrec * sizeof(Rec) + (size_t)kTilePix * kGdStride * sizeof(float) + (size_t)list_cap * sizeof(int);
-  KGDET_CHECK_SHAPE(s->B <= 65535 && ceil_div(s->C, kGdThreads) <= 65535, "batch / channel count beyond the launch grid");
-  const dim3 gd_grid(tiles_x * tiles_y, ceil_div(s->C, kGdThreads), s->B);
+  if (use_lists) {
+    hipStream_t st = (hipStream_t)stream;
+    const int list_waves = kThreads / 64;
+    hipLaunchKernelGGL(psroi_list_alloc, dim3((unsigned)ceil_div(NL, (long long)kThreads)), dim3(kThreads), 0, st, list_cnt,
+                       list_start, list_total, NL);
+    KGDET_CHECK_LAUNCH("psroi_list_alloc");
+    hipLaunchKernelGGL(psroi_list_fill, dim3((unsigned)ceil_div(T / 4, (long long)kThreads)), dim3(kThreads), 0, st, *s, rois,
+                       recs_ws, list_start, list_cnt, ent_slot, classes);
+    KGDET_CHECK_LAUNCH("psroi_list_fill");
+    hipLaunchKernelGGL(psroi_list_sort, dim3((unsigned)ceil_div(NL, (long long)list_waves)), dim3(kThreads), 0, st, list_start,
+                       list_cnt, ent_slot, ent_sorted, NL, (int)nrec, classes, s->sample_per_part * s->sample_per_part,
+                       s->pooled_size * s->pooled_size);
+    KGDET_CHECK_LAUNCH("psroi_list_sort");
+    const bool vec4 = ch_per_class % 4 == 0;
+    const int chunks = ceil_div(ch_per_class, vec4 ? 256 : 64);
+    const long long items = NL * chunks;
+    const long long blocks = ceil_div(ceil_div(items, (long long)list_waves), 8ll) * 8;
+    KGDET_CHECK_SHAPE(blocks < (1ll << 31), "grad_data: too many (pixel, channel run) items for one launch");
+    if (vec4)
+      hipLaunchKernelGGL(psroi_grad_data_lists<4>, dim3((unsigned)blocks), dim3(kThreads), 0, st, *s, list_start, list_cnt,
+                         ent_sorted, diffT, grad_data, classes, ch_per_class, chunks, items);
+    else
+      hipLaunchKernelGGL(psroi_grad_data_lists<1>, dim3((unsigned)blocks), dim3(kThreads), 0, st, *s, list_start, list_cnt,
+                         ent_sorted, diffT, grad_data, classes, ch_per_class, chunks, items);
+    KGDET_CHECK_LAUNCH("psroi_grad_data_lists");
+    const long long used = (long long)s->out_dim * s->group_size * s->group_size, HW = (long long)s->H * s->W;
+    if (used < s->C) {
+      const long long cnt = (s->C - used) * HW, zb = ceil_div(cnt, (long long)kThreads);
+      hipLaunchKernelGGL(psroi_zero_tail, dim3((unsigned)(zb > 1024 ? 1024 : zb), s->B), dim3(kThreads), 0, st, grad_data,
+                         (long long)s->C * HW, used * HW, cnt);
+      KGDET_CHECK_LAUNCH("psroi_zero_tail");
+    }
+  } else {
+    const int tiles_x = ceil_div(s->W, kTileW), tiles_y = ceil_div(s->H, kTileH);
+    const int list_cap = s->R < kListCap ? s->R : kListCap;
+    const size_t lds = nrec * sizeof(Rec) + (size_t)kTilePix * kGdStride * sizeof(float) + (size_t)list_cap * sizeof(int);
+    KGDET_CHECK_SHAPE(s->B <= 65535 && ceil_div(s->C, kGdThreads) <= 65535, "batch / channel count beyond the launch grid");
+    const dim3 gd_grid(tiles_x * tiles_y, ceil_div(s->C, kGdThreads), s->B);
 #define KGDET_GD_ARGS (hipStream_t)stream, *s, rois, bbox, recs_ws, diffT, grad_data, classes, ch_per_class, tiles_x, list_cap
-  if (nrec <= 4 * kGdThreads) hipLaunchKernelGGL(psroi_grad_data<4>, gd_grid, dim3(kGdThreads), lds, KGDET_GD_ARGS);
-  else if (nrec <= 13 * kGdThreads) hipLaunchKernelGGL(psroi_grad_data<13>, gd_grid, dim3(kGdThreads), lds, KGDET_GD_ARGS);
-  else hipLaunchKernelGGL(psroi_grad_data<32>, gd_grid, dim3(kGdThreads), lds, KGDET_GD_ARGS);
+    if (nrec <= 4 * kGdThreads) hipLaunchKernelGGL(psroi_grad_data<4>, gd_grid, dim3(kGdThreads), lds, KGDET_GD_ARGS);
+    else if (nrec <= 13 * kGdThreads) hipLaunchKernelGGL(psroi_grad_data<13>, gd_grid, dim3(kGdThreads), lds, KGDET_GD_ARGS);
+    else hipLaunchKernelGGL(psroi_grad_data<32>, gd_grid, dim3(kGdThreads), lds, KGDET_GD_ARGS);
 #undef KGDET_GD_ARGS
-  KGDET_CHECK_LAUNCH("psroi_grad_data");
+    KGDET_CHECK_LAUNCH("psroi_grad_data");
+  }
   if (!s->no_trans) {
     if (int rc = launch_cell_major(s, data, dataT, (hipStream_t)stream)) return rc;
     hipLaunchKernelGGL(psroi_gather<1>, dim3((unsigned)((long long)s->R * classes)), dim3(kThreads), gather_lds(s, 1),
