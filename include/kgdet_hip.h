@@ -334,7 +334,7 @@ int kgdet_deform_conv_backward_weight(const kgdet_dcn_shape *s, const float *inp
  * Backward OVERWRITES grad_input [B,C,H,W] and grad_trans (every element written exactly once: no pre-zeroing, no
  * atomics, bit-repeatable; the reference accumulates with atomicAdd into zero-filled tensors).  It needs
  * kgdet_deform_psroi_backward_workspace_bytes(s) bytes of caller-owned scratch (per-RoI bounding boxes + the
- * transposed grad_out / count quotient).
+ * transposed grad_out / count quotient + the per-pixel contribution lists grad_data is summed from).
  * Envelope (LDS record table): pooled_size^2 * sample_per_part^2 <= 2048, pooled_size <= 16, group_size <= 16 --
  * KGDET_E_SHAPE beyond (the reference's configs use 7 / 4 / 1 or 7).
  * ------------------------------------------------------------------------------------------ */

@@ -1185,8 +1185,9 @@ __global__ __launch_bounds__(256) void conv3x3_wsum(const float *__restrict__ pa
 template <int TAPS, int DX>
 __device__ __forceinline__ void conv_nt8_body(const float *__restrict__ a, const float *__restrict__ bm,
                                               float *__restrict__ partial, int M, int N, int L, int B, int n_mt, int n_nt,
-                                              int stages_per_image, int per, int H, int W, int Cin, unsigned char *smem) {
-  const int tile = blockIdx.x % (n_mt * n_nt), split = blockIdx.x / (n_mt * n_nt);
+                                              int stages_per_image, int per, int H, int W, int Cin, int unit,
+                                              unsigned char *smem) {
+  const int tile = unit % (n_mt * n_nt), split = unit / (n_mt * n_nt);
   const int mt = tile % n_mt, nt = tile / n_mt;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
   const int row = tid >> 2, q = tid & 3;
@@ -1315,20 +1316,258 @@ __device__ __forceinline__ void conv_nt8_body(const float *__restrict__ a, const
     }
 }
 
+// units > 0: the launch holds ceil(units / 8) * 8 workgroups and workgroup b takes unit xcd_tile(b, units) -- the tiles of one
+// split (same pixels of both operands; for TAPS == 9 the nine taps re-read the same x rows) run on ONE XCD and share its L2
+// instead of fetching the rows once per XCD; units == 0: workgroup b takes unit b (the order up to round 3, A/B).
 template <int TAPS>
 __global__ __launch_bounds__(kNNThreads) void conv_nt8(const float *__restrict__ a, const float *__restrict__ bm,
                                                        float *__restrict__ partial, int M, int N, int L, int B, int n_mt,
-                                                       int n_nt, int stages_per_image, int per, int H, int W, int Cin) {
+                                                       int n_nt, int stages_per_image, int per, int H, int W, int Cin,
+                                                       int units) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * kStage];
+  const int unit = units > 0 ? xcd_tile(blockIdx.x, units) : (int)blockIdx.x;
+  if (units > 0 && unit >= units) return;
   if (TAPS == 9) {
-    const int tile = blockIdx.x % (n_mt * n_nt), nt = tile / n_mt;
+    const int tile = unit % (n_mt * n_nt), nt = tile / n_mt;
     const int dx = ((nt * kTN) / Cin) % 3 - 1;   // uniform: one tap per tile
-    if (dx < 0) conv_nt8_body<TAPS, -1>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, smem);
-    else if (dx == 0) conv_nt8_body<TAPS, 0>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, smem);
-    else conv_nt8_body<TAPS, 1>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, smem);
+    if (dx < 0) conv_nt8_body<TAPS, -1>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem);
+    else if (dx == 0) conv_nt8_body<TAPS, 0>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem);
+    else conv_nt8_body<TAPS, 1>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem);
   } else {
-    conv_nt8_body<TAPS, 0>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, smem);
+    conv_nt8_body<TAPS, 0>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem);
   }
+}
+
+// conv_ntp (round 4): the same grad_weight tile (128 x 128 outputs, partial[split][m][n]) with the work of a stage divided
+// between PRODUCER and CONSUMER waves instead of done by every wave in turn.  Counters of conv_nt8 on a 3x3, 256 -> 256,
+// 50 x 84 problem (gpurun, rocprofv3 --pmc): the MFMA pipe busy 25 % of the kernel, ~76 vector instructions per wave and
+// 16-pixel stage for 6 MFMAs (index arithmetic, boundary selects, hi / lo split), vector ALU busy 46 %, the loads served by L2
+// in ~185 cycles, 33 MB fetched for 66 MB of operands -- not a bandwidth problem: eight waves that all convert, then all
+// multiply, between two barriers per 16 pixels, with both waves of a SIMD in the same phase at the same time.
+//   * stage = 32 pixels (a full 128-byte line of every operand row), two LDS stages, ONE barrier per stage;
+//   * 4 producer waves: thread = (row of a 32-row pass, 16-byte piece of the 128-byte row segment) -- 8 lanes read one
+//     contiguous row segment --, four passes for the 128 rows of each operand, loads two stages ahead in registers;
+//     boundary masks of the 3x3 taps once per stage and thread (the four passes share the pixels), none for the grad_y
+//     operand (rows beyond M / N are clamped duplicates whose outputs are not stored; pixels beyond the image multiply a
+//     zeroed x), image / stage counters advanced incrementally instead of divided out;
+//   * 4 consumer waves: 64 x 64 outputs each (four accumulator blocks), per 16 pixels 8 fragment reads for 12 MFMAs
+//     (conv_nt8: 6 for 6), products ordered so that consecutive MFMAs never share an accumulator;
+//   * LDS: the four (16-pixel step, k half) blocks of a stage start 16 banks apart (kPKH = 2048 + 64 bytes): the producers'
+//     8-byte stores of one instruction (8 pieces x 4 rows per half wave) fall on 64 different banks.
+constexpr int kPK = 32;                         // pixels per stage
+constexpr int kPKH = kTM * 16 + 64;             // [128 rows][8 bf16] + the bank offset
+constexpr int kPKS = 2 * kPKH;                  // one 16-pixel MFMA step: two k halves
+constexpr int kPPart = 2 * kPKS;                // one part (hi / lo) of one operand's stage
+constexpr int kPOperand = 2 * kPPart;
+constexpr int kPStage = 2 * kPOperand;          // A + B = 33792 bytes
+constexpr int kPThreads = 512;
+constexpr int kPLds = 2 * kPStage;
+
+template <int TAPS, int DX, bool PRODUCER>
+__device__ __forceinline__ void conv_ntp_role(const float *__restrict__ a, const float *__restrict__ bm,
+                                              float *__restrict__ partial, int M, int N, int L, int B, int n_mt, int n_nt,
+                                              int stages_per_image, int per, int H, int W, int Cin, int unit,
+                                              unsigned char *smem) {
+  const int tile = unit % (n_mt * n_nt), split = unit / (n_mt * n_nt);
+  const int mt = tile % n_mt, nt = tile / n_mt;
+  const int total = B * stages_per_image;
+  const int s_begin = split * per, s_end = min(total, s_begin + per);
+  const int n = s_end - s_begin;
+  const int wtid = threadIdx.x, tid = PRODUCER ? wtid - 256 : wtid;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  if constexpr (PRODUCER) {
+    const int rp = tid >> 3, q = tid & 7;
+    const int tap = TAPS == 9 ? (nt * kTN) / Cin : 0;
+    const int dy = TAPS == 9 ? tap / 3 - 1 : 0;
+    constexpr int dx = DX, off = dx < 0 ? -4 : 0, sh = dx - off;
+    constexpr int NV = (TAPS == 9 && dx != 0) ? 2 : 1;                  // 16-byte loads of bm per row pass
+    const int bcols = TAPS == 9 ? Cin : N;
+    const int bn0 = TAPS == 9 ? nt * kTN - tap * Cin : nt * kTN;
+    int a_off[4], b_off[4];                                             // element offsets of the four rows inside one image
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      a_off[k] = min(mt * kTM + rp + 32 * k, M - 1) * L;
+      b_off[k] = min(bn0 + rp + 32 * k, bcols - 1) * L;
+    }
+    const float inv_w = 1.0f / (float)W;
+    // LDS byte offset of this thread's piece inside an operand part: pixels 4q .. 4q + 3 = step q >> 2, k half (q >> 1) & 1
+    const int lds_o = (q >> 2) * kPKS + ((q >> 1) & 1) * kPKH + rp * 16 + (q & 1) * 8;
+
+    struct Regs {
+      f32x4 va[4];
+      f32x4 vb[4][NV];
+      int p0;
+    };
+    int img = s_begin / stages_per_image, st = s_begin - img * stages_per_image;   // of the NEXT stage to be issued
+    int issued = s_begin;
+    auto issue = [&](Regs &R) __attribute__((always_inline)) {
+      // (past the end of the range: the last stage again -- the loads stay unconditional, nothing is committed from them)
+      const int p0 = st * kPK + q * 4;
+      R.p0 = p0;
+      const float *ai = a + (long long)img * M * L, *bi = bm + (long long)img * bcols * L;
+      const int pa = min(p0, L - 4), base = p0 + dy * W + off;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        R.va[k] = *reinterpret_cast<const f32x4 *>(ai + a_off[k] + pa);
+#pragma unroll
+        for (int v = 0; v < NV; ++v)   // clamped chunks hold wrong pixels only where the tap is outside the image
+          R.vb[k][v] = *reinterpret_cast<const f32x4 *>(bi + b_off[k] + min(max(base + 4 * v, 0), L - 4));
+      }
+      if (issued + 1 < s_end) {
+        ++issued;
+        if (++st == stages_per_image) { st = 0; ++img; }
+      }
+    };
+    auto commit = [&](int buf, const Regs &R) __attribute__((always_inline)) {
+      unsigned char *As = smem + buf * kPStage + lds_o, *Bs = As + kPOperand;
+      bool ok[4];
+      {
+        const bool in_img = R.p0 < L;     // L % 4 == 0: a piece is entirely inside or outside the image
+        int w0 = 0;
+        bool row_ok = in_img;
+        if (TAPS == 9) {
+          const int h = (int)(((float)R.p0 + 0.5f) * inv_w);
+          w0 = R.p0 - h * W;
+          row_ok = row_ok && h + dy >= 0 && h + dy < H;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int col = w0 + i + dx;
+          ok[i] = TAPS == 9 ? (row_ok && col >= 0 && col < W) : row_ok;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int e = i + (TAPS == 9 ? sh : 0);
+          fb[i] = ok[i] ? R.vb[k][e >> 2][e & 3] : 0.0f;
+        }
+        uint2 ahi, alo, bhi, blo;
+        split_pair(R.va[k][0], R.va[k][1], ahi.x, alo.x);
+        split_pair(R.va[k][2], R.va[k][3], ahi.y, alo.y);
+        split_pair(fb[0], fb[1], bhi.x, blo.x);
+        split_pair(fb[2], fb[3], bhi.y, blo.y);
+        *reinterpret_cast<uint2 *>(As + k * 32 * 16) = ahi;
+        *reinterpret_cast<uint2 *>(As + kPPart + k * 32 * 16) = alo;
+        *reinterpret_cast<uint2 *>(Bs + k * 32 * 16) = bhi;
+        *reinterpret_cast<uint2 *>(Bs + kPPart + k * 32 * 16) = blo;
+      }
+    };
+    if (n > 0) {
+      Regs R0, R1;
+      issue(R0);
+      issue(R1);
+      commit(0, R0);
+      issue(R0);
+      __syncthreads();
+      for (int j = 0; j < n; j += 2) {
+        if (j + 1 < n) commit(1, R1);       // stage j + 1
+        issue(R1);                          // stage j + 3
+        __syncthreads();
+        if (j + 1 < n) {
+          if (j + 2 < n) commit(0, R0);     // stage j + 2
+          issue(R0);                        // stage j + 4
+          __syncthreads();
+        }
+      }
+    }
+  } else {
+    const int wm = wave & 1, wn = wave >> 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+    const int fo = (lane >> 5) * kPKH + (lane & 31) * 16;
+    auto multiply = [&](int buf) __attribute__((always_inline)) {
+      const unsigned char *A = smem + buf * kPStage + fo + wm * 64 * 16;
+      const unsigned char *Bp = smem + buf * kPStage + kPOperand + fo + wn * 64 * 16;
+      bf16x8 fa[2][2][2], fb[2][2][2];     // [step][part][block]
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            fa[ks][pt][i] = *reinterpret_cast<const bf16x8 *>(A + ks * kPKS + pt * kPPart + i * 32 * 16);
+            fb[ks][pt][i] = *reinterpret_cast<const bf16x8 *>(Bp + ks * kPKS + pt * kPPart + i * 32 * 16);
+          }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        // small terms first; four independent accumulators between two MFMAs on the same one
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][1][mi], fb[ks][0][ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][0][mi], fb[ks][1][ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][0][mi], fb[ks][0][ni], acc[mi][ni], 0, 0, 0);
+      }
+    };
+    if (n > 0) {
+      __syncthreads();
+      for (int j = 0; j < n; j += 2) {
+        multiply(0);
+        __syncthreads();
+        if (j + 1 < n) {
+          multiply(1);
+          __syncthreads();
+        }
+      }
+    }
+    float *out = partial + (long long)split * M * N;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int nn = nt * kTN + wn * 64 + ni * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mt * kTM + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (m < M && nn < N) out[(long long)m * N + nn] = acc[mi][ni][r];
+        }
+      }
+  }
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(kPThreads, 1) void conv_ntp(const float *__restrict__ a, const float *__restrict__ bm,
+                                                         float *__restrict__ partial, int M, int N, int L, int B, int n_mt,
+                                                         int n_nt, int stages_per_image, int per, int H, int W, int Cin,
+                                                         int units) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int unit = xcd_tile(blockIdx.x, units);
+  if (unit >= units) return;
+  const bool producer = threadIdx.x >= 256;
+#define KGDET_NTP_ROLE(DXV)                                                                                                  \
+  do {                                                                                                                       \
+    if (producer) conv_ntp_role<TAPS, DXV, true>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin,   \
+                                                 unit, smem);                                                               \
+    else conv_ntp_role<TAPS, 0, false>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem); \
+  } while (0)
+  if (TAPS == 9) {
+    const int tile = unit % (n_mt * n_nt), nt = tile / n_mt;
+    const int dx = ((nt * kTN) / Cin) % 3 - 1;   // uniform: one tap per tile
+    if (dx < 0) KGDET_NTP_ROLE(-1);
+    else if (dx == 0) KGDET_NTP_ROLE(0);
+    else KGDET_NTP_ROLE(1);
+  } else {
+    KGDET_NTP_ROLE(0);
+  }
+#undef KGDET_NTP_ROLE
 }
 
 namespace {
@@ -1359,6 +1598,29 @@ int nt_splits(int tiles, int total_stages) {
   if (splits > most) splits = most;
   if (splits > 128) splits = 128;
   return splits < 1 ? 1 : splits;
+}
+
+// launch shape of conv_nt8: XCD-contiguous unit order (KGDET_NT_XCD=0: workgroup b = unit b, the order up to round 3)
+bool nt_xcd() {
+  static const bool on = [] { const char *e = getenv("KGDET_NT_XCD"); return !e || atoi(e) != 0; }();   // A/B switch
+  return on;
+}
+int nt_units(int units) { return nt_xcd() ? units : 0; }
+int nt_grid(int units) { return nt_xcd() ? (units + 7) / 8 * 8 : units; }
+
+// conv_ntp (producer / consumer waves) instead of conv_nt8; KGDET_NT_PC=0: the kernel up to round 3 (A/B)
+bool ntp_on() {
+  static const bool on = [] { const char *e = getenv("KGDET_NT_PC"); return !e || atoi(e) != 0; }();
+  return on;
+}
+int ntp_attr() {
+  static thread_local bool set = false;
+  if (!set) {
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv_ntp<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLds));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv_ntp<9>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLds));
+    set = true;
+  }
+  return KGDET_OK;
 }
 
 // K parts of the NN kernel: only when the tiles alone leave most CUs idle
@@ -1742,9 +2004,17 @@ static int conv1x1_grad_weight_impl(const float *grad_y, const float *x, float *
   const int splits = nt_splits(tiles, total);
   const int per = (total + splits - 1) / splits;
   KGDET_CHECK_SHAPE(((long long)O * C) % 2 == 0, "O*C must be even");
-  hipLaunchKernelGGL(conv_nt8<1>, dim3(tiles * splits), dim3(kNNThreads), 0, (hipStream_t)stream, grad_y, x,
-                     (float *)workspace, O, C, (int)HW, (int)B, n_mt, n_nt, spi, per, 1, (int)HW, 0);
-  KGDET_CHECK_LAUNCH("conv_nt8<1>");
+  if (ntp_on() && (long long)(O > C ? O : C) * HW < (1ll << 31)) {
+    if (int rc = ntp_attr()) return rc;
+    const int spi32 = (int)((HW + kPK - 1) / kPK), total32 = (int)(B * spi32), per32 = (total32 + splits - 1) / splits;
+    hipLaunchKernelGGL(conv_ntp<1>, dim3((tiles * splits + 7) / 8 * 8), dim3(kPThreads), kPLds, (hipStream_t)stream, grad_y, x,
+                       (float *)workspace, O, C, (int)HW, (int)B, n_mt, n_nt, spi32, per32, 1, (int)HW, 0, tiles * splits);
+    KGDET_CHECK_LAUNCH("conv_ntp<1>");
+  } else {
+    hipLaunchKernelGGL(conv_nt8<1>, dim3(nt_grid(tiles * splits)), dim3(kNNThreads), 0, (hipStream_t)stream, grad_y, x,
+                       (float *)workspace, O, C, (int)HW, (int)B, n_mt, n_nt, spi, per, 1, (int)HW, 0, nt_units(tiles * splits));
+    KGDET_CHECK_LAUNCH("conv_nt8<1>");
+  }
   const long long n = (long long)O * C;
   if (fold) {
     hipLaunchKernelGGL(conv_wsum_fold<false>, dim3(O), dim3(256), 0, (hipStream_t)stream, (const float *)workspace, grad_w, C,
@@ -1828,9 +2098,17 @@ static int conv3x3_grad_weight_impl(const float *grad_y, const float *x, float *
   const int spi = (HW + kTK - 1) / kTK, total = (int)(B * spi);
   const int splits = nt_splits(tiles, total);
   const int per = (total + splits - 1) / splits;
-  hipLaunchKernelGGL(conv_nt8<9>, dim3(tiles * splits), dim3(kNNThreads), 0, (hipStream_t)stream, grad_y, x,
-                     (float *)workspace, O, 9 * C, HW, (int)B, n_mt, n_nt, spi, per, H, W, C);
-  KGDET_CHECK_LAUNCH("conv_nt8<9>");
+  if (ntp_on() && (long long)(O > C ? O : C) * HW < (1ll << 31)) {
+    if (int rc = ntp_attr()) return rc;
+    const int spi32 = (HW + kPK - 1) / kPK, total32 = (int)(B * spi32), per32 = (total32 + splits - 1) / splits;
+    hipLaunchKernelGGL(conv_ntp<9>, dim3((tiles * splits + 7) / 8 * 8), dim3(kPThreads), kPLds, (hipStream_t)stream, grad_y, x,
+                       (float *)workspace, O, 9 * C, HW, (int)B, n_mt, n_nt, spi32, per32, H, W, C, tiles * splits);
+    KGDET_CHECK_LAUNCH("conv_ntp<9>");
+  } else {
+    hipLaunchKernelGGL(conv_nt8<9>, dim3(nt_grid(tiles * splits)), dim3(kNNThreads), 0, (hipStream_t)stream, grad_y, x,
+                       (float *)workspace, O, 9 * C, HW, (int)B, n_mt, n_nt, spi, per, H, W, C, nt_units(tiles * splits));
+    KGDET_CHECK_LAUNCH("conv_nt8<9>");
+  }
   const long long n = (long long)O * C * 9;
   if (fold) {
     hipLaunchKernelGGL(conv_wsum_fold<true>, dim3(O), dim3(256), 0, (hipStream_t)stream, (const float *)workspace, grad_w, C, n,

@@ -5,10 +5,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from kgdet_amd import build_detector, configs, synthetic
 from kgdet_amd.dist import DistOptimizerHook
-cfg = configs.kgdet_r50_fpn()
+SERIAL = os.environ.get('CONFIG', 'kgdet') == 'serial'      # CONFIG=serial: BASELINE config 5 (five-level serial head, SGD)
+cfg = configs.reppoints_kp_r50_fpn() if SERIAL else configs.kgdet_r50_fpn()
 torch.manual_seed(0)
 model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
-opt = torch.optim.Adam(model.parameters(), lr=1e-5, fused=True)
+opt = (torch.optim.SGD(model.parameters(), lr=1e-5, momentum=0.9, fused=True) if SERIAL
+       else torch.optim.Adam(model.parameters(), lr=1e-5, fused=True))
 hook = DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2), overlap=True, bucket_size_mb=32)
 for shape in ((256, 320), (800, 1344)):
     batch = synthetic.make_batch(2, 'cuda', seed=0, img_shape=(shape[0], shape[1], 3), pad_shape=(shape[0], shape[1], 3))
