@@ -1361,7 +1361,7 @@ constexpr int kPPart = 2 * kPKS;                // one part (hi / lo) of one ope
 constexpr int kPOperand = 2 * kPPart;
 constexpr int kPStage = 2 * kPOperand;          // A + B = 33792 bytes
 constexpr int kPThreads = 512;
-constexpr int kPLds = 2 * kPStage;
+constexpr int kPLds = 2 * kPStage;       // (a request padded beyond 80 KB -- never two workgroups on a CU -- changed nothing)
 
 template <int TAPS, int DX, bool PRODUCER>
 __device__ __forceinline__ void conv_ntp_role(const float *__restrict__ a, const float *__restrict__ bm,
@@ -1549,8 +1549,8 @@ __global__ __launch_bounds__(kPThreads, 1) void conv_ntp(const float *__restrict
                                                          int n_nt, int stages_per_image, int per, int H, int W, int Cin,
                                                          int units) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int unit = xcd_tile(blockIdx.x, units);
-  if (unit >= units) return;
+  const int unit = units > 0 ? xcd_tile(blockIdx.x, units) : (int)blockIdx.x;      // (as conv_nt8)
+  if (units > 0 && unit >= units) return;
   const bool producer = threadIdx.x >= 256;
 #define KGDET_NTP_ROLE(DXV)                                                                                                  \
   do {                                                                                                                       \
@@ -1609,15 +1609,20 @@ int nt_units(int units) { return nt_xcd() ? units : 0; }
 int nt_grid(int units) { return nt_xcd() ? (units + 7) / 8 * 8 : units; }
 
 // conv_ntp (producer / consumer waves) instead of conv_nt8; KGDET_NT_PC=0: the kernel up to round 3 (A/B)
-bool ntp_on() {
-  static const bool on = [] { const char *e = getenv("KGDET_NT_PC"); return !e || atoi(e) != 0; }();
-  return on;
+// Measured (tools/bench_conv3x3_wgrad.py / bench_conv1x1_wgrad.py, with the sum pass): 3x3 76.2 / 81.7 / 99.9 / 43.2 us ->
+// 66.0 / 70.6 / 89.4 / 41.4 us; 1x1 3-5 % SLOWER (31.7 -> 33.4 us ...: ~17 long stages per workgroup, fill and drain weigh
+// more than the leaner stage) -- so the 3x3 problems take conv_ntp and the 1x1 problems stay on conv_nt8.  KGDET_NT_PC=0 / 2:
+// neither / both.
+bool ntp_on(int taps) {
+  static const int mode = [] { const char *e = getenv("KGDET_NT_PC"); return e ? atoi(e) : 1; }();
+  return mode == 2 || (mode == 1 && taps == 9);
 }
+int ntp_lds() { return kPLds; }
 int ntp_attr() {
   static thread_local bool set = false;
   if (!set) {
-    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv_ntp<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLds));
-    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv_ntp<9>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLds));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv_ntp<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ntp_lds()));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv_ntp<9>, hipFuncAttributeMaxDynamicSharedMemorySize, ntp_lds()));
     set = true;
   }
   return KGDET_OK;
@@ -2004,11 +2009,11 @@ static int conv1x1_grad_weight_impl(const float *grad_y, const float *x, float *
   const int splits = nt_splits(tiles, total);
   const int per = (total + splits - 1) / splits;
   KGDET_CHECK_SHAPE(((long long)O * C) % 2 == 0, "O*C must be even");
-  if (ntp_on() && (long long)(O > C ? O : C) * HW < (1ll << 31)) {
+  if (ntp_on(1) && (long long)(O > C ? O : C) * HW < (1ll << 31)) {
     if (int rc = ntp_attr()) return rc;
     const int spi32 = (int)((HW + kPK - 1) / kPK), total32 = (int)(B * spi32), per32 = (total32 + splits - 1) / splits;
-    hipLaunchKernelGGL(conv_ntp<1>, dim3((tiles * splits + 7) / 8 * 8), dim3(kPThreads), kPLds, (hipStream_t)stream, grad_y, x,
-                       (float *)workspace, O, C, (int)HW, (int)B, n_mt, n_nt, spi32, per32, 1, (int)HW, 0, tiles * splits);
+    hipLaunchKernelGGL(conv_ntp<1>, dim3(nt_grid(tiles * splits)), dim3(kPThreads), ntp_lds(), (hipStream_t)stream, grad_y, x,
+                       (float *)workspace, O, C, (int)HW, (int)B, n_mt, n_nt, spi32, per32, 1, (int)HW, 0, nt_units(tiles * splits));
     KGDET_CHECK_LAUNCH("conv_ntp<1>");
   } else {
     hipLaunchKernelGGL(conv_nt8<1>, dim3(nt_grid(tiles * splits)), dim3(kNNThreads), 0, (hipStream_t)stream, grad_y, x,
@@ -2098,11 +2103,11 @@ static int conv3x3_grad_weight_impl(const float *grad_y, const float *x, float *
   const int spi = (HW + kTK - 1) / kTK, total = (int)(B * spi);
   const int splits = nt_splits(tiles, total);
   const int per = (total + splits - 1) / splits;
-  if (ntp_on() && (long long)(O > C ? O : C) * HW < (1ll << 31)) {
+  if (ntp_on(9) && (long long)(O > C ? O : C) * HW < (1ll << 31)) {
     if (int rc = ntp_attr()) return rc;
     const int spi32 = (HW + kPK - 1) / kPK, total32 = (int)(B * spi32), per32 = (total32 + splits - 1) / splits;
-    hipLaunchKernelGGL(conv_ntp<9>, dim3((tiles * splits + 7) / 8 * 8), dim3(kPThreads), kPLds, (hipStream_t)stream, grad_y, x,
-                       (float *)workspace, O, 9 * C, HW, (int)B, n_mt, n_nt, spi32, per32, H, W, C, tiles * splits);
+    hipLaunchKernelGGL(conv_ntp<9>, dim3(nt_grid(tiles * splits)), dim3(kPThreads), ntp_lds(), (hipStream_t)stream, grad_y, x,
+                       (float *)workspace, O, 9 * C, HW, (int)B, n_mt, n_nt, spi32, per32, H, W, C, nt_units(tiles * splits));
     KGDET_CHECK_LAUNCH("conv_ntp<9>");
   } else {
     hipLaunchKernelGGL(conv_nt8<9>, dim3(nt_grid(tiles * splits)), dim3(kNNThreads), 0, (hipStream_t)stream, grad_y, x,
