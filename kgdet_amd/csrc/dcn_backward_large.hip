@@ -14,9 +14,12 @@
 //   * grad_offset: one workgroup per output pixel, a thread per channel: colT row x the four corner rows of x^T
 //     (NHWC copy) x the derivative weights, block-reduced per tap;
 //   * grad_input: the scatter turned around with an inverse index.  Every (image, tap, pixel, valid corner) becomes an
-//     entry keyed by its input cell; a STABLE radix sort (hipCUB) groups the entries by cell in enumeration order, so
-//     every cell's sum has a fixed order; one workgroup per 32 cells, a thread per channel, adds w * colT[p][t*C + c].
-#include <hipcub/hipcub.hpp>
+//     entry of its input cell's list: counted with integer atomics, storage handed out by a bump allocation, entries dropped
+//     in (slot order arbitrary) and every list then RANKED by its entries' (tap, pixel) numbers -- unique inside a cell -- so
+//     that every cell's sum has the enumeration order whatever order the atomics served the slots in (rounds 2-3: a stable
+//     hipCUB radix sort of all entries; round 4: these four small kernels, no third-party primitive on the path); one
+//     workgroup per 16 cells, a thread per channel, adds w * colT[p][t*C + c].
+#include <limits.h>
 #include <type_traits>
 
 #include "common.h"
@@ -71,9 +74,13 @@ __global__ __launch_bounds__(256) void large_permute_weight(const float *__restr
   }
 }
 
-// one thread per (image, tap, output pixel): its four corners as (cell key, (tap*P + pixel, weight)) entries
-__global__ __launch_bounds__(256) void large_build_entries(const DcnProblem p, unsigned *__restrict__ keys,
-                                                           unsigned long long *__restrict__ vals) {
+// one thread per (image, tap, output pixel): its four corners are entries (((tap*P + pixel) * 4 + corner) << 32 | weight) of
+// their cells' lists.
+// FILL = false: count (cnt[cell]); FILL = true: drop the entries into the lists (cnt serves as the cursor; slot order arbitrary)
+template <bool FILL>
+__global__ __launch_bounds__(256) void large_cell_entries(const DcnProblem p, int *__restrict__ cnt,
+                                                          const int *__restrict__ start,
+                                                          unsigned long long *__restrict__ vals) {
   const long long n = (long long)p.N * p.K * p.HoWo;
   const int HW = p.H * p.W;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -87,26 +94,93 @@ __global__ __launch_bounds__(256) void large_build_entries(const DcnProblem p, u
     TapGeom geo;
     make_tap(y, x, p.H, p.W, true, m, tap, geo);   // (v2: the modulation mask rides on the corner weights; m = 1 for v1)
     const int valid[4] = {geo.va, geo.vb, geo.vc, geo.vd};
-    const unsigned long long src = (unsigned long long)((unsigned)(t * p.HoWo + hw)) << 32;
+    const unsigned long long src = (unsigned long long)((unsigned)(t * p.HoWo + hw)) << 34;   // key = (tap, pixel, corner): unique
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      keys[i * 4 + e] = valid[e] ? (unsigned)(b * HW + tap.o[e]) : 0xffffffffu;
-      vals[i * 4 + e] = src | __float_as_uint(tap.w[e]);
+      if (!valid[e]) continue;
+      const int cell = b * HW + tap.o[e];
+      if constexpr (FILL)
+        vals[start[cell] + atomicAdd(cnt + cell, 1)] = src | ((unsigned long long)e << 32) | __float_as_uint(tap.w[e]);
+      else atomicAdd(cnt + cell, 1);
     }
   }
 }
 
-// row_ptr[cell] = first sorted entry with key >= cell, cells 0 .. n_cells (inclusive)
-__global__ __launch_bounds__(256) void large_row_ptr(const unsigned *__restrict__ keys, long long n_entries, int n_cells,
-                                                     int *__restrict__ row_ptr) {
-  const int cell = blockIdx.x * 256 + threadIdx.x;
-  if (cell > n_cells) return;
-  long long lo = 0, hi = n_entries;
-  while (lo < hi) {
-    const long long mid = (lo + hi) >> 1;
-    if (keys[mid] < (unsigned)cell) lo = mid + 1; else hi = mid;
+// storage for every cell's list (wave-aggregated bump allocation: where a list lies is arbitrary, what it will hold is not);
+// the counters are reset to serve as fill cursors
+__global__ __launch_bounds__(256) void large_cell_alloc(int *__restrict__ cnt, int *__restrict__ start, int *__restrict__ total,
+                                                        int n_cells) {
+  const int cell = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  const int c = cell < n_cells ? cnt[cell] : 0;
+  int incl = c;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
   }
-  row_ptr[cell] = (int)lo;
+  const int wave_sum = __shfl(incl, 63);
+  int base = 0;
+  if (lane == 63 && wave_sum > 0) base = atomicAdd(total, wave_sum);
+  base = __shfl(base, 63);
+  if (cell < n_cells) {
+    start[cell] = base + incl - c;
+    cnt[cell] = 0;
+  }
+}
+
+// wave = cell: its entries in slot order -> in (tap, pixel, corner) order.  The keys (upper halves) are unique, so an entry's
+// place is the number of smaller keys: by lane reads up to 64
+// entries, beyond through an LDS copy of the keys read as broadcasts.
+constexpr int kLargeSortChunk = 1024;
+__global__ __launch_bounds__(256) void large_cell_sort(const int *__restrict__ start, const int *__restrict__ len,
+                                                       const unsigned long long *__restrict__ in,
+                                                       unsigned long long *__restrict__ out, int n_cells) {
+  __shared__ __attribute__((aligned(16))) unsigned keys[4][kLargeSortChunk];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int cell = blockIdx.x * 4 + wave;
+  if (cell >= n_cells) return;
+  const int n = __builtin_amdgcn_readfirstlane(len[cell]);
+  if (n == 0) return;
+  const int base = __builtin_amdgcn_readfirstlane(start[cell]);
+  unsigned *kw = keys[wave];
+  constexpr unsigned long long kNone = ~0ull;
+  if (n <= 64) {
+    const unsigned long long e = lane < n ? in[base + lane] : kNone;
+    const unsigned key = (unsigned)(e >> 32);
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += (unsigned)__shfl((int)key, j) < key ? 1 : 0;
+    if (lane < n) out[base + rank] = e;
+    return;
+  }
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    unsigned long long e[4];
+    int rank[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = i0 + u * 64 + lane;
+      e[u] = idx < n ? in[base + idx] : kNone;
+    }
+    for (int c0 = 0; c0 < n; c0 += kLargeSortChunk) {
+      if (n > kLargeSortChunk || i0 == 0) {
+        __builtin_amdgcn_wave_barrier();
+        for (int j = lane; j < kLargeSortChunk; j += 64) kw[j] = c0 + j < n ? (unsigned)(in[base + c0 + j] >> 32) : 0xffffffffu;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+      }
+      const int m4 = (min(kLargeSortChunk, n - c0) + 3) & ~3;
+      for (int j = 0; j < m4; j += 4) {
+        const uint4 k4 = *reinterpret_cast<const uint4 *>(kw + j);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned key = (unsigned)(e[u] >> 32);
+          rank[u] += (k4.x < key ? 1 : 0) + (k4.y < key ? 1 : 0) + (k4.z < key ? 1 : 0) + (k4.w < key ? 1 : 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u * 64 + lane < n) out[base + rank[u]] = e[u];
+  }
 }
 
 // grad_input[b][c][q] = sum over the entries of cell (b, q), in sorted (= enumeration) order, of w * colT[b][p][t*C + c]
@@ -115,7 +189,8 @@ __global__ __launch_bounds__(256) void large_row_ptr(const unsigned *__restrict_
 // per workgroup keep the LDS tile at 16 KB, so eight workgroups share a CU (32 cells: four), and eight loads are in flight
 // per thread -- 319 -> ~190 us on [2, 256, 100, 168] 3x3.  The adds keep the sorted order whatever the batch size.
 constexpr int kGatherCells = 16;
-__global__ __launch_bounds__(256) void large_gather_input(const float *__restrict__ colT, const int *__restrict__ row_ptr,
+__global__ __launch_bounds__(256) void large_gather_input(const float *__restrict__ colT, const int *__restrict__ start,
+                                                          const int *__restrict__ len,
                                                           const unsigned long long *__restrict__ vals,
                                                           float *__restrict__ grad_input, int C, int K, int HW, int P) {
   __shared__ float tile[kGatherCells][257];
@@ -130,7 +205,7 @@ __global__ __launch_bounds__(256) void large_gather_input(const float *__restric
 #pragma unroll
     for (int u = 0; u < N; ++u) {
       const unsigned long long val = vals[e + u];
-      const unsigned tp = (unsigned)(val >> 32);
+      const unsigned tp = (unsigned)(val >> 34);
       const unsigned t = tp / (unsigned)P, px = tp - t * (unsigned)P;
       w[u] = __uint_as_float((unsigned)val);
       v[u] = base[(long long)px * KC + (long long)t * C];
@@ -142,7 +217,7 @@ __global__ __launch_bounds__(256) void large_gather_input(const float *__restric
     const int q = q0 + r;
     float acc = 0.0f;
     if (q < HW) {
-      const int e0 = row_ptr[b * HW + q], e1 = row_ptr[b * HW + q + 1];
+      const int e0 = start[b * HW + q], e1 = e0 + len[b * HW + q];
       int e = e0;
       for (; e + 8 <= e1; e += 8) batch(e, std::integral_constant<int, 8>{}, acc);
       if (e + 4 <= e1) { batch(e, std::integral_constant<int, 4>{}, acc); e += 4; }
@@ -221,7 +296,7 @@ __global__ __launch_bounds__(256) void large_grad_offset(const DcnProblem p, con
 }
 
 struct LargePlan {
-  size_t gT, xT, wp, colT, packed, conv_ws, keys, vals, cub, row_ptr, total;
+  size_t gT, xT, wp, colT, packed, conv_ws, vals, cells, total;
   long long n_entries;
 };
 
@@ -236,15 +311,9 @@ LargePlan large_plan(const DcnProblem &p) {
   L.colT = al((size_t)p.N * P * KC * 4);
   L.packed = al(kgdet_conv_packed_bytes((int)P, p.Og, 1));
   L.conv_ws = al(kgdet_conv_apply_workspace_bytes(1, (int)P, p.Og, 1, (int)KC, 1, 1));
-  L.keys = al((size_t)L.n_entries * 4);
-  L.vals = al((size_t)L.n_entries * 8);
-  size_t temp = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const unsigned *)nullptr, (unsigned *)nullptr,
-                                     (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
-                                     (int)L.n_entries, 0, 32, (hipStream_t)0);
-  L.cub = al(temp);
-  L.row_ptr = al((size_t)(p.N * HW + 1) * 4);
-  L.total = L.gT + L.xT + L.wp + L.colT + L.packed + L.conv_ws + 2 * L.keys + 2 * L.vals + L.cub + L.row_ptr;
+  L.vals = al((size_t)L.n_entries * 8);                       // twice: slot order, sorted
+  L.cells = al((size_t)(p.N * HW + 64) * 4);                  // twice: counters / cursors (+ the allocation counter), starts
+  L.total = L.gT + L.xT + L.wp + L.colT + L.packed + L.conv_ws + 2 * L.vals + 2 * L.cells;
   return L;
 }
 
@@ -256,7 +325,7 @@ bool dcn_bwd_large_ok(const DcnProblem &p, bool has_mask, int groups) {
   (void)has_mask;
   return groups == 1 && p.DG == 1 && p.Og % 16 == 0 && ((long long)p.K * p.C_total) % 2 == 0 &&
          p.K <= kLargeMaxK && n_entries < (1LL << 31) && (long long)p.N * p.H * p.W < (1LL << 31) - 2 &&
-         (long long)p.K * p.HoWo < (1LL << 32);
+         (long long)p.K * p.HoWo < (1LL << 30);
 }
 
 size_t dcn_bwd_large_workspace_bytes(const DcnProblem &p) { return large_plan(p).total; }
@@ -278,12 +347,10 @@ int dcn_bwd_large(const DcnProblem &p, const float *grad_output, int out_channel
   float *colT = (float *)w8; w8 += L.colT;
   void *packed = w8; w8 += L.packed;
   void *conv_ws = w8; w8 += L.conv_ws;
-  unsigned *keys_a = (unsigned *)w8; w8 += L.keys;
-  unsigned *keys_b = (unsigned *)w8; w8 += L.keys;
   unsigned long long *vals_a = (unsigned long long *)w8; w8 += L.vals;
   unsigned long long *vals_b = (unsigned long long *)w8; w8 += L.vals;
-  void *cub_tmp = w8; w8 += L.cub;
-  int *row_ptr = (int *)w8;
+  int *cell_cnt = (int *)w8; w8 += L.cells;
+  int *cell_start = (int *)w8;
   const int C = p.C_total, O = p.Og, K = p.K;
   const long long P = p.HoWo, HW = (long long)p.H * p.W, KC = (long long)K * C;
   const int O_total = out_channels_total > 0 ? out_channels_total : O;
@@ -302,19 +369,18 @@ int dcn_bwd_large(const DcnProblem &p, const float *grad_output, int out_channel
                                            (int)KC, 1, 1, conv_ws, L.conv_ws, stream))
       return rc;
   }
-  // inverse index
-  hipLaunchKernelGGL(large_build_entries, dim3(2048), dim3(256), 0, st, p, keys_a, vals_a);
-  size_t temp = L.cub;
-  if (hipcub::DeviceRadixSort::SortPairs(cub_tmp, temp, keys_a, keys_b, vals_a, vals_b, (int)L.n_entries, 0, 32, st) !=
-      hipSuccess) {
-    set_error("hipcub radix sort failed");
-    return KGDET_E_HIP;
-  }
+  // inverse index: per-cell lists, ranked into enumeration order
   const int n_cells = (int)(p.N * HW);
-  hipLaunchKernelGGL(large_row_ptr, dim3((n_cells + 1 + 255) / 256), dim3(256), 0, st, keys_b, L.n_entries, n_cells,
-                     row_ptr);
+  int *cell_total = cell_cnt + n_cells;
+  KGDET_HIP_TRY(hipMemsetAsync(cell_cnt, 0, (size_t)(n_cells + 64) * sizeof(int), st));
+  hipLaunchKernelGGL(large_cell_entries<false>, dim3(2048), dim3(256), 0, st, p, cell_cnt, (const int *)nullptr,
+                     (unsigned long long *)nullptr);
+  hipLaunchKernelGGL(large_cell_alloc, dim3((n_cells + 255) / 256), dim3(256), 0, st, cell_cnt, cell_start, cell_total, n_cells);
+  hipLaunchKernelGGL(large_cell_entries<true>, dim3(2048), dim3(256), 0, st, p, cell_cnt, (const int *)cell_start, vals_a);
+  hipLaunchKernelGGL(large_cell_sort, dim3((n_cells + 3) / 4), dim3(256), 0, st, (const int *)cell_start, (const int *)cell_cnt,
+                     (const unsigned long long *)vals_a, vals_b, n_cells);
   hipLaunchKernelGGL(large_gather_input, dim3((unsigned)((HW + kGatherCells - 1) / kGatherCells), p.N, (C + 255) / 256), dim3(256), 0, st, colT,
-                     row_ptr, vals_b, grad_input, C, K, (int)HW, (int)P);
+                     (const int *)cell_start, (const int *)cell_cnt, vals_b, grad_input, C, K, (int)HW, (int)P);
   hipLaunchKernelGGL(large_grad_offset, dim3((unsigned)P, p.N), dim3(256), 0, st, p, colT, xT, grad_offset,
                      p.mask ? grad_mask : nullptr);
   KGDET_CHECK_LAUNCH("dcn_bwd_large");
