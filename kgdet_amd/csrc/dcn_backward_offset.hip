@@ -149,12 +149,21 @@ __device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__res
       uint4 off;             // consumers: the record of (pixel, tap)
       f32x4 wy, wx, wm;
     };
+    // The three register sets live across the segments (a segment = the taps of one 16-channel chunk): the last bodies of a
+    // segment put the FIRST three stages of the next one in flight instead of re-reading their own last stage, so a segment
+    // does not start with a bare round trip to the weight image (21.7 MB per map, streamed once per pixel tile: it is served
+    // from beyond the XCD's L2) and the records -- 16 times per tile for a 3x3 problem with its nine stages per segment.
+    Regs R0, R1, R2;
+    bool prefetched = false;
 
     int s = s_begin;
     int c16 = s / K;
     int t0 = s - c16 * K;
     while (s < s_end) {
       const int n = min(K - t0, s_end - s);
+      const int n_pad = (n + 2) / 3 * 3;                         // bodies the loop below runs (three per round)
+      const bool has_next = s + n < s_end;
+      const int n_next = has_next ? min(K, s_end - (s + n)) : 1;
       // (buffer loads -- SGPR resource, 32-bit lane offset, scalar stage offset: no vector address arithmetic per stage;
       // VALU instructions beside the MFMA waves cost MFMA issue slots, tools/microbench/mfma_valu.hip)
       const dcn_rsrc_t rec_rs = dcn_make_rsrc(p.taps);
@@ -172,15 +181,21 @@ __device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__res
         const int c = idx & 15, khalf = (idx >> 4) & 1, o16 = idx >> 5;
         a_lane[r] = (unsigned)(min(o16, n_o16 - 1) * K) * (unsigned)(2 * kAPart) + khalf * (kTileM * 16) + (c_in + c) * 16;
       }
+      // the same for the next segment's chunk (its stages start at tap 0)
+      const int ct_n = ((c16 + 1 + p.c16_base) * kChunk) / kTileM, c_in_n = ((c16 + 1 + p.c16_base) * kChunk) % kTileM;
+      const unsigned wq_base_n = (unsigned)(ct_n * n_o16 * K) * (unsigned)(2 * kAPart);
+      const unsigned a_lane_d = (unsigned)((c_in_n - c_in) * 16);      // (added modulo 2^32: c_in_n may be below c_in)
 
       auto issue = [&](int j, Regs &R) {
-        const unsigned t = (unsigned)(t0 + min(j, n - 1));
+        const bool nxt = has_next && j >= n_pad;                       // (uniform)
+        const unsigned t = nxt ? (unsigned)min(j - n_pad, n_next - 1) : (unsigned)(t0 + min(j, n - 1));
         if constexpr (PRODUCER) {
+          const unsigned base = nxt ? wq_base_n : wq_base, dl = nxt ? a_lane_d : 0u;
 #pragma unroll
           for (int r = 0; r < 2; ++r) {
 #pragma unroll
             for (int part = 0; part < PARTS; ++part)
-              R.a[part][r] = __builtin_bit_cast(f32x4, dcn_buf_b128(wq_rs, a_lane[r], wq_base + t * (2 * kAPart) + part * kAPart));
+              R.a[part][r] = __builtin_bit_cast(f32x4, dcn_buf_b128(wq_rs, a_lane[r] + dl, base + t * (2 * kAPart) + part * kAPart));
           }
         } else {
           const unsigned so = rec_seg + t * (unsigned)(HoWo * RS * 16);
@@ -284,11 +299,13 @@ __device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__res
         }
       };
 
-      Regs R0, R1, R2;
       __syncthreads();  // the previous segment's readers of plane / A are done; offs_acc zeroing is visible
-      issue(0, R0);
-      issue(1, R1);
-      issue(2, R2);
+      if (!prefetched) {
+        issue(0, R0);
+        issue(1, R1);
+        issue(2, R2);
+      }
+      prefetched = has_next;
       load_plane();
       commit_weights(0, R0);
       __syncthreads();
