@@ -137,6 +137,34 @@ __device__ __forceinline__ long long list_base(const kgdet_psroi_shape &s, int b
   return (((long long)batch * classes + cls) * G * G + k) * s.H * s.W;
 }
 
+// This lane's slot in list L (live lanes only): lanes of a wave that name the same list share ONE atomic and take consecutive
+// slots (up to four distinct lists per call are served that way, the remaining lanes one atomic each).  A tiny RoI puts
+// hundreds of samples on one pixel: without this its corners serialise on a single counter.  Called by ALL lanes of the wave.
+__device__ __forceinline__ int list_take(int *__restrict__ cnt, int L, bool live) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int slot = 0;
+  bool pending = live;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const unsigned long long act = __ballot(pending);
+    if (act == 0ull) break;                                   // (uniform)
+    const int leader = __ffsll((long long)act) - 1;
+    const int Lf = __shfl(L, leader);
+    const bool mine = pending && L == Lf;
+    const unsigned long long m = __ballot(mine);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(cnt + Lf, __popcll(m));
+    base = __shfl(base, leader);
+    if (mine) {
+      slot = base + __popcll(m & below);
+      pending = false;
+    }
+  }
+  if (pending) slot = atomicAdd(cnt + L, 1);
+  return slot;
+}
+
 }  // namespace
 
 // data [B, C, H, W] -> dataT[b][k][pixel][ctop] with input channel c = ctop * G*G + k (k = group cell): lanes = output
@@ -323,18 +351,14 @@ __global__ __launch_bounds__(kThreads) void psroi_gather(const kgdet_psroi_shape
   }
 }
 
-// Backward preparation.  Block = RoI: (1) the sample records of every offset class, recs[n][class][bin][sample], and
-// the bounding box of every valid sample corner over all classes (bbox[n] = {xmin, xmax, ymin, ymax}; xmax < 0: the
-// RoI touches nothing), (2) diffT[n][bin][ctop] = grad_out / count (0 where count <= 0), transposed through LDS so that
-// both sides are coalesced.
+// Backward preparation.  Block = RoI: the sample records of every offset class, recs[n][class][bin][sample], the
+// bounding box of every valid sample corner over all classes (bbox[n] = {xmin, xmax, ymin, ymax}; xmax < 0: the
+// RoI touches nothing) and, for grad_data's lists, the number of corners per (image, class, group cell, pixel).
 __global__ __launch_bounds__(kThreads) void psroi_prepare(const kgdet_psroi_shape s, const float *__restrict__ rois,
-                                                          const float *__restrict__ trans,
-                                                          const float *__restrict__ grad_out,
-                                                          const float *__restrict__ count, int4 *__restrict__ bbox,
-                                                          float *__restrict__ diffT, Rec *__restrict__ recs_out,
-                                                          int classes, int *__restrict__ list_cnt /*nullable*/) {
+                                                          const float *__restrict__ trans, int4 *__restrict__ bbox,
+                                                          Rec *__restrict__ recs_out, int classes,
+                                                          int *__restrict__ list_cnt /*nullable*/) {
   __shared__ int bb[4];
-  __shared__ float tile[64 * 65];
   const int n = blockIdx.x, tid = threadIdx.x;
   const int P = s.pooled_size, S = s.sample_per_part, PP = P * P, SS = S * S;
   const Roi r = roi_setup(rois + 5 * n, s.spatial_scale, P, S);
@@ -342,18 +366,22 @@ __global__ __launch_bounds__(kThreads) void psroi_prepare(const kgdet_psroi_shap
   __syncthreads();
   if (r.batch >= 0 && r.batch < s.B) {      // (other RoIs are never visited: their records stay unwritten)
     int xmin = INT_MAX, xmax = -1, ymin = INT_MAX, ymax = -1;
-    for (int i = tid; i < classes * PP * SS; i += kThreads) {
+    const int total = classes * PP * SS;
+    for (int i0 = 0; i0 < total; i0 += kThreads) {       // (uniform trip count: list_take is a wave-wide operation)
+      const int i = min(i0 + tid, total - 1);
+      const bool in_range = i0 + tid < total;
       const int cls = i / (PP * SS), j = i - cls * PP * SS;
       const int bin = j / SS, si = j - bin * SS;
       const int ph = bin / P, pw = bin - ph * P, ih = si / S, iw = si - ih * S;
       const Rec q = make_record(s, r, n, cls, ph, pw, ih, iw, trans);
-      recs_out[(long long)n * classes * PP * SS + i] = q;
-      if (q.xa < 0) continue;
+      if (in_range) recs_out[(long long)n * classes * PP * SS + i] = q;
+      const bool live = in_range && q.xa >= 0;
       if (list_cnt) {     // entries of the per-pixel contribution lists (psroi_list_*): one per corner
-        int *lc = list_cnt + list_base(s, r.batch, classes, cls, ph, pw);
-        atomicAdd(lc + q.ya * s.W + q.xa, 1); atomicAdd(lc + q.yb * s.W + q.xa, 1);
-        atomicAdd(lc + q.ya * s.W + q.xb, 1); atomicAdd(lc + q.yb * s.W + q.xb, 1);
+        const int lb = (int)list_base(s, r.batch, classes, cls, ph, pw);
+        list_take(list_cnt, lb + q.ya * s.W + q.xa, live); list_take(list_cnt, lb + q.yb * s.W + q.xa, live);
+        list_take(list_cnt, lb + q.ya * s.W + q.xb, live); list_take(list_cnt, lb + q.yb * s.W + q.xb, live);
       }
+      if (!live) continue;
       xmin = min(xmin, (int)q.xa); xmax = max(xmax, (int)q.xb);
       ymin = min(ymin, (int)q.ya); ymax = max(ymax, (int)q.yb);
     }
@@ -363,27 +391,35 @@ __global__ __launch_bounds__(kThreads) void psroi_prepare(const kgdet_psroi_shap
   }
   __syncthreads();
   if (tid == 0) bbox[n] = make_int4(bb[0], bb[1], bb[2], bb[3]);
-  // transpose [out_dim][PP] -> [PP][out_dim] in 64 x 64 tiles
+}
+
+// diffT[n][bin][ctop] = grad_out / count (0 where count <= 0), transposed through LDS so that both sides are coalesced.
+// Block = (RoI, 64 output channels): [64][PP] -> [PP][64] in 64 x 64 tiles.  (Round 3 did this inside psroi_prepare, one block per
+// RoI walking the channel tiles in sequence: 58 us for 77 MB; 4 x as many blocks in flight: see profiles/r04_psroi.md.)
+__global__ __launch_bounds__(kThreads) void psroi_quotient_t(const kgdet_psroi_shape s, const float *__restrict__ grad_out,
+                                                             const float *__restrict__ count, float *__restrict__ diffT) {
+  __shared__ float tile[64 * 65];
+  const int n = blockIdx.x, c0 = blockIdx.y * 64, tid = threadIdx.x;
+  const int PP = s.pooled_size * s.pooled_size;
   const long long base = (long long)n * s.out_dim * PP;
-  for (int c0 = 0; c0 < s.out_dim; c0 += 64)
-    for (int b0 = 0; b0 < PP; b0 += 64) {
-      __syncthreads();
-      for (int e = tid; e < 64 * 64; e += kThreads) {
-        const int c = e >> 6, b = e & 63;
-        float v = 0.f;
-        if (c0 + c < s.out_dim && b0 + b < PP) {
-          const long long idx = base + (long long)(c0 + c) * PP + b0 + b;
-          const float cn = count[idx];
-          v = cn > 0.f ? grad_out[idx] / cn : 0.f;
-        }
-        tile[c * 65 + b] = v;
+  for (int b0 = 0; b0 < PP; b0 += 64) {
+    __syncthreads();
+    for (int e = tid; e < 64 * 64; e += kThreads) {
+      const int c = e >> 6, b = e & 63;
+      float v = 0.f;
+      if (c0 + c < s.out_dim && b0 + b < PP) {
+        const long long idx = base + (long long)(c0 + c) * PP + b0 + b;
+        const float cn = count[idx];
+        v = cn > 0.f ? grad_out[idx] / cn : 0.f;
       }
-      __syncthreads();
-      for (int e = tid; e < 64 * 64; e += kThreads) {
-        const int b = e >> 6, c = e & 63;
-        if (c0 + c < s.out_dim && b0 + b < PP) diffT[base + (long long)(b0 + b) * s.out_dim + c0 + c] = tile[c * 65 + b];
-      }
+      tile[c * 65 + b] = v;
     }
+    __syncthreads();
+    for (int e = tid; e < 64 * 64; e += kThreads) {
+      const int b = e >> 6, c = e & 63;
+      if (c0 + c < s.out_dim && b0 + b < PP) diffT[base + (long long)(b0 + b) * s.out_dim + c0 + c] = tile[c * 65 + b];
+    }
+  }
 }
 
 // grad_data as a gather by output tile; block = ONE WAVE = (tile, 64-channel chunk, image); thread = input channel.
@@ -570,6 +606,8 @@ __global__ __launch_bounds__(kGdThreads) void psroi_grad_data(const kgdet_psroi_
 // adds w * diff in list order.  Exactly one writer per element: no atomics on floats, bit-repeatable, and the same bits as
 // the serial float32 evaluation (same products, same order).
 constexpr int kSortChunk = 1024;       // keys of a list a wave holds in LDS at a time
+constexpr int kWaveSortMax = 512;      // longest list the per-wave rank sort takes
+constexpr int kLongSortLds = 8192;     // entries psroi_list_sort_long sorts in LDS (64 KB); longer lists in place in global memory
 
 // storage for every list (wave-aggregated bump allocation), counters reset to serve as fill cursors
 __global__ __launch_bounds__(kThreads) void psroi_list_alloc(int *__restrict__ cnt, int *__restrict__ start,
@@ -598,26 +636,30 @@ __global__ __launch_bounds__(kThreads) void psroi_list_fill(const kgdet_psroi_sh
                                                             const Rec *__restrict__ recs, const int *__restrict__ start,
                                                             int *__restrict__ cursor, int2 *__restrict__ ent, int classes) {
   const int P = s.pooled_size, SS = s.sample_per_part * s.sample_per_part, nrec = P * P * SS;
-  const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
-  if (i >= (long long)s.R * classes * nrec) return;
+  const long long total = (long long)s.R * classes * nrec;
+  const long long i_raw = (long long)blockIdx.x * kThreads + threadIdx.x;
+  const long long i = i_raw < total ? i_raw : total - 1;            // (no early exits: list_take is a wave-wide operation)
   const int nc = (int)(i / nrec), rec = (int)(i - (long long)nc * nrec);
   const int n = nc / classes, cls = nc - n * classes;
   const int batch = (int)rois[5 * n];
-  if (batch < 0 || batch >= s.B) return;
-  const int4 v = reinterpret_cast<const int4 *>(recs)[i];
+  const bool roi_ok = batch >= 0 && batch < s.B;
+  const int4 v = roi_ok ? reinterpret_cast<const int4 *>(recs)[i] : make_int4(-1, -1, 0, 0);
   const int xa = (short)(v.x & 0xffff), xb = (short)(v.x >> 16), ya = (short)(v.y & 0xffff), yb = (short)(v.y >> 16);
-  if (xa < 0) return;
+  const bool live = i_raw < total && roi_ok && xa >= 0;
   const float fx = __int_as_float(v.z), fy = __int_as_float(v.w);
   const int bin = rec / SS, ph = bin / P, pw = bin - ph * P;
-  const long long lb = list_base(s, batch, classes, cls, ph, pw);
+  const int lb = live ? (int)list_base(s, batch, classes, cls, ph, pw) : 0;
   const int seq = (int)i * 4;
   // the reference's four atomicAdds (:236-245), their order and their weight expressions
-  const long long L0 = lb + ya * s.W + xa, L1 = lb + yb * s.W + xa, L2 = lb + ya * s.W + xb, L3 = lb + yb * s.W + xb;
+  const int L0 = lb + ya * s.W + xa, L1 = lb + yb * s.W + xa, L2 = lb + ya * s.W + xb, L3 = lb + yb * s.W + xb;
   const float w0 = (1 - fx) * (1 - fy), w1 = (1 - fx) * fy, w2 = fx * (1 - fy), w3 = fx * fy;
-  ent[start[L0] + atomicAdd(cursor + L0, 1)] = make_int2(seq, __float_as_int(w0));
-  ent[start[L1] + atomicAdd(cursor + L1, 1)] = make_int2(seq + 1, __float_as_int(w1));
-  ent[start[L2] + atomicAdd(cursor + L2, 1)] = make_int2(seq + 2, __float_as_int(w2));
-  ent[start[L3] + atomicAdd(cursor + L3, 1)] = make_int2(seq + 3, __float_as_int(w3));
+  const int s0 = list_take(cursor, L0, live), s1 = list_take(cursor, L1, live);
+  const int s2 = list_take(cursor, L2, live), s3 = list_take(cursor, L3, live);
+  if (!live) return;
+  ent[start[L0] + s0] = make_int2(seq, __float_as_int(w0));
+  ent[start[L1] + s1] = make_int2(seq + 1, __float_as_int(w1));
+  ent[start[L2] + s2] = make_int2(seq + 2, __float_as_int(w2));
+  ent[start[L3] + s3] = make_int2(seq + 3, __float_as_int(w3));
 }
 
 // wave = list: entries (sequence number, weight) in slot order -> (diffT row, weight) in sequence order.  Rank sort: the keys
@@ -625,13 +667,18 @@ __global__ __launch_bounds__(kThreads) void psroi_list_fill(const kgdet_psroi_sh
 // keys read as broadcasts (four keys per ds_read_b128 against four entries per lane).
 __global__ __launch_bounds__(kThreads) void psroi_list_sort(const int *__restrict__ start, const int *__restrict__ len,
                                                             const int2 *__restrict__ ent_in, int2 *__restrict__ ent_out,
-                                                            long long NL, int nrec, int classes, int SS, int PP) {
+                                                            long long NL, int nrec, int classes, int SS, int PP,
+                                                            int *__restrict__ long_q, int *__restrict__ long_n) {
   __shared__ __attribute__((aligned(16))) int keys[kThreads / 64][kSortChunk];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const long long L = (long long)blockIdx.x * (kThreads / 64) + wave;
   if (L >= NL) return;
   const int n = __builtin_amdgcn_readfirstlane(len[L]);
   if (n == 0) return;
+  if (n > kWaveSortMax) {      // the rank sort is quadratic: long lists go to psroi_list_sort_long (order of the queue: irrelevant)
+    if (lane == 0) long_q[atomicAdd(long_n, 1)] = (int)L;
+    return;
+  }
   const int base = __builtin_amdgcn_readfirstlane(start[L]);
   int *kw = keys[wave];
   auto emit = [&](int2 e, int rank) {
@@ -671,6 +718,50 @@ __global__ __launch_bounds__(kThreads) void psroi_list_sort(const int *__restric
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if (i0 + u * 64 + lane < n) emit(e[u], rank[u]);
+  }
+}
+
+// workgroup = one LONG list (more than kWaveSortMax entries: pixels under many small RoIs): a bitonic network whose every
+// compare-exchange puts the smaller key at the lower index (the first step of a merge pairs i with its mirror image inside
+// the block, the others i with i + j), so the power-of-two padding can stay virtual -- a pair whose upper index is beyond
+// the list is a pair with +infinity and does nothing.  O(n log^2 n); up to kLongSortLds entries in LDS, longer lists in place
+// in the slot-order array (a workgroup barrier orders its global accesses).
+__global__ __launch_bounds__(kThreads) void psroi_list_sort_long(const int *__restrict__ start, const int *__restrict__ len,
+                                                                 int2 *__restrict__ ent_in, int2 *__restrict__ ent_out,
+                                                                 int nrec, int classes, int SS, int PP,
+                                                                 const int *__restrict__ long_q,
+                                                                 const int *__restrict__ long_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int2 *buf = reinterpret_cast<int2 *>(smem);
+  const int tid = threadIdx.x, count = *long_n;
+  for (int qi = blockIdx.x; qi < count; qi += gridDim.x) {
+    const int L = long_q[qi], n = len[L], base = start[L];
+    const bool in_lds = n <= kLongSortLds;
+    int2 *a = in_lds ? buf : ent_in + base;
+    if (in_lds)
+      for (int t = tid; t < n; t += kThreads) buf[t] = ent_in[base + t];
+    __syncthreads();
+    int n_pad = 1;
+    while (n_pad < n) n_pad <<= 1;
+    for (int k = 2; k <= n_pad; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        const bool flip = j == (k >> 1);
+        for (int t = tid; t < (n_pad >> 1); t += kThreads) {
+          const int i = 2 * t - (t & (j - 1));              // the t-th index with bit j clear
+          const int p2 = flip ? (i ^ (k - 1)) : (i + j);
+          if (p2 < n) {
+            const int2 x = a[i], y = a[p2];
+            if (x.x > y.x) { a[i] = y; a[p2] = x; }
+          }
+        }
+        __syncthreads();
+      }
+    for (int t = tid; t < n; t += kThreads) {
+      const int2 e = a[t];
+      const int q = e.x >> 2, nc = q / nrec, rec = q - nc * nrec;
+      ent_out[base + t] = make_int2((nc / classes) * PP + rec / SS, e.y);
+    }
+    __syncthreads();
   }
 }
 
@@ -830,7 +921,8 @@ bool lists_ok(const kgdet_psroi_shape *s) {
 size_t lists_bytes(const kgdet_psroi_shape *s) {
   if (!lists_ok(s)) return 0;
   const size_t NL = (size_t)lists_count(s), T = (size_t)lists_entries(s);
-  return align_up((NL + 64) * sizeof(int), 256) + align_up(NL * sizeof(int), 256) + 2 * align_up(T * sizeof(int2), 256);
+  return align_up((NL + 64) * sizeof(int), 256) + align_up(NL * sizeof(int), 256) + 2 * align_up(T * sizeof(int2), 256) +
+         align_up((T / kWaveSortMax + 64) * sizeof(int), 256);
 }
 }  // namespace
 
@@ -885,6 +977,9 @@ int kgdet_deform_psroi_backward(const kgdet_psroi_shape *s, const float *grad_ou
   int2 *ent_slot = reinterpret_cast<int2 *>(wsb);
   wsb += align_up((size_t)T * sizeof(int2), 256);
   int2 *ent_sorted = reinterpret_cast<int2 *>(wsb);
+  wsb += align_up((size_t)T * sizeof(int2), 256);
+  int *long_q = reinterpret_cast<int *>(wsb);                 // lists beyond the per-wave sort (at most T / kWaveSortMax)
+  int *long_n = list_cnt + NL + 1;                            // (zeroed with the counters)
   static thread_local bool attr_set = false;
   if (!attr_set) {
     KGDET_HIP_TRY(hipFuncSetAttribute((const void *)psroi_gather<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -892,12 +987,18 @@ int kgdet_deform_psroi_backward(const kgdet_psroi_shape *s, const float *grad_ou
     KGDET_HIP_TRY(hipFuncSetAttribute((const void *)psroi_grad_data<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     KGDET_HIP_TRY(hipFuncSetAttribute((const void *)psroi_grad_data<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     KGDET_HIP_TRY(hipFuncSetAttribute((const void *)psroi_grad_data<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)psroi_list_sort_long, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(kLongSortLds * sizeof(int2))));
     attr_set = true;
   }
   if (use_lists) KGDET_HIP_TRY(hipMemsetAsync(list_cnt, 0, (size_t)(NL + 64) * sizeof(int), (hipStream_t)stream));
-  hipLaunchKernelGGL(psroi_prepare, dim3(s->R), dim3(kThreads), 0, (hipStream_t)stream, *s, rois, trans, grad_out, count,
-                     bbox, diffT, recs_ws, classes, use_lists ? list_cnt : (int *)nullptr);
+  hipLaunchKernelGGL(psroi_prepare, dim3(s->R), dim3(kThreads), 0, (hipStream_t)stream, *s, rois, trans, bbox, recs_ws, classes,
+                     use_lists ? list_cnt : (int *)nullptr);
   KGDET_CHECK_LAUNCH("psroi_prepare");
+  KGDET_CHECK_SHAPE(ceil_div(s->out_dim, 64) <= 65535, "out_dim beyond the launch grid");
+  hipLaunchKernelGGL(psroi_quotient_t, dim3(s->R, ceil_div(s->out_dim, 64)), dim3(kThreads), 0, (hipStream_t)stream, *s, grad_out,
+                     count, diffT);
+  KGDET_CHECK_LAUNCH("psroi_quotient_t");
   if (use_lists) {
     hipStream_t st = (hipStream_t)stream;
     const int list_waves = kThreads / 64;
@@ -909,8 +1010,12 @@ int kgdet_deform_psroi_backward(const kgdet_psroi_shape *s, const float *grad_ou
     KGDET_CHECK_LAUNCH("psroi_list_fill");
     hipLaunchKernelGGL(psroi_list_sort, dim3((unsigned)ceil_div(NL, (long long)list_waves)), dim3(kThreads), 0, st, list_start,
                        list_cnt, ent_slot, ent_sorted, NL, (int)nrec, classes, s->sample_per_part * s->sample_per_part,
-                       s->pooled_size * s->pooled_size);
+                       s->pooled_size * s->pooled_size, long_q, long_n);
     KGDET_CHECK_LAUNCH("psroi_list_sort");
+    hipLaunchKernelGGL(psroi_list_sort_long, dim3(512), dim3(kThreads), kLongSortLds * sizeof(int2), st, list_start, list_cnt,
+                       ent_slot, ent_sorted, (int)nrec, classes, s->sample_per_part * s->sample_per_part,
+                       s->pooled_size * s->pooled_size, (const int *)long_q, (const int *)long_n);
+    KGDET_CHECK_LAUNCH("psroi_list_sort_long");
     const bool vec4 = ch_per_class % 4 == 0;
     const int chunks = ceil_div(ch_per_class, vec4 ? 256 : 64);
     const long long items = NL * chunks;

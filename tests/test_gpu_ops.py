@@ -331,6 +331,38 @@ def test_deform_psroi_pooling_at_size_bit_repeatable(no_trans, S, group_size, C,
 
 
 @pytest.mark.gpu
+def test_deform_psroi_grad_data_hot_pixels_take_the_long_list_sorts():
+    """csrc/psroi.hip grad_data lists: 200 copies of one tiny RoI put ~10^5 sample corners on a handful of pixels, five copies of
+    another ~4 000 -- contribution lists far beyond the per-wave rank sort (> 512 entries: psroi_list_sort_long, in LDS up to
+    8 192 entries, in place in global memory beyond) and the wave-aggregated slot counters; grad_data must still equal the serial
+    float32 oracle bit for bit, twice."""
+    from kgdet_amd.deform_pool import deform_roi_pooling
+    rng = np.random.default_rng(11)
+    B, C, H, W, P, S, out_c = 2, 16, 20, 24, 7, 4, 16
+    data = rng.normal(size=(B, C, H, W)).astype(np.float32)
+    rois = np.concatenate([
+        np.tile(np.array([[0, 100, 90, 112, 101]], np.float32), (200, 1)),     # < 1 map cell wide at scale 1/16
+        np.tile(np.array([[1, 200, 150, 215, 166]], np.float32), (5, 1)),
+        np.stack([rng.integers(0, B, 30), rng.uniform(0, 200, 30), rng.uniform(0, 150, 30),
+                  rng.uniform(200, 380, 30), rng.uniform(150, 310, 30)], 1).astype(np.float32)])
+    R = rois.shape[0]
+    offset = (rng.normal(size=(R, 2, P, P)) * 0.5).astype(np.float32)
+    go = rng.normal(size=(R, out_c, P, P)).astype(np.float32)
+    grads = []
+    for _ in range(2):
+        td = torch.from_numpy(data).cuda().requires_grad_()
+        to = torch.from_numpy(offset).cuda().requires_grad_()
+        out = deform_roi_pooling(td, torch.from_numpy(rois).cuda(), to, 1 / 16., P, out_c, False, 1, P, S, 0.1)
+        out.backward(torch.from_numpy(go).cuda())
+        grads.append(td.grad.clone())
+    _, rc = oracle.deform_psroi_forward(data, rois, offset, np.float32(1 / 16.), P, out_c, False, 1, P, S, np.float32(0.1))
+    gd, _ = oracle.deform_psroi_backward(go, rc, data, rois, offset, np.float32(1 / 16.), P, out_c, False, 1, P, S,
+                                         np.float32(0.1))
+    np.testing.assert_array_equal(grads[0].cpu().numpy(), gd)
+    assert torch.equal(grads[0], grads[1])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('N,C,frac,max_num', [(1000, 13, 0.05, 100), (257, 5, 0.5, 20), (64, 1, 1.0, 100), (1200, 13, 0.2, 100)])
 def test_multiclass_nms_fused_matches_per_image_reference_path(N, C, frac, max_num):
     """csrc/nms.hip multiclass_nms_segments + multiclass_select == bbox_nms_kp.py's per-image, per-class loop
