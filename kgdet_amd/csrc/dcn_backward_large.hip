@@ -132,15 +132,22 @@ __global__ __launch_bounds__(256) void large_cell_alloc(int *__restrict__ cnt, i
 // place is the number of smaller keys: by lane reads up to 64
 // entries, beyond through an LDS copy of the keys read as broadcasts.
 constexpr int kLargeSortChunk = 1024;
+constexpr int kLargeWaveSortMax = 512;     // longest list the per-wave rank sort (quadratic) takes
+constexpr int kLargeLongSortLds = 8192;    // entries large_cell_sort_long sorts in LDS (64 KB); longer lists in place
 __global__ __launch_bounds__(256) void large_cell_sort(const int *__restrict__ start, const int *__restrict__ len,
                                                        const unsigned long long *__restrict__ in,
-                                                       unsigned long long *__restrict__ out, int n_cells) {
+                                                       unsigned long long *__restrict__ out, int n_cells,
+                                                       int *__restrict__ long_q, int *__restrict__ long_n) {
   __shared__ __attribute__((aligned(16))) unsigned keys[4][kLargeSortChunk];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int cell = blockIdx.x * 4 + wave;
   if (cell >= n_cells) return;
   const int n = __builtin_amdgcn_readfirstlane(len[cell]);
   if (n == 0) return;
+  if (n > kLargeWaveSortMax) {     // (offsets trained onto a few cells: thousands of entries) -> large_cell_sort_long
+    if (lane == 0) long_q[atomicAdd(long_n, 1)] = cell;
+    return;
+  }
   const int base = __builtin_amdgcn_readfirstlane(start[cell]);
   unsigned *kw = keys[wave];
   constexpr unsigned long long kNone = ~0ull;
@@ -180,6 +187,44 @@ __global__ __launch_bounds__(256) void large_cell_sort(const int *__restrict__ s
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if (i0 + u * 64 + lane < n) out[base + rank[u]] = e[u];
+  }
+}
+
+// workgroup = one long list: a bitonic network whose every compare-exchange puts the smaller key at the lower index (first
+// step of a merge: i with its mirror image inside the block, then i with i + j), so the power-of-two padding stays virtual -- a
+// pair whose upper index lies beyond the list does nothing.  O(n log^2 n); in LDS up to kLargeLongSortLds entries, longer lists
+// in place in the slot-order array.  (The entries are 64-bit with the unique key in the upper half: compared whole.)
+__global__ __launch_bounds__(256) void large_cell_sort_long(const int *__restrict__ start, const int *__restrict__ len,
+                                                            unsigned long long *__restrict__ in,
+                                                            unsigned long long *__restrict__ out,
+                                                            const int *__restrict__ long_q, const int *__restrict__ long_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char large_smem[];
+  unsigned long long *buf = reinterpret_cast<unsigned long long *>(large_smem);
+  const int tid = threadIdx.x, count = *long_n;
+  for (int qi = blockIdx.x; qi < count; qi += gridDim.x) {
+    const int cell = long_q[qi], n = len[cell], base = start[cell];
+    const bool in_lds = n <= kLargeLongSortLds;
+    unsigned long long *a = in_lds ? buf : in + base;
+    if (in_lds)
+      for (int t = tid; t < n; t += 256) buf[t] = in[base + t];
+    __syncthreads();
+    int n_pad = 1;
+    while (n_pad < n) n_pad <<= 1;
+    for (int k = 2; k <= n_pad; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        const bool flip = j == (k >> 1);
+        for (int t = tid; t < (n_pad >> 1); t += 256) {
+          const int i = 2 * t - (t & (j - 1));
+          const int p2 = flip ? (i ^ (k - 1)) : (i + j);
+          if (p2 < n) {
+            const unsigned long long x = a[i], y = a[p2];
+            if (x > y) { a[i] = y; a[p2] = x; }
+          }
+        }
+        __syncthreads();
+      }
+    for (int t = tid; t < n; t += 256) out[base + t] = a[t];
+    __syncthreads();
   }
 }
 
@@ -296,7 +341,7 @@ __global__ __launch_bounds__(256) void large_grad_offset(const DcnProblem p, con
 }
 
 struct LargePlan {
-  size_t gT, xT, wp, colT, packed, conv_ws, vals, cells, total;
+  size_t gT, xT, wp, colT, packed, conv_ws, vals, cells, long_q, total;
   long long n_entries;
 };
 
@@ -313,7 +358,8 @@ LargePlan large_plan(const DcnProblem &p) {
   L.conv_ws = al(kgdet_conv_apply_workspace_bytes(1, (int)P, p.Og, 1, (int)KC, 1, 1));
   L.vals = al((size_t)L.n_entries * 8);                       // twice: slot order, sorted
   L.cells = al((size_t)(p.N * HW + 64) * 4);                  // twice: counters / cursors (+ the allocation counter), starts
-  L.total = L.gT + L.xT + L.wp + L.colT + L.packed + L.conv_ws + 2 * L.vals + 2 * L.cells;
+  L.long_q = al((size_t)(L.n_entries / kLargeWaveSortMax + 64) * 4);
+  L.total = L.gT + L.xT + L.wp + L.colT + L.packed + L.conv_ws + 2 * L.vals + 2 * L.cells + L.long_q;
   return L;
 }
 
@@ -350,7 +396,8 @@ int dcn_bwd_large(const DcnProblem &p, const float *grad_output, int out_channel
   unsigned long long *vals_a = (unsigned long long *)w8; w8 += L.vals;
   unsigned long long *vals_b = (unsigned long long *)w8; w8 += L.vals;
   int *cell_cnt = (int *)w8; w8 += L.cells;
-  int *cell_start = (int *)w8;
+  int *cell_start = (int *)w8; w8 += L.cells;
+  int *long_q = (int *)w8;
   const int C = p.C_total, O = p.Og, K = p.K;
   const long long P = p.HoWo, HW = (long long)p.H * p.W, KC = (long long)K * C;
   const int O_total = out_channels_total > 0 ? out_channels_total : O;
@@ -377,8 +424,17 @@ int dcn_bwd_large(const DcnProblem &p, const float *grad_output, int out_channel
                      (unsigned long long *)nullptr);
   hipLaunchKernelGGL(large_cell_alloc, dim3((n_cells + 255) / 256), dim3(256), 0, st, cell_cnt, cell_start, cell_total, n_cells);
   hipLaunchKernelGGL(large_cell_entries<true>, dim3(2048), dim3(256), 0, st, p, cell_cnt, (const int *)cell_start, vals_a);
+  int *long_n = cell_total + 1;      // (zeroed with the counters)
   hipLaunchKernelGGL(large_cell_sort, dim3((n_cells + 3) / 4), dim3(256), 0, st, (const int *)cell_start, (const int *)cell_cnt,
-                     (const unsigned long long *)vals_a, vals_b, n_cells);
+                     (const unsigned long long *)vals_a, vals_b, n_cells, long_q, long_n);
+  static thread_local bool long_attr = false;
+  if (!long_attr) {
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)large_cell_sort_long, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kLargeLongSortLds * 8));
+    long_attr = true;
+  }
+  hipLaunchKernelGGL(large_cell_sort_long, dim3(512), dim3(256), kLargeLongSortLds * 8, st, (const int *)cell_start,
+                     (const int *)cell_cnt, vals_a, vals_b, (const int *)long_q, (const int *)long_n);
   hipLaunchKernelGGL(large_gather_input, dim3((unsigned)((HW + kGatherCells - 1) / kGatherCells), p.N, (C + 255) / 256), dim3(256), 0, st, colT,
                      (const int *)cell_start, (const int *)cell_cnt, vals_b, grad_input, C, K, (int)HW, (int)P);
   hipLaunchKernelGGL(large_grad_offset, dim3((unsigned)P, p.N), dim3(256), 0, st, p, colT, xT, grad_offset,

@@ -248,6 +248,37 @@ def test_large_map_v2_backward_is_repeatable():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('frac', [0.4, 1.0])
+def test_large_map_backward_with_offsets_trained_onto_one_point(frac):
+    """csrc/dcn_backward_large.hip inverse index: every (pixel, tap) of `frac` of the output pixels samples next to ONE point of a
+    [1, 32, 40, 44] map -- the four cells around it collect thousands of entries each (0.4: ~6 300, sorted in LDS by
+    large_cell_sort_long; 1.0: ~15 800, sorted in place in global memory), the lists the per-wave rank sort does not take.
+    grad_input / grad_offset against the float64 oracle, and bit-repeatable."""
+    _require_gpu()
+    from kgdet_amd import dcn
+    case = (1, 32, 40, 44, 32, 3, 1, 1, 1, 1, 1)
+    N, C, H, W, O, k, s, p, d, g, dg = case
+    x, off, w, go, _ = _make(case, seed=13)
+    rng = np.random.default_rng(3)
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing='ij')
+    hot = rng.random((H, W)) < frac
+    for t in range(k * k):
+        ty, tx_ = 20.3 + 0.05 * rng.standard_normal((H, W)), 17.6 + 0.05 * rng.standard_normal((H, W))
+        base_y, base_x = ys - p + (t // k) * d, xs - p + (t % k) * d
+        off[0, 2 * t] = np.where(hot, ty - base_y, off[0, 2 * t]).astype(np.float32)
+        off[0, 2 * t + 1] = np.where(hot, tx_ - base_x, off[0, 2 * t + 1]).astype(np.float32)
+    grads = []
+    for _ in range(2):
+        tx, to, tw = (torch.from_numpy(a).cuda().requires_grad_() for a in (x, off, w))
+        dcn.deform_conv(tx, to, tw, s, p, d, g, dg).backward(torch.from_numpy(go).cuda())
+        grads.append((tx.grad.clone(), to.grad.clone()))
+    ref = oracle.deform_conv_backward(x.astype(np.float64), off.astype(np.float64), w.astype(np.float64),
+                                      go.astype(np.float64), s, p, d, g, dg)
+    _close(grads[0][0].cpu().numpy(), ref['grad_input'], 5e-5)
+    _close(grads[0][1].cpu().numpy(), ref['grad_offset'], 5e-5)
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+
+
 LARGE_WGRAD_CASES = [
     (2, 64, 40, 48, 64, 3, 1, 1, 1, 1, 1),      # one channel run
     (1, 64, 40, 48, 32, 3, 1, 1, 1, 2, 4),      # two weight groups x four deformable groups of 16 channels
