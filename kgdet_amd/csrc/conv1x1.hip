@@ -1363,7 +1363,7 @@ constexpr int kPStage = 2 * kPOperand;          // A + B = 33792 bytes
 constexpr int kPThreads = 512;
 constexpr int kPLds = 2 * kPStage;       // (a request padded beyond 80 KB -- never two workgroups on a CU -- changed nothing)
 
-template <int TAPS, int DX, bool PRODUCER>
+template <int TAPS, bool PRODUCER>
 __device__ __forceinline__ void conv_ntp_role(const float *__restrict__ a, const float *__restrict__ bm,
                                               float *__restrict__ partial, int M, int N, int L, int B, int n_mt, int n_nt,
                                               int stages_per_image, int per, int H, int W, int Cin, int unit,
@@ -1377,11 +1377,14 @@ __device__ __forceinline__ void conv_ntp_role(const float *__restrict__ a, const
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   if constexpr (PRODUCER) {
+    // 16-byte global loads need 4-byte alignment only on this part (tools/microbench/unaligned_x4.hip: same rate at every
+    // shift), so a tap is a shift of the load ADDRESS -- no aligned pair + selection, any map width, any pixel count: the
+    // zero-padded copies of rounds 2-3 (pad_rows2 for maps with W % 4 != 0) are gone for this kernel.
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
     const int rp = tid >> 3, q = tid & 7;
     const int tap = TAPS == 9 ? (nt * kTN) / Cin : 0;
-    const int dy = TAPS == 9 ? tap / 3 - 1 : 0;
-    constexpr int dx = DX, off = dx < 0 ? -4 : 0, sh = dx - off;
-    constexpr int NV = (TAPS == 9 && dx != 0) ? 2 : 1;                  // 16-byte loads of bm per row pass
+    const int dy = TAPS == 9 ? tap / 3 - 1 : 0, dx = TAPS == 9 ? tap % 3 - 1 : 0;
+    const int shift = dy * W + dx;                                      // of the flat pixel index
     const int bcols = TAPS == 9 ? Cin : N;
     const int bn0 = TAPS == 9 ? nt * kTN - tap * Cin : nt * kTN;
     int a_off[4], b_off[4];                                             // element offsets of the four rows inside one image
@@ -1395,8 +1398,7 @@ __device__ __forceinline__ void conv_ntp_role(const float *__restrict__ a, const
     const int lds_o = (q >> 2) * kPKS + ((q >> 1) & 1) * kPKH + rp * 16 + (q & 1) * 8;
 
     struct Regs {
-      f32x4 va[4];
-      f32x4 vb[4][NV];
+      f32x4 va[4], vb[4];
       int p0;
     };
     int img = s_begin / stages_per_image, st = s_begin - img * stages_per_image;   // of the NEXT stage to be issued
@@ -1406,48 +1408,60 @@ __device__ __forceinline__ void conv_ntp_role(const float *__restrict__ a, const
       const int p0 = st * kPK + q * 4;
       R.p0 = p0;
       const float *ai = a + (long long)img * M * L, *bi = bm + (long long)img * bcols * L;
-      const int pa = min(p0, L - 4), base = p0 + dy * W + off;
+      // addresses clamped into the image; a clamped piece holds its pixels at shifted positions: commit() moves them back
+      const int pa = min(p0, L - 4), pb = min(max(p0 + shift, 0), L - 4);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        R.va[k] = *reinterpret_cast<const f32x4 *>(ai + a_off[k] + pa);
-#pragma unroll
-        for (int v = 0; v < NV; ++v)   // clamped chunks hold wrong pixels only where the tap is outside the image
-          R.vb[k][v] = *reinterpret_cast<const f32x4 *>(bi + b_off[k] + min(max(base + 4 * v, 0), L - 4));
+        const f32x4u ua = *reinterpret_cast<const f32x4u *>(ai + a_off[k] + pa);
+        const f32x4u ub = *reinterpret_cast<const f32x4u *>(bi + b_off[k] + pb);
+        R.va[k] = f32x4{ua[0], ua[1], ua[2], ua[3]};
+        R.vb[k] = f32x4{ub[0], ub[1], ub[2], ub[3]};
       }
       if (issued + 1 < s_end) {
         ++issued;
         if (++st == stages_per_image) { st = 0; ++img; }
       }
     };
+    // element i of the piece that was meant to start `s` elements after the clamped load address (zero where that lies outside it)
+    auto moved = [](const f32x4 &v, int s) __attribute__((always_inline)) {
+      f32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = i + s;
+        o[i] = j == 0 ? v[0] : j == 1 ? v[1] : j == 2 ? v[2] : j == 3 ? v[3] : 0.0f;
+      }
+      return o;
+    };
     auto commit = [&](int buf, const Regs &R) __attribute__((always_inline)) {
       unsigned char *As = smem + buf * kPStage + lds_o, *Bs = As + kPOperand;
+      const int p0 = R.p0;
+      const int sa = p0 - min(p0, L - 4);                               // != 0: the ragged last piece of an image (L % 4 != 0)
+      const int sb = p0 + shift - min(max(p0 + shift, 0), L - 4);       // != 0: first / last pieces of an image under a tap
       bool ok[4];
       {
-        const bool in_img = R.p0 < L;     // L % 4 == 0: a piece is entirely inside or outside the image
-        int w0 = 0;
-        bool row_ok = in_img;
-        if (TAPS == 9) {
-          const int h = (int)(((float)R.p0 + 0.5f) * inv_w);
-          w0 = R.p0 - h * W;
-          row_ok = row_ok && h + dy >= 0 && h + dy < H;
-        }
+        const int h0 = TAPS == 9 ? (int)(((float)p0 + 0.5f) * inv_w) : 0;
+        const int w0 = p0 - h0 * W;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int col = w0 + i + dx;
-          ok[i] = TAPS == 9 ? (row_ok && col >= 0 && col < W) : row_ok;
+          bool v = p0 + i < L;
+          if (TAPS == 9) {
+            const bool wrap = w0 + i >= W;                              // (W >= 4: a piece touches at most two rows)
+            const int h = h0 + (wrap ? 1 : 0) + dy, w = w0 + i - (wrap ? W : 0) + dx;
+            v = v && h >= 0 && h < H && w >= 0 && w < W;
+          }
+          ok[i] = v;
         }
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        float fb[4];
+        f32x4 fa = R.va[k], fb = R.vb[k];
+        if (sa != 0) fa = moved(fa, sa);                                // (rare: the last stage of an image)
+        if (sb != 0) fb = moved(fb, sb);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int e = i + (TAPS == 9 ? sh : 0);
-          fb[i] = ok[i] ? R.vb[k][e >> 2][e & 3] : 0.0f;
-        }
+        for (int i = 0; i < 4; ++i) fb[i] = ok[i] ? fb[i] : 0.0f;       // pixels outside the image multiply a zero
         uint2 ahi, alo, bhi, blo;
-        split_pair(R.va[k][0], R.va[k][1], ahi.x, alo.x);
-        split_pair(R.va[k][2], R.va[k][3], ahi.y, alo.y);
+        split_pair(fa[0], fa[1], ahi.x, alo.x);
+        split_pair(fa[2], fa[3], ahi.y, alo.y);
         split_pair(fb[0], fb[1], bhi.x, blo.x);
         split_pair(fb[2], fb[3], bhi.y, blo.y);
         *reinterpret_cast<uint2 *>(As + k * 32 * 16) = ahi;
@@ -1551,23 +1565,8 @@ __global__ __launch_bounds__(kPThreads, 1) void conv_ntp(const float *__restrict
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int unit = units > 0 ? xcd_tile(blockIdx.x, units) : (int)blockIdx.x;      // (as conv_nt8)
   if (units > 0 && unit >= units) return;
-  const bool producer = threadIdx.x >= 256;
-#define KGDET_NTP_ROLE(DXV)                                                                                                  \
-  do {                                                                                                                       \
-    if (producer) conv_ntp_role<TAPS, DXV, true>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin,   \
-                                                 unit, smem);                                                               \
-    else conv_ntp_role<TAPS, 0, false>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem); \
-  } while (0)
-  if (TAPS == 9) {
-    const int tile = unit % (n_mt * n_nt), nt = tile / n_mt;
-    const int dx = ((nt * kTN) / Cin) % 3 - 1;   // uniform: one tap per tile
-    if (dx < 0) KGDET_NTP_ROLE(-1);
-    else if (dx == 0) KGDET_NTP_ROLE(0);
-    else KGDET_NTP_ROLE(1);
-  } else {
-    KGDET_NTP_ROLE(0);
-  }
-#undef KGDET_NTP_ROLE
+  if (threadIdx.x >= 256) conv_ntp_role<TAPS, true>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem);
+  else conv_ntp_role<TAPS, false>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem);
 }
 
 namespace {
@@ -1613,9 +1612,11 @@ int nt_grid(int units) { return nt_xcd() ? (units + 7) / 8 * 8 : units; }
 // 66.0 / 70.6 / 89.4 / 41.4 us; 1x1 3-5 % SLOWER (31.7 -> 33.4 us ...: ~17 long stages per workgroup, fill and drain weigh
 // more than the leaner stage) -- so the 3x3 problems take conv_ntp and the 1x1 problems stay on conv_nt8.  KGDET_NT_PC=0 / 2:
 // neither / both.
-bool ntp_on(int taps) {
+// Maps whose rows / pixel count are not a multiple of 4 (25 x 42, 13 x 21, 7 x 11) always take conv_ntp when it is on at all: it
+// reads them in place (4-byte aligned 16-byte loads), conv_nt8 needs zero-padded copies of both operands (pad_rows2).
+bool ntp_on(int taps, bool odd = false) {
   static const int mode = [] { const char *e = getenv("KGDET_NT_PC"); return e ? atoi(e) : 1; }();
-  return mode == 2 || (mode == 1 && taps == 9);
+  return mode == 2 || (mode == 1 && (taps == 9 || odd));
 }
 int ntp_lds() { return kPLds; }
 int ntp_attr() {
@@ -1984,8 +1985,12 @@ static int conv1x1_grad_weight_impl(const float *grad_y, const float *x, float *
   KGDET_CHECK_SHAPE(B > 0 && O > 0 && C > 0 && HW > 0 && HW < (1LL << 30), "bad sizes");
   KGDET_CHECK_SHAPE(grad_y && x && grad_w && workspace, "null pointer");
   KGDET_CHECK_SHAPE(workspace_bytes >= kgdet_conv1x1_grad_weight_workspace_bytes(B, O, C, HW), "workspace too small");
-  if (HW % 4) {
-    // 16-byte loads need H*W % 4 == 0 (25 x 42 = 1050): both operands go into the workspace with zero pixels up to a
+  const long long HW_true = HW;
+  const bool use_ntp = ntp_on(1, HW % 4 != 0) && HW >= 4 && (long long)(O > C ? O : C) * HW < (1ll << 31);
+  if (HW % 4 && use_ntp) {
+    HW = (HW + 3) & ~3LL;      // (the split count below is the one the workspace query computed for the padded size)
+  } else if (HW % 4) {
+    // conv_nt8's piece logic needs H*W % 4 == 0 (25 x 42 = 1050): both operands go into the workspace with zero pixels up to a
     // multiple of 4 (one launch; zero grad_y pixels contribute nothing).  The 8-byte-load kernel this replaces lost to
     // MIOpen's GEMM (50-54 against 41-47 us).
     const long long HWp = (HW + 3) & ~3LL;
@@ -2009,11 +2014,12 @@ static int conv1x1_grad_weight_impl(const float *grad_y, const float *x, float *
   const int splits = nt_splits(tiles, total);
   const int per = (total + splits - 1) / splits;
   KGDET_CHECK_SHAPE(((long long)O * C) % 2 == 0, "O*C must be even");
-  if (ntp_on(1) && (long long)(O > C ? O : C) * HW < (1ll << 31)) {
+  if (use_ntp) {
     if (int rc = ntp_attr()) return rc;
-    const int spi32 = (int)((HW + kPK - 1) / kPK), total32 = (int)(B * spi32), per32 = (total32 + splits - 1) / splits;
+    const int spi32 = (int)((HW_true + kPK - 1) / kPK), total32 = (int)(B * spi32), per32 = (total32 + splits - 1) / splits;
     hipLaunchKernelGGL(conv_ntp<1>, dim3(nt_grid(tiles * splits)), dim3(kPThreads), ntp_lds(), (hipStream_t)stream, grad_y, x,
-                       (float *)workspace, O, C, (int)HW, (int)B, n_mt, n_nt, spi32, per32, 1, (int)HW, 0, nt_units(tiles * splits));
+                       (float *)workspace, O, C, (int)HW_true, (int)B, n_mt, n_nt, spi32, per32, 1, (int)HW_true, 0,
+                       nt_units(tiles * splits));
     KGDET_CHECK_LAUNCH("conv_ntp<1>");
   } else {
     hipLaunchKernelGGL(conv_nt8<1>, dim3(nt_grid(tiles * splits)), dim3(kNNThreads), 0, (hipStream_t)stream, grad_y, x,
@@ -2078,8 +2084,12 @@ static int conv3x3_grad_weight_impl(const float *grad_y, const float *x, float *
   }
   KGDET_CHECK_SHAPE(grad_y && x && grad_w && workspace, "null pointer");
   KGDET_CHECK_SHAPE(workspace_bytes >= kgdet_conv3x3_grad_weight_workspace_bytes(B, O, C, H, W), "workspace too small");
-  if (W % 4) {
-    // the kernel's 16-byte row loads need W % 4 == 0 (25 x 42 head / FPN maps): zero columns on the right of BOTH operands
+  const int W_true = W;
+  const bool use_ntp = ntp_on(9) && W >= 4 && (long long)H * W >= 4 && (long long)(O > C ? O : C) * H * ((W + 3) & ~3) < (1ll << 31);
+  if (W % 4 && use_ntp) {
+    W = (W + 3) & ~3;          // (the split count below is the one the workspace query computed for the padded size)
+  } else if (W % 4) {
+    // conv_nt8's 16-byte row pieces need W % 4 == 0 (25 x 42 head / FPN maps): zero columns on the right of BOTH operands
     // change nothing -- grad_y is 0 there, and x's zeros are what the out-of-range taps read anyway.  One launch pads both
     // into the tail of the workspace.
     const int Wp = (W + 3) & ~3;
@@ -2103,11 +2113,12 @@ static int conv3x3_grad_weight_impl(const float *grad_y, const float *x, float *
   const int spi = (HW + kTK - 1) / kTK, total = (int)(B * spi);
   const int splits = nt_splits(tiles, total);
   const int per = (total + splits - 1) / splits;
-  if (ntp_on(9) && (long long)(O > C ? O : C) * HW < (1ll << 31)) {
+  if (use_ntp) {
     if (int rc = ntp_attr()) return rc;
-    const int spi32 = (HW + kPK - 1) / kPK, total32 = (int)(B * spi32), per32 = (total32 + splits - 1) / splits;
+    const int L = H * W_true;
+    const int spi32 = (L + kPK - 1) / kPK, total32 = (int)(B * spi32), per32 = (total32 + splits - 1) / splits;
     hipLaunchKernelGGL(conv_ntp<9>, dim3(nt_grid(tiles * splits)), dim3(kPThreads), ntp_lds(), (hipStream_t)stream, grad_y, x,
-                       (float *)workspace, O, 9 * C, HW, (int)B, n_mt, n_nt, spi32, per32, H, W, C, nt_units(tiles * splits));
+                       (float *)workspace, O, 9 * C, L, (int)B, n_mt, n_nt, spi32, per32, H, W_true, C, nt_units(tiles * splits));
     KGDET_CHECK_LAUNCH("conv_ntp<9>");
   } else {
     hipLaunchKernelGGL(conv_nt8<9>, dim3(nt_grid(tiles * splits)), dim3(kNNThreads), 0, (hipStream_t)stream, grad_y, x,
