@@ -21,6 +21,11 @@ PACK_BOTH = _os.environ.get('KGDET_PACK_BOTH', '1') == '1'
 
 
 PAD_GRAD_WEIGHT_3X3 = _os.environ.get('KGDET_NO_WPAD') is None   # (A/B switch for the zero-padded odd-width route)
+# Maps with an odd pixel count (13 x 21, 7 x 11: the two coarsest levels of a five-level head) go to the split kernels as they
+# are (round 4: tools/check_odd_maps.py -- forward 3e-7, gradients 5e-6 of torch's float64 convolution; 16-byte loads need 4-byte
+# alignment only on gfx950).  0: rounds 2-3's route, one zero column appended and cut off around every convolution (pad_odd /
+# unpad_odd below: six extra launches per convolution and step, ~130 of a config-5 step)
+DIRECT_ODD_MAPS = _os.environ.get('KGDET_DIRECT_ODD_MAPS', '1') == '1'
 ENABLED = True      # False: every dense convolution stays on MIOpen's fp32 kernels (dcn.arithmetic('exact'))
 
 
@@ -30,7 +35,8 @@ def applicable(x, weight, stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups
             and weight.shape[2] == weight.shape[3] and k in (1, 3) and tuple(stride) == (1, 1)
             and tuple(padding) == (k // 2, k // 2) and tuple(dilation) == (1, 1) and groups == 1
             and x.is_contiguous() and weight.shape[1] % 16 == 0 and weight.shape[0] % 16 == 0
-            and (x.shape[2] * x.shape[3]) % 2 == 0 and not torch.is_autocast_enabled())
+            and ((x.shape[2] * x.shape[3]) % 2 == 0 or DIRECT_ODD_MAPS) and x.shape[2] * x.shape[3] >= 4
+            and not torch.is_autocast_enabled())
 
 
 _L = None

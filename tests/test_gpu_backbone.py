@@ -470,9 +470,38 @@ def test_conv1x1_not_applicable_cases_fall_back():
     assert c1.applicable(x, w3, padding=(1, 1)) and not c1.applicable(x, w3) and not c1.applicable(x, w3, padding=(1, 1), dilation=(2, 2))
     assert not c1.applicable(x, w3, stride=(2, 2), padding=(1, 1)) and not c1.applicable(x, torch.randn(32, 64, 5, 5, device='cuda'), padding=(2, 2))
     assert not c1.applicable(torch.randn(2, 40, 8, 8, device='cuda'), torch.randn(32, 40, 1, 1, device='cuda'))
-    assert not c1.applicable(torch.randn(2, 64, 3, 3, device='cuda'), w)          # odd H*W
+    assert c1.applicable(torch.randn(2, 64, 3, 3, device='cuda'), w) == c1.DIRECT_ODD_MAPS     # odd H*W: in place since round 4
+    assert not c1.applicable(torch.randn(2, 64, 1, 3, device='cuda'), w)                       # fewer than 4 pixels
     with torch.autocast('cuda', dtype=torch.bfloat16):
         assert not c1.applicable(x, w)
+
+
+@pytest.mark.parametrize('H,W', [(13, 21), (7, 11), (5, 5), (3, 3), (2, 2), (25, 42), (9, 6)])
+@pytest.mark.parametrize('k', [1, 3])
+def test_split_convolutions_take_odd_and_unaligned_maps_in_place(H, W, k):
+    """csrc/conv1x1.hip on maps whose pixel count is odd / whose rows are not a multiple of 4 floats (the two coarsest levels of a
+    five-level head, 13 x 21 and 7 x 11; the 25 x 42 head maps): forward, grad_input and grad_weight (conv_ntp: a tap is a shift
+    of a 4-byte aligned 16-byte load, ragged last pieces moved back into place) against torch's float64 convolution, and the
+    biased convolution + ReLU of config 5's FPN.  Rounds 2-3 appended a zero column around every such convolution."""
+    from kgdet_amd import conv1x1 as c1
+    g = torch.Generator(device='cpu').manual_seed(H * 100 + W * 3 + k)
+    x = torch.randn(2, 64, H, W, generator=g).cuda().requires_grad_()
+    w = (torch.randn(128, 64, k, k, generator=g) * 0.1).cuda().requires_grad_()
+    gy = torch.randn(2, 128, H, W, generator=g).cuda()
+    assert c1.applicable(x, w, (1, 1), (k // 2, k // 2))
+    ref = F.conv2d(x.double(), w.double(), padding=k // 2)
+    gx_r, gw_r = torch.autograd.grad(ref, (x, w), gy.double())
+    y = c1.conv_split(x, w)
+    gx, gw = torch.autograd.grad(y, (x, w), gy)
+    for a, b in ((y, ref), (gx, gx_r), (gw, gw_r)):
+        assert float((a.double() - b).abs().max()) < 2e-5 * float(b.abs().max())
+    if k == 3:
+        conv = torch.nn.Conv2d(64, 128, 3, padding=1).cuda()
+        ref = F.relu(F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1))
+        r = torch.autograd.grad(ref, (x, conv.weight, conv.bias), gy.double())
+        o = torch.autograd.grad(c1.conv_bias_act(conv, x, relu=True), (x, conv.weight, conv.bias), gy)
+        for a, b in zip(o, r):
+            assert float((a.double() - b).abs().max()) < 2e-5 * float(b.abs().max())
 
 
 @pytest.mark.parametrize('B,C,O,H,W', [(2, 128, 128, 20, 36), (1, 64, 256, 17, 13), (2, 256, 256, 50, 84), (1, 64, 64, 9, 12),
