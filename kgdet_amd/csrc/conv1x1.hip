@@ -1408,35 +1408,34 @@ __device__ __forceinline__ void conv_ntp_role(const float *__restrict__ a, const
       const int p0 = st * kPK + q * 4;
       R.p0 = p0;
       const float *ai = a + (long long)img * M * L, *bi = bm + (long long)img * bcols * L;
-      // addresses clamped into the image; a clamped piece holds its pixels at shifted positions: commit() moves them back
-      const int pa = min(p0, L - 4), pb = min(max(p0 + shift, 0), L - 4);
+      // a piece that lies inside the image is ONE (4-byte aligned) 16-byte load; the few pieces that straddle the image's first /
+      // last pixel under a tap, and the ragged last piece of an image with L % 4 != 0, load their in-range pixels one by one
+      const int base = p0 + shift;
+      if (p0 <= L - 4 && base >= 0 && base <= L - 4) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const f32x4u ua = *reinterpret_cast<const f32x4u *>(ai + a_off[k] + pa);
-        const f32x4u ub = *reinterpret_cast<const f32x4u *>(bi + b_off[k] + pb);
-        R.va[k] = f32x4{ua[0], ua[1], ua[2], ua[3]};
-        R.vb[k] = f32x4{ub[0], ub[1], ub[2], ub[3]};
+        for (int k = 0; k < 4; ++k) {
+          const f32x4u ua = *reinterpret_cast<const f32x4u *>(ai + a_off[k] + p0);
+          const f32x4u ub = *reinterpret_cast<const f32x4u *>(bi + b_off[k] + base);
+          R.va[k] = f32x4{ua[0], ua[1], ua[2], ua[3]};
+          R.vb[k] = f32x4{ub[0], ub[1], ub[2], ub[3]};
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            R.va[k][i] = p0 + i < L ? ai[a_off[k] + p0 + i] : 0.0f;
+            R.vb[k][i] = (base + i >= 0 && base + i < L) ? bi[b_off[k] + base + i] : 0.0f;
+          }
       }
       if (issued + 1 < s_end) {
         ++issued;
         if (++st == stages_per_image) { st = 0; ++img; }
       }
     };
-    // element i of the piece that was meant to start `s` elements after the clamped load address (zero where that lies outside it)
-    auto moved = [](const f32x4 &v, int s) __attribute__((always_inline)) {
-      f32x4 o;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int j = i + s;
-        o[i] = j == 0 ? v[0] : j == 1 ? v[1] : j == 2 ? v[2] : j == 3 ? v[3] : 0.0f;
-      }
-      return o;
-    };
     auto commit = [&](int buf, const Regs &R) __attribute__((always_inline)) {
       unsigned char *As = smem + buf * kPStage + lds_o, *Bs = As + kPOperand;
       const int p0 = R.p0;
-      const int sa = p0 - min(p0, L - 4);                               // != 0: the ragged last piece of an image (L % 4 != 0)
-      const int sb = p0 + shift - min(max(p0 + shift, 0), L - 4);       // != 0: first / last pieces of an image under a tap
       bool ok[4];
       {
         const int h0 = TAPS == 9 ? (int)(((float)p0 + 0.5f) * inv_w) : 0;
@@ -1455,8 +1454,6 @@ __device__ __forceinline__ void conv_ntp_role(const float *__restrict__ a, const
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         f32x4 fa = R.va[k], fb = R.vb[k];
-        if (sa != 0) fa = moved(fa, sa);                                // (rare: the last stage of an image)
-        if (sb != 0) fb = moved(fb, sb);
 #pragma unroll
         for (int i = 0; i < 4; ++i) fb[i] = ok[i] ? fb[i] : 0.0f;       // pixels outside the image multiply a zero
         uint2 ahi, alo, bhi, blo;
