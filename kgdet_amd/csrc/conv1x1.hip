@@ -1363,7 +1363,7 @@ constexpr int kPStage = 2 * kPOperand;          // A + B = 33792 bytes
 constexpr int kPThreads = 512;
 constexpr int kPLds = 2 * kPStage;       // (a request padded beyond 80 KB -- never two workgroups on a CU -- changed nothing)
 
-template <int TAPS, bool PRODUCER>
+template <int TAPS, bool PRODUCER, bool ALIGNED>
 __device__ __forceinline__ void conv_ntp_role(const float *__restrict__ a, const float *__restrict__ bm,
                                               float *__restrict__ partial, int M, int N, int L, int B, int n_mt, int n_nt,
                                               int stages_per_image, int per, int H, int W, int Cin, int unit,
@@ -1412,10 +1412,12 @@ __device__ __forceinline__ void conv_ntp_role(const float *__restrict__ a, const
       // last pixel under a tap, and the ragged last piece of an image with L % 4 != 0, load their in-range pixels one by one
       const int base = p0 + shift;
       if (p0 <= L - 4 && base >= 0 && base <= L - 4) {
+        // (scalar image base + zero-extended 32-bit byte offset: the load's own addressing mode, no 64-bit vector arithmetic)
+        const char *ab = reinterpret_cast<const char *>(ai), *bb = reinterpret_cast<const char *>(bi);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const f32x4u ua = *reinterpret_cast<const f32x4u *>(ai + a_off[k] + p0);
-          const f32x4u ub = *reinterpret_cast<const f32x4u *>(bi + b_off[k] + base);
+          const f32x4u ua = *reinterpret_cast<const f32x4u *>(ab + (size_t)((unsigned)(a_off[k] + p0) * 4u));
+          const f32x4u ub = *reinterpret_cast<const f32x4u *>(bb + (size_t)((unsigned)(b_off[k] + base) * 4u));
           R.va[k] = f32x4{ua[0], ua[1], ua[2], ua[3]};
           R.vb[k] = f32x4{ub[0], ub[1], ub[2], ub[3]};
         }
@@ -1437,7 +1439,21 @@ __device__ __forceinline__ void conv_ntp_role(const float *__restrict__ a, const
       unsigned char *As = smem + buf * kPStage + lds_o, *Bs = As + kPOperand;
       const int p0 = R.p0;
       bool ok[4];
-      {
+      if constexpr (ALIGNED) {
+        // W % 4 == 0 (and so L % 4 == 0): a piece lies inside one row and entirely inside or outside the image -- one row test
+        // for the four pixels, a column test for the one pixel a +-1 tap can push out (each vector instruction beside the MFMA
+        // wave of its SIMD costs that wave ~10 cycles: the per-pixel form below is ~40 instructions per stage)
+        bool row_ok = p0 < L;
+        int w0 = 0;
+        if (TAPS == 9) {
+          const int h0 = (int)(((float)p0 + 0.5f) * inv_w);
+          w0 = p0 - h0 * W;
+          row_ok = row_ok && (unsigned)(h0 + dy) < (unsigned)H;
+        }
+        ok[0] = row_ok && (TAPS == 1 || dx >= 0 || w0 > 0);
+        ok[1] = ok[2] = row_ok;
+        ok[3] = row_ok && (TAPS == 1 || dx <= 0 || w0 + 4 < W);
+      } else {
         const int h0 = TAPS == 9 ? (int)(((float)p0 + 0.5f) * inv_w) : 0;
         const int w0 = p0 - h0 * W;
 #pragma unroll
@@ -1554,7 +1570,8 @@ __device__ __forceinline__ void conv_ntp_role(const float *__restrict__ a, const
   }
 }
 
-template <int TAPS>
+// ALIGNED: W % 4 == 0 (TAPS == 9) / L % 4 == 0 (TAPS == 1): the cheap boundary masks
+template <int TAPS, bool ALIGNED>
 __global__ __launch_bounds__(kPThreads, 1) void conv_ntp(const float *__restrict__ a, const float *__restrict__ bm,
                                                          float *__restrict__ partial, int M, int N, int L, int B, int n_mt,
                                                          int n_nt, int stages_per_image, int per, int H, int W, int Cin,
@@ -1562,8 +1579,10 @@ __global__ __launch_bounds__(kPThreads, 1) void conv_ntp(const float *__restrict
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int unit = units > 0 ? xcd_tile(blockIdx.x, units) : (int)blockIdx.x;      // (as conv_nt8)
   if (units > 0 && unit >= units) return;
-  if (threadIdx.x >= 256) conv_ntp_role<TAPS, true>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem);
-  else conv_ntp_role<TAPS, false>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem);
+  if (threadIdx.x >= 256)
+    conv_ntp_role<TAPS, true, ALIGNED>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem);
+  else
+    conv_ntp_role<TAPS, false, ALIGNED>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem);
 }
 
 namespace {
@@ -1619,8 +1638,10 @@ int ntp_lds() { return kPLds; }
 int ntp_attr() {
   static thread_local bool set = false;
   if (!set) {
-    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv_ntp<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ntp_lds()));
-    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv_ntp<9>, hipFuncAttributeMaxDynamicSharedMemorySize, ntp_lds()));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv_ntp<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ntp_lds()));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv_ntp<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ntp_lds()));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv_ntp<9, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ntp_lds()));
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)conv_ntp<9, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ntp_lds()));
     set = true;
   }
   return KGDET_OK;
@@ -1983,7 +2004,7 @@ static int conv1x1_grad_weight_impl(const float *grad_y, const float *x, float *
   KGDET_CHECK_SHAPE(grad_y && x && grad_w && workspace, "null pointer");
   KGDET_CHECK_SHAPE(workspace_bytes >= kgdet_conv1x1_grad_weight_workspace_bytes(B, O, C, HW), "workspace too small");
   const long long HW_true = HW;
-  const bool use_ntp = ntp_on(1, HW % 4 != 0) && HW >= 4 && (long long)(O > C ? O : C) * HW < (1ll << 31);
+  const bool use_ntp = ntp_on(1, HW % 4 != 0) && HW >= 4 && (long long)(O > C ? O : C) * HW < (1ll << 30);
   if (HW % 4 && use_ntp) {
     HW = (HW + 3) & ~3LL;      // (the split count below is the one the workspace query computed for the padded size)
   } else if (HW % 4) {
@@ -2014,9 +2035,14 @@ static int conv1x1_grad_weight_impl(const float *grad_y, const float *x, float *
   if (use_ntp) {
     if (int rc = ntp_attr()) return rc;
     const int spi32 = (int)((HW_true + kPK - 1) / kPK), total32 = (int)(B * spi32), per32 = (total32 + splits - 1) / splits;
-    hipLaunchKernelGGL(conv_ntp<1>, dim3(nt_grid(tiles * splits)), dim3(kPThreads), ntp_lds(), (hipStream_t)stream, grad_y, x,
-                       (float *)workspace, O, C, (int)HW_true, (int)B, n_mt, n_nt, spi32, per32, 1, (int)HW_true, 0,
-                       nt_units(tiles * splits));
+    if (HW_true % 4 == 0)
+      hipLaunchKernelGGL((conv_ntp<1, true>), dim3(nt_grid(tiles * splits)), dim3(kPThreads), ntp_lds(), (hipStream_t)stream, grad_y, x,
+                         (float *)workspace, O, C, (int)HW_true, (int)B, n_mt, n_nt, spi32, per32, 1, (int)HW_true, 0,
+                         nt_units(tiles * splits));
+    else
+      hipLaunchKernelGGL((conv_ntp<1, false>), dim3(nt_grid(tiles * splits)), dim3(kPThreads), ntp_lds(), (hipStream_t)stream, grad_y, x,
+                         (float *)workspace, O, C, (int)HW_true, (int)B, n_mt, n_nt, spi32, per32, 1, (int)HW_true, 0,
+                         nt_units(tiles * splits));
     KGDET_CHECK_LAUNCH("conv_ntp<1>");
   } else {
     hipLaunchKernelGGL(conv_nt8<1>, dim3(nt_grid(tiles * splits)), dim3(kNNThreads), 0, (hipStream_t)stream, grad_y, x,
@@ -2082,7 +2108,7 @@ static int conv3x3_grad_weight_impl(const float *grad_y, const float *x, float *
   KGDET_CHECK_SHAPE(grad_y && x && grad_w && workspace, "null pointer");
   KGDET_CHECK_SHAPE(workspace_bytes >= kgdet_conv3x3_grad_weight_workspace_bytes(B, O, C, H, W), "workspace too small");
   const int W_true = W;
-  const bool use_ntp = ntp_on(9) && W >= 4 && (long long)H * W >= 4 && (long long)(O > C ? O : C) * H * ((W + 3) & ~3) < (1ll << 31);
+  const bool use_ntp = ntp_on(9) && W >= 4 && (long long)H * W >= 4 && (long long)(O > C ? O : C) * H * ((W + 3) & ~3) < (1ll << 30);
   if (W % 4 && use_ntp) {
     W = (W + 3) & ~3;          // (the split count below is the one the workspace query computed for the padded size)
   } else if (W % 4) {
@@ -2114,8 +2140,12 @@ static int conv3x3_grad_weight_impl(const float *grad_y, const float *x, float *
     if (int rc = ntp_attr()) return rc;
     const int L = H * W_true;
     const int spi32 = (L + kPK - 1) / kPK, total32 = (int)(B * spi32), per32 = (total32 + splits - 1) / splits;
-    hipLaunchKernelGGL(conv_ntp<9>, dim3(nt_grid(tiles * splits)), dim3(kPThreads), ntp_lds(), (hipStream_t)stream, grad_y, x,
-                       (float *)workspace, O, 9 * C, L, (int)B, n_mt, n_nt, spi32, per32, H, W_true, C, nt_units(tiles * splits));
+    if (W_true % 4 == 0)
+      hipLaunchKernelGGL((conv_ntp<9, true>), dim3(nt_grid(tiles * splits)), dim3(kPThreads), ntp_lds(), (hipStream_t)stream, grad_y, x,
+                         (float *)workspace, O, 9 * C, L, (int)B, n_mt, n_nt, spi32, per32, H, W_true, C, nt_units(tiles * splits));
+    else
+      hipLaunchKernelGGL((conv_ntp<9, false>), dim3(nt_grid(tiles * splits)), dim3(kPThreads), ntp_lds(), (hipStream_t)stream, grad_y, x,
+                         (float *)workspace, O, 9 * C, L, (int)B, n_mt, n_nt, spi32, per32, H, W_true, C, nt_units(tiles * splits));
     KGDET_CHECK_LAUNCH("conv_ntp<9>");
   } else {
     hipLaunchKernelGGL(conv_nt8<9>, dim3(nt_grid(tiles * splits)), dim3(kNNThreads), 0, (hipStream_t)stream, grad_y, x,
