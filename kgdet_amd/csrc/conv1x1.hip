@@ -1360,7 +1360,12 @@ constexpr int kPKS = 2 * kPKH;                  // one 16-pixel MFMA step: two k
 constexpr int kPPart = 2 * kPKS;                // one part (hi / lo) of one operand's stage
 constexpr int kPOperand = 2 * kPPart;
 constexpr int kPStage = 2 * kPOperand;          // A + B = 33792 bytes
-constexpr int kPThreads = 512;
+#ifndef KGDET_NTP_CONS
+#define KGDET_NTP_CONS 4
+#endif
+constexpr int kPCons = KGDET_NTP_CONS;               // consumer waves: 4 (64 x 64 outputs each) or 8 (64 x 32: two per SIMD)
+constexpr int kPNI = kPCons == 8 ? 1 : 2;            // 32-column blocks per consumer wave
+constexpr int kPThreads = kPCons * 64 + 256;
 constexpr int kPLds = 2 * kPStage;       // (a request padded beyond 80 KB -- never two workgroups on a CU -- changed nothing)
 
 template <int TAPS, bool PRODUCER, bool ALIGNED>
@@ -1373,7 +1378,7 @@ __device__ __forceinline__ void conv_ntp_role(const float *__restrict__ a, const
   const int total = B * stages_per_image;
   const int s_begin = split * per, s_end = min(total, s_begin + per);
   const int n = s_end - s_begin;
-  const int wtid = threadIdx.x, tid = PRODUCER ? wtid - 256 : wtid;
+  const int wtid = threadIdx.x, tid = PRODUCER ? wtid - kPCons * 64 : wtid;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   if constexpr (PRODUCER) {
@@ -1417,7 +1422,11 @@ __device__ __forceinline__ void conv_ntp_role(const float *__restrict__ a, const
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const f32x4u ua = *reinterpret_cast<const f32x4u *>(ab + (size_t)((unsigned)(a_off[k] + p0) * 4u));
+#ifdef KGDET_NTP_ABL_NOBLOAD   // ablation: no global loads for the x operand (wrong results; how much of the time is the L2 -> CU traffic?)
+          const f32x4u ub = ua;
+#else
           const f32x4u ub = *reinterpret_cast<const f32x4u *>(bb + (size_t)((unsigned)(b_off[k] + base) * 4u));
+#endif
           R.va[k] = f32x4{ua[0], ua[1], ua[2], ua[3]};
           R.vb[k] = f32x4{ub[0], ub[1], ub[2], ub[3]};
         }
@@ -1502,45 +1511,45 @@ __device__ __forceinline__ void conv_ntp_role(const float *__restrict__ a, const
       }
     }
   } else {
-    const int wm = wave & 1, wn = wave >> 1;
-    f32x16 acc[2][2];
+    const int wm = wave & 1, wn = wave >> 1;           // rows wm * 64 .. + 63, columns wn * 32 * kPNI .. + 32 * kPNI - 1
+    f32x16 acc[2][kPNI];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < kPNI; ++ni)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
     const int fo = (lane >> 5) * kPKH + (lane & 31) * 16;
     auto multiply = [&](int buf) __attribute__((always_inline)) {
       const unsigned char *A = smem + buf * kPStage + fo + wm * 64 * 16;
-      const unsigned char *Bp = smem + buf * kPStage + kPOperand + fo + wn * 64 * 16;
-      bf16x8 fa[2][2][2], fb[2][2][2];     // [step][part][block]
+      const unsigned char *Bp = smem + buf * kPStage + kPOperand + fo + wn * (32 * kPNI) * 16;
+      bf16x8 fa[2][2][2], fb[2][2][kPNI];     // [step][part][block]
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
+        for (int pt = 0; pt < 2; ++pt) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            fa[ks][pt][i] = *reinterpret_cast<const bf16x8 *>(A + ks * kPKS + pt * kPPart + i * 32 * 16);
-            fb[ks][pt][i] = *reinterpret_cast<const bf16x8 *>(Bp + ks * kPKS + pt * kPPart + i * 32 * 16);
-          }
+          for (int i = 0; i < 2; ++i) fa[ks][pt][i] = *reinterpret_cast<const bf16x8 *>(A + ks * kPKS + pt * kPPart + i * 32 * 16);
+#pragma unroll
+          for (int i = 0; i < kPNI; ++i) fb[ks][pt][i] = *reinterpret_cast<const bf16x8 *>(Bp + ks * kPKS + pt * kPPart + i * 32 * 16);
+        }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        // small terms first; four independent accumulators between two MFMAs on the same one
+        // small terms first; the other accumulators' MFMAs between two on the same one
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
+          for (int ni = 0; ni < kPNI; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][1][mi], fb[ks][0][ni], acc[mi][ni], 0, 0, 0);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
+          for (int ni = 0; ni < kPNI; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][0][mi], fb[ks][1][ni], acc[mi][ni], 0, 0, 0);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
+          for (int ni = 0; ni < kPNI; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][0][mi], fb[ks][0][ni], acc[mi][ni], 0, 0, 0);
       }
     };
@@ -1559,8 +1568,8 @@ __device__ __forceinline__ void conv_ntp_role(const float *__restrict__ a, const
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int nn = nt * kTN + wn * 64 + ni * 32 + (lane & 31);
+      for (int ni = 0; ni < kPNI; ++ni) {
+        const int nn = nt * kTN + wn * (32 * kPNI) + ni * 32 + (lane & 31);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = mt * kTM + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -1570,7 +1579,6 @@ __device__ __forceinline__ void conv_ntp_role(const float *__restrict__ a, const
   }
 }
 
-// ALIGNED: W % 4 == 0 (TAPS == 9) / L % 4 == 0 (TAPS == 1): the cheap boundary masks
 template <int TAPS, bool ALIGNED>
 __global__ __launch_bounds__(kPThreads, 1) void conv_ntp(const float *__restrict__ a, const float *__restrict__ bm,
                                                          float *__restrict__ partial, int M, int N, int L, int B, int n_mt,
@@ -1579,7 +1587,7 @@ __global__ __launch_bounds__(kPThreads, 1) void conv_ntp(const float *__restrict
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int unit = units > 0 ? xcd_tile(blockIdx.x, units) : (int)blockIdx.x;      // (as conv_nt8)
   if (units > 0 && unit >= units) return;
-  if (threadIdx.x >= 256)
+  if (threadIdx.x >= kPCons * 64)
     conv_ntp_role<TAPS, true, ALIGNED>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem);
   else
     conv_ntp_role<TAPS, false, ALIGNED>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem);
