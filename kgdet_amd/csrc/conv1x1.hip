@@ -1482,10 +1482,15 @@ __device__ __forceinline__ void conv_ntp_role(const float *__restrict__ a, const
 #pragma unroll
         for (int i = 0; i < 4; ++i) fb[i] = ok[i] ? fb[i] : 0.0f;       // pixels outside the image multiply a zero
         uint2 ahi, alo, bhi, blo;
+#ifdef KGDET_NTP_ABL_NOSPLIT   // ablation: the operands' bits as they are (wrong results; what would operands split beforehand buy?)
+        ahi = uint2{__float_as_uint(fa[0]), __float_as_uint(fa[1])}; alo = uint2{__float_as_uint(fa[2]), __float_as_uint(fa[3])};
+        bhi = uint2{__float_as_uint(fb[0]), __float_as_uint(fb[1])}; blo = uint2{__float_as_uint(fb[2]), __float_as_uint(fb[3])};
+#else
         split_pair(fa[0], fa[1], ahi.x, alo.x);
         split_pair(fa[2], fa[3], ahi.y, alo.y);
         split_pair(fb[0], fb[1], bhi.x, blo.x);
         split_pair(fb[2], fb[3], bhi.y, blo.y);
+#endif
         *reinterpret_cast<uint2 *>(As + k * 32 * 16) = ahi;
         *reinterpret_cast<uint2 *>(As + kPPart + k * 32 * 16) = alo;
         *reinterpret_cast<uint2 *>(Bs + k * 32 * 16) = bhi;
