@@ -1077,12 +1077,17 @@ __global__ __launch_bounds__(256) void conv1x1_sum(const float *__restrict__ par
   for (long long i = (blockIdx.x * 256LL + threadIdx.x) * 2; i < n; i += gridDim.x * 512LL) {
     f32x2 s = {0.0f, 0.0f};
     int k = 0;
-    for (; k + 4 <= count; k += 4) {
+    for (; k + 8 <= count; k += 8) {      // eight loads in flight, added in slot order
+      f32x2 v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const f32x2 *>(parts + (long long)(k + e) * stride + i);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[e];
+    }
+    for (; k + 2 <= count; k += 2) {
       const f32x2 v0 = *reinterpret_cast<const f32x2 *>(parts + (long long)k * stride + i);
       const f32x2 v1 = *reinterpret_cast<const f32x2 *>(parts + (long long)(k + 1) * stride + i);
-      const f32x2 v2 = *reinterpret_cast<const f32x2 *>(parts + (long long)(k + 2) * stride + i);
-      const f32x2 v3 = *reinterpret_cast<const f32x2 *>(parts + (long long)(k + 3) * stride + i);
-      s = (((s + v0) + v1) + v2) + v3;
+      s = (s + v0) + v1;
     }
     for (; k < count; ++k) s += *reinterpret_cast<const f32x2 *>(parts + (long long)k * stride + i);
     *reinterpret_cast<f32x2 *>(out + i) = s;
@@ -1097,7 +1102,15 @@ __global__ __launch_bounds__(256) void conv1x1_sum_epilogue(const float *__restr
                                                             int relu, int M, long long HW) {
   for (long long i = (blockIdx.x * 256LL + threadIdx.x) * 2; i < n; i += gridDim.x * 512LL) {   // (HW is even: both in one plane)
     f32x2 s = {0.0f, 0.0f};
-    for (int k = 0; k < count; ++k) s += *reinterpret_cast<const f32x2 *>(parts + (long long)k * stride + i);
+    int k = 0;
+    for (; k + 4 <= count; k += 4) {      // (a K split has at most eight parts) four loads in flight, added in slot order
+      f32x2 v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = *reinterpret_cast<const f32x2 *>(parts + (long long)(k + e) * stride + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += v[e];
+    }
+    for (; k < count; ++k) s += *reinterpret_cast<const f32x2 *>(parts + (long long)k * stride + i);
     if (bias) {
       const float b = bias[(i / HW) % M];
       s[0] += b; s[1] += b;
@@ -1129,18 +1142,34 @@ __global__ __launch_bounds__(256) void conv_wsum_fold(const float *__restrict__ 
   const float *pr = parts + (long long)o * CK;
   float *gr = out + (long long)o * CK;
   float dot = 0.0f, sb = 0.0f;
-  for (int q = threadIdx.x; q < CK; q += 256) {          // q: the partials' column (coalesced reads)
-    const int j = T9 ? (q % C) * 9 + q / C : q;          // partial column (tap, channel) -> grad_w column (channel, tap)
-    float g = 0.0f;
+  // Two columns per thread and round, eight slots each: sixteen loads in flight (one workgroup per output channel = one per CU:
+  // with four loads per thread the kernel waited out ~16 memory round trips, 11 us per launch for 16-38 MB).  Every column is
+  // still added in slot order.
+  for (int q = threadIdx.x; q < CK; q += 512) {          // q, q + 256: the partials' columns (coalesced reads)
+    const int q1 = q + 256;
+    const bool two = q1 < CK;
+    const int qb = two ? q1 : q;                         // (a clamped duplicate where the second column does not exist)
+    float g0 = 0.0f, g1 = 0.0f;
     int k = 0;
-    for (; k + 4 <= count; k += 4) {                     // four loads in flight, added in slot order
-      const float v0 = pr[(long long)k * stride + q], v1 = pr[(long long)(k + 1) * stride + q];
-      const float v2 = pr[(long long)(k + 2) * stride + q], v3 = pr[(long long)(k + 3) * stride + q];
-      g = (((g + v0) + v1) + v2) + v3;
+    for (; k + 8 <= count; k += 8) {
+      float v[8], u[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] = pr[(long long)(k + e) * stride + q];
+        u[e] = pr[(long long)(k + e) * stride + qb];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { g0 += v[e]; g1 += u[e]; }
     }
-    for (; k < count; ++k) g += pr[(long long)k * stride + q];
-    dot += wr[j] * g;
-    gr[j] = g * so;
+    for (; k < count; ++k) { g0 += pr[(long long)k * stride + q]; g1 += pr[(long long)k * stride + qb]; }
+    const int j0 = T9 ? (q % C) * 9 + q / C : q;         // partial column (tap, channel) -> grad_w column (channel, tap)
+    dot += wr[j0] * g0;
+    gr[j0] = g0 * so;
+    if (two) {
+      const int j1 = T9 ? (q1 % C) * 9 + q1 / C : q1;
+      dot += wr[j1] * g1;
+      gr[j1] = g1 * so;
+    }
   }
   for (int k = threadIdx.x; k < f.P; k += 256) sb += f.bn_partial[(long long)o * f.P + k];
 #pragma unroll
