@@ -79,5 +79,8 @@ def test_runner_trains_the_hip_detector_on_the_demo_pipeline_and_resumes_bit_ide
                  if a.is_floating_point())
     diff = max(float((a - b).abs().max()) for a, b in zip(model.state_dict().values(), model2.state_dict().values())
                if a.is_floating_point())
-    assert diff <= 4 * spread + 1e-7, (diff, spread)
+    # (the spread of ONE repeat is itself a random number -- 1e-6 .. 3e-5 over this round's runs, the more of the step runs on
+    #  deterministic kernels the smaller --, and Adam turns last-bit gradient differences of near-zero gradients into updates of
+    #  up to lr = 1e-4 per step; a resume that lost the optimizer state differs by >= 1e-4 after its first step)
+    assert diff <= max(4 * spread, 5e-5), (diff, spread)
     assert again.iter == part.iter == 6
