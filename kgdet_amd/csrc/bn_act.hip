@@ -147,18 +147,23 @@ __global__ __launch_bounds__(256) void relu_sum_bwd_kernel(const float *__restri
   const long long base = (long long)plane * HW;
   const int lo = blockIdx.x * per, hi = min(HW, lo + per);
   float s1 = 0.f;
-  if ((HW & 3) == 0) {
-    for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
-      float4 v = *reinterpret_cast<const float4 *>(gz + base + i);
+  {
+    // 16-byte accesses need 4-byte alignment only on gfx950 (tools/microbench/unaligned_x4.hip), so planes whose pixel count is
+    // not a multiple of 4 (25 x 42: the whole of layer 4) take the vector loop too; `per` is a multiple of 4, only the plane's
+    // last chunk can end on a ragged piece, which the first lanes finish one pixel at a time (round 3: a scalar loop for
+    // every such plane)
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int hi4 = lo + ((hi - lo) & ~3);
+    for (int i = lo + threadIdx.x * 4; i < hi4; i += 1024) {
+      f32x4u v = *reinterpret_cast<const f32x4u *>(gz + base + i);
       if (RELU) {
-        const float4 zv = *reinterpret_cast<const float4 *>(z + base + i);
-        v.x = zv.x > 0.f ? v.x : 0.f; v.y = zv.y > 0.f ? v.y : 0.f; v.z = zv.z > 0.f ? v.z : 0.f; v.w = zv.w > 0.f ? v.w : 0.f;
-        *reinterpret_cast<float4 *>(g + base + i) = v;
+        const f32x4u zv = *reinterpret_cast<const f32x4u *>(z + base + i);
+        v[0] = zv[0] > 0.f ? v[0] : 0.f; v[1] = zv[1] > 0.f ? v[1] : 0.f; v[2] = zv[2] > 0.f ? v[2] : 0.f; v[3] = zv[3] > 0.f ? v[3] : 0.f;
+        *reinterpret_cast<f32x4u *>(g + base + i) = v;
       }
-      s1 += (v.x + v.y) + (v.z + v.w);
+      s1 += (v[0] + v[1]) + (v[2] + v[3]);
     }
-  } else {
-    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+    for (int i = hi4 + threadIdx.x; i < hi; i += 256) {
       float v = gz[base + i];
       if (RELU) { v = z[base + i] > 0.f ? v : 0.f; g[base + i] = v; }
       s1 += v;
