@@ -77,13 +77,42 @@ __global__ __launch_bounds__(256) void large_permute_weight(const float *__restr
 // one thread per (image, tap, output pixel): its four corners are entries (((tap*P + pixel) * 4 + corner) << 32 | weight) of
 // their cells' lists.
 // FILL = false: count (cnt[cell]); FILL = true: drop the entries into the lists (cnt serves as the cursor; slot order arbitrary)
+// This lane's slot in the list of `cell` (live lanes only): lanes of a wave that name the same cell share ONE atomic and take
+// consecutive slots (up to four distinct cells per call that way, the remaining lanes one atomic each) -- offsets trained onto a
+// few points put thousands of corners on one counter.  Called by ALL lanes of the wave.
+__device__ __forceinline__ int large_take(int *__restrict__ cnt, int cell, bool live) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int slot = 0;
+  bool pending = live;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const unsigned long long act = __ballot(pending);
+    if (act == 0ull) break;                                   // (uniform)
+    const int leader = __ffsll((long long)act) - 1;
+    const int cf = __shfl(cell, leader);
+    const bool mine = pending && cell == cf;
+    const unsigned long long m = __ballot(mine);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(cnt + cf, __popcll(m));
+    base = __shfl(base, leader);
+    if (mine) {
+      slot = base + __popcll(m & below);
+      pending = false;
+    }
+  }
+  if (pending) slot = atomicAdd(cnt + cell, 1);
+  return slot;
+}
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void large_cell_entries(const DcnProblem p, int *__restrict__ cnt,
                                                           const int *__restrict__ start,
                                                           unsigned long long *__restrict__ vals) {
   const long long n = (long long)p.N * p.K * p.HoWo;
   const int HW = p.H * p.W;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+  for (long long i0 = (long long)blockIdx.x * 256; i0 < n; i0 += (long long)gridDim.x * 256) {   // (uniform trip count per wave)
+    const long long i_raw = i0 + threadIdx.x, i = i_raw < n ? i_raw : n - 1;
     const int hw = (int)(i % p.HoWo);
     const int t = (int)((i / p.HoWo) % p.K);
     const int b = (int)(i / ((long long)p.HoWo * p.K));
@@ -97,11 +126,10 @@ __global__ __launch_bounds__(256) void large_cell_entries(const DcnProblem p, in
     const unsigned long long src = (unsigned long long)((unsigned)(t * p.HoWo + hw)) << 34;   // key = (tap, pixel, corner): unique
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      if (!valid[e]) continue;
-      const int cell = b * HW + tap.o[e];
-      if constexpr (FILL)
-        vals[start[cell] + atomicAdd(cnt + cell, 1)] = src | ((unsigned long long)e << 32) | __float_as_uint(tap.w[e]);
-      else atomicAdd(cnt + cell, 1);
+      const bool live = i_raw < n && valid[e];
+      const int cell = live ? b * HW + tap.o[e] : 0;
+      const int slot = large_take(cnt, cell, live);
+      if (FILL && live) vals[start[cell] + slot] = src | ((unsigned long long)e << 32) | __float_as_uint(tap.w[e]);
     }
   }
 }
@@ -261,7 +289,7 @@ __global__ __launch_bounds__(256) void large_gather_input(const float *__restric
   for (int r = 0; r < kGatherCells; ++r) {
     const int q = q0 + r;
     float acc = 0.0f;
-    if (q < HW) {
+    if (q < HW && len[b * HW + q] <= kLargeWaveSortMax) {     // (longer lists: large_gather_long, chunked over many workgroups)
       const int e0 = start[b * HW + q], e1 = e0 + len[b * HW + q];
       int e = e0;
       for (; e + 8 <= e1; e += 8) batch(e, std::integral_constant<int, 8>{}, acc);
@@ -275,7 +303,82 @@ __global__ __launch_bounds__(256) void large_gather_input(const float *__restric
   const int lane_q = threadIdx.x & (kGatherCells - 1), ch_sub = threadIdx.x / kGatherCells;
   for (int c2 = ch_sub; c2 < 256; c2 += 256 / kGatherCells) {
     const int ch = blockIdx.z * 256 + c2, q = q0 + lane_q;
-    if (ch < C && q < HW) grad_input[((long long)b * C + ch) * HW + q] = tile[lane_q][c2];
+    if (ch < C && q < HW && len[b * HW + q] <= kLargeWaveSortMax) grad_input[((long long)b * C + ch) * HW + q] = tile[lane_q][c2];
+  }
+}
+
+// Cells with more than kLargeWaveSortMax entries (offsets trained onto a few points: tens of thousands of corners on one cell) --
+// in the kernel above one workgroup would walk such a list alone, 4.4 ms per launch at [2, 256, 100, 168] with every sample next
+// to one of 17 points per image.  Their lists are cut into chunks of kLongChunk entries: large_long_chunks numbers the chunks,
+// large_gather_long sums one chunk per workgroup (thread = channel, the same batches of eight loads), large_gather_long_sum adds
+// a cell's chunk sums in chunk order: deterministic, and the cost follows the number of entries, not their distribution.
+constexpr int kLongChunk = 512;
+__global__ __launch_bounds__(256) void large_long_chunks(const int *__restrict__ len, const int *__restrict__ long_q,
+                                                         const int *__restrict__ long_n, int *__restrict__ chunk_total,
+                                                         int *__restrict__ chunk_first, int2 *__restrict__ rec) {
+  const int count = *long_n;
+  for (int qi = blockIdx.x * 256 + threadIdx.x; qi < count; qi += gridDim.x * 256) {
+    const int n = len[long_q[qi]], nch = (n + kLongChunk - 1) / kLongChunk;
+    const int first = atomicAdd(chunk_total, nch);      // (which records a cell gets is arbitrary, what they hold is not)
+    chunk_first[qi] = first;
+    for (int j = 0; j < nch; ++j) rec[first + j] = make_int2(qi, j);
+  }
+}
+
+__global__ __launch_bounds__(256) void large_gather_long(const float *__restrict__ colT, const int *__restrict__ start,
+                                                         const int *__restrict__ len,
+                                                         const unsigned long long *__restrict__ vals,
+                                                         const int *__restrict__ long_q, const int *__restrict__ chunk_total,
+                                                         const int2 *__restrict__ rec, float *__restrict__ part, int C, int K,
+                                                         int HW, int P) {
+  const int total = *chunk_total;
+  const long long KC = (long long)K * C;
+  for (int r = blockIdx.x; r < total; r += gridDim.x) {
+    const int2 rc = rec[r];
+    const int cell = long_q[rc.x], b = cell / HW;
+    const int e0 = start[cell] + rc.y * kLongChunk, e1 = min(start[cell] + len[cell], e0 + kLongChunk);
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const float *base = colT + (long long)b * P * KC + c;
+      float acc = 0.0f;
+      int e = e0;
+      for (; e + 8 <= e1; e += 8) {
+        float v[8], w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const unsigned long long val = vals[e + u];
+          const unsigned tp = (unsigned)(val >> 34);
+          const unsigned t = tp / (unsigned)P, px = tp - t * (unsigned)P;
+          w[u] = __uint_as_float((unsigned)val);
+          v[u] = base[(long long)px * KC + (long long)t * C];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += w[u] * v[u];
+      }
+      for (; e < e1; ++e) {
+        const unsigned long long val = vals[e];
+        const unsigned tp = (unsigned)(val >> 34);
+        const unsigned t = tp / (unsigned)P, px = tp - t * (unsigned)P;
+        acc += __uint_as_float((unsigned)val) * base[(long long)px * KC + (long long)t * C];
+      }
+      part[(long long)r * C + c] = acc;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void large_gather_long_sum(const int *__restrict__ len, const int *__restrict__ long_q,
+                                                             const int *__restrict__ long_n,
+                                                             const int *__restrict__ chunk_first,
+                                                             const float *__restrict__ part, float *__restrict__ grad_input,
+                                                             int C, int HW) {
+  const int count = *long_n;
+  for (int qi = blockIdx.x; qi < count; qi += gridDim.x) {
+    const int cell = long_q[qi], b = cell / HW, q = cell - b * HW;
+    const int nch = (len[cell] + kLongChunk - 1) / kLongChunk, first = chunk_first[qi];
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float s = 0.0f;
+      for (int j = 0; j < nch; ++j) s += part[(long long)(first + j) * C + c];      // chunk order
+      grad_input[((long long)b * C + c) * HW + q] = s;
+    }
   }
 }
 
@@ -341,7 +444,7 @@ __global__ __launch_bounds__(256) void large_grad_offset(const DcnProblem p, con
 }
 
 struct LargePlan {
-  size_t gT, xT, wp, colT, packed, conv_ws, vals, cells, long_q, total;
+  size_t gT, xT, wp, colT, packed, conv_ws, vals, cells, long_q, rec, part, total;
   long long n_entries;
 };
 
@@ -358,8 +461,10 @@ LargePlan large_plan(const DcnProblem &p) {
   L.conv_ws = al(kgdet_conv_apply_workspace_bytes(1, (int)P, p.Og, 1, (int)KC, 1, 1));
   L.vals = al((size_t)L.n_entries * 8);                       // twice: slot order, sorted
   L.cells = al((size_t)(p.N * HW + 64) * 4);                  // twice: counters / cursors (+ the allocation counter), starts
-  L.long_q = al((size_t)(L.n_entries / kLargeWaveSortMax + 64) * 4);
-  L.total = L.gT + L.xT + L.wp + L.colT + L.packed + L.conv_ws + 2 * L.vals + 2 * L.cells + L.long_q;
+  L.long_q = al((size_t)(L.n_entries / kLargeWaveSortMax + 64) * 4);      // twice: the queue, the cells' first chunk records
+  L.rec = al((size_t)(2 * (L.n_entries / kLongChunk) + 64) * 8);             // (long cell, chunk) records
+  L.part = al((size_t)(2 * (L.n_entries / kLongChunk) + 64) * p.C_total * 4);   // chunk sums
+  L.total = L.gT + L.xT + L.wp + L.colT + L.packed + L.conv_ws + 2 * L.vals + 2 * L.cells + 2 * L.long_q + L.rec + L.part;
   return L;
 }
 
@@ -397,7 +502,10 @@ int dcn_bwd_large(const DcnProblem &p, const float *grad_output, int out_channel
   unsigned long long *vals_b = (unsigned long long *)w8; w8 += L.vals;
   int *cell_cnt = (int *)w8; w8 += L.cells;
   int *cell_start = (int *)w8; w8 += L.cells;
-  int *long_q = (int *)w8;
+  int *long_q = (int *)w8; w8 += L.long_q;
+  int *chunk_first = (int *)w8; w8 += L.long_q;
+  int2 *chunk_rec = (int2 *)w8; w8 += L.rec;
+  float *chunk_part = (float *)w8;
   const int C = p.C_total, O = p.Og, K = p.K;
   const long long P = p.HoWo, HW = (long long)p.H * p.W, KC = (long long)K * C;
   const int O_total = out_channels_total > 0 ? out_channels_total : O;
@@ -437,6 +545,13 @@ int dcn_bwd_large(const DcnProblem &p, const float *grad_output, int out_channel
                      (const int *)cell_cnt, vals_a, vals_b, (const int *)long_q, (const int *)long_n);
   hipLaunchKernelGGL(large_gather_input, dim3((unsigned)((HW + kGatherCells - 1) / kGatherCells), p.N, (C + 255) / 256), dim3(256), 0, st, colT,
                      (const int *)cell_start, (const int *)cell_cnt, vals_b, grad_input, C, K, (int)HW, (int)P);
+  int *chunk_total = cell_total + 2;     // (zeroed with the counters)
+  hipLaunchKernelGGL(large_long_chunks, dim3(64), dim3(256), 0, st, (const int *)cell_cnt, (const int *)long_q, (const int *)long_n,
+                     chunk_total, chunk_first, chunk_rec);
+  hipLaunchKernelGGL(large_gather_long, dim3(2048), dim3(256), 0, st, colT, (const int *)cell_start, (const int *)cell_cnt, vals_b,
+                     (const int *)long_q, (const int *)chunk_total, (const int2 *)chunk_rec, chunk_part, C, K, (int)HW, (int)P);
+  hipLaunchKernelGGL(large_gather_long_sum, dim3(1024), dim3(256), 0, st, (const int *)cell_cnt, (const int *)long_q,
+                     (const int *)long_n, (const int *)chunk_first, (const float *)chunk_part, grad_input, C, (int)HW);
   hipLaunchKernelGGL(large_grad_offset, dim3((unsigned)P, p.N), dim3(256), 0, st, p, colT, xT, grad_offset,
                      p.mask ? grad_mask : nullptr);
   KGDET_CHECK_LAUNCH("dcn_bwd_large");
