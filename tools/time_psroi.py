@@ -1,5 +1,5 @@
 """event-timed deformable PS-RoI pooling at the DeformRoIPoolingPack shape: 512 RoIs x 256 channels x 7x7 bins on
-[2, 256, 50, 84]; prints us per launch and the algorithmic HBM rate (python tools/time_psroi.py [S] [no_trans])"""
+[2, 256, 50, 84]; prints us per launch and the algorithmic HBM rate (python tools/time_psroi.py [S] [no_trans] [clustered])"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,6 +13,12 @@ data = torch.from_numpy(rng.normal(size=(B, C, H, W)).astype(np.float32)).cuda()
 x1 = rng.uniform(-30, 1250, R); y1 = rng.uniform(-30, 720, R)
 rois = torch.from_numpy(np.stack([rng.integers(0, B, R), x1, y1, x1 + rng.uniform(8, 600, R), y1 + rng.uniform(8, 500, R)],
                                  1).astype(np.float32)).cuda()
+if len(sys.argv) > 3 and sys.argv[3] == 'clustered':     # proposals as an RPN leaves them: jittered copies around 8 objects per image
+    objs = np.stack([rng.uniform(100, 1100, 16), rng.uniform(100, 600, 16), rng.uniform(60, 400, 16), rng.uniform(60, 400, 16)], 1)
+    which = rng.integers(0, 16, R)
+    cx, cy = objs[which, 0] + rng.normal(0, 12, R), objs[which, 1] + rng.normal(0, 12, R)
+    w, h = objs[which, 2] * np.exp(rng.normal(0, 0.15, R)), objs[which, 3] * np.exp(rng.normal(0, 0.15, R))
+    rois = torch.from_numpy(np.stack([which % 2, cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1).astype(np.float32)).cuda()
 off = torch.from_numpy((rng.normal(size=(R, 2, P, P)) * 0.5).astype(np.float32)).cuda().requires_grad_()
 go = torch.randn(R, C, P, P, device='cuda')
 
