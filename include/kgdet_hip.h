@@ -480,6 +480,11 @@ int kgdet_gn_act_backward_split(const float *grad_y, const float *x, const float
  * x and y [N, C, HW], or both channels-last [N, HW, C] when x_channels_last != 0. */
 int kgdet_gn_act_forward_bf16(const void *x, int32_t x_channels_last, const float *gamma, const float *beta, int32_t groups,
                               float eps, int32_t relu, void *y, int64_t N, int32_t C, int64_t HW, void *stream);
+/* the same for groups of any size (the 100 x 168 level of a five-level head: 8 channels x 16800 pixels per group): beyond 65536
+ * elements the split kernels, `scratch` of kgdet_gn_act_scratch_floats(...) floats (NULL when that is 0) */
+int kgdet_gn_act_forward_bf16_split(const void *x, int32_t x_channels_last, const float *gamma, const float *beta, int32_t groups,
+                                    float eps, int32_t relu, void *y, float *scratch, int64_t N, int32_t C, int64_t HW,
+                                    void *stream);
 
 /*
  * Weighted smooth-L1 sum of the head's box / keypoint losses in one pass each way: what the reference computes as a chain of

@@ -143,24 +143,38 @@ __device__ __forceinline__ void gn_slice(int HW, int S, int s, int &p0, int &p1)
   p1 = min(HW, p0 + per);
 }
 
-__global__ __launch_bounds__(kGnThreads) void gn_split_moments(const float *__restrict__ x, float *__restrict__ parts, int C,
+// (T = __bf16, NHWC: the inference towers' largest level -- 8 channels x 16800 pixels per group -- which the one-workgroup kernel
+//  does not take; element (d, p) of the group at x[n][p][g D + d])
+template <typename T = float, bool NHWC = false>
+__global__ __launch_bounds__(kGnThreads) void gn_split_moments(const T *__restrict__ x, float *__restrict__ parts, int C,
                                                                int G, int HW, int S) {
   __shared__ float red[16];
   const int n = blockIdx.x / G, g = blockIdx.x % G, D = C / G;
-  const long long base = ((long long)n * C + (long long)g * D) * HW;
+  const long long base = NHWC ? (long long)n * HW * C + (long long)g * D : ((long long)n * C + (long long)g * D) * HW;
+  auto at = [&](int d, int p) { return NHWC ? base + (long long)p * C + d : base + (long long)d * HW + p; };
   int p0, p1;
   gn_slice(HW, S, blockIdx.y, p0, p1);
   const float cnt = (float)D * (float)(p1 - p0);
-  float sum = 0.f;
-  for (int d = 0; d < D; ++d)
-    for (int p = p0 + threadIdx.x; p < p1; p += kGnThreads) sum += x[base + (long long)d * HW + p];
-  const float mean = cnt > 0.f ? gn_block_sum(sum, red) / cnt : 0.f;
-  float q = 0.f;
-  for (int d = 0; d < D; ++d)
-    for (int p = p0 + threadIdx.x; p < p1; p += kGnThreads) {
-      const float v = x[base + (long long)d * HW + p] - mean;
+  float sum = 0.f, q = 0.f;
+  float mean;
+  if (NHWC) {      // the D channels of a pixel are contiguous: thread = (pixel, channel)
+    const int ni = (p1 - p0) * D;
+    for (int i = threadIdx.x; i < ni; i += kGnThreads) sum += (float)x[at(i % D, p0 + i / D)];
+    mean = cnt > 0.f ? gn_block_sum(sum, red) / cnt : 0.f;
+    for (int i = threadIdx.x; i < ni; i += kGnThreads) {
+      const float v = (float)x[at(i % D, p0 + i / D)] - mean;
       q += v * v;
     }
+  } else {
+    for (int d = 0; d < D; ++d)
+      for (int p = p0 + threadIdx.x; p < p1; p += kGnThreads) sum += (float)x[at(d, p)];
+    mean = cnt > 0.f ? gn_block_sum(sum, red) / cnt : 0.f;
+    for (int d = 0; d < D; ++d)
+      for (int p = p0 + threadIdx.x; p < p1; p += kGnThreads) {
+        const float v = (float)x[at(d, p)] - mean;
+        q += v * v;
+      }
+  }
   q = gn_block_sum(q, red);
   if (threadIdx.x == 0) {
     float *dst = parts + ((long long)blockIdx.x * S + blockIdx.y) * 2;
@@ -169,13 +183,14 @@ __global__ __launch_bounds__(kGnThreads) void gn_split_moments(const float *__re
   }
 }
 
-__global__ __launch_bounds__(kGnThreads) void gn_split_forward(const float *__restrict__ x, const float *__restrict__ gamma,
+template <typename T = float, bool NHWC = false>
+__global__ __launch_bounds__(kGnThreads) void gn_split_forward(const T *__restrict__ x, const float *__restrict__ gamma,
                                                                const float *__restrict__ beta, float eps, int relu,
-                                                               float *__restrict__ y, float *__restrict__ mean_out,
+                                                               T *__restrict__ y, float *__restrict__ mean_out,
                                                                float *__restrict__ rstd_out, const float *__restrict__ parts,
                                                                int C, int G, int HW, int S) {
   const int n = blockIdx.x / G, g = blockIdx.x % G, D = C / G;
-  const long long base = ((long long)n * C + (long long)g * D) * HW;
+  const long long base = NHWC ? (long long)n * HW * C + (long long)g * D : ((long long)n * C + (long long)g * D) * HW;
   const float *pp = parts + (long long)blockIdx.x * S * 2;
   const float total = (float)D * (float)HW;
   float mean = 0.f;
@@ -193,20 +208,32 @@ __global__ __launch_bounds__(kGnThreads) void gn_split_forward(const float *__re
     m2 += pp[2 * s + 1] + (float)D * (float)(b - a) * dm * dm;
   }
   const float rstd = 1.0f / sqrtf(m2 / total + eps);
-  if (threadIdx.x == 0 && blockIdx.y == 0) {
+  if (threadIdx.x == 0 && blockIdx.y == 0 && mean_out) {
     mean_out[blockIdx.x] = mean;
     rstd_out[blockIdx.x] = rstd;
   }
   int p0, p1;
   gn_slice(HW, S, blockIdx.y, p0, p1);
+  if (NHWC) {      // the D channels of a pixel are contiguous: thread = (pixel, channel)
+    const int cnt = (p1 - p0) * D;
+    for (int i = threadIdx.x; i < cnt; i += kGnThreads) {
+      const int p = p0 + i / D, d = i % D, c = g * D + d;
+      const float sc = rstd * (gamma ? gamma[c] : 1.0f), sh = (beta ? beta[c] : 0.0f) - mean * sc;
+      const long long a = base + (long long)p * C + d;
+      float v = (float)x[a] * sc + sh;
+      if (relu) v = fmaxf(v, 0.0f);
+      y[a] = (T)v;
+    }
+    return;
+  }
   for (int d = 0; d < D; ++d) {
     const int c = g * D + d;
     const float sc = rstd * (gamma ? gamma[c] : 1.0f), sh = (beta ? beta[c] : 0.0f) - mean * sc;
     const long long cb = base + (long long)d * HW;
     for (int p = p0 + threadIdx.x; p < p1; p += kGnThreads) {
-      float v = x[cb + p] * sc + sh;
+      float v = (float)x[cb + p] * sc + sh;
       if (relu) v = fmaxf(v, 0.0f);
-      y[cb + p] = v;
+      y[cb + p] = (T)v;
     }
   }
 }
@@ -335,9 +362,9 @@ extern "C" int kgdet_gn_act_forward_split(const float *x, const float *gamma, co
     hipLaunchKernelGGL(gn_act_forward<float>, dim3((unsigned)(N * groups)), dim3(kGnThreads), 0, (hipStream_t)stream, x, gamma, beta,
                        eps, relu, y, mean, rstd, C, groups, (int)HW);
   } else {
-    hipLaunchKernelGGL(gn_split_moments, dim3((unsigned)(N * groups), S), dim3(kGnThreads), 0, (hipStream_t)stream, x, scratch,
+    hipLaunchKernelGGL((gn_split_moments<float, false>), dim3((unsigned)(N * groups), S), dim3(kGnThreads), 0, (hipStream_t)stream, x, scratch,
                        C, groups, (int)HW, S);
-    hipLaunchKernelGGL(gn_split_forward, dim3((unsigned)(N * groups), S), dim3(kGnThreads), 0, (hipStream_t)stream, x, gamma,
+    hipLaunchKernelGGL((gn_split_forward<float, false>), dim3((unsigned)(N * groups), S), dim3(kGnThreads), 0, (hipStream_t)stream, x, gamma,
                        beta, eps, relu, y, mean, rstd, (const float *)scratch, C, groups, (int)HW, S);
   }
   KGDET_CHECK_LAUNCH("gn_act_forward_split");
@@ -364,6 +391,35 @@ extern "C" int kgdet_gn_act_backward_split(const float *grad_y, const float *x, 
                        y, gamma, mean, rstd, relu, grad_x, dgamma_dbeta, (const float *)scratch, (int)N, C, groups, (int)HW, S);
   }
   KGDET_CHECK_LAUNCH("gn_act_backward_split");
+  return KGDET_OK;
+}
+
+// bf16 in, bf16 out, fp32 arithmetic, groups of ANY size: beyond 65536 elements the pixels of a group are cut into
+// kgdet_gn_act_slices(...) slices (moments per slice, combined in slice order; `scratch` of kgdet_gn_act_scratch_floats(...) floats)
+extern "C" int kgdet_gn_act_forward_bf16_split(const void *x, int32_t x_channels_last, const float *gamma, const float *beta,
+                                               int32_t groups, float eps, int32_t relu, void *y, float *scratch, int64_t N,
+                                               int32_t C, int64_t HW, void *stream) {
+  KGDET_CHECK_SHAPE(N >= 0 && C > 0 && groups > 0 && C % groups == 0 && HW >= 0 && HW < (1LL << 31) &&
+                    (long long)(C / groups) * HW < (1LL << 31), "bad sizes");
+  KGDET_CHECK_SHAPE(C / groups <= 64 && N * groups < (1LL << 31), "at most 64 channels per group");
+  if (N * HW == 0) return KGDET_OK;
+  const int S = gn_slices(N, C, groups, HW);
+  KGDET_CHECK_SHAPE(x && y && (S == 1 || scratch), "null pointer");
+  if (S == 1)
+    return kgdet_gn_act_forward_bf16(x, x_channels_last, gamma, beta, groups, eps, relu, y, N, C, HW, stream);
+  const dim3 grid((unsigned)(N * groups), S);
+  if (x_channels_last) {
+    hipLaunchKernelGGL((gn_split_moments<__bf16, true>), grid, dim3(kGnThreads), 0, (hipStream_t)stream, (const __bf16 *)x, scratch,
+                       C, groups, (int)HW, S);
+    hipLaunchKernelGGL((gn_split_forward<__bf16, true>), grid, dim3(kGnThreads), 0, (hipStream_t)stream, (const __bf16 *)x, gamma,
+                       beta, eps, relu, (__bf16 *)y, (float *)nullptr, (float *)nullptr, (const float *)scratch, C, groups, (int)HW, S);
+  } else {
+    hipLaunchKernelGGL((gn_split_moments<__bf16, false>), grid, dim3(kGnThreads), 0, (hipStream_t)stream, (const __bf16 *)x, scratch,
+                       C, groups, (int)HW, S);
+    hipLaunchKernelGGL((gn_split_forward<__bf16, false>), grid, dim3(kGnThreads), 0, (hipStream_t)stream, (const __bf16 *)x, gamma,
+                       beta, eps, relu, (__bf16 *)y, (float *)nullptr, (float *)nullptr, (const float *)scratch, C, groups, (int)HW, S);
+  }
+  KGDET_CHECK_LAUNCH("gn_act_forward_bf16_split");
   return KGDET_OK;
 }
 

@@ -116,13 +116,23 @@ def gn_act_bf16_applicable(x, norm):
             and (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last))
             and x.numel() > 0 and not torch.is_grad_enabled()
             and norm.num_channels // norm.num_groups <= 64
-            and (norm.num_channels // norm.num_groups) * x.shape[2] * x.shape[3] <= 65536)
+            and (norm.num_channels // norm.num_groups) * x.shape[2] * x.shape[3] < (2 ** 31 if GN_SPLIT else 65537))
 
 
 def gn_act_bf16(x, norm, relu):
     from . import _lib
     N, C = x.shape[0], x.shape[1]
     y = torch.empty_like(x)      # (x's layout: a channels-last tower stays channels-last)
+    if (C // norm.num_groups) * x.shape[2] * x.shape[3] > 65536:
+        # the largest level of a five-level head (8 channels x 16800 pixels per group): the split kernels (round 4; torch's
+        # path here was RowwiseMoments + two element-wise passes + casts per layer: ~0.25 ms of a config-5 batch each)
+        scratch = _gn_scratch(x, N, C, norm.num_groups, x.shape[2] * x.shape[3])
+        _lib.check(_lib.lib().kgdet_gn_act_forward_bf16_split(
+            _lib.ptr(x), ctypes.c_int32(0 if x.is_contiguous() else 1), _lib.ptr(norm.weight), _lib.ptr(norm.bias),
+            ctypes.c_int32(norm.num_groups), ctypes.c_float(norm.eps), ctypes.c_int32(1 if relu else 0), _lib.ptr(y),
+            _lib.ptr(scratch), ctypes.c_int64(N), ctypes.c_int32(C), ctypes.c_int64(x.shape[2] * x.shape[3]),
+            _lib.current_stream()), 'gn_act_forward_bf16_split')
+        return y
     _lib.check(_lib.lib().kgdet_gn_act_forward_bf16(
         _lib.ptr(x), ctypes.c_int32(0 if x.is_contiguous() else 1), _lib.ptr(norm.weight), _lib.ptr(norm.bias), ctypes.c_int32(norm.num_groups), ctypes.c_float(norm.eps),
         ctypes.c_int32(1 if relu else 0), _lib.ptr(y), ctypes.c_int64(N), ctypes.c_int32(C),

@@ -645,8 +645,9 @@ def test_fused_offset_to_pts_equals_the_torch_chain(B, C, H, W, stride, y_first)
 
 
 @pytest.mark.parametrize('channels_last', [False, True])
+@pytest.mark.parametrize('shape', [(2, 256, 25, 42), (3, 256, 100, 168)])
 @pytest.mark.parametrize('relu', [True, False])
-def test_bf16_group_norm_relu_equals_autocast_chain(relu, channels_last):
+def test_bf16_group_norm_relu_equals_autocast_chain(relu, channels_last, shape):
     """inference under autocast: GroupNorm (+ ReLU) reading and writing bf16 (csrc/group_norm.hip gn_act_forward<bf16>) against
     torch's chain -- bf16 -> fp32 cast, fp32 group_norm, ReLU, fp32 -> bf16 cast: the same tensor up to one bf16 ulp where the fp32
     results differ in rounding"""
@@ -656,7 +657,8 @@ def test_bf16_group_norm_relu_equals_autocast_chain(relu, channels_last):
     gn = torch.nn.GroupNorm(32, 256).cuda()
     gn.weight.data.normal_(1.0, 0.5)
     gn.bias.data.normal_(0, 0.5)
-    x = (torch.randn(8, 256, 25, 42, device='cuda') * 3 + 1).bfloat16()
+    # (100 x 168: 8 channels x 16800 pixels per group -- the split kernels, kgdet_gn_act_forward_bf16_split)
+    x = (torch.randn(*shape, device='cuda') * 3 + 1).bfloat16()
     if channels_last:
         x = x.contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
