@@ -54,8 +54,9 @@ class RepPointsDetectorKp(nn.Module):
         x = self.backbone(img)
         if self.with_neck:
             x = self.neck(x)
-        if not torch.is_grad_enabled():
+        if not torch.is_grad_enabled() and not getattr(self.bbox_head, 'channels_last_inference', False):
             # the bf16 inference backbone runs channels-last (backbone.conv_bn); the head's kernels take NCHW
+            # (a head whose towers stay channels-last -- heads_serial -- takes the maps as they come)
             x = tuple(o.contiguous() for o in x)
         return x
 

@@ -16,6 +16,8 @@ keypoint weights are normalised per row without the x4 of the KGDet head (SER:46
 from __future__ import division
 
 import numpy as np
+import os as _os
+
 import torch
 import torch.nn as nn
 
@@ -141,6 +143,12 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
         if self.parallel_reppts:
             normal_init(self.reppts_init_conv, std=0.01)
             normal_init(self.reppts_refine_dfmconv, std=0.01)
+
+    # KGDET_SERIAL_CL=1 (A/B, off): inference under autocast with the towers on the pyramid's channels-last maps as they come --
+    # MIOpen's NHWC kernels without the layout conversions it wraps around NCHW calls (~100 launches, ~1 ms of a batch of 8).
+    # Measured 402.8 against 424.0 img/s: GroupNorm on a channels-last map reads 16 bytes of every 512 (a group's 8 channels of
+    # a pixel) -- gn_split_moments 150 us against 51 us at 100 x 168 -- and the deformable stages need an NCHW copy per tower.
+    channels_last_inference = _os.environ.get('KGDET_SERIAL_CL', '0') == '1'
 
     def _dfm(self, conv, feat, offset):
         """relu(deform_conv) with the ReLU fused into the kernel epilogue"""
