@@ -26,6 +26,7 @@ from .heads import PointHeadMixin
 from .layers import ConvModule, bias_init_with_prob, normal_init
 
 GROUPED_REFINE = __import__('os').environ.get('KGDET_SERIAL_GROUPED_DCN', '1') == '1'   # 0: one call per deformable convolution (A/B)
+SELECT_FIRST = __import__('os').environ.get('KGDET_SERIAL_SELECT_FIRST', '1') == '1'     # 0: convert whole maps, then keep nms_pre rows (A/B)
 from .losses import SmoothL1Loss
 import os
 
@@ -415,19 +416,25 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
             return False
         return n * 36 <= 160 * 1024 - 256 and C <= 64 and C * cfg.max_per_img <= 16384
 
-    def _decode_level_batch(self, cls_score, bbox_pred, kpt_pred, points, stride, lim_w, lim_h, cfg):
-        """one level of get_bboxes_single for all images at once: boxes [B,n,4], scores [B,n,C], landmarks [B,n,K,3]"""
-        B, num_kpt = cls_score.shape[0], self.num_keypts
+    def _decode_level_batch(self, cls_score, bbox_pred, kpt_pred, points, stride, lim_w, lim_h, cfg, selected=None):
+        """one level of get_bboxes_single for all images at once: boxes [B,n,4], scores [B,n,C], landmarks [B,n,K,3].
+        selected = (scores [B,k,C], centres [B,k,2]): the nms_pre candidates were chosen beforehand and bbox_pred / kpt_pred hold
+        THEIR rows as [B, 4, k, 1] / [B, K ch, k, 1] (get_bboxes_packed_tensor: the conversions then run on k = 1000 rows per
+        level instead of the whole map -- 474 MB of landmark rows at 100 x 168 for a batch of 8)"""
+        B, num_kpt = cls_score.shape[0] if selected is None else selected[0].shape[0], self.num_keypts
         ch = kpt_pred.size(1) // num_kpt
         assert ch == 2 or ch == 3
-        scores = cls_score.permute(0, 2, 3, 1).reshape(B, -1, self.cls_out_channels).sigmoid()
+        if selected is None:
+            scores = cls_score.permute(0, 2, 3, 1).reshape(B, -1, self.cls_out_channels).sigmoid()
+        else:
+            scores = selected[0]
         bbox_pred = bbox_pred.permute(0, 2, 3, 1).reshape(B, -1, 4)
         kpt_pred = kpt_pred.permute(0, 2, 3, 1).reshape(B, -1, num_kpt, ch)
         if ch == 2:
             kpt_pred = torch.cat([kpt_pred, kpt_pred.new_ones(kpt_pred[..., :1].shape)], dim=-1)
-        ctr = points[:, :2].unsqueeze(0).expand(B, -1, -1)
+        ctr = points[:, :2].unsqueeze(0).expand(B, -1, -1) if selected is None else selected[1]
         nms_pre = cfg.get('nms_pre', -1)
-        if nms_pre > 0 and scores.shape[1] > nms_pre:
+        if selected is None and nms_pre > 0 and scores.shape[1] > nms_pre:
             _, top = scores.max(dim=2)[0].topk(nms_pre, dim=1)
             ctr = torch.gather(ctr, 1, top.unsqueeze(-1).expand(B, nms_pre, 2))
             bbox_pred = torch.gather(bbox_pred, 1, top.unsqueeze(-1).expand(B, nms_pre, 4))
@@ -449,7 +456,7 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
         kpts[:, :, 1::3] = clamp(kpts[:, :, 1::3], lim_h)
         return bboxes, scores, kpts
 
-    def get_bboxes_packed(self, cls_scores, bbox_preds, kpt_preds, mlvl_points, img_metas, cfg, rescale=True):
+    def get_bboxes_packed(self, cls_scores, bbox_preds, kpt_preds, mlvl_points, img_metas, cfg, rescale=True, selected=None):
         """refine-stage maps -> fixed-size device tensors (det [B,M,5], labels [B,M], landmarks [B,M,3K], count [B])"""
         from .heads import RepPointsHeadKp3RepCas1AssignOnce as _K
         from .postprocess import multiclass_nms_kp_fused, multiclass_soft_nms_kp_fused
@@ -458,7 +465,8 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
         lim_h = _K._per_image([float(m['img_shape'][0]) for m in img_metas], device)
         decoded = [self._decode_level_batch(cls_scores[i].detach().float(), bbox_preds[i].detach().float(),
                                             kpt_preds[i].detach().float(), mlvl_points[i], self.point_strides[i],
-                                            lim_w, lim_h, cfg) for i in range(len(cls_scores))]
+                                            lim_w, lim_h, cfg, None if selected is None else selected[i])
+                   for i in range(len(cls_scores))]
         bboxes = torch.cat([d[0] for d in decoded], dim=1)
         scores = torch.cat([d[1] for d in decoded], dim=1)
         kpts = torch.cat([d[2] for d in decoded], dim=1)
@@ -482,11 +490,34 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
         cls = [t.float() for t in cls_scores]
         if not self._packed_ok(cls, img_metas, cfg, rescale):
             return None
-        box = [self.points2bbox(r.float()) for r in reppts_preds_refine]
-        kpt = [self.points2kpt(k.float()) for k in keypts_preds_refine]
         points = [self.point_generators[i].grid_points(cls[i].size()[-2:], self.point_strides[i], device=cls[i].device)
                   for i in range(len(cls))]
-        det, label, kp, count = self.get_bboxes_packed(cls, box, kpt, points, img_metas, cfg, rescale)
+        nms_pre = cfg.get('nms_pre', -1)
+        if SELECT_FIRST and nms_pre > 0:
+            # The nms_pre candidates of a level are a function of its scores alone: choose them FIRST and convert only their
+            # rows of the 588-channel point maps (get_bboxes_single, like the reference, converts every location of the map and
+            # then keeps 1000: for a batch of 8 at 100 x 168 the float cast, the (y, x) -> (x, y) swap and the visibility column
+            # moved ~1.5 GB).  Gathering rows commutes with the per-location arithmetic: same values.
+            box, kpt, selected = [], [], []
+            for i in range(len(cls)):
+                B, n = cls[i].shape[0], cls[i].shape[2] * cls[i].shape[3]
+                scores = cls[i].permute(0, 2, 3, 1).reshape(B, n, self.cls_out_channels).sigmoid()
+                ctr = points[i][:, :2].unsqueeze(0).expand(B, -1, -1)
+                rep, kp_ = reppts_preds_refine[i].detach().reshape(B, -1, n), keypts_preds_refine[i].detach().reshape(B, -1, n)
+                if n > nms_pre:
+                    _, top = scores.max(dim=2)[0].topk(nms_pre, dim=1)
+                    ctr = torch.gather(ctr, 1, top.unsqueeze(-1).expand(B, nms_pre, 2))
+                    scores = torch.gather(scores, 1, top.unsqueeze(-1).expand(B, nms_pre, scores.shape[2]))
+                    rep = torch.gather(rep, 2, top.unsqueeze(1).expand(B, rep.shape[1], nms_pre))
+                    kp_ = torch.gather(kp_, 2, top.unsqueeze(1).expand(B, kp_.shape[1], nms_pre))
+                box.append(self.points2bbox(rep.float().unsqueeze(-1)))
+                kpt.append(self.points2kpt(kp_.float().unsqueeze(-1)))
+                selected.append((scores, ctr))
+            det, label, kp, count = self.get_bboxes_packed(cls, box, kpt, points, img_metas, cfg, rescale, selected=selected)
+        else:
+            box = [self.points2bbox(r.float()) for r in reppts_preds_refine]
+            kpt = [self.points2kpt(k.float()) for k in keypts_preds_refine]
+            det, label, kp, count = self.get_bboxes_packed(cls, box, kpt, points, img_metas, cfg, rescale)
         B, M = label.shape
         return torch.cat([det, label.unsqueeze(-1).float(), count.view(B, 1, 1).expand(B, M, 1).float(), kp], dim=-1)
 
