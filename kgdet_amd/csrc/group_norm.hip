@@ -157,7 +157,27 @@ __global__ __launch_bounds__(kGnThreads) void gn_split_moments(const T *__restri
   const float cnt = (float)D * (float)(p1 - p0);
   float sum = 0.f, q = 0.f;
   float mean;
-  if (NHWC) {      // the D channels of a pixel are contiguous: thread = (pixel, channel)
+  if (NHWC && D == 8 && sizeof(T) == 2 && C % 8 == 0) {
+    // the usual case (256 channels in 32 groups, bf16): the group's 8 channels of a pixel are ONE 16-byte load
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto px = [&](int p) { return *reinterpret_cast<const u32x4 *>(x + base + (long long)p * C); };
+    auto lo = [](unsigned u) { return __uint_as_float(u << 16); };
+    auto hi = [](unsigned u) { return __uint_as_float(u & 0xffff0000u); };
+    for (int p = p0 + threadIdx.x; p < p1; p += kGnThreads) {
+      const u32x4 u = px(p);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sum += lo(u[k]) + hi(u[k]);
+    }
+    mean = cnt > 0.f ? gn_block_sum(sum, red) / cnt : 0.f;
+    for (int p = p0 + threadIdx.x; p < p1; p += kGnThreads) {
+      const u32x4 u = px(p);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float a = lo(u[k]) - mean, b = hi(u[k]) - mean;
+        q += a * a + b * b;
+      }
+    }
+  } else if (NHWC) {      // the D channels of a pixel are contiguous: thread = (pixel, channel)
     const int ni = (p1 - p0) * D;
     for (int i = threadIdx.x; i < ni; i += kGnThreads) sum += (float)x[at(i % D, p0 + i / D)];
     mean = cnt > 0.f ? gn_block_sum(sum, red) / cnt : 0.f;
@@ -214,6 +234,32 @@ __global__ __launch_bounds__(kGnThreads) void gn_split_forward(const T *__restri
   }
   int p0, p1;
   gn_slice(HW, S, blockIdx.y, p0, p1);
+  if (NHWC && D == 8 && sizeof(T) == 2 && C % 8 == 0) {      // 16 bytes = the group's 8 bf16 channels of a pixel
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    float sc[8], sh[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const int c = g * 8 + d;
+      sc[d] = rstd * (gamma ? gamma[c] : 1.0f);
+      sh[d] = (beta ? beta[c] : 0.0f) - mean * sc[d];
+    }
+    for (int p = p0 + threadIdx.x; p < p1; p += kGnThreads) {
+      const long long a = base + (long long)p * C;
+      const u32x4 u = *reinterpret_cast<const u32x4 *>(x + a);
+      u32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float v0 = __uint_as_float(u[k] << 16) * sc[2 * k] + sh[2 * k];
+        float v1 = __uint_as_float(u[k] & 0xffff0000u) * sc[2 * k + 1] + sh[2 * k + 1];
+        if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
+        o[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v0, v1}, bf16x2));
+      }
+      *reinterpret_cast<u32x4 *>(y + a) = o;
+    }
+    return;
+  }
   if (NHWC) {      // the D channels of a pixel are contiguous: thread = (pixel, channel)
     const int cnt = (p1 - p0) * D;
     for (int i = threadIdx.x; i < cnt; i += kGnThreads) {
