@@ -46,6 +46,54 @@ __global__ __launch_bounds__(kGnThreads) void gn_act_forward(const T *__restrict
   const int total = D * HW;
   // element i of the group: NHWC walks the D channels of a pixel first (contiguous in x)
   auto x_at = [&](int i) { return NHWC ? xbase + (long long)(i / D) * C + (i % D) : xbase + i; };
+  if constexpr (NHWC && sizeof(T) == 2) {
+    if (D == 8 && C % 8 == 0) {      // the group's 8 bf16 channels of a pixel: one 16-byte access (thread = pixel)
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      auto px = [&](int p) { return *reinterpret_cast<const u32x4 *>(x + xbase + (long long)p * C); };
+      float s8 = 0.f;
+      for (int p = threadIdx.x; p < HW; p += kGnThreads) {
+        const u32x4 u = px(p);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s8 += __uint_as_float(u[k] << 16) + __uint_as_float(u[k] & 0xffff0000u);
+      }
+      const float mean8 = gn_block_sum(s8, red) / (float)total;
+      float q8 = 0.f;
+      for (int p = threadIdx.x; p < HW; p += kGnThreads) {
+        const u32x4 u = px(p);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float a = __uint_as_float(u[k] << 16) - mean8, b = __uint_as_float(u[k] & 0xffff0000u) - mean8;
+          q8 += a * a + b * b;
+        }
+      }
+      const float rstd8 = 1.0f / sqrtf(gn_block_sum(q8, red) / (float)total + eps);
+      if (threadIdx.x == 0 && mean_out) {
+        mean_out[blockIdx.x] = mean8;
+        rstd_out[blockIdx.x] = rstd8;
+      }
+      float ga[8], be[8];
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        ga[d] = gamma ? gamma[g * 8 + d] : 1.0f;
+        be[d] = beta ? beta[g * 8 + d] : 0.0f;
+      }
+      for (int p = threadIdx.x; p < HW; p += kGnThreads) {
+        const u32x4 u = px(p);
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float v0 = (__uint_as_float(u[k] << 16) - mean8) * rstd8 * ga[2 * k] + be[2 * k];
+          float v1 = (__uint_as_float(u[k] & 0xffff0000u) - mean8) * rstd8 * ga[2 * k + 1] + be[2 * k + 1];
+          if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
+          o[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v0, v1}, bf16x2));
+        }
+        *reinterpret_cast<u32x4 *>(y + xbase + (long long)p * C) = o;
+      }
+      return;
+    }
+  }
   float s = 0.f;
   for (int i = threadIdx.x; i < total; i += kGnThreads) s += (float)x[x_at(i)];
   const float mean = gn_block_sum(s, red) / (float)total;
