@@ -428,7 +428,9 @@ int gn_slices(int64_t N, int32_t C, int32_t groups, int64_t HW) {
   const long long elems = (long long)(C / groups) * HW;
   if (elems <= kGnSplitElems) return 1;
   long long S = (elems + 16383) / 16384;
-  while (S > 1 && N * groups * S > 1024) --S;          // (enough workgroups to fill the chip twice is plenty)
+  // (enough workgroups to fill the chip twice is plenty; never back to ONE slice: the one-workgroup kernels reject groups
+  // beyond kGnSplitElems, and large batches -- N * groups >= 1024 -- would be sent there)
+  while (S > 2 && N * groups * S > 1024) --S;
   return (int)(S > kGnMaxSlices ? kGnMaxSlices : S);
 }
 }  // namespace

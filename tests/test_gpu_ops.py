@@ -645,7 +645,7 @@ def test_fused_offset_to_pts_equals_the_torch_chain(B, C, H, W, stride, y_first)
 
 
 @pytest.mark.parametrize('channels_last', [False, True])
-@pytest.mark.parametrize('shape', [(2, 256, 25, 42), (3, 256, 100, 168)])
+@pytest.mark.parametrize('shape', [(2, 256, 25, 42), (3, 256, 100, 168), (32, 256, 100, 168)])
 @pytest.mark.parametrize('relu', [True, False])
 def test_bf16_group_norm_relu_equals_autocast_chain(relu, channels_last, shape):
     """inference under autocast: GroupNorm (+ ReLU) reading and writing bf16 (csrc/group_norm.hip gn_act_forward<bf16>) against
@@ -657,7 +657,8 @@ def test_bf16_group_norm_relu_equals_autocast_chain(relu, channels_last, shape):
     gn = torch.nn.GroupNorm(32, 256).cuda()
     gn.weight.data.normal_(1.0, 0.5)
     gn.bias.data.normal_(0, 0.5)
-    # (100 x 168: 8 channels x 16800 pixels per group -- the split kernels, kgdet_gn_act_forward_bf16_split)
+    # (100 x 168: 8 channels x 16800 pixels per group -- the split kernels, kgdet_gn_act_forward_bf16_split; 32 images x 32 groups
+    # = 1024 (image, group) pairs: the slice count must not fall back to ONE slice, which the one-workgroup kernel rejects)
     x = (torch.randn(*shape, device='cuda') * 3 + 1).bfloat16()
     if channels_last:
         x = x.contiguous(memory_format=torch.channels_last)

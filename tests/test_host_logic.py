@@ -306,6 +306,21 @@ def test_shared_library_exports_every_declared_symbol():
     assert b'too small' in L.kgdet_last_error()
 
 
+def test_group_norm_slice_count_never_returns_to_one_workgroup_for_large_groups():
+    """a group beyond the one-workgroup kernels' 65536 elements keeps at least two slices however many
+    (image, group) pairs there are (batch 32 x 32 groups at 100 x 168 used to get S = 1 and then a shape error)"""
+    import ctypes
+    from kgdet_amd import _lib
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    L.kgdet_gn_act_slices.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64]
+    L.kgdet_gn_act_slices.restype = ctypes.c_int32
+    assert L.kgdet_gn_act_slices(2, 256, 32, 25 * 42) == 1                  # 8 x 1050 elements: one workgroup
+    for n in (1, 2, 8, 31, 32, 64, 1000):
+        s = L.kgdet_gn_act_slices(n, 256, 32, 100 * 168)                   # 8 x 16800 = 134400 elements per group
+        assert 2 <= s <= 16, (n, s)
+    assert L.kgdet_gn_act_slices(4096, 64, 1, 200 * 336) >= 2
+
+
 def test_ops_have_no_cpu_fallback():
     from kgdet_amd import dcn, focal_loss, moment
     with pytest.raises(NotImplementedError):
