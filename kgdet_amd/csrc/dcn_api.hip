@@ -339,7 +339,10 @@ size_t kgdet_dcn_workspace_bytes(const kgdet_dcn_shape *s) {
   if (derive(s, d)) return 0;
   // slabs for stream-K partial tiles + (forward) the tap records / (backward-weight) a packed gradient image
   const size_t after_slabs = (size_t)s->groups * d.fwd_image_floats() * sizeof(float);
-  const size_t fwd_and_wgrad = slab_bytes() + (after_slabs > tap_table_bytes(s, d) ? after_slabs : tap_table_bytes(s, d));
+  // (forward: the tap records and, for the column-wave kernel, the blocked copy of the input behind them)
+  const size_t fwd_tables = tap_table_bytes(s, d) +
+                            (plane_ok(s, d) ? 512 + s->groups * align_up(dcn_fwd_cw_xblk_bytes(s->N, d.Cg_pad, s->H * s->W), 256) : 0);
+  const size_t fwd_and_wgrad = slab_bytes() + (after_slabs > fwd_tables ? after_slabs : fwd_tables);
   const BwdLdsPlan pl = plan_bwd_lds(s, d);
   const size_t bwd_in = pl.ok ? (pl.slab_floats + pl.off_floats + pl.mask_floats) * sizeof(float) +
                                     pl.rowptr_ints * sizeof(int) + pl.entry_pairs * 8 + 64
@@ -376,6 +379,8 @@ size_t kgdet_dcn_group_workspace_bytes(int32_t n, const kgdet_dcn_shape *const *
     Derived d;
     if (!shapes || derive(shapes[i], d)) return 0;
     tables += tap_table_bytes(shapes[i], d);
+    if (plane_ok(shapes[i], d))   // (column-wave forward: a blocked copy of the input behind the tap records)
+      tables += 512 + shapes[i]->groups * align_up(dcn_fwd_cw_xblk_bytes(shapes[i]->N, d.Cg_pad, shapes[i]->H * shapes[i]->W), 256);
     if (plane_bwd_input_ok(shapes[i], d)) bwd_tables += inv_tables_all(shapes[i], d) + inv_sums_all(shapes[i], d);
     wgrad_tables += align_up(tap_table_bytes(shapes[i], d), 256) +
                     (size_t)shapes[i]->groups * (d.Og_pad / kTileM) * shapes[i]->N * ceil_div(d.Ho * d.Wo, kChunk) * 16384;
@@ -532,6 +537,13 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
   int max_hw = 0;
   static const bool pairs_env = getenv("KGDET_DCN_PAIRS") != nullptr && atoi(getenv("KGDET_DCN_PAIRS")) != 0;   // A/B switch
   const bool pairs_off = !(pairs_env || g_options[KGDET_OPT_TAP_PAIRS] != 0);   // (off by default: measured slower)
+  static const int cw_env = getenv("KGDET_DCN_CW") ? atoi(getenv("KGDET_DCN_CW")) : 0;   // A/B switch
+  auto cw_ok = [&]() {
+    if (!cw_env || parts != 2 || grp_pair || !grp.static_ranges) return false;
+    for (int i = 0; i < grp.n; ++i)
+      if (grp.p[i].K < 3 || grp.p[i].H * grp.p[i].W > kPlaneMaxHW) return false;
+    return true;
+  };
   auto flush = [&]() -> int {
     if (grp.n == 0) return KGDET_OK;
     const int Gf = G;                                  // (the full grid: record builders)
@@ -546,6 +558,30 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
       attr_set = true;
     }
     grp.pair_mode = grp_pair ? 1 : 0;
+    const bool use_cw = cw_ok();
+    for (int i = 0; i < grp.n; ++i) { grp.p[i].xblk = nullptr; grp.p[i].build_xblk = 0; }
+    if (use_cw) {   // blocked copies of the distinct inputs behind the tap records (written by dcn_build_taps' blocks)
+      size_t used = align_up(table_used, 256);
+      for (int i = 0; i < grp.n; ++i) {
+        DcnProblem &q = grp.p[i];
+        for (int j = 0; j < i && !q.xblk; ++j) {
+          const DcnProblem &o = grp.p[j];
+          if (o.x == q.x && o.c_base == q.c_base && o.Cg == q.Cg && o.N == q.N && o.H == q.H && o.W == q.W && o.C_total == q.C_total)
+            q.xblk = o.xblk;
+        }
+        if (!q.xblk) {
+          const size_t xb = align_up(dcn_fwd_cw_xblk_bytes(q.N, q.Cg_pad, q.H * q.W), 256);
+          if (slab_bytes() + used + xb > workspace_bytes) {
+            set_error("workspace too small for the blocked inputs: need %zu bytes, got %zu (kgdet_dcn_group_workspace_bytes)",
+                      slab_bytes() + used + xb, workspace_bytes);
+            return KGDET_E_WORKSPACE;
+          }
+          q.xblk = reinterpret_cast<const float *>(table_base + used);
+          q.build_xblk = 1;
+          used += xb;
+        }
+      }
+    }
     hipLaunchKernelGGL(dcn_build_taps, dim3(2 * Gf, grp.n), dim3(256), 0, (hipStream_t)stream, grp);
     const int threads = dcn_fwd_plane_threads();
     if (grp_pair) {   // K >= 7 everywhere in the group: half-chunk planes, tap-pair stages (dcn_plane_pairs.h)
@@ -565,6 +601,15 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
         hipLaunchKernelGGL(dcn_fwd_plane_pairs<1>, dim3(G), dim3(768), ldsp, (hipStream_t)stream, grp, (float *)workspace);
       else
         hipLaunchKernelGGL(dcn_fwd_plane_pairs<2>, dim3(G), dim3(768), ldsp, (hipStream_t)stream, grp, (float *)workspace);
+    } else if (use_cw) {   // column-wave kernel (dcn_forward_cw.hip): static ranges of whole chunks, K >= 3, split operands
+      static thread_local bool cw_attr_set = false;
+      if (!cw_attr_set) {
+        KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_fwd_cw<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+        cw_attr_set = true;
+      }
+      grp.wave_layout = 1;   // (its slabs are written in the register-image format of layout 1)
+      hipLaunchKernelGGL((dcn_fwd_cw<2>), dim3(G), dim3(dcn_fwd_cw_threads()), dcn_fwd_cw_lds_bytes(parts), (hipStream_t)stream, grp,
+                         (float *)workspace);
     } else {
       const size_t lds2 = plan_plane_lds(grp, lds, dcn_fwd_plane_fixed_lds_bytes(parts));
       grp.wave_layout = dcn_plane_wave_layout();

@@ -182,6 +182,8 @@ struct DcnProblem {
   int gov_slots, gov_ld;  //         slots per (image, tap); floats per slot (all output channels of the convolution, padded to 16)
   int gov_c0;             //         first channel of this (sub-)problem's grad_out window inside a Gov vector
   int build_taps;         // this problem owns `taps` (others of the group may alias it: same offsets and geometry)
+  const float *xblk;      // column-wave forward kernel: the blocked copy of x (dcn_forward_cw.hip), or nullptr
+  int build_xblk;         // this problem owns `xblk` (dcn_build_taps writes it)
   const float *bias;    // [O_total] or nullptr
   float *out;           // forward: [N, O_total, Ho, Wo]
   const float *gout;    // grad_offset kernel: grad_output [N, O_total, Ho, Wo]
@@ -232,6 +234,29 @@ struct DcnFwdGroup {
   DcnProblem p[kMaxFwdGroup];
 };
 
+// The blocked copy of x the column-wave kernel's LDS-DMA reads: x[image, c_base + 16 c .. + 15, :, :] as
+// [image][chunk c][quad][pixels padded to 64][4 channels] fp32 -- exactly the LDS plane's units, each 1 KiB contiguous.  Channels
+// past Cg repeat the last one, pixels past H*W the last pixel (as dcn_plane_copy does).  One wave per unit; called from
+// dcn_build_taps' blocks.
+__device__ __forceinline__ void dcn_block_x_body(const DcnProblem &p, int first_unit, int unit_step) {
+  const int HW = p.H * p.W, nblk = (HW + 63) >> 6, P64 = nblk * 64, n_c16 = p.chunks_per_tap;
+  const int lane = threadIdx.x & 63;
+  const long long total = (long long)p.N * n_c16 * 4 * nblk;
+  for (long long u = first_unit; u < total; u += unit_step) {
+    const int blk = (int)(u % nblk);
+    const int quad = (int)((u / nblk) & 3);
+    const int c = (int)((u / (4 * nblk)) % n_c16);
+    const int b = (int)(u / ((long long)4 * nblk * n_c16));
+    const int px = min(blk * 64 + lane, HW - 1);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ch = min(c * kChunk + quad * 4 + e, p.Cg - 1);
+      v[e] = p.x[((long long)b * p.C_total + p.c_base + ch) * HW + px];
+    }
+    reinterpret_cast<f32x4 *>(const_cast<float *>(p.xblk))[(((long long)b * n_c16 + c) * 4 + quad) * P64 + blk * 64 + lane] = v;
+  }
+}
 // Unit order of the plane kernel.  The weight image of a 7x7 conv is 25 MB (bf16 hi + lo) and every pixel tile
 // streams all of it: with tile-major units the 256 workgroups pull ~0.8 GB per grouped launch through the
 // fabric, which is what bounds the kernel (the per-XCD L2 is 4 MB).  So the reduction range of problem p is cut

@@ -103,7 +103,7 @@ size_t dcn_fwd_plane_pairs_lds_bytes(int parts, int HW) {
 #ifdef KGDET_PLANE_TRACE
 }  // namespace kgdet
 extern "C" int kgdet_debug_read_plane_trace(unsigned long long *out) {   // the forward kernel's copy
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(kgdet::g_plane_trace), sizeof(unsigned long long) * 256 * 2 * 10);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(kgdet::g_plane_trace), sizeof(unsigned long long) * 256 * 16 * 10);
 }
 namespace kgdet {
 #endif
@@ -114,6 +114,7 @@ namespace kgdet {
 // modulated (v2) problems fold the mask into the weights (:570-632).
 __global__ __launch_bounds__(256) void dcn_build_taps(const DcnFwdGroup grp) {
   const DcnProblem &p = grp.p[blockIdx.y];
+  if (p.build_xblk) dcn_block_x_body(p, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), (int)gridDim.x * 4);
   if (!p.build_taps) return;
   const long long n_rec = (long long)p.N * p.DG * p.K * p.HoWo;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_rec; i += (long long)gridDim.x * 256) {

@@ -18,6 +18,12 @@ __global__ void dcn_to_pixel_major(const float *__restrict__ src, float *__restr
                                    long long src_image_stride);
 size_t dcn_fwd_plane_fixed_lds_bytes(int parts);
 int dcn_fwd_plane_threads();
+// column-wave variant (dcn_forward_cw.hip): four waves, each samples the B fragment it multiplies; NR = plane units per wave
+template <int PARTS>
+__global__ void dcn_fwd_cw(const DcnFwdGroup grp, float *__restrict__ slabs);
+int dcn_fwd_cw_threads();
+size_t dcn_fwd_cw_lds_bytes(int parts);
+size_t dcn_fwd_cw_xblk_bytes(int N, int Cg_pad, int HW);
 template <int PARTS>
 __global__ void dcn_fwd_plane_pairs(const DcnFwdGroup grp, float *__restrict__ slabs);
 size_t dcn_fwd_plane_pairs_fixed_lds_bytes(int parts);

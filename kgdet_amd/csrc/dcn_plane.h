@@ -18,7 +18,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 //   [block][role][cat]: 0 prologue barrier wait, 1 prologue loads + plane copy, 2 prologue second barrier wait,
 //   3 prologue sample + third barrier, 4 group work (top of group .. before barrier), 5 group barrier wait,
 //   6 epilogue (slab / output store), 7 whole kernel, 8 stages, 9 segments
-static __device__ unsigned long long g_plane_trace[256 * 2 * 10];   // one copy per translation unit
+static __device__ unsigned long long g_plane_trace[256 * 16 * 10];   // [block][wave][cat]; one copy per translation unit
 #ifdef KGDET_PLANE_TRACE_REALTIME   // the constant 100 MHz counter instead of the core clock: cycles / ticks = the clock the kernel ran at
 #define KGDET_TR_NOW() __builtin_amdgcn_s_memrealtime()
 #else
@@ -77,6 +77,20 @@ constexpr bool kAFromL2 = true;   // (grad_weight kernel) consumers take their A
 #endif
 #ifndef KGDET_PLANE_PRODUCER_PRIO
 #define KGDET_PLANE_PRODUCER_PRIO 0   // (with eight producer waves they have slack: prio 2 costs the consumers 5 %)
+#endif
+// Segment chaining (round 5): under the LAST group of a segment the producers copy the next segment's plane (all of it, one
+// batch of loads per wave), a MID-GROUP barrier publishes it after the consumers' second stage, and the producers sample the
+// next segment's FIRST group into the free B buffer while the consumers multiply stages three and four -- the next segment
+// starts with its first group sampled and its first weight fragments in flight.  0: round 3's hand-over (plane under the last
+// group, first group sampled with the consumers idle: ~5.7 k cycles per segment, phase trace of round 5's first run).
+#ifndef KGDET_PLANE_CHAIN
+#define KGDET_PLANE_CHAIN 5           // bit MODE: 1 forward, 2 grad_input, 4 forward on large maps (gather)
+#endif
+#ifndef KGDET_PLANE_ALTERNATE
+#define KGDET_PLANE_ALTERNATE 0       // > 0: the consumer waves of a SIMD alternate between this priority and 0, stage by stage
+#endif
+#ifndef KGDET_PLANE_CHAIN_ROUNDS
+#define KGDET_PLANE_CHAIN_ROUNDS 9    // plane units a producer wave has in flight in the chained copy (68 units / 8 waves)
 #endif
 
 // MODE of the plane kernels
@@ -257,6 +271,10 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
                            // g + 1 from the other set: a whole group to land, and no register moves (the iterations are
                            // unrolled by two)
     bool primed = false;   // the segment's plane and first records were loaded under the last group of the one before
+    bool first_ready = false;   // ... and its first group sampled, its first two weight fragment sets requested (chained)
+    unsigned bsel = 0;     // B buffer numbering of this segment: logical buffer b is physical buffer b ^ bsel (a chained
+                           // segment finds its first group in the buffer the previous segment's last group did not use)
+    constexpr unsigned kGroupBytes = (unsigned)(kGroupTaps * PARTS * kBPart);
     while (s < s_end) {
       const int n = min(K - t0, s_end - s);  // stages of this segment: taps t0 .. t0+n-1 of chunk c16
       // Groups of the segment: a FIRST group of r = 1..4 stages (n - r is a multiple of 4), then full groups.  The
@@ -267,7 +285,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       const int n_groups = 1 + (n - r) / kGroupTaps;
       const bool has_next = s + n < s_end;
       const unsigned rec_base = seg_records(c16);
-      const unsigned xg_seg = xg_img + (unsigned)(c16 * kChunk * 4);   // (MODE 2) this segment's channel chunk
+      unsigned xg_seg = xg_img + (unsigned)(c16 * kChunk * 4);   // (MODE 2) this segment's channel chunk
 
       // consumers: the wave's A (weight) fragments of stage j straight from the weight image (L2), 16 bytes per lane
       // and fragment, coalesced
@@ -285,17 +303,24 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         const int row = k42 ? wm * 64 + mi * 32 + (lane & 31) : wave * 32 + (lane & 31);
         a_lane[mi] = (unsigned)((lane >> 5) * (kTileM * 16) + min(p.row0 + row, kTileM - 1) * 16);
       }
-      auto a_issue = [&](int j, AFrag &F) {
-#ifdef KGDET_ABL_NOALOAD
-        if (j > 1) return;
-#endif
-        const unsigned t = (unsigned)(t0 + min(j, n - 1));
+      // fragments of the stage at byte offset `so` of the weight image (scalar)
+      auto a_issue_at = [&](unsigned so, AFrag &F) {
 #pragma unroll
         for (int part = 0; part < PARTS; ++part)
 #pragma unroll
           for (int mi = 0; mi < (k42 ? 2 : 1); ++mi)
-            F.a[part][mi] = __builtin_bit_cast(bf16x8, dcn_buf_b128(wq_rs, a_lane[mi], wq_seg + t * (2 * kAPart) + part * kAPart));
+            F.a[part][mi] = __builtin_bit_cast(bf16x8, dcn_buf_b128(wq_rs, a_lane[mi], so + part * kAPart));
       };
+      auto a_issue = [&](int j, AFrag &F) {
+#ifdef KGDET_ABL_NOALOAD
+        if (j > 1) return;
+#endif
+        a_issue_at(wq_seg + (unsigned)(t0 + min(j, n - 1)) * (2 * kAPart), F);
+      };
+      // chained hand-over: what the NEXT segment (chunk c16 + 1, taps 0 .. n2 - 1, first group of r2 stages) needs
+      const int n2 = has_next ? min(K, s_end - (s + n)) : 1, r2 = ((n2 - 1) & 3) + 1;
+      const unsigned wq_seg2 = wq_seg + (unsigned)K * (2 * kAPart);   // (chunk c16 + 1 of the same row tile)
+      const bool chain = ((KGDET_PLANE_CHAIN >> MODE) & 1) && has_next && n_groups >= 2;   // the last group is a full one: chain under it
       // ---- B stage, producers.  A group has four stages; producer wave pair w (2 waves = 128 pixels) samples stages
       // w and w + 2 of it -- a thread does ALL 16 channels of its pixel for a stage, as two half-stages of 8 channels
       // (one ds_read_b128 per corner and channel quad).  So a producer wave has TWO stage times for one stage of work
@@ -381,7 +406,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
             }
           }
         const bf16x8 hi = __builtin_bit_cast(bf16x8, hi_u), lo = __builtin_bit_cast(bf16x8, lo_u);
-        unsigned char *dst = Bs + (buf * kGroupTaps + gi) * PARTS * kBPart + half * (kTileN * 16) + n_local * 16;
+        unsigned char *dst = Bs + ((unsigned)buf ^ bsel) * kGroupBytes + gi * PARTS * kBPart + half * (kTileN * 16) + n_local * 16;
 #ifdef KGDET_ABL_NOBSTORE
         if (sv[0][0][0] != 1234.56789f) return;
 #endif
@@ -495,7 +520,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         return;
 #endif
         if constexpr (!PRODUCER) {
-          const unsigned char *B = Bs + (buf * kGroupTaps + gi) * PARTS * kBPart + (lane >> 5) * (kTileN * 16) +
+          const unsigned char *B = Bs + ((unsigned)buf ^ bsel) * kGroupBytes + gi * PARTS * kBPart + (lane >> 5) * (kTileN * 16) +
                                    (lane & 31) * 16;
           if constexpr (k42) {
             bf16x8 b[PARTS][2];
@@ -548,6 +573,17 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         }
       };
 
+      // The two consumer waves of a SIMD (w and w + 4) take turns at s_setprio 1, stage by stage: at equal priority the
+      // arbiter prefers the older wave, which then waits ~20 % of every group at the barrier for its younger partner
+      // (per-wave phase trace, round 5: waves 0-3 work 1716 / wait 615, waves 4-7 work 2145 / wait 187 per 200 stages)
+      auto lead = [&](int k) {
+#if KGDET_PLANE_ALTERNATE
+        if constexpr (!PRODUCER) {
+          if (((wave_s >> 2) ^ k) & 1) __builtin_amdgcn_s_setprio(KGDET_PLANE_ALTERNATE);
+          else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
+      };
       AFrag F0, F1;      // consumers: weight fragments two stages ahead, alternating (a third set in the loop spills): stage
                          // j of a segment sits in F0 when j - r is even, so that full groups find F0, F1, F0, F1
 #ifdef KGDET_PLANE_TRACE
@@ -568,14 +604,16 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         KGDET_TR_ADD(2, tr_t);
       }
       // first group (buffer 0).  One stage: each wave pair samples one 8-channel half of it (both hold its record)
-      if constexpr (PRODUCER) {
-        if (r == 1) { if (pair < 2) sample_half(0, 0, pair, E0); }
-        else sample_group(0, E0, E1, pair < r, pair + 2 < r, [] {});
-      } else {   // full groups find their stages in F0, F1, F0, F1: an odd first group starts with F1
-        if (r & 1) { a_issue(0, F1); a_issue(1, F0); }
-        else { a_issue(0, F0); a_issue(1, F1); }
+      if (!first_ready) {
+        if constexpr (PRODUCER) {
+          if (r == 1) { if (pair < 2) sample_half(0, 0, pair, E0); }
+          else sample_group(0, E0, E1, pair < r, pair + 2 < r, [] {});
+        } else {   // full groups find their stages in F0, F1, F0, F1: an odd first group starts with F1
+          if (r & 1) { a_issue(0, F1); a_issue(1, F0); }
+          else { a_issue(0, F0); a_issue(1, F1); }
+        }
+        __syncthreads();
       }
-      __syncthreads();
       KGDET_TR_ADD(3, tr_t);
       // producers, while the consumers multiply group gi: sample group gi + 1 into the other buffer from (Sa, Sb) and
       // load the records of group gi + 2 into (Ia, Ib); under the last group, the next segment's records and plane instead
@@ -590,12 +628,30 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
             sample_group(buf_next, Sa, Sb, true, true, [] {});
           }
         } else if (has_next) {
-          const int n2 = min(K, s_end - (s + n)), r2 = ((n2 - 1) & 3) + 1;
           const unsigned rb2 = seg_records(c16 + 1);
           issue(rb2, 0, r2 - 1, pair, E0);
           issue(rb2, 0, n2 - 1, r2 + pair, O0);
           if constexpr (kRolePairs == 2) { issue(rb2, 0, r2 - 1, pair + 2, E1); issue(rb2, 0, n2 - 1, r2 + pair + 2, O1); }
-          if constexpr (MODE != 2) load_plane(c16 + 1, wave_s, ProducerWaves{}, FullRounds{}, 0, plane_split);
+          if (chain) {
+            // the whole plane by the producers, one batch of loads per wave; then, behind the mid-group barrier that
+            // publishes it, the next segment's first group into the B buffer this segment's last group does not use
+            // (logical buffer n_groups & 1 of this segment = logical buffer 0 of the next one)
+            if constexpr (MODE != 2) {
+#ifndef KGDET_ABL_NOCHAINPLANE   // (ablation: what a free plane copy would buy -- results are wrong)
+              load_plane(c16 + 1, wave_s, ProducerWaves{}, std::integral_constant<int, KGDET_PLANE_CHAIN_ROUNDS>{}, 0, plane_items);
+#endif
+              KGDET_TR_ADD(4, tr_t);
+              __syncthreads();
+              KGDET_TR_ADD(0, tr_t);   // (trace: category 0 = wait at the mid-group barrier)
+            } else {
+              xg_seg += (unsigned)(kChunk * 4);   // (gathered corners: the next segment's channel chunk)
+            }
+            const int fb = n_groups & 1;
+            if (r2 == 1) { if (pair < 2) sample_half(fb, 0, pair, E0); }
+            else sample_group(fb, E0, E1, pair < r2, pair + 2 < r2, [] {});
+          } else {
+            if constexpr (MODE != 2) load_plane(c16 + 1, wave_s, ProducerWaves{}, FullRounds{}, 0, plane_split);
+          }
         }
       };
       // group 0
@@ -622,19 +678,36 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         } else {
           const int jg = r + (gi - 1) * kGroupTaps;
           // (one scheduling region per stage: across all four, hipcc hoists the B reads of later stages and spills)
+          lead(0);
           multiply(buf, 0, F0);
           a_issue(jg + 2, F0);
           __builtin_amdgcn_sched_barrier(0);
+          lead(1);
           multiply(buf, 1, F1);
           a_issue(jg + 3, F1);
           __builtin_amdgcn_sched_barrier(0);
-          multiply(buf, 2, F0);
-          a_issue(jg + 4, F0);
-          __builtin_amdgcn_sched_barrier(0);
-          multiply(buf, 3, F1);
-          a_issue(jg + 5, F1);
+          // chained hand-over under the last group: the plane of the next segment is complete behind the mid-group barrier
+          // (its sampling overlaps stages three and four); the fragment sets take the next segment's first two stages
+          const bool hand = chain && gi + 1 == n_groups;
           if constexpr (MODE != 2)
-            if (gi + 1 == n_groups && has_next)
+            if (hand) {
+              KGDET_TR_ADD(4, tr_t);
+              __syncthreads();
+              KGDET_TR_ADD(0, tr_t);
+            }
+          const unsigned so0 = hand ? wq_seg2 + (unsigned)min((r2 & 1) ? 1 : 0, n2 - 1) * (2 * kAPart)
+                                    : wq_seg + (unsigned)(t0 + min(jg + 4, n - 1)) * (2 * kAPart);
+          const unsigned so1 = hand ? wq_seg2 + (unsigned)min((r2 & 1) ? 0 : 1, n2 - 1) * (2 * kAPart)
+                                    : wq_seg + (unsigned)(t0 + min(jg + 5, n - 1)) * (2 * kAPart);
+          lead(0);
+          multiply(buf, 2, F0);
+          a_issue_at(so0, F0);
+          __builtin_amdgcn_sched_barrier(0);
+          lead(1);
+          multiply(buf, 3, F1);
+          a_issue_at(so1, F1);
+          if constexpr (MODE != 2)
+            if (!chain && gi + 1 == n_groups && has_next)
               load_plane(c16 + 1, wave_s, ConsumerWaves{}, HalfRounds{}, plane_split, plane_items);
         }
         KGDET_TR_ADD(4, tr_t);
@@ -646,6 +719,8 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         if (gi + 1 < n_groups) group(gi + 1, std::integral_constant<int, 0>{});
       }
       primed = has_next;
+      first_ready = chain;
+      if (chain && (n_groups & 1)) bsel ^= 1u;
       s += n;
       ++c16;
       t0 = 0;
@@ -672,9 +747,9 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
   }
 #ifdef KGDET_PLANE_TRACE
   tr[7] = KGDET_TR_NOW() - tr_start;
-  if ((tid & 63) == 0 && (tid >> 6) == 0) {
+  if ((tid & 63) == 0) {
 #pragma unroll
-    for (int c = 0; c < 10; ++c) g_plane_trace[((int)blockIdx.x * 2 + (PRODUCER ? 1 : 0)) * 10 + c] = tr[c];
+    for (int c = 0; c < 10; ++c) g_plane_trace[((int)blockIdx.x * 16 + wave_all) * 10 + c] = tr[c];
   }
 #endif
 }

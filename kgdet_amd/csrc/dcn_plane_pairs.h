@@ -344,7 +344,7 @@ __device__ __forceinline__ void pair_role(const DcnFwdGroup &grp, float *__restr
   tr[7] = KGDET_TR_NOW() - tr_start;
   if ((tid & 63) == 0 && (tid >> 6) == 0) {
 #pragma unroll
-    for (int c = 0; c < 10; ++c) g_plane_trace[((int)blockIdx.x * 2 + (PRODUCER ? 1 : 0)) * 10 + c] = tr[c];
+    for (int c = 0; c < 10; ++c) g_plane_trace[((int)blockIdx.x * 16 + (PRODUCER ? 8 : 0)) * 10 + c] = tr[c];
   }
 #endif
 }

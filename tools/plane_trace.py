@@ -1,5 +1,6 @@
 """phase breakdown of the plane forward kernel from the trace build (make VARIANT=trace EXTRA=-DKGDET_PLANE_TRACE):
-KGDET_LIB=kgdet_amd/libkgdet_hip_trace.so python tools/plane_trace.py [B] [prec]"""
+KGDET_LIB=kgdet_amd/libkgdet_hip_trace.so python tools/plane_trace.py [B] [prec]
+per wave (0-7 consumers, 8-15 producers) and per problem class: hundreds of shader cycles spent in each phase"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -18,18 +19,17 @@ with torch.no_grad(), dcn.forward_precision(prec):
     for _ in range(3):
         dcn.deform_conv_cat_multi(xs, offs, ws, [k // 2 for k in ks])
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * (256 * 2 * 10))()
+buf = (ctypes.c_ulonglong * (256 * 16 * 10))()
 assert _lib.lib().kgdet_debug_read_plane_trace(buf) == 0
-t = np.array(buf[:], dtype=np.float64).reshape(256, 2, 10) / 100.0     # s_memtime ticks at 100 MHz -> us
-names = ['pro_wait0', 'pro_load', 'pro_wait1', 'pro_sample', 'stage_work', 'stage_wait', 'epilogue', 'total', 'stages', 'segments']
-for role, rn in ((0, 'consumer wave 0'), (1, 'producer wave 8')):
-    print(rn)
-    for c, nme in enumerate(names):
-        v = t[:, role, c] * (100.0 if c >= 8 else 1.0)
-        print('  %-11s mean %8.1f  min %8.1f  max %8.1f' % (nme, v.mean(), v.min(), v.max()))
+t = np.array(buf[:], dtype=np.float64).reshape(256, 16, 10) / 100.0     # s_memtime ticks = shader cycles; / 100
+names = ['mid_wait', 'pro_load', 'pro_wait1', 'pro_sample', 'stage_work', 'stage_wait', 'epilogue', 'total', 'stages', 'segments']
 seg = t[:, 0, 9] * 100
-for lo, hi, tag in ((0, 6, '<=5 segments (7x7)'), (6, 12, '6-11 (5x5)'), (12, 99, '>=12 (3x3)')):
+classes = [(0, 6, '7x7'), (6, 12, '5x5'), (12, 99, '3x3')]
+for lo, hi, tag in classes:
     m = (seg >= lo) & (seg < hi)
-    if m.any():
-        print(tag, 'workgroups', int(m.sum()), 'total us mean %.1f' % t[m, 0, 7].mean(),
-              ' '.join('%s %.1f' % (names[c], t[m, 0, c].mean()) for c in range(7)))
+    if not m.any():
+        continue
+    print('%s: %d workgroups, %d stages, %d segments' % (tag, int(m.sum()), int(t[m, 0, 8].mean() * 100), int(seg[m].mean())))
+    print('  wave ' + ' '.join('%10s' % n for n in names[:8]))
+    for w in range(16):
+        print('  %4d ' % w + ' '.join('%10.1f' % t[m, w, c].mean() for c in range(8)))
