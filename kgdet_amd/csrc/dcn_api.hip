@@ -559,8 +559,10 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
     }
     grp.pair_mode = grp_pair ? 1 : 0;
     const bool use_cw = cw_ok();
+    static const int chain_dma = getenv("KGDET_DCN_CHAIN_DMA") ? atoi(getenv("KGDET_DCN_CHAIN_DMA")) : 1;   // A/B switch
+    const bool use_xblk = use_cw || (chain_dma && parts == 2 && !grp_pair);   // (plane kernel: chained segment hand-over by LDS-DMA)
     for (int i = 0; i < grp.n; ++i) { grp.p[i].xblk = nullptr; grp.p[i].build_xblk = 0; }
-    if (use_cw) {   // blocked copies of the distinct inputs behind the tap records (written by dcn_build_taps' blocks)
+    if (use_xblk) {   // blocked copies of the distinct inputs behind the tap records (written by dcn_build_taps' blocks)
       size_t used = align_up(table_used, 256);
       for (int i = 0; i < grp.n; ++i) {
         DcnProblem &q = grp.p[i];

@@ -94,6 +94,18 @@ __device__ __forceinline__ float dcn_buf_f32(dcn_rsrc_t r, unsigned voff, unsign
 __device__ __forceinline__ u32x4_t dcn_buf_b128(dcn_rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
 }
+// One 1 KiB piece of the blocked feature image straight into LDS (LDS-DMA: no registers, no ds_write): lane l's 16 bytes
+// from buffer offset voff + soff land at lds + 16 l.  hipcc does not count this load in its vmcnt bookkeeping (its own
+// counted waits only get stricter by it); the caller waits with dcn_wait_vm0() before the barrier that publishes the data.
+__device__ __forceinline__ void dcn_dma_b128(u32x4_t rsrc, unsigned voff, unsigned soff, unsigned lds) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds)
+               : "memory");
+}
+__device__ __forceinline__ void dcn_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <int ROUNDS, bool ZERO_PAD = false>
 __device__ __forceinline__ void dcn_plane_copy(const float *__restrict__ xb, int HW, int Cg, int c0, unsigned char *plane,
                                                unsigned stride, int u_first, int u_step, int u_hi, int lane) {

@@ -74,18 +74,6 @@ static __device__ unsigned long long g_cw_trace[256 * 4 * 12];
 #define CW_TR(cat) do { } while (0)
 #endif
 
-// One 1 KiB piece of the blocked feature image straight into LDS (LDS-DMA: no registers, no ds_write): lane l's 16 bytes
-// from buffer offset voff + soff land at lds + 16 l.  hipcc does not count this load in its vmcnt bookkeeping (its own
-// counted waits only get stricter by it); the caller waits with cw_wait_vm0() before the barrier that publishes the data.
-__device__ __forceinline__ void cw_dma_b128(u32x4_t rsrc, unsigned voff, unsigned soff, unsigned lds) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds)
-               : "memory");
-}
-__device__ __forceinline__ void cw_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
 template <int PARTS>
 __global__ __launch_bounds__(kCwThreads, 1) void dcn_fwd_cw(const DcnFwdGroup grp, float *__restrict__ slabs) {
   static_assert(PARTS == 2, "split operands only (the one-product kernel keeps dcn_fwd_plane<1>)");
@@ -145,7 +133,7 @@ __global__ __launch_bounds__(kCwThreads, 1) void dcn_fwd_cw(const DcnFwdGroup gr
       const unsigned so = __builtin_amdgcn_readfirstlane(xb_img + (unsigned)c * plane_bytes);
       for (int u = wave; u < n_units; u += 4) {
         const int quad = u / nblk, blk = u - quad * nblk;
-        cw_dma_b128(xb_rs, (unsigned)(lane * 16), so + (unsigned)(u * 1024),
+        dcn_dma_b128(xb_rs, (unsigned)(lane * 16), so + (unsigned)(u * 1024),
                     (unsigned)quad * (unsigned)kPlaneQuadStride + (unsigned)(blk * 1024));
       }
     };
@@ -232,7 +220,7 @@ __global__ __launch_bounds__(kCwThreads, 1) void dcn_fwd_cw(const DcnFwdGroup gr
     piece_store(1, Ap[1]);
     piece_issue(4, Ap[0]);
     piece_issue(5, Ap[1]);
-    cw_wait_vm0();                         // (the plane pieces; hipcc's own waits cover its loads)
+    dcn_wait_vm0();                         // (the plane pieces; hipcc's own waits cover its loads)
     __syncthreads();
     gathers(Roff[0], Cn[0]);
     gathers(Roff[1], Cn[1]);
@@ -366,7 +354,7 @@ __global__ __launch_bounds__(kCwThreads, 1) void dcn_fwd_cw(const DcnFwdGroup gr
       if (++tk == K) tk = 0;
       front_next();
       CW_TR(1);
-      if (sw2) cw_wait_vm0();                      // the new plane is in LDS before anybody gathers from it
+      if (sw2) dcn_wait_vm0();                      // the new plane is in LDS before anybody gathers from it
 #ifndef KGDET_CW_ABL_NOBARRIER
       __syncthreads();
 #endif

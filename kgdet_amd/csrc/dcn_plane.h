@@ -89,6 +89,9 @@ constexpr bool kAFromL2 = true;   // (grad_weight kernel) consumers take their A
 #ifndef KGDET_PLANE_ALTERNATE
 #define KGDET_PLANE_ALTERNATE 0       // > 0: the consumer waves of a SIMD alternate between this priority and 0, stage by stage
 #endif
+#ifndef KGDET_PLANE_CHAIN_REGS
+#define KGDET_PLANE_CHAIN_REGS 0      // 1: chain also where the plane copy goes through registers (measured slower: the producers'
+#endif                                // 36 loads per wave beside the MFMA waves take ~5 k cycles)
 #ifndef KGDET_PLANE_CHAIN_ROUNDS
 #define KGDET_PLANE_CHAIN_ROUNDS 9    // plane units a producer wave has in flight in the chained copy (68 units / 8 waves)
 #endif
@@ -243,6 +246,12 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
     const dcn_rsrc_t xg_rs = dcn_make_rsrc(p.x);
     const unsigned xg_img = (unsigned)(((long long)tile_b * HW * p.C_total + p.c_base) * 4);
     constexpr bool kBf16Plane = PARTS == 1 && MODE == 0;   // one-product forward: the plane holds bf16 (dcn_common.h)
+    // chained hand-over by LDS-DMA: the blocked copy of x (p.xblk, written by dcn_build_taps; forward with split operands only)
+    const bool xb_dma = MODE == 0 && !kBf16Plane && p.xblk != nullptr;
+    const unsigned long long xba = reinterpret_cast<unsigned long long>(p.xblk);
+    const u32x4_t xb_rs = {(unsigned)__builtin_amdgcn_readfirstlane((unsigned)xba),
+                           (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(xba >> 32)), 0xffffffffu, 0x00020000u};
+    const unsigned xblk_img = (unsigned)(tile_b * n_c16) * (unsigned)((kBf16Plane ? dcn_plane_units_bf16(HW) : dcn_plane_units(HW)) * 1024);
     auto load_plane = [&](int c, int w, auto NW_, auto ROUNDS_, int unit_lo, int unit_hi) {
       constexpr int NW = decltype(NW_)::value;
       constexpr int ROUNDS = decltype(ROUNDS_)::value;
@@ -320,7 +329,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       // chained hand-over: what the NEXT segment (chunk c16 + 1, taps 0 .. n2 - 1, first group of r2 stages) needs
       const int n2 = has_next ? min(K, s_end - (s + n)) : 1, r2 = ((n2 - 1) & 3) + 1;
       const unsigned wq_seg2 = wq_seg + (unsigned)K * (2 * kAPart);   // (chunk c16 + 1 of the same row tile)
-      const bool chain = ((KGDET_PLANE_CHAIN >> MODE) & 1) && has_next && n_groups >= 2;   // the last group is a full one: chain under it
+      const bool chain = ((KGDET_PLANE_CHAIN >> MODE) & 1) && has_next && n_groups >= 2 && (MODE == 2 || xb_dma || KGDET_PLANE_CHAIN_REGS);   // the last group is a full one: chain under it
       // ---- B stage, producers.  A group has four stages; producer wave pair w (2 waves = 128 pixels) samples stages
       // w and w + 2 of it -- a thread does ALL 16 channels of its pixel for a stage, as two half-stages of 8 channels
       // (one ds_read_b128 per corner and channel quad).  So a producer wave has TWO stage times for one stage of work
@@ -638,7 +647,18 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
             // (logical buffer n_groups & 1 of this segment = logical buffer 0 of the next one)
             if constexpr (MODE != 2) {
 #ifndef KGDET_ABL_NOCHAINPLANE   // (ablation: what a free plane copy would buy -- results are wrong)
-              load_plane(c16 + 1, wave_s, ProducerWaves{}, std::integral_constant<int, KGDET_PLANE_CHAIN_ROUNDS>{}, 0, plane_items);
+              if (xb_dma) {   // LDS-DMA from the blocked copy of x: no registers, no ds_write, ~nine instructions per wave
+                const unsigned so = __builtin_amdgcn_readfirstlane(xblk_img + (unsigned)(c16 + 1) * (unsigned)(plane_items * 1024));
+                const int nblk = plane_items >> 2;
+                for (int u = wave_s; u < plane_items; u += kRoleProducers / 64) {
+                  const int quad = u / nblk, blk = u - quad * nblk;
+                  dcn_dma_b128(xb_rs, (unsigned)(lane * 16), so + (unsigned)(u * 1024),
+                               (unsigned)quad * (unsigned)kPlaneQuadStride + (unsigned)(blk * 1024));
+                }
+                dcn_wait_vm0();
+              } else {
+                load_plane(c16 + 1, wave_s, ProducerWaves{}, std::integral_constant<int, KGDET_PLANE_CHAIN_ROUNDS>{}, 0, plane_items);
+              }
 #endif
               KGDET_TR_ADD(4, tr_t);
               __syncthreads();
