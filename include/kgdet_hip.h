@@ -448,6 +448,16 @@ int kgdet_multi_grad_norm(const int64_t *table_dev, int32_t n, int64_t total_blo
 int kgdet_multi_clip_adam(const int64_t *table_dev, int32_t n, int64_t total_blocks, const float *norm, float max_norm, float lr,
                           double beta1, double beta2, float eps, float weight_decay, float bias_correction1,
                           float bias_correction2_sqrt, void *stream);
+/*
+ * The same clip + Adam update with the step's schedule in DEVICE memory, for a training step captured as one HIP graph (kernel
+ * arguments are frozen at capture; the reference's optimizer.step() -- dist_utils.py:57 -- takes them from host state every call):
+ * sched[4] = {learning rate, 1 - beta1^t, sqrt(1 - beta2^t), t}.  The call first advances the schedule (t <- t + 1, corrections
+ * recomputed in double precision; learning rate <- lr_ring[t % ring] when lr_ring != NULL: `ring` floats of page-locked host memory
+ * the device reads in place, slot k written by the host before it launches step k), then applies the update with it.
+ */
+int kgdet_multi_clip_adam_dev(const int64_t *table_dev, int32_t n, int64_t total_blocks, const float *norm, float max_norm,
+                              float *sched, const float *lr_ring /*nullable*/, int32_t ring, double beta1, double beta2, float eps,
+                              float weight_decay, void *stream);
 
 /*
  * GroupNorm (+ ReLU) of the ConvModules of the head towers and the neck as one pass each way -- ATen runs it as ten kernels

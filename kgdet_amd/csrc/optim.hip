@@ -71,10 +71,31 @@ __global__ __launch_bounds__(1024) void multi_sqnorm_finish(const float *__restr
   }
 }
 
+// The step's schedule in device memory (round 5: the whole training step as ONE captured HIP graph -- kernel arguments are
+// frozen at capture time, so the step count, the two bias corrections and the learning rate cannot be arguments there):
+//   sched[0] = learning rate   sched[1] = 1 - beta1^t   sched[2] = sqrt(1 - beta2^t)   sched[3] = t (steps taken, as a float)
+// adam_schedule_step advances t by one, recomputes the corrections in double precision (the host path's expressions:
+// 1.0 - beta1 ** t, math.sqrt(1.0 - beta2 ** t)) and takes this step's learning rate from slot t % ring of `lr_ring` -- page-locked
+// host memory the device reads in place; the host writes slot k before it launches step k (kgdet_amd/optim.py).
+__global__ void adam_schedule_step(float *__restrict__ sched, const float *__restrict__ lr_ring, int ring, double beta1, double beta2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float t = sched[3] + 1.0f;
+  sched[3] = t;
+  sched[1] = (float)(1.0 - pow(beta1, (double)t));
+  sched[2] = (float)sqrt(1.0 - pow(beta2, (double)t));
+  if (lr_ring) sched[0] = lr_ring[(long long)t % ring];
+}
+
 __global__ __launch_bounds__(256) void multi_clip_adam(const long long *__restrict__ table, int n, const float *__restrict__ norm,
                                                        float max_norm, float lr, float beta1, float beta2, float eps,
                                                        float weight_decay, float bias_correction1, float bias_correction2_sqrt,
-                                                       float one_minus_beta1, float one_minus_beta2) {
+                                                       float one_minus_beta1, float one_minus_beta2,
+                                                       const float *__restrict__ sched) {
+  if (sched) {   // (device schedule: the arguments above are capture-time values)
+    lr = sched[0];
+    bias_correction1 = sched[1];
+    bias_correction2_sqrt = sched[2];
+  }
   const long long *row = opt_row(table, n, blockIdx.x);
   float *p = reinterpret_cast<float *>(row[0]), *g = reinterpret_cast<float *>(row[1]);
   float *m = reinterpret_cast<float *>(row[2]), *v = reinterpret_cast<float *>(row[3]);
@@ -131,7 +152,25 @@ extern "C" int kgdet_multi_clip_adam(const int64_t *table_dev, int32_t n, int64_
   KGDET_CHECK_SHAPE(max_norm <= 0.0f || norm, "a positive max_norm needs the norm");
   hipLaunchKernelGGL(multi_clip_adam, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const long long *)table_dev,
                      n, norm, max_norm, lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2_sqrt,
-                     (float)(1.0 - (double)beta1_d), (float)(1.0 - (double)beta2_d));
+                     (float)(1.0 - (double)beta1_d), (float)(1.0 - (double)beta2_d), (const float *)nullptr);
   KGDET_CHECK_LAUNCH("multi_clip_adam");
+  return KGDET_OK;
+}
+
+// The same update with the step's schedule read from device memory (see adam_schedule_step): first the schedule advances
+// (sched[3] = steps taken so far on entry), then the update uses it.  `lr_ring`: `ring` floats of page-locked host memory
+// (device-readable), slot t % ring = the learning rate of step t (1-based), or NULL: sched[0] is left as it is.
+extern "C" int kgdet_multi_clip_adam_dev(const int64_t *table_dev, int32_t n, int64_t total_blocks, const float *norm,
+                                         float max_norm, float *sched, const float *lr_ring, int32_t ring, double beta1_d,
+                                         double beta2_d, float eps, float weight_decay, void *stream) {
+  const float beta1 = (float)beta1_d, beta2 = (float)beta2_d;
+  KGDET_CHECK_SHAPE(table_dev && n > 0 && total_blocks > 0 && total_blocks < (1LL << 31) && sched, "bad arguments");
+  KGDET_CHECK_SHAPE(max_norm <= 0.0f || norm, "a positive max_norm needs the norm");
+  KGDET_CHECK_SHAPE(lr_ring == nullptr || ring > 0, "empty learning-rate ring");
+  hipLaunchKernelGGL(adam_schedule_step, dim3(1), dim3(64), 0, (hipStream_t)stream, sched, lr_ring, (int)ring, beta1_d, beta2_d);
+  hipLaunchKernelGGL(multi_clip_adam, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const long long *)table_dev,
+                     n, norm, max_norm, 0.0f, beta1, beta2, eps, weight_decay, 1.0f, 1.0f,
+                     (float)(1.0 - (double)beta1_d), (float)(1.0 - (double)beta2_d), (const float *)sched);
+  KGDET_CHECK_LAUNCH("multi_clip_adam_dev");
   return KGDET_OK;
 }

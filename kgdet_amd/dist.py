@@ -369,7 +369,15 @@ class DistOptimizerHook(object):
             self._fused = FusedClipAdam()
         if len(optimizer.param_groups) == 1 and self._fused.applicable(optimizer, self._params, self.grad_clip):
             # clip + Adam as two multi-tensor HIP passes (csrc/optim.hip); the first step (no state yet) and anything else: torch
+            # (device-side schedule -- FusedClipAdam.enable_device_schedule, the graphed step of runner.GraphedTrainStep --: the
+            #  learning rate is published and the step counted by the host around the launch; inside a capture the replaying
+            #  caller does both)
+            dev_sched = self._fused._sched is not None and not torch.cuda.is_current_stream_capturing()
+            if dev_sched:
+                self._fused.publish_lr(optimizer)
             if self._fused.step(optimizer, self._params, self.grad_clip):
+                if dev_sched:
+                    self._fused.step_published()
                 return
         self._fused.invalidate()       # torch advances the step counters below: the fused path re-reads them next time
         if self.grad_clip is not None:

@@ -31,6 +31,62 @@ class FusedClipAdam(object):
         self._host_step = None
         self._step_ref = None
         self._n_steps = 0
+        # device-side schedule (the step inside a captured HIP graph): see enable_device_schedule
+        self._sched = None        # device float [4]: lr, 1 - beta1^t, sqrt(1 - beta2^t), t
+        self._lr_ring = None      # page-locked float [LR_RING]: slot k % LR_RING = learning rate of step k (1-based)
+        self._dev_steps = 0       # steps taken through the device schedule (host mirror of sched[3])
+        self._pending = 0         # ... of which not yet added to the optimizer's own step tensors
+        self._ring_events = []
+
+    LR_RING = 64
+
+    def enable_device_schedule(self, optimizer):
+        """From now on the step count, the bias corrections and the learning rate of the fused step live in device memory
+        (csrc/optim.hip adam_schedule_step): the step can be captured in a HIP graph and replayed.  The host's part per step is
+        ``publish_lr(optimizer)`` BEFORE the launch (replay) of step k: it writes that step's learning rate into its ring slot.
+        ``sync_optimizer_state(optimizer)`` adds the steps taken to the optimizer's own ``step`` tensors (state_dict / checkpoint
+        compatibility; called by the graphed runner before anything reads them)."""
+        group = optimizer.param_groups[0]
+        steps = [optimizer.state[p]['step'] for p in group['params'] if p.grad is not None or p in optimizer.state]
+        steps = [s for s in steps if isinstance(s, torch.Tensor)]
+        both = torch.stack([s.detach().reshape(()).float().cpu() for s in steps]).aminmax()
+        if float(both.min) != float(both.max):
+            raise RuntimeError('per-parameter step counters differ: the fused step does not apply')
+        t = int(round(float(both.min)))
+        dev = group['params'][0].device
+        beta1, beta2 = group['betas']
+        self._sched = torch.tensor([float(group['lr']), 1.0 - beta1 ** max(t, 1), math.sqrt(1.0 - beta2 ** max(t, 1)), float(t)],
+                                   dtype=torch.float32, device=dev)
+        self._lr_ring = torch.full((self.LR_RING,), float(group['lr']), dtype=torch.float32).pin_memory()
+        self._dev_steps, self._pending = t, 0
+        self._ring_events = [None] * self.LR_RING
+        self._host_step = None
+        return self
+
+    def publish_lr(self, optimizer):
+        """host side of step ``self._dev_steps + 1`` under the device schedule: its learning rate into its ring slot (waiting,
+        if the host ran a whole ring ahead, for the step that last read the slot)"""
+        k = self._dev_steps + 1
+        slot = k % self.LR_RING
+        ev = self._ring_events[slot]
+        if ev is not None:
+            ev.synchronize()
+        self._lr_ring[slot] = float(optimizer.param_groups[0]['lr'])
+
+    def step_published(self):
+        """after the launch (replay) of the step whose rate ``publish_lr`` wrote"""
+        self._dev_steps += 1
+        self._pending += 1
+        ev = torch.cuda.Event()
+        ev.record()
+        self._ring_events[self._dev_steps % self.LR_RING] = ev
+
+    def sync_optimizer_state(self, optimizer):
+        if self._pending:
+            group = optimizer.param_groups[0]
+            steps = [optimizer.state[p]['step'] for p in group['params'] if p in optimizer.state]
+            torch._foreach_add_(steps, float(self._pending))
+            self._pending = 0
 
     def invalidate(self):
         """A step was taken outside this object (torch's ``optimizer.step()``): the host copy of the step count is stale."""
@@ -81,18 +137,24 @@ class FusedClipAdam(object):
             return True
         key = tuple(rows)
         dev = group['params'][0].device       # (the step counters live on the CPU unless the optimizer is fused / capturable)
+        capturing = torch.cuda.is_current_stream_capturing()
         if key != self._key:
             # (the gradients are fresh tensors every step, but the caching allocator hands out the same blocks for the same
             #  sequence of requests: the table is uploaded again only when an address moved)
-            if self._event is not None:
+            if self._event is not None and not capturing:
                 self._event.synchronize()        # the previous upload has left the pinned buffer
             if self._pinned is None or self._pinned.shape[0] < len(rows):
                 self._pinned = torch.empty((len(rows), 6), dtype=torch.int64).pin_memory()
             host = self._pinned[:len(rows)]
             host.copy_(torch.tensor(rows, dtype=torch.int64))
             self._table = host.to(dev, non_blocking=True)
-            self._event = torch.cuda.Event()
-            self._event.record()
+            if capturing:      # (a copy node of the graph, re-run by every replay from the same page-locked rows: keep them)
+                self._pinned = None
+                self._capture_rows = host
+                self._event = None
+            else:
+                self._event = torch.cuda.Event()
+                self._event.record()
             self._key = key
             if self._partial is None or self._partial.numel() < first:
                 self._partial = torch.empty(first, dtype=torch.float32, device=dev)
@@ -104,6 +166,19 @@ class FusedClipAdam(object):
             _lib.check(L.kgdet_multi_grad_norm(ctypes.c_void_p(self._table.data_ptr()), ctypes.c_int32(len(rows)),
                                                ctypes.c_int64(first), _lib.ptr(self._partial), _lib.ptr(self._norm), stream),
                        'multi_grad_norm')
+        if self._sched is not None:
+            # device schedule: nothing of the step is read or advanced on the host (the call may be a graph capture); the
+            # caller publishes the learning rate and counts the steps (publish_lr / step_published)
+            beta1, beta2 = group['betas']
+            _lib.check(L.kgdet_multi_clip_adam_dev(
+                ctypes.c_void_p(self._table.data_ptr()), ctypes.c_int32(len(rows)), ctypes.c_int64(first), _lib.ptr(self._norm),
+                ctypes.c_float(max_norm), _lib.ptr(self._sched), ctypes.c_void_p(self._lr_ring.data_ptr()),
+                ctypes.c_int32(self.LR_RING), ctypes.c_double(beta1), ctypes.c_double(beta2), ctypes.c_float(group['eps']),
+                ctypes.c_float(group['weight_decay']), stream), 'multi_clip_adam_dev')
+            if not capturing:
+                torch.autograd.graph.increment_version([p for p in group['params'] if p.grad is not None])
+            self.last_norm = self._norm[0] if grad_clip is not None else None
+            return True
         if self._host_step is None or steps[0] is not self._step_ref or len(steps) != self._n_steps:
             # ONE read-back, at the first fused step -- and again whenever the optimizer's state was replaced
             # (load_state_dict on resume creates new step tensors), the set of stepped tensors changed, or a step went

@@ -130,6 +130,83 @@ class LrSchedule(object):
             self._set(optimizer, self.regular_lr if cur_iter == self.warmup_iters else self.warm(cur_iter))
 
 
+class GraphedTrainStep(object):
+    """One training step of a FIXED-shape batch -- forward, the nine losses, backward, gradient clip, Adam -- as ONE HIP graph.
+
+    The eager step is ~560 kernel launches whose enqueue (Python module calls + launch latency, ~11 ms at full size) takes as
+    long as the GPU needs to run them (``tools/host_step_cost.py``): every kernel gain below a few percent is invisible in
+    images/s.  Nothing in the step reads back to the host (``tests/test_gpu_head.py::test_training_step_has_no_host_syncs``), the
+    optimizer's schedule lives in device memory (``optim.FusedClipAdam.enable_device_schedule``: step count, bias corrections
+    and the learning rate are not kernel arguments), so the whole step is captured once (``torch.cuda.CUDAGraph`` = hipGraph)
+    and replayed per iteration.  The reference has no equivalent (``mmdet/apis/train.py:17-134`` + mmcv's Runner issue every
+    op eagerly); the arithmetic is the eager step's, kernel by kernel.
+
+    ``batch``: the dict ``forward_train`` takes (``img`` [B, 3, H, W], ``img_meta``, ``gt_bboxes`` / ``gt_labels`` /
+    ``gt_keypoints`` lists of CUDA tensors): these tensors become the graph's input buffers; ``load(batch)`` copies another
+    batch of the SAME shapes (same number of ground-truth rows per image) into them, ``step()`` publishes the step's learning
+    rate (``optimizer.param_groups[0]['lr']``, as set by ``LrSchedule``), replays the graph and returns the loss tensors of
+    the step (device tensors, overwritten by the next replay).  One rank only: the gradient exchange of a multi-rank job
+    stays on the eager path (``DistOptimizerHook``).  ``sync_optimizer_state()`` before the optimizer's state is read
+    (checkpoints): the replayed steps are added to its ``step`` counters then."""
+
+    def __init__(self, model, optimizer, opt_hook, batch, warmup=3, batch_processor=batch_processor):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise NotImplementedError('the graphed step covers one rank; a multi-rank job exchanges gradients eagerly')
+        from .optim import FusedClipAdam
+        self.model, self.optimizer, self.hook = model, optimizer, opt_hook
+        self.static = batch
+        self.static_tensors = [batch['img']] + [t for k in ('gt_bboxes', 'gt_labels', 'gt_keypoints') for t in batch.get(k, [])]
+        assert all(t.is_cuda for t in self.static_tensors) and model.training
+
+        def one_step():
+            out = batch_processor(model, self.static, train_mode=True)
+            opt_hook.step(model, optimizer, out['loss'])
+            return out
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(int(warmup), 2)):      # optimizer state, weight-image sets, MIOpen find: all before the capture
+                one_step()
+        torch.cuda.current_stream().wait_stream(side)
+        fused = opt_hook._fused
+        if fused is None or len(optimizer.param_groups) != 1 or \
+                not FusedClipAdam.applicable(optimizer, opt_hook._params, opt_hook.grad_clip):
+            raise NotImplementedError('the graphed step needs the fused clip + Adam step (one parameter group, torch.optim.Adam)')
+        if fused._sched is None:
+            fused.enable_device_schedule(optimizer)
+        self.fused = fused
+        with torch.cuda.stream(side):                  # one eager step on the device schedule (its table, its buffers)
+            one_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        fused.publish_lr(optimizer)
+        with torch.cuda.graph(self.graph):
+            self.out = one_step()
+        # (the capture itself does not run the step: nothing was counted yet)
+        self.steps = 0
+
+    def load(self, batch):
+        new = [batch['img']] + [t for k in ('gt_bboxes', 'gt_labels', 'gt_keypoints') for t in batch.get(k, [])]
+        if len(new) != len(self.static_tensors) or any(a.shape != b.shape for a, b in zip(new, self.static_tensors)):
+            raise ValueError('the graphed step was captured for other tensor shapes')
+        with torch.no_grad():
+            torch._foreach_copy_(self.static_tensors, [t.to(s.device, non_blocking=True) for t, s in zip(new, self.static_tensors)])
+
+    def step(self):
+        self.fused.publish_lr(self.optimizer)
+        self.graph.replay()
+        self.fused.step_published()
+        self.steps += 1
+        return self.out
+
+    def sync_optimizer_state(self):
+        self.fused.sync_optimizer_state(self.optimizer)
+
+
 class Runner(object):
     def __init__(self, model, optimizer, work_dir=None, lr_config=None, optimizer_config=None, checkpoint_config=None,
                  log_interval=50, logger=print, batch_processor=batch_processor):
