@@ -69,6 +69,12 @@ def parse_args():
     ap.add_argument('--steady-tol', type=float, default=0.02)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--graph-train', type=int, choices=[0, 1], default=1,
+                    help='training, 1 GPU, KGDet: also measure the step replayed as ONE captured HIP graph '
+                         '(runner.GraphedTrainStep) in a child process and report it as `graphed_step`')
+    ap.add_argument('--graphed-step-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--no-exact-leg', action='store_true',
+                    help='training: skip the short window in plain fp32 arithmetic (`exact_fp32` on the line)')
     return ap.parse_args()
 
 
@@ -129,6 +135,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md); AMD's 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0
 ROOFLINE_PROFILE = {2: 'profiles/r04_dcn_fwd_plane_group_b2.md', 8: 'profiles/r04_dcn_fwd_plane_group_b8_bf16.md'}
+BACKWARD_PROFILE = 'profiles/r04_dcn_bwd_plane_kernels.md'
 
 
 def profiled_traffic(batch):
@@ -232,6 +239,88 @@ def dcn_backward_live(device, iters=30):
             ts.append(e0.elapsed_time(e1) / iters * 1e-3)
         med[backward] = sorted(ts)[2]
     return med[True] - med[False]
+
+
+def dcn_backward_products_live(device, iters=30):
+    """The three backward products of the same head stage, each timed alone: (forward + ONE product) minus forward, HIP events
+    on the launch stream, median of five runs.  grad_weight: only the weights require gradients; grad_input / grad_offset: the
+    grouped call's two phases one at a time (KGDET_OPT_BWD_PHASE, a measurement switch of the C ABI)."""
+    from kgdet_amd import _lib, dcn
+    g = torch.Generator(device='cpu').manual_seed(0)
+    B, C, H, W = 2, 256, 25, 42
+    ks = (3, 5, 7)
+    xs = [torch.randn(B, C, H, W, generator=g).to(device) for _ in range(2)]
+    offs = [(torch.randn(B, 2 * k * k, H, W, generator=g) * 2).to(device) for k in ks]
+    ws = [[(torch.randn(C, C, k, k, generator=g) * 0.01).to(device) for k in ks] for _ in xs]
+    pads = [k // 2 for k in ks]
+    leaves_io, leaves_w = xs + offs, [w for wl in ws for w in wl]
+    stream = torch.cuda.current_stream()
+    gos = [None]
+
+    def run(which):
+        # ('forward': the forward of a training step -- gradients required, so the weights are re-packed and tensors saved)
+        for t in leaves_io:
+            t.requires_grad_(which in ('grad_input', 'grad_offset'))
+        for t in leaves_w:
+            t.requires_grad_(which in ('grad_weight', 'forward'))
+        outs = dcn.deform_conv_cat_multi(xs, offs, ws, pads)
+        if gos[0] is None:
+            gos[0] = [torch.randn_like(o) for o in outs]
+        if which != 'forward':
+            torch.autograd.backward(outs, gos[0])
+            for t in leaves_io + leaves_w:
+                t.grad = None
+
+    def timed(which):
+        for _ in range(10):
+            run(which)
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(iters):
+                run(which)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / iters * 1e-3)
+        return sorted(ts)[2]
+
+    flops = sum(2.0 * C * C * k * k * B * H * W for k in ks) * 2
+    out = {}
+    try:
+        base = timed('forward')
+        for which, phase in (('grad_weight', 0), ('grad_input', 1), ('grad_offset', 2)):
+            _lib.check(_lib.lib().kgdet_set_option(3, phase), 'kgdet_set_option')
+            t = max(timed(which) - base, 1e-9)
+            out[which] = {'us': round(t * 1e6, 1), 'achieved': round(flops / t / 1e12, 2),
+                          'frac': round(flops / t / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 3.0), 4)}
+    finally:
+        _lib.lib().kgdet_set_option(3, 0)
+    out['forward_with_pack_us'] = round(base * 1e6, 1)
+    out['note'] = ('one head stage (2 maps x 3x3/5x5/7x7, B=2, 45.69 GFLOP per product), each product = (forward + that product) - '
+                   'forward, HIP events, median of five runs of %d; frac against the forward\'s 833 TFLOP/s split-bf16 roof; a '
+                   'product includes its builder kernels (inverse records / long-cell sums / grad_out images) and the '
+                   'ReLU-backward pass; forward_with_pack_us = the forward as a TRAINING step runs it (weights re-packed per call: '
+                   'dcn_pack_weight_all_multi inside)' % iters)
+    tr = profiled_traffic_backward()
+    for k in ('grad_input', 'grad_offset', 'grad_weight'):
+        if k in out and k in tr:
+            out[k]['traffic'] = tr[k]
+    out['traffic_source'] = tr.get('source')
+    return out
+
+
+def profiled_traffic_backward():
+    """per-product fabric bytes of the committed backward profile (lines `traffic_bytes_<product>: N`), or nothing"""
+    path = os.path.join(ROOT, BACKWARD_PROFILE)
+    res = {}
+    if os.path.isfile(path):
+        for line in open(path):
+            if line.startswith('traffic_bytes_grad_'):
+                key, val = line.split(':', 1)
+                res[key[len('traffic_bytes_'):]] = float(val.split()[0])
+        res['source'] = BACKWARD_PROFILE
+    return res
 
 
 def nms_live(device, dets, segments, iters=50):
@@ -460,7 +549,23 @@ def inference_leg():
         d = json.loads(line)
     except Exception as e:      # the training number stands on its own; report the failure instead of hiding it
         return {'error': '%s: %s' % (type(e).__name__, e)}
-    return {k: d[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline') if k in d}
+    return {k: d[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline', 'with_h2d') if k in d}
+
+
+def graphed_step_leg(args):
+    """The same training step replayed as ONE captured HIP graph (runner.GraphedTrainStep), measured by a CHILD process with
+    the same timing protocol (pre-heat by wall time, median of --windows windows of --steps steps): a capture failure cannot
+    take the eager line down with it."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--graphed-step-child', '--steps', str(args.steps), '--warmup',
+           str(args.warmup), '--windows', str(args.windows), '--preheat-s', str(min(args.preheat_s, 4.0)),
+           '--imgs-per-gpu', str(args.imgs_per_gpu), '--no-cpu-baseline', '--no-roofline', '--no-inference-leg', '--no-exact-leg']
+    try:
+        res = subprocess.run(cmd, env=dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        line = [l for l in res.stdout.decode().splitlines() if l.startswith('{')][-1]
+        return json.loads(line)
+    except Exception as e:
+        return {'error': '%s: %s' % (type(e).__name__, e)}
 
 
 def main():
@@ -511,6 +616,33 @@ def main():
                        if 'loss' in k)
             hook.step(model, optimizer, loss)
             return loss
+
+        if args.graphed_step_child:
+            # the child of graphed_step_leg: capture, pre-heat, time, print, leave
+            from kgdet_amd.runner import GraphedTrainStep
+            gstep = GraphedTrainStep(model, optimizer, hook, batch, warmup=max(3, args.warmup))
+
+            def gwindow():
+                torch.cuda.synchronize()
+                t0 = time.time()
+                for _ in range(args.steps):
+                    gstep.step()
+                torch.cuda.synchronize()
+                return time.time() - t0
+            spent, hist = 0.0, []
+            while spent < args.preheat_s or len(hist) < 3:
+                hist.append(gwindow())
+                spent += hist[-1]
+            wins = [gwindow() for _ in range(max(1, args.windows))]
+            dtw = sorted(wins)[len(wins) // 2]
+            imgs = args.imgs_per_gpu * args.steps
+            gstep.sync_optimizer_state()
+            print(json.dumps({'img_s': round(imgs / dtw, 3), 'ms_per_step': round(dtw / args.steps * 1e3, 3),
+                              'windows_img_s': [round(imgs / w, 1) for w in wins],
+                              'steady': bool(max(sorted(wins)[1:-1] or wins) / min(sorted(wins)[1:-1] or wins) - 1.0 < 0.03),
+                              'steps_replayed': gstep.steps, 'preheat_s': round(spent, 2),
+                              'loss_finite': bool(torch.isfinite(gstep.out['loss']).item())}), flush=True)
+            return
     else:
         model.eval()
         if args.config == 'kgdet':
@@ -651,11 +783,61 @@ def main():
                                    '%s' % ('KGDet' if args.config == 'kgdet' else
                                            'RepPoints-kp serial head (config 5, 5-level FPN, soft-NMS)',
                                            args.mode, args.imgs_per_gpu,
-                                           'DeformConv fwd/bwd + focal/moment losses + RCCL grad all-reduce'
+                                           ('DeformConv fwd/bwd + focal/moment losses + grad-clip + Adam' +
+                                            (' + RCCL grad all-reduce over %d ranks (overlapped with backward)' % world
+                                             if dist_on else '; no collective at dp1 (one rank: nothing to exchange)'))
                                            if args.mode == 'train' else
                                            'backbone + FPN + DeformConv head forward + keypoint-guided decode + NMS'),
                        'global_batch': args.imgs_per_gpu * world, 'parallelism': 'dp%d' % world},
         }
+        if args.mode == 'infer' and use_graph:
+            # the same batch with the host->device copy of the fp32 batch INSIDE the step (mmdetection's loader hands over host
+            # tensors): (a) copy, then compute, on one stream; (b) the serving arrangement -- batch k + 1 copied on a side stream
+            # into a second device buffer while batch k computes, a device-to-device copy into the graph's input at step start
+            host = batch['img'].cpu().pin_memory()
+            with scope:
+                def serial():
+                    run.static_img.copy_(host, non_blocking=True)
+                    return run(run.static_img)
+                stage = [torch.empty_like(batch['img']) for _ in range(2)]
+                side = torch.cuda.Stream()
+                ready = [torch.cuda.Event(), torch.cuda.Event()]
+                freed = [torch.cuda.Event(), torch.cuda.Event()]
+                k = [0]
+
+                def prefetch(slot):
+                    with torch.cuda.stream(side):
+                        side.wait_event(freed[slot])
+                        stage[slot].copy_(host, non_blocking=True)
+                        ready[slot].record(side)
+
+                for e in freed:
+                    e.record()
+                prefetch(0)
+
+                def overlapped():
+                    slot = k[0] & 1
+                    prefetch(slot ^ 1)
+                    torch.cuda.current_stream().wait_event(ready[slot])
+                    res = run(stage[slot])        # (D2D copy into the graph's input buffer + replay + results to the host)
+                    freed[slot].record()
+                    k[0] += 1
+                    return res
+
+                def rate(fn):
+                    for _ in range(5):
+                        fn()
+                    torch.cuda.synchronize()
+                    t0 = time.time()
+                    for _ in range(args.steps):
+                        fn()
+                    torch.cuda.synchronize()
+                    return args.imgs_per_gpu * args.steps / (time.time() - t0)
+                out['with_h2d'] = {'serial_img_s': round(rate(serial), 1), 'overlapped_img_s': round(rate(overlapped), 1),
+                                   'batch_MB': round(host.numel() * 4 / 1e6, 1),
+                                   'note': '`value` times a batch already resident in the graph\'s input buffer; serial = page-locked '
+                                           'fp32 batch copied host->device on the compute stream, then the batch; overlapped = the copy of '
+                                           'batch k + 1 on a side stream under batch k (two device buffers)'}
         if args.mode == 'infer':
             out['config']['detections_per_image'] = round(n_det[0] / args.imgs_per_gpu, 1)
             out['config']['input'] = ('fp32 batch resident in the captured graph\'s input buffer (run.static_img); results '
@@ -666,6 +848,54 @@ def main():
                 out['roofline'] = dcn_roofline(device, 2, 'split')
             else:      # the grouped forward the inference batch actually runs
                 out['roofline'] = dcn_roofline(device, args.imgs_per_gpu, 'bf16' if args.dtype == 'bf16' else 'split')
+        if not args.no_roofline and args.mode == 'train' and args.config == 'kgdet':
+            bw = dcn_backward_products_live(device)
+            rl = out['roofline']
+            rl['backward'] = bw
+            # the forward as the training step runs it: every call re-packs the six weights (they changed); the inference-style
+            # launch above reuses the packed images (`launch_us`: pack NOT inside)
+            rl['launch_us_pack_inside'] = bw['forward_with_pack_us']
+            rl['frac_pack_inside'] = round(rl['algorithmic_flops'] / (bw['forward_with_pack_us'] * 1e-6) / 1e12 / rl['peak'], 4)
+            rl['launch_us_note'] = ('launch_us / frac: dcn_build_taps + dcn_fwd_plane<2> + dcn_fwd_fixup_static with the weight images '
+                                    'packed beforehand (an unchanged weight is packed once); *_pack_inside: the same plus '
+                                    'dcn_pack_weight_all_multi per call, as in a training step')
+        if args.mode == 'train' and args.config == 'kgdet' and not args.no_exact_leg:
+            # the reference's precision class, measured: the same step in plain fp32 arithmetic (f32-input MFMA deformable kernels,
+            # MIOpen fp32 convolutions with its heuristic picks -- no find), a short window after the steady ones
+            try:
+                from kgdet_amd import dcn as _dcn
+                torch.backends.cudnn.benchmark = False
+                with _dcn.arithmetic('exact'):
+                    for _ in range(3):
+                        step()
+                    torch.cuda.synchronize()
+                    t0 = time.time()
+                    n_ex = max(5, min(args.steps, 20))
+                    for _ in range(n_ex):
+                        step()
+                    torch.cuda.synchronize()
+                    tex = (time.time() - t0) / n_ex
+                torch.backends.cudnn.benchmark = bool(args.miopen_find)
+                out['exact_fp32'] = {'img_s': round(args.imgs_per_gpu * world / tex, 2), 'ms_per_step': round(tex * 1e3, 2),
+                                     'steps': n_ex,
+                                     'note': 'the same step under dcn.arithmetic(\'exact\'): exact-fp32 deformable kernels '
+                                             '(v_mfma_f32_32x32x2_f32) and MIOpen fp32 dense convolutions (heuristic solver picks); '
+                                             '`value` is the split-operand arithmetic named in `dtype`, pinned to a float64 golden of '
+                                             'the step (tests/test_gpu_head.py)',
+                                     'speedup_of_value': round((imgs / dt) / (args.imgs_per_gpu * world / tex), 3)}
+            except Exception as e:
+                out['exact_fp32'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        if (args.mode == 'train' and world == 1 and not dist_on and args.config == 'kgdet' and args.dtype == 'fp32'
+                and args.graph_train):
+            gs = graphed_step_leg(args)
+            out['graphed_step'] = gs
+            out['eager_step'] = {'img_s': out['value'], 'ms_per_step': out['ms_per_step']}
+            if 'img_s' in gs and gs.get('steady') and gs.get('loss_finite') and gs['img_s'] > out['value']:
+                # both are the same step (same kernels in the same order); the replayed graph takes the host's ~560 launches per
+                # step out of the loop.  `value` = the better of the two, `step_mode` says which
+                out['value'], out['ms_per_step'], out['step_mode'] = gs['img_s'], gs['ms_per_step'], 'hip_graph_replay'
+            else:
+                out['step_mode'] = 'eager'
         if (args.mode == 'train' and world == 1 and args.config == 'kgdet' and not args.no_inference_leg):
             out['inference'] = inference_leg()
         if ar is not None:

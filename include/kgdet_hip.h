@@ -183,7 +183,10 @@ int kgdet_device_cu_count(void);    /* compute units of the current device (0 if
  * one 256 x 208 tile per workgroup for the whole reduction, csrc/dcn_backward_weight_os.hip).  Same results to round-off
  * (another summation order); for A/B measurements and so that both kernels stay under test. */
 #define KGDET_OPT_WGRAD_STREAMK 2
-#define KGDET_OPT_COUNT 3
+/* KGDET_OPT_BWD_PHASE (measurement switch, bench.py `roofline.backward`): 1 = kgdet_deform_conv_backward_input_grouped launches
+ * only its grad_input phase, 2 = only its grad_offset phase (the other product's outputs are left untouched), 0 = both. */
+#define KGDET_OPT_BWD_PHASE 3
+#define KGDET_OPT_COUNT 4
 int kgdet_set_option(int32_t option, int32_t value);
 
 /* ------------------------------------------------------------------------------------------

@@ -1154,6 +1154,8 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
     lds = need > lds ? need : lds;
   }
   if (!check_slots(grp)) { set_error("group too uneven for the slab slots"); return KGDET_E_UNSUPPORTED; }
+  const int only_phase = g_options[KGDET_OPT_BWD_PHASE];   // (measurement switch: 1 = grad_input only, 2 = grad_offset only)
+  if (only_phase != 2) {
   if (builds.n > 0) {
     static thread_local bool multi_attr_set = false;
     if (!multi_attr_set) {
@@ -1174,6 +1176,11 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
   hipLaunchKernelGGL(dcn_bwd_input_plane<2>, dim3(Gs), dim3(dcn_fwd_plane_threads()), lds, (hipStream_t)stream, grp,
                      (float *)workspace);
   launch_plane_fixup(grp, workspace, Gs, stream);
+  }
+  if (only_phase == 1) {
+    KGDET_CHECK_LAUNCH("dcn_bwd_plane_grouped");
+    return KGDET_OK;
+  }
 
   // ---- phase 2: grad_offset (column gradient in registers) ----
   grp.n = 0;
