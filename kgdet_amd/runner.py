@@ -12,6 +12,9 @@ What the reference gets from ``mmcv==0.2.13``'s ``Runner`` + hooks (third-party,
   regular rate.
 * ``Runner`` -- epoch loop, ``DistOptimizerHook`` (all-reduce + grad-clip 35 + step), checkpoint every ``interval``
   epochs as ``epoch_{n}.pth`` + ``latest.pth`` with ``meta = {epoch, iter}`` and the optimizer state, ``resume``.
+* ``single_gpu_test`` / ``multi_gpu_test`` / ``collect_results`` -- ``mmdetection/tools/test.py:18-100``: inference over a
+  dataset, sharded by rank (sample i of the padded index list goes to rank i % world_size, the ``DistributedSampler(shuffle=False)``
+  of ``mmdet/datasets/loader/build_loader.py``), results gathered on rank 0 in dataset order, padding samples dropped.
 """
 import os
 import shutil
@@ -128,6 +131,79 @@ class LrSchedule(object):
                 self._set(optimizer, self.warm(cur_iter))
         elif self.warmup is not None and cur_iter <= self.warmup_iters:
             self._set(optimizer, self.regular_lr if cur_iter == self.warmup_iters else self.warm(cur_iter))
+
+
+def test_shard(n, world_size, rank):
+    """Indices of rank ``rank``: the reference's test-time ``DistributedSampler(dataset, world_size, rank, shuffle=False)`` -- the
+    index list padded by wrapping to a multiple of ``world_size``, then every ``world_size``-th index from ``rank`` on."""
+    total = int(-(-n // world_size)) * world_size
+    idx = list(range(n))
+    idx += idx[:total - n]
+    return idx[rank:total:world_size]
+
+
+def _test_on(model, dataset, indices, rescale, to_device, imgs_per_gpu=1):
+    """results of the samples ``indices`` in that order.  imgs_per_gpu == 1: the reference's call, one image per forward
+    (``model(return_loss=False, rescale=..., **data)``, tools/test.py:25-28); > 1: runs of consecutive samples with identical
+    tensor shapes and one augmentation go through ``simple_test_batch`` together (the same per-image results: nothing in
+    backbone / neck / head / decode / NMS mixes the images of a batch)."""
+    model.eval()
+    results, i = [], 0
+    while i < len(indices):
+        data = dataset[indices[i]]
+        group = [data]
+        while (imgs_per_gpu > 1 and len(group) < imgs_per_gpu and i + len(group) < len(indices) and len(data['img']) == 1):
+            nxt = dataset[indices[i + len(group)]]
+            if len(nxt['img']) != 1 or nxt['img'][0].shape != data['img'][0].shape:
+                break
+            group.append(nxt)
+        with torch.no_grad():
+            if len(group) == 1:
+                imgs = [t[None] for t in data['img']]
+                metas = [[m] for m in data['img_meta']]
+                if to_device is not None:
+                    imgs = [to_device(t) for t in imgs]
+                results.append(model(imgs, metas, return_loss=False, rescale=rescale))
+            else:
+                img = torch.stack([g['img'][0] for g in group])
+                if to_device is not None:
+                    img = to_device(img)
+                results.extend(model.simple_test_batch(img, [g['img_meta'][0] for g in group], rescale=rescale))
+        i += len(group)
+    return results
+
+
+def single_gpu_test(model, dataset, rescale=True, to_device=None, imgs_per_gpu=1):
+    """tools/test.py:18-35 without the progress bar: one result per sample, in dataset order"""
+    return _test_on(model, dataset, list(range(len(dataset))), rescale, to_device, imgs_per_gpu)
+
+
+def collect_results(result_part, size, group=None):
+    """tools/test.py:61-100 with the gather done by the process group instead of pickles in a shared temporary directory:
+    rank 0 receives every rank's list, interleaves them (sample k of rank r is dataset index k * world_size + r), cuts the
+    padding samples off and returns ``size`` results; the other ranks return None."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return list(result_part)[:size]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(result_part, parts, dst=0, group=group)
+    if rank != 0:
+        return None
+    ordered = []
+    for res in zip(*parts):          # (every rank holds the same number of samples: the index list was padded)
+        ordered.extend(list(res))
+    return ordered[:size]
+
+
+def multi_gpu_test(model, dataset, rescale=True, to_device=None, imgs_per_gpu=1, group=None):
+    """tools/test.py:38-58: every rank runs its shard of the dataset, rank 0 returns all results in dataset order"""
+    import torch.distributed as dist
+    on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if on else 1
+    rank = dist.get_rank(group) if on else 0
+    part = _test_on(model, dataset, test_shard(len(dataset), world, rank), rescale, to_device, imgs_per_gpu)
+    return collect_results(part, len(dataset), group)
 
 
 class GraphedTrainStep(object):
