@@ -432,42 +432,57 @@ def modulated_deform_conv(*args):
     return _autocast_apply(ModulatedDeformConvFunction.apply, args)
 
 
-class DeformConv(nn.Module):
+def _fan_in_uniform_(weight, in_channels, kernel_size):
+    """the reference modules' initialisation (deform_conv.py:227-232, :291-298): U(-1/sqrt(fan), +1/sqrt(fan)), fan = in_channels * kh * kw
+    (the FULL in_channels, also for grouped weights -- kept as the reference has it)"""
+    bound = 1.0 / math.sqrt(in_channels * kernel_size[0] * kernel_size[1])
+    with torch.no_grad():
+        weight.uniform_(-bound, bound)
 
-    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
-                 groups=1, deformable_groups=1, bias=False):
-        super(DeformConv, self).__init__()
 
-        assert not bias
-        assert in_channels % groups == 0, \
-            'in_channels {} cannot be divisible by groups {}'.format(in_channels, groups)
-        assert out_channels % groups == 0, \
-            'out_channels {} cannot be divisible by groups {}'.format(out_channels, groups)
+class _DeformConvBase(nn.Module):
+    """what the four op modules share: the constructor contract of the reference (argument names, attribute names, the
+    ``weight`` / ``bias`` parameters and their checkpoint keys) and the weight-image cache rule"""
 
-        self.in_channels = in_channels
-        self.out_channels = out_channels
+    def _configure(self, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, deformable_groups):
+        for name, c in (('in_channels', in_channels), ('out_channels', out_channels)):
+            if c % groups:
+                raise AssertionError('%s = %d is not a multiple of groups = %d' % (name, c, groups))
+        self.in_channels, self.out_channels = in_channels, out_channels
         self.kernel_size = _pair(kernel_size)
-        self.stride = _pair(stride)
-        self.padding = _pair(padding)
-        self.dilation = _pair(dilation)
-        self.groups = groups
-        self.deformable_groups = deformable_groups
-
-        self.weight = nn.Parameter(
-            torch.Tensor(out_channels, in_channels // self.groups, *self.kernel_size))
-
-        self.reset_parameters()
+        self.groups, self.deformable_groups = groups, deformable_groups
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, *self.kernel_size))
+        return stride, padding, dilation
 
     def train(self, mode=True):
         clear_pack_cache()   # weights may have been updated without a version bump (fused optimizers)
         return super().train(mode)
 
     def reset_parameters(self):
-        n = self.in_channels
-        for k in self.kernel_size:
-            n *= k
-        stdv = 1. / math.sqrt(n)
-        self.weight.data.uniform_(-stdv, stdv)
+        _fan_in_uniform_(self.weight, self.in_channels, self.kernel_size)
+        if getattr(self, 'bias', None) is not None:
+            nn.init.zeros_(self.bias)
+
+    def _offset_conv(self, maps_per_tap):
+        """the Pack variants' zero-initialised convolution that predicts the offsets (and masks) from the input itself"""
+        conv = nn.Conv2d(self.in_channels, self.deformable_groups * maps_per_tap * self.kernel_size[0] * self.kernel_size[1],
+                         kernel_size=self.kernel_size, stride=_pair(self.stride), padding=_pair(self.padding), bias=True)
+        nn.init.zeros_(conv.weight)
+        nn.init.zeros_(conv.bias)
+        return conv
+
+
+class DeformConv(_DeformConvBase):
+    """mmdet/ops/dcn/deform_conv.py:190-236 (v1: no bias, stride / padding / dilation as pairs)"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, deformable_groups=1, bias=False):
+        super(DeformConv, self).__init__()
+        assert not bias, 'DeformConv has no bias (deform_conv.py:204)'
+        stride, padding, dilation = self._configure(in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                                                    deformable_groups)
+        self.stride, self.padding, self.dilation = _pair(stride), _pair(padding), _pair(dilation)
+        self.reset_parameters()
 
     def forward(self, x, offset):
         return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation,
@@ -475,62 +490,35 @@ class DeformConv(nn.Module):
 
 
 class DeformConvPack(DeformConv):
+    """deform_conv.py:239-262: the offsets come from ``conv_offset(x)``"""
 
     def __init__(self, *args, **kwargs):
         super(DeformConvPack, self).__init__(*args, **kwargs)
-
-        self.conv_offset = nn.Conv2d(
-            self.in_channels,
-            self.deformable_groups * 2 * self.kernel_size[0] * self.kernel_size[1],
-            kernel_size=self.kernel_size, stride=_pair(self.stride), padding=_pair(self.padding),
-            bias=True)
-        self.init_offset()
+        self.conv_offset = self._offset_conv(2)
 
     def init_offset(self):
-        self.conv_offset.weight.data.zero_()
-        self.conv_offset.bias.data.zero_()
+        nn.init.zeros_(self.conv_offset.weight)
+        nn.init.zeros_(self.conv_offset.bias)
 
     def forward(self, x):
-        offset = self.conv_offset(x)
-        return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation,
+        return deform_conv(x, self.conv_offset(x), self.weight, self.stride, self.padding, self.dilation,
                            self.groups, self.deformable_groups)
 
 
-class ModulatedDeformConv(nn.Module):
+class ModulatedDeformConv(_DeformConvBase):
+    """deform_conv.py:265-305 (v2: optional bias, stride / padding / dilation kept as given)"""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
                  groups=1, deformable_groups=1, bias=True):
         super(ModulatedDeformConv, self).__init__()
-        self.in_channels = in_channels
-        self.out_channels = out_channels
-        self.kernel_size = _pair(kernel_size)
-        self.stride = stride
-        self.padding = padding
-        self.dilation = dilation
-        self.groups = groups
-        self.deformable_groups = deformable_groups
+        self.stride, self.padding, self.dilation = self._configure(in_channels, out_channels, kernel_size, stride, padding,
+                                                                   dilation, groups, deformable_groups)
         self.with_bias = bias
-
-        self.weight = nn.Parameter(
-            torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
         if bias:
-            self.bias = nn.Parameter(torch.Tensor(out_channels))
+            self.bias = nn.Parameter(torch.empty(out_channels))
         else:
             self.register_parameter('bias', None)
         self.reset_parameters()
-
-    def train(self, mode=True):
-        clear_pack_cache()   # weights may have been updated without a version bump (fused optimizers)
-        return super().train(mode)
-
-    def reset_parameters(self):
-        n = self.in_channels
-        for k in self.kernel_size:
-            n *= k
-        stdv = 1. / math.sqrt(n)
-        self.weight.data.uniform_(-stdv, stdv)
-        if self.bias is not None:
-            self.bias.data.zero_()
 
     def forward(self, x, offset, mask):
         return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride,
@@ -539,26 +527,20 @@ class ModulatedDeformConv(nn.Module):
 
 
 class ModulatedDeformConvPack(ModulatedDeformConv):
+    """deform_conv.py:308-337: offsets and masks from ``conv_offset_mask(x)`` (first two thirds: offsets, last third: sigmoid masks)"""
 
     def __init__(self, *args, **kwargs):
         super(ModulatedDeformConvPack, self).__init__(*args, **kwargs)
-
-        self.conv_offset_mask = nn.Conv2d(
-            self.in_channels,
-            self.deformable_groups * 3 * self.kernel_size[0] * self.kernel_size[1],
-            kernel_size=self.kernel_size, stride=_pair(self.stride), padding=_pair(self.padding),
-            bias=True)
-        self.init_offset()
+        self.conv_offset_mask = self._offset_conv(3)
 
     def init_offset(self):
-        self.conv_offset_mask.weight.data.zero_()
-        self.conv_offset_mask.bias.data.zero_()
+        nn.init.zeros_(self.conv_offset_mask.weight)
+        nn.init.zeros_(self.conv_offset_mask.bias)
 
     def forward(self, x):
-        out = self.conv_offset_mask(x)
-        o1, o2, mask = torch.chunk(out, 3, dim=1)
-        offset = torch.cat((o1, o2), dim=1)
-        mask = torch.sigmoid(mask)
+        both = self.conv_offset_mask(x)
+        n_off = both.shape[1] // 3 * 2
+        offset, mask = both[:, :n_off], torch.sigmoid(both[:, n_off:])
         return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride,
                                      self.padding, self.dilation, self.groups,
                                      self.deformable_groups)

@@ -210,7 +210,7 @@ def check_kgdet_head(head, device, tol_map=2e-4, tol_loss=2e-4, tol_grad=1e-3):
     err_u = np.abs(gx_unpinned - gx_ref) / np.abs(gx_ref).max()
     worst['grad:x:unpinned'] = float(err_u.max())
     worst['grad:x:unpinned:frac'] = float((err_u > tol_grad).mean())
-    assert worst['grad:x:unpinned'] < 10 * tol_grad and worst['grad:x:unpinned:frac'] < 0.005, \
+    assert worst['grad:x:unpinned'] < 3 * tol_grad and worst['grad:x:unpinned:frac'] < 0.002, \
         (worst['grad:x:unpinned'], worst['grad:x:unpinned:frac'])
     params = dict(head.named_parameters())
     for key in G.files:
