@@ -174,10 +174,12 @@ int kgdet_device_cu_count(void);    /* compute units of the current device (0 if
  * instead of the split-bf16 plane kernels it prefers for v1 problems -- the arithmetic of the reference's fp32
  * col2im path (deform_conv_cuda.cpp:260-371), used to measure what the hi/lo split costs over a training step. */
 #define KGDET_OPT_EXACT_BACKWARD 0
-/* KGDET_OPT_TAP_PAIRS != 0: deformable forwards with >= 7 taps on small maps take the tap-pair kernel (8-channel half-planes
- * in a ring of three, stages = pairs of taps: csrc/dcn_plane_pairs.h) instead of the default plane kernel.  Same results to
- * round-off; measured slower on MI355X (192 against 174 us for a KGDet head stage), kept as a working alternative. */
-#define KGDET_OPT_TAP_PAIRS 1
+/* KGDET_OPT_FWD_COLUMN_WAVE != 0 (or the environment variable KGDET_DCN_CW=1): split-operand forwards on the LDS plane take the
+ * column-wave kernel (csrc/dcn_forward_cw.hip: four waves, each samples the B fragment it multiplies, feature planes by LDS-DMA from a
+ * blocked copy of the input) where its conditions hold (static ranges of whole chunks, >= 3 taps).  Same results to round-off;
+ * measured slower than the default plane kernel on MI355X (198 against 168 us for a KGDet head stage): an experiment kept under test.
+ * (Slot 1 was KGDET_OPT_TAP_PAIRS in rounds 2-4: that kernel left the library, tools/experiments/dcn_plane_pairs.h.) */
+#define KGDET_OPT_FWD_COLUMN_WAVE 1
 /* KGDET_OPT_WGRAD_STREAMK != 0: kgdet_deform_conv_grad_weight_grouped keeps rounds 1-3's schedule -- 256 x 128 tiles, (tile,
  * stage) units dealt stream-K, partial tiles + fix-up -- where it would otherwise run the output-stationary kernel (round 4:
  * one 256 x 208 tile per workgroup for the whole reduction, csrc/dcn_backward_weight_os.hip).  Same results to round-off

@@ -533,13 +533,11 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
   unsigned char *const table_base = (unsigned char *)workspace + slab_bytes();
   size_t table_used = 0;  // bytes of tap records placed behind the slabs for the pending group
   const int parts = (flags & KGDET_DCN_BF16) ? 1 : 2;
-  bool grp_pair = false;   // the pending group runs the tap-pair kernel (all its problems must agree)
+  const bool grp_pair = false;   // (the tap-pair kernel of rounds 2-4 left the library in round 5: tools/experiments/dcn_plane_pairs.h)
   int max_hw = 0;
-  static const bool pairs_env = getenv("KGDET_DCN_PAIRS") != nullptr && atoi(getenv("KGDET_DCN_PAIRS")) != 0;   // A/B switch
-  const bool pairs_off = !(pairs_env || g_options[KGDET_OPT_TAP_PAIRS] != 0);   // (off by default: measured slower)
   static const int cw_env = getenv("KGDET_DCN_CW") ? atoi(getenv("KGDET_DCN_CW")) : 0;   // A/B switch
   auto cw_ok = [&]() {
-    if (!cw_env || parts != 2 || grp_pair || !grp.static_ranges) return false;
+    if (!(cw_env || g_options[KGDET_OPT_FWD_COLUMN_WAVE] != 0) || parts != 2 || grp_pair || !grp.static_ranges) return false;
     for (int i = 0; i < grp.n; ++i)
       if (grp.p[i].K < 3 || grp.p[i].H * grp.p[i].W > kPlaneMaxHW) return false;
     return true;
@@ -586,24 +584,7 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
     }
     hipLaunchKernelGGL(dcn_build_taps, dim3(2 * Gf, grp.n), dim3(256), 0, (hipStream_t)stream, grp);
     const int threads = dcn_fwd_plane_threads();
-    if (grp_pair) {   // K >= 7 everywhere in the group: half-chunk planes, tap-pair stages (dcn_plane_pairs.h)
-      static thread_local bool pairs_attr_set = false;
-      if (!pairs_attr_set) {
-        KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_fwd_plane_pairs<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)kMaxLds));
-        KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_fwd_plane_pairs<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)kMaxLds));
-        pairs_attr_set = true;
-      }
-      grp.plane_bytes = (int)dcn_fwd_plane_pairs_plane_bytes(max_hw);
-      grp.dbl_plane = 0;
-      grp.wave_layout = 1;
-      const size_t ldsp = dcn_fwd_plane_pairs_lds_bytes(parts, max_hw);
-      if (parts == 1)
-        hipLaunchKernelGGL(dcn_fwd_plane_pairs<1>, dim3(G), dim3(768), ldsp, (hipStream_t)stream, grp, (float *)workspace);
-      else
-        hipLaunchKernelGGL(dcn_fwd_plane_pairs<2>, dim3(G), dim3(768), ldsp, (hipStream_t)stream, grp, (float *)workspace);
-    } else if (use_cw) {   // column-wave kernel (dcn_forward_cw.hip): static ranges of whole chunks, K >= 3, split operands
+    if (use_cw) {   // column-wave kernel (dcn_forward_cw.hip): static ranges of whole chunks, K >= 3, split operands
       static thread_local bool cw_attr_set = false;
       if (!cw_attr_set) {
         KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_fwd_cw<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
@@ -650,17 +631,7 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
       p.n_mtiles = d.Og_pad / kTileM;
       p.chunks_per_tap = d.Cg_pad / kChunk;
       p.chunks_per_tile = d.K * p.chunks_per_tap;
-      const bool pair = use_plane && !pairs_off && d.K >= 7 &&
-                        dcn_fwd_plane_pairs_lds_bytes(parts, s->H * s->W) <= kMaxLds;
-      if (use_plane && grp.n > 0 && pair != grp_pair)
-        if (int rc = flush()) return rc;
-      if (use_plane && pair) {   // stages = (8-channel half-chunk, tap pair)
-        p.seg_stages = (d.K + 1) / 2;
-        p.chunks_per_tap = 2 * (d.Cg_pad / kChunk);
-        p.chunks_per_tile = p.seg_stages * p.chunks_per_tap;
-      }
       if (use_plane) {
-        grp_pair = pair;
         max_hw = s->H * s->W > max_hw ? s->H * s->W : max_hw;
         p.wq = packed_weights[i] + (size_t)s->groups * (d.fwd_image_floats() + d.bwd_image_floats()) +
                (size_t)g * d.plane_image_floats();

@@ -216,7 +216,7 @@ struct DcnProblem {
   long long total_units;  // n_ntiles * n_mtiles * chunks_per_tile
   int tiles_per_image;    // > 0: pixel tiles never straddle images (plane kernel); 0: tiles run over N*Ho*Wo
   int kparts;             // plane kernel: the reduction range of every tile is cut into kparts parts (see DcnFwdGroup)
-  int seg_stages;         // stages per chunk of the reduction: K, or ceil(K / 2) with tap-pair stages (dcn_plane_pairs.h)
+  int seg_stages;         // stages per chunk of the reduction: K
   unsigned flags;
 };
 
@@ -233,7 +233,7 @@ struct DcnFwdGroup {
   int plane_bytes; // plane kernels: bytes of the largest feature plane of the group
   int wave_layout;    // accumulator layout of the slabs: 0 = 4 x 2 waves of 64 x 64 (2 x 2 MFMA blocks each),
                       // 1 = 8 x 1 waves of 32 x 128 (1 x 4 blocks each; plane kernels: every wave loads DISTINCT weight rows)
-  int pair_mode;      // 1: tap-pair stages on 8-channel half-planes (dcn_plane_pairs.h): tap records address 32-byte rows
+  int pair_mode;      // (unused since round 5: the tap-pair kernel left the library, tools/experiments/dcn_plane_pairs.h)
   int gather_mode;    // 1: no LDS plane (maps beyond kPlaneMaxHW): x is a pixel-major copy [N][H*W][C] and the tap records hold
                       //    byte offsets of its rows -- the producers gather 16-byte channel quads with buffer loads (plane_role MODE 2)
   int rounds;         // static schedule: the workgroup of slice r computes ranges r, r + G, ..., r + (rounds - 1) G

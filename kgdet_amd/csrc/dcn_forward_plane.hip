@@ -34,7 +34,6 @@
 //   lane l of a wave reads row/col (l & 31) of k-half (l >> 5) as one 16-byte ds_read_b128; reduction
 //   element k = khalf*8 + j is channel c16*16 + k for both operands.
 #include "dcn_plane.h"
-#include "dcn_plane_pairs.h"
 
 namespace kgdet {
 
@@ -85,21 +84,6 @@ __global__ __launch_bounds__(256) void dcn_to_pixel_major(const float *__restric
 int dcn_fwd_plane_threads() { return kRoleThreads; }
 int dcn_plane_wave_layout() { return KGDET_PLANE_WAVES42 ? 0 : 1; }   // DcnFwdGroup::wave_layout of plane_role's slabs
 
-// K >= 7 taps: half-chunk planes, tap-pair stages (dcn_plane_pairs.h)
-template <int PARTS>
-__global__ __launch_bounds__(kPlaneThreads, 1) void dcn_fwd_plane_pairs(const DcnFwdGroup grp, float *__restrict__ slabs) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if (threadIdx.x >= kThreads) pair_role<PARTS, true>(grp, slabs, smem);
-  else pair_role<PARTS, false>(grp, slabs, smem);
-}
-template __global__ void dcn_fwd_plane_pairs<1>(const DcnFwdGroup grp, float *__restrict__ slabs);
-template __global__ void dcn_fwd_plane_pairs<2>(const DcnFwdGroup grp, float *__restrict__ slabs);
-size_t dcn_fwd_plane_pairs_fixed_lds_bytes(int parts) { return (size_t)2 * kPairGroup * parts * kBPart; }
-size_t dcn_fwd_plane_pairs_plane_bytes(int HW) { return ((size_t)kPairRow * HW + 255) & ~(size_t)255; }
-size_t dcn_fwd_plane_pairs_lds_bytes(int parts, int HW) {
-  return dcn_fwd_plane_pairs_fixed_lds_bytes(parts) + kPairPlanes * dcn_fwd_plane_pairs_plane_bytes(HW);
-}
-
 #ifdef KGDET_PLANE_TRACE
 }  // namespace kgdet
 extern "C" int kgdet_debug_read_plane_trace(unsigned long long *out) {   // the forward kernel's copy
@@ -134,9 +118,8 @@ __global__ __launch_bounds__(256) void dcn_build_taps(const DcnFwdGroup grp) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int q = tap.o[e];
-      r.off[e] = grp.pair_mode ? (unsigned)(q * kPairRow + (((q >> 3) & 1) << 4))      // half-plane rows (dcn_plane_pairs.h)
-                 : grp.gather_mode ? (unsigned)q * (unsigned)(p.C_total * 4)           // rows of the pixel-major image
-                                   : (unsigned)dcn_plane_offset(q);
+      r.off[e] = grp.gather_mode ? (unsigned)q * (unsigned)(p.C_total * 4)           // rows of the pixel-major image
+                                 : (unsigned)dcn_plane_offset(q);
       r.w[e] = tap.w[e];
     }
     const_cast<DcnTapRec *>(p.taps)[i] = r;

@@ -24,11 +24,6 @@ __global__ void dcn_fwd_cw(const DcnFwdGroup grp, float *__restrict__ slabs);
 int dcn_fwd_cw_threads();
 size_t dcn_fwd_cw_lds_bytes(int parts);
 size_t dcn_fwd_cw_xblk_bytes(int N, int Cg_pad, int HW);
-template <int PARTS>
-__global__ void dcn_fwd_plane_pairs(const DcnFwdGroup grp, float *__restrict__ slabs);
-size_t dcn_fwd_plane_pairs_fixed_lds_bytes(int parts);
-size_t dcn_fwd_plane_pairs_plane_bytes(int HW);
-size_t dcn_fwd_plane_pairs_lds_bytes(int parts, int HW);
 // large-map v1 backward without atomics (dcn_backward_large.hip)
 bool dcn_bwd_large_ok(const DcnProblem &p, bool has_mask, int groups);
 size_t dcn_bwd_large_workspace_bytes(const DcnProblem &p);

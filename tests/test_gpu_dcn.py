@@ -709,12 +709,13 @@ def test_random_shapes_split_kernels_agree_with_exact_fp32():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('B', [2, 5])
-def test_tap_pair_kernel_matches_default_plane_kernel(B):
-    """KGDET_OPT_TAP_PAIRS: the alternative forward kernel for >= 7 taps (8-channel half-planes in a ring of three, stages
-    = pairs of taps, csrc/dcn_plane_pairs.h) on the KGDet head stage -- 3x3 / 5x5 / 7x7, odd tap counts (a missing
-    second tap per half-chunk), static ranges (B = 2) and rounds (B = 5), ReLU + channel-offset epilogue -- against the
-    default plane kernel to fp32 round-off of the output scale."""
+def test_column_wave_kernel_matches_default_plane_kernel_and_oracle(B):
+    """KGDET_OPT_FWD_COLUMN_WAVE: the experimental forward kernel of round 5 (csrc/dcn_forward_cw.hip -- four waves, each samples
+    the B fragment it multiplies, planes by LDS-DMA from the blocked input copy) on the KGDet head stage -- 3x3 / 5x5 / 7x7,
+    static ranges (B = 2) and rounds (B = 5), ReLU + channel-offset epilogue, partial last pixel tiles -- against the default
+    plane kernel to fp32 round-off of the output scale, and one of its convolutions against the float64 oracle."""
     _require_gpu()
+    import oracle
     from kgdet_amd import dcn, _lib
     torch.manual_seed(7)
     C, H, W = 256, 25, 42
@@ -734,3 +735,6 @@ def test_tap_pair_kernel_matches_default_plane_kernel(B):
     for g, a, w in zip(got, again, want):
         assert torch.equal(g, a), 'deterministic'
         _close(g.cpu().numpy(), w.double().cpu().numpy(), 5e-6)   # (two split kernels with different summation orders)
+    ref = oracle.deform_conv_forward(xs[1].cpu().numpy().astype(np.float64), offsets[1].cpu().numpy().astype(np.float64),
+                                     weights[1][1].cpu().numpy().astype(np.float64), 1, 2, 1)
+    _close(got[1][:, 64:128].cpu().numpy(), np.maximum(ref, 0.0), 2e-5)
