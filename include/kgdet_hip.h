@@ -233,6 +233,14 @@ int kgdet_dcn_pack_weight(const kgdet_dcn_shape *s, const float *weight, float *
  * same images as n kgdet_dcn_pack_weight calls. */
 int kgdet_dcn_pack_weight_multi(int32_t n, const kgdet_dcn_shape *const *shapes, const float *const *weights,
                                 float *const *packeds, void *stream);
+/* The same with a choice of images (training re-packs every weight every step: 170 MB written per KGDet head stage for all four
+ * images): bit 0 of `images` = the two fp32 images (exact-fp32 forward, fallback backward kernels), bit 1 = the two split (bf16
+ * hi/lo) images of the default kernels.  kgdet_dcn_split_path_complete(shape) = 1 when every product of a convolution of that
+ * shape has a split-operand kernel, i.e. nothing reads the fp32 images unless an exact-arithmetic switch is set.  The packed
+ * buffer's layout and size do not change; images that are not packed are left as they are. */
+int kgdet_dcn_pack_weight_images(int32_t n, const kgdet_dcn_shape *const *shapes, const float *const *weights,
+                                 float *const *packeds, uint32_t images, void *stream);
+int32_t kgdet_dcn_split_path_complete(const kgdet_dcn_shape *shape);
 /* packed gradient image -> grad_weight [O, C/groups, kh, kw]; accumulate != 0 adds into grad_weight */
 int kgdet_dcn_unpack_weight_grad(const kgdet_dcn_shape *s, const float *packed, float *grad_weight,
                                  int accumulate, void *stream);

@@ -2150,7 +2150,10 @@ static int conv3x3_grad_weight_impl(const float *grad_y, const float *x, float *
   KGDET_CHECK_SHAPE(grad_y && x && grad_w && workspace, "null pointer");
   KGDET_CHECK_SHAPE(workspace_bytes >= kgdet_conv3x3_grad_weight_workspace_bytes(B, O, C, H, W), "workspace too small");
   const int W_true = W;
-  const bool use_ntp = ntp_on(9) && W >= 4 && (long long)H * W >= 4 && (long long)(O > C ? O : C) * H * ((W + 3) & ~3) < (1ll << 30);
+  // (H * W <= 2^21: conv_ntp derives a stage's row as (int)((p0 + 0.5f) * (1.0f / W)) -- exact while p0 < 2^24 and the product's
+  //  rounding error stays below half a row; larger maps take conv_nt8, which counts rows)
+  const bool use_ntp = ntp_on(9) && W >= 4 && (long long)H * W >= 4 && (long long)H * W <= (1ll << 21) &&
+                       (long long)(O > C ? O : C) * H * ((W + 3) & ~3) < (1ll << 30);
   if (W % 4 && use_ntp) {
     W = (W + 3) & ~3;          // (the split count below is the one the workspace query computed for the padded size)
   } else if (W % 4) {

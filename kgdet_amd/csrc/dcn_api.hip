@@ -442,7 +442,22 @@ int kgdet_dcn_pack_weight(const kgdet_dcn_shape *s, const float *weight, float *
 // n weights in ONE launch (every weight: one weight group, fused pack kernel); anything else: one call each
 int kgdet_dcn_pack_weight_multi(int32_t n, const kgdet_dcn_shape *const *shapes, const float *const *weights,
                                 float *const *packeds, void *stream) {
+  return kgdet_dcn_pack_weight_images(n, shapes, weights, packeds, 3, stream);
+}
+
+// 1 when EVERY product of a convolution of this shape -- forward, grad_input, grad_offset, grad_weight -- has a split-operand
+// kernel: such a convolution never reads the two fp32 images of its packed weight
+int32_t kgdet_dcn_split_path_complete(const kgdet_dcn_shape *s) {
+  Derived d;
+  if (!s || derive(s, d)) return 0;
+  return s->groups == 1 && s->deformable_groups == 1 && plane_ok(s, d) && plane_bwd_input_ok(s, d) && plane_bwd_offset_ok(s, d)
+             ? 1 : 0;
+}
+
+int kgdet_dcn_pack_weight_images(int32_t n, const kgdet_dcn_shape *const *shapes, const float *const *weights,
+                                 float *const *packeds, uint32_t images, void *stream) {
   KGDET_CHECK_SHAPE(n >= 1 && shapes && weights && packeds, "null pointer");
+  KGDET_CHECK_SHAPE((images & 3u) != 0 && (images & ~3u) == 0, "images: bit 0 = the fp32 images, bit 1 = the split (bf16 hi/lo) images");
   int i = 0;
   while (i < n) {
     DcnPackGroup grp;
@@ -454,7 +469,7 @@ int kgdet_dcn_pack_weight_multi(int32_t n, const kgdet_dcn_shape *const *shapes,
       if (int rc = derive(s, d)) return rc;
       KGDET_CHECK_SHAPE(weights[i] && packeds[i], "null pointer (weight %d)", i);
       const size_t lds_all = (size_t)8 * 33 * (d.K + 1) * sizeof(float);
-      if (s->groups != 1 || lds_all > kMaxLds - 64) {   // not the fused single-group case: on its own
+      if (s->groups != 1 || lds_all > kMaxLds - 64) {   // not the fused single-group case: on its own (all images)
         if (m > 0) break;
         if (int rc = kgdet_dcn_pack_weight(s, weights[i], packeds[i], stream)) return rc;
         continue;
@@ -465,10 +480,12 @@ int kgdet_dcn_pack_weight_multi(int32_t n, const kgdet_dcn_shape *const *shapes,
       DcnPackOne &e = grp.e[m++];
       float *packed = packeds[i];
       e.w = weights[i];
-      e.wpk = packed;
-      e.wpt = packed + d.fwd_image_floats();
-      e.wq = plane ? (void *)(packed + d.fwd_image_floats() + d.bwd_image_floats()) : nullptr;
-      e.wqt = plane ? (void *)(packed + d.fwd_image_floats() + d.bwd_image_floats() + d.plane_image_floats()) : nullptr;
+      // (a weight without split images keeps its fp32 ones whatever the mask says: nothing else could serve it)
+      const bool fp32_images = (images & 1u) || !plane || !(images & 2u);
+      e.wpk = fp32_images ? packed : nullptr;
+      e.wpt = fp32_images ? packed + d.fwd_image_floats() : nullptr;
+      e.wq = plane && (images & 2u) ? (void *)(packed + d.fwd_image_floats() + d.bwd_image_floats()) : nullptr;
+      e.wqt = plane && (images & 2u) ? (void *)(packed + d.fwd_image_floats() + d.bwd_image_floats() + d.plane_image_floats()) : nullptr;
       e.Og = d.Og; e.Cg = d.Cg; e.K = d.K; e.Cg_pad = d.Cg_pad; e.Og_pad = d.Og_pad; e.Og_pad16 = d.Og_pad16;
       e.Cg_pad256 = d.Cg_pad256;
       gx = d.Cg_pad256 / 8 > gx ? d.Cg_pad256 / 8 : gx;

@@ -172,8 +172,9 @@ __device__ __forceinline__ void pack_weight_all_body(const float *__restrict__ w
   const int cbase = c8 * 8;
   if (cbase < Cg_pad && o0 < Og_pad) {
     const int oo = tid & 31, cc = tid >> 5;
-    for (int t = 0; t < K; ++t)
-      wpk[((long long)t * Cg_pad + cbase + cc) * Og_pad + o0 + oo] = tile[(cc * 33 + oo) * ld + t];
+    if (wpk)
+      for (int t = 0; t < K; ++t)
+        wpk[((long long)t * Cg_pad + cbase + cc) * Og_pad + o0 + oo] = tile[(cc * 33 + oo) * ld + t];
     if (wq) {
       const int n_c16 = Cg_pad / kChunk;
       const int c16 = c8 >> 1, khalf = c8 & 1;
@@ -196,7 +197,7 @@ __device__ __forceinline__ void pack_weight_all_body(const float *__restrict__ w
   }
   if (o0 < Og_pad16) {
     const int cc = tid & 7, oo = tid >> 3;
-    if (o0 + oo < Og_pad16)
+    if (wpt && o0 + oo < Og_pad16)
       for (int t = 0; t < K; ++t)
         wpt[((long long)t * Og_pad16 + o0 + oo) * Cg_pad256 + cbase + cc] = tile[(cc * 33 + oo) * ld + t];
     if (wqt) {  // transposed operand image: rows = input channels, reduction = output channels

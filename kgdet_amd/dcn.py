@@ -10,6 +10,7 @@ Reference interface mirrored (R = mmdetection/mmdet/ops/dcn/deform_conv.py):
 As in the reference there is no CPU implementation: non-GPU tensors raise NotImplementedError.
 """
 import ctypes
+import os
 import math
 import weakref
 
@@ -172,10 +173,24 @@ def clear_pack_cache():
 _inference_depth = 0   # > 0 while a public op was entered with autograd disabled (torch.no_grad inference)
 
 
-def pack_weights(weights, shapes):
+SPLIT_ONLY_PACKS = os.environ.get('KGDET_DCN_SPLIT_ONLY_PACKS', '1') == '1'   # 0: training packs all four images (A/B)
+
+
+def split_images_suffice(shapes):
+    """True when no product of these convolutions will read the fp32 weight images: the default arithmetic is selected and
+    every shape has split-operand kernels for forward, grad_input, grad_offset and grad_weight"""
+    if not SPLIT_ONLY_PACKS or _FORWARD_PRECISION == 'exact' or _EXACT_BACKWARD:
+        return False
+    L = _lib.lib()
+    return all(L.kgdet_dcn_split_path_complete(ctypes.byref(s)) == 1 for s in shapes)
+
+
+def pack_weights(weights, shapes, split_only=False):
     """pack_weight for several weights: those that need packing (all of them in training) go to the GPU as ONE launch
-    (kgdet_dcn_pack_weight_multi)"""
+    (kgdet_dcn_pack_weight_images).  ``split_only``: only the bf16 hi/lo images (training: half the bytes written -- the caller
+    vouches with ``split_images_suffice`` that nothing will read the fp32 images); cached inference packs are always complete."""
     cacheable = _inference_depth > 0
+    split_only = bool(split_only) and not cacheable
     L = _lib.lib()
     out, todo = [None] * len(weights), []
     for i, (w, s) in enumerate(zip(weights, shapes)):
@@ -193,8 +208,8 @@ def pack_weights(weights, shapes):
         shape_arr = (ctypes.POINTER(_lib.DcnShape) * n)(*[ctypes.pointer(shapes[i]) for i, _ in todo])
         w_arr = (ctypes.c_void_p * n)(*[weights[i].data_ptr() for i, _ in todo])
         p_arr = (ctypes.c_void_p * n)(*[out[i].data_ptr() for i, _ in todo])
-        _lib.check(L.kgdet_dcn_pack_weight_multi(ctypes.c_int32(n), shape_arr, w_arr, p_arr, _lib.current_stream()),
-                   'kgdet_dcn_pack_weight_multi')
+        _lib.check(L.kgdet_dcn_pack_weight_images(ctypes.c_int32(n), shape_arr, w_arr, p_arr, ctypes.c_uint32(2 if split_only else 3),
+                                                  _lib.current_stream()), 'kgdet_dcn_pack_weight_images')
         if cacheable:
             for i, key in todo:
                 if len(_pack_cache) >= _PACK_CACHE_MAX:
@@ -587,7 +602,8 @@ class DeformConvCatFunction(Function):
                 wcs.append(ws_i[k].contiguous())
                 o_base += ws_i[k].shape[0]
             outs.append(out)
-        packs = pack_weights(wcs, shapes)      # one launch for all of them
+        split_only = split_images_suffice(shapes)
+        packs = pack_weights(wcs, shapes, split_only)      # one launch for all of them
         n = n_x * n_k
         arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
         shape_arr = (ctypes.POINTER(_lib.DcnShape) * n)(*[ctypes.pointer(s) for s in shapes])
@@ -597,7 +613,7 @@ class DeformConvCatFunction(Function):
             arr([offsets[j % n_k] for j in range(n)]), None, arr(packs), None,
             arr([outs[j // n_k] for j in range(n)]), _fwd_flags(relu), _lib.ptr(ws), ctypes.c_size_t(ws.numel()),
             _lib.current_stream()), 'kgdet_deform_conv_forward_grouped')
-        ctx.shapes, ctx.relu, ctx.n_x, ctx.n_k = shapes, relu, n_x, n_k
+        ctx.shapes, ctx.relu, ctx.n_x, ctx.n_k, ctx.split_only = shapes, relu, n_x, n_k, split_only
         ctx.save_for_backward(*xs, *outs, *offsets, *weights, *packs)
         return tuple(outs)
 
@@ -659,6 +675,9 @@ class DeformConvCatFunction(Function):
                              weight=need[n_x + n_k + j] and not done_w, bias=False)
                 if not any(needs.values()):
                     continue
+                if ctx.split_only:     # (a fallback kernel after all: it reads the fp32 images the forward did not pack)
+                    packs = pack_weights([w.contiguous() for w in weights], ctx.shapes)
+                    ctx.split_only = False
                 gi, go, _, gw, _ = _backward(xs[i], offsets[k], None, weights[j], None, gouts[i], ctx.shapes[j],
                                              packs[j], needs)
                 if gi is not None and needs['input']:

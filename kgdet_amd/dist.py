@@ -82,8 +82,11 @@ class OverlappedGradReducer(object):
     (parameter count, sizes and dtypes in bucket order) and one tiny all-gather compares the hashes -- a mismatch
     raises on every rank instead of hanging in the first differently-sized collective; (b) every flat buffer carries
     one has-gradient flag per parameter behind the payload, summed by the same all-reduce; the sums are copied to
-    page-locked host memory without a synchronisation and inspected at the NEXT step's ``finish()``: a parameter
+    page-locked host memory without a synchronisation and inspected at the NEXT step's ``finish()``: a BUCKETED parameter
     with a gradient on some ranks only (0 < count < world size) raises there -- one step late, never silently.
+    NOT covered: a parameter OUTSIDE the buckets (no gradient when they were built) that starts to receive a
+    gradient on some ranks only -- those ranks rebuild (an all-gather) while the others issue the next all-reduce: mismatched
+    collectives.  The same event on EVERY rank (a branch that becomes active) rebuilds consistently.
     """
 
     def __init__(self, params, bucket_size_mb=32, process_group=None):
