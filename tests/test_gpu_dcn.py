@@ -368,6 +368,35 @@ def test_grouped_forward_matches_single_calls(B):
         _close(a.cpu().numpy(), o.grad.double().cpu().numpy(), 1e-5)
 
 
+@pytest.mark.parametrize('B,prec,tol', [(8, 'bf16', 1e-2), (8, 'split', 2e-5), (2, 'split', 2e-5)])
+def test_grouped_head_stage_launch_against_the_oracle(B, prec, tol):
+    """BASELINE config 2's exact launch (and the bench's roofline launch): the grouped head-stage forward -- 2 maps x 3x3 / 5x5 /
+    7x7 at FULL width (256 -> 256 channels) on [B, 256, 25, 42], ReLU and the three channel windows of one buffer per map, in the
+    arithmetic the inference batch uses (bf16 operands, B = 8) and in the training arithmetic -- compared DIRECTLY with the float64
+    oracle (deform_conv_cuda.cpp:151-258 restated), not only with single calls of the same kernels."""
+    _require_gpu()
+    from kgdet_amd import dcn
+    g = torch.Generator().manual_seed(11)
+    C, H, W = 256, 25, 42
+    xs = [torch.randn(B, C, H, W, generator=g) for _ in range(2)]
+    ks = (3, 5, 7)
+    offsets = [torch.randn(B, 2 * k * k, H, W, generator=g) * 2 for k in ks]
+    weights = [[torch.randn(C, C, k, k, generator=g) * 0.02 for k in ks] for _ in xs]
+    pads = [k // 2 for k in ks]
+    with torch.no_grad(), dcn.forward_precision(prec):
+        outs = dcn.deform_conv_cat_multi([x.cuda() for x in xs], [o.cuda() for o in offsets],
+                                         [[w.cuda() for w in wl] for wl in weights], pads, relu=True)
+    for i in range(2):
+        got = outs[i].cpu().numpy()
+        assert got.shape == (B, 3 * C, H, W)
+        for k in range(3):
+            # (images 0 and B - 1: the first and the last pixel tiles of the launch; the oracle's im2col + GEMM in float64)
+            for b in (0, B - 1):
+                ref = oracle.deform_conv_forward(xs[i][b:b + 1].numpy().astype(np.float64), offsets[k][b:b + 1].numpy().astype(np.float64),
+                                                 weights[i][k].numpy().astype(np.float64), 1, pads[k], 1)
+                _close(got[b:b + 1, k * C:(k + 1) * C], np.maximum(ref, 0.0), tol)
+
+
 def test_autocast_contract():
     """under torch.autocast(bfloat16) the ops cast activations up to float32, use bf16 products
     (KGDET_DCN_BF16) and return float32; a non-float32 tensor outside autocast is rejected, never
