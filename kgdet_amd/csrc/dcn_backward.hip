@@ -7,12 +7,10 @@
 //   deform_conv_backward_parameters_cuda deform_conv_cuda.cpp:373-484 = a second im2col + addmm_.
 // Neither column matrix exists here.
 //
-// dcn_bwd_input_mfma : per (tap t, 256 channels c, 128 pixels p) tile
-//       colgrad[c,p] = sum_o Wt[t][o][c] * g[o,p]            (MFMA, reduction over o)
-//   and, while the tile is still in registers,
-//       grad_offset[p,t,{y,x}] = sum_c colgrad * d(sample_c)/d{y,x}   (wave shuffle + LDS reduce)
-//       grad_mask[p,t]         = sum_c colgrad * sample_c             (v2)
-//       grad_input[b,c,corner] += colgrad * bilinear weight           (float atomics, as the reference)
+// (backward w.r.t. input / offset / mask: dcn_backward_plane.hip, dcn_backward_offset.hip, dcn_backward_gather.hip and, for maps
+//  beyond the LDS plane and any grouping, dcn_backward_large.hip.  Rounds 1-4 kept dcn_bwd_input_mfma here -- the column gradient
+//  scattered with float atomics, as the reference does -- for weight groups / deformable groups on large maps: removed in round 5,
+//  the library has no float atomic left.)
 // dcn_bwd_weight_mfma: per (tap t, 256 out-channels o, 128 channels c) tile
 //       gW[t][c][o] = sum_p g[o,p] * sample_c(p,t)             (MFMA, reduction over pixels,
 //   stream-K over pixel stages with deterministic slab fix-up), written in the packed layout.
@@ -20,173 +18,6 @@
 #include "dcn_kernels.h"
 
 namespace kgdet {
-
-namespace {
-constexpr int kLdsA = kChunk * kTileM;
-constexpr int kLdsB = kChunk * kTileN;
-}  // namespace
-
-// ------------------------------------------------------------------------------------------------
-// backward w.r.t. input / offset / mask
-// p.wpk here is the TRANSPOSED packed image Wt[t][o (pad 16)][c (pad 256)]; p.out is unused.
-// ------------------------------------------------------------------------------------------------
-
-__global__ __launch_bounds__(kThreads, 2) void dcn_bwd_input_mfma(const DcnProblem p, const DcnBwdInputArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * kLdsA + 2 * kLdsB];
-  float *As = lds;
-  float *Bs = lds + 2 * kLdsA;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 3, wn = wave >> 2;
-  const int n_local = tid & (kTileN - 1), kq = tid >> 7;
-  const int HW = p.H * p.W;
-  const int n_stages = a.Og_pad16 / kChunk;
-
-  for (int unit = blockIdx.x; unit < a.n_units; unit += gridDim.x) {
-    // unit -> (tap, channel tile, pixel tile); pixel tile fastest so neighbours share Wt[t]
-    const int nt = unit % a.n_ntiles;
-    const int ct = (unit / a.n_ntiles) % a.n_ctiles;
-    const int t = unit / (a.n_ntiles * a.n_ctiles);
-    const int c_tile0 = ct * kTileM;
-
-    // B operand source: grad_out[b, o, hw] for this thread's pixel
-    const int pix = nt * kTileN + n_local;
-    const bool live = pix < p.P;
-    const int pb = live ? pix / p.HoWo : 0;
-    const int hw = live ? pix - pb * p.HoWo : 0;
-    const float *gsrc = a.grad_out + ((long long)pb * p.O_total + p.o_base) * p.HoWo + hw;
-
-    f32x16 acc[2][2];
-    zero_acc(acc);
-    float gv[4];
-
-    auto stage_w = [&](int s, float *Adst) {  // Wt[t][16 o][256 c] -> LDS, lane-linear
-      const int wave_base = wave << 6;
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int q = tid + kThreads * r;
-        const int k = q >> 6, col4 = q & 63;
-        const float *src = p.wpk + ((long long)(t * a.Og_pad16 + s * kChunk + k) * a.Cg_pad256 + c_tile0 + col4 * 4);
-        float *dst = Adst + (wave_base + kThreads * r) * 4;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-      }
-    };
-    auto g_issue = [&](int s) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        // unconditional load from a clamped row (a select would make hipcc branch + drain vmcnt);
-        // rows >= Og meet zero weights, dead pixels are never stored
-        const int o = min(s * kChunk + kq * 4 + j, p.Og - 1);
-        gv[j] = gsrc[(long long)o * p.HoWo];
-      }
-    };
-    auto g_commit = [&](float *Bdst) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) Bdst[(kq * 4 + j) * kTileN + n_local] = gv[j];
-    };
-
-    stage_w(0, As);
-    g_issue(0);
-    g_commit(Bs);
-    __syncthreads();
-    int buf = 0;
-    for (int s = 0; s < n_stages; ++s) {
-      const bool more = (s + 1) < n_stages;
-      if (more) {
-        stage_w(s + 1, As + (buf ^ 1) * kLdsA);
-        g_issue(s + 1);
-      }
-      mfma_stage(As + buf * kLdsA, kTileM, Bs + buf * kLdsB, kTileN, wm * 64, wn * 64, lane, acc);
-      if (more) g_commit(Bs + (buf ^ 1) * kLdsB);
-      __syncthreads();
-      buf ^= 1;
-    }
-
-    // ---- epilogue: the tile holds colgrad[c, p] for tap t -------------------------------------
-    // lane owns pixel columns (ni) and 32 channel rows per column.
-    float *red = lds;  // [4 wm][128 px][3] partial sums, reuses the stage buffers (all reads done)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int px = nt * kTileN + wn * 64 + ni * 32 + (lane & 31);
-      const bool plive = px < p.P;
-      const int b = plive ? px / p.HoWo : 0;
-      const int phw = plive ? px - b * p.HoWo : 0;
-      const int oy = phw / p.Wo, ox = phw - oy * p.Wo;
-      const int dgi = (p.c_base + min(c_tile0, p.Cg - 1)) / p.cpdg;  // whole tile in one deformable group
-      float y = 0.f, x = 0.f, m = 0.f;
-      if (plive) tap_position(p, b, dgi, t, phw, oy, ox, y, x, m);
-      Tap tap;
-      TapGeom geo;
-      make_tap(y, x, p.H, p.W, plive, m, tap, geo);
-      const float hy = 1.0f - geo.ly, hx = 1.0f - geo.lx;
-      // unmasked bilinear weights for grad_mask; slopes use the raw corner values
-      const float ua = geo.va ? hy * hx : 0.f, ub = geo.vb ? hy * geo.lx : 0.f;
-      const float uc = geo.vc ? geo.ly * hx : 0.f, ud = geo.vd ? geo.ly * geo.lx : 0.f;
-      float sum_y = 0.f, sum_x = 0.f, sum_m = 0.f;
-      const float *xin = p.x + ((long long)b * p.C_total + p.c_base) * HW;
-      float *gin = a.grad_input + ((long long)b * p.C_total + p.c_base) * HW;
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int c = c_tile0 + wm * 64 + mi * 32 + mfma_row(r, lane);
-          if (c >= p.Cg || !geo.in_range) continue;
-          const float cg = acc[mi][ni][r];
-          const float *plane = xin + (long long)c * HW;
-          float *gplane = gin + (long long)c * HW;
-          const float va = geo.va ? plane[tap.o[0]] : 0.f;
-          const float vb = geo.vb ? plane[tap.o[1]] : 0.f;
-          const float vc = geo.vc ? plane[tap.o[2]] : 0.f;
-          const float vd = geo.vd ? plane[tap.o[3]] : 0.f;
-          // d/dy and d/dx of the bilinear sample (deform_conv_cuda_kernel.cu:144-187)
-          sum_y += cg * (hx * (vc - va) + geo.lx * (vd - vb));
-          sum_x += cg * (hy * (vb - va) + geo.ly * (vd - vc));
-          sum_m += cg * (ua * va + ub * vb + uc * vc + ud * vd);
-          // scatter to the four corners (deform_conv_cuda_kernel.cu:279-334)
-          if (geo.va) atomicAdd(gplane + tap.o[0], tap.w[0] * cg);
-          if (geo.vb) atomicAdd(gplane + tap.o[1], tap.w[1] * cg);
-          if (geo.vc) atomicAdd(gplane + tap.o[2], tap.w[2] * cg);
-          if (geo.vd) atomicAdd(gplane + tap.o[3], tap.w[3] * cg);
-        }
-      // the other half-wave holds the remaining rows of the same pixel
-      sum_y += __shfl_xor(sum_y, 32);
-      sum_x += __shfl_xor(sum_x, 32);
-      sum_m += __shfl_xor(sum_m, 32);
-      if (lane < 32) {
-        float *dst = red + ((wm * kTileN) + wn * 64 + ni * 32 + lane) * 3;
-        dst[0] = sum_y * m;  // v2: grad_offset carries the mask factor (:757); m == 1 for v1
-        dst[1] = sum_x * m;
-        dst[2] = sum_m;
-      }
-    }
-    __syncthreads();
-    if (tid < kTileN) {
-      const int px = nt * kTileN + tid;
-      if (px < p.P) {
-        float gy = 0.f, gx = 0.f, gm = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          const float *src = red + (w * kTileN + tid) * 3;
-          gy += src[0]; gx += src[1]; gm += src[2];
-        }
-        const int b = px / p.HoWo, phw = px - b * p.HoWo;
-        const int dgi = (p.c_base + min(c_tile0, p.Cg - 1)) / p.cpdg;
-        // several channel tiles / weight groups of one deformable group add up
-        float *go = a.grad_offset + ((long long)(b * p.DG + dgi) * 2 * p.K + 2 * t) * p.HoWo + phw;
-        if (a.direct) {
-          go[0] = gy; go[p.HoWo] = gx;
-          if (a.grad_mask) a.grad_mask[((long long)(b * p.DG + dgi) * p.K + t) * p.HoWo + phw] = gm;
-        } else {
-          atomicAdd(go, gy); atomicAdd(go + p.HoWo, gx);
-          if (a.grad_mask) atomicAdd(a.grad_mask + ((long long)(b * p.DG + dgi) * p.K + t) * p.HoWo + phw, gm);
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // backward w.r.t. weight

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void large_cell_entries(const DcnProblem p, in
     const int b = (int)(i / ((long long)p.HoWo * p.K));
     const int oy = hw / p.Wo, ox = hw - oy * p.Wo;
     float y, x, m;
-    tap_position(p, b, 0, t, hw, oy, ox, y, x, m);
+    tap_position(p, b, p.dgi, t, hw, oy, ox, y, x, m);
     Tap tap;
     TapGeom geo;
     make_tap(y, x, p.H, p.W, true, m, tap, geo);   // (v2: the modulation mask rides on the corner weights; m = 1 for v1)
@@ -265,7 +265,9 @@ constexpr int kGatherCells = 16;
 __global__ __launch_bounds__(256) void large_gather_input(const float *__restrict__ colT, const int *__restrict__ start,
                                                           const int *__restrict__ len,
                                                           const unsigned long long *__restrict__ vals,
-                                                          float *__restrict__ grad_input, int C, int K, int HW, int P) {
+                                                          float *__restrict__ grad_input, int C, int K, int HW, int P,
+                                                          int c_base, int C_all) {
+  // (grad_input: channels c_base .. c_base + C - 1 of a [N, C_all, HW] tensor -- a channel run of a grouped convolution)
   __shared__ float tile[kGatherCells][257];
   const int q0 = blockIdx.x * kGatherCells, b = blockIdx.y, c = blockIdx.z * 256 + threadIdx.x;
   const bool live = c < C;
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(256) void large_gather_input(const float *__restric
   const int lane_q = threadIdx.x & (kGatherCells - 1), ch_sub = threadIdx.x / kGatherCells;
   for (int c2 = ch_sub; c2 < 256; c2 += 256 / kGatherCells) {
     const int ch = blockIdx.z * 256 + c2, q = q0 + lane_q;
-    if (ch < C && q < HW && len[b * HW + q] <= kLargeWaveSortMax) grad_input[((long long)b * C + ch) * HW + q] = tile[lane_q][c2];
+    if (ch < C && q < HW && len[b * HW + q] <= kLargeWaveSortMax) grad_input[((long long)b * C_all + c_base + ch) * HW + q] = tile[lane_q][c2];
   }
 }
 
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(256) void large_gather_long_sum(const int *__restri
                                                              const int *__restrict__ long_n,
                                                              const int *__restrict__ chunk_first,
                                                              const float *__restrict__ part, float *__restrict__ grad_input,
-                                                             int C, int HW) {
+                                                             int C, int HW, int c_base, int C_all) {
   const int count = *long_n;
   for (int qi = blockIdx.x; qi < count; qi += gridDim.x) {
     const int cell = long_q[qi], b = cell / HW, q = cell - b * HW;
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256) void large_gather_long_sum(const int *__restri
     for (int c = threadIdx.x; c < C; c += 256) {
       float s = 0.0f;
       for (int j = 0; j < nch; ++j) s += part[(long long)(first + j) * C + c];      // chunk order
-      grad_input[((long long)b * C + c) * HW + q] = s;
+      grad_input[((long long)b * C_all + c_base + c) * HW + q] = s;
     }
   }
 }
@@ -388,7 +390,9 @@ __global__ __launch_bounds__(256) void large_gather_long_sum(const int *__restri
 constexpr int kLargeMaxK = 49;
 __global__ __launch_bounds__(256) void large_grad_offset(const DcnProblem p, const float *__restrict__ colT,
                                                          const float *__restrict__ xT, float *__restrict__ grad_offset,
-                                                         float *__restrict__ grad_mask) {
+                                                         float *__restrict__ grad_mask, int accumulate) {
+  // (p.C_total channels = one channel run; p.dgi: its deformable group; accumulate: a later run of the same deformable group
+  //  adds to the sums of the earlier ones -- launches run one after the other, so the order of the sum is fixed)
   __shared__ float red[4][3];
   const int hw = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int oy = hw / p.Wo, ox = hw - oy * p.Wo;
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(256) void large_grad_offset(const DcnProblem p, con
   const float *ximg = xT + (long long)b * HW * C;
   for (int t = 0; t < K; ++t) {
     float y, x, m;
-    tap_position(p, b, 0, t, hw, oy, ox, y, x, m);
+    tap_position(p, b, p.dgi, t, hw, oy, ox, y, x, m);
     Tap tap;
     TapGeom geo;
     make_tap(y, x, p.H, p.W, true, 1.0f, tap, geo);   // tap.w: the plain bilinear weights (d out / d mask = the sample)
@@ -435,10 +439,14 @@ __global__ __launch_bounds__(256) void large_grad_offset(const DcnProblem p, con
     if (tid == 0) {
       const float ty = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
       const float tx = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
-      float *dst = grad_offset + ((long long)b * 2 * K + 2 * t) * p.HoWo + hw;
-      dst[0] = ty;
-      dst[p.HoWo] = tx;
-      if (grad_mask) grad_mask[((long long)b * K + t) * p.HoWo + hw] = ((red[0][2] + red[1][2]) + red[2][2]) + red[3][2];
+      float *dst = grad_offset + ((long long)(b * p.DG + p.dgi) * 2 * K + 2 * t) * p.HoWo + hw;
+      dst[0] = accumulate ? dst[0] + ty : ty;
+      dst[p.HoWo] = accumulate ? dst[p.HoWo] + tx : tx;
+      if (grad_mask) {
+        float *dm = grad_mask + ((long long)(b * p.DG + p.dgi) * K + t) * p.HoWo + hw;
+        const float tm = ((red[0][2] + red[1][2]) + red[2][2]) + red[3][2];
+        *dm = accumulate ? *dm + tm : tm;
+      }
     }
   }
 }
@@ -470,21 +478,28 @@ LargePlan large_plan(const DcnProblem &p) {
 
 }  // namespace
 
-// eligible: v1 or v2 (mask), one weight group, one deformable group, O % 16 == 0, entry count within int range
+// eligible (p describes ONE channel run: C_total = the run's channels, Og = the output channels of its weight group):
+// v1 or v2 (mask), O % 16 == 0, entry count within int range
 bool dcn_bwd_large_ok(const DcnProblem &p, bool has_mask, int groups) {
   const long long n_entries = (long long)p.N * p.K * p.HoWo * 4;
-  (void)has_mask;
-  return groups == 1 && p.DG == 1 && p.Og % 16 == 0 && ((long long)p.K * p.C_total) % 2 == 0 &&
+  (void)has_mask; (void)groups;
+  return p.Og % 16 == 0 && ((long long)p.K * p.C_total) % 2 == 0 &&
          p.K <= kLargeMaxK && n_entries < (1LL << 31) && (long long)p.N * p.H * p.W < (1LL << 31) - 2 &&
          (long long)p.K * p.HoWo < (1LL << 30);
 }
 
 size_t dcn_bwd_large_workspace_bytes(const DcnProblem &p) { return large_plan(p).total; }
 
-// p: the FORWARD problem (x, offset, wpk = the [K][Cg_pad][Og_pad] fp32 weight image, geometry; Og = O, C_total = C)
+// p: the FORWARD problem of ONE CHANNEL RUN (round 5: weight groups and deformable groups run as channel runs, so the float-atomic
+// scatter kernel of rounds 1-4 is gone): x = the input's first channel of the run, C_total = the run's channel count, Og = the
+// output channels of the run's weight group, wpk = that group's [K][Cg_pad][Og_pad] fp32 weight image at the run's first channel,
+// DG / dgi = deformable groups of the convolution / the run's; x_channels = channels of the whole input tensor, c_base = the
+// run's first channel in it (grad_input is written there), accumulate_offset: an earlier run of the same deformable group
+// has written grad_offset / grad_mask already.  grad_output: the convolution's gradient buffer; out_channel_offset: first
+// channel of the run's weight group in it.
 int dcn_bwd_large(const DcnProblem &p, const float *grad_output, int out_channels_total,
                   int out_channel_offset, float *grad_input, float *grad_offset, float *grad_mask, void *workspace,
-                  size_t workspace_bytes, void *stream) {
+                  size_t workspace_bytes, void *stream, int x_channels, int c_base, int accumulate_offset) {
   const LargePlan L = large_plan(p);
   if (workspace == nullptr || workspace_bytes < L.total) {
     set_error("workspace too small for the large-map backward: need %zu bytes, got %zu", L.total, workspace_bytes);
@@ -514,7 +529,7 @@ int dcn_bwd_large(const DcnProblem &p, const float *grad_output, int out_channel
   hipLaunchKernelGGL(large_transpose, dim3((unsigned)((P + 31) / 32), (O + 31) / 32, p.N), dim3(256), 0, st,
                      grad_output + (long long)out_channel_offset * P, gT, O, P, (long long)O_total * P);
   hipLaunchKernelGGL(large_transpose, dim3((unsigned)((HW + 31) / 32), (C + 31) / 32, p.N), dim3(256), 0, st, p.x, xT, C,
-                     HW, (long long)C * HW);
+                     HW, (long long)x_channels * HW);
   hipLaunchKernelGGL(large_permute_weight, dim3(1024), dim3(256), 0, st, p.wpk, wp, O, C, K, p.Cg_pad, p.Og_pad);
   // colT[b] = gT[b] (P x O) * wp (O x KC): the pixels are the "output channels" of a 1x1 convolution over the KC-pixel
   // "image" wp
@@ -544,16 +559,16 @@ int dcn_bwd_large(const DcnProblem &p, const float *grad_output, int out_channel
   hipLaunchKernelGGL(large_cell_sort_long, dim3(512), dim3(256), kLargeLongSortLds * 8, st, (const int *)cell_start,
                      (const int *)cell_cnt, vals_a, vals_b, (const int *)long_q, (const int *)long_n);
   hipLaunchKernelGGL(large_gather_input, dim3((unsigned)((HW + kGatherCells - 1) / kGatherCells), p.N, (C + 255) / 256), dim3(256), 0, st, colT,
-                     (const int *)cell_start, (const int *)cell_cnt, vals_b, grad_input, C, K, (int)HW, (int)P);
+                     (const int *)cell_start, (const int *)cell_cnt, vals_b, grad_input, C, K, (int)HW, (int)P, c_base, x_channels);
   int *chunk_total = cell_total + 2;     // (zeroed with the counters)
   hipLaunchKernelGGL(large_long_chunks, dim3(64), dim3(256), 0, st, (const int *)cell_cnt, (const int *)long_q, (const int *)long_n,
                      chunk_total, chunk_first, chunk_rec);
   hipLaunchKernelGGL(large_gather_long, dim3(2048), dim3(256), 0, st, colT, (const int *)cell_start, (const int *)cell_cnt, vals_b,
                      (const int *)long_q, (const int *)chunk_total, (const int2 *)chunk_rec, chunk_part, C, K, (int)HW, (int)P);
   hipLaunchKernelGGL(large_gather_long_sum, dim3(1024), dim3(256), 0, st, (const int *)cell_cnt, (const int *)long_q,
-                     (const int *)long_n, (const int *)chunk_first, (const float *)chunk_part, grad_input, C, (int)HW);
+                     (const int *)long_n, (const int *)chunk_first, (const float *)chunk_part, grad_input, C, (int)HW, c_base, x_channels);
   hipLaunchKernelGGL(large_grad_offset, dim3((unsigned)P, p.N), dim3(256), 0, st, p, colT, xT, grad_offset,
-                     p.mask ? grad_mask : nullptr);
+                     p.mask ? grad_mask : nullptr, accumulate_offset);
   KGDET_CHECK_LAUNCH("dcn_bwd_large");
   return KGDET_OK;
 }

@@ -28,7 +28,8 @@ size_t dcn_fwd_cw_xblk_bytes(int N, int Cg_pad, int HW);
 bool dcn_bwd_large_ok(const DcnProblem &p, bool has_mask, int groups);
 size_t dcn_bwd_large_workspace_bytes(const DcnProblem &p);
 int dcn_bwd_large(const DcnProblem &p, const float *grad_output, int out_channels_total, int out_channel_offset,
-                  float *grad_input, float *grad_offset, float *grad_mask, void *workspace, size_t workspace_bytes, void *stream);
+                  float *grad_input, float *grad_offset, float *grad_mask, void *workspace, size_t workspace_bytes, void *stream,
+                  int x_channels, int c_base, int accumulate_offset);
 __global__ void dcn_build_taps(const DcnFwdGroup grp);
 // grad_input on the plane kernel (dcn_backward_plane.hip)
 template <int PARTS>
@@ -159,7 +160,6 @@ __global__ void dcn_bwd_input_fixup(const DcnProblem p, const DcnBwdInputLdsArgs
 __global__ void dcn_bwd_offset_fixup(const float *__restrict__ off_part, const float *__restrict__ mask_part,
                                      float *__restrict__ grad_offset, float *__restrict__ grad_mask, int n_slices,
                                      int N, int DG, int K, int HoWo, int n_cslices, int Cg, int cpdg);
-__global__ void dcn_bwd_input_mfma(const DcnProblem p, const DcnBwdInputArgs a);
 __global__ void dcn_bwd_weight_mfma(const DcnProblem p, const DcnBwdWeightArgs a, float *__restrict__ slabs);
 __global__ void dcn_bwd_weight_fixup(const DcnProblem p, const DcnBwdWeightArgs a, const float *__restrict__ slabs,
                                      int G);

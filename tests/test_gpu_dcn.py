@@ -233,6 +233,49 @@ def test_backward_v2(case):
     _close(tb.grad.cpu().numpy(), ref['grad_bias'], 5e-5)
 
 
+LARGE_GROUP_CASES = [
+    # maps beyond the LDS plane (1344 pixels) with weight groups / deformable groups: channel runs on the column-gradient path
+    (2, 32, 40, 40, 32, 3, 1, 1, 1, 2, 1),      # two weight groups
+    (1, 64, 38, 42, 32, 3, 1, 1, 1, 1, 4),      # four deformable groups of 16 channels
+    (2, 64, 40, 36, 64, 3, 1, 1, 1, 2, 4),      # two weight groups x four deformable groups
+    (1, 96, 38, 38, 48, 3, 1, 1, 1, 3, 1),      # three weight groups
+]
+
+
+@pytest.mark.parametrize('with_mask', [False, True])
+@pytest.mark.parametrize('case', LARGE_GROUP_CASES)
+def test_large_map_backward_input_with_groups_has_no_atomics(case, with_mask):
+    """Rounds 1-4 sent weight groups / deformable groups on maps beyond the LDS plane to a float-atomic scatter kernel (the
+    reference's own non-determinism, deform_conv_cuda_kernel.cu:329).  Round 5: channel runs on the column-gradient path
+    (csrc/dcn_backward_large.hip) -- grad_input, grad_offset (summed over the runs of a deformable group) and grad_mask against
+    the float64 oracle, and bit-identical on a second call."""
+    _require_gpu()
+    from kgdet_amd import dcn
+    N, C, H, W, O, k, s, p, d, g, dg = case
+    x, off, w, go, mask = _make(case, seed=3, with_mask=with_mask)
+    ref = oracle.deform_conv_backward(x.astype(np.float64), off.astype(np.float64), w.astype(np.float64), go.astype(np.float64),
+                                      s, p, d, g, dg, mask=None if mask is None else mask.astype(np.float64))
+    want = (ref['grad_input'], ref['grad_offset'], ref.get('grad_mask'))
+    outs = []
+    for _ in range(2):
+        tx, to = torch.from_numpy(x).cuda().requires_grad_(), torch.from_numpy(off).cuda().requires_grad_()
+        tw = torch.from_numpy(w).cuda().requires_grad_()
+        if with_mask:
+            tm = torch.from_numpy(mask).cuda().requires_grad_()
+            y = dcn.modulated_deform_conv(tx, to, tm, tw, None, s, p, d, g, dg)
+        else:
+            tm = None
+            y = dcn.deform_conv(tx, to, tw, s, p, d, g, dg)
+        y.backward(torch.from_numpy(go).cuda())
+        outs.append((tx.grad.clone(), to.grad.clone(), None if tm is None else tm.grad.clone()))
+    _close(outs[0][0].cpu().numpy(), want[0], 5e-5)
+    _close(outs[0][1].cpu().numpy(), want[1], 5e-5)
+    if with_mask:
+        _close(outs[0][2].cpu().numpy(), want[2], 5e-5)
+    for a, b in zip(outs[0], outs[1]):
+        assert a is None or torch.equal(a, b)
+
+
 def test_large_map_v2_backward_is_repeatable():
     """modulated DCN on a map beyond the LDS-plane kernels: the column-gradient path (no float atomics) serves v2 too"""
     _require_gpu()
