@@ -56,6 +56,14 @@ int kgdet_conv_apply_epilogue_fmt(const void *packed, const float *x, float *y, 
                                   int32_t relu, int64_t B, int32_t M, int32_t K, int32_t H, int32_t W, int32_t taps,
                                   int32_t stride, int32_t operand_format, void *workspace, size_t workspace_bytes,
                                   void *stream);
+/* ... with gate [B, M, Ho, Wo] (nullable): y = [gate > 0] * ([relu](conv + bias [+ residual])).  The backward of the ReLU in
+ * front of a convolution (mmdet/models/backbones/resnet.py:240-262: relu(norm(conv(.))) feeding the next conv) applied in the
+ * store of that convolution's grad_input kernel, gate = its forward input: the producer of the input then receives its
+ * gradient already masked (kgdet_amd/backbone.py _GateLink). */
+int kgdet_conv_apply_gated_fmt(const void *packed, const float *x, float *y, const float *bias, const float *residual,
+                               int32_t relu, const float *gate, int64_t B, int32_t M, int32_t K, int32_t H, int32_t W,
+                               int32_t taps, int32_t stride, int32_t operand_format, void *workspace, size_t workspace_bytes,
+                               void *stream);
 int kgdet_stem_conv7x7_s2_fmt(const void *packed, const float *x, float *y, int64_t B, int32_t H, int32_t W,
                               int32_t operand_format, void *stream);
 /* forward and grad_input images of one weight in one launch (O and C multiples of 16) */

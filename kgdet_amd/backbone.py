@@ -259,6 +259,23 @@ def _bn_fold_lib():
     return L
 
 
+GATE_FUSION = _os.environ.get('KGDET_GATE_FUSION', '1') == '1'    # 0: every ReLU node masks its own gradient (A/B)
+
+
+class _GateLink(object):
+    """Hand-over between two ``_ConvBNActFold`` nodes ``z = relu(...)`` -> ``u = conv(z)`` where u's node is the ONLY consumer of z
+    (inside a bottleneck: conv1 -> conv2 -> conv3; between the bottlenecks of a layer: block output -> next block's conv1, whose
+    ``skip`` alias also carries the identity branch).  The consumer's backward zeroes grad_z where z <= 0 in the store of its
+    grad_input kernel (``conv1x1.grad_input(gate=z)``) and sets ``gated``; the producer's backward, which runs later, then skips
+    its masking pass (read gradient, read z, write masked gradient: three passes over the activation, `relu_sum_bwd_kernel<true>`)
+    and only sums the gradient per channel.  The mask is idempotent, so a producer whose link was never set (the consumer took
+    another route) masks as before: nothing depends on the two nodes agreeing in advance."""
+    __slots__ = ('gated',)
+
+    def __init__(self):
+        self.gated = False
+
+
 class _ConvBNActFold(torch.autograd.Function):
     """``[relu](batch_norm_eval(conv(x, w)) [+ residual])`` with the BatchNorm FOLDED into the convolution: the step scope's
     pack launch wrote the operand images of ``w * s`` (s = gamma / sqrt(var + eps)), so the forward is ONE kernel --
@@ -270,10 +287,14 @@ class _ConvBNActFold(torch.autograd.Function):
     pair's second step on (conv1x1.fold_images); same arguments and results."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, mean, var, eps, residual, relu, skip, fold):
+    def forward(ctx, x, weight, gamma, beta, mean, var, eps, residual, relu, skip, fold, gate_in=None, gate_out=None):
+        # gate_in: the _GateLink through which this node's output gradient may arrive already masked by [z > 0];
+        # gate_out: the link of the node that produced x = relu(.) -- this node masks grad_x with [x > 0] and says so
         img, ctx.img_t, s, t = fold
         z = conv1x1._apply(img, x, weight.shape[0], weight.shape[2] * weight.shape[3], 1, t, residual, relu)
         ctx.eps, ctx.relu, ctx.has_res = eps, relu, residual is not None
+        ctx.gate_in = gate_in if relu else None
+        ctx.gate_out = gate_out if (gate_out is not None and conv1x1.gate_applicable(x.shape)) else None
         ctx.save_for_backward(x, weight, z if relu else None, s, mean, var)
         return (z, x) if skip else z
 
@@ -289,13 +310,19 @@ class _ConvBNActFold(torch.autograd.Function):
         if P is None:
             P = _bn_partials[(N, O, HW)] = L.kgdet_bn_act_partials(N, O, HW)
         partial = torch.empty((O, max(P, 1)), dtype=torch.float32, device=gz.device)
-        g = torch.empty_like(gz) if ctx.relu else gz
+        mask = ctx.relu and not (ctx.gate_in is not None and ctx.gate_in.gated)    # (gated: the consumer of z masked gz already)
+        g = torch.empty_like(gz) if mask else gz
         st = _lib.raw_stream(gz.device.index)
-        _lib.check(L.kgdet_bn_fold_backward(_p(gz), _p(z), 1 if ctx.relu else 0, _p(g) if ctx.relu else None, _p(partial), N, O,
-                                            HW, st), 'bn_fold_backward')
+        _lib.check(L.kgdet_bn_fold_backward(_p(gz), _p(z) if mask else None, 1 if mask else 0, _p(g) if mask else None, _p(partial),
+                                            N, O, HW, st), 'bn_fold_backward')
         if gskip is not None and (gskip.dtype != torch.float32 or not gskip.is_contiguous()):
             gskip = gskip.float().contiguous()
-        gx = conv1x1.grad_input(weight, ctx.img_t, g, residual=gskip) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gate = x if (ctx.gate_out is not None and GATE_FUSION) else None
+            gx = conv1x1.grad_input(weight, ctx.img_t, g, residual=gskip, gate=gate)
+            if gate is not None:
+                ctx.gate_out.gated = True
         need_w, need_g, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
         gw = sums = None
         if need_w or need_g:      # the split sum of the weight gradient, grad_w = s G and the BatchNorm sums in one launch
@@ -311,7 +338,7 @@ class _ConvBNActFold(torch.autograd.Function):
                                               weight.numel() // O, st), 'bn_fold_finish')
         gres = g if (ctx.has_res and ctx.needs_input_grad[7]) else None
         return (gx, gw if need_w else None, sums[1] if need_g else None, sums[0] if need_b else None, None, None, None, gres,
-                None, None, None)
+                None, None, None, None, None)
 
 
 FUSE_STEM = _os.environ.get('KGDET_FUSE_STEM', '1') == '1'   # 0 / False: conv_bn + nn.MaxPool2d (the tests compare the two)
@@ -460,16 +487,17 @@ def _conv1x1_as_gemm(conv, hit, x, residual, relu, in_bias=None):
     return gemm()
 
 
-def conv_bn(conv, bn, x, relu=False, residual=None, skip=False):
+def conv_bn(conv, bn, x, relu=False, residual=None, skip=False, gate_in=None, gate_out=None):
     """``[relu](bn(conv(x)) [+ residual])``; ``skip=True``: returns (that, x) where the second is x or an alias of it whose
-    gradient is folded into this convolution's grad_input (_ConvBNAct)."""
-    out = _conv_bn(conv, bn, x, relu, residual, skip)
+    gradient is folded into this convolution's grad_input (_ConvBNAct).  ``gate_in`` / ``gate_out``: _GateLink objects of the
+    caller, who vouches that x has no other consumer (gate_out) -- see _GateLink; honoured by the folded training node only."""
+    out = _conv_bn(conv, bn, x, relu, residual, skip, gate_in=gate_in, gate_out=gate_out)
     if skip and not isinstance(out, tuple):
         return out, x
     return out
 
 
-def _conv_bn(conv, bn, x, relu=False, residual=None, skip=False, raw=False, in_bias=None):
+def _conv_bn(conv, bn, x, relu=False, residual=None, skip=False, raw=False, in_bias=None, gate_in=None, gate_out=None):
     """conv_bn's body (with ``skip`` the training fast path may return the (output, alias) pair itself).  In inference (autograd off, BatchNorm in eval mode, plain bias-free
     Conv2d) the frozen statistics are folded into the convolution -- w' = w * gamma / sigma,
     b' = beta - mu * gamma / sigma -- and bias, residual add and ReLU run as ONE in-place pass over the activation
@@ -491,9 +519,10 @@ def _conv_bn(conv, bn, x, relu=False, residual=None, skip=False, raw=False, in_b
                 if fold is not None:     # from the pair's second step on: BatchNorm folded into the convolution
                     if skip and SKIP_ALIAS and x.requires_grad:
                         return _ConvBNActFold.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                                    bn.eps, residual, relu, True, fold)
+                                                    bn.eps, residual, relu, True, fold, gate_in, gate_out)
+                    # (skip without the alias: x has a second consumer, the identity branch -- its gradient must not be gated)
                     out = _ConvBNActFold.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
-                                               residual, relu, False, fold)
+                                               residual, relu, False, fold, gate_in, None if skip else gate_out)
                     return (out, x) if skip else out
                 if skip and SKIP_ALIAS and x.requires_grad:
                     return _ConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
@@ -623,10 +652,16 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         identity = x
+        # gradient hand-overs (_GateLink): l1 / l2 inside the block; `arriving` = the link the previous block of this layer left
+        # on its output (x is then that block's relu(.) and this block -- conv1 with the skip alias -- its only consumer);
+        # `leaving` goes out on this block's output for the next block.  Training on the folded path only (see conv_bn).
+        fuse = GATE_FUSION and torch.is_grad_enabled() and not self.with_dcn
+        l1, l2, leaving = (_GateLink(), _GateLink(), _GateLink()) if fuse else (None, None, None)
+        arriving = x.__dict__.pop('_kgdet_gate_link', None) if fuse else None
         if self.downsample is None and not self.with_dcn:
-            out, identity = conv_bn(self.conv1, self.norm1, x, relu=True, skip=True)
+            out, identity = conv_bn(self.conv1, self.norm1, x, relu=True, skip=True, gate_in=l1, gate_out=arriving)
         else:
-            out = conv_bn(self.conv1, self.norm1, x, relu=True)
+            out = conv_bn(self.conv1, self.norm1, x, relu=True, gate_in=l1)
         if not self.with_dcn:
             if (not torch.is_grad_enabled() and out.dtype == torch.bfloat16 and self.conv2.stride == (1, 1)
                     and fused_residual_ready(self.conv3, out.shape[0], out.shape[2], out.shape[3])):
@@ -635,10 +670,13 @@ class Bottleneck(nn.Module):
                 if self.downsample is not None:
                     identity = conv_bn(self.downsample[0], self.downsample[1], x)
                 return _conv_bn(self.conv3, self.norm3, out, relu=True, residual=identity, in_bias=shift2)
-            out = conv_bn(self.conv2, self.norm2, out, relu=True)
+            out = conv_bn(self.conv2, self.norm2, out, relu=True, gate_in=l2, gate_out=l1)
             if self.downsample is not None:
                 identity = conv_bn(self.downsample[0], self.downsample[1], x)
-            return conv_bn(self.conv3, self.norm3, out, relu=True, residual=identity)
+            out = conv_bn(self.conv3, self.norm3, out, relu=True, residual=identity, gate_in=leaving, gate_out=l2)
+            if fuse:
+                out._kgdet_gate_link = leaving      # (taken -- and removed -- by the next bottleneck of the layer, if there is one)
+            return out
         elif self.with_modulated_dcn:
             offset_mask = self.conv2_offset(out)
             offset = offset_mask[:, :18, :, :]

@@ -61,6 +61,8 @@ def _lib_sizes():
                 ('kgdet_conv_apply', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
                 ('kgdet_conv_apply_epilogue_fmt', ctypes.c_int,
                  [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+                ('kgdet_conv_apply_gated_fmt', ctypes.c_int,
+                 [vp, vp, vp, vp, vp, i32, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
                 ('kgdet_conv3x3_s2_grad_input', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i32, i32, vp]),
                 ('kgdet_conv1x1_grad_weight', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i64, vp, sz, vp]),
                 ('kgdet_conv1x1_grad_weight_fold', ctypes.c_int,
@@ -121,18 +123,27 @@ def _pack_both(weight):
     return _mark(img, FORWARD_F16), _mark(img_t, False)
 
 
-def _apply(img, x, M, taps, stride=1, bias=None, residual=None, relu=False):
-    """y = conv(x) through the packed image; inference epilogue [relu](y + bias [+ residual]) fused into the store"""
+def _apply(img, x, M, taps, stride=1, bias=None, residual=None, relu=False, gate=None):
+    """y = conv(x) through the packed image; inference epilogue [relu](y + bias [+ residual]) fused into the store;
+    ``gate`` (shape of y): y is zeroed where gate <= 0 (kgdet_conv_apply_gated_fmt: a ReLU's backward in the store)"""
     L = _lib_sizes()
     B, K, H, W = x.shape
     y = torch.empty((B, M, (H + stride - 1) // stride, (W + stride - 1) // stride), dtype=torch.float32, device=x.device)
     nbytes = _size('kgdet_conv_apply_workspace_bytes', B, M, K, H, W, taps, stride)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
-    _lib.check(L.kgdet_conv_apply_epilogue_fmt(
+    if gate is not None and (gate.shape != y.shape or gate.dtype != torch.float32 or not gate.is_contiguous()):
+        raise ValueError('gate must be a contiguous fp32 tensor of the output\'s shape')
+    _lib.check(L.kgdet_conv_apply_gated_fmt(
         img.data_ptr(), x.data_ptr(), y.data_ptr(), bias.data_ptr() if bias is not None else None,
-        residual.data_ptr() if residual is not None else None, 1 if relu else 0, B, M, K, H, W, taps, stride,
+        residual.data_ptr() if residual is not None else None, 1 if relu else 0,
+        gate.data_ptr() if gate is not None else None, B, M, K, H, W, taps, stride,
         1 if getattr(img, 'kgdet_f16', False) else 0, ws.data_ptr() if nbytes else None, nbytes, _stream()), 'conv_apply')
     return y
+
+
+def gate_applicable(y_shape):
+    """can `_apply(..., gate=)` serve an output of this shape?  (the K-split sum handles pixel pairs)"""
+    return (y_shape[2] * y_shape[3]) % 2 == 0
 
 
 # ---- one pack launch per training step --------------------------------------------------------------------------------
@@ -355,10 +366,11 @@ def grad_weight_fold(x, weight, gy, s, mean, var, eps, bn_partial, P, want_gamma
     return None
 
 
-def grad_input(weight, img_t, gy, residual=None):
-    """grad of ``conv(x, weight)`` with respect to x [+ residual: another gradient of x, added in the kernel's store]"""
+def grad_input(weight, img_t, gy, residual=None, gate=None):
+    """grad of ``conv(x, weight)`` with respect to x [+ residual: another gradient of x, added in the kernel's store]
+    [zeroed where gate <= 0: x = relu(.) and gate = x applies that ReLU's backward in the same store]"""
     C, k = weight.shape[1], weight.shape[2]
-    return _apply(img_t if img_t is not None else _pack(weight, True), gy, C, k * k, residual=residual)
+    return _apply(img_t if img_t is not None else _pack(weight, True), gy, C, k * k, residual=residual, gate=gate)
 
 
 class _ConvSplit(torch.autograd.Function):

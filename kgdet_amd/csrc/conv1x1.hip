@@ -312,7 +312,8 @@ __global__ __launch_bounds__(128 * NW) void conv_nn(const unsigned char *__restr
                                                       int H, int W, int n_mt, int n_nt, int tiles, int ksplit,
                                                       long long part_stride, int Hin, int Win, int stride,
                                                       const float *__restrict__ bias,
-                                                      const float *__restrict__ residual, int relu) {
+                                                      const float *__restrict__ residual, int relu,
+    const float *__restrict__ gate = nullptr) {
   // bias [M] / residual [B, M, H, W] / relu: inference epilogue y = [relu](acc + bias[m] [+ residual]) (ksplit == 1)
   // H x W: the OUTPUT map; Hin x Win: the input map; stride 1 (Hin = H, Win = W) or 2 (H = ceil(Hin / 2), ...)
   constexpr int TN = 32 * NW, kPartB = 2 * TN * 16, kBuf = kStage + 2 * kPartB;   // B part: [khalf][TN][8 bf16]
@@ -475,6 +476,22 @@ __global__ __launch_bounds__(128 * NW) void conv_nn(const unsigned char *__restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][r] += add[mi][r];
   }
+  if (gate) {   // y *= [gate > 0]: the backward of the ReLU that produced this convolution's input (gate = that input), see
+                // kgdet_conv_apply_gated_fmt -- the consumer of y no longer takes a masking pass over it
+    const int nc = min(n, N - 1);
+    float gv[2][16];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = min(mt * kTM + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), M - 1);
+        gv[mi][r] = gate[((long long)b * M + m) * N + nc];
+      }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][r] = gv[mi][r] > 0.0f ? acc[mi][r] : 0.0f;
+  }
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -508,7 +525,8 @@ __global__ __launch_bounds__(kNNThreads) void conv3x3_patch(const unsigned char 
                                                             int K, int H, int W, int n_mt, int tiles_x, int n_nt, int tiles,
                                                             int ksplit, long long part_stride, int TX, int TY,
                                                             const float *__restrict__ bias,
-                                                            const float *__restrict__ residual, int relu) {
+                                                            const float *__restrict__ residual, int relu,
+    const float *__restrict__ gate = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // kPatchLds: A x 6 (two sets of three stages) | B x 2
   const int unit = xcd_tile(blockIdx.x, tiles * ksplit);
   if (unit >= tiles * ksplit) return;
@@ -690,6 +708,20 @@ __global__ __launch_bounds__(kNNThreads) void conv3x3_patch(const unsigned char 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][r] += add[mi][r];
   }
+  if (gate) {   // (as conv_nn)
+    float gv[2][16];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = min(mt * kTM + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), M - 1);
+        gv[mi][r] = gate[((long long)b * M + m) * N + n];
+      }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][r] = gv[mi][r] > 0.0f ? acc[mi][r] : 0.0f;
+  }
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -716,7 +748,8 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_patch4(const unsigned char
                                                              int K, int H, int W, int n_mt, int tiles_x, int n_nt,
                                                              int tiles, int ksplit, long long part_stride, int TX, int TY,
                                                              const float *__restrict__ bias,
-                                                             const float *__restrict__ residual, int relu) {
+                                                             const float *__restrict__ residual, int relu,
+    const float *__restrict__ gate = nullptr) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kPatchBuf];
   if constexpr (F16) f16_saturate_on();
   constexpr int HALVES = 4 / WAVES, THREADS = 64 * WAVES, PXT = kPatchMax / THREADS;   // patch pixels per thread
@@ -854,6 +887,13 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_patch4(const unsigned char
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nb][r] += add[r];
+    }
+    if (gate) {   // (as conv_nn)
+      float gv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gv[r] = gate[((long long)b * M + min(m0 + (r & 3) + 8 * (r >> 2), M - 1)) * N + o_n[nb]];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][r] = gv[r] > 0.0f ? acc[nb][r] : 0.0f;
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1099,7 +1139,8 @@ __global__ __launch_bounds__(256) void conv1x1_sum(const float *__restrict__ par
 __global__ __launch_bounds__(256) void conv1x1_sum_epilogue(const float *__restrict__ parts, float *__restrict__ out,
                                                             long long n, long long stride, int count,
                                                             const float *__restrict__ bias, const float *__restrict__ residual,
-                                                            int relu, int M, long long HW) {
+                                                            int relu, int M, long long HW,
+                                                            const float *__restrict__ gate = nullptr) {
   for (long long i = (blockIdx.x * 256LL + threadIdx.x) * 2; i < n; i += gridDim.x * 512LL) {   // (HW is even: both in one plane)
     f32x2 s = {0.0f, 0.0f};
     int k = 0;
@@ -1117,6 +1158,10 @@ __global__ __launch_bounds__(256) void conv1x1_sum_epilogue(const float *__restr
     }
     if (residual) s += *reinterpret_cast<const f32x2 *>(residual + i);
     if (relu) { s[0] = fmaxf(s[0], 0.0f); s[1] = fmaxf(s[1], 0.0f); }
+    if (gate) {
+      const f32x2 gv = *reinterpret_cast<const f32x2 *>(gate + i);
+      s[0] = gv[0] > 0.0f ? s[0] : 0.0f; s[1] = gv[1] > 0.0f ? s[1] : 0.0f;
+    }
     *reinterpret_cast<f32x2 *>(out + i) = s;
   }
 }
@@ -1859,10 +1904,27 @@ extern "C" size_t kgdet_conv_apply_workspace_bytes(int64_t B, int32_t M, int32_t
 extern "C" int kgdet_bias_act(void *x, const float *bias, const void *residual, int64_t N, int32_t C, int64_t HW,
                               int32_t dtype, int32_t relu, int32_t channels_last, void *stream);
 
+extern "C" int kgdet_conv_apply_gated_fmt(const void *packed, const float *x, float *y, const float *bias,
+                                          const float *residual, int32_t relu, const float *gate, int64_t B, int32_t M,
+                                          int32_t K, int32_t H, int32_t W, int32_t taps, int32_t stride,
+                                          int32_t operand_format, void *workspace, size_t workspace_bytes, void *stream);
+
 extern "C" int kgdet_conv_apply_epilogue_fmt(const void *packed, const float *x, float *y, const float *bias,
                                              const float *residual, int32_t relu, int64_t B, int32_t M, int32_t K,
                                              int32_t H, int32_t W, int32_t taps, int32_t stride, int32_t operand_format,
                                              void *workspace, size_t workspace_bytes, void *stream) {
+  return kgdet_conv_apply_gated_fmt(packed, x, y, bias, residual, relu, nullptr, B, M, K, H, W, taps, stride, operand_format,
+                                    workspace, workspace_bytes, stream);
+}
+
+// ... and `gate` [B, M, Ho, Wo] (or NULL): y = [gate > 0] * ([relu](conv + bias [+ residual])).  In the backward of
+// `z = relu(...); u = conv(z)` the gradient of z is conv_grad_input(grad_u) [+ the identity branch's gradient = `residual`], and
+// the node that produced z masks it with [z > 0] first thing: with gate = z (this convolution's own forward input) the mask rides
+// on this kernel's store and that node's pass over the activation (read gradient, read z, write masked gradient) is not taken.
+extern "C" int kgdet_conv_apply_gated_fmt(const void *packed, const float *x, float *y, const float *bias,
+                                          const float *residual, int32_t relu, const float *gate, int64_t B, int32_t M,
+                                          int32_t K, int32_t H, int32_t W, int32_t taps, int32_t stride,
+                                          int32_t operand_format, void *workspace, size_t workspace_bytes, void *stream) {
   const bool f16 = operand_format == 1;      // the image and the on-the-fly split of x in fp16 parts (forward operands)
   KGDET_CHECK_SHAPE(B >= 0 && M > 0 && K > 0 && H >= 0 && W >= 0 && (long long)H * W < (1LL << 30), "bad sizes");
   KGDET_CHECK_SHAPE(taps == 1 || taps == 9, "taps must be 1 (1x1) or 9 (3x3)");
@@ -1881,6 +1943,7 @@ extern "C" int kgdet_conv_apply_epilogue_fmt(const void *packed, const float *x,
   if (ks > 1) {
     KGDET_CHECK_SHAPE(workspace && workspace_bytes >= (size_t)ks * part_stride * sizeof(float), "workspace too small");
     KGDET_CHECK_SHAPE(part_stride % 2 == 0, "B*M*Ho*Wo must be even");
+    KGDET_CHECK_SHAPE(!gate || HW % 2 == 0, "a gated K-split convolution needs an even pixel count");
   }
   const int per = (int)((tiles * ks + 7) / 8);
   float *dst = ks > 1 ? (float *)workspace : y;
@@ -1890,7 +1953,8 @@ extern "C" int kgdet_conv_apply_epilogue_fmt(const void *packed, const float *x,
     // ... and M <= 64 (layer 1): the second half has no rows and leaves at once instead of multiplying zeros
     const bool halves = force_halves >= 0 ? force_halves != 0 : ((ks == 1 && tiles > 256 && tiles < 400) || M <= 64);
 #define KGDET_P4_ARGS (const unsigned char *)packed, x, dst, M, K, H, W, n_mt, plan.tiles_x, n_nt, (int)tiles, ks, part_stride, \
-                      plan.TX, plan.TY, ks > 1 ? nullptr : bias, ks > 1 ? nullptr : residual, ks > 1 ? 0 : relu
+                      plan.TX, plan.TY, ks > 1 ? nullptr : bias, ks > 1 ? nullptr : residual, ks > 1 ? 0 : relu, \
+                      ks > 1 ? nullptr : gate
 #define KGDET_P4_LAUNCH(WV, NBK, GRID, THR)                                                                                  \
     do {                                                                                                                     \
       if (f16) hipLaunchKernelGGL((conv3x3_patch4<WV, NBK, true>), dim3(GRID), dim3(THR), 0, (hipStream_t)stream, KGDET_P4_ARGS); \
@@ -1913,10 +1977,10 @@ extern "C" int kgdet_conv_apply_epilogue_fmt(const void *packed, const float *x,
     hipLaunchKernelGGL(conv3x3_patch, dim3(per * 8), dim3(kNNThreads), kPatchLds, (hipStream_t)stream,
                        (const unsigned char *)packed, x, dst, M, K, H, W, n_mt, plan.tiles_x, n_nt, (int)tiles, ks,
                        part_stride, plan.TX, plan.TY, ks > 1 ? nullptr : bias, ks > 1 ? nullptr : residual,
-                       ks > 1 ? 0 : relu);
+                       ks > 1 ? 0 : relu, ks > 1 ? nullptr : gate);
   } else {
 #define KGDET_NN_ARGS (const unsigned char *)packed, x, dst, M, K, Ho, Wo, n_mt, n_nt, (int)tiles, ks, part_stride, H, W, stride, \
-                      ks > 1 ? nullptr : bias, ks > 1 ? nullptr : residual, ks > 1 ? 0 : relu
+                      ks > 1 ? nullptr : bias, ks > 1 ? nullptr : residual, ks > 1 ? 0 : relu, ks > 1 ? nullptr : gate
 #define KGDET_NN_LAUNCH(TP, NWK, THR)                                                                                        \
     do {                                                                                                                     \
       if (f16) hipLaunchKernelGGL((conv_nn<TP, NWK, true>), dim3(per * 8), dim3(THR), 0, (hipStream_t)stream, KGDET_NN_ARGS);  \
@@ -1936,10 +2000,10 @@ extern "C" int kgdet_conv_apply_epilogue_fmt(const void *packed, const float *x,
   KGDET_CHECK_LAUNCH("conv_nn");
   if (ks > 1) {
     const long long blocks = (part_stride / 2 + 255) / 256;
-    if ((bias || residual || relu) && HW % 2 == 0)   // the epilogue in the sum's store
+    if ((bias || residual || relu || gate) && HW % 2 == 0)   // the epilogue in the sum's store
       hipLaunchKernelGGL(conv1x1_sum_epilogue, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0,
                          (hipStream_t)stream, (const float *)workspace, y, part_stride, part_stride, ks, bias, residual, relu,
-                         M, (long long)HW);
+                         M, (long long)HW, gate);
     else
       hipLaunchKernelGGL(conv1x1_sum, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, (hipStream_t)stream,
                          (const float *)workspace, y, part_stride, part_stride, ks);
