@@ -142,7 +142,10 @@ int kgdet_bn_fold_finish(const float *partial, int32_t P, const float *w, float 
                          const float *mean, const float *var, float eps, float *grad_beta /*nullable*/,
                          float *grad_gamma /*nullable*/, int32_t O, int32_t CK, void *stream);
 /* kgdet_conv1x1_grad_weight / kgdet_conv3x3_grad_weight with kgdet_bn_fold_finish as the epilogue of their split sum (one
- * launch less per convolution): grad_w = s * G, grad_beta, grad_gamma as above; bn_partial / P from kgdet_bn_fold_backward. */
+ * launch less per convolution): grad_w = s * G, grad_beta, grad_gamma as above; bn_partial / P from kgdet_bn_fold_backward --
+ * or bn_partial == NULL with P == 0: grad_y is final (no ReLU mask to apply, or applied already by kgdet_conv_apply_gated_fmt) and
+ * its per-channel sums are formed inside the weight-gradient kernel, from the operand values it loads anyway (no pass of
+ * kgdet_bn_fold_backward over grad_y at all). */
 int kgdet_conv1x1_grad_weight_fold(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O, int32_t C,
                                    int64_t HW, void *workspace, size_t workspace_bytes, const float *w, const float *s,
                                    const float *mean, const float *var, float eps, const float *bn_partial, int32_t P,

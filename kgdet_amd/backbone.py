@@ -309,12 +309,17 @@ class _ConvBNActFold(torch.autograd.Function):
         P = _bn_partials.get((N, O, HW))
         if P is None:
             P = _bn_partials[(N, O, HW)] = L.kgdet_bn_act_partials(N, O, HW)
-        partial = torch.empty((O, max(P, 1)), dtype=torch.float32, device=gz.device)
         mask = ctx.relu and not (ctx.gate_in is not None and ctx.gate_in.gated)    # (gated: the consumer of z masked gz already)
+        need_w, need_g, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        # gz is final (no mask to apply here): no pass over it at all when the weight-gradient kernel can sum its rows
+        sums_in_wgrad = (not mask and GATE_FUSION and (need_w or need_g) and conv1x1.grad_weight_fold_route(x, weight) != 0)
         g = torch.empty_like(gz) if mask else gz
         st = _lib.raw_stream(gz.device.index)
-        _lib.check(L.kgdet_bn_fold_backward(_p(gz), _p(z) if mask else None, 1 if mask else 0, _p(g) if mask else None, _p(partial),
-                                            N, O, HW, st), 'bn_fold_backward')
+        partial = None
+        if not sums_in_wgrad:
+            partial = torch.empty((O, max(P, 1)), dtype=torch.float32, device=gz.device)
+            _lib.check(L.kgdet_bn_fold_backward(_p(gz), _p(z) if mask else None, 1 if mask else 0, _p(g) if mask else None,
+                                                _p(partial), N, O, HW, st), 'bn_fold_backward')
         if gskip is not None and (gskip.dtype != torch.float32 or not gskip.is_contiguous()):
             gskip = gskip.float().contiguous()
         gx = None
@@ -323,10 +328,10 @@ class _ConvBNActFold(torch.autograd.Function):
             gx = conv1x1.grad_input(weight, ctx.img_t, g, residual=gskip, gate=gate)
             if gate is not None:
                 ctx.gate_out.gated = True
-        need_w, need_g, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
         gw = sums = None
         if need_w or need_g:      # the split sum of the weight gradient, grad_w = s G and the BatchNorm sums in one launch
             both = conv1x1.grad_weight_fold(x, weight, g, s, mean, var, ctx.eps, partial, max(P, 1))
+            assert both is not None or partial is not None
             if both is not None:
                 gw, sums = both
             else:

@@ -336,11 +336,29 @@ def grad_weight(x, weight, gy):
     return gw
 
 
+def grad_weight_fold_route(x, weight):
+    """3 / 1: grad_weight_fold serves this problem with the 3x3 / 1x1 split kernels; 0: it returns None"""
+    C, k = weight.shape[1], weight.shape[2]
+    if k == 3 and SPLIT_GRAD_WEIGHT_3X3 and C % 128 == 0 and (x.shape[3] % 4 == 0 or PAD_GRAD_WEIGHT_3X3):
+        return 3
+    if k == 1 and ((x.shape[2] * x.shape[3]) % 4 == 0 or PAD_GRAD_WEIGHT_3X3):
+        return 1
+    return 0
+
+
 def grad_weight_fold(x, weight, gy, s, mean, var, eps, bn_partial, P, want_gamma=True):
     """grad_weight of a convolution with a folded BatchNorm (backbone._ConvBNActFold): (s * G, sums [2, O] = grad_beta,
-    grad_gamma) from ONE launch behind the split kernel -- or None where grad_weight would take another route"""
+    grad_gamma) from ONE launch behind the split kernel -- or None where grad_weight would take another route.
+    ``bn_partial=None`` (P = 0): the per-channel sums of gy are formed inside the weight-gradient kernel."""
     O, C, k = weight.shape[0], weight.shape[1], weight.shape[2]
     L = _lib_sizes()
+    if bn_partial is None:
+        P = 0
+
+        class bn_partial(object):        # (a null pointer for the two calls below)
+            @staticmethod
+            def data_ptr():
+                return None
     if k == 3 and SPLIT_GRAD_WEIGHT_3X3 and C % 128 == 0 and (x.shape[3] % 4 == 0 or PAD_GRAD_WEIGHT_3X3):
         B, H, W = x.shape[0], x.shape[2], x.shape[3]
         nbytes = _size('kgdet_conv3x3_grad_weight_workspace_bytes', B, O, C, H, W)

@@ -1260,11 +1260,16 @@ template <int TAPS, int DX>
 __device__ __forceinline__ void conv_nt8_body(const float *__restrict__ a, const float *__restrict__ bm,
                                               float *__restrict__ partial, int M, int N, int L, int B, int n_mt, int n_nt,
                                               int stages_per_image, int per, int H, int W, int Cin, int unit,
-                                              unsigned char *smem) {
+                                              unsigned char *smem, float *__restrict__ row_sums, int rs_stride) {
   const int tile = unit % (n_mt * n_nt), split = unit / (n_mt * n_nt);
   const int mt = tile % n_mt, nt = tile / n_mt;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
   const int row = tid >> 2, q = tid & 3;
+  // row_sums[m * rs_stride + split] = sum over the split's pixels of a[., m, .] (the BatchNorm beta gradient of a folded
+  // convolution whose output gradient arrived already masked: kgdet_conv*_grad_weight_fold with bn_partial == NULL) -- written by
+  // the first column tile of every (row tile, split); the values pass through this thread's registers anyway
+  const bool rs_on = row_sums != nullptr && nt == 0;
+  float rs = 0.0f;
   const int total = B * stages_per_image;
   const int s_begin = split * per, s_end = min(total, s_begin + per);
   const int am = min(mt * kTM + row, M - 1);
@@ -1305,7 +1310,7 @@ __device__ __forceinline__ void conv_nt8_body(const float *__restrict__ a, const
       for (int e = 0; e < 4; ++e) R.vb[4 * k + e] = w[e];
     }
   };
-  auto commit = [&](int buf, const Regs &R) {
+  auto commit = [&](int buf, const Regs &R, bool real = true) {   // real: not the clamped duplicate past the last stage
     unsigned char *As = smem + buf * 2 * kStage, *Bs = As + kStage;
     const bool in_img = R.p0 < L;       // L % 4 == 0: a chunk is entirely inside or outside the image
     bool row_ok = in_img && b_real;
@@ -1323,6 +1328,7 @@ __device__ __forceinline__ void conv_nt8_body(const float *__restrict__ a, const
       const bool ok = TAPS == 9 ? (row_ok && col >= 0 && col < W) : row_ok;
       fb[i] = ok ? R.vb[i + (TAPS == 9 ? sh : 0)] : 0.0f;
     }
+    if (rs_on && real) rs += (fa[0] + fa[1]) + (fa[2] + fa[3]);
     uint2 ahi, alo, bhi, blo;
     split_pair(fa[0], fa[1], ahi.x, alo.x);
     split_pair(fa[2], fa[3], ahi.y, alo.y);
@@ -1366,7 +1372,7 @@ __device__ __forceinline__ void conv_nt8_body(const float *__restrict__ a, const
         __syncthreads();
         issue(s_begin + j + PF, R[u]);
         multiply(j & 1);
-        commit((j + 1) & 1, R[(u + 1) % PF]);
+        commit((j + 1) & 1, R[(u + 1) % PF], j + 1 < n);
       }
     }
 #pragma unroll
@@ -1388,6 +1394,11 @@ __device__ __forceinline__ void conv_nt8_body(const float *__restrict__ a, const
       const int m = mt * kTM + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (m < M && nn < N) out[(long long)m * N + nn] = acc[mi][r];
     }
+  if (rs_on) {     // the row's four quarters sit in adjacent lanes: fixed order
+    rs += __shfl_xor(rs, 1);
+    rs += __shfl_xor(rs, 2);
+    if (q == 0 && a_real) row_sums[(long long)(mt * kTM + row) * rs_stride + split] = rs;
+  }
 }
 
 // units > 0: the launch holds ceil(units / 8) * 8 workgroups and workgroup b takes unit xcd_tile(b, units) -- the tiles of one
@@ -1397,18 +1408,18 @@ template <int TAPS>
 __global__ __launch_bounds__(kNNThreads) void conv_nt8(const float *__restrict__ a, const float *__restrict__ bm,
                                                        float *__restrict__ partial, int M, int N, int L, int B, int n_mt,
                                                        int n_nt, int stages_per_image, int per, int H, int W, int Cin,
-                                                       int units) {
+                                                       int units, float *__restrict__ row_sums = nullptr, int rs_stride = 0) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * kStage];
   const int unit = units > 0 ? xcd_tile(blockIdx.x, units) : (int)blockIdx.x;
   if (units > 0 && unit >= units) return;
   if (TAPS == 9) {
     const int tile = unit % (n_mt * n_nt), nt = tile / n_mt;
     const int dx = ((nt * kTN) / Cin) % 3 - 1;   // uniform: one tap per tile
-    if (dx < 0) conv_nt8_body<TAPS, -1>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem);
-    else if (dx == 0) conv_nt8_body<TAPS, 0>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem);
-    else conv_nt8_body<TAPS, 1>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem);
+    if (dx < 0) conv_nt8_body<TAPS, -1>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem, row_sums, rs_stride);
+    else if (dx == 0) conv_nt8_body<TAPS, 0>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem, row_sums, rs_stride);
+    else conv_nt8_body<TAPS, 1>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem, row_sums, rs_stride);
   } else {
-    conv_nt8_body<TAPS, 0>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem);
+    conv_nt8_body<TAPS, 0>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem, row_sums, rs_stride);
   }
 }
 
@@ -1446,7 +1457,7 @@ template <int TAPS, bool PRODUCER, bool ALIGNED>
 __device__ __forceinline__ void conv_ntp_role(const float *__restrict__ a, const float *__restrict__ bm,
                                               float *__restrict__ partial, int M, int N, int L, int B, int n_mt, int n_nt,
                                               int stages_per_image, int per, int H, int W, int Cin, int unit,
-                                              unsigned char *smem) {
+                                              unsigned char *smem, float *__restrict__ row_sums, int rs_stride) {
   const int tile = unit % (n_mt * n_nt), split = unit / (n_mt * n_nt);
   const int mt = tile % n_mt, nt = tile / n_mt;
   const int total = B * stages_per_image;
@@ -1482,6 +1493,8 @@ __device__ __forceinline__ void conv_ntp_role(const float *__restrict__ a, const
     };
     int img = s_begin / stages_per_image, st = s_begin - img * stages_per_image;   // of the NEXT stage to be issued
     int issued = s_begin;
+    const bool rs_on = row_sums != nullptr && nt == 0;      // (as conv_nt8_body: per-row sums of the grad_y operand)
+    float rs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     auto issue = [&](Regs &R) __attribute__((always_inline)) {
       // (past the end of the range: the last stage again -- the loads stay unconditional, nothing is committed from them)
       const int p0 = st * kPK + q * 4;
@@ -1553,6 +1566,7 @@ __device__ __forceinline__ void conv_ntp_role(const float *__restrict__ a, const
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         f32x4 fa = R.va[k], fb = R.vb[k];
+        if (rs_on) rs[k] += (p0 < L) ? (fa[0] + fa[1]) + (fa[2] + fa[3]) : 0.0f;   // (beyond L - 4 the loads zero-filled the rest)
 #pragma unroll
         for (int i = 0; i < 4; ++i) fb[i] = ok[i] ? fb[i] : 0.0f;       // pixels outside the image multiply a zero
         uint2 ahi, alo, bhi, blo;
@@ -1587,6 +1601,17 @@ __device__ __forceinline__ void conv_ntp_role(const float *__restrict__ a, const
           issue(R0);                        // stage j + 4
           __syncthreads();
         }
+      }
+    }
+    if (rs_on) {    // the eight pieces of a row segment sit in adjacent lanes: fixed order
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float v = rs[k];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        const int m = mt * kTM + rp + 32 * k;
+        if (q == 0 && m < M) row_sums[(long long)m * rs_stride + split] = v;
       }
     }
   } else {
@@ -1662,14 +1687,14 @@ template <int TAPS, bool ALIGNED>
 __global__ __launch_bounds__(kPThreads, 1) void conv_ntp(const float *__restrict__ a, const float *__restrict__ bm,
                                                          float *__restrict__ partial, int M, int N, int L, int B, int n_mt,
                                                          int n_nt, int stages_per_image, int per, int H, int W, int Cin,
-                                                         int units) {
+                                                         int units, float *__restrict__ row_sums = nullptr, int rs_stride = 0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int unit = units > 0 ? xcd_tile(blockIdx.x, units) : (int)blockIdx.x;      // (as conv_nt8)
   if (units > 0 && unit >= units) return;
   if (threadIdx.x >= kPCons * 64)
-    conv_ntp_role<TAPS, true, ALIGNED>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem);
+    conv_ntp_role<TAPS, true, ALIGNED>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem, row_sums, rs_stride);
   else
-    conv_ntp_role<TAPS, false, ALIGNED>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem);
+    conv_ntp_role<TAPS, false, ALIGNED>(a, bm, partial, M, N, L, B, n_mt, n_nt, stages_per_image, per, H, W, Cin, unit, smem, row_sums, rs_stride);
 }
 
 namespace {
@@ -2093,14 +2118,23 @@ __global__ __launch_bounds__(256) void pad_rows2(const float *__restrict__ a, fl
   }
 }
 
-extern "C" size_t kgdet_conv1x1_grad_weight_workspace_bytes(int64_t B, int32_t O, int32_t C, int64_t HW) {
-  if (B <= 0 || O <= 0 || C <= 0 || HW <= 0) return 0;
+// workspace = [split partials | padded operand copies (maps with H*W % 4 != 0 on the conv_nt8 route) | per-row sums of grad_y,
+// [O][splits], for the folded variant called without bn_partial]; *rows_at = byte offset of the last region
+static size_t conv1x1_gw_workspace(int64_t B, int32_t O, int32_t C, int64_t HW, size_t *rows_at) {
   const long long HWp = (HW + 3) & ~3LL;
   const int tiles = ((O + kTM - 1) / kTM) * ((C + kTN - 1) / kTN);
   const int stages = (int)(B * ((HWp + kTK - 1) / kTK));
-  size_t bytes = (size_t)nt_splits(tiles, stages) * O * C * sizeof(float);
+  const int splits = nt_splits(tiles, stages);
+  size_t bytes = (size_t)splits * O * C * sizeof(float);
   if (HWp != HW) bytes = ((bytes + 255) & ~(size_t)255) + (size_t)B * (O + C) * HWp * sizeof(float);   // padded copies of grad_y and x
-  return bytes;
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (rows_at) *rows_at = bytes;
+  return bytes + (size_t)splits * O * sizeof(float);
+}
+
+extern "C" size_t kgdet_conv1x1_grad_weight_workspace_bytes(int64_t B, int32_t O, int32_t C, int64_t HW) {
+  if (B <= 0 || O <= 0 || C <= 0 || HW <= 0) return 0;
+  return conv1x1_gw_workspace(B, O, C, HW, nullptr);
 }
 
 static int conv1x1_grad_weight_impl(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O, int32_t C,
@@ -2110,6 +2144,10 @@ static int conv1x1_grad_weight_impl(const float *grad_y, const float *x, float *
   KGDET_CHECK_SHAPE(grad_y && x && grad_w && workspace, "null pointer");
   KGDET_CHECK_SHAPE(workspace_bytes >= kgdet_conv1x1_grad_weight_workspace_bytes(B, O, C, HW), "workspace too small");
   const long long HW_true = HW;
+  size_t rows_at = 0;
+  conv1x1_gw_workspace(B, O, C, HW, &rows_at);
+  // the folded variant without bn_partial: the kernels below also write the per-row sums of grad_y (one slot per split)
+  float *row_sums = (fold && !fold->bn_partial) ? reinterpret_cast<float *>(static_cast<unsigned char *>(workspace) + rows_at) : nullptr;
   const bool use_ntp = ntp_on(1, HW % 4 != 0) && HW >= 4 && (long long)(O > C ? O : C) * HW < (1ll << 30);
   if (HW % 4 && use_ntp) {
     HW = (HW + 3) & ~3LL;      // (the split count below is the one the workspace query computed for the padded size)
@@ -2144,21 +2182,24 @@ static int conv1x1_grad_weight_impl(const float *grad_y, const float *x, float *
     if (HW_true % 4 == 0)
       hipLaunchKernelGGL((conv_ntp<1, true>), dim3(nt_grid(tiles * splits)), dim3(kPThreads), ntp_lds(), (hipStream_t)stream, grad_y, x,
                          (float *)workspace, O, C, (int)HW_true, (int)B, n_mt, n_nt, spi32, per32, 1, (int)HW_true, 0,
-                         nt_units(tiles * splits));
+                         nt_units(tiles * splits), row_sums, splits);
     else
       hipLaunchKernelGGL((conv_ntp<1, false>), dim3(nt_grid(tiles * splits)), dim3(kPThreads), ntp_lds(), (hipStream_t)stream, grad_y, x,
                          (float *)workspace, O, C, (int)HW_true, (int)B, n_mt, n_nt, spi32, per32, 1, (int)HW_true, 0,
-                         nt_units(tiles * splits));
+                         nt_units(tiles * splits), row_sums, splits);
     KGDET_CHECK_LAUNCH("conv_ntp<1>");
   } else {
     hipLaunchKernelGGL(conv_nt8<1>, dim3(nt_grid(tiles * splits)), dim3(kNNThreads), 0, (hipStream_t)stream, grad_y, x,
-                       (float *)workspace, O, C, (int)HW, (int)B, n_mt, n_nt, spi, per, 1, (int)HW, 0, nt_units(tiles * splits));
+                       (float *)workspace, O, C, (int)HW, (int)B, n_mt, n_nt, spi, per, 1, (int)HW, 0, nt_units(tiles * splits),
+                       row_sums, splits);
     KGDET_CHECK_LAUNCH("conv_nt8<1>");
   }
   const long long n = (long long)O * C;
   if (fold) {
+    ConvFoldArgs f = *fold;
+    if (row_sums) { f.bn_partial = row_sums; f.P = splits; }
     hipLaunchKernelGGL(conv_wsum_fold<false>, dim3(O), dim3(256), 0, (hipStream_t)stream, (const float *)workspace, grad_w, C,
-                       n, splits, *fold);
+                       n, splits, f);
     KGDET_CHECK_LAUNCH("conv_wsum_fold");
     return KGDET_OK;
   }
@@ -2177,7 +2218,8 @@ extern "C" int kgdet_conv1x1_grad_weight(const float *grad_y, const float *x, fl
 
 static int fold_args(ConvFoldArgs &f, const float *w, const float *s, const float *mean, const float *var, float eps,
                      const float *bn_partial, int32_t P, float *grad_beta, float *grad_gamma) {
-  KGDET_CHECK_SHAPE(w && s && mean && var && bn_partial && P > 0, "null pointer (folded BatchNorm arguments)");
+  KGDET_CHECK_SHAPE(w && s && mean && var && ((bn_partial && P > 0) || (!bn_partial && P == 0)),
+                    "null pointer (folded BatchNorm arguments; bn_partial == NULL goes with P == 0)");
   f.w = w; f.s = s; f.mean = mean; f.var = var; f.bn_partial = bn_partial; f.grad_beta = grad_beta; f.grad_gamma = grad_gamma;
   f.eps = eps; f.P = P;
   return KGDET_OK;
@@ -2193,14 +2235,21 @@ extern "C" int kgdet_conv1x1_grad_weight_fold(const float *grad_y, const float *
   return conv1x1_grad_weight_impl(grad_y, x, grad_w, B, O, C, HW, workspace, workspace_bytes, stream, &f);
 }
 
-extern "C" size_t kgdet_conv3x3_grad_weight_workspace_bytes(int64_t B, int32_t O, int32_t C, int32_t H, int32_t W) {
-  if (B <= 0 || O <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+static size_t conv3x3_gw_workspace(int64_t B, int32_t O, int32_t C, int32_t H, int32_t W, size_t *rows_at) {   // (as conv1x1_gw_workspace)
   const int Wp = (W + 3) & ~3;
   const int tiles = ((O + kTM - 1) / kTM) * (9 * C / kTN);
   const int stages = (int)(B * (((long long)H * Wp + kTK - 1) / kTK));
-  size_t bytes = (size_t)nt_splits(tiles, stages) * O * C * 9 * sizeof(float);
+  const int splits = nt_splits(tiles, stages);
+  size_t bytes = (size_t)splits * O * C * 9 * sizeof(float);
   if (Wp != W) bytes = ((bytes + 255) & ~(size_t)255) + (size_t)B * (O + C) * H * Wp * sizeof(float);   // padded copies of grad_y and x
-  return bytes;
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (rows_at) *rows_at = bytes;
+  return bytes + (size_t)splits * O * sizeof(float);
+}
+
+extern "C" size_t kgdet_conv3x3_grad_weight_workspace_bytes(int64_t B, int32_t O, int32_t C, int32_t H, int32_t W) {
+  if (B <= 0 || O <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+  return conv3x3_gw_workspace(B, O, C, H, W, nullptr);
 }
 
 static int conv3x3_grad_weight_impl(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O, int32_t C,
@@ -2214,6 +2263,9 @@ static int conv3x3_grad_weight_impl(const float *grad_y, const float *x, float *
   KGDET_CHECK_SHAPE(grad_y && x && grad_w && workspace, "null pointer");
   KGDET_CHECK_SHAPE(workspace_bytes >= kgdet_conv3x3_grad_weight_workspace_bytes(B, O, C, H, W), "workspace too small");
   const int W_true = W;
+  size_t rows_at = 0;
+  conv3x3_gw_workspace(B, O, C, H, W, &rows_at);
+  float *row_sums = (fold && !fold->bn_partial) ? reinterpret_cast<float *>(static_cast<unsigned char *>(workspace) + rows_at) : nullptr;
   // (H * W <= 2^21: conv_ntp derives a stage's row as (int)((p0 + 0.5f) * (1.0f / W)) -- exact while p0 < 2^24 and the product's
   //  rounding error stays below half a row; larger maps take conv_nt8, which counts rows)
   const bool use_ntp = ntp_on(9) && W >= 4 && (long long)H * W >= 4 && (long long)H * W <= (1ll << 21) &&
@@ -2251,20 +2303,25 @@ static int conv3x3_grad_weight_impl(const float *grad_y, const float *x, float *
     const int spi32 = (L + kPK - 1) / kPK, total32 = (int)(B * spi32), per32 = (total32 + splits - 1) / splits;
     if (W_true % 4 == 0)
       hipLaunchKernelGGL((conv_ntp<9, true>), dim3(nt_grid(tiles * splits)), dim3(kPThreads), ntp_lds(), (hipStream_t)stream, grad_y, x,
-                         (float *)workspace, O, 9 * C, L, (int)B, n_mt, n_nt, spi32, per32, H, W_true, C, nt_units(tiles * splits));
+                         (float *)workspace, O, 9 * C, L, (int)B, n_mt, n_nt, spi32, per32, H, W_true, C, nt_units(tiles * splits),
+                         row_sums, splits);
     else
       hipLaunchKernelGGL((conv_ntp<9, false>), dim3(nt_grid(tiles * splits)), dim3(kPThreads), ntp_lds(), (hipStream_t)stream, grad_y, x,
-                         (float *)workspace, O, 9 * C, L, (int)B, n_mt, n_nt, spi32, per32, H, W_true, C, nt_units(tiles * splits));
+                         (float *)workspace, O, 9 * C, L, (int)B, n_mt, n_nt, spi32, per32, H, W_true, C, nt_units(tiles * splits),
+                         row_sums, splits);
     KGDET_CHECK_LAUNCH("conv_ntp<9>");
   } else {
     hipLaunchKernelGGL(conv_nt8<9>, dim3(nt_grid(tiles * splits)), dim3(kNNThreads), 0, (hipStream_t)stream, grad_y, x,
-                       (float *)workspace, O, 9 * C, HW, (int)B, n_mt, n_nt, spi, per, H, W, C, nt_units(tiles * splits));
+                       (float *)workspace, O, 9 * C, HW, (int)B, n_mt, n_nt, spi, per, H, W, C, nt_units(tiles * splits), row_sums,
+                       splits);
     KGDET_CHECK_LAUNCH("conv_nt8<9>");
   }
   const long long n = (long long)O * C * 9;
   if (fold) {
+    ConvFoldArgs f = *fold;
+    if (row_sums) { f.bn_partial = row_sums; f.P = splits; }
     hipLaunchKernelGGL(conv_wsum_fold<true>, dim3(O), dim3(256), 0, (hipStream_t)stream, (const float *)workspace, grad_w, C, n,
-                       splits, *fold);
+                       splits, f);
     KGDET_CHECK_LAUNCH("conv_wsum_fold");
     return KGDET_OK;
   }

@@ -564,6 +564,119 @@ def test_conv_apply_epilogue_flags(B, C, O, H, W, k, stride):
                 assert ((got.double() - want).abs().max() / ref0.abs().max()).item() < 1e-5, (use_b, use_r, relu)
 
 
+@pytest.mark.parametrize('k', [1, 3])
+@pytest.mark.parametrize('B,C,O,H,W', [(2, 64, 128, 20, 34), (1, 512, 64, 6, 8), (2, 128, 256, 13, 10), (2, 128, 128, 100, 168),
+                                       (2, 256, 64, 50, 84)])
+def test_conv_apply_gate_is_the_mask_of_the_ungated_result(B, C, O, H, W, k):
+    """kgdet_conv_apply_gated_fmt: y = [gate > 0] * (conv + residual), bit for bit the ungated result with the mask applied
+    afterwards -- direct-store kernels (conv_nn, conv3x3_patch4: large maps) and the K-split sum (small maps)."""
+    from kgdet_amd import conv1x1 as c1
+    g = torch.Generator(device='cpu').manual_seed(B * C + H + k)
+    x = torch.randn(B, C, H, W, generator=g).cuda()
+    w = (torch.randn(O, C, k, k, generator=g) * 0.1).cuda()
+    res = torch.randn(B, O, H, W, generator=g).cuda()
+    gate = torch.randn(B, O, H, W, generator=g).clamp(min=0).cuda()        # a ReLU output: half zeros
+    for img in (c1._pack(w, False), ):
+        for use_r in (False, True):
+            plain = c1._apply(img, x, O, k * k, 1, None, res if use_r else None, False)
+            gated = c1._apply(img, x, O, k * k, 1, None, res if use_r else None, False, gate=gate)
+            assert torch.equal(gated, torch.where(gate > 0, plain, torch.zeros_like(plain))), (use_r,)
+    with pytest.raises(ValueError):
+        c1._apply(img, x, O, k * k, gate=gate[:, :1])
+
+
+@pytest.mark.gpu
+def test_gate_fusion_step_equals_the_separate_mask_passes():
+    """backbone._GateLink: with the ReLU backward of conv1 / conv2 / the block output applied in the store of the NEXT
+    convolution's grad_input kernel, a ResNet-50 training step returns bit-identical outputs and parameter gradients, and
+    the masking pass (relu_sum_bwd<true>) is taken only where a ReLU output has more than one consumer."""
+    from kgdet_amd import backbone as bb, conv1x1
+    x = torch.randn(2, 3, 128, 160, device='cuda', generator=torch.Generator('cuda').manual_seed(5))
+
+    def run(fuse):
+        conv1x1._entries.clear(); conv1x1._fold_entries.clear()
+        torch.manual_seed(0)
+        net = bb.ResNet(depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1, style='pytorch').cuda()
+        for n, m in net.named_modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+                m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.1)
+        net.train()
+        opt = torch.optim.SGD(net.parameters(), lr=1e-3)
+        bb.GATE_FUSION = fuse
+        masked = [0, 0]
+        real = bb._bn_fold_lib().kgdet_bn_fold_backward
+
+        class Spy(object):            # counts the masking / sum-only calls of the last step
+            def __call__(self, gz, z, relu, *rest):
+                masked[1 if relu else 0] += 1
+                return real(gz, z, relu, *rest)
+        try:
+            for step in range(3):
+                opt.zero_grad()
+                with conv1x1.step_scope():
+                    outs = net(x)
+                if step == 2:
+                    bb._bn_fold_lib().kgdet_bn_fold_backward = Spy()
+                sum(o.square().mean() for o in outs).backward()
+                if step == 2:
+                    return ([o.detach().clone() for o in outs],
+                            {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}, masked)
+                opt.step()
+        finally:
+            bb._bn_fold_lib().kgdet_bn_fold_backward = real
+            bb.GATE_FUSION = True
+            conv1x1._entries.clear(); conv1x1._fold_entries.clear()
+
+    outs, grads, calls = run(True)
+    outs_ref, grads_ref, calls_ref = run(False)
+    for a, b in zip(outs, outs_ref):
+        assert torch.equal(a, b)
+    assert grads.keys() == grads_ref.keys() and len(grads) > 100
+    for n in grads:
+        if grads[n].dim() == 4:       # convolution weights: the same kernels on the same values
+            assert torch.equal(grads[n], grads_ref[n]), n
+        else:                         # BatchNorm gamma / beta: the per-channel sums are formed in another (fixed) order
+            scale = grads_ref[n].abs().max().item() + 1e-30
+            assert (grads[n] - grads_ref[n]).abs().max().item() <= 2e-5 * scale, n
+    # layers 2-4 train (13 bottlenecks): 39 ReLU nodes, 36 of them folded nodes (the three stride-2 conv2 are not) + 3 downsample
+    # nodes without ReLU.  Fused: what still masks are the three layer outputs (several consumers) and conv1 of each layer's first
+    # block (its consumer is the stride-2 convolution); nobody takes a sum-only pass: the weight-gradient kernels sum the rows
+    assert calls_ref == [3, 36] and calls == [0, 6], (calls, calls_ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,C,O,H,W,k', [(2, 128, 512, 20, 36, 1), (2, 512, 128, 25, 42, 1), (1, 64, 256, 13, 21, 1), (2, 256, 64, 100, 168, 1),
+                                         (2, 128, 128, 20, 36, 3), (2, 256, 256, 25, 42, 3), (1, 128, 128, 13, 21, 3),
+                                         (2, 128, 128, 100, 168, 3), (3, 128, 200, 9, 12, 1)])
+def test_weight_gradient_kernels_sum_the_rows_of_grad_y(B, C, O, H, W, k):
+    """kgdet_conv*_grad_weight_fold with bn_partial == NULL: grad_beta / grad_gamma from row sums formed inside the
+    weight-gradient kernel (conv_nt8 / conv_ntp, aligned and ragged maps) equal those from kgdet_bn_fold_backward's partials,
+    the weight gradient itself is bit-identical, and both match float64."""
+    from kgdet_amd import backbone as bb, conv1x1 as c1, _lib
+    g = torch.Generator(device='cpu').manual_seed(B * C + H + k)
+    x = torch.randn(B, C, H, W, generator=g).cuda()
+    gy = torch.randn(B, O, H, W, generator=g).cuda()
+    w = (torch.randn(O, C, k, k, generator=g) * 0.1).cuda()
+    s = (torch.rand(O, generator=g) + 0.5).cuda()
+    mean, var = torch.randn(O, generator=g).cuda(), (torch.rand(O, generator=g) + 0.5).cuda()
+    assert c1.grad_weight_fold_route(x, w) == k
+    L = bb._bn_fold_lib()
+    P = L.kgdet_bn_act_partials(B, O, H * W)
+    partial = torch.empty((O, max(P, 1)), device='cuda')
+    _lib.check(L.kgdet_bn_fold_backward(gy.data_ptr(), None, 0, None, partial.data_ptr(), B, O, H * W, _lib.raw_stream(0)), 'sum')
+    gw_a, sums_a = c1.grad_weight_fold(x, w, gy, s, mean, var, 1e-5, partial, max(P, 1))
+    gw_b, sums_b = c1.grad_weight_fold(x, w, gy, s, mean, var, 1e-5, None, 0)
+    assert torch.equal(gw_a, gw_b)
+    beta = gy.double().sum((0, 2, 3))
+    G = torch.nn.grad.conv2d_weight(x.double(), w.shape, gy.double(), padding=k // 2)
+    gamma = ((G * w.double()).sum((1, 2, 3)) - mean.double() * beta) / (var.double() + 1e-5).sqrt()
+    for got in (sums_a, sums_b):
+        assert (got[0].double() - beta).abs().max().item() <= 1e-5 * beta.abs().max().item()
+        assert (got[1].double() - gamma).abs().max().item() <= 2e-4 * gamma.abs().max().item()
+    assert (gw_b.double() - G * s.double().view(-1, 1, 1, 1)).abs().max().item() <= 2e-4 * G.abs().max().item() * 1.5
+
+
 @pytest.mark.gpu
 def test_multi_pack_images_equal_single_packs_bit_for_bit():
     """the step's one-launch pack of all weights (conv1x1_pack_multi; 3x3 forward images: one thread per 72 contiguous floats)
