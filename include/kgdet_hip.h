@@ -128,7 +128,8 @@ int kgdet_bn_act_backward(const float *grad_y, const float *x, const float *y, c
  * of conv(x, .) against g, and G scaled by s in place (= grad_w).  Deterministic. */
 /* Inference, bf16 channels-last: conv3 + folded bn3 + identity add + ReLU of a bottleneck (mmdet/models/backbones/resnet.py:
  * 240-262) as ONE kernel: out[m][n] = [relu](bf16(sum_k x[m][k] weight[n][k]) + bias[n] + residual[m][n]); x [M, K], weight
- * [N, K], residual / out [M, N] bf16 (M = B*H*W), bias fp32 [N]; K % 16 == 0, K <= 384, N % 128 == 0. */
+ * [N, K], residual / out [M, N] bf16 (M = B*H*W), bias fp32 [N]; K % 16 == 0, K <= 512, N % 128 == 0 or N == 64.
+ * residual == NULL: conv1 + folded bn1 + ReLU (no identity add) on the same kernel. */
 int kgdet_conv1x1_nhwc_residual(const void *x, const void *weight, const float *bias, const void *residual, void *out,
                                 int64_t M, int32_t K, int32_t N, int32_t relu, void *stream);
 /* the same with x = the RAW output of the convolution in front (conv2 without its epilogue): relu(x + in_bias[k]) (rounded to

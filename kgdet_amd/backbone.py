@@ -259,6 +259,8 @@ def _bn_fold_lib():
     return L
 
 
+NHWC_EXTENDED = _os.environ.get('KGDET_NHWC_EXTENDED', '1') == '1'
+RAW_BRANCHES = _os.environ.get('KGDET_RAW_BRANCHES', '1') == '1'   # 0: downsample / stride-2 conv2 take their own bias pass at bf16 inference (A/B)
 GATE_FUSION = _os.environ.get('KGDET_GATE_FUSION', '1') == '1'    # 0: every ReLU node masks its own gradient (A/B)
 
 
@@ -414,7 +416,25 @@ def fused_residual_ready(conv3, B, H, W):
             _gemm_choice.get((conv3.in_channels, conv3.out_channels, B, H, W, True, True)) == 'fused')
 
 
-def _conv1x1_as_gemm(conv, hit, x, residual, relu, in_bias=None):
+_bias_sums = {}     # (id(bias), id(other)) -> (weakref(bias), weakref(other), bias + other)
+
+
+def _summed_bias(bias, other):
+    """bias + other (fp32 [C]), cached for as long as both tensors live (the folded biases of conv3 and of the downsample branch:
+    entries of _fold_cache, replaced -- never updated in place -- when a weight changes)"""
+    if other is None:
+        return bias
+    key = (id(bias), id(other))
+    hit = _bias_sums.get(key)
+    if hit is None or hit[0]() is not bias or hit[1]() is not other:
+        if len(_bias_sums) > 256:      # (ids of dead tensors: drop what no longer resolves)
+            for k in [k for k, v in _bias_sums.items() if v[0]() is None or v[1]() is None]:
+                del _bias_sums[k]
+        hit = _bias_sums[key] = (weakref.ref(bias), weakref.ref(other), (bias + other).contiguous())
+    return hit[2]
+
+
+def _conv1x1_as_gemm(conv, hit, x, residual, relu, in_bias=None, res_bias=None):
     """bf16 channels-last inference: a 1x1 stride-1 convolution IS the GEMM [B*H*W, Cin] x [Cin, Cout] on the channels-last
     storage, and hipBLASLt takes the folded-BatchNorm bias (+ ReLU) as its epilogue -- no separate bias / ReLU pass over the
     activation (csrc/epilogue.hip bias_act_nhwc was the largest kernel of the inference batch).  With a residual the GEMM adds
@@ -430,13 +450,15 @@ def _conv1x1_as_gemm(conv, hit, x, residual, relu, in_bias=None):
         return None
     w2 = hit[1].view(cout, cin)
     bias16 = hit[5] if len(hit) > 5 else None
+    # res_bias: the residual is the RAW output of the downsample convolution, whose folded bias joins this one's
+    bias32 = _summed_bias(hit[2], res_bias)
 
     def gemm():
         x2 = x.permute(0, 2, 3, 1).reshape(-1, cin)
         if residual is not None:
             y2 = torch.addmm(residual.permute(0, 2, 3, 1).reshape(-1, cout), x2, w2.t())
             y = y2.view(B, H, W, cout).permute(0, 3, 1, 2)
-            return _epilogue_(y, hit[2], None, relu)
+            return _epilogue_(y, bias32, None, relu)
         if relu:
             y2 = torch._addmm_activation(bias16, x2, w2.t(), use_gelu=False)
         else:
@@ -446,17 +468,21 @@ def _conv1x1_as_gemm(conv, hit, x, residual, relu, in_bias=None):
     def fused():
         # conv3 + bn3 + identity + ReLU as ONE kernel (csrc/conv_nhwc.hip): x, the residual and the output cross the fabric once;
         # with in_bias, x is conv2's RAW output and its bias + ReLU happen as the activations are loaded
+        # (residual None: conv1 + bn1 + ReLU, the same kernel without the identity add)
         from . import _lib
-        y = torch.empty_like(residual)
+        y = torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         _lib.check(_lib.lib().kgdet_conv1x1_nhwc_residual_in(
-            _lib.ptr(x), _lib.ptr(in_bias), _lib.ptr(hit[1]), _lib.ptr(hit[2]), _lib.ptr(residual), _lib.ptr(y),
+            _lib.ptr(x), _lib.ptr(in_bias), _lib.ptr(hit[1]), _lib.ptr(bias32), _lib.ptr(residual), _lib.ptr(y),
             ctypes.c_int64(B * H * W), ctypes.c_int32(cin), ctypes.c_int32(cout), ctypes.c_int32(1 if relu else 0),
             _lib.current_stream()), 'conv1x1_nhwc_residual')
         return y
 
-    fused_ok = (residual is not None and cin % 16 == 0 and cin <= 384 and cout % 128 == 0
-                and x.is_contiguous(memory_format=torch.channels_last) and residual.is_contiguous(memory_format=torch.channels_last)
-                and residual.shape == (B, cout, H, W) and hit[1].is_contiguous(memory_format=torch.channels_last))
+    ext = NHWC_EXTENDED      # (round 5: no residual, N = 64, K up to 512; 0 = round 4's envelope, A/B)
+    fused_ok = (cin % 16 == 0 and cin <= (512 if ext else 384) and (cout % 128 == 0 or (ext and cout == 64))
+                and (ext or residual is not None)
+                and x.is_contiguous(memory_format=torch.channels_last) and hit[1].is_contiguous(memory_format=torch.channels_last)
+                and (residual is None or (residual.is_contiguous(memory_format=torch.channels_last)
+                                          and residual.shape == (B, cout, H, W))))
     if choice == 'fused' and fused_ok:   # the choice is keyed by shape; layout / contiguity are properties of THIS call
         return fused()
     if in_bias is not None:          # (only passed once the choice is 'fused', fused_residual_ready: the caller's problem)
@@ -466,7 +492,7 @@ def _conv1x1_as_gemm(conv, hit, x, residual, relu, in_bias=None):
     if choice is None:
         def conv_path():
             y = F.conv2d(x, hit[1], None, conv.stride, conv.padding, conv.dilation, conv.groups)
-            return _epilogue_(y, hit[2], residual, relu)
+            return _epilogue_(y, bias32, residual, relu)
 
         def timed(fn):
             for _ in range(2):
@@ -502,7 +528,8 @@ def conv_bn(conv, bn, x, relu=False, residual=None, skip=False, gate_in=None, ga
     return out
 
 
-def _conv_bn(conv, bn, x, relu=False, residual=None, skip=False, raw=False, in_bias=None, gate_in=None, gate_out=None):
+def _conv_bn(conv, bn, x, relu=False, residual=None, skip=False, raw=False, in_bias=None, gate_in=None, gate_out=None,
+             res_bias=None):
     """conv_bn's body (with ``skip`` the training fast path may return the (output, alias) pair itself).  In inference (autograd off, BatchNorm in eval mode, plain bias-free
     Conv2d) the frozen statistics are folded into the convolution -- w' = w * gamma / sigma,
     b' = beta - mu * gamma / sigma -- and bias, residual add and ReLU run as ONE in-place pass over the activation
@@ -574,21 +601,22 @@ def _conv_bn(conv, bn, x, relu=False, residual=None, skip=False, raw=False, in_b
         x = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     if (bf16 and GEMM_1X1 and not raw and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
             and conv.groups == 1 and x.dtype == torch.bfloat16 and (residual is None or residual.dtype == torch.bfloat16)):
-        out = _conv1x1_as_gemm(conv, hit, x, residual, relu, in_bias)
+        out = _conv1x1_as_gemm(conv, hit, x, residual, relu, in_bias, res_bias)
         if out is not None:
             return out
     if in_bias is not None:      # the convolution route after all: conv2's epilogue as its own pass
         x = _epilogue_(x, in_bias, None, True)
+    bias = _summed_bias(hit[2], res_bias)     # (res_bias: `residual` is a RAW convolution output whose bias is added here)
     if hit[3] is not None and x.dtype == torch.float32 and x.is_contiguous() and x.shape[2] * x.shape[3] % 2 == 0:
         if _FUSE_EPI and (residual is None or (residual.dtype == torch.float32 and residual.is_contiguous())):
             # bias, residual and ReLU ride on the convolution's store: no separate epilogue pass
-            return conv1x1._apply(hit[3], x, hit[1].shape[0], hit[1].shape[2] * hit[1].shape[3], 1, hit[2], residual, relu)
+            return conv1x1._apply(hit[3], x, hit[1].shape[0], hit[1].shape[2] * hit[1].shape[3], 1, bias, residual, relu)
         out = conv1x1._apply(hit[3], x, hit[1].shape[0], hit[1].shape[2] * hit[1].shape[3])
     else:
         out = F.conv2d(x, hit[1], None, conv.stride, conv.padding, conv.dilation, conv.groups)
     if raw:     # (the stem: the caller fuses bias + ReLU with the pooling)
         return out, hit[2]
-    return _epilogue_(out, hit[2], residual, relu)
+    return _epilogue_(out, bias, residual, relu)
 
 
 class Bottleneck(nn.Module):
@@ -668,16 +696,30 @@ class Bottleneck(nn.Module):
         else:
             out = conv_bn(self.conv1, self.norm1, x, relu=True, gate_in=l1)
         if not self.with_dcn:
-            if (not torch.is_grad_enabled() and out.dtype == torch.bfloat16 and self.conv2.stride == (1, 1)
-                    and fused_residual_ready(self.conv3, out.shape[0], out.shape[2], out.shape[3])):
+            infer16 = not torch.is_grad_enabled() and out.dtype == torch.bfloat16 and RAW_BRANCHES
+            shift_ds = None
+            if (self.downsample is not None and infer16 and isinstance(self.downsample, nn.Sequential) and len(self.downsample) == 2
+                    and getattr(self.downsample[0], 'stride', None) == (2, 2)):     # (stride 1: the GEMM route has the bias in its epilogue)
+                # bf16 inference: the downsample branch stays RAW (no bias pass over the widest activation of the block); its
+                # folded bias joins conv3's, whose epilogue adds the residual anyway -- one rounding to bf16 fewer
+                res = _conv_bn(self.downsample[0], self.downsample[1], x, raw=True)
+                if isinstance(res, tuple):
+                    identity, shift_ds = res
+                else:
+                    identity = res
+            s2 = self.conv2.stride[0]
+            if (infer16 and self.conv2.stride in ((1, 1), (2, 2))
+                    and fused_residual_ready(self.conv3, out.shape[0], (out.shape[2] + s2 - 1) // s2, (out.shape[3] + s2 - 1) // s2)):
                 # bf16 inference: conv2's bias + ReLU ride on the activation loads of the fused conv3 kernel
                 out, shift2 = _conv_bn(self.conv2, self.norm2, out, relu=True, raw=True)
-                if self.downsample is not None:
+                if self.downsample is not None and shift_ds is None and identity is x:
                     identity = conv_bn(self.downsample[0], self.downsample[1], x)
-                return _conv_bn(self.conv3, self.norm3, out, relu=True, residual=identity, in_bias=shift2)
+                return _conv_bn(self.conv3, self.norm3, out, relu=True, residual=identity, in_bias=shift2, res_bias=shift_ds)
             out = conv_bn(self.conv2, self.norm2, out, relu=True, gate_in=l2, gate_out=l1)
-            if self.downsample is not None:
+            if self.downsample is not None and shift_ds is None and identity is x:
                 identity = conv_bn(self.downsample[0], self.downsample[1], x)
+            if shift_ds is not None:
+                return _conv_bn(self.conv3, self.norm3, out, relu=True, residual=identity, res_bias=shift_ds)
             out = conv_bn(self.conv3, self.norm3, out, relu=True, residual=identity, gate_in=leaving, gate_out=l2)
             if fuse:
                 out._kgdet_gate_link = leaving      # (taken -- and removed -- by the next bottleneck of the layer, if there is one)

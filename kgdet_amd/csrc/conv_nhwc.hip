@@ -32,6 +32,9 @@ constexpr int kStageBytes = 32 * kStageRow;       // 4608 per wave
 
 // IN_EPI: x is the RAW output of the convolution in front (conv2 without its epilogue): relu(x + in_bias[k]) is applied to
 // the activation fragments as they are loaded -- the pass over conv2's output that did it is gone.
+// R == NULL: no residual (conv1 + bn1 + ReLU of a bottleneck: MIOpen's convolution + the bias / ReLU pass over its output as ONE
+// kernel); N == 64 (layer 1): the tile's upper 64 channels do not exist -- their weight rows are zero-filled, their two
+// accumulator blocks are multiplied (the kernel is memory-bound there) and not stored.
 template <bool RELU, int WAVES, bool IN_EPI>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 2) void conv1x1_nhwc_res(
     const __bf16 *__restrict__ A, const __bf16 *__restrict__ Wt, const float *__restrict__ bias, const __bf16 *__restrict__ R,
@@ -45,10 +48,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 2) void conv1x1_nhwc_r
   const int k8s = K >> 3;
   for (int i = tid; i < k8s * 128; i += THREADS) {        // weight tile -> LDS, 16-byte pieces
     const int n = i & 127, k8 = i >> 7;
-    *reinterpret_cast<bf16x8 *>(smem + (size_t)i * 16) = *reinterpret_cast<const bf16x8 *>(Wt + (long long)(n0 + n) * K + k8 * 8);
+    bf16x8 wv = {};
+    if (n0 + n < N) wv = *reinterpret_cast<const bf16x8 *>(Wt + (long long)(n0 + n) * K + k8 * 8);
+    *reinterpret_cast<bf16x8 *>(smem + (size_t)i * 16) = wv;
   }
   float *lbias = reinterpret_cast<float *>(smem + (size_t)K * 128 * 2 + WAVES * kStageBytes);   // the tile's 128 bias values
-  if (tid < 128) lbias[tid] = bias[n0 + tid];
+  if (tid < 128) lbias[tid] = n0 + tid < N ? bias[n0 + tid] : 0.0f;
+  const int halves = N - n0 >= 128 ? 2 : 1;                 // 64-channel halves of this tile that exist
   float *libias = lbias + 128;                                                                   // IN_EPI: the K input biases
   if constexpr (IN_EPI)
     for (int i = tid; i < K; i += THREADS) libias[i] = in_bias[i];
@@ -68,7 +74,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 2) void conv1x1_nhwc_r
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const long long m = m0 + 8 * j + rrow;
-        rv[h][j] = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const unsigned char *>(R + (m < M ? m : M - 1) * N + n0 + h * 64) + rcol);
+        rv[h][j] = bf16x8{};
+        if (R && h < halves)
+          rv[h][j] = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const unsigned char *>(R + (m < M ? m : M - 1) * N + n0 + h * 64) + rcol);
       }
     f32x16 acc[4];
 #pragma unroll
@@ -102,6 +110,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 2) void conv1x1_nhwc_r
     for (; ks < ksteps; ++ks) kstep(ks, *reinterpret_cast<const bf16x8 *>(arow + ks * 16));
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+      if (h >= halves) break;
       // residual half through the staging tile into the accumulator layout (a lane: ONE pixel, runs of four channels)
 #pragma unroll
       for (int j = 0; j < 4; ++j) *reinterpret_cast<bf16x8 *>(stage + (8 * j + rrow) * kStageRow + rcol) = rv[h][j];
@@ -142,14 +151,20 @@ using namespace kgdet;
 extern "C" int kgdet_conv1x1_nhwc_residual_in(const void *x, const float *in_bias, const void *weight, const float *bias,
                                               const void *residual, void *out, int64_t M, int32_t K, int32_t N, int32_t relu,
                                               void *stream) {
-  KGDET_CHECK_SHAPE(M >= 0 && K > 0 && N > 0 && K % 16 == 0 && N % 128 == 0 && K <= 448, "bad sizes (K %% 16, N %% 128, K <= 448)");
+  KGDET_CHECK_SHAPE(M >= 0 && K > 0 && N > 0 && K % 16 == 0 && (N % 128 == 0 || N == 64) && K <= 512,
+                    "bad sizes (K %% 16, N %% 128 or N = 64, K <= 512)");
   if (M == 0) return KGDET_OK;
-  KGDET_CHECK_SHAPE(x && weight && bias && residual && out, "null pointer");
-  const int n_ctiles = N / 128;
-  const int waves = K >= 256 ? 8 : 4;                       // a 64 KB+ weight tile is shared by eight waves
+  KGDET_CHECK_SHAPE(x && weight && bias && out, "null pointer");       // (residual: nullable)
+  const int n_ctiles = (N + 127) / 128;
+  // a 64 KB+ weight tile is shared by eight waves; beyond K = 384 tile + eight staging tiles no longer fit the 160 KB: four
+  const int waves = (K >= 256 && K <= 384) ? 8 : 4;
   const long long n_rtiles = (M + 32 * waves - 1) / (32 * waves);
   const size_t lds = (size_t)K * 128 * 2 + (size_t)waves * kStageBytes + 512 + (size_t)K * 4;
   long long groups = n_rtiles < 768 ? n_rtiles : 768;      // persistent: a few workgroups per CU
+  if (K > 384) {   // one workgroup per CU, 128 KB of weights each: as many row tiles per workgroup as the grid allows
+    const long long fit = 256 / n_ctiles > 0 ? 256 / n_ctiles : 1;
+    if (groups > fit) groups = fit;
+  }
   const dim3 grid((unsigned)(groups * n_ctiles));
 #define KGDET_NHWC_LAUNCH(RELU_, W_, IN_)                                                                                   \
   do {                                                                                                                      \

@@ -538,6 +538,69 @@ def test_conv3x3_stride2_forward_matches_fp64(B, C, O, H, W):
     assert torch.equal(g1, x.grad)
 
 
+@pytest.mark.parametrize('B,K,N,H,W,res,relu', [(2, 64, 64, 50, 84, False, True), (1, 256, 64, 25, 42, False, True), (2, 256, 128, 13, 21, False, True),
+                                               (1, 512, 2048, 25, 42, True, True), (2, 512, 128, 9, 7, False, False), (1, 512, 256, 13, 21, True, False)])
+def test_fused_conv_nhwc_without_residual_narrow_tiles_and_long_reductions(B, K, N, H, W, res, relu):
+    """csrc/conv_nhwc.hip beyond the bottleneck's conv3: no residual (conv1 + bn1 + ReLU), N = 64 (layer 1: half a channel tile),
+    K = 512 (layer 4's conv3: the four-wave variant with the 128 KB weight tile), with and without the deferred input epilogue --
+    against F.conv2d + the separate pass, same rounding sequence."""
+    import ctypes
+    from kgdet_amd import _lib
+    g = torch.Generator('cuda').manual_seed(B * 1000 + K + N)
+    x = torch.randn(B, K, H, W, device='cuda', generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    r = torch.randn(B, N, H, W, device='cuda', generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if res else None
+    w = (torch.randn(N, K, 1, 1, device='cuda', generator=g) * 0.1).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(N, device='cuda', generator=g)
+    ib = torch.randn(K, device='cuda', generator=g)
+    for in_bias in (None, ib):
+        out = torch.full((B, N, H, W), float('nan'), device='cuda', dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        _lib.check(_lib.lib().kgdet_conv1x1_nhwc_residual_in(_lib.ptr(x), _lib.ptr(in_bias), _lib.ptr(w), _lib.ptr(b), _lib.ptr(r),
+                                                             _lib.ptr(out), ctypes.c_int64(B * H * W), ctypes.c_int32(K),
+                                                             ctypes.c_int32(N), ctypes.c_int32(1 if relu else 0),
+                                                             _lib.current_stream()), 'nhwc')
+        xin = x if in_bias is None else torch.relu(x.float() + ib.view(1, -1, 1, 1)).to(torch.bfloat16)
+        ref = F.conv2d(xin.float(), w.float()).to(torch.bfloat16).float() + b.view(1, -1, 1, 1) + (r.float() if res else 0)
+        ref = (torch.relu(ref) if relu else ref).to(torch.bfloat16)
+        assert not torch.isnan(out.float()).any()
+        assert float((out.float() - ref.float()).abs().max()) <= 2 ** -7 * float(ref.float().abs().max())
+        assert float((out.float() - ref.float()).abs().mean()) <= 1e-3 * float(ref.float().abs().mean())
+
+
+def test_bf16_inference_backbone_with_raw_branches_matches_separate_passes():
+    """bf16 inference: the stride-2 downsample branch and the stride-2 conv2 of a layer's first bottleneck stay RAW (their folded
+    biases join conv3's epilogue / ride on conv3's activation loads) -- same features as with their own bias passes, to bf16
+    rounding (one rounding fewer on the raw route)."""
+    from kgdet_amd import backbone as bb
+    torch.manual_seed(0)
+    net = bb.ResNet(depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1, style='pytorch').cuda()
+    net.eval()
+    for n, m in net.named_modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.1)
+    x = torch.randn(2, 3, 256, 320, device='cuda', generator=torch.Generator('cuda').manual_seed(7))
+
+    def run(raw):
+        bb.RAW_BRANCHES = raw
+        bb.clear_fold_cache(); bb._gemm_choice.clear()
+        try:
+            with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+                for _ in range(3):        # (the measured route choices settle in the first calls)
+                    outs = net(x)
+            return [o.float() for o in outs]
+        finally:
+            bb.RAW_BRANCHES = True
+    a, b = run(True), run(False)
+    with torch.no_grad():
+        ref = [o.float() for o in net(x)]     # fp32
+    for u, v, r in zip(a, b, ref):
+        scale = r.abs().max().item()
+        assert (u - v).abs().max().item() <= 0.05 * scale
+        # both routes are equally far from the fp32 features
+        eu, ev = (u - r).abs().mean().item(), (v - r).abs().mean().item()
+        assert eu <= 1.15 * ev + 1e-6 * scale, (eu, ev)
+
+
 @pytest.mark.parametrize('k,stride', [(1, 1), (3, 1), (3, 2), (1, 2)])
 @pytest.mark.parametrize('B,C,O,H,W', [(2, 64, 128, 20, 34), (1, 512, 64, 6, 8), (2, 128, 256, 13, 10)])
 def test_conv_apply_epilogue_flags(B, C, O, H, W, k, stride):
