@@ -576,6 +576,9 @@ int kgdet_multiclass_nms(const float *boxes, const float *scores, int32_t B, int
  * column is the decayed score.  Limits: N * 36 bytes of LDS (N <= 4544), C <= 64, C * max_num <= 16384.
  * workspace: kgdet_multiclass_soft_nms_workspace_bytes(B, N, C). */
 size_t kgdet_multiclass_soft_nms_workspace_bytes(int32_t B, int32_t N, int32_t C);
+/* 1 when kgdet_multiclass_soft_nms serves this problem on chip (N * 36 bytes of LDS per segment, C <= 64, C * max_num keys <=
+ * 16384), 0 when it returns KGDET_E_UNSUPPORTED: the one statement of the limits (callers deciding before a graph capture). */
+int kgdet_multiclass_soft_nms_supported(int32_t B, int32_t N, int32_t C, int32_t max_num);
 int kgdet_multiclass_soft_nms(const float *boxes, const float *scores, int32_t B, int32_t N, int32_t C,
                               int32_t score_stride, int32_t score_col0, float score_thr, float iou_thr,
                               int32_t method, float sigma, float min_score, int32_t max_num, float *out_det,

@@ -60,9 +60,12 @@ def lib():
         for name in ('kgdet_dcn_packed_weight_bytes', 'kgdet_dcn_workspace_bytes', 'kgdet_dcn_group_workspace_bytes',
                      'kgdet_nms_workspace_bytes', 'kgdet_deform_psroi_backward_workspace_bytes',
                      'kgdet_deform_psroi_forward_workspace_bytes', 'kgdet_head_loss_workspace_bytes',
-                     'kgdet_moment_bbox_backward_workspace_bytes'):
+                     'kgdet_moment_bbox_backward_workspace_bytes', 'kgdet_multiclass_soft_nms_workspace_bytes'):
             if hasattr(L, name):
                 getattr(L, name).restype = ctypes.c_size_t
+        if hasattr(L, 'kgdet_multiclass_soft_nms_supported'):
+            L.kgdet_multiclass_soft_nms_supported.restype = ctypes.c_int
+            L.kgdet_multiclass_soft_nms_supported.argtypes = [ctypes.c_int32] * 4
         _lib = L
     return _lib
 

@@ -358,6 +358,23 @@ __global__ __launch_bounds__(128 * NW) void conv_nn(const unsigned char *__restr
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
+  // gate (see the store below).  -DKGDET_GATE_EARLY (experiment, measured SLOWER: 11.35 against 11.19 ms per training step):
+  // its 32 values per lane requested BEFORE the reduction loop, where their round trip hides behind the first stages -- but the
+  // 32 live registers (96 -> 138) cost the gradient variants their second workgroup per CU
+  float gv[2][16];
+#ifdef KGDET_GATE_EARLY
+  if (!F16 && gate) {     // (gradient kernels only: the forward variants are never gated and keep their register count)
+    const int ng = min(n0 + wn * 32 + (lane & 31), N - 1);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = min(mt * kTM + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), M - 1);
+        gv[mi][r] = gate[((long long)b * M + m) * N + ng];
+      }
+  }
+#endif
+
   auto issue = [&](int s, Regs &R) {   // clamped: unconditional loads keep hipcc's vmcnt counting exact
     const int sc = s_begin + min(s, stages - 1);
     R.a = *reinterpret_cast<const f32x4 *>(ai + (long long)sc * kStage);
@@ -423,6 +440,15 @@ __global__ __launch_bounds__(128 * NW) void conv_nn(const unsigned char *__restr
     Regs R[kPF];
 #pragma unroll
     for (int i = 0; i < kPF; ++i) issue(i, R[i]);
+#ifdef KGDET_GATE_EARLY
+    if (!F16 && gate) {   // (pins the gate values HERE: hipcc otherwise sinks the loads to their use behind the loop.  They are older than
+                  //  the first stage's loads, which the commit below waits for anyway)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(gv[mi][r]));
+    }
+#endif
     commit(0, R[0]);
     // stage s: set s % kPF was committed one body ago and is free -> loads of stage s + kPF; set (s+1) % kPF is
     // converted into the other LDS buffer while stage s is multiplied.  The main loop runs whole groups of kPF
@@ -478,8 +504,11 @@ __global__ __launch_bounds__(128 * NW) void conv_nn(const unsigned char *__restr
   }
   if (gate) {   // y *= [gate > 0]: the backward of the ReLU that produced this convolution's input (gate = that input), see
                 // kgdet_conv_apply_gated_fmt -- the consumer of y no longer takes a masking pass over it
+#ifdef KGDET_GATE_EARLY
+    if constexpr (F16)
+#endif
+    {
     const int nc = min(n, N - 1);
-    float gv[2][16];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -487,6 +516,7 @@ __global__ __launch_bounds__(128 * NW) void conv_nn(const unsigned char *__restr
         const int m = min(mt * kTM + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), M - 1);
         gv[mi][r] = gate[((long long)b * M + m) * N + nc];
       }
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll

@@ -815,6 +815,14 @@ size_t kgdet_multiclass_soft_nms_workspace_bytes(int32_t B, int32_t N, int32_t C
   return (size_t)B * C * N * (5 * sizeof(float) + sizeof(int)) + (size_t)B * C * sizeof(int) + 64;
 }
 
+// the on-chip limits of kgdet_multiclass_soft_nms in ONE place (callers that must decide before a graph capture ask here)
+int kgdet_multiclass_soft_nms_supported(int32_t B, int32_t N, int32_t C, int32_t max_num) {
+  if (B < 0 || N < 0 || C <= 0 || C > 64 || max_num <= 0) return 0;
+  int np2 = 64;
+  while (np2 < C * max_num && np2 <= 16384) np2 <<= 1;
+  return ((size_t)N * 9 * 4 <= 160 * 1024 - 256 && np2 <= 16384) ? 1 : 0;
+}
+
 int kgdet_multiclass_soft_nms(const float *boxes, const float *scores, int32_t B, int32_t N, int32_t C,
                               int32_t score_stride, int32_t score_col0, float score_thr, float iou_thr, int32_t method,
                               float sigma, float min_score, int32_t max_num, float *out_det, int64_t *out_label,
@@ -836,7 +844,7 @@ int kgdet_multiclass_soft_nms(const float *boxes, const float *scores, int32_t B
   const size_t lds = (size_t)N * 9 * 4;
   int np2 = 64;
   while (np2 < C * max_num) np2 <<= 1;
-  if (lds > 160 * 1024 - 256 || np2 > 16384) {
+  if (!kgdet_multiclass_soft_nms_supported(B, N, C, max_num)) {
     set_error("multiclass_soft_nms: %d candidates (limit %d) / %d classes x %d detections (limit 16384 keys) exceed the "
               "on-chip limits", N, (160 * 1024 - 256) / 36, C, max_num);
     return KGDET_E_UNSUPPORTED;

@@ -414,7 +414,8 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
             return n <= 4096 and n * C <= 16384 and C <= 64
         if cfg.nms.get('method', 'linear') not in ('linear', 'gaussian'):
             return False
-        return n * 36 <= 160 * 1024 - 256 and C <= 64 and C * cfg.max_per_img <= 16384
+        from .postprocess import soft_nms_fused_supported
+        return soft_nms_fused_supported(len(img_metas), n, C, cfg.max_per_img)
 
     def _decode_level_batch(self, cls_score, bbox_pred, kpt_pred, points, stride, lim_w, lim_h, cfg, selected=None):
         """one level of get_bboxes_single for all images at once: boxes [B,n,4], scores [B,n,C], landmarks [B,n,K,3].

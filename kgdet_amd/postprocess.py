@@ -130,6 +130,12 @@ def multiclass_nms_kp_fused(bboxes, scores, kpts, score_thr, iou_thr, max_num):
 _SOFT_METHODS = {'linear': 1, 'gaussian': 2}      # (nms_wrapper.py:66-68; anything else is the reference's ValueError)
 
 
+def soft_nms_fused_supported(B, N, C, max_num):
+    """the library's own statement of the fused soft-NMS limits (csrc/nms.hip kgdet_multiclass_soft_nms_supported)"""
+    from . import _lib
+    return bool(_lib.lib().kgdet_multiclass_soft_nms_supported(int(B), int(N), int(C), int(max_num)))
+
+
 def multiclass_soft_nms_kp_fused(bboxes, scores, kpts, score_thr, nms_cfg, max_num):
     """``multiclass_nms_kp`` with ``nms_cfg['type'] == 'soft_nms'`` for a batch with nothing read by the host: two HIP launches
     (csrc/nms.hip ``multiclass_soft_nms_segments`` + ``multiclass_soft_select``) and one landmark gather -- what lets the
@@ -145,11 +151,10 @@ def multiclass_soft_nms_kp_fused(bboxes, scores, kpts, score_thr, nms_cfg, max_n
         raise ValueError('Invalid method for SoftNMS: {}'.format(method))
     iou_thr, sigma, min_score = float(cfg['iou_thr']), float(cfg.get('sigma', 0.5)), float(cfg.get('min_score', 1e-3))
     B, N, C = scores.shape
-    if N * 36 > 160 * 1024 - 256 or C > 64 or C * max_num > 16384:
+    if not soft_nms_fused_supported(B, N, C, max_num):
         raise NotImplementedError('beyond the fused soft-NMS limits')
     bboxes, scores = bboxes.contiguous().float(), scores.contiguous().float()
-    L = _lib.lib()
-    L.kgdet_multiclass_soft_nms_workspace_bytes.restype = ctypes.c_size_t
+    L = _lib.lib()           # (restype of the size query: set once at library load, kgdet_amd/_lib.py)
     ws_bytes = L.kgdet_multiclass_soft_nms_workspace_bytes(ctypes.c_int32(B), ctypes.c_int32(N), ctypes.c_int32(C))
     ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=bboxes.device)
     det = torch.empty((B, max_num, 5), dtype=torch.float32, device=bboxes.device)
