@@ -137,6 +137,37 @@ class RepPointsDetectorKp(nn.Module):
             # (d.copy(): the score column of the result is a view of d; labels and the per-class rows are copies already)
             return [self.bbox2result_kp(d.copy(), lab, k, num_classes) for d, lab, k in dets]
 
+        # Pipelined use (a serving loop): ``slot = run.submit()`` replays the graph on the batch in ``run.static_img`` and starts
+        # the device->host copy of its packed results on a side stream; ``run.collect(slot)`` waits for that copy and unpacks.
+        # Calling submit(k + 1) before collect(k) puts batch k's copy and host-side unpacking UNDER batch k + 1's kernels (the
+        # serial ``run`` leaves the GPU idle for both).  Two result slots: collect(k) must have returned before submit(k + 2).
+        stash = [torch.empty_like(static_out) for _ in range(2)]
+        hosts = [torch.empty(static_out.shape, dtype=static_out.dtype, pin_memory=True) for _ in range(2)]
+        ready = [torch.cuda.Event() for _ in range(2)]
+        landed = [torch.cuda.Event() for _ in range(2)]
+        copy_stream = torch.cuda.Stream()
+        counter = [0]
+
+        def submit(new_img=None):
+            if new_img is not None and new_img is not static_img:
+                static_img.copy_(new_img)
+            slot = counter[0] & 1
+            counter[0] += 1
+            graph.replay()
+            stash[slot].copy_(static_out)              # (2.8 MB device copy: the next replay overwrites static_out)
+            ready[slot].record()
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(ready[slot])
+                hosts[slot].copy_(stash[slot], non_blocking=True)
+                landed[slot].record()
+            return slot
+
+        def collect(slot):
+            landed[slot].synchronize()
+            dets = self.bbox_head.unpack_results(hosts[slot].numpy())
+            return [self.bbox2result_kp(d.copy(), lab, k, num_classes) for d, lab, k in dets]
+
+        run.submit, run.collect = submit, collect
         run.graph, run.static_img, run.static_out = graph, static_img, static_out
         # The captured kernels hold raw pointers into the module-level weight-image caches (packed deformable-conv
         # operands, folded conv+BN weights).  Those caches are cleared on mode switches / when they fill up, which

@@ -384,6 +384,37 @@ def test_graphed_test_batch_matches_eager(bf16):
 
 
 @pytest.mark.gpu
+def test_pipelined_graph_batches_return_what_serial_batches_return():
+    """run.submit / run.collect (batch k's result copy and unpacking under batch k + 1's kernels) hand back, batch for batch and
+    bit for bit, what the one-at-a-time ``run`` returns -- three different images through the two result slots, collected one
+    submit late."""
+    from kgdet_amd import build_detector, configs, synthetic
+    cfg = configs.kgdet_r50_fpn()
+    torch.manual_seed(0)
+    model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().eval()
+    batches = [synthetic.make_batch(2, torch.device('cuda'), seed=s) for s in (0, 5, 9)]
+    synthetic.calibrate_scores(model, batches[0], cfg.test_cfg.score_thr, 0.03, torch.autocast('cuda', enabled=False))
+    run = model.graphed_test_batch(batches[0]['img'], batches[0]['img_meta'], rescale=True)
+    order = [0, 1, 2, 1, 0, 2, 2]
+    want = [run(batches[i]['img']) for i in order]
+    got, pending = [], None
+    for i in order:
+        slot = run.submit(batches[i]['img'])
+        if pending is not None:
+            got.append(run.collect(pending))
+        pending = slot
+    got.append(run.collect(pending))
+    assert len(got) == len(want) and sum(len(d) for d in want[0][0][0]) > 10
+    for g_batch, w_batch in zip(got, want):
+        for g, w in zip(g_batch, w_batch):
+            assert len(g) == len(w) == 3 and np.array_equal(g[1], w[1])
+            for c in range(13):
+                assert np.array_equal(g[0][c], w[0][c]) and np.array_equal(g[2][c], w[2][c])
+    # different images did give different results (the comparison above is not vacuous)
+    assert not all(np.array_equal(a, b) for a, b in zip(want[0][0][0], want[1][0][0]))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('soft', [True, False])
 def test_serial_head_packed_postprocess_and_graph_match_the_per_image_path(soft):
     """config 5 (serial head, five levels, <= 3350 candidates per image): the whole-batch decode + fused (soft-)NMS ==
