@@ -146,7 +146,17 @@ __device__ __forceinline__ int dcn_plane_units(int HW) { return 4 * ((HW + 63) >
 // stride -- a corner of EIGHT channels is one ds_read_b128, half the gathers and half the LDS bytes of the fp32 planes (the
 // bf16 kernel's producers are what bounds it: one MFMA per product).  x is rounded to bf16 before the interpolation instead
 // of after it; same error class.  Units = (oct, block of 64 pixels): eight buffer loads, four v_cvt_pk, one 16-byte store.
+// KGDET_PLANE_F16 (round 5, default): the same planes hold FP16 -- three more mantissa bits than bf16, and the producers' fp32
+// interpolation reads them through v_fma_mix_f32 (the fp16 -> fp32 conversion of a corner value is a source modifier of the
+// FMA: eight instructions per corner of eight channels instead of eight shift / mask unpacks + eight FMAs).  Range: |x| <=
+// 65504, beyond that the value saturates (the MODE register's FP16_OVFL bit, set by the kernel) where bf16 kept the exponent:
+// activations behind GroupNorm / ReLU towers sit far inside.  -DKGDET_PLANE_F16=0: the bf16 planes of rounds 2-4 (A/B).
+#ifndef KGDET_PLANE_F16
+#define KGDET_PLANE_F16 1
+#endif
 typedef __bf16 dcn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 dcn_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 dcn_f16x2 __attribute__((ext_vector_type(2)));
 template <int ROUNDS>
 __device__ __forceinline__ void dcn_plane_copy_bf16(const float *__restrict__ xb, int HW, int Cg, int c0, unsigned char *plane,
                                                     unsigned stride, int u_first, int u_step, int u_hi, int lane) {
@@ -172,10 +182,20 @@ __device__ __forceinline__ void dcn_plane_copy_bf16(const float *__restrict__ xb
       if (u < u_hi) {
         const int oct = 1 + ((u - nblk) >> 31);
         const int blk = u - oct * nblk;
+#if KGDET_PLANE_F16
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        u32x4_ o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)     // (v_cvt_pk_f16_f32: round to nearest even, saturating with FP16_OVFL set)
+          o[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_{v[r][2 * e], v[r][2 * e + 1]}, dcn_f16x2));
+        *reinterpret_cast<u32x4_ *>(plane + oct * stride + (unsigned)(blk * 64 + lane) * 16u) = o;
+#else
         dcn_bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[r][e];
         *reinterpret_cast<dcn_bf16x8 *>(plane + oct * stride + (unsigned)(blk * 64 + lane) * 16u) = o;
+#endif
       }
     }
   }

@@ -40,6 +40,11 @@ namespace kgdet {
 template <int PARTS>
 __global__ __launch_bounds__(kRoleThreads, 1) void dcn_fwd_plane(const DcnFwdGroup grp, float *__restrict__ slabs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#if KGDET_PLANE_F16
+  // the one-product kernel's fp16 plane: conversions beyond 65504 saturate instead of producing inf (MODE.FP16_OVFL, see
+  // csrc/conv1x1.hip f16_saturate_on)
+  if constexpr (PARTS == 1) __builtin_amdgcn_s_setreg(1 /*HW_REG_MODE*/ | (23 << 6) | (0 << 11), 1u);
+#endif
   if (threadIdx.x >= kThreads) plane_role<PARTS, true, 0>(grp, slabs, smem);
   else plane_role<PARTS, false, 0>(grp, slabs, smem);
 }

@@ -345,6 +345,12 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         const unsigned o[4] = {R.off[gq].x, R.off[gq].y, R.off[gq].z,
                                (MODE == 1 && gq == NG - 1) ? (R.off[gq].w & 0x1ffffu) : R.off[gq].w};   // (upper bits: flag + slot)
         if constexpr (kBf16Plane) {   // eight channels of a corner in ONE read; bf16 -> fp32 is a shift / a mask per value
+#if KGDET_PLANE_F16
+          // (fp16 plane: the four dwords stay as they are -- corner_fma converts inside its FMAs)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[0][e] = lds_quad(o[e] + (unsigned)(half * kPlaneQuadStride));
+          return;
+#endif
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const u32x4_t raw = __builtin_bit_cast(u32x4_t, lds_quad(o[e] + (unsigned)(half * kPlaneQuadStride)));
@@ -369,6 +375,26 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
 #endif
       };
       auto corner_fma = [&](const Regs &R, int gq, const Corners &v, f32x2 (&sv)[2][2], bool first) {
+#if KGDET_PLANE_F16
+        if constexpr (kBf16Plane) {
+          // dword q = c * 2 + h2 of a corner holds channels 2 q, 2 q + 1 as fp16: fma(w, (float)half, acc) = v_fma_mix_f32
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                // (through a scalar: __builtin_bit_cast applied to the vector-element expression itself reads element 0
+                //  whatever the index -- clang 19 / ROCm 7, reproduced on the host)
+                const float dw = v[0][e][c * 2 + h2];
+                const dcn_f16x2 hv = __builtin_bit_cast(dcn_f16x2, dw);
+                const float w1 = R.w[gq][e];
+                if (first && e == 0) { sv[c][h2][0] = w1 * (float)hv[0]; sv[c][h2][1] = w1 * (float)hv[1]; }
+                else { sv[c][h2][0] = __builtin_fmaf(w1, (float)hv[0], sv[c][h2][0]); sv[c][h2][1] = __builtin_fmaf(w1, (float)hv[1], sv[c][h2][1]); }
+              }
+          return;
+        }
+#endif
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
