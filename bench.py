@@ -552,7 +552,7 @@ def inference_leg():
         d = json.loads(line)
     except Exception as e:      # the training number stands on its own; report the failure instead of hiding it
         return {'error': '%s: %s' % (type(e).__name__, e)}
-    return {k: d[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline', 'with_h2d') if k in d}
+    return {k: d[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline', 'with_h2d', 'batch_at_a_time') if k in d}
 
 
 def graphed_step_leg(args):
