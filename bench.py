@@ -562,7 +562,8 @@ def graphed_step_leg(args):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), '--graphed-step-child', '--steps', str(args.steps), '--warmup',
            str(args.warmup), '--windows', str(args.windows), '--preheat-s', str(min(args.preheat_s, 4.0)),
-           '--imgs-per-gpu', str(args.imgs_per_gpu), '--no-cpu-baseline', '--no-roofline', '--no-inference-leg', '--no-exact-leg']
+           '--imgs-per-gpu', str(args.imgs_per_gpu), '--config', args.config, '--no-cpu-baseline', '--no-roofline',
+           '--no-inference-leg', '--no-exact-leg']
     try:
         res = subprocess.run(cmd, env=dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         line = [l for l in res.stdout.decode().splitlines() if l.startswith('{')][-1]
@@ -931,8 +932,7 @@ def main():
                                      'speedup_of_value': round((imgs / dt) / (args.imgs_per_gpu * world / tex), 3)}
             except Exception as e:
                 out['exact_fp32'] = {'error': '%s: %s' % (type(e).__name__, e)}
-        if (args.mode == 'train' and world == 1 and not dist_on and args.config == 'kgdet' and args.dtype == 'fp32'
-                and args.graph_train):
+        if args.mode == 'train' and world == 1 and not dist_on and args.dtype == 'fp32' and args.graph_train:
             gs = graphed_step_leg(args)
             out['graphed_step'] = gs
             out['eager_step'] = {'img_s': out['value'], 'ms_per_step': out['ms_per_step']}

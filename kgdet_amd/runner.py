@@ -207,7 +207,8 @@ def multi_gpu_test(model, dataset, rescale=True, to_device=None, imgs_per_gpu=1,
 
 
 class GraphedTrainStep(object):
-    """One training step of a FIXED-shape batch -- forward, the nine losses, backward, gradient clip, Adam -- as ONE HIP graph.
+    """One training step of a FIXED-shape batch -- forward, the nine losses, backward, gradient clip, Adam (or torch's fused
+    SGD: config 5) -- as ONE HIP graph.
 
     The eager step is ~560 kernel launches whose enqueue (Python module calls + launch latency, ~11 ms at full size) takes as
     long as the GPU needs to run them (``tools/host_step_cost.py``): every kernel gain below a few percent is invisible in
@@ -236,6 +237,8 @@ class GraphedTrainStep(object):
         assert all(t.is_cuda for t in self.static_tensors) and model.training
 
         def one_step():
+            if getattr(self, 'lr_t', None) is not None and torch.cuda.is_current_stream_capturing():
+                self.lr_t.copy_(self.lr_pin[0], non_blocking=True)
             out = batch_processor(model, self.static, train_mode=True)
             opt_hook.step(model, optimizer, out['loss'])
             return out
@@ -247,21 +250,44 @@ class GraphedTrainStep(object):
                 one_step()
         torch.cuda.current_stream().wait_stream(side)
         fused = opt_hook._fused
-        if fused is None or len(optimizer.param_groups) != 1 or \
-                not FusedClipAdam.applicable(optimizer, opt_hook._params, opt_hook.grad_clip):
-            raise NotImplementedError('the graphed step needs the fused clip + Adam step (one parameter group, torch.optim.Adam)')
-        if fused._sched is None:
-            fused.enable_device_schedule(optimizer)
-        self.fused = fused
-        with torch.cuda.stream(side):                  # one eager step on the device schedule (its table, its buffers)
-            one_step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        optimizer.zero_grad(set_to_none=True)
-        fused.publish_lr(optimizer)
-        with torch.cuda.graph(self.graph):
-            self.out = one_step()
+        self.fused, self.lr_t = None, None
+        if fused is not None and len(optimizer.param_groups) == 1 and \
+                FusedClipAdam.applicable(optimizer, opt_hook._params, opt_hook.grad_clip):
+            if fused._sched is None:
+                fused.enable_device_schedule(optimizer)
+            self.fused = fused
+        elif (type(optimizer) is torch.optim.SGD and len(optimizer.param_groups) == 1
+              and optimizer.param_groups[0].get('fused') and not optimizer.param_groups[0].get('nesterov')):
+            # torch's fused SGD (config 5: momentum 0.9, weight decay 1e-4) keeps no step count; with the learning rate as a
+            # DEVICE scalar the whole step -- clip_grad_norm_'s foreach chain included -- is capturable: `step()` writes the
+            # scheduler's rate into that scalar before every replay (a fill kernel, no read-back)
+            group = optimizer.param_groups[0]
+            self.lr_t = torch.tensor(float(group['lr']), dtype=torch.float32, device=self.static_tensors[0].device)
+            # the rate reaches the device scalar through a copy node at the head of the graph, from ONE page-locked host scalar that
+            # `step()` rewrites only when the scheduler's value changed (after waiting for the replays that still read the old one)
+            self.lr_pin = torch.tensor([float(group['lr'])], dtype=torch.float32).pin_memory()
+            self._lr_last = float(group['lr'])
+        else:
+            raise NotImplementedError('the graphed step needs the fused clip + Adam step or torch.optim.SGD(fused=True) '
+                                      '(one parameter group)')
+        group = optimizer.param_groups[0]
+        lr_host = group['lr']
+        if self.lr_t is not None:
+            group['lr'] = self.lr_t
+        try:
+            with torch.cuda.stream(side):                  # one eager step in the captured form (its table, its buffers)
+                one_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            optimizer.zero_grad(set_to_none=True)
+            if self.fused is not None:
+                self.fused.publish_lr(optimizer)
+            with torch.cuda.graph(self.graph):
+                self.out = one_step()
+        finally:
+            if self.lr_t is not None:
+                group['lr'] = lr_host                      # (schedulers keep seeing and setting a float)
         # (the capture itself does not run the step: nothing was counted yet)
         self.steps = 0
 
@@ -269,18 +295,33 @@ class GraphedTrainStep(object):
         new = [batch['img']] + [t for k in ('gt_bboxes', 'gt_labels', 'gt_keypoints') for t in batch.get(k, [])]
         if len(new) != len(self.static_tensors) or any(a.shape != b.shape for a, b in zip(new, self.static_tensors)):
             raise ValueError('the graphed step was captured for other tensor shapes')
+        if self.lr_t is not None:
+            # Observed on this stack (ROCm 7.0 / torch 2.10, tools/graph_serial_probe.py): an eager kernel enqueued BEHIND an in-flight
+            # replay of the config-5 (serial head, SGD) graph ends in an HSA hardware exception (0x1016) -- the KGDet graph takes the
+            # same pattern without complaint (tools/graph_load_probe.py), a replay that has finished is fine in both.  Cause not
+            # found; until it is, this flow waits for the replay before it touches the graph's input buffers.
+            torch.cuda.current_stream().synchronize()
         with torch.no_grad():
             torch._foreach_copy_(self.static_tensors, [t.to(s.device, non_blocking=True) for t, s in zip(new, self.static_tensors)])
 
     def step(self):
-        self.fused.publish_lr(self.optimizer)
-        self.graph.replay()
-        self.fused.step_published()
+        if self.fused is not None:
+            self.fused.publish_lr(self.optimizer)
+            self.graph.replay()
+            self.fused.step_published()
+        else:
+            lr = float(self.optimizer.param_groups[0]['lr'])
+            if lr != self._lr_last:
+                torch.cuda.current_stream().synchronize()     # (replays in flight read the scalar's old value)
+                self.lr_pin[0] = lr
+                self._lr_last = lr
+            self.graph.replay()
         self.steps += 1
         return self.out
 
     def sync_optimizer_state(self):
-        self.fused.sync_optimizer_state(self.optimizer)
+        if self.fused is not None:
+            self.fused.sync_optimizer_state(self.optimizer)
 
 
 class Runner(object):

@@ -84,3 +84,59 @@ def test_runner_trains_the_hip_detector_on_the_demo_pipeline_and_resumes_bit_ide
     #  up to lr = 1e-4 per step; a resume that lost the optimizer state differs by >= 1e-4 after its first step)
     assert diff <= max(4 * spread, 5e-5), (diff, spread)
     assert again.iter == part.iter == 6
+
+
+def _graph_case(config):
+    from kgdet_amd import build_detector, configs, synthetic
+    from kgdet_amd.dist import DistOptimizerHook
+
+    def make():
+        cfg = configs.kgdet_r50_fpn() if config == 'kgdet' else configs.reppoints_kp_r50_fpn(soft_nms=True)
+        torch.manual_seed(0)
+        model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = torch.optim.Adam(params, lr=1e-5) if config == 'kgdet' else \
+            torch.optim.SGD(params, lr=5e-3, momentum=0.9, weight_decay=1e-4, fused=True)
+        return model, opt, DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2))
+    return make, synthetic.make_batch(2, 'cuda', seed=0)
+
+
+@pytest.mark.parametrize('config', ['kgdet', 'serial'])
+def test_graphed_train_step_follows_the_eager_steps(config):
+    """runner.GraphedTrainStep (forward, losses, backward, clip, optimizer as ONE replayed HIP graph; Adam through the fused step
+    with its schedule in device memory, config 5's SGD through torch's fused kernel with the rate in a device scalar): after the
+    same number of steps from the same state the parameters equal the eager loop's to rounding (the library GEMMs of the head's
+    1x1 output convolutions use float atomics: two EAGER runs differ by as much, tools/determinism_probe.py), the learning rate
+    set between replays takes effect, and the optimizer's own step counters are right after sync_optimizer_state()."""
+    make, batch = _graph_case(config)
+    warm, replays = 3, 4
+    m1, o1, h1 = make()
+    g = rn.GraphedTrainStep(m1, o1, h1, batch, warmup=warm)
+    for k in range(replays):
+        if k == 2:
+            o1.param_groups[0]['lr'] *= 0.5          # a scheduler's change between two replays
+        out = g.step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out['loss']).item()
+    g.sync_optimizer_state()
+    m2, o2, h2 = make()
+    for k in range(warm + 1 + replays):             # (the class runs `warm` steps + one in its captured form before the capture)
+        if k == warm + 1 + 2:
+            o2.param_groups[0]['lr'] *= 0.5
+        o = rn.batch_processor(m2, batch)
+        h2.step(m2, o2, o['loss'])
+    torch.cuda.synchronize()
+    if h2._fused is not None and h2._fused._pending:
+        h2._fused.sync_optimizer_state(o2)
+    # the two runs' UPDATES (parameters minus the common initial state) point the same way and have the same length -- element by
+    # element Adam turns a gradient that is rounding noise around zero into a step of +-lr, so single elements may differ by a
+    # whole step; a missed learning-rate change (the last two of eight steps at half the rate) would change the length by > 5 %
+    m3, _, _ = make()
+    u1 = torch.cat([(a.detach() - c.detach()).flatten() for a, c in zip(m1.parameters(), m3.parameters()) if a.requires_grad])
+    u2 = torch.cat([(b.detach() - c.detach()).flatten() for b, c in zip(m2.parameters(), m3.parameters()) if b.requires_grad])
+    cos = float(torch.dot(u1, u2) / (u1.norm() * u2.norm()))
+    ratio = float(u1.norm() / u2.norm())
+    assert float(u1.norm()) > 0 and cos >= 0.995 and abs(ratio - 1.0) <= 0.01, (cos, ratio)
+    if config == 'kgdet':
+        s1 = float(next(iter(o1.state.values()))['step'])
+        assert s1 == warm + 1 + replays, s1

@@ -5,13 +5,14 @@ import torch
 from kgdet_amd import build_detector, configs, synthetic
 from kgdet_amd.dist import DistOptimizerHook
 dev = torch.device('cuda:0')
-cfg = configs.kgdet_r50_fpn()
+cfg = configs.reppoints_kp_r50_fpn(soft_nms=True) if os.environ.get('CONFIG') == 'serial' else configs.kgdet_r50_fpn()
 torch.manual_seed(0)
 model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).to(dev)
 batch = synthetic.make_batch(2, dev, seed=0)
 model.train()
-opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4, fused=True)
-hook = DistOptimizerHook(grad_clip=dict(cfg.optimizer_config.grad_clip))
+opt = (torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=5e-3, momentum=0.9, weight_decay=1e-4, fused=True)
+       if os.environ.get('CONFIG') == 'serial' else torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4, fused=True))
+hook = DistOptimizerHook(grad_clip=dict(max_norm=35, norm_type=2))
 def step():
     losses = model(batch['img'], batch['img_meta'], return_loss=True, gt_bboxes=batch['gt_bboxes'],
                    gt_labels=batch['gt_labels'], gt_keypoints=batch['gt_keypoints'])
