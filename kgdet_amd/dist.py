@@ -84,9 +84,12 @@ class OverlappedGradReducer(object):
     one has-gradient flag per parameter behind the payload, summed by the same all-reduce; the sums are copied to
     page-locked host memory without a synchronisation and inspected at the NEXT step's ``finish()``: a BUCKETED parameter
     with a gradient on some ranks only (0 < count < world size) raises there -- one step late, never silently.
-    NOT covered: a parameter OUTSIDE the buckets (no gradient when they were built) that starts to receive a
-    gradient on some ranks only -- those ranks rebuild (an all-gather) while the others issue the next all-reduce: mismatched
-    collectives.  The same event on EVERY rank (a branch that becomes active) rebuilds consistently.
+    (c) (round 5) a parameter OUTSIDE the buckets (no gradient when they were built) that starts to receive a gradient: the
+    decision to rebuild is COLLECTIVE.  Every step the ranks sum one "I saw such a gradient" bit (a one-element all-reduce on
+    the side stream behind the last bucket, copied to page-locked memory like the flags); the rank that sees the gradient
+    DROPS it for that step (``grad = None``: no rank updates the parameter, the replicas stay identical) and raises its bit;
+    at the NEXT ``finish()`` every rank reads a non-zero sum and rebuilds in the same step -- if the late joiner then has a
+    gradient on some ranks only, the layout check (a) raises everywhere.  At one rank the rebuild happens at once, as before.
     """
 
     def __init__(self, params, bucket_size_mb=32, process_group=None):
@@ -101,6 +104,14 @@ class OverlappedGradReducer(object):
         self._hooks = []
         self._pending = []
         self.launched_from_hooks = 0   # buckets whose exchange started inside backward (diagnostics / tests)
+        # late joiners (docstring (c)): this step's bit on the device, last step's sum in page-locked memory
+        dev = self.params[0].device if self.params else torch.device('cpu')
+        self._late = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._late_host = torch.zeros(1, dtype=torch.float32)
+        if self.use_cuda:
+            self._late_host = self._late_host.pin_memory()
+        self._late_event = None
+        self.late_joiner_rebuilds = 0      # (diagnostics / tests)
         # Sentinel mode (begin_step() callers only): after one step with a hook on EVERY parameter -- 161 Python calls per
         # step, ~0.4 ms of a 13 ms step -- the reducer keeps ONE hook per bucket, on the parameter whose gradient arrived
         # last, and launches bucket b from it once every gradient of the bucket is there (they were all None at
@@ -278,8 +289,24 @@ class OverlappedGradReducer(object):
     def finish(self):
         """Call after ``loss.backward()``: completes the exchange; afterwards every bucketed parameter's
         ``.grad`` is the averaged gradient (a view of its bucket)."""
-        if self.buckets is not None and any(p.grad is not None for p in self._inactive):
+        rebuild, late = False, []
+        if self.buckets is not None:
+            late = [p for p in self._inactive if p.grad is not None]
+            if self.world_size == 1:
+                rebuild = bool(late)
+            else:
+                # last step's sum of the late-joiner bits (its host copy is a step old: no stall)
+                if self._late_event is not None:
+                    if self.use_cuda:
+                        self._late_event.synchronize()
+                    self._late_event = None
+                    rebuild = float(self._late_host[0]) > 0.5
+                if not rebuild and late:
+                    for p in late:           # this step goes on without them, on every rank; the bit goes out below
+                        p.grad = None
+        if rebuild:
             # a parameter started to receive gradients: nothing of this step is usable as launched
+            self.late_joiner_rebuilds += 1
             for _, work in self._pending:
                 work.wait()
             if self.use_cuda:
@@ -287,6 +314,7 @@ class OverlappedGradReducer(object):
             for h in self._hooks:
                 h.remove()
             self._hooks, self.buckets = [], None
+            late = []
         if self.buckets is None:
             # first step: learn which params get gradients, build the buckets and exchange through them (all
             # launched from here, in index order; no second whole-payload buffer)
@@ -308,6 +336,15 @@ class OverlappedGradReducer(object):
                     self._flag_event[b] = True
                 if self.world_size > 1:      # (sum, then ONE division: dist_utils.py:17-19; x / 1 is x)
                     self._flat[b][:self._flat[b].numel() - len(self.buckets[b])].div_(self.world_size)
+            if self.world_size > 1:          # the late-joiner bit of THIS step (read at the next finish())
+                self._late.fill_(1.0 if late else 0.0)
+                dist.all_reduce(self._late, group=self.group)
+                self._late_host.copy_(self._late, non_blocking=True)
+                if self.use_cuda:
+                    self._late_event = torch.cuda.Event()
+                    self._late_event.record(self.stream)
+                else:
+                    self._late_event = True
         if self.use_cuda:
             torch.cuda.current_stream().wait_stream(self.stream)
         for plist, views in zip(self.buckets, self._views):

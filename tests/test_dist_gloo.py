@@ -82,12 +82,19 @@ def _worker_body(rank, world, port, q):
     dead = {id(p) for p in model[2].parameters()}
     ok &= all(float(v.abs().max()) == 0.0 for pl, vl in zip(red.buckets, red._views) for p, v in zip(pl, vl)
               if id(p) in dead)
-    # ... and a parameter that starts to receive gradients later is picked up (buckets rebuild)
+    # ... and a parameter that starts to receive gradients later is picked up (buckets rebuild) -- at N ranks one step after it
+    # showed up: the step in which it appears drops its gradient on every rank (the decision to rebuild is collective, dist.py (c))
+    for p in params:
+        p.grad = None
+    (model(x).pow(2).sum() + unused(x[:, :3]).pow(2).sum()).backward()
+    red.finish()
+    ok &= all(p.grad is None for p in unused.parameters()) and red.late_joiner_rebuilds == 0
     for p in params:
         p.grad = None
     (model(x).pow(2).sum() + unused(x[:, :3]).pow(2).sum()).backward()
     gu = [p.grad.clone() for p in unused.parameters()]
     red.finish()
+    ok &= red.late_joiner_rebuilds == 1
     dist.all_gather_object(gathered, [g.numpy() for g in gu])
     for i, p in enumerate(unused.parameters()):
         mean = sum(torch.from_numpy(gathered[r][i]) for r in range(world)) / world
@@ -282,6 +289,86 @@ def test_two_rank_preconditions_are_enforced():
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker_enforce, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == {0: True, 1: True}
+
+
+def _worker_late(rank, world, port, q):
+    """Round 5 (dist.py): a parameter outside the buckets that starts to receive a gradient -- the rebuild is a collective
+    decision, one step late, and a late joiner on ONE rank only raises on both instead of mismatching the collectives."""
+    ok = True
+    try:
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        from kgdet_amd.dist import OverlappedGradReducer
+        torch.manual_seed(0)
+        model = nn.Sequential(nn.Linear(8, 16), nn.ReLU(), nn.Linear(16, 4))
+        extra = nn.Linear(8, 2)                       # joins at step 2
+        params = list(model.parameters()) + list(extra.parameters())
+        x = torch.randn(5, 8, generator=torch.Generator().manual_seed(100 + rank))
+
+        def step(red, with_extra):
+            for p in params:
+                p.grad = None
+            loss = model(x).pow(2).sum()
+            if with_extra:
+                loss = loss + extra(x).pow(2).sum()
+            loss.backward()
+            local = [None if p.grad is None else p.grad.clone() for p in extra.parameters()]
+            red.finish()
+            return local
+
+        # (1) the branch becomes active on BOTH ranks in step 2: dropped in step 2 (no rank updates it), every rank rebuilds
+        #     in step 3, from then on its gradient is the rank average
+        red = OverlappedGradReducer(params, bucket_size_mb=0.0005)
+        for s in range(5):
+            local = step(red, with_extra=s >= 2)
+            if s < 2:
+                ok &= all(p.grad is None for p in extra.parameters())
+            elif s == 2:
+                ok &= all(p.grad is None for p in extra.parameters()) and red.late_joiner_rebuilds == 0
+            else:
+                ok &= red.late_joiner_rebuilds == 1
+                gathered = [None] * world
+                dist.all_gather_object(gathered, [g.numpy() for g in local])
+                for i, p in enumerate(extra.parameters()):
+                    mean = sum(torch.from_numpy(gathered[r][i]) for r in range(world)) / world
+                    ok &= p.grad is not None and bool(torch.allclose(p.grad, mean, atol=1e-6))
+        n_before = len(red.buckets)
+        red.close()
+
+        # (2) the branch becomes active on rank 1 ONLY: step 2 completes on both ranks (rank 1 drops the gradient), step 3
+        #     raises on BOTH ranks (the ranks would cut different buckets) -- no hang, no mismatched collective
+        red = OverlappedGradReducer(params, bucket_size_mb=0.0005)
+        for s in range(2):
+            step(red, with_extra=False)
+        step(red, with_extra=(rank == 1))
+        ok &= all(p.grad is None for p in extra.parameters())
+        try:
+            step(red, with_extra=(rank == 1))
+            ok = False
+        except RuntimeError as e:
+            ok &= 'disagree on the gradient buckets' in str(e)
+        ok &= n_before >= 1
+        q.put((rank, bool(ok)))
+        dist.destroy_process_group()
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        q.put((rank, False))
+        raise
+
+
+def test_two_rank_late_joiner_is_a_collective_decision():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_late, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=180) for _ in range(2))
