@@ -1207,53 +1207,66 @@ struct ConvFoldArgs {
   float eps;
   int P;
 };
+// Launch shape (round 5): ONE workgroup per output channel with as many threads as the row has columns (up to 1024), every
+// thread one or two columns, a column's partials requested in batches of 16 -- a row's 16-38 MB / O of partials arrive in one or
+// two memory round trips instead of the ~9 dependent ones of the 256-thread form (7.6 / 15.6 us per launch for the 1x1 / 3x3
+// problems of the backbone, i.e. 1-2 TB/s on data that sits in the Infinity Cache).  T9: the (tap, channel) -> (channel, tap)
+// transposition goes through LDS (the row, <= 18 KB), so that grad_w is stored and w is read in whole lines instead of 4-byte
+// pieces 36 bytes apart.
 template <bool T9>
-__global__ __launch_bounds__(256) void conv_wsum_fold(const float *__restrict__ parts, float *__restrict__ out, int C,
-                                                      long long stride, int count, const ConvFoldArgs f) {
-  __shared__ float red[2][4];
+__global__ __launch_bounds__(1024) void conv_wsum_fold(const float *__restrict__ parts, float *__restrict__ out, int C,
+                                                       long long stride, int count, const ConvFoldArgs f) {
+  extern __shared__ float row_s[];       // T9: the summed row in grad_w's column order
+  __shared__ float red[2][16];
   const int o = blockIdx.x, CK = T9 ? 9 * C : C;
+  const int nthr = blockDim.x, tid = threadIdx.x;
   const float so = f.s[o];
   const float *wr = f.w + (long long)o * CK;
   const float *pr = parts + (long long)o * CK;
   float *gr = out + (long long)o * CK;
   float dot = 0.0f, sb = 0.0f;
-  // Two columns per thread and round, eight slots each: sixteen loads in flight (one workgroup per output channel = one per CU:
-  // with four loads per thread the kernel waited out ~16 memory round trips, 11 us per launch for 16-38 MB).  Every column is
-  // still added in slot order.
-  for (int q = threadIdx.x; q < CK; q += 512) {          // q, q + 256: the partials' columns (coalesced reads)
-    const int q1 = q + 256;
-    const bool two = q1 < CK;
-    const int qb = two ? q1 : q;                         // (a clamped duplicate where the second column does not exist)
-    float g0 = 0.0f, g1 = 0.0f;
+  for (int q = tid; q < CK; q += nthr) {                  // the partials' columns (coalesced reads); every column in slot order
+    float g0 = 0.0f;
     int k = 0;
-    for (; k + 8 <= count; k += 8) {
-      float v[8], u[8];
+    for (; k + 16 <= count; k += 16) {
+      float v[16];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[e] = pr[(long long)(k + e) * stride + q];
-        u[e] = pr[(long long)(k + e) * stride + qb];
-      }
+      for (int e = 0; e < 16; ++e) v[e] = pr[(long long)(k + e) * stride + q];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { g0 += v[e]; g1 += u[e]; }
+      for (int e = 0; e < 16; ++e) g0 += v[e];
     }
-    for (; k < count; ++k) { g0 += pr[(long long)k * stride + q]; g1 += pr[(long long)k * stride + qb]; }
-    const int j0 = T9 ? (q % C) * 9 + q / C : q;         // partial column (tap, channel) -> grad_w column (channel, tap)
-    dot += wr[j0] * g0;
-    gr[j0] = g0 * so;
-    if (two) {
-      const int j1 = T9 ? (q1 % C) * 9 + q1 / C : q1;
-      dot += wr[j1] * g1;
-      gr[j1] = g1 * so;
+    if (k + 8 <= count) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = pr[(long long)(k + e) * stride + q];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g0 += v[e];
+      k += 8;
+    }
+    for (; k < count; ++k) g0 += pr[(long long)k * stride + q];
+    if constexpr (T9) {
+      row_s[(q % C) * 9 + q / C] = g0;                    // partial column (tap, channel) -> grad_w column (channel, tap)
+    } else {
+      dot += wr[q] * g0;
+      gr[q] = g0 * so;
     }
   }
-  for (int k = threadIdx.x; k < f.P; k += 256) sb += f.bn_partial[(long long)o * f.P + k];
+  if constexpr (T9) {
+    __syncthreads();
+    for (int j = tid; j < CK; j += nthr) {
+      const float g0 = row_s[j];
+      dot += wr[j] * g0;
+      gr[j] = g0 * so;
+    }
+  }
+  for (int k = tid; k < f.P; k += nthr) sb += f.bn_partial[(long long)o * f.P + k];
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) { dot += __shfl_xor(dot, d); sb += __shfl_xor(sb, d); }
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sb; red[1][threadIdx.x >> 6] = dot; }
+  if ((tid & 63) == 0) { red[0][tid >> 6] = sb; red[1][tid >> 6] = dot; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const float b = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    const float d = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  if (tid == 0) {
+    float b = 0.0f, d = 0.0f;
+    for (int w = 0; w < (nthr >> 6); ++w) { b += red[0][w]; d += red[1][w]; }     // wave order: fixed
     if (f.grad_beta) f.grad_beta[o] = b;
     if (f.grad_gamma) f.grad_gamma[o] = (d - f.mean[o] * b) / sqrtf(f.var[o] + f.eps);
   }
@@ -2148,6 +2161,12 @@ __global__ __launch_bounds__(256) void pad_rows2(const float *__restrict__ a, fl
   }
 }
 
+// threads of conv_wsum_fold for a row of `cols` columns: one column per thread up to 1024 (whole waves)
+static int fold_threads(int cols) {
+  const int t = (cols + 63) / 64 * 64;
+  return t < 64 ? 64 : (t > 1024 ? 1024 : t);
+}
+
 // workspace = [split partials | padded operand copies (maps with H*W % 4 != 0 on the conv_nt8 route) | per-row sums of grad_y,
 // [O][splits], for the folded variant called without bn_partial]; *rows_at = byte offset of the last region
 static size_t conv1x1_gw_workspace(int64_t B, int32_t O, int32_t C, int64_t HW, size_t *rows_at) {
@@ -2228,8 +2247,8 @@ static int conv1x1_grad_weight_impl(const float *grad_y, const float *x, float *
   if (fold) {
     ConvFoldArgs f = *fold;
     if (row_sums) { f.bn_partial = row_sums; f.P = splits; }
-    hipLaunchKernelGGL(conv_wsum_fold<false>, dim3(O), dim3(256), 0, (hipStream_t)stream, (const float *)workspace, grad_w, C,
-                       n, splits, f);
+    hipLaunchKernelGGL(conv_wsum_fold<false>, dim3(O), dim3(fold_threads(C)), 0, (hipStream_t)stream,
+                       (const float *)workspace, grad_w, C, n, splits, f);
     KGDET_CHECK_LAUNCH("conv_wsum_fold");
     return KGDET_OK;
   }
@@ -2350,8 +2369,8 @@ static int conv3x3_grad_weight_impl(const float *grad_y, const float *x, float *
   if (fold) {
     ConvFoldArgs f = *fold;
     if (row_sums) { f.bn_partial = row_sums; f.P = splits; }
-    hipLaunchKernelGGL(conv_wsum_fold<true>, dim3(O), dim3(256), 0, (hipStream_t)stream, (const float *)workspace, grad_w, C, n,
-                       splits, f);
+    hipLaunchKernelGGL(conv_wsum_fold<true>, dim3(O), dim3(fold_threads(9 * C)), (size_t)9 * C * sizeof(float),
+                       (hipStream_t)stream, (const float *)workspace, grad_w, C, n, splits, f);
     KGDET_CHECK_LAUNCH("conv_wsum_fold");
     return KGDET_OK;
   }
