@@ -906,7 +906,8 @@ def main():
             rl['launch_us_note'] = ('launch_us / frac: dcn_build_taps + dcn_fwd_plane<2> + dcn_fwd_fixup_static with the weight images '
                                     'packed beforehand (an unchanged weight is packed once); *_pack_inside: the same plus '
                                     'dcn_pack_weight_all_multi per call, as in a training step')
-        if args.mode == 'train' and args.config == 'kgdet' and not args.no_exact_leg:
+        if args.mode == 'train' and args.config == 'kgdet' and not args.no_exact_leg and world == 1 and not dist_on:
+            # (one rank only: this block runs on rank 0 alone, a step of an N-rank job contains collectives)
             # the reference's precision class, measured: the same step in plain fp32 arithmetic (f32-input MFMA deformable kernels,
             # MIOpen fp32 convolutions with its heuristic picks -- no find), a short window after the steady ones
             try:
