@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void dcn_build_taps(const DcnFwdGroup grp) {
 
 // LDS of dcn_fwd_plane: the four quad planes at their fixed stride (whatever the image size: the quad is an immediate
 // offset of the corner reads) + two groups of B stages
-size_t dcn_fwd_plane_fixed_lds_bytes(int parts) { return (size_t)2 * kGroupTaps * parts * kBPart; }
+// two group buffers (+ the extra stage's slot of the KGDET_PLANE_STREAM variants)
+size_t dcn_fwd_plane_fixed_lds_bytes(int parts) { return (size_t)(2 * kGroupTaps + (KGDET_PLANE_STREAM ? 1 : 0)) * parts * kBPart; }
 size_t dcn_fwd_plane_lds_bytes(int parts, int HW) {
   return HW <= kPlaneMaxHW ? dcn_fwd_plane_fixed_lds_bytes(parts) + (size_t)4 * kPlaneQuadStride : (size_t)1 << 30;
 }

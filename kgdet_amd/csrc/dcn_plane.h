@@ -46,6 +46,17 @@ constexpr int kRoleThreads = kThreads + kRoleProducers;
 static_assert(kRolePairs == 2 || kRolePairs == 4, "two or four producer wave pairs");
 constexpr int kPlaneRounds = 6;                          // (pixel, quad) items a thread has in flight while copying a plane
 constexpr int kGroupTaps = 4;                            // stages (taps) between two workgroup barriers
+// KGDET_PLANE_STREAM (round 5, forward with split operands): a segment of 4 q + 1 stages (9 / 25 / 49 taps) runs as q FULL groups
+// and ONE extra stage that has its own B slot behind the two group buffers: it is sampled together with the last full group
+// and multiplied behind it, while the producers bring in the next plane and sample the next segment's first FULL group.  The
+// short group of one stage used to be the segment's first: the consumers multiplied it while the producers needed a whole
+// group time for the next four stages -- a bubble per segment (profiles/r05_dcn_fwd_plane_group_b2.md).  Built, correct (the 61
+// forward tests), and MEASURED SLOWER: 163.2 / 162.5 against 161.0 / 160.1 us per launch sequence (1), 168.4 / 167.5 against
+// 164.1 / 163.7 with the hand-over barrier one stage earlier (2) -- although the trace build counts 2.7 % FEWER cycles for the 5x5
+// workgroups.  Default 0 (off); -DKGDET_PLANE_STREAM=1|2 builds the variants.
+#ifndef KGDET_PLANE_STREAM
+#define KGDET_PLANE_STREAM 0
+#endif
 constexpr bool kAFromL2 = true;   // (grad_weight kernel) consumers take their A fragments from the operand image in L2
 
 // Ablation switches for experiment builds (make VARIANT=... EXTRA=-DKGDET_ABL_...; results are WRONG by design):
@@ -275,6 +286,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
     typedef std::integral_constant<int, kThreads / 64> ConsumerWaves;
     typedef std::integral_constant<int, kPlaneRounds> FullRounds;
     typedef std::integral_constant<int, kPlaneRounds / 2> HalfRounds;   // the consumers' share is the small one
+    Regs X0;               // producers, stream mode: the record of the segment's extra stage
     Regs E0, E1, O0, O1;   // producers: this wave pair's two records of the even-numbered (E) and of the odd-numbered (O)
                            // groups of the segment.  Group g + 2's are loaded at the TOP of iteration g, which samples group
                            // g + 1 from the other set: a whole group to land, and no register moves (the iterations are
@@ -290,8 +302,11 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       // consumers have nothing to multiply while the first group is sampled, so it is the short one (r = 1 for the
       // 9 / 25 / 49 taps of 3x3 / 5x5 / 7x7), and the LAST group is a full one: the plane is not read any more once its
       // stages are sampled, and the producers copy the next segment's plane under its four stages of MFMAs.
-      const int r = ((n - 1) & 3) + 1;
-      const int n_groups = 1 + (n - r) / kGroupTaps;
+      constexpr bool kStreamable = (KGDET_PLANE_STREAM != 0) && MODE == 0 && PARTS == 2 && kRolePairs == 4;
+      // (stream: see KGDET_PLANE_STREAM above -- q = n_groups full groups + the extra stage n - 1)
+      const bool stream = kStreamable && xb_dma && (n & 3) == 1 && n >= 9;
+      const int r = stream ? 4 : ((n - 1) & 3) + 1;
+      const int n_groups = stream ? (n - 1) / kGroupTaps : 1 + (n - r) / kGroupTaps;
       const bool has_next = s + n < s_end;
       const unsigned rec_base = seg_records(c16);
       unsigned xg_seg = xg_img + (unsigned)(c16 * kChunk * 4);   // (MODE 2) this segment's channel chunk
@@ -327,7 +342,9 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         a_issue_at(wq_seg + (unsigned)(t0 + min(j, n - 1)) * (2 * kAPart), F);
       };
       // chained hand-over: what the NEXT segment (chunk c16 + 1, taps 0 .. n2 - 1, first group of r2 stages) needs
-      const int n2 = has_next ? min(K, s_end - (s + n)) : 1, r2 = ((n2 - 1) & 3) + 1;
+      const int n2 = has_next ? min(K, s_end - (s + n)) : 1;
+      const bool stream2 = kStreamable && xb_dma && has_next && (n2 & 3) == 1 && n2 >= 9;
+      const int r2 = stream2 ? 4 : ((n2 - 1) & 3) + 1;
       const unsigned wq_seg2 = wq_seg + (unsigned)K * (2 * kAPart);   // (chunk c16 + 1 of the same row tile)
       const bool chain = ((KGDET_PLANE_CHAIN >> MODE) & 1) && has_next && n_groups >= 2 && (MODE == 2 || xb_dma || KGDET_PLANE_CHAIN_REGS);   // the last group is a full one: chain under it
       // ---- B stage, producers.  A group has four stages; producer wave pair w (2 waves = 128 pixels) samples stages
@@ -441,7 +458,9 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
             }
           }
         const bf16x8 hi = __builtin_bit_cast(bf16x8, hi_u), lo = __builtin_bit_cast(bf16x8, lo_u);
-        unsigned char *dst = Bs + ((unsigned)buf ^ bsel) * kGroupBytes + gi * PARTS * kBPart + half * (kTileN * 16) + n_local * 16;
+        // (buf 2: the extra stage's slot behind the two group buffers)
+        unsigned char *dst = Bs + (buf == 2 ? 2u * kGroupBytes : ((unsigned)buf ^ bsel) * kGroupBytes + gi * PARTS * kBPart) +
+                             half * (kTileN * 16) + n_local * 16;
 #ifdef KGDET_ABL_NOBSTORE
         if (sv[0][0][0] != 1234.56789f) return;
 #endif
@@ -555,7 +574,8 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         return;
 #endif
         if constexpr (!PRODUCER) {
-          const unsigned char *B = Bs + ((unsigned)buf ^ bsel) * kGroupBytes + gi * PARTS * kBPart + (lane >> 5) * (kTileN * 16) +
+          const unsigned char *B = Bs + (buf == 2 ? 2u * kGroupBytes : ((unsigned)buf ^ bsel) * kGroupBytes + gi * PARTS * kBPart) +
+                                   (lane >> 5) * (kTileN * 16) +
                                    (lane & 31) * 16;
           if constexpr (k42) {
             bf16x8 b[PARTS][2];
@@ -632,6 +652,8 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
           issue(rec_base, t0, r - 1, pair, E0);
           issue(rec_base, t0, n - 1, r + pair, O0);
           if constexpr (kRolePairs == 2) { issue(rec_base, t0, r - 1, pair + 2, E1); issue(rec_base, t0, n - 1, r + pair + 2, O1); }
+          if constexpr (kStreamable)
+            if (stream && n_groups == 2) issue(rec_base, t0, n - 1, n - 1, X0);
         }
         if constexpr (MODE != 2) load_plane(c16, wave_all, AllWaves{}, FullRounds{}, 0, plane_items);
         KGDET_TR_ADD(1, tr_t);
@@ -660,13 +682,19 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
           } else {
             issue(rec_base, t0, n - 1, jn + pair, Ia);
             if constexpr (kRolePairs == 2) issue(rec_base, t0, n - 1, jn + pair + 2, Ib);
+            if constexpr (kStreamable)
+              if (stream && gi + 3 == n_groups) issue(rec_base, t0, n - 1, n - 1, X0);   // (group gi + 2 is the last full one)
             sample_group(buf_next, Sa, Sb, true, true, [] {});
+            if constexpr (kStreamable)
+              if (stream && gi + 2 == n_groups && pair < 2) sample_half(2, 0, pair, X0);  // behind the last full group: the extra stage
           }
         } else if (has_next) {
           const unsigned rb2 = seg_records(c16 + 1);
           issue(rb2, 0, r2 - 1, pair, E0);
           issue(rb2, 0, n2 - 1, r2 + pair, O0);
           if constexpr (kRolePairs == 2) { issue(rb2, 0, r2 - 1, pair + 2, E1); issue(rb2, 0, n2 - 1, r2 + pair + 2, O1); }
+          if constexpr (kStreamable)
+            if (stream2 && (n2 - 1) / kGroupTaps == 2) issue(rb2, 0, n2 - 1, n2 - 1, X0);
           if (chain) {
             // the whole plane by the producers, one batch of loads per wave; then, behind the mid-group barrier that
             // publishes it, the next segment's first group into the B buffer this segment's last group does not use
@@ -724,27 +752,40 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
         } else {
           const int jg = r + (gi - 1) * kGroupTaps;
           // (one scheduling region per stage: across all four, hipcc hoists the B reads of later stages and spills)
+          const bool hand = chain && gi + 1 == n_groups;
+          const bool extra = kStreamable && stream && gi + 1 == n_groups;      // the extra stage n - 1 follows this group
           lead(0);
           multiply(buf, 0, F0);
           a_issue(jg + 2, F0);
           __builtin_amdgcn_sched_barrier(0);
+#if KGDET_PLANE_STREAM == 2   // (variant: the hand-over barrier one stage earlier -- the producers only wait for their DMA)
+          if constexpr (MODE != 2)
+            if (hand && extra) {
+              KGDET_TR_ADD(4, tr_t);
+              __syncthreads();
+              KGDET_TR_ADD(0, tr_t);
+            }
+#endif
           lead(1);
           multiply(buf, 1, F1);
           a_issue(jg + 3, F1);
           __builtin_amdgcn_sched_barrier(0);
           // chained hand-over under the last group: the plane of the next segment is complete behind the mid-group barrier
           // (its sampling overlaps stages three and four); the fragment sets take the next segment's first two stages
-          const bool hand = chain && gi + 1 == n_groups;
           if constexpr (MODE != 2)
-            if (hand) {
+            if (hand && !((KGDET_PLANE_STREAM == 2) && extra)) {
               KGDET_TR_ADD(4, tr_t);
               __syncthreads();
               KGDET_TR_ADD(0, tr_t);
             }
-          const unsigned so0 = hand ? wq_seg2 + (unsigned)min((r2 & 1) ? 1 : 0, n2 - 1) * (2 * kAPart)
-                                    : wq_seg + (unsigned)(t0 + min(jg + 4, n - 1)) * (2 * kAPart);
-          const unsigned so1 = hand ? wq_seg2 + (unsigned)min((r2 & 1) ? 0 : 1, n2 - 1) * (2 * kAPart)
-                                    : wq_seg + (unsigned)(t0 + min(jg + 5, n - 1)) * (2 * kAPart);
+          unsigned so0 = hand ? wq_seg2 + (unsigned)min((r2 & 1) ? 1 : 0, n2 - 1) * (2 * kAPart)
+                              : wq_seg + (unsigned)(t0 + min(jg + 4, n - 1)) * (2 * kAPart);
+          unsigned so1 = hand ? wq_seg2 + (unsigned)min((r2 & 1) ? 0 : 1, n2 - 1) * (2 * kAPart)
+                              : wq_seg + (unsigned)(t0 + min(jg + 5, n - 1)) * (2 * kAPart);
+          if (extra) {   // F0: the extra stage; F1: the next segment's stage 0 (no next segment: anything)
+            so0 = wq_seg + (unsigned)(t0 + n - 1) * (2 * kAPart);
+            so1 = hand ? wq_seg2 : so0;
+          }
           lead(0);
           multiply(buf, 2, F0);
           a_issue_at(so0, F0);
@@ -752,6 +793,20 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
           lead(1);
           multiply(buf, 3, F1);
           a_issue_at(so1, F1);
+          if constexpr (kStreamable) {
+            if (extra) {
+              __builtin_amdgcn_sched_barrier(0);
+              lead(0);
+              multiply(2, 0, F0);
+              a_issue_at(hand ? wq_seg2 + (unsigned)min(1, n2 - 1) * (2 * kAPart) : so0, F0);     // the next segment's stage 1
+              // the next segment's first stages sit in (F1, F0); an even first group expects (F0, F1)
+              if (hand && !(r2 & 1)) {
+                const AFrag T = F0;
+                F0 = F1;
+                F1 = T;
+              }
+            }
+          }
           if constexpr (MODE != 2)
             if (!chain && gi + 1 == n_groups && has_next)
               load_plane(c16 + 1, wave_s, ConsumerWaves{}, HalfRounds{}, plane_split, plane_items);
