@@ -488,3 +488,36 @@ def test_bench_world_size_mismatch_exits_nonzero():
                    {'RANK': '0', 'LOCAL_RANK': '0', 'WORLD_SIZE': '2', 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '29999'})
     assert r.returncode != 0
     assert b'WORLD_SIZE=2' in r.stderr and not any(l.startswith(b'{') for l in r.stdout.splitlines())
+
+
+def test_bench_rank0_block_never_steps_a_multi_rank_job_alone():
+    """bench.py prints from rank 0 and measures a few extra legs there; a training step of an N-rank job contains collectives, so
+    every `step()` (or `timed_window()`) call inside the `if rank == 0:` block must sit under a condition that says `world == 1`
+    (round 5: the exact-fp32 leg was added without it and would have hung the N-rank scaling run)."""
+    import os
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py')).read().splitlines()
+    start = next(i for i, l in enumerate(src) if l.startswith('    if rank == 0:'))
+    end = next(i for i in range(start + 1, len(src)) if src[i].strip() and len(src[i]) - len(src[i].lstrip()) <= 4)
+    calls = 0
+    for i in range(start + 1, end):
+        line = src[i]
+        code = line.split('#')[0]
+        if 'step()' not in code and 'timed_window()' not in code:
+            continue
+        if code.lstrip().startswith(('def ', "'", '"')):
+            continue
+        calls += 1
+        indent = len(line) - len(line.lstrip())
+        guarded, j = False, i - 1
+        while j > start:
+            l = src[j]
+            if l.strip():
+                ind = len(l) - len(l.lstrip())
+                if ind < indent:
+                    indent = ind
+                    if l.lstrip().startswith(('if ', 'elif ')) and 'world == 1' in l:
+                        guarded = True
+                        break
+            j -= 1
+        assert guarded, 'bench.py:%d calls a step inside the rank-0 block without a `world == 1` guard: %s' % (i + 1, line.strip())
+    assert calls >= 1
