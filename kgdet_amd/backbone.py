@@ -409,6 +409,24 @@ GEMM_1X1 = _os.environ.get('KGDET_INFER_GEMM_1X1', '1') == '1'     # 0: every in
 _gemm_choice = {}       # (Cin, Cout, B, H, W, residual?, relu) -> True: hipBLASLt GEMM, False: MIOpen convolution
 
 
+def _load_gemm_choices():
+    """KGDET_GEMM_CHOICES=<file.json>: the measured route choices are read from the file when it exists (so that a PROFILED process
+    takes the routes an un-profiled one measured -- a tracer's per-launch overhead shifts the timings the choice is made on) and
+    written to it at exit otherwise."""
+    path = _os.environ.get('KGDET_GEMM_CHOICES')
+    if not path:
+        return
+    import atexit, json
+    if _os.path.isfile(path):
+        for k, v in json.load(open(path)):
+            _gemm_choice[tuple(k)] = v
+    else:
+        atexit.register(lambda: json.dump([[list(k), v] for k, v in _gemm_choice.items()], open(path, 'w')))
+
+
+_load_gemm_choices()
+
+
 def fused_residual_ready(conv3, B, H, W):
     """True when conv3 + bn3 + add + ReLU of this shape runs on the fused kernel (measured choice): the caller may then hand it
     conv2's RAW output and bias (`_conv_bn(..., in_bias=...)`) instead of running conv2's epilogue pass"""
