@@ -90,7 +90,7 @@ def launch_ranks(args):
     import subprocess
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and os.environ.get('KGDET_BENCH_REHEARSAL') != '1':
         sys.exit('bench.py: --gpus %d requested but this node exposes %d GPU(s); refusing to print a %d-GPU line '
                  'from fewer devices' % (args.gpus, have, args.gpus))
     s = socket.socket()
@@ -578,12 +578,19 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert torch.cuda.is_available(), 'bench.py needs a GPU: the HIP path is the product, there is no fallback'
+    # KGDET_BENCH_REHEARSAL=1: a dry run of the N-rank FLOW on a box with fewer GPUs -- every rank on device 0, gloo instead of
+    # RCCL (two ranks cannot share a device under RCCL).  Exercises what a scaling run executes (rank start-up, broadcast, the
+    # reducer's collectives in the timed windows, the barriers, rank 0's extra legs) so that a hang shows up here; the line it
+    # prints says `rehearsal: true` and is NOT a measurement.
+    rehearsal = os.environ.get('KGDET_BENCH_REHEARSAL') == '1'
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist_on = world > 1 or args.force_dist      # the N-rank code path (forced: a one-rank RCCL group)
     if dist_on:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl')
+        dist.init_process_group(backend='gloo' if rehearsal else 'nccl')
 
     import kgdet_amd
     from kgdet_amd import configs, synthetic
@@ -784,6 +791,7 @@ def main():
     if rank == 0:
         imgs = args.imgs_per_gpu * world * args.steps
         out = {
+            **({'rehearsal': True} if os.environ.get('KGDET_BENCH_REHEARSAL') == '1' else {}),
             'metric': ('training images/sec (whole node) %s R50-FPN 800x1333' if args.mode == 'train'
                        else 'inference images/sec %s R50-FPN 800x1333') % (
                            'KGDet' if args.config == 'kgdet' else 'RepPoints-kp serial (config 5)'),

@@ -277,3 +277,28 @@ def test_bench_force_dist_runs_the_n_rank_path_on_one_gpu():
     ar = d['allreduce']
     assert ar['payload_MB'] > 200 and ar['ms'] > 0 and 'exposed_ms' in ar
     assert ar['buckets'] >= 6 and ar['buckets_issued_inside_backward_per_step'] >= ar['buckets'] - 1
+
+
+@pytest.mark.parametrize('mode', ['train', 'infer'])
+def test_bench_two_rank_rehearsal_completes(mode):
+    """`KGDET_BENCH_REHEARSAL=1 python bench.py --gpus 2`: the whole TWO-rank flow of the bench -- rank start-up, weight broadcast,
+    the reducer's bucket exchanges and its late-joiner bit inside the timed windows, the exposed-time windows, the barriers, the
+    legs rank 0 runs alone -- on ONE device over gloo (RCCL refuses two ranks on a device).  Not a measurement (`rehearsal: true`
+    on the line): it is what catches a leg that steps a multi-rank job from rank 0 alone (a hang, here a timeout)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MIOPEN_USER_DB_PATH')}
+    env['KGDET_BENCH_REHEARSAL'] = '1'
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2', '--windows', '2',
+           '--preheat-s', '0', '--no-roofline', '--no-cpu-baseline']
+    if mode == 'infer':
+        cmd += ['--mode', 'infer', '--dtype', 'bf16', '--imgs-per-gpu', '2']
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    d = json.loads([l for l in res.stdout.decode().splitlines() if l.startswith('{')][-1])
+    assert d['rehearsal'] is True and d['n_gpus'] == 2 and d['value'] > 0 and d['config']['parallelism'] == 'dp2'
+    if mode == 'train':
+        assert d['allreduce']['buckets'] >= 6 and 'exact_fp32' not in d and 'graphed_step' not in d and 'inference' not in d
