@@ -268,6 +268,50 @@ bool plane_bwd_offset_ok(const kgdet_dcn_shape *s, const Derived &d, bool masked
          slab_slots_ok((long long)s->N * ceil_div(d.Ho * d.Wo, kTileN), d.K * (ceil_div(cpdg, kChunk)));
 }
 size_t grad_tap_bytes(const kgdet_dcn_shape *s, const Derived &d) { return (size_t)s->N * s->deformable_groups * d.K * d.Ho * d.Wo * 64; }   // (v2 records: 64 B; one table per deformable group)
+// grad_offset on tap pairs (dcn_backward_offset_pair.hip): v1, split operands, one static range per workgroup, K >= 5 (a tap's
+// running sum is re-read one segment later, two slots ahead of its use: with fewer than three pairs per segment that would be the
+// slot it is written in)
+bool offset_pair_ok(const DcnFwdGroup &grp) {
+  static const bool off = getenv("KGDET_DCN_OFFSET_PAIR") && atoi(getenv("KGDET_DCN_OFFSET_PAIR")) == 0;   // A/B switch
+  if (off || !grp.static_ranges || grp.rounds != 1) return false;
+  for (int i = 0; i < grp.n; ++i) {
+    const DcnProblem &q = grp.p[i];
+    if (q.mask || q.K < 5 || q.Og > 256 || q.Og % 32 != 0 || q.H * q.W > kPlaneMaxHW) return false;   // (Og % 32: a DMA piece = two 16-o chunks)
+  }
+  return true;
+}
+// Blocked copies of the distinct inputs of a grad_offset group behind its record tables (written by dcn_build_grad_taps), where
+// the workspace has room for them; without one a problem's plane switches copy through registers.
+void place_offset_xblk(DcnFwdGroup &grp, unsigned char *table_base, size_t used, size_t table_cap) {
+  static const bool off = getenv("KGDET_DCN_OFFSET_XBLK") && atoi(getenv("KGDET_DCN_OFFSET_XBLK")) == 0;   // A/B switch
+  used = align_up(used, 256);
+  for (int i = 0; i < grp.n; ++i) {
+    DcnProblem &q = grp.p[i];
+    q.xblk = nullptr; q.build_xblk = 0;
+    if (off) continue;
+    for (int j = 0; j < i && !q.xblk; ++j) {
+      const DcnProblem &o = grp.p[j];
+      if (o.xblk && o.x == q.x && o.c_base == q.c_base && o.Cg == q.Cg && o.N == q.N && o.H == q.H && o.W == q.W && o.C_total == q.C_total)
+        q.xblk = o.xblk;
+    }
+    if (q.xblk) continue;
+    const size_t xb = align_up(dcn_xblk_bytes(q.N, q.Cg_pad, q.H * q.W), 256);
+    if (used + xb > table_cap) continue;
+    q.xblk = reinterpret_cast<const float *>(table_base + used);
+    q.build_xblk = 1;
+    used += xb;
+  }
+}
+int launch_offset_pair(const DcnFwdGroup &grp, int G, void *workspace, int max_K, void *stream) {
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_bwd_offset_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(dcn_bwd_offset_pair, dim3(G), dim3(dcn_bwd_offset_pair_threads()), dcn_bwd_offset_pair_lds_bytes(),
+                     (hipStream_t)stream, grp, (float *)workspace, max_K);
+  return KGDET_OK;
+}
 struct InvTables {
   size_t rec_bytes, hdr_bytes, cell_bytes, spill_bytes;
   size_t total() const { return rec_bytes + hdr_bytes + cell_bytes + spill_bytes; }
@@ -341,15 +385,15 @@ size_t kgdet_dcn_workspace_bytes(const kgdet_dcn_shape *s) {
   const size_t after_slabs = (size_t)s->groups * d.fwd_image_floats() * sizeof(float);
   // (forward: the tap records and, for the column-wave kernel, the blocked copy of the input behind them)
   const size_t fwd_tables = tap_table_bytes(s, d) +
-                            (plane_ok(s, d) ? 512 + s->groups * align_up(dcn_fwd_cw_xblk_bytes(s->N, d.Cg_pad, s->H * s->W), 256) : 0);
+                            (plane_ok(s, d) ? 512 + s->groups * align_up(dcn_xblk_bytes(s->N, d.Cg_pad, s->H * s->W), 256) : 0);
   const size_t fwd_and_wgrad = slab_bytes() + (after_slabs > fwd_tables ? after_slabs : fwd_tables);
   const BwdLdsPlan pl = plan_bwd_lds(s, d);
   const size_t bwd_in = pl.ok ? (pl.slab_floats + pl.off_floats + pl.mask_floats) * sizeof(float) +
                                     pl.rowptr_ints * sizeof(int) + pl.entry_pairs * 8 + 64
                               : 0;
   size_t bwd_in_plane = plane_bwd_input_ok(s, d) ? slab_bytes() + inv_tables_all(s, d) + inv_sums_all(s, d) : 0;
-  if (plane_bwd_offset_ok(s, d) && slab_bytes() + grad_tap_bytes(s, d) > bwd_in_plane)
-    bwd_in_plane = slab_bytes() + grad_tap_bytes(s, d);
+  const size_t off_tabs = align_up(grad_tap_bytes(s, d), 256) + s->deformable_groups * align_up(dcn_xblk_bytes(s->N, d.Cg_pad, s->H * s->W), 256);
+  if (plane_bwd_offset_ok(s, d) && slab_bytes() + off_tabs > bwd_in_plane) bwd_in_plane = slab_bytes() + off_tabs;
   size_t need = fwd_and_wgrad > bwd_in ? fwd_and_wgrad : bwd_in;
   need = need > bwd_in_plane ? need : bwd_in_plane;
   if (plane_ok(s, d)) {   // grad_weight on the plane kernel: records + one grad_out image per weight group
@@ -376,20 +420,23 @@ size_t kgdet_dcn_workspace_bytes(const kgdet_dcn_shape *s) {
 }
 
 size_t kgdet_dcn_group_workspace_bytes(int32_t n, const kgdet_dcn_shape *const *shapes) {
-  size_t tables = 0, bwd_tables = 0, wgrad_tables = 0, single = 0;
+  size_t tables = 0, bwd_tables = 0, wgrad_tables = 0, off_tables = 0, single = 0;
   for (int i = 0; i < n; ++i) {
     Derived d;
     if (!shapes || derive(shapes[i], d)) return 0;
     tables += tap_table_bytes(shapes[i], d);
     if (plane_ok(shapes[i], d))   // (column-wave forward: a blocked copy of the input behind the tap records)
-      tables += 512 + shapes[i]->groups * align_up(dcn_fwd_cw_xblk_bytes(shapes[i]->N, d.Cg_pad, shapes[i]->H * shapes[i]->W), 256);
+      tables += 512 + shapes[i]->groups * align_up(dcn_xblk_bytes(shapes[i]->N, d.Cg_pad, shapes[i]->H * shapes[i]->W), 256);
     if (plane_bwd_input_ok(shapes[i], d)) bwd_tables += inv_tables_all(shapes[i], d) + inv_sums_all(shapes[i], d);
+    if (plane_bwd_offset_ok(shapes[i], d))   // (grad_offset phase: records + the blocked copy of the input of the tap-pair kernel)
+      off_tables += align_up(grad_tap_bytes(shapes[i], d), 256) + align_up(dcn_xblk_bytes(shapes[i]->N, d.Cg_pad, shapes[i]->H * shapes[i]->W), 256) + 256;
     wgrad_tables += align_up(tap_table_bytes(shapes[i], d), 256) +
                     (size_t)shapes[i]->groups * (d.Og_pad / kTileM) * shapes[i]->N * ceil_div(d.Ho * d.Wo, kChunk) * 16384;
     const size_t w = kgdet_dcn_workspace_bytes(shapes[i]);
     single = w > single ? w : single;
   }
   if (wgrad_tables > bwd_tables) bwd_tables = wgrad_tables;
+  if (off_tables > bwd_tables) bwd_tables = off_tables;
   const size_t grouped = slab_bytes() + (tables > bwd_tables ? tables : bwd_tables);
   return grouped > single ? grouped : single;
 }
@@ -589,7 +636,7 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
             q.xblk = o.xblk;
         }
         if (!q.xblk) {
-          const size_t xb = align_up(dcn_fwd_cw_xblk_bytes(q.N, q.Cg_pad, q.H * q.W), 256);
+          const size_t xb = align_up(dcn_xblk_bytes(q.N, q.Cg_pad, q.H * q.W), 256);
           if (slab_bytes() + used + xb > workspace_bytes) {
             set_error("workspace too small for the blocked inputs: need %zu bytes, got %zu (kgdet_dcn_group_workspace_bytes)",
                       slab_bytes() + used + xb, workspace_bytes);
@@ -983,6 +1030,9 @@ static int grad_offset_plane(const kgdet_dcn_shape *s, const float *input, const
     set_error("grad_offset plane kernel (v2): more (part, tile) ranges than workgroups");
     return KGDET_E_UNSUPPORTED;
   }
+  const bool use_pair = parts == 2 && !mask && offset_pair_ok(grp);
+  if (use_pair)
+    place_offset_xblk(grp, (unsigned char *)workspace + slab_bytes(), grad_tap_bytes(s, d), workspace_bytes - slab_bytes());
   hipLaunchKernelGGL(dcn_build_grad_taps, dim3(2 * G, grp.n), dim3(256), 0, (hipStream_t)stream, grp);
   const size_t lds = dcn_bwd_offset_plane_lds_bytes(parts, d.K, s->H * s->W, mask != nullptr);
   const int threads = dcn_bwd_offset_plane_threads();
@@ -997,7 +1047,9 @@ static int grad_offset_plane(const kgdet_dcn_shape *s, const float *input, const
   if (parts == 1)
     hipLaunchKernelGGL(dcn_bwd_offset_plane<1>, dim3(Gs), dim3(threads), lds, (hipStream_t)stream, grp,
                        (float *)workspace, d.K);
-  else
+  else if (use_pair) {
+    if (int rc = launch_offset_pair(grp, Gs, workspace, d.K, stream)) return rc;
+  } else
     hipLaunchKernelGGL(dcn_bwd_offset_plane<2>, dim3(Gs), dim3(threads), lds, (hipStream_t)stream, grp,
                        (float *)workspace, d.K);
   hipLaunchKernelGGL(dcn_bwd_offset_plane_fixup, dim3(grp.tile_begin[grp.n], 8), dim3(256), 0, (hipStream_t)stream, grp,
@@ -1205,9 +1257,14 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
   if (lds > kMaxLds || !check_slots(grp)) { set_error("group does not fit the grad_offset kernel"); return KGDET_E_UNSUPPORTED; }
   const int Go = small_launch_grid(grp, G);
   plan_static_ranges(grp, Go);
+  const bool use_pair = offset_pair_ok(grp);
+  if (use_pair) place_offset_xblk(grp, tab, rec_total, workspace_bytes - slab_bytes());
   hipLaunchKernelGGL(dcn_build_grad_taps, dim3(2 * G, grp.n), dim3(256), 0, (hipStream_t)stream, grp);
-  hipLaunchKernelGGL(dcn_bwd_offset_plane<2>, dim3(Go), dim3(dcn_bwd_offset_plane_threads()), lds, (hipStream_t)stream, grp,
-                     (float *)workspace, max_K);
+  if (use_pair) {
+    if (int rc = launch_offset_pair(grp, Go, workspace, max_K, stream)) return rc;
+  } else
+    hipLaunchKernelGGL(dcn_bwd_offset_plane<2>, dim3(Go), dim3(dcn_bwd_offset_plane_threads()), lds, (hipStream_t)stream, grp,
+                       (float *)workspace, max_K);
   hipLaunchKernelGGL(dcn_bwd_offset_plane_fixup, dim3(grp.tile_begin[grp.n], 8), dim3(256), 0, (hipStream_t)stream, grp,
                      (const float *)workspace, Go, max_K);
   KGDET_CHECK_LAUNCH("dcn_bwd_plane_grouped");

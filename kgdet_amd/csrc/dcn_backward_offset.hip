@@ -36,6 +36,8 @@ typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
 // weights -- d out / d mask is the sampled value itself (deform_conv_cuda_kernel.cu:636-766) -- 64 bytes per record.
 __global__ __launch_bounds__(256) void dcn_build_grad_taps(const DcnFwdGroup grp) {
   const DcnProblem &p = grp.p[blockIdx.y];
+  // (tap-pair kernel: the blocked copy of x its plane switches read by LDS-DMA, as dcn_build_taps does for the forward)
+  if (p.build_xblk) dcn_block_x_body(p, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), (int)gridDim.x * 4);
   if (!p.build_taps) return;
   const long long n_rec = (long long)p.N * p.K * p.HoWo;
   uint4 *out = reinterpret_cast<uint4 *>(const_cast<DcnTapRec *>(p.taps));

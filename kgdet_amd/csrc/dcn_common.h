@@ -270,6 +270,9 @@ struct DcnFwdGroup {
 // [image][chunk c][quad][pixels padded to 64][4 channels] fp32 -- exactly the LDS plane's units, each 1 KiB contiguous.  Channels
 // past Cg repeat the last one, pixels past H*W the last pixel (as dcn_plane_copy does).  One wave per unit; called from
 // dcn_build_taps' blocks.
+__host__ __device__ __forceinline__ size_t dcn_xblk_bytes(int N, int Cg_pad, int HW) {
+  return (size_t)N * (Cg_pad / kChunk) * 4 * (((HW + 63) >> 6) * 64) * 16;
+}
 __device__ __forceinline__ void dcn_block_x_body(const DcnProblem &p, int first_unit, int unit_step) {
   const int HW = p.H * p.W, nblk = (HW + 63) >> 6, P64 = nblk * 64, n_c16 = p.chunks_per_tap;
   const int lane = threadIdx.x & 63;

@@ -410,7 +410,6 @@ __global__ __launch_bounds__(kCwThreads, 1) void dcn_fwd_cw(const DcnFwdGroup gr
 
 template __global__ void dcn_fwd_cw<2>(const DcnFwdGroup grp, float *__restrict__ slabs);
 
-size_t dcn_fwd_cw_xblk_bytes(int N, int Cg_pad, int HW) { return (size_t)N * (Cg_pad / kChunk) * 4 * (((HW + 63) >> 6) * 64) * 16; }
 
 #ifdef KGDET_CW_TRACE
 }  // namespace kgdet

@@ -23,7 +23,6 @@ template <int PARTS>
 __global__ void dcn_fwd_cw(const DcnFwdGroup grp, float *__restrict__ slabs);
 int dcn_fwd_cw_threads();
 size_t dcn_fwd_cw_lds_bytes(int parts);
-size_t dcn_fwd_cw_xblk_bytes(int N, int Cg_pad, int HW);
 // large-map v1 backward without atomics (dcn_backward_large.hip)
 bool dcn_bwd_large_ok(const DcnProblem &p, bool has_mask, int groups);
 size_t dcn_bwd_large_workspace_bytes(const DcnProblem &p);
@@ -97,6 +96,10 @@ size_t dcn_bwd_offset_plane_lds_bytes(int parts, int K, int HW, int masked = 0);
 __global__ void dcn_bwd_offset_plane_masked(const DcnFwdGroup grp, float *__restrict__ slabs, int max_K);
 __global__ void dcn_bwd_offset_plane_fixup_masked(const DcnFwdGroup grp, const float *__restrict__ slabs, int G, int max_K);
 int dcn_bwd_offset_plane_threads();
+// round 6: tap pairs on 32x32 MFMA blocks, two alternating wave halves, W^T by LDS-DMA (dcn_backward_offset_pair.hip)
+__global__ void dcn_bwd_offset_pair(const DcnFwdGroup grp, float *__restrict__ slabs, int max_K);
+size_t dcn_bwd_offset_pair_lds_bytes();
+int dcn_bwd_offset_pair_threads();
 // grad_weight on an LDS-resident plane (dcn_backward_weight_plane.hip)
 template <int PARTS>
 __global__ void dcn_bwd_weight_plane(const DcnFwdGroup grp, float *__restrict__ slabs);
