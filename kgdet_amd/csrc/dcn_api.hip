@@ -268,15 +268,15 @@ bool plane_bwd_offset_ok(const kgdet_dcn_shape *s, const Derived &d, bool masked
          slab_slots_ok((long long)s->N * ceil_div(d.Ho * d.Wo, kTileN), d.K * (ceil_div(cpdg, kChunk)));
 }
 size_t grad_tap_bytes(const kgdet_dcn_shape *s, const Derived &d) { return (size_t)s->N * s->deformable_groups * d.K * d.Ho * d.Wo * 64; }   // (v2 records: 64 B; one table per deformable group)
-// grad_offset on tap pairs (dcn_backward_offset_pair.hip): v1, split operands, one static range per workgroup, K >= 5 (a tap's
-// running sum is re-read one segment later, two slots ahead of its use: with fewer than three pairs per segment that would be the
-// slot it is written in)
+// grad_offset on tap pairs (dcn_backward_offset_pair.hip): v1, split operands, one static range per workgroup, K >= 3 (a tap's
+// running sum is re-read one segment later, one slot ahead of its use: with a single pair per segment that would be the slot it is
+// written in)
 bool offset_pair_ok(const DcnFwdGroup &grp) {
   static const bool off = getenv("KGDET_DCN_OFFSET_PAIR") && atoi(getenv("KGDET_DCN_OFFSET_PAIR")) == 0;   // A/B switch
   if (off || !grp.static_ranges || grp.rounds != 1) return false;
   for (int i = 0; i < grp.n; ++i) {
     const DcnProblem &q = grp.p[i];
-    if (q.mask || q.K < 5 || q.Og > 256 || q.Og % 32 != 0 || q.H * q.W > kPlaneMaxHW) return false;   // (Og % 32: a DMA piece = two 16-o chunks)
+    if (q.mask || q.K < 3 || q.Og > 256 || q.Og % 32 != 0 || q.H * q.W > kPlaneMaxHW) return false;   // (Og % 32: a DMA piece = two 16-o chunks)
   }
   return true;
 }

@@ -22,16 +22,22 @@
 //     SIMD, one workgroup barrier per PAIR of stages;
 //   * W^T pairs (2 taps x (hi, lo) x 8 KB) arrive by LDS-DMA (buffer_load ... lds, no registers, no ds_write, no
 //     producer waves: all eight waves have 256 registers) one slot ahead, into the buffer the other half read in
-//     the slot before;
+//     the slot before.  A 1 KiB piece costs its wave 100-185 cycles of issue in this loop (phase trace, tools/pair_trace.py);
+//     the tail half issues five of a wave's eight behind its dot products, the matrix half three between its MFMAs;
 //   * the accumulator layout gives a lane two channel quads of each tap for one pixel; after the dot products the two
 //     lane halves are combined with ONE v_permlane32_swap (lower lanes end up with d/dy, upper lanes with d/dx);
 //   * a tap occurs once per segment (chunk-major / tap-minor order), so its running sum needs no fast accumulator:
 //     it lives in the range's slab (or in grad_offset itself when the range is the whole reduction) and is
 //     read-modify-written with one coalesced load / store per pair and lane -- no LDS accumulators, any K.
 // LDS: x plane [4 quads][1344 px][4 ch] fp32 at address 0 (86 016 B, tap-record offsets are absolute addresses and the
-// quad is an immediate) | two pair buffers of 32 KB.
-// Static (problem, part, tile) ranges only, one range per workgroup; v1, split operands; everything else stays on
-// dcn_bwd_offset_plane.  Deterministic (fixed summation orders, no atomics).
+// quad is an immediate) | two pair buffers of 32 KB.  The plane of the next chunk arrives by LDS-DMA from a blocked copy of x
+// (dcn_build_grad_taps) where the workspace has room for one: 2.7 k instead of 8.4 k cycles per switch.
+// Static (problem, part, tile) ranges only, one range per workgroup; v1, split operands, K >= 3, Og % 32 == 0; everything else
+// stays on dcn_bwd_offset_plane.  Deterministic (fixed summation orders, no atomics).
+// Measured (one head stage at B = 2, kernel average of 30 under rocprofv3): 169-173 us against 254 for dcn_bwd_offset_plane<2>.
+// What bounds it now: matrix phase + tail phase of a SIMD's two waves stay ~5.2 k cycles per pair of slots whatever is moved
+// between them -- beside the wave whose next MFMA waits for the matrix pipe the other wave's vector instructions are not free
+// (tools/experiments/README.md, round 6; a single-stream variant with one wave per SIMD is kept there).
 #include "dcn_plane.h"
 
 namespace kgdet {
@@ -47,6 +53,9 @@ constexpr int kPairKs = 16;                             // k-steps of 16 output 
 #endif
 #ifndef KGDET_PAIR_DMA_POS
 #define KGDET_PAIR_DMA_POS 1                            // where the tail half issues its DMA pieces: 0 behind the corner reads, 1 behind the dot products
+#endif
+#ifndef KGDET_PAIR_M_PIECES
+#define KGDET_PAIR_M_PIECES 3                           // DMA pieces (of a wave's eight) the MATRIX half issues between its MFMAs; the tail half issues the rest
 #endif
 #ifndef KGDET_PAIR_PACE
 #define KGDET_PAIR_PACE 0                               // > 0: s_nop (PACE - 1) behind every MFMA (leaves the SIMD's issue port to the tail wave)
@@ -256,12 +265,10 @@ __global__ __launch_bounds__(kPairThreads, 1) void dcn_bwd_offset_pair(const Dcn
     RB.off = dcn_buf_b128(rec_rs, rec_lane, soB);
     RB.wy = __builtin_bit_cast(f32x4, dcn_buf_b128(rec_rs, rec_lane + 16, soB));
     RB.wx = __builtin_bit_cast(f32x4, dcn_buf_b128(rec_rs, rec_lane + 32, soB));
-    // the taps' running sums: written one segment ago = np - 1 >= 2 slots before the slot this runs in (K >= 5); first segment: not used
+    // the taps' running sums: written one segment ago = np >= 2 slots before the slot this runs in (K >= 3); first segment: not used
     RA.prev = dcn_buf_f32(acc_rs, acc_voff, (unsigned)tA * acc_tstride);
     RB.prev = dcn_buf_f32(acc_rs, acc_voff, (unsigned)tB * acc_tstride);
   };
-  constexpr int kRecordLoads = 8;       // vector memory instructions of load_records
-  load_records(half);                   // (pair `half` of the range: np >= 3, so it lies in segment 0)
 
   // pair q = (segment seg, pair j inside it); slot q: half (q & 1) multiplies pair q, the other half finishes pair q - 1
   int seg = 0, j = 0;          // pair of this slot
@@ -276,7 +283,10 @@ __global__ __launch_bounds__(kPairThreads, 1) void dcn_bwd_offset_pair(const Dcn
     const bool matrix_half = ((q ^ half) & 1) == 0;
     if (matrix_half) {
       if (q < Q) {
-        // ---- matrix phase: 48 MFMAs on the pair buffer of this half
+        // ---- matrix phase: the pair's records and running sums requested (used one slot later), then 48 MFMAs on the pair
+        // buffer of this half
+        load_records(j);
+        __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise sinks these loads below the MFMAs, right in front of the slot's vmcnt(0))
 #ifndef KGDET_PAIR_ABL_NOMFMA
         __builtin_amdgcn_s_setprio(KGDET_PAIR_MATRIX_PRIO);
         // W^T fragments kDepth k-steps ahead of the MFMAs that use them (the fragment ring shares its registers with the tail's
@@ -295,6 +305,10 @@ __global__ __launch_bounds__(kPairThreads, 1) void dcn_bwd_offset_pair(const Dcn
           if (ks + kDepth < kPairKs) {
             fa[(ks + kDepth) % (kDepth + 1)][0] = lds_frag(a_lane + (ks + kDepth) * 512);
             fa[(ks + kDepth) % (kDepth + 1)][1] = lds_frag(a_lane + kAPart + (ks + kDepth) * 512);
+          }
+          if constexpr (KGDET_PAIR_M_PIECES > 0) {
+            constexpr int kEvery = 12 / (KGDET_PAIR_M_PIECES > 0 ? KGDET_PAIR_M_PIECES : 1);
+            if (ks % kEvery == kEvery - 1 && ks / kEvery < KGDET_PAIR_M_PIECES) dma_piece(8 - KGDET_PAIR_M_PIECES + ks / kEvery);
           }
           const bf16x8p ah = fa[ks % (kDepth + 1)][0], al = fa[ks % (kDepth + 1)][1];
           if (ks == 0) {   // (the chains start from the inline constant 0: no 32 v_mov per pair)
@@ -329,7 +343,7 @@ __global__ __launch_bounds__(kPairThreads, 1) void dcn_bwd_offset_pair(const Dcn
       KGDET_PT_ADD(2);
     } else if (q == 0) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) dma_piece(i);
+      for (int i = 0; i < 8 - KGDET_PAIR_M_PIECES; ++i) dma_piece(i);
     } else {
       // ---- tail of pair q - 1: the lane holds colgrad of channel quads hh and 2 + hh of both taps for its pixel
       const bool first = pseg == 0;
@@ -354,7 +368,7 @@ __global__ __launch_bounds__(kPairThreads, 1) void dcn_bwd_offset_pair(const Dcn
         __builtin_amdgcn_sched_barrier(0);
 #if KGDET_PAIR_DMA_POS == 0
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma_piece(piece + i);
+        for (int i = 0; i < 4; ++i) if (piece + i < 8 - KGDET_PAIR_M_PIECES) dma_piece(piece + i);
         __builtin_amdgcn_sched_barrier(0);
 #endif
         float gy = 0.f, gx = 0.f;
@@ -370,7 +384,7 @@ __global__ __launch_bounds__(kPairThreads, 1) void dcn_bwd_offset_pair(const Dcn
 #if KGDET_PAIR_DMA_POS == 1     // behind the dot products: the LDS queue is empty here
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma_piece(piece + i);
+        for (int i = 0; i < 4; ++i) if (piece + i < 8 - KGDET_PAIR_M_PIECES) dma_piece(piece + i);
         __builtin_amdgcn_sched_barrier(0);
 #endif
         // lower lanes (channel quads 0, 2) + upper lanes (quads 1, 3): one v_permlane32_swap; lower lanes keep d/dy, upper d/dx
@@ -385,25 +399,18 @@ __global__ __launch_bounds__(kPairThreads, 1) void dcn_bwd_offset_pair(const Dcn
       if (hasB) tail(RB, cg + 8, tA + 1, 4);
       else {
 #pragma unroll
-        for (int i = 4; i < 8; ++i) dma_piece(i);
+        for (int i = 4; i < 8 - KGDET_PAIR_M_PIECES; ++i) dma_piece(i);
       }
 #else
 #pragma unroll
-      for (int i = 0; i < 8; ++i) dma_piece(i);
+      for (int i = 0; i < 8 - KGDET_PAIR_M_PIECES; ++i) dma_piece(i);
       if (cg[0] == 1234.5f) tail(RA, cg, tA, 0);
 #endif
-      // records of this wave's next pair, q + 1 (pair q of the other half lies between): in flight across the barrier
-      __builtin_amdgcn_sched_barrier(0);
-      load_records(q + 1 < Q ? nj : pj);
-      __builtin_amdgcn_sched_barrier(0);
     }
     KGDET_PT_ADD(3);         // (the matrix half arrives here with a fresh time stamp: nothing is added for it)
-    // the tail half's DMA pieces have landed and its stores are out before the barrier publishes them (vector memory operations
-    // retire in order: only the record loads issued behind them may still be in flight)
-    if (!matrix_half) {
-      if (q == 0) dcn_wait_vm0();
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRecordLoads) : "memory");
-    }
+    // the tail half's DMA pieces have landed and its stores are out before the barrier publishes them (the matrix half's record
+    // loads were requested a whole matrix phase ago)
+    dcn_wait_vm0();
     KGDET_PT_ADD(4);
     __syncthreads();
     KGDET_PT_ADD(5);
