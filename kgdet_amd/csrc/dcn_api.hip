@@ -882,6 +882,7 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
     sg.n = 0;
     for (int dgi = 0; dgi < s->deformable_groups; ++dgi) {
       if (sg.n == kMaxFwdGroup) {
+        sg.sched.on = 0;
         hipLaunchKernelGGL(dcn_inv_overflow_sums, dim3(s->N * d.K, kInvSumSplit, sg.n), dim3(256), 0, (hipStream_t)stream, sg);
         sg.n = 0;
       }
@@ -891,6 +892,7 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
                                (float *)(sums_base + (size_t)dgi * inv_gov_bytes(s, d)), s->N * d.K, d.K, d.Ho * d.Wo, s->O,
                                d.Og, d.Og_pad16, gov_ld, gov_slots, s->W};
     }
+    sg.sched.on = 0;
     hipLaunchKernelGGL(dcn_inv_overflow_sums, dim3(s->N * d.K, kInvSumSplit, sg.n), dim3(256), 0, (hipStream_t)stream, sg);
   }
   const int G = grid_size();
@@ -1198,19 +1200,59 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
   if (!check_slots(grp)) { set_error("group too uneven for the slab slots"); return KGDET_E_UNSUPPORTED; }
   const int only_phase = g_options[KGDET_OPT_BWD_PHASE];   // (measurement switch: 1 = grad_input only, 2 = grad_offset only)
   if (only_phase != 2) {
-  if (builds.n > 0) {
+  {
+    static const bool fused_off = getenv("KGDET_DCN_BWD_PREPARE") && atoi(getenv("KGDET_DCN_BWD_PREPARE")) == 0;   // A/B switch
     static thread_local bool multi_attr_set = false;
     if (!multi_attr_set) {
       KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_build_inverse_taps_multi, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)kMaxLds - 64));
+      KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_bwd_input_prepare, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)kMaxLds - 64 - 2 * 32 * 33 * 4 - 64));
       multi_attr_set = true;
     }
-    hipLaunchKernelGGL(dcn_build_inverse_taps_multi, dim3(build_blocks, builds.n), dim3(256), build_lds, (hipStream_t)stream,
-                       builds);
+    const int pm_bx = ceil_div(pm_px, 32), pm_by = ceil_div(pm_c, 32);
+    if (!fused_off && build_lds + 2 * 32 * 33 * 4 + 128 <= kMaxLds - 64) {
+      const int pm_blocks = ceil_div(pm_bx * pm_by * pm_images, 2);
+      hipLaunchKernelGGL(dcn_bwd_input_prepare, dim3(build_blocks * builds.n + pm_blocks), dim3(512), build_lds, (hipStream_t)stream,
+                         builds, pmg, build_blocks, pm_bx, pm_by);
+    } else {
+      if (builds.n > 0)
+        hipLaunchKernelGGL(dcn_build_inverse_taps_multi, dim3(build_blocks, builds.n), dim3(256), build_lds, (hipStream_t)stream,
+                           builds);
+      hipLaunchKernelGGL(dcn_gout_pixel_major_multi, dim3(pm_bx, pm_by, pm_images), dim3(256), 0, (hipStream_t)stream, pmg);
+    }
   }
-  hipLaunchKernelGGL(dcn_gout_pixel_major_multi, dim3(ceil_div(pm_px, 32), ceil_div(pm_c, 32), pm_images), dim3(256), 0,
-                     (hipStream_t)stream, pmg);
-  hipLaunchKernelGGL(dcn_inv_overflow_sums, dim3(sums_blocks, kInvSumSplit, sums.n), dim3(256), 0, (hipStream_t)stream, sums);
+  {   // (problem, image) groups onto XCDs, largest first onto the least loaded one (DcnInvSumSched)
+    static const bool xcd_off = getenv("KGDET_DCN_SUMS_XCD") && atoi(getenv("KGDET_DCN_SUMS_XCD")) == 0;   // A/B switch
+    DcnInvSumSched &sc = sums.sched;
+    sc.on = 0;
+    int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int x = 0; x < 8; ++x) sc.n_seg[x] = 0;
+    struct G_ { int z, b, units; } gs[kMaxFwdGroup * 64];
+    int ng = 0;
+    bool fits = !xcd_off;
+    for (int z = 0; z < sums.n && fits; ++z)
+      for (int b = 0; b < shapes[z]->N && fits; ++b) {
+        if (ng >= kMaxFwdGroup * 64) { fits = false; break; }
+        gs[ng++] = G_{z, b, sums.e[z].K * kInvSumSplit};
+      }
+    std::stable_sort(gs, gs + ng, [](const G_ &a, const G_ &b) { return a.units > b.units; });
+    for (int i = 0; i < ng && fits; ++i) {
+      int x = 0;
+      for (int y = 1; y < 8; ++y) if (load[y] < load[x]) x = y;
+      if (sc.n_seg[x] >= kInvSumSegs) { fits = false; break; }
+      sc.seg[x][sc.n_seg[x]++] = DcnInvSumSeg{gs[i].z, gs[i].b, load[x], gs[i].units};
+      load[x] += gs[i].units;
+    }
+    if (fits) {
+      sc.on = 1;
+      int longest = 0;
+      for (int x = 0; x < 8; ++x) longest = load[x] > longest ? load[x] : longest;
+      hipLaunchKernelGGL(dcn_inv_overflow_sums, dim3(8 * longest), dim3(256), 0, (hipStream_t)stream, sums);
+    } else {
+      hipLaunchKernelGGL(dcn_inv_overflow_sums, dim3(sums_blocks, kInvSumSplit, sums.n), dim3(256), 0, (hipStream_t)stream, sums);
+    }
+  }
   lds = plan_plane_lds(grp, lds, dcn_bwd_input_plane_fixed_lds_bytes(2));
   grp.wave_layout = dcn_plane_wave_layout();   // plane_role's accumulator layout (slabs are decoded by dcn_fwd_fixup)
   const int Gs = small_launch_grid(grp, G);

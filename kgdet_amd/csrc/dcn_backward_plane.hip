@@ -49,6 +49,7 @@ size_t dcn_bwd_input_plane_lds_bytes(int parts, int plane_pixels) {
 // insertion-sorted every list -- quadratic in a cell's length -- and the builder of a head stage went from 37 to 118 us
 // while the training step's offsets concentrated).
 // ------------------------------------------------------------------------------------------------
+template <int THREADS>
 __device__ __forceinline__ void build_inverse_taps_body(const DcnProblem &p, uint4 *__restrict__ inv, int *__restrict__ hdr,
                                                         DcnInvOvfCell *__restrict__ cells, int2 *__restrict__ spill,
                                                         int block, int *sm) {
@@ -56,16 +57,16 @@ __device__ __forceinline__ void build_inverse_taps_body(const DcnProblem &p, uin
   int *cnt = sm;                                          // [HW + 1]
   int *cursor = sm + (HW + 1);                            // [HW]
   int2 *ent = reinterpret_cast<int2 *>(sm + 2 * HW + 2);  // [4 * HoWo]
-  __shared__ int wave_tot[4];
+  __shared__ int wave_tot[THREADS / 64];
 
   const int t = block % p.K, b = block / p.K;
   const int tid = threadIdx.x;
   const int max_slots = dcn_inv_max_slots(HW, p.HoWo);
 
-  for (int i = tid; i <= HW; i += 256) cnt[i] = 0;
+  for (int i = tid; i <= HW; i += THREADS) cnt[i] = 0;
   __syncthreads();
   // pass 1: count the corners landing in each cell
-  for (int px = tid; px < p.HoWo; px += 256) {
+  for (int px = tid; px < p.HoWo; px += THREADS) {
     const int oy = px / p.Wo, ox = px - oy * p.Wo;
     float y, x, m;
     tap_position(p, b, p.dgi, t, px, oy, ox, y, x, m);
@@ -80,7 +81,7 @@ __device__ __forceinline__ void build_inverse_taps_body(const DcnProblem &p, uin
   __syncthreads();
   // exclusive scan of an int array a[0..HW) into out[] (each thread owns a contiguous run); returns the total
   auto scan = [&](const int *a, int *out) -> int {
-    const int per = (HW + 255) / 256;
+    const int per = (HW + THREADS - 1) / THREADS;
     const int lo = min(HW, tid * per), hi = min(HW, lo + per);
     int local = 0;
     for (int i = lo; i < hi; ++i) local += a[i];
@@ -101,13 +102,14 @@ __device__ __forceinline__ void build_inverse_taps_body(const DcnProblem &p, uin
       out[i] = run;
       run += c;
     }
-    const int total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    int total = 0;
+    for (int w = 0; w < THREADS / 64; ++w) total += wave_tot[w];
     __syncthreads();
     return total;
   };
   const int n_entries = scan(cnt, cursor);
   // pass 2: fill (slot order inside a cell is arbitrary here ...)
-  for (int px = tid; px < p.HoWo; px += 256) {
+  for (int px = tid; px < p.HoWo; px += THREADS) {
     const int oy = px / p.Wo, ox = px - oy * p.Wo;
     float y, x, m;
     tap_position(p, b, p.dgi, t, px, oy, ox, y, x, m);
@@ -125,7 +127,7 @@ __device__ __forceinline__ void build_inverse_taps_body(const DcnProblem &p, uin
   __syncthreads();
   // ... so the SHORT lists (the ones that stay inline) are sorted by pixel here; two corners of one pixel never share a
   // cell.  Longer lists are summed in pixel order by dcn_inv_overflow_sums without being sorted.
-  for (int cell = tid; cell < HW; cell += 256) {
+  for (int cell = tid; cell < HW; cell += THREADS) {
     const int n = cnt[cell];
     if (n > kInvInline) continue;
     const int e1 = cursor[cell];  // end (cursor advanced by the fill)
@@ -142,12 +144,12 @@ __device__ __forceinline__ void build_inverse_taps_body(const DcnProblem &p, uin
   uint4 *inv_bt = inv + (size_t)(b * p.K + t) * HW * 4;
   int *extra = reinterpret_cast<int *>(ent + (size_t)4 * p.HoWo);  // [HW] ints right behind the entries (LDS sized for it)
   int *epos = extra + HW;                                          // [HW]
-  for (int cell = tid; cell < HW; cell += 256) extra[cell] = cnt[cell] > kInvInline ? 1 : 0;
+  for (int cell = tid; cell < HW; cell += THREADS) extra[cell] = cnt[cell] > kInvInline ? 1 : 0;
   __syncthreads();
   const int n_flagged = scan(extra, epos);     // epos[cell] = the cell's slot among the (image, tap)'s long cells
   const size_t bt = (size_t)(b * p.K + t);
   if (tid == 0) hdr[bt] = n_flagged < max_slots ? n_flagged : max_slots;   // (cannot exceed the bound: 9 entries per long cell)
-  for (int cell = tid; cell < HW; cell += 256) {
+  for (int cell = tid; cell < HW; cell += THREADS) {
     const int n = cnt[cell], e0 = cursor[cell] - n;
     const bool long_cell = n > kInvInline;
     unsigned off[8];
@@ -173,14 +175,14 @@ __device__ __forceinline__ void build_inverse_taps_body(const DcnProblem &p, uin
   // the entry list leaves as it lies (coalesced); only the long cells' ranges of it are ever read
   if (n_flagged > 0) {
     int2 *spill_bt = spill + bt * 4 * p.HoWo;
-    for (int i = tid; i < n_entries; i += 256) spill_bt[i] = ent[i];
+    for (int i = tid; i < n_entries; i += THREADS) spill_bt[i] = ent[i];
   }
 }
 
 __global__ __launch_bounds__(256) void dcn_build_inverse_taps(const DcnProblem p, uint4 *__restrict__ inv, int *__restrict__ hdr,
                                                               DcnInvOvfCell *__restrict__ cells, int2 *__restrict__ spill) {
   extern __shared__ __attribute__((aligned(16))) int sm[];
-  build_inverse_taps_body(p, inv, hdr, cells, spill, (int)blockIdx.x, sm);
+  build_inverse_taps_body<256>(p, inv, hdr, cells, spill, (int)blockIdx.x, sm);
 }
 
 // the inverse tables of several problems in ONE launch: block (x, y) = (image, tap) x of problem y.  (A problem has N * K
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256) void dcn_build_inverse_taps_multi(const DcnInv
   extern __shared__ __attribute__((aligned(16))) int sm[];
   const DcnInvBuild &e = grp.e[blockIdx.y];
   if ((int)blockIdx.x >= e.p.N * e.p.K) return;
-  build_inverse_taps_body(e.p, e.inv, e.hdr, e.cells, e.spill, (int)blockIdx.x, sm);
+  build_inverse_taps_body<256>(e.p, e.inv, e.hdr, e.cells, e.spill, (int)blockIdx.x, sm);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -209,11 +211,24 @@ __global__ __launch_bounds__(256) void dcn_inv_overflow_sums(const DcnInvSumGrou
   __shared__ unsigned bitmap[64];
   __shared__ int prefix[64];
   __shared__ float part[16][256];
-  const DcnInvSum &e = grp.e[blockIdx.z];
-  const int bt = blockIdx.x;
+  int uz = blockIdx.z, ubt = blockIdx.x, uy = blockIdx.y;
+  if (grp.sched.on) {   // XCD-local units (DcnInvSumSched): linear workgroup id L -> XCD L % 8, unit r = L / 8 of that XCD's segments
+    const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+    int si = 0;
+    const int ns = grp.sched.n_seg[xcd];
+    while (si < ns && r >= grp.sched.seg[xcd][si].first + grp.sched.seg[xcd][si].n) ++si;
+    if (si >= ns) return;
+    const DcnInvSumSeg sg = grp.sched.seg[xcd][si];
+    const int u = r - sg.first;
+    uz = sg.z;
+    ubt = sg.b * grp.e[sg.z].K + u / kInvSumSplit;
+    uy = u % kInvSumSplit;
+  }
+  const DcnInvSum &e = grp.e[uz];
+  const int bt = ubt;
   if (bt >= e.NK) return;
   const int count = e.hdr[bt];
-  if ((int)blockIdx.y >= count) return;
+  if (uy >= count) return;
   const int tid = threadIdx.x;
   const int b = bt / e.K;
   const int HoWo = e.HoWo, O = e.O, O_ld = e.O_ld;
@@ -222,6 +237,20 @@ __global__ __launch_bounds__(256) void dcn_inv_overflow_sums(const DcnInvSumGrou
   const float *gt = e.gout_t + (size_t)b * HoWo * O;
   const int g16 = tid >> 4, l = tid & 15;
   const bool vec = (O & 3) == 0;
+  // the (image, tap)'s long cells, once, into LDS (round 6: the loops below read them one dependent global load at a time -- the
+  // medium-cell loop in every wave, the cluster rule in ONE thread: with converged key points that serial chain, not the row reads,
+  // was the kernel's time: 134 us per head stage whatever XCD the rows came from)
+  constexpr int kMaxCells = 4 * kPlaneMaxHW / (kInvInline + 1) + 8;
+  __shared__ int c_start[kMaxCells];
+  __shared__ short c_n[kMaxCells], c_cell[kMaxCells];
+  const int n_cells = count < kMaxCells ? count : kMaxCells;
+  for (int i = tid; i < n_cells; i += 256) {
+    const DcnInvOvfCell c = e.cells[(size_t)bt * e.max_slots + i];
+    c_start[i] = c.start;
+    c_n[i] = (short)c.n;
+    c_cell[i] = (short)c.cell;
+  }
+  __syncthreads();
   // ---- cells with at most 64 contributions: ONE WAVE per cell, no workgroup barrier (the four waves work on four cells at
   // once).  Lane i holds entry i; its rank = the number of entries with a smaller pixel (pixels of a cell are distinct); the
   // entries go to the wave's LDS slots in rank order and the wave walks them in that order, lanes = 64 channel quads (one
@@ -233,9 +262,12 @@ __global__ __launch_bounds__(256) void dcn_inv_overflow_sums(const DcnInvSumGrou
     __shared__ float w_w[4][64];
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     int small_idx = 0;
-    for (int slot = blockIdx.y; slot < count; slot += gridDim.y) {
-      const DcnInvOvfCell c = e.cells[(size_t)bt * e.max_slots + slot];
+    for (int slot = uy; slot < n_cells; slot += kInvSumSplit) {
+      const DcnInvOvfCell c = {c_start[slot], (int)c_n[slot], (int)c_cell[slot], 0};
       if (c.n > 64) continue;
+#ifdef KGDET_SUMS_ABL_NOMEDIUM
+      continue;
+#endif
       if ((small_idx++ & 3) != wave) continue;
       int2 en = make_int2(0x7fffffff, 0);
       if (lane < c.n) en = spill_bt[c.start + lane];
@@ -289,8 +321,8 @@ __global__ __launch_bounds__(256) void dcn_inv_overflow_sums(const DcnInvSumGrou
   __shared__ int n_clusters_s;
   if (tid == 0) {
     int nb = 0;
-    for (int sl = 0; sl < count && nb < 96; ++sl)
-      if (e.cells[(size_t)bt * e.max_slots + sl].n > 64) big[nb++] = (short)sl;
+    for (int sl = 0; sl < n_cells && nb < 96; ++sl)
+      if (c_n[sl] > 64) big[nb++] = (short)sl;
     unsigned long long taken0 = 0ull, taken1 = 0ull;
     auto is_taken = [&](int i) { return i < 64 ? (taken0 >> i) & 1ull : (taken1 >> (i - 64)) & 1ull; };
     auto take = [&](int i) { if (i < 64) taken0 |= 1ull << i; else taken1 |= 1ull << (i - 64); };
@@ -298,13 +330,13 @@ __global__ __launch_bounds__(256) void dcn_inv_overflow_sums(const DcnInvSumGrou
     for (int i = 0; i < nb; ++i) {
       if (is_taken(i)) continue;
       take(i);
-      const int q = e.cells[(size_t)bt * e.max_slots + big[i]].cell, x = q % e.W;
+      const int q = c_cell[big[i]], x = q % e.W;
       short m[4] = {big[i], -1, -1, -1};
       int k = 1;
       const int want[3] = {x + 1 < e.W ? q + 1 : -1, q + e.W, x + 1 < e.W ? q + e.W + 1 : -1};
       for (int j = i + 1; j < nb && k < 4; ++j) {
         if (is_taken(j)) continue;
-        const int cj = e.cells[(size_t)bt * e.max_slots + big[j]].cell;
+        const int cj = c_cell[big[j]];
         if (cj > q + e.W + 1) break;
         if (cj == want[0] || cj == want[1] || cj == want[2]) { m[k++] = big[j]; take(j); }
       }
@@ -314,9 +346,13 @@ __global__ __launch_bounds__(256) void dcn_inv_overflow_sums(const DcnInvSumGrou
     n_clusters_s = nc;
   }
   __syncthreads();
+#ifdef KGDET_SUMS_ABL_NOCLUSTER
+  const int n_clusters = 0;
+#else
   const int n_clusters = n_clusters_s;
+#endif
   float *wd4 = wd;                  // [4][HoWo]: by-pixel weights of the members
-  for (int cl = blockIdx.y; cl < n_clusters; cl += gridDim.y) {
+  for (int cl = uy; cl < n_clusters; cl += kInvSumSplit) {
     int slot[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) slot[k] = members[cl][k];
@@ -326,7 +362,7 @@ __global__ __launch_bounds__(256) void dcn_inv_overflow_sums(const DcnInvSumGrou
     for (int i = tid; i < nm * HoWo; i += 256) wd4[i] = 0.0f;
     __syncthreads();
     for (int k = 0; k < nm; ++k) {
-      const DcnInvOvfCell c = e.cells[(size_t)bt * e.max_slots + slot[k]];
+      const DcnInvOvfCell c = {c_start[slot[k]], (int)c_n[slot[k]], (int)c_cell[slot[k]], 0};
       for (int i = tid; i < c.n; i += 256) {
         const int2 en = spill_bt[c.start + i];
         wd4[k * HoWo + en.x] = __int_as_float(en.y);
@@ -351,7 +387,11 @@ __global__ __launch_bounds__(256) void dcn_inv_overflow_sums(const DcnInvSumGrou
       if ((m >> (px & 31)) & 1u) sorted[prefix[px >> 5] + __popc(m & ((1u << (px & 31)) - 1u))] = (unsigned short)px;
     }
     __syncthreads();
+#ifdef KGDET_SUMS_ABL_NOLOOP
+    const int r0 = 0, r1 = n_px > 0 ? 1 : 0;
+#else
     const int r0 = (int)((long long)g16 * n_px / 16), r1 = (int)((long long)(g16 + 1) * n_px / 16);
+#endif
     for (int c0 = 0; c0 < O; c0 += 256) {
       f32x4 acc[4][4];   // [member][channel block j]
 #pragma unroll
@@ -367,6 +407,10 @@ __global__ __launch_bounds__(256) void dcn_inv_overflow_sums(const DcnInvSumGrou
         for (int j = 0; j < 4; ++j) {
           const int ch = c0 + j * 64 + l * 4;
           v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef KGDET_SUMS_ABL_NOLOAD
+          v[j][0] = (float)px;
+          continue;
+#endif
           if (vec) {
             if (ch < O) v[j] = *reinterpret_cast<const f32x4 *>(src + ch);
           } else {
@@ -436,6 +480,50 @@ __global__ __launch_bounds__(256) void dcn_gout_pixel_major_multi(const DcnPixel
     const int px = p0 + r, c = c0 + tx;
     if (px < P && c < C) d[(size_t)px * C + c] = tile[tx][r];
   }
+}
+
+// Everything grad_input needs before its sums and its plane kernel, ONE launch (round 6): workgroups [0, build_blocks * builds.n)
+// build the inverse records of the distinct offset tensors (512 threads per (image, tap): the builder is a chain of short
+// block-wide phases), the rest transpose the grad_output windows into their pixel-major copies -- two launches of round 5, of which
+// the first kept 166 workgroups busy for 30 us and left the rest of the chip idle.
+__global__ __launch_bounds__(512) void dcn_bwd_input_prepare(const DcnInvBuildGroup grp, const DcnPixelMajorGroup pm, int build_blocks,
+                                                            int pm_bx, int pm_by) {
+  extern __shared__ __attribute__((aligned(16))) int sm[];
+  __shared__ float tile[2][32][33];
+  const int n_build = build_blocks * grp.n;
+  if ((int)blockIdx.x < n_build) {
+    const int y = (int)blockIdx.x / build_blocks, x = (int)blockIdx.x - y * build_blocks;
+    const DcnInvBuild &e = grp.e[y];
+    if (x >= e.p.N * e.p.K) return;
+    build_inverse_taps_body<512>(e.p, e.inv, e.hdr, e.cells, e.spill, x, sm);
+    return;
+  }
+  // two 32 x 32 tiles per workgroup (one per 256 threads)
+  const int half = threadIdx.x >> 8, t256 = threadIdx.x & 255;
+  const int u = ((int)blockIdx.x - n_build) * 2 + half;
+  int z = u / (pm_bx * pm_by);
+  const int rem = u - z * (pm_bx * pm_by);
+  const int by = rem / pm_bx, bx = rem - by * pm_bx;
+  int pi = 0;
+  while (pi + 1 < pm.n && z >= pm.e[pi].N) { z -= pm.e[pi].N; ++pi; }
+  const DcnPixelMajorItem &it = pm.e[pi];
+  const int P = it.P, C = it.C;
+  const int p0 = bx * 32, c0 = by * 32;
+  const bool live = z < it.N && p0 < P && c0 < C;     // (uniform per half; both halves reach the barrier)
+  const int tx = t256 & 31, ty = t256 >> 5;  // 32 x 8
+  const float *src = it.src + (size_t)z * it.src_image_stride;
+  float *dst = it.dst + (size_t)z * P * C;
+  if (live)
+    for (int r = ty; r < 32; r += 8) {
+      const int c = c0 + r, px = p0 + tx;
+      tile[half][r][tx] = (c < C && px < P) ? src[(size_t)c * P + px] : 0.0f;
+    }
+  __syncthreads();
+  if (live)
+    for (int r = ty; r < 32; r += 8) {
+      const int px = p0 + r, c = c0 + tx;
+      if (px < P && c < C) dst[(size_t)px * C + c] = tile[half][tx][r];
+    }
 }
 
 size_t dcn_build_inverse_taps_lds_bytes(int HW, int HoWo) {

@@ -71,9 +71,21 @@ struct DcnInvSum {
   int NK, K, HoWo, O, Og, Og_pad16, O_ld, max_slots;
   int W;                 // width of the INPUT map (cells q = y * W + x): neighbours of a cell for the cluster rule
 };
+// XCD-local schedule of the grouped launch: workgroups are dealt to the 8 XCDs round-robin by linear id, so workgroup L runs on XCD
+// L % 8; every (problem, image) -- whose 1 MB pixel-major grad_output all its (tap, split) units read row by row -- is given to ONE
+// XCD, where those rows stay in that XCD's L2 (with units dealt in launch order every XCD streamed all of the group's 12 MB:
+// 350 MB of fabric reads per head stage on converged offsets, ~95 us per launch in the training step's profile of round 5).
+constexpr int kInvSumSegs = 6;
+struct DcnInvSumSeg { int z, b, first, n; };          // problem, image, first unit index r on its XCD, units (K * kInvSumSplit)
+struct DcnInvSumSched {
+  int on;                                             // 0: grid = (N * K, kInvSumSplit, problems), unit = blockIdx
+  int n_seg[8];
+  DcnInvSumSeg seg[8][kInvSumSegs];
+};
 struct DcnInvSumGroup {
   int n;
   DcnInvSum e[kMaxFwdGroup];
+  DcnInvSumSched sched;
 };
 __global__ void dcn_inv_overflow_sums(const DcnInvSumGroup grp);
 struct DcnPixelMajorItem {
@@ -87,6 +99,7 @@ struct DcnPixelMajorGroup {
   DcnPixelMajorItem e[kMaxFwdGroup];
 };
 __global__ void dcn_gout_pixel_major_multi(const DcnPixelMajorGroup grp);
+__global__ void dcn_bwd_input_prepare(const DcnInvBuildGroup grp, const DcnPixelMajorGroup pm, int build_blocks, int pm_bx, int pm_by);
 // grad_offset on an LDS-resident plane (dcn_backward_offset.hip)
 template <int PARTS>
 __global__ void dcn_bwd_offset_plane(const DcnFwdGroup grp, float *__restrict__ slabs, int max_K);

@@ -1,14 +1,15 @@
 #!/bin/bash
 # kernel averages of one head stage's forward + backward for several experiment builds of the library:
-#   bash tools/kstats_variants.sh "<variant> <variant> ..." [B] [filter]     ("-" = the product build)
+#   bash tools/kstats_variants.sh "<variant> <variant> ..." [B] [filter] [random|trained]     ("-" = the product build)
 # (variants are built with `make -C kgdet_amd/csrc VARIANT=<v> EXTRA=-D...` -> kgdet_amd/libkgdet_hip_<v>.so)
 B=${2:-2}
 F=${3:-dcn_bwd}
+MODE=${4:-random}
 cd /tmp && export TMPDIR=/tmp
 for v in $1; do
   if [ "$v" = "-" ]; then unset KGDET_LIB; else export KGDET_LIB=$GRAFT_REPO_ROOT/kgdet_amd/libkgdet_hip_$v.so; fi
   rm -rf /tmp/ksv
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ksv -o k -- python3 $GRAFT_REPO_ROOT/tools/run_group_bwd.py $B 30 > /tmp/ksv.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ksv -o k -- python3 $GRAFT_REPO_ROOT/tools/run_group_bwd.py $B 30 $MODE > /tmp/ksv.log 2>&1
   echo "== $v"
   FILTER=$F python3 - <<'PY'
 import csv, os
