@@ -68,6 +68,9 @@ def parse_args():
     ap.add_argument('--preheat-max-s', type=float, default=30.0, help='give up waiting for a steady state after this long')
     ap.add_argument('--steady-tol', type=float, default=0.02)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--mixed-shapes', action='store_true',
+                    help='every second image of the batch has a smaller pad_shape of its own (invalid grid points); without the flag '
+                         'the training bench times ONE extra window on such a batch and reports it as `mixed_shapes`')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--pipeline', type=int, choices=[0, 1], default=1,
                     help='inference with --graph 1: overlap the result copy + host unpacking of batch k with batch k + 1 '
@@ -153,6 +156,73 @@ def profiled_traffic(batch):
         if line.startswith('traffic_bytes_per_launch:'):
             return float(line.split(':', 1)[1].split()[0]), os.path.relpath(path, ROOT)
     return None, None
+
+
+def kgdet_step_flops(B, H=800, W=1344):
+    """Algorithmic flops of ONE KGDet R50-FPN training step on B images of H x W (2 per multiply-add): every convolution's forward,
+    + grad_weight of every trainable one, + grad_input wherever something trainable lies upstream (frozen_stages = 1: stem and
+    layer 1 are forward only, and layer 2's first conv1 / downsample need no grad_input), deformable convolutions x 3 (forward,
+    the column-gradient GEMM W^T grad_out ONCE -- the reference shares it between col2im and col2im_coord,
+    deform_conv_cuda.cpp:329-371; this build multiplies it in both kernels --, grad_weight).  Returns (total, by family)."""
+    conv = lambda cin, cout, k, px: 2.0 * cin * cout * k * k * px
+    px = lambda s: (H // s) * (W // s)
+    fwd = frozen = no_dgrad = 0.0
+    frozen += conv(3, 64, 7, px(2))                                   # stem
+    cin = 64
+    for li, (planes, blocks, s_in, s_out) in enumerate([(64, 3, 4, 4), (128, 4, 4, 8), (256, 6, 8, 16), (512, 3, 16, 32)]):
+        for b in range(blocks):
+            first = b == 0
+            layer = [conv(cin, planes, 1, px(s_in if first else s_out)), conv(planes, planes, 3, px(s_out)),
+                     conv(planes, planes * 4, 1, px(s_out))] + ([conv(cin, planes * 4, 1, px(s_out))] if first else [])
+            if li == 0:
+                frozen += sum(layer)
+            else:
+                fwd += sum(layer)
+                if li == 1 and first:
+                    no_dgrad += layer[0] + layer[3]
+            cin = planes * 4
+    backbone = frozen + 3 * fwd - no_dgrad
+    p32 = px(32)
+    fpn = 3 * (conv(2048, 256, 1, p32) + conv(256, 256, 3, p32))      # FPN2 select_out=[2]: lateral_convs[2] + fpn_convs[2]
+    dense = 6 * conv(256, 256, 3, p32) + 2 * conv(256, 256, 3, p32) + conv(256, 13, 1, p32) + conv(256, 588, 1, p32) + \
+        conv(588, 166, 1, p32) + 2 * (conv(768, 13, 1, p32) + conv(768, 588, 1, p32) + conv(588, 166, 1, p32))
+    dcn = 2 * 2 * sum(conv(256, 256, k, p32) for k in (3, 5, 7))      # two deformable stages x (cls, keypoint) branch
+    head = 3 * dense + 3 * dcn
+    fam = {'backbone': B * backbone, 'fpn': B * fpn, 'head_dense': B * 3 * dense, 'head_deformable': B * 3 * dcn}
+    return B * (backbone + fpn + head), fam
+
+
+# algorithmic flops of ONE training step per GPU: (config, images per GPU) -> flops
+STEP_FLOPS = {('kgdet', 2): kgdet_step_flops(2)[0]}
+STEP_PROFILE = 'profiles/r06_train_step_fp32_steady.md'
+STEP_F64 = 'profiles/r06_step_vs_f64.json'
+
+
+def step_families():
+    """kernel time per family of the committed steady-state profile (lines `family_us <name>: <us per step>`), or nothing"""
+    path = os.path.join(ROOT, STEP_PROFILE)
+    res = {}
+    if os.path.isfile(path):
+        for line in open(path):
+            if line.startswith('family_us '):
+                k, v = line[len('family_us '):].split(':', 1)
+                res[k.strip()] = float(v.split()[0])
+        res['source'] = STEP_PROFILE
+    return res or None
+
+
+def value_error_vs_f64():
+    """the split-operand step's measured deviation from the float64 golden of the same step (tools/step_vs_f64.py --json on the GPU,
+    committed): worst relative deviation of a module group's gradient norm and of the nine losses"""
+    path = os.path.join(ROOT, STEP_F64)
+    if not os.path.isfile(path):
+        return None
+    try:
+        d = json.load(open(path))
+        d['source'] = STEP_F64
+        return d
+    except Exception:
+        return None
 
 
 def dcn_roofline(device, batch=2, precision='split', iters=100):
@@ -244,10 +314,30 @@ def dcn_backward_live(device, iters=30):
     return med[True] - med[False]
 
 
-def dcn_backward_products_live(device, iters=30):
+def _trained_offsets(offs, ks, B, H, W):
+    """the offsets of a converged keypoint-guided head (tests/test_gpu_dcn.py::_keypoint_offsets): tap t of every location of an
+    image samples one of two key points -- the regime the training step is in after a few hundred steps"""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    gy, gx = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
+    which = (gx * 2 // W).clip(0, 1)
+    out = []
+    for o, k in zip(offs, ks):
+        a = o.cpu().numpy().copy()
+        for b in range(B):
+            for t in range(k * k):
+                ky, kx = rng.uniform(1, H - 2, size=2), rng.uniform(1, W - 2, size=2)
+                a[b, 2 * t] = ky[which] - (gy - k // 2 + t // k) + 0.03 * a[b, 2 * t]
+                a[b, 2 * t + 1] = kx[which] - (gx - k // 2 + t % k) + 0.03 * a[b, 2 * t + 1]
+        out.append(torch.from_numpy(a).to(o.device))
+    return out
+
+
+def dcn_backward_products_live(device, iters=30, regime='random'):
     """The three backward products of the same head stage, each timed alone: (forward + ONE product) minus forward, HIP events
     on the launch stream, median of five runs.  grad_weight: only the weights require gradients; grad_input / grad_offset: the
-    grouped call's two phases one at a time (KGDET_OPT_BWD_PHASE, a measurement switch of the C ABI)."""
+    grouped call's two phases one at a time (KGDET_OPT_BWD_PHASE, a measurement switch of the C ABI).  ``regime``: 'random'
+    N(0, 2^2)-pixel offsets, or 'trained' (``_trained_offsets``)."""
     from kgdet_amd import _lib, dcn
     g = torch.Generator(device='cpu').manual_seed(0)
     B, C, H, W = 2, 256, 25, 42
@@ -255,6 +345,8 @@ def dcn_backward_products_live(device, iters=30):
     xs = [torch.randn(B, C, H, W, generator=g).to(device) for _ in range(2)]
     offs = [(torch.randn(B, 2 * k * k, H, W, generator=g) * 2).to(device) for k in ks]
     ws = [[(torch.randn(C, C, k, k, generator=g) * 0.01).to(device) for k in ks] for _ in xs]
+    if regime == 'trained':
+        offs = _trained_offsets(offs, ks, B, H, W)
     pads = [k // 2 for k in ks]
     leaves_io, leaves_w = xs + offs, [w for wl in ws for w in wl]
     stream = torch.cuda.current_stream()
@@ -274,15 +366,38 @@ def dcn_backward_products_live(device, iters=30):
             for t in leaves_io + leaves_w:
                 t.grad = None
 
+    replayed = [True]
+
     def timed(which):
+        """the launches of one call captured as a HIP graph and replayed back to back (what the GPU-bound training step looks like
+        to the device: a Python loop of forward + one product enqueues ~250 us per iteration, more than the product itself, and the
+        gaps were billed to the kernels); eager enqueue if the capture fails"""
         for _ in range(10):
             run(which)
+        torch.cuda.synchronize()
+        graph = None
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                run(which)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    run(which)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+        except Exception:
+            graph = None
+            replayed[0] = False
         ts = []
         for _ in range(5):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
             for _ in range(iters):
-                run(which)
+                if graph is not None:
+                    graph.replay()
+                else:
+                    run(which)
             e1.record(stream)
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) / iters * 1e-3)
@@ -300,11 +415,17 @@ def dcn_backward_products_live(device, iters=30):
     finally:
         _lib.lib().kgdet_set_option(3, 0)
     out['forward_with_pack_us'] = round(base * 1e6, 1)
+    out['offsets'] = regime
+    out['timed_as'] = 'hip graph replay of one call\'s launches, back to back' if replayed[0] else 'eager enqueue'
     out['note'] = ('one head stage (2 maps x 3x3/5x5/7x7, B=2, 45.69 GFLOP per product), each product = (forward + that product) - '
                    'forward, HIP events, median of five runs of %d; frac against the forward\'s 833 TFLOP/s split-bf16 roof; a '
                    'product includes its builder kernels (inverse records / long-cell sums / grad_out images) and the '
                    'ReLU-backward pass; forward_with_pack_us = the forward as a TRAINING step runs it (weights re-packed per call: '
-                   'dcn_pack_weight_all_multi inside)' % iters)
+                   'dcn_pack_weight_all_multi inside).  Kernels inside each live figure -- grad_input: dcn_bwd_input_prepare (inverse records '
+                   '+ pixel-major grad_out) + dcn_inv_overflow_sums + dcn_bwd_input_plane<2> + dcn_fwd_fixup_static; grad_offset: '
+                   'dcn_build_grad_taps + dcn_bwd_offset_pair + dcn_bwd_offset_plane_fixup; grad_weight: dcn_build_taps + dcn_pack_grad_out '
+                   '+ dcn_bwd_weight_os; each + the autograd node\'s ReLU-backward pass on grad_out.  The profile\'s per-kernel averages '
+                   '(profiles/) exclude the launch gaps and that pass' % iters)
     tr = profiled_traffic_backward()
     for k in ('grad_input', 'grad_offset', 'grad_weight'):
         if k in out and k in tr:
@@ -607,7 +728,7 @@ def main():
     if dist_on:  # same initial weights everywhere (the reference broadcasts once at start-up)
         for p in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(p.data, 0)
-    batch = synthetic.make_batch(args.imgs_per_gpu, device, seed=rank)
+    batch = synthetic.make_batch(args.imgs_per_gpu, device, seed=rank, mixed_shapes=args.mixed_shapes)
     autocast = torch.autocast('cuda', dtype=torch.bfloat16, enabled=args.dtype == 'bf16')
 
     if args.mode == 'train':
@@ -620,7 +741,7 @@ def main():
                                  force_distributed=args.force_dist)
 
         def step():
-            with autocast:
+            with autocast:     # (`batch` is read at call time: the mixed-shapes window rebinds it)
                 losses = model(batch['img'], batch['img_meta'], return_loss=True, gt_bboxes=batch['gt_bboxes'],
                                gt_labels=batch['gt_labels'], gt_keypoints=batch['gt_keypoints'])
             loss = sum(v.float() if torch.is_tensor(v) else sum(x.float() for x in v) for k, v in losses.items()
@@ -754,6 +875,15 @@ def main():
         windows = [timed_window() for _ in range(max(1, args.windows))]
         if board is not None:
             board.stop()
+        mixed_window = None
+        if args.mode == 'train' and not args.mixed_shapes and not dist_on:
+            # the step real DeepFashion2 batches take (imgs_per_gpu = 2 mixes aspect ratios): one window on a mixed-shape batch
+            keep = batch
+            batch = synthetic.make_batch(args.imgs_per_gpu, device, seed=rank, mixed_shapes=True)
+            for _ in range(3):
+                step()
+            mixed_window = timed_window()
+            batch = keep
         exposed, reducer_stats = None, None
         if dist_on and args.mode == 'train':
             red = hook._reducer
@@ -885,7 +1015,12 @@ def main():
                                           'note': 'the resident batch replayed, copied to the host and unpacked BEFORE the next '
                                                   'one starts (`value` overlaps batch k\'s result copy and unpacking with batch '
                                                   'k + 1 when config.pipelined is true)'}
-                out['with_h2d'] = {'serial_img_s': round(rate(serial), 1), 'overlapped_img_s': round(rate(overlapped), 1),
+                serial_rate = rate(serial)
+                out['reference_protocol_img_s'] = round(serial_rate, 1)      # = with_h2d.serial_img_s
+                out['reference_protocol_note'] = ('the figure comparable to the reference\'s tools/benchmark.py:84-108 / MODEL_ZOO.md:31 protocol '
+                                                  '(data hand-over inside, one batch at a time): the page-locked fp32 batch copied host->device, '
+                                                  'then the batch, results on the host before the next one starts')
+                out['with_h2d'] = {'serial_img_s': round(serial_rate, 1), 'overlapped_img_s': round(rate(overlapped), 1),
                                    'overlapped_in_and_out_img_s': round(both, 1),
                                    'batch_MB': round(host.numel() * 4 / 1e6, 1),
                                    'note': '`value` times a batch already resident in the graph\'s input buffer; serial = page-locked '
@@ -898,6 +1033,26 @@ def main():
                                       'copied to page-locked host memory and unpacked per image and class inside the timed window'
                                       if use_graph else 'fp32 batch resident in HBM')
             out['config']['pipelined'] = bool(pipelined)
+        if args.mode == 'train':
+            # the whole step against the split-operand MFMA roof: algorithmic flops of one step (tools/step_flops.py: dense + deformable
+            # convolutions, forward + the gradients a step computes; frozen stem / layer 1 forward only) over the measured step time
+            # (kgdet_step_flops above)
+            sf = STEP_FLOPS.get((args.config, args.imgs_per_gpu))
+            if sf:
+                out['roofline_step'] = {'algorithmic_flops': sf, 'achieved': round(sf * world / (dt / args.steps) / 1e12 / world, 1),
+                                        'peak': round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1), 'unit': 'TFLOP/s per GPU',
+                                        'frac': round(sf / (dt / args.steps) / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 3.0), 4),
+                                        'source': 'bench.py::kgdet_step_flops', 'flops_by_family': kgdet_step_flops(args.imgs_per_gpu)[1] if args.config == 'kgdet' else None,
+                                        'kernel_us_by_family': step_families()}
+            err = value_error_vs_f64()
+            if err is not None and args.config == 'kgdet' and args.dtype == 'fp32':
+                out['value_error_vs_f64'] = err
+        if args.mode == 'train' and mixed_window is not None:
+            out['mixed_shapes'] = {'img_s': round(imgs / mixed_window, 3), 'ms_per_step': round(mixed_window / args.steps * 1e3, 2),
+                                   'vs_value': round((imgs / mixed_window) / (imgs / dt), 4),
+                                   'note': 'one more timed window of the same step on a batch whose second image has a smaller '
+                                           'pad_shape of its own (synthetic.mixed_shapes_of): invalid grid points, same sync-free path '
+                                           '(valid extents in the dense targets / fused loss kernels; tests/test_gpu_head.py)'}
         if not args.no_roofline:
             if args.mode == 'train':
                 out['roofline'] = dcn_roofline(device, 2, 'split')
@@ -905,8 +1060,16 @@ def main():
                 out['roofline'] = dcn_roofline(device, args.imgs_per_gpu, 'bf16' if args.dtype == 'bf16' else 'split')
         if not args.no_roofline and args.mode == 'train' and args.config == 'kgdet':
             bw = dcn_backward_products_live(device)
+            bw_t = dcn_backward_products_live(device, regime='trained')
             rl = out['roofline']
             rl['backward'] = bw
+            rl['backward_trained_offsets'] = bw_t
+            # (scalar copies: a parser that drops nested objects still sees the fractions)
+            for name in ('grad_input', 'grad_offset', 'grad_weight'):
+                if name in bw:
+                    rl['bwd_%s_frac' % name], rl['bwd_%s_us' % name] = bw[name]['frac'], bw[name]['us']
+                if name in bw_t:
+                    rl['bwd_%s_frac_trained' % name], rl['bwd_%s_us_trained' % name] = bw_t[name]['frac'], bw_t[name]['us']
             # the forward as the training step runs it: every call re-packs the six weights (they changed); the inference-style
             # launch above reuses the packed images (`launch_us`: pack NOT inside)
             rl['launch_us_pack_inside'] = bw['forward_with_pack_us']
@@ -945,12 +1108,9 @@ def main():
             gs = graphed_step_leg(args)
             out['graphed_step'] = gs
             out['eager_step'] = {'img_s': out['value'], 'ms_per_step': out['ms_per_step']}
-            if 'img_s' in gs and gs.get('steady') and gs.get('loss_finite') and gs['img_s'] > out['value']:
-                # both are the same step (same kernels in the same order); the replayed graph takes the host's ~560 launches per
-                # step out of the loop.  `value` = the better of the two, `step_mode` says which
-                out['value'], out['ms_per_step'], out['step_mode'] = gs['img_s'], gs['ms_per_step'], 'hip_graph_replay'
-            else:
-                out['step_mode'] = 'eager'
+            # `value` is ALWAYS the median of the timed eager windows above (the ones the driver's clock brackets); the replayed
+            # graph -- the same kernels in the same order, measured in a child process -- is reported beside it
+            out['step_mode'] = 'eager'
         if (args.mode == 'train' and world == 1 and args.config == 'kgdet' and not args.no_inference_leg):
             out['inference'] = inference_leg()
         if ar is not None:

@@ -306,6 +306,12 @@ int kgdet_deform_conv_grad_offset(const kgdet_dcn_shape *s, const float *input, 
  * kgdet_deform_conv_grad_input + kgdet_deform_conv_grad_offset per problem.  n <= 8; every problem must be
  * eligible for both kernels and have groups == 1, deformable_groups == 1 (KGDET_E_UNSUPPORTED otherwise -- call the
  * single entry points).
+ * ALIASED OUTPUTS ARE SUMMED (round 6): problems that pass the SAME grad_input pointer (the 3x3 / 5x5 / 7x7 convolutions of one
+ * feature map) or the same grad_offset pointer (the two maps of a Kp3RepBlock, which share their offsets) get the SUM of their
+ * results in that tensor -- added by the fix-up kernels in fixed order (problems ascending, reduction parts ascending), what
+ * autograd's accumulation of the reference's per-call gradients (deform_conv.py:62-93) produces.  Up to four problems per pointer;
+ * they must tile alike (same N, pixels, channel rows; grad_offset: same kernel size) and the launch must fit the static schedule,
+ * else KGDET_E_UNSUPPORTED before anything is launched for that quantity (pass one tensor per problem and add them yourself).
  * workspace >= kgdet_dcn_group_workspace_bytes(n, shapes). */
 int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *const *shapes, const float *const *inputs,
                                              const float *const *offsets, const float *const *packed_weights,
@@ -414,6 +420,10 @@ typedef struct kgdet_head_targets {
   const float *gt_bboxes[KGDET_HEAD_MAX_IMAGES];     /* [num_gt, 4] */
   const int64_t *gt_labels[KGDET_HEAD_MAX_IMAGES];   /* [num_gt], NULL: every label 1 */
   const float *gt_keypoints[KGDET_HEAD_MAX_IMAGES];  /* [num_gt, num_keypoints, 3] (x, y, visibility) */
+  /* valid extent of image b on the grid: rows < valid_h[b] and columns < valid_w[b] (ceil(pad_shape / stride), the flags of
+   * reppoints_head_kp3rep_cas_1_assign_once.py:524-535); 0 = the whole grid.  Points beyond it are no candidates of the
+   * assigner and carry label weight 0 (point_target_kp.py:107-161 with unmap): no loss, zero gradient. */
+  int32_t valid_h[KGDET_HEAD_MAX_IMAGES], valid_w[KGDET_HEAD_MAX_IMAGES];
 } kgdet_head_targets;
 typedef struct kgdet_head_loss_cfg {
   int32_t pos_num;               /* PointAssigner.pos_num */

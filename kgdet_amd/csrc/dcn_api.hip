@@ -268,6 +268,39 @@ bool plane_bwd_offset_ok(const kgdet_dcn_shape *s, const Derived &d, bool masked
          slab_slots_ok((long long)s->N * ceil_div(d.Ho * d.Wo, kTileN), d.K * (ceil_div(cpdg, kChunk)));
 }
 size_t grad_tap_bytes(const kgdet_dcn_shape *s, const Derived &d) { return (size_t)s->N * s->deformable_groups * d.K * d.Ho * d.Wo * 64; }   // (v2 records: 64 B; one table per deformable group)
+// Sum groups of a backward launch (DcnProblem::sum_count): problems whose OUTPUT POINTERS coincide are summed into that one tensor
+// by the fix-up.  Members must tile alike (same images, pixels, rows); at most four per group.  Returns false otherwise.
+bool assign_sum_groups(DcnFwdGroup &grp, const void *const *outs, bool same_taps) {
+  for (int i = 0; i < grp.n; ++i) { grp.p[i].sum_count = 0; }
+  for (int i = 0; i < grp.n; ++i) {
+    int lead = i;
+    for (int j = 0; j < i; ++j)
+      if (outs[j] == outs[i]) { lead = j; break; }
+    if (lead == i) continue;
+    DcnProblem &L = grp.p[lead];
+    const DcnProblem &q = grp.p[i];
+    if (L.sum_count == 0) { L.sum_count = 1; L.sum_members[0] = lead; }
+    if (L.sum_count >= 4 || q.N != L.N || q.HoWo != L.HoWo || q.Og != L.Og || q.n_ntiles != L.n_ntiles || q.n_mtiles != L.n_mtiles ||
+        q.tiles_per_image != L.tiles_per_image || (same_taps && q.K != L.K))
+      return false;
+    L.sum_members[L.sum_count++] = i;
+  }
+  for (int i = 0; i < grp.n; ++i) {        // every member carries the group (the kernels test sum_count, the fix-up the leader)
+    const DcnProblem &L = grp.p[i];
+    if (L.sum_count > 1 && L.sum_members[0] == i)
+      for (int m = 1; m < L.sum_count; ++m) {
+        DcnProblem &q = grp.p[L.sum_members[m]];
+        q.sum_count = L.sum_count;
+        for (int e = 0; e < 4; ++e) q.sum_members[e] = L.sum_members[e];
+      }
+  }
+  return true;
+}
+bool has_sum_groups(const DcnFwdGroup &grp) {
+  for (int i = 0; i < grp.n; ++i)
+    if (grp.p[i].sum_count > 1) return true;
+  return false;
+}
 // grad_offset on tap pairs (dcn_backward_offset_pair.hip): v1, split operands, one static range per workgroup, K >= 3 (a tap's
 // running sum is re-read one segment later, one slot ahead of its use: with a single pair per segment that would be the slot it is
 // written in)
@@ -1198,6 +1231,19 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
     lds = need > lds ? need : lds;
   }
   if (!check_slots(grp)) { set_error("group too uneven for the slab slots"); return KGDET_E_UNSUPPORTED; }
+  // problems that share a grad_input pointer are summed into it by the fix-up (sum groups); planned before anything is launched
+  if (!assign_sum_groups(grp, (const void *const *)grad_inputs, false)) {
+    set_error("aliased grad_input pointers: the problems do not tile alike (or more than four share one)");
+    return KGDET_E_UNSUPPORTED;
+  }
+  lds = plan_plane_lds(grp, lds, dcn_bwd_input_plane_fixed_lds_bytes(2));
+  grp.wave_layout = dcn_plane_wave_layout();   // plane_role's accumulator layout (slabs are decoded by dcn_fwd_fixup)
+  const int Gs = small_launch_grid(grp, G);
+  plan_static_ranges(grp, Gs, false, kSlabSlots - 2);
+  if (has_sum_groups(grp) && !grp.static_ranges) {
+    set_error("aliased grad_input pointers need the static schedule (one range per workgroup)");
+    return KGDET_E_UNSUPPORTED;
+  }
   const int only_phase = g_options[KGDET_OPT_BWD_PHASE];   // (measurement switch: 1 = grad_input only, 2 = grad_offset only)
   if (only_phase != 2) {
   {
@@ -1253,10 +1299,6 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
       hipLaunchKernelGGL(dcn_inv_overflow_sums, dim3(sums_blocks, kInvSumSplit, sums.n), dim3(256), 0, (hipStream_t)stream, sums);
     }
   }
-  lds = plan_plane_lds(grp, lds, dcn_bwd_input_plane_fixed_lds_bytes(2));
-  grp.wave_layout = dcn_plane_wave_layout();   // plane_role's accumulator layout (slabs are decoded by dcn_fwd_fixup)
-  const int Gs = small_launch_grid(grp, G);
-  plan_static_ranges(grp, Gs, false, kSlabSlots - 2);
   hipLaunchKernelGGL(dcn_bwd_input_plane<2>, dim3(Gs), dim3(dcn_fwd_plane_threads()), lds, (hipStream_t)stream, grp,
                      (float *)workspace);
   launch_plane_fixup(grp, workspace, Gs, stream);
@@ -1297,8 +1339,16 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
     lds = need > lds ? need : lds;
   }
   if (lds > kMaxLds || !check_slots(grp)) { set_error("group does not fit the grad_offset kernel"); return KGDET_E_UNSUPPORTED; }
+  if (!assign_sum_groups(grp, (const void *const *)grad_offsets, true)) {
+    set_error("aliased grad_offset pointers: the problems do not tile alike (or more than four share one)");
+    return KGDET_E_UNSUPPORTED;
+  }
   const int Go = small_launch_grid(grp, G);
   plan_static_ranges(grp, Go);
+  if (has_sum_groups(grp) && !grp.static_ranges) {
+    set_error("aliased grad_offset pointers need the static schedule (one range per workgroup)");
+    return KGDET_E_UNSUPPORTED;
+  }
   const bool use_pair = offset_pair_ok(grp);
   if (use_pair) place_offset_xblk(grp, tab, rec_total, workspace_bytes - slab_bytes());
   hipLaunchKernelGGL(dcn_build_grad_taps, dim3(2 * G, grp.n), dim3(256), 0, (hipStream_t)stream, grp);

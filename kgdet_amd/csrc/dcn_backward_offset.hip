@@ -343,7 +343,7 @@ __device__ __forceinline__ void offset_role(const DcnFwdGroup &grp, float *__res
     // the range's tap sums: straight to grad_offset if the range is the whole tile, else to a slab
     __syncthreads();
     {
-      const bool whole = s_begin == 0 && s_end == cpt;
+      const bool whole = s_begin == 0 && s_end == cpt && p.sum_count <= 1;
       float *slab = slabs + ((long long)g * grp.slots + slot) * (size_t)(max_K * kTileN * ACC);
       for (int i = wtid; i < K * kTileN; i += kOffThreads) {
         const int t = i / kTileN, col = i - t * kTileN;
@@ -440,18 +440,22 @@ __global__ __launch_bounds__(256) void dcn_bwd_offset_plane_fixup(const DcnFwdGr
   const long long total = grp.unit_begin[grp.n];
   const size_t slab_floats0 = (size_t)max_K * kTileN * 2;
   if (grp.static_ranges) {   // one workgroup per (part, tile) range: add the parts' slabs in order
-    if (p.kparts == 1) return;  // written directly
+    const bool grouped = p.sum_count > 1;      // (sum group: the leader's block adds every member's parts, DcnProblem::sum_count)
+    if (grouped ? p.sum_members[0] != pi : p.kparts == 1) return;  // (no group, one part: written directly)
     const int tiles_ = p.n_ntiles * p.n_mtiles;
     const int tb_ = tile / p.tiles_per_image, px0_ = (tile - tb_ * p.tiles_per_image) * kTileN;
     for (int e = 0; e < 4; ++e) {
       const int i = (blockIdx.y + e * gridDim.y) * 256 + threadIdx.x;
       if (i >= p.K * kTileN) continue;
       float sy = 0.f, sx = 0.f;
-      for (int part = 0; part < p.kparts; ++part) {
-        const int range = grp.range_begin[pi] + part * tiles_ + tile;
-        const float2 v = reinterpret_cast<const float2 *>(slabs + (size_t)sk_block_of_slice(range, G) * grp.slots * slab_floats0)[i];
-        sy += v.x;
-        sx += v.y;
+      for (int m = 0; m < (grouped ? p.sum_count : 1); ++m) {
+        const int mi = grouped ? p.sum_members[m] : pi;
+        for (int part = 0; part < grp.p[mi].kparts; ++part) {
+          const int range = grp.range_begin[mi] + part * tiles_ + tile;
+          const float2 v = reinterpret_cast<const float2 *>(slabs + (size_t)sk_block_of_slice(range, G) * grp.slots * slab_floats0)[i];
+          sy += v.x;
+          sx += v.y;
+        }
       }
       const int t = i / kTileN, px = px0_ + (i - t * kTileN);
       if (px < p.HoWo) {

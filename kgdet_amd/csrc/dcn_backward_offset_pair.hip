@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kPairThreads, 1) void dcn_bwd_offset_pair(const Dcn
   const int tile_px0 = (pos.tile - tile_b * p.tiles_per_image) * kTileN;
   const int n_o16 = (Og + kChunk - 1) / kChunk;
   const int s_begin = pos.s, s_end = pos.s + (int)(my_end - my_begin);
-  const bool whole = s_begin == 0 && s_end == p.chunks_per_tile;
+  const bool whole = s_begin == 0 && s_end == p.chunks_per_tile && p.sum_count <= 1;   // (sum group: every range through its slab)
   const int seg0 = s_begin / K, nseg = (s_end - s_begin) / K;        // (static ranges are whole channel chunks)
   const int np = (K + 1) >> 1, Q = nseg * np;
   const int c16_base = p.c16_base;

@@ -236,6 +236,12 @@ struct DcnProblem {
   long long total_units;  // n_ntiles * n_mtiles * chunks_per_tile
   int tiles_per_image;    // > 0: pixel tiles never straddle images (plane kernel); 0: tiles run over N*Ho*Wo
   int kparts;             // plane kernel: the reduction range of every tile is cut into kparts parts (see DcnFwdGroup)
+  // SUM GROUP (round 6; backward plane kernels, static ranges): problems of a launch whose results are one tensor -- grad_input
+  // of the 3x3 / 5x5 / 7x7 convolutions of one feature map, grad_offset of the two maps that share an offset tensor.  Every
+  // member writes ALL its ranges to slabs (none writes its output directly), and the fix-up block of the LEADER's tile adds the
+  // members' parts in fixed order (members ascending, parts ascending) and writes the sum once: the autograd node's
+  // stack + sum passes (5 cat + 5 reduce launches, 54 us per head stage) are gone.  sum_count <= 1: no group.
+  int sum_count, sum_members[4];
   int seg_stages;         // stages per chunk of the reduction: K
   unsigned flags;
 };

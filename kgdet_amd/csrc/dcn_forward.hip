@@ -296,7 +296,8 @@ __global__ __launch_bounds__(kThreads) void dcn_fwd_fixup_static(const DcnFwdGro
   int pi = 0;
   while (pi + 1 < grp.n && gtile >= grp.tile_begin[pi + 1]) ++pi;
   const DcnProblem &p = grp.p[pi];
-  if (p.kparts == 1) return;  // written directly by the tile's only workgroup
+  const bool grouped = p.sum_count > 1;   // (sum group, DcnProblem::sum_count: the leader's block adds every member's parts)
+  if (grouped ? p.sum_members[0] != pi : p.kparts == 1) return;  // (no group, one part: written directly by the tile's only workgroup)
   const int tile = gtile - grp.tile_begin[pi];
   const int tiles = p.n_ntiles * p.n_mtiles;
   constexpr int kCols = 8;
@@ -304,15 +305,18 @@ __global__ __launch_bounds__(kThreads) void dcn_fwd_fixup_static(const DcnFwdGro
   f32x4 sum[kCols];
 #pragma unroll
   for (int c = 0; c < kCols; ++c) sum[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int part = 0; part < p.kparts; ++part) {
-    const int range = grp.range_begin[pi] + part * tiles + tile;
-    // (range r is computed by the workgroup of slice r % G in its round r / G: slab slot r / G)
-    const f32x4 *s4 = reinterpret_cast<const f32x4 *>(slabs + ((long long)sk_block_of_slice(range % G, G) * grp.slots + range / G) * kTileElems);
-    f32x4 v[kCols];
+  for (int m = 0; m < (grouped ? p.sum_count : 1); ++m) {
+    const int mi = grouped ? p.sum_members[m] : pi;
+    for (int part = 0; part < grp.p[mi].kparts; ++part) {
+      const int range = grp.range_begin[mi] + part * tiles + tile;
+      // (range r is computed by the workgroup of slice r % G in its round r / G: slab slot r / G)
+      const f32x4 *s4 = reinterpret_cast<const f32x4 *>(slabs + ((long long)sk_block_of_slice(range % G, G) * grp.slots + range / G) * kTileElems);
+      f32x4 v[kCols];
 #pragma unroll
-    for (int c = 0; c < kCols; ++c) v[c] = s4[(j0 + c) * kThreads + tid];
+      for (int c = 0; c < kCols; ++c) v[c] = s4[(j0 + c) * kThreads + tid];
 #pragma unroll
-    for (int c = 0; c < kCols; ++c) sum[c] += v[c];
+      for (int c = 0; c < kCols; ++c) sum[c] += v[c];
+    }
   }
   const int mt = tile % p.n_mtiles, nt = tile / p.n_mtiles;
   const int lane = tid & 63, wave = tid >> 6;

@@ -832,7 +832,7 @@ __device__ __forceinline__ void plane_role(const DcnFwdGroup &grp, float *__rest
       // the stores' lane-dependent addresses to the top of the range and, at 128 registers, spills them)
       int tid_e = wave_s * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
       asm volatile("" : "+v"(tid_e));
-      if (s_begin == 0 && s_end == cpt) {
+      if (s_begin == 0 && s_end == cpt && p.sum_count <= 1) {
         if constexpr (k42) store_output(p, mt, nt, tid_e, acc);
         else store_output_w8(p, mt, nt, tid_e, acc);
       } else {

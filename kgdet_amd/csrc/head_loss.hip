@@ -100,18 +100,21 @@ __global__ __launch_bounds__(256) void head_assign_select(const kgdet_head_targe
   const float cx = (box[0] + box[2]) / 2, cy = (box[1] + box[3]) / 2;
   const float w = fmaxf(box[2] - box[0], 1e-6f), h = fmaxf(box[3] - box[1], 1e-6f);
   if (tid == 0) { s_tbits = 0; s_count = 0; }
+  // the image's valid extent (point_target_kp.py:107-118: the assigner only sees the points inside it)
+  const int vh = t.valid_h[b] > 0 ? min(t.valid_h[b], t.H) : t.H, vw = t.valid_w[b] > 0 ? min(t.valid_w[b], t.W) : t.W;
   for (int i = tid; i < N; i += 256) {
-    const float px = (float)(i % t.W) * t.stride, py = (float)(i / t.W) * t.stride;
+    const int col = i % t.W, row = i / t.W;
+    const float px = (float)col * t.stride, py = (float)row * t.stride;
     const float dx = (px - cx) / w, dy = (py - cy) / h;
-    dist[i] = sqrtf(dx * dx + dy * dy);
+    dist[i] = (row < vh && col < vw) ? sqrtf(dx * dx + dy * dy) : INFINITY;
   }
   __syncthreads();
   int side = 1;
   while (side * side < pos_num) ++side;
-  float T = INFINITY;
-  if (side <= t.H && side <= t.W) {
-    const int j0 = min(max((int)floorf(cx / t.stride + 0.5f) - side / 2, 0), t.W - side);
-    const int i0 = min(max((int)floorf(cy / t.stride + 0.5f) - side / 2, 0), t.H - side);
+  float T = FLT_MAX;           // (every valid point is a candidate; invalid ones -- distance +inf -- never are)
+  if (side <= vh && side <= vw) {
+    const int j0 = min(max((int)floorf(cx / t.stride + 0.5f) - side / 2, 0), vw - side);
+    const int i0 = min(max((int)floorf(cy / t.stride + 0.5f) - side / 2, 0), vh - side);
     for (int e = tid; e < side * side; e += 256)
       atomicMax(&s_tbits, __float_as_int(dist[(i0 + e / side) * t.W + j0 + e % side]));   // (distances are >= 0)
     __syncthreads();
@@ -192,7 +195,9 @@ __global__ __launch_bounds__(256) void head_loss_rows(const kgdet_head_targets t
   p.py = (float)(ic / t.W) * t.stride;
   const float *gbox = t.gt_bboxes[b] + 4 * max(p.a - 1, 0);
   const float *gkp = t.gt_keypoints[b] + (long long)max(p.a - 1, 0) * K * 3;
-  const float label_w = p.a > 0 ? cfg.pos_weight : 1.0f;             // point_target_kp.py:140-147
+  const int vh = t.valid_h[b] > 0 ? min(t.valid_h[b], t.H) : t.H, vw = t.valid_w[b] > 0 ? min(t.valid_w[b], t.W) : t.W;
+  const bool inside = ic / t.W < vh && ic % t.W < vw;                // (a point outside is never assigned: p.a == 0)
+  const float label_w = p.a > 0 ? cfg.pos_weight : (inside ? 1.0f : 0.0f);   // point_target_kp.py:140-147, unmap fill 0
   const float kp_w = p.nvis > 0 ? 1.0f / (float)(2 * p.nvis) * 4.0f : 0.0f;
   const float nt = cfg.normalize_term;
 
@@ -316,6 +321,12 @@ static int head_check(const kgdet_head_targets *t, const kgdet_head_loss_cfg *cf
   KGDET_CHECK_SHAPE(t->H > 0 && t->W > 0 && t->H * t->W <= kMaxPoints, "point grid beyond %d points", kMaxPoints);
   KGDET_CHECK_SHAPE(t->num_classes > 0 && t->num_keypoints > 0, "bad channel counts");
   KGDET_CHECK_SHAPE(cfg->pos_num >= 1 && cfg->normalize_term > 0.0f, "bad assigner / normaliser");
+  for (int b = 0; b < t->B; ++b) {
+    const int vh = t->valid_h[b] > 0 ? (t->valid_h[b] < t->H ? t->valid_h[b] : t->H) : t->H;
+    const int vw = t->valid_w[b] > 0 ? (t->valid_w[b] < t->W ? t->valid_w[b] : t->W) : t->W;
+    KGDET_CHECK_SHAPE(t->valid_h[b] >= 0 && t->valid_w[b] >= 0 && (long long)vh * vw >= cfg->pos_num,
+                      "image %d: fewer valid points than pos_num", b);
+  }
   int g = 0;
   for (int b = 0; b < t->B; ++b) {
     KGDET_CHECK_SHAPE(t->num_gt[b] >= 1 && t->num_gt[b] <= kMaxGt, "image %d: %d ground-truth boxes (1..%d)", b,

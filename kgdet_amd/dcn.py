@@ -564,6 +564,9 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
 # ------------------------------------------------------------------------------------------------
 # Fused multi-kernel deformable convolution:  relu(cat([dconv_k(x, offset_k, W_k) for k], dim=1))
 # ------------------------------------------------------------------------------------------------
+_SUM_IN_FIXUP = os.environ.get('KGDET_DCN_SUM_IN_FIXUP', '1') == '1'     # A/B switch: aliased gradient outputs, summed by the fix-up kernels
+
+
 class DeformConvCatFunction(Function):
     """KGDet runs a 3x3, a 5x5 and a 7x7 deformable conv on a feature map, applies ReLU to each and
     concatenates them -- once on the classification features and once on the keypoint features, with
@@ -642,24 +645,41 @@ class DeformConvCatFunction(Function):
             # grad_input / grad_offset of all n_x * n_k convs: two grouped launches
             L = _lib.lib()
             n = n_x * n_k
-            gis = [torch.empty_like(xs[j // n_k]) for j in range(n)]
-            gos = [torch.empty_like(offsets[j % n_k]) for j in range(n)]
             arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
             shape_arr = (ctypes.POINTER(_lib.DcnShape) * n)(*[ctypes.pointer(s) for s in ctx.shapes])
             ws = _workspace(xs[0].device, L.kgdet_dcn_group_workspace_bytes(ctypes.c_int32(n), shape_arr))
-            rc = L.kgdet_deform_conv_backward_input_grouped(
-                ctypes.c_int32(n), shape_arr, arr([xs[j // n_k] for j in range(n)]),
-                arr([offsets[j % n_k] for j in range(n)]), arr(packs), arr([gouts[j // n_k] for j in range(n)]),
-                arr(gis), arr(gos), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.current_stream())
+
+            def grouped(gis, gos):
+                return L.kgdet_deform_conv_backward_input_grouped(
+                    ctypes.c_int32(n), shape_arr, arr([xs[j // n_k] for j in range(n)]),
+                    arr([offsets[j % n_k] for j in range(n)]), arr(packs), arr([gouts[j // n_k] for j in range(n)]),
+                    arr(gis), arr(gos), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.current_stream())
+            # ONE grad_input tensor per feature map and ONE grad_offset tensor per offset tensor: problems that share an output
+            # pointer are summed into it by the kernels' fix-up (include/kgdet_hip.h) -- no stack + sum passes here
+            gi_x, go_k = [torch.empty_like(x) for x in xs], [torch.empty_like(o) for o in offsets]
+            rc = grouped([gi_x[j // n_k] for j in range(n)], [go_k[j % n_k] for j in range(n)]) if _SUM_IN_FIXUP else \
+                _lib.KGDET_E_UNSUPPORTED
             if rc == _lib.KGDET_OK:
                 done_io = True
                 for i in range(n_x):
                     if need[i]:
-                        grad_xs[i] = torch.stack(gis[i * n_k:(i + 1) * n_k]).sum(0) if n_k > 1 else gis[i * n_k]
+                        grad_xs[i] = gi_x[i]
                 for k in range(n_k):
                     if need[n_x + k]:
-                        grad_offs[k] = torch.stack(gos[k::n_k]).sum(0) if n_x > 1 else gos[k]
-            elif rc != _lib.KGDET_E_UNSUPPORTED:
+                        grad_offs[k] = go_k[k]
+            else:     # (shapes that do not tile alike / no static schedule: one output per problem, summed here)
+                gis = [torch.empty_like(xs[j // n_k]) for j in range(n)]
+                gos = [torch.empty_like(offsets[j % n_k]) for j in range(n)]
+                rc = grouped(gis, gos)
+                if rc == _lib.KGDET_OK:
+                    done_io = True
+                    for i in range(n_x):
+                        if need[i]:
+                            grad_xs[i] = torch.stack(gis[i * n_k:(i + 1) * n_k]).sum(0) if n_k > 1 else gis[i * n_k]
+                    for k in range(n_k):
+                        if need[n_x + k]:
+                            grad_offs[k] = torch.stack(gos[k::n_k]).sum(0) if n_x > 1 else gos[k]
+            if rc not in (_lib.KGDET_OK, _lib.KGDET_E_UNSUPPORTED):
                 _lib.check(rc, 'kgdet_deform_conv_backward_input_grouped')
         done_w = False
         if all(need[n_x + n_k:]) and not _EXACT_BACKWARD:

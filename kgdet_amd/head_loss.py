@@ -25,7 +25,8 @@ class HeadTargets(ctypes.Structure):
     _fields_ = [('B', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32), ('num_classes', ctypes.c_int32),
                 ('num_keypoints', ctypes.c_int32), ('stride', ctypes.c_float),
                 ('num_gt', ctypes.c_int32 * MAX_IMAGES), ('gt_bboxes', ctypes.c_void_p * MAX_IMAGES),
-                ('gt_labels', ctypes.c_void_p * MAX_IMAGES), ('gt_keypoints', ctypes.c_void_p * MAX_IMAGES)]
+                ('gt_labels', ctypes.c_void_p * MAX_IMAGES), ('gt_keypoints', ctypes.c_void_p * MAX_IMAGES),
+                ('valid_h', ctypes.c_int32 * MAX_IMAGES), ('valid_w', ctypes.c_int32 * MAX_IMAGES)]
 
 
 class HeadLossCfg(ctypes.Structure):
@@ -46,8 +47,9 @@ def _maps(tensors):
 
 
 def applicable(head, cfg, cls_scores, kpt_preds, bbox_preds, gt_bboxes, gt_labels, gt_keypoints, gt_bboxes_ignore,
-               all_valid):
-    """the fused kernels cover exactly the case ``points.dense_targets_applicable`` covers, on the GPU, in float32"""
+               all_valid=True, valid_sizes=None):
+    """the fused kernels cover exactly the case ``points.dense_targets_applicable`` covers for one level, on the GPU, in
+    float32; ``valid_sizes``: per image the (rows, columns) of the grid inside its pad_shape (None: all of it)"""
     from .losses import FocalLoss, SmoothL1Loss
     from .points import dense_targets_applicable
     if not ENABLED or head.sampling or not head.use_sigmoid_cls or len(head.point_strides) != 1:
@@ -68,6 +70,8 @@ def applicable(head, cfg, cls_scores, kpt_preds, bbox_preds, gt_bboxes, gt_label
             if len(per_level) != 1 or per_level[0].dtype != torch.float32:
                 return False
     if cfg.assigner.get('pos_num', 3) > H * W:
+        return False
+    if valid_sizes is not None and any(vh * vw < cfg.assigner.get('pos_num', 3) for vh, vw in valid_sizes):
         return False
     for b in range(B):
         g = gt_bboxes[b].shape[0]
@@ -126,7 +130,7 @@ class _HeadLoss(torch.autograd.Function):
         return (None, None, None) + grads
 
 
-def head_loss(head, cfg, cls_scores, kpt_preds, bbox_preds, gt_bboxes, gt_labels, gt_keypoints):
+def head_loss(head, cfg, cls_scores, kpt_preds, bbox_preds, gt_bboxes, gt_labels, gt_keypoints, valid_sizes=None):
     """The nine losses of ``head.loss`` as a dict of 0-dim tensors (one list entry per level, as the reference returns).
     ``cls_scores`` / ``kpt_preds`` / ``bbox_preds``: three stages x [one level] of NCHW maps."""
     t0 = cls_scores[0][0]
@@ -142,6 +146,8 @@ def head_loss(head, cfg, cls_scores, kpt_preds, bbox_preds, gt_bboxes, gt_labels
         lab = None if gt_labels is None or gt_labels[b] is None else gt_labels[b].contiguous()
         keep += [bb, kp, lab]
         t.num_gt[b] = bb.shape[0]
+        if valid_sizes is not None:
+            t.valid_h[b], t.valid_w[b] = int(valid_sizes[b][0]), int(valid_sizes[b][1])
         t.gt_bboxes[b], t.gt_keypoints[b] = bb.data_ptr(), kp.data_ptr()
         t.gt_labels[b] = lab.data_ptr() if lab is not None else None
     c = HeadLossCfg()

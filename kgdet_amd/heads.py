@@ -463,19 +463,21 @@ class RepPointsHeadKp3RepCas1AssignOnce(PointHeadMixin, nn.Module):
 
         if cfg.uniform.assigner['type'] != 'PointAssigner':
             raise NotImplementedError
-        # every grid point valid?  (host arithmetic on the image metas, the flags themselves live on the device)
-        all_valid = all(
-            min(int(np.ceil(meta['pad_shape'][0] / s)), fs[0]) == fs[0] and
-            min(int(np.ceil(meta['pad_shape'][1] / s)), fs[1]) == fs[1]
-            for meta in img_metas for s, fs in zip(self.point_strides, featmap_sizes))
+        # the part of every level's grid inside each image's own pad_shape (KP3:524-535; host arithmetic on the image
+        # metas): a batch of mixed shapes leaves some grid points invalid in almost every step, and they take the SAME
+        # sync-free path (round 6: valid extents in the dense targets and in the fused loss)
+        valid_sizes = [[(min(int(np.ceil(meta['pad_shape'][0] / s)), fs[0]), min(int(np.ceil(meta['pad_shape'][1] / s)), fs[1]))
+                        for s, fs in zip(self.point_strides, featmap_sizes)] for meta in img_metas]
+        all_valid = all(v == tuple(fs) for per_img in valid_sizes for v, fs in zip(per_img, featmap_sizes))
         from . import head_loss
         stages = ((cls_scores_1, cls_scores_2, cls_scores_3), (keypts_preds_1, keypts_preds_2, keypts_preds_3),
                   (bbox_preds_1, bbox_preds_2, bbox_preds_3))
+        level0 = None if all_valid else [per_img[0] for per_img in valid_sizes]
         if head_loss.applicable(self, cfg.uniform, stages[0], stages[1], stages[2], gt_bboxes, gt_labels, gt_keypoints,
-                                gt_bboxes_ignore, all_valid):
+                                gt_bboxes_ignore, valid_sizes=level0):
             # assignment + targets + the nine losses from the raw maps: four HIP launches (csrc/head_loss.hip)
             return head_loss.head_loss(self, cfg.uniform, stages[0], stages[1], stages[2], gt_bboxes, gt_labels,
-                                       gt_keypoints)
+                                       gt_keypoints, valid_sizes=level0)
 
         center_list, valid_flag_list = self.get_points(featmap_sizes, img_metas, device=device)
         kpt_coords = [self.offset_to_pts(center_list, p) for p in (keypts_preds_1, keypts_preds_2, keypts_preds_3)]
@@ -485,7 +487,8 @@ class RepPointsHeadKp3RepCas1AssignOnce(PointHeadMixin, nn.Module):
         if not self.sampling and dense_targets_applicable(cfg.uniform, len(self.point_strides), all_valid,
                                                           gt_bboxes_ignore):
             cls_reg_targets = point_target_kp_dense(candidate_list, gt_bboxes, gt_keypoints, cfg.uniform,
-                                                    gt_labels_list=gt_labels)   # no host syncs
+                                                    gt_labels_list=gt_labels,
+                                                    valid_flag_list=None if all_valid else valid_flag_list)   # no host syncs
         else:
             cls_reg_targets = point_target_kp(candidate_list, valid_flag_list, gt_bboxes, gt_keypoints, img_metas,
                                               cfg.uniform, gt_bboxes_ignore_list=gt_bboxes_ignore,

@@ -269,7 +269,7 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
             candidate_list = center_list
         else:
             candidate_list = self.centers_to_bboxes(center_list)
-        # every grid point valid?  (host arithmetic on the image metas) -> the sync-free dense target path
+        # every grid point valid?  (host arithmetic on the image metas; if not, the dense path takes the valid flags)
         all_valid = all(
             min(int(np.ceil(meta['pad_shape'][0] / s)), fs[0]) == fs[0] and
             min(int(np.ceil(meta['pad_shape'][1] / s)), fs[1]) == fs[1]
@@ -277,7 +277,8 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
         dense_ok = lambda c: (not self.sampling and DENSE_TARGETS and
                               dense_targets_applicable(c, len(self.point_strides), all_valid, gt_bboxes_ignore))
         if dense_ok(cfg.init):
-            targets_init = point_target_kp_dense(candidate_list, gt_bboxes, gt_keypoints, cfg.init, gt_labels_list=gt_labels)
+            targets_init = point_target_kp_dense(candidate_list, gt_bboxes, gt_keypoints, cfg.init, gt_labels_list=gt_labels,
+                                                 valid_flag_list=None if all_valid else valid_flag_list)
         else:
             targets_init = point_target_kp(candidate_list, valid_flag_list, gt_bboxes, gt_keypoints, img_metas, cfg.init,
                                            gt_bboxes_ignore_list=gt_bboxes_ignore, gt_labels_list=gt_labels,
@@ -300,7 +301,8 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
                 bbox.append(bbox_center + init_boxes[i_lvl][i_img].permute(1, 2, 0).reshape(-1, 4))
             bbox_list.append(bbox)
         if dense_ok(cfg.refine):
-            targets_refine = point_target_kp_dense(bbox_list, gt_bboxes, gt_keypoints, cfg.refine, gt_labels_list=gt_labels)
+            targets_refine = point_target_kp_dense(bbox_list, gt_bboxes, gt_keypoints, cfg.refine, gt_labels_list=gt_labels,
+                                                   valid_flag_list=None if all_valid else valid_flag_list)
         else:
             targets_refine = point_target_kp(bbox_list, valid_flag_list, gt_bboxes, gt_keypoints, img_metas, cfg.refine,
                                              gt_bboxes_ignore_list=gt_bboxes_ignore, gt_labels_list=gt_labels,

@@ -22,12 +22,31 @@ def make_img_metas(batch, img_shape=IMG_SHAPE, pad_shape=PAD_SHAPE):
             for _ in range(batch)]
 
 
-def make_batch(batch, device, seed=0, num_gt=2, img_shape=IMG_SHAPE, pad_shape=PAD_SHAPE, dtype=torch.float32):
+def mixed_shapes_of(img_shape=IMG_SHAPE, pad_shape=PAD_SHAPE):
+    """(img_shape, pad_shape) of the SMALLER images of a mixed batch: a portrait-ish 7/8 x 5/6 of the batch's padded size,
+    rounded down to the 32-pixel divisor -- (672, 1120) inside (800, 1344); the reference fixture `kgdet_invalid_points` pins the
+    targets of such a batch ((704, 1120) beside (800, 1344)).  mmdetection collates a batch to its largest pad_shape and keeps every image's own in its
+    meta: the grid points beyond it are invalid for that image (reppoints_head_kp3rep_cas_1_assign_once.py:524-535)."""
+    ph, pw = (pad_shape[0] * 7 // 8) // 32 * 32, (pad_shape[1] * 5 // 6) // 32 * 32
+    return (ph, pw - 10, 3), (ph, pw, 3)
+
+
+def make_batch(batch, device, seed=0, num_gt=2, img_shape=IMG_SHAPE, pad_shape=PAD_SHAPE, dtype=torch.float32,
+               mixed_shapes=False):
+    """``mixed_shapes``: every second image (1, 3, ...) is a smaller one (``mixed_shapes_of``) padded into the batch tensor; its
+    ground truth lies inside its own shape and its meta carries its own pad_shape"""
     g = torch.Generator().manual_seed(seed)
-    H, W = img_shape[0], img_shape[1]
     img = torch.randn(batch, 3, pad_shape[0], pad_shape[1], generator=g, dtype=dtype)
+    small_img, small_pad = mixed_shapes_of(img_shape, pad_shape)
+    metas = make_img_metas(batch, img_shape, pad_shape)
     gt_bboxes, gt_labels, gt_keypoints = [], [], []
-    for _ in range(batch):
+    for b in range(batch):
+        H, W = img_shape[0], img_shape[1]
+        if mixed_shapes and b % 2 == 1:
+            H, W = small_img[0], small_img[1]
+            metas[b] = make_img_metas(1, small_img, small_pad)[0]
+            img[b, :, small_pad[0]:, :] = 0      # (the collate's zero padding)
+            img[b, :, :, small_pad[1]:] = 0
         wh = torch.rand(num_gt, 2, generator=g) * 500 + 200
         wh[:, 0].clamp_(max=W - 2)
         wh[:, 1].clamp_(max=H - 2)
@@ -44,8 +63,7 @@ def make_batch(batch, device, seed=0, num_gt=2, img_shape=IMG_SHAPE, pad_shape=P
         gt_bboxes.append(boxes.to(device))
         gt_labels.append(labels.to(device))
         gt_keypoints.append(kps.to(device))
-    return dict(img=img.to(device), img_meta=make_img_metas(batch, img_shape, pad_shape), gt_bboxes=gt_bboxes,
-                gt_labels=gt_labels, gt_keypoints=gt_keypoints)
+    return dict(img=img.to(device), img_meta=metas, gt_bboxes=gt_bboxes, gt_labels=gt_labels, gt_keypoints=gt_keypoints)
 
 
 def calibrate_scores(model, batch, score_thr, frac=0.02, autocast=None):

@@ -75,7 +75,8 @@ def run_point_target(case, device, dense):
         all_valid = all(bool(torch.cat(fl).all()) for fl in flags)
         assert points.dense_targets_applicable(cfg, len(case['strides']), all_valid)
         return points.point_target_kp_dense(props, to(case['gt_bboxes']), to(case['gt_keypoints']), cfg,
-                                            gt_labels_list=to(case['gt_labels']))
+                                            gt_labels_list=to(case['gt_labels']),
+                                            valid_flag_list=None if all_valid else flags)
     metas = [dict(pad_shape=ps) for ps in case['pad_shapes']]
     return points.point_target_kp(props, flags, to(case['gt_bboxes']), to(case['gt_keypoints']), metas, cfg,
                                   gt_bboxes_ignore_list=None, gt_labels_list=to(case['gt_labels']),

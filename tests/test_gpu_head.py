@@ -160,19 +160,24 @@ def test_config5_detector_with_soft_nms():
     assert len(res) in (1, 3)
 
 
-def test_training_step_has_no_host_syncs_and_dense_targets_match():
+@pytest.mark.parametrize('mixed', [False, True])
+def test_training_step_has_no_host_syncs_and_dense_targets_match(mixed):
     """The KGDet training step (forward, targets, 9 losses, backward, clip, fused Adam) must not stall the launch
-    queue: torch's sync debug mode raises on any device->host read or blocking host->device copy.  The dense
-    (sync-free) target path must give the same losses as the reference-mirroring path."""
+    queue: torch's sync debug mode raises on any device->host read or blocking host->device copy.  The fused loss
+    kernels, the dense torch chain and the list-returning front-end must give the same losses.  ``mixed``: the second
+    image has a smaller pad_shape of its own -- a batch with INVALID grid points takes the same sync-free path
+    (round 6; the targets of such a batch are pinned to the reference by the `kgdet_invalid_points` fixture)."""
     from kgdet_amd import points
     from kgdet_amd.dist import DistOptimizerHook
     from kgdet_amd.registry import build_detector
     cfg = configs.kgdet_r50_fpn()
     torch.manual_seed(0)
     model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda()
-    batch = synthetic.make_batch(2, 'cuda', seed=0, img_shape=(384, 480, 3), pad_shape=(384, 480, 3))
+    batch = synthetic.make_batch(2, 'cuda', seed=0, img_shape=(384, 480, 3), pad_shape=(384, 480, 3), mixed_shapes=mixed)
     for k in ('gt_bboxes', 'gt_keypoints'):
-        batch[k] = [t.clamp(max=370) for t in batch[k]]
+        batch[k] = [t.clamp(max=370 if i == 0 or not mixed else 300) for i, t in enumerate(batch[k])]
+    if mixed:
+        assert batch['img_meta'][1]['pad_shape'] == (320, 384, 3) and batch['img_meta'][0]['pad_shape'] == (384, 480, 3)
     model.train()
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-6, fused=True)
     hook = DistOptimizerHook(grad_clip=dict(cfg.optimizer_config.grad_clip))
@@ -196,6 +201,15 @@ def test_training_step_has_no_host_syncs_and_dense_targets_match():
     torch.cuda.synchronize()
 
     from kgdet_amd import head_loss
+    if mixed:     # the fused kernels did run on the mixed batch (not a fallback), and invalid points carry no gradient
+        seen = []
+        real = head_loss.head_loss
+        head_loss.head_loss = lambda *a, **k: (seen.append(k.get('valid_sizes')), real(*a, **k))[1]
+        try:
+            forward()
+        finally:
+            head_loss.head_loss = real
+        assert seen == [[(12, 15), (10, 12)]], seen
     with torch.no_grad():
         fused = forward()                       # csrc/head_loss.hip: assignment + losses from the raw maps
         assert head_loss.ENABLED

@@ -14,9 +14,10 @@ pytestmark = pytest.mark.gpu
 CASES = ref_cases.target_cases()
 
 
-@pytest.mark.parametrize('name', ['kgdet_1gt', 'kgdet_overlap', 'kgdet_extremes', 'pyramid_init', 'pyramid_refine'])
+@pytest.mark.parametrize('name', [n for n in CASES if n != 'kgdet_empty_gt'])
 def test_dense_targets_on_gpu_equal_reference(name):
-    """points.point_target_kp_dense on the device (what bench.py's training step runs) == point_target_kp.py:98-169"""
+    """points.point_target_kp_dense on the device (what bench.py's training step runs) == point_target_kp.py:98-169, incl. the
+    two batches of mixed pad_shapes whose grid has invalid points (`kgdet_invalid_points`, `pyramid_init_pos3`: round 6)"""
     G = ref_checks.load('ref_targets_golden.npz')
     ref_checks.check_points_and_flags(G, name, CASES[name], 'cuda')
     ref_checks.check_point_target(G, name, ref_checks.run_point_target(CASES[name], 'cuda', dense=True))
@@ -24,6 +25,7 @@ def test_dense_targets_on_gpu_equal_reference(name):
 
 @pytest.mark.parametrize('name', [n for n in CASES if n != 'kgdet_empty_gt'])
 def test_mirrored_targets_on_gpu_equal_reference(name):
+    """the list-returning front-end (point_target_kp) of the same dense rules"""
     G = ref_checks.load('ref_targets_golden.npz')
     ref_checks.check_point_target(G, name, ref_checks.run_point_target(CASES[name], 'cuda', dense=False))
 

@@ -140,3 +140,26 @@ def test_graphed_train_step_follows_the_eager_steps(config):
     if config == 'kgdet':
         s1 = float(next(iter(o1.state.values()))['step'])
         assert s1 == warm + 1 + replays, s1
+
+
+def test_graphed_train_step_captures_a_batch_of_mixed_shapes():
+    """Round 6: a batch whose images have different pad_shapes (invalid grid points for the smaller one) takes the same
+    sync-free step -- valid extents in the fused loss kernels -- so the WHOLE step captures as one HIP graph and its replays
+    reproduce the eager step's losses (before: such a batch fell to the host-syncing target path, which cannot be captured)."""
+    from kgdet_amd import synthetic
+    make, _ = _graph_case('kgdet')
+    batch = synthetic.make_batch(2, 'cuda', seed=0, mixed_shapes=True)
+    assert batch['img_meta'][1]['pad_shape'] != batch['img_meta'][0]['pad_shape']
+    m1, o1, h1 = make()
+    g = rn.GraphedTrainStep(m1, o1, h1, batch, warmup=2)
+    out = g.step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out['loss']).item()
+    m2, o2, h2 = make()
+    losses = []
+    for _ in range(2 + 1 + 1):
+        o = rn.batch_processor(m2, batch)
+        losses.append(float(o['loss']))
+        h2.step(m2, o2, o['loss'])
+    torch.cuda.synchronize()
+    assert abs(float(out['loss']) - losses[-1]) <= 2e-3 * abs(losses[-1]), (float(out['loss']), losses)
