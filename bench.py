@@ -141,7 +141,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md); AMD's 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0
 ROOFLINE_PROFILE = {2: 'profiles/r05_dcn_fwd_plane_group_b2.md', 8: 'profiles/r05_dcn_fwd_plane_group_b8_bf16.md'}
-BACKWARD_PROFILE = 'profiles/r05_dcn_bwd_plane_kernels.md'
+BACKWARD_PROFILE = 'profiles/r06_dcn_bwd_plane_kernels.md'
 
 
 def profiled_traffic(batch):
@@ -426,7 +426,7 @@ def dcn_backward_products_live(device, iters=30, regime='random'):
                    'dcn_build_grad_taps + dcn_bwd_offset_pair + dcn_bwd_offset_plane_fixup; grad_weight: dcn_build_taps + dcn_pack_grad_out '
                    '+ dcn_bwd_weight_os; each + the autograd node\'s ReLU-backward pass on grad_out.  The profile\'s per-kernel averages '
                    '(profiles/) exclude the launch gaps and that pass' % iters)
-    tr = profiled_traffic_backward()
+    tr = profiled_traffic_backward('trained_' if regime == 'trained' else '')
     for k in ('grad_input', 'grad_offset', 'grad_weight'):
         if k in out and k in tr:
             out[k]['traffic'] = tr[k]
@@ -434,15 +434,15 @@ def dcn_backward_products_live(device, iters=30, regime='random'):
     return out
 
 
-def profiled_traffic_backward():
-    """per-product fabric bytes of the committed backward profile (lines `traffic_bytes_<product>: N`), or nothing"""
+def profiled_traffic_backward(prefix=''):
+    """per-product fabric bytes of the committed backward profile (lines `traffic_bytes_[trained_]<product>: N`), or nothing"""
     path = os.path.join(ROOT, BACKWARD_PROFILE)
     res = {}
     if os.path.isfile(path):
         for line in open(path):
-            if line.startswith('traffic_bytes_grad_'):
+            if line.startswith('traffic_bytes_' + prefix + 'grad_'):
                 key, val = line.split(':', 1)
-                res[key[len('traffic_bytes_'):]] = float(val.split()[0])
+                res[key[len('traffic_bytes_' + prefix):]] = float(val.split()[0])
         res['source'] = BACKWARD_PROFILE
     return res
 
