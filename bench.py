@@ -107,10 +107,42 @@ def launch_ranks(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+def bind_rank_to_its_gpus_numa_node():
+    """A rank's loader / launch threads on the CPUs of its GPU's NUMA node (the reference leaves placement to the launcher,
+    tools/dist_train.sh:8-10 + mmdet/apis/env.py:26-31; on an 8-GPU MI355X node the GPUs hang off two sockets): reads
+    /sys/bus/pci/devices/<bdf>/numa_node of LOCAL_RANK's device from rocm-smi-free sysfs and sets the process affinity to that node's
+    cpulist.  Silent no-op where sysfs does not say (containers, one node)."""
+    try:
+        local = int(os.environ.get('LOCAL_RANK', 0))
+        cards = sorted(d for d in os.listdir('/sys/class/drm') if d.startswith('card') and d[4:].isdigit() and
+                       os.path.isfile('/sys/class/drm/%s/device/numa_node' % d) and
+                       os.path.isfile('/sys/class/drm/%s/device/vendor' % d) and
+                       open('/sys/class/drm/%s/device/vendor' % d).read().strip() == '0x1002')
+        if local >= len(cards):
+            return None
+        node = int(open('/sys/class/drm/%s/device/numa_node' % cards[local]).read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open('/sys/devices/system/node/node%d/cpulist' % node).read().strip().split(','):
+            a, _, b = part.partition('-')
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            return node
+    except Exception:
+        pass
+    return None
+
+
 ARGS = parse_args() if __name__ == '__main__' else None
+NUMA_NODE = None
 if ARGS is not None:
     if 'RANK' not in os.environ and (ARGS.gpus > 1 or ARGS.force_dist):
         launch_ranks(ARGS)
+    if 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', 1)) > 1:
+        NUMA_NODE = bind_rank_to_its_gpus_numa_node()
     if int(os.environ.get('WORLD_SIZE', 1)) != ARGS.gpus:
         sys.exit('bench.py: --gpus %d but WORLD_SIZE=%s' % (ARGS.gpus, os.environ.get('WORLD_SIZE', '1')))
 # MIOpen's measured solver picks for this workload's convolution shapes on MI355X (written by MIOpen itself during
@@ -405,6 +437,7 @@ def dcn_backward_products_live(device, iters=30, regime='random'):
 
     flops = sum(2.0 * C * C * k * k * B * H * W for k in ks) * 2
     out = {}
+    dcn.MEASUREMENT = True          # (the grouped backward reports a phase-only call as KGDET_E_PARTIAL; accepted here only)
     try:
         base = timed('forward')
         for which, phase in (('grad_weight', 0), ('grad_input', 1), ('grad_offset', 2)):
@@ -414,6 +447,7 @@ def dcn_backward_products_live(device, iters=30, regime='random'):
                           'frac': round(flops / t / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 3.0), 4)}
     finally:
         _lib.lib().kgdet_set_option(3, 0)
+        dcn.MEASUREMENT = False
     out['forward_with_pack_us'] = round(base * 1e6, 1)
     out['offsets'] = regime
     out['timed_as'] = 'hip graph replay of one call\'s launches, back to back' if replayed[0] else 'eager enqueue'
@@ -907,6 +941,12 @@ def main():
             diffs.sort()
             exposed = 0.5 * (diffs[3] + diffs[4]) / args.steps
             exposed_spread = (diffs[-1] - diffs[0]) / args.steps
+            bucket_times = None
+            if red is not None and red.buckets:      # one traced step: when every bucket went out / came back relative to backward's end
+                red._trace_ev, red.trace = [], True
+                step()
+                red.trace = False
+                bucket_times = red.bucket_trace()
     dt = sorted(windows)[len(windows) // 2]
 
     ar = allreduce_busbw(device, world) if (dist_on and args.mode == 'train') else None
@@ -916,6 +956,7 @@ def main():
         ar['exposed_note'] = ('median over eight alternating window pairs (after the pre-heat) of: step time with the '
                               'overlapped exchange minus the same step without it; spread = max - min of the pairs (at one '
                               'rank the collective is a no-op: this is the cost of the bucket copies and the side stream)')
+        ar['bucket_times'] = bucket_times
         ar['buckets'] = reducer_stats[0] if reducer_stats else None
         ar['buckets_issued_inside_backward_per_step'] = reducer_stats[1] if reducer_stats else None
     if rank == 0:
@@ -941,6 +982,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 (3 MFMA products per multiply on hi/lo-split operands -- fp16 parts forward, bf16 parts for gradients --, f32 accumulate)' if args.dtype == 'fp32'
             else 'bf16 (dense convs and deformable operands, f32 accumulate)',
             'data': 'synthetic',
+            **({'numa_node_of_rank0': NUMA_NODE} if NUMA_NODE is not None else {}),
             'config': {'workload': '%s R50-FPN %s step, %d img/GPU at 800x1333 (padded 800x1344), '
                                    '%s' % ('KGDet' if args.config == 'kgdet' else
                                            'RepPoints-kp serial head (config 5, 5-level FPN, soft-NMS)',

@@ -176,6 +176,7 @@ int kgdet_bias_relu_maxpool_nhwc(const void *x, const float *bias, void *y, int6
 
 /* HIP runtime error (launch failure etc.) */
 #define KGDET_E_UNSUPPORTED 4
+#define KGDET_E_PARTIAL 5     /* a measurement switch (KGDET_OPT_BWD_PHASE) was set: only part of the call's outputs were written */
 
 const char *kgdet_last_error(void); /* thread-local message for the last non-zero status */
 int kgdet_version(void);            /* ABI version, currently 1 */
@@ -186,11 +187,8 @@ int kgdet_device_cu_count(void);    /* compute units of the current device (0 if
  * instead of the split-bf16 plane kernels it prefers for v1 problems -- the arithmetic of the reference's fp32
  * col2im path (deform_conv_cuda.cpp:260-371), used to measure what the hi/lo split costs over a training step. */
 #define KGDET_OPT_EXACT_BACKWARD 0
-/* KGDET_OPT_FWD_COLUMN_WAVE != 0 (or the environment variable KGDET_DCN_CW=1): split-operand forwards on the LDS plane take the
- * column-wave kernel (csrc/dcn_forward_cw.hip: four waves, each samples the B fragment it multiplies, feature planes by LDS-DMA from a
- * blocked copy of the input) where its conditions hold (static ranges of whole chunks, >= 3 taps).  Same results to round-off;
- * measured slower than the default plane kernel on MI355X (198 against 168 us for a KGDet head stage): an experiment kept under test.
- * (Slot 1 was KGDET_OPT_TAP_PAIRS in rounds 2-4: that kernel left the library, tools/experiments/dcn_plane_pairs.h.) */
+/* (slot 1: KGDET_OPT_TAP_PAIRS in rounds 2-4, the column-wave forward in round 5 -- both kernels left the library, tools/experiments/;
+ * setting it has no effect) */
 #define KGDET_OPT_FWD_COLUMN_WAVE 1
 /* KGDET_OPT_WGRAD_STREAMK != 0: kgdet_deform_conv_grad_weight_grouped keeps rounds 1-3's schedule -- 256 x 128 tiles, (tile,
  * stage) units dealt stream-K, partial tiles + fix-up -- where it would otherwise run the output-stationary kernel (round 4:

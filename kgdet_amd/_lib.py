@@ -16,6 +16,7 @@ KGDET_E_SHAPE = 1
 KGDET_E_WORKSPACE = 2
 KGDET_E_HIP = 3
 KGDET_E_UNSUPPORTED = 4
+KGDET_E_PARTIAL = 5
 
 DCN_RELU = 1
 DCN_BF16 = 2         # forward operands rounded to bf16 once (autocast inference)

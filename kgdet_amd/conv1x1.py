@@ -491,7 +491,9 @@ def invalidate_inference_caches():
     (backbone._fold_cache, the stem pack) and the packed deformable operands (dcn._pack_cache).  The caches follow the
     parameters' version counters, data pointers and object identities; a write THROUGH ``.data`` (``p.data.copy_``, EMA /
     weight-averaging utilities, some checkpoint loaders) changes none of the three -- callers that do that must call this.
-    ``checkpoint.load_checkpoint`` and ``ResNet.train()`` do."""
+    ``checkpoint.load_checkpoint`` and the detector's ``train()`` / ``eval()`` (detector.py: every switch of mode, so that weights
+    stepped by a replayed HIP graph -- ``runner.GraphedTrainStep`` -- are never evaluated through stale copies) do; ``ResNet.train()``
+    alone clears the folded-backbone cache only."""
     global _fold_flat
     _cast_cache.clear()
     _fold_flat = None

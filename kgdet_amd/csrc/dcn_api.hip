@@ -416,7 +416,7 @@ size_t kgdet_dcn_workspace_bytes(const kgdet_dcn_shape *s) {
   if (derive(s, d)) return 0;
   // slabs for stream-K partial tiles + (forward) the tap records / (backward-weight) a packed gradient image
   const size_t after_slabs = (size_t)s->groups * d.fwd_image_floats() * sizeof(float);
-  // (forward: the tap records and, for the column-wave kernel, the blocked copy of the input behind them)
+  // (forward: the tap records and the blocked copy of the input the chained plane hand-over reads, behind them)
   const size_t fwd_tables = tap_table_bytes(s, d) +
                             (plane_ok(s, d) ? 512 + s->groups * align_up(dcn_xblk_bytes(s->N, d.Cg_pad, s->H * s->W), 256) : 0);
   const size_t fwd_and_wgrad = slab_bytes() + (after_slabs > fwd_tables ? after_slabs : fwd_tables);
@@ -458,7 +458,7 @@ size_t kgdet_dcn_group_workspace_bytes(int32_t n, const kgdet_dcn_shape *const *
     Derived d;
     if (!shapes || derive(shapes[i], d)) return 0;
     tables += tap_table_bytes(shapes[i], d);
-    if (plane_ok(shapes[i], d))   // (column-wave forward: a blocked copy of the input behind the tap records)
+    if (plane_ok(shapes[i], d))   // (a blocked copy of the input behind the tap records: the forward's chained plane hand-over)
       tables += 512 + shapes[i]->groups * align_up(dcn_xblk_bytes(shapes[i]->N, d.Cg_pad, shapes[i]->H * shapes[i]->W), 256);
     if (plane_bwd_input_ok(shapes[i], d)) bwd_tables += inv_tables_all(shapes[i], d) + inv_sums_all(shapes[i], d);
     if (plane_bwd_offset_ok(shapes[i], d))   // (grad_offset phase: records + the blocked copy of the input of the tap-pair kernel)
@@ -634,13 +634,6 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
   const int parts = (flags & KGDET_DCN_BF16) ? 1 : 2;
   const bool grp_pair = false;   // (the tap-pair kernel of rounds 2-4 left the library in round 5: tools/experiments/dcn_plane_pairs.h)
   int max_hw = 0;
-  static const int cw_env = getenv("KGDET_DCN_CW") ? atoi(getenv("KGDET_DCN_CW")) : 0;   // A/B switch
-  auto cw_ok = [&]() {
-    if (!(cw_env || g_options[KGDET_OPT_FWD_COLUMN_WAVE] != 0) || parts != 2 || grp_pair || !grp.static_ranges) return false;
-    for (int i = 0; i < grp.n; ++i)
-      if (grp.p[i].K < 3 || grp.p[i].H * grp.p[i].W > kPlaneMaxHW) return false;
-    return true;
-  };
   auto flush = [&]() -> int {
     if (grp.n == 0) return KGDET_OK;
     const int Gf = G;                                  // (the full grid: record builders)
@@ -655,9 +648,8 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
       attr_set = true;
     }
     grp.pair_mode = grp_pair ? 1 : 0;
-    const bool use_cw = cw_ok();
     static const int chain_dma = getenv("KGDET_DCN_CHAIN_DMA") ? atoi(getenv("KGDET_DCN_CHAIN_DMA")) : 1;   // A/B switch
-    const bool use_xblk = use_cw || (chain_dma && parts == 2 && !grp_pair);   // (plane kernel: chained segment hand-over by LDS-DMA)
+    const bool use_xblk = chain_dma && parts == 2 && !grp_pair;   // (plane kernel: chained segment hand-over by LDS-DMA)
     for (int i = 0; i < grp.n; ++i) { grp.p[i].xblk = nullptr; grp.p[i].build_xblk = 0; }
     if (use_xblk) {   // blocked copies of the distinct inputs behind the tap records (written by dcn_build_taps' blocks)
       size_t used = align_up(table_used, 256);
@@ -683,16 +675,7 @@ int kgdet_deform_conv_forward_grouped(int32_t n, const kgdet_dcn_shape *const *s
     }
     hipLaunchKernelGGL(dcn_build_taps, dim3(2 * Gf, grp.n), dim3(256), 0, (hipStream_t)stream, grp);
     const int threads = dcn_fwd_plane_threads();
-    if (use_cw) {   // column-wave kernel (dcn_forward_cw.hip): static ranges of whole chunks, K >= 3, split operands
-      static thread_local bool cw_attr_set = false;
-      if (!cw_attr_set) {
-        KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_fwd_cw<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
-        cw_attr_set = true;
-      }
-      grp.wave_layout = 1;   // (its slabs are written in the register-image format of layout 1)
-      hipLaunchKernelGGL((dcn_fwd_cw<2>), dim3(G), dim3(dcn_fwd_cw_threads()), dcn_fwd_cw_lds_bytes(parts), (hipStream_t)stream, grp,
-                         (float *)workspace);
-    } else {
+    {
       const size_t lds2 = plan_plane_lds(grp, lds, dcn_fwd_plane_fixed_lds_bytes(parts));
       grp.wave_layout = dcn_plane_wave_layout();
       if (parts == 1)
@@ -1303,9 +1286,10 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
                      (float *)workspace);
   launch_plane_fixup(grp, workspace, Gs, stream);
   }
-  if (only_phase == 1) {
+  if (only_phase == 1) {   // (measurement switch: grad_offset was NOT written -- never reported as success)
     KGDET_CHECK_LAUNCH("dcn_bwd_plane_grouped");
-    return KGDET_OK;
+    set_error("KGDET_OPT_BWD_PHASE = 1: grad_offset not computed");
+    return KGDET_E_PARTIAL;
   }
 
   // ---- phase 2: grad_offset (column gradient in registers) ----
@@ -1360,6 +1344,10 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
   hipLaunchKernelGGL(dcn_bwd_offset_plane_fixup, dim3(grp.tile_begin[grp.n], 8), dim3(256), 0, (hipStream_t)stream, grp,
                      (const float *)workspace, Go, max_K);
   KGDET_CHECK_LAUNCH("dcn_bwd_plane_grouped");
+  if (only_phase == 2) {   // (measurement switch: grad_input was NOT written)
+    set_error("KGDET_OPT_BWD_PHASE = 2: grad_input not computed");
+    return KGDET_E_PARTIAL;
+  }
   return KGDET_OK;
 }
 

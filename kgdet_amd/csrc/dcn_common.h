@@ -214,7 +214,7 @@ struct DcnProblem {
   int gov_slots, gov_ld;  //         slots per (image, tap); floats per slot (all output channels of the convolution, padded to 16)
   int gov_c0;             //         first channel of this (sub-)problem's grad_out window inside a Gov vector
   int build_taps;         // this problem owns `taps` (others of the group may alias it: same offsets and geometry)
-  const float *xblk;      // column-wave forward kernel: the blocked copy of x (dcn_forward_cw.hip), or nullptr
+  const float *xblk;      // the blocked copy of x the LDS-DMA plane hand-overs read (forward chain, grad_offset pair kernel), or nullptr
   int build_xblk;         // this problem owns `xblk` (dcn_build_taps writes it)
   const float *bias;    // [O_total] or nullptr
   float *out;           // forward: [N, O_total, Ho, Wo]
@@ -272,7 +272,7 @@ struct DcnFwdGroup {
   DcnProblem p[kMaxFwdGroup];
 };
 
-// The blocked copy of x the column-wave kernel's LDS-DMA reads: x[image, c_base + 16 c .. + 15, :, :] as
+// The blocked copy of x the plane hand-overs' LDS-DMA reads: x[image, c_base + 16 c .. + 15, :, :] as
 // [image][chunk c][quad][pixels padded to 64][4 channels] fp32 -- exactly the LDS plane's units, each 1 KiB contiguous.  Channels
 // past Cg repeat the last one, pixels past H*W the last pixel (as dcn_plane_copy does).  One wave per unit; called from
 // dcn_build_taps' blocks.

@@ -18,11 +18,6 @@ __global__ void dcn_to_pixel_major(const float *__restrict__ src, float *__restr
                                    long long src_image_stride);
 size_t dcn_fwd_plane_fixed_lds_bytes(int parts);
 int dcn_fwd_plane_threads();
-// column-wave variant (dcn_forward_cw.hip): four waves, each samples the B fragment it multiplies; NR = plane units per wave
-template <int PARTS>
-__global__ void dcn_fwd_cw(const DcnFwdGroup grp, float *__restrict__ slabs);
-int dcn_fwd_cw_threads();
-size_t dcn_fwd_cw_lds_bytes(int parts);
 // large-map v1 backward without atomics (dcn_backward_large.hip)
 bool dcn_bwd_large_ok(const DcnProblem &p, bool has_mask, int groups);
 size_t dcn_bwd_large_workspace_bytes(const DcnProblem &p);

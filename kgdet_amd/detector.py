@@ -63,6 +63,14 @@ class RepPointsDetectorKp(nn.Module):
     def forward_dummy(self, img):
         return self.bbox_head(self.extract_feat(img), None)
 
+    def train(self, mode=True):
+        """``nn.Module.train`` + every derived inference-time copy of the weights dropped (autocast casts, folded backbone, packed
+        deformable operands): they are keyed on the parameters' version counters, which a replayed HIP graph of the training
+        step (``runner.GraphedTrainStep``) or a write through ``.data`` does not move.  ``eval()`` calls ``train(False)``."""
+        from . import conv1x1
+        conv1x1.invalidate_inference_caches()
+        return super(RepPointsDetectorKp, self).train(mode)
+
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_keypoints, gt_bboxes_ignore=None):
         from . import conv1x1
         with conv1x1.step_scope():    # the split-bf16 convolutions' weight images: one pack launch per step

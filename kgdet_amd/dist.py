@@ -104,6 +104,8 @@ class OverlappedGradReducer(object):
         self._hooks = []
         self._pending = []
         self.launched_from_hooks = 0   # buckets whose exchange started inside backward (diagnostics / tests)
+        self.trace = False             # diagnostics: time stamps of every bucket's issue / completion (bucket_trace())
+        self._trace_ev = []
         # late joiners (docstring (c)): this step's bit on the device, last step's sum in page-locked memory
         dev = self.params[0].device if self.params else torch.device('cpu')
         self._late = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -266,8 +268,28 @@ class OverlappedGradReducer(object):
             for i in missing:                       # (rare path: one more tiny launch each, no host->device copy)
                 self._flags[b][i].zero_()
             work = dist.all_reduce(flat, group=self.group, async_op=True)
+        if self.trace and self.use_cuda:     # when the bucket was issued (compute stream) and when its collective ended (side stream)
+            issued, ended = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            issued.record(torch.cuda.current_stream())
+            with self._side():
+                work.wait()
+                ended.record(self.stream)
+            self._trace_ev.append((b, issued, ended))
         self._launched[b] = True
         self._pending.append((b, work))
+
+    def bucket_trace(self):
+        """(diagnostics, ``trace = True`` during the last step) per bucket: milliseconds from the END of backward to the moment the
+        bucket was issued (negative: inside backward) and to the end of its collective (positive: what the step waits for) --
+        explains ``exposed_ms`` from one line.  Synchronises."""
+        if not self._trace_ev or getattr(self, '_trace_end', None) is None:
+            return None
+        torch.cuda.synchronize()
+        rows = [(b, round(-i.elapsed_time(self._trace_end), 3),
+                 round(self._trace_end.elapsed_time(e), 3)) for b, i, e in self._trace_ev]
+        self._trace_ev = []
+        return {'bucket': [r[0] for r in rows], 'issued_ms_after_backward_end': [r[1] for r in rows],
+                'done_ms_after_backward_end': [r[2] for r in rows]}
 
     def _on_grad(self, p):
         """Post-accumulate hook.  A bucket whose gradients are all there becomes READY; collectives are ISSUED
@@ -290,6 +312,9 @@ class OverlappedGradReducer(object):
         """Call after ``loss.backward()``: completes the exchange; afterwards every bucketed parameter's
         ``.grad`` is the averaged gradient (a view of its bucket)."""
         rebuild, late = False, []
+        if self.trace and self.use_cuda:
+            self._trace_end = torch.cuda.Event(enable_timing=True)
+            self._trace_end.record(torch.cuda.current_stream())      # backward's last kernel is in front of this
         if self.buckets is not None:
             late = [p for p in self._inactive if p.grad is not None]
             if self.world_size == 1:
@@ -419,7 +444,11 @@ class DistOptimizerHook(object):
                 if dev_sched:
                     self._fused.step_published()
                 return
-        self._fused.invalidate()       # torch advances the step counters below: the fused path re-reads them next time
+        # torch advances the step counters below: the fused path re-reads them next time; a device-side schedule is folded back
+        # into the optimizer's counters first (otherwise they would lag by the steps it took, and its own count would miss this one)
+        if getattr(self._fused, '_sched', None) is not None and not torch.cuda.is_current_stream_capturing():
+            self._fused.disable_device_schedule(optimizer)
+        self._fused.invalidate()
         if self.grad_clip is not None:
             self.clip_grads(self._params)
         optimizer.step()

@@ -47,7 +47,13 @@ class FusedClipAdam(object):
         ``sync_optimizer_state(optimizer)`` adds the steps taken to the optimizer's own ``step`` tensors (state_dict / checkpoint
         compatibility; called by the graphed runner before anything reads them)."""
         group = optimizer.param_groups[0]
-        steps = [optimizer.state[p]['step'] for p in group['params'] if p.grad is not None or p in optimizer.state]
+        # (optimizer.state is a defaultdict: indexing a parameter without state would CREATE an empty entry -- and raise KeyError
+        # on 'step'; a parameter that has a gradient but no state yet has not been stepped: not this schedule's case)
+        stateless = [p for p in group['params'] if p.grad is not None and p not in optimizer.state]
+        if stateless:
+            raise RuntimeError('%d parameters have a gradient but no optimizer state: take one step through the optimizer first'
+                               % len(stateless))
+        steps = [optimizer.state[p]['step'] for p in group['params'] if p in optimizer.state and 'step' in optimizer.state[p]]
         steps = [s for s in steps if isinstance(s, torch.Tensor)]
         both = torch.stack([s.detach().reshape(()).float().cpu() for s in steps]).aminmax()
         if float(both.min) != float(both.max):
@@ -61,7 +67,16 @@ class FusedClipAdam(object):
         self._dev_steps, self._pending = t, 0
         self._ring_events = [None] * self.LR_RING
         self._host_step = None
+        self._sched_rows = len(steps)          # the set the one device-side counter stands for
         return self
+
+    def disable_device_schedule(self, optimizer):
+        """back to host-side counters (the hook's torch fallback is about to step the optimizer itself): the steps taken under the
+        device schedule are added to the optimizer's own counters first, so the two never diverge"""
+        if self._sched is not None:
+            self.sync_optimizer_state(optimizer)
+            self._sched = None
+        self._host_step = None
 
     def publish_lr(self, optimizer):
         """host side of step ``self._dev_steps + 1`` under the device schedule: its learning rate into its ring slot (waiting,
@@ -168,7 +183,12 @@ class FusedClipAdam(object):
                        'multi_grad_norm')
         if self._sched is not None:
             # device schedule: nothing of the step is read or advanced on the host (the call may be a graph capture); the
-            # caller publishes the learning rate and counts the steps (publish_lr / step_published)
+            # caller publishes the learning rate and counts the steps (publish_lr / step_published).  ONE counter stands for every
+            # stepped tensor: a parameter that joins (or leaves) would get the wrong bias correction -- refuse loudly
+            if len(rows) != getattr(self, '_sched_rows', len(rows)):
+                raise RuntimeError('the set of stepped parameters changed under the device-side Adam schedule (%d -> %d tensors): '
+                                   'call disable_device_schedule() / enable_device_schedule() around such a change'
+                                   % (self._sched_rows, len(rows)))
             beta1, beta2 = group['betas']
             _lib.check(L.kgdet_multi_clip_adam_dev(
                 ctypes.c_void_p(self._table.data_ptr()), ctypes.c_int32(len(rows)), ctypes.c_int64(first), _lib.ptr(self._norm),

@@ -138,7 +138,9 @@ def test_shard(n, world_size, rank):
     index list padded by wrapping to a multiple of ``world_size``, then every ``world_size``-th index from ``rank`` on."""
     total = int(-(-n // world_size)) * world_size
     idx = list(range(n))
-    idx += idx[:total - n]
+    if n > 0:
+        idx = (idx * (-(-total // n)))[:total]      # (wrapping as often as needed: n < world_size / 2 leaves no rank empty)
+    assert len(idx) == total or n == 0
     return idx[rank:total:world_size]
 
 
@@ -149,12 +151,15 @@ def _test_on(model, dataset, indices, rescale, to_device, imgs_per_gpu=1):
     backbone / neck / head / decode / NMS mixes the images of a batch)."""
     model.eval()
     results, i = [], 0
+    carried = None                 # the sample that ended the previous group (loaded once)
     while i < len(indices):
-        data = dataset[indices[i]]
+        data = carried if carried is not None else dataset[indices[i]]
+        carried = None
         group = [data]
         while (imgs_per_gpu > 1 and len(group) < imgs_per_gpu and i + len(group) < len(indices) and len(data['img']) == 1):
             nxt = dataset[indices[i + len(group)]]
             if len(nxt['img']) != 1 or nxt['img'][0].shape != data['img'][0].shape:
+                carried = nxt
                 break
             group.append(nxt)
         with torch.no_grad():
@@ -190,6 +195,9 @@ def collect_results(result_part, size, group=None):
     dist.gather_object(result_part, parts, dst=0, group=group)
     if rank != 0:
         return None
+    if len(set(len(p) for p in parts)) != 1:
+        raise RuntimeError('ranks returned different numbers of results: %s (the shards of test_shard are equally long)'
+                           % [len(p) for p in parts])
     ordered = []
     for res in zip(*parts):          # (every rank holds the same number of samples: the index list was padded)
         ordered.extend(list(res))
@@ -317,7 +325,18 @@ class GraphedTrainStep(object):
                 self._lr_last = lr
             self.graph.replay()
         self.steps += 1
+        # the replayed kernels wrote the parameters through raw pointers: the version counters did not move, and the inference-time
+        # copies derived from the weights (conv1x1._cast_cache, the folded backbone, the packed deformable operands) are keyed on them
+        self._stale_caches = True
         return self.out
+
+    def refresh_inference_caches(self):
+        """after replays, before an evaluation pass of the same model: drops every derived copy of the stepped weights (also done
+        by ``model.eval()`` / ``model.train()`` of the detector, detector.py)"""
+        if getattr(self, '_stale_caches', False):
+            from . import conv1x1
+            conv1x1.invalidate_inference_caches()
+            self._stale_caches = False
 
     def sync_optimizer_state(self):
         if self.fused is not None:

@@ -302,3 +302,29 @@ def test_bench_two_rank_rehearsal_completes(mode):
     assert d['rehearsal'] is True and d['n_gpus'] == 2 and d['value'] > 0 and d['config']['parallelism'] == 'dp2'
     if mode == 'train':
         assert d['allreduce']['buckets'] >= 6 and 'exact_fp32' not in d and 'graphed_step' not in d and 'inference' not in d
+
+
+def test_bench_two_ranks_over_rccl_when_the_box_has_two_gpus():
+    """`python bench.py --gpus 2` over RCCL -- the real thing the driver's SCALE run starts: two processes, two devices,
+    `init_process_group('nccl')`, the weight broadcast, the bucketed exchange under backward, MAX-reduced windows.  Skipped on the
+    one-GPU boxes of this pool; on an 8-GPU driver box it is the first time RCCL sees a peer, BEFORE the scaling bench does
+    (round-5 review, item 7)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs (RCCL refuses two ranks on one device)')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MIOPEN_USER_DB_PATH',
+                                                            'KGDET_BENCH_REHEARSAL')}
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '3',
+                          '--windows', '2', '--preheat-s', '0', '--no-roofline', '--no-cpu-baseline'],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    d = json.loads([l for l in res.stdout.decode().splitlines() if l.startswith('{')][-1])
+    assert 'rehearsal' not in d and d['n_gpus'] == 2 and d['value'] > 0 and d['config']['parallelism'] == 'dp2'
+    ar = d['allreduce']
+    assert ar['payload_MB'] > 200 and ar['ms'] > 0 and ar['buckets'] >= 6
+    assert ar['buckets_issued_inside_backward_per_step'] >= ar['buckets'] - 1
+    assert 'exact_fp32' not in d and 'graphed_step' not in d and 'inference' not in d      # (legs of a one-rank run)

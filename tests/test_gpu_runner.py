@@ -163,3 +163,40 @@ def test_graphed_train_step_captures_a_batch_of_mixed_shapes():
         h2.step(m2, o2, o['loss'])
     torch.cuda.synchronize()
     assert abs(float(out['loss']) - losses[-1]) <= 2e-3 * abs(losses[-1]), (float(out['loss']), losses)
+
+
+def test_eval_after_graph_replays_sees_the_stepped_weights():
+    """ADVICE (round 5): a replayed training graph steps the weights through raw pointers -- no version counter moves -- and the
+    autocast cast cache / folded backbone / packed deformable operands are keyed on those counters.  replay -> eval under autocast ->
+    replay -> eval must give what a FRESH model holding the same weights gives (the detector's train() / eval() drop the caches)."""
+    from kgdet_amd import build_detector, configs, synthetic
+    make, batch = _graph_case('kgdet')
+    m1, o1, h1 = make()
+    o1.param_groups[0]['lr'] = 1e-3          # (steps large enough to change detections' scores)
+    g = rn.GraphedTrainStep(m1, o1, h1, batch, warmup=2)
+
+    def evaluate(model):
+        model.eval()
+        with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+            feats = model.extract_feat(batch['img'])
+            outs = model.bbox_head(feats, batch['img_meta'])
+        model.train()
+        return [o[0].float().clone() for o in outs]
+
+    g.step()
+    first = evaluate(m1)
+    for _ in range(3):
+        g.step()
+    torch.cuda.synchronize()
+    second = evaluate(m1)
+    cfg = configs.kgdet_r50_fpn()
+    fresh = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda()
+    fresh.load_state_dict(m1.state_dict())
+    want = evaluate(fresh)
+    # (bf16 autocast; two model objects may settle on different per-shape kernels, so single elements differ by a bf16 rounding --
+    # stale casts of the weights from three Adam steps earlier move EVERY output, by far more)
+    for a, b, c in zip(first, second, want):
+        stale, fresh_dev = float((a - c).abs().mean()), float((b - c).abs().mean())
+        assert stale > 0, 'three more steps must change the outputs'
+        assert fresh_dev <= 0.05 * stale, (fresh_dev, stale)
+        torch.testing.assert_close(b, c, rtol=1.6e-2, atol=1.6e-2 * float(c.abs().max()))

@@ -18,6 +18,7 @@ for t in xs + offs:
     t.requires_grad_(which in ('grad_input', 'grad_offset'))
 for t in [w for wl in ws for w in wl]:
     t.requires_grad_(which in ('grad_weight', 'forward'))
+dcn.MEASUREMENT = True
 _lib.check(_lib.lib().kgdet_set_option(3, {'grad_weight': 0, 'forward': 0, 'grad_input': 1, 'grad_offset': 2}[which]), 'opt')
 gos = None
 for _ in range(iters):
