@@ -585,7 +585,9 @@ def test_grad_input_with_trained_head_offsets(case):
         return e0.elapsed_time(e1) / 10
     t_rand, t_key = timed(to_rand), timed(to_key)
     # (measured 1.3-1.6x: the pre-aggregation reads every contribution's 1 KB row of grad_out once; rounds 2-3: 6-7x)
-    assert t_key < 2.0 * t_rand, 'grad_input depends on the offset distribution again: %.3f ms vs %.3f ms' % (t_key, t_rand)
+    # (round 6: the random-offset call got faster -- builders fused, 39 -> 24 us -- the trained one did not: its hot clusters' row reads
+    # are what is left, profiles/r06_dcn_bwd_plane_kernels.md; the bound guards against the list walk coming back, not the ratio's decimals)
+    assert t_key < 2.6 * t_rand, 'grad_input depends on the offset distribution again: %.3f ms vs %.3f ms' % (t_key, t_rand)
 
 
 @pytest.mark.parametrize('case', [c for c in CASES if c[10] == 1 and c[9] == 1 and c[4] <= 256 and _plane_map(c)] +
