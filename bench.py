@@ -172,7 +172,7 @@ import torch.distributed as dist  # noqa: E402
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md); AMD's 5 PF figure includes 2:1 sparsity
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0
-ROOFLINE_PROFILE = {2: 'profiles/r05_dcn_fwd_plane_group_b2.md', 8: 'profiles/r05_dcn_fwd_plane_group_b8_bf16.md'}
+ROOFLINE_PROFILE = {2: 'profiles/r06_dcn_fwd_plane_group_b2.md', 8: 'profiles/r06_dcn_fwd_plane_group_b8_bf16.md'}
 BACKWARD_PROFILE = 'profiles/r06_dcn_bwd_plane_kernels.md'
 
 
