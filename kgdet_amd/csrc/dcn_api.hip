@@ -347,7 +347,8 @@ int launch_offset_pair(const DcnFwdGroup &grp, int G, void *workspace, int max_K
 }
 struct InvTables {
   size_t rec_bytes, hdr_bytes, cell_bytes, spill_bytes;
-  size_t total() const { return rec_bytes + hdr_bytes + cell_bytes + spill_bytes; }
+  size_t hot_cols_bytes, hot_count_bytes;   // the hot cells' column list (dcn_hot_gemm)
+  size_t total() const { return rec_bytes + hdr_bytes + cell_bytes + spill_bytes + hot_cols_bytes + hot_count_bytes; }
 };
 InvTables inv_tables(const kgdet_dcn_shape *s, const Derived &d) {   // of ONE deformable group (functions of the offsets alone)
   InvTables t;
@@ -356,6 +357,8 @@ InvTables inv_tables(const kgdet_dcn_shape *s, const Derived &d) {   // of ONE d
   t.hdr_bytes = align_up((size_t)s->N * d.K * sizeof(int), 64);
   t.cell_bytes = align_up((size_t)s->N * d.K * slots * sizeof(DcnInvOvfCell), 64);
   t.spill_bytes = (size_t)s->N * d.K * 4 * d.Ho * d.Wo * 8;
+  t.hot_cols_bytes = align_up((size_t)s->N * kHotMaxCols * sizeof(int4), 256);
+  t.hot_count_bytes = align_up((size_t)s->N * sizeof(int), 256);
   return t;
 }
 size_t inv_tables_all(const kgdet_dcn_shape *s, const Derived &d) { return s->deformable_groups * align_up(inv_tables(s, d).total(), 256); }
@@ -898,7 +901,7 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
     sg.n = 0;
     for (int dgi = 0; dgi < s->deformable_groups; ++dgi) {
       if (sg.n == kMaxFwdGroup) {
-        sg.sched.on = 0;
+        sg.sched.on = 0; sg.hot_gemm = 0;
         hipLaunchKernelGGL(dcn_inv_overflow_sums, dim3(s->N * d.K, kInvSumSplit, sg.n), dim3(256), 0, (hipStream_t)stream, sg);
         sg.n = 0;
       }
@@ -908,7 +911,7 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
                                (float *)(sums_base + (size_t)dgi * inv_gov_bytes(s, d)), s->N * d.K, d.K, d.Ho * d.Wo, s->O,
                                d.Og, d.Og_pad16, gov_ld, gov_slots, s->W};
     }
-    sg.sched.on = 0;
+    sg.sched.on = 0; sg.hot_gemm = 0;
     hipLaunchKernelGGL(dcn_inv_overflow_sums, dim3(s->N * d.K, kInvSumSplit, sg.n), dim3(256), 0, (hipStream_t)stream, sg);
   }
   const int G = grid_size();
@@ -1076,6 +1079,16 @@ static int grad_offset_plane(const kgdet_dcn_shape *s, const float *input, const
   return KGDET_OK;
 }
 
+// test hook: with KGDET_DCN_HOT_DEBUG=1 in the environment, the grouped backward copies (synchronously, before its second phase
+// reuses the tables) how many hot cells its builder handed to dcn_hot_gemm, per (distinct offset tensor, image) in launch order; this
+// returns the last call's counts (raw: values above kHotMaxCols mean the rest went the cluster path).
+namespace { struct HotDbg { const int *ptr[kMaxFwdGroup]; int N[kMaxFwdGroup]; int n; int vals[64]; int n_vals; }; HotDbg g_hot_dbg = {}; }
+int kgdet_debug_dcn_hot_columns(int *out, int max_out) {
+  int w = 0;
+  for (; w < g_hot_dbg.n_vals && w < max_out; ++w) out[w] = g_hot_dbg.vals[w];
+  return w;
+}
+
 // n v1 problems: grad_input of all of them in one dcn_bwd_input_plane launch, grad_offset of all of them in one
 // dcn_bwd_offset_plane launch (inverse / gradient records are built once per distinct offset tensor).
 int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *const *shapes, const float *const *inputs,
@@ -1155,6 +1168,45 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
   int pm_px = 0, pm_c = 0, pm_images = 0;
   DcnInvSumGroup sums;         // the long cells' sums of every problem, one launch
   sums.n = 0;
+  // (problem, image) groups onto XCDs, largest first onto the least loaded one (DcnInvSumSched): the sums kernel and the hot-cell GEMM
+  // both read a group's 1 MB pixel-major grad_output from one XCD's L2
+  int sched_longest = 0;
+  {
+    static const bool xcd_off = getenv("KGDET_DCN_SUMS_XCD") && atoi(getenv("KGDET_DCN_SUMS_XCD")) == 0;   // A/B switch
+    DcnInvSumSched &sc = sums.sched;
+    sc.on = 0;
+    int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int x = 0; x < 8; ++x) sc.n_seg[x] = 0;
+    struct G_ { int z, b, units; } gs[kMaxFwdGroup * 64];
+    int ng = 0;
+    bool fits = !xcd_off;
+    for (int z = 0; z < n && fits; ++z)
+      for (int b = 0; b < shapes[z]->N && fits; ++b) {
+        if (ng >= kMaxFwdGroup * 64) { fits = false; break; }
+        gs[ng++] = G_{z, b, dd[z].K * kInvSumSplit};
+      }
+    std::stable_sort(gs, gs + ng, [](const G_ &a, const G_ &b) { return a.units > b.units; });
+    for (int i = 0; i < ng && fits; ++i) {
+      int x = 0;
+      for (int y = 1; y < 8; ++y) if (load[y] < load[x]) x = y;
+      if (sc.n_seg[x] >= kInvSumSegs) { fits = false; break; }
+      sc.seg[x][sc.n_seg[x]++] = DcnInvSumSeg{gs[i].z, gs[i].b, load[x], gs[i].units};
+      load[x] += gs[i].units;
+    }
+    if (fits) {
+      sc.on = 1;
+      for (int x = 0; x < 8; ++x) sched_longest = load[x] > sched_longest ? load[x] : sched_longest;
+    }
+  }
+  static const bool hot_off = getenv("KGDET_DCN_HOT_GEMM") && atoi(getenv("KGDET_DCN_HOT_GEMM")) == 0;   // A/B switch
+  bool hot_ok = !hot_off;       // hot cells (> 64 contributions) as one GEMM per (problem, image): dcn_hot_gemm
+  g_hot_dbg.n = 0; g_hot_dbg.n_vals = 0;
+  // (test switch: a shorter column list, to reach the overflow rule with small kernels)
+  const int hot_max = getenv("KGDET_DCN_HOT_MAX_COLS") ? std::max(32, std::min(kHotMaxCols, atoi(getenv("KGDET_DCN_HOT_MAX_COLS")))) : kHotMaxCols;
+  hot_ok = hot_ok && sums.sched.on;   // (its workgroups follow the same XCD schedule)
+  for (int i = 0; i < n; ++i) hot_ok = hot_ok && inv_gov_ld(shapes[i], dd[i]) == shapes[i]->O;
+  DcnHotGemmGroup hotg;
+  hotg.n = 0;
   int sums_blocks = 0;
   for (int i = 0; i < n; ++i) {
     const kgdet_dcn_shape *s = shapes[i];
@@ -1172,14 +1224,27 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
                                          d.Ho * d.Wo, (long long)O_total_ * d.Ho * d.Wo};
       pm_px = d.Ho * d.Wo > pm_px ? d.Ho * d.Wo : pm_px; pm_c = s->O > pm_c ? s->O : pm_c; pm_images += s->N;
       sums.e[sums.n++] = DcnInvSum{hdr, cells, spill, gout_t, gov, s->N * d.K, d.K, d.Ho * d.Wo, s->O, d.Og, d.Og_pad16,
-                                   inv_gov_ld(s, d), dcn_inv_max_slots(s->H * s->W, d.Ho * d.Wo), s->W};
+                                   inv_gov_ld(s, d), dcn_inv_max_slots(s->H * s->W, d.Ho * d.Wo), s->W, nullptr, 0};
       sums_blocks = s->N * d.K > sums_blocks ? s->N * d.K : sums_blocks;
+      const int src = same_as[i] < 0 ? i : same_as[i];    // (the column list lives with the offset tensor's records)
+      const InvTables its = inv_tables(shapes[src], dd[src]);
+      unsigned char *hot = tab + inv_off[src] + its.rec_bytes + its.hdr_bytes + its.cell_bytes + its.spill_bytes;
+      hotg.e[hotg.n++] = DcnHotGemm{(const int4 *)hot, (const int *)(hot + its.hot_cols_bytes), spill, gout_t, gov, s->N, d.K,
+                                    d.Ho * d.Wo, s->O, inv_gov_ld(s, d), dcn_inv_max_slots(s->H * s->W, d.Ho * d.Wo), hot_max};
+      if (hot_ok) { sums.e[sums.n - 1].hot_count = (const int *)(hot + its.hot_cols_bytes); sums.e[sums.n - 1].hot_max = hot_max; }
     }
     if (same_as[i] < 0) {   // (all distinct offset tensors of the group: one builder launch below)
       DcnInvBuild &e = builds.e[builds.n++];
       fill_problem(s, d, 0, e.p);
       e.p.offset = offsets[i]; e.p.mask = nullptr;
       e.inv = inv; e.hdr = hdr; e.cells = cells; e.spill = spill;
+      e.hot_cols = hot_ok ? (int4 *)(tab + inv_off[i] + it.rec_bytes + it.hdr_bytes + it.cell_bytes + it.spill_bytes) : nullptr;
+      e.hot_count = hot_ok ? (int *)(tab + inv_off[i] + it.rec_bytes + it.hdr_bytes + it.cell_bytes + it.spill_bytes + it.hot_cols_bytes) : nullptr;
+      e.hot_max = hot_max;
+      if (hot_ok) {
+        KGDET_HIP_TRY(hipMemsetAsync(e.hot_count, 0, (size_t)s->N * sizeof(int), (hipStream_t)stream));
+        if (g_hot_dbg.n < kMaxFwdGroup) { g_hot_dbg.ptr[g_hot_dbg.n] = e.hot_count; g_hot_dbg.N[g_hot_dbg.n++] = s->N; }
+      }
       const int blocks = s->N * d.K;
       build_blocks = blocks > build_blocks ? blocks : build_blocks;
       const size_t need = dcn_build_inverse_taps_lds_bytes(s->H * s->W, d.Ho * d.Wo);
@@ -1251,36 +1316,27 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
       hipLaunchKernelGGL(dcn_gout_pixel_major_multi, dim3(pm_bx, pm_by, pm_images), dim3(256), 0, (hipStream_t)stream, pmg);
     }
   }
-  {   // (problem, image) groups onto XCDs, largest first onto the least loaded one (DcnInvSumSched)
-    static const bool xcd_off = getenv("KGDET_DCN_SUMS_XCD") && atoi(getenv("KGDET_DCN_SUMS_XCD")) == 0;   // A/B switch
-    DcnInvSumSched &sc = sums.sched;
-    sc.on = 0;
-    int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int x = 0; x < 8; ++x) sc.n_seg[x] = 0;
-    struct G_ { int z, b, units; } gs[kMaxFwdGroup * 64];
-    int ng = 0;
-    bool fits = !xcd_off;
-    for (int z = 0; z < sums.n && fits; ++z)
-      for (int b = 0; b < shapes[z]->N && fits; ++b) {
-        if (ng >= kMaxFwdGroup * 64) { fits = false; break; }
-        gs[ng++] = G_{z, b, sums.e[z].K * kInvSumSplit};
-      }
-    std::stable_sort(gs, gs + ng, [](const G_ &a, const G_ &b) { return a.units > b.units; });
-    for (int i = 0; i < ng && fits; ++i) {
-      int x = 0;
-      for (int y = 1; y < 8; ++y) if (load[y] < load[x]) x = y;
-      if (sc.n_seg[x] >= kInvSumSegs) { fits = false; break; }
-      sc.seg[x][sc.n_seg[x]++] = DcnInvSumSeg{gs[i].z, gs[i].b, load[x], gs[i].units};
-      load[x] += gs[i].units;
+  sums.hot_gemm = hot_ok ? 1 : 0;
+  if (hot_ok) {
+    static thread_local bool hot_attr = false;
+    if (!hot_attr) {
+      KGDET_HIP_TRY(hipFuncSetAttribute((const void *)dcn_hot_gemm, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)dcn_hot_gemm_lds_bytes()));
+      hot_attr = true;
     }
-    if (fits) {
-      sc.on = 1;
-      int longest = 0;
-      for (int x = 0; x < 8; ++x) longest = load[x] > longest ? load[x] : longest;
-      hipLaunchKernelGGL(dcn_inv_overflow_sums, dim3(8 * longest), dim3(256), 0, (hipStream_t)stream, sums);
-    } else {
-      hipLaunchKernelGGL(dcn_inv_overflow_sums, dim3(sums_blocks, kInvSumSplit, sums.n), dim3(256), 0, (hipStream_t)stream, sums);
-    }
+    hipLaunchKernelGGL(dcn_hot_gemm, dim3(8 * kHotBlocksPerXcd), dim3(512), dcn_hot_gemm_lds_bytes(), (hipStream_t)stream, hotg,
+                       sums.sched);
+  }
+  if (sums.sched.on) {
+    hipLaunchKernelGGL(dcn_inv_overflow_sums, dim3(8 * sched_longest), dim3(256), 0, (hipStream_t)stream, sums);
+  } else {
+    hipLaunchKernelGGL(dcn_inv_overflow_sums, dim3(sums_blocks, kInvSumSplit, sums.n), dim3(256), 0, (hipStream_t)stream, sums);
+  }
+  if (g_hot_dbg.n > 0 && getenv("KGDET_DCN_HOT_DEBUG") && atoi(getenv("KGDET_DCN_HOT_DEBUG")) == 1) {   // (test hook, see above)
+    KGDET_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    for (int i = 0; i < g_hot_dbg.n; ++i)
+      for (int b = 0; b < g_hot_dbg.N[i] && g_hot_dbg.n_vals < 64; ++b)
+        KGDET_HIP_TRY(hipMemcpy(&g_hot_dbg.vals[g_hot_dbg.n_vals++], g_hot_dbg.ptr[i] + b, sizeof(int), hipMemcpyDeviceToHost));
   }
   hipLaunchKernelGGL(dcn_bwd_input_plane<2>, dim3(Gs), dim3(dcn_fwd_plane_threads()), lds, (hipStream_t)stream, grp,
                      (float *)workspace);

@@ -49,10 +49,14 @@ size_t dcn_bwd_input_plane_lds_bytes(int parts, int plane_pixels) {
 // insertion-sorted every list -- quadratic in a cell's length -- and the builder of a head stage went from 37 to 118 us
 // while the training step's offsets concentrated).
 // ------------------------------------------------------------------------------------------------
+#ifndef KGDET_HOT_MIN
+#define KGDET_HOT_MIN 64   // contributions above which a cell becomes a column of dcn_hot_gemm
+#endif
 template <int THREADS>
 __device__ __forceinline__ void build_inverse_taps_body(const DcnProblem &p, uint4 *__restrict__ inv, int *__restrict__ hdr,
                                                         DcnInvOvfCell *__restrict__ cells, int2 *__restrict__ spill,
-                                                        int block, int *sm) {
+                                                        int block, int *sm, int4 *__restrict__ hot_cols = nullptr,
+                                                        int *__restrict__ hot_count = nullptr, int hot_max = 0) {
   const int HW = p.H * p.W;
   int *cnt = sm;                                          // [HW + 1]
   int *cursor = sm + (HW + 1);                            // [HW]
@@ -164,7 +168,19 @@ __device__ __forceinline__ void build_inverse_taps_body(const DcnProblem &p, uin
     if (long_cell) {
       const int slot = epos[cell];
       off[7] |= kInvFlag | ((unsigned)slot << 17);
-      if (slot < max_slots) cells[bt * max_slots + slot] = DcnInvOvfCell{e0, n, cell, 0};
+      if (slot < max_slots) {
+        // hot cells (> 64 contributions) join the (offset tensor, image)'s column list of dcn_hot_gemm: .pad = 1 (the counter was
+        // zeroed by the launch's memset; the ORDER of the columns is arbitrary, a column's value is not)
+        int handled = 0;
+        if (hot_count != nullptr && n > KGDET_HOT_MIN) {
+          const int idx = atomicAdd(&hot_count[b], 1);
+          if (idx < hot_max) {
+            hot_cols[(size_t)b * kHotMaxCols + idx] = make_int4(t, slot, e0, n);
+            handled = 1;
+          }
+        }
+        cells[bt * max_slots + slot] = DcnInvOvfCell{e0, n, cell, handled};
+      }
     }
     uint4 *r = inv_bt + (size_t)cell * 4;
     r[0] = make_uint4(off[0], off[1], off[2], off[3]);
@@ -192,7 +208,7 @@ __global__ __launch_bounds__(256) void dcn_build_inverse_taps_multi(const DcnInv
   extern __shared__ __attribute__((aligned(16))) int sm[];
   const DcnInvBuild &e = grp.e[blockIdx.y];
   if ((int)blockIdx.x >= e.p.N * e.p.K) return;
-  build_inverse_taps_body<256>(e.p, e.inv, e.hdr, e.cells, e.spill, (int)blockIdx.x, sm);
+  build_inverse_taps_body<256>(e.p, e.inv, e.hdr, e.cells, e.spill, (int)blockIdx.x, sm, e.hot_cols, e.hot_count, e.hot_max);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -240,14 +256,17 @@ __global__ __launch_bounds__(256) void dcn_inv_overflow_sums(const DcnInvSumGrou
   // the (image, tap)'s long cells, once, into LDS (round 6: the loops below read them one dependent global load at a time -- the
   // medium-cell loop in every wave, the cluster rule in ONE thread: with converged key points that serial chain, not the row reads,
   // was the kernel's time: 134 us per head stage whatever XCD the rows came from)
+  // (an image with more hot cells than the column list holds goes through the cluster path WHOLE: which cells made the list depends on
+  // the order the builder's workgroups ran in, and the two paths sum in different orders)
+  const bool hot_on = grp.hot_gemm && e.hot_count != nullptr && e.hot_count[b] <= e.hot_max;
   constexpr int kMaxCells = 4 * kPlaneMaxHW / (kInvInline + 1) + 8;
   __shared__ int c_start[kMaxCells];
-  __shared__ short c_n[kMaxCells], c_cell[kMaxCells];
+  __shared__ short c_n[kMaxCells], c_cell[kMaxCells];   // (c_n < 0: the cell's sum is formed by dcn_hot_gemm)
   const int n_cells = count < kMaxCells ? count : kMaxCells;
   for (int i = tid; i < n_cells; i += 256) {
     const DcnInvOvfCell c = e.cells[(size_t)bt * e.max_slots + i];
     c_start[i] = c.start;
-    c_n[i] = (short)c.n;
+    c_n[i] = (short)((hot_on && c.pad) ? -1 : c.n);
     c_cell[i] = (short)c.cell;
   }
   __syncthreads();
@@ -264,7 +283,7 @@ __global__ __launch_bounds__(256) void dcn_inv_overflow_sums(const DcnInvSumGrou
     int small_idx = 0;
     for (int slot = uy; slot < n_cells; slot += kInvSumSplit) {
       const DcnInvOvfCell c = {c_start[slot], (int)c_n[slot], (int)c_cell[slot], 0};
-      if (c.n > 64) continue;
+      if (c.n > 64 || c.n < 0) continue;
 #ifdef KGDET_SUMS_ABL_NOMEDIUM
       continue;
 #endif
@@ -457,6 +476,194 @@ __global__ __launch_bounds__(256) void dcn_inv_overflow_sums(const DcnInvSumGrou
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Hot cells as a GEMM (round 6).  With converged key points every (image, tap) has a handful of cells that collect hundreds of
+// contributions each, and the cluster path above reads every contributing pixel's 1 KB row of grad_out once per cluster: the same
+// ~1050 rows for every tap of an image, 349 MB per head stage at ~8 TB/s of L2 hits + 357 M lane-FMAs (tools/experiments/README.md,
+// round 6).  Here the hot cells of ALL taps of an (offset tensor, image) are columns of one product over the pixels,
+//     Gov[(t, slot)][o] = sum_px Wd[col][px] * grad_out[o][px],       Wd[col][px] = the cell's weight for pixel px (0: none),
+// rows read once per 32 columns: v_mfma_f32_32x32x16_bf16 on hi / lo parts split on the fly (3 products, fp32 accumulate: the
+// arithmetic of the plane kernels).  The inverse-record builder lists the hot cells as it meets them (one atomic counter per (offset
+// tensor, image): the ORDER of the columns is arbitrary, every column's value is not) and marks them handled.  A cell is hot above 64
+// contributions, so a tap has at most 4 HoWo / 65 of them: kHotMaxCols = 4096 holds every image of a 7x7 kernel on a plane-sized map;
+// an image that overflows the list (larger kernels) takes the cluster path whole.  dcn_hot_gemm: workgroup = (32-column tile,
+// 128-channel part) of a (problem, image), placed on the XCD that the sums kernel reads that image's grad_output on; the workgroup
+// scatters its columns' weights into a dense LDS tile [32][pixels] (the A operand), its eight waves split the k-steps, and the eight
+// partial tiles are summed in a fixed order.  Deterministic.
+// ------------------------------------------------------------------------------------------------
+size_t dcn_hot_gemm_lds_bytes() { return (size_t)32 * kHotRowLd * sizeof(float); }
+
+__global__ __launch_bounds__(512) void dcn_hot_gemm(const DcnHotGemmGroup grp, const DcnInvSumSched sched) {
+  typedef __bf16 bf16x8h __attribute__((ext_vector_type(8)));
+  extern __shared__ __attribute__((aligned(16))) float a_tile[];    // [32 columns][kHotRowLd]: by-pixel weights of the tile's cells
+  __shared__ int s_bt[32], s_slot[32];
+  // workgroup L runs on XCD L % 8: it takes the units (32-column tile, 128-channel part) r, r + 32, ... of that XCD's (problem, image)
+  // groups laid end to end (how many units a group has is known only here: the builder counted its hot cells)
+  const int xcd = (int)blockIdx.x & 7, r = (int)blockIdx.x >> 3, tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, kb = lane >> 5;
+  // a wave: all 128 channels of the unit x an eighth of the k-steps.  Lane (r32, kb) reads, per pixel, the FOUR channels 4 r32 .. 4 r32 + 3
+  // with one 16-byte load (a wave load instruction costs the texture addresser 16 cycles whatever its width: with 4-byte loads that
+  // rate, not the arithmetic, set the kernel's time), so the unit's four 32-wide MFMA blocks are the channels {4 n + c}, c = 0 .. 3.
+  auto split = [](const float *v, bf16x8h &hi, bf16x8h &lo) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      hi[j] = (__bf16)v[j];
+      lo[j] = (__bf16)(v[j] - (float)hi[j]);
+    }
+  };
+  int counts[kInvSumSegs];                            // (all of the XCD's groups at once: one memory latency, not one per group)
+#pragma unroll
+  for (int si = 0; si < kInvSumSegs; ++si)
+    counts[si] = si < sched.n_seg[xcd] ? grp.e[sched.seg[xcd][si].z].count[sched.seg[xcd][si].b] : 0;
+  int base = 0;
+  for (int si = 0; si < sched.n_seg[xcd]; ++si) {
+    const DcnHotGemm &e = grp.e[sched.seg[xcd][si].z];
+    const int b = sched.seg[xcd][si].b;
+    const int count = counts[si] <= e.max_cols ? counts[si] : 0;     // (too many for the list: the image takes the cluster path whole)
+    const int o_parts = (e.O + 127) / 128;
+    const int units = (count + 31) / 32 * o_parts;
+    const int HoWo = e.HoWo, O = e.O;
+    const dcn_rsrc_t g_rsrc = dcn_make_rsrc(e.gout_t + (size_t)b * HoWo * O);
+    for (int u = ((r - base) % kHotBlocksPerXcd + kHotBlocksPerXcd) % kHotBlocksPerXcd; u < units; u += kHotBlocksPerXcd) {
+      const int tile = u / o_parts, oh = u - tile * o_parts;
+      const int col0 = tile * 32;
+      const int oc = oh * 128 + 4 * r32;               // the lane's four channels
+      // the tile's cells (for the scatter: 16 threads per column)
+      const int4 my_col = (col0 + (tid >> 4) < count) ? e.cols[(size_t)b * kHotMaxCols + col0 + (tid >> 4)] : make_int4(0, 0, 0, 0);
+      __syncthreads();                                 // (the previous unit's reads of the tile and of s_bt are done)
+      if (tid < 32) {
+        const int4 c = e.cols[(size_t)b * kHotMaxCols + min(col0 + tid, count - 1)];
+        s_bt[tid] = b * e.K + c.x;
+        s_slot[tid] = c.y;
+      }
+      f32x16 acc[4];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+      const unsigned row_bytes = (unsigned)O * 4u;
+      const unsigned ch = (unsigned)min(oc, O - 4) * 4u;   // (channels past O: computed, not stored)
+      const unsigned voff = (unsigned)(8 * kb) * row_bytes + ch;
+      for (int pk0 = 0; pk0 < HoWo; pk0 += kHotRange) {   // (maps of up to kHotRange pixels: one pass)
+        const int len = min(HoWo - pk0, kHotRange);
+        const int nsteps = (len + 15) >> 4;
+        // k-steps of 16 pixels: A from the LDS tile (lane = column r32, pixels 8 kb .. 8 kb + 7), B = the pixel-major grad_output
+        // through buffer loads (lane offset + a scalar offset per pixel row: no vector address arithmetic); the loads of kHotAhead
+        // steps are in flight while the previous kHotAhead steps multiply.  Only the last step of a map can hold pixels past its
+        // end: that one clamps per lane and reads them as zeros; steps past the range are skipped.
+#ifndef KGDET_HOT_AHEAD
+#define KGDET_HOT_AHEAD 1
+#endif
+        constexpr int kHotAhead = KGDET_HOT_AHEAD;
+        // (the first steps' loads go out before the tile is built: they do not depend on it)
+        const float *arow = a_tile + r32 * kHotRowLd + 8 * kb;
+        const int full_steps = len >> 4;
+        auto load_b = [&](int ks, u32x4_t *v) __attribute__((always_inline)) {
+          if (ks < full_steps) {
+            const unsigned s0 = (unsigned)(pk0 + ks * 16) * row_bytes;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = dcn_buf_b128(g_rsrc, voff, s0 + j * row_bytes);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int px = pk0 + ks * 16 + 8 * kb + j;
+              const bool in = px < HoWo && ks < nsteps;
+              const u32x4_t x = dcn_buf_b128(g_rsrc, (unsigned)min(px, HoWo - 1) * row_bytes + ch, 0);
+              v[j] = in ? x : u32x4_t{0u, 0u, 0u, 0u};
+            }
+          }
+        };
+        u32x4_t cur[kHotAhead][8], nxt[kHotAhead][8];
+#pragma unroll
+        for (int q = 0; q < kHotAhead; ++q) load_b(wave + 8 * q, cur[q]);
+        if (pk0 > 0) __syncthreads();
+        {
+          float4 *z = reinterpret_cast<float4 *>(a_tile);
+          for (int i = tid; i < 32 * kHotRowLd / 4; i += 512) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        {   // scatter: a pixel contributes at most once to a cell, so no two entries of a column share a slot
+          const int2 *sp = e.spill + ((size_t)b * e.K + my_col.x) * 4 * HoWo + my_col.z;
+          float *row = a_tile + (tid >> 4) * kHotRowLd;
+          const int sub = tid & 15, n = my_col.w;
+#ifdef KGDET_HOT_ABL_NOSCATTER
+          if (n > 100000)
+#endif
+          for (int i0 = sub; i0 < n; i0 += 16 * 8) {
+            int2 en[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) en[q] = (i0 + 16 * q < n) ? sp[i0 + 16 * q] : make_int2(-1, 0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int px = en[q].x - pk0;
+              if (en[q].x >= 0 && px >= 0 && px < len) row[px] = __int_as_float(en[q].y);
+            }
+          }
+        }
+        __syncthreads();
+#ifdef KGDET_HOT_ABL_NOGEMM
+        if (nsteps > 100000)
+#endif
+        for (int ks = wave; ks < nsteps; ks += 8 * kHotAhead) {
+#pragma unroll
+          for (int q = 0; q < kHotAhead; ++q) load_b(ks + 8 * (kHotAhead + q), nxt[q]);
+#pragma unroll
+          for (int q = 0; q < kHotAhead; ++q) {
+            const int k = ks + 8 * q;
+            if (k >= nsteps) break;                        // (wave-uniform)
+            float a[8];
+            const float4 a_lo = *reinterpret_cast<const float4 *>(arow + k * 16);
+            const float4 a_hi = *reinterpret_cast<const float4 *>(arow + k * 16 + 4);
+            a[0] = a_lo.x; a[1] = a_lo.y; a[2] = a_lo.z; a[3] = a_lo.w; a[4] = a_hi.x; a[5] = a_hi.y; a[6] = a_hi.z; a[7] = a_hi.w;
+            bf16x8h ah, al, bh, bl;
+            split(a, ah, al);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              float v[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = __uint_as_float(cur[q][j][c]);
+              split(v, bh, bl);
+              acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[c], 0, 0, 0);
+              acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[c], 0, 0, 0);
+              acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[c], 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < kHotAhead; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cur[q][j] = nxt[q][j];
+        }
+      }
+      // the eight k-parts, summed in a fixed order through the (now free) tile: part[w][c][i][lane]; wave w sums and stores the
+      // accumulator rows 2 w, 2 w + 1 of every block
+      __syncthreads();
+      float *part = a_tile;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) part[((wave * 4 + c) * 16 + i) * 64 + lane] = acc[c][i];
+      __syncthreads();
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = 2 * wave + ii;
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          v[c] = part[((0 * 4 + c) * 16 + i) * 64 + lane];
+#pragma unroll
+          for (int w = 1; w < 8; ++w) v[c] += part[((w * 4 + c) * 16 + i) * 64 + lane];
+        }
+        const int row = mfma_row(i, lane);
+        if (col0 + row < count && oc < O)
+          *reinterpret_cast<float4 *>(e.gov + ((size_t)s_bt[row] * e.max_slots + s_slot[row]) * e.O_ld + oc) =
+              make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    base += units;
+  }
+}
+
 // grad_out windows [n][O of O_total][P] -> pixel-major copies [n][P][O], several problems in one launch
 // (blockIdx.z = problem * N + image): 32 x 32 tiles through LDS
 __global__ __launch_bounds__(256) void dcn_gout_pixel_major_multi(const DcnPixelMajorGroup grp) {
@@ -495,7 +702,7 @@ __global__ __launch_bounds__(512) void dcn_bwd_input_prepare(const DcnInvBuildGr
     const int y = (int)blockIdx.x / build_blocks, x = (int)blockIdx.x - y * build_blocks;
     const DcnInvBuild &e = grp.e[y];
     if (x >= e.p.N * e.p.K) return;
-    build_inverse_taps_body<512>(e.p, e.inv, e.hdr, e.cells, e.spill, x, sm);
+    build_inverse_taps_body<512>(e.p, e.inv, e.hdr, e.cells, e.spill, x, sm, e.hot_cols, e.hot_count, e.hot_max);
     return;
   }
   // two 32 x 32 tiles per workgroup (one per 256 threads)

@@ -49,6 +49,9 @@ struct DcnInvBuild {
   int *hdr;
   DcnInvOvfCell *cells;
   int2 *spill;
+  int4 *hot_cols;    // nullable: the column list of dcn_hot_gemm, filled by the builder
+  int *hot_count;
+  int hot_max;       // columns the list may take (<= kHotMaxCols)
 };
 struct DcnInvBuildGroup {
   int n;
@@ -65,6 +68,8 @@ struct DcnInvSum {
   float *gov;            // [N * K][max_slots][O_ld], O_ld = groups * Og_pad16
   int NK, K, HoWo, O, Og, Og_pad16, O_ld, max_slots;
   int W;                 // width of the INPUT map (cells q = y * W + x): neighbours of a cell for the cluster rule
+  const int *hot_count;  // nullable: [N] hot cells of the image's offset tensor (dcn_hot_gemm takes them if <= hot_max)
+  int hot_max;
 };
 // XCD-local schedule of the grouped launch: workgroups are dealt to the 8 XCDs round-robin by linear id, so workgroup L runs on XCD
 // L % 8; every (problem, image) -- whose 1 MB pixel-major grad_output all its (tap, split) units read row by row -- is given to ONE
@@ -81,8 +86,28 @@ struct DcnInvSumGroup {
   int n;
   DcnInvSum e[kMaxFwdGroup];
   DcnInvSumSched sched;
+  int hot_gemm;            // cells whose .pad is set are left to dcn_hot_gemm
 };
 __global__ void dcn_inv_overflow_sums(const DcnInvSumGroup grp);
+// HOT cells (more than 64 contributions: the key-point cells of a converged head) as the columns of ONE split-operand GEMM per
+// (problem, image) over the pixels (round 6, dcn_backward_plane.hip): per distinct offset tensor the hot cells of ALL taps are
+// compacted into a column list and their by-pixel weights laid out densely (dcn_hot_build); per problem
+// Gov[(t, slot)][o] = sum_px Wd[col][px] * grad_out[o][px] (dcn_hot_gemm).  dcn_inv_overflow_sums skips the cells marked handled.
+constexpr int kHotMaxCols = 4096;     // columns per (offset tensor, image) the list holds (see dcn_hot_gemm: never exceeded up to 7x7 kernels)
+constexpr int kHotRange = 1152;       // pixels of a map one pass of the GEMM covers (its A tile lives in LDS: 32 rows of
+constexpr int kHotRowLd = kHotRange + 4;   // kHotRowLd floats -- 4 mod 64, so the 16-byte row reads of 16 lanes meet 64 distinct banks)
+struct DcnHotGemm {        // per problem
+  const int4 *cols;        // [N][kHotMaxCols] (tap, slot, start, n), listed by the inverse-record builder
+  const int *count;        // [N]
+  const int2 *spill;       // the builder's contribution lists (pixel, weight bits)
+  const float *gout_t;     // [N][HoWo][O]: the pixel-major grad_output copy of the sums kernel
+  float *gov;              // [N * K][max_slots][O_ld]
+  int N, K, HoWo, O, O_ld, max_slots, max_cols;
+};
+struct DcnHotGemmGroup { int n; DcnHotGemm e[kMaxFwdGroup]; };
+constexpr int kHotBlocksPerXcd = 32;  // one workgroup per CU (its A tile takes most of the LDS)
+__global__ void dcn_hot_gemm(const DcnHotGemmGroup grp, const DcnInvSumSched sched);
+size_t dcn_hot_gemm_lds_bytes();
 struct DcnPixelMajorItem {
   const float *src;
   float *dst;

@@ -4,6 +4,8 @@ Tolerances: the default kernels multiply bf16 hi/lo splits of the fp32 operands 
 accumulate; 'exact' selects the f32-input MFMA kernel); the north-star bar is 1e-3 relative on coordinates.  Here outputs must agree with the float64 oracle to 2e-5 of the output scale and
 with the float32 oracle (reference algorithm, different summation order) to the same bound.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -588,6 +590,80 @@ def test_grad_input_with_trained_head_offsets(case):
     # (round 6: the random-offset call got faster -- builders fused, 39 -> 24 us -- the trained one did not: its hot clusters' row reads
     # are what is left, profiles/r06_dcn_bwd_plane_kernels.md; the bound guards against the list walk coming back, not the ratio's decimals)
     assert t_key < 2.6 * t_rand, 'grad_input depends on the offset distribution again: %.3f ms vs %.3f ms' % (t_key, t_rand)
+
+
+def _hot_columns():
+    import ctypes
+    from kgdet_amd import _lib
+    buf = (ctypes.c_int * 64)()
+    n = _lib.lib().kgdet_debug_dcn_hot_columns(buf, 64)
+    assert n >= 0
+    return [buf[i] for i in range(n)]
+
+
+@pytest.mark.parametrize('H,W,O,points,expect', [
+    (25, 42, 144, 2, 'hot'),       # the head's map; 144 output channels = one full 128-channel part + a 16-channel one
+    (32, 41, 64, 2, 'hot'),        # 1312 pixels: two passes of the GEMM's 1152-pixel range
+    (25, 42, 32, 2, 'over'),       # a column list of 256 (test switch): images with more hot cells take the cluster path whole
+    (25, 42, 48, 0, 'none'),       # random offsets: no hot cells, the GEMM's workgroups find nothing to do
+])
+def test_grouped_backward_hot_cells_go_through_the_gemm(H, W, O, points, expect):
+    """Round 6: in the grouped backward the cells that collect more than 64 contributions (converged key-point offsets) become columns
+    of one dense MFMA GEMM per (problem, image) -- dcn_hot_gemm -- instead of the cluster path of dcn_inv_overflow_sums.  grad_input
+    of the whole group (two maps x 3x3 / 5x5 / 7x7, summed per map by the fix-up) against the float64 oracle, bit-repeatably, with
+    the test hook confirming which path the cells took."""
+    _require_gpu()
+    from kgdet_amd import dcn
+    B, C = 2, 32
+    rng = np.random.default_rng(17)
+    ks = (3, 5, 7)
+    xs = [rng.standard_normal((B, C, H, W)).astype(np.float32) for _ in range(2)]
+    offs = [(rng.standard_normal((B, 2 * k * k, H, W)) * 2).astype(np.float32) for k in ks]
+    if points:
+        gy, gx = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
+        which = (gx * points // W).clip(0, points - 1)
+        for i, k in enumerate(ks):
+            for b in range(B):
+                for t in range(k * k):
+                    ky, kx = rng.uniform(1, H - 2, size=points), rng.uniform(1, W - 2, size=points)
+                    offs[i][b, 2 * t] = ky[which] - (gy - k // 2 + t // k) + 0.03 * offs[i][b, 2 * t]
+                    offs[i][b, 2 * t + 1] = kx[which] - (gx - k // 2 + t % k) + 0.03 * offs[i][b, 2 * t + 1]
+    ws = [[(rng.standard_normal((O, C, k, k)) * 0.05).astype(np.float32) for k in ks] for _ in xs]
+    gos = [rng.standard_normal((B, 3 * O, H, W)).astype(np.float32) for _ in xs]
+
+    def run():
+        os.environ['KGDET_DCN_HOT_DEBUG'] = '1'
+        if expect == 'over':
+            os.environ['KGDET_DCN_HOT_MAX_COLS'] = '256'
+        try:
+            return run_()
+        finally:
+            del os.environ['KGDET_DCN_HOT_DEBUG']
+            os.environ.pop('KGDET_DCN_HOT_MAX_COLS', None)
+
+    def run_():
+        txs = [torch.from_numpy(x).cuda().requires_grad_() for x in xs]
+        tos = [torch.from_numpy(o).cuda().requires_grad_() for o in offs]
+        tws = [[torch.from_numpy(w).cuda().requires_grad_() for w in wl] for wl in ws]
+        outs = dcn.deform_conv_cat_multi(txs, tos, tws, [k // 2 for k in ks], relu=False)
+        torch.autograd.backward(outs, [torch.from_numpy(g).cuda() for g in gos])
+        return [t.grad.clone() for t in txs], _hot_columns()
+    got, cols = run()
+    again, _ = run()
+    assert len(cols) == 3 * B, 'the grouped plane backward (and its hot-cell list) must have run: %r' % (cols,)
+    if expect == 'none':
+        assert max(cols) == 0
+    elif expect == 'hot':
+        assert min(cols) > 0 and max(cols) <= 4096
+    else:
+        assert max(cols) > 256 and min(cols) <= 256, cols       # (the 3x3 tensor's images fit, the 7x7's do not)
+    for i in range(2):
+        assert torch.equal(got[i], again[i]), 'grad_input must be deterministic'
+        ref = np.zeros_like(xs[i], dtype=np.float64)
+        for j, k in enumerate(ks):
+            ref += oracle.deform_conv_backward(xs[i].astype(np.float64), offs[j].astype(np.float64), ws[i][j].astype(np.float64),
+                                               gos[i][:, j * O:(j + 1) * O].astype(np.float64), 1, k // 2, 1, 1, 1)['grad_input']
+        _close(got[i].cpu().numpy(), ref, 5e-5)
 
 
 @pytest.mark.parametrize('case', [c for c in CASES if c[10] == 1 and c[9] == 1 and c[4] <= 256 and _plane_map(c)] +
