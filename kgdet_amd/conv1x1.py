@@ -29,12 +29,19 @@ DIRECT_ODD_MAPS = _os.environ.get('KGDET_DIRECT_ODD_MAPS', '1') == '1'
 ENABLED = True      # False: every dense convolution stays on MIOpen's fp32 kernels (dcn.arithmetic('exact'))
 
 
+# 1x1 convolutions of ANY channel counts (round 6: the head's 13- / 588- / 166-channel output convolutions): the operand images pad
+# a reduction that ends inside a 16-channel chunk with zeros, the kernel re-reads the last channel for them.  0: those stay with
+# the vendor libraries (A/B).
+RAGGED_1X1 = _os.environ.get('KGDET_CONV_RAGGED_1X1', '1') == '1'
+
+
 def applicable(x, weight, stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1):
     k = weight.shape[2]
+    aligned = weight.shape[1] % 16 == 0 and weight.shape[0] % 16 == 0
     return (ENABLED and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
             and weight.shape[2] == weight.shape[3] and k in (1, 3) and tuple(stride) == (1, 1)
             and tuple(padding) == (k // 2, k // 2) and tuple(dilation) == (1, 1) and groups == 1
-            and x.is_contiguous() and weight.shape[1] % 16 == 0 and weight.shape[0] % 16 == 0
+            and x.is_contiguous() and (aligned or (k == 1 and RAGGED_1X1 and (weight.shape[0] * weight.shape[1]) % 2 == 0))
             and ((x.shape[2] * x.shape[3]) % 2 == 0 or DIRECT_ODD_MAPS) and x.shape[2] * x.shape[3] >= 4
             and not torch.is_autocast_enabled())
 
@@ -286,7 +293,7 @@ class step_scope(object):
 
 def forward_images(x, weight):
     """(forward operand image, grad_input operand image or None) of a contiguous weight"""
-    both = PACK_BOTH and x.requires_grad and weight.shape[0] % 16 == 0
+    both = PACK_BOTH and x.requires_grad and (weight.shape[0] % 16 == 0 or weight.shape[2] == 1)
     if both and PACK_MULTI and _token:
         e = _entries.get(id(weight))
         if e is not None and e.ref() is weight and e.ptr == weight.data_ptr():

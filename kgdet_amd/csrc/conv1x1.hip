@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void conv1x1_pack(const float *__restrict__ w,
   const bool f16 = f16_forward && !transpose;     // only the forward image (activations x weights) takes fp16 parts
   f16_saturate_on();
   const int M = transpose ? C : O, K = transpose ? O : C;
-  const int k16s = K / kTK;
+  const int k16s = (K + kTK - 1) / kTK;     // (a 1x1 weight's reduction may end inside a chunk: zeros up to its end)
   const long long total = (long long)((M + kTM - 1) / kTM) * k16s * T * 2 * kTM;   // (mt, k16, t, khalf, row)
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += gridDim.x * 256LL) {
     const int row = (int)(i % kTM);
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void conv1x1_pack(const float *__restrict__ w,
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const long long o = transpose ? k0 + j : m, ch = transpose ? m : k0 + j;
-      v[j] = m < M ? w[(o * C + ch) * T + (transpose ? T - 1 - t : t)] : 0.0f;
+      v[j] = (m < M && k0 + j < K) ? w[(o * C + ch) * T + (transpose ? T - 1 - t : t)] : 0.0f;
     }
     bf16x8 hi, lo;
     if (f16) {
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void conv1x1_pack_multi(const long long *__res
   for (int transpose = 0; transpose < 2; ++transpose) {
     unsigned char *img = reinterpret_cast<unsigned char *>(d[1 + transpose]);
     const int M = transpose ? C : O, K = transpose ? O : C;
-    const int k16s = K / kTK;
+    const int k16s = (K + kTK - 1) / kTK;
     const long long total = (long long)((M + kTM - 1) / kTM) * k16s * T * 2 * kTM;
     if (!transpose && T == 9) {
       // forward image of a 3x3 weight: a lane's row is an output channel, whose 8 channels x 9 taps are 72 CONTIGUOUS floats
@@ -273,8 +273,8 @@ __global__ __launch_bounds__(256) void conv1x1_pack_multi(const long long *__res
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const long long o = transpose ? k0 + j : m, ch = transpose ? m : k0 + j;
-      v[j] = m < M ? w[(o * C + ch) * T + (transpose ? T - 1 - t : t)] : 0.0f;
-      if (scale && m < M) v[j] *= scale[o];
+      v[j] = (m < M && k0 + j < K) ? w[(o * C + ch) * T + (transpose ? T - 1 - t : t)] : 0.0f;
+      if (scale && m < M && k0 + j < K) v[j] *= scale[o];
     }
     bf16x8 hi8, lo8;
     if (f16_forward && !transpose) {
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(128 * NW) void conv_nn(const unsigned char *__restr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
   const int n_local = tid % TN, kq = tid / TN;   // pixel column, quarter of the stage's 16 channels
   const int N = H * W;
-  const int S = TAPS * (K / kTK), per = (S + ksplit - 1) / ksplit;
+  const int S = TAPS * ((K + kTK - 1) / kTK), per = (S + ksplit - 1) / ksplit;
   const int s_begin = part * per, s_end = max(s_begin, min(S, s_begin + per));
   const int stages = s_end - s_begin;
   struct Regs {
@@ -386,8 +386,15 @@ __global__ __launch_bounds__(128 * NW) void conv_nn(const unsigned char *__restr
       shift = R.live ? (t / 3 - 1) * Win + (t % 3 - 1) : 0;
     }
     const float *xp = xb + (long long)(c16 * kTK + kq * 4) * Nin + shift;
+    if (TAPS == 1 && (K & (kTK - 1)) && c16 == K / kTK) {
+      // the last chunk of a reduction that is not a multiple of 16 (the head's 588-channel key-point maps): channels past the end
+      // re-read the last one -- their weights are the image's zero padding (wave-uniform branch)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) R.v[j] = xp[(long long)j * Nin];
+      for (int j = 0; j < 4; ++j) R.v[j] = xb[(long long)min(c16 * kTK + kq * 4 + j, K - 1) * Nin];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) R.v[j] = xp[(long long)j * Nin];
+    }
   };
   auto commit = [&](int buf, const Regs &R) {
     unsigned char *As = smem + buf * kBuf, *Bs = As + kStage;
@@ -1868,7 +1875,7 @@ NNPlan plan_nn(long long B, int M, int K, int H, int W, int taps, int stride) {
     }
   }
   p.tiles = (long long)n_mt * p.n_nt * B;
-  p.ks = nn_ksplit(p.tiles, taps * (K / kTK));
+  p.ks = nn_ksplit(p.tiles, taps * ((K + kTK - 1) / kTK));
   if (p.patch && p.tiles < 200) {
     // patch kernels: parts of whole chunks (>= 2 each), chosen by rounds over the CUs x chunks per part (+ the partials to add)
     static const int old_rule = [] { const char *e = getenv("KGDET_CONV_KS_OLD"); return e ? atoi(e) : 0; }();   // A/B
@@ -1901,8 +1908,8 @@ extern "C" int kgdet_debug_read_conv_trace(unsigned long long *out) {
 #endif
 
 extern "C" size_t kgdet_conv_packed_bytes(int32_t M, int32_t K, int32_t taps) {
-  if (M <= 0 || K <= 0 || K % kTK || (taps != 1 && taps != 9)) return 0;
-  return (size_t)((M + kTM - 1) / kTM) * (K / kTK) * taps * kStage;
+  if (M <= 0 || K <= 0 || (taps == 9 && K % kTK) || (taps != 1 && taps != 9)) return 0;
+  return (size_t)((M + kTM - 1) / kTM) * ((K + kTK - 1) / kTK) * taps * kStage;
 }
 
 extern "C" int kgdet_conv_pack_fmt(const float *w, int32_t O, int32_t C, int32_t taps, int32_t transpose, void *packed,
@@ -1910,9 +1917,9 @@ extern "C" int kgdet_conv_pack_fmt(const float *w, int32_t O, int32_t C, int32_t
   // weight [O, C, taps]; transpose = 0: rows O, reduction C (forward); 1: rows C, reduction O, taps mirrored (grad_input)
   const int M = transpose ? C : O, K = transpose ? O : C;
   KGDET_CHECK_SHAPE(taps == 1 || taps == 9, "taps must be 1 (1x1) or 9 (3x3)");
-  KGDET_CHECK_SHAPE(O > 0 && C > 0 && K % kTK == 0, "reduction length %d is not a multiple of 16", K);
+  KGDET_CHECK_SHAPE(O > 0 && C > 0 && (taps == 1 || K % kTK == 0), "reduction length %d is not a multiple of 16", K);
   KGDET_CHECK_SHAPE(w && packed, "null pointer");
-  const long long total = (long long)((M + kTM - 1) / kTM) * (K / kTK) * taps * 2 * kTM;
+  const long long total = (long long)((M + kTM - 1) / kTM) * ((K + kTK - 1) / kTK) * taps * 2 * kTM;
   const long long blocks = (total + 255) / 256;
   hipLaunchKernelGGL(conv1x1_pack, dim3((unsigned)(blocks > 65535 ? 65535 : blocks)), dim3(256), 0, (hipStream_t)stream, w,
                      O, C, taps, transpose, (unsigned char *)packed, (unsigned char *)nullptr, operand_format == 1 ? 1 : 0);
@@ -1928,10 +1935,10 @@ extern "C" int kgdet_conv_pack(const float *w, int32_t O, int32_t C, int32_t tap
 extern "C" int kgdet_conv_pack_both_fmt(const float *w, int32_t O, int32_t C, int32_t taps, void *packed, void *packed_t,
                                         int32_t forward_format, void *stream) {
   KGDET_CHECK_SHAPE(taps == 1 || taps == 9, "taps must be 1 (1x1) or 9 (3x3)");
-  KGDET_CHECK_SHAPE(O > 0 && C > 0 && O % kTK == 0 && C % kTK == 0, "O and C must be multiples of 16");
+  KGDET_CHECK_SHAPE(O > 0 && C > 0 && (taps == 1 || (O % kTK == 0 && C % kTK == 0)), "O and C must be multiples of 16");
   KGDET_CHECK_SHAPE(w && packed && packed_t, "null pointer");
-  const long long t0 = (long long)((O + kTM - 1) / kTM) * (C / kTK) * taps * 2 * kTM;
-  const long long t1 = (long long)((C + kTM - 1) / kTM) * (O / kTK) * taps * 2 * kTM;
+  const long long t0 = (long long)((O + kTM - 1) / kTM) * ((C + kTK - 1) / kTK) * taps * 2 * kTM;
+  const long long t1 = (long long)((C + kTM - 1) / kTM) * ((O + kTK - 1) / kTK) * taps * 2 * kTM;
   const long long blocks = ((t0 > t1 ? t0 : t1) + 255) / 256;
   hipLaunchKernelGGL(conv1x1_pack, dim3((unsigned)(blocks > 32768 ? 32768 : blocks), 2), dim3(256), 0,
                      (hipStream_t)stream, w, O, C, taps, 0, (unsigned char *)packed, (unsigned char *)packed_t,
@@ -1946,9 +1953,9 @@ extern "C" int kgdet_conv_pack_both(const float *w, int32_t O, int32_t C, int32_
 }
 
 extern "C" int64_t kgdet_conv_pack_blocks(int32_t O, int32_t C, int32_t taps) {
-  if (O <= 0 || C <= 0 || O % kTK || C % kTK || (taps != 1 && taps != 9)) return 0;
-  const long long t0 = (long long)((O + kTM - 1) / kTM) * (C / kTK) * taps * 2 * kTM;
-  const long long t1 = (long long)((C + kTM - 1) / kTM) * (O / kTK) * taps * 2 * kTM;
+  if (O <= 0 || C <= 0 || (taps == 9 && (O % kTK || C % kTK)) || (taps != 1 && taps != 9)) return 0;
+  const long long t0 = (long long)((O + kTM - 1) / kTM) * ((C + kTK - 1) / kTK) * taps * 2 * kTM;
+  const long long t1 = (long long)((C + kTM - 1) / kTM) * ((O + kTK - 1) / kTK) * taps * 2 * kTM;
   return ((t0 > t1 ? t0 : t1) + 255) / 256;
 }
 
@@ -1963,7 +1970,7 @@ extern "C" int kgdet_conv_pack_multi(const int64_t *desc_dev, int32_t n, int64_t
 // H, W below are the INPUT map; the output map is ceil(H / stride) x ceil(W / stride) (1x1: padding 0, 3x3: padding 1)
 extern "C" size_t kgdet_conv_apply_workspace_bytes(int64_t B, int32_t M, int32_t K, int32_t H, int32_t W,
                                                     int32_t taps, int32_t stride) {
-  if (B <= 0 || M <= 0 || K <= 0 || H <= 0 || W <= 0 || K % kTK || stride < 1 || stride > 2) return 0;
+  if (B <= 0 || M <= 0 || K <= 0 || H <= 0 || W <= 0 || (taps == 9 && K % kTK) || stride < 1 || stride > 2) return 0;
   const long long HW = (long long)((H + stride - 1) / stride) * ((W + stride - 1) / stride);
   const int ks = plan_nn(B, M, K, H, W, taps, stride).ks;
   return ks > 1 ? (size_t)ks * B * M * HW * sizeof(float) : 0;
@@ -1997,7 +2004,7 @@ extern "C" int kgdet_conv_apply_gated_fmt(const void *packed, const float *x, fl
   KGDET_CHECK_SHAPE(B >= 0 && M > 0 && K > 0 && H >= 0 && W >= 0 && (long long)H * W < (1LL << 30), "bad sizes");
   KGDET_CHECK_SHAPE(taps == 1 || taps == 9, "taps must be 1 (1x1) or 9 (3x3)");
   KGDET_CHECK_SHAPE(stride == 1 || stride == 2, "stride must be 1 or 2");
-  KGDET_CHECK_SHAPE(K % kTK == 0, "reduction length %d is not a multiple of 16", K);
+  KGDET_CHECK_SHAPE(taps == 1 || K % kTK == 0, "reduction length %d is not a multiple of 16", K);
   const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
   const long long HW = (long long)Ho * Wo;
   if (B * HW == 0) return KGDET_OK;

@@ -902,6 +902,7 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
     for (int dgi = 0; dgi < s->deformable_groups; ++dgi) {
       if (sg.n == kMaxFwdGroup) {
         sg.sched.on = 0; sg.hot_gemm = 0;
+        hipLaunchKernelGGL(dcn_inv_medium_sums, dim3(s->N * d.K, kInvSumSplit, sg.n), dim3(256), 0, (hipStream_t)stream, sg);
         hipLaunchKernelGGL(dcn_inv_overflow_sums, dim3(s->N * d.K, kInvSumSplit, sg.n), dim3(256), 0, (hipStream_t)stream, sg);
         sg.n = 0;
       }
@@ -912,6 +913,7 @@ int kgdet_deform_conv_grad_input(const kgdet_dcn_shape *s, const float *offset, 
                                d.Og, d.Og_pad16, gov_ld, gov_slots, s->W};
     }
     sg.sched.on = 0; sg.hot_gemm = 0;
+    hipLaunchKernelGGL(dcn_inv_medium_sums, dim3(s->N * d.K, kInvSumSplit, sg.n), dim3(256), 0, (hipStream_t)stream, sg);
     hipLaunchKernelGGL(dcn_inv_overflow_sums, dim3(s->N * d.K, kInvSumSplit, sg.n), dim3(256), 0, (hipStream_t)stream, sg);
   }
   const int G = grid_size();
@@ -1177,20 +1179,25 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
     sc.on = 0;
     int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int x = 0; x < 8; ++x) sc.n_seg[x] = 0;
-    struct G_ { int z, b, units; } gs[kMaxFwdGroup * 64];
+    // (KGDET_DCN_SUMS_HALVES=1, measured and left off: every pair as TWO segments -- its first and second half of the taps; six
+    // problems x two images are 12 pairs for 8 XCDs.  dcn_inv_medium_sums 43.6 against 44.1 us, dcn_hot_gemm 36 against 21 us)
+    struct G_ { int z, b, units, u0; } gs[kMaxFwdGroup * 128];
     int ng = 0;
     bool fits = !xcd_off;
     for (int z = 0; z < n && fits; ++z)
       for (int b = 0; b < shapes[z]->N && fits; ++b) {
-        if (ng >= kMaxFwdGroup * 64) { fits = false; break; }
-        gs[ng++] = G_{z, b, dd[z].K * kInvSumSplit};
+        if (ng + 2 > kMaxFwdGroup * 128) { fits = false; break; }
+        static const bool no_halves = !(getenv("KGDET_DCN_SUMS_HALVES") && atoi(getenv("KGDET_DCN_SUMS_HALVES")) == 1);   // (experiment, off)
+        const int units = dd[z].K * kInvSumSplit, h0 = no_halves ? units : (dd[z].K + 1) / 2 * kInvSumSplit;
+        gs[ng++] = G_{z, b, h0, 0};
+        if (units > h0) gs[ng++] = G_{z, b, units - h0, h0};
       }
     std::stable_sort(gs, gs + ng, [](const G_ &a, const G_ &b) { return a.units > b.units; });
     for (int i = 0; i < ng && fits; ++i) {
       int x = 0;
       for (int y = 1; y < 8; ++y) if (load[y] < load[x]) x = y;
       if (sc.n_seg[x] >= kInvSumSegs) { fits = false; break; }
-      sc.seg[x][sc.n_seg[x]++] = DcnInvSumSeg{gs[i].z, gs[i].b, load[x], gs[i].units};
+      sc.seg[x][sc.n_seg[x]++] = DcnInvSumSeg{gs[i].z, gs[i].b, load[x], gs[i].units, gs[i].u0};
       load[x] += gs[i].units;
     }
     if (fits) {
@@ -1328,8 +1335,10 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
                        sums.sched);
   }
   if (sums.sched.on) {
+    hipLaunchKernelGGL(dcn_inv_medium_sums, dim3(8 * sched_longest), dim3(256), 0, (hipStream_t)stream, sums);
     hipLaunchKernelGGL(dcn_inv_overflow_sums, dim3(8 * sched_longest), dim3(256), 0, (hipStream_t)stream, sums);
   } else {
+    hipLaunchKernelGGL(dcn_inv_medium_sums, dim3(sums_blocks, kInvSumSplit, sums.n), dim3(256), 0, (hipStream_t)stream, sums);
     hipLaunchKernelGGL(dcn_inv_overflow_sums, dim3(sums_blocks, kInvSumSplit, sums.n), dim3(256), 0, (hipStream_t)stream, sums);
   }
   if (g_hot_dbg.n > 0 && getenv("KGDET_DCN_HOT_DEBUG") && atoi(getenv("KGDET_DCN_HOT_DEBUG")) == 1) {   // (test hook, see above)

@@ -17,6 +17,7 @@
 // plane_role<MODE = 1>: grad_out planes in LDS, weights from the transposed operand image `wqt`, bf16 hi/lo
 // split MFMA, stream-K with the forward's fix-up.  No atomics, deterministic, no pre-zeroing of grad_input.
 // Deformable groups > 1 (different cells lists per channel group inside one M tile) stay on the older kernels.
+#include <type_traits>
 #include "dcn_plane.h"
 
 namespace kgdet {
@@ -211,6 +212,25 @@ __global__ __launch_bounds__(256) void dcn_build_inverse_taps_multi(const DcnInv
   build_inverse_taps_body<256>(e.p, e.inv, e.hdr, e.cells, e.spill, (int)blockIdx.x, sm, e.hot_cols, e.hot_count, e.hot_max);
 }
 
+// unit (problem uz, (image, tap) ubt, split uy) of a workgroup of the sums kernels: grid = (N * K, kInvSumSplit, problems), or with
+// XCD-local units (DcnInvSumSched) linear workgroup id L -> XCD L % 8, unit r = L / 8 of that XCD's segments.  false: no unit.
+__device__ __forceinline__ bool inv_sum_unit(const DcnInvSumGroup &grp, int &uz, int &ubt, int &uy) {
+  uz = blockIdx.z; ubt = blockIdx.x; uy = blockIdx.y;
+  if (grp.sched.on) {
+    const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+    int si = 0;
+    const int ns = grp.sched.n_seg[xcd];
+    while (si < ns && r >= grp.sched.seg[xcd][si].first + grp.sched.seg[xcd][si].n) ++si;
+    if (si >= ns) return false;
+    const DcnInvSumSeg sg = grp.sched.seg[xcd][si];
+    const int u = r - sg.first + sg.u0;
+    uz = sg.z;
+    ubt = sg.b * grp.e[sg.z].K + u / kInvSumSplit;
+    uy = u % kInvSumSplit;
+  }
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Gov[image, tap, slot][o] = sum over the contributions e of a long cell of w_e * grad_out[image, o, p_e], all output
 // channels o of the convolution at once (the plane kernel would walk the list once per 16-channel chunk).
@@ -227,19 +247,8 @@ __global__ __launch_bounds__(256) void dcn_inv_overflow_sums(const DcnInvSumGrou
   __shared__ unsigned bitmap[64];
   __shared__ int prefix[64];
   __shared__ float part[16][256];
-  int uz = blockIdx.z, ubt = blockIdx.x, uy = blockIdx.y;
-  if (grp.sched.on) {   // XCD-local units (DcnInvSumSched): linear workgroup id L -> XCD L % 8, unit r = L / 8 of that XCD's segments
-    const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
-    int si = 0;
-    const int ns = grp.sched.n_seg[xcd];
-    while (si < ns && r >= grp.sched.seg[xcd][si].first + grp.sched.seg[xcd][si].n) ++si;
-    if (si >= ns) return;
-    const DcnInvSumSeg sg = grp.sched.seg[xcd][si];
-    const int u = r - sg.first;
-    uz = sg.z;
-    ubt = sg.b * grp.e[sg.z].K + u / kInvSumSplit;
-    uy = u % kInvSumSplit;
-  }
+  int uz, ubt, uy;
+  if (!inv_sum_unit(grp, uz, ubt, uy)) return;
   const DcnInvSum &e = grp.e[uz];
   const int bt = ubt;
   if (bt >= e.NK) return;
@@ -259,6 +268,7 @@ __global__ __launch_bounds__(256) void dcn_inv_overflow_sums(const DcnInvSumGrou
   // (an image with more hot cells than the column list holds goes through the cluster path WHOLE: which cells made the list depends on
   // the order the builder's workgroups ran in, and the two paths sum in different orders)
   const bool hot_on = grp.hot_gemm && e.hot_count != nullptr && e.hot_count[b] <= e.hot_max;
+  if (hot_on) return;       // (every cell above 64 contributions of this image is a column of the GEMM: nothing left for this kernel)
   constexpr int kMaxCells = 4 * kPlaneMaxHW / (kInvInline + 1) + 8;
   __shared__ int c_start[kMaxCells];
   __shared__ short c_n[kMaxCells], c_cell[kMaxCells];   // (c_n < 0: the cell's sum is formed by dcn_hot_gemm)
@@ -270,65 +280,7 @@ __global__ __launch_bounds__(256) void dcn_inv_overflow_sums(const DcnInvSumGrou
     c_cell[i] = (short)c.cell;
   }
   __syncthreads();
-  // ---- cells with at most 64 contributions: ONE WAVE per cell, no workgroup barrier (the four waves work on four cells at
-  // once).  Lane i holds entry i; its rank = the number of entries with a smaller pixel (pixels of a cell are distinct); the
-  // entries go to the wave's LDS slots in rank order and the wave walks them in that order, lanes = 64 channel quads (one
-  // 16-byte load per entry and lane).  On converged key-point offsets an (image, tap) has dozens of such medium cells (the
-  // cells within the key point's jitter) beside the few hot ones: through the seven-barrier workgroup path below they were
-  // most of the kernel's time.
-  {
-    __shared__ unsigned short w_px[4][64];
-    __shared__ float w_w[4][64];
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    int small_idx = 0;
-    for (int slot = uy; slot < n_cells; slot += kInvSumSplit) {
-      const DcnInvOvfCell c = {c_start[slot], (int)c_n[slot], (int)c_cell[slot], 0};
-      if (c.n > 64 || c.n < 0) continue;
-#ifdef KGDET_SUMS_ABL_NOMEDIUM
-      continue;
-#endif
-      if ((small_idx++ & 3) != wave) continue;
-      int2 en = make_int2(0x7fffffff, 0);
-      if (lane < c.n) en = spill_bt[c.start + lane];
-      int rank = 0;
-      for (int j = 0; j < c.n; ++j) rank += __builtin_amdgcn_readlane(en.x, j) < en.x ? 1 : 0;
-      __builtin_amdgcn_wave_barrier();                 // (the previous cell's reads of the slots are done: same wave, in order)
-      if (lane < c.n) {
-        w_px[wave][rank] = (unsigned short)en.x;
-        w_w[wave][rank] = __int_as_float(en.y);
-      }
-      __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0)
-      __builtin_amdgcn_wave_barrier();
-      float *dst = e.gov + ((size_t)bt * e.max_slots + slot) * O_ld;
-      for (int d = lane; d < O_ld; d += 64)
-        if (d % e.Og_pad16 >= e.Og) dst[d] = 0.0f;
-      for (int c0 = 0; c0 < O; c0 += 256) {
-        const int ch = c0 + lane * 4;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-        for (int r = 0; r < c.n; ++r) {
-          const int px = w_px[wave][r];
-          const float w = w_w[wave][r];
-          const float *src = gt + (size_t)px * O;
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (vec) {
-            if (ch < O) v = *reinterpret_cast<const f32x4 *>(src + ch);
-          } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-              if (ch + k < O) v[k] = src[ch + k];
-          }
-          acc[0] = __builtin_fmaf(w, v[0], acc[0]);
-          acc[1] = __builtin_fmaf(w, v[1], acc[1]);
-          acc[2] = __builtin_fmaf(w, v[2], acc[2]);
-          acc[3] = __builtin_fmaf(w, v[3], acc[3]);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (ch + k < O) dst[((ch + k) / e.Og) * e.Og_pad16 + (ch + k) % e.Og] = acc[k];
-      }
-    }
-  }
+  // (cells with at most 64 contributions: dcn_inv_medium_sums, below)
   // ---- longer lists: the whole workgroup per CLUSTER of up to four such cells (q, q + 1, q + W, q + W + 1: the four bilinear
   // corners of a sample).  With converged key points those four cells list (nearly) the same pixels, each with its own corner
   // weight: the cluster is summed in ONE pass over the union of the pixels -- a pixel's 1 KB row of grad_out is loaded once and
@@ -477,6 +429,183 @@ __global__ __launch_bounds__(256) void dcn_inv_overflow_sums(const DcnInvSumGrou
 }
 
 // ------------------------------------------------------------------------------------------------
+// Gov of the cells with 9 .. 64 contributions: ONE WAVE per cell, no workgroup barrier in the loop.  In the training step's own
+// steady state (tools/dump_step_offsets.py: the offsets after 700 steps on the bench's batch) no cell is hot, but a quarter of all
+// contributions sit in ~76 such cells per (image, tap) -- 25 000 cell sums and 360 MB of grad_output rows per head stage.  As a
+// section of dcn_inv_overflow_sums (45 KB of LDS for the cluster path: 3 workgroups per CU) this took 71 us of that kernel's 91: a
+// chain of three dependent memory latencies per cell at 12 waves per CU.  Here: 3 KB of LDS (8 workgroups per CU), the workgroup's
+// medium cells compacted into a list first, the NEXT cell's entries requested before the current cell's rows, up to 16 rows in flight.
+// Lane i holds entry i; its rank = the number of entries with a smaller pixel (pixels of a cell are distinct); the wave walks the
+// entries in rank order, lanes = 64 channel quads (one 16-byte load per entry and lane).  Same units as dcn_inv_overflow_sums
+// (XCD-local: the rows come from the L2 that holds the image's pixel-major grad_output).  Deterministic.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dcn_inv_medium_sums(const DcnInvSumGroup grp) {
+  constexpr int kMaxCells = 4 * kPlaneMaxHW / (kInvInline + 1) + 8;
+  constexpr int kMine = (kMaxCells + kInvSumSplit - 1) / kInvSumSplit;     // cells of one split (<= 256: one per thread)
+  static_assert(kMine <= 256, "one thread per cell of the split");
+  __shared__ int m_start[kMine];
+  __shared__ unsigned short m_n[kMine], m_slot[kMine];
+  __shared__ unsigned short w_px[4][64];
+  __shared__ float w_w[4][64];
+  __shared__ int wave_count[4];
+  int uz, ubt, uy;
+  if (!inv_sum_unit(grp, uz, ubt, uy)) return;
+  const DcnInvSum &e = grp.e[uz];
+  const int bt = ubt;
+  if (bt >= e.NK) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // this split's cells, one per thread -- requested together with the header that says how many of them are real (two dependent
+  // round trips to memory the builder wrote from another XCD would be ~4 us before the first useful load)
+  const int slot = uy + tid * kInvSumSplit;
+  DcnInvOvfCell c = {0, 0, 0, 0};
+  if (slot < e.max_slots && slot < kMaxCells) c = e.cells[(size_t)bt * e.max_slots + slot];
+  const int count = e.hdr[bt];
+  if (uy >= count) return;
+  const int b = bt / e.K;
+  const int HoWo = e.HoWo, O = e.O, O_ld = e.O_ld;
+  const int2 *spill_bt = e.spill + (size_t)bt * 4 * HoWo;
+  const float *gt = e.gout_t + (size_t)b * HoWo * O;
+  const bool vec = (O & 3) == 0;
+  const int n_cells = count < kMaxCells ? count : kMaxCells;
+  // the medium ones compacted in slot order (ballot ranks inside a wave, wave totals across)
+  const bool medium = slot < n_cells && c.n > 0 && c.n <= 64;
+  const unsigned long long mask = __ballot(medium);
+  if (lane == 0) wave_count[wave] = __popcll(mask);
+  __syncthreads();
+  int base = 0, n_medium = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    base += w < wave ? wave_count[w] : 0;
+    n_medium += wave_count[w];
+  }
+  if (medium) {
+    const int at = base + __popcll(mask & ((1ull << lane) - 1ull));
+    m_start[at] = c.start;
+    m_n[at] = (unsigned short)c.n;
+    m_slot[at] = (unsigned short)slot;
+  }
+  __syncthreads();
+#ifdef KGDET_SUMS_ABL_NOMEDIUM
+  return;
+#endif
+  auto entries = [&](int i) {
+    int2 en = make_int2(0x7fffffff, 0);
+#ifdef KGDET_MED_ABL_NOENTRIES
+    if (i < n_medium && lane < (int)m_n[i]) en = make_int2(lane * 16 + i, 0x3f800000);
+    return en;
+#endif
+    if (i < n_medium && lane < (int)m_n[i]) en = spill_bt[m_start[i] + lane];
+    return en;
+  };
+  int2 en_next = entries(wave);
+  if (vec && O_ld == O && O <= 256) {
+    // the head's shapes (<= 256 channels, no padding inside a Gov vector).  Branch-free: every lane loads 16 bytes of every row from
+    // a clamped channel offset (lanes past O compute and drop).  Results wait in LDS and leave four cells at a time: with loads AND
+    // stores in flight the memory counter cannot tell them apart, so a wait for a cell's rows right after the previous cell's store
+    // waited for that store's whole round trip too (~4 us per cell measured: more than the rows themselves).
+    __shared__ f32x4 res[4][4][64];
+    __shared__ unsigned short res_slot[4][4];
+    // (buffer loads: one multiply-add per row address instead of a 64-bit pointer computation -- a third of the kernel's vector
+    // instructions were address arithmetic)
+    const dcn_rsrc_t g_rsrc = dcn_make_rsrc(gt);
+    const unsigned row_bytes = (unsigned)O * 4u, ch_bytes = (unsigned)min(lane * 4, O - 4) * 4u;
+    constexpr int kRows = 12;                          // rows in flight (48 registers: six waves per SIMD stay resident)
+    int pend = 0;
+    auto flush = [&]() __attribute__((always_inline)) {
+      for (int q = 0; q < pend; ++q)
+        if (lane * 4 < O)
+          *reinterpret_cast<f32x4 *>(e.gov + ((size_t)bt * e.max_slots + res_slot[wave][q]) * O_ld + lane * 4) = res[wave][q][lane];
+      pend = 0;
+    };
+    for (int i = wave; i < n_medium; i += 4) {
+      const int2 en = en_next;
+      const int n = m_n[i];
+      en_next = entries(i + 4);                        // (in flight under this cell's rows)
+      int rank = 0;
+      for (int j = 0; j < n; ++j) rank += __builtin_amdgcn_readlane(en.x, j) < en.x ? 1 : 0;
+      __builtin_amdgcn_wave_barrier();                 // (the previous cell's reads of the slots are done: same wave, in order)
+      if (lane < n) {
+        w_px[wave][rank] = (unsigned short)en.x;
+        w_w[wave][rank] = __int_as_float(en.y);
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0)
+      __builtin_amdgcn_wave_barrier();
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int r0 = 0; r0 < n; r0 += kRows) {
+        f32x4 v[kRows];
+        float w[kRows];
+#pragma unroll
+        for (int u = 0; u < kRows; ++u) {              // (a batch's surplus rows re-read the cell's last row with weight 0)
+          const int idx = min(r0 + u, n - 1);
+          w[u] = r0 + u < n ? w_w[wave][idx] : 0.0f;
+#ifdef KGDET_MED_ABL_NOROWS
+          v[u] = f32x4{(float)idx, 0.f, 0.f, 0.f}; continue;
+#endif
+          v[u] = __builtin_bit_cast(f32x4, dcn_buf_b128(g_rsrc, (unsigned)w_px[wave][idx] * row_bytes + ch_bytes, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < kRows; ++u) {
+          acc[0] = __builtin_fmaf(w[u], v[u][0], acc[0]);
+          acc[1] = __builtin_fmaf(w[u], v[u][1], acc[1]);
+          acc[2] = __builtin_fmaf(w[u], v[u][2], acc[2]);
+          acc[3] = __builtin_fmaf(w[u], v[u][3], acc[3]);
+        }
+      }
+      res[wave][pend][lane] = acc;
+      if (lane == 0) res_slot[wave][pend] = m_slot[i];
+      if (++pend == 4) flush();
+    }
+    flush();
+    return;
+  }
+  for (int i = wave; i < n_medium; i += 4) {           // any other shape: a cell at a time
+    const int2 en = en_next;
+    const int n = m_n[i];
+    en_next = entries(i + 4);
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += __builtin_amdgcn_readlane(en.x, j) < en.x ? 1 : 0;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < n) {
+      w_px[wave][rank] = (unsigned short)en.x;
+      w_w[wave][rank] = __int_as_float(en.y);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    // a Gov vector holds the convolution's weight groups one after the other, each padded to whole 16-channel chunks (zeros: the
+    // chunk's padding channels meet zero weights, but must be finite)
+    float *dst = e.gov + ((size_t)bt * e.max_slots + m_slot[i]) * O_ld;
+    if (O_ld != O)
+      for (int d = lane; d < O_ld; d += 64)
+        if (d % e.Og_pad16 >= e.Og) dst[d] = 0.0f;
+    for (int c0 = 0; c0 < O; c0 += 256) {
+      const int ch = c0 + lane * 4;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+      for (int r = 0; r < n; ++r) {
+        const int px = w_px[wave][r];
+        const float w = w_w[wave][r];
+        const float *src = gt + (size_t)px * O;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (vec) {
+          if (ch < O) v = *reinterpret_cast<const f32x4 *>(src + ch);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (ch + k < O) v[k] = src[ch + k];
+        }
+        acc[0] = __builtin_fmaf(w, v[0], acc[0]);
+        acc[1] = __builtin_fmaf(w, v[1], acc[1]);
+        acc[2] = __builtin_fmaf(w, v[2], acc[2]);
+        acc[3] = __builtin_fmaf(w, v[3], acc[3]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (ch + k < O) dst[((ch + k) / e.Og) * e.Og_pad16 + (ch + k) % e.Og] = acc[k];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Hot cells as a GEMM (round 6).  With converged key points every (image, tap) has a handful of cells that collect hundreds of
 // contributions each, and the cluster path above reads every contributing pixel's 1 KB row of grad_out once per cluster: the same
 // ~1050 rows for every tap of an image, 349 MB per head stage at ~8 TB/s of L2 hits + 357 M lane-FMAs (tools/experiments/README.md,
@@ -515,7 +644,8 @@ __global__ __launch_bounds__(512) void dcn_hot_gemm(const DcnHotGemmGroup grp, c
   int counts[kInvSumSegs];                            // (all of the XCD's groups at once: one memory latency, not one per group)
 #pragma unroll
   for (int si = 0; si < kInvSumSegs; ++si)
-    counts[si] = si < sched.n_seg[xcd] ? grp.e[sched.seg[xcd][si].z].count[sched.seg[xcd][si].b] : 0;
+    counts[si] = (si < sched.n_seg[xcd] && sched.seg[xcd][si].u0 == 0)     // (a pair's second segment: its columns are the first one's)
+                     ? grp.e[sched.seg[xcd][si].z].count[sched.seg[xcd][si].b] : 0;
   int base = 0;
   for (int si = 0; si < sched.n_seg[xcd]; ++si) {
     const DcnHotGemm &e = grp.e[sched.seg[xcd][si].z];

@@ -76,7 +76,8 @@ struct DcnInvSum {
 // XCD, where those rows stay in that XCD's L2 (with units dealt in launch order every XCD streamed all of the group's 12 MB:
 // 350 MB of fabric reads per head stage on converged offsets, ~95 us per launch in the training step's profile of round 5).
 constexpr int kInvSumSegs = 6;
-struct DcnInvSumSeg { int z, b, first, n; };          // problem, image, first unit index r on its XCD, units (K * kInvSumSplit)
+struct DcnInvSumSeg { int z, b, first, n, u0; };      // problem, image, first unit index r on its XCD, units, the segment's first unit
+                                                      // within the (problem, image) -- a pair's K * kInvSumSplit units come as two segments
 struct DcnInvSumSched {
   int on;                                             // 0: grid = (N * K, kInvSumSplit, problems), unit = blockIdx
   int n_seg[8];
@@ -88,7 +89,8 @@ struct DcnInvSumGroup {
   DcnInvSumSched sched;
   int hot_gemm;            // cells whose .pad is set are left to dcn_hot_gemm
 };
-__global__ void dcn_inv_overflow_sums(const DcnInvSumGroup grp);
+__global__ void dcn_inv_overflow_sums(const DcnInvSumGroup grp);   // cells above 64 contributions (clusters)
+__global__ void dcn_inv_medium_sums(const DcnInvSumGroup grp);     // cells with 9 .. 64 (same grid)
 // HOT cells (more than 64 contributions: the key-point cells of a converged head) as the columns of ONE split-operand GEMM per
 // (problem, image) over the pixels (round 6, dcn_backward_plane.hip): per distinct offset tensor the hot cells of ALL taps are
 // compacted into a column list and their by-pixel weights laid out densely (dcn_hot_build); per problem

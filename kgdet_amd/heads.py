@@ -184,13 +184,15 @@ class Kp3RepBlock(nn.Module):
                 [cls_feat, pts_feat], offsets,
                 [[getattr(self, 'cls_dfmconv_%d' % k).weight for k in _KERNELS],
                  [getattr(self, 'keypts_dfmconv_%d' % k).weight for k in _KERNELS]], pads)
-            cls_out = conv1x1.conv_infer(self.cls_out, cls_dfmconv_feat)
-            keypts_out = conv1x1.conv_infer(self.keypts_out, keypts_dfmconv_feat)
-            reppts_out = conv1x1.conv_infer(self.reppts_out, keypts_out)
+            # (conv_bias_act: training takes the split MFMA kernels -- also for these 13 / 588 / 166-channel outputs, whose reductions
+            # end inside a 16-channel chunk -- and falls back to conv_infer everywhere else)
+            cls_out = conv1x1.conv_bias_act(self.cls_out, cls_dfmconv_feat)
+            keypts_out = conv1x1.conv_bias_act(self.keypts_out, keypts_dfmconv_feat)
+            reppts_out = conv1x1.conv_bias_act(self.reppts_out, keypts_out)
         else:
-            cls_out = conv1x1.conv_infer(self.cls_out, conv1x1.conv_bias_act(self.cls_conv, cls_feat, relu=True))
-            keypts_out = conv1x1.conv_infer(self.keypts_out, conv1x1.conv_bias_act(self.keypts_conv, pts_feat, relu=True))
-            reppts_out = conv1x1.conv_infer(self.reppts_out, keypts_out)
+            cls_out = conv1x1.conv_bias_act(self.cls_out, conv1x1.conv_bias_act(self.cls_conv, cls_feat, relu=True))
+            keypts_out = conv1x1.conv_bias_act(self.keypts_out, conv1x1.conv_bias_act(self.keypts_conv, pts_feat, relu=True))
+            reppts_out = conv1x1.conv_bias_act(self.reppts_out, keypts_out)
         return cls_out, keypts_out, reppts_out
 
 

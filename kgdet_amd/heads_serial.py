@@ -178,11 +178,11 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
             pts_feat = reg_conv(pts_feat)
         # init stage
         # (the biased 3x3 convolutions + ReLU on the split-operand MFMA kernels, as in the KGDet head's first stage)
-        keypts_out_init = self.keypts_init_out(conv1x1.conv_bias_act(self.keypts_init_conv, pts_feat, relu=True))
+        keypts_out_init = conv1x1.conv_bias_act(self.keypts_init_out, conv1x1.conv_bias_act(self.keypts_init_conv, pts_feat, relu=True))
         if self.parallel_reppts:
-            reppts_out_init = self.reppts_init_out(conv1x1.conv_bias_act(self.reppts_init_conv, pts_feat, relu=True))
+            reppts_out_init = conv1x1.conv_bias_act(self.reppts_init_out, conv1x1.conv_bias_act(self.reppts_init_conv, pts_feat, relu=True))
         else:
-            reppts_out_init = self.reppts_init_out(keypts_out_init)
+            reppts_out_init = conv1x1.conv_bias_act(self.reppts_init_out, keypts_out_init)
         # (adding the integer 0 of the centre-init case would be a pass over a [B, 588, H, W] tensor for nothing)
         if not (isinstance(reppts_init, int) and reppts_init == 0):
             reppts_out_init = reppts_out_init + reppts_init
@@ -200,12 +200,12 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
         else:
             cls_dfm = self._dfm(self.cls_refine_dfmconv, cls_feat, dcn_offset)
             kpt_dfm = self._dfm(self.keypts_refine_dfmconv, pts_feat, dcn_offset)
-        cls_out = self.cls_refine_out(cls_dfm)
-        keypts_out_refine = self.keypts_refine_out(kpt_dfm)
+        cls_out = conv1x1.conv_bias_act(self.cls_refine_out, cls_dfm)
+        keypts_out_refine = conv1x1.conv_bias_act(self.keypts_refine_out, kpt_dfm)
         if self.parallel_reppts:
-            reppts_out_refine = self.reppts_refine_out(self._dfm(self.reppts_refine_dfmconv, pts_feat, dcn_offset))
+            reppts_out_refine = conv1x1.conv_bias_act(self.reppts_refine_out, self._dfm(self.reppts_refine_dfmconv, pts_feat, dcn_offset))
         else:
-            reppts_out_refine = self.reppts_refine_out(keypts_out_refine)
+            reppts_out_refine = conv1x1.conv_bias_act(self.reppts_refine_out, keypts_out_refine)
         keypts_out_refine = keypts_out_refine + keypts_out_init.detach()
         reppts_out_refine = reppts_out_refine + reppts_out_init.detach()
         return (cls_out, keypts_out_init, keypts_out_refine, reppts_out_init, reppts_out_refine)

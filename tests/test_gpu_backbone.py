@@ -421,6 +421,48 @@ def test_conv_bias_act_matches_fp64(B, C, O, H, W, k, relu):
     assert (y0 - y).abs().max().item() <= 1e-4 * y.abs().max().item()
 
 
+@pytest.mark.parametrize('B,C,O,H,W', [(2, 768, 13, 25, 42), (2, 768, 588, 25, 42), (2, 588, 166, 25, 42), (2, 256, 13, 100, 168),
+                                       (1, 588, 166, 13, 21), (2, 40, 24, 8, 8), (2, 7, 6, 6, 6), (2, 256, 588, 50, 84), (3, 17, 130, 9, 10)])
+def test_ragged_1x1_convolutions_match_fp64(B, C, O, H, W):
+    """Round 6: the head's 13- / 588- / 166-channel output convolutions on the split MFMA kernels.  Channel counts that are not
+    multiples of 16 on either side: the operand images pad the reduction with zeros, conv_nn re-reads the last channel for the
+    padding, the weight-gradient kernels take partial tiles.  Output and all three gradients against the fp64 module, bit-repeatably
+    (the vendor GEMMs these replaced made no such promise), inside a step scope too (second step: the one-launch pack)."""
+    from kgdet_amd import conv1x1 as c1
+    torch.manual_seed(C + O + H)
+    conv = torch.nn.Conv2d(C, O, 1).cuda()
+    conv.bias.data.normal_(0, 0.5)
+    x = torch.randn(B, C, H, W, device='cuda', requires_grad=True)
+    gy = torch.randn(B, O, H, W, device='cuda')
+    conv_d = torch.nn.Conv2d(C, O, 1).cuda().double()
+    conv_d.load_state_dict({n: v.double() for n, v in conv.state_dict().items()})
+    xd = x.detach().double().requires_grad_()
+    yd = conv_d(xd)
+    yd.backward(gy.double())
+    runs = []
+    c1._entries.clear()
+    try:
+        for scoped in (False, True, True):
+            x.grad = None; conv.weight.grad = None; conv.bias.grad = None
+            if scoped:
+                with c1.step_scope():
+                    y = c1.conv_bias_act(conv, x)
+            else:
+                y = c1.conv_bias_act(conv, x)
+            assert type(y.grad_fn).__name__ == '_ConvBiasActBackward'
+            y.backward(gy)
+            runs.append((y.detach().clone(), x.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()))
+            for name, a_, b_ in (('y', y, yd), ('grad_x', x.grad, xd.grad), ('grad_w', conv.weight.grad, conv_d.weight.grad),
+                                 ('grad_b', conv.bias.grad, conv_d.bias.grad)):
+                err = (a_.double() - b_).abs().max().item() / b_.abs().max().item()
+                assert err < 1e-5, (name, err, scoped)
+    finally:
+        c1._entries.clear()
+    for later in runs[1:]:
+        for a_, b_ in zip(runs[0][:3], later[:3]):
+            assert torch.equal(a_, b_)
+
+
 def test_dense_conv_kernels_random_shapes_against_fp64():
     """60 random problems through the dense convolution kernels (1x1, 3x3 stride 1 on the patch kernels, 3x3 stride 2 with its
     parity-class grad_input): tiny and ragged maps, one-chunk reductions, row counts around the 32 / 64 / 128-row tile edges,
@@ -469,7 +511,9 @@ def test_conv1x1_not_applicable_cases_fall_back():
     w3 = torch.randn(32, 64, 3, 3, device='cuda')
     assert c1.applicable(x, w3, padding=(1, 1)) and not c1.applicable(x, w3) and not c1.applicable(x, w3, padding=(1, 1), dilation=(2, 2))
     assert not c1.applicable(x, w3, stride=(2, 2), padding=(1, 1)) and not c1.applicable(x, torch.randn(32, 64, 5, 5, device='cuda'), padding=(2, 2))
-    assert not c1.applicable(torch.randn(2, 40, 8, 8, device='cuda'), torch.randn(32, 40, 1, 1, device='cuda'))
+    assert c1.applicable(torch.randn(2, 40, 8, 8, device='cuda'), torch.randn(32, 40, 1, 1, device='cuda')) == c1.RAGGED_1X1
+    assert not c1.applicable(torch.randn(2, 40, 8, 8, device='cuda'), torch.randn(32, 40, 3, 3, device='cuda'), padding=(1, 1))
+    assert not c1.applicable(torch.randn(2, 7, 8, 8, device='cuda'), torch.randn(5, 7, 1, 1, device='cuda'))     # (the weight-gradient sum handles pairs)
     assert c1.applicable(torch.randn(2, 64, 3, 3, device='cuda'), w) == c1.DIRECT_ODD_MAPS     # odd H*W: in place since round 4
     assert not c1.applicable(torch.randn(2, 64, 1, 3, device='cuda'), w)                       # fewer than 4 pixels
     with torch.autocast('cuda', dtype=torch.bfloat16):
@@ -747,7 +791,8 @@ def test_multi_pack_images_equal_single_packs_bit_for_bit():
     at and above one 128-row tile"""
     from kgdet_amd import conv1x1
     torch.manual_seed(1)
-    shapes = [(64, 32, 1), (64, 32, 3), (256, 128, 3), (128, 512, 1), (144, 48, 3), (16, 16, 1), (512, 256, 1), (272, 160, 3)]
+    shapes = [(64, 32, 1), (64, 32, 3), (256, 128, 3), (128, 512, 1), (144, 48, 3), (16, 16, 1), (512, 256, 1), (272, 160, 3),
+              (13, 768, 1), (588, 768, 1), (166, 588, 1), (5, 7, 1)]      # (round 6: reductions that end inside a 16-channel chunk)
     ws = [torch.nn.Parameter(torch.randn(O, C, k, k, device='cuda')) for O, C, k in shapes]
     x = [torch.randn(1, C, 6, 8, device='cuda', requires_grad=True) for O, C, k in shapes]
     for _ in range(2):          # first scope: every weight joins the set (packed on its own); second: ONE launch for all

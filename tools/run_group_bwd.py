@@ -1,5 +1,5 @@
 """Forward + backward of one head stage's grouped DeformConv (2 feature maps x 3x3/5x5/7x7 on [B, 256, 25, 42]) a few
-times (profiling target for the three backward plane kernels): python tools/run_group_bwd.py [B] [iters] [random|trained]
+times (profiling target for the three backward plane kernels): python tools/run_group_bwd.py [B] [iters] [random|trained|step]
 `trained`: the offsets of a converged keypoint-guided head (tests/test_gpu_dcn.py::_keypoint_offsets: tap t of every location of
 an image samples one of two key points), the regime the training step is in after a few hundred steps."""
 import os, sys
@@ -27,6 +27,14 @@ if len(sys.argv) > 3 and sys.argv[3] == 'trained':
                 o[b, 2 * t] = ky[which] - (gy_ - k // 2 + t // k) + 0.03 * o[b, 2 * t]
                 o[b, 2 * t + 1] = kx[which] - (gx_ - k // 2 + t % k) + 0.03 * o[b, 2 * t + 1]
         offs[i] = torch.from_numpy(o).to(dev)
+if len(sys.argv) > 3 and sys.argv[3] == 'step':
+    # the offsets of the bench's own steady training state (tools/dump_step_offsets.py: second head stage, step 700): no hot cells,
+    # but a quarter of the contributions in cells of 9 .. 64 -- the regime the training step's kernels actually run in
+    import numpy as np
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'step_offsets_call1_f16.npz'))
+    for i, k in enumerate(ks):
+        o = torch.from_numpy(d['call1_k%d' % k].astype('float32'))
+        offs[i] = o.repeat((B + 1) // 2, 1, 1, 1)[:B].contiguous().to(dev)
 offs = [o.requires_grad_() for o in offs]
 ws = [[(torch.randn(C, C, k, k, device=dev) * 0.01).requires_grad_() for k in ks] for _ in xs]
 gos = None
