@@ -249,6 +249,13 @@ class ConvModule(nn.Module):
                 elif (type(conv) is nn.Conv2d and conv.bias is None and torch.is_grad_enabled()
                         and conv1x1.odd_map_applicable(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)):
                     x = conv1x1.unpad_odd(conv1x1.conv_split(conv1x1.pad_odd(x), conv.weight), x.shape[3])
+                elif (type(conv) is nn.Conv2d and torch.is_grad_enabled()
+                        and conv1x1.applicable_stride2(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)):
+                    # (the FPN's extra levels: 3x3 stride 2.  MIOpen's fp32 forward for the 13 x 21 and 7 x 11 outputs splits K with
+                    #  float atomics -- every tensor computed on those two levels differed in its last bits from run to run)
+                    x = conv1x1.conv3x3_stride2(x, conv.weight)
+                    if conv.bias is not None:
+                        x = x + conv.bias.view(1, -1, 1, 1)
                 elif type(conv) is nn.Conv2d and conv.bias is not None and torch.is_grad_enabled():
                     x = conv1x1.conv_bias_act(conv, x, relu=False)   # (config 5's FPN: biased convolutions without a norm)
                 else:

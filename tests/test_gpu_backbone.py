@@ -549,7 +549,8 @@ def test_split_convolutions_take_odd_and_unaligned_maps_in_place(H, W, k):
 
 
 @pytest.mark.parametrize('B,C,O,H,W', [(2, 128, 128, 20, 36), (1, 64, 256, 17, 13), (2, 256, 256, 50, 84), (1, 64, 64, 9, 12),
-                                       (2, 128, 128, 200, 336), (2, 512, 512, 50, 84), (3, 32, 48, 7, 20), (1, 160, 16, 33, 11)])
+                                       (2, 128, 128, 200, 336), (2, 512, 512, 50, 84), (3, 32, 48, 7, 20), (1, 160, 16, 33, 11),
+                                       (2, 256, 256, 25, 42), (2, 256, 256, 13, 21), (1, 64, 32, 5, 5)])     # (odd output maps: 13 x 21, 7 x 11, 3 x 3)
 def test_conv3x3_stride2_forward_matches_fp64(B, C, O, H, W):
     """conv_nn<9> with stride 2 (padding 1): forward against the fp64 convolution; grad_input on conv3x3_s2_grad_input (the four
     parity classes of the output pixels; odd input sizes, ragged tiles, C not a multiple of 128) against fp64 to 1e-5;
@@ -561,6 +562,7 @@ def test_conv3x3_stride2_forward_matches_fp64(B, C, O, H, W):
     if not c1.applicable_stride2(x, w, (2, 2), (1, 1), (1, 1), 1):
         pytest.skip('odd number of output pixels')
     y = c1.conv3x3_stride2(x, w)
+    assert torch.equal(y, c1.conv3x3_stride2(x, w)), 'forward must be deterministic'
     ref = F.conv2d(x.detach().double(), w.detach().double(), stride=2, padding=1)
     assert y.shape == ref.shape
     assert ((y.double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
