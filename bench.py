@@ -365,11 +365,23 @@ def _trained_offsets(offs, ks, B, H, W):
     return out
 
 
+STEP_OFFSETS = 'tools/data/step_offsets_call1_f16.npz'
+
+
+def _step_offsets(device, ks):
+    """the offsets the benched training step itself produces in its steady state (second head stage, step 700 of this bench's model
+    on its synthetic batch; tools/dump_step_offsets.py, stored in fp16): no cell collects more than 64 contributions, but a quarter
+    of all contributions sit in cells of 9 .. 64 -- neither the random nor the converged-key-point regime"""
+    import numpy as np
+    d = np.load(os.path.join(ROOT, STEP_OFFSETS))
+    return [torch.from_numpy(d['call1_k%d' % k].astype('float32')).to(device) for k in ks]
+
+
 def dcn_backward_products_live(device, iters=30, regime='random'):
     """The three backward products of the same head stage, each timed alone: (forward + ONE product) minus forward, HIP events
     on the launch stream, median of five runs.  grad_weight: only the weights require gradients; grad_input / grad_offset: the
     grouped call's two phases one at a time (KGDET_OPT_BWD_PHASE, a measurement switch of the C ABI).  ``regime``: 'random'
-    N(0, 2^2)-pixel offsets, or 'trained' (``_trained_offsets``)."""
+    N(0, 2^2)-pixel offsets, 'trained' (``_trained_offsets``) or 'step' (``_step_offsets``: the benched step's own)."""
     from kgdet_amd import _lib, dcn
     g = torch.Generator(device='cpu').manual_seed(0)
     B, C, H, W = 2, 256, 25, 42
@@ -379,6 +391,8 @@ def dcn_backward_products_live(device, iters=30, regime='random'):
     ws = [[(torch.randn(C, C, k, k, generator=g) * 0.01).to(device) for k in ks] for _ in xs]
     if regime == 'trained':
         offs = _trained_offsets(offs, ks, B, H, W)
+    elif regime == 'step':
+        offs = _step_offsets(device, ks)
     pads = [k // 2 for k in ks]
     leaves_io, leaves_w = xs + offs, [w for wl in ws for w in wl]
     stream = torch.cuda.current_stream()
@@ -456,11 +470,11 @@ def dcn_backward_products_live(device, iters=30, regime='random'):
                    'product includes its builder kernels (inverse records / long-cell sums / grad_out images) and the '
                    'ReLU-backward pass; forward_with_pack_us = the forward as a TRAINING step runs it (weights re-packed per call: '
                    'dcn_pack_weight_all_multi inside).  Kernels inside each live figure -- grad_input: dcn_bwd_input_prepare (inverse records '
-                   '+ pixel-major grad_out) + dcn_inv_overflow_sums + dcn_bwd_input_plane<2> + dcn_fwd_fixup_static; grad_offset: '
+                   '+ pixel-major grad_out) + dcn_hot_gemm + dcn_inv_medium_sums + dcn_bwd_input_plane<2> + dcn_fwd_fixup_static; grad_offset: '
                    'dcn_build_grad_taps + dcn_bwd_offset_pair + dcn_bwd_offset_plane_fixup; grad_weight: dcn_build_taps + dcn_pack_grad_out '
                    '+ dcn_bwd_weight_os; each + the autograd node\'s ReLU-backward pass on grad_out.  The profile\'s per-kernel averages '
                    '(profiles/) exclude the launch gaps and that pass' % iters)
-    tr = profiled_traffic_backward('trained_' if regime == 'trained' else '')
+    tr = profiled_traffic_backward('trained_' if regime == 'trained' else '') if regime != 'step' else {}
     for k in ('grad_input', 'grad_offset', 'grad_weight'):
         if k in out and k in tr:
             out[k]['traffic'] = tr[k]
@@ -1103,15 +1117,19 @@ def main():
         if not args.no_roofline and args.mode == 'train' and args.config == 'kgdet':
             bw = dcn_backward_products_live(device)
             bw_t = dcn_backward_products_live(device, regime='trained')
+            bw_s = dcn_backward_products_live(device, regime='step') if os.path.isfile(os.path.join(ROOT, STEP_OFFSETS)) else {}
             rl = out['roofline']
             rl['backward'] = bw
             rl['backward_trained_offsets'] = bw_t
+            rl['backward_step_offsets'] = bw_s
             # (scalar copies: a parser that drops nested objects still sees the fractions)
             for name in ('grad_input', 'grad_offset', 'grad_weight'):
                 if name in bw:
                     rl['bwd_%s_frac' % name], rl['bwd_%s_us' % name] = bw[name]['frac'], bw[name]['us']
                 if name in bw_t:
                     rl['bwd_%s_frac_trained' % name], rl['bwd_%s_us_trained' % name] = bw_t[name]['frac'], bw_t[name]['us']
+                if name in bw_s:
+                    rl['bwd_%s_frac_step' % name], rl['bwd_%s_us_step' % name] = bw_s[name]['frac'], bw_s[name]['us']
             # the forward as the training step runs it: every call re-packs the six weights (they changed); the inference-style
             # launch above reuses the packed images (`launch_us`: pack NOT inside)
             rl['launch_us_pack_inside'] = bw['forward_with_pack_us']

@@ -291,9 +291,24 @@ class step_scope(object):
         _token = self.prev
 
 
+# proxy tensor -> the Parameter whose storage it shares (layers.shared_levels: the levels of a shared-weight head run on per-level
+# leaf aliases of the parameters; the persistent operand images belong to the parameter)
+_aliases = {}        # id(proxy) -> (weakref to the proxy, weakref to the parameter); entries leave with their proxy
+
+
+def alias(proxy, param):
+    key = id(proxy)
+    _aliases[key] = (weakref.ref(proxy, lambda _r, key=key: _aliases.pop(key, None)), weakref.ref(param))
+
+
 def forward_images(x, weight):
     """(forward operand image, grad_input operand image or None) of a contiguous weight"""
     both = PACK_BOTH and x.requires_grad and (weight.shape[0] % 16 == 0 or weight.shape[2] == 1)
+    a = _aliases.get(id(weight))
+    if a is not None and a[0]() is weight:
+        origin = a[1]()
+        if origin is not None and origin.data_ptr() == weight.data_ptr() and origin.shape == weight.shape:
+            weight = origin      # (same storage: the images are the parameter's)
     if both and PACK_MULTI and _token:
         e = _entries.get(id(weight))
         if e is not None and e.ref() is weight and e.ptr == weight.data_ptr():

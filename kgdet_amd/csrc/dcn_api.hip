@@ -1334,9 +1334,15 @@ int kgdet_deform_conv_backward_input_grouped(int32_t n, const kgdet_dcn_shape *c
     hipLaunchKernelGGL(dcn_hot_gemm, dim3(8 * kHotBlocksPerXcd), dim3(512), dcn_hot_gemm_lds_bytes(), (hipStream_t)stream, hotg,
                        sums.sched);
   }
+  // the cluster kernel serves the cells above 64 contributions that dcn_hot_gemm does not take: none, if the GEMM is on and no image
+  // can overflow its column list (a tap has at most 4 HoWo / 65 such cells)
+  bool clusters_needed = !hot_ok;
+  for (int i = 0; i < n && !clusters_needed; ++i)
+    clusters_needed = (long long)dd[i].K * (4 * dd[i].Ho * dd[i].Wo / 65) > hot_max;
   if (sums.sched.on) {
     hipLaunchKernelGGL(dcn_inv_medium_sums, dim3(8 * sched_longest), dim3(256), 0, (hipStream_t)stream, sums);
-    hipLaunchKernelGGL(dcn_inv_overflow_sums, dim3(8 * sched_longest), dim3(256), 0, (hipStream_t)stream, sums);
+    if (clusters_needed)
+      hipLaunchKernelGGL(dcn_inv_overflow_sums, dim3(8 * sched_longest), dim3(256), 0, (hipStream_t)stream, sums);
   } else {
     hipLaunchKernelGGL(dcn_inv_medium_sums, dim3(sums_blocks, kInvSumSplit, sums.n), dim3(256), 0, (hipStream_t)stream, sums);
     hipLaunchKernelGGL(dcn_inv_overflow_sums, dim3(sums_blocks, kInvSumSplit, sums.n), dim3(256), 0, (hipStream_t)stream, sums);

@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from . import conv1x1, dcn
 from .heads import PointHeadMixin
-from .layers import ConvModule, bias_init_with_prob, normal_init
+from .layers import ConvModule, bias_init_with_prob, normal_init, shared_levels
 
 GROUPED_REFINE = __import__('os').environ.get('KGDET_SERIAL_GROUPED_DCN', '1') == '1'   # 0: one call per deformable convolution (A/B)
 SELECT_FIRST = __import__('os').environ.get('KGDET_SERIAL_SELECT_FIRST', '1') == '1'     # 0: convert whole maps, then keep nms_pre rows (A/B)
@@ -35,6 +35,7 @@ from .points import (PointGenerator, dense_targets_applicable, multi_apply, poin
 from .postprocess import multiclass_nms_kp
 from .registry import HEADS, build_loss
 
+SHARED_LEVELS = os.environ.get('KGDET_SERIAL_SHARED_LEVELS', '1') == '1'     # 0: five autograd sub-graphs, engine-side gradient adds (A/B)
 DENSE_TARGETS = os.environ.get('KGDET_SERIAL_DENSE_TARGETS', '1') == '1'     # 0: the reference-mirroring (host-syncing) path (A/B)
 
 
@@ -211,6 +212,10 @@ class _RepPointsHeadKpTwoStage(PointHeadMixin, nn.Module):
         return (cls_out, keypts_out_init, keypts_out_refine, reppts_out_init, reppts_out_refine)
 
     def forward(self, feats, img_metas):
+        if SHARED_LEVELS and torch.is_grad_enabled() and feats[0].is_cuda and any(p.requires_grad for p in self.parameters()):
+            # training: the five levels as ONE autograd node -- the shared parameters' gradients are summed over the levels by a few
+            # multi-tensor launches inside it instead of 235 engine-side `add`s (layers.shared_levels)
+            return shared_levels(self, self.forward_single, list(feats))
         return multi_apply(self.forward_single, feats)
 
     # ------------------------------------------------------------------------------------------

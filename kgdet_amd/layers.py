@@ -275,3 +275,78 @@ class ConvModule(nn.Module):
                 if not fused_act:
                     x = self.activate(x)
         return x
+
+
+
+# ------------------------------------------------------------------------------------------------
+# A module shared by several pyramid levels as ONE autograd node
+# ------------------------------------------------------------------------------------------------
+class _SharedLevels(torch.autograd.Function):
+    """``run(l, x_l, params)`` for every level l, recorded as ONE node of the outer graph.  The reference applies its head to the
+    five FPN levels one after the other (reppoints_head_kp_serial.py:495-497 multi_apply): every shared parameter then receives
+    five gradients, which the autograd engine adds pairwise as they arrive -- 235 `add` launches (1.1 ms) of a config-5 step.  Here
+    each level runs on leaf ALIASES of the parameters (same storage) under its own recorded sub-graph; backward differentiates the
+    five sub-graphs and sums the parameter gradients with multi-tensor adds: four launch groups for all parameters together.  The sum
+    runs level 0 + level 1 + ... in that order for every parameter: deterministic."""
+
+    @staticmethod
+    def forward(ctx, run, n_levels, *flat):
+        xs, params = flat[:n_levels], flat[n_levels:]
+        ctx.levels, ctx.n_params = [], len(params)
+        outs_flat = []
+        for l, x in enumerate(xs):
+            with torch.enable_grad():
+                xin = x.detach().requires_grad_(x.requires_grad)
+                proxies = [p.detach().requires_grad_(p.requires_grad) for p in params]
+                outs = tuple(run(l, xin, proxies))
+            ctx.levels.append((xin, proxies, outs))
+            outs_flat.extend(o.detach() for o in outs)
+        ctx.n_out = len(outs_flat) // max(n_levels, 1)
+        return tuple(outs_flat)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gouts):
+        gxs, acc = [], [None] * ctx.n_params
+        for l, (xin, proxies, outs) in enumerate(ctx.levels):
+            gl = gouts[l * ctx.n_out:(l + 1) * ctx.n_out]
+            sel = [(o, g) for o, g in zip(outs, gl) if g is not None and o.requires_grad]
+            inputs = ([xin] if xin.requires_grad else []) + [p for p in proxies if p.requires_grad]
+            if not sel or not inputs:
+                gxs.append(None)
+                continue
+            grads = torch.autograd.grad([o for o, _ in sel], inputs, [g for _, g in sel], allow_unused=True)
+            grads = list(grads)
+            gxs.append(grads.pop(0) if xin.requires_grad else None)
+            it = iter(grads)
+            mine, theirs = [], []
+            for i, p in enumerate(proxies):
+                if not p.requires_grad:
+                    continue
+                g = next(it)
+                if g is None:
+                    continue
+                if acc[i] is None:
+                    acc[i] = g if g.is_contiguous() else g.contiguous()
+                else:
+                    mine.append(acc[i])
+                    theirs.append(g)
+            if mine:
+                torch._foreach_add_(mine, theirs)      # (multi-tensor: a few launches for all parameters of the level)
+        ctx.levels = None
+        return (None, None) + tuple(gxs) + tuple(acc)
+
+
+def shared_levels(module, single, xs):
+    """``[single(x) for x in xs]`` transposed (as multi_apply) with ``module``'s parameters shared through ``_SharedLevels``"""
+    from torch.nn.utils import stateless
+    names, params = zip(*[(n, p) for n, p in module.named_parameters()])
+
+    def run(l, x, proxies):
+        for q, p in zip(proxies, params):
+            conv1x1.alias(q, p)
+        with stateless._reparametrize_module(module, dict(zip(names, proxies))):
+            return single(x)
+    flat = _SharedLevels.apply(run, len(xs), *xs, *params)
+    n_out = len(flat) // len(xs)
+    return tuple([flat[l * n_out + j] for l in range(len(xs))] for j in range(n_out))
