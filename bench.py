@@ -474,7 +474,7 @@ def dcn_backward_products_live(device, iters=30, regime='random'):
                    'dcn_build_grad_taps + dcn_bwd_offset_pair + dcn_bwd_offset_plane_fixup; grad_weight: dcn_build_taps + dcn_pack_grad_out '
                    '+ dcn_bwd_weight_os; each + the autograd node\'s ReLU-backward pass on grad_out.  The profile\'s per-kernel averages '
                    '(profiles/) exclude the launch gaps and that pass' % iters)
-    tr = profiled_traffic_backward('trained_' if regime == 'trained' else '') if regime != 'step' else {}
+    tr = profiled_traffic_backward({'trained': 'trained_', 'step': 'step_'}.get(regime, ''))
     for k in ('grad_input', 'grad_offset', 'grad_weight'):
         if k in out and k in tr:
             out[k]['traffic'] = tr[k]
