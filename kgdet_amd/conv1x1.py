@@ -472,6 +472,17 @@ def unpad_odd(y, width):
 conv1x1 = conv_split
 
 
+BIAS_GRAD_IN_WGRAD = _os.environ.get('KGDET_BIAS_GRAD_IN_WGRAD', '1') == '1'     # 0: gy.sum((0, 2, 3)) as its own reduce launch (A/B)
+_ones_cache = {}
+
+
+def _ones(n, device):
+    t = _ones_cache.get((n, device))
+    if t is None:
+        t = _ones_cache[(n, device)] = torch.ones(n, dtype=torch.float32, device=device)
+    return t
+
+
 class _ConvBiasAct(torch.autograd.Function):
     """``[relu](conv(x, weight) + bias)`` with bias and ReLU in the convolution's store (the plain biased 3x3 convolutions of
     the head's first stage, KP3:69-71: MIOpen's fp32 Winograd takes 62 us for each of their three passes at 25 x 42)."""
@@ -492,6 +503,14 @@ class _ConvBiasAct(torch.autograd.Function):
             gy = torch.ops.aten.threshold_backward(gy, y, 0)
         gy = gy.contiguous()
         gx = grad_input(weight, ctx.img_t, gy) if ctx.needs_input_grad[0] else None
+        if BIAS_GRAD_IN_WGRAD and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and grad_weight_fold_route(x, weight):
+            # the bias gradient = the row sums of grad_y, which the weight-gradient kernel forms on its way (the folded-BatchNorm
+            # variant with s = 1: grad_w = 1 * G, grad_beta = the row sums) -- instead of one more pass over grad_y per convolution
+            # (45 reduce launches of a config-5 step, 11 of a KGDet step)
+            one = _ones(weight.shape[0], weight.device)
+            res = grad_weight_fold(x, weight, gy, one, one, one, 0.0, None, 0, want_gamma=False)
+            if res is not None:
+                return gx, res[0], res[1][0], None
         gw = grad_weight(x, weight, gy) if ctx.needs_input_grad[1] else None
         gb = gy.sum((0, 2, 3)) if ctx.needs_input_grad[2] else None
         return gx, gw, gb, None
