@@ -5,15 +5,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torch.profiler import profile, ProfilerActivity
 from kgdet_amd import build_detector, configs, synthetic
-cfg = configs.kgdet_r50_fpn()
+cfg = configs.kgdet_r50_fpn() if (len(sys.argv) > 1 and sys.argv[1] == "kgdet") else configs.reppoints_kp_r50_fpn()
 torch.manual_seed(0)
 model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
-opt = torch.optim.Adam(model.parameters(), lr=1e-5, fused=True)
+opt = torch.optim.SGD(model.parameters(), lr=1e-5, momentum=0.9, fused=True)
+vals = lambda v: v if isinstance(v, (list, tuple)) else [v]
 batch = synthetic.make_batch(2, 'cuda', seed=0)
 def step():
     losses = model(batch['img'], batch['img_meta'], return_loss=True, gt_bboxes=batch['gt_bboxes'],
                    gt_labels=batch['gt_labels'], gt_keypoints=batch['gt_keypoints'])
-    sum(sum(v) for v in losses.values()).backward()
+    sum(sum(vals(v)) for v in losses.values()).backward()
     opt.step(); opt.zero_grad(set_to_none=True)
 for _ in range(4): step()
 torch.cuda.synchronize()
