@@ -618,7 +618,9 @@ __global__ __launch_bounds__(256) void dcn_inv_medium_sums(const DcnInvSumGroup 
 // an image that overflows the list (larger kernels) takes the cluster path whole.  dcn_hot_gemm: workgroup = (32-column tile,
 // 128-channel part) of a (problem, image), placed on the XCD that the sums kernel reads that image's grad_output on; the workgroup
 // scatters its columns' weights into a dense LDS tile [32][pixels] (the A operand), its eight waves split the k-steps, and the eight
-// partial tiles are summed in a fixed order.  Deterministic.
+// partial tiles are summed in a fixed order.  Deterministic.  (A dense product multiplies every pixel of the image with a cell's
+// weight, zero for the pixels that do not contribute: an Inf / NaN anywhere in an image's grad_output reaches all hot cells of that image
+// as NaN, where the reference's scatter would confine it to the cells its pixel feeds -- a gradient that is lost either way.)
 // ------------------------------------------------------------------------------------------------
 size_t dcn_hot_gemm_lds_bytes() { return (size_t)32 * kHotRowLd * sizeof(float); }
 
