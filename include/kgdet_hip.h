@@ -93,6 +93,12 @@ int kgdet_stem_conv7x7_s2(const void *packed, const float *x, float *y, int64_t 
  * of its weight (kgdet_conv_pack(w, O, C, 9, 1, ...)); O % 16 == 0.  Replaces ATen's convolution_backward (MIOpen). */
 int kgdet_conv3x3_s2_grad_input(const void *packed_t, const float *grad_y, float *grad_x, int64_t B, int32_t C, int32_t O,
                                 int32_t Hin, int32_t Win, void *stream);
+/* grad_w [O, C, 3, 3] of the same stride-2 convolution: x [B, C, H, W], grad_y [B, O, ceil(H/2), ceil(W/2)].  The nine strided views of x are
+ * gathered into the workspace once, the product over the pixels runs on the 1x1 weight-gradient kernels (deterministic).  O * C even.
+ * Replaces ATen's convolution_backward (MIOpen igemm_wrw + layout transposes), mmdet/models/backbones/resnet.py:142-186. */
+size_t kgdet_conv3x3_s2_grad_weight_workspace_bytes(int64_t B, int32_t O, int32_t C, int32_t H, int32_t W);
+int kgdet_conv3x3_s2_grad_weight(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O, int32_t C, int32_t H,
+                                 int32_t W, void *workspace, size_t workspace_bytes, void *stream);
 size_t kgdet_conv1x1_grad_weight_workspace_bytes(int64_t B, int32_t O, int32_t C, int64_t HW);
 int kgdet_conv1x1_grad_weight(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O, int32_t C,
                               int64_t HW, void *workspace, size_t workspace_bytes, void *stream);

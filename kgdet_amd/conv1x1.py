@@ -71,6 +71,8 @@ def _lib_sizes():
                 ('kgdet_conv_apply_gated_fmt', ctypes.c_int,
                  [vp, vp, vp, vp, vp, i32, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
                 ('kgdet_conv3x3_s2_grad_input', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i32, i32, vp]),
+                ('kgdet_conv3x3_s2_grad_weight_workspace_bytes', sz, [i64, i32, i32, i32, i32]),
+                ('kgdet_conv3x3_s2_grad_weight', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i32, i32, vp, sz, vp]),
                 ('kgdet_conv1x1_grad_weight', ctypes.c_int, [vp, vp, vp, i64, i32, i32, i64, vp, sz, vp]),
                 ('kgdet_conv1x1_grad_weight_fold', ctypes.c_int,
                  [vp, vp, vp, i64, i32, i32, i64, vp, sz, vp, vp, vp, vp, ctypes.c_float, vp, i32, vp, vp, vp]),
@@ -591,7 +593,8 @@ def conv_bias_act(conv, x, relu=False):
 
 class _ConvSplitStride2(torch.autograd.Function):
     """3x3 stride-2 padding-1 convolution: forward on conv_nn<9> (MIOpen's fp32 strided kernels run at 15-20 TFLOP/s),
-    backward through MIOpen (a transposed strided convolution does not map onto the kernel's tap loop)."""
+    grad_input on conv3x3_s2_grad_input (four parity classes), grad_weight on a gather of the nine strided views + the 1x1
+    weight-gradient GEMM (round 6); MIOpen behind the switches."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -613,17 +616,32 @@ class _ConvSplitStride2(torch.autograd.Function):
                 img_t.data_ptr(), gy.data_ptr(), gx.data_ptr(), x.shape[0], x.shape[1], weight.shape[0], x.shape[2], x.shape[3],
                 _stream()), 'conv3x3_s2_grad_input')
         need_gx = ctx.needs_input_grad[0] and gx is None
-        if need_gx or ctx.needs_input_grad[1]:
-            gx2, gw, _ = torch.ops.aten.convolution_backward(
-                gy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [need_gx, ctx.needs_input_grad[1], False])
+        gw = None
+        need_gw = ctx.needs_input_grad[1]
+        if need_gw and STRIDE2_GRAD_WEIGHT and (weight.shape[0] * weight.shape[1]) % 2 == 0:
+            # the nine strided views of x gathered once, then the 1x1 weight-gradient GEMM over (tap, channel) columns
+            # (csrc/conv1x1.hip kgdet_conv3x3_s2_grad_weight): MIOpen's igemm_wrw + its layout transposes were the last vendor
+            # kernels of the training step
+            L = _lib_sizes()
+            B, C, H, W = x.shape
+            O = weight.shape[0]
+            nbytes = _size('kgdet_conv3x3_s2_grad_weight_workspace_bytes', B, O, C, H, W)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            gw = torch.empty_like(weight)
+            _lib.check(L.kgdet_conv3x3_s2_grad_weight(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), B, O, C, H, W, ws.data_ptr(), nbytes,
+                                                      _stream()), 'conv3x3_s2_grad_weight')
+            need_gw = False
+        if need_gx or need_gw:
+            gx2, gw2, _ = torch.ops.aten.convolution_backward(
+                gy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [need_gx, need_gw, False])
             gx = gx2 if need_gx else gx
-        else:
-            gw = None
+            gw = gw2 if need_gw else gw
         return gx, gw
 
 
 STRIDE2 = _os.environ.get('KGDET_CONV_S2', '1') == '1'
 STRIDE2_GRAD_INPUT = _os.environ.get('KGDET_CONV_S2_GI', '1') == '1'    # 0: MIOpen for the stride-2 grad_input (A/B)
+STRIDE2_GRAD_WEIGHT = _os.environ.get('KGDET_CONV_S2_GW', '1') == '1'   # 0: MIOpen for the stride-2 grad_weight (A/B)
 
 
 def applicable_stride2(x, weight, stride, padding, dilation, groups):

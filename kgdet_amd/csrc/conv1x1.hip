@@ -2195,7 +2195,9 @@ extern "C" size_t kgdet_conv1x1_grad_weight_workspace_bytes(int64_t B, int32_t O
 
 static int conv1x1_grad_weight_impl(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O, int32_t C,
                                     int64_t HW, void *workspace, size_t workspace_bytes, void *stream,
-                                    const ConvFoldArgs *fold) {
+                                    const ConvFoldArgs *fold, int wsum3x3_C = 0) {
+  // wsum3x3_C > 0: the columns are (tap, channel) of a 3x3 problem with wsum3x3_C channels (C = 9 * wsum3x3_C): the final sum
+  // writes grad_w [O, wsum3x3_C, 3, 3] (kgdet_conv3x3_s2_grad_weight)
   KGDET_CHECK_SHAPE(B > 0 && O > 0 && C > 0 && HW > 0 && HW < (1LL << 30), "bad sizes");
   KGDET_CHECK_SHAPE(grad_y && x && grad_w && workspace, "null pointer");
   KGDET_CHECK_SHAPE(workspace_bytes >= kgdet_conv1x1_grad_weight_workspace_bytes(B, O, C, HW), "workspace too small");
@@ -2259,11 +2261,73 @@ static int conv1x1_grad_weight_impl(const float *grad_y, const float *x, float *
     KGDET_CHECK_LAUNCH("conv_wsum_fold");
     return KGDET_OK;
   }
+  if (wsum3x3_C > 0) {
+    const long long blocks9 = (n + 255) / 256;
+    hipLaunchKernelGGL(conv3x3_wsum, dim3((unsigned)(blocks9 > 4096 ? 4096 : blocks9)), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)workspace, grad_w, O, wsum3x3_C, splits);
+    KGDET_CHECK_LAUNCH("conv3x3_wsum");
+    return KGDET_OK;
+  }
   const long long blocks = (n / 2 + 255) / 256;
   hipLaunchKernelGGL(conv1x1_sum, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, (hipStream_t)stream,
                      (const float *)workspace, grad_w, n, n, splits);
   KGDET_CHECK_LAUNCH("conv1x1_sum");
   return KGDET_OK;
+}
+
+// ---- 3x3 stride-2 padding-1 weight gradient (the bottleneck's conv2 at the head of layers 2-4; the FPN's extra levels) -------------
+// grad_w[o][c][ky][kx] = sum_{b, oy, ox} grad_y[b][o][oy][ox] * x[b][c][2 oy + ky - 1][2 ox + kx - 1].  The nine strided views of x are
+// gathered once into col [B][(tap, channel)][Ho * Wo] (zero outside the image: 9/4 of x's bytes), and the product over the pixels is the
+// 1x1 weight-gradient GEMM with 9 C columns -- conv_nt8<1> / conv_ntp<1>, K split, partials added in slot order by conv3x3_wsum, which
+// also turns the (tap, channel) columns into grad_w's (channel, tap) order.  Replaces MIOpen's fp32 `igemm_wrw` + its layout transposes
+// (366 us per KGDet step for three convolutions), the last vendor kernels of the training step.
+__global__ __launch_bounds__(256) void conv_s2_gather9(const float *__restrict__ x, float *__restrict__ col, int C, int H, int W,
+                                                       int Ho, int Wo, long long rows) {
+  const int HWo = Ho * Wo;
+  const long long total = rows * HWo;           // rows = B * C
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / HWo;                // b * C + c
+    const int p = (int)(i - r * HWo), oy = p / Wo, ox = p - oy * Wo;
+    const long long b = r / C;
+    const int c = (int)(r - b * C);
+    const float *xp = x + r * (long long)H * W;
+    float *cp = col + (b * 9 * C + c) * (long long)HWo + p;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = 2 * oy + t / 3 - 1, xx = 2 * ox + t % 3 - 1;
+      cp[(long long)t * C * HWo] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xp[(long long)yy * W + xx] : 0.0f;
+    }
+  }
+}
+
+static size_t conv3x3_s2_col_bytes(int64_t B, int32_t C, int32_t H, int32_t W) {
+  const long long HWo = (long long)((H + 1) / 2) * ((W + 1) / 2);
+  return ((size_t)B * 9 * C * HWo * sizeof(float) + 255) & ~(size_t)255;
+}
+
+extern "C" size_t kgdet_conv3x3_s2_grad_weight_workspace_bytes(int64_t B, int32_t O, int32_t C, int32_t H, int32_t W) {
+  if (B <= 0 || O <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+  const long long HWo = (long long)((H + 1) / 2) * ((W + 1) / 2);
+  return conv3x3_s2_col_bytes(B, C, H, W) + conv1x1_gw_workspace(B, O, 9 * C, HWo, nullptr);
+}
+
+extern "C" int kgdet_conv3x3_s2_grad_weight(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O, int32_t C,
+                                            int32_t H, int32_t W, void *workspace, size_t workspace_bytes, void *stream) {
+  // x [B, C, H, W], grad_y [B, O, ceil(H/2), ceil(W/2)], grad_w [O, C, 3, 3]
+  KGDET_CHECK_SHAPE(B > 0 && O > 0 && C > 0 && H > 0 && W > 0 && (long long)9 * C * ((H + 1) / 2) * ((W + 1) / 2) < (1LL << 30), "bad sizes");
+  KGDET_CHECK_SHAPE(grad_y && x && grad_w && workspace, "null pointer");
+  KGDET_CHECK_SHAPE(workspace_bytes >= kgdet_conv3x3_s2_grad_weight_workspace_bytes(B, O, C, H, W), "workspace too small");
+  KGDET_CHECK_SHAPE(((long long)O * C) % 2 == 0, "O*C must be even");
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  float *col = static_cast<float *>(workspace);
+  const long long total = (long long)B * C * Ho * Wo;
+  const long long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(conv_s2_gather9, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, (hipStream_t)stream, x, col, C,
+                     H, W, Ho, Wo, (long long)B * C);
+  KGDET_CHECK_LAUNCH("conv_s2_gather9");
+  const size_t cb = conv3x3_s2_col_bytes(B, C, H, W);
+  return conv1x1_grad_weight_impl(grad_y, col, grad_w, B, O, 9 * C, (long long)Ho * Wo, static_cast<unsigned char *>(workspace) + cb,
+                                  workspace_bytes - cb, stream, nullptr, C);
 }
 
 extern "C" int kgdet_conv1x1_grad_weight(const float *grad_y, const float *x, float *grad_w, int64_t B, int32_t O,

@@ -572,16 +572,18 @@ def test_conv3x3_stride2_forward_matches_fp64(B, C, O, H, W):
     F.conv2d(xr, wr, stride=2, padding=1).backward(gy)
     assert (x.grad - xr.grad).abs().max().item() <= 1e-4 * xr.grad.abs().max().item()
     assert (w.grad - wr.grad).abs().max().item() <= 1e-4 * wr.grad.abs().max().item()
-    xd = x.detach().double().requires_grad_()
-    F.conv2d(xd, w.detach().double(), stride=2, padding=1).backward(gy.double())
+    xd, wd = x.detach().double().requires_grad_(), w.detach().double().requires_grad_()
+    F.conv2d(xd, wd, stride=2, padding=1).backward(gy.double())
     assert ((x.grad.double() - xd.grad).abs().max() / xd.grad.abs().max()).item() < 1e-5
-    assert torch.isfinite(x.grad).all()
-    x.grad = None
+    # (round 6: grad_weight on the gather + 1x1 weight-gradient GEMM, csrc/conv1x1.hip kgdet_conv3x3_s2_grad_weight)
+    assert ((w.grad.double() - wd.grad).abs().max() / wd.grad.abs().max()).item() < 1e-5
+    assert torch.isfinite(x.grad).all() and torch.isfinite(w.grad).all()
+    x.grad = None; w.grad = None
     c1.conv3x3_stride2(x, w).backward(gy)          # deterministic
-    g1 = x.grad.clone()
-    x.grad = None
+    g1, gw1 = x.grad.clone(), w.grad.clone()
+    x.grad = None; w.grad = None
     c1.conv3x3_stride2(x, w).backward(gy)
-    assert torch.equal(g1, x.grad)
+    assert torch.equal(g1, x.grad) and torch.equal(gw1, w.grad)
 
 
 @pytest.mark.parametrize('B,K,N,H,W,res,relu', [(2, 64, 64, 50, 84, False, True), (1, 256, 64, 25, 42, False, True), (2, 256, 128, 13, 21, False, True),

@@ -5,7 +5,7 @@ import re, sys
 
 FAMILIES = [
     ('deformable (forward, three gradients, builders, fix-ups, packs)', r'kgdet::dcn_|kgdet::\(anonymous namespace\)::large_'),
-    ('dense grad_weight', r'conv_nt8|conv_ntp|igemm_wrw|batched_transpose'),
+    ('dense grad_weight', r'conv_nt8|conv_ntp|conv_s2_gather9|igemm_wrw|batched_transpose'),
     ('partial sums / BatchNorm fold / packs of the dense kernels', r'conv1x1_sum|conv_wsum_fold|conv3x3_wsum|conv1x1_pack|bn_partial_sum|pad_rows2'),
     ('dense forward / grad_input (split MFMA)', r'conv_nn<|conv3x3_patch|conv3x3_s2_grad_input|stem_conv7x7'),
     ('library GEMMs (vendor)', r'Cijk_|igemm_(?!wrw)|naive_conv|gridwise'),
