@@ -521,3 +521,48 @@ def test_bench_rank0_block_never_steps_a_multi_rank_job_alone():
             j -= 1
         assert guarded, 'bench.py:%d calls a step inside the rank-0 block without a `world == 1` guard: %s' % (i + 1, line.strip())
     assert calls >= 1
+
+
+def test_shared_levels_node_equals_per_level_graphs():
+    """layers.shared_levels (config 5's head: the FPN levels of a shared-weight module as ONE autograd node whose backward sums the
+    parameter gradients over the levels) == the plain per-level application (reppoints_head_kp_serial.py:495-497 multi_apply): outputs,
+    input gradients and parameter gradients, including a parameter one level does not use and an output without gradient."""
+    import torch
+    import torch.nn as nn
+    from kgdet_amd.layers import shared_levels
+
+    class Head(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = nn.Conv2d(3, 4, 3, padding=1)
+            self.d = nn.Conv2d(4, 2, 1)
+            self.only_small = nn.Parameter(torch.ones(1))
+
+        def single(self, x):
+            h = torch.relu(self.c(x))
+            if x.shape[-1] <= 4:
+                h = h * self.only_small
+            return self.d(h), h.mean(1, keepdim=True).detach(), h.sum(1, keepdim=True) * 0.1
+
+    torch.manual_seed(0)
+    m = Head()
+    xs = [torch.randn(2, 3, 8, 8, requires_grad=True), torch.randn(2, 3, 4, 4, requires_grad=True), torch.randn(1, 3, 6, 5)]
+    outs = shared_levels(m, m.single, xs)
+    assert len(outs) == 3 and all(len(o) == 3 for o in outs)
+    sum(o.pow(2).sum() for j in (0, 2) for o in outs[j]).backward()
+    got_p = [p.grad.clone() for p in m.parameters()]
+    got_x = [x.grad.clone() for x in xs[:2]]
+    for p in m.parameters():
+        p.grad = None
+    for x in xs[:2]:
+        x.grad = None
+    ref = [m.single(x) for x in xs]
+    for j in range(3):
+        for l in range(3):
+            assert torch.equal(outs[j][l], ref[l][j])
+    sum(r[j].pow(2).sum() for r in ref for j in (0, 2)).backward()
+    for a, p in zip(got_p, m.parameters()):
+        assert torch.allclose(a, p.grad, rtol=1e-6, atol=1e-7)
+    for a, x in zip(got_x, xs[:2]):
+        assert torch.allclose(a, x.grad, rtol=1e-6, atol=1e-7)
+    assert xs[2].grad is None
