@@ -509,7 +509,10 @@ __global__ __launch_bounds__(256) void dcn_inv_medium_sums(const DcnInvSumGroup 
     // instructions were address arithmetic)
     const dcn_rsrc_t g_rsrc = dcn_make_rsrc(gt);
     const unsigned row_bytes = (unsigned)O * 4u, ch_bytes = (unsigned)min(lane * 4, O - 4) * 4u;
-    constexpr int kRows = 12;                          // rows in flight (48 registers: six waves per SIMD stay resident)
+#ifndef KGDET_MED_ROWS
+#define KGDET_MED_ROWS 12
+#endif
+    constexpr int kRows = KGDET_MED_ROWS;              // rows in flight (48 registers: six waves per SIMD stay resident; 10: 37.3, 12: 36.4, 16: 44.8 us)
     int pend = 0;
     auto flush = [&]() __attribute__((always_inline)) {
       for (int q = 0; q < pend; ++q)
